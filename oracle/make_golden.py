@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE — regenerate tests/golden/* from the REAL reference.
+
+Runs oracle/_ref/ref_harness (the reference's own libff/libfqfft/libsnark code compiled by `make -C oracle ref`; only
+possible in the build container, where /root/reference exists) and stores its OUTPUTS as fixtures:
+
+  ref_vectors.txt            field / curve / domain / MSM / pairing known answers
+  groth16_small/             a 60-constraint R1CS + witness (inputs made by tests/r1cs_util.py, seed 7), the key pair
+                             the reference generator produced for it (pk.txt / vk.txt in the reference's on-disk
+                             format), fixed (r, s), the H coefficients and the proof bytes of the reference prover
+  groth16_step/              same on a step-radix-2 domain (40 constraints + 4 inputs + 1 -> m = 48)
+  sha256_gadget.json         constraint / variable counts, digest and SHA-256 of the R1CS / witness dumps of libsnark's
+                             sha256_two_to_one_hash_gadget on the reference's own KAT input and on seeded inputs
+  merkle_gadget.json         same for merkle_tree_check_read_gadget (depth 2 and 8)
+
+Fixtures are data only; no reference source is copied.
+"""
+import hashlib, json, os, subprocess, sys, tempfile
+HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import pyoracle as o
+from r1cs_util import random_r1cs
+HARNESS = os.path.join(HERE, "_ref", "ref_harness"); GOLD = os.path.join(ROOT, "tests", "golden")
+
+def run(*args):
+    r = subprocess.run([HARNESS, *args], capture_output=True, text=True)
+    if r.returncode != 0: raise RuntimeError(r.stdout + r.stderr)
+    return r.stdout
+
+def sha(path): return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+def groth16_fixture(name, seed, ni, nv, nc, rs_seed):
+    d = os.path.join(GOLD, name); os.makedirs(d, exist_ok=True)
+    cs, z = random_r1cs(seed, ni, nv, nc); assert o.r1cs_is_satisfied(cs, z)
+    cs.save(os.path.join(d, "r1cs.bin")); o.save_witness(os.path.join(d, "wit.bin"), z)
+    g = o.SplitMix64(rs_seed); r, s = g.field(), g.field()
+    out = run("e2e", os.path.join(d, "r1cs.bin"), os.path.join(d, "wit.bin"), "%x" % r, "%x" % s, d)
+    proof = [l.split()[1] for l in out.splitlines() if l.startswith("proof ")][0]
+    assert "verify 1" in out and "verify_hex_roundtrip 1" in out
+    json.dump({"seed": seed, "n_inputs": ni, "n_vars": nv, "n_cons": nc, "domain_m": cs.domain_m, "r": "%x" % r, "s": "%x" % s, "proof": proof},
+              open(os.path.join(d, "meta.json"), "w"), indent=1)
+
+def gadget_fixture():
+    res = {}
+    with tempfile.TemporaryDirectory() as t:
+        for seed in (0, 1, 2):
+            out = run("sha256gadget", t + "/r.bin", t + "/w.bin", str(seed)); kv = dict(p.split("=") for p in out.split()[1:])
+            res["seed%d" % seed] = {"constraints": int(kv["constraints"]), "variables": int(kv["variables"]), "digest_bits": kv["digest"], "r1cs_sha256": sha(t + "/r.bin"), "witness_sha256": sha(t + "/w.bin")}
+        json.dump(res, open(os.path.join(GOLD, "sha256_gadget.json"), "w"), indent=1)
+        res = {}
+        for depth, seed in ((2, 5), (8, 6)):
+            out = run("merklegadget", str(depth), t + "/r.bin", t + "/w.bin", str(seed)); kv = dict(p.split("=") for p in out.split()[1:])
+            res["depth%d" % depth] = {"seed": seed, "constraints": int(kv["constraints"]), "variables": int(kv["variables"]), "address": int(kv["address"]), "r1cs_sha256": sha(t + "/r.bin"), "witness_sha256": sha(t + "/w.bin")}
+        json.dump(res, open(os.path.join(GOLD, "merkle_gadget.json"), "w"), indent=1)
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    run("vectors", os.path.join(GOLD, "ref_vectors.txt"))
+    groth16_fixture("groth16_small", 7, 3, 40, 60, 99)
+    groth16_fixture("groth16_step", 8, 4, 30, 40, 100)
+    gadget_fixture()
+    print("golden fixtures written to", GOLD)
