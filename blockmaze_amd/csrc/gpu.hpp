@@ -1,0 +1,88 @@
+// Host-side interface to the HIP kernels (implemented in gpu.hip).  Plain pointers and sizes only; device buffers are
+// owned by the objects declared here.  Everything runs on one HIP stream per GpuContext; results that the host needs
+// come back through pinned buffers after a single stream synchronisation.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "hostmath.hpp"
+
+namespace zk {
+
+struct GpuError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// raw 32-byte field element / point records as they sit in HBM (Montgomery form, little-endian limbs)
+struct Fe32 { uint32_t l[8]; };
+struct G1AffineRaw { Fe32 x, y; };            // 64 B
+struct G2AffineRaw { Fe32 x0, x1, y0, y1; };  // 128 B
+
+class GpuContext;
+GpuContext &gpu();                             // lazily initialised process-wide context (device from ZK_DEVICE / LOCAL_RANK)
+bool gpu_available();                          // false if no HIP device is visible
+
+template <class T> class DevBuf {              // RAII device allocation
+ public:
+  DevBuf() = default; explicit DevBuf(size_t n); ~DevBuf(); DevBuf(DevBuf &&o) noexcept; DevBuf &operator=(DevBuf &&o) noexcept;
+  DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
+  T *get() const { return p_; } size_t size() const { return n_; }
+  void upload(const T *host, size_t n); void download(T *host, size_t n) const; void zero();
+ private:
+  T *p_ = nullptr; size_t n_ = 0;
+};
+
+// A fixed set of base points resident in HBM (one query of a proving key) plus the reusable MSM workspace for it.
+class MsmG1 {
+ public:
+  MsmG1(const G1AffineRaw *host_points, size_t n, int window_bits, bool filter_ones);
+  ~MsmG1();
+  // scalars_dev: Fr (Montgomery) on the device.  scalar_index_dev: optional gather map (point i uses scalars[index[i]]).
+  // Enqueues the kernels; result() synchronises and finishes the combine on the host.
+  void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
+  host::HG1 result();
+  size_t size() const; const G1AffineRaw *points_dev() const;
+  struct Impl; std::unique_ptr<Impl> impl;
+};
+class MsmG2 {
+ public:
+  MsmG2(const G2AffineRaw *host_points, size_t n, int window_bits, bool filter_ones);
+  ~MsmG2();
+  void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
+  host::HG2 result();
+  struct Impl; std::unique_ptr<Impl> impl;
+};
+
+// Evaluation domain of size m = 2^k or 2^k + 2^r (libfqfft get_evaluation_domain, get_evaluation_domain.tcc:33-52) with
+// its twiddle / coset tables resident in HBM.
+class Domain {
+ public:
+  explicit Domain(size_t min_size); ~Domain();
+  size_t m() const; bool is_step() const;
+  // in place on `batch` device vectors of m elements each, `stride` elements apart (Montgomery form)
+  void fft(Fe32 *data, int batch, size_t stride); void ifft(Fe32 *data, int batch, size_t stride);
+  void coset_fft(Fe32 *data, int batch, size_t stride); void icoset_fft(Fe32 *data, int batch, size_t stride);
+  // a = (a*b - c) / Z on the coset
+  void qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c);
+  struct Impl; std::unique_ptr<Impl> impl;
+};
+
+// R1CS in CSR form resident in HBM (three matrices, coefficient table) — kernel K1
+struct R1csHost {                               // as parsed from a key file or emitted by a circuit
+  size_t n_inputs = 0, n_vars = 0, n_cons = 0;  // n_vars excludes ONE
+  std::vector<uint32_t> rowptr[3], col[3]; std::vector<Fe32> coeff[3];   // coeff canonical (non-Montgomery), col 0 = ONE
+};
+class R1csDev {
+ public:
+  explicit R1csDev(const R1csHost &h); ~R1csDev();
+  // z_dev: n_vars+1 Fr (Montgomery, z[0] = 1).  abc: 3 vectors of m (zero padded, aA[n_cons + i] = z_i for i <= n_inputs; r1cs_to_qap.tcc:227-230)
+  void eval(const Fe32 *z_dev, Fe32 *abc, size_t m);
+  bool satisfied(const Fe32 *abc, size_t m);    // synchronises
+  struct Impl; std::unique_ptr<Impl> impl;
+};
+
+void fr_to_mont_dev(Fe32 *a, size_t n); void fr_from_mont_dev(Fe32 *a, size_t n);
+void gpu_sync();
+
+}  // namespace zk

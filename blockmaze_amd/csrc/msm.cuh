@@ -1,0 +1,152 @@
+// Multi-scalar multiplication  sum_i k_i * P_i  on CDNA4 — the prover's K3/K4/K5 kernels.
+//
+// Replaces libff's multi_exp / multi_exp_with_mixed_addition (FF/algebra/scalar_multiplication/multiexp.tcc:165-282,
+// :443-496) and libsnark's kc_multi_exp_with_mixed_addition (SNARK/knowledge_commitment/kc_multiexp.tcc:21-85).
+// Like the reference it splits the scalars three ways — zero: skipped; one: plain point sum; anything else: Pippenger
+// buckets — but the structure is a GPU one:
+//   classify   one thread per (point, scalar): leave Montgomery form, drop zeros / points at infinity, append "ones" to
+//              a compacted index list, histogram the signed c-bit digits of the rest per window
+//   scan       exclusive prefix sum of the histogram -> bucket offsets
+//   scatter    counting sort of (point index, sign) by (window, |digit|)
+//   accumulate LANES lanes per bucket walk the bucket's slice of the sorted list with mixed additions (XYZZ accumulator
+//              in VGPRs), then combine across lanes with wave shuffles
+//   reduce     per window, sum_b b*B_b by segment: running sums inside a segment, a small scalar multiple for the
+//              segment offset, then a wave-per-window tree
+//   ones       strided partial sums over the compacted list + the same tree
+// The W window sums and the ones-sum go back to the host, which does the c*W doublings of the Horner combine (254
+// dependent doublings are faster on one CPU core than on one GPU lane).
+// Signed digits halve the bucket count: digit d in [-2^(c-1), 2^(c-1)], bucket |d|, sign applied to y on load.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "curve.cuh"
+
+namespace zk {
+
+constexpr int MSM_MAX_WINDOWS = 64;
+
+__host__ __device__ inline int msm_num_windows(int c) { return 254 / c + 1; }
+
+// Signed c-bit digits of a canonical 254-bit scalar.  Returns via callback-free loop in callers: digit(w) needs the carry
+// chain, so decompose once into a small array.
+__device__ __forceinline__ void signed_digits(const uint32_t k[8], int c, int W, int *dig) {
+  uint32_t carry = 0; const uint32_t half = 1u << (c - 1), full = 1u << c, mask = full - 1;
+  for (int w = 0; w < W; w++) {
+    int bit = w * c, word = bit >> 5, sh = bit & 31;
+    uint64_t v = word < 8 ? k[word] : 0; if (word + 1 < 8) v |= (uint64_t)k[word + 1] << 32;
+    uint32_t d = ((uint32_t)(v >> sh) & mask) + carry;
+    if (d > half) { dig[w] = (int)d - (int)full; carry = 1; } else { dig[w] = (int)d; carry = 0; }
+  }
+}
+
+struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; };
+
+// scalars: Fr in Montgomery form.  scalar_index (optional): scalar for point i is scalars[scalar_index[i]] (sparse
+// B-query, kc_multiexp.tcc:52-56); otherwise scalars[i].  point_is_inf (optional): byte flags of key points at infinity.
+template <int DUMMY = 0>
+__global__ void k_msm_classify(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
+                               uint32_t n, int c, int W, int filter_ones, uint32_t *__restrict__ hist, uint32_t *__restrict__ ones, MsmCounters *cnt) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+  if (point_is_inf && point_is_inf[i]) return;
+  Fr k = scalars[scalar_index ? scalar_index[i] : i].from_mont();
+  if (k.is_zero()) return;
+  if (filter_ones) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; if (o == 0) { ones[atomicAdd(&cnt->n_ones, 1u)] = i; return; } }
+  int dig[MSM_MAX_WINDOWS]; signed_digits(k.l, c, W, dig); const uint32_t NB = 1u << (c - 1);
+  for (int w = 0; w < W; w++) { int d = dig[w]; if (d) atomicAdd(&hist[(uint32_t)w * NB + (uint32_t)(d < 0 ? -d : d) - 1], 1u); }
+  atomicAdd(&cnt->n_other, 1u);
+}
+
+template <int DUMMY = 0>
+__global__ void k_msm_scatter(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
+                              uint32_t n, int c, int W, int filter_ones, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ fill, uint32_t *__restrict__ entries) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+  if (point_is_inf && point_is_inf[i]) return;
+  Fr k = scalars[scalar_index ? scalar_index[i] : i].from_mont();
+  if (k.is_zero()) return;
+  if (filter_ones) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; if (o == 0) return; }
+  int dig[MSM_MAX_WINDOWS]; signed_digits(k.l, c, W, dig); const uint32_t NB = 1u << (c - 1);
+  for (int w = 0; w < W; w++) { int d = dig[w]; if (!d) continue; uint32_t key = (uint32_t)w * NB + (uint32_t)(d < 0 ? -d : d) - 1;
+    entries[offsets[key] + atomicAdd(&fill[key], 1u)] = i | (d < 0 ? 0x80000000u : 0u); }
+}
+
+// ---- exclusive scan over uint32 (three small kernels; the arrays are <= 2^21 entries) ------------------------------
+constexpr int SCAN_BLOCK = 1024, SCAN_ITEMS = 4;   // 4096 items per block
+__global__ void k_scan_local(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums, uint32_t n) {
+  __shared__ uint32_t sh[SCAN_BLOCK]; uint32_t base = blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + threadIdx.x * SCAN_ITEMS; uint32_t v[SCAN_ITEMS], s = 0;
+  for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = base + j < n ? in[base + j] : 0; s += v[j]; }
+  sh[threadIdx.x] = s; __syncthreads();
+  for (int d = 1; d < SCAN_BLOCK; d <<= 1) { uint32_t t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+  uint32_t excl = sh[threadIdx.x] - s;
+  for (int j = 0; j < SCAN_ITEMS; j++) { if (base + j < n) out[base + j] = excl; excl += v[j]; }
+  if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = sh[SCAN_BLOCK - 1];
+}
+__global__ void k_scan_block_sums(uint32_t *block_sums, uint32_t nblocks) {   // single block, nblocks <= SCAN_BLOCK*? handled by loop
+  __shared__ uint32_t sh[SCAN_BLOCK]; uint32_t carry = 0;
+  for (uint32_t base = 0; base < nblocks; base += SCAN_BLOCK) {
+    uint32_t i = base + threadIdx.x, v = i < nblocks ? block_sums[i] : 0; sh[threadIdx.x] = v; __syncthreads();
+    for (int d = 1; d < SCAN_BLOCK; d <<= 1) { uint32_t t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+    if (i < nblocks) block_sums[i] = carry + sh[threadIdx.x] - v; uint32_t tot = sh[SCAN_BLOCK - 1]; __syncthreads(); carry += tot;
+  }
+}
+__global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ block_sums, uint32_t n) {
+  uint32_t base = blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + threadIdx.x * SCAN_ITEMS, add = block_sums[blockIdx.x];
+  for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) out[base + j] += add;
+}
+
+// ---- wave-level helpers ------------------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ T shfl_down_struct(const T &v, int delta) {
+  static_assert(sizeof(T) % 4 == 0, "word multiple"); T r; const uint32_t *src = reinterpret_cast<const uint32_t *>(&v); uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) dst[i] = __shfl_down(src[i], delta, 64);
+  return r;
+}
+
+// ---- bucket accumulation: LANES lanes per bucket -------------------------------------------------------------------
+template <class F, int LANES>
+__global__ void __launch_bounds__(256) k_msm_accumulate(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ offsets,
+                                                        const uint32_t *__restrict__ counts, uint32_t n_buckets, XYZZ<F> *__restrict__ buckets) {
+  uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, b = gid / LANES, lane = gid % LANES;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  if (b < n_buckets) {
+    uint32_t beg = offsets[b], end = beg + counts[b];
+    for (uint32_t e = beg + lane; e < end; e += LANES) { uint32_t v = entries[e]; Affine<F> p = points[v & 0x7fffffffu]; if (v >> 31) p.y = p.y.neg(); acc.madd(p); }
+  }
+  if (LANES > 1) {
+#pragma unroll
+    for (int d = LANES / 2; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); acc.add(o); }
+  }
+  if (b < n_buckets && lane == 0) buckets[b] = acc;
+}
+
+// ---- bucket reduction: sum_{b=1..NB} b * B_b per window, by segments of SEG buckets --------------------------------
+// thread (w, s) handles buckets [s*SEG, (s+1)*SEG) of window w (bucket index j holds multiplier j+1):
+//   run = sum B_j ; acc = sum (j - lo + 1) B_j  (running sums from the top) ; out = acc + lo * run
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_reduce_segments(const XYZZ<F> *__restrict__ buckets, uint32_t NB, uint32_t SEG, uint32_t n_seg_total, XYZZ<F> *__restrict__ seg_out) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= n_seg_total) return;
+  uint32_t segs_per_window = NB / SEG, w = t / segs_per_window, s = t % segs_per_window, lo = s * SEG;
+  const XYZZ<F> *B = buckets + (size_t)w * NB + lo; XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
+  for (int j = (int)SEG - 1; j >= 0; j--) { run.add(B[j]); acc.add(run); }
+  if (lo) { XYZZ<F> off = run.mul_small(lo); acc.add(off); }
+  seg_out[t] = acc;
+}
+
+// ---- generic grouped sum: out[g] = sum_{j<len} in[g*len + j], one wave per group ------------------------------------
+template <class F>
+__global__ void __launch_bounds__(64) k_xyzz_group_sum(const XYZZ<F> *__restrict__ in, uint32_t len, XYZZ<F> *__restrict__ out) {
+  uint32_t g = blockIdx.x, lane = threadIdx.x; XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t j = lane; j < len; j += 64) acc.add(in[(size_t)g * len + j]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); acc.add(o); }
+  if (lane == 0) out[g] = acc;
+}
+
+// ---- ones: strided partial sums over the compacted index list ---------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_sum_ones(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ ones, const MsmCounters *cnt, uint32_t n_threads, XYZZ<F> *__restrict__ partial) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= n_threads) return;
+  uint32_t n = cnt->n_ones; XYZZ<F> acc = XYZZ<F>::inf();
+  for (uint32_t j = t; j < n; j += n_threads) acc.madd(points[ones[j]]);
+  partial[t] = acc;
+}
+
+}  // namespace zk

@@ -1,0 +1,83 @@
+// Radix-2 number-theoretic transform over Fr and the pointwise steps of the R1CS->QAP witness map (kernel K2,
+// SURVEY.md §8a rows P2/P2').
+//
+// Replaces libfqfft's basic_radix2_domain::{FFT,iFFT,cosetFFT,icosetFFT,divide_by_Z_on_coset}
+// (FQFFT/evaluation_domain/domains/basic_radix2_domain.tcc:48-112, basic_radix2_domain_aux.tcc:44-79,171-180) and, via
+// the pre/post passes in step_domain kernels, step_radix2_domain (domains/step_radix2_domain.tcc:39-153,242-260).
+// Field arithmetic is exact, so any butterfly schedule gives bit-identical vectors; the schedule here is the GPU one:
+//   * bit-reversal gather, then log2(n) decimation-in-time stages
+//   * the first LOCAL_LOG stages run inside one workgroup on a tile held in LDS (wavefront-level butterflies,
+//     twiddles read through a strided table), the remaining stages stream the vector once per stage
+//   * `batch` independent vectors per launch (the witness map transforms A, B, C together)
+//   * scaling by 1/n and the coset shift g^i are folded into one table multiply
+#pragma once
+#include <hip/hip_runtime.h>
+#include "field.cuh"
+
+namespace zk {
+
+constexpr int NTT_LOCAL_LOG = 10;            // 1024-point tiles: 32 KiB of LDS per workgroup
+constexpr int NTT_LOCAL_THREADS = 512;
+
+__device__ __forceinline__ uint32_t bitrev32(uint32_t x, int bits) { return __brev(x) >> (32 - bits); }
+
+// out[i] = in[bitrev(i)] * (scale ? scale[bitrev(i)] : 1)   (out != in)
+__global__ void k_ntt_bitrev_scale(const Fr *__restrict__ in, Fr *__restrict__ out, const Fr *__restrict__ scale, int logn, size_t stride_in, size_t stride_out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = 1u << logn; if (i >= n) return;
+  const Fr *src = in + blockIdx.y * stride_in; Fr *dst = out + blockIdx.y * stride_out; uint32_t r = bitrev32(i, logn);
+  Fr v = src[r]; if (scale) v = v * scale[r]; dst[i] = v;
+}
+
+// stages 1..min(logn, NTT_LOCAL_LOG) on contiguous 2^L tiles in LDS.  tw[j] = w^j, j < n/2, w the n-th root for this direction.
+__global__ void __launch_bounds__(NTT_LOCAL_THREADS) k_ntt_local(Fr *__restrict__ data, const Fr *__restrict__ tw, int logn, int L, size_t stride) {
+  extern __shared__ uint32_t lds_raw[]; Fr *tile = reinterpret_cast<Fr *>(lds_raw);
+  const uint32_t T = 1u << L, half_n = 1u << (logn - 1); Fr *d = data + blockIdx.y * stride + (size_t)blockIdx.x * T;
+  for (uint32_t i = threadIdx.x; i < T; i += blockDim.x) tile[i] = d[i];
+  __syncthreads();
+  for (int s = 1; s <= L; s++) {
+    const uint32_t half = 1u << (s - 1);
+    for (uint32_t b = threadIdx.x; b < T / 2; b += blockDim.x) {
+      uint32_t j = b & (half - 1), k = (b >> (s - 1)) << s, i0 = k + j, i1 = i0 + half;
+      Fr t = tile[i1]; if (j) t = t * tw[j * (half_n >> (s - 1))];
+      Fr u = tile[i0]; tile[i0] = u + t; tile[i1] = u - t;
+    }
+    __syncthreads();
+  }
+  for (uint32_t i = threadIdx.x; i < T; i += blockDim.x) d[i] = tile[i];
+}
+
+// one global stage s (s > NTT_LOCAL_LOG): thread per butterfly
+__global__ void k_ntt_stage(Fr *__restrict__ data, const Fr *__restrict__ tw, int logn, int s, size_t stride) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, half_n = 1u << (logn - 1); if (b >= half_n) return;
+  Fr *d = data + blockIdx.y * stride; const uint32_t half = 1u << (s - 1); uint32_t j = b & (half - 1), i0 = ((b >> (s - 1)) << s) + j, i1 = i0 + half;
+  Fr t = d[i1]; if (j) t = t * tw[j * (half_n >> (s - 1))];
+  Fr u = d[i0]; d[i0] = u + t; d[i1] = u - t;
+}
+
+// a[i] *= table[i]
+__global__ void k_fr_mul_table(Fr *__restrict__ a, const Fr *__restrict__ table, uint32_t n, size_t stride) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; Fr *d = a + blockIdx.y * stride; d[i] = d[i] * table[i];
+}
+// h[i] = (a[i]*b[i] - c[i]) * zinv[i or 0]   (r1cs_to_qap.tcc:281-310: H_tmp = A*B - C, then divide_by_Z_on_coset)
+__global__ void k_qap_pointwise(Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ c, const Fr *__restrict__ zinv, int zinv_is_table, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; a[i] = (a[i] * b[i] - c[i]) * zinv[zinv_is_table ? i : 0];
+}
+__global__ void k_fr_to_mont(Fr *__restrict__ a, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = a[i].to_mont(); }
+__global__ void k_fr_from_mont(Fr *__restrict__ a, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = a[i].from_mont(); }
+
+// ---- R1CS rows times assignment (kernel K1; r1cs_to_qap.tcc:224-236,281-285; linear_combination::evaluate) ---------
+// CSR with coefficient *indices* into a small table (the circuits use a few hundred distinct coefficients: +-1, +-2^k).
+// out[row] = sum coeff[cid] * z[col]   for row < n_rows; rows are per matrix, one thread per row.
+__global__ void k_r1cs_rows(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col, const uint32_t *__restrict__ cid, const Fr *__restrict__ ctab,
+                            const Fr *__restrict__ z, uint32_t n_rows, Fr *__restrict__ out) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= n_rows) return; Fr acc = Fr::zero();
+  for (uint32_t k = rowptr[r]; k < rowptr[r + 1]; k++) { uint32_t ci = cid[k]; Fr v = z[col[k]];
+    if (ci == 0) acc = acc + v; else if (ci == 1) acc = acc - v; else acc = acc + ctab[ci] * v; }   // table slots 0 / 1 are +1 / -1
+  out[r] = acc;
+}
+// satisfiability: flag[0] |= (a[i]*b[i] != c[i]) over the constraint rows (protoboard::is_satisfied, sendcgo.cpp:209)
+__global__ void k_r1cs_check(const Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ c, uint32_t n_rows, uint32_t *flag) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= n_rows) return; if (a[r] * b[r] != c[r]) atomicOr(flag, 1u);
+}
+
+}  // namespace zk

@@ -1,0 +1,100 @@
+"""ctypes binding of libzkgpu.so's engine layer (include/zkgpu.h).
+
+This is plumbing for tests and the benchmark: numpy arrays in, numpy arrays out, every call goes through the C-ABI into
+the HIP kernels.  There is no Python or CPU implementation behind it — if the shared library is missing or no MI355X is
+visible the calls raise.
+"""
+import ctypes, os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkgpu.so")
+
+class ZkGpuError(RuntimeError):
+    pass
+
+_lib = None
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ZkGpuError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.zkgpu_last_error.restype = ctypes.c_char_p; L.zkgpu_version.restype = ctypes.c_char_p
+        L.zkgpu_domain_size.restype = ctypes.c_size_t; L.zkgpu_domain_size.argtypes = [ctypes.c_size_t]
+        L.zkgpu_msm_create.restype = ctypes.c_void_p; L.zkgpu_r1cs_create.restype = ctypes.c_void_p
+        _lib = L
+    return _lib
+
+def _check(rc):
+    if rc != 0:
+        raise ZkGpuError("zkgpu error %d: %s" % (rc, lib().zkgpu_last_error().decode()))
+
+def _bytes(a):
+    a = np.ascontiguousarray(a); return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+def device_count(): return int(lib().zkgpu_device_count())
+def init(): _check(lib().zkgpu_init())
+
+# arrays are uint64 with 4 words per field element (canonical, little-endian), same convention as oracle/pyoracle.py
+def field_op(field, op, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64); out = np.zeros_like(a); n = a.size // 4
+    bb = np.ascontiguousarray(b, dtype=np.uint64) if b is not None else None
+    _check(lib().zkgpu_test_field_op(field, {"mul": 0, "add": 1, "sub": 2, "inv": 3, "sqr": 4, "neg": 5}[op], _bytes(a), _bytes(bb) if bb is not None else None, _bytes(out), ctypes.c_size_t(n))); return out
+def fq2_op(op, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64); out = np.zeros_like(a); n = a.size // 8
+    bb = np.ascontiguousarray(b, dtype=np.uint64) if b is not None else None
+    _check(lib().zkgpu_test_fq2_op({"mul": 0, "sqr": 1, "inv": 2}[op], _bytes(a), _bytes(bb) if bb is not None else None, _bytes(out), ctypes.c_size_t(n))); return out
+def group_op(group, op, a, b=None):
+    """group 1: (n,8) words, group 2: (n,16) words.  op: add / dbl / madd / mul_small (b = uint32 multipliers)"""
+    a = np.ascontiguousarray(a, dtype=np.uint64); out = np.zeros_like(a); n = a.shape[0]
+    if op == "mul_small":
+        bb = np.zeros_like(a); bb[:, 0] = np.asarray(b, dtype=np.uint64)
+    else:
+        bb = np.ascontiguousarray(b, dtype=np.uint64) if b is not None else None
+    _check(lib().zkgpu_test_group_op(group, {"add": 0, "dbl": 1, "madd": 2, "mul_small": 3}[op], _bytes(a), _bytes(bb) if bb is not None else None, _bytes(out), ctypes.c_size_t(n))); return out
+
+def msm(group, points, scalars, window_bits=0, filter_ones=False):
+    points = np.ascontiguousarray(points, dtype=np.uint64); scalars = np.ascontiguousarray(scalars, dtype=np.uint64); n = scalars.size // 4
+    out = np.zeros(8 if group == 1 else 16, dtype=np.uint64)
+    fn = lib().zkgpu_msm_g1 if group == 1 else lib().zkgpu_msm_g2
+    _check(fn(_bytes(points), _bytes(scalars), ctypes.c_size_t(n), int(window_bits), int(filter_ones), _bytes(out))); return out
+
+class ResidentMsm:
+    """bases resident in HBM (one proving-key query); run() launches only the kernels + the host combine"""
+    def __init__(self, group, points, window_bits=0, filter_ones=False):
+        points = np.ascontiguousarray(points, dtype=np.uint64); self.group = group; self.n = points.shape[0]
+        self.h = lib().zkgpu_msm_create(group, _bytes(points), ctypes.c_size_t(self.n), int(window_bits), int(filter_ones))
+        if not self.h: raise ZkGpuError(lib().zkgpu_last_error().decode())
+    def set_scalars(self, scalars):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64); _check(lib().zkgpu_msm_set_scalars(ctypes.c_void_p(self.h), _bytes(scalars), ctypes.c_size_t(scalars.size // 4)))
+    def run(self):
+        out = np.zeros(8 if self.group == 1 else 16, dtype=np.uint64); _check(lib().zkgpu_msm_run(ctypes.c_void_p(self.h), _bytes(out))); return out
+    def close(self):
+        if self.h: lib().zkgpu_msm_destroy(ctypes.c_void_p(self.h)); self.h = None
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+def domain_size(min_size): return int(lib().zkgpu_domain_size(min_size))
+def domain_transform(min_size, op, data):
+    data = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    _check(lib().zkgpu_domain_transform(ctypes.c_size_t(min_size), {"fft": 0, "ifft": 1, "cosetfft": 2, "icosetfft": 3}[op], _bytes(data))); return data
+
+class R1cs:
+    def __init__(self, n_inputs, n_vars, n_cons, rowptr, col, coeff):
+        self.n_inputs, self.n_vars, self.n_cons = n_inputs, n_vars, n_cons
+        self._keep = [[np.ascontiguousarray(x, dtype=np.uint32) for x in rowptr], [np.ascontiguousarray(x, dtype=np.uint32) for x in col], [np.ascontiguousarray(x, dtype=np.uint64) for x in coeff]]
+        P32 = ctypes.POINTER(ctypes.c_uint32); P8 = ctypes.POINTER(ctypes.c_uint8)
+        rp = (P32 * 3)(*[x.ctypes.data_as(P32) for x in self._keep[0]]); cl = (P32 * 3)(*[x.ctypes.data_as(P32) for x in self._keep[1]]); co = (P8 * 3)(*[x.ctypes.data_as(P8) for x in self._keep[2]])
+        self.h = lib().zkgpu_r1cs_create(ctypes.c_size_t(n_inputs), ctypes.c_size_t(n_vars), ctypes.c_size_t(n_cons), rp, cl, co)
+        if not self.h: raise ZkGpuError(lib().zkgpu_last_error().decode())
+        self.m = domain_size(n_cons + n_inputs + 1)
+    def witness_map(self, z):
+        z = np.ascontiguousarray(z, dtype=np.uint64); H = np.zeros((self.m + 1, 4), dtype=np.uint64)
+        _check(lib().zkgpu_witness_map(ctypes.c_void_p(self.h), _bytes(z), _bytes(H))); return H
+    def close(self):
+        if self.h: lib().zkgpu_r1cs_destroy(ctypes.c_void_p(self.h)); self.h = None
+    def __del__(self):
+        try: self.close()
+        except Exception: pass

@@ -1,0 +1,76 @@
+/* zkgpu.h — C-ABI of libzkgpu.so, the MI355X-native engine behind BlockMaze's libzk_{mint,send,deposit,redeem}.so.
+ *
+ * Two layers:
+ *   1. the drop-in layer: the exact cgo symbols of the reference (declared in zk_mint.h / zk_send.h / zk_deposit.h /
+ *      zk_redeem.h next to this file), exported by libzkgpu.so and re-exported by the four thin libzk_*.so;
+ *   2. this header: the building blocks underneath, exposed so that parity tests and the benchmark can drive each
+ *      kernel on its own.  They correspond to the reference's C++ entry points one level below the cgo wrappers:
+ *        zkgpu_msm_g1/g2      <- libff::multi_exp / multi_exp_with_mixed_addition
+ *                                (libsnark-vnt/depends/libsnark/depends/libff/libff/algebra/scalar_multiplication/multiexp.tcc:403-496)
+ *        zkgpu_domain_*       <- libfqfft::evaluation_domain::{FFT,iFFT,cosetFFT,icosetFFT}
+ *                                (depends/libfqfft/libfqfft/evaluation_domain/domains/basic_radix2_domain.tcc:48-88, step_radix2_domain.tcc:39-167)
+ *        zkgpu_witness_map    <- libsnark::r1cs_to_qap_witness_map (libsnark/reductions/r1cs_to_qap/r1cs_to_qap.tcc:206-334)
+ *        zkgpu_prover_*       <- libsnark::r1cs_gg_ppzksnark_prover (zk_proof_systems/ppzksnark/r1cs_gg_ppzksnark/r1cs_gg_ppzksnark.tcc:391-506)
+ *                                + the key loading of libsnark-vnt/src/send/sendcgo.cpp:64-81,345
+ *
+ * Conventions: all pointers are HOST pointers.  A field element is 32 bytes, little-endian, CANONICAL (not Montgomery).
+ * G1 affine = x | y (64 bytes), G2 affine = x.c0 | x.c1 | y.c0 | y.c1 (128 bytes); the point at infinity is all zero bytes.
+ * Every function returns 0 on success and a negative code on failure; zkgpu_last_error() gives the message.
+ * There is NO CPU fallback: without a HIP device every compute entry point fails with ZKGPU_ERR_NO_DEVICE.
+ */
+#ifndef ZKGPU_H
+#define ZKGPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKGPU_OK 0
+#define ZKGPU_ERR_NO_DEVICE (-1)
+#define ZKGPU_ERR_ARG (-2)
+#define ZKGPU_ERR_RUNTIME (-3)
+#define ZKGPU_ERR_UNSATISFIED (-4)
+
+const char *zkgpu_last_error(void);
+const char *zkgpu_version(void);
+int zkgpu_device_count(void);                       /* number of visible HIP devices (0 on a CPU-only host) */
+int zkgpu_init(void);                               /* create the device context now instead of lazily */
+
+/* ---- device arithmetic probes (parity tests of the __device__ field / curve code) ---------------------------------- */
+/* field: 0 = Fr, 1 = Fq.  op: 0 mul, 1 add, 2 sub, 3 inverse(a), 4 square(a), 5 negate(a) */
+int zkgpu_test_field_op(int field, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
+/* op: 0 mul, 1 square(a), 2 inverse(a) on Fq2 (64-byte elements c0 | c1) */
+int zkgpu_test_fq2_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
+/* group: 1 = G1, 2 = G2.  op: 0 general add, 1 double(a), 2 mixed add (b affine), 3 a*k for 32-bit k (k in b's first 4 bytes) */
+int zkgpu_test_group_op(int group, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
+
+/* ---- multi-scalar multiplication ------------------------------------------------------------------------------------ */
+/* window_bits 0 = choose from n.  filter_ones != 0 = treat scalars 0 / 1 specially like multi_exp_with_mixed_addition. */
+int zkgpu_msm_g1(const uint8_t *points, const uint8_t *scalars, size_t n, int window_bits, int filter_ones, uint8_t out[64]);
+int zkgpu_msm_g2(const uint8_t *points, const uint8_t *scalars, size_t n, int window_bits, int filter_ones, uint8_t out[128]);
+
+/* resident form for benchmarking: bases stay in HBM, scalars are uploaded once, run() times only the kernels */
+typedef struct zkgpu_msm zkgpu_msm;
+zkgpu_msm *zkgpu_msm_create(int group, const uint8_t *points, size_t n, int window_bits, int filter_ones);
+int zkgpu_msm_set_scalars(zkgpu_msm *h, const uint8_t *scalars, size_t n);
+int zkgpu_msm_run(zkgpu_msm *h, uint8_t *out);     /* out: 64 or 128 bytes */
+void zkgpu_msm_destroy(zkgpu_msm *h);
+
+/* ---- evaluation domains --------------------------------------------------------------------------------------------- */
+size_t zkgpu_domain_size(size_t min_size);          /* m chosen by get_evaluation_domain for this minimum size, 0 if none */
+/* op: 0 FFT, 1 iFFT, 2 cosetFFT (g = 5), 3 icosetFFT.  data: m elements, transformed in place */
+int zkgpu_domain_transform(size_t min_size, int op, uint8_t *data);
+
+/* ---- R1CS / QAP ------------------------------------------------------------------------------------------------------- */
+typedef struct zkgpu_r1cs zkgpu_r1cs;
+/* CSR per matrix: rowptr (n_cons+1), col (nnz, 0 = the constant ONE), coeff (nnz x 32 bytes canonical) */
+zkgpu_r1cs *zkgpu_r1cs_create(size_t n_inputs, size_t n_vars, size_t n_cons, const uint32_t *const rowptr[3], const uint32_t *const col[3], const uint8_t *const coeff[3]);
+void zkgpu_r1cs_destroy(zkgpu_r1cs *cs);
+/* z: n_vars elements (without ONE).  h_out: (m+1) elements, m = zkgpu_domain_size(n_cons + n_inputs + 1).  Returns ZKGPU_ERR_UNSATISFIED if z violates a constraint. */
+int zkgpu_witness_map(zkgpu_r1cs *cs, const uint8_t *z, uint8_t *h_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
