@@ -1,0 +1,186 @@
+// BlockMaze statement circuits — see blockmaze_circuits.hpp.  Allocation and constraint order follow the reference's
+// gadget constructors / generate_r1cs_constraints() line by line (cited per class); the code itself is written against
+// circuit::Board.
+#include <cstring>
+#include <stdexcept>
+#include "blockmaze_circuits.hpp"
+
+namespace zk {
+using namespace circuit;
+
+const char *circuit_name(CircuitKind k) { static const char *n[] = {"mint", "send", "deposit", "redeem"}; return n[(int)k]; }
+
+// ---- bit order helpers (src/send/circuit/utils.tcc:23-66, src/send/util.h:96-107) --------------------------------------
+std::vector<bool> blob_bits(const uint8_t *b, size_t nbytes) { std::vector<bool> v(nbytes * 8); for (size_t i = 0; i < nbytes; i++) for (int j = 0; j < 8; j++) v[i * 8 + j] = (b[i] >> (7 - j)) & 1; return v; }
+std::vector<bool> u64_bits(uint64_t x) { uint8_t le[8]; for (int i = 0; i < 8; i++) le[i] = (uint8_t)(x >> (8 * i)); return blob_bits(le, 8); }
+std::vector<Fe32> pack_public_bits(const std::vector<bool> &bits) {
+  const size_t chunk = 253; size_t n = (bits.size() + chunk - 1) / chunk; std::vector<Fe32> r(n);
+  for (size_t i = 0; i < n; i++) { memset(&r[i], 0, 32); for (size_t j = 0; j < chunk && i * chunk + j < bits.size(); j++) if (bits[i * chunk + j]) r[i].l[j / 32] |= 1u << (j % 32); }
+  return r; }
+
+void Circuit::export_assignment(std::vector<Fe32> &z) const { size_t n = board.val.size() - 1; z.resize(n); for (size_t i = 0; i < n; i++) { HFr c = board.val[i + 1].from_mont(); memcpy(&z[i], c.l, 32); } }
+
+namespace {
+const LC ONE_LC = LC::constant(HFr::one());
+
+// value from bits "by order" (pb_variable.tcc:119-133): big-endian bytes, MSB-first bits == the integer itself for a
+// 64-bit value stored as little-endian bytes
+HFr value_by_order(const Board &b, const VarArray &bits) { HFr r = HFr::zero(); size_t n = bits.size();
+  for (size_t i = 0; i < n / 8; i++) for (size_t j = 0; j < 8; j++) { r = r.dbl(); r = r + b.val[bits[n - 1 - i * 8 - (7 - j)]]; } return r; }
+void fill(Board &b, const VarArray &vars, const std::vector<bool> &bits) { for (size_t i = 0; i < vars.size(); i++) b.set_bit(vars[i], bits[i]); }
+
+struct MultiPacking {   // basic_gadgets.tcc:60-108, chunk = Fr capacity = 253 bits
+  Board &b; std::vector<Packing> packers;
+  MultiPacking(Board &b, const VarArray &bits, const VarArray &packed) : b(b) { const size_t chunk = 253;
+    for (size_t i = 0; i < packed.size(); i++) { VarArray part(bits.begin() + i * chunk, bits.begin() + std::min((i + 1) * chunk, bits.size())); packers.emplace_back(b, to_lcs(part), packed[i]); } }
+  void constraints(bool bitness) { for (auto &p : packers) p.constraints(bitness); }
+  void witness_from_bits() { for (auto &p : packers) p.witness_from_bits(); }
+};
+struct Disjunction {    // basic_gadgets.tcc:197-261
+  Board &b; VarArray inputs; Var output, inv;
+  Disjunction(Board &b, const VarArray &inputs, Var output) : b(b), inputs(inputs), output(output), inv(b.alloc()) {}
+  void constraints() { LC sum; for (Var v : inputs) sum.add(LC(v)); b.constraint(LC(inv), sum, LC(output)); b.constraint(ONE_LC - LC(output), sum, LC()); }
+  void witness() { HFr sum = HFr::zero(); for (Var v : inputs) sum = sum + b.val[v]; if (sum.is_zero()) { b.val[inv] = HFr::zero(); b.val[output] = HFr::zero(); } else { b.val[inv] = sum.inv(); b.val[output] = HFr::one(); } }
+};
+// less_comparison_gadget (src/send/circuit/comparison.tcc:5-96): proves A <= B for 64-bit values.  alpha[64] is the
+// constant ONE (alpha.emplace_back(0) appends variable index 0), so packed(alpha) = 2^64 + B - A forces B - A >= 0.
+struct LessCmp {
+  Board &b; VarArray alpha; Var alpha_packed, not_all_zeros; LC A, B; std::unique_ptr<Disjunction> dis;
+  LessCmp(Board &b, const LC &A, const LC &B) : b(b), A(A), B(B) { alpha = b.alloc_array(64); alpha.push_back(0); alpha_packed = b.alloc(); not_all_zeros = b.alloc();
+    dis.reset(new Disjunction(b, VarArray(alpha.begin(), alpha.begin() + 64), not_all_zeros)); }
+  void constraints() { boolean_constraint(b, LC(not_all_zeros)); Packing(b, to_lcs(alpha), alpha_packed).constraints(true);
+    b.constraint(ONE_LC, LC::constant(HFr::from_u64(2).pow_u64(64)) + B - A, LC(alpha_packed)); dis->constraints(); b.constraint(ONE_LC, LC(not_all_zeros), LC(not_all_zeros)); }
+  void witness() { b.val[alpha_packed] = HFr::from_u64(2).pow_u64(64) + b.eval(B) - b.eval(A); fill_bits_of_value(b, alpha, b.val[alpha_packed]); dis->witness(); }
+};
+
+// two-/one-block SHA-256 wrappers with hard-wired padding (src/send/circuit/commitment.tcc); `pad` is the bit pattern of
+// the padding, realised with the constant ONE and the variable ZERO (utils.tcc:3-12)
+VarArray pad_bits(Var ZERO, size_t msg_bits, size_t total_bits) { VarArray p(total_bits - msg_bits, ZERO); p[0] = 0 /* ONE */;
+  for (int i = 0; i < 64; i++) if ((msg_bits >> i) & 1) p[p.size() - 1 - i] = 0; return p; }
+VarArray concat(std::initializer_list<VarArray> parts) { VarArray r; for (auto &p : parts) r.insert(r.end(), p.begin(), p.end()); return r; }
+struct ShaTwoBlock {   // CMTA / CMTS / PRF: intermediate digest allocated first, then hasher1, hasher2
+  Board &b; Digest inter; std::unique_ptr<Sha256Compression> h1, h2;
+  ShaTwoBlock(Board &b, const VarArray &message_and_padding /* 1024 bits */, const VarArray &out) : b(b), inter(b, 256) {
+    VarArray b1(message_and_padding.begin(), message_and_padding.begin() + 512), b2(message_and_padding.begin() + 512, message_and_padding.end());
+    h1.reset(new Sha256Compression(b, sha256_default_iv(), b1, inter.bits)); h2.reset(new Sha256Compression(b, to_lcs(inter.bits), b2, out)); }
+  void constraints() { inter.constraints(); h1->constraints(); h2->constraints(); }
+  void witness() { h1->witness(); h2->witness(); }
+};
+struct ShaOneBlock {   // CRH
+  std::unique_ptr<Sha256Compression> h1;
+  ShaOneBlock(Board &b, const VarArray &block, const VarArray &out) { h1.reset(new Sha256Compression(b, sha256_default_iv(), block, out)); }
+  void constraints() { h1->constraints(); }
+  void witness() { h1->witness(); }
+};
+std::unique_ptr<ShaTwoBlock> make_cmta(Board &b, Var ZERO, const VarArray &v, const VarArray &sn, const VarArray &r, const VarArray &out) { return std::unique_ptr<ShaTwoBlock>(new ShaTwoBlock(b, concat({v, sn, r, pad_bits(ZERO, 576, 1024)}), out)); }
+std::unique_ptr<ShaTwoBlock> make_cmts(Board &b, Var ZERO, const VarArray &v, const VarArray &pk, const VarArray &r, const VarArray &sn_old, const VarArray &out) { return std::unique_ptr<ShaTwoBlock>(new ShaTwoBlock(b, concat({v, pk, r, sn_old, pad_bits(ZERO, 736, 1024)}), out)); }
+std::unique_ptr<ShaTwoBlock> make_prf(Board &b, Var ZERO, const VarArray &sk, const VarArray &r, const VarArray &out) { return std::unique_ptr<ShaTwoBlock>(new ShaTwoBlock(b, concat({sk, r, pad_bits(ZERO, 512, 1024)}), out)); }
+std::unique_ptr<ShaOneBlock> make_crh(Board &b, Var ZERO, const VarArray &pk, const VarArray &r, const VarArray &out) { return std::unique_ptr<ShaOneBlock>(new ShaOneBlock(b, concat({pk, r, pad_bits(ZERO, 416, 512)}), out)); }
+
+void bool64(Board &b, const VarArray &v) { for (Var x : v) boolean_constraint(b, LC(x)); }
+
+// ======================================================================================================================
+// send (src/send/circuit/gadget.tcc:27-326, note.tcc, less_cmp.tcc)
+// ======================================================================================================================
+struct SendCircuit : Circuit {
+  VarArray packed_inputs, unpacked; std::unique_ptr<Digest> cmtA_old, sn_old, cmtS, cmtA, r_old, pk_recv, pk_sender, r_s, sn, r, sk; std::unique_ptr<MultiPacking> unpacker;
+  Var ZERO; VarArray value_old, value_s, value;
+  Var l_value_old_packed, l_value_s_packed; std::unique_ptr<LessCmp> less;          // note_gadget_with_comparison_for_value_old
+  Var s_value_old_packed, s_value_s_packed, s_value_packed;                           // note_gadget_with_packing_and_SUB
+  std::unique_ptr<ShaOneBlock> crh; std::unique_ptr<ShaTwoBlock> prf, cmt_old, cmt_s, cmt_new;
+  explicit SendCircuit(bool emit) : Circuit(emit) {
+    Board &b = board;
+    packed_inputs = b.alloc_array(5); b.set_input_sizes(5);                                                       // gadget.tcc:87-88
+    auto alloc256 = [&](std::unique_ptr<Digest> &d) { d.reset(new Digest(b, 256)); unpacked.insert(unpacked.end(), d->bits.begin(), d->bits.end()); };
+    alloc256(cmtA_old); alloc256(sn_old); alloc256(cmtS); alloc256(cmtA);                                           // :90-93
+    unpacker.reset(new MultiPacking(b, unpacked, packed_inputs));
+    ZERO = b.alloc();                                                                                               // :108
+    value_old = b.alloc_array(64); r_old.reset(new Digest(b, 256));                                                 // :110-111
+    value_s = b.alloc_array(64); pk_recv.reset(new Digest(b, 160)); pk_sender.reset(new Digest(b, 160)); r_s.reset(new Digest(b, 256));   // :114-117
+    value = b.alloc_array(64); sn.reset(new Digest(b, 256)); r.reset(new Digest(b, 256)); sk.reset(new Digest(b, 256));                   // :119-123
+    l_value_old_packed = b.alloc(); l_value_s_packed = b.alloc(); less.reset(new LessCmp(b, LC(l_value_s_packed), LC(l_value_old_packed)));   // note.tcc:35-37, less_cmp.tcc:23-24
+    s_value_old_packed = b.alloc(); s_value_s_packed = b.alloc(); s_value_packed = b.alloc();                                                   // note.tcc:35-37,116
+    crh = make_crh(b, ZERO, pk_sender->bits, r->bits, r_s->bits);                                                    // gadget.tcc:153-159
+    prf = make_prf(b, ZERO, sk->bits, r->bits, sn->bits);
+    cmt_old = make_cmta(b, ZERO, value_old, sn_old->bits, r_old->bits, cmtA_old->bits);
+    cmt_s = make_cmts(b, ZERO, value_s, pk_recv->bits, r_s->bits, sn_old->bits, cmtS->bits);
+    cmt_new = make_cmta(b, ZERO, value, sn->bits, r->bits, cmtA->bits);
+    if (emit) emit_constraints();
+    b.finish();
+  }
+  void note_packing_constraints() { Board &b = board; bool64(b, value_old); bool64(b, value_s); sn_old->constraints(); r_old->constraints(); pk_recv->constraints(); r_s->constraints(); }   // note.tcc:40-62
+  void emit_constraints() { Board &b = board;                                                                         // gadget.tcc:196-225
+    unpacker->constraints(true);
+    note_packing_constraints(); less->constraints();                                                                  // lessCMP
+    note_packing_constraints(); bool64(b, value); sn->constraints(); r->constraints(); sk->constraints(); pk_sender->constraints();   // noteSUB (note.tcc:119-140)
+    b.constraint(ONE_LC, LC(s_value_old_packed) - LC(s_value_s_packed), LC(s_value_packed));
+    b.constraint(ONE_LC, LC(ZERO), LC());                                                                             // ZERO == 0
+    r_s->constraints(); crh->constraints(); sn->constraints(); prf->constraints(); sn_old->constraints();
+    cmtA_old->constraints(); cmt_old->constraints(); cmtS->constraints(); cmt_s->constraints(); cmtA->constraints(); cmt_new->constraints(); }
+  void assign(const SendInputs &in) { Board &b = board;                                                               // gadget.tcc:228-271
+    auto note_fill = [&](Var vo_packed, Var vs_packed) { fill(b, value_old, u64_bits(in.value_old)); b.val[vo_packed] = value_by_order(b, value_old);
+      sn_old->fill(blob_bits(in.sn_old.b, 32)); r_old->fill(blob_bits(in.r_old.b, 32)); fill(b, value_s, u64_bits(in.value_s)); b.val[vs_packed] = value_by_order(b, value_s);
+      pk_recv->fill(blob_bits(in.pk_recv.b, 20)); r_s->fill(blob_bits(in.r_s.b, 32)); };
+    note_fill(l_value_old_packed, l_value_s_packed); less->witness();
+    note_fill(s_value_old_packed, s_value_s_packed); fill(b, value, u64_bits(in.value)); b.val[s_value_packed] = value_by_order(b, value);
+    sn->fill(blob_bits(in.sn.b, 32)); r->fill(blob_bits(in.r.b, 32)); sk->fill(blob_bits(in.sk.b, 32)); pk_sender->fill(blob_bits(in.pk_sender.b, 20));
+    b.val[ZERO] = HFr::zero();
+    crh->witness(); prf->witness(); cmt_old->witness(); cmt_s->witness(); cmt_new->witness();
+    cmtA_old->fill(blob_bits(in.cmtA_old.b, 32)); cmtS->fill(blob_bits(in.cmtS.b, 32)); cmtA->fill(blob_bits(in.cmtA.b, 32));
+    unpacker->witness_from_bits(); }
+};
+
+// ======================================================================================================================
+// mint (src/mint/circuit/gadget.tcc, note.tcc, add_cmp.tcc) and redeem (src/redeem/circuit/gadget.tcc, note.tcc, sub_cmp.tcc)
+// ======================================================================================================================
+struct MintRedeemCircuit : Circuit {
+  bool redeem; VarArray packed_inputs, unpacked; std::unique_ptr<Digest> cmtA_old, sn_old, cmtA, sk, r, r_old, sn; std::unique_ptr<MultiPacking> unpacker;
+  Var ZERO; VarArray value, value_old, value_s; Var value_packed, value_old_packed, value_s_packed; std::unique_ptr<LessCmp> less; std::unique_ptr<ShaTwoBlock> prf, cmt_old, cmt_new;
+  MintRedeemCircuit(bool emit, bool redeem) : Circuit(emit), redeem(redeem) { Board &b = board;
+    packed_inputs = b.alloc_array(4); b.set_input_sizes(4);
+    auto alloc256 = [&](std::unique_ptr<Digest> &d) { d.reset(new Digest(b, 256)); unpacked.insert(unpacked.end(), d->bits.begin(), d->bits.end()); };
+    alloc256(cmtA_old); alloc256(sn_old); alloc256(cmtA); value_s = b.alloc_array(64); unpacked.insert(unpacked.end(), value_s.begin(), value_s.end());   // mint/gadget.tcc:84-88
+    unpacker.reset(new MultiPacking(b, unpacked, packed_inputs));
+    ZERO = b.alloc(); value = b.alloc_array(64); value_old = b.alloc_array(64); sk.reset(new Digest(b, 256)); r.reset(new Digest(b, 256)); r_old.reset(new Digest(b, 256)); sn.reset(new Digest(b, 256));
+    value_packed = b.alloc(); value_old_packed = b.alloc(); value_s_packed = b.alloc();                                 // note.tcc:39-43
+    if (redeem) less.reset(new LessCmp(b, LC(value_s_packed), LC(value_old_packed)));                                   // sub_cmp.tcc:25-27
+    prf = make_prf(b, ZERO, sk->bits, r->bits, sn->bits); cmt_old = make_cmta(b, ZERO, value_old, sn_old->bits, r_old->bits, cmtA_old->bits); cmt_new = make_cmta(b, ZERO, value, sn->bits, r->bits, cmtA->bits);
+    if (emit) emit_constraints();
+    b.finish(); }
+  void emit_constraints() { Board &b = board; unpacker->constraints(true);
+    bool64(b, value_old); bool64(b, value_s); bool64(b, value); sk->constraints(); r->constraints(); r_old->constraints();
+    if (redeem) { sn->constraints(); sn_old->constraints(); b.constraint(ONE_LC, LC(value_old_packed) - LC(value_s_packed), LC(value_packed)); less->constraints(); }   // redeem/note.tcc:50-79, sub_cmp.tcc:30-37
+    else b.constraint(ONE_LC, LC(value_old_packed) + LC(value_s_packed), LC(value_packed));                                                                       // add_cmp.tcc:23-29
+    b.constraint(ONE_LC, LC(ZERO), LC());
+    sn->constraints(); prf->constraints(); sn_old->constraints(); cmtA_old->constraints(); cmt_old->constraints(); cmtA->constraints(); cmt_new->constraints(); }
+  template <class In> void assign(const In &in) { Board &b = board;
+    fill(b, value, u64_bits(in.value)); b.val[value_packed] = value_by_order(b, value); fill(b, value_old, u64_bits(in.value_old)); b.val[value_old_packed] = value_by_order(b, value_old);
+    fill(b, value_s, u64_bits(in.value_s)); b.val[value_s_packed] = value_by_order(b, value_s);
+    sk->fill(blob_bits(in.sk.b, 32)); r->fill(blob_bits(in.r.b, 32)); r_old->fill(blob_bits(in.r_old.b, 32));
+    if (redeem) { sn->fill(blob_bits(in.sn.b, 32)); sn_old->fill(blob_bits(in.sn_old.b, 32)); less->witness(); }
+    b.val[ZERO] = HFr::zero(); prf->witness();
+    if (!redeem) { sn->fill(blob_bits(in.sn.b, 32)); sn_old->fill(blob_bits(in.sn_old.b, 32)); }                        // mint/gadget.tcc:213-221
+    cmt_old->witness(); cmt_new->witness(); cmtA_old->fill(blob_bits(in.cmtA_old.b, 32)); cmtA->fill(blob_bits(in.cmtA.b, 32)); unpacker->witness_from_bits(); }
+};
+
+// libsnark's own two-to-one hash test circuit (test_sha256_gadget.cpp:20-41)
+struct Sha256TwoToOne : Circuit {
+  std::unique_ptr<Digest> left, right, output; std::unique_ptr<Sha256Compression> f;
+  explicit Sha256TwoToOne(bool emit) : Circuit(emit) { Board &b = board; left.reset(new Digest(b, 256)); right.reset(new Digest(b, 256)); output.reset(new Digest(b, 256));
+    f.reset(new Sha256Compression(b, sha256_default_iv(), concat({left->bits, right->bits}), output->bits)); if (emit) f->constraints(); b.finish(); }
+};
+}  // namespace
+
+std::unique_ptr<Circuit> make_send_circuit(bool emit) { return std::unique_ptr<Circuit>(new SendCircuit(emit)); }
+void assign_send(Circuit &c, const SendInputs &in) { static_cast<SendCircuit &>(c).assign(in); }
+std::unique_ptr<Circuit> make_mint_circuit(bool emit) { return std::unique_ptr<Circuit>(new MintRedeemCircuit(emit, false)); }
+void assign_mint(Circuit &c, const MintInputs &in) { static_cast<MintRedeemCircuit &>(c).assign(in); }
+std::unique_ptr<Circuit> make_redeem_circuit(bool emit) { return std::unique_ptr<Circuit>(new MintRedeemCircuit(emit, true)); }
+void assign_redeem(Circuit &c, const RedeemInputs &in) { static_cast<MintRedeemCircuit &>(c).assign(in); }
+std::unique_ptr<Circuit> make_sha256_two_to_one(bool emit) { return std::unique_ptr<Circuit>(new Sha256TwoToOne(emit)); }
+void assign_sha256_two_to_one(Circuit &c, const std::vector<bool> &l, const std::vector<bool> &r) { auto &s = static_cast<Sha256TwoToOne &>(c); s.left->fill(l); s.right->fill(r); s.f->witness(); }
+
+}  // namespace zk
+namespace zk {
+// deposit: implemented in blockmaze_deposit.cpp
+}

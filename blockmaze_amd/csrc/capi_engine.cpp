@@ -17,6 +17,7 @@ using namespace zk;
 using namespace zk::host;
 
 static thread_local std::string g_err;
+void zkgpu_set_error(const std::string &s) { g_err = s; }
 std::mutex g_gpu_mutex;   // one proof pipeline at a time on the device (cgo calls arrive on arbitrary OS threads)
 
 template <class Fn> static int guarded(Fn fn) {

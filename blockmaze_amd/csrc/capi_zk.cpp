@@ -1,0 +1,160 @@
+// The drop-in layer: the C symbols go-ethereum/zktx binds through cgo (include/zk_{common,mint,send,deposit,redeem}.h).
+// Behavioural contract restated from libsnark-vnt/src/{mint,send,deposit,redeem}/*cgo.cpp:
+//   * hex strings in, freshly allocated NUL-terminated hex strings out (the Go side never frees them);
+//   * a witness that violates the circuit yields the hex of the default proof (G1::one, G2::one, G1::one), whose first
+//     characters are "000000..." — the failure sentinel go-ethereum checks (internal/ethapi/api.go:1690);
+//   * keys are looked up under /usr/local/prfKey/ (override: ZK_PRFKEY_DIR); unlike the reference they are parsed once
+//     and kept resident in HBM, re-read only when the file's size or mtime changes;
+//   * no exception, abort or signal handler ever crosses this boundary; calls may arrive concurrently on any thread.
+#include <sys/stat.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include "../../include/zk_deposit.h"
+#include "../../include/zk_mint.h"
+#include "../../include/zk_redeem.h"
+#include "../../include/zk_send.h"
+#include "../../include/zkgpu.h"
+#include "blockmaze_circuits.hpp"
+#include "groth16.hpp"
+
+using namespace zk;
+extern std::mutex g_gpu_mutex;
+extern void zkgpu_set_error(const std::string &s);
+
+namespace {
+char *dup_string(const std::string &s) { char *p = (char *)malloc(s.size() + 1); if (p) memcpy(p, s.c_str(), s.size() + 1); return p; }
+char *hash_out(const Blob256 &h) { return dup_string(blob_to_hex(h.b, 32)); }
+std::string key_dir() { const char *e = getenv("ZK_PRFKEY_DIR"); return e && *e ? e : "/usr/local/prfKey"; }
+std::string key_path(CircuitKind k, bool pk) { return key_dir() + "/" + circuit_name(k) + (pk ? "pk.txt" : "vk.txt"); }
+
+struct FileStamp { off_t size = -1; time_t mtime = 0; long mtime_ns = 0; bool operator==(const FileStamp &o) const { return size == o.size && mtime == o.mtime && mtime_ns == o.mtime_ns; } };
+bool stamp_of(const std::string &p, FileStamp &s) { struct stat st; if (stat(p.c_str(), &st)) return false; s.size = st.st_size; s.mtime = st.st_mtim.tv_sec; s.mtime_ns = st.st_mtim.tv_nsec; return true; }
+
+struct ProverSlot { FileStamp stamp; std::shared_ptr<Prover> prover; std::unique_ptr<Circuit> circuit; };
+struct VkSlot { FileStamp stamp; std::shared_ptr<VerifyingKeyHost> vk; };
+std::mutex g_cache_mutex; std::map<std::string, ProverSlot> g_provers; std::map<std::string, VkSlot> g_vks;
+
+std::unique_ptr<Circuit> make_circuit(CircuitKind k, bool emit) {
+  switch (k) { case CircuitKind::Mint: return make_mint_circuit(emit); case CircuitKind::Send: return make_send_circuit(emit); case CircuitKind::Redeem: return make_redeem_circuit(emit); default: return make_deposit_circuit(emit, 8); } }
+
+// caller holds g_gpu_mutex
+ProverSlot &prover_for(CircuitKind k) {
+  std::string path = key_path(k, true); FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("proving key not found: " + path);
+  ProverSlot &slot = g_provers[path];
+  if (!slot.prover || !(slot.stamp == st)) { ProvingKeyHost pk = load_proving_key(path); slot.prover.reset(new Prover(pk)); slot.stamp = st; slot.circuit = make_circuit(k, false);
+    if (slot.circuit->board.num_variables() != slot.prover->num_variables() || slot.circuit->num_inputs() != slot.prover->num_inputs()) { slot.prover.reset(); throw std::runtime_error("proving key does not belong to the " + std::string(circuit_name(k)) + " circuit"); } }
+  return slot;
+}
+std::shared_ptr<VerifyingKeyHost> vk_for(CircuitKind k) {
+  std::string path = key_path(k, false); FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("verification key not found: " + path);
+  std::lock_guard<std::mutex> lk(g_cache_mutex); VkSlot &slot = g_vks[path];
+  if (!slot.vk || !(slot.stamp == st)) { slot.vk.reset(new VerifyingKeyHost(load_verifying_key(path))); slot.stamp = st; }
+  return slot.vk;
+}
+bool parse_fixed_rs(Fe32 &r, Fe32 &s) {   // test hook: ZK_FIXED_RS="<r hex>:<s hex>" makes proofs reproducible (the reference draws r, s from std::random_device)
+  const char *e = getenv("ZK_FIXED_RS"); if (!e) return false; const char *colon = strchr(e, ':'); if (!colon) return false;
+  auto parse = [](const char *b, const char *en, Fe32 &o) { memset(&o, 0, sizeof o); int n = 0; for (const char *p = en; p-- > b;) { char ch = *p; int d = ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : -1; if (d < 0 || n >= 64) return false; o.l[n / 8] |= (uint32_t)d << (4 * (n % 8)); n++; } return n > 0; };
+  return parse(e, colon, r) && parse(colon + 1, e + strlen(e), s);
+}
+
+// shared tail of the gen*proof functions: assign() has filled the circuit's board
+template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
+  try {
+    if (!gpu_available()) { zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback"); fprintf(stderr, "libzkgpu: no HIP device visible, cannot generate %s proof\n", circuit_name(k)); return dup_string(proof_to_hex(default_proof())); }
+    std::lock_guard<std::mutex> lk(g_gpu_mutex);
+    ProverSlot &slot = prover_for(k); assign(*slot.circuit);
+    std::vector<Fe32> z; slot.circuit->export_assignment(z);
+    printf("Trying to generate %s proof...\n", circuit_name(k)); fflush(stdout);
+    Fe32 r, s; bool fixed = parse_fixed_rs(r, s); Proof proof;
+    if (!slot.prover->prove(z.data(), fixed ? &r : nullptr, fixed ? &s : nullptr, proof)) { printf("can not generate %s proof\n", circuit_name(k)); fflush(stdout); proof = default_proof(); }
+    return dup_string(proof_to_hex(proof));
+  } catch (const std::exception &e) { zkgpu_set_error(e.what()); fprintf(stderr, "libzkgpu: %s\n", e.what()); return dup_string(proof_to_hex(default_proof())); }
+  catch (...) { zkgpu_set_error("unknown error"); return dup_string(proof_to_hex(default_proof())); }
+}
+bool verify(CircuitKind k, const char *data, const std::vector<bool> &public_bits) {
+  bool ok = false;
+  try { Proof p; if (data && strnlen(data, 512) == 512 && proof_from_hex(data, p)) { std::vector<Fe32> inputs = pack_public_bits(public_bits); ok = verify_proof(*vk_for(k), inputs.data(), inputs.size(), p); } }
+  catch (const std::exception &e) { zkgpu_set_error(e.what()); fprintf(stderr, "libzkgpu: %s\n", e.what()); ok = false; } catch (...) { ok = false; }
+  printf("Verifying %s proof %s!!!\n", circuit_name(k), ok ? "successfully" : "unsuccessfully"); fflush(stdout); return ok;
+}
+void append(std::vector<bool> &v, const std::vector<bool> &w) { v.insert(v.end(), w.begin(), w.end()); }
+}  // namespace
+
+template <class Fn> static int guarded(Fn fn) {
+  try { if (!gpu_available()) { zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback"); return ZKGPU_ERR_NO_DEVICE; } std::lock_guard<std::mutex> lk(g_gpu_mutex); return fn(); }
+  catch (const std::exception &e) { zkgpu_set_error(e.what()); return ZKGPU_ERR_RUNTIME; } catch (...) { zkgpu_set_error("unknown error"); return ZKGPU_ERR_RUNTIME; } }
+template <class Fn> static int guarded_host(Fn fn) { try { return fn(); } catch (const std::exception &e) { zkgpu_set_error(e.what()); return ZKGPU_ERR_RUNTIME; } catch (...) { zkgpu_set_error("unknown error"); return ZKGPU_ERR_RUNTIME; } }
+
+extern "C" {
+char *genCMT(uint64_t value, char *sn_string, char *r_string) { return hash_out(note_cm(value, blob256_from_hex(sn_string), blob256_from_hex(r_string))); }
+char *genCMTS(uint64_t value_s, char *pk_string, char *r_s_string, char *sn_old_string) { return hash_out(note_s_cm(value_s, blob160_from_hex(pk_string), blob256_from_hex(r_s_string), blob256_from_hex(sn_old_string))); }
+char *computePRF(char *sk_string, char *r_string) { return hash_out(compute_prf(blob256_from_hex(sk_string), blob256_from_hex(r_string))); }
+char *computeCRH(char *pk_string, char *r_string) { return hash_out(compute_crh(blob160_from_hex(pk_string), blob256_from_hex(r_string))); }
+static std::vector<Blob256> parse_cmtarray(const char *cmtarray, int n) { std::vector<Blob256> leaves; std::string s = cmtarray ? cmtarray : ""; if (n > 256) n = 256;   // boost::array<uint256, 256> (depositcgo.cpp:304)
+  for (int i = 0; i < n; i++) leaves.push_back(blob256_from_hex((size_t)i * 66 < s.size() ? s.substr((size_t)i * 66, 66).c_str() : "")); return leaves; }
+char *genRoot(char *cmtarray, int n) { return hash_out(merkle_root(parse_cmtarray(cmtarray, n), 8)); }
+
+char *genMintproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk) {
+  MintInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn), blob256_from_hex(r), blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
+  return generate(CircuitKind::Mint, [&](Circuit &c) { assign_mint(c, in); }); }
+bool verifyMintproof(char *data, char *cmtA_old, char *sn_old, char *cmtA, uint64_t value_s) {   // mint_gadget::witness_map (mint/circuit/gadget.tcc:252-269)
+  std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(cmtA_old).b, 32)); append(bits, blob_bits(blob256_from_hex(sn_old).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtA).b, 32)); append(bits, u64_bits(value_s));
+  return verify(CircuitKind::Mint, data, bits); }
+char *genRedeemproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk) {
+  RedeemInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn), blob256_from_hex(r), blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
+  return generate(CircuitKind::Redeem, [&](Circuit &c) { assign_redeem(c, in); }); }
+bool verifyRedeemproof(char *data, char *cmtA_old, char *sn_old, char *cmtA, uint64_t value_s) {
+  std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(cmtA_old).b, 32)); append(bits, blob_bits(blob256_from_hex(sn_old).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtA).b, 32)); append(bits, u64_bits(value_s));
+  return verify(CircuitKind::Redeem, data, bits); }
+
+static SendInputs send_inputs(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender) {
+  SendInputs in;   // sendcgo.cpp:317-333: note_old = (value_A, sn, r), notes = (value_s, pk_recv, r_s, sn), note_new = (value_A_new, sn_A_new, r_A_new)
+  in.value_old = value_A; in.value_s = value_s; in.value = value_A_new; in.sn_old = blob256_from_hex(sn); in.r_old = blob256_from_hex(r); in.r_s = blob256_from_hex(r_s); in.sn = blob256_from_hex(sn_A_new); in.r = blob256_from_hex(r_A_new);
+  in.cmtA_old = blob256_from_hex(cmtA); in.cmtS = blob256_from_hex(cmt_s); in.cmtA = blob256_from_hex(cmt_A_new); in.sk = blob256_from_hex(sk); in.pk_recv = blob160_from_hex(pk_recv); in.pk_sender = blob160_from_hex(pk_sender); return in; }
+char *genSendproof(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender) {
+  SendInputs in = send_inputs(value_A, r_s, sn, r, cmt_s, cmtA, value_s, pk_recv, value_A_new, sn_A_new, r_A_new, cmt_A_new, sk, pk_sender);
+  return generate(CircuitKind::Send, [&](Circuit &c) { assign_send(c, in); }); }
+bool verifySendproof(char *data, char *cmtA_old, char *sn_old, char *cmtS, char *cmtA_new) {   // send_gadget::witness_map (send/circuit/gadget.tcc:274-291)
+  std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(cmtA_old).b, 32)); append(bits, blob_bits(blob256_from_hex(sn_old).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtS).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtA_new).b, 32));
+  return verify(CircuitKind::Send, data, bits); }
+
+// ---- engine-level entry points for keys, circuits and the resident prover (include/zkgpu.h) ---------------------------
+struct zkgpu_prover { std::shared_ptr<Prover> p; };
+
+static void write_r1cs_file(const char *path, const R1csHost &cs) { FILE *f = fopen(path, "wb"); if (!f) throw std::runtime_error(std::string("cannot write ") + path);
+  uint64_t hdr[3] = {cs.n_inputs, cs.n_vars, cs.n_cons}; fwrite("R1CSBM01", 1, 8, f); fwrite(hdr, 8, 3, f);
+  for (int m = 0; m < 3; m++) { uint64_t nnz = cs.col[m].size(); fwrite(&nnz, 8, 1, f); fwrite(cs.rowptr[m].data(), 4, cs.rowptr[m].size(), f); fwrite(cs.col[m].data(), 4, nnz, f); fwrite(cs.coeff[m].data(), 32, nnz, f); } fclose(f); }
+static R1csHost read_r1cs_file(const char *path) { FILE *f = fopen(path, "rb"); if (!f) throw std::runtime_error(std::string("cannot open ") + path); char mg[8]; uint64_t hdr[3]; R1csHost cs;
+  if (fread(mg, 1, 8, f) != 8 || memcmp(mg, "R1CSBM01", 8) || fread(hdr, 8, 3, f) != 3) { fclose(f); throw std::runtime_error("bad R1CS file"); } cs.n_inputs = hdr[0]; cs.n_vars = hdr[1]; cs.n_cons = hdr[2];
+  for (int m = 0; m < 3; m++) { uint64_t nnz; if (fread(&nnz, 8, 1, f) != 1) { fclose(f); throw std::runtime_error("bad R1CS file"); } cs.rowptr[m].resize(cs.n_cons + 1); cs.col[m].resize(nnz); cs.coeff[m].resize(nnz);
+    if (fread(cs.rowptr[m].data(), 4, cs.n_cons + 1, f) != cs.n_cons + 1 || fread(cs.col[m].data(), 4, nnz, f) != nnz || fread(cs.coeff[m].data(), 32, nnz, f) != nnz) { fclose(f); throw std::runtime_error("truncated R1CS file"); } } fclose(f); return cs; }
+static void write_witness_file(const char *path, const std::vector<Fe32> &z) { FILE *f = fopen(path, "wb"); if (!f) throw std::runtime_error(std::string("cannot write ") + path); uint64_t n = z.size(); fwrite(&n, 8, 1, f); fwrite(z.data(), 32, n, f); fclose(f); }
+
+int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path) { return guarded_host([&] { std::unique_ptr<Circuit> c = kind == 100 ? make_sha256_two_to_one(true) : kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true); write_r1cs_file(r1cs_path, c->r1cs()); return ZKGPU_OK; }); }
+int zkgpu_witness_sha256(const uint8_t left[32], const uint8_t right[32], const char *wit_path) { return guarded_host([&] { auto c = make_sha256_two_to_one(false); assign_sha256_two_to_one(*c, blob_bits(left, 32), blob_bits(right, 32)); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
+int zkgpu_witness_send(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender, const char *wit_path) {
+  return guarded_host([&] { auto c = make_send_circuit(false); assign_send(*c, send_inputs(value_A, r_s, sn, r, cmt_s, cmtA, value_s, pk_recv, value_A_new, sn_A_new, r_A_new, cmt_A_new, sk, pk_sender)); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
+int zkgpu_witness_mint_redeem(int redeem, uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk, const char *wit_path) {
+  return guarded_host([&] { MintInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn), blob256_from_hex(r), blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
+    auto c = redeem ? make_redeem_circuit(false) : make_mint_circuit(false); if (redeem) { RedeemInputs ri{in.value, in.value_old, in.value_s, in.sn_old, in.r_old, in.sn, in.r, in.cmtA_old, in.cmtA, in.sk}; assign_redeem(*c, ri); } else assign_mint(*c, in);
+    std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
+
+int zkgpu_keygen_from_r1cs(const char *r1cs_path, uint64_t seed, const char *pk_path, const char *vk_path) { return guarded([&] { R1csHost cs = read_r1cs_file(r1cs_path); ProvingKeyHost pk; VerifyingKeyHost vk;
+  generate_keys(cs, seed ? ToxicWaste::from_seed(seed) : ToxicWaste::random(), pk, vk); save_proving_key(pk_path, pk); save_verifying_key(vk_path, vk); return ZKGPU_OK; }); }
+int zkgpu_keygen(int kind, int tree_depth, uint64_t seed, const char *pk_path, const char *vk_path) { return guarded([&] { std::unique_ptr<Circuit> c = kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true);
+  ProvingKeyHost pk; VerifyingKeyHost vk; generate_keys(c->r1cs(), seed ? ToxicWaste::from_seed(seed) : ToxicWaste::random(), pk, vk); save_proving_key(pk_path, pk); save_verifying_key(vk_path, vk); return ZKGPU_OK; }); }
+
+zkgpu_prover *zkgpu_prover_load(const char *pk_path) { zkgpu_prover *h = nullptr; guarded([&] { ProvingKeyHost pk = load_proving_key(pk_path); std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(pk)); h = p.release(); return ZKGPU_OK; }); return h; }
+void zkgpu_prover_destroy(zkgpu_prover *h) { guarded([&] { delete h; return ZKGPU_OK; }); }
+int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]) { if (!h) return ZKGPU_ERR_ARG; out[0] = h->p->num_variables(); out[1] = h->p->num_inputs(); out[2] = h->p->domain_size(); return ZKGPU_OK; }
+int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded([&] { if (!h) return ZKGPU_ERR_ARG; Proof p;
+  if (!h->p->prove((const Fe32 *)z, (const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
+int zkgpu_prover_timings(zkgpu_prover *h, double out[5]) { if (!h) return ZKGPU_ERR_ARG; out[0] = h->p->last.upload_ms; out[1] = h->p->last.qap_ms; out[2] = h->p->last.msm_ms; out[3] = h->p->last.finish_ms; out[4] = h->p->last.total_ms; return ZKGPU_OK; }
+int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs) { int res = 0; int rc = guarded_host([&] { VerifyingKeyHost vk = load_verifying_key(vk_path); Proof p;
+  if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK; } res = verify_proof(vk, (const Fe32 *)inputs, n_inputs, p) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
+}  // extern "C"

@@ -1,0 +1,147 @@
+// gadgetlib1 subset restated on circuit::Board — see circuit.hpp for the source map.
+#include <algorithm>
+#include <cstring>
+#include "circuit.hpp"
+
+namespace zk { namespace circuit {
+
+// ---- Board -------------------------------------------------------------------------------------------------------------
+void Board::push(int m, const LC &lc) {
+  // canonical row: sorted by variable, duplicates merged, zero coefficients dropped
+  std::vector<Term> t = lc.t; std::stable_sort(t.begin(), t.end(), [](const Term &a, const Term &b) { return a.v < b.v; });
+  for (size_t i = 0; i < t.size();) { HFr c = t[i].c; size_t j = i + 1; while (j < t.size() && t[j].v == t[i].v) { c = c + t[j].c; j++; }
+    if (!c.is_zero()) { cs.col[m].push_back(t[i].v); HFr cc = c.from_mont(); Fe32 f; memcpy(&f, cc.l, 32); cs.coeff[m].push_back(f); } i = j; }
+  cs.rowptr[m].push_back((uint32_t)cs.col[m].size());
+}
+void Board::constraint(const LC &a, const LC &b, const LC &c) { if (!emit) return; push(0, a); push(1, b); push(2, c); }
+
+HFr pack_bits_value(const Board &b, const LCArray &bits) { HFr r = HFr::zero(); for (size_t i = bits.size(); i-- > 0;) { r = r.dbl(); r = r + b.eval(bits[i]); } return r; }
+LC packing_sum(const LCArray &bits) { LC r; HFr two_i = HFr::one(); for (const LC &x : bits) { r.add(x.scaled(two_i)); two_i = two_i.dbl(); } return r; }
+void fill_bits_of_value(Board &b, const VarArray &bits, const HFr &value) { HFr c = value.from_mont(); for (size_t i = 0; i < bits.size(); i++) b.set_bit(bits[i], i < 256 && ((c.l[i / 64] >> (i % 64)) & 1)); }
+void boolean_constraint(Board &b, const LC &x) { b.constraint(x, LC::constant(HFr::one()) - x, LC()); }
+void Packing::constraints(bool enforce_bitness) { b.constraint(LC::constant(HFr::one()), packing_sum(bits), packed); if (enforce_bitness) for (const LC &x : bits) boolean_constraint(b, x); }
+
+static const uint32_t SHA256_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+    0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+    0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static const uint32_t SHA256_H[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+
+LCArray sha256_default_iv() { LCArray r; r.reserve(256);
+  for (int i = 0; i < 256; i++) { int bit = (SHA256_H[i / 32] >> (31 - (i % 32))) & 1; r.push_back(bit ? LC::constant(HFr::one()) : LC()); } return r; }
+
+// ---- sha256_aux.tcc ------------------------------------------------------------------------------------------------------
+namespace {
+const LC ONE_LC = LC::constant(HFr::one());
+const HFr TWO = HFr::from_u64(2);
+
+struct LastBits {     // X has X_bits bits; result = the low |result_bits| of them
+  Board &b; Var X; size_t X_bits; Var result; VarArray result_bits, full_bits;
+  LastBits(Board &b, Var X, size_t X_bits, Var result, const VarArray &result_bits) : b(b), X(X), X_bits(X_bits), result(result), result_bits(result_bits), full_bits(result_bits) {
+    for (size_t i = result_bits.size(); i < X_bits; i++) full_bits.push_back(b.alloc()); }
+  void constraints() { Packing(b, to_lcs(full_bits), X).constraints(true); Packing(b, to_lcs(result_bits), result).constraints(false); }
+  void witness() { fill_bits_of_value(b, full_bits, b.val[X]); b.val[result] = pack_bits_value(b, to_lcs(result_bits)); }
+};
+struct Xor3 {
+  Board &b; LC A, B, C; bool c_zero; Var out, tmp = 0;
+  Xor3(Board &b, const LC &A, const LC &B, const LC &C, bool c_zero, Var out) : b(b), A(A), B(B), C(C), c_zero(c_zero), out(out) { if (!c_zero) tmp = b.alloc(); }
+  void constraints() {
+    if (c_zero) b.constraint(A.scaled(TWO), B, A + B - LC(out));
+    else { b.constraint(A.scaled(TWO), B, A + B - LC(tmp)); b.constraint(LC(tmp).scaled(TWO), C, LC(tmp) + C - LC(out)); } }
+  void witness() { bool a = !b.eval(A).is_zero(), bb = !b.eval(B).is_zero();
+    if (c_zero) b.set_bit(out, a ^ bb); else { bool t = a ^ bb, c = !b.eval(C).is_zero(); b.set_bit(tmp, t); b.set_bit(out, t ^ c); } }
+};
+inline const LC &rotr(const LCArray &A, size_t i, size_t k) { return A[(i + k) % 32]; }
+struct SmallSigma {
+  Board &b; Var result; VarArray result_bits; std::vector<Xor3> x;
+  SmallSigma(Board &b, const LCArray &W, Var result, size_t rot1, size_t rot2, size_t shift) : b(b), result(result), result_bits(b.alloc_array(32)) {
+    for (size_t i = 0; i < 32; i++) x.emplace_back(b, rotr(W, i, rot1), rotr(W, i, rot2), (i + shift < 32 ? W[i + shift] : ONE_LC), i + shift >= 32, result_bits[i]); }
+  void constraints() { for (auto &g : x) g.constraints(); Packing(b, to_lcs(result_bits), result).constraints(false); }
+  void witness() { for (auto &g : x) g.witness(); b.val[result] = pack_bits_value(b, to_lcs(result_bits)); }
+};
+struct BigSigma {
+  Board &b; Var result; VarArray result_bits; std::vector<Xor3> x;
+  BigSigma(Board &b, const LCArray &W, Var result, size_t r1, size_t r2, size_t r3) : b(b), result(result), result_bits(b.alloc_array(32)) {
+    for (size_t i = 0; i < 32; i++) x.emplace_back(b, rotr(W, i, r1), rotr(W, i, r2), rotr(W, i, r3), false, result_bits[i]); }
+  void constraints() { for (auto &g : x) g.constraints(); Packing(b, to_lcs(result_bits), result).constraints(false); }
+  void witness() { for (auto &g : x) g.witness(); b.val[result] = pack_bits_value(b, to_lcs(result_bits)); }
+};
+struct Choice {
+  Board &b; LCArray X, Y, Z; Var result; VarArray result_bits;
+  Choice(Board &b, const LCArray &X, const LCArray &Y, const LCArray &Z, Var result) : b(b), X(X), Y(Y), Z(Z), result(result), result_bits(b.alloc_array(32)) {}
+  void constraints() { for (size_t i = 0; i < 32; i++) b.constraint(X[i], Y[i] - Z[i], LC(result_bits[i]) - Z[i]); Packing(b, to_lcs(result_bits), result).constraints(false); }
+  void witness() { for (size_t i = 0; i < 32; i++) { bool x = !b.eval(X[i]).is_zero(); b.set_bit(result_bits[i], x ? !b.eval(Y[i]).is_zero() : !b.eval(Z[i]).is_zero()); } b.val[result] = pack_bits_value(b, to_lcs(result_bits)); }
+};
+struct Majority {
+  Board &b; LCArray X, Y, Z; Var result; VarArray result_bits;
+  Majority(Board &b, const LCArray &X, const LCArray &Y, const LCArray &Z, Var result) : b(b), X(X), Y(Y), Z(Z), result(result), result_bits(b.alloc_array(32)) {}
+  void constraints() { for (size_t i = 0; i < 32; i++) { boolean_constraint(b, LC(result_bits[i])); LC s = X[i] + Y[i] + Z[i] - LC(result_bits[i]).scaled(TWO); b.constraint(s, ONE_LC - s, LC()); }
+    Packing(b, to_lcs(result_bits), result).constraints(false); }
+  void witness() { for (size_t i = 0; i < 32; i++) { int v = (int)!b.eval(X[i]).is_zero() + (int)!b.eval(Y[i]).is_zero() + (int)!b.eval(Z[i]).is_zero(); b.set_bit(result_bits[i], v >= 2); } b.val[result] = pack_bits_value(b, to_lcs(result_bits)); }
+};
+
+// ---- sha256_components.tcc ---------------------------------------------------------------------------------------------
+struct MessageSchedule {
+  Board &b; VarArray packed_W; std::vector<VarArray> W_bits; VarArray sigma0, sigma1, unreduced_W; std::vector<SmallSigma> cs0, cs1; std::vector<LastBits> red;
+  MessageSchedule(Board &b, const VarArray &M, const VarArray &packed_W) : b(b), packed_W(packed_W), W_bits(64), sigma0(64), sigma1(64), unreduced_W(64) {
+    for (size_t i = 0; i < 16; i++) { W_bits[i].resize(32); for (size_t k = 0; k < 32; k++) W_bits[i][k] = M[32 * i + 31 - k]; }
+    cs0.reserve(48); cs1.reserve(48); red.reserve(48);
+    for (size_t i = 16; i < 64; i++) { sigma0[i] = b.alloc(); sigma1[i] = b.alloc();
+      cs0.emplace_back(b, to_lcs(W_bits[i - 15]), sigma0[i], 7, 18, 3); cs1.emplace_back(b, to_lcs(W_bits[i - 2]), sigma1[i], 17, 19, 10);
+      unreduced_W[i] = b.alloc(); W_bits[i] = b.alloc_array(32); red.emplace_back(b, unreduced_W[i], 32 + 2, packed_W[i], W_bits[i]); } }
+  void constraints() { for (size_t i = 0; i < 16; i++) Packing(b, to_lcs(W_bits[i]), packed_W[i]).constraints(false);
+    for (size_t i = 16; i < 64; i++) { cs0[i - 16].constraints(); cs1[i - 16].constraints();
+      b.constraint(ONE_LC, LC(sigma0[i]) + LC(sigma1[i]) + LC(packed_W[i - 16]) + LC(packed_W[i - 7]), LC(unreduced_W[i])); red[i - 16].constraints(); } }
+  void witness() { for (size_t i = 0; i < 16; i++) b.val[packed_W[i]] = pack_bits_value(b, to_lcs(W_bits[i]));
+    for (size_t i = 16; i < 64; i++) { cs0[i - 16].witness(); cs1[i - 16].witness(); b.val[unreduced_W[i]] = b.val[sigma0[i]] + b.val[sigma1[i]] + b.val[packed_W[i - 16]] + b.val[packed_W[i - 7]]; red[i - 16].witness(); } }
+};
+struct RoundFunction {
+  Board &b; LCArray a, bb, c, d, e, f, g, h; Var W; uint32_t K; VarArray new_a, new_e;
+  Var sigma0, sigma1, choice, majority, packed_d, packed_h, unreduced_new_a, unreduced_new_e, packed_new_a, packed_new_e;
+  std::unique_ptr<BigSigma> s0, s1; std::unique_ptr<Choice> ch; std::unique_ptr<Majority> mj; std::unique_ptr<LastBits> ra, re;
+  RoundFunction(Board &b, const LCArray &a, const LCArray &bb, const LCArray &c, const LCArray &d, const LCArray &e, const LCArray &f, const LCArray &g, const LCArray &h,
+                Var W, uint32_t K, const VarArray &new_a, const VarArray &new_e) : b(b), a(a), bb(bb), c(c), d(d), e(e), f(f), g(g), h(h), W(W), K(K), new_a(new_a), new_e(new_e) {
+    sigma0 = b.alloc(); sigma1 = b.alloc(); s0.reset(new BigSigma(b, a, sigma0, 2, 13, 22)); s1.reset(new BigSigma(b, e, sigma1, 6, 11, 25));
+    choice = b.alloc(); ch.reset(new Choice(b, e, f, g, choice)); majority = b.alloc(); mj.reset(new Majority(b, a, bb, c, majority));
+    packed_d = b.alloc(); packed_h = b.alloc(); unreduced_new_a = b.alloc(); unreduced_new_e = b.alloc(); packed_new_a = b.alloc(); packed_new_e = b.alloc();
+    ra.reset(new LastBits(b, unreduced_new_a, 32 + 3, packed_new_a, new_a)); re.reset(new LastBits(b, unreduced_new_e, 32 + 3, packed_new_e, new_e)); }
+  void constraints() { s0->constraints(); s1->constraints(); ch->constraints(); mj->constraints();
+    b.constraint(ONE_LC, packing_sum(d), LC(packed_d)); b.constraint(ONE_LC, packing_sum(h), LC(packed_h));
+    LC k = LC::constant_u64(K);
+    b.constraint(ONE_LC, LC(packed_h) + LC(sigma1) + LC(choice) + k + LC(W) + LC(sigma0) + LC(majority), LC(unreduced_new_a));
+    b.constraint(ONE_LC, LC(packed_d) + LC(packed_h) + LC(sigma1) + LC(choice) + k + LC(W), LC(unreduced_new_e));
+    ra->constraints(); re->constraints(); }
+  void witness() { s0->witness(); s1->witness(); ch->witness(); mj->witness(); b.val[packed_d] = pack_bits_value(b, d); b.val[packed_h] = pack_bits_value(b, h); HFr k = HFr::from_u64(K);
+    b.val[unreduced_new_a] = b.val[packed_h] + b.val[sigma1] + b.val[choice] + k + b.val[W] + b.val[sigma0] + b.val[majority];
+    b.val[unreduced_new_e] = b.val[packed_d] + b.val[packed_h] + b.val[sigma1] + b.val[choice] + k + b.val[W]; ra->witness(); re->witness(); }
+};
+}  // namespace
+
+// ---- sha256_gadget.tcc:20-140 -----------------------------------------------------------------------------------------
+struct Sha256Compression::Impl {
+  Board &b; VarArray packed_W; std::unique_ptr<MessageSchedule> ms; std::vector<std::unique_ptr<RoundFunction>> rounds; VarArray unreduced_output, reduced_output; std::vector<LastBits> reduce;
+  Impl(Board &b, const LCArray &prev, const VarArray &block, const VarArray &output) : b(b) {
+    packed_W = b.alloc_array(64); ms.reset(new MessageSchedule(b, block, packed_W));
+    auto word = [&](int w) { LCArray r(32); for (int k = 0; k < 32; k++) r[k] = prev[32 * w + 31 - k]; return r; };   // word w, little-endian bits
+    std::vector<LCArray> ra{word(0)}, rb{word(1)}, rc{word(2)}, rd{word(3)}, re{word(4)}, rf{word(5)}, rg{word(6)}, rh{word(7)};
+    for (size_t i = 0; i < 64; i++) {
+      rh.push_back(rg[i]); rg.push_back(rf[i]); rf.push_back(re[i]); rd.push_back(rc[i]); rc.push_back(rb[i]); rb.push_back(ra[i]);
+      VarArray na = b.alloc_array(32); ra.push_back(to_lcs(na)); VarArray ne = b.alloc_array(32); re.push_back(to_lcs(ne));
+      rounds.emplace_back(new RoundFunction(b, ra[i], rb[i], rc[i], rd[i], re[i], rf[i], rg[i], rh[i], packed_W[i], SHA256_K[i], na, ne));
+    }
+    unreduced_output = b.alloc_array(8); reduced_output = b.alloc_array(8); reduce.reserve(8);
+    for (size_t i = 0; i < 8; i++) { VarArray ob(32); for (size_t k = 0; k < 32; k++) ob[k] = output[32 * i + 31 - k]; reduce.emplace_back(b, unreduced_output[i], 32 + 1, reduced_output[i], ob); }
+  }
+};
+Sha256Compression::Sha256Compression(Board &b, const LCArray &prev, const VarArray &block, const VarArray &output) : impl(new Impl(b, prev, block, output)) {}
+void Sha256Compression::constraints() { Impl &s = *impl; s.ms->constraints(); for (auto &r : s.rounds) r->constraints();
+  for (size_t i = 0; i < 4; i++) { s.b.constraint(ONE_LC, LC(s.rounds[3 - i]->packed_d) + LC(s.rounds[63 - i]->packed_new_a), LC(s.unreduced_output[i]));
+                                   s.b.constraint(ONE_LC, LC(s.rounds[3 - i]->packed_h) + LC(s.rounds[63 - i]->packed_new_e), LC(s.unreduced_output[4 + i])); }
+  for (auto &r : s.reduce) r.constraints(); }
+void Sha256Compression::witness() { Impl &s = *impl; s.ms->witness(); for (auto &r : s.rounds) r->witness();
+  for (size_t i = 0; i < 4; i++) { s.b.val[s.unreduced_output[i]] = s.b.val[s.rounds[3 - i]->packed_d] + s.b.val[s.rounds[63 - i]->packed_new_a];
+                                   s.b.val[s.unreduced_output[4 + i]] = s.b.val[s.rounds[3 - i]->packed_h] + s.b.val[s.rounds[63 - i]->packed_new_e]; }
+  for (auto &r : s.reduce) r.witness(); }
+
+}  }  // namespace zk::circuit

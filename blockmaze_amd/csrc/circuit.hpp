@@ -1,0 +1,95 @@
+// R1CS circuit construction and witness generation for BlockMaze's four circuits (host side, row W1 of SURVEY.md §8a).
+//
+// The reference builds its circuits with libsnark's gadgetlib1 (protoboard + gadget objects) every time a proof is
+// made (libsnark-vnt/src/send/sendcgo.cpp:203-207).  Variable numbering is fixed by the order in which gadget
+// constructors allocate, constraint numbering by the order of the generate_r1cs_constraints() calls; both are part of
+// the proving key (the key stores the constraint system and one group element per variable), so a drop-in prover has
+// to reproduce them exactly.  This file restates the needed subset of gadgetlib1 with the same three phases
+// (construct = allocate, constraints(), witness()) on a much lighter board: variables are plain indices, linear
+// combinations are short term lists, constraints go straight into CSR arrays, values are host field elements.
+//
+// Restated gadgets and their sources (all under libsnark-vnt/depends/libsnark/libsnark/gadgetlib1/):
+//   Board                      protoboard.tcc:19-130, pb_variable.tcc:27-133
+//   Packing / MultiPacking     gadgets/basic_gadgets.tcc:31-108
+//   Disjunction                gadgets/basic_gadgets.tcc:197-261
+//   Digest (bit array)         gadgets/hashes/hash_io.tcc:17-60
+//   LastBits, Xor3, SmallSigma, BigSigma, Choice, Majority      gadgets/hashes/sha256/sha256_aux.tcc:20-291
+//   MessageSchedule, RoundFunction                              gadgets/hashes/sha256/sha256_components.tcc:52-243
+//   Sha256Compression                                           gadgets/hashes/sha256/sha256_gadget.tcc:20-140
+//   MerkleRead                 gadgets/merkle_tree/merkle_tree_check_read_gadget.tcc, merkle_authentication_path_variable.tcc,
+//                              gadgets/hashes/digest_selector_gadget.tcc
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <vector>
+#include "gpu.hpp"
+#include "hostmath.hpp"
+
+namespace zk { namespace circuit {
+
+using host::HFr;
+typedef uint32_t Var;                 // 0 is the constant ONE
+typedef std::vector<Var> VarArray;
+
+struct Term { Var v; HFr c; };
+struct LC {
+  std::vector<Term> t;
+  LC() {}
+  LC(Var v) { t.push_back({v, HFr::one()}); }
+  static LC constant(const HFr &c) { LC r; r.t.push_back({0, c}); return r; }
+  static LC constant_u64(uint64_t c) { return constant(HFr::from_u64(c)); }
+  LC &add(const LC &o) { t.insert(t.end(), o.t.begin(), o.t.end()); return *this; }
+  LC &sub(const LC &o) { for (const Term &x : o.t) t.push_back({x.v, x.c.neg()}); return *this; }
+  LC &add_term(Var v, const HFr &c) { t.push_back({v, c}); return *this; }
+  LC scaled(const HFr &k) const { LC r; for (const Term &x : t) r.t.push_back({x.v, x.c * k}); return r; }
+  friend LC operator+(LC a, const LC &b) { a.add(b); return a; }
+  friend LC operator-(LC a, const LC &b) { a.sub(b); return a; }
+};
+typedef std::vector<LC> LCArray;
+inline LCArray to_lcs(const VarArray &v) { LCArray r; r.reserve(v.size()); for (Var x : v) r.emplace_back(x); return r; }
+
+class Board {
+ public:
+  explicit Board(bool emit_constraints) : emit(emit_constraints) { val.push_back(HFr::one()); for (int m = 0; m < 3; m++) cs.rowptr[m].push_back(0); }
+  bool emit;                                   // false: witness-only pass (allocation still happens, constraints are skipped)
+  std::vector<HFr> val;                        // val[0] = 1
+  R1csHost cs;
+  Var alloc() { val.push_back(HFr::zero()); return (Var)(val.size() - 1); }
+  VarArray alloc_array(size_t n) { VarArray a(n); for (size_t i = 0; i < n; i++) a[i] = alloc(); return a; }
+  void set_input_sizes(size_t n) { cs.n_inputs = n; }
+  size_t num_variables() const { return val.size() - 1; }
+  void constraint(const LC &a, const LC &b, const LC &c);
+  HFr eval(const LC &lc) const { HFr s = HFr::zero(); for (const Term &x : lc.t) s = s + x.c * val[x.v]; return s; }
+  void set_bit(Var v, bool b) { if (v) val[v] = b ? HFr::one() : HFr::zero(); }   // writes to ONE are dropped (see LessCmp)
+  bool bit(Var v) const { return !val[v].is_zero(); }
+  void finish() { cs.n_vars = num_variables(); cs.n_cons = cs.rowptr[0].size() - 1; }
+ private:
+  void push(int m, const LC &lc);
+};
+
+// value of bits[i] * 2^i, bits little-endian
+HFr pack_bits_value(const Board &b, const LCArray &bits);
+LC packing_sum(const LCArray &bits);
+void fill_bits_of_value(Board &b, const VarArray &bits, const HFr &value);     // fill_with_bits_of_field_element
+void boolean_constraint(Board &b, const LC &x);                                 // basic_gadgets.tcc:17-22
+
+struct Packing {      // packed = sum bits[i] 2^i
+  Board &b; LCArray bits; LC packed; bool packed_is_var; Var packed_var;
+  Packing(Board &b, const LCArray &bits, Var packed) : b(b), bits(bits), packed(packed), packed_is_var(true), packed_var(packed) {}
+  void constraints(bool enforce_bitness);
+  void witness_from_bits() { b.val[packed_var] = pack_bits_value(b, bits); }
+};
+
+struct Digest { Board &b; VarArray bits; Digest(Board &b, size_t n) : b(b), bits(b.alloc_array(n)) {} void constraints() { for (Var v : bits) boolean_constraint(b, LC(v)); }
+  void fill(const std::vector<bool> &v) { for (size_t i = 0; i < bits.size(); i++) b.set_bit(bits[i], v[i]); }
+  std::vector<bool> get() const { std::vector<bool> r(bits.size()); for (size_t i = 0; i < bits.size(); i++) r[i] = b.bit(bits[i]); return r; } };
+
+struct Sha256Compression {
+  struct Impl; std::shared_ptr<Impl> impl;
+  // prev_output: 256 LCs (MSB-first words), block: 512 variables, output: 256 variables
+  Sha256Compression(Board &b, const LCArray &prev_output, const VarArray &block, const VarArray &output);
+  void constraints(); void witness();
+};
+LCArray sha256_default_iv();          // sha256_components.tcc:38-56
+
+}  }  // namespace zk::circuit

@@ -83,6 +83,13 @@ class R1csDev {
 };
 
 void fr_to_mont_dev(Fe32 *a, size_t n); void fr_from_mont_dev(Fe32 *a, size_t n);
+
+// Key loading: y-coordinates of compressed points (x Montgomery; flags bit0 = parity of canonical y, bit1 = point at infinity).  Throws if an x is not on the curve.
+void decompress_g1(const Fe32 *xs, const uint8_t *flags, size_t n, G1AffineRaw *out);
+void decompress_g2(const Fe32 *xs /* 2 per point */, const uint8_t *flags, size_t n, G2AffineRaw *out);
+// Key generation: out[i] = scalars[i] * base (scalars canonical), results affine Montgomery
+void fixed_base_mul_g1(const host::HG1 &base, const Fe32 *scalars, size_t n, G1AffineRaw *out);
+void fixed_base_mul_g2(const host::HG2 &base, const Fe32 *scalars, size_t n, G2AffineRaw *out);
 void gpu_sync();
 
 }  // namespace zk

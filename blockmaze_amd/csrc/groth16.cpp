@@ -1,0 +1,253 @@
+// see groth16.hpp
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include "groth16.hpp"
+
+namespace zk {
+using namespace host;
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static HFq fq_of(const Fe32 &f) { HFq r; memcpy(r.l, &f, 32); return r; }
+static HFr fr_of(const Fe32 &f) { HFr r; memcpy(r.l, &f, 32); return r; }
+static Fe32 fe_of(const HFq &f) { Fe32 r; memcpy(&r, f.l, 32); return r; }
+static Fe32 fe_of_r(const HFr &f) { Fe32 r; memcpy(&r, f.l, 32); return r; }
+static HG1 g1_of(const G1AffineRaw &p) { return HG1::from_affine(fq_of(p.x), fq_of(p.y)); }
+static HFq2 fq2_of(const Fe32 &a, const Fe32 &b) { return {fq_of(a), fq_of(b)}; }
+static HG2 g2_of(const G2AffineRaw &p) { return HG2::from_affine(fq2_of(p.x0, p.x1), fq2_of(p.y0, p.y1)); }
+static G1AffineRaw raw_of(const HG1 &p) { HFq x, y; p.to_affine(x, y); return {fe_of(x), fe_of(y)}; }
+static G2AffineRaw raw_of(const HG2 &p) { HFq2 x, y; p.to_affine(x, y); return {fe_of(x.c0), fe_of(x.c1), fe_of(y.c0), fe_of(y.c1)}; }
+static bool is_zero_raw(const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; i++) if (b[i]) return false; return true; }
+
+// ======================================================================================================================
+// key files
+// ======================================================================================================================
+namespace {
+struct Cursor {
+  const uint8_t *p, *end; const char *what;
+  void fail(const char *msg) const { throw std::runtime_error(std::string(what) + ": " + msg); }
+  void skip_ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++; }
+  void dec(uint32_t out[8]) { skip_ws(); memset(out, 0, 32); int nd = 0;
+    while (p < end && *p >= '0' && *p <= '9') { uint64_t carry = *p - '0'; for (int i = 0; i < 8; i++) { uint64_t v = (uint64_t)out[i] * 10 + carry; out[i] = (uint32_t)v; carry = v >> 32; } p++; nd++; }
+    if (!nd) fail("expected a decimal number"); }
+  size_t size() { uint32_t v[8]; dec(v); return (size_t)v[0] | ((size_t)v[1] << 32); }
+  void eat(char c) { if (p < end && *p == (uint8_t)c) p++; else fail("unexpected byte"); }
+  // compressed points: ASCII is_zero, raw Montgomery X, ASCII lsb(Y)   (alt_bn128_g1.cpp:404-418, alt_bn128_g2.cpp:418-431)
+  void g1(std::vector<Fe32> &xs, std::vector<uint8_t> &flags) { if (end - p < 34) fail("truncated G1"); uint8_t z = *p++ - '0'; Fe32 x; memcpy(&x, p, 32); p += 32; uint8_t lsb = *p++ - '0'; if (z > 1 || lsb > 1) fail("bad G1 flag"); xs.push_back(x); flags.push_back((uint8_t)(lsb | (z << 1))); }
+  void g2(std::vector<Fe32> &xs, std::vector<uint8_t> &flags) { if (end - p < 66) fail("truncated G2"); uint8_t z = *p++ - '0'; Fe32 x[2]; memcpy(x, p, 64); p += 64; uint8_t lsb = *p++ - '0'; if (z > 1 || lsb > 1) fail("bad G2 flag"); xs.push_back(x[0]); xs.push_back(x[1]); flags.push_back((uint8_t)(lsb | (z << 1))); }
+};
+std::vector<uint8_t> slurp(const std::string &path) { std::ifstream f(path, std::ios::binary); if (!f) throw std::runtime_error("cannot open " + path); f.seekg(0, std::ios::end); size_t n = (size_t)f.tellg(); f.seekg(0); std::vector<uint8_t> b(n); f.read((char *)b.data(), n); return b; }
+
+void put_dec(std::string &o, const uint32_t v[8]) { uint32_t t[8]; memcpy(t, v, 32); char buf[80]; int n = 0; bool zero = true; for (int i = 0; i < 8; i++) if (t[i]) zero = false;
+  if (zero) { o.push_back('0'); return; }
+  while (true) { uint64_t rem = 0; bool nz = false; for (int i = 7; i >= 0; i--) { uint64_t cur = (rem << 32) | t[i]; t[i] = (uint32_t)(cur / 1000000000u); rem = cur % 1000000000u; if (t[i]) nz = true; }
+    for (int k = 0; k < 9; k++) { buf[n++] = (char)('0' + rem % 10); rem /= 10; } if (!nz) break; }
+  while (n > 1 && buf[n - 1] == '0') n--; while (n) o.push_back(buf[--n]); }
+void put_size(std::string &o, size_t v) { o += std::to_string(v); }
+void put_fq_mont(std::string &o, const Fe32 &x) { o.append((const char *)&x, 32); }
+void put_g1(std::string &o, const G1AffineRaw &p) { bool z = is_zero_raw(&p, sizeof p); o.push_back(z ? '1' : '0'); put_fq_mont(o, p.x); o.push_back(z ? '1' : (char)('0' + (fq_of(p.y).from_mont().l[0] & 1))); }   // zero = (0, 1, 0): lsb(Y) = 1
+void put_g2(std::string &o, const G2AffineRaw &p) { bool z = is_zero_raw(&p, sizeof p); o.push_back(z ? '1' : '0'); put_fq_mont(o, p.x0); put_fq_mont(o, p.x1); o.push_back(z ? '1' : (char)('0' + (fq_of(p.y0).from_mont().l[0] & 1))); }
+void put_g1_vec(std::string &o, const std::vector<G1AffineRaw> &v) { put_size(o, v.size()); o.push_back('\n'); for (auto &p : v) put_g1(o, p); }   // vector<G1> operator of libff.so: no per-element newline
+}  // namespace
+
+ProvingKeyHost load_proving_key(const std::string &path) {
+  std::vector<uint8_t> buf = slurp(path); Cursor c{buf.data(), buf.data() + buf.size(), "proving key"}; ProvingKeyHost pk;
+  std::vector<Fe32> x1, x2; std::vector<uint8_t> f1, f2;     // every G1 / G2 of the file, decompressed in one batch each
+  c.g1(x1, f1); c.eat('\n'); c.g1(x1, f1); c.eat('\n'); c.g2(x2, f2); c.eat('\n'); c.g1(x1, f1); c.eat('\n'); c.g2(x2, f2); c.eat('\n');   // alpha_g1 beta_g1 beta_g2 delta_g1 delta_g2 (r1cs_gg_ppzksnark.tcc:52-66)
+  size_t nA = c.size(); c.eat('\n'); for (size_t i = 0; i < nA; i++) c.g1(x1, f1);
+  size_t dom = c.size(); size_t ni = c.size(); pk.B_idx.resize(ni); for (size_t i = 0; i < ni; i++) pk.B_idx[i] = (uint32_t)c.size();             // sparse_vector.tcc:272-288
+  size_t nB = c.size(); c.eat('\n'); if (nB != ni || dom != nA) c.fail("inconsistent B query");
+  for (size_t i = 0; i < nB; i++) { c.g2(x2, f2); c.eat(' '); c.g1(x1, f1); c.eat('\n'); }                                                          // knowledge_commitment.tcc:121-125
+  size_t nH = c.size(); c.eat('\n'); for (size_t i = 0; i < nH; i++) c.g1(x1, f1);
+  size_t nL = c.size(); c.eat('\n'); for (size_t i = 0; i < nL; i++) c.g1(x1, f1);
+  R1csHost &cs = pk.cs; cs.n_inputs = c.size(); cs.n_vars = cs.n_inputs + c.size(); cs.n_cons = c.size();                                          // r1cs.tcc:242-254
+  for (int m = 0; m < 3; m++) { cs.rowptr[m].reserve(cs.n_cons + 1); cs.rowptr[m].push_back(0); }
+  for (size_t i = 0; i < cs.n_cons; i++) for (int m = 0; m < 3; m++) { size_t nt = c.size();
+    for (size_t k = 0; k < nt; k++) { size_t idx = c.size(); if (idx > cs.n_vars) c.fail("variable index out of range"); Fe32 co; c.dec(co.l); cs.col[m].push_back((uint32_t)idx); cs.coeff[m].push_back(co); }
+    cs.rowptr[m].push_back((uint32_t)cs.col[m].size()); }
+  if (nA != cs.n_vars + 1 || nL != cs.n_vars - cs.n_inputs) c.fail("query sizes do not match the constraint system");
+  std::vector<G1AffineRaw> p1(x1.size()); std::vector<G2AffineRaw> p2(f2.size());
+  decompress_g1(x1.data(), f1.data(), x1.size(), p1.data()); decompress_g2(x2.data(), f2.data(), f2.size(), p2.data());
+  size_t i1 = 0, i2 = 0; pk.alpha_g1 = p1[i1++]; pk.beta_g1 = p1[i1++]; pk.beta_g2 = p2[i2++]; pk.delta_g1 = p1[i1++]; pk.delta_g2 = p2[i2++];
+  pk.A.assign(p1.begin() + i1, p1.begin() + i1 + nA); i1 += nA; pk.B_g1.assign(p1.begin() + i1, p1.begin() + i1 + nB); i1 += nB; pk.B_g2.assign(p2.begin() + i2, p2.begin() + i2 + nB);
+  pk.H.assign(p1.begin() + i1, p1.begin() + i1 + nH); i1 += nH; pk.L.assign(p1.begin() + i1, p1.begin() + i1 + nL); return pk;
+}
+
+// host-only square roots for the handful of points in a verification key
+static G1AffineRaw decompress_host_g1(const Fe32 &xm, uint8_t flags) { if (flags & 2) { G1AffineRaw z; memset(&z, 0, sizeof z); return z; } HFq x = fq_of(xm), y2 = x.sqr() * x + HFq::from_u64(3), y; if (!fq_sqrt(y2, y)) throw std::runtime_error("verification key: G1 point not on the curve");
+  if ((y.from_mont().l[0] & 1) != (uint64_t)(flags & 1)) y = y.neg(); return {fe_of(x), fe_of(y)}; }
+static bool fq2_sqrt_host(const HFq2 &a, HFq2 &out) {   // Adj & Rodriguez-Henriquez Alg. 9, q = 3 mod 4
+  if (a.is_zero()) { out = a; return true; }
+  uint64_t e34[4], e12[4]; { uint64_t t[4]; uint64_t br = 3; for (int i = 0; i < 4; i++) { u128 d = (u128)HFq::mod(i) - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } for (int i = 0; i < 4; i++) e34[i] = (t[i] >> 2) | (i < 3 ? t[i + 1] << 62 : 0);
+    br = 1; for (int i = 0; i < 4; i++) { u128 d = (u128)HFq::mod(i) - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } for (int i = 0; i < 4; i++) e12[i] = (t[i] >> 1) | (i < 3 ? t[i + 1] << 63 : 0); }
+  HFq2 a1 = a.pow(e34, 4), x0 = a1 * a, alpha = a1 * x0, a0 = alpha.frob(1) * alpha, m1 = HFq2::one().neg();
+  if (a0 == m1) return false; if (alpha == m1) out = HFq2{x0.c1.neg(), x0.c0}; else out = (HFq2::one() + alpha).pow(e12, 4) * x0; return out.sqr() == a; }
+static G2AffineRaw decompress_host_g2(const Fe32 &x0, const Fe32 &x1, uint8_t flags) { if (flags & 2) { G2AffineRaw z; memset(&z, 0, sizeof z); return z; }
+  HFq2 x = fq2_of(x0, x1), tb = HFq2{HFq::from_u64(3), HFq::zero()} * HFq2{HFq::from_u64(9), HFq::one()}.inv(), y2 = x.sqr() * x + tb, y; if (!fq2_sqrt_host(y2, y)) throw std::runtime_error("verification key: G2 point not on the twist");
+  if ((y.c0.from_mont().l[0] & 1) != (uint64_t)(flags & 1)) y = y.neg(); return {fe_of(x.c0), fe_of(x.c1), fe_of(y.c0), fe_of(y.c1)}; }
+
+VerifyingKeyHost load_verifying_key(const std::string &path) {   // r1cs_gg_ppzksnark.tcc:100-108, accumulation_vector.tcc:63-69
+  std::vector<uint8_t> buf = slurp(path); Cursor c{buf.data(), buf.data() + buf.size(), "verification key"}; VerifyingKeyHost vk;
+  HFq *gt = reinterpret_cast<HFq *>(&vk.alpha_g1_beta_g2); for (int i = 0; i < 12; i++) { Fe32 v; c.dec(v.l); gt[i] = fq_of(v).to_mont(); } c.eat('\n');
+  std::vector<Fe32> x; std::vector<uint8_t> f; c.g2(x, f); c.eat('\n'); vk.gamma_g2 = decompress_host_g2(x[0], x[1], f[0]); x.clear(); f.clear(); c.g2(x, f); c.eat('\n'); vk.delta_g2 = decompress_host_g2(x[0], x[1], f[0]);
+  x.clear(); f.clear(); c.g1(x, f); c.eat('\n'); vk.IC.push_back(decompress_host_g1(x[0], f[0]));
+  size_t dom = c.size(), ni = c.size(); for (size_t i = 0; i < ni; i++) if (c.size() != i) c.fail("sparse IC vector"); size_t nv = c.size(); c.eat('\n'); if (nv != ni || dom != ni) c.fail("inconsistent IC vector");
+  for (size_t i = 0; i < nv; i++) { x.clear(); f.clear(); c.g1(x, f); c.eat('\n'); vk.IC.push_back(decompress_host_g1(x[0], f[0])); }
+  return vk;
+}
+
+void save_proving_key(const std::string &path, const ProvingKeyHost &pk) {
+  std::string o; o.reserve(64 * (pk.A.size() + pk.H.size() + pk.L.size()) + 200 * pk.B_idx.size() + 40 * (pk.cs.col[0].size() + pk.cs.col[1].size() + pk.cs.col[2].size()));
+  put_g1(o, pk.alpha_g1); o.push_back('\n'); put_g1(o, pk.beta_g1); o.push_back('\n'); put_g2(o, pk.beta_g2); o.push_back('\n'); put_g1(o, pk.delta_g1); o.push_back('\n'); put_g2(o, pk.delta_g2); o.push_back('\n');
+  put_g1_vec(o, pk.A);
+  put_size(o, pk.A.size()); o.push_back('\n'); put_size(o, pk.B_idx.size()); o.push_back('\n'); for (uint32_t i : pk.B_idx) { put_size(o, i); o.push_back('\n'); }
+  put_size(o, pk.B_idx.size()); o.push_back('\n'); for (size_t i = 0; i < pk.B_idx.size(); i++) { put_g2(o, pk.B_g2[i]); o.push_back(' '); put_g1(o, pk.B_g1[i]); o.push_back('\n'); }
+  put_g1_vec(o, pk.H); put_g1_vec(o, pk.L);
+  const R1csHost &cs = pk.cs; put_size(o, cs.n_inputs); o.push_back('\n'); put_size(o, cs.n_vars - cs.n_inputs); o.push_back('\n'); put_size(o, cs.n_cons); o.push_back('\n');
+  for (size_t i = 0; i < cs.n_cons; i++) for (int m = 0; m < 3; m++) { put_size(o, cs.rowptr[m][i + 1] - cs.rowptr[m][i]); o.push_back('\n');
+    for (uint32_t k = cs.rowptr[m][i]; k < cs.rowptr[m][i + 1]; k++) { put_size(o, cs.col[m][k]); o.push_back('\n'); put_dec(o, cs.coeff[m][k].l); o.push_back('\n'); } }
+  std::ofstream f(path, std::ios::binary); if (!f) throw std::runtime_error("cannot write " + path); f.write(o.data(), (std::streamsize)o.size());
+}
+void save_verifying_key(const std::string &path, const VerifyingKeyHost &vk) {
+  std::string o; const HFq *gt = reinterpret_cast<const HFq *>(&vk.alpha_g1_beta_g2);
+  for (int i = 0; i < 12; i++) { HFq c = gt[i].from_mont(); Fe32 v = fe_of(c); put_dec(o, v.l); if (i < 11) o.push_back(' '); } o.push_back('\n');
+  put_g2(o, vk.gamma_g2); o.push_back('\n'); put_g2(o, vk.delta_g2); o.push_back('\n'); put_g1(o, vk.IC[0]); o.push_back('\n');
+  size_t n = vk.IC.size() - 1; put_size(o, n); o.push_back('\n'); put_size(o, n); o.push_back('\n'); for (size_t i = 0; i < n; i++) { put_size(o, i); o.push_back('\n'); }
+  put_size(o, n); o.push_back('\n'); for (size_t i = 0; i < n; i++) { put_g1(o, vk.IC[i + 1]); o.push_back('\n'); } o.push_back('\n'); o.push_back('\n');
+  std::ofstream f(path, std::ios::binary); if (!f) throw std::runtime_error("cannot write " + path); f.write(o.data(), (std::streamsize)o.size());
+}
+
+// ======================================================================================================================
+// generator
+// ======================================================================================================================
+static void urandom(void *p, size_t n) { FILE *f = fopen("/dev/urandom", "rb"); if (!f || fread(p, 1, n, f) != n) { if (f) fclose(f); throw std::runtime_error("cannot read /dev/urandom"); } fclose(f); }
+static HFr random_fr() { for (;;) { HFr v; urandom(v.l, 32); v.l[3] &= (1ull << 62) - 1; if (!HFr::geq_mod(v.l)) return v.to_mont(); } }   // uniform in [0, r) by rejection (bigint.tcc:167-179 / fp.tcc:695-721)
+static uint64_t splitmix(uint64_t &s) { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+ToxicWaste ToxicWaste::random() { ToxicWaste t; HFr *f = &t.t; for (int i = 0; i < 7; i++) { do f[i] = random_fr(); while (f[i].is_zero()); } return t; }
+ToxicWaste ToxicWaste::from_seed(uint64_t seed) { ToxicWaste t; HFr *f = &t.t; for (int i = 0; i < 7; i++) { HFr v; for (int k = 0; k < 4; k++) v.l[k] = splitmix(seed); v.l[3] &= (1ull << 61) - 1; f[i] = v.to_mont(); } return t; }
+
+static size_t ceil_log2(size_t n) { size_t r = ((n & (n - 1)) == 0 ? 0 : 1); while (n > 1) { n >>= 1; r++; } return r; }
+static HFr root_of_unity(size_t n) { HFr w; memcpy(w.l, FR_ROOT_OF_UNITY_2_28, 32); for (size_t i = 28; i > ceil_log2(n); --i) w = w.sqr(); return w; }
+static void batch_inverse(std::vector<HFr> &v) { std::vector<HFr> pre(v.size()); HFr acc = HFr::one(); for (size_t i = 0; i < v.size(); i++) { pre[i] = acc; acc = acc * v[i]; } HFr ai = acc.inv(); for (size_t i = v.size(); i-- > 0;) { HFr t = ai * pre[i]; ai = ai * v[i]; v[i] = t; } }
+// L_i(t) on a power-of-two domain (basic_radix2_domain_aux.tcc:182-236)
+static std::vector<HFr> radix2_lagrange(size_t m, const HFr &t) {
+  std::vector<HFr> u(m, HFr::zero()); if (m == 1) { u[0] = HFr::one(); return u; } HFr w = root_of_unity(m), tm = t.pow_u64(m), one = HFr::one();
+  if (tm == one) { HFr wi = one; for (size_t i = 0; i < m; i++) { if (wi == t) { u[i] = one; return u; } wi = wi * w; } }
+  HFr Z = tm - one, l = Z * HFr::from_u64(m).inv(), r = one; std::vector<HFr> den(m); for (size_t i = 0; i < m; i++) { den[i] = t - r; r = r * w; } batch_inverse(den);
+  for (size_t i = 0; i < m; i++) { u[i] = l * den[i]; l = l * w; } return u; }
+struct DomainShape { size_t m; bool step; size_t B, S; };
+static DomainShape domain_shape(size_t min_size) { DomainShape d{0, false, 0, 0}; size_t lg = ceil_log2(min_size); if (min_size == ((size_t)1 << lg)) { d.m = min_size; return d; }
+  size_t big = (size_t)1 << (lg - 1), small = min_size - big, rs = (size_t)1 << ceil_log2(small); d.m = small == rs ? min_size : big + rs; if (d.m != ((size_t)1 << ceil_log2(d.m))) { d.step = true; d.B = (size_t)1 << (ceil_log2(d.m) - 1); d.S = d.m - d.B; } return d; }
+// all Lagrange polynomials at t and Z(t)  (basic_radix2_domain.tcc:90-101; step_radix2_domain.tcc:169-215)
+static std::vector<HFr> domain_lagrange(const DomainShape &d, const HFr &t, HFr &Zt) { HFr one = HFr::one();
+  if (!d.step) { Zt = t.pow_u64(d.m) - one; return radix2_lagrange(d.m, t); }
+  HFr w = root_of_unity((size_t)1 << ceil_log2(d.m)), wb = w.sqr(), wS = w.pow_u64(d.S); std::vector<HFr> ib = radix2_lagrange(d.B, t), is = radix2_lagrange(d.S, t * w.inv()), u(d.m);
+  HFr L0 = t.pow_u64(d.S) - wS, bwS = wb.pow_u64(d.S), elt = one; std::vector<HFr> den(d.B); for (size_t i = 0; i < d.B; i++) { den[i] = elt - wS; elt = elt * bwS; } batch_inverse(den);
+  for (size_t i = 0; i < d.B; i++) u[i] = ib[i] * L0 * den[i];
+  HFr L1 = (t.pow_u64(d.B) - one) * (w.pow_u64(d.B) - one).inv(); for (size_t i = 0; i < d.S; i++) u[d.B + i] = L1 * is[i];
+  Zt = (t.pow_u64(d.B) - one) * (t.pow_u64(d.S) - wS); return u; }
+
+static HG2 default_g2_generator() { HFq v[4]; for (int k = 0; k < 4; k++) memcpy(v[k].l, G2_GENERATOR[k], 32); return HG2{HFq2{v[0], v[1]}, HFq2{v[2], v[3]}, HFq2::one()}; }
+static R1csHost swap_ab_if_beneficial(const R1csHost &in) {   // r1cs.tcc:182-231
+  std::vector<uint8_t> ta(in.n_vars + 1, 0), tb(in.n_vars + 1, 0); for (uint32_t c : in.col[0]) ta[c] = 1; for (uint32_t c : in.col[1]) tb[c] = 1; size_t na = 0, nb = 0; for (size_t i = 0; i <= in.n_vars; i++) { na += ta[i]; nb += tb[i]; }
+  R1csHost out = in; if (nb > na) { std::swap(out.rowptr[0], out.rowptr[1]); std::swap(out.col[0], out.col[1]); std::swap(out.coeff[0], out.coeff[1]); } return out; }
+
+void generate_keys(const R1csHost &cs_in, const ToxicWaste &tw, ProvingKeyHost &pk, VerifyingKeyHost &vk) {
+  pk.cs = swap_ab_if_beneficial(cs_in); const R1csHost &cs = pk.cs; size_t nv = cs.n_vars, ni = cs.n_inputs, nc = cs.n_cons; DomainShape d = domain_shape(nc + ni + 1); size_t m = d.m;
+  HFr Zt; std::vector<HFr> u = domain_lagrange(d, tw.t, Zt); std::vector<HFr> M[3]; for (int k = 0; k < 3; k++) M[k].assign(nv + 1, HFr::zero());
+  for (size_t i = 0; i <= ni; i++) M[0][i] = u[nc + i];                                                                                     // r1cs_to_qap.tcc:128-131
+  for (int k = 0; k < 3; k++) for (size_t i = 0; i < nc; i++) for (uint32_t e = cs.rowptr[k][i]; e < cs.rowptr[k][i + 1]; e++) M[k][cs.col[k][e]] = M[k][cs.col[k][e]] + u[i] * fr_of(cs.coeff[k][e]).to_mont();
+  HFr gi = tw.gamma.inv(), di = tw.delta.inv();
+  auto canon = [](const HFr &x) { return fe_of_r(x.from_mont()); };
+  std::vector<Fe32> sA(nv + 1), sB, sH(m - 1), sL(nv - ni), sIC(ni + 1);
+  for (size_t i = 0; i <= nv; i++) sA[i] = canon(M[0][i]);
+  pk.B_idx.clear(); for (size_t i = 0; i <= nv; i++) if (!M[1][i].is_zero()) { pk.B_idx.push_back((uint32_t)i); sB.push_back(canon(M[1][i])); }     // kc_multiexp.tcc:105-112
+  { HFr x = Zt * di; for (size_t i = 0; i + 1 < m; i++) { sH[i] = canon(x); x = x * tw.t; } }                                                   // :330 batch_exp_with_coeff(Zt/delta, Ht), Ht truncated by 2 (:281)
+  for (size_t i = 0; i < nv - ni; i++) { size_t j = ni + 1 + i; sL[i] = canon((tw.beta * M[0][j] + tw.alpha * M[1][j] + M[2][j]) * di); }          // :264-273
+  for (size_t i = 0; i <= ni; i++) sIC[i] = canon((tw.beta * M[0][i] + tw.alpha * M[1][i] + M[2][i]) * gi);                                        // :253-260
+  HG1 g1{HFq::from_u64(1), HFq::from_u64(2), HFq::one()};                                                                                     // G1 generator (1, 2)
+  HG2 g2 = default_g2_generator();
+  { HFr k1 = tw.g1_scalar.from_mont(), k2 = tw.g2_scalar.from_mont(); g1 = g1.mul(k1.l); g2 = g2.mul(k2.l); }                                   // random generators (:297,:307)
+  auto mul1 = [&](const HFr &k) { HFr c = k.from_mont(); return raw_of(g1.mul(c.l)); }; auto mul2 = [&](const HFr &k) { HFr c = k.from_mont(); return raw_of(g2.mul(c.l)); };
+  pk.alpha_g1 = mul1(tw.alpha); pk.beta_g1 = mul1(tw.beta); pk.beta_g2 = mul2(tw.beta); pk.delta_g1 = mul1(tw.delta); pk.delta_g2 = mul2(tw.delta);
+  pk.A.resize(nv + 1); fixed_base_mul_g1(g1, sA.data(), nv + 1, pk.A.data());
+  pk.B_g1.resize(sB.size()); pk.B_g2.resize(sB.size()); fixed_base_mul_g1(g1, sB.data(), sB.size(), pk.B_g1.data()); fixed_base_mul_g2(g2, sB.data(), sB.size(), pk.B_g2.data());
+  pk.H.resize(m - 1); fixed_base_mul_g1(g1, sH.data(), m - 1, pk.H.data()); pk.L.resize(nv - ni); fixed_base_mul_g1(g1, sL.data(), nv - ni, pk.L.data());
+  vk.IC.resize(ni + 1); fixed_base_mul_g1(g1, sIC.data(), ni + 1, vk.IC.data()); vk.gamma_g2 = mul2(tw.gamma); vk.delta_g2 = pk.delta_g2;
+  vk.alpha_g1_beta_g2 = reduced_pairing(fq_of(pk.alpha_g1.x), fq_of(pk.alpha_g1.y), fq2_of(pk.beta_g2.x0, pk.beta_g2.x1), fq2_of(pk.beta_g2.y0, pk.beta_g2.y1));   // :355
+}
+
+// ======================================================================================================================
+// prover
+// ======================================================================================================================
+struct Prover::Impl {
+  size_t nv, ni, m; HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
+  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; std::vector<Fe32> z_host;
+};
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+Prover::Prover(const ProvingKeyHost &pk) : impl(new Impl) {
+  Impl &p = *impl; p.nv = pk.cs.n_vars; p.ni = pk.cs.n_inputs; p.cs.reset(new R1csDev(pk.cs)); p.dom.reset(new Domain(pk.cs.n_cons + p.ni + 1)); p.m = p.dom->m();
+  if (pk.A.size() != p.nv + 1 || pk.H.size() != p.m - 1 || pk.L.size() != p.nv - p.ni) throw std::runtime_error("proving key: query sizes do not match the constraint system");
+  p.alpha_g1 = g1_of(pk.alpha_g1); p.beta_g1 = g1_of(pk.beta_g1); p.delta_g1 = g1_of(pk.delta_g1); p.beta_g2 = g2_of(pk.beta_g2); p.delta_g2 = g2_of(pk.delta_g2);
+  int cw = env_int("ZK_MSM_WITNESS_WINDOW", 8), ch = env_int("ZK_MSM_H_WINDOW", 13);
+  p.A.reset(new MsmG1(pk.A.data(), pk.A.size(), cw, true)); p.L.reset(new MsmG1(pk.L.data(), pk.L.size(), cw, true));
+  p.B1.reset(new MsmG1(pk.B_g1.data(), pk.B_g1.size(), cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data(), pk.B_g2.size(), cw, true)); p.H.reset(new MsmG1(pk.H.data(), pk.H.size(), ch, false));
+  p.B_idx = DevBuf<uint32_t>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx.upload(pk.B_idx.data(), pk.B_idx.size());
+  p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host.resize(p.nv + 1);
+}
+Prover::~Prover() = default;
+size_t Prover::num_variables() const { return impl->nv; }
+size_t Prover::num_inputs() const { return impl->ni; }
+size_t Prover::domain_size() const { return impl->m; }
+
+bool Prover::prove(const Fe32 *z, const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
+  Impl &p = *impl; double t0 = now_ms();
+  memset(&p.z_host[0], 0, 32); p.z_host[0].l[0] = 1; memcpy(&p.z_host[1], z, 32 * p.nv);
+  p.z.upload(p.z_host.data(), p.nv + 1); fr_to_mont_dev(p.z.get(), p.nv + 1);
+  p.cs->eval(p.z.get(), p.abc.get(), p.m); double t1 = now_ms();
+  if (!p.cs->satisfied(p.abc.get(), p.m)) return false;
+  // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322)
+  p.dom->ifft(p.abc.get(), 3, p.m); p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); p.dom->icoset_fft(p.abc.get(), 1, p.m);
+  // the four multi-exponentiations (r1cs_gg_ppzksnark.tcc:442-484); scalars stay on the device
+  p.H->run(p.abc.get(), nullptr); p.A->run(p.z.get(), nullptr); p.L->run(p.z.get() + p.ni + 1, nullptr); p.B1->run(p.z.get(), p.B_idx.get()); p.B2->run(p.z.get(), p.B_idx.get());
+  gpu_sync(); double t2 = now_ms();
+  HG1 eH = p.H->result(), eA = p.A->result(), eL = p.L->result(), eB1 = p.B1->result(); HG2 eB2 = p.B2->result(); double t3 = now_ms();
+  HFr r = r_in ? fr_of(*r_in) : random_fr().from_mont(), s = s_in ? fr_of(*s_in) : random_fr().from_mont(), rs = (r.to_mont() * s.to_mont()).from_mont();   // canonical scalars
+  HG1 gA = p.alpha_g1.add(eA).add(p.delta_g1.mul(r.l));                                                                  // :488
+  HG1 gB1 = p.beta_g1.add(eB1).add(p.delta_g1.mul(s.l)); HG2 gB2 = p.beta_g2.add(eB2).add(p.delta_g2.mul(s.l));        // :491-492
+  HG1 gC = eH.add(eL).add(gA.mul(s.l)).add(gB1.mul(r.l)).add(p.delta_g1.mul(rs.l).neg());                               // :495
+  out.A = raw_of(gA); out.B = raw_of(gB2); out.C = raw_of(gC); double t4 = now_ms();
+  last.upload_ms = t1 - t0; last.qap_ms = 0; last.msm_ms = t2 - t1; last.finish_ms = t4 - t2; last.total_ms = t4 - t0; return true;
+}
+
+// ======================================================================================================================
+// verifier and proof encoding
+// ======================================================================================================================
+bool verify_proof(const VerifyingKeyHost &vk, const Fe32 *inputs, size_t n_inputs, const Proof &proof) {
+  if (vk.IC.size() != n_inputs + 1) return false;                                                                       // strong IC (:584-590)
+  HG1 acc = g1_of(vk.IC[0]); for (size_t i = 0; i < n_inputs; i++) { HFr k = fr_of(inputs[i]); acc = acc.add(g1_of(vk.IC[i + 1]).mul(k.l)); }
+  HFq ax = fq_of(proof.A.x), ay = fq_of(proof.A.y), cx = fq_of(proof.C.x), cy = fq_of(proof.C.y); HFq2 bx = fq2_of(proof.B.x0, proof.B.x1), by = fq2_of(proof.B.y0, proof.B.y1);
+  bool well_formed = g1_on_curve(ax, ay) && g2_on_curve(bx, by) && g1_on_curve(cx, cy);                                 // is_well_formed: on-curve only
+  if (is_zero_raw(&proof.A, sizeof proof.A) || is_zero_raw(&proof.B, sizeof proof.B) || is_zero_raw(&proof.C, sizeof proof.C)) return false;   // a proof read from hex has Z = 1, so these are (0,0): off-curve in the reference as well
+  if (!well_formed) return false;
+  HFq accx, accy; acc.to_affine(accx, accy);
+  HFq12 q1 = miller_loop(ax, ay, precompute_g2(bx, by));
+  HFq12 q2 = acc.is_inf() ? HFq12::one() : miller_loop(accx, accy, precompute_g2(fq2_of(vk.gamma_g2.x0, vk.gamma_g2.x1), fq2_of(vk.gamma_g2.y0, vk.gamma_g2.y1)));
+  HFq12 q3 = miller_loop(cx, cy, precompute_g2(fq2_of(vk.delta_g2.x0, vk.delta_g2.x1), fq2_of(vk.delta_g2.y0, vk.delta_g2.y1)));
+  return final_exponentiation(q1 * (q2 * q3).conj()) == vk.alpha_g1_beta_g2;                                            // :556-560
+}
+
+static void put_hex_fq(std::string &o, const Fe32 &mont) { HFq c = fq_of(mont).from_mont(); static const char *d = "0123456789abcdef"; for (int i = 3; i >= 0; i--) for (int k = 15; k >= 0; k--) o.push_back(d[(c.l[i] >> (4 * k)) & 15]); }
+std::string proof_to_hex(const Proof &p) { std::string o; o.reserve(512); put_hex_fq(o, p.A.x); put_hex_fq(o, p.A.y); put_hex_fq(o, p.B.x1); put_hex_fq(o, p.B.x0); put_hex_fq(o, p.B.y1); put_hex_fq(o, p.B.y0); put_hex_fq(o, p.C.x); put_hex_fq(o, p.C.y); return o; }
+bool proof_from_hex(const char *hex, Proof &p) {
+  Fe32 v[8];
+  for (int k = 0; k < 8; k++) { HFq c = HFq::zero(); for (int i = 0; i < 64; i++) { char ch = hex[64 * k + i]; int dgt = ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : -1; if (dgt < 0) return false; c.l[(63 - i) / 16] |= (uint64_t)dgt << (4 * ((63 - i) % 16)); }
+    // values >= q cannot come from a prover; the reference would reduce them inside Fp's constructor — reject instead of aliasing
+    if (HFq::geq_mod(c.l)) return false; v[k] = fe_of(c.to_mont()); }
+  p.A = {v[0], v[1]}; p.B = {v[3], v[2], v[5], v[4]}; p.C = {v[6], v[7]}; return true;
+}
+Proof default_proof() { Proof p; HG1 g{HFq::from_u64(1), HFq::from_u64(2), HFq::one()}; p.A = raw_of(g); p.C = p.A; p.B = raw_of(default_g2_generator()); return p; }
+
+}  // namespace zk

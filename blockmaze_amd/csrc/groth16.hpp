@@ -1,0 +1,57 @@
+// Groth16 (libsnark's r1cs_gg_ppzksnark) on the MI355X engine: key containers, the reference's key-file format, key
+// generation, the prover pipeline and the verifier.
+// Reference: SNARK/zk_proof_systems/ppzksnark/r1cs_gg_ppzksnark/r1cs_gg_ppzksnark.{hpp,tcc}.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+#include "gpu.hpp"
+#include "pairing_host.hpp"
+
+namespace zk {
+
+// All group elements affine, Montgomery form; the all-zero record is the point at infinity.
+struct ProvingKeyHost {                           // r1cs_gg_ppzksnark.hpp:72-110
+  G1AffineRaw alpha_g1, beta_g1, delta_g1; G2AffineRaw beta_g2, delta_g2;
+  std::vector<G1AffineRaw> A;                     // n_vars + 1 (entries may be infinity)
+  std::vector<uint32_t> B_idx; std::vector<G2AffineRaw> B_g2; std::vector<G1AffineRaw> B_g1;   // sparse knowledge-commitment vector
+  std::vector<G1AffineRaw> H;                     // m - 1
+  std::vector<G1AffineRaw> L;                     // n_vars - n_inputs
+  R1csHost cs;                                    // as stored in the key (A/B already swapped if the generator found it beneficial)
+};
+struct VerifyingKeyHost {                         // r1cs_gg_ppzksnark.hpp:170-200
+  host::HFq12 alpha_g1_beta_g2; G2AffineRaw gamma_g2, delta_g2; std::vector<G1AffineRaw> IC;   // IC[0] = gamma_ABC_g1.first
+};
+struct Proof { G1AffineRaw A; G2AffineRaw B; G1AffineRaw C; };   // affine, Montgomery
+
+// ---- the reference's on-disk format (hybrid binary/decimal) ---------------------------------------------
+ProvingKeyHost load_proving_key(const std::string &path);       // point decompression runs on the GPU
+VerifyingKeyHost load_verifying_key(const std::string &path);   // host only
+void save_proving_key(const std::string &path, const ProvingKeyHost &pk);
+void save_verifying_key(const std::string &path, const VerifyingKeyHost &vk);
+
+// ---- generator (r1cs_gg_ppzksnark.tcc:212-388) --------------------------------------------------------------------------
+struct ToxicWaste { host::HFr t, alpha, beta, gamma, delta, g1_scalar, g2_scalar; static ToxicWaste random(); static ToxicWaste from_seed(uint64_t seed); };
+void generate_keys(const R1csHost &cs, const ToxicWaste &tw, ProvingKeyHost &pk, VerifyingKeyHost &vk);
+
+// ---- prover (r1cs_gg_ppzksnark.tcc:391-506) -------------------------------------------------------------------------------
+class Prover {                                    // a proving key resident in HBM
+ public:
+  explicit Prover(const ProvingKeyHost &pk); ~Prover();
+  size_t num_variables() const; size_t num_inputs() const; size_t domain_size() const;
+  // z: full assignment without ONE (canonical).  r, s: prover randomness (canonical; nullptr = fresh CSPRNG values).
+  // Returns false if z does not satisfy the constraint system (the reference then emits its default proof, sendcgo.cpp:209-214).
+  bool prove(const Fe32 *z, const Fe32 *r, const Fe32 *s, Proof &out);
+  struct Timings { double upload_ms, qap_ms, msm_ms, finish_ms, total_ms; } last{};
+  struct Impl; std::unique_ptr<Impl> impl;
+};
+
+// ---- verifier (r1cs_gg_ppzksnark.tcc:509-623) -------------------------------------------------------------------------------
+bool verify_proof(const VerifyingKeyHost &vk, const Fe32 *inputs /* canonical */, size_t n_inputs, const Proof &proof);
+
+// proof <-> the 512-hex-character form of the cgo wrappers (sendcgo.cpp:113-188, :388-448)
+std::string proof_to_hex(const Proof &p);
+bool proof_from_hex(const char *hex, Proof &p);   // reads exactly 512 characters; false on a non-hex character
+Proof default_proof();                            // (G1::one, G2::one, G1::one) — r1cs_gg_ppzksnark.hpp:309-315
+
+}  // namespace zk

@@ -70,6 +70,30 @@ void zkgpu_r1cs_destroy(zkgpu_r1cs *cs);
 /* z: n_vars elements (without ONE).  h_out: (m+1) elements, m = zkgpu_domain_size(n_cons + n_inputs + 1).  Returns ZKGPU_ERR_UNSATISFIED if z violates a constraint. */
 int zkgpu_witness_map(zkgpu_r1cs *cs, const uint8_t *z, uint8_t *h_out);
 
+/* ---- circuits, keys, resident prover, verifier -------------------------------------------------------------------- */
+/* kind: 0 mint, 1 send, 2 deposit, 3 redeem (100 = libsnark's sha256 two-to-one test circuit).  tree_depth only matters for deposit (reference: 8). */
+/* writes the circuit's constraint system as an "R1CSBM01" file: magic, u64 n_inputs / n_vars / n_cons, then per matrix u64 nnz, u32 rowptr[n_cons+1], u32 col[nnz], 32-byte coeff[nnz] */
+int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path);
+/* witness files: u64 n, then n 32-byte canonical values (the full assignment without ONE).  Same arguments as the gen*proof symbols. */
+int zkgpu_witness_sha256(const uint8_t left[32], const uint8_t right[32], const char *wit_path);
+int zkgpu_witness_send(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new,
+                       char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender, const char *wit_path);
+int zkgpu_witness_mint_redeem(int redeem, uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk, const char *wit_path);
+/* key generation (r1cs_gg_ppzksnark_generator, r1cs_gg_ppzksnark.tcc:212-388; the *_key executables of libsnark-vnt/src/X/getpvk.cpp).  seed 0 = fresh randomness from the
+ * OS; any other seed gives reproducible TEST keys.  Files are written in the reference's key-file format. */
+int zkgpu_keygen(int kind, int tree_depth, uint64_t seed, const char *pk_path, const char *vk_path);
+int zkgpu_keygen_from_r1cs(const char *r1cs_path, uint64_t seed, const char *pk_path, const char *vk_path);
+/* resident prover over a reference-format proving key file */
+typedef struct zkgpu_prover zkgpu_prover;
+zkgpu_prover *zkgpu_prover_load(const char *pk_path);
+void zkgpu_prover_destroy(zkgpu_prover *h);
+int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]);          /* n_vars, n_inputs, domain size m */
+/* z: n_vars elements; r, s: 32-byte canonical prover randomness or NULL for fresh values.  proof_hex: 512 hex characters + NUL. */
+int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]);
+int zkgpu_prover_timings(zkgpu_prover *h, double out[5]);       /* ms of the last prove(): upload+rows, (unused), device kernels, host finish, total */
+/* 1 = accept, 0 = reject, negative = error.  inputs: n_inputs canonical field elements (the packed public input) */
+int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs);
+
 #ifdef __cplusplus
 }
 #endif
