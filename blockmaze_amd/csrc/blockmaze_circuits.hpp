@@ -35,7 +35,7 @@ const char *circuit_name(CircuitKind k);
 struct MintInputs { uint64_t value, value_old, value_s; Blob256 sn_old, r_old, sn, r, cmtA_old, cmtA, sk; };
 struct RedeemInputs { uint64_t value, value_old, value_s; Blob256 sn_old, r_old, sn, r, cmtA_old, cmtA, sk; };
 struct SendInputs { uint64_t value_old, value_s, value; Blob256 sn_old, r_old, r_s, sn, r, cmtA_old, cmtS, cmtA, sk; Blob160 pk_recv, pk_sender; };
-struct DepositInputs { uint64_t value, value_old, value_s; Blob256 sn_old, r_old, sn, r, sn_s, r_s, cmtB_old, cmtB, cmtS, sk, rt; Blob160 pk_recv; std::vector<Blob256> path; std::vector<bool> index_bits; };
+struct DepositInputs { uint64_t value, value_old, value_s; Blob256 sn_old, r_old, sn, r, sn_s, r_s, sn_A_old, cmtB_old, cmtB, cmtS, sk, rt; Blob160 pk_recv; std::vector<Blob256> path; std::vector<bool> index_bits; };
 
 // A circuit instance: construct once (allocates variables; with emit = true also emits the constraint system), then
 // assign() any number of witnesses.

@@ -123,6 +123,20 @@ bool verifySendproof(char *data, char *cmtA_old, char *sn_old, char *cmtS, char 
   std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(cmtA_old).b, 32)); append(bits, blob_bits(blob256_from_hex(sn_old).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtS).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtA_new).b, 32));
   return verify(CircuitKind::Send, data, bits); }
 
+// depositcgo.cpp:327-444: the Merkle path of cmtS is rebuilt from cmtarray (the tree holds the leaves up to and including the first occurrence of cmtS plus
+// everything appended afterwards, i.e. all n leaves); RT is ignored and the root recomputed
+char *genDepositproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old, char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *RT, char *sk) {
+  (void)RT; DepositInputs in; in.value = value; in.value_old = value_old; in.value_s = value_s; in.sn_old = blob256_from_hex(sn_old); in.r_old = blob256_from_hex(r_old); in.sn = blob256_from_hex(sn); in.r = blob256_from_hex(r);
+  in.sn_s = blob256_from_hex(sns); in.r_s = blob256_from_hex(rs); in.cmtB_old = blob256_from_hex(cmtB_old); in.cmtB = blob256_from_hex(cmtB); in.cmtS = blob256_from_hex(cmtS); in.sk = blob256_from_hex(sk); in.pk_recv = blob160_from_hex(pk);
+  in.sn_A_old = blob256_from_hex(sn_A_old);
+  std::vector<Blob256> leaves = parse_cmtarray(cmtarray, n); size_t index = 0; bool found = false; for (size_t i = 0; i < leaves.size(); i++) if (!memcmp(leaves[i].b, in.cmtS.b, 32)) { index = i; found = true; break; }
+  if (!found) { leaves.clear(); index = 0; }   // reference: the witness of an empty tree — position 0 with empty-subtree siblings and the empty root; such a proof cannot satisfy the circuit unless value_s = 0
+  in.path = merkle_path(leaves, 8, index, in.index_bits); in.rt = merkle_root(leaves, 8);
+  return generate(CircuitKind::Deposit, [&](Circuit &c) { assign_deposit(c, in); }); }
+bool verifyDepositproof(char *data, char *RT, char *pk, char *cmtb_old, char *snold, char *cmtb, char *sns) {   // deposit_gadget::witness_map (deposit/circuit/gadget.tcc:301-323)
+  std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(RT).b, 32)); append(bits, blob_bits(blob160_from_hex(pk).b, 20)); append(bits, blob_bits(blob256_from_hex(cmtb_old).b, 32)); append(bits, blob_bits(blob256_from_hex(snold).b, 32));
+  append(bits, blob_bits(blob256_from_hex(cmtb).b, 32)); append(bits, blob_bits(blob256_from_hex(sns).b, 32)); return verify(CircuitKind::Deposit, data, bits); }
+
 // ---- engine-level entry points for keys, circuits and the resident prover (include/zkgpu.h) ---------------------------
 struct zkgpu_prover { std::shared_ptr<Prover> p; };
 

@@ -98,3 +98,66 @@ class R1cs:
     def __del__(self):
         try: self.close()
         except Exception: pass
+
+# ---- circuits, keys, prover, verifier ---------------------------------------------------------------------------------
+KIND = {"mint": 0, "send": 1, "deposit": 2, "redeem": 3, "sha256": 100}
+def circuit_export(kind, path, tree_depth=8): _check(lib().zkgpu_circuit_export(KIND[kind], tree_depth, path.encode()))
+def keygen(kind, pk_path, vk_path, seed=0, tree_depth=8): _check(lib().zkgpu_keygen(KIND[kind], tree_depth, ctypes.c_uint64(seed), pk_path.encode(), vk_path.encode()))
+def keygen_from_r1cs(r1cs_path, pk_path, vk_path, seed=0): _check(lib().zkgpu_keygen_from_r1cs(r1cs_path.encode(), ctypes.c_uint64(seed), pk_path.encode(), vk_path.encode()))
+def witness_sha256(left32, right32, path): _check(lib().zkgpu_witness_sha256(bytes(left32), bytes(right32), path.encode()))
+def _s(x): return x if isinstance(x, bytes) else x.encode()
+def witness_send(value_A, r_s, sn, r, cmt_s, cmtA, value_s, pk_recv, value_A_new, sn_A_new, r_A_new, cmt_A_new, sk, pk_sender, path):
+    _check(lib().zkgpu_witness_send(ctypes.c_uint64(value_A), _s(r_s), _s(sn), _s(r), _s(cmt_s), _s(cmtA), ctypes.c_uint64(value_s), _s(pk_recv), ctypes.c_uint64(value_A_new), _s(sn_A_new), _s(r_A_new), _s(cmt_A_new), _s(sk), _s(pk_sender), path.encode()))
+def witness_mint_redeem(redeem, value, value_old, sn_old, r_old, sn, r, cmtA_old, cmtA, value_s, sk, path):
+    _check(lib().zkgpu_witness_mint_redeem(int(redeem), ctypes.c_uint64(value), ctypes.c_uint64(value_old), _s(sn_old), _s(r_old), _s(sn), _s(r), _s(cmtA_old), _s(cmtA), ctypes.c_uint64(value_s), _s(sk), path.encode()))
+
+class Prover:
+    """a reference-format proving key resident in HBM"""
+    def __init__(self, pk_path):
+        lib().zkgpu_prover_load.restype = ctypes.c_void_p
+        self.h = lib().zkgpu_prover_load(pk_path.encode())
+        if not self.h: raise ZkGpuError(lib().zkgpu_last_error().decode())
+        info = (ctypes.c_size_t * 3)(); _check(lib().zkgpu_prover_info(ctypes.c_void_p(self.h), info)); self.n_vars, self.n_inputs, self.m = (int(x) for x in info)
+    def prove(self, z, r=None, s=None):
+        """z: (n_vars, 4) uint64 canonical.  r, s: ints or None.  Returns the 512-character proof hex."""
+        z = np.ascontiguousarray(z, dtype=np.uint64); assert z.size == 4 * self.n_vars
+        R = int(r).to_bytes(32, "little") if r is not None else None; S = int(s).to_bytes(32, "little") if s is not None else None
+        out = ctypes.create_string_buffer(513); _check(lib().zkgpu_prover_prove(ctypes.c_void_p(self.h), _bytes(z), R, S, out)); return out.value.decode()
+    def timings(self):
+        t = (ctypes.c_double * 5)(); _check(lib().zkgpu_prover_timings(ctypes.c_void_p(self.h), t)); return dict(zip(("upload_ms", "qap_ms", "device_ms", "finish_ms", "total_ms"), (float(x) for x in t)))
+    def close(self):
+        if self.h: lib().zkgpu_prover_destroy(ctypes.c_void_p(self.h)); self.h = None
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+def verify(vk_path, proof_hex, inputs):
+    """inputs: list of ints (packed public input).  True / False."""
+    buf = b"".join(int(x).to_bytes(32, "little") for x in inputs)
+    rc = lib().zkgpu_verify(vk_path.encode(), proof_hex.encode(), buf, ctypes.c_size_t(len(inputs)))
+    if rc < 0: _check(rc)
+    return bool(rc)
+
+class Zk:
+    """the drop-in symbols (what go-ethereum/zktx calls through cgo), bound the way zktx.go marshals them: "0x…" hex strings and uint64"""
+    def __init__(self):
+        L = lib()
+        for f in ("genCMT", "genCMTS", "computePRF", "computeCRH", "genRoot", "genMintproof", "genSendproof", "genRedeemproof", "genDepositproof"): getattr(L, f).restype = ctypes.c_char_p
+        for f in ("verifyMintproof", "verifySendproof", "verifyRedeemproof", "verifyDepositproof"): getattr(L, f).restype = ctypes.c_bool
+        self.L = L
+    @staticmethod
+    def hx(b): return ("0x" + bytes(b).hex()).encode()          # common.ToHex
+    def GenCMT(self, value, sn, r): return bytes.fromhex(self.L.genCMT(ctypes.c_uint64(value), self.hx(sn), self.hx(r)).decode())
+    def GenCMTS(self, value, pk, rs, sn_old): return bytes.fromhex(self.L.genCMTS(ctypes.c_uint64(value), self.hx(pk), self.hx(rs), self.hx(sn_old)).decode())
+    def ComputePRF(self, sk, r): return bytes.fromhex(self.L.computePRF(self.hx(sk), self.hx(r)).decode())
+    def ComputeCRH(self, pk, r): return bytes.fromhex(self.L.computeCRH(self.hx(pk), self.hx(r)).decode())
+    def GenRT(self, cmts): return bytes.fromhex(self.L.genRoot(b"".join(self.hx(c) for c in cmts), len(cmts)).decode())
+    def GenSendProof(self, valueA, rS, snA, rA, cmtS, cmtA, valueS, pk_recv, valueANew, snAnew, rAnew, cmtAnew, sk, pk_sender):   # zktx.go:406-430
+        return self.L.genSendproof(ctypes.c_uint64(valueA), self.hx(rS), self.hx(snA), self.hx(rA), self.hx(cmtS), self.hx(cmtA), ctypes.c_uint64(valueS), self.hx(pk_recv), ctypes.c_uint64(valueANew), self.hx(snAnew), self.hx(rAnew), self.hx(cmtAnew), self.hx(sk), self.hx(pk_sender)).decode()
+    def VerifySendProof(self, proof, cmtA_old, sn_old, cmtS, cmtA_new): return bool(self.L.verifySendproof(proof.encode(), self.hx(cmtA_old), self.hx(sn_old), self.hx(cmtS), self.hx(cmtA_new)))
+    def GenMintProof(self, value, value_old, sn_old, r_old, sn, r, cmtA_old, cmtA, value_s, sk):
+        return self.L.genMintproof(ctypes.c_uint64(value), ctypes.c_uint64(value_old), self.hx(sn_old), self.hx(r_old), self.hx(sn), self.hx(r), self.hx(cmtA_old), self.hx(cmtA), ctypes.c_uint64(value_s), self.hx(sk)).decode()
+    def VerifyMintProof(self, proof, cmtA_old, sn_old, cmtA, value_s): return bool(self.L.verifyMintproof(proof.encode(), self.hx(cmtA_old), self.hx(sn_old), self.hx(cmtA), ctypes.c_uint64(value_s)))
+    def GenRedeemProof(self, value, value_old, sn_old, r_old, sn, r, cmtA_old, cmtA, value_s, sk):
+        return self.L.genRedeemproof(ctypes.c_uint64(value), ctypes.c_uint64(value_old), self.hx(sn_old), self.hx(r_old), self.hx(sn), self.hx(r), self.hx(cmtA_old), self.hx(cmtA), ctypes.c_uint64(value_s), self.hx(sk)).decode()
+    def VerifyRedeemProof(self, proof, cmtA_old, sn_old, cmtA, value_s): return bool(self.L.verifyRedeemproof(proof.encode(), self.hx(cmtA_old), self.hx(sn_old), self.hx(cmtA), ctypes.c_uint64(value_s)))

@@ -45,6 +45,9 @@ def gadget_fixture():
     with tempfile.TemporaryDirectory() as t:
         for seed in (0, 1, 2):
             out = run("sha256gadget", t + "/r.bin", t + "/w.bin", str(seed)); kv = dict(p.split("=") for p in out.split()[1:])
+            if seed == 0:
+                from test_circuits_cpu import canonical_hash
+                res["canonical_r1cs_sha256"] = canonical_hash(o.R1CS.load(t + "/r.bin"))   # term-order independent digest, see tests/test_circuits_cpu.py
             res["seed%d" % seed] = {"constraints": int(kv["constraints"]), "variables": int(kv["variables"]), "digest_bits": kv["digest"], "r1cs_sha256": sha(t + "/r.bin"), "witness_sha256": sha(t + "/w.bin")}
         json.dump(res, open(os.path.join(GOLD, "sha256_gadget.json"), "w"), indent=1)
         res = {}

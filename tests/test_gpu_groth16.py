@@ -1,0 +1,79 @@
+"""GPU parity of the whole proving path through the C-ABI:
+  * proof BYTES equal to the real reference prover's on the reference-made key files committed under tests/golden
+  * keys made by the GPU key generator are accepted by the oracle's reader, and oracle / engine / (when the compiled
+    reference harness travelled with the repo) the real libsnark prover and verifier all agree on them
+  * the full-size send circuit: key generation, proof with fixed (r, s), verification, and the drop-in cgo symbols."""
+import json, os, subprocess
+import numpy as np
+import pytest
+from oracle import pyoracle as o
+from blockmaze_amd import engine as e
+import workload as w
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+have_ref = os.path.exists(HARNESS)
+
+def ref(*args):
+    r = subprocess.run([HARNESS, *args], capture_output=True, text=True); return r.returncode, r.stdout
+
+@pytest.mark.parametrize("name", ["groth16_small", "groth16_step"])
+def test_proof_bytes_match_reference_prover(golden_dir, name):
+    d = os.path.join(golden_dir, name); meta = json.load(open(os.path.join(d, "meta.json"))); z = o.load_witness(os.path.join(d, "wit.bin"))
+    p = e.Prover(os.path.join(d, "pk.txt")); assert (p.n_vars, p.n_inputs, p.m) == (meta["n_vars"], meta["n_inputs"], meta["domain_m"])
+    proof = p.prove(z, int(meta["r"], 16), int(meta["s"], 16))
+    assert proof == meta["proof"]                                                     # the reference prover's serialized bytes
+    inputs = o.from_arr(z[:meta["n_inputs"]]); vk = os.path.join(d, "vk.txt")
+    assert e.verify(vk, proof, inputs)
+    assert not e.verify(vk, proof, [inputs[0] ^ 1] + inputs[1:]) and not e.verify(vk, proof, inputs[:-1])
+    tampered = proof[:130] + ("0" if proof[130] != "0" else "1") + proof[131:]; assert not e.verify(vk, tampered, inputs)
+    assert not e.verify(vk, "zz" + proof[2:], inputs)                                 # non-hex input is rejected, not UB (sendcgo.cpp:25-35)
+    z2 = z.copy(); z2[meta["n_vars"] - 1, 0] ^= 1
+    if not o.r1cs_is_satisfied(o.parse_pk(os.path.join(d, "pk.txt"))[1], z2):
+        with pytest.raises(e.ZkGpuError): p.prove(z2, 1, 1)
+    p2 = p.prove(z); assert p2 != proof and e.verify(vk, p2, inputs)                   # fresh randomness: different bytes, still valid
+    p.close()
+
+@pytest.mark.parametrize("name,seed", [("groth16_small", 11), ("groth16_step", 12)])
+def test_keygen_agrees_with_oracle_and_reference(golden_dir, tmp_path, name, seed):
+    d = os.path.join(golden_dir, name); pk_path, vk_path = str(tmp_path / "pk.txt"), str(tmp_path / "vk.txt")
+    e.keygen_from_r1cs(os.path.join(d, "r1cs.bin"), pk_path, vk_path, seed=seed)
+    z = o.load_witness(os.path.join(d, "wit.bin")); pk, cs = o.parse_pk(pk_path); vk = o.parse_vk(vk_path)     # oracle reads the engine's key files
+    g = o.SplitMix64(seed); r, s = g.field(), g.field()
+    exp = o.proof_hex(o.prove(cs, z, pk, r, s)); assert o.verify(vk, z[:cs.n_inputs], o.prove(cs, z, pk, r, s))
+    p = e.Prover(pk_path); got = p.prove(z, r, s); p.close(); assert got == exp
+    assert e.verify(vk_path, got, o.from_arr(z[:cs.n_inputs]))
+    if have_ref:                                                                       # the real libsnark on the engine's key files
+        rc, out = ref("prove", pk_path, os.path.join(d, "wit.bin"), str(cs.n_inputs), "%x" % r, "%x" % s); assert rc == 0 and ("proof " + got) in out
+        rc, out = ref("verify", vk_path, got, str(cs.n_inputs), *[str(x) for x in o.from_arr(z[:cs.n_inputs])]); assert rc == 0 and "verify 1" in out
+
+@pytest.fixture(scope="module")
+def send_keys(tmp_path_factory):
+    d = tmp_path_factory.mktemp("prfKey"); e.keygen("send", str(d / "sendpk.txt"), str(d / "sendvk.txt"), seed=0xB10C4A2E); return d
+
+def hexargs(args): return [("0x" + a.hex()) if isinstance(a, bytes) else a for a in args]
+
+def test_send_proof_full_size(send_keys, tmp_path):
+    pk_path, vk_path = str(send_keys / "sendpk.txt"), str(send_keys / "sendvk.txt"); p = e.Prover(pk_path); assert (p.n_vars, p.n_inputs, p.m) == (227046, 5, 262144)
+    d = w.reference_send_fixture(); wp = str(tmp_path / "w.bin"); e.witness_send(*hexargs(w.send_args(d)), wp); z = o.load_witness(wp)
+    g = o.SplitMix64(2024); r, s = g.field(), g.field(); proof = p.prove(z, r, s); inputs = w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]])
+    assert e.verify(vk_path, proof, inputs) and not e.verify(vk_path, proof, inputs[::-1])
+    assert p.prove(z, r, s) == proof                                                    # deterministic given (r, s)
+    d2 = w.send_instance(1); e.witness_send(*hexargs(w.send_args(d2)), wp); z2 = o.load_witness(wp); proof2 = p.prove(z2)
+    assert e.verify(vk_path, proof2, w.pack_public([d2["cmtA_old"], d2["sn_old"], d2["cmtS"], d2["cmtA"]])) and not e.verify(vk_path, proof2, inputs)
+    print("timings", p.timings()); p.close()
+    if have_ref and os.environ.get("ZK_SKIP_SLOW_REF") != "1":                           # the real libsnark prover on the engine-made send key: identical bytes (about 70 s of CPU)
+        e.witness_send(*hexargs(w.send_args(d)), wp); rc, out = ref("prove", pk_path, wp, "5", "%x" % r, "%x" % s); assert rc == 0 and ("proof " + proof) in out
+        rc, out = ref("verify", vk_path, proof, "5", *[str(x) for x in inputs]); assert rc == 0 and "verify 1" in out
+
+def test_dropin_symbols_send(send_keys, monkeypatch):
+    monkeypatch.setenv("ZK_PRFKEY_DIR", str(send_keys)); zk = e.Zk(); d = w.send_instance(5)
+    proof = zk.GenSendProof(*w.send_args(d)); assert len(proof) == 512 and not proof.startswith("0000000000")
+    assert zk.VerifySendProof(proof, d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"])
+    assert not zk.VerifySendProof(proof, d["cmtA"], d["sn_old"], d["cmtS"], d["cmtA_old"])
+    assert zk.GenSendProof(*w.send_args(d)) != proof                                    # second call reuses the resident key; r, s are fresh
+    bad = dict(d); bad["value_s"] = d["value_s"] + 1                                    # cmtS no longer matches: unsatisfied -> default proof, the failure sentinel of api.go:1690
+    sentinel = zk.GenSendProof(*w.send_args(bad)); assert sentinel.startswith("0000000000") and sentinel[:128] == "%064x%064x" % (1, 2)
+    assert not zk.VerifySendProof(sentinel, d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"])
+    monkeypatch.setenv("ZK_FIXED_RS", "1234:5678"); a = zk.GenSendProof(*w.send_args(d)); b = zk.GenSendProof(*w.send_args(d)); assert a == b and zk.VerifySendProof(a, d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"])
