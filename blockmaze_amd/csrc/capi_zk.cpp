@@ -169,6 +169,8 @@ int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]) { if (!h) return ZKGPU_ERR
 int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded([&] { if (!h) return ZKGPU_ERR_ARG; Proof p;
   if (!h->p->prove((const Fe32 *)z, (const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
 int zkgpu_prover_timings(zkgpu_prover *h, double out[5]) { if (!h) return ZKGPU_ERR_ARG; out[0] = h->p->last.upload_ms; out[1] = h->p->last.qap_ms; out[2] = h->p->last.msm_ms; out[3] = h->p->last.finish_ms; out[4] = h->p->last.total_ms; return ZKGPU_OK; }
+int zkgpu_profile_enable(int on) { return guarded([&] { profile_enable(on != 0); return ZKGPU_OK; }); }
+int zkgpu_profile_report(char *buf, size_t cap) { return guarded([&] { std::string r = profile_report(); if (r.size() + 1 > cap) return ZKGPU_ERR_ARG; memcpy(buf, r.c_str(), r.size() + 1); return ZKGPU_OK; }); }
 int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs) { int res = 0; int rc = guarded_host([&] { VerifyingKeyHost vk = load_verifying_key(vk_path); Proof p;
   if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK; } res = verify_proof(vk, (const Fe32 *)inputs, n_inputs, p) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
 }  // extern "C"

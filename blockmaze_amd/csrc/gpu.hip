@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include "gpu.hpp"
 #include "msm.cuh"
@@ -26,6 +27,22 @@ GpuContext &gpu() { static GpuContext ctx; hipSetDevice(ctx.device); return ctx;
 bool gpu_available() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0; }
 void gpu_sync() { HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
 hipStream_t gpu_stream() { return gpu().stream; }
+
+// ---- optional per-stage timing with HIP events on the compute stream (bench.py's roofline leg; off by default) ----------
+struct StageTimer {
+  struct Span { std::string name; hipEvent_t a, b; };
+  bool enabled = false; std::vector<Span> open; std::vector<hipEvent_t> pool; std::map<std::string, std::pair<double, long>> acc;
+  hipEvent_t get() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; } hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e; }
+  size_t begin(const char *name) { if (!enabled) return (size_t)-1; Span s{name, get(), get()}; HIP_CHECK(hipEventRecord(s.a, gpu().stream)); open.push_back(s); return open.size() - 1; }
+  void end(size_t id) { if (id == (size_t)-1) return; HIP_CHECK(hipEventRecord(open[id].b, gpu().stream)); }
+  void collect() { if (open.empty()) return; HIP_CHECK(hipStreamSynchronize(gpu().stream));
+    for (Span &s : open) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { auto &e = acc[s.name]; e.first += ms; e.second++; } pool.push_back(s.a); pool.push_back(s.b); } open.clear(); }
+};
+static StageTimer g_timer;
+struct Stage { size_t id; explicit Stage(const char *n) : id(g_timer.begin(n)) {} ~Stage() { g_timer.end(id); } };
+void profile_enable(bool on) { g_timer.collect(); g_timer.enabled = on; g_timer.acc.clear(); }
+std::string profile_report() { g_timer.collect(); std::string o = "{"; bool first = true;
+  for (auto &kv : g_timer.acc) { char buf[256]; snprintf(buf, sizeof buf, "%s\"%s\": {\"ms_total\": %.6f, \"count\": %ld}", first ? "" : ", ", kv.first.c_str(), kv.second.first, kv.second.second); o += buf; first = false; } return o + "}"; }
 
 template <class T> DevBuf<T>::DevBuf(size_t n) : n_(n) { gpu(); if (n) HIP_CHECK(hipMalloc((void **)&p_, n * sizeof(T))); }
 template <class T> DevBuf<T>::~DevBuf() { if (p_) hipFree(p_); }
@@ -55,7 +72,7 @@ struct Scanner {
 // ======================================================================================================================
 template <class F, class RawAffine>
 struct MsmImpl {
-  size_t n; int c, W; uint32_t NB; bool filter_ones; uint32_t seg, n_ones_threads;
+  size_t n; int c, W; uint32_t NB; bool filter_ones; uint32_t seg, n_ones_threads; std::string label = "msm";
   DevBuf<RawAffine> points; DevBuf<uint8_t> inf; bool any_inf = false;
   DevBuf<uint32_t> hist, offsets, fill, entries, ones; DevBuf<uint8_t> counters; Scanner scanner;
   DevBuf<uint8_t> buckets, seg_out, ones_partial, ones_l2, result;   // XYZZ<F> arrays, kept as bytes to stay out of the header
@@ -86,12 +103,15 @@ struct MsmImpl {
     hipStream_t s = gpu().stream; size_t nbk = (size_t)W * NB; const uint8_t *infp = any_inf ? inf.get() : nullptr; MsmCounters *cnt = (MsmCounters *)counters.get();
     hist.zero(); fill.zero(); counters.zero();
     if (n) {
+      Stage st((label + ".sort").c_str());
       hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist.get(), ones.get(), cnt);
       scanner.run(hist.get(), offsets.get(), nbk);
       hipLaunchKernelGGL(k_msm_scatter<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, offsets.get(), fill.get(), entries.get());
     }
     size_t avg = n / NB;   // expected entries per bucket for full-width scalars
-    if (avg >= 256) launch_accumulate<16>(s); else if (avg >= 64) launch_accumulate<8>(s); else if (avg >= 24) launch_accumulate<4>(s); else if (avg >= 8) launch_accumulate<2>(s); else launch_accumulate<1>(s);
+    { Stage st((label + ".accumulate").c_str());
+    if (avg >= 256) launch_accumulate<16>(s); else if (avg >= 64) launch_accumulate<8>(s); else if (avg >= 24) launch_accumulate<4>(s); else if (avg >= 8) launch_accumulate<2>(s); else launch_accumulate<1>(s); }
+    Stage st_red((label + ".reduce").c_str());
     uint32_t nseg = (uint32_t)(W * (NB / seg));
     hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3(cdiv(nseg, 64)), dim3(64), 0, s, (const XYZZ<F> *)buckets.get(), NB, seg, nseg, (XYZZ<F> *)seg_out.get());
     hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W), dim3(64), 0, s, (const XYZZ<F> *)seg_out.get(), NB / seg, (XYZZ<F> *)result.get());
@@ -124,6 +144,8 @@ struct MsmG2::Impl : MsmImpl<Fq2, G2AffineRaw> { using MsmImpl::MsmImpl; };
 MsmG1::MsmG1(const G1AffineRaw *p, size_t n, int c, bool fo) : impl(new Impl(p, n, c, fo)) {}
 MsmG1::~MsmG1() = default;
 void MsmG1::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
+void MsmG1::set_label(const char *l) { impl->label = l; }
+void MsmG2::set_label(const char *l) { impl->label = l; }
 host::HG1 MsmG1::result() { gpu_sync(); return combine<host::HFq, Fq>(impl->h_result, impl->W, impl->c); }
 size_t MsmG1::size() const { return impl->n; }
 const G1AffineRaw *MsmG1::points_dev() const { return impl->points.get(); }
@@ -232,7 +254,7 @@ bool Domain::is_step() const { return impl->step; }
 static void mul_table(Fe32 *a, const Fe32 *t, size_t n, int batch, size_t stride) { hipLaunchKernelGGL(k_fr_mul_table, dim3(cdiv(n, 256), batch), dim3(256), 0, gpu().stream, (Fr *)a, (const Fr *)t, (uint32_t)n, stride); }
 
 void Domain::fft(Fe32 *data, int batch, size_t stride) {
-  Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
+  Stage st("ntt.forward"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
   if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->tw.get(), d.big->logn, nullptr, batch, stride, d.scratch_stride); return; }
   hipStream_t s = gpu().stream;
   for (int b = 0; b < batch; b++) {   // scratch layout per vector: [c (B) | e (S)] in slot 0, d (B) in slot 1, bitrev scratch in slot 2
@@ -244,7 +266,7 @@ void Domain::fft(Fe32 *data, int batch, size_t stride) {
   }
 }
 void Domain::ifft(Fe32 *data, int batch, size_t stride) {
-  Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
+  Stage st("ntt.inverse"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
   if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, nullptr, batch, stride, d.scratch_stride); mul_table(data, d.scale_big.get(), d.m, batch, stride); return; }
   hipStream_t s = gpu().stream;
   for (int b = 0; b < batch; b++) {
@@ -259,7 +281,7 @@ void Domain::ifft(Fe32 *data, int batch, size_t stride) {
 void Domain::coset_fft(Fe32 *data, int batch, size_t stride) { mul_table(data, impl->coset_fwd.get(), impl->m, batch, stride); fft(data, batch, stride); }
 void Domain::icoset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl;
-  if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, nullptr, batch, stride, d.scratch_stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride); return; }   // coset_inv carries 1/m
+  if (!d.step) { Stage st("ntt.inverse"); radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, nullptr, batch, stride, d.scratch_stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride); return; }   // coset_inv carries 1/m
   ifft(data, batch, stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride);
 }
 void Domain::qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c) {
@@ -302,7 +324,7 @@ R1csDev::R1csDev(const R1csHost &h) : impl(new Impl) {
 }
 R1csDev::~R1csDev() = default;
 void R1csDev::eval(const Fe32 *z, Fe32 *abc, size_t m) {
-  Impl &d = *impl; hipStream_t s = gpu().stream; if (m < d.n_cons + d.n_inputs + 1) throw GpuError("r1cs: domain too small");
+  Stage st("r1cs.rows"); Impl &d = *impl; hipStream_t s = gpu().stream; if (m < d.n_cons + d.n_inputs + 1) throw GpuError("r1cs: domain too small");
   HIP_CHECK(hipMemsetAsync(abc, 0, 3 * m * sizeof(Fe32), s));
   for (int mm = 0; mm < 3; mm++) if (d.n_cons) hipLaunchKernelGGL(k_r1cs_rows, dim3(cdiv(d.n_cons, 256)), dim3(256), 0, s, d.rowptr[mm].get(), d.col[mm].get(), d.cid[mm].get(), (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)d.n_cons, (Fr *)(abc + mm * m));
   HIP_CHECK(hipMemcpyAsync(abc + d.n_cons, z, (d.n_inputs + 1) * sizeof(Fe32), hipMemcpyDeviceToDevice, s));   // input-consistency rows (r1cs_to_qap.tcc:227-230)

@@ -42,7 +42,7 @@ class MsmG1 {
   // Enqueues the kernels; result() synchronises and finishes the combine on the host.
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
   host::HG1 result();
-  size_t size() const; const G1AffineRaw *points_dev() const;
+  size_t size() const; const G1AffineRaw *points_dev() const; void set_label(const char *l);
   struct Impl; std::unique_ptr<Impl> impl;
 };
 class MsmG2 {
@@ -50,7 +50,7 @@ class MsmG2 {
   MsmG2(const G2AffineRaw *host_points, size_t n, int window_bits, bool filter_ones);
   ~MsmG2();
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
-  host::HG2 result();
+  host::HG2 result(); void set_label(const char *l);
   struct Impl; std::unique_ptr<Impl> impl;
 };
 
@@ -91,5 +91,7 @@ void decompress_g2(const Fe32 *xs /* 2 per point */, const uint8_t *flags, size_
 void fixed_base_mul_g1(const host::HG1 &base, const Fe32 *scalars, size_t n, G1AffineRaw *out);
 void fixed_base_mul_g2(const host::HG2 &base, const Fe32 *scalars, size_t n, G2AffineRaw *out);
 void gpu_sync();
+// per-stage device timing (HIP events on the compute stream); report = JSON object {stage: {ms_total, count}}
+void profile_enable(bool on); std::string profile_report();
 
 }  // namespace zk

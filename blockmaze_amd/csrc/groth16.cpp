@@ -194,6 +194,7 @@ Prover::Prover(const ProvingKeyHost &pk) : impl(new Impl) {
   int cw = env_int("ZK_MSM_WITNESS_WINDOW", 8), ch = env_int("ZK_MSM_H_WINDOW", 13);
   p.A.reset(new MsmG1(pk.A.data(), pk.A.size(), cw, true)); p.L.reset(new MsmG1(pk.L.data(), pk.L.size(), cw, true));
   p.B1.reset(new MsmG1(pk.B_g1.data(), pk.B_g1.size(), cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data(), pk.B_g2.size(), cw, true)); p.H.reset(new MsmG1(pk.H.data(), pk.H.size(), ch, false));
+  p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
   p.B_idx = DevBuf<uint32_t>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx.upload(pk.B_idx.data(), pk.B_idx.size());
   p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host.resize(p.nv + 1);
 }

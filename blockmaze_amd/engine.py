@@ -131,6 +131,11 @@ class Prover:
         try: self.close()
         except Exception: pass
 
+def profile_enable(on=True): _check(lib().zkgpu_profile_enable(int(on)))
+def profile_report():
+    import json
+    buf = ctypes.create_string_buffer(1 << 16); _check(lib().zkgpu_profile_report(buf, ctypes.c_size_t(len(buf)))); return json.loads(buf.value.decode())
+
 def verify(vk_path, proof_hex, inputs):
     """inputs: list of ints (packed public input).  True / False."""
     buf = b"".join(int(x).to_bytes(32, "little") for x in inputs)

@@ -91,6 +91,9 @@ int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]);          /* n_vars, n_inp
 /* z: n_vars elements; r, s: 32-byte canonical prover randomness or NULL for fresh values.  proof_hex: 512 hex characters + NUL. */
 int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]);
 int zkgpu_prover_timings(zkgpu_prover *h, double out[5]);       /* ms of the last prove(): upload+rows, (unused), device kernels, host finish, total */
+/* per-stage device timing with HIP events on the compute stream (for the benchmark's roofline leg).  report: JSON {"stage": {"ms_total": x, "count": n}, ...} */
+int zkgpu_profile_enable(int on);
+int zkgpu_profile_report(char *buf, size_t cap);
 /* 1 = accept, 0 = reject, negative = error.  inputs: n_inputs canonical field elements (the packed public input) */
 int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs);
 
