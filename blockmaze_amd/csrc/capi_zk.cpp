@@ -7,6 +7,7 @@
 //     and kept resident in HBM, re-read only when the file's size or mtime changes;
 //   * no exception, abort or signal handler ever crosses this boundary; calls may arrive concurrently on any thread.
 #include <sys/stat.h>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -68,10 +69,10 @@ template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
     if (!gpu_available()) { zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback"); fprintf(stderr, "libzkgpu: no HIP device visible, cannot generate %s proof\n", circuit_name(k)); return dup_string(proof_to_hex(default_proof())); }
     std::lock_guard<std::mutex> lk(g_gpu_mutex);
     ProverSlot &slot = prover_for(k); assign(*slot.circuit);
-    std::vector<Fe32> z; slot.circuit->export_assignment(z);
     printf("Trying to generate %s proof...\n", circuit_name(k)); fflush(stdout);
     Fe32 r, s; bool fixed = parse_fixed_rs(r, s); Proof proof;
-    if (!slot.prover->prove(z.data(), fixed ? &r : nullptr, fixed ? &s : nullptr, proof)) { printf("can not generate %s proof\n", circuit_name(k)); fflush(stdout); proof = default_proof(); }
+    slot.prover->set_witness(reinterpret_cast<const Fe32 *>(slot.circuit->board.val.data() + 1), true);   // the board holds Montgomery values: no conversion on either side
+    if (!slot.prover->prove_resident(fixed ? &r : nullptr, fixed ? &s : nullptr, proof)) { printf("can not generate %s proof\n", circuit_name(k)); fflush(stdout); proof = default_proof(); }
     return dup_string(proof_to_hex(proof));
   } catch (const std::exception &e) { zkgpu_set_error(e.what()); fprintf(stderr, "libzkgpu: %s\n", e.what()); return dup_string(proof_to_hex(default_proof())); }
   catch (...) { zkgpu_set_error("unknown error"); return dup_string(proof_to_hex(default_proof())); }
@@ -158,6 +159,9 @@ int zkgpu_witness_mint_redeem(int redeem, uint64_t value, uint64_t value_old, ch
     auto c = redeem ? make_redeem_circuit(false) : make_mint_circuit(false); if (redeem) { RedeemInputs ri{in.value, in.value_old, in.value_s, in.sn_old, in.r_old, in.sn, in.r, in.cmtA_old, in.cmtA, in.sk}; assign_redeem(*c, ri); } else assign_mint(*c, in);
     std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
 
+int zkgpu_debug_time_send_witness(double out[3]) { return guarded_host([&] { auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  SendInputs in{}; in.value_old = 22; in.value_s = 8; in.value = 14; double t0 = now(); auto c = make_send_circuit(false); double t1 = now(); assign_send(*c, in); double t2 = now(); std::vector<Fe32> z; c->export_assignment(z); double t3 = now();
+  assign_send(*c, in); double t4 = now(); out[0] = t1 - t0; out[1] = t4 - t3; out[2] = t3 - t2; return ZKGPU_OK; }); }
 int zkgpu_keygen_from_r1cs(const char *r1cs_path, uint64_t seed, const char *pk_path, const char *vk_path) { return guarded([&] { R1csHost cs = read_r1cs_file(r1cs_path); ProvingKeyHost pk; VerifyingKeyHost vk;
   generate_keys(cs, seed ? ToxicWaste::from_seed(seed) : ToxicWaste::random(), pk, vk); save_proving_key(pk_path, pk); save_verifying_key(vk_path, vk); return ZKGPU_OK; }); }
 int zkgpu_keygen(int kind, int tree_depth, uint64_t seed, const char *pk_path, const char *vk_path) { return guarded([&] { std::unique_ptr<Circuit> c = kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true);
@@ -168,6 +172,9 @@ void zkgpu_prover_destroy(zkgpu_prover *h) { guarded([&] { delete h; return ZKGP
 int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]) { if (!h) return ZKGPU_ERR_ARG; out[0] = h->p->num_variables(); out[1] = h->p->num_inputs(); out[2] = h->p->domain_size(); return ZKGPU_OK; }
 int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded([&] { if (!h) return ZKGPU_ERR_ARG; Proof p;
   if (!h->p->prove((const Fe32 *)z, (const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
+int zkgpu_prover_set_witness(zkgpu_prover *h, const uint8_t *z) { return guarded([&] { if (!h) return ZKGPU_ERR_ARG; h->p->set_witness((const Fe32 *)z, false); gpu_sync(); return ZKGPU_OK; }); }
+int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded([&] { if (!h) return ZKGPU_ERR_ARG; Proof p;
+  if (!h->p->prove_resident((const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
 int zkgpu_prover_timings(zkgpu_prover *h, double out[5]) { if (!h) return ZKGPU_ERR_ARG; out[0] = h->p->last.upload_ms; out[1] = h->p->last.qap_ms; out[2] = h->p->last.msm_ms; out[3] = h->p->last.finish_ms; out[4] = h->p->last.total_ms; return ZKGPU_OK; }
 int zkgpu_profile_enable(int on) { return guarded([&] { profile_enable(on != 0); return ZKGPU_OK; }); }
 int zkgpu_profile_report(char *buf, size_t cap) { return guarded([&] { std::string r = profile_report(); if (r.size() + 1 > cap) return ZKGPU_ERR_ARG; memcpy(buf, r.c_str(), r.size() + 1); return ZKGPU_OK; }); }

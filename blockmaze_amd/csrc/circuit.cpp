@@ -15,7 +15,9 @@ void Board::push(int m, const LC &lc) {
 }
 void Board::constraint(const LC &a, const LC &b, const LC &c) { if (!emit) return; push(0, a); push(1, b); push(2, c); }
 
-HFr pack_bits_value(const Board &b, const LCArray &bits) { HFr r = HFr::zero(); for (size_t i = bits.size(); i-- > 0;) { r = r.dbl(); r = r + b.eval(bits[i]); } return r; }
+HFr pack_bits_value(const Board &b, const LCArray &bits) {   // the operands are bits: assemble the integer natively, one conversion to Montgomery form at the end
+  if (bits.size() <= 253) { HFr c = HFr::zero(); for (size_t i = 0; i < bits.size(); i++) if (b.eval_bit(bits[i])) c.l[i / 64] |= 1ull << (i % 64); return c.to_mont(); }
+  HFr r = HFr::zero(); for (size_t i = bits.size(); i-- > 0;) { r = r.dbl(); r = r + b.eval(bits[i]); } return r; }
 LC packing_sum(const LCArray &bits) { LC r; HFr two_i = HFr::one(); for (const LC &x : bits) { r.add(x.scaled(two_i)); two_i = two_i.dbl(); } return r; }
 void fill_bits_of_value(Board &b, const VarArray &bits, const HFr &value) { HFr c = value.from_mont(); for (size_t i = 0; i < bits.size(); i++) b.set_bit(bits[i], i < 256 && ((c.l[i / 64] >> (i % 64)) & 1)); }
 void boolean_constraint(Board &b, const LC &x) { b.constraint(x, LC::constant(HFr::one()) - x, LC()); }
@@ -42,27 +44,34 @@ struct LastBits {     // X has X_bits bits; result = the low |result_bits| of th
     for (size_t i = result_bits.size(); i < X_bits; i++) full_bits.push_back(b.alloc()); }
   void constraints() { Packing(b, to_lcs(full_bits), X).constraints(true); Packing(b, to_lcs(result_bits), result).constraints(false); }
   void witness() { fill_bits_of_value(b, full_bits, b.val[X]); b.val[result] = pack_bits_value(b, to_lcs(result_bits)); }
+  // native form: X is known as an integer (< 2^36)
+  uint32_t witness_native(uint64_t x) { b.val[X] = HFr::from_u64(x); for (size_t i = 0; i < full_bits.size(); i++) b.set_bit(full_bits[i], (x >> i) & 1); uint32_t r = (uint32_t)x; b.val[result] = HFr::from_u64(r); return r; }
 };
+inline uint32_t rotr32(uint32_t x, unsigned n) { return (x >> n) | (x << (32 - n)); }
 struct Xor3 {
   Board &b; LC A, B, C; bool c_zero; Var out, tmp = 0;
   Xor3(Board &b, const LC &A, const LC &B, const LC &C, bool c_zero, Var out) : b(b), A(A), B(B), C(C), c_zero(c_zero), out(out) { if (!c_zero) tmp = b.alloc(); }
   void constraints() {
     if (c_zero) b.constraint(A.scaled(TWO), B, A + B - LC(out));
     else { b.constraint(A.scaled(TWO), B, A + B - LC(tmp)); b.constraint(LC(tmp).scaled(TWO), C, LC(tmp) + C - LC(out)); } }
-  void witness() { bool a = !b.eval(A).is_zero(), bb = !b.eval(B).is_zero();
-    if (c_zero) b.set_bit(out, a ^ bb); else { bool t = a ^ bb, c = !b.eval(C).is_zero(); b.set_bit(tmp, t); b.set_bit(out, t ^ c); } }
+  void witness() { bool a = b.eval_bit(A), bb = b.eval_bit(B);
+    if (c_zero) b.set_bit(out, a ^ bb); else { bool t = a ^ bb, c = b.eval_bit(C); b.set_bit(tmp, t); b.set_bit(out, t ^ c); } }
 };
 inline const LC &rotr(const LCArray &A, size_t i, size_t k) { return A[(i + k) % 32]; }
 struct SmallSigma {
-  Board &b; Var result; VarArray result_bits; std::vector<Xor3> x;
-  SmallSigma(Board &b, const LCArray &W, Var result, size_t rot1, size_t rot2, size_t shift) : b(b), result(result), result_bits(b.alloc_array(32)) {
+  Board &b; Var result; VarArray result_bits; std::vector<Xor3> x; unsigned r1, r2, sh;
+  uint32_t witness_native(uint32_t w) { uint32_t t = rotr32(w, r1) ^ rotr32(w, r2), res = t ^ (w >> sh);
+    for (size_t k = 0; k < 32; k++) { if (!x[k].c_zero) b.set_bit(x[k].tmp, (t >> k) & 1); b.set_bit(result_bits[k], (res >> k) & 1); } b.val[result] = HFr::from_u64(res); return res; }
+  SmallSigma(Board &b, const LCArray &W, Var result, size_t rot1, size_t rot2, size_t shift) : b(b), result(result), result_bits(b.alloc_array(32)), r1((unsigned)rot1), r2((unsigned)rot2), sh((unsigned)shift) {
     for (size_t i = 0; i < 32; i++) x.emplace_back(b, rotr(W, i, rot1), rotr(W, i, rot2), (i + shift < 32 ? W[i + shift] : ONE_LC), i + shift >= 32, result_bits[i]); }
   void constraints() { for (auto &g : x) g.constraints(); Packing(b, to_lcs(result_bits), result).constraints(false); }
   void witness() { for (auto &g : x) g.witness(); b.val[result] = pack_bits_value(b, to_lcs(result_bits)); }
 };
 struct BigSigma {
-  Board &b; Var result; VarArray result_bits; std::vector<Xor3> x;
-  BigSigma(Board &b, const LCArray &W, Var result, size_t r1, size_t r2, size_t r3) : b(b), result(result), result_bits(b.alloc_array(32)) {
+  Board &b; Var result; VarArray result_bits; std::vector<Xor3> x; unsigned q1, q2, q3;
+  uint32_t witness_native(uint32_t w) { uint32_t t = rotr32(w, q1) ^ rotr32(w, q2), res = t ^ rotr32(w, q3);
+    for (size_t k = 0; k < 32; k++) { b.set_bit(x[k].tmp, (t >> k) & 1); b.set_bit(result_bits[k], (res >> k) & 1); } b.val[result] = HFr::from_u64(res); return res; }
+  BigSigma(Board &b, const LCArray &W, Var result, size_t r1, size_t r2, size_t r3) : b(b), result(result), result_bits(b.alloc_array(32)), q1((unsigned)r1), q2((unsigned)r2), q3((unsigned)r3) {
     for (size_t i = 0; i < 32; i++) x.emplace_back(b, rotr(W, i, r1), rotr(W, i, r2), rotr(W, i, r3), false, result_bits[i]); }
   void constraints() { for (auto &g : x) g.constraints(); Packing(b, to_lcs(result_bits), result).constraints(false); }
   void witness() { for (auto &g : x) g.witness(); b.val[result] = pack_bits_value(b, to_lcs(result_bits)); }
@@ -71,14 +80,16 @@ struct Choice {
   Board &b; LCArray X, Y, Z; Var result; VarArray result_bits;
   Choice(Board &b, const LCArray &X, const LCArray &Y, const LCArray &Z, Var result) : b(b), X(X), Y(Y), Z(Z), result(result), result_bits(b.alloc_array(32)) {}
   void constraints() { for (size_t i = 0; i < 32; i++) b.constraint(X[i], Y[i] - Z[i], LC(result_bits[i]) - Z[i]); Packing(b, to_lcs(result_bits), result).constraints(false); }
-  void witness() { for (size_t i = 0; i < 32; i++) { bool x = !b.eval(X[i]).is_zero(); b.set_bit(result_bits[i], x ? !b.eval(Y[i]).is_zero() : !b.eval(Z[i]).is_zero()); } b.val[result] = pack_bits_value(b, to_lcs(result_bits)); }
+  void witness() { for (size_t i = 0; i < 32; i++) { bool x = b.eval_bit(X[i]); b.set_bit(result_bits[i], x ? b.eval_bit(Y[i]) : b.eval_bit(Z[i])); } b.val[result] = pack_bits_value(b, to_lcs(result_bits)); }
+  uint32_t witness_native(uint32_t e, uint32_t f, uint32_t g) { uint32_t res = (e & f) ^ (~e & g); for (size_t k = 0; k < 32; k++) b.set_bit(result_bits[k], (res >> k) & 1); b.val[result] = HFr::from_u64(res); return res; }
 };
 struct Majority {
   Board &b; LCArray X, Y, Z; Var result; VarArray result_bits;
   Majority(Board &b, const LCArray &X, const LCArray &Y, const LCArray &Z, Var result) : b(b), X(X), Y(Y), Z(Z), result(result), result_bits(b.alloc_array(32)) {}
   void constraints() { for (size_t i = 0; i < 32; i++) { boolean_constraint(b, LC(result_bits[i])); LC s = X[i] + Y[i] + Z[i] - LC(result_bits[i]).scaled(TWO); b.constraint(s, ONE_LC - s, LC()); }
     Packing(b, to_lcs(result_bits), result).constraints(false); }
-  void witness() { for (size_t i = 0; i < 32; i++) { int v = (int)!b.eval(X[i]).is_zero() + (int)!b.eval(Y[i]).is_zero() + (int)!b.eval(Z[i]).is_zero(); b.set_bit(result_bits[i], v >= 2); } b.val[result] = pack_bits_value(b, to_lcs(result_bits)); }
+  void witness() { for (size_t i = 0; i < 32; i++) { int v = (int)b.eval_bit(X[i]) + (int)b.eval_bit(Y[i]) + (int)b.eval_bit(Z[i]); b.set_bit(result_bits[i], v >= 2); } b.val[result] = pack_bits_value(b, to_lcs(result_bits)); }
+  uint32_t witness_native(uint32_t x, uint32_t y, uint32_t z) { uint32_t res = (x & y) ^ (x & z) ^ (y & z); for (size_t k = 0; k < 32; k++) b.set_bit(result_bits[k], (res >> k) & 1); b.val[result] = HFr::from_u64(res); return res; }
 };
 
 // ---- sha256_components.tcc ---------------------------------------------------------------------------------------------
@@ -93,6 +104,9 @@ struct MessageSchedule {
   void constraints() { for (size_t i = 0; i < 16; i++) Packing(b, to_lcs(W_bits[i]), packed_W[i]).constraints(false);
     for (size_t i = 16; i < 64; i++) { cs0[i - 16].constraints(); cs1[i - 16].constraints();
       b.constraint(ONE_LC, LC(sigma0[i]) + LC(sigma1[i]) + LC(packed_W[i - 16]) + LC(packed_W[i - 7]), LC(unreduced_W[i])); red[i - 16].constraints(); } }
+  void witness_native(uint32_t W[64]) {   // W[0..15] given; the message bits themselves are inputs of the gadget and already assigned
+    for (size_t i = 0; i < 16; i++) b.val[packed_W[i]] = HFr::from_u64(W[i]);
+    for (size_t i = 16; i < 64; i++) { uint32_t s0 = cs0[i - 16].witness_native(W[i - 15]), s1 = cs1[i - 16].witness_native(W[i - 2]); W[i] = red[i - 16].witness_native((uint64_t)s0 + s1 + W[i - 16] + W[i - 7]); } }
   void witness() { for (size_t i = 0; i < 16; i++) b.val[packed_W[i]] = pack_bits_value(b, to_lcs(W_bits[i]));
     for (size_t i = 16; i < 64; i++) { cs0[i - 16].witness(); cs1[i - 16].witness(); b.val[unreduced_W[i]] = b.val[sigma0[i]] + b.val[sigma1[i]] + b.val[packed_W[i - 16]] + b.val[packed_W[i - 7]]; red[i - 16].witness(); } }
 };
@@ -112,6 +126,10 @@ struct RoundFunction {
     b.constraint(ONE_LC, LC(packed_h) + LC(sigma1) + LC(choice) + k + LC(W) + LC(sigma0) + LC(majority), LC(unreduced_new_a));
     b.constraint(ONE_LC, LC(packed_d) + LC(packed_h) + LC(sigma1) + LC(choice) + k + LC(W), LC(unreduced_new_e));
     ra->constraints(); re->constraints(); }
+  void witness_native(uint32_t wa, uint32_t wb, uint32_t wc, uint32_t wd, uint32_t we, uint32_t wf, uint32_t wg, uint32_t wh, uint32_t Wi, uint32_t &na, uint32_t &ne) {
+    uint32_t S0 = s0->witness_native(wa), S1 = s1->witness_native(we), chv = ch->witness_native(we, wf, wg), mjv = mj->witness_native(wa, wb, wc);
+    b.val[packed_d] = HFr::from_u64(wd); b.val[packed_h] = HFr::from_u64(wh);
+    na = ra->witness_native((uint64_t)wh + S1 + chv + K + Wi + S0 + mjv); ne = re->witness_native((uint64_t)wd + wh + S1 + chv + K + Wi); }
   void witness() { s0->witness(); s1->witness(); ch->witness(); mj->witness(); b.val[packed_d] = pack_bits_value(b, d); b.val[packed_h] = pack_bits_value(b, h); HFr k = HFr::from_u64(K);
     b.val[unreduced_new_a] = b.val[packed_h] + b.val[sigma1] + b.val[choice] + k + b.val[W] + b.val[sigma0] + b.val[majority];
     b.val[unreduced_new_e] = b.val[packed_d] + b.val[packed_h] + b.val[sigma1] + b.val[choice] + k + b.val[W]; ra->witness(); re->witness(); }
@@ -120,8 +138,8 @@ struct RoundFunction {
 
 // ---- sha256_gadget.tcc:20-140 -----------------------------------------------------------------------------------------
 struct Sha256Compression::Impl {
-  Board &b; VarArray packed_W; std::unique_ptr<MessageSchedule> ms; std::vector<std::unique_ptr<RoundFunction>> rounds; VarArray unreduced_output, reduced_output; std::vector<LastBits> reduce;
-  Impl(Board &b, const LCArray &prev, const VarArray &block, const VarArray &output) : b(b) {
+  Board &b; LCArray prev; VarArray block; VarArray packed_W; std::unique_ptr<MessageSchedule> ms; std::vector<std::unique_ptr<RoundFunction>> rounds; VarArray unreduced_output, reduced_output; std::vector<LastBits> reduce;
+  Impl(Board &b, const LCArray &prev, const VarArray &block, const VarArray &output) : b(b), prev(prev), block(block) {
     packed_W = b.alloc_array(64); ms.reset(new MessageSchedule(b, block, packed_W));
     auto word = [&](int w) { LCArray r(32); for (int k = 0; k < 32; k++) r[k] = prev[32 * w + 31 - k]; return r; };   // word w, little-endian bits
     std::vector<LCArray> ra{word(0)}, rb{word(1)}, rc{word(2)}, rd{word(3)}, re{word(4)}, rf{word(5)}, rg{word(6)}, rh{word(7)};
@@ -139,7 +157,17 @@ void Sha256Compression::constraints() { Impl &s = *impl; s.ms->constraints(); fo
   for (size_t i = 0; i < 4; i++) { s.b.constraint(ONE_LC, LC(s.rounds[3 - i]->packed_d) + LC(s.rounds[63 - i]->packed_new_a), LC(s.unreduced_output[i]));
                                    s.b.constraint(ONE_LC, LC(s.rounds[3 - i]->packed_h) + LC(s.rounds[63 - i]->packed_new_e), LC(s.unreduced_output[4 + i])); }
   for (auto &r : s.reduce) r.constraints(); }
-void Sha256Compression::witness() { Impl &s = *impl; s.ms->witness(); for (auto &r : s.rounds) r->witness();
+void Sha256Compression::witness() {   // native SHA-256 arithmetic; every variable gets exactly the value the gadget-by-gadget evaluation (witness_reference) assigns
+  Impl &s = *impl; Board &b = s.b; uint32_t W[64], st[8];
+  for (int i = 0; i < 16; i++) { uint32_t w = 0; for (int k = 0; k < 32; k++) w |= (uint32_t)b.bit(s.block[32 * i + 31 - k]) << k; W[i] = w; }
+  for (int i = 0; i < 8; i++) { uint32_t w = 0; for (int k = 0; k < 32; k++) w |= (uint32_t)b.eval_bit(s.prev[32 * i + 31 - k]) << k; st[i] = w; }
+  s.ms->witness_native(W);
+  uint32_t a = st[0], bb = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7], hist_d[64], hist_h[64], hist_na[64], hist_ne[64];
+  for (int i = 0; i < 64; i++) { uint32_t na, ne; hist_d[i] = d; hist_h[i] = h; s.rounds[i]->witness_native(a, bb, c, d, e, f, g, h, W[i], na, ne); hist_na[i] = na; hist_ne[i] = ne; h = g; g = f; f = e; e = ne; d = c; c = bb; bb = a; a = na; }
+  for (int i = 0; i < 4; i++) { s.reduce[i].witness_native((uint64_t)hist_d[3 - i] + hist_na[63 - i]); s.reduce[4 + i].witness_native((uint64_t)hist_h[3 - i] + hist_ne[63 - i]); }
+  for (int i = 0; i < 8; i++) b.val[s.unreduced_output[i]] = b.val[s.reduce[i].X];
+}
+void Sha256Compression::witness_reference() { Impl &s = *impl; s.ms->witness(); for (auto &r : s.rounds) r->witness();
   for (size_t i = 0; i < 4; i++) { s.b.val[s.unreduced_output[i]] = s.b.val[s.rounds[3 - i]->packed_d] + s.b.val[s.rounds[63 - i]->packed_new_a];
                                    s.b.val[s.unreduced_output[4 + i]] = s.b.val[s.rounds[3 - i]->packed_h] + s.b.val[s.rounds[63 - i]->packed_new_e]; }
   for (auto &r : s.reduce) r.witness(); }

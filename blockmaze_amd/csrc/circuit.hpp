@@ -31,17 +31,17 @@ using host::HFr;
 typedef uint32_t Var;                 // 0 is the constant ONE
 typedef std::vector<Var> VarArray;
 
-struct Term { Var v; HFr c; };
+struct Term { Var v; HFr c; bool one; };   // one: c == 1 (evaluation skips the multiply)
 struct LC {
   std::vector<Term> t;
   LC() {}
-  LC(Var v) { t.push_back({v, HFr::one()}); }
-  static LC constant(const HFr &c) { LC r; r.t.push_back({0, c}); return r; }
+  LC(Var v) { t.push_back({v, HFr::one(), true}); }
+  static LC constant(const HFr &c) { LC r; r.t.push_back({0, c, c == HFr::one()}); return r; }
   static LC constant_u64(uint64_t c) { return constant(HFr::from_u64(c)); }
   LC &add(const LC &o) { t.insert(t.end(), o.t.begin(), o.t.end()); return *this; }
-  LC &sub(const LC &o) { for (const Term &x : o.t) t.push_back({x.v, x.c.neg()}); return *this; }
-  LC &add_term(Var v, const HFr &c) { t.push_back({v, c}); return *this; }
-  LC scaled(const HFr &k) const { LC r; for (const Term &x : t) r.t.push_back({x.v, x.c * k}); return r; }
+  LC &sub(const LC &o) { for (const Term &x : o.t) t.push_back({x.v, x.c.neg(), false}); return *this; }
+  LC &add_term(Var v, const HFr &c) { t.push_back({v, c, c == HFr::one()}); return *this; }
+  LC scaled(const HFr &k) const { LC r; for (const Term &x : t) { HFr c = x.c * k; r.t.push_back({x.v, c, c == HFr::one()}); } return r; }
   friend LC operator+(LC a, const LC &b) { a.add(b); return a; }
   friend LC operator-(LC a, const LC &b) { a.sub(b); return a; }
 };
@@ -59,7 +59,8 @@ class Board {
   void set_input_sizes(size_t n) { cs.n_inputs = n; }
   size_t num_variables() const { return val.size() - 1; }
   void constraint(const LC &a, const LC &b, const LC &c);
-  HFr eval(const LC &lc) const { HFr s = HFr::zero(); for (const Term &x : lc.t) s = s + x.c * val[x.v]; return s; }
+  HFr eval(const LC &lc) const { if (lc.t.size() == 1 && lc.t[0].one) return val[lc.t[0].v]; HFr s = HFr::zero(); for (const Term &x : lc.t) s = s + (x.one ? val[x.v] : x.c * val[x.v]); return s; }
+  bool eval_bit(const LC &lc) const { if (lc.t.size() == 1 && lc.t[0].one) return !val[lc.t[0].v].is_zero(); if (lc.t.empty()) return false; return !eval(lc).is_zero(); }
   void set_bit(Var v, bool b) { if (v) val[v] = b ? HFr::one() : HFr::zero(); }   // writes to ONE are dropped (see LessCmp)
   bool bit(Var v) const { return !val[v].is_zero(); }
   void finish() { cs.n_vars = num_variables(); cs.n_cons = cs.rowptr[0].size() - 1; }
@@ -89,6 +90,7 @@ struct Sha256Compression {
   // prev_output: 256 LCs (MSB-first words), block: 512 variables, output: 256 variables
   Sha256Compression(Board &b, const LCArray &prev_output, const VarArray &block, const VarArray &output);
   void constraints(); void witness();
+  void witness_reference();   // gadget-by-gadget evaluation exactly as libsnark does it; kept as the cross-check of the native path
 };
 LCArray sha256_default_iv();          // sha256_components.tcc:38-56
 

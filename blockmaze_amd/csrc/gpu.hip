@@ -16,16 +16,18 @@ namespace zk {
 
 class GpuContext {
  public:
-  int device = 0; hipStream_t stream = nullptr; hipDeviceProp_t prop;
+  int device = 0; hipStream_t stream = nullptr; hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t fork_event = nullptr; hipDeviceProp_t prop;
   GpuContext() {
     int n = 0; if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
     const char *e = getenv("ZK_DEVICE"); if (!e) e = getenv("LOCAL_RANK"); device = e ? atoi(e) % n : 0;
     HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipGetDeviceProperties(&prop, device)); HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking)); HIP_CHECK(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming));
   }
 };
 GpuContext &gpu() { static GpuContext ctx; hipSetDevice(ctx.device); return ctx; }
 bool gpu_available() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0; }
-void gpu_sync() { HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
+void gpu_sync() { HIP_CHECK(hipStreamSynchronize(gpu().stream)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamSynchronize(gpu().aux[i])); }
+void gpu_fork_aux() { GpuContext &g = gpu(); HIP_CHECK(hipEventRecord(g.fork_event, g.stream)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(g.aux[i], g.fork_event, 0)); }
 hipStream_t gpu_stream() { return gpu().stream; }
 
 // ---- optional per-stage timing with HIP events on the compute stream (bench.py's roofline leg; off by default) ----------
@@ -33,13 +35,15 @@ struct StageTimer {
   struct Span { std::string name; hipEvent_t a, b; };
   bool enabled = false; std::vector<Span> open; std::vector<hipEvent_t> pool; std::map<std::string, std::pair<double, long>> acc;
   hipEvent_t get() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; } hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e; }
-  size_t begin(const char *name) { if (!enabled) return (size_t)-1; Span s{name, get(), get()}; HIP_CHECK(hipEventRecord(s.a, gpu().stream)); open.push_back(s); return open.size() - 1; }
-  void end(size_t id) { if (id == (size_t)-1) return; HIP_CHECK(hipEventRecord(open[id].b, gpu().stream)); }
-  void collect() { if (open.empty()) return; HIP_CHECK(hipStreamSynchronize(gpu().stream));
-    for (Span &s : open) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { auto &e = acc[s.name]; e.first += ms; e.second++; } pool.push_back(s.a); pool.push_back(s.b); } open.clear(); }
+  struct Open { hipStream_t st; };
+  std::vector<hipStream_t> open_streams;
+  size_t begin(const char *name, hipStream_t st) { if (!enabled) return (size_t)-1; Span s{name, get(), get()}; HIP_CHECK(hipEventRecord(s.a, st)); open.push_back(s); open_streams.push_back(st); return open.size() - 1; }
+  void end(size_t id) { if (id == (size_t)-1) return; HIP_CHECK(hipEventRecord(open[id].b, open_streams[id])); }
+  void collect() { if (open.empty()) return; HIP_CHECK(hipDeviceSynchronize());
+    for (Span &s : open) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { auto &e = acc[s.name]; e.first += ms; e.second++; } pool.push_back(s.a); pool.push_back(s.b); } open.clear(); open_streams.clear(); }
 };
 static StageTimer g_timer;
-struct Stage { size_t id; explicit Stage(const char *n) : id(g_timer.begin(n)) {} ~Stage() { g_timer.end(id); } };
+struct Stage { size_t id; explicit Stage(const char *n, hipStream_t st = nullptr) : id(g_timer.begin(n, st ? st : gpu().stream)) {} ~Stage() { g_timer.end(id); } };
 void profile_enable(bool on) { g_timer.collect(); g_timer.enabled = on; g_timer.acc.clear(); }
 std::string profile_report() { g_timer.collect(); std::string o = "{"; bool first = true;
   for (auto &kv : g_timer.acc) { char buf[256]; snprintf(buf, sizeof buf, "%s\"%s\": {\"ms_total\": %.6f, \"count\": %ld}", first ? "" : ", ", kv.first.c_str(), kv.second.first, kv.second.second); o += buf; first = false; } return o + "}"; }
@@ -53,14 +57,20 @@ template <class T> void DevBuf<T>::download(T *h, size_t n) const { HIP_CHECK(hi
 template <class T> void DevBuf<T>::zero() { if (n_) HIP_CHECK(hipMemsetAsync(p_, 0, n_ * sizeof(T), gpu().stream)); }
 template class DevBuf<uint8_t>; template class DevBuf<uint32_t>; template class DevBuf<Fe32>; template class DevBuf<G1AffineRaw>; template class DevBuf<G2AffineRaw>;
 
+template <class T> PinnedBuf<T>::PinnedBuf(size_t n) : n_(n) { gpu(); if (n) HIP_CHECK(hipHostMalloc((void **)&p_, n * sizeof(T))); }
+template <class T> PinnedBuf<T>::~PinnedBuf() { release(); }
+template <class T> void PinnedBuf<T>::release() { if (p_) hipHostFree(p_); p_ = nullptr; n_ = 0; }
+template class PinnedBuf<Fe32>;
+void upload_async(void *dev, const void *host, size_t bytes) { HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, gpu().stream)); }
+
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 // exclusive scan of a uint32 array on the stream
 struct Scanner {
   DevBuf<uint32_t> block_sums; size_t cap;
   explicit Scanner(size_t n) : block_sums(cdiv(n, SCAN_BLOCK * SCAN_ITEMS) + 1), cap(n) {}
-  void run(const uint32_t *in, uint32_t *out, size_t n) {
-    unsigned nb = cdiv(n, SCAN_BLOCK * SCAN_ITEMS); hipStream_t s = gpu().stream;
+  void run(const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
+    unsigned nb = cdiv(n, SCAN_BLOCK * SCAN_ITEMS);
     hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, out, block_sums.get(), (uint32_t)n);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, block_sums.get(), nb);
     hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_BLOCK), 0, s, out, block_sums.get(), (uint32_t)n);
@@ -72,51 +82,61 @@ struct Scanner {
 // ======================================================================================================================
 template <class F, class RawAffine>
 struct MsmImpl {
-  size_t n; int c, W; uint32_t NB; bool filter_ones; uint32_t seg, n_ones_threads; std::string label = "msm";
+  size_t n; int c, W; uint32_t NB; bool filter_ones; uint32_t seg, n_ones_threads; std::string label = "msm"; int stream_id = -1;   // -1: main stream, 0..3: auxiliary stream
   DevBuf<RawAffine> points; DevBuf<uint8_t> inf; bool any_inf = false;
-  DevBuf<uint32_t> hist, offsets, fill, entries, ones; DevBuf<uint8_t> counters; Scanner scanner;
-  DevBuf<uint8_t> buckets, seg_out, ones_partial, ones_l2, result;   // XYZZ<F> arrays, kept as bytes to stay out of the header
+  DevBuf<uint32_t> hist, offsets, fill, entries, ones, ntasks, task_off; DevBuf<uint8_t> counters; Scanner scanner, task_scanner; uint32_t max_tasks;
+  DevBuf<uint8_t> buckets, partials, seg_out, seg_l2, ones_partial, ones_l2, result;   // XYZZ<F> arrays, kept as bytes to stay out of the header
   XYZZ<F> *h_result = nullptr;                                      // pinned: W window sums + ones sum
   MsmCounters *h_cnt = nullptr;
 
   MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo)
       : n(n_), c(c_), W(msm_num_windows(c_)), NB(1u << (c_ - 1)), filter_ones(fo), points(n_ ? n_ : 1), inf(n_ ? n_ : 1),
-        hist((size_t)W * NB), offsets((size_t)W * NB), fill((size_t)W * NB), entries((n_ ? n_ : 1) * (size_t)W), ones(n_ ? n_ : 1), counters(sizeof(MsmCounters)),
-        scanner((size_t)W * NB) {
+        hist((size_t)W * NB), offsets((size_t)W * NB), fill((size_t)W * NB), entries((n_ ? n_ : 1) * (size_t)W), ones(n_ ? n_ : 1), ntasks((size_t)W * NB + 1), task_off((size_t)W * NB + 1), counters(sizeof(MsmCounters)),
+        scanner((size_t)W * NB), task_scanner((size_t)W * NB + 1) {
     if (c < 6 || c > 20 || W > MSM_MAX_WINDOWS) throw GpuError("msm: unsupported window size");
-    seg = 32; n_ones_threads = 4096;
+    seg = NB >= 4096 ? 8 : 4; n_ones_threads = 16384;
     std::vector<uint8_t> flags(n ? n : 1, 0); const uint8_t zero[sizeof(RawAffine)] = {0};
     for (size_t i = 0; i < n; i++) if (!memcmp(&host_points[i], zero, sizeof(RawAffine))) { flags[i] = 1; any_inf = true; }
     if (n) { points.upload(host_points, n); inf.upload(flags.data(), n); }
-    buckets = DevBuf<uint8_t>((size_t)W * NB * sizeof(XYZZ<F>)); seg_out = DevBuf<uint8_t>((size_t)W * (NB / seg) * sizeof(XYZZ<F>));
+    max_tasks = (uint32_t)((n * (size_t)W) / MSM_TASK + (size_t)W * NB + 1);
+    buckets = DevBuf<uint8_t>((size_t)W * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>((size_t)max_tasks * sizeof(XYZZ<F>));
+    seg_out = DevBuf<uint8_t>((size_t)W * (NB / seg) * sizeof(XYZZ<F>)); seg_l2 = DevBuf<uint8_t>((size_t)W * cdiv(NB / seg, 64) * sizeof(XYZZ<F>));
     ones_partial = DevBuf<uint8_t>((size_t)n_ones_threads * sizeof(XYZZ<F>)); ones_l2 = DevBuf<uint8_t>((size_t)(n_ones_threads / 64) * sizeof(XYZZ<F>));
     result = DevBuf<uint8_t>((size_t)(W + 1) * sizeof(XYZZ<F>));
     HIP_CHECK(hipHostMalloc((void **)&h_result, (size_t)(W + 1) * sizeof(XYZZ<F>))); HIP_CHECK(hipHostMalloc((void **)&h_cnt, sizeof(MsmCounters)));
   }
   ~MsmImpl() { if (h_result) hipHostFree(h_result); if (h_cnt) hipHostFree(h_cnt); }
+  hipStream_t stream() { return stream_id < 0 ? gpu().stream : gpu().aux[stream_id & 3]; }
 
-  template <int LANES> void launch_accumulate(hipStream_t s) {
-    size_t nbk = (size_t)W * NB; hipLaunchKernelGGL((k_msm_accumulate<F, LANES>), dim3(cdiv(nbk * LANES, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist.get(),
-                                                   (uint32_t)nbk, (XYZZ<F> *)buckets.get());
-  }
   void run(const Fe32 *scalars, const uint32_t *scalar_index) {
-    hipStream_t s = gpu().stream; size_t nbk = (size_t)W * NB; const uint8_t *infp = any_inf ? inf.get() : nullptr; MsmCounters *cnt = (MsmCounters *)counters.get();
-    hist.zero(); fill.zero(); counters.zero();
-    if (n) {
-      Stage st((label + ".sort").c_str());
-      hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist.get(), ones.get(), cnt);
-      scanner.run(hist.get(), offsets.get(), nbk);
-      hipLaunchKernelGGL(k_msm_scatter<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, offsets.get(), fill.get(), entries.get());
+    hipStream_t s = stream(); size_t nbk = (size_t)W * NB; const uint8_t *infp = any_inf ? inf.get() : nullptr; MsmCounters *cnt = (MsmCounters *)counters.get();
+    HIP_CHECK(hipMemsetAsync(hist.get(), 0, nbk * 4, s)); HIP_CHECK(hipMemsetAsync(fill.get(), 0, nbk * 4, s)); HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(MsmCounters), s));
+    { Stage st((label + ".sort").c_str(), s);
+      if (n) {
+        hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist.get(), ones.get(), cnt);
+        scanner.run(hist.get(), offsets.get(), nbk, s);
+        hipLaunchKernelGGL(k_msm_scatter<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, offsets.get(), fill.get(), entries.get());
+      }
+      hipLaunchKernelGGL(k_msm_plan, dim3(cdiv(nbk + 1, 256)), dim3(256), 0, s, hist.get(), (uint32_t)nbk, ntasks.get());
+      task_scanner.run(ntasks.get(), task_off.get(), nbk + 1, s);
     }
-    size_t avg = n / NB;   // expected entries per bucket for full-width scalars
-    { Stage st((label + ".accumulate").c_str());
-    if (avg >= 256) launch_accumulate<16>(s); else if (avg >= 64) launch_accumulate<8>(s); else if (avg >= 24) launch_accumulate<4>(s); else if (avg >= 8) launch_accumulate<2>(s); else launch_accumulate<1>(s); }
-    Stage st_red((label + ".reduce").c_str());
-    uint32_t nseg = (uint32_t)(W * (NB / seg));
-    hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3(cdiv(nseg, 64)), dim3(64), 0, s, (const XYZZ<F> *)buckets.get(), NB, seg, nseg, (XYZZ<F> *)seg_out.get());
-    hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W), dim3(64), 0, s, (const XYZZ<F> *)seg_out.get(), NB / seg, (XYZZ<F> *)result.get());
+    { Stage st((label + ".accumulate").c_str(), s);
+      hipLaunchKernelGGL((k_msm_accumulate_tasks<F>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist.get(), task_off.get(), (uint32_t)nbk, max_tasks,
+                         (XYZZ<F> *)buckets.get(), (XYZZ<F> *)partials.get());
+    }
+    { Stage st((label + ".combine").c_str(), s);
+      hipLaunchKernelGGL((k_msm_combine_tasks<F, 8>), dim3(cdiv(nbk * 8, 256)), dim3(256), 0, s, hist.get(), task_off.get(), (uint32_t)nbk, (const XYZZ<F> *)partials.get(), (XYZZ<F> *)buckets.get());
+    }
+    { Stage st_red((label + ".reduce").c_str(), s);
+      uint32_t spw = NB / seg, nseg = (uint32_t)W * spw;
+      hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3(cdiv(nseg, 64)), dim3(64), 0, s, (const XYZZ<F> *)buckets.get(), NB, seg, nseg, (XYZZ<F> *)seg_out.get());
+      if (spw > 64) { uint32_t g = cdiv(spw, 64);   // two-level tree per window keeps the dependent chain short
+        hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W * g), dim3(64), 0, s, (const XYZZ<F> *)seg_out.get(), 64u, (XYZZ<F> *)seg_l2.get());
+        hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W), dim3(64), 0, s, (const XYZZ<F> *)seg_l2.get(), g, (XYZZ<F> *)result.get());
+      } else hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W), dim3(64), 0, s, (const XYZZ<F> *)seg_out.get(), spw, (XYZZ<F> *)result.get());
+    }
     XYZZ<F> *ones_dst = (XYZZ<F> *)result.get() + W;
-    if (filter_ones && n) {
+    if (filter_ones && n) { Stage st((label + ".ones").c_str(), s);
       hipLaunchKernelGGL((k_msm_sum_ones<F>), dim3(cdiv(n_ones_threads, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), ones.get(), cnt, n_ones_threads, (XYZZ<F> *)ones_partial.get());
       hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(n_ones_threads / 64), dim3(64), 0, s, (const XYZZ<F> *)ones_partial.get(), 64u, (XYZZ<F> *)ones_l2.get());
       hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(64), 0, s, (const XYZZ<F> *)ones_l2.get(), n_ones_threads / 64, ones_dst);
@@ -146,13 +166,15 @@ MsmG1::~MsmG1() = default;
 void MsmG1::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
 void MsmG1::set_label(const char *l) { impl->label = l; }
 void MsmG2::set_label(const char *l) { impl->label = l; }
-host::HG1 MsmG1::result() { gpu_sync(); return combine<host::HFq, Fq>(impl->h_result, impl->W, impl->c); }
+void MsmG1::set_stream(int aux) { impl->stream_id = aux; }
+void MsmG2::set_stream(int aux) { impl->stream_id = aux; }
+host::HG1 MsmG1::result() { HIP_CHECK(hipStreamSynchronize(impl->stream())); return combine<host::HFq, Fq>(impl->h_result, impl->W, impl->c); }
 size_t MsmG1::size() const { return impl->n; }
 const G1AffineRaw *MsmG1::points_dev() const { return impl->points.get(); }
 MsmG2::MsmG2(const G2AffineRaw *p, size_t n, int c, bool fo) : impl(new Impl(p, n, c, fo)) {}
 MsmG2::~MsmG2() = default;
 void MsmG2::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
-host::HG2 MsmG2::result() { gpu_sync(); return combine<host::HFq2, Fq2>(impl->h_result, impl->W, impl->c); }
+host::HG2 MsmG2::result() { HIP_CHECK(hipStreamSynchronize(impl->stream())); return combine<host::HFq2, Fq2>(impl->h_result, impl->W, impl->c); }
 
 // ======================================================================================================================
 // Evaluation domains
@@ -329,6 +351,12 @@ void R1csDev::eval(const Fe32 *z, Fe32 *abc, size_t m) {
   for (int mm = 0; mm < 3; mm++) if (d.n_cons) hipLaunchKernelGGL(k_r1cs_rows, dim3(cdiv(d.n_cons, 256)), dim3(256), 0, s, d.rowptr[mm].get(), d.col[mm].get(), d.cid[mm].get(), (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)d.n_cons, (Fr *)(abc + mm * m));
   HIP_CHECK(hipMemcpyAsync(abc + d.n_cons, z, (d.n_inputs + 1) * sizeof(Fe32), hipMemcpyDeviceToDevice, s));   // input-consistency rows (r1cs_to_qap.tcc:227-230)
 }
+void R1csDev::check_async(const Fe32 *abc, size_t m) {
+  Impl &d = *impl; hipStream_t s = gpu().stream; HIP_CHECK(hipMemsetAsync(d.flag.get(), 0, 4, s));
+  if (d.n_cons) hipLaunchKernelGGL(k_r1cs_check, dim3(cdiv(d.n_cons, 256)), dim3(256), 0, s, (const Fr *)abc, (const Fr *)(abc + m), (const Fr *)(abc + 2 * m), (uint32_t)d.n_cons, d.flag.get());
+  HIP_CHECK(hipMemcpyAsync(d.h_flag, d.flag.get(), 4, hipMemcpyDeviceToHost, s));
+}
+bool R1csDev::check_result() const { return *impl->h_flag == 0; }
 bool R1csDev::satisfied(const Fe32 *abc, size_t m) {
   Impl &d = *impl; hipStream_t s = gpu().stream; d.flag.zero();
   if (d.n_cons) hipLaunchKernelGGL(k_r1cs_check, dim3(cdiv(d.n_cons, 256)), dim3(256), 0, s, (const Fr *)abc, (const Fr *)(abc + m), (const Fr *)(abc + 2 * m), (uint32_t)d.n_cons, d.flag.get());

@@ -33,6 +33,16 @@ template <class T> class DevBuf {              // RAII device allocation
   T *p_ = nullptr; size_t n_ = 0;
 };
 
+template <class T> class PinnedBuf {           // page-locked host staging buffer
+ public:
+  PinnedBuf() = default; explicit PinnedBuf(size_t n); ~PinnedBuf(); PinnedBuf(const PinnedBuf &) = delete; PinnedBuf &operator=(const PinnedBuf &) = delete;
+  PinnedBuf &operator=(PinnedBuf &&o) noexcept { if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }
+  T *get() const { return p_; } size_t size() const { return n_; }
+ private:
+  void release(); T *p_ = nullptr; size_t n_ = 0;
+};
+void upload_async(void *dev, const void *pinned_host, size_t bytes);   // on the main stream, no synchronisation
+
 // A fixed set of base points resident in HBM (one query of a proving key) plus the reusable MSM workspace for it.
 class MsmG1 {
  public:
@@ -42,7 +52,7 @@ class MsmG1 {
   // Enqueues the kernels; result() synchronises and finishes the combine on the host.
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
   host::HG1 result();
-  size_t size() const; const G1AffineRaw *points_dev() const; void set_label(const char *l);
+  size_t size() const; const G1AffineRaw *points_dev() const; void set_label(const char *l); void set_stream(int aux /* -1 main, 0..3 auxiliary */);
   struct Impl; std::unique_ptr<Impl> impl;
 };
 class MsmG2 {
@@ -50,7 +60,7 @@ class MsmG2 {
   MsmG2(const G2AffineRaw *host_points, size_t n, int window_bits, bool filter_ones);
   ~MsmG2();
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
-  host::HG2 result(); void set_label(const char *l);
+  host::HG2 result(); void set_label(const char *l); void set_stream(int aux);
   struct Impl; std::unique_ptr<Impl> impl;
 };
 
@@ -79,6 +89,8 @@ class R1csDev {
   // z_dev: n_vars+1 Fr (Montgomery, z[0] = 1).  abc: 3 vectors of m (zero padded, aA[n_cons + i] = z_i for i <= n_inputs; r1cs_to_qap.tcc:227-230)
   void eval(const Fe32 *z_dev, Fe32 *abc, size_t m);
   bool satisfied(const Fe32 *abc, size_t m);    // synchronises
+  void check_async(const Fe32 *abc, size_t m);  // same check queued on the main stream; check_result() after the stream has been synchronised
+  bool check_result() const;
   struct Impl; std::unique_ptr<Impl> impl;
 };
 
@@ -90,7 +102,8 @@ void decompress_g2(const Fe32 *xs /* 2 per point */, const uint8_t *flags, size_
 // Key generation: out[i] = scalars[i] * base (scalars canonical), results affine Montgomery
 void fixed_base_mul_g1(const host::HG1 &base, const Fe32 *scalars, size_t n, G1AffineRaw *out);
 void fixed_base_mul_g2(const host::HG2 &base, const Fe32 *scalars, size_t n, G2AffineRaw *out);
-void gpu_sync();
+void gpu_sync();            // all streams
+void gpu_fork_aux();        // auxiliary streams wait for everything queued on the main stream so far
 // per-stage device timing (HIP events on the compute stream); report = JSON object {stage: {ms_total, count}}
 void profile_enable(bool on); std::string profile_report();
 

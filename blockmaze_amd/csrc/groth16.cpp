@@ -184,43 +184,52 @@ void generate_keys(const R1csHost &cs_in, const ToxicWaste &tw, ProvingKeyHost &
 // ======================================================================================================================
 struct Prover::Impl {
   size_t nv, ni, m; HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
-  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; std::vector<Fe32> z_host;
+  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; PinnedBuf<Fe32> z_host;
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 Prover::Prover(const ProvingKeyHost &pk) : impl(new Impl) {
   Impl &p = *impl; p.nv = pk.cs.n_vars; p.ni = pk.cs.n_inputs; p.cs.reset(new R1csDev(pk.cs)); p.dom.reset(new Domain(pk.cs.n_cons + p.ni + 1)); p.m = p.dom->m();
   if (pk.A.size() != p.nv + 1 || pk.H.size() != p.m - 1 || pk.L.size() != p.nv - p.ni) throw std::runtime_error("proving key: query sizes do not match the constraint system");
   p.alpha_g1 = g1_of(pk.alpha_g1); p.beta_g1 = g1_of(pk.beta_g1); p.delta_g1 = g1_of(pk.delta_g1); p.beta_g2 = g2_of(pk.beta_g2); p.delta_g2 = g2_of(pk.delta_g2);
-  int cw = env_int("ZK_MSM_WITNESS_WINDOW", 8), ch = env_int("ZK_MSM_H_WINDOW", 13);
+  int cw = env_int("ZK_MSM_WITNESS_WINDOW", 8), ch = env_int("ZK_MSM_H_WINDOW", 16);
   p.A.reset(new MsmG1(pk.A.data(), pk.A.size(), cw, true)); p.L.reset(new MsmG1(pk.L.data(), pk.L.size(), cw, true));
   p.B1.reset(new MsmG1(pk.B_g1.data(), pk.B_g1.size(), cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data(), pk.B_g2.size(), cw, true)); p.H.reset(new MsmG1(pk.H.data(), pk.H.size(), ch, false));
+  p.A->set_stream(0); p.L->set_stream(1); p.B1->set_stream(2); p.B2->set_stream(3);   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
   p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
   p.B_idx = DevBuf<uint32_t>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx.upload(pk.B_idx.data(), pk.B_idx.size());
-  p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host.resize(p.nv + 1);
+  p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host = PinnedBuf<Fe32>(p.nv + 1);
 }
 Prover::~Prover() = default;
 size_t Prover::num_variables() const { return impl->nv; }
 size_t Prover::num_inputs() const { return impl->ni; }
 size_t Prover::domain_size() const { return impl->m; }
 
-bool Prover::prove(const Fe32 *z, const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
-  Impl &p = *impl; double t0 = now_ms();
-  memset(&p.z_host[0], 0, 32); p.z_host[0].l[0] = 1; memcpy(&p.z_host[1], z, 32 * p.nv);
-  p.z.upload(p.z_host.data(), p.nv + 1); fr_to_mont_dev(p.z.get(), p.nv + 1);
-  p.cs->eval(p.z.get(), p.abc.get(), p.m); double t1 = now_ms();
-  if (!p.cs->satisfied(p.abc.get(), p.m)) return false;
-  // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322)
+void Prover::set_witness(const Fe32 *z, bool montgomery) {
+  Impl &p = *impl; double t0 = now_ms(); Fe32 *h = p.z_host.get();
+  if (montgomery) memcpy(&h[0], FrParams::R1, 32); else { memset(&h[0], 0, 32); h[0].l[0] = 1; }
+  memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * (p.nv + 1)); if (!montgomery) fr_to_mont_dev(p.z.get(), p.nv + 1);
+  last.upload_ms = now_ms() - t0;
+}
+bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
+  Impl &p = *impl; double t1 = now_ms();
+  gpu_fork_aux();
+  p.A->run(p.z.get(), nullptr); p.L->run(p.z.get() + p.ni + 1, nullptr); p.B1->run(p.z.get(), p.B_idx.get()); p.B2->run(p.z.get(), p.B_idx.get());   // r1cs_gg_ppzksnark.tcc:442-462,477-484
+  p.cs->eval(p.z.get(), p.abc.get(), p.m);
+  // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the satisfiability flag is read back together with the results
+  p.cs->check_async(p.abc.get(), p.m);
   p.dom->ifft(p.abc.get(), 3, p.m); p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); p.dom->icoset_fft(p.abc.get(), 1, p.m);
-  // the four multi-exponentiations (r1cs_gg_ppzksnark.tcc:442-484); scalars stay on the device
-  p.H->run(p.abc.get(), nullptr); p.A->run(p.z.get(), nullptr); p.L->run(p.z.get() + p.ni + 1, nullptr); p.B1->run(p.z.get(), p.B_idx.get()); p.B2->run(p.z.get(), p.B_idx.get());
-  gpu_sync(); double t2 = now_ms();
-  HG1 eH = p.H->result(), eA = p.A->result(), eL = p.L->result(), eB1 = p.B1->result(); HG2 eB2 = p.B2->result(); double t3 = now_ms();
+  p.H->run(p.abc.get(), nullptr);                                                                                         // :466-473
+  // while the device works: everything that depends only on (r, s) and the key  (:488-495)
   HFr r = r_in ? fr_of(*r_in) : random_fr().from_mont(), s = s_in ? fr_of(*s_in) : random_fr().from_mont(), rs = (r.to_mont() * s.to_mont()).from_mont();   // canonical scalars
-  HG1 gA = p.alpha_g1.add(eA).add(p.delta_g1.mul(r.l));                                                                  // :488
-  HG1 gB1 = p.beta_g1.add(eB1).add(p.delta_g1.mul(s.l)); HG2 gB2 = p.beta_g2.add(eB2).add(p.delta_g2.mul(s.l));        // :491-492
-  HG1 gC = eH.add(eL).add(gA.mul(s.l)).add(gB1.mul(r.l)).add(p.delta_g1.mul(rs.l).neg());                               // :495
+  HG1 r_delta = p.delta_g1.mul(r.l), s_delta = p.delta_g1.mul(s.l), rs_delta_neg = p.delta_g1.mul(rs.l).neg(); HG2 s_delta2 = p.delta_g2.mul(s.l);
+  double t2 = now_ms(); gpu_sync(); double t3 = now_ms();
+  if (!p.cs->check_result()) return false;
+  HG1 eH = p.H->result(), eA = p.A->result(), eL = p.L->result(), eB1 = p.B1->result(); HG2 eB2 = p.B2->result();
+  HG1 gA = p.alpha_g1.add(eA).add(r_delta);                                                                              // :488
+  HG1 gB1 = p.beta_g1.add(eB1).add(s_delta); HG2 gB2 = p.beta_g2.add(eB2).add(s_delta2);                                // :491-492
+  HG1 gC = eH.add(eL).add(gA.mul(s.l)).add(gB1.mul(r.l)).add(rs_delta_neg);                                             // :495
   out.A = raw_of(gA); out.B = raw_of(gB2); out.C = raw_of(gC); double t4 = now_ms();
-  last.upload_ms = t1 - t0; last.qap_ms = 0; last.msm_ms = t2 - t1; last.finish_ms = t4 - t2; last.total_ms = t4 - t0; return true;
+  last.qap_ms = t2 - t1; last.msm_ms = t3 - t1; last.finish_ms = t4 - t3; last.total_ms = last.upload_ms + (t4 - t1); return true;
 }
 
 // ======================================================================================================================

@@ -41,7 +41,10 @@ class Prover {                                    // a proving key resident in H
   size_t num_variables() const; size_t num_inputs() const; size_t domain_size() const;
   // z: full assignment without ONE (canonical).  r, s: prover randomness (canonical; nullptr = fresh CSPRNG values).
   // Returns false if z does not satisfy the constraint system (the reference then emits its default proof, sendcgo.cpp:209-214).
-  bool prove(const Fe32 *z, const Fe32 *r, const Fe32 *s, Proof &out);
+  bool prove(const Fe32 *z, const Fe32 *r, const Fe32 *s, Proof &out) { set_witness(z, false); return prove_resident(r, s, out); }
+  // the two halves of prove(): hand the assignment over (canonical, or already in Montgomery form as the circuit boards hold it), then prove from HBM
+  void set_witness(const Fe32 *z, bool montgomery);
+  bool prove_resident(const Fe32 *r, const Fe32 *s, Proof &out);
   struct Timings { double upload_ms, qap_ms, msm_ms, finish_ms, total_ms; } last{};
   struct Impl; std::unique_ptr<Impl> impl;
 };

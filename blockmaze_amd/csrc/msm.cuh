@@ -100,21 +100,36 @@ template <class T> __device__ __forceinline__ T shfl_down_struct(const T &v, int
   return r;
 }
 
-// ---- bucket accumulation: LANES lanes per bucket -------------------------------------------------------------------
-template <class F, int LANES>
-__global__ void __launch_bounds__(256) k_msm_accumulate(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ offsets,
-                                                        const uint32_t *__restrict__ counts, uint32_t n_buckets, XYZZ<F> *__restrict__ buckets) {
-  uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, b = gid / LANES, lane = gid % LANES;
+// ---- bucket accumulation, balanced by entries ---------------------------------------------------------------------------
+// A bucket with `count` sorted entries is cut into tasks of at most TASK entries; one lane per task, whatever the digit
+// distribution looks like (uniform H coefficients, the short top window, 0/1-heavy witnesses).  task_off is the exclusive
+// scan of the per-bucket task counts (n_buckets + 1 entries, the last one = total).
+constexpr uint32_t MSM_TASK = 16;
+__global__ void k_msm_plan(const uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t *__restrict__ ntasks) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; if (b <= n_buckets) ntasks[b] = b < n_buckets ? (counts[b] + MSM_TASK - 1) / MSM_TASK : 0;
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
+                                                              const uint32_t *__restrict__ task_off, uint32_t n_buckets, uint32_t max_tasks, XYZZ<F> *__restrict__ buckets, XYZZ<F> *__restrict__ partials) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= max_tasks || t >= task_off[n_buckets]) return;
+  uint32_t lo = 0, hi = n_buckets;                         // largest b with task_off[b] <= t
+  while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (task_off[mid] <= t) lo = mid; else hi = mid; }
+  uint32_t b = lo, j = t - task_off[b], cnt = counts[b], beg = offsets[b] + j * MSM_TASK, end = offsets[b] + min(cnt, (j + 1) * MSM_TASK);
   XYZZ<F> acc = XYZZ<F>::inf();
-  if (b < n_buckets) {
-    uint32_t beg = offsets[b], end = beg + counts[b];
-    for (uint32_t e = beg + lane; e < end; e += LANES) { uint32_t v = entries[e]; Affine<F> p = points[v & 0x7fffffffu]; if (v >> 31) p.y = p.y.neg(); acc.madd(p); }
-  }
-  if (LANES > 1) {
+  for (uint32_t e = beg; e < end; e++) { uint32_t v = entries[e]; Affine<F> p = points[v & 0x7fffffffu]; if (v >> 31) p.y = p.y.neg(); acc.madd(p); }
+  if (cnt <= MSM_TASK) buckets[b] = acc; else partials[t] = acc;
+}
+// buckets that were cut into several tasks: LANES lanes add up the partial sums
+template <class F, int LANES>
+__global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ task_off, uint32_t n_buckets, const XYZZ<F> *__restrict__ partials, XYZZ<F> *__restrict__ buckets) {
+  uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, b = gid / LANES, lane = gid % LANES; bool active = b < n_buckets;
+  uint32_t cnt = active ? counts[b] : 0; bool multi = cnt > MSM_TASK;
+  if (!__any(multi)) { if (active && cnt == 0 && lane == 0) buckets[b] = XYZZ<F>::inf(); return; }
+  XYZZ<F> acc = XYZZ<F>::inf();
+  if (multi) { uint32_t beg = task_off[b], nt = task_off[b + 1] - beg; for (uint32_t j = lane; j < nt; j += LANES) acc.add(partials[beg + j]); }
 #pragma unroll
-    for (int d = LANES / 2; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); acc.add(o); }
-  }
-  if (b < n_buckets && lane == 0) buckets[b] = acc;
+  for (int d = LANES / 2; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); acc.add(o); }
+  if (active && lane == 0) { if (multi) buckets[b] = acc; else if (cnt == 0) buckets[b] = XYZZ<F>::inf(); }
 }
 
 // ---- bucket reduction: sum_{b=1..NB} b * B_b per window, by segments of SEG buckets --------------------------------
@@ -134,7 +149,7 @@ __global__ void __launch_bounds__(64) k_msm_reduce_segments(const XYZZ<F> *__res
 template <class F>
 __global__ void __launch_bounds__(64) k_xyzz_group_sum(const XYZZ<F> *__restrict__ in, uint32_t len, XYZZ<F> *__restrict__ out) {
   uint32_t g = blockIdx.x, lane = threadIdx.x; XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t j = lane; j < len; j += 64) acc.add(in[(size_t)g * len + j]);
+  for (uint32_t j = lane; j < len; j += 64) { if (j == lane) acc = in[(size_t)g * len + j]; else acc.add(in[(size_t)g * len + j]); }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); acc.add(o); }
   if (lane == 0) out[g] = acc;

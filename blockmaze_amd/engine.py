@@ -123,8 +123,13 @@ class Prover:
         z = np.ascontiguousarray(z, dtype=np.uint64); assert z.size == 4 * self.n_vars
         R = int(r).to_bytes(32, "little") if r is not None else None; S = int(s).to_bytes(32, "little") if s is not None else None
         out = ctypes.create_string_buffer(513); _check(lib().zkgpu_prover_prove(ctypes.c_void_p(self.h), _bytes(z), R, S, out)); return out.value.decode()
+    def set_witness(self, z):
+        z = np.ascontiguousarray(z, dtype=np.uint64); assert z.size == 4 * self.n_vars; _check(lib().zkgpu_prover_set_witness(ctypes.c_void_p(self.h), _bytes(z)))
+    def prove_resident(self, r=None, s=None):
+        R = int(r).to_bytes(32, "little") if r is not None else None; S = int(s).to_bytes(32, "little") if s is not None else None
+        out = ctypes.create_string_buffer(513); _check(lib().zkgpu_prover_prove_resident(ctypes.c_void_p(self.h), R, S, out)); return out.value.decode()
     def timings(self):
-        t = (ctypes.c_double * 5)(); _check(lib().zkgpu_prover_timings(ctypes.c_void_p(self.h), t)); return dict(zip(("upload_ms", "qap_ms", "device_ms", "finish_ms", "total_ms"), (float(x) for x in t)))
+        t = (ctypes.c_double * 5)(); _check(lib().zkgpu_prover_timings(ctypes.c_void_p(self.h), t)); return dict(zip(("upload_ms", "enqueue_ms", "device_ms", "finish_ms", "total_ms"), (float(x) for x in t)))
     def close(self):
         if self.h: lib().zkgpu_prover_destroy(ctypes.c_void_p(self.h)); self.h = None
     def __del__(self):

@@ -90,6 +90,9 @@ void zkgpu_prover_destroy(zkgpu_prover *h);
 int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]);          /* n_vars, n_inputs, domain size m */
 /* z: n_vars elements; r, s: 32-byte canonical prover randomness or NULL for fresh values.  proof_hex: 512 hex characters + NUL. */
 int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]);
+/* the two halves of zkgpu_prover_prove: upload the assignment into HBM (returns when it is resident), then prove from there any number of times */
+int zkgpu_prover_set_witness(zkgpu_prover *h, const uint8_t *z);
+int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t *s, char proof_hex[513]);
 int zkgpu_prover_timings(zkgpu_prover *h, double out[5]);       /* ms of the last prove(): upload+rows, (unused), device kernels, host finish, total */
 /* per-stage device timing with HIP events on the compute stream (for the benchmark's roofline leg).  report: JSON {"stage": {"ms_total": x, "count": n}, ...} */
 int zkgpu_profile_enable(int on);
