@@ -163,6 +163,89 @@ struct MintRedeemCircuit : Circuit {
     cmt_old->witness(); cmt_new->witness(); cmtA_old->fill(blob_bits(in.cmtA_old.b, 32)); cmtA->fill(blob_bits(in.cmtA.b, 32)); unpacker->witness_from_bits(); }
 };
 
+
+// ======================================================================================================================
+// deposit (src/deposit/circuit/gadget.tcc:24-368, note.tcc, merkle.tcc) over libsnark's Merkle gadgets
+// (gadgets/merkle_tree/merkle_tree_check_read_gadget.tcc:20-112, merkle_authentication_path_variable.tcc:17-50,
+//  gadgets/hashes/digest_selector_gadget.tcc:17-64, gadgets/basic_gadgets.tcc:110-194 bit_vector_copy / field_vector_copy)
+// ======================================================================================================================
+struct MerkleRead {
+  Board &b; size_t depth; VarArray positions; std::vector<Digest> left, right, internal; std::unique_ptr<Digest> computed_root; std::vector<std::unique_ptr<Sha256Compression>> hashers;
+  VarArray leaf, root; Var enforce; VarArray packed_source, packed_target; std::unique_ptr<MultiPacking> pack_source, pack_target; bool own_positions;
+  // given_positions empty: BlockMaze's merkle_tree_gadget (allocates and boolean-constrains the position bits itself, merkle.tcc:20,41-50)
+  MerkleRead(Board &b, size_t depth, const VarArray &leaf, const VarArray &root, Var enforce, const VarArray &given_positions = VarArray()) : b(b), depth(depth), leaf(leaf), root(root), enforce(enforce), own_positions(given_positions.empty()) {
+    positions = own_positions ? b.alloc_array(depth) : given_positions;
+    for (size_t i = 0; i < depth; i++) { left.emplace_back(b, 256); right.emplace_back(b, 256); }              // merkle_authentication_path_variable.tcc:22-26
+    for (size_t i = 0; i + 1 < depth; i++) internal.emplace_back(b, 256);                                    // merkle_tree_check_read_gadget.tcc:49-52
+    computed_root.reset(new Digest(b, 256));
+    for (size_t i = 0; i < depth; i++) hashers.emplace_back(new Sha256Compression(b, sha256_default_iv(), concat({left[i].bits, right[i].bits}), i == 0 ? computed_root->bits : internal[i - 1].bits));
+    packed_source = b.alloc_array(2); pack_source.reset(new MultiPacking(b, computed_root->bits, packed_source)); packed_target = b.alloc_array(2); pack_target.reset(new MultiPacking(b, root, packed_target));   // bit_vector_copy_gadget, chunk 253
+  }
+  const VarArray &input_of(size_t i) const { return i + 1 < depth ? internal[i].bits : leaf; }
+  void constraints() {
+    if (own_positions) for (Var p : positions) boolean_constraint(b, LC(p));                                // merkle.tcc:41-50
+    for (size_t i = 0; i < depth; i++) { left[i].constraints(); right[i].constraints(); }
+    for (auto &h : hashers) h->constraints();
+    for (size_t i = 0; i < depth; i++) { Var is_right = positions[depth - 1 - i]; const VarArray &in = input_of(i);   // digest_selector: is_right * (right - left) = input - left
+      for (size_t k = 0; k < 256; k++) b.constraint(LC(is_right), LC(right[i].bits[k]) - LC(left[i].bits[k]), LC(in[k]) - LC(left[i].bits[k])); }
+    pack_source->constraints(false); pack_target->constraints(false);
+    for (size_t k = 0; k < 2; k++) b.constraint(LC(enforce), LC(packed_source[k]) - LC(packed_target[k]), LC());       // field_vector_copy_gadget
+  }
+  // path: siblings from the leaf level upwards; index_bits[d] = bit d of the leaf position
+  void witness(const std::vector<Blob256> &path, const std::vector<bool> &index_bits) {
+    for (size_t d = 0; d < depth; d++) b.set_bit(positions[d], index_bits[d]);                               // fill_with_bits_of_ulong(path_index)
+    for (size_t i = 0; i < depth; i++) { size_t level = depth - 1 - i; std::vector<bool> sib = blob_bits(path[level].b, 32); if (index_bits[level]) left[i].fill(sib); else right[i].fill(sib); }   // authvars (address bit depth-1-i)
+    for (size_t i = depth; i-- > 0;) { bool is_right = b.bit(positions[depth - 1 - i]); const VarArray &in = input_of(i); Digest &dst = is_right ? right[i] : left[i];
+      for (size_t k = 0; k < 256; k++) b.set_bit(dst.bits[k], b.bit(in[k])); hashers[i]->witness(); }
+    if (b.bit(enforce)) for (size_t k = 0; k < 256; k++) b.set_bit(root[k], b.bit(computed_root->bits[k]));
+    pack_source->witness_from_bits(); pack_target->witness_from_bits();
+  }
+};
+struct DepositCircuit : Circuit {
+  size_t depth; VarArray packed_inputs, unpacked; std::unique_ptr<Digest> rt, pk_recv, cmtB_old, sn_old, cmtB, sn_s, r_s, sn_A_old, cmtS, r_old, sn, r, sk; std::unique_ptr<MultiPacking> unpacker;
+  Var value_enforce, ZERO; VarArray value_s, value_old, value; Var value_s_packed, value_old_packed, value_packed;
+  std::unique_ptr<ShaTwoBlock> prf_sn, prf_sn_s, cmt_s, cmt_old, cmt_new; std::unique_ptr<MerkleRead> merkle;
+  DepositCircuit(bool emit, size_t depth) : Circuit(emit), depth(depth) { Board &b = board;
+    packed_inputs = b.alloc_array(6); b.set_input_sizes(6);
+    auto alloc_in = [&](std::unique_ptr<Digest> &d, size_t n) { d.reset(new Digest(b, n)); unpacked.insert(unpacked.end(), d->bits.begin(), d->bits.end()); };
+    alloc_in(rt, 256); alloc_in(pk_recv, 160); alloc_in(cmtB_old, 256); alloc_in(sn_old, 256); alloc_in(cmtB, 256); alloc_in(sn_s, 256);   // gadget.tcc:91-96
+    unpacker.reset(new MultiPacking(b, unpacked, packed_inputs));
+    value_enforce = b.alloc(); ZERO = b.alloc(); value_s = b.alloc_array(64); r_s.reset(new Digest(b, 256)); sn_A_old.reset(new Digest(b, 256)); cmtS.reset(new Digest(b, 256));
+    value_old = b.alloc_array(64); r_old.reset(new Digest(b, 256)); value = b.alloc_array(64); sn.reset(new Digest(b, 256)); r.reset(new Digest(b, 256)); sk.reset(new Digest(b, 256));
+    value_s_packed = b.alloc(); value_old_packed = b.alloc(); value_packed = b.alloc();                      // note.tcc (note_gadget_with_packing_and_ADD ctor)
+    prf_sn = make_prf(b, ZERO, sk->bits, r->bits, sn->bits); prf_sn_s = make_prf(b, ZERO, sk->bits, r_s->bits, sn_s->bits);
+    cmt_s = make_cmts(b, ZERO, value_s, pk_recv->bits, r_s->bits, sn_A_old->bits, cmtS->bits); cmt_old = make_cmta(b, ZERO, value_old, sn_old->bits, r_old->bits, cmtB_old->bits); cmt_new = make_cmta(b, ZERO, value, sn->bits, r->bits, cmtB->bits);
+    merkle.reset(new MerkleRead(b, depth, cmtS->bits, rt->bits, value_enforce));
+    if (emit) emit_constraints();
+    b.finish(); }
+  void emit_constraints() { Board &b = board;                                                               // gadget.tcc:196-233
+    unpacker->constraints(true);
+    bool64(b, value_s); bool64(b, value_old); bool64(b, value); b.constraint(ONE_LC, LC(value_old_packed) + LC(value_s_packed), LC(value_packed));
+    pk_recv->constraints(); r_s->constraints(); sn_A_old->constraints(); sn_old->constraints(); r_old->constraints(); sn->constraints(); r->constraints(); sk->constraints();
+    b.constraint(ONE_LC, LC(ZERO), LC());
+    sn_s->constraints(); prf_sn_s->constraints(); sn->constraints(); prf_sn->constraints(); sn_old->constraints();
+    cmtS->constraints(); cmt_s->constraints(); cmtB_old->constraints(); cmt_old->constraints(); cmtB->constraints(); cmt_new->constraints();
+    rt->constraints(); boolean_constraint(b, LC(value_enforce)); merkle->constraints(); }
+  void assign(const DepositInputs &in) { Board &b = board;                                                  // gadget.tcc:235-298
+    fill(b, value_s, u64_bits(in.value_s)); b.val[value_s_packed] = value_by_order(b, value_s); fill(b, value_old, u64_bits(in.value_old)); b.val[value_old_packed] = value_by_order(b, value_old);
+    fill(b, value, u64_bits(in.value)); b.val[value_packed] = value_by_order(b, value);
+    pk_recv->fill(blob_bits(in.pk_recv.b, 20)); r_s->fill(blob_bits(in.r_s.b, 32)); sn_A_old->fill(blob_bits(in.sn_A_old.b, 32)); sn_old->fill(blob_bits(in.sn_old.b, 32)); r_old->fill(blob_bits(in.r_old.b, 32));
+    sn->fill(blob_bits(in.sn.b, 32)); r->fill(blob_bits(in.r.b, 32)); sk->fill(blob_bits(in.sk.b, 32));
+    b.set_bit(value_enforce, in.value_s != 0); b.val[ZERO] = HFr::zero();
+    prf_sn->witness(); prf_sn_s->witness(); sn_s->fill(blob_bits(in.sn_s.b, 32));
+    cmt_s->witness(); cmt_old->witness(); cmt_new->witness(); cmtS->fill(blob_bits(in.cmtS.b, 32)); cmtB_old->fill(blob_bits(in.cmtB_old.b, 32)); cmtB->fill(blob_bits(in.cmtB.b, 32));
+    if (in.path.size() != depth || in.index_bits.size() != depth) throw std::runtime_error("deposit: Merkle path length does not match the tree depth");
+    merkle->witness(in.path, in.index_bits); rt->fill(blob_bits(in.rt.b, 32)); unpacker->witness_from_bits(); }
+};
+
+// libsnark's merkle_tree_check_read_gadget composed as its own self-test does (merkle_tree_check_read_gadget.tcc:131-196): address bits, leaf, root,
+// path variable, then the gadget with read_successful = ONE
+struct MerkleTestCircuit : Circuit {
+  size_t depth; VarArray address; std::unique_ptr<Digest> leaf, root; std::unique_ptr<MerkleRead> ml;
+  MerkleTestCircuit(bool emit, size_t depth) : Circuit(emit), depth(depth) { Board &b = board; address = b.alloc_array(depth); leaf.reset(new Digest(b, 256)); root.reset(new Digest(b, 256));
+    ml.reset(new MerkleRead(b, depth, leaf->bits, root->bits, 0 /* ONE */, address)); if (emit) ml->constraints(); b.finish(); }
+};
+
 // libsnark's own two-to-one hash test circuit (test_sha256_gadget.cpp:20-41)
 struct Sha256TwoToOne : Circuit {
   std::unique_ptr<Digest> left, right, output; std::unique_ptr<Sha256Compression> f;
@@ -182,5 +265,9 @@ void assign_sha256_two_to_one(Circuit &c, const std::vector<bool> &l, const std:
 
 }  // namespace zk
 namespace zk {
-// deposit: implemented in blockmaze_deposit.cpp
+std::unique_ptr<Circuit> make_merkle_test_circuit(bool emit, size_t depth) { return std::unique_ptr<Circuit>(new MerkleTestCircuit(emit, depth)); }
+void assign_merkle_test(Circuit &c, const Blob256 &leaf, const std::vector<Blob256> &path, const std::vector<bool> &index_bits, const Blob256 &root) { auto &m = static_cast<MerkleTestCircuit &>(c);
+  m.leaf->fill(blob_bits(leaf.b, 32)); m.ml->witness(path, index_bits); m.root->fill(blob_bits(root.b, 32)); }
+std::unique_ptr<Circuit> make_deposit_circuit(bool emit, size_t tree_depth) { return std::unique_ptr<Circuit>(new DepositCircuit(emit, tree_depth)); }
+void assign_deposit(Circuit &c, const DepositInputs &in) { static_cast<DepositCircuit &>(c).assign(in); }
 }

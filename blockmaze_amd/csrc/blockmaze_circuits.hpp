@@ -61,6 +61,10 @@ void assign_deposit(Circuit &c, const DepositInputs &in);
 std::unique_ptr<Circuit> make_sha256_two_to_one(bool emit);
 void assign_sha256_two_to_one(Circuit &c, const std::vector<bool> &left, const std::vector<bool> &right);
 
+// test circuit: libsnark's merkle_tree_check_read_gadget as its self-test composes it (merkle_tree_check_read_gadget.tcc:131-196)
+std::unique_ptr<Circuit> make_merkle_test_circuit(bool emit, size_t depth);
+void assign_merkle_test(Circuit &c, const Blob256 &leaf, const std::vector<Blob256> &path /* leaf level first */, const std::vector<bool> &index_bits, const Blob256 &root);
+
 // public inputs of a statement packed the way the verifier side does it (X_gadget::witness_map, e.g. send/circuit/gadget.tcc:274-291;
 // pack_bit_vector_into_field_element_vector, field_utils.tcc:78-102): 253-bit chunks, little-endian within a chunk
 std::vector<Fe32> pack_public_bits(const std::vector<bool> &bits);

@@ -126,14 +126,15 @@ bool verifySendproof(char *data, char *cmtA_old, char *sn_old, char *cmtS, char 
 
 // depositcgo.cpp:327-444: the Merkle path of cmtS is rebuilt from cmtarray (the tree holds the leaves up to and including the first occurrence of cmtS plus
 // everything appended afterwards, i.e. all n leaves); RT is ignored and the root recomputed
-char *genDepositproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old, char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *RT, char *sk) {
-  (void)RT; DepositInputs in; in.value = value; in.value_old = value_old; in.value_s = value_s; in.sn_old = blob256_from_hex(sn_old); in.r_old = blob256_from_hex(r_old); in.sn = blob256_from_hex(sn); in.r = blob256_from_hex(r);
+static DepositInputs deposit_inputs(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old, char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *sk, size_t depth) {
+  DepositInputs in; in.value = value; in.value_old = value_old; in.value_s = value_s; in.sn_old = blob256_from_hex(sn_old); in.r_old = blob256_from_hex(r_old); in.sn = blob256_from_hex(sn); in.r = blob256_from_hex(r);
   in.sn_s = blob256_from_hex(sns); in.r_s = blob256_from_hex(rs); in.cmtB_old = blob256_from_hex(cmtB_old); in.cmtB = blob256_from_hex(cmtB); in.cmtS = blob256_from_hex(cmtS); in.sk = blob256_from_hex(sk); in.pk_recv = blob160_from_hex(pk);
   in.sn_A_old = blob256_from_hex(sn_A_old);
   std::vector<Blob256> leaves = parse_cmtarray(cmtarray, n); size_t index = 0; bool found = false; for (size_t i = 0; i < leaves.size(); i++) if (!memcmp(leaves[i].b, in.cmtS.b, 32)) { index = i; found = true; break; }
-  if (!found) { leaves.clear(); index = 0; }   // reference: the witness of an empty tree — position 0 with empty-subtree siblings and the empty root; such a proof cannot satisfy the circuit unless value_s = 0
-  in.path = merkle_path(leaves, 8, index, in.index_bits); in.rt = merkle_root(leaves, 8);
-  return generate(CircuitKind::Deposit, [&](Circuit &c) { assign_deposit(c, in); }); }
+  if (!found) throw std::runtime_error("cmtS is not among the commitments of cmtarray");   // the reference throws out of IncrementalMerkleTree::path() here (IncrementalMerkleTree.tcc:214-216), taking the Go process with it
+  in.path = merkle_path(leaves, depth, index, in.index_bits); in.rt = merkle_root(leaves, depth); return in; }
+char *genDepositproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old, char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *RT, char *sk) {
+  (void)RT; return generate(CircuitKind::Deposit, [&](Circuit &c) { assign_deposit(c, deposit_inputs(value, value_old, sn_old, r_old, sn, r, sns, rs, cmtB_old, cmtB, value_s, pk, sn_A_old, cmtS, cmtarray, n, sk, 8)); }); }
 bool verifyDepositproof(char *data, char *RT, char *pk, char *cmtb_old, char *snold, char *cmtb, char *sns) {   // deposit_gadget::witness_map (deposit/circuit/gadget.tcc:301-323)
   std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(RT).b, 32)); append(bits, blob_bits(blob160_from_hex(pk).b, 20)); append(bits, blob_bits(blob256_from_hex(cmtb_old).b, 32)); append(bits, blob_bits(blob256_from_hex(snold).b, 32));
   append(bits, blob_bits(blob256_from_hex(cmtb).b, 32)); append(bits, blob_bits(blob256_from_hex(sns).b, 32)); return verify(CircuitKind::Deposit, data, bits); }
@@ -150,8 +151,16 @@ static R1csHost read_r1cs_file(const char *path) { FILE *f = fopen(path, "rb"); 
     if (fread(cs.rowptr[m].data(), 4, cs.n_cons + 1, f) != cs.n_cons + 1 || fread(cs.col[m].data(), 4, nnz, f) != nnz || fread(cs.coeff[m].data(), 32, nnz, f) != nnz) { fclose(f); throw std::runtime_error("truncated R1CS file"); } } fclose(f); return cs; }
 static void write_witness_file(const char *path, const std::vector<Fe32> &z) { FILE *f = fopen(path, "wb"); if (!f) throw std::runtime_error(std::string("cannot write ") + path); uint64_t n = z.size(); fwrite(&n, 8, 1, f); fwrite(z.data(), 32, n, f); fclose(f); }
 
-int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path) { return guarded_host([&] { std::unique_ptr<Circuit> c = kind == 100 ? make_sha256_two_to_one(true) : kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true); write_r1cs_file(r1cs_path, c->r1cs()); return ZKGPU_OK; }); }
+int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path) { return guarded_host([&] { std::unique_ptr<Circuit> c = kind == 100 ? make_sha256_two_to_one(true) : kind == 101 ? make_merkle_test_circuit(true, tree_depth) : kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true); write_r1cs_file(r1cs_path, c->r1cs()); return ZKGPU_OK; }); }
 int zkgpu_witness_sha256(const uint8_t left[32], const uint8_t right[32], const char *wit_path) { return guarded_host([&] { auto c = make_sha256_two_to_one(false); assign_sha256_two_to_one(*c, blob_bits(left, 32), blob_bits(right, 32)); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
+/* Merkle test circuit: leaf and depth siblings (leaf level first, 32 bytes each, in hashing byte order), position of the leaf; the root is computed */
+int zkgpu_witness_merkle(int depth, const uint8_t leaf[32], const uint8_t *siblings, uint64_t position, const char *wit_path) { return guarded_host([&] { auto c = make_merkle_test_circuit(false, depth);
+  Blob256 lf; memcpy(lf.b, leaf, 32); std::vector<Blob256> path(depth); std::vector<bool> idx(depth); Blob256 cur = lf;
+  for (int d = 0; d < depth; d++) { memcpy(path[d].b, siblings + 32 * d, 32); idx[d] = (position >> d) & 1; Blob256 nx; if (idx[d]) sha256_compress_raw(path[d].b, cur.b, nx.b); else sha256_compress_raw(cur.b, path[d].b, nx.b); cur = nx; }
+  assign_merkle_test(*c, lf, path, idx, cur); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
+int zkgpu_witness_deposit(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old, char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *sk, int tree_depth, const char *wit_path) {
+  return guarded_host([&] { DepositInputs in = deposit_inputs(value, value_old, sn_old, r_old, sn, r, sns, rs, cmtB_old, cmtB, value_s, pk, sn_A_old, cmtS, cmtarray, n, sk, (size_t)tree_depth);
+    auto c = make_deposit_circuit(false, (size_t)tree_depth); assign_deposit(*c, in); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
 int zkgpu_witness_send(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender, const char *wit_path) {
   return guarded_host([&] { auto c = make_send_circuit(false); assign_send(*c, send_inputs(value_A, r_s, sn, r, cmt_s, cmtA, value_s, pk_recv, value_A_new, sn_A_new, r_A_new, cmt_A_new, sk, pk_sender)); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
 int zkgpu_witness_mint_redeem(int redeem, uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk, const char *wit_path) {

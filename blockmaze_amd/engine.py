@@ -100,7 +100,7 @@ class R1cs:
         except Exception: pass
 
 # ---- circuits, keys, prover, verifier ---------------------------------------------------------------------------------
-KIND = {"mint": 0, "send": 1, "deposit": 2, "redeem": 3, "sha256": 100}
+KIND = {"mint": 0, "send": 1, "deposit": 2, "redeem": 3, "sha256": 100, "merkle": 101}
 def circuit_export(kind, path, tree_depth=8): _check(lib().zkgpu_circuit_export(KIND[kind], tree_depth, path.encode()))
 def keygen(kind, pk_path, vk_path, seed=0, tree_depth=8): _check(lib().zkgpu_keygen(KIND[kind], tree_depth, ctypes.c_uint64(seed), pk_path.encode(), vk_path.encode()))
 def keygen_from_r1cs(r1cs_path, pk_path, vk_path, seed=0): _check(lib().zkgpu_keygen_from_r1cs(r1cs_path.encode(), ctypes.c_uint64(seed), pk_path.encode(), vk_path.encode()))
@@ -110,6 +110,10 @@ def witness_send(value_A, r_s, sn, r, cmt_s, cmtA, value_s, pk_recv, value_A_new
     _check(lib().zkgpu_witness_send(ctypes.c_uint64(value_A), _s(r_s), _s(sn), _s(r), _s(cmt_s), _s(cmtA), ctypes.c_uint64(value_s), _s(pk_recv), ctypes.c_uint64(value_A_new), _s(sn_A_new), _s(r_A_new), _s(cmt_A_new), _s(sk), _s(pk_sender), path.encode()))
 def witness_mint_redeem(redeem, value, value_old, sn_old, r_old, sn, r, cmtA_old, cmtA, value_s, sk, path):
     _check(lib().zkgpu_witness_mint_redeem(int(redeem), ctypes.c_uint64(value), ctypes.c_uint64(value_old), _s(sn_old), _s(r_old), _s(sn), _s(r), _s(cmtA_old), _s(cmtA), ctypes.c_uint64(value_s), _s(sk), path.encode()))
+
+def witness_deposit(value, value_old, sn_old, r_old, sn, r, sns, rs, cmtB_old, cmtB, value_s, pk, sn_A_old, cmtS, cmtarray, n, sk, path, tree_depth=8):
+    _check(lib().zkgpu_witness_deposit(ctypes.c_uint64(value), ctypes.c_uint64(value_old), _s(sn_old), _s(r_old), _s(sn), _s(r), _s(sns), _s(rs), _s(cmtB_old), _s(cmtB), ctypes.c_uint64(value_s), _s(pk), _s(sn_A_old), _s(cmtS), _s(cmtarray), int(n), _s(sk), int(tree_depth), path.encode()))
+def witness_merkle(depth, leaf32, siblings, position, path): _check(lib().zkgpu_witness_merkle(int(depth), bytes(leaf32), b"".join(bytes(x) for x in siblings), ctypes.c_uint64(position), path.encode()))
 
 class Prover:
     """a reference-format proving key resident in HBM"""
@@ -165,6 +169,10 @@ class Zk:
     def GenSendProof(self, valueA, rS, snA, rA, cmtS, cmtA, valueS, pk_recv, valueANew, snAnew, rAnew, cmtAnew, sk, pk_sender):   # zktx.go:406-430
         return self.L.genSendproof(ctypes.c_uint64(valueA), self.hx(rS), self.hx(snA), self.hx(rA), self.hx(cmtS), self.hx(cmtA), ctypes.c_uint64(valueS), self.hx(pk_recv), ctypes.c_uint64(valueANew), self.hx(snAnew), self.hx(rAnew), self.hx(cmtAnew), self.hx(sk), self.hx(pk_sender)).decode()
     def VerifySendProof(self, proof, cmtA_old, sn_old, cmtS, cmtA_new): return bool(self.L.verifySendproof(proof.encode(), self.hx(cmtA_old), self.hx(sn_old), self.hx(cmtS), self.hx(cmtA_new)))
+    def GenDepositProof(self, value, value_old, sn_old, r_old, sn, r, sns, rs, cmtB_old, cmtB, value_s, pk, sn_A_old, cmtS, cmts, RT, sk):
+        return self.L.genDepositproof(ctypes.c_uint64(value), ctypes.c_uint64(value_old), self.hx(sn_old), self.hx(r_old), self.hx(sn), self.hx(r), self.hx(sns), self.hx(rs), self.hx(cmtB_old), self.hx(cmtB), ctypes.c_uint64(value_s),
+                                      self.hx(pk), self.hx(sn_A_old), self.hx(cmtS), b"".join(self.hx(c) for c in cmts), len(cmts), self.hx(RT), self.hx(sk)).decode()
+    def VerifyDepositProof(self, proof, RT, pk, cmtb_old, sn_old, cmtb, sns): return bool(self.L.verifyDepositproof(proof.encode(), self.hx(RT), self.hx(pk), self.hx(cmtb_old), self.hx(sn_old), self.hx(cmtb), self.hx(sns)))
     def GenMintProof(self, value, value_old, sn_old, r_old, sn, r, cmtA_old, cmtA, value_s, sk):
         return self.L.genMintproof(ctypes.c_uint64(value), ctypes.c_uint64(value_old), self.hx(sn_old), self.hx(r_old), self.hx(sn), self.hx(r), self.hx(cmtA_old), self.hx(cmtA), ctypes.c_uint64(value_s), self.hx(sk)).decode()
     def VerifyMintProof(self, proof, cmtA_old, sn_old, cmtA, value_s): return bool(self.L.verifyMintproof(proof.encode(), self.hx(cmtA_old), self.hx(sn_old), self.hx(cmtA), ctypes.c_uint64(value_s)))

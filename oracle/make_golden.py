@@ -53,13 +53,15 @@ def gadget_fixture():
         res = {}
         for depth, seed in ((2, 5), (8, 6)):
             out = run("merklegadget", str(depth), t + "/r.bin", t + "/w.bin", str(seed)); kv = dict(p.split("=") for p in out.split()[1:])
-            res["depth%d" % depth] = {"seed": seed, "constraints": int(kv["constraints"]), "variables": int(kv["variables"]), "address": int(kv["address"]), "r1cs_sha256": sha(t + "/r.bin"), "witness_sha256": sha(t + "/w.bin")}
+            from test_circuits_cpu import canonical_hash
+            res["depth%d" % depth] = {"canonical_r1cs_sha256": canonical_hash(o.R1CS.load(t + "/r.bin")), "seed": seed, "constraints": int(kv["constraints"]), "variables": int(kv["variables"]), "address": int(kv["address"]), "r1cs_sha256": sha(t + "/r.bin"), "witness_sha256": sha(t + "/w.bin")}
         json.dump(res, open(os.path.join(GOLD, "merkle_gadget.json"), "w"), indent=1)
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    run("vectors", os.path.join(GOLD, "ref_vectors.txt"))
-    groth16_fixture("groth16_small", 7, 3, 40, 60, 99)
-    groth16_fixture("groth16_step", 8, 4, 30, 40, 100)
+    if "--gadgets-only" not in sys.argv:      # the key fixtures come from the reference generator's std::random_device: regenerating them changes pk/vk/proof (consistently)
+        run("vectors", os.path.join(GOLD, "ref_vectors.txt"))
+        groth16_fixture("groth16_small", 7, 3, 40, 60, 99)
+        groth16_fixture("groth16_step", 8, 4, 30, 40, 100)
     gadget_fixture()
     print("golden fixtures written to", GOLD)

@@ -49,3 +49,48 @@ def pack_public(bits_be_blobs, extra_u64=None):
     if extra_u64 is not None:
         for byte in struct.pack("<Q", extra_u64): bits += [(byte >> (7 - j)) & 1 for j in range(8)]
     return [sum(bit << j for j, bit in enumerate(bits[i:i + 253])) for i in range(0, len(bits), 253)]
+
+def merkle_root_and_path(leaves_be, index, depth=8):
+    """tree of 2^depth leaves padded with zero leaves, nodes = SHA-256 compression of left||right (no padding) in blob byte order; returns (root, siblings leaf level first), big-endian like everything else here"""
+    from oracle.pyoracle import lib as _unused  # noqa: F401  (keeps the import graph explicit: the hash below is local)
+    def comp(l, r): return _sha256_compress(l + r)
+    level = [rev(x) for x in leaves_be]; empty = bytes(32); sibs = []; pos = index
+    for d in range(depth):
+        sib = pos ^ 1; sibs.append(level[sib] if sib < len(level) else empty)
+        nxt = [comp(level[i], level[i + 1] if i + 1 < len(level) else empty) for i in range(0, len(level), 2)]
+        level = nxt if nxt else [comp(empty, empty)]; empty = comp(empty, empty); pos >>= 1
+    return rev(level[0]), [rev(s) for s in sibs]
+
+_K = [0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174,
+      0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967,
+      0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+      0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
+def _sha256_compress(block):
+    """one SHA-256 compression of a 64-byte block from the standard IV, no padding (FIPS 180-4 §6.2.2)"""
+    M = 0xFFFFFFFF; rotr = lambda x, n: ((x >> n) | (x << (32 - n))) & M
+    w = list(struct.unpack(">16I", block))
+    for i in range(16, 64):
+        s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3); s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10); w.append((w[i - 16] + s0 + w[i - 7] + s1) & M)
+    H = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]; a, b, c, d, e, f, g, h = H
+    for i in range(64):
+        t1 = (h + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + _K[i] + w[i]) & M; t2 = ((rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c))) & M
+        h, g, f, e, d, c, b, a = g, f, e, (d + t1) & M, c, b, a, (t1 + t2) & M
+    return struct.pack(">8I", *[(x + y) & M for x, y in zip(H, [a, b, c, d, e, f, g, h])])
+
+def deposit_instance(i, n_leaves=16):
+    g = SplitMix64(0x5EED2000 + i)
+    def rb(n): return b"".join(struct.pack(">Q", g.next()) for _ in range((n + 7) // 8))[:n]
+    sk, r_old, r, r_s, sn_A_old = rb(32), rb(32), rb(32), rb(32), rb(32); pk_recv = rb(20); value_old = 1 + g.next() % ((1 << 62) - 1); value_s = 1 + g.next() % ((1 << 61) - 1); value = value_old + value_s
+    sn_old = prf(sk, r_old); cmtB_old = cmt(value_old, sn_old, r_old); sn_s = prf(sk, r_s); cmtS = cmts(value_s, pk_recv, r_s, sn_A_old); sn = prf(sk, r); cmtB = cmt(value, sn, r)
+    index = g.next() % n_leaves; leaves = [rb(32) for _ in range(n_leaves)]; leaves[index] = cmtS; rt, _ = merkle_root_and_path(leaves, index)
+    return dict(sk=sk, r_old=r_old, r=r, r_s=r_s, sn_A_old=sn_A_old, pk_recv=pk_recv, value=value, value_old=value_old, value_s=value_s, sn_old=sn_old, cmtB_old=cmtB_old, sn_s=sn_s, cmtS=cmtS, sn=sn, cmtB=cmtB, leaves=leaves, index=index, rt=rt)
+def reference_deposit_fixture():
+    """libsnark-vnt/src/deposit/main.cpp:131-167,331-333"""
+    def u(h, n=32): return int(h, 16).to_bytes(n, "big")
+    sk, r_old, r, r_s, sn_A_old = u("1"), u("123456"), u("12"), u("123"), u("123"); pk_recv = u("123", 20); value, value_old, value_s = 264, 255, 9
+    sn_old = prf(sk, r_old); cmtB_old = cmt(value_old, sn_old, r_old); sn_s = prf(sk, r_s); cmtS = cmts(value_s, pk_recv, r_s, sn_A_old); sn = prf(sk, r); cmtB = cmt(value, sn, r)
+    leaves = [u(str(k)) for k in range(1, 17)]; leaves[9] = cmtS; rt, _ = merkle_root_and_path(leaves, 9)
+    return dict(sk=sk, r_old=r_old, r=r, r_s=r_s, sn_A_old=sn_A_old, pk_recv=pk_recv, value=value, value_old=value_old, value_s=value_s, sn_old=sn_old, cmtB_old=cmtB_old, sn_s=sn_s, cmtS=cmtS, sn=sn, cmtB=cmtB, leaves=leaves, index=9, rt=rt)
+def deposit_args(d):
+    """argument order of genDepositproof (depositcgo.hpp:13-31) without cmtarray/n/RT/sk, which callers append"""
+    return (d["value"], d["value_old"], d["sn_old"], d["r_old"], d["sn"], d["r"], d["sn_s"], d["r_s"], d["cmtB_old"], d["cmtB"], d["value_s"], d["pk_recv"], d["sn_A_old"], d["cmtS"])
