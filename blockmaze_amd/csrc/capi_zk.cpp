@@ -92,24 +92,24 @@ template <class Fn> static int guarded(Fn fn) {
 template <class Fn> static int guarded_host(Fn fn) { try { return fn(); } catch (const std::exception &e) { zkgpu_set_error(e.what()); return ZKGPU_ERR_RUNTIME; } catch (...) { zkgpu_set_error("unknown error"); return ZKGPU_ERR_RUNTIME; } }
 
 extern "C" {
-char *genCMT(uint64_t value, char *sn_string, char *r_string) { return hash_out(note_cm(value, blob256_from_hex(sn_string), blob256_from_hex(r_string))); }
-char *genCMTS(uint64_t value_s, char *pk_string, char *r_s_string, char *sn_old_string) { return hash_out(note_s_cm(value_s, blob160_from_hex(pk_string), blob256_from_hex(r_s_string), blob256_from_hex(sn_old_string))); }
-char *computePRF(char *sk_string, char *r_string) { return hash_out(compute_prf(blob256_from_hex(sk_string), blob256_from_hex(r_string))); }
-char *computeCRH(char *pk_string, char *r_string) { return hash_out(compute_crh(blob160_from_hex(pk_string), blob256_from_hex(r_string))); }
+char *zkgpu_abi_genCMT(uint64_t value, char *sn_string, char *r_string) { return hash_out(note_cm(value, blob256_from_hex(sn_string), blob256_from_hex(r_string))); }
+char *zkgpu_abi_genCMTS(uint64_t value_s, char *pk_string, char *r_s_string, char *sn_old_string) { return hash_out(note_s_cm(value_s, blob160_from_hex(pk_string), blob256_from_hex(r_s_string), blob256_from_hex(sn_old_string))); }
+char *zkgpu_abi_computePRF(char *sk_string, char *r_string) { return hash_out(compute_prf(blob256_from_hex(sk_string), blob256_from_hex(r_string))); }
+char *zkgpu_abi_computeCRH(char *pk_string, char *r_string) { return hash_out(compute_crh(blob160_from_hex(pk_string), blob256_from_hex(r_string))); }
 static std::vector<Blob256> parse_cmtarray(const char *cmtarray, int n) { std::vector<Blob256> leaves; std::string s = cmtarray ? cmtarray : ""; if (n > 256) n = 256;   // boost::array<uint256, 256> (depositcgo.cpp:304)
   for (int i = 0; i < n; i++) leaves.push_back(blob256_from_hex((size_t)i * 66 < s.size() ? s.substr((size_t)i * 66, 66).c_str() : "")); return leaves; }
-char *genRoot(char *cmtarray, int n) { return hash_out(merkle_root(parse_cmtarray(cmtarray, n), 8)); }
+char *zkgpu_abi_genRoot(char *cmtarray, int n) { return hash_out(merkle_root(parse_cmtarray(cmtarray, n), 8)); }
 
-char *genMintproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk) {
+char *zkgpu_abi_genMintproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk) {
   MintInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn), blob256_from_hex(r), blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
   return generate(CircuitKind::Mint, [&](Circuit &c) { assign_mint(c, in); }); }
-bool verifyMintproof(char *data, char *cmtA_old, char *sn_old, char *cmtA, uint64_t value_s) {   // mint_gadget::witness_map (mint/circuit/gadget.tcc:252-269)
+bool zkgpu_abi_verifyMintproof(char *data, char *cmtA_old, char *sn_old, char *cmtA, uint64_t value_s) {   // mint_gadget::witness_map (mint/circuit/gadget.tcc:252-269)
   std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(cmtA_old).b, 32)); append(bits, blob_bits(blob256_from_hex(sn_old).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtA).b, 32)); append(bits, u64_bits(value_s));
   return verify(CircuitKind::Mint, data, bits); }
-char *genRedeemproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk) {
+char *zkgpu_abi_genRedeemproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk) {
   RedeemInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn), blob256_from_hex(r), blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
   return generate(CircuitKind::Redeem, [&](Circuit &c) { assign_redeem(c, in); }); }
-bool verifyRedeemproof(char *data, char *cmtA_old, char *sn_old, char *cmtA, uint64_t value_s) {
+bool zkgpu_abi_verifyRedeemproof(char *data, char *cmtA_old, char *sn_old, char *cmtA, uint64_t value_s) {
   std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(cmtA_old).b, 32)); append(bits, blob_bits(blob256_from_hex(sn_old).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtA).b, 32)); append(bits, u64_bits(value_s));
   return verify(CircuitKind::Redeem, data, bits); }
 
@@ -117,10 +117,10 @@ static SendInputs send_inputs(uint64_t value_A, char *r_s, char *sn, char *r, ch
   SendInputs in;   // sendcgo.cpp:317-333: note_old = (value_A, sn, r), notes = (value_s, pk_recv, r_s, sn), note_new = (value_A_new, sn_A_new, r_A_new)
   in.value_old = value_A; in.value_s = value_s; in.value = value_A_new; in.sn_old = blob256_from_hex(sn); in.r_old = blob256_from_hex(r); in.r_s = blob256_from_hex(r_s); in.sn = blob256_from_hex(sn_A_new); in.r = blob256_from_hex(r_A_new);
   in.cmtA_old = blob256_from_hex(cmtA); in.cmtS = blob256_from_hex(cmt_s); in.cmtA = blob256_from_hex(cmt_A_new); in.sk = blob256_from_hex(sk); in.pk_recv = blob160_from_hex(pk_recv); in.pk_sender = blob160_from_hex(pk_sender); return in; }
-char *genSendproof(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender) {
+char *zkgpu_abi_genSendproof(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender) {
   SendInputs in = send_inputs(value_A, r_s, sn, r, cmt_s, cmtA, value_s, pk_recv, value_A_new, sn_A_new, r_A_new, cmt_A_new, sk, pk_sender);
   return generate(CircuitKind::Send, [&](Circuit &c) { assign_send(c, in); }); }
-bool verifySendproof(char *data, char *cmtA_old, char *sn_old, char *cmtS, char *cmtA_new) {   // send_gadget::witness_map (send/circuit/gadget.tcc:274-291)
+bool zkgpu_abi_verifySendproof(char *data, char *cmtA_old, char *sn_old, char *cmtS, char *cmtA_new) {   // send_gadget::witness_map (send/circuit/gadget.tcc:274-291)
   std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(cmtA_old).b, 32)); append(bits, blob_bits(blob256_from_hex(sn_old).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtS).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtA_new).b, 32));
   return verify(CircuitKind::Send, data, bits); }
 
@@ -133,9 +133,9 @@ static DepositInputs deposit_inputs(uint64_t value, uint64_t value_old, char *sn
   std::vector<Blob256> leaves = parse_cmtarray(cmtarray, n); size_t index = 0; bool found = false; for (size_t i = 0; i < leaves.size(); i++) if (!memcmp(leaves[i].b, in.cmtS.b, 32)) { index = i; found = true; break; }
   if (!found) throw std::runtime_error("cmtS is not among the commitments of cmtarray");   // the reference throws out of IncrementalMerkleTree::path() here (IncrementalMerkleTree.tcc:214-216), taking the Go process with it
   in.path = merkle_path(leaves, depth, index, in.index_bits); in.rt = merkle_root(leaves, depth); return in; }
-char *genDepositproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old, char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *RT, char *sk) {
+char *zkgpu_abi_genDepositproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old, char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *RT, char *sk) {
   (void)RT; return generate(CircuitKind::Deposit, [&](Circuit &c) { assign_deposit(c, deposit_inputs(value, value_old, sn_old, r_old, sn, r, sns, rs, cmtB_old, cmtB, value_s, pk, sn_A_old, cmtS, cmtarray, n, sk, 8)); }); }
-bool verifyDepositproof(char *data, char *RT, char *pk, char *cmtb_old, char *snold, char *cmtb, char *sns) {   // deposit_gadget::witness_map (deposit/circuit/gadget.tcc:301-323)
+bool zkgpu_abi_verifyDepositproof(char *data, char *RT, char *pk, char *cmtb_old, char *snold, char *cmtb, char *sns) {   // deposit_gadget::witness_map (deposit/circuit/gadget.tcc:301-323)
   std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(RT).b, 32)); append(bits, blob_bits(blob160_from_hex(pk).b, 20)); append(bits, blob_bits(blob256_from_hex(cmtb_old).b, 32)); append(bits, blob_bits(blob256_from_hex(snold).b, 32));
   append(bits, blob_bits(blob256_from_hex(cmtb).b, 32)); append(bits, blob_bits(blob256_from_hex(sns).b, 32)); return verify(CircuitKind::Deposit, data, bits); }
 
@@ -189,4 +189,18 @@ int zkgpu_profile_enable(int on) { return guarded([&] { profile_enable(on != 0);
 int zkgpu_profile_report(char *buf, size_t cap) { return guarded([&] { std::string r = profile_report(); if (r.size() + 1 > cap) return ZKGPU_ERR_ARG; memcpy(buf, r.c_str(), r.size() + 1); return ZKGPU_OK; }); }
 int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs) { int res = 0; int rc = guarded_host([&] { VerifyingKeyHost vk = load_verifying_key(vk_path); Proof p;
   if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK; } res = verify_proof(vk, (const Fe32 *)inputs, n_inputs, p) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
+// the reference's symbol names, exported by libzkgpu.so itself (the four libzk_*.so forward to the zkgpu_abi_* names above)
+char *genCMT(uint64_t v, char *a, char *b) { return zkgpu_abi_genCMT(v, a, b); }
+char *genCMTS(uint64_t v, char *a, char *b, char *c) { return zkgpu_abi_genCMTS(v, a, b, c); }
+char *computePRF(char *a, char *b) { return zkgpu_abi_computePRF(a, b); }
+char *computeCRH(char *a, char *b) { return zkgpu_abi_computeCRH(a, b); }
+char *genRoot(char *a, int n) { return zkgpu_abi_genRoot(a, n); }
+char *genMintproof(uint64_t a, uint64_t b, char *c, char *d, char *e, char *f, char *g, char *h, uint64_t i, char *j) { return zkgpu_abi_genMintproof(a, b, c, d, e, f, g, h, i, j); }
+bool verifyMintproof(char *a, char *b, char *c, char *d, uint64_t e) { return zkgpu_abi_verifyMintproof(a, b, c, d, e); }
+char *genRedeemproof(uint64_t a, uint64_t b, char *c, char *d, char *e, char *f, char *g, char *h, uint64_t i, char *j) { return zkgpu_abi_genRedeemproof(a, b, c, d, e, f, g, h, i, j); }
+bool verifyRedeemproof(char *a, char *b, char *c, char *d, uint64_t e) { return zkgpu_abi_verifyRedeemproof(a, b, c, d, e); }
+char *genSendproof(uint64_t a, char *b, char *c, char *d, char *e, char *f, uint64_t g, char *h, uint64_t i, char *j, char *k, char *l, char *m, char *n) { return zkgpu_abi_genSendproof(a, b, c, d, e, f, g, h, i, j, k, l, m, n); }
+bool verifySendproof(char *a, char *b, char *c, char *d, char *e) { return zkgpu_abi_verifySendproof(a, b, c, d, e); }
+char *genDepositproof(uint64_t a, uint64_t b, char *c, char *d, char *e, char *f, char *g, char *h, char *i, char *j, uint64_t k, char *l, char *m, char *n, char *o, int p, char *q, char *r) { return zkgpu_abi_genDepositproof(a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p, q, r); }
+bool verifyDepositproof(char *a, char *b, char *c, char *d, char *e, char *f, char *g) { return zkgpu_abi_verifyDepositproof(a, b, c, d, e, f, g); }
 }  // extern "C"

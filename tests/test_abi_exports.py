@@ -37,3 +37,34 @@ def test_domain_size_matches_oracle(zkgpu):
     zkgpu.zkgpu_domain_size.restype = ctypes.c_size_t; zkgpu.zkgpu_domain_size.argtypes = [ctypes.c_size_t]
     for m in [2, 3, 5, 16, 17, 24, 100, 167275, 252292, 503870, 1177046, 1 << 20]:
         assert zkgpu.zkgpu_domain_size(m) == o.domain_size(m), m
+
+SYMS = {"zk_mint": ["genCMT", "computePRF", "genMintproof", "verifyMintproof"], "zk_redeem": ["genCMT", "computePRF", "genRedeemproof", "verifyRedeemproof"],
+        "zk_send": ["genCMT", "genCMTS", "computePRF", "computeCRH", "genSendproof", "verifySendproof"], "zk_deposit": ["genCMT", "genCMTS", "computePRF", "genRoot", "genDepositproof", "verifyDepositproof"]}
+
+def test_dropin_libraries_export_exactly_the_reference_symbols(zkgpu):
+    """13 distinct symbols, 20 definitions (mint 4, send 6, deposit 6, redeem 4); headers in include/ declare the same sets"""
+    import subprocess
+    for lib, syms in SYMS.items():
+        path = os.path.join(ROOT, "blockmaze_amd", "lib", "lib%s.so" % lib); out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+        defined = sorted(l.split()[-1] for l in out.splitlines() if " T " in l); assert defined == sorted(syms), lib
+        assert sorted(set(declared_symbols(lib + ".h") + declared_symbols("zk_common.h"))) == sorted(syms), lib
+        ctypes.CDLL(path)                                                    # loads (resolves libzkgpu.so through its rpath)
+    for s in sorted(set(sum(SYMS.values(), []))): assert hasattr(zkgpu, s) and hasattr(zkgpu, "zkgpu_abi_" + s)
+    for stub in ("libff.so", "libsnark.so"): assert os.path.exists(os.path.join(ROOT, "blockmaze_amd", "lib", stub))
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory, zkgpu):
+    import subprocess
+    exe = str(tmp_path_factory.mktemp("drv") / "dropin_driver"); lib = os.path.join(ROOT, "blockmaze_amd", "lib")
+    subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(ROOT, "tests", "dropin_driver.c"), "-L" + lib, "-lzk_mint", "-lzk_send", "-lzk_deposit", "-lzk_redeem", "-lff", "-lsnark",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath-link," + os.path.join(ROOT, "blockmaze_amd")])     # the reference's cgo link line (zktx.go:4) minus gmp/stdc++
+    return exe
+
+def test_c_driver_links_like_cgo_and_hashes_match(driver):
+    import subprocess
+    out = dict(l.split() for l in subprocess.run([driver, "hashes"], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert out["computePRF"] == "98a493490d506d579a6af5bd1d179e471de2be83252014f9db7c2a4c61b1472c" and out["genCMT0"] == "0044f0b699cd2d866c8da0201dcc2a8b28bdf7d47f39e13ebe4e53a29b704a83"
+    assert out["computeCRH"] == "53d843629c72b6d8fff202285172ec85389122fa7c71251bea73832d3c4a7029" and out["genRoot0"] == "8eb3c27b218349e6b9b6037b8042f3751ee820e8a0319a1bda439b247456088c"
+    import hashlib, struct
+    sk = b"\x01" * 32; r = bytes(range(32)); pk = bytes.fromhex("00112233445566778899aabbccddeeff00112233")
+    assert out["genCMTS"] == hashlib.sha256(struct.pack("<Q", 77) + pk[::-1] + r[::-1] + sk[::-1]).digest()[::-1].hex()   # = rev(SHA256(LE64(v) | rev(pk) | rev(r_s) | rev(sn))), SURVEY.md §8c

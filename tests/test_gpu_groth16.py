@@ -77,3 +77,31 @@ def test_dropin_symbols_send(send_keys, monkeypatch):
     sentinel = zk.GenSendProof(*w.send_args(bad)); assert sentinel.startswith("0000000000") and sentinel[:128] == "%064x%064x" % (1, 2)
     assert not zk.VerifySendProof(sentinel, d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"])
     monkeypatch.setenv("ZK_FIXED_RS", "1234:5678"); a = zk.GenSendProof(*w.send_args(d)); b = zk.GenSendProof(*w.send_args(d)); assert a == b and zk.VerifySendProof(a, d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"])
+
+@pytest.fixture(scope="module")
+def all_keys(tmp_path_factory, send_keys):
+    """config 4 of BASELINE.json: all four pk/vk pairs in one key directory"""
+    d = send_keys
+    for kind in ("mint", "redeem", "deposit"): e.keygen(kind, str(d / (kind + "pk.txt")), str(d / (kind + "vk.txt")), seed=0xB10C4A2E + len(kind))
+    return d
+
+def test_dropin_symbols_all_four_circuits_mixed(all_keys, monkeypatch):
+    """mint + redeem (step domain 196,608), deposit (2^19, depth-8 Merkle), send (2^18), interleaved on one GPU through the cgo symbols"""
+    monkeypatch.setenv("ZK_PRFKEY_DIR", str(all_keys)); zk = e.Zk()
+    for rnd in range(2):
+        m = w.mint_instance(rnd); p = zk.GenMintProof(*w.mint_args(m)); assert len(p) == 512 and zk.VerifyMintProof(p, m["cmtA_old"], m["sn_old"], m["cmtA"], m["value_s"]) and not zk.VerifyMintProof(p, m["cmtA_old"], m["sn_old"], m["cmtA"], m["value_s"] + 1)
+        dd = w.deposit_instance(rnd); p = zk.GenDepositProof(*w.deposit_args(dd), dd["leaves"], dd["rt"], dd["sk"])
+        assert zk.VerifyDepositProof(p, dd["rt"], dd["pk_recv"], dd["cmtB_old"], dd["sn_old"], dd["cmtB"], dd["sn_s"]) and not zk.VerifyDepositProof(p, dd["cmtB"], dd["pk_recv"], dd["cmtB_old"], dd["sn_old"], dd["cmtB"], dd["sn_s"])
+        r = w.mint_instance(rnd, redeem=True); p = zk.GenRedeemProof(*w.mint_args(r)); assert zk.VerifyRedeemProof(p, r["cmtA_old"], r["sn_old"], r["cmtA"], r["value_s"])
+        s = w.send_instance(10 + rnd); p = zk.GenSendProof(*w.send_args(s)); assert zk.VerifySendProof(p, s["cmtA_old"], s["sn_old"], s["cmtS"], s["cmtA"])
+    bad = dict(r); bad["value_s"] = r["value_old"] + 1; bad["value"] = 0; assert zk.GenRedeemProof(*w.mint_args(bad)).startswith("0000000000")       # value_s > value_old
+    dd = w.reference_deposit_fixture(); p = zk.GenDepositProof(*w.deposit_args(dd), dd["leaves"], dd["rt"], dd["sk"]); assert zk.VerifyDepositProof(p, dd["rt"], dd["pk_recv"], dd["cmtB_old"], dd["sn_old"], dd["cmtB"], dd["sn_s"])
+    wrong_rt = bytes.fromhex("39524a6ae253fca75a89240d93c0c6d893bcb66e783606dbb1fc7dff92dc543c"); assert not zk.VerifyDepositProof(p, wrong_rt, dd["pk_recv"], dd["cmtB_old"], dd["sn_old"], dd["cmtB"], dd["sn_s"])   # deposit/main.cpp wrong_rt (SURVEY.md §8c)
+    missing = dict(dd); missing["leaves"] = dd["leaves"][:9]; assert zk.GenDepositProof(*w.deposit_args(missing), missing["leaves"], dd["rt"], dd["sk"]).startswith("0000000000")   # cmtS not in cmtarray: sentinel, not a crash
+
+def test_c_driver_send_through_thin_libraries(send_keys, tmp_path):
+    """tests/dropin_driver.c linked with the reference's cgo link line: genSendproof + verifySendproof on the reference's send fixture"""
+    lib = os.path.join(ROOT, "blockmaze_amd", "lib"); exe = str(tmp_path / "drv")
+    subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(ROOT, "tests", "dropin_driver.c"), "-L" + lib, "-lzk_mint", "-lzk_send", "-lzk_deposit", "-lzk_redeem", "-lff", "-lsnark", "-Wl,-rpath," + lib, "-Wl,-rpath-link," + os.path.join(ROOT, "blockmaze_amd")])
+    out = subprocess.run([exe, "send"], capture_output=True, text=True, env=dict(os.environ, ZK_PRFKEY_DIR=str(send_keys))).stdout
+    assert "proof_len 512" in out and "verify 1" in out and "verify_wrong 0" in out and "head 0000000000" not in out
