@@ -24,7 +24,9 @@ HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s
 
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true"); args = ap.parse_args()
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-msm", action="store_true", help="N > 1 only: all ranks prove ONE proof per step together, each holding 1/N of every query; one all-gather of 384-byte partial records per proof (strong scaling)")
+    args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("ZK_DEVICE", str(local_rank))
     import torch
@@ -41,40 +43,48 @@ def main():
     # ---- untimed setup: test keys for the send circuit (seeded toxic waste), resident prover, witnesses -----------------
     tmp = tempfile.mkdtemp(prefix="zkbench_%d_" % rank); pk_path, vk_path = os.path.join(tmp, "sendpk.txt"), os.path.join(tmp, "sendvk.txt")
     t0 = time.time(); e.keygen("send", pk_path, vk_path, seed=0xB10C4A2E); t_keygen = time.time() - t0
-    t0 = time.time(); prover = e.Prover(pk_path); t_load = time.time() - t0
+    shard = args.shard_msm and world > 1
+    t0 = time.time(); prover = e.Prover(pk_path, rank, world) if shard else e.Prover(pk_path); t_load = time.time() - t0
     n_inst = 4; insts, zs = [], []
     for i in range(n_inst):
-        d = w.send_instance(rank + i * world); wp = os.path.join(tmp, "w%d.bin" % i)
+        d = w.send_instance(i if shard else rank + i * world); wp = os.path.join(tmp, "w%d.bin" % i)
         e.witness_send(*[("0x" + a.hex()) if isinstance(a, bytes) else a for a in w.send_args(d)], wp); insts.append(d); zs.append(o.load_witness(wp))
 
     def barrier():
         if dist is not None: dist.barrier()
         if torch.cuda.is_available(): torch.cuda.synchronize()
 
+    from blockmaze_amd import sharding
     prover.set_witness(zs[0])                                                  # the assignment is resident in HBM before the timed region starts
-    for i in range(args.warmup): prover.prove_resident()
+    if shard:
+        def one_proof(i):                                                      # every rank runs the device pipeline on its slice; 384 B per rank are exchanged; rank 0 assembles
+            recs = sharding.gather_partials(prover.prove_partial(), dist, "cuda")
+            return prover.finish(recs, 0x1234567 + i, 0x7654321 + i) if rank == 0 else None
+    else:
+        def one_proof(i): return prover.prove_resident()                        # synchronous: fresh (r, s), returns the serialized proof
+    for i in range(args.warmup): one_proof(i)
     barrier(); t0 = time.perf_counter()
     last = None
-    for i in range(args.steps): last = prover.prove_resident()                # synchronous: fresh (r, s), returns the serialized proof
+    for i in range(args.steps): last = one_proof(i)
     barrier(); dt = time.perf_counter() - t0
-    from blockmaze_amd import sharding
-    rate, dt = sharding.aggregate_throughput(args.steps, dt, dist, "cuda" if dist is not None else None)      # max over ranks, units summed
+    rate, dt = sharding.aggregate_throughput((args.steps if rank == 0 else 0) if shard else args.steps, dt, dist, "cuda" if dist is not None else None)      # max over ranks, units summed
     d = insts[0]
-    assert e.verify(vk_path, last, w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]])), "proof from the timed region does not verify"
+    assert last is None or e.verify(vk_path, last, w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]])), "proof from the timed region does not verify"
 
     # ---- not part of `value`: the same proofs with the witness handed over as a host buffer each time (PCIe inclusive), and through the
     # drop-in cgo symbol genSendproof (adds witness generation on the host and hex marshalling)
-    t0 = time.perf_counter(); nx = max(3, min(args.steps, 10))
-    for i in range(nx): prover.prove(zs[i % n_inst])
-    ms_pcie = 1e3 * (time.perf_counter() - t0) / nx
-    os.environ["ZK_PRFKEY_DIR"] = tmp; zk = e.Zk(); zk.GenSendProof(*w.send_args(insts[0])); t0 = time.perf_counter()
-    import contextlib, io
-    for i in range(nx): zk.GenSendProof(*w.send_args(insts[i % n_inst]))
-    ms_abi = 1e3 * (time.perf_counter() - t0) / nx
+    nx = max(3, min(args.steps, 10)); ms_pcie = ms_abi = None
+    if not shard:
+        t0 = time.perf_counter()
+        for i in range(nx): prover.prove(zs[i % n_inst])
+        ms_pcie = 1e3 * (time.perf_counter() - t0) / nx
+        os.environ["ZK_PRFKEY_DIR"] = tmp; zk = e.Zk(); zk.GenSendProof(*w.send_args(insts[0])); t0 = time.perf_counter()
+        for i in range(nx): zk.GenSendProof(*w.send_args(insts[i % n_inst]))
+        ms_abi = 1e3 * (time.perf_counter() - t0) / nx
 
     # ---- roofline leg: HIP-event time of the dominant kernel, same stream, after the timed region --------------------------
     e.profile_enable(True); nprof = max(3, min(args.steps, 10))
-    for i in range(nprof): prover.prove_resident()
+    for i in range(nprof): one_proof(i)
     stages = e.profile_report(); e.profile_enable(False)
     per_proof = {k: v["ms_total"] / nprof for k, v in stages.items()}
     dom = "msm_H.accumulate"; dom_ms = stages[dom]["ms_total"] / stages[dom]["count"]
@@ -108,10 +118,10 @@ def main():
         total = args.steps * world
         print(json.dumps({
             "metric": "Groth16 proofs/sec (send circuit, alt_bn128)", "value": round(rate, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery)", "data": "synthetic",
-            "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": world, "parallelism": "independent proofs per GPU, no collective",
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery)", "data": "synthetic",
+            "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
                        "includes": "R1CS rows + 7 NTT + 5 MSM + host proof assembly + hex serialisation, assignment resident in HBM; excludes witness generation and key load"},
-            "ms_per_proof_host_buffer_in": round(ms_pcie, 4), "ms_per_proof_through_genSendproof": round(ms_abi, 4),
+            "ms_per_proof_host_buffer_in": ms_pcie and round(ms_pcie, 4), "ms_per_proof_through_genSendproof": ms_abi and round(ms_abi, 4),
             "roofline": roofline, "cpu_baseline": cpu,
             "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2)}}))
     prover.close()

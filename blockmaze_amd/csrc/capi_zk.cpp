@@ -176,7 +176,11 @@ int zkgpu_keygen_from_r1cs(const char *r1cs_path, uint64_t seed, const char *pk_
 int zkgpu_keygen(int kind, int tree_depth, uint64_t seed, const char *pk_path, const char *vk_path) { return guarded([&] { std::unique_ptr<Circuit> c = kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true);
   ProvingKeyHost pk; VerifyingKeyHost vk; generate_keys(c->r1cs(), seed ? ToxicWaste::from_seed(seed) : ToxicWaste::random(), pk, vk); save_proving_key(pk_path, pk); save_verifying_key(vk_path, vk); return ZKGPU_OK; }); }
 
-zkgpu_prover *zkgpu_prover_load(const char *pk_path) { zkgpu_prover *h = nullptr; guarded([&] { ProvingKeyHost pk = load_proving_key(pk_path); std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(pk)); h = p.release(); return ZKGPU_OK; }); return h; }
+zkgpu_prover *zkgpu_prover_load_shard(const char *pk_path, size_t shard_rank, size_t shard_world) { zkgpu_prover *h = nullptr; guarded([&] { ProvingKeyHost pk = load_proving_key(pk_path); std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(pk, shard_rank, shard_world)); h = p.release(); return ZKGPU_OK; }); return h; }
+zkgpu_prover *zkgpu_prover_load(const char *pk_path) { return zkgpu_prover_load_shard(pk_path, 0, 1); }
+int zkgpu_prover_prove_partial(zkgpu_prover *h, uint8_t out[384]) { return guarded([&] { if (!h) return ZKGPU_ERR_ARG; if (!h->p->prove_partial(out)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } return ZKGPU_OK; }); }
+int zkgpu_prover_finish(zkgpu_prover *h, const uint8_t *records, size_t n, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_host([&] { if (!h) return ZKGPU_ERR_ARG; Proof p; h->p->finish_from_partials(records, n, (const Fe32 *)r, (const Fe32 *)s, p);
+  std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
 void zkgpu_prover_destroy(zkgpu_prover *h) { guarded([&] { delete h; return ZKGPU_OK; }); }
 int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]) { if (!h) return ZKGPU_ERR_ARG; out[0] = h->p->num_variables(); out[1] = h->p->num_inputs(); out[2] = h->p->domain_size(); return ZKGPU_OK; }
 int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded([&] { if (!h) return ZKGPU_ERR_ARG; Proof p;

@@ -183,17 +183,21 @@ void generate_keys(const R1csHost &cs_in, const ToxicWaste &tw, ProvingKeyHost &
 // prover
 // ======================================================================================================================
 struct Prover::Impl {
-  size_t nv, ni, m; HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
+  size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
+  HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
   std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; PinnedBuf<Fe32> z_host;
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
-Prover::Prover(const ProvingKeyHost &pk) : impl(new Impl) {
-  Impl &p = *impl; p.nv = pk.cs.n_vars; p.ni = pk.cs.n_inputs; p.cs.reset(new R1csDev(pk.cs)); p.dom.reset(new Domain(pk.cs.n_cons + p.ni + 1)); p.m = p.dom->m();
+static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &e) { size_t base = n / world, rem = n % world; b = rank * base + (rank < rem ? rank : rem); e = b + base + (rank < rem ? 1 : 0); }
+Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) : impl(new Impl) {
+  Impl &p = *impl; p.nv = pk.cs.n_vars; p.ni = pk.cs.n_inputs; if (shard_world == 0 || shard_rank >= shard_world) throw std::runtime_error("prover: bad shard"); p.cs.reset(new R1csDev(pk.cs)); p.dom.reset(new Domain(pk.cs.n_cons + p.ni + 1)); p.m = p.dom->m();
   if (pk.A.size() != p.nv + 1 || pk.H.size() != p.m - 1 || pk.L.size() != p.nv - p.ni) throw std::runtime_error("proving key: query sizes do not match the constraint system");
   p.alpha_g1 = g1_of(pk.alpha_g1); p.beta_g1 = g1_of(pk.beta_g1); p.delta_g1 = g1_of(pk.delta_g1); p.beta_g2 = g2_of(pk.beta_g2); p.delta_g2 = g2_of(pk.delta_g2);
   int cw = env_int("ZK_MSM_WITNESS_WINDOW", 8), ch = env_int("ZK_MSM_H_WINDOW", 16);
-  p.A.reset(new MsmG1(pk.A.data(), pk.A.size(), cw, true)); p.L.reset(new MsmG1(pk.L.data(), pk.L.size(), cw, true));
-  p.B1.reset(new MsmG1(pk.B_g1.data(), pk.B_g1.size(), cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data(), pk.B_g2.size(), cw, true)); p.H.reset(new MsmG1(pk.H.data(), pk.H.size(), ch, false));
+  size_t e; shard_range(pk.A.size(), shard_rank, shard_world, p.a0, e); size_t nA = e - p.a0; shard_range(pk.L.size(), shard_rank, shard_world, p.l0, e); size_t nL = e - p.l0;
+  shard_range(pk.B_idx.size(), shard_rank, shard_world, p.b0, e); size_t nB = e - p.b0; shard_range(pk.H.size(), shard_rank, shard_world, p.h0, e); size_t nH = e - p.h0;
+  p.A.reset(new MsmG1(pk.A.data() + p.a0, nA, cw, true)); p.L.reset(new MsmG1(pk.L.data() + p.l0, nL, cw, true));
+  p.B1.reset(new MsmG1(pk.B_g1.data() + p.b0, nB, cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data() + p.b0, nB, cw, true)); p.H.reset(new MsmG1(pk.H.data() + p.h0, nH, ch, false));
   p.A->set_stream(0); p.L->set_stream(1); p.B1->set_stream(2); p.B2->set_stream(3);   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
   p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
   p.B_idx = DevBuf<uint32_t>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx.upload(pk.B_idx.data(), pk.B_idx.size());
@@ -210,26 +214,45 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * (p.nv + 1)); if (!montgomery) fr_to_mont_dev(p.z.get(), p.nv + 1);
   last.upload_ms = now_ms() - t0;
 }
-bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
-  Impl &p = *impl; double t1 = now_ms();
+struct RsTerms { HFr r, s; HG1 r_delta, s_delta, rs_delta_neg; HG2 s_delta2; };
+static RsTerms rs_terms(const Fe32 *r_in, const Fe32 *s_in, const HG1 &delta_g1, const HG2 &delta_g2) {   // everything that depends only on (r, s) and the key (:488-495)
+  RsTerms t; t.r = r_in ? fr_of(*r_in) : random_fr().from_mont(); t.s = s_in ? fr_of(*s_in) : random_fr().from_mont(); HFr rs = (t.r.to_mont() * t.s.to_mont()).from_mont();   // canonical scalars
+  t.r_delta = delta_g1.mul(t.r.l); t.s_delta = delta_g1.mul(t.s.l); t.rs_delta_neg = delta_g1.mul(rs.l).neg(); t.s_delta2 = delta_g2.mul(t.s.l); return t; }
+static void enqueue_all(Prover::Impl &p) {
   gpu_fork_aux();
-  p.A->run(p.z.get(), nullptr); p.L->run(p.z.get() + p.ni + 1, nullptr); p.B1->run(p.z.get(), p.B_idx.get()); p.B2->run(p.z.get(), p.B_idx.get());   // r1cs_gg_ppzksnark.tcc:442-462,477-484
+  p.A->run(p.z.get() + p.a0, nullptr); p.L->run(p.z.get() + p.ni + 1 + p.l0, nullptr); p.B1->run(p.z.get(), p.B_idx.get() + p.b0); p.B2->run(p.z.get(), p.B_idx.get() + p.b0);   // r1cs_gg_ppzksnark.tcc:442-462,477-484
   p.cs->eval(p.z.get(), p.abc.get(), p.m);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the satisfiability flag is read back together with the results
   p.cs->check_async(p.abc.get(), p.m);
   p.dom->ifft(p.abc.get(), 3, p.m); p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); p.dom->icoset_fft(p.abc.get(), 1, p.m);
-  p.H->run(p.abc.get(), nullptr);                                                                                         // :466-473
-  // while the device works: everything that depends only on (r, s) and the key  (:488-495)
-  HFr r = r_in ? fr_of(*r_in) : random_fr().from_mont(), s = s_in ? fr_of(*s_in) : random_fr().from_mont(), rs = (r.to_mont() * s.to_mont()).from_mont();   // canonical scalars
-  HG1 r_delta = p.delta_g1.mul(r.l), s_delta = p.delta_g1.mul(s.l), rs_delta_neg = p.delta_g1.mul(rs.l).neg(); HG2 s_delta2 = p.delta_g2.mul(s.l);
+  p.H->run(p.abc.get() + p.h0, nullptr);                                                                                  // :466-473
+}
+static void assemble(const Prover::Impl &p, const RsTerms &t, const HG1 &eA, const HG1 &eB1, const HG2 &eB2, const HG1 &eH, const HG1 &eL, Proof &out) {
+  HG1 gA = p.alpha_g1.add(eA).add(t.r_delta);                                                                            // :488
+  HG1 gB1 = p.beta_g1.add(eB1).add(t.s_delta); HG2 gB2 = p.beta_g2.add(eB2).add(t.s_delta2);                            // :491-492
+  HG1 gC = eH.add(eL).add(gA.mul(t.s.l)).add(gB1.mul(t.r.l)).add(t.rs_delta_neg);                                       // :495
+  out.A = raw_of(gA); out.B = raw_of(gB2); out.C = raw_of(gC); }
+bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
+  Impl &p = *impl; double t1 = now_ms(); enqueue_all(p);
+  RsTerms t = rs_terms(r_in, s_in, p.delta_g1, p.delta_g2);                                                              // host work overlapped with the kernels
   double t2 = now_ms(); gpu_sync(); double t3 = now_ms();
   if (!p.cs->check_result()) return false;
   HG1 eH = p.H->result(), eA = p.A->result(), eL = p.L->result(), eB1 = p.B1->result(); HG2 eB2 = p.B2->result();
-  HG1 gA = p.alpha_g1.add(eA).add(r_delta);                                                                              // :488
-  HG1 gB1 = p.beta_g1.add(eB1).add(s_delta); HG2 gB2 = p.beta_g2.add(eB2).add(s_delta2);                                // :491-492
-  HG1 gC = eH.add(eL).add(gA.mul(s.l)).add(gB1.mul(r.l)).add(rs_delta_neg);                                             // :495
-  out.A = raw_of(gA); out.B = raw_of(gB2); out.C = raw_of(gC); double t4 = now_ms();
+  assemble(p, t, eA, eB1, eB2, eH, eL, out); double t4 = now_ms();
   last.qap_ms = t2 - t1; last.msm_ms = t3 - t1; last.finish_ms = t4 - t3; last.total_ms = last.upload_ms + (t4 - t1); return true;
+}
+static void put_canon_g1(const HG1 &p, uint8_t *o) { HFq x, y; p.to_affine(x, y); x = x.from_mont(); y = y.from_mont(); memcpy(o, x.l, 32); memcpy(o + 32, y.l, 32); }
+static HG1 get_canon_g1(const uint8_t *o) { HFq x, y; memcpy(x.l, o, 32); memcpy(y.l, o + 32, 32); if (x.is_zero() && y.is_zero()) return HG1::inf(); return HG1::from_affine(x.to_mont(), y.to_mont()); }
+bool Prover::prove_partial(uint8_t out[PARTIAL_BYTES]) {
+  Impl &p = *impl; enqueue_all(p); gpu_sync(); if (!p.cs->check_result()) return false;
+  put_canon_g1(p.A->result(), out); put_canon_g1(p.B1->result(), out + 64); put_canon_g1(p.H->result(), out + 128); put_canon_g1(p.L->result(), out + 192);
+  HFq2 x, y; p.B2->result().to_affine(x, y); HFq v[4] = {x.c0.from_mont(), x.c1.from_mont(), y.c0.from_mont(), y.c1.from_mont()}; for (int k = 0; k < 4; k++) memcpy(out + 256 + 32 * k, v[k].l, 32); return true;
+}
+void Prover::finish_from_partials(const uint8_t *records, size_t n, const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
+  Impl &p = *impl; HG1 eA = HG1::inf(), eB1 = HG1::inf(), eH = HG1::inf(), eL = HG1::inf(); HG2 eB2 = HG2::inf();
+  for (size_t k = 0; k < n; k++) { const uint8_t *q = records + k * PARTIAL_BYTES; eA = eA.add(get_canon_g1(q)); eB1 = eB1.add(get_canon_g1(q + 64)); eH = eH.add(get_canon_g1(q + 128)); eL = eL.add(get_canon_g1(q + 192));
+    HFq v[4]; bool z = true; for (int i = 0; i < 4; i++) { memcpy(v[i].l, q + 256 + 32 * i, 32); if (!v[i].is_zero()) z = false; v[i] = v[i].to_mont(); } if (!z) eB2 = eB2.add(HG2::from_affine(HFq2{v[0], v[1]}, HFq2{v[2], v[3]})); }
+  assemble(p, rs_terms(r_in, s_in, p.delta_g1, p.delta_g2), eA, eB1, eB2, eH, eL, out);
 }
 
 // ======================================================================================================================

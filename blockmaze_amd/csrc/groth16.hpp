@@ -37,7 +37,9 @@ void generate_keys(const R1csHost &cs, const ToxicWaste &tw, ProvingKeyHost &pk,
 // ---- prover (r1cs_gg_ppzksnark.tcc:391-506) -------------------------------------------------------------------------------
 class Prover {                                    // a proving key resident in HBM
  public:
-  explicit Prover(const ProvingKeyHost &pk); ~Prover();
+  // shard_rank / shard_world: this object holds only the contiguous slice [n*rank/world, n*(rank+1)/world) of every query (kernel K7);
+  // a sharded prover produces partial sums (prove_partial), any process then adds the ranks' partials and assembles the proof (finish_from_partials)
+  explicit Prover(const ProvingKeyHost &pk, size_t shard_rank = 0, size_t shard_world = 1); ~Prover();
   size_t num_variables() const; size_t num_inputs() const; size_t domain_size() const;
   // z: full assignment without ONE (canonical).  r, s: prover randomness (canonical; nullptr = fresh CSPRNG values).
   // Returns false if z does not satisfy the constraint system (the reference then emits its default proof, sendcgo.cpp:209-214).
@@ -45,6 +47,11 @@ class Prover {                                    // a proving key resident in H
   // the two halves of prove(): hand the assignment over (canonical, or already in Montgomery form as the circuit boards hold it), then prove from HBM
   void set_witness(const Fe32 *z, bool montgomery);
   bool prove_resident(const Fe32 *r, const Fe32 *s, Proof &out);
+  // partial multi-exponentiation results of this shard, affine canonical: eA(64) eB1(64) eH(64) eL(64) eB2(128) = 384 bytes.  false if z is unsatisfying.
+  static constexpr size_t PARTIAL_BYTES = 384;
+  bool prove_partial(uint8_t out[PARTIAL_BYTES]);
+  // sum `n` shard records and assemble the proof (r1cs_gg_ppzksnark.tcc:487-495); needs only the key's alpha/beta/delta, no device work
+  void finish_from_partials(const uint8_t *records, size_t n, const Fe32 *r, const Fe32 *s, Proof &out);
   struct Timings { double upload_ms, qap_ms, msm_ms, finish_ms, total_ms; } last{};
   struct Impl; std::unique_ptr<Impl> impl;
 };

@@ -117,9 +117,9 @@ def witness_merkle(depth, leaf32, siblings, position, path): _check(lib().zkgpu_
 
 class Prover:
     """a reference-format proving key resident in HBM"""
-    def __init__(self, pk_path):
-        lib().zkgpu_prover_load.restype = ctypes.c_void_p
-        self.h = lib().zkgpu_prover_load(pk_path.encode())
+    def __init__(self, pk_path, shard_rank=0, shard_world=1):
+        lib().zkgpu_prover_load_shard.restype = ctypes.c_void_p
+        self.h = lib().zkgpu_prover_load_shard(pk_path.encode(), ctypes.c_size_t(shard_rank), ctypes.c_size_t(shard_world))
         if not self.h: raise ZkGpuError(lib().zkgpu_last_error().decode())
         info = (ctypes.c_size_t * 3)(); _check(lib().zkgpu_prover_info(ctypes.c_void_p(self.h), info)); self.n_vars, self.n_inputs, self.m = (int(x) for x in info)
     def prove(self, z, r=None, s=None):
@@ -132,6 +132,13 @@ class Prover:
     def prove_resident(self, r=None, s=None):
         R = int(r).to_bytes(32, "little") if r is not None else None; S = int(s).to_bytes(32, "little") if s is not None else None
         out = ctypes.create_string_buffer(513); _check(lib().zkgpu_prover_prove_resident(ctypes.c_void_p(self.h), R, S, out)); return out.value.decode()
+    def prove_partial(self):
+        """this shard's 384-byte record of partial sums (device pipeline on the resident witness)"""
+        out = ctypes.create_string_buffer(384); _check(lib().zkgpu_prover_prove_partial(ctypes.c_void_p(self.h), out)); return out.raw
+    def finish(self, records, r, s):
+        """add the shard records (list of 384-byte strings, any order) and assemble the proof with the given randomness"""
+        buf = b"".join(records); out = ctypes.create_string_buffer(513)
+        _check(lib().zkgpu_prover_finish(ctypes.c_void_p(self.h), buf, ctypes.c_size_t(len(records)), int(r).to_bytes(32, "little"), int(s).to_bytes(32, "little"), out)); return out.value.decode()
     def timings(self):
         t = (ctypes.c_double * 5)(); _check(lib().zkgpu_prover_timings(ctypes.c_void_p(self.h), t)); return dict(zip(("upload_ms", "enqueue_ms", "device_ms", "finish_ms", "total_ms"), (float(x) for x in t)))
     def close(self):

@@ -90,6 +90,12 @@ int zkgpu_keygen_from_r1cs(const char *r1cs_path, uint64_t seed, const char *pk_
 /* resident prover over a reference-format proving key file */
 typedef struct zkgpu_prover zkgpu_prover;
 zkgpu_prover *zkgpu_prover_load(const char *pk_path);
+/* MSM sharding across GPUs (one process per GPU): a shard holds the contiguous slice rank/world of every query of the key.  prove_partial() runs the whole
+ * device pipeline on the resident witness and returns this shard's five partial sums (affine canonical: eA 64 | eB1 64 | eH 64 | eL 64 | eB2 128 = 384 bytes);
+ * the records of all ranks are exchanged by the caller (one all-gather) and zkgpu_prover_finish() adds them and assembles the proof on the host. */
+zkgpu_prover *zkgpu_prover_load_shard(const char *pk_path, size_t shard_rank, size_t shard_world);
+int zkgpu_prover_prove_partial(zkgpu_prover *h, uint8_t out[384]);
+int zkgpu_prover_finish(zkgpu_prover *h, const uint8_t *records, size_t n_records, const uint8_t *r, const uint8_t *s, char proof_hex[513]);
 void zkgpu_prover_destroy(zkgpu_prover *h);
 int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]);          /* n_vars, n_inputs, domain size m */
 /* z: n_vars elements; r, s: 32-byte canonical prover randomness or NULL for fresh values.  proof_hex: 512 hex characters + NUL. */

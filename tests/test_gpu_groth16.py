@@ -105,3 +105,17 @@ def test_c_driver_send_through_thin_libraries(send_keys, tmp_path):
     subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(ROOT, "tests", "dropin_driver.c"), "-L" + lib, "-lzk_mint", "-lzk_send", "-lzk_deposit", "-lzk_redeem", "-lff", "-lsnark", "-Wl,-rpath," + lib, "-Wl,-rpath-link," + os.path.join(ROOT, "blockmaze_amd")])
     out = subprocess.run([exe, "send"], capture_output=True, text=True, env=dict(os.environ, ZK_PRFKEY_DIR=str(send_keys))).stdout
     assert "proof_len 512" in out and "verify 1" in out and "verify_wrong 0" in out and "head 0000000000" not in out
+
+def test_msm_sharding_matches_unsharded(send_keys, golden_dir, tmp_path):
+    """K7: the queries cut into 1, 2, 3 and 8 contiguous shards (here all on one GPU), partial records added on the host: same proof bytes"""
+    g = o.SplitMix64(77); r, s = g.field(), g.field()
+    for pk_path, z in ((os.path.join(golden_dir, "groth16_step", "pk.txt"), o.load_witness(os.path.join(golden_dir, "groth16_step", "wit.bin"))),):
+        full = e.Prover(pk_path); exp = full.prove(z, r, s); full.close()
+        for world in (1, 2, 3, 8):
+            recs = []
+            for rank in range(world): p = e.Prover(pk_path, rank, world); p.set_witness(z); recs.append(p.prove_partial()); last = p
+            assert last.finish(recs[::-1], r, s) == exp, world                      # record order does not matter
+    pk_path = str(send_keys / "sendpk.txt"); d = w.send_instance(3); wp = str(tmp_path / "w.bin"); e.witness_send(*hexargs(w.send_args(d)), wp); z = o.load_witness(wp)
+    full = e.Prover(pk_path); exp = full.prove(z, r, s); full.close(); recs = []
+    for rank in range(2): p = e.Prover(pk_path, rank, 2); p.set_witness(z); recs.append(p.prove_partial()); p.close() if rank == 0 else None
+    assert p.finish(recs, r, s) == exp and e.verify(str(send_keys / "sendvk.txt"), exp, w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]]))
