@@ -39,8 +39,10 @@ struct XYZZ {
     F U = Y.dbl(), V = U.sqr(), W = U * V, S = X * V, X2 = X.sqr(), M = X2.dbl() + X2;
     XYZZ r; r.X = M.sqr() - S.dbl(); r.Y = M * (S - r.X) - W * Y; r.ZZ = V * ZZ; r.ZZZ = W * ZZZ; return r;
   }
-  // mixed addition acc += p (EFD madd-2008-s), complete: handles acc = inf, p = inf, p = +-acc
-  ZK_NI void madd(const Affine<F> &p) {
+  // mixed addition acc += p (EFD madd-2008-s), complete: handles acc = inf, p = inf, p = +-acc.  The *_inl forms are for the hot loops, where the
+  // accumulator has to stay in VGPRs: an out-of-line call passes `this` through scratch memory (measured: 2.5 GB of scratch traffic per H accumulation)
+  ZK_NI void madd(const Affine<F> &p) { madd_inl(p); }
+  ZK_HD void madd_inl(const Affine<F> &p) {
     if (p.is_inf()) return;
     if (is_inf()) { X = p.x; Y = p.y; ZZ = F::one(); ZZZ = F::one(); return; }
     F U2 = p.x * ZZ, S2 = p.y * ZZZ, Pv = U2 - X, Rv = S2 - Y;
@@ -50,7 +52,8 @@ struct XYZZ {
     Y = Rv * (Q - X3) - Y * PPP; X = X3; ZZ = ZZ * PP; ZZZ = ZZZ * PPP;
   }
   // general addition acc += o (EFD add-2008-s), complete
-  ZK_NI void add(const XYZZ &o) {
+  ZK_NI void add(const XYZZ &o) { add_inl(o); }
+  ZK_HD void add_inl(const XYZZ &o) {
     if (o.is_inf()) return;
     if (is_inf()) { *this = o; return; }
     F U1 = X * o.ZZ, U2 = o.X * ZZ, S1 = Y * o.ZZZ, S2 = o.Y * ZZZ, Pv = U2 - U1, Rv = S2 - S1;

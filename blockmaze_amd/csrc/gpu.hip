@@ -5,28 +5,23 @@
 #include <cstring>
 #include <map>
 #include <mutex>
-#include "gpu.hpp"
-#include "msm.cuh"
+#include "gpu_internal.hpp"
 #include "ntt.cuh"
-#include "keyops.cuh"
 
 namespace zk {
 
-#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw GpuError(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
-
-class GpuContext {
- public:
-  int device = 0; hipStream_t stream = nullptr; hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t fork_event = nullptr; hipDeviceProp_t prop;
-  GpuContext() {
-    int n = 0; if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
-    const char *e = getenv("ZK_DEVICE"); if (!e) e = getenv("LOCAL_RANK"); device = e ? atoi(e) % n : 0;
-    HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipGetDeviceProperties(&prop, device)); HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking)); HIP_CHECK(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming));
-  }
-};
 GpuContext &gpu() { static GpuContext ctx; hipSetDevice(ctx.device); return ctx; }
 bool gpu_available() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0; }
 void gpu_sync() { HIP_CHECK(hipStreamSynchronize(gpu().stream)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamSynchronize(gpu().aux[i])); }
+void gpu_join_aux() { GpuContext &g = gpu(); for (int i = 0; i < 4; i++) { HIP_CHECK(hipEventRecord(g.join_event[i], g.aux[i])); HIP_CHECK(hipStreamWaitEvent(g.stream, g.join_event[i], 0)); } }
+// the whole device side of one proof is a fixed sequence of launches on fixed buffers: capture it once, replay it with one call
+struct GpuGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+bool profiling_enabled();
+void gpu_graph_begin() { HIP_CHECK(hipStreamBeginCapture(gpu().stream, hipStreamCaptureModeThreadLocal)); }
+GpuGraph *gpu_graph_end() { std::unique_ptr<GpuGraph> g(new GpuGraph); HIP_CHECK(hipStreamEndCapture(gpu().stream, &g->graph)); HIP_CHECK(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0)); return g.release(); }
+void gpu_graph_abort() { hipGraph_t g = nullptr; hipStreamEndCapture(gpu().stream, &g); if (g) hipGraphDestroy(g); (void)hipGetLastError(); }
+void gpu_graph_launch(GpuGraph *g) { HIP_CHECK(hipGraphLaunch(g->exec, gpu().stream)); }
+void gpu_graph_destroy(GpuGraph *g) { if (!g) return; if (g->exec) hipGraphExecDestroy(g->exec); if (g->graph) hipGraphDestroy(g->graph); delete g; }
 void gpu_fork_aux() { GpuContext &g = gpu(); HIP_CHECK(hipEventRecord(g.fork_event, g.stream)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(g.aux[i], g.fork_event, 0)); }
 hipStream_t gpu_stream() { return gpu().stream; }
 
@@ -43,7 +38,9 @@ struct StageTimer {
     for (Span &s : open) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { auto &e = acc[s.name]; e.first += ms; e.second++; } pool.push_back(s.a); pool.push_back(s.b); } open.clear(); open_streams.clear(); }
 };
 static StageTimer g_timer;
-struct Stage { size_t id; explicit Stage(const char *n, hipStream_t st = nullptr) : id(g_timer.begin(n, st ? st : gpu().stream)) {} ~Stage() { g_timer.end(id); } };
+Stage::Stage(const char *n, hipStream_t st) : id(g_timer.begin(n, st ? st : gpu().stream)) {}
+Stage::~Stage() { g_timer.end(id); }
+bool profiling_enabled() { return g_timer.enabled; }
 void profile_enable(bool on) { g_timer.collect(); g_timer.enabled = on; g_timer.acc.clear(); }
 std::string profile_report() { g_timer.collect(); std::string o = "{"; bool first = true;
   for (auto &kv : g_timer.acc) { char buf[256]; snprintf(buf, sizeof buf, "%s\"%s\": {\"ms_total\": %.6f, \"count\": %ld}", first ? "" : ", ", kv.first.c_str(), kv.second.first, kv.second.second); o += buf; first = false; } return o + "}"; }
@@ -63,118 +60,6 @@ template <class T> void PinnedBuf<T>::release() { if (p_) hipHostFree(p_); p_ = 
 template class PinnedBuf<Fe32>;
 void upload_async(void *dev, const void *host, size_t bytes) { HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, gpu().stream)); }
 
-static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
-
-// exclusive scan of a uint32 array on the stream
-struct Scanner {
-  DevBuf<uint32_t> block_sums; size_t cap;
-  explicit Scanner(size_t n) : block_sums(cdiv(n, SCAN_BLOCK * SCAN_ITEMS) + 1), cap(n) {}
-  void run(const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
-    unsigned nb = cdiv(n, SCAN_BLOCK * SCAN_ITEMS);
-    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, out, block_sums.get(), (uint32_t)n);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, block_sums.get(), nb);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_BLOCK), 0, s, out, block_sums.get(), (uint32_t)n);
-  }
-};
-
-// ======================================================================================================================
-// MSM
-// ======================================================================================================================
-template <class F, class RawAffine>
-struct MsmImpl {
-  size_t n; int c, W; uint32_t NB; bool filter_ones; uint32_t seg, n_ones_threads; std::string label = "msm"; int stream_id = -1;   // -1: main stream, 0..3: auxiliary stream
-  DevBuf<RawAffine> points; DevBuf<uint8_t> inf; bool any_inf = false;
-  DevBuf<uint32_t> hist, offsets, fill, entries, ones, ntasks, task_off; DevBuf<uint8_t> counters; Scanner scanner, task_scanner; uint32_t max_tasks;
-  DevBuf<uint8_t> buckets, partials, seg_out, seg_l2, ones_partial, ones_l2, result;   // XYZZ<F> arrays, kept as bytes to stay out of the header
-  XYZZ<F> *h_result = nullptr;                                      // pinned: W window sums + ones sum
-  MsmCounters *h_cnt = nullptr;
-
-  MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo)
-      : n(n_), c(c_), W(msm_num_windows(c_)), NB(1u << (c_ - 1)), filter_ones(fo), points(n_ ? n_ : 1), inf(n_ ? n_ : 1),
-        hist((size_t)W * NB), offsets((size_t)W * NB), fill((size_t)W * NB), entries((n_ ? n_ : 1) * (size_t)W), ones(n_ ? n_ : 1), ntasks((size_t)W * NB + 1), task_off((size_t)W * NB + 1), counters(sizeof(MsmCounters)),
-        scanner((size_t)W * NB), task_scanner((size_t)W * NB + 1) {
-    if (c < 6 || c > 20 || W > MSM_MAX_WINDOWS) throw GpuError("msm: unsupported window size");
-    seg = NB >= 4096 ? 8 : 4; n_ones_threads = 16384;
-    std::vector<uint8_t> flags(n ? n : 1, 0); const uint8_t zero[sizeof(RawAffine)] = {0};
-    for (size_t i = 0; i < n; i++) if (!memcmp(&host_points[i], zero, sizeof(RawAffine))) { flags[i] = 1; any_inf = true; }
-    if (n) { points.upload(host_points, n); inf.upload(flags.data(), n); }
-    max_tasks = (uint32_t)((n * (size_t)W) / MSM_TASK + (size_t)W * NB + 1);
-    buckets = DevBuf<uint8_t>((size_t)W * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>((size_t)max_tasks * sizeof(XYZZ<F>));
-    seg_out = DevBuf<uint8_t>((size_t)W * (NB / seg) * sizeof(XYZZ<F>)); seg_l2 = DevBuf<uint8_t>((size_t)W * cdiv(NB / seg, 64) * sizeof(XYZZ<F>));
-    ones_partial = DevBuf<uint8_t>((size_t)n_ones_threads * sizeof(XYZZ<F>)); ones_l2 = DevBuf<uint8_t>((size_t)(n_ones_threads / 64) * sizeof(XYZZ<F>));
-    result = DevBuf<uint8_t>((size_t)(W + 1) * sizeof(XYZZ<F>));
-    HIP_CHECK(hipHostMalloc((void **)&h_result, (size_t)(W + 1) * sizeof(XYZZ<F>))); HIP_CHECK(hipHostMalloc((void **)&h_cnt, sizeof(MsmCounters)));
-  }
-  ~MsmImpl() { if (h_result) hipHostFree(h_result); if (h_cnt) hipHostFree(h_cnt); }
-  hipStream_t stream() { return stream_id < 0 ? gpu().stream : gpu().aux[stream_id & 3]; }
-
-  void run(const Fe32 *scalars, const uint32_t *scalar_index) {
-    hipStream_t s = stream(); size_t nbk = (size_t)W * NB; const uint8_t *infp = any_inf ? inf.get() : nullptr; MsmCounters *cnt = (MsmCounters *)counters.get();
-    HIP_CHECK(hipMemsetAsync(hist.get(), 0, nbk * 4, s)); HIP_CHECK(hipMemsetAsync(fill.get(), 0, nbk * 4, s)); HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(MsmCounters), s));
-    { Stage st((label + ".sort").c_str(), s);
-      if (n) {
-        hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist.get(), ones.get(), cnt);
-        scanner.run(hist.get(), offsets.get(), nbk, s);
-        hipLaunchKernelGGL(k_msm_scatter<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, offsets.get(), fill.get(), entries.get());
-      }
-      hipLaunchKernelGGL(k_msm_plan, dim3(cdiv(nbk + 1, 256)), dim3(256), 0, s, hist.get(), (uint32_t)nbk, ntasks.get());
-      task_scanner.run(ntasks.get(), task_off.get(), nbk + 1, s);
-    }
-    { Stage st((label + ".accumulate").c_str(), s);
-      hipLaunchKernelGGL((k_msm_accumulate_tasks<F>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist.get(), task_off.get(), (uint32_t)nbk, max_tasks,
-                         (XYZZ<F> *)buckets.get(), (XYZZ<F> *)partials.get());
-    }
-    { Stage st((label + ".combine").c_str(), s);
-      hipLaunchKernelGGL((k_msm_combine_tasks<F, 8>), dim3(cdiv(nbk * 8, 256)), dim3(256), 0, s, hist.get(), task_off.get(), (uint32_t)nbk, (const XYZZ<F> *)partials.get(), (XYZZ<F> *)buckets.get());
-    }
-    { Stage st_red((label + ".reduce").c_str(), s);
-      uint32_t spw = NB / seg, nseg = (uint32_t)W * spw;
-      hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3(cdiv(nseg, 64)), dim3(64), 0, s, (const XYZZ<F> *)buckets.get(), NB, seg, nseg, (XYZZ<F> *)seg_out.get());
-      if (spw > 64) { uint32_t g = cdiv(spw, 64);   // two-level tree per window keeps the dependent chain short
-        hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W * g), dim3(64), 0, s, (const XYZZ<F> *)seg_out.get(), 64u, (XYZZ<F> *)seg_l2.get());
-        hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W), dim3(64), 0, s, (const XYZZ<F> *)seg_l2.get(), g, (XYZZ<F> *)result.get());
-      } else hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W), dim3(64), 0, s, (const XYZZ<F> *)seg_out.get(), spw, (XYZZ<F> *)result.get());
-    }
-    XYZZ<F> *ones_dst = (XYZZ<F> *)result.get() + W;
-    if (filter_ones && n) { Stage st((label + ".ones").c_str(), s);
-      hipLaunchKernelGGL((k_msm_sum_ones<F>), dim3(cdiv(n_ones_threads, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), ones.get(), cnt, n_ones_threads, (XYZZ<F> *)ones_partial.get());
-      hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(n_ones_threads / 64), dim3(64), 0, s, (const XYZZ<F> *)ones_partial.get(), 64u, (XYZZ<F> *)ones_l2.get());
-      hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(64), 0, s, (const XYZZ<F> *)ones_l2.get(), n_ones_threads / 64, ones_dst);
-    } else HIP_CHECK(hipMemsetAsync(ones_dst, 0, sizeof(XYZZ<F>), s));
-    HIP_CHECK(hipMemcpyAsync(h_result, result.get(), (size_t)(W + 1) * sizeof(XYZZ<F>), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipMemcpyAsync(h_cnt, cnt, sizeof(MsmCounters), hipMemcpyDeviceToHost, s));
-  }
-};
-
-template <class HF> static HF load_hf(const void *p);
-template <> host::HFq load_hf<host::HFq>(const void *p) { host::HFq r; memcpy(r.l, p, 32); return r; }
-template <> host::HFq2 load_hf<host::HFq2>(const void *p) { host::HFq2 r; memcpy(r.c0.l, p, 32); memcpy(r.c1.l, (const char *)p + 32, 32); return r; }
-
-// Horner combine of the window sums (c doublings per window) plus the ones-sum, on the host
-template <class HF, class F> static host::HPoint<HF> combine(const XYZZ<F> *res, int W, int c) {
-  auto get = [&](int i) { const char *b = (const char *)&res[i]; size_t fs = sizeof(F);
-    return host::HPoint<HF>::from_xyzz(load_hf<HF>(b), load_hf<HF>(b + fs), load_hf<HF>(b + 2 * fs), load_hf<HF>(b + 3 * fs)); };
-  host::HPoint<HF> acc = host::HPoint<HF>::inf();
-  for (int w = W - 1; w >= 0; w--) { if (!acc.is_inf()) for (int i = 0; i < c; i++) acc = acc.dbl(); acc = acc.add(get(w)); }
-  return acc.add(get(W));
-}
-
-struct MsmG1::Impl : MsmImpl<Fq, G1AffineRaw> { using MsmImpl::MsmImpl; };
-struct MsmG2::Impl : MsmImpl<Fq2, G2AffineRaw> { using MsmImpl::MsmImpl; };
-MsmG1::MsmG1(const G1AffineRaw *p, size_t n, int c, bool fo) : impl(new Impl(p, n, c, fo)) {}
-MsmG1::~MsmG1() = default;
-void MsmG1::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
-void MsmG1::set_label(const char *l) { impl->label = l; }
-void MsmG2::set_label(const char *l) { impl->label = l; }
-void MsmG1::set_stream(int aux) { impl->stream_id = aux; }
-void MsmG2::set_stream(int aux) { impl->stream_id = aux; }
-host::HG1 MsmG1::result() { HIP_CHECK(hipStreamSynchronize(impl->stream())); return combine<host::HFq, Fq>(impl->h_result, impl->W, impl->c); }
-size_t MsmG1::size() const { return impl->n; }
-const G1AffineRaw *MsmG1::points_dev() const { return impl->points.get(); }
-MsmG2::MsmG2(const G2AffineRaw *p, size_t n, int c, bool fo) : impl(new Impl(p, n, c, fo)) {}
-MsmG2::~MsmG2() = default;
-void MsmG2::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
-host::HG2 MsmG2::result() { HIP_CHECK(hipStreamSynchronize(impl->stream())); return combine<host::HFq2, Fq2>(impl->h_result, impl->W, impl->c); }
 
 // ======================================================================================================================
 // Evaluation domains
@@ -317,7 +202,7 @@ void fr_from_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_from_m
 // R1CS rows
 // ======================================================================================================================
 struct R1csDev::Impl {
-  size_t n_inputs, n_vars, n_cons; DevBuf<uint32_t> rowptr[3], col[3], cid[3]; DevBuf<Fe32> ctab; DevBuf<uint32_t> flag; uint32_t *h_flag = nullptr;
+  size_t n_inputs, n_vars, n_cons; DevBuf<uint32_t> rowptr[3], col[3], cid[3], long_rows[3]; size_t n_long[3] = {0, 0, 0}; DevBuf<Fe32> ctab; DevBuf<uint32_t> flag; uint32_t *h_flag = nullptr;
   ~Impl() { if (h_flag) hipHostFree(h_flag); }
 };
 R1csDev::R1csDev(const R1csHost &h) : impl(new Impl) {
@@ -341,6 +226,8 @@ R1csDev::R1csDev(const R1csHost &h) : impl(new Impl) {
     d.rowptr[m] = DevBuf<uint32_t>(h.n_cons + 1); d.rowptr[m].upload(h.rowptr[m].data(), h.n_cons + 1);
     d.col[m] = DevBuf<uint32_t>(ids.size() + 1); d.cid[m] = DevBuf<uint32_t>(ids.size() + 1);
     if (!ids.empty()) { d.col[m].upload(h.col[m].data(), ids.size()); d.cid[m].upload(ids.data(), ids.size()); }
+    std::vector<uint32_t> lr; for (size_t i = 0; i < h.n_cons; i++) if (h.rowptr[m][i + 1] - h.rowptr[m][i] > R1CS_LONG_ROW) lr.push_back((uint32_t)i);
+    d.n_long[m] = lr.size(); d.long_rows[m] = DevBuf<uint32_t>(lr.size() + 1); if (!lr.empty()) d.long_rows[m].upload(lr.data(), lr.size());
   }
   d.ctab = DevBuf<Fe32>(tab.size()); d.ctab.upload(tab.data(), tab.size()); d.flag = DevBuf<uint32_t>(1); HIP_CHECK(hipHostMalloc((void **)&d.h_flag, 4));
 }
@@ -349,6 +236,7 @@ void R1csDev::eval(const Fe32 *z, Fe32 *abc, size_t m) {
   Stage st("r1cs.rows"); Impl &d = *impl; hipStream_t s = gpu().stream; if (m < d.n_cons + d.n_inputs + 1) throw GpuError("r1cs: domain too small");
   HIP_CHECK(hipMemsetAsync(abc, 0, 3 * m * sizeof(Fe32), s));
   for (int mm = 0; mm < 3; mm++) if (d.n_cons) hipLaunchKernelGGL(k_r1cs_rows, dim3(cdiv(d.n_cons, 256)), dim3(256), 0, s, d.rowptr[mm].get(), d.col[mm].get(), d.cid[mm].get(), (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)d.n_cons, (Fr *)(abc + mm * m));
+  for (int mm = 0; mm < 3; mm++) if (d.n_long[mm]) hipLaunchKernelGGL(k_r1cs_long_rows, dim3((unsigned)d.n_long[mm]), dim3(64), 0, s, d.long_rows[mm].get(), d.rowptr[mm].get(), d.col[mm].get(), d.cid[mm].get(), (const Fr *)d.ctab.get(), (const Fr *)z, (Fr *)(abc + mm * m));
   HIP_CHECK(hipMemcpyAsync(abc + d.n_cons, z, (d.n_inputs + 1) * sizeof(Fe32), hipMemcpyDeviceToDevice, s));   // input-consistency rows (r1cs_to_qap.tcc:227-230)
 }
 void R1csDev::check_async(const Fe32 *abc, size_t m) {
@@ -362,39 +250,5 @@ bool R1csDev::satisfied(const Fe32 *abc, size_t m) {
   if (d.n_cons) hipLaunchKernelGGL(k_r1cs_check, dim3(cdiv(d.n_cons, 256)), dim3(256), 0, s, (const Fr *)abc, (const Fr *)(abc + m), (const Fr *)(abc + 2 * m), (uint32_t)d.n_cons, d.flag.get());
   HIP_CHECK(hipMemcpyAsync(d.h_flag, d.flag.get(), 4, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); return *d.h_flag == 0;
 }
-
-// ======================================================================================================================
-// Key-side operations
-// ======================================================================================================================
-static FqPowConsts fq_pow_consts() {
-  FqPowConsts pc; auto shr = [](const uint32_t *a, int k, uint32_t *o) { for (int i = 0; i < 8; i++) o[i] = (a[i] >> k) | (i < 7 ? a[i + 1] << (32 - k) : 0); };
-  uint32_t t[8]; uint64_t c = 1; for (int i = 0; i < 8; i++) { c += FqParams::MOD[i]; t[i] = (uint32_t)c; c >>= 32; } shr(t, 2, pc.sqrt_exp);     // (q+1)/4
-  uint64_t b = 3; for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)FqParams::MOD[i] - b; t[i] = (uint32_t)d; b = (d >> 32) & 1; } shr(t, 2, pc.qm3o4);   // (q-3)/4
-  b = 1; for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)FqParams::MOD[i] - b; t[i] = (uint32_t)d; b = (d >> 32) & 1; } shr(t, 1, pc.qm1o2);            // (q-1)/2
-  return pc;
-}
-static void check_bad(DevBuf<uint32_t> &bad, const char *what) { uint32_t h = 0; bad.download(&h, 1); if (h) throw GpuError(std::string(what) + ": " + std::to_string(h) + " x-coordinates are not on the curve"); }
-void decompress_g1(const Fe32 *xs, const uint8_t *flags, size_t n, G1AffineRaw *out) {
-  if (!n) return; DevBuf<Fe32> dx(n); DevBuf<uint8_t> df(n); DevBuf<G1AffineRaw> dout(n); DevBuf<uint32_t> bad(1); dx.upload(xs, n); df.upload(flags, n); bad.zero();
-  hipLaunchKernelGGL(k_g1_decompress, dim3(cdiv(n, 128)), dim3(128), 0, gpu().stream, (const Fq *)dx.get(), df.get(), (Affine<Fq> *)dout.get(), (uint32_t)n, fq_pow_consts(), bad.get());
-  HIP_CHECK(hipGetLastError()); dout.download(out, n); check_bad(bad, "G1 decompression");
-}
-void decompress_g2(const Fe32 *xs, const uint8_t *flags, size_t n, G2AffineRaw *out) {
-  if (!n) return; DevBuf<Fe32> dx(2 * n); DevBuf<uint8_t> df(n); DevBuf<G2AffineRaw> dout(n); DevBuf<uint32_t> bad(1); dx.upload(xs, 2 * n); df.upload(flags, n); bad.zero();
-  host::HFq2 tb = host::HFq2{host::HFq::from_u64(3), host::HFq::zero()} * host::HFq2{host::HFq::from_u64(9), host::HFq::one()}.inv();   // 3 / (9 + u)  (alt_bn128_init.cpp:193)
-  Fq2 twist_b; memcpy(&twist_b.c0, tb.c0.l, 32); memcpy(&twist_b.c1, tb.c1.l, 32);
-  hipLaunchKernelGGL(k_g2_decompress, dim3(cdiv(n, 64)), dim3(64), 0, gpu().stream, (const Fq2 *)dx.get(), df.get(), (Affine<Fq2> *)dout.get(), (uint32_t)n, fq_pow_consts(), twist_b, bad.get());
-  HIP_CHECK(hipGetLastError()); dout.download(out, n); check_bad(bad, "G2 decompression");
-}
-template <class HF, class Raw> static void store_affine(const host::HPoint<HF> &p, Raw &o) { HF x, y; p.to_affine(x, y); memcpy(&o, &x, sizeof(HF)); memcpy((char *)&o + sizeof(HF), &y, sizeof(HF)); }
-template <class HF, class F, class Raw> static void fixed_base_mul(const host::HPoint<HF> &base, const Fe32 *scalars, size_t n, Raw *out) {
-  if (!n) return; std::vector<Raw> table(32 * 255); host::HPoint<HF> wbase = base;
-  for (int w = 0; w < 32; w++) { host::HPoint<HF> acc = wbase; for (int d = 1; d <= 255; d++) { store_affine(acc, table[w * 255 + d - 1]); acc = acc.add(wbase); } wbase = acc; }   // after 255 additions acc = 256 * wbase
-  DevBuf<Raw> dt(table.size()), dout(n); DevBuf<Fe32> ds(n); dt.upload(table.data(), table.size()); ds.upload(scalars, n);
-  hipLaunchKernelGGL((k_fixed_base_mul<F>), dim3(cdiv(n, 128)), dim3(128), 0, gpu().stream, (const Affine<F> *)dt.get(), (const Fr *)ds.get(), (Affine<F> *)dout.get(), (uint32_t)n);
-  HIP_CHECK(hipGetLastError()); dout.download(out, n);
-}
-void fixed_base_mul_g1(const host::HG1 &base, const Fe32 *scalars, size_t n, G1AffineRaw *out) { fixed_base_mul<host::HFq, Fq, G1AffineRaw>(base, scalars, n, out); }
-void fixed_base_mul_g2(const host::HG2 &base, const Fe32 *scalars, size_t n, G2AffineRaw *out) { fixed_base_mul<host::HFq2, Fq2, G2AffineRaw>(base, scalars, n, out); }
 
 }  // namespace zk

@@ -1,0 +1,39 @@
+// Shared by the HIP translation units of libzkgpu (gpu.hip, gpu_msm_g1.hip, gpu_msm_g2.hip, gpu_keyops.hip): device context, error macro, scan helper, stage timer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "gpu.hpp"
+#include "msm.cuh"
+
+namespace zk {
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw GpuError(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+class GpuContext {
+ public:
+  int device = 0; hipStream_t stream = nullptr; hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t fork_event = nullptr; hipEvent_t join_event[4] = {nullptr, nullptr, nullptr, nullptr}; hipDeviceProp_t prop;
+  GpuContext() {
+    int n = 0; if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
+    const char *e = getenv("ZK_DEVICE"); if (!e) e = getenv("LOCAL_RANK"); device = e ? atoi(e) % n : 0;
+    HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipGetDeviceProperties(&prop, device)); HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking)); HIP_CHECK(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming)); for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&join_event[i], hipEventDisableTiming));
+  }
+};
+GpuContext &gpu();
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+struct Stage { size_t id; explicit Stage(const char *n, hipStream_t st = nullptr); ~Stage(); };   // optional HIP-event timing of a pipeline stage (bench.py's roofline leg)
+
+// exclusive scan of a uint32 array on the stream
+struct Scanner {
+  DevBuf<uint32_t> block_sums; size_t cap;
+  explicit Scanner(size_t n) : block_sums(cdiv(n, SCAN_BLOCK * SCAN_ITEMS) + 1), cap(n) {}
+  void run(const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
+    unsigned nb = cdiv(n, SCAN_BLOCK * SCAN_ITEMS);
+    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(SCAN_BLOCK), 0, s, in, out, block_sums.get(), (uint32_t)n);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, s, block_sums.get(), nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_BLOCK), 0, s, out, block_sums.get(), (uint32_t)n);
+  }
+};
+
+
+}  // namespace zk

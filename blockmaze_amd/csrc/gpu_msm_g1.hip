@@ -1,0 +1,13 @@
+// G1 instantiation of the MSM pipeline (kept in its own translation unit: the inlined field arithmetic makes these kernels slow to compile)
+#include "msm_impl.hpp"
+namespace zk {
+struct MsmG1::Impl : MsmImpl<Fq, G1AffineRaw> { using MsmImpl::MsmImpl; };
+MsmG1::MsmG1(const G1AffineRaw *p, size_t n, int c, bool fo) : impl(new Impl(p, n, c, fo)) {}
+MsmG1::~MsmG1() = default;
+void MsmG1::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
+void MsmG1::set_label(const char *l) { impl->label = l; }
+void MsmG1::set_stream(int aux) { impl->stream_id = aux; }
+host::HG1 MsmG1::result() { HIP_CHECK(hipStreamSynchronize(impl->stream())); return combine<host::HFq, Fq>(impl->h_result, impl->W, impl->c); }
+size_t MsmG1::size() const { return impl->n; }
+const G1AffineRaw *MsmG1::points_dev() const { return impl->points.get(); }
+}  // namespace zk

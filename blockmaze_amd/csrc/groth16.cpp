@@ -185,7 +185,8 @@ void generate_keys(const R1csHost &cs_in, const ToxicWaste &tw, ProvingKeyHost &
 struct Prover::Impl {
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
-  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; PinnedBuf<Fe32> z_host;
+  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; PinnedBuf<Fe32> z_host; GpuGraph *graph = nullptr; bool graph_failed = false;
+  ~Impl() { gpu_graph_destroy(graph); }
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &e) { size_t base = n / world, rem = n % world; b = rank * base + (rank < rem ? rank : rem); e = b + base + (rank < rem ? 1 : 0); }
@@ -227,13 +228,23 @@ static void enqueue_all(Prover::Impl &p) {
   p.dom->ifft(p.abc.get(), 3, p.m); p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); p.dom->icoset_fft(p.abc.get(), 1, p.m);
   p.H->run(p.abc.get() + p.h0, nullptr);                                                                                  // :466-473
 }
+// one proof's device work: replayed from a captured hipGraph (about 70 launches on 5 streams collapse into one submission); opt-in with ZK_USE_GRAPH=1
+static void run_device(Prover::Impl &p) {
+  static const bool no_graph = getenv("ZK_USE_GRAPH") == nullptr;   // measured on ROCm 7.2 / MI355X: replay of this 5-stream graph is slower than eager submission (5.9 vs 5.2 ms per proof), so it is opt-in
+  if (no_graph || p.graph_failed || profiling_enabled()) { enqueue_all(p); return; }
+  if (!p.graph) {
+    try { gpu_graph_begin(); enqueue_all(p); gpu_join_aux(); p.graph = gpu_graph_end(); }
+    catch (const std::exception &) { gpu_graph_abort(); p.graph_failed = true; p.graph = nullptr; enqueue_all(p); return; }
+  }
+  gpu_graph_launch(p.graph);
+}
 static void assemble(const Prover::Impl &p, const RsTerms &t, const HG1 &eA, const HG1 &eB1, const HG2 &eB2, const HG1 &eH, const HG1 &eL, Proof &out) {
   HG1 gA = p.alpha_g1.add(eA).add(t.r_delta);                                                                            // :488
   HG1 gB1 = p.beta_g1.add(eB1).add(t.s_delta); HG2 gB2 = p.beta_g2.add(eB2).add(t.s_delta2);                            // :491-492
   HG1 gC = eH.add(eL).add(gA.mul(t.s.l)).add(gB1.mul(t.r.l)).add(t.rs_delta_neg);                                       // :495
   out.A = raw_of(gA); out.B = raw_of(gB2); out.C = raw_of(gC); }
 bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
-  Impl &p = *impl; double t1 = now_ms(); enqueue_all(p);
+  Impl &p = *impl; double t1 = now_ms(); run_device(p);
   RsTerms t = rs_terms(r_in, s_in, p.delta_g1, p.delta_g2);                                                              // host work overlapped with the kernels
   double t2 = now_ms(); gpu_sync(); double t3 = now_ms();
   if (!p.cs->check_result()) return false;
@@ -244,7 +255,7 @@ bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
 static void put_canon_g1(const HG1 &p, uint8_t *o) { HFq x, y; p.to_affine(x, y); x = x.from_mont(); y = y.from_mont(); memcpy(o, x.l, 32); memcpy(o + 32, y.l, 32); }
 static HG1 get_canon_g1(const uint8_t *o) { HFq x, y; memcpy(x.l, o, 32); memcpy(y.l, o + 32, 32); if (x.is_zero() && y.is_zero()) return HG1::inf(); return HG1::from_affine(x.to_mont(), y.to_mont()); }
 bool Prover::prove_partial(uint8_t out[PARTIAL_BYTES]) {
-  Impl &p = *impl; enqueue_all(p); gpu_sync(); if (!p.cs->check_result()) return false;
+  Impl &p = *impl; run_device(p); gpu_sync(); if (!p.cs->check_result()) return false;
   put_canon_g1(p.A->result(), out); put_canon_g1(p.B1->result(), out + 64); put_canon_g1(p.H->result(), out + 128); put_canon_g1(p.L->result(), out + 192);
   HFq2 x, y; p.B2->result().to_affine(x, y); HFq v[4] = {x.c0.from_mont(), x.c1.from_mont(), y.c0.from_mont(), y.c1.from_mont()}; for (int k = 0; k < 4; k++) memcpy(out + 256 + 32 * k, v[k].l, 32); return true;
 }

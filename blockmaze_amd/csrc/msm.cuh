@@ -70,7 +70,7 @@ __global__ void k_msm_scatter(const Fr *__restrict__ scalars, const uint32_t *__
 
 // ---- exclusive scan over uint32 (three small kernels; the arrays are <= 2^21 entries) ------------------------------
 constexpr int SCAN_BLOCK = 1024, SCAN_ITEMS = 4;   // 4096 items per block
-__global__ void k_scan_local(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums, uint32_t n) {
+static __global__ void k_scan_local(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums, uint32_t n) {
   __shared__ uint32_t sh[SCAN_BLOCK]; uint32_t base = blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + threadIdx.x * SCAN_ITEMS; uint32_t v[SCAN_ITEMS], s = 0;
   for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = base + j < n ? in[base + j] : 0; s += v[j]; }
   sh[threadIdx.x] = s; __syncthreads();
@@ -79,7 +79,7 @@ __global__ void k_scan_local(const uint32_t *__restrict__ in, uint32_t *__restri
   for (int j = 0; j < SCAN_ITEMS; j++) { if (base + j < n) out[base + j] = excl; excl += v[j]; }
   if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = sh[SCAN_BLOCK - 1];
 }
-__global__ void k_scan_block_sums(uint32_t *block_sums, uint32_t nblocks) {   // single block, nblocks <= SCAN_BLOCK*? handled by loop
+static __global__ void k_scan_block_sums(uint32_t *block_sums, uint32_t nblocks) {   // single block, nblocks <= SCAN_BLOCK*? handled by loop
   __shared__ uint32_t sh[SCAN_BLOCK]; uint32_t carry = 0;
   for (uint32_t base = 0; base < nblocks; base += SCAN_BLOCK) {
     uint32_t i = base + threadIdx.x, v = i < nblocks ? block_sums[i] : 0; sh[threadIdx.x] = v; __syncthreads();
@@ -87,7 +87,7 @@ __global__ void k_scan_block_sums(uint32_t *block_sums, uint32_t nblocks) {   //
     if (i < nblocks) block_sums[i] = carry + sh[threadIdx.x] - v; uint32_t tot = sh[SCAN_BLOCK - 1]; __syncthreads(); carry += tot;
   }
 }
-__global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ block_sums, uint32_t n) {
+static __global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ block_sums, uint32_t n) {
   uint32_t base = blockIdx.x * SCAN_BLOCK * SCAN_ITEMS + threadIdx.x * SCAN_ITEMS, add = block_sums[blockIdx.x];
   for (int j = 0; j < SCAN_ITEMS; j++) if (base + j < n) out[base + j] += add;
 }
@@ -105,30 +105,44 @@ template <class T> __device__ __forceinline__ T shfl_down_struct(const T &v, int
 // distribution looks like (uniform H coefficients, the short top window, 0/1-heavy witnesses).  task_off is the exclusive
 // scan of the per-bucket task counts (n_buckets + 1 entries, the last one = total).
 constexpr uint32_t MSM_TASK = 16;
-__global__ void k_msm_plan(const uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t *__restrict__ ntasks) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; if (b <= n_buckets) ntasks[b] = b < n_buckets ? (counts[b] + MSM_TASK - 1) / MSM_TASK : 0;
+// Buckets are visited in order of decreasing entry count, so that the 64 lanes of a wave walk slices of (nearly) equal length: with Poisson-distributed
+// bucket sizes the longest of 64 random buckets is about twice the mean, and every lane of the wave would wait for it.
+constexpr uint32_t BSORT_CLASSES = 64, BSORT_BLOCK = 256;
+__device__ __forceinline__ uint32_t bsort_class(uint32_t count) { return BSORT_CLASSES - 1 - min(count, BSORT_CLASSES - 1); }   // class 0 = the fullest buckets
+static __global__ void __launch_bounds__(BSORT_BLOCK) k_bsort_hist(const uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t n_blocks, uint32_t *__restrict__ block_hist) {
+  __shared__ uint32_t h[BSORT_CLASSES]; if (threadIdx.x < BSORT_CLASSES) h[threadIdx.x] = 0; __syncthreads();
+  uint32_t b = blockIdx.x * BSORT_BLOCK + threadIdx.x; if (b < n_buckets) atomicAdd(&h[bsort_class(counts[b])], 1u); __syncthreads();
+  if (threadIdx.x < BSORT_CLASSES) block_hist[threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];          // class-major, so one exclusive scan yields every (class, block) base
 }
+static __global__ void __launch_bounds__(BSORT_BLOCK) k_bsort_scatter(const uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t n_blocks, const uint32_t *__restrict__ block_off,
+                                                               uint32_t *__restrict__ order, uint32_t *__restrict__ rank_of, uint32_t *__restrict__ ntasks) {
+  __shared__ uint32_t h[BSORT_CLASSES]; if (threadIdx.x < BSORT_CLASSES) h[threadIdx.x] = 0; __syncthreads();
+  uint32_t b = blockIdx.x * BSORT_BLOCK + threadIdx.x;
+  if (b < n_buckets) { uint32_t cnt = counts[b], cls = bsort_class(cnt), pos = block_off[cls * n_blocks + blockIdx.x] + atomicAdd(&h[cls], 1u); order[pos] = b; rank_of[b] = pos; ntasks[pos] = (cnt + MSM_TASK - 1) / MSM_TASK; }
+  if (b == 0) ntasks[n_buckets] = 0;
+}
+// task_off: exclusive scan of ntasks over the SORTED bucket list (n_buckets + 1 entries, the last one = total)
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
-                                                              const uint32_t *__restrict__ task_off, uint32_t n_buckets, uint32_t max_tasks, XYZZ<F> *__restrict__ buckets, XYZZ<F> *__restrict__ partials) {
+                                                              const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, uint32_t n_buckets, uint32_t max_tasks, XYZZ<F> *__restrict__ buckets, XYZZ<F> *__restrict__ partials) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= max_tasks || t >= task_off[n_buckets]) return;
-  uint32_t lo = 0, hi = n_buckets;                         // largest b with task_off[b] <= t
+  uint32_t lo = 0, hi = n_buckets;                         // largest i with task_off[i] <= t
   while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (task_off[mid] <= t) lo = mid; else hi = mid; }
-  uint32_t b = lo, j = t - task_off[b], cnt = counts[b], beg = offsets[b] + j * MSM_TASK, end = offsets[b] + min(cnt, (j + 1) * MSM_TASK);
+  uint32_t b = order[lo], j = t - task_off[lo], cnt = counts[b], beg = offsets[b] + j * MSM_TASK, end = offsets[b] + min(cnt, (j + 1) * MSM_TASK);
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t e = beg; e < end; e++) { uint32_t v = entries[e]; Affine<F> p = points[v & 0x7fffffffu]; if (v >> 31) p.y = p.y.neg(); acc.madd(p); }
+  for (uint32_t e = beg; e < end; e++) { uint32_t v = entries[e]; Affine<F> p = points[v & 0x7fffffffu]; if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); }
   if (cnt <= MSM_TASK) buckets[b] = acc; else partials[t] = acc;
 }
 // buckets that were cut into several tasks: LANES lanes add up the partial sums
 template <class F, int LANES>
-__global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ task_off, uint32_t n_buckets, const XYZZ<F> *__restrict__ partials, XYZZ<F> *__restrict__ buckets) {
+__global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ rank_of, const uint32_t *__restrict__ task_off, uint32_t n_buckets, const XYZZ<F> *__restrict__ partials, XYZZ<F> *__restrict__ buckets) {
   uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, b = gid / LANES, lane = gid % LANES; bool active = b < n_buckets;
   uint32_t cnt = active ? counts[b] : 0; bool multi = cnt > MSM_TASK;
   if (!__any(multi)) { if (active && cnt == 0 && lane == 0) buckets[b] = XYZZ<F>::inf(); return; }
   XYZZ<F> acc = XYZZ<F>::inf();
-  if (multi) { uint32_t beg = task_off[b], nt = task_off[b + 1] - beg; for (uint32_t j = lane; j < nt; j += LANES) acc.add(partials[beg + j]); }
-#pragma unroll
-  for (int d = LANES / 2; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); acc.add(o); }
+  if (multi) { uint32_t i = rank_of[b], beg = task_off[i], nt = task_off[i + 1] - beg; for (uint32_t j = lane; j < nt; j += LANES) acc.add_inl(partials[beg + j]); }
+#pragma unroll 1
+  for (int d = LANES / 2; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); acc.add_inl(o); }
   if (active && lane == 0) { if (multi) buckets[b] = acc; else if (cnt == 0) buckets[b] = XYZZ<F>::inf(); }
 }
 
@@ -140,7 +154,7 @@ __global__ void __launch_bounds__(64) k_msm_reduce_segments(const XYZZ<F> *__res
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= n_seg_total) return;
   uint32_t segs_per_window = NB / SEG, w = t / segs_per_window, s = t % segs_per_window, lo = s * SEG;
   const XYZZ<F> *B = buckets + (size_t)w * NB + lo; XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
-  for (int j = (int)SEG - 1; j >= 0; j--) { run.add(B[j]); acc.add(run); }
+  for (int j = (int)SEG - 1; j >= 0; j--) { run.add_inl(B[j]); acc.add_inl(run); }
   if (lo) { XYZZ<F> off = run.mul_small(lo); acc.add(off); }
   seg_out[t] = acc;
 }
@@ -149,9 +163,9 @@ __global__ void __launch_bounds__(64) k_msm_reduce_segments(const XYZZ<F> *__res
 template <class F>
 __global__ void __launch_bounds__(64) k_xyzz_group_sum(const XYZZ<F> *__restrict__ in, uint32_t len, XYZZ<F> *__restrict__ out) {
   uint32_t g = blockIdx.x, lane = threadIdx.x; XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t j = lane; j < len; j += 64) { if (j == lane) acc = in[(size_t)g * len + j]; else acc.add(in[(size_t)g * len + j]); }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); acc.add(o); }
+  for (uint32_t j = lane; j < len; j += 64) { if (j == lane) acc = in[(size_t)g * len + j]; else acc.add_inl(in[(size_t)g * len + j]); }
+#pragma unroll 1
+  for (int d = 32; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); acc.add_inl(o); }
   if (lane == 0) out[g] = acc;
 }
 
@@ -160,7 +174,7 @@ template <class F>
 __global__ void __launch_bounds__(256) k_msm_sum_ones(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ ones, const MsmCounters *cnt, uint32_t n_threads, XYZZ<F> *__restrict__ partial) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= n_threads) return;
   uint32_t n = cnt->n_ones; XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t j = t; j < n; j += n_threads) acc.madd(points[ones[j]]);
+  for (uint32_t j = t; j < n; j += n_threads) acc.madd_inl(points[ones[j]]);
   partial[t] = acc;
 }
 

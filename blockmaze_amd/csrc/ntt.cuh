@@ -65,15 +65,26 @@ __global__ void k_qap_pointwise(Fr *__restrict__ a, const Fr *__restrict__ b, co
 __global__ void k_fr_to_mont(Fr *__restrict__ a, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = a[i].to_mont(); }
 __global__ void k_fr_from_mont(Fr *__restrict__ a, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = a[i].from_mont(); }
 
+constexpr uint32_t R1CS_LONG_ROW = 16;   // rows with more terms than this get a whole wave (k_r1cs_long_rows)
 // ---- R1CS rows times assignment (kernel K1; r1cs_to_qap.tcc:224-236,281-285; linear_combination::evaluate) ---------
 // CSR with coefficient *indices* into a small table (the circuits use a few hundred distinct coefficients: +-1, +-2^k).
 // out[row] = sum coeff[cid] * z[col]   for row < n_rows; rows are per matrix, one thread per row.
 __global__ void k_r1cs_rows(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col, const uint32_t *__restrict__ cid, const Fr *__restrict__ ctab,
                             const Fr *__restrict__ z, uint32_t n_rows, Fr *__restrict__ out) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= n_rows) return; Fr acc = Fr::zero();
+  if (rowptr[r + 1] - rowptr[r] > R1CS_LONG_ROW) return;                        // handled by k_r1cs_long_rows
   for (uint32_t k = rowptr[r]; k < rowptr[r + 1]; k++) { uint32_t ci = cid[k]; Fr v = z[col[k]];
     if (ci == 0) acc = acc + v; else if (ci == 1) acc = acc - v; else acc = acc + ctab[ci] * v; }   // table slots 0 / 1 are +1 / -1
   out[r] = acc;
+}
+// rows with many terms (bit-packing constraints: 32 ... 253 terms) get one wave each: lanes stride over the terms, then a shuffle tree over the partial sums
+__global__ void __launch_bounds__(64) k_r1cs_long_rows(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col, const uint32_t *__restrict__ cid, const Fr *__restrict__ ctab,
+                                                        const Fr *__restrict__ z, Fr *__restrict__ out) {
+  uint32_t r = rows[blockIdx.x], lane = threadIdx.x; Fr acc = Fr::zero();
+  for (uint32_t k = rowptr[r] + lane; k < rowptr[r + 1]; k += 64) { uint32_t ci = cid[k]; Fr v = z[col[k]]; if (ci == 0) acc = acc + v; else if (ci == 1) acc = acc - v; else acc = acc + ctab[ci] * v; }
+#pragma unroll 1
+  for (int d = 32; d >= 1; d >>= 1) { Fr o; for (int i = 0; i < 8; i++) o.l[i] = __shfl_down(acc.l[i], d, 64); acc = acc + o; }
+  if (lane == 0) out[r] = acc;
 }
 // satisfiability: flag[0] |= (a[i]*b[i] != c[i]) over the constraint rows (protoboard::is_satisfied, sendcgo.cpp:209)
 __global__ void k_r1cs_check(const Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ c, uint32_t n_rows, uint32_t *flag) {
