@@ -17,9 +17,11 @@ void gpu_join_aux() { GpuContext &g = gpu(); for (int i = 0; i < 4; i++) { HIP_C
 // the whole device side of one proof is a fixed sequence of launches on fixed buffers: capture it once, replay it with one call
 struct GpuGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
 bool profiling_enabled();
-void gpu_graph_begin() { HIP_CHECK(hipStreamBeginCapture(gpu().stream, hipStreamCaptureModeThreadLocal)); }
-GpuGraph *gpu_graph_end() { std::unique_ptr<GpuGraph> g(new GpuGraph); HIP_CHECK(hipStreamEndCapture(gpu().stream, &g->graph)); HIP_CHECK(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0)); return g.release(); }
-void gpu_graph_abort() { hipGraph_t g = nullptr; hipStreamEndCapture(gpu().stream, &g); if (g) hipGraphDestroy(g); (void)hipGetLastError(); }
+static bool g_capturing = false;
+bool gpu_capturing() { return g_capturing; }
+void gpu_graph_begin() { HIP_CHECK(hipStreamBeginCapture(gpu().stream, hipStreamCaptureModeThreadLocal)); g_capturing = true; }
+GpuGraph *gpu_graph_end() { g_capturing = false; std::unique_ptr<GpuGraph> g(new GpuGraph); HIP_CHECK(hipStreamEndCapture(gpu().stream, &g->graph)); HIP_CHECK(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0)); return g.release(); }
+void gpu_graph_abort() { g_capturing = false; hipGraph_t g = nullptr; hipStreamEndCapture(gpu().stream, &g); if (g) hipGraphDestroy(g); (void)hipGetLastError(); }
 void gpu_graph_launch(GpuGraph *g) { HIP_CHECK(hipGraphLaunch(g->exec, gpu().stream)); }
 void gpu_graph_destroy(GpuGraph *g) { if (!g) return; if (g->exec) hipGraphExecDestroy(g->exec); if (g->graph) hipGraphDestroy(g->graph); delete g; }
 void gpu_fork_aux() { GpuContext &g = gpu(); HIP_CHECK(hipEventRecord(g.fork_event, g.stream)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(g.aux[i], g.fork_event, 0)); }

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
+#include <thread>
 #include "groth16.hpp"
 
 namespace zk {
@@ -221,19 +222,25 @@ static RsTerms rs_terms(const Fe32 *r_in, const Fe32 *s_in, const HG1 &delta_g1,
   t.r_delta = delta_g1.mul(t.r.l); t.s_delta = delta_g1.mul(t.s.l); t.rs_delta_neg = delta_g1.mul(rs.l).neg(); t.s_delta2 = delta_g2.mul(t.s.l); return t; }
 static void enqueue_all(Prover::Impl &p) {
   gpu_fork_aux();
-  p.A->run(p.z.get() + p.a0, nullptr); p.L->run(p.z.get() + p.ni + 1 + p.l0, nullptr); p.B1->run(p.z.get(), p.B_idx.get() + p.b0); p.B2->run(p.z.get(), p.B_idx.get() + p.b0);   // r1cs_gg_ppzksnark.tcc:442-462,477-484
+  // about 100 launches per proof: a second host thread submits the four witness MSMs (auxiliary streams) while this one submits the critical chain
+  std::exception_ptr aux_error; bool threaded = !gpu_capturing();
+  auto aux = [&] { try { p.B2->run(p.z.get(), p.B_idx.get() + p.b0); p.L->run(p.z.get() + p.ni + 1 + p.l0, nullptr); p.A->run(p.z.get() + p.a0, nullptr); p.B1->run(p.z.get(), p.B_idx.get() + p.b0); }   // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
+                   catch (...) { aux_error = std::current_exception(); } };
+  std::thread helper; if (threaded) helper = std::thread(aux); else aux();
+  struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{helper};
   p.cs->eval(p.z.get(), p.abc.get(), p.m);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the satisfiability flag is read back together with the results
   p.cs->check_async(p.abc.get(), p.m);
   p.dom->ifft(p.abc.get(), 3, p.m); p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); p.dom->icoset_fft(p.abc.get(), 1, p.m);
   p.H->run(p.abc.get() + p.h0, nullptr);                                                                                  // :466-473
+  if (helper.joinable()) helper.join(); if (aux_error) std::rethrow_exception(aux_error);
 }
 // one proof's device work: replayed from a captured hipGraph (about 70 launches on 5 streams collapse into one submission); opt-in with ZK_USE_GRAPH=1
 static void run_device(Prover::Impl &p) {
   static const bool no_graph = getenv("ZK_USE_GRAPH") == nullptr;   // measured on ROCm 7.2 / MI355X: replay of this 5-stream graph is slower than eager submission (5.9 vs 5.2 ms per proof), so it is opt-in
   if (no_graph || p.graph_failed || profiling_enabled()) { enqueue_all(p); return; }
   if (!p.graph) {
-    try { gpu_graph_begin(); enqueue_all(p); gpu_join_aux(); p.graph = gpu_graph_end(); }
+    try { gpu_graph_begin(); enqueue_all(p); gpu_join_aux(); p.graph = gpu_graph_end(); }   // (enqueue_all stays single-threaded while capturing)
     catch (const std::exception &) { gpu_graph_abort(); p.graph_failed = true; p.graph = nullptr; enqueue_all(p); return; }
   }
   gpu_graph_launch(p.graph);
