@@ -70,6 +70,64 @@ struct XYZZ {
   }
 };
 
+#if defined(__HIPCC__)
+// ---- quad-cooperative group law ------------------------------------------------------------------------------------------
+// The tails of an MSM (bucket reduction, tree sums) are chains of dependent additions on few points: one lane per point leaves the chip idle and each
+// addition costs 14 sequential field multiplications (a single wave issues one in ~0.9 us).  Here FOUR adjacent lanes (a DPP quad) hold the same point
+// and share an addition: every lane computes one of the products of a round, quad_perm broadcasts hand the four products back to all lanes, and the cheap
+// additions/subtractions are done redundantly.  add = 4 rounds (14 products), dbl = 3 rounds (9 products).  All data-dependent branches are uniform within
+// a quad because the state is replicated.  k = lane & 3.
+template <int K, class P> __device__ __forceinline__ Fp<P> quad_pick(const Fp<P> &v) {
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], K * 0x55, 0xf, 0xf, false);   // quad_perm:[K,K,K,K]
+  return r;
+}
+template <int K> __device__ __forceinline__ Fq2 quad_pick(const Fq2 &v) { return {quad_pick<K>(v.c0), quad_pick<K>(v.c1)}; }
+template <class P> __device__ __forceinline__ Fp<P> lane_sel(bool c, const Fp<P> &a, const Fp<P> &b) {
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = c ? a.l[i] : b.l[i];
+  return r;
+}
+__device__ __forceinline__ Fq2 lane_sel(bool c, const Fq2 &a, const Fq2 &b) { return {lane_sel(c, a.c0, b.c0), lane_sel(c, a.c1, b.c1)}; }
+template <class F> __device__ __forceinline__ F quad_sel(int k, const F &a, const F &b, const F &c, const F &d) { return lane_sel(k < 2, lane_sel(k == 0, a, b), lane_sel(k == 2, c, d)); }
+
+// dbl-2008-s-1 (a = 0):  round 1: V = U^2 | X^2      round 2: W = U*V | S = X*V | M^2 | V*ZZ      round 3: M*(S - X3) | W*Y | W*ZZZ
+template <class F> __device__ __forceinline__ XYZZ<F> quad_dbl_inl(const XYZZ<F> &a, int k) {
+  if (a.is_inf()) return a;
+  F U = a.Y.dbl(), m = lane_sel(k == 0, U, a.X); m = m * m;
+  F V = quad_pick<0>(m), X2 = quad_pick<1>(m), M = X2.dbl() + X2;
+  m = quad_sel(k, U, a.X, M, V) * quad_sel(k, V, V, M, a.ZZ);
+  F W = quad_pick<0>(m), S = quad_pick<1>(m), MM = quad_pick<2>(m); XYZZ<F> r; r.ZZ = quad_pick<3>(m); r.X = MM - S.dbl();
+  m = quad_sel(k, M, W, W, W) * quad_sel(k, S - r.X, a.Y, a.ZZZ, a.ZZZ);
+  r.Y = quad_pick<0>(m) - quad_pick<1>(m); r.ZZZ = quad_pick<2>(m); return r;
+}
+template <class F> __device__ __noinline__ XYZZ<F> quad_dbl(const XYZZ<F> &a, int k) { return quad_dbl_inl(a, k); }   // out-of-line copy for the rare doubling branch of an addition
+// add-2008-s:  round 1: U1 = X1*ZZ2 | U2 = X2*ZZ1 | S1 = Y1*ZZZ2 | S2 = Y2*ZZZ1      round 2: P^2 | R^2 | ZZ1*ZZ2 | ZZZ1*ZZZ2
+//              round 3: P*PP | U1*PP | ZZ12*PP      round 4: R*(Q - X3) | S1*PPP | ZZZ12*PPP
+template <class F> __device__ __forceinline__ XYZZ<F> quad_add(const XYZZ<F> &a, const XYZZ<F> &b, int k) {
+  if (b.is_inf()) return a;
+  if (a.is_inf()) return b;
+  F m = quad_sel(k, a.X, b.X, a.Y, b.Y) * quad_sel(k, b.ZZ, a.ZZ, b.ZZZ, a.ZZZ);
+  F U1 = quad_pick<0>(m), S1 = quad_pick<2>(m), Pv = quad_pick<1>(m) - U1, Rv = quad_pick<3>(m) - S1;
+  if (Pv.is_zero()) { if (Rv.is_zero()) return quad_dbl(a, k); return XYZZ<F>::inf(); }
+  m = quad_sel(k, Pv, Rv, a.ZZ, a.ZZZ) * quad_sel(k, Pv, Rv, b.ZZ, b.ZZZ);
+  F PP = quad_pick<0>(m), RR = quad_pick<1>(m), ZZ12 = quad_pick<2>(m), ZZZ12 = quad_pick<3>(m);
+  m = quad_sel(k, Pv, U1, ZZ12, ZZ12) * PP;
+  F PPP = quad_pick<0>(m), Q = quad_pick<1>(m); XYZZ<F> r; r.ZZ = quad_pick<2>(m); r.X = RR - PPP - Q.dbl();
+  m = quad_sel(k, Rv, S1, ZZZ12, ZZZ12) * lane_sel(k == 0, Q - r.X, PPP);
+  r.Y = quad_pick<0>(m) - quad_pick<1>(m); r.ZZZ = quad_pick<2>(m); return r;
+}
+// n * a for a small scalar, MSB first
+template <class F> __device__ __forceinline__ XYZZ<F> quad_mul_small(const XYZZ<F> &a, uint32_t n, int k) {
+  XYZZ<F> r = XYZZ<F>::inf(); if (!n) return r;
+#pragma unroll 1
+  for (int i = 31 - __clz(n); i >= 0; i--) { r = quad_dbl_inl(r, k); if ((n >> i) & 1) r = quad_add(r, a, k); }
+  return r;
+}
+#endif
+
 using G1Affine = Affine<Fq>;
 using G2Affine = Affine<Fq2>;
 using G1XYZZ = XYZZ<Fq>;

@@ -83,14 +83,28 @@ struct Radix2Tables {
 };
 static std::vector<Fe32> geometric_table(size_t n, const HFr &first, const HFr &ratio) { std::vector<Fe32> t(n); HFr x = first; for (size_t i = 0; i < n; i++) { memcpy(&t[i], x.l, 32); x = x * ratio; } return t; }
 
-// in-place radix-2 transform of `batch` vectors: out = DIT(bitrev(in * pre_scale)); scratch holds the permuted copy
-static void radix2_transform(Fe32 *data, Fe32 *scratch, const Fe32 *tw, int logn, const Fe32 *pre_scale, int batch, size_t stride, size_t scratch_stride) {
+// in-place radix-2 transform of `batch` vectors: data = post * NTT(pre * data), natural order in and out.  Up to 2^22 points: two LDS-tiled passes
+// (k_ntt_cols: data -> scratch, k_ntt_rows: scratch -> data; one pass in place when the whole vector fits a tile); beyond that the stage-per-launch path.
+static int ntt_pref_log_c() { static const int v = [] { const char *e = getenv("ZK_NTT_LOGC"); int x = e ? atoi(e) : 1; return x < 0 ? 0 : x > 3 ? 3 : x; }(); return v; }
+static void radix2_transform(Fe32 *data, Fe32 *scratch, const Fe32 *tw, int logn, const Fe32 *pre_scale, const Fe32 *post_scale, int batch, size_t stride, size_t scratch_stride) {
   hipStream_t s = gpu().stream; size_t n = (size_t)1 << logn;
+  if (logn <= NTT_TILE_LOG) {          // n2 = 1: the column pass alone is the whole transform
+    if (post_scale) throw GpuError("ntt: post scale on a single-pass transform");
+    hipLaunchKernelGGL(k_ntt_cols, dim3(1, batch), dim3(NTT_TILE_THREADS), sizeof(Fr) << logn, s, (const Fr *)data, (Fr *)data, (const Fr *)pre_scale, (const Fr *)tw, logn, logn, 0, stride, stride);
+    return;
+  }
+  if (logn <= 2 * NTT_TILE_LOG) {
+    int l1 = logn / 2, l2 = logn - l1, c1 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l1, l2)), c2 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l2, l1));
+    hipLaunchKernelGGL(k_ntt_cols, dim3((unsigned)(1u << (l2 - c1)), batch), dim3(NTT_TILE_THREADS), sizeof(Fr) << (l1 + c1), s, (const Fr *)data, (Fr *)scratch, (const Fr *)pre_scale, (const Fr *)tw, logn, l1, c1, stride, scratch_stride);
+    hipLaunchKernelGGL(k_ntt_rows, dim3((unsigned)(1u << (l1 - c2)), batch), dim3(NTT_TILE_THREADS), sizeof(Fr) << (l2 + c2), s, (const Fr *)scratch, (Fr *)data, (const Fr *)post_scale, (const Fr *)tw, logn, l1, c2, scratch_stride, stride);
+    return;
+  }
   hipLaunchKernelGGL(k_ntt_bitrev_scale, dim3(cdiv(n, 256), batch), dim3(256), 0, s, (const Fr *)data, (Fr *)scratch, (const Fr *)pre_scale, logn, stride, scratch_stride);
-  int L = logn < NTT_LOCAL_LOG ? logn : NTT_LOCAL_LOG;
-  if (L > 0) hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> L), batch), dim3(NTT_LOCAL_THREADS), sizeof(Fr) << L, s, (Fr *)scratch, (const Fr *)tw, logn, L, scratch_stride);
+  int L = NTT_LOCAL_LOG;
+  hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> L), batch), dim3(NTT_LOCAL_THREADS), sizeof(Fr) << L, s, (Fr *)scratch, (const Fr *)tw, logn, L, scratch_stride);
   for (int st = L + 1; st <= logn; st++) hipLaunchKernelGGL(k_ntt_stage, dim3(cdiv(n / 2, 256), batch), dim3(256), 0, s, (Fr *)scratch, (const Fr *)tw, logn, st, scratch_stride);
   for (int b = 0; b < batch; b++) HIP_CHECK(hipMemcpyAsync(data + b * stride, scratch + b * scratch_stride, n * sizeof(Fe32), hipMemcpyDeviceToDevice, s));
+  if (post_scale) hipLaunchKernelGGL(k_fr_mul_table, dim3(cdiv(n, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)post_scale, (uint32_t)n, stride);
 }
 
 // ---- step-radix-2 helper kernels (domains/step_radix2_domain.tcc:39-153) ---------------------------------------------
@@ -164,33 +178,39 @@ static void mul_table(Fe32 *a, const Fe32 *t, size_t n, int batch, size_t stride
 
 void Domain::fft(Fe32 *data, int batch, size_t stride) {
   Stage st("ntt.forward"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
-  if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->tw.get(), d.big->logn, nullptr, batch, stride, d.scratch_stride); return; }
+  if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->tw.get(), d.big->logn, nullptr, nullptr, batch, stride, d.scratch_stride); return; }
   hipStream_t s = gpu().stream;
   for (int b = 0; b < batch; b++) {   // scratch layout per vector: [c (B) | e (S)] in slot 0, d (B) in slot 1, bitrev scratch in slot 2
     Fe32 *a = data + b * stride, *cb = d.scratch.get(), *db = d.scratch.get() + d.m, *tmp = d.scratch.get() + 2 * d.m, *e = cb + d.B;
     hipLaunchKernelGGL(k_step_fwd_pre, dim3(cdiv(d.B, 256)), dim3(256), 0, s, (const Fr *)a, (Fr *)cb, (Fr *)db, (const Fr *)d.wpow.get(), (uint32_t)d.B, (uint32_t)d.S);
     hipLaunchKernelGGL(k_step_fold, dim3(cdiv(d.S, 256)), dim3(256), 0, s, (const Fr *)db, (Fr *)e, (uint32_t)d.B, (uint32_t)d.S);
-    radix2_transform(cb, tmp, d.big->tw.get(), d.big->logn, nullptr, 1, 0, 0); radix2_transform(e, tmp, d.small->tw.get(), d.small->logn, nullptr, 1, 0, 0);
+    radix2_transform(cb, tmp, d.big->tw.get(), d.big->logn, nullptr, nullptr, 1, 0, 0); radix2_transform(e, tmp, d.small->tw.get(), d.small->logn, nullptr, nullptr, 1, 0, 0);
     HIP_CHECK(hipMemcpyAsync(a, cb, d.m * sizeof(Fe32), hipMemcpyDeviceToDevice, s));
   }
 }
 void Domain::ifft(Fe32 *data, int batch, size_t stride) {
   Stage st("ntt.inverse"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
-  if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, nullptr, batch, stride, d.scratch_stride); mul_table(data, d.scale_big.get(), d.m, batch, stride); return; }
+  if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, d.scale_big.get(), nullptr, batch, stride, d.scratch_stride); return; }   // 1/m folded into the load
   hipStream_t s = gpu().stream;
   for (int b = 0; b < batch; b++) {
     Fe32 *a = data + b * stride, *U = d.scratch.get(), *tmp = d.scratch.get() + 2 * d.m;
     HIP_CHECK(hipMemcpyAsync(U, a, d.m * sizeof(Fe32), hipMemcpyDeviceToDevice, s));
-    radix2_transform(U, tmp, d.big->itw.get(), d.big->logn, nullptr, 1, 0, 0); radix2_transform(U + d.B, tmp, d.small->itw.get(), d.small->logn, nullptr, 1, 0, 0);
-    mul_table(U, d.scale_big.get(), d.B, 1, 0); mul_table(U + d.B, d.scale_small.get(), d.S, 1, 0);
+    radix2_transform(U, tmp, d.big->itw.get(), d.big->logn, d.scale_big.get(), nullptr, 1, 0, 0); radix2_transform(U + d.B, tmp, d.small->itw.get(), d.small->logn, d.scale_small.get(), nullptr, 1, 0, 0);   // 1/B, 1/S folded into the loads
     Fr half; memcpy(&half, d.half.l, 32);
     hipLaunchKernelGGL(k_step_inv_post, dim3(cdiv(d.B, 256)), dim3(256), 0, s, (const Fr *)U, (const Fr *)(U + d.B), (Fr *)a, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half, (uint32_t)d.B, (uint32_t)d.S);
   }
 }
-void Domain::coset_fft(Fe32 *data, int batch, size_t stride) { mul_table(data, impl->coset_fwd.get(), impl->m, batch, stride); fft(data, batch, stride); }
+void Domain::coset_fft(Fe32 *data, int batch, size_t stride) {
+  Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
+  if (!d.step) { Stage st("ntt.forward"); radix2_transform(data, d.scratch.get(), d.big->tw.get(), d.big->logn, d.coset_fwd.get(), nullptr, batch, stride, d.scratch_stride); return; }   // g^i folded into the load
+  mul_table(data, d.coset_fwd.get(), d.m, batch, stride); fft(data, batch, stride);
+}
 void Domain::icoset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl;
-  if (!d.step) { Stage st("ntt.inverse"); radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, nullptr, batch, stride, d.scratch_stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride); return; }   // coset_inv carries 1/m
+  if (!d.step) { Stage st("ntt.inverse");   // coset_inv carries 1/m; it is folded into the store unless the transform is a single pass
+    if (d.big->logn <= NTT_TILE_LOG) { radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, nullptr, nullptr, batch, stride, d.scratch_stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride); }
+    else radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, nullptr, d.coset_inv.get(), batch, stride, d.scratch_stride);
+    return; }
   ifft(data, batch, stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride);
 }
 void Domain::qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c) {

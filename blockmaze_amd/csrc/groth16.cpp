@@ -4,6 +4,7 @@
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
+#include <functional>
 #include <thread>
 #include "groth16.hpp"
 
@@ -222,18 +223,22 @@ static RsTerms rs_terms(const Fe32 *r_in, const Fe32 *s_in, const HG1 &delta_g1,
   t.r_delta = delta_g1.mul(t.r.l); t.s_delta = delta_g1.mul(t.s.l); t.rs_delta_neg = delta_g1.mul(rs.l).neg(); t.s_delta2 = delta_g2.mul(t.s.l); return t; }
 static void enqueue_all(Prover::Impl &p) {
   gpu_fork_aux();
-  // about 100 launches per proof: a second host thread submits the four witness MSMs (auxiliary streams) while this one submits the critical chain
-  std::exception_ptr aux_error; bool threaded = !gpu_capturing();
-  auto aux = [&] { try { p.B2->run(p.z.get(), p.B_idx.get() + p.b0); p.L->run(p.z.get() + p.ni + 1 + p.l0, nullptr); p.A->run(p.z.get() + p.a0, nullptr); p.B1->run(p.z.get(), p.B_idx.get() + p.b0); }   // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
-                   catch (...) { aux_error = std::current_exception(); } };
-  std::thread helper; if (threaded) helper = std::thread(aux); else aux();
-  struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{helper};
+  // about 170 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
+  // (auxiliary streams) while this one submits the critical chain
+  static const int n_helpers = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); int v = e ? atoi(e) : 4; return v < 0 ? 0 : v > 4 ? 4 : v; }();
+  std::function<void()> jobs[4] = { [&] { p.B2->run(p.z.get(), p.B_idx.get() + p.b0); }, [&] { p.L->run(p.z.get() + p.ni + 1 + p.l0, nullptr); },       // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
+                                    [&] { p.A->run(p.z.get() + p.a0, nullptr); }, [&] { p.B1->run(p.z.get(), p.B_idx.get() + p.b0); } };
+  int nh = (gpu_capturing() || profiling_enabled()) ? 0 : n_helpers;   // (the stage timers are not thread-safe: profiling runs submit from one thread)
+  std::exception_ptr aux_error[4]; std::thread helpers[4];
+  struct Joiner { std::thread *t; ~Joiner() { for (int i = 0; i < 4; i++) if (t[i].joinable()) t[i].join(); } } joiner{helpers};
+  for (int h = 0; h < nh; h++) helpers[h] = std::thread([&, h] { try { for (int j = h; j < 4; j += nh) jobs[j](); } catch (...) { aux_error[h] = std::current_exception(); } });
+  if (!nh) for (auto &j : jobs) j();
   p.cs->eval(p.z.get(), p.abc.get(), p.m);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the satisfiability flag is read back together with the results
   p.cs->check_async(p.abc.get(), p.m);
   p.dom->ifft(p.abc.get(), 3, p.m); p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); p.dom->icoset_fft(p.abc.get(), 1, p.m);
   p.H->run(p.abc.get() + p.h0, nullptr);                                                                                  // :466-473
-  if (helper.joinable()) helper.join(); if (aux_error) std::rethrow_exception(aux_error);
+  for (int h = 0; h < nh; h++) { helpers[h].join(); if (aux_error[h]) std::rethrow_exception(aux_error[h]); }
 }
 // one proof's device work: replayed from a captured hipGraph (about 70 launches on 5 streams collapse into one submission); opt-in with ZK_USE_GRAPH=1
 static void run_device(Prover::Impl &p) {

@@ -147,26 +147,29 @@ __global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__res
 }
 
 // ---- bucket reduction: sum_{b=1..NB} b * B_b per window, by segments of SEG buckets --------------------------------
-// thread (w, s) handles buckets [s*SEG, (s+1)*SEG) of window w (bucket index j holds multiplier j+1):
+// quad (w, s) handles buckets [s*SEG, (s+1)*SEG) of window w (bucket index j holds multiplier j+1):
 //   run = sum B_j ; acc = sum (j - lo + 1) B_j  (running sums from the top) ; out = acc + lo * run
+// Four lanes share each addition (curve.cuh, quad_add): the chain of 2*SEG additions and the ~log2(lo) doublings is what bounds this kernel.
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_reduce_segments(const XYZZ<F> *__restrict__ buckets, uint32_t NB, uint32_t SEG, uint32_t n_seg_total, XYZZ<F> *__restrict__ seg_out) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= n_seg_total) return;
+  uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; int k = threadIdx.x & 3; if (t >= n_seg_total) return;
   uint32_t segs_per_window = NB / SEG, w = t / segs_per_window, s = t % segs_per_window, lo = s * SEG;
   const XYZZ<F> *B = buckets + (size_t)w * NB + lo; XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
-  for (int j = (int)SEG - 1; j >= 0; j--) { run.add_inl(B[j]); acc.add_inl(run); }
-  if (lo) { XYZZ<F> off = run.mul_small(lo); acc.add(off); }
-  seg_out[t] = acc;
+#pragma unroll 1
+  for (int j = (int)SEG - 1; j >= 0; j--) { run = quad_add(run, B[j], k); acc = quad_add(acc, run, k); }
+  if (lo) acc = quad_add(acc, quad_mul_small(run, lo, k), k);
+  if (k == 0) seg_out[t] = acc;
 }
 
-// ---- generic grouped sum: out[g] = sum_{j<len} in[g*len + j], one wave per group ------------------------------------
+// ---- generic grouped sum: out[g] = sum_{j<len} in[g*len + j], one wave (16 quads) per group -------------------------
 template <class F>
 __global__ void __launch_bounds__(64) k_xyzz_group_sum(const XYZZ<F> *__restrict__ in, uint32_t len, XYZZ<F> *__restrict__ out) {
-  uint32_t g = blockIdx.x, lane = threadIdx.x; XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t j = lane; j < len; j += 64) { if (j == lane) acc = in[(size_t)g * len + j]; else acc.add_inl(in[(size_t)g * len + j]); }
+  uint32_t g = blockIdx.x, q = threadIdx.x >> 2; int k = threadIdx.x & 3; XYZZ<F> acc = XYZZ<F>::inf();
 #pragma unroll 1
-  for (int d = 32; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); acc.add_inl(o); }
-  if (lane == 0) out[g] = acc;
+  for (uint32_t j = q; j < len; j += 16) acc = quad_add(acc, in[(size_t)g * len + j], k);
+#pragma unroll 1
+  for (int d = 8; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (q + d < 16) acc = quad_add(acc, o, k); }
+  if (threadIdx.x == 0) out[g] = acc;
 }
 
 // ---- ones: strided partial sums over the compacted index list ---------------------------------------------------------

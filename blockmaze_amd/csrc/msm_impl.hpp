@@ -19,7 +19,7 @@ struct MsmImpl {
         hist((size_t)W * NB), offsets((size_t)W * NB), fill((size_t)W * NB), entries((n_ ? n_ : 1) * (size_t)W), ones(n_ ? n_ : 1), ntasks((size_t)W * NB + 1), task_off((size_t)W * NB + 1), counters(sizeof(MsmCounters)),
         scanner((size_t)W * NB), task_scanner((size_t)W * NB + 1) {
     if (c < 6 || c > 20 || W > MSM_MAX_WINDOWS) throw GpuError("msm: unsupported window size");
-    seg = NB >= 4096 ? 8 : 4; n_ones_threads = 16384;
+    { const char *e = getenv("ZK_MSM_SEG"); uint32_t big = e ? (uint32_t)atoi(e) : 16; if (big < 2 || big > 256 || (big & (big - 1))) big = 8; seg = NB >= 4096 ? big : 4; } n_ones_threads = 16384;
     std::vector<uint8_t> flags(n ? n : 1, 0); const uint8_t zero[sizeof(RawAffine)] = {0};
     for (size_t i = 0; i < n; i++) if (!memcmp(&host_points[i], zero, sizeof(RawAffine))) { flags[i] = 1; any_inf = true; }
     if (n) { points.upload(host_points, n); inf.upload(flags.data(), n); }
@@ -57,7 +57,7 @@ struct MsmImpl {
     }
     { Stage st_red((label + ".reduce").c_str(), s);
       uint32_t spw = NB / seg, nseg = (uint32_t)W * spw;
-      hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3(cdiv(nseg, 64)), dim3(64), 0, s, (const XYZZ<F> *)buckets.get(), NB, seg, nseg, (XYZZ<F> *)seg_out.get());
+      hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3(cdiv(nseg, 16)), dim3(64), 0, s, (const XYZZ<F> *)buckets.get(), NB, seg, nseg, (XYZZ<F> *)seg_out.get());
       if (spw > 64) { uint32_t g = cdiv(spw, 64);   // two-level tree per window keeps the dependent chain short
         hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W * g), dim3(64), 0, s, (const XYZZ<F> *)seg_out.get(), 64u, (XYZZ<F> *)seg_l2.get());
         hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W), dim3(64), 0, s, (const XYZZ<F> *)seg_l2.get(), g, (XYZZ<F> *)result.get());

@@ -54,6 +54,58 @@ __global__ void k_ntt_stage(Fr *__restrict__ data, const Fr *__restrict__ tw, in
   Fr u = d[i0]; d[i0] = u + t; d[i1] = u - t;
 }
 
+// ---- two-pass transform for n = n1 * n2 (both tiles fit LDS): natural order in, natural order out, no bit-reversal pass over HBM ----
+//   X[k1 + n1*k2] = sum_{i2} w_n2^(i2 k2) * [ w_n^(i2 k1) * sum_{i1} x[i1*n2 + i2] * w_n1^(i1 k1) ]
+// k_ntt_cols: the inner sums — for C adjacent columns i2 a workgroup loads the n1 x C tile (runs of C contiguous elements), runs log2(n1)
+//   decimation-in-frequency stages in LDS, multiplies by the step twiddles and stores Y[k1*n2 + i2] to the same positions (safe in place).
+// k_ntt_rows: the outer sums — C adjacent rows k1 (contiguous loads), log2(n2) stages in LDS, stores X[k1 + n1*k2] in runs of C.
+// tw[j] = w_n^j for j < n/2.  Optional tables: `pre` multiplies the input (natural index), `post` the output (natural index).
+constexpr int NTT_TILE_LOG = 11;             // at most 2048 elements (64 KiB of LDS) per workgroup
+constexpr int NTT_TILE_THREADS = 256;
+
+__device__ __forceinline__ Fr ntt_twiddle(const Fr *__restrict__ tw, uint32_t e, uint32_t half_n) { return e < half_n ? tw[e] : tw[e - half_n].neg(); }   // w^(n/2) = -1
+
+// log2(N) DIF stages over the rows of tile[N][C] (element i of column c at tile[i*C + c]); afterwards position p holds output bitrev(p).  tws = n / N
+__device__ __forceinline__ void ntt_lds_dif(Fr *tile, int logN, int logC, const Fr *__restrict__ tw, uint32_t tws) {
+  const uint32_t work = (1u << (logN - 1)) << logC, cmask = (1u << logC) - 1;
+  for (int s = logN; s >= 1; s--) {
+    const uint32_t half = 1u << (s - 1);
+    for (uint32_t w = threadIdx.x; w < work; w += blockDim.x) {
+      uint32_t b = w >> logC, c = w & cmask, j = b & (half - 1), i0 = ((b >> (s - 1)) << s) + j, p0 = (i0 << logC) + c, p1 = p0 + (half << logC);
+      Fr u = tile[p0], v = tile[p1]; tile[p0] = u + v; Fr d = u - v; if (j) d = d * tw[(j << (logN - s)) * tws]; tile[p1] = d;
+    }
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(const Fr *__restrict__ src, Fr *__restrict__ dst, const Fr *__restrict__ pre, const Fr *__restrict__ tw,
+                                                               int logn, int log_n1, int logC, size_t stride_in, size_t stride_out) {
+  extern __shared__ uint32_t lds_raw[]; Fr *tile = reinterpret_cast<Fr *>(lds_raw);
+  const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, c0 = blockIdx.x << logC, elems = (1u << log_n1) << logC, half_n = 1u << (logn - 1);
+  const Fr *s = src + blockIdx.y * stride_in; Fr *d = dst + blockIdx.y * stride_out;
+  for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t g = ((w >> logC) << log_n2) + c0 + (w & (C - 1)); Fr v = s[g]; if (pre) v = v * pre[g]; tile[w] = v; }
+  __syncthreads();
+  ntt_lds_dif(tile, log_n1, logC, tw, n2);
+  for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
+    uint32_t k1 = w >> logC, c = w & (C - 1), i2 = c0 + c, p = log_n1 ? bitrev32(k1, log_n1) : 0; Fr v = tile[(p << logC) + c];
+    uint32_t e = i2 * k1; if (e) v = v * ntt_twiddle(tw, e, half_n);
+    d[(k1 << log_n2) + i2] = v;
+  }
+}
+__global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_rows(const Fr *__restrict__ src, Fr *__restrict__ dst, const Fr *__restrict__ post, const Fr *__restrict__ tw,
+                                                               int logn, int log_n1, int logC, size_t stride_in, size_t stride_out) {
+  extern __shared__ uint32_t lds_raw[]; Fr *tile = reinterpret_cast<Fr *>(lds_raw);
+  const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, r0 = blockIdx.x << logC, elems = n2 << logC;
+  const Fr *s = src + blockIdx.y * stride_in; Fr *d = dst + blockIdx.y * stride_out;
+  for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t c = w >> log_n2, i2 = w & (n2 - 1); tile[(i2 << logC) + c] = s[((size_t)(r0 + c) << log_n2) + i2]; }
+  __syncthreads();
+  ntt_lds_dif(tile, log_n2, logC, tw, 1u << log_n1);
+  for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
+    uint32_t k2 = w >> logC, c = w & (C - 1), p = bitrev32(k2, log_n2), o = (k2 << log_n1) + r0 + c; Fr v = tile[(p << logC) + c];
+    if (post) v = v * post[o];
+    d[o] = v;
+  }
+}
+
 // a[i] *= table[i]
 __global__ void k_fr_mul_table(Fr *__restrict__ a, const Fr *__restrict__ table, uint32_t n, size_t stride) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; Fr *d = a + blockIdx.y * stride; d[i] = d[i] * table[i];

@@ -91,7 +91,7 @@ def test_msm_linearity_at_scale():
     K3 = o.to_arr([(a + b) % o.R_MOD for a, b in zip(k1, k2)]); assert run(K3) == o.g1_op("add", r1, r2)
     m.close()
 
-@pytest.mark.parametrize("m", [2, 4, 16, 24, 48, 64, 80, 1024, 1536, 4096, 5120])
+@pytest.mark.parametrize("m", [2, 4, 16, 24, 48, 64, 80, 1024, 1536, 2048, 4096, 5120, 1 << 13, (1 << 14) + (1 << 12), 1 << 16])
 def test_domain_transforms_match_oracle(m):
     assert e.domain_size(m) == o.domain_size(m); a = rand_field_arr(40 + m, o.domain_size(m))
     for op in ("fft", "ifft", "cosetfft", "icosetfft"):
@@ -103,6 +103,13 @@ def test_domain_roundtrip_at_scale(m):
     a = np.random.default_rng(m).integers(0, 1 << 62, size=(m, 4), dtype=np.uint64); a[:, 3] >>= 2
     assert np.array_equal(e.domain_transform(m, "ifft", e.domain_transform(m, "fft", a)), a)
     assert np.array_equal(e.domain_transform(m, "icosetfft", e.domain_transform(m, "cosetfft", a)), a)
+
+def test_domain_beyond_two_pass_tiles():
+    """2^23 points take the stage-per-launch path: FFT of the unit impulse at index 1 is the table of powers of the root of unity, and the round trip is exact"""
+    m = 1 << 23; a = np.zeros((m, 4), dtype=np.uint64); a[1, 0] = 1; f = e.domain_transform(m, "fft", a)
+    w = pow(pow(5, (o.R_MOD - 1) >> 28, o.R_MOD), 1 << 5, o.R_MOD)      # alt_bn128_init.cpp:112-116: Fr::root_of_unity = 5^((r-1)/2^28), squared down to order 2^23
+    for k in (0, 1, 2, 12345, m // 2, m - 1): assert o.from_arr(f[k:k + 1])[0] == pow(w, k, o.R_MOD), k
+    assert np.array_equal(e.domain_transform(m, "ifft", f), a)
 
 @pytest.mark.parametrize("seed,ni,nv,nc", [(7, 3, 40, 60), (8, 4, 30, 40), (21, 5, 600, 1019), (22, 2, 900, 1400)])
 def test_witness_map_matches_oracle(seed, ni, nv, nc):
