@@ -119,6 +119,20 @@ template <class F> __device__ __forceinline__ XYZZ<F> quad_add(const XYZZ<F> &a,
   m = quad_sel(k, Rv, S1, ZZZ12, ZZZ12) * lane_sel(k == 0, Q - r.X, PPP);
   r.Y = quad_pick<0>(m) - quad_pick<1>(m); r.ZZZ = quad_pick<2>(m); return r;
 }
+// madd-2008-s (affine operand):  round 1: U2 = X2*ZZ1 | S2 = Y2*ZZZ1      round 2: P^2 | R^2      round 3: P*PP | X1*PP | ZZ1*PP      round 4: R*(Q - X3) | Y1*PPP | ZZZ1*PPP
+template <class F> __device__ __forceinline__ XYZZ<F> quad_madd(const XYZZ<F> &a, const Affine<F> &p, int k) {
+  if (p.is_inf()) return a;
+  if (a.is_inf()) return XYZZ<F>::from_affine(p);
+  F m = lane_sel(k == 0, p.x, p.y) * lane_sel(k == 0, a.ZZ, a.ZZZ);
+  F Pv = quad_pick<0>(m) - a.X, Rv = quad_pick<1>(m) - a.Y;
+  if (Pv.is_zero()) { if (Rv.is_zero()) return quad_dbl(a, k); return XYZZ<F>::inf(); }
+  m = lane_sel(k == 0, Pv, Rv); m = m * m;
+  F PP = quad_pick<0>(m), RR = quad_pick<1>(m);
+  m = quad_sel(k, Pv, a.X, a.ZZ, a.ZZ) * PP;
+  F PPP = quad_pick<0>(m), Q = quad_pick<1>(m); XYZZ<F> r; r.ZZ = quad_pick<2>(m); r.X = RR - PPP - Q.dbl();
+  m = quad_sel(k, Rv, a.Y, a.ZZZ, a.ZZZ) * lane_sel(k == 0, Q - r.X, PPP);
+  r.Y = quad_pick<0>(m) - quad_pick<1>(m); r.ZZZ = quad_pick<2>(m); return r;
+}
 // n * a for a small scalar, MSB first
 template <class F> __device__ __forceinline__ XYZZ<F> quad_mul_small(const XYZZ<F> &a, uint32_t n, int k) {
   XYZZ<F> r = XYZZ<F>::inf(); if (!n) return r;

@@ -115,11 +115,42 @@ static __global__ void __launch_bounds__(BSORT_BLOCK) k_bsort_hist(const uint32_
   if (threadIdx.x < BSORT_CLASSES) block_hist[threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];          // class-major, so one exclusive scan yields every (class, block) base
 }
 static __global__ void __launch_bounds__(BSORT_BLOCK) k_bsort_scatter(const uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t n_blocks, const uint32_t *__restrict__ block_off,
-                                                               uint32_t *__restrict__ order, uint32_t *__restrict__ rank_of, uint32_t *__restrict__ ntasks) {
+                                                               uint32_t *__restrict__ order, uint32_t *__restrict__ rank_of, uint32_t *__restrict__ ntasks, uint32_t *__restrict__ cls_start, uint4 *__restrict__ bucket_mem, uint32_t bucket_u4) {
   __shared__ uint32_t h[BSORT_CLASSES]; if (threadIdx.x < BSORT_CLASSES) h[threadIdx.x] = 0; __syncthreads();
   uint32_t b = blockIdx.x * BSORT_BLOCK + threadIdx.x;
-  if (b < n_buckets) { uint32_t cnt = counts[b], cls = bsort_class(cnt), pos = block_off[cls * n_blocks + blockIdx.x] + atomicAdd(&h[cls], 1u); order[pos] = b; rank_of[b] = pos; ntasks[pos] = (cnt + MSM_TASK - 1) / MSM_TASK; }
+  if (b < n_buckets) { uint32_t cnt = counts[b], cls = bsort_class(cnt), pos = block_off[cls * n_blocks + blockIdx.x] + atomicAdd(&h[cls], 1u); order[pos] = b; rank_of[b] = pos; ntasks[pos] = (cnt + MSM_TASK - 1) / MSM_TASK;
+    if (cnt == 0) for (uint32_t j = 0; j < bucket_u4; j++) bucket_mem[(size_t)b * bucket_u4 + j] = make_uint4(0, 0, 0, 0); }      // empty bucket = point at infinity (all-zero record)
   if (b == 0) ntasks[n_buckets] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < BSORT_CLASSES) cls_start[threadIdx.x] = block_off[threadIdx.x * n_blocks];                  // rank of the first bucket of each size class
+}
+
+// The same planning for a small bucket array (witness MSMs: 32 windows x 128 buckets) in ONE launch of one workgroup instead of eleven launches:
+// offsets = exclusive scan of the histogram; order / rank_of = buckets by decreasing size class; task_off = exclusive scan of the task counts in that order.
+constexpr uint32_t PLAN_SMALL_MAX = 16384, PLAN_THREADS = 1024;
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *sh, uint32_t *total) {
+  sh[threadIdx.x] = v; __syncthreads();
+  for (int d = 1; d < (int)PLAN_THREADS; d <<= 1) { uint32_t t = threadIdx.x >= (uint32_t)d ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+  uint32_t r = sh[threadIdx.x] - v; *total = sh[PLAN_THREADS - 1]; __syncthreads(); return r;
+}
+static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_small(const uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t *__restrict__ offsets, uint32_t *__restrict__ order, uint32_t *__restrict__ rank_of,
+                                                                  uint32_t *__restrict__ task_off, uint32_t *__restrict__ cls_start, uint4 *__restrict__ bucket_mem, uint32_t bucket_u4) {
+  __shared__ uint32_t sh[PLAN_THREADS]; __shared__ uint32_t cls_cnt[BSORT_CLASSES], cls_base[BSORT_CLASSES];
+  const uint32_t per = (n_buckets + PLAN_THREADS - 1) / PLAN_THREADS, lo = threadIdx.x * per; uint32_t s = 0, total;
+  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) s += counts[lo + j];
+  uint32_t ex = block_exclusive_scan_1024(s, sh, &total);
+  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) { offsets[lo + j] = ex; ex += counts[lo + j]; }
+  if (threadIdx.x < BSORT_CLASSES) cls_cnt[threadIdx.x] = 0; __syncthreads();
+  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) { uint32_t b = lo + j, cnt = counts[b]; rank_of[b] = atomicAdd(&cls_cnt[bsort_class(cnt)], 1u);
+    if (cnt == 0) for (uint32_t q = 0; q < bucket_u4; q++) bucket_mem[(size_t)b * bucket_u4 + q] = make_uint4(0, 0, 0, 0); }
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t a = 0; for (uint32_t c = 0; c < BSORT_CLASSES; c++) { cls_base[c] = a; cls_start[c] = a; a += cls_cnt[c]; } }
+  __syncthreads();
+  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) { uint32_t b = lo + j, pos = cls_base[bsort_class(counts[b])] + rank_of[b]; rank_of[b] = pos; order[pos] = b; }
+  __threadfence_block(); __syncthreads();
+  s = 0; for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) s += (counts[order[lo + j]] + MSM_TASK - 1) / MSM_TASK;
+  ex = block_exclusive_scan_1024(s, sh, &total);
+  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) { task_off[lo + j] = ex; ex += (counts[order[lo + j]] + MSM_TASK - 1) / MSM_TASK; }
+  if (threadIdx.x == 0) task_off[n_buckets] = total;
 }
 // task_off: exclusive scan of ntasks over the SORTED bucket list (n_buckets + 1 entries, the last one = total)
 template <class F>
@@ -133,17 +164,38 @@ __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *_
   for (uint32_t e = beg; e < end; e++) { uint32_t v = entries[e]; Affine<F> p = points[v & 0x7fffffffu]; if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); }
   if (cnt <= MSM_TASK) buckets[b] = acc; else partials[t] = acc;
 }
-// buckets that were cut into several tasks: LANES lanes add up the partial sums
-template <class F, int LANES>
-__global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ rank_of, const uint32_t *__restrict__ task_off, uint32_t n_buckets, const XYZZ<F> *__restrict__ partials, XYZZ<F> *__restrict__ buckets) {
-  uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, b = gid / LANES, lane = gid % LANES; bool active = b < n_buckets;
-  uint32_t cnt = active ? counts[b] : 0; bool multi = cnt > MSM_TASK;
-  if (!__any(multi)) { if (active && cnt == 0 && lane == 0) buckets[b] = XYZZ<F>::inf(); return; }
-  XYZZ<F> acc = XYZZ<F>::inf();
-  if (multi) { uint32_t i = rank_of[b], beg = task_off[i], nt = task_off[i + 1] - beg; for (uint32_t j = lane; j < nt; j += LANES) acc.add_inl(partials[beg + j]); }
+// ---- sums by the 64 quads of a 256-thread workgroup ------------------------------------------------------------------------
+// quad q adds elements q, q+64, ...; then a tree over the 16 quads of each wave (shuffles) and over the 4 waves (LDS).  The result is valid in lanes 0..3.
+template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<F> *__restrict__ src, uint32_t len, XYZZ<F> *lds) {
+  const uint32_t q = threadIdx.x >> 2, wq = q & 15, wave = threadIdx.x >> 6; const int k = threadIdx.x & 3; XYZZ<F> acc = XYZZ<F>::inf();
 #pragma unroll 1
-  for (int d = LANES / 2; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); acc.add_inl(o); }
-  if (active && lane == 0) { if (multi) buckets[b] = acc; else if (cnt == 0) buckets[b] = XYZZ<F>::inf(); }
+  for (uint32_t j = q; j < len; j += 64) acc = quad_add(acc, src[j], k);
+#pragma unroll 1
+  for (int d = 8; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (wq + d < 16) acc = quad_add(acc, o, k); }
+  if ((threadIdx.x & 63) == 0) lds[wave] = acc;
+  __syncthreads();
+  if (wave == 0) { acc = q < 4 ? lds[q] : XYZZ<F>::inf();
+#pragma unroll 1
+    for (int d = 2; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (q + d < 4) acc = quad_add(acc, o, k); } }
+  return acc;
+}
+
+// buckets that were cut into several tasks: add up the partial sums.  Buckets are ranked by decreasing size (order[], cls_start[]): the first `heavy_blocks`
+// workgroups walk the heavy buckets (>= 49 entries, i.e. 4 tasks or more) one workgroup per bucket, the others take one light bucket (2..3 tasks) per quad.
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, const uint32_t *__restrict__ cls_start, uint32_t heavy_blocks,
+                                                           const XYZZ<F> *__restrict__ partials, XYZZ<F> *__restrict__ buckets) {
+  __shared__ XYZZ<F> lds[4];
+  const uint32_t n_heavy = cls_start[BSORT_CLASSES - 1 - 3 * MSM_TASK], n_multi = cls_start[BSORT_CLASSES - 1 - MSM_TASK];   // ranks below: count > 48, count > 16
+  if (blockIdx.x < heavy_blocks) {
+    for (uint32_t r = blockIdx.x; r < n_heavy; r += heavy_blocks) { uint32_t beg = task_off[r]; XYZZ<F> acc = block_quad_sum(partials + beg, task_off[r + 1] - beg, lds); if (threadIdx.x == 0) buckets[order[r]] = acc; __syncthreads(); }
+    return;
+  }
+  uint32_t r = n_heavy + (blockIdx.x - heavy_blocks) * 64 + (threadIdx.x >> 2); int k = threadIdx.x & 3; if (r >= n_multi) return;
+  uint32_t beg = task_off[r], nt = task_off[r + 1] - beg; XYZZ<F> acc = partials[beg];
+#pragma unroll 1
+  for (uint32_t j = 1; j < nt; j++) acc = quad_add(acc, partials[beg + j], k);
+  if (k == 0) buckets[order[r]] = acc;
 }
 
 // ---- bucket reduction: sum_{b=1..NB} b * B_b per window, by segments of SEG buckets --------------------------------
@@ -161,24 +213,23 @@ __global__ void __launch_bounds__(64) k_msm_reduce_segments(const XYZZ<F> *__res
   if (k == 0) seg_out[t] = acc;
 }
 
-// ---- generic grouped sum: out[g] = sum_{j<len} in[g*len + j], one wave (16 quads) per group -------------------------
+// ---- generic grouped sum: out[g] = sum_{j<len} in[g*len + j] (the last group may be short: n_in elements in total), one 256-thread workgroup per group.
+// copy_src/copy_dst (optional): 16 bytes carried along by block 0 (the MSM counters travel to the host next to the result)
 template <class F>
-__global__ void __launch_bounds__(64) k_xyzz_group_sum(const XYZZ<F> *__restrict__ in, uint32_t len, XYZZ<F> *__restrict__ out) {
-  uint32_t g = blockIdx.x, q = threadIdx.x >> 2; int k = threadIdx.x & 3; XYZZ<F> acc = XYZZ<F>::inf();
-#pragma unroll 1
-  for (uint32_t j = q; j < len; j += 16) acc = quad_add(acc, in[(size_t)g * len + j], k);
-#pragma unroll 1
-  for (int d = 8; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (q + d < 16) acc = quad_add(acc, o, k); }
-  if (threadIdx.x == 0) out[g] = acc;
+__global__ void __launch_bounds__(256) k_xyzz_group_sum(const XYZZ<F> *__restrict__ in, uint32_t len, uint32_t n_in, XYZZ<F> *__restrict__ out, const uint4 *copy_src, uint4 *copy_dst) {
+  __shared__ XYZZ<F> lds[4]; uint32_t g = blockIdx.x, beg = g * len, l = beg >= n_in ? 0 : min(len, n_in - beg);
+  XYZZ<F> acc = block_quad_sum(in + beg, l, lds);
+  if (threadIdx.x == 0) { out[g] = acc; if (copy_src && g == 0) *copy_dst = *copy_src; }
 }
 
-// ---- ones: strided partial sums over the compacted index list ---------------------------------------------------------
+// ---- ones: strided partial sums over the compacted index list, one quad per partial -------------------------------------
 template <class F>
-__global__ void __launch_bounds__(256) k_msm_sum_ones(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ ones, const MsmCounters *cnt, uint32_t n_threads, XYZZ<F> *__restrict__ partial) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= n_threads) return;
+__global__ void __launch_bounds__(256) k_msm_sum_ones(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ ones, const MsmCounters *cnt, uint32_t n_quads, XYZZ<F> *__restrict__ partial) {
+  uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; int k = threadIdx.x & 3; if (t >= n_quads) return;
   uint32_t n = cnt->n_ones; XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t j = t; j < n; j += n_threads) acc.madd_inl(points[ones[j]]);
-  partial[t] = acc;
+#pragma unroll 1
+  for (uint32_t j = t; j < n; j += n_quads) acc = quad_madd(acc, points[ones[j]], k);
+  if (k == 0) partial[t] = acc;
 }
 
 }  // namespace zk

@@ -90,7 +90,58 @@ template <class P> __device__ __forceinline__ Fp<P> mul_vb(const Fp<P> &a, const
   for (int j = 0; j < 8; j++) { c += col[8 + j]; r.l[j] = (uint32_t)c; c >>= 32; }
   return Fp<P>::reduce_once(r);
 }
-template <int V> __device__ __forceinline__ Fq mulv(const Fq &a, const Fq &b) { if (V == 0) return a * b; if (V == 1) return mul_va(a, b); return mul_vb(a, b); }
+// VC: product scanning (Comba) with a 96-bit column accumulator: every 32x32 MAC is one v_mad_u64_u32 whose carry-out feeds one v_addc into the third word
+__device__ __forceinline__ void mac96(uint64_t &acc, uint32_t &top, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(top) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ void mac96s(uint64_t &acc, uint32_t &top, uint32_t a, uint32_t b_const) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(top) : "v"(a), "s"(b_const) : "vcc");
+}
+template <class P> __device__ __forceinline__ Fp<P> mul_vc(const Fp<P> &a, const Fp<P> &b) {
+  uint64_t acc = 0; uint32_t top = 0, m[8]; Fp<P> r;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) mac96(acc, top, a.l[i], b.l[k - i]);
+#pragma unroll
+    for (int i = 0; i < k; i++) mac96s(acc, top, m[i], P::MOD[k - i]);
+    m[k] = (uint32_t)acc * P::INV; mac96s(acc, top, m[k], P::MOD[0]);
+    acc = (acc >> 32) | ((uint64_t)top << 32); top = 0;
+  }
+#pragma unroll
+  for (int k = 8; k < 16; k++) {
+#pragma unroll
+    for (int i = k - 7; i < 8; i++) mac96(acc, top, a.l[i], b.l[k - i]);
+#pragma unroll
+    for (int i = k - 7; i < 8; i++) mac96s(acc, top, m[i], P::MOD[k - i]);
+    r.l[k - 8] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)top << 32); top = 0;
+  }
+  return Fp<P>::reduce_once(r);
+}
+// VD: the same schedule in plain C++ (what the compiler makes of a 96-bit accumulator)
+__device__ __forceinline__ void mac96c(uint64_t &acc, uint32_t &top, uint32_t a, uint32_t b) { uint64_t p = (uint64_t)a * b, s = acc + p; top += s < p; acc = s; }
+template <class P> __device__ __forceinline__ Fp<P> mul_vd(const Fp<P> &a, const Fp<P> &b) {
+  uint64_t acc = 0; uint32_t top = 0, m[8]; Fp<P> r;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) mac96c(acc, top, a.l[i], b.l[k - i]);
+#pragma unroll
+    for (int i = 0; i < k; i++) mac96c(acc, top, m[i], P::MOD[k - i]);
+    m[k] = (uint32_t)acc * P::INV; mac96c(acc, top, m[k], P::MOD[0]);
+    acc = (acc >> 32) | ((uint64_t)top << 32); top = 0;
+  }
+#pragma unroll
+  for (int k = 8; k < 16; k++) {
+#pragma unroll
+    for (int i = k - 7; i < 8; i++) mac96c(acc, top, a.l[i], b.l[k - i]);
+#pragma unroll
+    for (int i = k - 7; i < 8; i++) mac96c(acc, top, m[i], P::MOD[k - i]);
+    r.l[k - 8] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)top << 32); top = 0;
+  }
+  return Fp<P>::reduce_once(r);
+}
+template <int V> __device__ __forceinline__ Fq mulv(const Fq &a, const Fq &b) { if (V == 0) return a * b; if (V == 1) return mul_va(a, b); if (V == 2) return mul_vb(a, b); if (V == 3) return mul_vc(a, b); return mul_vd(a, b); }
 template <int V> __global__ void k_mont(const Fq *in, Fq *out, int iters) {
   int i = blockIdx.x * blockDim.x + threadIdx.x; Fq x = in[i], y = in[i + 1], z = in[i + 2], w = in[i + 3];
   for (int k = 0; k < iters; k++) { x = mulv<V>(x, y); z = mulv<V>(z, w); y = mulv<V>(y, x); w = mulv<V>(w, z); }   // two independent chains
@@ -120,6 +171,10 @@ int main() {
   ms = timeit(k_mont<0>, dim3(blocks), dim3(threads), fin, fout, it); printf("mont mul V0 (CIOS, current) 2 chains: %.2f Gmul/s\n", (double)n * it * 4 / ms / 1e6);
   ms = timeit(k_mont<1>, dim3(blocks), dim3(threads), fin, fout, it); printf("mont mul VA (row products + 2 carry chains) 2 chains: %.2f Gmul/s\n", (double)n * it * 4 / ms / 1e6);
   ms = timeit(k_mont<2>, dim3(blocks), dim3(threads), fin, fout, it); printf("mont mul VB (column sums 64-bit) 2 chains: %.2f Gmul/s\n", (double)n * it * 4 / ms / 1e6);
+  ms = timeit(k_mont<3>, dim3(blocks), dim3(threads), fin, fout, it); printf("mont mul VC (Comba, 96-bit accumulator, asm carry) 2 chains: %.2f Gmul/s\n", (double)n * it * 4 / ms / 1e6);
+  ms = timeit(k_mont<4>, dim3(blocks), dim3(threads), fin, fout, it); printf("mont mul VD (Comba, plain C++) 2 chains: %.2f Gmul/s\n", (double)n * it * 4 / ms / 1e6);
+  ms = timeit(k_mont1<3>, dim3(blocks), dim3(threads), fin, fout, it); printf("mont mul VC 1 chain: %.2f Gmul/s\n", (double)n * it * 4 / ms / 1e6);
+  ms = timeit(k_mont1<3>, dim3(256), dim3(64), fin, fout, it); printf("mont mul VC latency (1 wave/CU): %.1f ns per mul\n", ms * 1e6 / (it * 4.0));
   ms = timeit(k_mont1<0>, dim3(blocks), dim3(threads), fin, fout, it); printf("mont mul V0 1 chain: %.2f Gmul/s\n", (double)n * it * 4 / ms / 1e6);
   ms = timeit(k_mont1<1>, dim3(blocks), dim3(threads), fin, fout, it); printf("mont mul VA 1 chain: %.2f Gmul/s\n", (double)n * it * 4 / ms / 1e6);
   ms = timeit(k_mont1<2>, dim3(blocks), dim3(threads), fin, fout, it); printf("mont mul VB 1 chain: %.2f Gmul/s\n", (double)n * it * 4 / ms / 1e6);
@@ -130,5 +185,7 @@ int main() {
   std::vector<uint32_t> o0(n * 8), o1(n * 8), o2(n * 8); hipLaunchKernelGGL(k_mont<0>, dim3(blocks), dim3(threads), 0, 0, fin, fout, 3); CK(hipMemcpy(o0.data(), fout, n * 32, hipMemcpyDeviceToHost));
   hipLaunchKernelGGL(k_mont<1>, dim3(blocks), dim3(threads), 0, 0, fin, fout, 3); CK(hipMemcpy(o1.data(), fout, n * 32, hipMemcpyDeviceToHost)); hipLaunchKernelGGL(k_mont<2>, dim3(blocks), dim3(threads), 0, 0, fin, fout, 3); CK(hipMemcpy(o2.data(), fout, n * 32, hipMemcpyDeviceToHost));
   printf("VA == V0: %s, VB == V0: %s\n", o0 == o1 ? "yes" : "NO", o0 == o2 ? "yes" : "NO");
+  hipLaunchKernelGGL(k_mont<3>, dim3(blocks), dim3(threads), 0, 0, fin, fout, 3); CK(hipMemcpy(o1.data(), fout, n * 32, hipMemcpyDeviceToHost)); hipLaunchKernelGGL(k_mont<4>, dim3(blocks), dim3(threads), 0, 0, fin, fout, 3); CK(hipMemcpy(o2.data(), fout, n * 32, hipMemcpyDeviceToHost));
+  printf("VC == V0: %s, VD == V0: %s\n", o0 == o1 ? "yes" : "NO", o0 == o2 ? "yes" : "NO");
   return 0;
 }

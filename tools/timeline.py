@@ -13,7 +13,9 @@ def col(r, *names):
         if n in r: return r[n]
     raise KeyError(names)
 ev = sorted(((int(col(r, "Start_Timestamp")), int(col(r, "End_Timestamp")), col(r, "Kernel_Name"), col(r, "Stream_Id", "Queue_Id")) for r in rows), key=lambda t: t[0])
-starts = [i for i, e in enumerate(ev) if e[2].startswith("zk::k_r1cs_rows") or "k_r1cs_rows" in e[2]]
+starts = []
+for i, e in enumerate(ev):
+    if "k_r1cs_rows" in e[2] and (not starts or e[0] - ev[starts[-1]][0] > 1000000): starts.append(i)      # three row kernels per proof: keep the first
 k = back if back < len(starts) - 1 else len(starts) - 2          # argument = proof number from the start of the trace
 lo = ev[starts[k]][0] - 100000; hi = ev[starts[k + 1]][0] - 100000
 sel = [e for e in ev if lo <= e[0] < hi]
