@@ -83,20 +83,23 @@ struct Radix2Tables {
 };
 static std::vector<Fe32> geometric_table(size_t n, const HFr &first, const HFr &ratio) { std::vector<Fe32> t(n); HFr x = first; for (size_t i = 0; i < n; i++) { memcpy(&t[i], x.l, 32); x = x * ratio; } return t; }
 
-// in-place radix-2 transform of `batch` vectors: data = post * NTT(pre * data), natural order in and out.  Up to 2^22 points: two LDS-tiled passes
+// in-place radix-2 transform of `batch` vectors: data = post * NTT(pre * data), natural order in and out.  Up to 2^20 points: two LDS-tiled passes
 // (k_ntt_cols: data -> scratch, k_ntt_rows: scratch -> data; one pass in place when the whole vector fits a tile); beyond that the stage-per-launch path.
 static int ntt_pref_log_c() { static const int v = [] { const char *e = getenv("ZK_NTT_LOGC"); int x = e ? atoi(e) : 1; return x < 0 ? 0 : x > 3 ? 3 : x; }(); return v; }
 static void radix2_transform(Fe32 *data, Fe32 *scratch, const Fe32 *tw, int logn, const Fe32 *pre_scale, const Fe32 *post_scale, int batch, size_t stride, size_t scratch_stride) {
   hipStream_t s = gpu().stream; size_t n = (size_t)1 << logn;
+  static const int rl = [] { const char *e = getenv("ZK_NTT_RADIX_LOG"); int x = e ? atoi(e) : 3; return x < 1 ? 1 : x > 3 ? 3 : x; }();   // radix-8 passes measured best with three vectors per launch
+  auto threads_for = [](int logN, int logC) { int g = logN + logC - rl; unsigned t = 1u << (g < 6 ? 6 : g > 8 ? 8 : g); return t; };   // one butterfly group per thread and pass, 64..256 threads
+  auto lds_for = [](int logN, int logC) { return (sizeof(Fr) << (logN + logC)) + (sizeof(Fr) << logN) / 2; };                            // tile + twiddle table
   if (logn <= NTT_TILE_LOG) {          // n2 = 1: the column pass alone is the whole transform
     if (post_scale) throw GpuError("ntt: post scale on a single-pass transform");
-    hipLaunchKernelGGL(k_ntt_cols, dim3(1, batch), dim3(NTT_TILE_THREADS), sizeof(Fr) << logn, s, (const Fr *)data, (Fr *)data, (const Fr *)pre_scale, (const Fr *)tw, logn, logn, 0, stride, stride);
+    hipLaunchKernelGGL(k_ntt_cols, dim3(1, batch), dim3(threads_for(logn, 0)), lds_for(logn, 0), s, (const Fr *)data, (Fr *)data, (const Fr *)pre_scale, (const Fr *)tw, logn, logn, 0, rl, stride, stride);
     return;
   }
   if (logn <= 2 * NTT_TILE_LOG) {
     int l1 = logn / 2, l2 = logn - l1, c1 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l1, l2)), c2 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l2, l1));
-    hipLaunchKernelGGL(k_ntt_cols, dim3((unsigned)(1u << (l2 - c1)), batch), dim3(NTT_TILE_THREADS), sizeof(Fr) << (l1 + c1), s, (const Fr *)data, (Fr *)scratch, (const Fr *)pre_scale, (const Fr *)tw, logn, l1, c1, stride, scratch_stride);
-    hipLaunchKernelGGL(k_ntt_rows, dim3((unsigned)(1u << (l1 - c2)), batch), dim3(NTT_TILE_THREADS), sizeof(Fr) << (l2 + c2), s, (const Fr *)scratch, (Fr *)data, (const Fr *)post_scale, (const Fr *)tw, logn, l1, c2, scratch_stride, stride);
+    hipLaunchKernelGGL(k_ntt_cols, dim3((unsigned)(1u << (l2 - c1)), batch), dim3(threads_for(l1, c1)), lds_for(l1, c1), s, (const Fr *)data, (Fr *)scratch, (const Fr *)pre_scale, (const Fr *)tw, logn, l1, c1, rl, stride, scratch_stride);
+    hipLaunchKernelGGL(k_ntt_rows, dim3((unsigned)(1u << (l1 - c2)), batch), dim3(threads_for(l2, c2)), lds_for(l2, c2), s, (const Fr *)scratch, (Fr *)data, (const Fr *)post_scale, (const Fr *)tw, logn, l1, c2, rl, scratch_stride, stride);
     return;
   }
   hipLaunchKernelGGL(k_ntt_bitrev_scale, dim3(cdiv(n, 256), batch), dim3(256), 0, s, (const Fr *)data, (Fr *)scratch, (const Fr *)pre_scale, logn, stride, scratch_stride);

@@ -60,31 +60,47 @@ __global__ void k_ntt_stage(Fr *__restrict__ data, const Fr *__restrict__ tw, in
 //   decimation-in-frequency stages in LDS, multiplies by the step twiddles and stores Y[k1*n2 + i2] to the same positions (safe in place).
 // k_ntt_rows: the outer sums — C adjacent rows k1 (contiguous loads), log2(n2) stages in LDS, stores X[k1 + n1*k2] in runs of C.
 // tw[j] = w_n^j for j < n/2.  Optional tables: `pre` multiplies the input (natural index), `post` the output (natural index).
-constexpr int NTT_TILE_LOG = 11;             // at most 2048 elements (64 KiB of LDS) per workgroup
+constexpr int NTT_TILE_LOG = 10;             // at most 1024 elements per workgroup: 32 KiB of LDS for the tile + 16 KiB for its twiddles
 constexpr int NTT_TILE_THREADS = 256;
 
 __device__ __forceinline__ Fr ntt_twiddle(const Fr *__restrict__ tw, uint32_t e, uint32_t half_n) { return e < half_n ? tw[e] : tw[e - half_n].neg(); }   // w^(n/2) = -1
 
-// log2(N) DIF stages over the rows of tile[N][C] (element i of column c at tile[i*C + c]); afterwards position p holds output bitrev(p).  tws = n / N
-__device__ __forceinline__ void ntt_lds_dif(Fr *tile, int logN, int logC, const Fr *__restrict__ tw, uint32_t tws) {
-  const uint32_t work = (1u << (logN - 1)) << logC, cmask = (1u << logC) - 1;
-  for (int s = logN; s >= 1; s--) {
-    const uint32_t half = 1u << (s - 1);
-    for (uint32_t w = threadIdx.x; w < work; w += blockDim.x) {
-      uint32_t b = w >> logC, c = w & cmask, j = b & (half - 1), i0 = ((b >> (s - 1)) << s) + j, p0 = (i0 << logC) + c, p1 = p0 + (half << logC);
-      Fr u = tile[p0], v = tile[p1]; tile[p0] = u + v; Fr d = u - v; if (j) d = d * tw[(j << (logN - s)) * tws]; tile[p1] = d;
+// R decimation-in-frequency stages (s, s-1, ..., s-R+1) of the N-point transforms over the rows of tile[N][C] (element i of column c at tile[i*C + c]) with the
+// 2^R values of a butterfly group held in registers: one LDS round trip and one barrier per R stages.  twl[j] = w_N^j (j < N/2) is an LDS copy of the twiddles.
+template <int R> __device__ __forceinline__ void ntt_lds_pass(Fr *tile, const Fr *twl, int logN, int logC, int s) {
+  const uint32_t groups = (1u << (logN - R)) << logC, cmask = (1u << logC) - 1; const int sh = s - R;
+  for (uint32_t w = threadIdx.x; w < groups; w += blockDim.x) {
+    const uint32_t g = w >> logC, c = w & cmask, base = ((g >> sh) << s) | (g & ((1u << sh) - 1)); Fr x[1 << R];
+#pragma unroll
+    for (int q = 0; q < (1 << R); q++) x[q] = tile[((base + ((uint32_t)q << sh)) << logC) + c];
+#pragma unroll
+    for (int t = 0; t < R; t++) { const int st = s - t, hx = 1 << (R - 1 - t);
+#pragma unroll
+      for (int q = 0; q < (1 << R); q++) if (!(q & hx)) {
+        uint32_t j = (base + ((uint32_t)q << sh)) & ((1u << (st - 1)) - 1); Fr u = x[q], v = x[q + hx]; x[q] = u + v; Fr d = u - v; if (j) d = d * twl[j << (logN - st)]; x[q + hx] = d; }
     }
-    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < (1 << R); q++) tile[((base + ((uint32_t)q << sh)) << logC) + c] = x[q];
   }
+  __syncthreads();
+}
+// log2(N) DIF stages; afterwards position p holds output bitrev(p).  tws = n / N: twl[j] = tw[j * tws]
+__device__ __forceinline__ void ntt_lds_dif(Fr *tile, Fr *twl, int logN, int logC, const Fr *__restrict__ tw, uint32_t tws, int radix_log) {
+  for (uint32_t j = threadIdx.x; j < (1u << logN) / 2; j += blockDim.x) twl[j] = tw[j * tws];
+  __syncthreads();
+  int s = logN;
+  if (radix_log >= 3) for (; s >= 3; s -= 3) ntt_lds_pass<3>(tile, twl, logN, logC, s);
+  if (radix_log >= 2) for (; s >= 2; s -= 2) ntt_lds_pass<2>(tile, twl, logN, logC, s);
+  for (; s >= 1; s -= 1) ntt_lds_pass<1>(tile, twl, logN, logC, s);
 }
 __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(const Fr *__restrict__ src, Fr *__restrict__ dst, const Fr *__restrict__ pre, const Fr *__restrict__ tw,
-                                                               int logn, int log_n1, int logC, size_t stride_in, size_t stride_out) {
+                                                               int logn, int log_n1, int logC, int radix_log, size_t stride_in, size_t stride_out) {
   extern __shared__ uint32_t lds_raw[]; Fr *tile = reinterpret_cast<Fr *>(lds_raw);
   const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, c0 = blockIdx.x << logC, elems = (1u << log_n1) << logC, half_n = 1u << (logn - 1);
   const Fr *s = src + blockIdx.y * stride_in; Fr *d = dst + blockIdx.y * stride_out;
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t g = ((w >> logC) << log_n2) + c0 + (w & (C - 1)); Fr v = s[g]; if (pre) v = v * pre[g]; tile[w] = v; }
   __syncthreads();
-  ntt_lds_dif(tile, log_n1, logC, tw, n2);
+  ntt_lds_dif(tile, tile + elems, log_n1, logC, tw, n2, radix_log);
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
     uint32_t k1 = w >> logC, c = w & (C - 1), i2 = c0 + c, p = log_n1 ? bitrev32(k1, log_n1) : 0; Fr v = tile[(p << logC) + c];
     uint32_t e = i2 * k1; if (e) v = v * ntt_twiddle(tw, e, half_n);
@@ -92,13 +108,13 @@ __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(const Fr *__restr
   }
 }
 __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_rows(const Fr *__restrict__ src, Fr *__restrict__ dst, const Fr *__restrict__ post, const Fr *__restrict__ tw,
-                                                               int logn, int log_n1, int logC, size_t stride_in, size_t stride_out) {
+                                                               int logn, int log_n1, int logC, int radix_log, size_t stride_in, size_t stride_out) {
   extern __shared__ uint32_t lds_raw[]; Fr *tile = reinterpret_cast<Fr *>(lds_raw);
   const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, r0 = blockIdx.x << logC, elems = n2 << logC;
   const Fr *s = src + blockIdx.y * stride_in; Fr *d = dst + blockIdx.y * stride_out;
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t c = w >> log_n2, i2 = w & (n2 - 1); tile[(i2 << logC) + c] = s[((size_t)(r0 + c) << log_n2) + i2]; }
   __syncthreads();
-  ntt_lds_dif(tile, log_n2, logC, tw, 1u << log_n1);
+  ntt_lds_dif(tile, tile + elems, log_n2, logC, tw, 1u << log_n1, radix_log);
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
     uint32_t k2 = w >> logC, c = w & (C - 1), p = bitrev32(k2, log_n2), o = (k2 << log_n1) + r0 + c; Fr v = tile[(p << logC) + c];
     if (post) v = v * post[o];
