@@ -228,7 +228,8 @@ void fr_from_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_from_m
 // ======================================================================================================================
 struct R1csDev::Impl {
   size_t n_inputs, n_vars, n_cons; DevBuf<uint32_t> rowptr[3], col[3], cid[3], long_rows[3]; size_t n_long[3] = {0, 0, 0}; DevBuf<Fe32> ctab; DevBuf<uint32_t> flag; uint32_t *h_flag = nullptr;
-  ~Impl() { if (h_flag) hipHostFree(h_flag); }
+  DevBuf<uint32_t> long_any; size_t n_long_any = 0; uint32_t *h_fail = nullptr, *d_fail = nullptr, seq = 0;   // h_fail: mapped host word the prover's row kernels store the evaluation number to when a constraint is violated
+  ~Impl() { if (h_flag) hipHostFree(h_flag); if (h_fail) hipHostFree(h_fail); }
 };
 R1csDev::R1csDev(const R1csHost &h) : impl(new Impl) {
   Impl &d = *impl; d.n_inputs = h.n_inputs; d.n_vars = h.n_vars; d.n_cons = h.n_cons;
@@ -254,22 +255,20 @@ R1csDev::R1csDev(const R1csHost &h) : impl(new Impl) {
     std::vector<uint32_t> lr; for (size_t i = 0; i < h.n_cons; i++) if (h.rowptr[m][i + 1] - h.rowptr[m][i] > R1CS_LONG_ROW) lr.push_back((uint32_t)i);
     d.n_long[m] = lr.size(); d.long_rows[m] = DevBuf<uint32_t>(lr.size() + 1); if (!lr.empty()) d.long_rows[m].upload(lr.data(), lr.size());
   }
+  { std::vector<uint32_t> lr; for (size_t i = 0; i < h.n_cons; i++) { bool lg = false; for (int m = 0; m < 3; m++) lg |= h.rowptr[m][i + 1] - h.rowptr[m][i] > R1CS_LONG_ROW; if (lg) lr.push_back((uint32_t)i); }
+    d.n_long_any = lr.size(); d.long_any = DevBuf<uint32_t>(lr.size() + 1); if (!lr.empty()) d.long_any.upload(lr.data(), lr.size()); }
   d.ctab = DevBuf<Fe32>(tab.size()); d.ctab.upload(tab.data(), tab.size()); d.flag = DevBuf<uint32_t>(1); HIP_CHECK(hipHostMalloc((void **)&d.h_flag, 4));
+  HIP_CHECK(hipHostMalloc((void **)&d.h_fail, 4, hipHostMallocMapped)); *d.h_fail = 0; HIP_CHECK(hipHostGetDevicePointer((void **)&d.d_fail, d.h_fail, 0));
 }
 R1csDev::~R1csDev() = default;
 void R1csDev::eval(const Fe32 *z, Fe32 *abc, size_t m) {
   Stage st("r1cs.rows"); Impl &d = *impl; hipStream_t s = gpu().stream; if (m < d.n_cons + d.n_inputs + 1) throw GpuError("r1cs: domain too small");
-  HIP_CHECK(hipMemsetAsync(abc, 0, 3 * m * sizeof(Fe32), s));
-  for (int mm = 0; mm < 3; mm++) if (d.n_cons) hipLaunchKernelGGL(k_r1cs_rows, dim3(cdiv(d.n_cons, 256)), dim3(256), 0, s, d.rowptr[mm].get(), d.col[mm].get(), d.cid[mm].get(), (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)d.n_cons, (Fr *)(abc + mm * m));
-  for (int mm = 0; mm < 3; mm++) if (d.n_long[mm]) hipLaunchKernelGGL(k_r1cs_long_rows, dim3((unsigned)d.n_long[mm]), dim3(64), 0, s, d.long_rows[mm].get(), d.rowptr[mm].get(), d.col[mm].get(), d.cid[mm].get(), (const Fr *)d.ctab.get(), (const Fr *)z, (Fr *)(abc + mm * m));
-  HIP_CHECK(hipMemcpyAsync(abc + d.n_cons, z, (d.n_inputs + 1) * sizeof(Fe32), hipMemcpyDeviceToDevice, s));   // input-consistency rows (r1cs_to_qap.tcc:227-230)
+  R1csMatrices M; for (int mm = 0; mm < 3; mm++) { M.rowptr[mm] = d.rowptr[mm].get(); M.col[mm] = d.col[mm].get(); M.cid[mm] = d.cid[mm].get(); }
+  if (++d.seq == 0) d.seq = 1;
+  hipLaunchKernelGGL(k_r1cs_rows3, dim3(cdiv(m, 256)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)d.n_cons, (uint32_t)d.n_inputs, (uint32_t)m, (Fr *)abc, d.seq, d.d_fail);
+  if (d.n_long_any) hipLaunchKernelGGL(k_r1cs_long_rows3, dim3((unsigned)d.n_long_any), dim3(64), 0, s, d.long_any.get(), M, (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)m, (Fr *)abc, d.seq, d.d_fail);
 }
-void R1csDev::check_async(const Fe32 *abc, size_t m) {
-  Impl &d = *impl; hipStream_t s = gpu().stream; HIP_CHECK(hipMemsetAsync(d.flag.get(), 0, 4, s));
-  if (d.n_cons) hipLaunchKernelGGL(k_r1cs_check, dim3(cdiv(d.n_cons, 256)), dim3(256), 0, s, (const Fr *)abc, (const Fr *)(abc + m), (const Fr *)(abc + 2 * m), (uint32_t)d.n_cons, d.flag.get());
-  HIP_CHECK(hipMemcpyAsync(d.h_flag, d.flag.get(), 4, hipMemcpyDeviceToHost, s));
-}
-bool R1csDev::check_result() const { return *impl->h_flag == 0; }
+bool R1csDev::check_result() const { return *impl->h_fail != impl->seq; }   // valid once the main stream has been synchronised after eval()
 bool R1csDev::satisfied(const Fe32 *abc, size_t m) {
   Impl &d = *impl; hipStream_t s = gpu().stream; d.flag.zero();
   if (d.n_cons) hipLaunchKernelGGL(k_r1cs_check, dim3(cdiv(d.n_cons, 256)), dim3(256), 0, s, (const Fr *)abc, (const Fr *)(abc + m), (const Fr *)(abc + 2 * m), (uint32_t)d.n_cons, d.flag.get());

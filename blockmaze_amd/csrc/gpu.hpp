@@ -89,8 +89,7 @@ class R1csDev {
   // z_dev: n_vars+1 Fr (Montgomery, z[0] = 1).  abc: 3 vectors of m (zero padded, aA[n_cons + i] = z_i for i <= n_inputs; r1cs_to_qap.tcc:227-230)
   void eval(const Fe32 *z_dev, Fe32 *abc, size_t m);
   bool satisfied(const Fe32 *abc, size_t m);    // synchronises
-  void check_async(const Fe32 *abc, size_t m);  // same check queued on the main stream; check_result() after the stream has been synchronised
-  bool check_result() const;
+  bool check_result() const;                    // eval() also tests a*b == c row by row; true if the last eval() found every constraint satisfied (read after the main stream has been synchronised)
   struct Impl; std::unique_ptr<Impl> impl;
 };
 

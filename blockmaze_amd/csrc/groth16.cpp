@@ -234,8 +234,7 @@ static void enqueue_all(Prover::Impl &p) {
   for (int h = 0; h < nh; h++) helpers[h] = std::thread([&, h] { try { for (int j = h; j < 4; j += nh) jobs[j](); } catch (...) { aux_error[h] = std::current_exception(); } });
   if (!nh) for (auto &j : jobs) j();
   p.cs->eval(p.z.get(), p.abc.get(), p.m);
-  // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the satisfiability flag is read back together with the results
-  p.cs->check_async(p.abc.get(), p.m);
+  // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
   p.dom->ifft(p.abc.get(), 3, p.m); p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); p.dom->icoset_fft(p.abc.get(), 1, p.m);
   p.H->run(p.abc.get() + p.h0, nullptr);                                                                                  // :466-473
   for (int h = 0; h < nh; h++) { helpers[h].join(); if (aux_error[h]) std::rethrow_exception(aux_error[h]); }

@@ -154,6 +154,32 @@ __global__ void __launch_bounds__(64) k_r1cs_long_rows(const uint32_t *__restric
   for (int d = 32; d >= 1; d >>= 1) { Fr o; for (int i = 0; i < 8; i++) o.l[i] = __shfl_down(acc.l[i], d, 64); acc = acc + o; }
   if (lane == 0) out[r] = acc;
 }
+// The prover's form of the two kernels above: all three matrices in one launch, the evaluation vectors completed (input-consistency rows
+// r1cs_to_qap.tcc:227-230, zero padding up to the domain size) and the satisfiability test a*b == c (protoboard::is_satisfied, sendcgo.cpp:209) done on the
+// values while they are in registers.  A violated row stores `seq` (the number of this evaluation) to *fail, a word in mapped host memory: no reset, no copy.
+struct R1csMatrices { const uint32_t *rowptr[3], *col[3], *cid[3]; };
+__device__ __forceinline__ Fr r1cs_row_dot(const R1csMatrices &M, int mm, uint32_t r, const Fr *__restrict__ ctab, const Fr *__restrict__ z) {
+  Fr acc = Fr::zero(); const uint32_t *col = M.col[mm], *cid = M.cid[mm];
+  for (uint32_t k = M.rowptr[mm][r], e = M.rowptr[mm][r + 1]; k < e; k++) { uint32_t ci = cid[k]; Fr v = z[col[k]]; if (ci == 0) acc = acc + v; else if (ci == 1) acc = acc - v; else acc = acc + ctab[ci] * v; }
+  return acc;
+}
+__global__ void __launch_bounds__(256) k_r1cs_rows3(R1csMatrices M, const Fr *__restrict__ ctab, const Fr *__restrict__ z, uint32_t n_rows, uint32_t n_inputs, uint32_t m, Fr *__restrict__ abc, uint32_t seq, uint32_t *fail) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= m) return;
+  if (r >= n_rows) { abc[r] = r <= n_rows + n_inputs ? z[r - n_rows] : Fr::zero(); abc[m + r] = Fr::zero(); abc[2 * (size_t)m + r] = Fr::zero(); return; }
+  if (M.rowptr[0][r + 1] - M.rowptr[0][r] > R1CS_LONG_ROW || M.rowptr[1][r + 1] - M.rowptr[1][r] > R1CS_LONG_ROW || M.rowptr[2][r + 1] - M.rowptr[2][r] > R1CS_LONG_ROW) return;   // k_r1cs_long_rows3
+  Fr a = r1cs_row_dot(M, 0, r, ctab, z), b = r1cs_row_dot(M, 1, r, ctab, z), c = r1cs_row_dot(M, 2, r, ctab, z);
+  abc[r] = a; abc[m + r] = b; abc[2 * (size_t)m + r] = c;
+  if (a * b != c) *fail = seq;
+}
+__global__ void __launch_bounds__(64) k_r1cs_long_rows3(const uint32_t *__restrict__ rows, R1csMatrices M, const Fr *__restrict__ ctab, const Fr *__restrict__ z, uint32_t m, Fr *__restrict__ abc, uint32_t seq, uint32_t *fail) {
+  uint32_t r = rows[blockIdx.x], lane = threadIdx.x; Fr v[3];
+  for (int mm = 0; mm < 3; mm++) { Fr acc = Fr::zero(); const uint32_t *col = M.col[mm], *cid = M.cid[mm];
+    for (uint32_t k = M.rowptr[mm][r] + lane, e = M.rowptr[mm][r + 1]; k < e; k += 64) { uint32_t ci = cid[k]; Fr x = z[col[k]]; if (ci == 0) acc = acc + x; else if (ci == 1) acc = acc - x; else acc = acc + ctab[ci] * x; }
+#pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) { Fr o; for (int i = 0; i < 8; i++) o.l[i] = __shfl_down(acc.l[i], d, 64); acc = acc + o; }
+    v[mm] = acc; }
+  if (lane == 0) { abc[r] = v[0]; abc[m + r] = v[1]; abc[2 * (size_t)m + r] = v[2]; if (v[0] * v[1] != v[2]) *fail = seq; }
+}
 // satisfiability: flag[0] |= (a[i]*b[i] != c[i]) over the constraint rows (protoboard::is_satisfied, sendcgo.cpp:209)
 __global__ void k_r1cs_check(const Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ c, uint32_t n_rows, uint32_t *flag) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= n_rows) return; if (a[r] * b[r] != c[r]) atomicOr(flag, 1u);
