@@ -60,38 +60,13 @@ struct Fp {
 
   // Montgomery product a*b/R mod p.
   // Device: product scanning (columns of a*b and of m*p interleaved, FIPS order) on a 96-bit column accumulator.  Every 32x32 multiply-accumulate is ONE
-  // v_mad_u64_u32 whose carry-out goes into the third accumulator word with one v_addc: 128 + 128 instructions for the 128 products.  The compiler's own
+  // v_mad_u64_u32 whose carry-out goes into the third accumulator word with one v_addc: 128 + 128 instructions for the 128 products (the 64 a_i*b_j and the 64 m_i*p_j).  The compiler's own
   // lowering of the C++ below (row-wise CIOS) needs ~600 instructions per product, mostly zero-extensions and 64-bit adds around the same 128 mads;
-  // measured on MI355X: 97 -> 126 G products/s chip-wide (tools/fmul_bench.hip).
+  // measured on MI355X: 97 -> 126 G products/s chip-wide, single-wave latency 889 -> 620 ns (tools/fmul_bench.hip).
   // Host (and the reference point for the above): coarsely integrated operand scanning, one row of a*b_i followed by one reduction row m*p.
 #if defined(__HIP_DEVICE_COMPILE__)
-  static __device__ __forceinline__ void mac96(uint64_t &acc, uint32_t &top, uint32_t a, uint32_t b) {
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(top) : "v"(a), "v"(b) : "vcc");
-  }
-  static __device__ __forceinline__ void mac96_const(uint64_t &acc, uint32_t &top, uint32_t a, uint32_t b) {   // b: a modulus limb, kept in an SGPR
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(top) : "v"(a), "s"(b) : "vcc");
-  }
-  friend __device__ __forceinline__ Fp operator*(const Fp &a, const Fp &b) {
-    uint64_t acc = 0; uint32_t top = 0, m[8]; Fp r;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-#pragma unroll
-      for (int i = 0; i <= k; i++) mac96(acc, top, a.l[i], b.l[k - i]);
-#pragma unroll
-      for (int i = 0; i < k; i++) mac96_const(acc, top, m[i], P::MOD[k - i]);
-      m[k] = (uint32_t)acc * P::INV; mac96_const(acc, top, m[k], P::MOD[0]);      // the column's low word is now zero
-      acc = (acc >> 32) | ((uint64_t)top << 32); top = 0;
-    }
-#pragma unroll
-    for (int k = 8; k < 16; k++) {
-#pragma unroll
-      for (int i = k - 7; i < 8; i++) mac96(acc, top, a.l[i], b.l[k - i]);
-#pragma unroll
-      for (int i = k - 7; i < 8; i++) mac96_const(acc, top, m[i], P::MOD[k - i]);
-      r.l[k - 8] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)top << 32); top = 0;
-    }
-    return reduce_once(r);   // the value before this is < 2p < 2^255: nothing is left in the accumulator
-  }
+#include "field_mul_gfx950.inc"   // mul_columns(): the same schedule fully unrolled, one asm statement per column half (gen_field_mul.py)
+  friend __device__ __forceinline__ Fp operator*(const Fp &a, const Fp &b) { return mul_columns(a, b); }
 #else
   friend ZK_HD Fp operator*(const Fp &a, const Fp &b) {
     uint32_t t[8];
