@@ -29,6 +29,7 @@ def main():
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("ZK_DEVICE", str(local_rank))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # the prover runs five streams; the HIP runtime (initialised by torch below) maps them onto 4 hardware queues by default
     import torch
     dist = None
     if world > 1:

@@ -93,9 +93,14 @@ template <class P> __device__ __forceinline__ Fp<P> lane_sel(bool c, const Fp<P>
 __device__ __forceinline__ Fq2 lane_sel(bool c, const Fq2 &a, const Fq2 &b) { return {lane_sel(c, a.c0, b.c0), lane_sel(c, a.c1, b.c1)}; }
 template <class F> __device__ __forceinline__ F quad_sel(int k, const F &a, const F &b, const F &c, const F &d) { return lane_sel(k < 2, lane_sel(k == 0, a, b), lane_sel(k == 2, c, d)); }
 
+template <class F> __device__ __forceinline__ XYZZ<F> xyzz_sel(bool c, const XYZZ<F> &a, const XYZZ<F> &b) { return {lane_sel(c, a.X, b.X), lane_sel(c, a.Y, b.Y), lane_sel(c, a.ZZ, b.ZZ), lane_sel(c, a.ZZZ, b.ZZZ)}; }
+// The special cases (an operand at infinity, equal or opposite operands) are resolved with limb-wise selects AFTER the general formulas have run on
+// whatever the inputs were: an early `return a` / `return b` makes the compiler park both points in scratch memory and select between the two copies
+// by address, which put a memory round trip into every addition of the dependent chain.
+
 // dbl-2008-s-1 (a = 0):  round 1: V = U^2 | X^2      round 2: W = U*V | S = X*V | M^2 | V*ZZ      round 3: M*(S - X3) | W*Y | W*ZZZ
+// (the point at infinity needs no special case: ZZ = 0 gives ZZ3 = V*ZZ = 0)
 template <class F> __device__ __forceinline__ XYZZ<F> quad_dbl_inl(const XYZZ<F> &a, int k) {
-  if (a.is_inf()) return a;
   F U = a.Y.dbl(), m = lane_sel(k == 0, U, a.X); m = m * m;
   F V = quad_pick<0>(m), X2 = quad_pick<1>(m), M = X2.dbl() + X2;
   m = quad_sel(k, U, a.X, M, V) * quad_sel(k, V, V, M, a.ZZ);
@@ -107,31 +112,32 @@ template <class F> __device__ __noinline__ XYZZ<F> quad_dbl(const XYZZ<F> &a, in
 // add-2008-s:  round 1: U1 = X1*ZZ2 | U2 = X2*ZZ1 | S1 = Y1*ZZZ2 | S2 = Y2*ZZZ1      round 2: P^2 | R^2 | ZZ1*ZZ2 | ZZZ1*ZZZ2
 //              round 3: P*PP | U1*PP | ZZ12*PP      round 4: R*(Q - X3) | S1*PPP | ZZZ12*PPP
 template <class F> __device__ __forceinline__ XYZZ<F> quad_add(const XYZZ<F> &a, const XYZZ<F> &b, int k) {
-  if (b.is_inf()) return a;
-  if (a.is_inf()) return b;
+  const bool a_inf = a.is_inf(), b_inf = b.is_inf();
   F m = quad_sel(k, a.X, b.X, a.Y, b.Y) * quad_sel(k, b.ZZ, a.ZZ, b.ZZZ, a.ZZZ);
   F U1 = quad_pick<0>(m), S1 = quad_pick<2>(m), Pv = quad_pick<1>(m) - U1, Rv = quad_pick<3>(m) - S1;
-  if (Pv.is_zero()) { if (Rv.is_zero()) return quad_dbl(a, k); return XYZZ<F>::inf(); }
   m = quad_sel(k, Pv, Rv, a.ZZ, a.ZZZ) * quad_sel(k, Pv, Rv, b.ZZ, b.ZZZ);
   F PP = quad_pick<0>(m), RR = quad_pick<1>(m), ZZ12 = quad_pick<2>(m), ZZZ12 = quad_pick<3>(m);
   m = quad_sel(k, Pv, U1, ZZ12, ZZ12) * PP;
   F PPP = quad_pick<0>(m), Q = quad_pick<1>(m); XYZZ<F> r; r.ZZ = quad_pick<2>(m); r.X = RR - PPP - Q.dbl();
   m = quad_sel(k, Rv, S1, ZZZ12, ZZZ12) * lane_sel(k == 0, Q - r.X, PPP);
-  r.Y = quad_pick<0>(m) - quad_pick<1>(m); r.ZZZ = quad_pick<2>(m); return r;
+  r.Y = quad_pick<0>(m) - quad_pick<1>(m); r.ZZZ = quad_pick<2>(m);
+  if (Pv.is_zero() && !a_inf && !b_inf) { if (Rv.is_zero()) r = quad_dbl(a, k); else r = XYZZ<F>::inf(); }      // b = +-a: rare, uniform within the quad
+  return xyzz_sel(b_inf, a, xyzz_sel(a_inf, b, r));
 }
 // madd-2008-s (affine operand):  round 1: U2 = X2*ZZ1 | S2 = Y2*ZZZ1      round 2: P^2 | R^2      round 3: P*PP | X1*PP | ZZ1*PP      round 4: R*(Q - X3) | Y1*PPP | ZZZ1*PPP
 template <class F> __device__ __forceinline__ XYZZ<F> quad_madd(const XYZZ<F> &a, const Affine<F> &p, int k) {
-  if (p.is_inf()) return a;
-  if (a.is_inf()) return XYZZ<F>::from_affine(p);
+  const bool a_inf = a.is_inf(), p_inf = p.is_inf();
   F m = lane_sel(k == 0, p.x, p.y) * lane_sel(k == 0, a.ZZ, a.ZZZ);
   F Pv = quad_pick<0>(m) - a.X, Rv = quad_pick<1>(m) - a.Y;
-  if (Pv.is_zero()) { if (Rv.is_zero()) return quad_dbl(a, k); return XYZZ<F>::inf(); }
   m = lane_sel(k == 0, Pv, Rv); m = m * m;
   F PP = quad_pick<0>(m), RR = quad_pick<1>(m);
   m = quad_sel(k, Pv, a.X, a.ZZ, a.ZZ) * PP;
   F PPP = quad_pick<0>(m), Q = quad_pick<1>(m); XYZZ<F> r; r.ZZ = quad_pick<2>(m); r.X = RR - PPP - Q.dbl();
   m = quad_sel(k, Rv, a.Y, a.ZZZ, a.ZZZ) * lane_sel(k == 0, Q - r.X, PPP);
-  r.Y = quad_pick<0>(m) - quad_pick<1>(m); r.ZZZ = quad_pick<2>(m); return r;
+  r.Y = quad_pick<0>(m) - quad_pick<1>(m); r.ZZZ = quad_pick<2>(m);
+  if (Pv.is_zero() && !a_inf && !p_inf) { if (Rv.is_zero()) r = quad_dbl(a, k); else r = XYZZ<F>::inf(); }
+  XYZZ<F> lifted = {p.x, p.y, F::one(), F::one()};
+  return xyzz_sel(p_inf, a, xyzz_sel(a_inf, lifted, r));
 }
 // n * a for a small scalar, MSB first
 template <class F> __device__ __forceinline__ XYZZ<F> quad_mul_small(const XYZZ<F> &a, uint32_t n, int k) {

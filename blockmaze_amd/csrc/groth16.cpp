@@ -249,25 +249,27 @@ static void run_device(Prover::Impl &p) {
   }
   gpu_graph_launch(p.graph);
 }
-// proof assembly (r1cs_gg_ppzksnark.tcc:487-495) in two steps: everything that needs only the witness MSMs, then the H term
-struct Partial { HG1 gA, c_without_h; HG2 gB2; };
-static Partial assemble_witness_part(const Prover::Impl &p, const RsTerms &t, const HG1 &eA, const HG1 &eB1, const HG2 &eB2, const HG1 &eL) {
-  Partial q; q.gA = p.alpha_g1.add(eA).add(t.r_delta);                                                                   // :488
-  HG1 gB1 = p.beta_g1.add(eB1).add(t.s_delta); q.gB2 = p.beta_g2.add(eB2).add(t.s_delta2);                              // :491-492
-  q.c_without_h = eL.add(q.gA.mul(t.s.l)).add(gB1.mul(t.r.l)).add(t.rs_delta_neg); return q; }                          // :495 minus the H term
+// proof assembly (r1cs_gg_ppzksnark.tcc:487-495)
 static void assemble(const Prover::Impl &p, const RsTerms &t, const HG1 &eA, const HG1 &eB1, const HG2 &eB2, const HG1 &eH, const HG1 &eL, Proof &out) {
-  Partial q = assemble_witness_part(p, t, eA, eB1, eB2, eL); out.A = raw_of(q.gA); out.B = raw_of(q.gB2); out.C = raw_of(eH.add(q.c_without_h)); }
+  HG1 gA = p.alpha_g1.add(eA).add(t.r_delta);                                                                            // :488
+  HG1 gB1 = p.beta_g1.add(eB1).add(t.s_delta); HG2 gB2 = p.beta_g2.add(eB2).add(t.s_delta2);                            // :491-492
+  HG1 gC = eH.add(eL).add(gA.mul(t.s.l)).add(gB1.mul(t.r.l)).add(t.rs_delta_neg);                                       // :495
+  out.A = raw_of(gA); out.B = raw_of(gB2); out.C = raw_of(gC); }
 bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
   Impl &p = *impl; double t1 = now_ms(); run_device(p);
   RsTerms t = rs_terms(r_in, s_in, p.delta_g1, p.delta_g2);                                                              // host work overlapped with the kernels
   double t2 = now_ms();
-  // the witness MSMs finish well before the H chain (row products, 7 transforms, the largest MSM): their Horner combines, the two scalar multiples and
-  // the affine conversions of A and B run on the host meanwhile (each result() waits for its own stream only)
-  HG1 eA = p.A->result(), eB1 = p.B1->result(); HG2 eB2 = p.B2->result(); HG1 eL = p.L->result();
-  Partial q = assemble_witness_part(p, t, eA, eB1, eB2, eL); out.A = raw_of(q.gA); out.B = raw_of(q.gB2);
+  // The witness MSMs finish well before the H chain (row products, 7 transforms, the largest MSM).  Their Horner combines, the two scalar multiples and the
+  // affine conversions of A and B run on the host meanwhile, in the order the streams complete (each result() waits for its own stream only).
+  static const bool trace = getenv("ZK_TRACE_TIMES") != nullptr;
+  HG1 gA = p.alpha_g1.add(p.A->result()).add(t.r_delta), c_part = gA.mul(t.s.l).add(t.rs_delta_neg); out.A = raw_of(gA); double ta = now_ms();     // :488 and s*A of :495
+  c_part = c_part.add(p.L->result()); double tl = now_ms();
+  HG1 gB1 = p.beta_g1.add(p.B1->result()).add(t.s_delta); c_part = c_part.add(gB1.mul(t.r.l)); double tb1 = now_ms();                                // :491 and r*B1 of :495
+  HG2 gB2 = p.beta_g2.add(p.B2->result()).add(t.s_delta2); out.B = raw_of(gB2); double tb2 = now_ms();                                              // :492
   gpu_sync(); double t3 = now_ms();
+  if (trace) fprintf(stderr, "trace: enqueue %.3f A %.3f L %.3f B1 %.3f B2 %.3f sync %.3f\n", t2 - t1, ta - t1, tl - t1, tb1 - t1, tb2 - t1, t3 - t1);
   if (!p.cs->check_result()) return false;
-  out.C = raw_of(p.H->result().add(q.c_without_h)); double t4 = now_ms();
+  out.C = raw_of(p.H->result().add(c_part)); double t4 = now_ms();                                                                                    // :495
   last.qap_ms = t2 - t1; last.msm_ms = t3 - t1; last.finish_ms = t4 - t3; last.total_ms = last.upload_ms + (t4 - t1); return true;
 }
 static void put_canon_g1(const HG1 &p, uint8_t *o) { HFq x, y; p.to_affine(x, y); x = x.from_mont(); y = y.from_mont(); memcpy(o, x.l, 32); memcpy(o + 32, y.l, 32); }
