@@ -28,44 +28,41 @@ struct XYZZ {
   ZK_HD XYZZ neg() const { return {X, Y.neg(), ZZ, ZZZ}; }
 
   // doubling of an affine point (EFD mdbl-2008-s-1)
-  static ZK_NI XYZZ dbl_affine(const Affine<F> &p) {
-    if (p.is_inf()) return inf();
+  static ZK_HD XYZZ dbl_affine_inl(const Affine<F> &p) {      // (an affine point at infinity is (0,0): U = 0 gives ZZ = 0, i.e. infinity, without a test)
     F U = p.y.dbl(), V = U.sqr(), W = U * V, S = p.x * V, X2 = p.x.sqr(), M = X2.dbl() + X2;
     XYZZ r; r.X = M.sqr() - S.dbl(); r.Y = M * (S - r.X) - W * p.y; r.ZZ = V; r.ZZZ = W; return r;
   }
   // general doubling (EFD dbl-2008-s-1, a = 0)
-  ZK_NI XYZZ dbl() const {
-    if (is_inf()) return *this;
+  ZK_HD XYZZ dbl_inl() const {                                 // (ZZ = 0 gives ZZ3 = V*ZZ = 0: infinity stays infinity without a test)
     F U = Y.dbl(), V = U.sqr(), W = U * V, S = X * V, X2 = X.sqr(), M = X2.dbl() + X2;
     XYZZ r; r.X = M.sqr() - S.dbl(); r.Y = M * (S - r.X) - W * Y; r.ZZ = V * ZZ; r.ZZZ = W * ZZZ; return r;
   }
-  // mixed addition acc += p (EFD madd-2008-s), complete: handles acc = inf, p = inf, p = +-acc.  The *_inl forms are for the hot loops, where the
-  // accumulator has to stay in VGPRs: an out-of-line call passes `this` through scratch memory (measured: 2.5 GB of scratch traffic per H accumulation)
-  ZK_NI void madd(const Affine<F> &p) { madd_inl(p); }
+  // mixed addition acc += p (EFD madd-2008-s), complete: handles acc = inf, p = inf, p = +-acc.  Everything here is inlined into the kernels: an out-of-line
+  // call passes `this` through scratch memory (measured: 2.5 GB of scratch traffic per H accumulation), and hipcc 7.2 was seen to drop the save/restore of
+  // callee-saved SGPRs in large out-of-line functions holding the inline-asm field product (the caller's second call then jumped to a clobbered address)
   ZK_HD void madd_inl(const Affine<F> &p) {
     if (p.is_inf()) return;
     if (is_inf()) { X = p.x; Y = p.y; ZZ = F::one(); ZZZ = F::one(); return; }
     F U2 = p.x * ZZ, S2 = p.y * ZZZ, Pv = U2 - X, Rv = S2 - Y;
-    if (Pv.is_zero()) { if (Rv.is_zero()) *this = dbl_affine(p); else *this = inf(); return; }
+    if (Pv.is_zero()) { if (Rv.is_zero()) *this = dbl_affine_inl(p); else *this = inf(); return; }   // (inlined: an out-of-line call takes p by address, which pins it in scratch memory for every iteration of the caller's loop)
     F PP = Pv.sqr(), PPP = Pv * PP, Q = X * PP;
     F X3 = Rv.sqr() - PPP - Q.dbl();
     Y = Rv * (Q - X3) - Y * PPP; X = X3; ZZ = ZZ * PP; ZZZ = ZZZ * PPP;
   }
   // general addition acc += o (EFD add-2008-s), complete
-  ZK_NI void add(const XYZZ &o) { add_inl(o); }
   ZK_HD void add_inl(const XYZZ &o) {
     if (o.is_inf()) return;
     if (is_inf()) { *this = o; return; }
     F U1 = X * o.ZZ, U2 = o.X * ZZ, S1 = Y * o.ZZZ, S2 = o.Y * ZZZ, Pv = U2 - U1, Rv = S2 - S1;
-    if (Pv.is_zero()) { if (Rv.is_zero()) *this = dbl(); else *this = inf(); return; }
+    if (Pv.is_zero()) { if (Rv.is_zero()) *this = dbl_inl(); else *this = inf(); return; }
     F PP = Pv.sqr(), PPP = Pv * PP, Q = U1 * PP;
     F X3 = Rv.sqr() - PPP - Q.dbl();
     Y = Rv * (Q - X3) - S1 * PPP; X = X3; ZZ = ZZ * o.ZZ * PP; ZZZ = ZZZ * o.ZZZ * PPP;
   }
   // k * this for a small scalar (double-and-add, MSB first) — used for segment offsets in the bucket reduction
-  ZK_NI XYZZ mul_small(uint32_t k) const {
+  ZK_HD XYZZ mul_small(uint32_t k) const {
     XYZZ r = inf(); bool found = false;
-    for (int i = 31; i >= 0; i--) { if (found) r = r.dbl(); if ((k >> i) & 1) { found = true; r.add(*this); } }
+    for (int i = 31; i >= 0; i--) { if (found) r = r.dbl_inl(); if ((k >> i) & 1) { found = true; r.add_inl(*this); } }
     return r;
   }
 };
@@ -108,7 +105,6 @@ template <class F> __device__ __forceinline__ XYZZ<F> quad_dbl_inl(const XYZZ<F>
   m = quad_sel(k, M, W, W, W) * quad_sel(k, S - r.X, a.Y, a.ZZZ, a.ZZZ);
   r.Y = quad_pick<0>(m) - quad_pick<1>(m); r.ZZZ = quad_pick<2>(m); return r;
 }
-template <class F> __device__ __noinline__ XYZZ<F> quad_dbl(const XYZZ<F> &a, int k) { return quad_dbl_inl(a, k); }   // out-of-line copy for the rare doubling branch of an addition
 // add-2008-s:  round 1: U1 = X1*ZZ2 | U2 = X2*ZZ1 | S1 = Y1*ZZZ2 | S2 = Y2*ZZZ1      round 2: P^2 | R^2 | ZZ1*ZZ2 | ZZZ1*ZZZ2
 //              round 3: P*PP | U1*PP | ZZ12*PP      round 4: R*(Q - X3) | S1*PPP | ZZZ12*PPP
 template <class F> __device__ __forceinline__ XYZZ<F> quad_add(const XYZZ<F> &a, const XYZZ<F> &b, int k) {
@@ -121,7 +117,7 @@ template <class F> __device__ __forceinline__ XYZZ<F> quad_add(const XYZZ<F> &a,
   F PPP = quad_pick<0>(m), Q = quad_pick<1>(m); XYZZ<F> r; r.ZZ = quad_pick<2>(m); r.X = RR - PPP - Q.dbl();
   m = quad_sel(k, Rv, S1, ZZZ12, ZZZ12) * lane_sel(k == 0, Q - r.X, PPP);
   r.Y = quad_pick<0>(m) - quad_pick<1>(m); r.ZZZ = quad_pick<2>(m);
-  if (Pv.is_zero() && !a_inf && !b_inf) { if (Rv.is_zero()) r = quad_dbl(a, k); else r = XYZZ<F>::inf(); }      // b = +-a: rare, uniform within the quad
+  if (Pv.is_zero() && !a_inf && !b_inf) { if (Rv.is_zero()) r = quad_dbl_inl(a, k); else r = XYZZ<F>::inf(); }      // b = +-a: rare, uniform within the quad; inlined so that `a` never has its address taken
   return xyzz_sel(b_inf, a, xyzz_sel(a_inf, b, r));
 }
 // madd-2008-s (affine operand):  round 1: U2 = X2*ZZ1 | S2 = Y2*ZZZ1      round 2: P^2 | R^2      round 3: P*PP | X1*PP | ZZ1*PP      round 4: R*(Q - X3) | Y1*PPP | ZZZ1*PPP
@@ -135,7 +131,7 @@ template <class F> __device__ __forceinline__ XYZZ<F> quad_madd(const XYZZ<F> &a
   F PPP = quad_pick<0>(m), Q = quad_pick<1>(m); XYZZ<F> r; r.ZZ = quad_pick<2>(m); r.X = RR - PPP - Q.dbl();
   m = quad_sel(k, Rv, a.Y, a.ZZZ, a.ZZZ) * lane_sel(k == 0, Q - r.X, PPP);
   r.Y = quad_pick<0>(m) - quad_pick<1>(m); r.ZZZ = quad_pick<2>(m);
-  if (Pv.is_zero() && !a_inf && !p_inf) { if (Rv.is_zero()) r = quad_dbl(a, k); else r = XYZZ<F>::inf(); }
+  if (Pv.is_zero() && !a_inf && !p_inf) { if (Rv.is_zero()) r = quad_dbl_inl(a, k); else r = XYZZ<F>::inf(); }
   XYZZ<F> lifted = {p.x, p.y, F::one(), F::one()};
   return xyzz_sel(p_inf, a, xyzz_sel(a_inf, lifted, r));
 }

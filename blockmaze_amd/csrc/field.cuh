@@ -55,7 +55,7 @@ struct Fp {
     for (int i = 0; i < 8; i++) { c += (uint64_t)d.l[i] + (P::MOD[i] & mask); d.l[i] = (uint32_t)c; c >>= 32; }
     return d;
   }
-  ZK_HD Fp neg() const { return is_zero() ? *this : (zero() - *this); }
+  ZK_HD Fp neg() const { return zero() - *this; }   // 0 - 0 borrows nothing, so zero stays zero; (a `cond ? *this : ...` here makes the compiler select between two memory copies and pins the operand in scratch)
   ZK_HD Fp dbl() const { return *this + *this; }
 
   // Montgomery product a*b/R mod p.

@@ -47,7 +47,7 @@ template <class F>
 __global__ void __launch_bounds__(128) k_fixed_base_mul(const Affine<F> *__restrict__ table, const Fr *__restrict__ scalars, Affine<F> *__restrict__ out, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
   Fr k = scalars[i]; XYZZ<F> acc = XYZZ<F>::inf();
-  for (int w = 0; w < 32; w++) { uint32_t d = (k.l[w >> 2] >> ((w & 3) * 8)) & 0xffu; if (d) acc.madd(table[w * 255 + d - 1]); }
+  for (int w = 0; w < 32; w++) { uint32_t d = (k.l[w >> 2] >> ((w & 3) * 8)) & 0xffu; if (d) acc.madd_inl(table[w * 255 + d - 1]); }
   if (acc.is_inf()) { out[i] = Affine<F>::inf(); return; }
   F zi = acc.ZZ.inv(), z3i = acc.ZZZ.inv(); out[i] = {acc.X * zi, acc.Y * z3i};
 }

@@ -93,11 +93,16 @@ static __global__ void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__
 }
 
 // ---- wave-level helpers ------------------------------------------------------------------------------------------------
-template <class T> __device__ __forceinline__ T shfl_down_struct(const T &v, int delta) {
-  static_assert(sizeof(T) % 4 == 0, "word multiple"); T r; const uint32_t *src = reinterpret_cast<const uint32_t *>(&v); uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
+// (member by member: a reinterpret_cast of the struct's address would force the point into scratch memory)
+template <class P> __device__ __forceinline__ Fp<P> shfl_down_struct(const Fp<P> &v, int delta) {
+  Fp<P> r;
 #pragma unroll
-  for (unsigned i = 0; i < sizeof(T) / 4; i++) dst[i] = __shfl_down(src[i], delta, 64);
+  for (int i = 0; i < 8; i++) r.l[i] = __shfl_down(v.l[i], delta, 64);
   return r;
+}
+__device__ __forceinline__ Fq2 shfl_down_struct(const Fq2 &v, int delta) { return {shfl_down_struct(v.c0, delta), shfl_down_struct(v.c1, delta)}; }
+template <class F> __device__ __forceinline__ XYZZ<F> shfl_down_struct(const XYZZ<F> &v, int delta) {
+  return {shfl_down_struct(v.X, delta), shfl_down_struct(v.Y, delta), shfl_down_struct(v.ZZ, delta), shfl_down_struct(v.ZZZ, delta)};
 }
 
 // ---- bucket accumulation, balanced by entries ---------------------------------------------------------------------------

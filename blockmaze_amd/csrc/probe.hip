@@ -30,9 +30,9 @@ template <class F> __device__ __forceinline__ Affine<F> to_affine(const XYZZ<F> 
 template <class F> __global__ void k_probe_group(int op, const Affine<F> *a, const Affine<F> *b, Affine<F> *out, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
   Affine<F> pa = {fin(a[i].x), fin(a[i].y)}; XYZZ<F> acc = XYZZ<F>::from_affine(pa);
-  if (op == 0) { Affine<F> pb = {fin(b[i].x), fin(b[i].y)}; XYZZ<F> o = XYZZ<F>::from_affine(pb); o = o.dbl(); o.add(XYZZ<F>::from_affine(pb).neg()); acc.add(o); }   // o = 2b - b: a non-trivial ZZ, exercises the general formulas
-  else if (op == 1) { acc = acc.dbl().dbl(); acc.add(XYZZ<F>::from_affine(pa).dbl().neg()); }                                                                  // 4a - 2a = 2a through dbl() of a non-affine point
-  else if (op == 2) { Affine<F> pb = {fin(b[i].x), fin(b[i].y)}; acc.madd(pb); }
+  if (op == 0) { Affine<F> pb = {fin(b[i].x), fin(b[i].y)}; XYZZ<F> o = XYZZ<F>::from_affine(pb); o = o.dbl_inl(); o.add_inl(XYZZ<F>::from_affine(pb).neg()); acc.add_inl(o); }   // o = 2b - b: a non-trivial ZZ, exercises the general formulas
+  else if (op == 1) { acc = acc.dbl_inl().dbl_inl(); acc.add_inl(XYZZ<F>::from_affine(pa).dbl_inl().neg()); }                                                                  // 4a - 2a = 2a through dbl() of a non-affine point
+  else if (op == 2) { Affine<F> pb = {fin(b[i].x), fin(b[i].y)}; acc.madd_inl(pb); }
   else { uint32_t k = reinterpret_cast<const uint32_t *>(&b[i])[0]; acc = acc.mul_small(k); }
   Affine<F> r = to_affine(acc); out[i] = {fout(r.x), fout(r.y)};
 }
