@@ -193,6 +193,17 @@ int zkgpu_profile_enable(int on) { return guarded([&] { profile_enable(on != 0);
 int zkgpu_profile_report(char *buf, size_t cap) { return guarded([&] { std::string r = profile_report(); if (r.size() + 1 > cap) return ZKGPU_ERR_ARG; memcpy(buf, r.c_str(), r.size() + 1); return ZKGPU_OK; }); }
 int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs) { int res = 0; int rc = guarded_host([&] { VerifyingKeyHost vk = load_verifying_key(vk_path); Proof p;
   if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK; } res = verify_proof(vk, (const Fe32 *)inputs, n_inputs, p) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
+// batched verification on the GPU (kernel K9).  proofs_hex: n * 512 characters; inputs: n * n_inputs canonical field elements; ok[i] = 1 accept / 0 reject
+// (a record that is not 512 hex digits of values below q is rejected without reaching the device, like proof_from_hex in zkgpu_verify)
+int zkgpu_verify_batch(const char *vk_path, const char *proofs_hex, const uint8_t *inputs, size_t n_inputs, size_t n, uint8_t *ok) { return guarded([&] {
+  if (!vk_path || (!proofs_hex && n) || !ok) return ZKGPU_ERR_ARG;
+  struct Slot { FileStamp stamp; std::unique_ptr<BatchVerifier> v; }; static std::map<std::string, Slot> cache;        // caller holds the device mutex (guarded)
+  FileStamp st; if (!stamp_of(vk_path, st)) throw std::runtime_error(std::string("verification key not found: ") + vk_path);
+  Slot &slot = cache[vk_path]; if (!slot.v || !(slot.stamp == st)) { VerifyingKeyHost vk = load_verifying_key(vk_path); slot.v = make_batch_verifier(vk); slot.stamp = st; }
+  if (slot.v->num_inputs() != n_inputs) { for (size_t i = 0; i < n; i++) ok[i] = 0; return ZKGPU_OK; }                // strong IC: wrong input count rejects (r1cs_gg_ppzksnark.tcc:584-590)
+  std::vector<Proof> ps(n); std::vector<uint8_t> parsed(n);
+  for (size_t i = 0; i < n; i++) { parsed[i] = strnlen(proofs_hex + 512 * i, 512) == 512 && proof_from_hex(proofs_hex + 512 * i, ps[i]); if (!parsed[i]) memset(&ps[i], 0, sizeof(Proof)); }
+  slot.v->verify(ps.data(), (const Fe32 *)inputs, n, ok); for (size_t i = 0; i < n; i++) if (!parsed[i]) ok[i] = 0; return ZKGPU_OK; }); }
 // the reference's symbol names, exported by libzkgpu.so itself (the four libzk_*.so forward to the zkgpu_abi_* names above)
 char *genCMT(uint64_t v, char *a, char *b) { return zkgpu_abi_genCMT(v, a, b); }
 char *genCMTS(uint64_t v, char *a, char *b, char *c) { return zkgpu_abi_genCMTS(v, a, b, c); }

@@ -130,6 +130,8 @@ struct Fq2 {
   // complex squaring: 2 base-field products
   ZK_HD Fq2 sqr() const { Fq ab = c0 * c1; return {(c0 + c1) * (c0 - c1), ab.dbl()}; }
   ZK_HD Fq2 mul_fq(const Fq &k) const { return {c0 * k, c1 * k}; }
+  ZK_HD Fq2 mul_xi() const { Fq a = c0.dbl().dbl().dbl() + c0, b = c1.dbl().dbl().dbl() + c1; return {a - c1, b + c0}; }   // times xi = 9 + u, the Fq6 non-residue (alt_bn128_init.cpp:158)
+  ZK_HD Fq2 frob(unsigned p) const { return (p & 1) ? Fq2{c0, c1.neg()} : *this; }                                          // x -> x^(q^p)
   ZK_HD Fq2 inv() const { Fq t = (c0.sqr() + c1.sqr()).inv(); return {c0 * t, (c1 * t).neg()}; }
 };
 

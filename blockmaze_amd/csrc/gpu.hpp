@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "hostmath.hpp"
+#include "pairing_host.hpp"
 
 namespace zk {
 
@@ -61,6 +62,17 @@ class MsmG2 {
   ~MsmG2();
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
   host::HG2 result(); void set_label(const char *l); void set_stream(int aux);
+  struct Impl; std::unique_ptr<Impl> impl;
+};
+
+// Batched Groth16 verification on the GPU (kernel K9, pairing.cuh): one lane per proof, the key-dependent tables and the verification program resident in HBM.
+class BatchVerifier {
+ public:
+  BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2AffineRaw &gamma_g2, const G2AffineRaw &delta_g2, const G1AffineRaw *ic, size_t n_ic);   // all Montgomery, affine
+  ~BatchVerifier();
+  size_t num_inputs() const; size_t program_length() const;
+  // proofs_mont: n records of 256 bytes (A.x A.y | B.x.c0 B.x.c1 B.y.c0 B.y.c1 | C.x C.y, Montgomery); inputs: n * num_inputs() canonical field elements; ok[i] = 1 accept / 0 reject
+  void verify(const void *proofs_mont, const Fe32 *inputs_canonical, size_t n, uint8_t *ok);
   struct Impl; std::unique_ptr<Impl> impl;
 };
 

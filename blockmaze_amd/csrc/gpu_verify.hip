@@ -1,0 +1,89 @@
+// Host driver of the batched GPU verifier (kernel K9, pairing.cuh): assembles the bytecode and the per-key tables once, then checks any number of proofs per launch.
+#include <cstring>
+#include "gpu_internal.hpp"
+#include "pairing.cuh"
+#include "pairing_host.hpp"
+
+namespace zk {
+using host::HFq; using host::HFq2; using host::HG1;
+
+static const uint64_t BN_Z = 4965661367192848881ull;                         // alt_bn128_init.cpp:327 (final_exponent_z)
+static const uint64_t ATE_LOOP[2] = {0x9d797039be763ba8ull, 0x1ull};          // 6z+2 (alt_bn128_init.cpp:324)
+
+// typed view of a byte allocation (DevBuf is instantiated for the raw interface types only)
+template <class T> struct DevArr { DevBuf<uint8_t> b; DevArr() = default; explicit DevArr(size_t n) : b(n * sizeof(T)) {} T *get() const { return (T *)b.get(); }
+  void upload(const T *h, size_t n) { b.upload((const uint8_t *)h, n * sizeof(T)); } };
+struct BatchVerifier::Impl {
+  size_t n_inputs = 0; DevBuf<uint32_t> prog; DevArr<EllCoeffsDev> gamma, delta; DevArr<FrobeniusDev> frob; DevArr<Fq12> alpha_beta; DevArr<Affine<Fq>> tables; Affine<Fq> ic0; VerifyConsts K; size_t prog_len = 0;
+};
+
+// registers of the program
+enum { rF = 0, rT = 1, r2 = 2, r3 = 3, r4 = 4, r5 = 5, r6 = 6, r7 = 7, r8 = 8, r9 = 9, rONE = 10 };
+static void emit_exp_neg_z(std::vector<uint32_t> &p, uint32_t dst, uint32_t src) {   // exp_by_neg_z :84-96: conj(src^z), square-and-multiply from the top bit of z
+  bool found = false;
+  for (int i = 63; i >= 0; i--) { bool bit = (BN_Z >> i) & 1; if (found) p.push_back(vm_ins(VM_MUL, r9, r9, r9)); if (bit) { if (!found) p.push_back(vm_ins(VM_MUL, r9, rONE, src)); else p.push_back(vm_ins(VM_MUL, r9, r9, src)); found = true; } }
+  p.push_back(vm_ins(VM_CONJ, dst, r9, 0));
+}
+static std::vector<uint32_t> assemble_program(size_t n_lines) {
+  std::vector<uint32_t> p; uint32_t idx = 0; bool found = false;
+  auto lines = [&] { p.push_back(vm_ins(VM_MUL, rF, rF, rT)); p.push_back(vm_ins(VM_LINE, rT, 1, idx)); p.push_back(vm_ins(VM_MUL, rF, rF, rT)); p.push_back(vm_ins(VM_LINE, rT, 2, idx)); p.push_back(vm_ins(VM_MUL, rF, rF, rT)); idx++; };
+  p.push_back(vm_ins(VM_ONE, rF, 0, 0)); p.push_back(vm_ins(VM_ONE, rONE, 0, 0));
+  for (int i = 127; i >= 0; i--) { bool bit = (ATE_LOOP[i / 64] >> (i % 64)) & 1; if (!found) { found |= bit; continue; }                      // miller_loop :368-418 / precomputation :305-366
+    p.push_back(vm_ins(VM_MUL, rF, rF, rF)); p.push_back(vm_ins(VM_DBL, rT, 0, 0)); lines();
+    if (bit) { p.push_back(vm_ins(VM_ADD, rT, 0, 0)); lines(); } }
+  p.push_back(vm_ins(VM_ADD, rT, 0, 1)); lines(); p.push_back(vm_ins(VM_ADD, rT, 0, 2)); lines();
+  if (idx != n_lines || idx > 255) throw GpuError("verify: line count");
+  // final_exponentiation :110-238 (first chunk :110-129, last chunk :131-238)
+  p.push_back(vm_ins(VM_CONJ, r3, rF, 0)); p.push_back(vm_ins(VM_INV, r4, rF, 0)); p.push_back(vm_ins(VM_MUL, r3, r3, r4));                 // C0 = conj(f) * f^-1
+  p.push_back(vm_ins(VM_FROB, r4, r3, 2)); p.push_back(vm_ins(VM_MUL, r2, r4, r3));                                                          // first = C0^(q^2) * C0
+  emit_exp_neg_z(p, r3, r2);                                                                                                                   // A
+  p.push_back(vm_ins(VM_MUL, r4, r3, r3)); p.push_back(vm_ins(VM_MUL, r5, r4, r4)); p.push_back(vm_ins(VM_MUL, r6, r5, r4));                  // B = A^2, C = B^2, D = C*B
+  emit_exp_neg_z(p, r7, r6);                                                                                                                   // E
+  p.push_back(vm_ins(VM_MUL, r5, r7, r7)); emit_exp_neg_z(p, r8, r5);                                                                          // F = E^2, G
+  p.push_back(vm_ins(VM_CONJ, r6, r6, 0)); p.push_back(vm_ins(VM_CONJ, r8, r8, 0));                                                            // H = conj(D), I = conj(G)
+  p.push_back(vm_ins(VM_MUL, r8, r8, r7)); p.push_back(vm_ins(VM_MUL, r8, r8, r6));                                                            // J = I*E, K = J*H
+  p.push_back(vm_ins(VM_MUL, r6, r8, r4)); p.push_back(vm_ins(VM_MUL, r7, r8, r7)); p.push_back(vm_ins(VM_MUL, r7, r7, r2));                  // L = K*B, M = K*E, N = M*first
+  p.push_back(vm_ins(VM_FROB, r4, r6, 1)); p.push_back(vm_ins(VM_MUL, r4, r4, r7));                                                            // O = L^q, P = O*N
+  p.push_back(vm_ins(VM_FROB, r5, r8, 2)); p.push_back(vm_ins(VM_MUL, r4, r5, r4));                                                            // Q = K^(q^2), R = Q*P
+  p.push_back(vm_ins(VM_CONJ, r2, r2, 0)); p.push_back(vm_ins(VM_MUL, r2, r2, r6)); p.push_back(vm_ins(VM_FROB, r2, r2, 3));                  // S = conj(first), T = S*L, U = T^(q^3)
+  p.push_back(vm_ins(VM_MUL, rF, r2, r4)); p.push_back(vm_ins(VM_END, 0, 0, 0)); return p;                                                     // result = U*R
+}
+template <class T, class H> static T to_dev(const H &h) { static_assert(sizeof(T) == sizeof(H), "layout"); T t; memcpy(&t, &h, sizeof(T)); return t; }
+
+BatchVerifier::BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2AffineRaw &gamma_g2, const G2AffineRaw &delta_g2, const G1AffineRaw *ic, size_t n_ic) : impl(new Impl) {
+  Impl &d = *impl; if (n_ic < 1 || n_ic > 17) throw GpuError("verify: IC size"); d.n_inputs = n_ic - 1;
+  auto fq2_of = [](const Fe32 &a, const Fe32 &b) { HFq2 r; memcpy(r.c0.l, &a, 32); memcpy(r.c1.l, &b, 32); return r; };
+  host::G2Precomp pg = host::precompute_g2(fq2_of(gamma_g2.x0, gamma_g2.x1), fq2_of(gamma_g2.y0, gamma_g2.y1)), pd = host::precompute_g2(fq2_of(delta_g2.x0, delta_g2.x1), fq2_of(delta_g2.y0, delta_g2.y1));
+  std::vector<EllCoeffsDev> lg(pg.size()), ld(pd.size()); for (size_t i = 0; i < pg.size(); i++) { lg[i] = to_dev<EllCoeffsDev>(pg[i]); ld[i] = to_dev<EllCoeffsDev>(pd[i]); }
+  d.gamma = DevArr<EllCoeffsDev>(lg.size()); d.gamma.upload(lg.data(), lg.size()); d.delta = DevArr<EllCoeffsDev>(ld.size()); d.delta.upload(ld.data(), ld.size());
+  std::vector<uint32_t> prog = assemble_program(pg.size()); d.prog_len = prog.size(); d.prog = DevBuf<uint32_t>(prog.size()); d.prog.upload(prog.data(), prog.size());
+  FrobeniusDev fr = to_dev<FrobeniusDev>(host::frobenius_tables()); d.frob = DevArr<FrobeniusDev>(1); d.frob.upload(&fr, 1);
+  Fq12 ab = to_dev<Fq12>(alpha_g1_beta_g2); d.alpha_beta = DevArr<Fq12>(1); d.alpha_beta.upload(&ab, 1);
+  HFq2 tb = HFq2{HFq::from_u64(3), HFq::zero()} * HFq2{HFq::from_u64(9), HFq::one()}.inv(); d.K.twist_b = to_dev<Fq2>(tb); d.K.two_inv = to_dev<Fq>(HFq::from_u64(2).inv());
+  memcpy(&d.ic0, &ic[0], sizeof(G1AffineRaw));
+  // window tables of IC[1..]: table[j][w*255 + (dgt-1)] = dgt * 2^(8w) * IC[j+1], affine; one batch inversion per point
+  std::vector<G1AffineRaw> tab(d.n_inputs * 32 * 255 + 1);
+  for (size_t j = 0; j < d.n_inputs; j++) {
+    HFq x, y; memcpy(x.l, &ic[j + 1].x, 32); memcpy(y.l, &ic[j + 1].y, 32); HG1 wbase = (x.is_zero() && y.is_zero()) ? HG1::inf() : HG1::from_affine(x, y); std::vector<HG1> pts(32 * 255);
+    for (int w = 0; w < 32; w++) { HG1 acc = wbase; for (int dg = 1; dg <= 255; dg++) { pts[w * 255 + dg - 1] = acc; acc = acc.add(wbase); } wbase = acc; }
+    std::vector<HFq> pre(pts.size()); HFq run = HFq::one(); for (size_t k = 0; k < pts.size(); k++) { pre[k] = run; if (!pts[k].is_inf()) run = run * pts[k].Z; }
+    HFq inv = run.inv();
+    for (size_t k = pts.size(); k-- > 0;) { G1AffineRaw &o = tab[j * 32 * 255 + k]; if (pts[k].is_inf()) { memset(&o, 0, sizeof o); continue; }
+      HFq zi = inv * pre[k]; inv = inv * pts[k].Z; HFq z2 = zi.sqr(), ax = pts[k].X * z2, ay = pts[k].Y * z2 * zi; memcpy(&o.x, ax.l, 32); memcpy(&o.y, ay.l, 32); }
+  }
+  d.tables = DevArr<Affine<Fq>>(tab.size()); d.tables.upload((const Affine<Fq> *)tab.data(), tab.size());
+}
+BatchVerifier::~BatchVerifier() = default;
+size_t BatchVerifier::num_inputs() const { return impl->n_inputs; }
+size_t BatchVerifier::program_length() const { return impl->prog_len; }
+void BatchVerifier::verify(const void *proofs_mont, const Fe32 *inputs_canonical, size_t n, uint8_t *ok) {
+  if (!n) return; Impl &d = *impl; hipStream_t s = gpu().stream; static_assert(sizeof(VerifyItem) == 256, "proof record");
+  DevArr<VerifyItem> items(n); DevBuf<Fe32> in(n * d.n_inputs + 1); DevArr<Affine<Fq>> acc(n); DevBuf<uint8_t> out(n);
+  items.upload((const VerifyItem *)proofs_mont, n); if (d.n_inputs) in.upload(inputs_canonical, n * d.n_inputs);
+  Stage st("verify.batch");
+  hipLaunchKernelGGL(k_verify_acc, dim3(cdiv(n, 64)), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(), (uint32_t)d.n_inputs, (uint32_t)n, acc.get());
+  hipLaunchKernelGGL(k_verify_batch, dim3(cdiv(n, 64)), dim3(64), 0, s, d.prog.get(), items.get(), acc.get(), d.gamma.get(), d.delta.get(), d.frob.get(), d.alpha_beta.get(), d.K, (uint32_t)n, out.get());
+  HIP_CHECK(hipGetLastError()); out.download(ok, n);
+}
+
+}  // namespace zk

@@ -303,6 +303,8 @@ bool verify_proof(const VerifyingKeyHost &vk, const Fe32 *inputs, size_t n_input
   return final_exponentiation(q1 * (q2 * q3).conj()) == vk.alpha_g1_beta_g2;                                            // :556-560
 }
 
+std::unique_ptr<BatchVerifier> make_batch_verifier(const VerifyingKeyHost &vk) { return std::unique_ptr<BatchVerifier>(new BatchVerifier(vk.alpha_g1_beta_g2, vk.gamma_g2, vk.delta_g2, vk.IC.data(), vk.IC.size())); }
+
 static void put_hex_fq(std::string &o, const Fe32 &mont) { HFq c = fq_of(mont).from_mont(); static const char *d = "0123456789abcdef"; for (int i = 3; i >= 0; i--) for (int k = 15; k >= 0; k--) o.push_back(d[(c.l[i] >> (4 * k)) & 15]); }
 std::string proof_to_hex(const Proof &p) { std::string o; o.reserve(512); put_hex_fq(o, p.A.x); put_hex_fq(o, p.A.y); put_hex_fq(o, p.B.x1); put_hex_fq(o, p.B.x0); put_hex_fq(o, p.B.y1); put_hex_fq(o, p.B.y0); put_hex_fq(o, p.C.x); put_hex_fq(o, p.C.y); return o; }
 bool proof_from_hex(const char *hex, Proof &p) {

@@ -59,6 +59,10 @@ class Prover {                                    // a proving key resident in H
 // ---- verifier (r1cs_gg_ppzksnark.tcc:509-623) -------------------------------------------------------------------------------
 bool verify_proof(const VerifyingKeyHost &vk, const Fe32 *inputs /* canonical */, size_t n_inputs, const Proof &proof);
 
+// the same decision for n proofs at once on the GPU (kernel K9): one BatchVerifier per verifying key
+std::unique_ptr<BatchVerifier> make_batch_verifier(const VerifyingKeyHost &vk);
+static_assert(sizeof(Proof) == 256, "proof record");
+
 // proof <-> the 512-hex-character form of the cgo wrappers (sendcgo.cpp:113-188, :388-448)
 std::string proof_to_hex(const Proof &p);
 bool proof_from_hex(const char *hex, Proof &p);   // reads exactly 512 characters; false on a non-hex character

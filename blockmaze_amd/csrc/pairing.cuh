@@ -1,0 +1,105 @@
+// Batched Groth16 verification on the GPU (kernel K9): one lane per proof.
+//
+// Restates r1cs_gg_ppzksnark_verifier_strong_IC (SNARK/.../r1cs_gg_ppzksnark.tcc:509-623) over libff's optimal-ate pairing
+// (FF/algebra/curves/alt_bn128/alt_bn128_pairing.cpp: doubling / mixed-addition steps :242-293, G2 precomputation :305-366, miller_loop :368-418,
+// final_exponentiation :110-238 — the exact chain, so that the GT value compares equal to the vk's alpha_g1_beta_g2) on the tower
+// Fq2 = Fq[u]/(u^2+1), Fq6 = Fq2[v]/(v^3-(9+u)), Fq12 = Fq6[w]/(w^2-v) (fp6_3over2.tcc, fp12_2over3over2.tcc).
+//
+// GPU shape: a proof's check is ~30,000 dependent field products, far too long a chain to inline call by call, and hipcc's out-of-line device functions
+// are not trustworthy with the inline-asm product (curve.cuh).  The whole check is therefore a small BYTECODE program (about 1,000 instructions: MUL,
+// CONJ, FROB, INV on a file of Fq12 registers in per-lane memory, plus the G2 line steps) that the host assembles once per verifying key and every lane
+// interprets in lock step: one inlined copy of each primitive, no divergence (the program does not depend on the proof), any batch size.
+// The three Miller loops of the reference — e(A,B), and the double loop e(acc,gamma)·e(C,delta) that is conjugated before the final exponentiation —
+// run as ONE accumulator with acc and C negated: f1·conj(f2·f3) and f1·f(-acc)·f(-C) have the same final exponentiation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "curve.cuh"
+
+namespace zk {
+
+struct Fq6 {
+  Fq2 c0, c1, c2;
+  static __device__ __forceinline__ Fq6 zero() { return {Fq2::zero(), Fq2::zero(), Fq2::zero()}; }
+  static __device__ __forceinline__ Fq6 one() { return {Fq2::one(), Fq2::zero(), Fq2::zero()}; }
+  friend __device__ __forceinline__ Fq6 operator+(const Fq6 &a, const Fq6 &b) { return {a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2}; }
+  friend __device__ __forceinline__ Fq6 operator-(const Fq6 &a, const Fq6 &b) { return {a.c0 - b.c0, a.c1 - b.c1, a.c2 - b.c2}; }
+  __device__ __forceinline__ Fq6 neg() const { return {c0.neg(), c1.neg(), c2.neg()}; }
+  friend __device__ __forceinline__ Fq6 operator*(const Fq6 &a, const Fq6 &b) {   // Karatsuba, fp6_3over2.tcc:94-108
+    Fq2 aA = a.c0 * b.c0, bB = a.c1 * b.c1, cC = a.c2 * b.c2;
+    return {aA + ((a.c1 + a.c2) * (b.c1 + b.c2) - bB - cC).mul_xi(), (a.c0 + a.c1) * (b.c0 + b.c1) - aA - bB + cC.mul_xi(), (a.c0 + a.c2) * (b.c0 + b.c2) - aA + bB - cC}; }
+  __device__ __forceinline__ Fq6 mul_by_v() const { return {c2.mul_xi(), c0, c1}; }
+  __device__ __forceinline__ bool operator==(const Fq6 &o) const { return c0 == o.c0 && c1 == o.c1 && c2 == o.c2; }
+};
+struct Fq12 { Fq6 c0, c1; __device__ __forceinline__ bool operator==(const Fq12 &o) const { return c0 == o.c0 && c1 == o.c1; } };
+
+struct FrobeniusDev { Fq2 fq6_c1[6], fq6_c2[6], fq12_c1[12], twist_mul_by_q_x, twist_mul_by_q_y; };   // same layout as host::FrobeniusTables
+struct EllCoeffsDev { Fq2 ell_0, ell_VW, ell_VV; };
+struct VerifyItem { Affine<Fq> A; Affine<Fq2> B; Affine<Fq> C; };                                        // Montgomery form, as parsed from the 512 hex characters
+
+enum VmOp : uint32_t { VM_MUL = 0, VM_CONJ, VM_FROB, VM_INV, VM_ONE, VM_DBL, VM_ADD, VM_LINE, VM_END };
+__host__ __device__ inline uint32_t vm_ins(uint32_t op, uint32_t d, uint32_t a, uint32_t b) { return op | d << 8 | a << 16 | b << 24; }
+constexpr int VM_REGS = 12;
+
+struct VerifyConsts { Fq2 twist_b; Fq two_inv; };
+
+// acc_i = IC[0] + sum_j inputs[i][j] * IC[j+1] from 8-bit window tables (table[j][w*255 + d-1] = d * 2^(8w) * IC[j+1]); output affine with y NEGATED
+// (the pairing uses -acc), all-zero record if acc is the point at infinity.  inputs canonical.  r1cs_gg_ppzksnark.tcc:584-590 (strong IC).
+__global__ void __launch_bounds__(64) k_verify_acc(const Affine<Fq> *__restrict__ tables, Affine<Fq> ic0, const Fr *__restrict__ inputs, uint32_t n_inputs, uint32_t n, Affine<Fq> *__restrict__ acc_out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; XYZZ<Fq> acc = XYZZ<Fq>::from_affine(ic0);
+  for (uint32_t j = 0; j < n_inputs; j++) { Fr k = inputs[(size_t)i * n_inputs + j]; const Affine<Fq> *t = tables + (size_t)j * 32 * 255;
+    for (int w = 0; w < 32; w++) { uint32_t d = (k.l[w >> 2] >> ((w & 3) * 8)) & 0xffu; if (d) acc.madd_inl(t[w * 255 + d - 1]); } }
+  if (acc.is_inf()) { acc_out[i] = Affine<Fq>::inf(); return; }
+  Fq zi = acc.ZZ.inv(), z3i = acc.ZZZ.inv(); acc_out[i] = {acc.X * zi, (acc.Y * z3i).neg()};
+}
+
+__device__ __forceinline__ Fq6 fq6_frob(const Fq6 &a, unsigned p, const FrobeniusDev &t) { return {a.c0.frob(p), t.fq6_c1[p % 6] * a.c1.frob(p), t.fq6_c2[p % 6] * a.c2.frob(p)}; }
+__device__ __forceinline__ Fq6 fq6_mul_fq2(const Fq6 &a, const Fq2 &k) { return {a.c0 * k, a.c1 * k, a.c2 * k}; }
+__device__ __forceinline__ Fq12 fq12_sparse(const Fq2 &ell_0, const Fq2 &ell_VW, const Fq2 &ell_VV) { return {{ell_0, Fq2::zero(), ell_VV}, {Fq2::zero(), ell_VW, Fq2::zero()}}; }   // the operand of mul_by_024
+
+// prog: the bytecode.  lines[0] / lines[1]: precomputed G2 line coefficients of the vk's gamma / delta.  ok[i] = 1 if proof i is accepted.
+__global__ void __launch_bounds__(64) k_verify_batch(const uint32_t *__restrict__ prog, const VerifyItem *__restrict__ items, const Affine<Fq> *__restrict__ neg_acc,
+                                                    const EllCoeffsDev *__restrict__ gamma_lines, const EllCoeffsDev *__restrict__ delta_lines, const FrobeniusDev *__restrict__ frob,
+                                                    const Fq12 *__restrict__ alpha_beta, VerifyConsts K, uint32_t n, uint8_t *__restrict__ ok) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+  const VerifyItem it = items[i]; const Affine<Fq> nacc = neg_acc[i]; const FrobeniusDev &T = *frob;
+  // is_well_formed (on-curve only, alt_bn128_g1.cpp:92-117, alt_bn128_g2.cpp:98-127); a proof parsed from hex has Z = 1, so (0,0) is simply off-curve
+  bool good = !it.A.is_inf() && !it.B.is_inf() && !it.C.is_inf() && it.A.y.sqr() == it.A.x.sqr() * it.A.x + Fq::from_u64(3) && it.C.y.sqr() == it.C.x.sqr() * it.C.x + Fq::from_u64(3)
+              && it.B.y.sqr() == it.B.x.sqr() * it.B.x + K.twist_b;
+  const bool acc_inf = nacc.is_inf();
+  Fq12 R[VM_REGS]; Fq2 X = it.B.x, Y = it.B.y, Z = Fq2::one();                                   // G2 point of the running loop, homogeneous projective
+  const Fq2 q1x = T.twist_mul_by_q_x * it.B.x.frob(1), q1y = T.twist_mul_by_q_y * it.B.y.frob(1), q2x = T.twist_mul_by_q_x * q1x.frob(1), q2y = (T.twist_mul_by_q_y * q1y.frob(1)).neg();   // mul_by_q, alt_bn128_g2.cpp:367-372
+  const Fq cny = it.C.y.neg();
+#pragma unroll 1
+  for (uint32_t pc = 0;; pc++) {
+    const uint32_t ins = prog[pc], op = ins & 0xff, d = (ins >> 8) & 0xff, a = (ins >> 16) & 0xff, b = ins >> 24;
+    if (op == VM_END) break;
+    if (op == VM_MUL) { const Fq12 x = R[a], y = R[b]; Fq6 aA = x.c0 * y.c0, bB = x.c1 * y.c1; R[d] = {aA + bB.mul_by_v(), (x.c0 + x.c1) * (y.c0 + y.c1) - aA - bB}; }   // fp12_2over3over2.tcc:91-104
+    else if (op == VM_CONJ) { const Fq12 x = R[a]; R[d] = {x.c0, x.c1.neg()}; }                                                                                    // unitary_inverse
+    else if (op == VM_FROB) { const Fq12 x = R[a]; R[d] = {fq6_frob(x.c0, b, T), fq6_mul_fq2(fq6_frob(x.c1, b, T), T.fq12_c1[b % 12])}; }
+    else if (op == VM_INV) {                                                                                                                                          // fp12 :128-137 over fp6 :128-146
+      const Fq12 x = R[a]; Fq6 s0 = x.c0 * x.c0, s1 = x.c1 * x.c1, t = s0 - s1.mul_by_v();
+      Fq2 t0 = t.c0.sqr(), t1 = t.c1.sqr(), t2 = t.c2.sqr(), t3 = t.c0 * t.c1, t4 = t.c0 * t.c2, t5 = t.c1 * t.c2, d0 = t0 - t5.mul_xi(), d1 = t2.mul_xi() - t3, d2 = t1 - t4;
+      Fq2 t6 = (t.c0 * d0 + (t.c2 * d1 + t.c1 * d2).mul_xi()).inv(); Fq6 ti = {t6 * d0, t6 * d1, t6 * d2}; R[d] = {x.c0 * ti, (x.c1 * ti).neg()};
+    }
+    else if (op == VM_ONE) R[d] = {Fq6::one(), Fq6::zero()};
+    else if (op == VM_DBL) {                                                                                                                                          // doubling_step_for_flipped_miller_loop :242-268
+      Fq2 A = (X * Y).mul_fq(K.two_inv), B = Y.sqr(), C = Z.sqr(), D = C + C + C, E = K.twist_b * D, F = E + E + E, G = (B + F).mul_fq(K.two_inv), H = (Y + Z).sqr() - (B + C), I = E - B, J = X.sqr(), E2 = E.sqr();
+      X = A * (B - F); Y = G.sqr() - (E2 + E2 + E2); Z = B * H;
+      R[d] = fq12_sparse(I.mul_xi(), H.neg().mul_fq(it.A.y), (J + J + J).mul_fq(it.A.x));
+    }
+    else if (op == VM_ADD) {                                                                                                                                          // mixed_addition_step_for_flipped_miller_loop :270-293
+      const Fq2 x2 = b == 0 ? it.B.x : b == 1 ? q1x : q2x, y2 = b == 0 ? it.B.y : b == 1 ? q1y : q2y;
+      Fq2 D = X - x2 * Z, E = Y - y2 * Z, F = D.sqr(), G = E.sqr(), H = D * F, I = X * F, J = H + Z * G - (I + I), Y1 = Y;
+      X = D * J; Y = E * (I - J) - H * Y1; Z = Z * H;
+      R[d] = fq12_sparse((E * x2 - D * y2).mul_xi(), D.mul_fq(it.A.y), E.neg().mul_fq(it.A.x));
+    }
+    else if (op == VM_LINE) {                                                                                                                                         // miller_loop :387-411 with a precomputed G2
+      const EllCoeffsDev c = a == 1 ? gamma_lines[b] : delta_lines[b];
+      if (a == 1) R[d] = acc_inf ? Fq12{Fq6::one(), Fq6::zero()} : fq12_sparse(c.ell_0, c.ell_VW.mul_fq(nacc.y), c.ell_VV.mul_fq(nacc.x));
+      else R[d] = fq12_sparse(c.ell_0, c.ell_VW.mul_fq(cny), c.ell_VV.mul_fq(it.C.x));
+    }
+  }
+  ok[i] = (good && R[0] == *alpha_beta) ? 1 : 0;                                                                                                                    // :556-560
+}
+
+}  // namespace zk

@@ -152,6 +152,15 @@ def profile_report():
     import json
     buf = ctypes.create_string_buffer(1 << 16); _check(lib().zkgpu_profile_report(buf, ctypes.c_size_t(len(buf)))); return json.loads(buf.value.decode())
 
+def verify_batch(vk_path, proofs_hex, inputs):
+    """proofs_hex: list of n 512-character strings; inputs: list of n lists of canonical ints -> list of n booleans (GPU, kernel K9)"""
+    n = len(proofs_hex); ni = len(inputs[0]) if n else 0; blob = "".join(proofs_hex).encode(); assert len(blob) == 512 * n
+    buf = (ctypes.c_uint8 * max(1, 32 * n * ni))(); 
+    for i, row in enumerate(inputs):
+        assert len(row) == ni
+        for j, v in enumerate(row): buf[32 * (i * ni + j):32 * (i * ni + j + 1)] = list(int(v).to_bytes(32, "little"))
+    ok = (ctypes.c_uint8 * max(1, n))(); _check(lib().zkgpu_verify_batch(vk_path.encode(), blob, buf, ctypes.c_size_t(ni), ctypes.c_size_t(n), ok)); return [bool(ok[i]) for i in range(n)]
+
 def verify(vk_path, proof_hex, inputs):
     """inputs: list of ints (packed public input).  True / False."""
     buf = b"".join(int(x).to_bytes(32, "little") for x in inputs)

@@ -109,6 +109,9 @@ int zkgpu_profile_enable(int on);
 int zkgpu_profile_report(char *buf, size_t cap);
 /* 1 = accept, 0 = reject, negative = error.  inputs: n_inputs canonical field elements (the packed public input) */
 int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs);
+/* the same decision for n proofs in one GPU launch (kernel K9; r1cs_gg_ppzksnark_verifier_strong_IC, r1cs_gg_ppzksnark.tcc:509-623, one lane per proof).
+   proofs_hex: n * 512 characters (no separators); inputs: n * n_inputs canonical field elements of 32 bytes; ok[i] = 1 accept / 0 reject.  Returns ZKGPU_OK or an error */
+int zkgpu_verify_batch(const char *vk_path, const char *proofs_hex, const uint8_t *inputs, size_t n_inputs, size_t n, uint8_t *ok);
 
 #ifdef __cplusplus
 }

@@ -119,3 +119,38 @@ def test_msm_sharding_matches_unsharded(send_keys, golden_dir, tmp_path):
     full = e.Prover(pk_path); exp = full.prove(z, r, s); full.close(); recs = []
     for rank in range(2): p = e.Prover(pk_path, rank, 2); p.set_witness(z); recs.append(p.prove_partial()); p.close() if rank == 0 else None
     assert p.finish(recs, r, s) == exp and e.verify(str(send_keys / "sendvk.txt"), exp, w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]]))
+
+@pytest.mark.parametrize("name", ["groth16_small", "groth16_step"])
+def test_batched_gpu_verifier_matches_host_verifier(golden_dir, name):
+    """K9: one lane per proof.  A batch mixing the reference prover's proof, fresh proofs, tampered proofs (each coordinate), wrong public inputs, the
+    default proof and garbage must be decided exactly like the host verifier (which is pinned against libsnark's verifier and GT values)."""
+    d = os.path.join(golden_dir, name); meta = json.load(open(os.path.join(d, "meta.json"))); z = o.load_witness(os.path.join(d, "wit.bin")); vk = os.path.join(d, "vk.txt")
+    inputs = o.from_arr(z[:meta["n_inputs"]]); p = e.Prover(os.path.join(d, "pk.txt")); good = [meta["proof"]] + [p.prove(z) for _ in range(3)]; p.close()
+    proofs, ins = [], []
+    for g in good: proofs.append(g); ins.append(inputs)
+    for k in range(8):                                                                   # one flipped hex digit in each of the 8 coordinates
+        g = good[k % len(good)]; pos = 64 * k + 37; proofs.append(g[:pos] + ("0" if g[pos] != "0" else "1") + g[pos + 1:]); ins.append(inputs)
+    for j in range(len(inputs)): bad = list(inputs); bad[j] = (bad[j] + 1) % o.R_MOD; proofs.append(good[0]); ins.append(bad)
+    proofs.append(good[1]); ins.append([0] * len(inputs))
+    proofs.append("0" * 512); ins.append(inputs)                                          # all-zero record: (0,0) is off-curve
+    proofs.append("zz" + good[0][2:]); ins.append(inputs)                                 # not hex
+    proofs.append(good[2][:128] + good[3][128:]); ins.append(inputs)                      # A of one valid proof with B, C of another
+    got = e.verify_batch(vk, proofs, ins); exp = [e.verify(vk, pr, x) for pr, x in zip(proofs, ins)]
+    assert got == exp and got[:len(good)] == [True] * len(good) and not any(got[len(good):])
+    assert e.verify_batch(vk, [], []) == []
+    assert e.verify_batch(vk, [good[0]], [inputs[:-1]]) == [False]                        # wrong number of public inputs (strong IC)
+
+def test_batched_gpu_verifier_send_at_scale(send_keys, tmp_path):
+    """512 send proofs in one launch (4 distinct valid proofs and their corrupted twins, interleaved)"""
+    pk_path, vk_path = str(send_keys / "sendpk.txt"), str(send_keys / "sendvk.txt"); p = e.Prover(pk_path); proofs, ins, exp = [], [], []
+    base = []; wp = str(tmp_path / "w.bin")
+    for i in range(4):
+        d = w.send_instance(40 + i); e.witness_send(*hexargs(w.send_args(d)), wp); z = o.load_witness(wp); base.append((p.prove(z), w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]])))
+    p.close()
+    for k in range(512):
+        pr, x = base[k % 4]
+        if k % 3 == 1: pr = pr[:300] + ("5" if pr[300] != "5" else "6") + pr[301:]
+        if k % 3 == 2: x = list(x); x[k % len(x)] = (x[k % len(x)] + k) % o.R_MOD
+        proofs.append(pr); ins.append(x); exp.append(k % 3 == 0)
+    assert e.verify_batch(vk_path, proofs, ins) == exp
+    assert all(e.verify(vk_path, *base[i]) for i in range(4))
