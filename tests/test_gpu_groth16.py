@@ -154,3 +154,16 @@ def test_batched_gpu_verifier_send_at_scale(send_keys, tmp_path):
         proofs.append(pr); ins.append(x); exp.append(k % 3 == 0)
     assert e.verify_batch(vk_path, proofs, ins) == exp
     assert all(e.verify(vk_path, *base[i]) for i in range(4))
+
+def test_deposit_depth32_single_gpu(tmp_path):
+    """BASELINE.json configs[4] on one GPU: the deposit circuit with the Merkle tree depth raised to 32: 1,070,591 variables, step domain
+    2^20 + 2^17 = 1,179,648, H-query MSM of 1,179,647 points.  Key generation, witness, proof with fixed (r, s) (deterministic), host verifier, batched GPU verifier."""
+    pk_path, vk_path, wp = str(tmp_path / "pk.txt"), str(tmp_path / "vk.txt"), str(tmp_path / "w.bin"); e.keygen("deposit", pk_path, vk_path, seed=32, tree_depth=32)
+    p = e.Prover(pk_path); assert (p.n_vars, p.n_inputs, p.m) == (1070591, 6, 1179648)
+    dd = w.deposit_instance(3); rt, _ = w.merkle_root_and_path(dd["leaves"], dd["index"], depth=32)
+    cmtarray = "".join("0x" + l.hex() for l in dd["leaves"])
+    e.witness_deposit(*hexargs(w.deposit_args(dd)), cmtarray, len(dd["leaves"]), "0x" + dd["sk"].hex(), wp, tree_depth=32); z = o.load_witness(wp)
+    inputs = w.pack_public([rt, dd["pk_recv"], dd["cmtB_old"], dd["sn_old"], dd["cmtB"], dd["sn_s"]]); assert o.from_arr(z[:6]) == inputs
+    proof = p.prove(z, 5, 7); assert p.prove(z, 5, 7) == proof; print("timings", p.timings()); p.close()
+    assert e.verify(vk_path, proof, inputs) and not e.verify(vk_path, proof, inputs[::-1])
+    assert e.verify_batch(vk_path, [proof, proof], [inputs, inputs[::-1]]) == [True, False]
