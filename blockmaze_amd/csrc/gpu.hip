@@ -112,20 +112,22 @@ static void radix2_transform(Fe32 *data, Fe32 *scratch, const Fe32 *tw, int logn
 
 // ---- step-radix-2 helper kernels (domains/step_radix2_domain.tcc:39-153) ---------------------------------------------
 // forward pre-pass: c[i] = a[i] + a[i+B] (i<S) else a[i];  d[i] = w^i * (a[i] - a[i+B] (i<S) else a[i]);  e[i] = sum_j d[i + j*S]
-__global__ void k_step_fwd_pre(const Fr *__restrict__ a, Fr *__restrict__ cbuf, Fr *__restrict__ dbuf, const Fr *__restrict__ wpow, uint32_t B, uint32_t S) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= B) return; Fr x = a[i];
-  if (i < S) { Fr y = a[i + B]; cbuf[i] = x + y; dbuf[i] = wpow[i] * (x - y); } else { cbuf[i] = x; dbuf[i] = wpow[i] * x; }
+// (in place: c overwrites a[0..B); blockIdx.y = vector of the batch)
+__global__ void k_step_fwd_pre(Fr *a_all, Fr *__restrict__ dbuf_all, const Fr *__restrict__ wpow, uint32_t B, uint32_t S, size_t stride) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= B) return; Fr *a = a_all + blockIdx.y * stride, *dbuf = dbuf_all + (size_t)blockIdx.y * B; Fr x = a[i];
+  if (i < S) { Fr y = a[i + B]; a[i] = x + y; dbuf[i] = wpow[i] * (x - y); } else { dbuf[i] = wpow[i] * x; }
 }
-__global__ void k_step_fold(const Fr *__restrict__ dbuf, Fr *__restrict__ e, uint32_t B, uint32_t S) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= S) return; Fr acc = Fr::zero(); for (uint32_t j = i; j < B; j += S) acc = acc + dbuf[j]; e[i] = acc;
+__global__ void k_step_fold(const Fr *__restrict__ dbuf_all, Fr *__restrict__ a_all, uint32_t B, uint32_t S, size_t stride) {   // e overwrites a[B..B+S)
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= S) return; const Fr *dbuf = dbuf_all + (size_t)blockIdx.y * B; Fr acc = Fr::zero(); for (uint32_t j = i; j < B; j += S) acc = acc + dbuf[j];
+  a_all[blockIdx.y * stride + B + i] = acc;
 }
 // inverse post-pass.  U0 (B values, already scaled by 1/B), U1 (S values, scaled by 1/S):
 //   tmp[i] = U0[i]*w^i ; U1[i] -= sum_{j>=1} tmp[i + j*S] ; U1[i] *= w^-i ; a[i] = (U0[i]+U1[i])/2 (i<S) ; a[B+i] = (U0[i]-U1[i])/2 ; a[i] = U0[i] (S<=i<B)
-__global__ void k_step_inv_post(const Fr *__restrict__ U0, const Fr *__restrict__ U1, Fr *__restrict__ a, const Fr *__restrict__ wpow, const Fr *__restrict__ winvpow, Fr half, uint32_t B, uint32_t S) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= B) return;
-  if (i >= S) { a[i] = U0[i]; return; }
-  Fr u1 = U1[i]; for (uint32_t j = i + S; j < B; j += S) u1 = u1 - U0[j] * wpow[j];
-  u1 = u1 * winvpow[i]; Fr u0 = U0[i]; a[i] = (u0 + u1) * half; a[B + i] = (u0 - u1) * half;
+// In place on a = [U0 (B) | U1 (S)]: thread i < S reads U0[i], U0[i + kS], U1[i] and writes a[i], a[B+i]; entries a[S..B) = U0[S..B) stay as they are.
+__global__ void k_step_inv_post(Fr *a_all, const Fr *__restrict__ wpow, const Fr *__restrict__ winvpow, Fr half, uint32_t B, uint32_t S, size_t stride) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= S) return; Fr *a = a_all + blockIdx.y * stride;
+  Fr u1 = a[B + i]; for (uint32_t j = i + S; j < B; j += S) u1 = u1 - a[j] * wpow[j];
+  u1 = u1 * winvpow[i]; Fr u0 = a[i]; a[i] = (u0 + u1) * half; a[B + i] = (u0 - u1) * half;
 }
 
 struct Domain::Impl {
@@ -171,7 +173,7 @@ Domain::Domain(size_t min_size) : impl(new Impl) {
     HFr cw = g * w, Z1 = ((cw.pow_u64(d.B) - one) * (cw.pow_u64(d.S) - wS)).inv(); for (size_t i = 0; i < d.S; i++) memcpy(&zt[d.B + i], Z1.l, 32);
     d.zinv = DevBuf<Fe32>(d.m); d.zinv.upload(zt.data(), d.m);
   }
-  d.scratch_stride = d.m; d.scratch = DevBuf<Fe32>(3 * d.m);
+  d.scratch_stride = d.m; d.scratch = DevBuf<Fe32>(d.step ? 6 * d.B : 3 * d.m);
 }
 Domain::~Domain() = default;
 size_t Domain::m() const { return impl->m; }
@@ -182,26 +184,20 @@ static void mul_table(Fe32 *a, const Fe32 *t, size_t n, int batch, size_t stride
 void Domain::fft(Fe32 *data, int batch, size_t stride) {
   Stage st("ntt.forward"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
   if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->tw.get(), d.big->logn, nullptr, nullptr, batch, stride, d.scratch_stride); return; }
-  hipStream_t s = gpu().stream;
-  for (int b = 0; b < batch; b++) {   // scratch layout per vector: [c (B) | e (S)] in slot 0, d (B) in slot 1, bitrev scratch in slot 2
-    Fe32 *a = data + b * stride, *cb = d.scratch.get(), *db = d.scratch.get() + d.m, *tmp = d.scratch.get() + 2 * d.m, *e = cb + d.B;
-    hipLaunchKernelGGL(k_step_fwd_pre, dim3(cdiv(d.B, 256)), dim3(256), 0, s, (const Fr *)a, (Fr *)cb, (Fr *)db, (const Fr *)d.wpow.get(), (uint32_t)d.B, (uint32_t)d.S);
-    hipLaunchKernelGGL(k_step_fold, dim3(cdiv(d.S, 256)), dim3(256), 0, s, (const Fr *)db, (Fr *)e, (uint32_t)d.B, (uint32_t)d.S);
-    radix2_transform(cb, tmp, d.big->tw.get(), d.big->logn, nullptr, nullptr, 1, 0, 0); radix2_transform(e, tmp, d.small->tw.get(), d.small->logn, nullptr, nullptr, 1, 0, 0);
-    HIP_CHECK(hipMemcpyAsync(a, cb, d.m * sizeof(Fe32), hipMemcpyDeviceToDevice, s));
-  }
+  // step_radix2_domain::FFT (:39-77): c / d / e pre-pass in place, then a B-point and an S-point transform of every vector; scratch = [d: 3B | transform scratch: 3B]
+  hipStream_t s = gpu().stream; Fe32 *dbuf = d.scratch.get(), *tmp = d.scratch.get() + 3 * d.B;
+  hipLaunchKernelGGL(k_step_fwd_pre, dim3(cdiv(d.B, 256), batch), dim3(256), 0, s, (Fr *)data, (Fr *)dbuf, (const Fr *)d.wpow.get(), (uint32_t)d.B, (uint32_t)d.S, stride);
+  hipLaunchKernelGGL(k_step_fold, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (const Fr *)dbuf, (Fr *)data, (uint32_t)d.B, (uint32_t)d.S, stride);
+  radix2_transform(data, tmp, d.big->tw.get(), d.big->logn, nullptr, nullptr, batch, stride, d.B); radix2_transform(data + d.B, tmp, d.small->tw.get(), d.small->logn, nullptr, nullptr, batch, stride, d.B);
 }
 void Domain::ifft(Fe32 *data, int batch, size_t stride) {
   Stage st("ntt.inverse"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
   if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, d.scale_big.get(), nullptr, batch, stride, d.scratch_stride); return; }   // 1/m folded into the load
-  hipStream_t s = gpu().stream;
-  for (int b = 0; b < batch; b++) {
-    Fe32 *a = data + b * stride, *U = d.scratch.get(), *tmp = d.scratch.get() + 2 * d.m;
-    HIP_CHECK(hipMemcpyAsync(U, a, d.m * sizeof(Fe32), hipMemcpyDeviceToDevice, s));
-    radix2_transform(U, tmp, d.big->itw.get(), d.big->logn, d.scale_big.get(), nullptr, 1, 0, 0); radix2_transform(U + d.B, tmp, d.small->itw.get(), d.small->logn, d.scale_small.get(), nullptr, 1, 0, 0);   // 1/B, 1/S folded into the loads
-    Fr half; memcpy(&half, d.half.l, 32);
-    hipLaunchKernelGGL(k_step_inv_post, dim3(cdiv(d.B, 256)), dim3(256), 0, s, (const Fr *)U, (const Fr *)(U + d.B), (Fr *)a, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half, (uint32_t)d.B, (uint32_t)d.S);
-  }
+  // step_radix2_domain::iFFT (:79-140): both inverse transforms in place (1/B, 1/S folded into their loads), then the recombination pass
+  hipStream_t s = gpu().stream; Fe32 *tmp = d.scratch.get() + 3 * d.B;
+  radix2_transform(data, tmp, d.big->itw.get(), d.big->logn, d.scale_big.get(), nullptr, batch, stride, d.B); radix2_transform(data + d.B, tmp, d.small->itw.get(), d.small->logn, d.scale_small.get(), nullptr, batch, stride, d.B);
+  Fr half; memcpy(&half, d.half.l, 32);
+  hipLaunchKernelGGL(k_step_inv_post, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half, (uint32_t)d.B, (uint32_t)d.S, stride);
 }
 void Domain::coset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
