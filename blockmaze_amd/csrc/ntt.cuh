@@ -175,8 +175,9 @@ __global__ void __launch_bounds__(64) k_r1cs_long_rows3(const uint32_t *__restri
   uint32_t r = rows[blockIdx.x], lane = threadIdx.x; Fr v[3];
   for (int mm = 0; mm < 3; mm++) { Fr acc = Fr::zero(); const uint32_t *col = M.col[mm], *cid = M.cid[mm];
     for (uint32_t k = M.rowptr[mm][r] + lane, e = M.rowptr[mm][r + 1]; k < e; k += 64) { uint32_t ci = cid[k]; Fr x = z[col[k]]; if (ci == 0) acc = acc + x; else if (ci == 1) acc = acc - x; else acc = acc + ctab[ci] * x; }
+    const uint32_t len = M.rowptr[mm][r + 1] - M.rowptr[mm][r];      // (wave-uniform) the long matrix of a packing constraint has 32..35 terms, the other two have one: no tree for those
 #pragma unroll 1
-    for (int d = 32; d >= 1; d >>= 1) { Fr o; for (int i = 0; i < 8; i++) o.l[i] = __shfl_down(acc.l[i], d, 64); acc = acc + o; }
+    for (int d = 32; d >= 1; d >>= 1) { if ((uint32_t)d >= len) continue; Fr o; for (int i = 0; i < 8; i++) o.l[i] = __shfl_down(acc.l[i], d, 64); acc = acc + o; }
     v[mm] = acc; }
   if (lane == 0) { abc[r] = v[0]; abc[m + r] = v[1]; abc[2 * (size_t)m + r] = v[2]; if (v[0] * v[1] != v[2]) *fail = seq; }
 }
