@@ -47,7 +47,7 @@ void profile_enable(bool on) { g_timer.collect(); g_timer.enabled = on; g_timer.
 std::string profile_report() { g_timer.collect(); std::string o = "{"; bool first = true;
   for (auto &kv : g_timer.acc) { char buf[256]; snprintf(buf, sizeof buf, "%s\"%s\": {\"ms_total\": %.6f, \"count\": %ld}", first ? "" : ", ", kv.first.c_str(), kv.second.first, kv.second.second); o += buf; first = false; } return o + "}"; }
 
-template <class T> DevBuf<T>::DevBuf(size_t n) : n_(n) { gpu(); if (n) HIP_CHECK(hipMalloc((void **)&p_, n * sizeof(T))); }
+template <class T> DevBuf<T>::DevBuf(size_t n) : n_(n) { gpu(); if (n) { hipError_t e = hipMalloc((void **)&p_, n * sizeof(T)); if (e != hipSuccess) { p_ = nullptr; throw GpuError("hipMalloc of " + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e)); } } }
 template <class T> DevBuf<T>::~DevBuf() { if (p_) hipFree(p_); }
 template <class T> DevBuf<T>::DevBuf(DevBuf &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
 template <class T> DevBuf<T> &DevBuf<T>::operator=(DevBuf &&o) noexcept { if (this != &o) { if (p_) hipFree(p_); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }

@@ -7,5 +7,5 @@ void MsmG2::set_stream(int aux) { impl->stream_id = aux; }
 MsmG2::MsmG2(const G2AffineRaw *p, size_t n, int c, bool fo) : impl(new Impl(p, n, c, fo)) {}
 MsmG2::~MsmG2() = default;
 void MsmG2::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
-host::HG2 MsmG2::result() { HIP_CHECK(hipStreamSynchronize(impl->stream())); return combine<host::HFq2, Fq2>(impl->host_sums(), impl->W, impl->c); }
+host::HG2 MsmG2::result() { HIP_CHECK(hipStreamSynchronize(impl->stream())); return combine<host::HFq2, Fq2>(impl->host_sums(), impl->WB, impl->c); }
 }  // namespace zk

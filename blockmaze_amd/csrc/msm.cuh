@@ -44,28 +44,28 @@ struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; };
 // B-query, kc_multiexp.tcc:52-56); otherwise scalars[i].  point_is_inf (optional): byte flags of key points at infinity.
 template <int DUMMY = 0>
 __global__ void k_msm_classify(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
-                               uint32_t n, int c, int W, int filter_ones, uint32_t *__restrict__ hist, uint32_t *__restrict__ ones, MsmCounters *cnt) {
+                               uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t *__restrict__ hist, uint32_t *__restrict__ ones, MsmCounters *cnt) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
   if (point_is_inf && point_is_inf[i]) return;
   Fr k = scalars[scalar_index ? scalar_index[i] : i].from_mont();
   if (k.is_zero()) return;
   if (filter_ones) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; if (o == 0) { ones[atomicAdd(&cnt->n_ones, 1u)] = i; return; } }
   int dig[MSM_MAX_WINDOWS]; signed_digits(k.l, c, W, dig); const uint32_t NB = 1u << (c - 1);
-  for (int w = 0; w < W; w++) { int d = dig[w]; if (d) atomicAdd(&hist[(uint32_t)w * NB + (uint32_t)(d < 0 ? -d : d) - 1], 1u); }
+  for (int w = 0; w < W; w++) { int d = dig[w]; if (d) atomicAdd(&hist[(uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1], 1u); }   // hist_stride = 2^(c-1): buckets per window; 0: all windows share one bucket array (precomputed 2^(cw) P)
   atomicAdd(&cnt->n_other, 1u);
 }
 
 template <int DUMMY = 0>
 __global__ void k_msm_scatter(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
-                              uint32_t n, int c, int W, int filter_ones, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ fill, uint32_t *__restrict__ entries) {
+                              uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t point_stride, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ fill, uint32_t *__restrict__ entries) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
   if (point_is_inf && point_is_inf[i]) return;
   Fr k = scalars[scalar_index ? scalar_index[i] : i].from_mont();
   if (k.is_zero()) return;
   if (filter_ones) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; if (o == 0) return; }
   int dig[MSM_MAX_WINDOWS]; signed_digits(k.l, c, W, dig); const uint32_t NB = 1u << (c - 1);
-  for (int w = 0; w < W; w++) { int d = dig[w]; if (!d) continue; uint32_t key = (uint32_t)w * NB + (uint32_t)(d < 0 ? -d : d) - 1;
-    entries[offsets[key] + atomicAdd(&fill[key], 1u)] = i | (d < 0 ? 0x80000000u : 0u); }
+  for (int w = 0; w < W; w++) { int d = dig[w]; if (!d) continue; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1;
+    entries[offsets[key] + atomicAdd(&fill[key], 1u)] = (i + (uint32_t)w * point_stride) | (d < 0 ? 0x80000000u : 0u); }   // point_stride = n: the entry addresses 2^(cw) P_i in the precomputed table
 }
 
 // ---- exclusive scan over uint32 (three small kernels; the arrays are <= 2^21 entries) ------------------------------
@@ -166,7 +166,11 @@ __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *_
   while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (task_off[mid] <= t) lo = mid; else hi = mid; }
   uint32_t b = order[lo], j = t - task_off[lo], cnt = counts[b], beg = offsets[b] + j * MSM_TASK, end = offsets[b] + min(cnt, (j + 1) * MSM_TASK);
   XYZZ<F> acc = XYZZ<F>::inf();
-  for (uint32_t e = beg; e < end; e++) { uint32_t v = entries[e]; Affine<F> p = points[v & 0x7fffffffu]; if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); }
+  uint32_t v = entries[beg]; Affine<F> p = points[v & 0x7fffffffu];                         // (beg < end: tasks exist only for non-empty slices)
+#pragma unroll 1
+  for (uint32_t e = beg; e < end; e++) {                                                       // the next point is in flight while this one is added: the table gathers are random HBM reads
+    uint32_t vn = e + 1 < end ? entries[e + 1] : v; Affine<F> pn = points[vn & 0x7fffffffu];
+    if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; }
   if (cnt <= MSM_TASK) buckets[b] = acc; else partials[t] = acc;
 }
 // ---- sums by the 64 quads of a 256-thread workgroup ------------------------------------------------------------------------
@@ -185,19 +189,22 @@ template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<
   return acc;
 }
 
-// buckets that were cut into several tasks: add up the partial sums.  Buckets are ranked by decreasing size (order[], cls_start[]): the first `heavy_blocks`
-// workgroups walk the heavy buckets (>= 49 entries, i.e. 4 tasks or more) one workgroup per bucket, the others take one light bucket (2..3 tasks) per quad.
+// buckets that were cut into several tasks: add up the partial sums.  Buckets are ranked by decreasing size (order[], cls_start[]).  One quad per bucket adds up
+// to COMBINE_QUAD_MAX partials serially (with precomputed tables every bucket of the H query holds ~8 of them); buckets with more get a whole workgroup each
+// (the first `heavy_blocks` workgroups walk the ranks of the fullest size class and pick those).
+constexpr uint32_t COMBINE_QUAD_MAX = 24;
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, const uint32_t *__restrict__ cls_start, uint32_t heavy_blocks,
                                                            const XYZZ<F> *__restrict__ partials, XYZZ<F> *__restrict__ buckets) {
   __shared__ XYZZ<F> lds[4];
-  const uint32_t n_heavy = cls_start[BSORT_CLASSES - 1 - 3 * MSM_TASK], n_multi = cls_start[BSORT_CLASSES - 1 - MSM_TASK];   // ranks below: count > 48, count > 16
+  const uint32_t n_big = cls_start[1], n_multi = cls_start[BSORT_CLASSES - 1 - MSM_TASK];   // ranks below: count >= 63 (the only class that can hold more than COMBINE_QUAD_MAX tasks), count > 16
   if (blockIdx.x < heavy_blocks) {
-    for (uint32_t r = blockIdx.x; r < n_heavy; r += heavy_blocks) { uint32_t beg = task_off[r]; XYZZ<F> acc = block_quad_sum(partials + beg, task_off[r + 1] - beg, lds); if (threadIdx.x == 0) buckets[order[r]] = acc; __syncthreads(); }
+    for (uint32_t r = blockIdx.x; r < n_big; r += heavy_blocks) { uint32_t beg = task_off[r], nt = task_off[r + 1] - beg; if (nt <= COMBINE_QUAD_MAX) continue;
+      XYZZ<F> acc = block_quad_sum(partials + beg, nt, lds); if (threadIdx.x == 0) buckets[order[r]] = acc; __syncthreads(); }
     return;
   }
-  uint32_t r = n_heavy + (blockIdx.x - heavy_blocks) * 64 + (threadIdx.x >> 2); int k = threadIdx.x & 3; if (r >= n_multi) return;
-  uint32_t beg = task_off[r], nt = task_off[r + 1] - beg; XYZZ<F> acc = partials[beg];
+  uint32_t r = (blockIdx.x - heavy_blocks) * 64 + (threadIdx.x >> 2); int k = threadIdx.x & 3; if (r >= n_multi) return;
+  uint32_t beg = task_off[r], nt = task_off[r + 1] - beg; if (nt > COMBINE_QUAD_MAX) return; XYZZ<F> acc = partials[beg];
 #pragma unroll 1
   for (uint32_t j = 1; j < nt; j++) acc = quad_add(acc, partials[beg + j], k);
   if (k == 0) buckets[order[r]] = acc;
@@ -235,6 +242,27 @@ __global__ void __launch_bounds__(256) k_msm_sum_ones(const Affine<F> *__restric
 #pragma unroll 1
   for (uint32_t j = t; j < n; j += n_quads) acc = quad_madd(acc, points[ones[j]], k);
   if (k == 0) partial[t] = acc;
+}
+
+// ---- fixed-base precomputation: table[w*n + i] = 2^(c*w) * P_i, affine ------------------------------------------------
+// The query points of a proving key never change, and 288 GB of HBM is plenty: with every window's multiple of every point stored, all windows of an MSM
+// share ONE array of 2^(c-1) buckets — the bucket reduction shrinks by the number of windows and the host's c*W Horner doublings disappear.
+// One lane per point: c doublings per window in XYZZ, the W-1 conversions to affine share one inversion (x = X/ZZ, y = Y/ZZZ, 1/ZZ = t*ZZZ, 1/ZZZ = t*ZZ with
+// t = 1/(ZZ*ZZZ); Montgomery's trick over the windows).  tmp: (W-1)*n XYZZ, pref: (W-1)*n field elements, both window-major.
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_precompute(Affine<F> *__restrict__ table, uint32_t n, int c, int W, XYZZ<F> *__restrict__ tmp, F *__restrict__ pref) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; const Affine<F> P = table[i];
+  if (P.is_inf()) { for (int w = 1; w < W; w++) table[(size_t)w * n + i] = Affine<F>::inf(); return; }
+  XYZZ<F> cur = XYZZ<F>::from_affine(P); F acc = F::one();
+#pragma unroll 1
+  for (int w = 1; w < W; w++) {
+#pragma unroll 1
+    for (int k = 0; k < c; k++) cur = cur.dbl_inl();
+    tmp[(size_t)(w - 1) * n + i] = cur; pref[(size_t)(w - 1) * n + i] = acc; acc = acc * (cur.ZZ * cur.ZZZ);
+  }
+  F inv = acc.inv();
+#pragma unroll 1
+  for (int w = W - 1; w >= 1; w--) { const XYZZ<F> q = tmp[(size_t)(w - 1) * n + i]; F t = inv * pref[(size_t)(w - 1) * n + i]; inv = inv * (q.ZZ * q.ZZZ); table[(size_t)w * n + i] = {q.X * (t * q.ZZZ), q.Y * (t * q.ZZ)}; }
 }
 
 }  // namespace zk

@@ -7,7 +7,8 @@
 namespace zk {
 template <class F, class RawAffine>
 struct MsmImpl {
-  size_t n; int c, W; uint32_t NB; bool filter_ones; uint32_t seg, n_ones_quads; std::string label = "msm"; int stream_id = -1;   // -1: main stream, 0..3: auxiliary stream
+  size_t n; int c, W, WB; uint32_t NB;   // W digit windows; WB bucket arrays (1 when the multiples 2^(cw) P are precomputed, else W)
+   bool filter_ones; uint32_t seg, n_ones_quads; std::string label = "msm"; int stream_id = -1;   // -1: main stream, 0..3: auxiliary stream
   DevBuf<RawAffine> points; DevBuf<uint8_t> inf; bool any_inf = false;
   DevBuf<uint32_t> zeroed;                                          // [hist | fill | counters]: cleared by one memset per run
   DevBuf<uint32_t> offsets, entries, ones, ntasks, task_off, order, rank_of, block_hist, block_off, cls_start; uint32_t bsort_blocks; std::unique_ptr<Scanner> bsort_scanner; Scanner scanner, task_scanner; uint32_t max_tasks;
@@ -16,25 +17,37 @@ struct MsmImpl {
   static constexpr uint32_t HEAVY_BLOCKS = 256, GROUP = 256;
 
   uint32_t *hist() { return zeroed.get(); }
-  uint32_t *fill() { return zeroed.get() + (size_t)W * NB; }
-  MsmCounters *counters() { return (MsmCounters *)(zeroed.get() + 2 * (size_t)W * NB); }
-  size_t result_bytes() const { return (size_t)(W + 1) * sizeof(XYZZ<F>) + sizeof(MsmCounters); }
+  uint32_t *fill() { return zeroed.get() + (size_t)WB * NB; }
+  MsmCounters *counters() { return (MsmCounters *)(zeroed.get() + 2 * (size_t)WB * NB); }
+  size_t result_bytes() const { return (size_t)(WB + 1) * sizeof(XYZZ<F>) + sizeof(MsmCounters); }
   const XYZZ<F> *host_sums() const { return (const XYZZ<F> *)h_result; }
-  const MsmCounters *host_counters() const { return (const MsmCounters *)(h_result + (size_t)(W + 1) * sizeof(XYZZ<F>)); }
+  const MsmCounters *host_counters() const { return (const MsmCounters *)(h_result + (size_t)(WB + 1) * sizeof(XYZZ<F>)); }
 
+  // Precomputed multiples 2^(cw) P unless switched off (ZK_MSM_PRECOMPUTE=0), the table would pass ZK_MSM_PRECOMPUTE_MAX_MB (default 768 MB: measured on MI355X, the
+  // random 64-byte gathers from a table far beyond the 256 MB Infinity Cache cost more than the smaller bucket reduction saves — deposit at depth 32: 9.1 ms
+  // without, 13.1 ms with 2-9 GB tables; send / mint / deposit-8 gain 1-5 %), or its indices would not fit the 31 bits of a sorted entry.
+  static bool use_precompute(size_t n_, int W_) { static const bool on = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE"); return !e || atoi(e) != 0; }();
+    static const size_t cap = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE_MAX_MB"); return (size_t)(e ? atol(e) : 768) << 20; }();
+    return on && n_ > 0 && W_ > 1 && n_ * (size_t)W_ < (1ull << 31) && n_ * (size_t)W_ * sizeof(RawAffine) <= cap; }
   MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo)
-      : n(n_), c(c_), W(msm_num_windows(c_)), NB(1u << (c_ - 1)), filter_ones(fo), points(n_ ? n_ : 1), inf(n_ ? n_ : 1),
-        zeroed(2 * (size_t)W * NB + sizeof(MsmCounters) / 4), offsets((size_t)W * NB), entries((n_ ? n_ : 1) * (size_t)W), ones(n_ ? n_ : 1), ntasks((size_t)W * NB + 1), task_off((size_t)W * NB + 1), cls_start(BSORT_CLASSES),
-        scanner((size_t)W * NB), task_scanner((size_t)W * NB + 1) {
+      : n(n_), c(c_), W(msm_num_windows(c_)), WB(use_precompute(n_, msm_num_windows(c_)) ? 1 : msm_num_windows(c_)), NB(1u << (c_ - 1)), filter_ones(fo), points((n_ ? n_ : 1) * (size_t)(WB == 1 ? W : 1)), inf(n_ ? n_ : 1),
+        zeroed(2 * (size_t)WB * NB + sizeof(MsmCounters) / 4), offsets((size_t)WB * NB), entries((n_ ? n_ : 1) * (size_t)W), ones(n_ ? n_ : 1), ntasks((size_t)WB * NB + 1), task_off((size_t)WB * NB + 1), cls_start(BSORT_CLASSES),
+        scanner((size_t)WB * NB), task_scanner((size_t)WB * NB + 1) {
     if (c < 6 || c > 20 || W > MSM_MAX_WINDOWS) throw GpuError("msm: unsupported window size");
-    { const char *e = getenv("ZK_MSM_SEG"); uint32_t big = e ? (uint32_t)atoi(e) : 16; if (big < 2 || big > 256 || (big & (big - 1))) big = 16; seg = NB >= 4096 ? big : 4; } n_ones_quads = 16384;
+    { const char *e = getenv("ZK_MSM_SEG"); uint32_t big = e ? (uint32_t)atoi(e) : 16; if (big < 2 || big > 256 || (big & (big - 1))) big = 16; seg = NB >= 4096 ? (WB == 1 ? 4 : big) : 4; }   // one bucket array: few segments, keep the dependent chain short
+    n_ones_quads = 16384;
     std::vector<uint8_t> flags(n ? n : 1, 0); const uint8_t zero[sizeof(RawAffine)] = {0};
     for (size_t i = 0; i < n; i++) if (!memcmp(&host_points[i], zero, sizeof(RawAffine))) { flags[i] = 1; any_inf = true; }
     if (n) { points.upload(host_points, n); inf.upload(flags.data(), n); }
-    max_tasks = (uint32_t)((n * (size_t)W) / MSM_TASK + (size_t)W * NB + 1);
-    { size_t nbk = (size_t)W * NB; bsort_blocks = cdiv(nbk, BSORT_BLOCK); order = DevBuf<uint32_t>(nbk); rank_of = DevBuf<uint32_t>(nbk); block_hist = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); block_off = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); bsort_scanner.reset(new Scanner((size_t)bsort_blocks * BSORT_CLASSES)); }
-    buckets = DevBuf<uint8_t>((size_t)W * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>((size_t)max_tasks * sizeof(XYZZ<F>));
-    seg_out = DevBuf<uint8_t>((size_t)W * (NB / seg) * sizeof(XYZZ<F>)); seg_l2 = DevBuf<uint8_t>((size_t)W * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
+    if (WB == 1 && W > 1 && n) {   // table[w*n + i] = 2^(c*w) * P_i (k_msm_precompute); the scratch arrays live only for this launch
+      DevBuf<uint8_t> tmp((size_t)(W - 1) * n * sizeof(XYZZ<F>)), pref((size_t)(W - 1) * n * sizeof(F));
+      hipLaunchKernelGGL((k_msm_precompute<F>), dim3(cdiv(n, 64)), dim3(64), 0, gpu().stream, (Affine<F> *)points.get(), (uint32_t)n, c, W, (XYZZ<F> *)tmp.get(), (F *)pref.get());
+      HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream));
+    }
+    max_tasks = (uint32_t)((n * (size_t)W) / MSM_TASK + (size_t)WB * NB + 1);
+    { size_t nbk = (size_t)WB * NB; bsort_blocks = cdiv(nbk, BSORT_BLOCK); order = DevBuf<uint32_t>(nbk); rank_of = DevBuf<uint32_t>(nbk); block_hist = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); block_off = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); bsort_scanner.reset(new Scanner((size_t)bsort_blocks * BSORT_CLASSES)); }
+    buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>((size_t)max_tasks * sizeof(XYZZ<F>));
+    seg_out = DevBuf<uint8_t>((size_t)WB * (NB / seg) * sizeof(XYZZ<F>)); seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
     ones_partial = DevBuf<uint8_t>((size_t)n_ones_quads * sizeof(XYZZ<F>)); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
     result = DevBuf<uint8_t>(result_bytes()); result.zero();          // the ones slot stays the point at infinity when the ones path is off
     HIP_CHECK(hipHostMalloc((void **)&h_result, result_bytes())); HIP_CHECK(hipStreamSynchronize(gpu().stream));
@@ -43,11 +56,11 @@ struct MsmImpl {
   hipStream_t stream() { return stream_id < 0 ? gpu().stream : gpu().aux[stream_id & 3]; }
 
   void run(const Fe32 *scalars, const uint32_t *scalar_index) {
-    hipStream_t s = stream(); size_t nbk = (size_t)W * NB; const uint8_t *infp = any_inf ? inf.get() : nullptr; MsmCounters *cnt = counters();
+    hipStream_t s = stream(); size_t nbk = (size_t)WB * NB; const uint32_t hist_stride = WB == 1 ? 0 : NB, point_stride = WB == 1 && W > 1 ? (uint32_t)n : 0; const uint8_t *infp = any_inf ? inf.get() : nullptr; MsmCounters *cnt = counters();
     const uint32_t bucket_u4 = sizeof(XYZZ<F>) / 16; XYZZ<F> *res = (XYZZ<F> *)result.get();
     HIP_CHECK(hipMemsetAsync(zeroed.get(), 0, zeroed.size() * 4, s));
     { Stage st((label + ".sort").c_str(), s);
-      if (n) hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist(), ones.get(), cnt);
+      if (n) hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, hist(), ones.get(), cnt);
       if (nbk <= PLAN_SMALL_MAX) {
         hipLaunchKernelGGL(k_msm_plan_small, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, offsets.get(), order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
       } else {
@@ -57,7 +70,7 @@ struct MsmImpl {
         hipLaunchKernelGGL(k_bsort_scatter, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_off.get(), order.get(), rank_of.get(), ntasks.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
         task_scanner.run(ntasks.get(), task_off.get(), nbk + 1, s);
       }
-      if (n) hipLaunchKernelGGL(k_msm_scatter<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, offsets.get(), fill(), entries.get());
+      if (n) hipLaunchKernelGGL(k_msm_scatter<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, point_stride, offsets.get(), fill(), entries.get());
     }
     { Stage st((label + ".accumulate").c_str(), s);
       hipLaunchKernelGGL((k_msm_accumulate_tasks<F>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), order.get(), task_off.get(), (uint32_t)nbk, max_tasks,
@@ -67,17 +80,17 @@ struct MsmImpl {
       hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(HEAVY_BLOCKS + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), HEAVY_BLOCKS, (const XYZZ<F> *)partials.get(), (XYZZ<F> *)buckets.get());
     }
     { Stage st_red((label + ".reduce").c_str(), s);
-      uint32_t spw = NB / seg, nseg = (uint32_t)W * spw; const uint4 *csrc = (const uint4 *)cnt; uint4 *cdst = (uint4 *)(res + W + 1);
+      uint32_t spw = NB / seg, nseg = (uint32_t)WB * spw; const uint4 *csrc = (const uint4 *)cnt; uint4 *cdst = (uint4 *)(res + WB + 1);
       hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3(cdiv(nseg, 16)), dim3(64), 0, s, (const XYZZ<F> *)buckets.get(), NB, seg, nseg, (XYZZ<F> *)seg_out.get());
       if (spw > GROUP) { uint32_t g = spw / GROUP;   // two-level tree per window keeps the dependent chain short (spw is a power of two)
-        hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W * g), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), GROUP, nseg, (XYZZ<F> *)seg_l2.get(), (const uint4 *)nullptr, (uint4 *)nullptr);
-        hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W), dim3(256), 0, s, (const XYZZ<F> *)seg_l2.get(), g, (uint32_t)W * g, res, csrc, cdst);
-      } else hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(W), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), spw, nseg, res, csrc, cdst);
+        hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(WB * g), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), GROUP, nseg, (XYZZ<F> *)seg_l2.get(), (const uint4 *)nullptr, (uint4 *)nullptr);
+        hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(WB), dim3(256), 0, s, (const XYZZ<F> *)seg_l2.get(), g, (uint32_t)WB * g, res, csrc, cdst);
+      } else hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(WB), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), spw, nseg, res, csrc, cdst);
     }
     if (filter_ones && n) { Stage st((label + ".ones").c_str(), s); uint32_t g = cdiv(n_ones_quads, GROUP);
       hipLaunchKernelGGL((k_msm_sum_ones<F>), dim3(cdiv((size_t)n_ones_quads * 4, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), ones.get(), cnt, n_ones_quads, (XYZZ<F> *)ones_partial.get());
       hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(g), dim3(256), 0, s, (const XYZZ<F> *)ones_partial.get(), GROUP, n_ones_quads, (XYZZ<F> *)ones_l2.get(), (const uint4 *)nullptr, (uint4 *)nullptr);
-      hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(256), 0, s, (const XYZZ<F> *)ones_l2.get(), g, g, res + W, (const uint4 *)nullptr, (uint4 *)nullptr);
+      hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(256), 0, s, (const XYZZ<F> *)ones_l2.get(), g, g, res + WB, (const uint4 *)nullptr, (uint4 *)nullptr);
     }
     HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s));
   }
