@@ -25,11 +25,12 @@ HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2, help="extra leg (not `value`): this many prover objects per GPU, one host thread each, proofs overlapping on the device; 0/1 = skip")
     ap.add_argument("--shard-msm", action="store_true", help="N > 1 only: all ranks prove ONE proof per step together, each holding 1/N of every query; one all-gather of 384-byte partial records per proof (strong scaling)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("ZK_DEVICE", str(local_rank))
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # the prover runs five streams; the HIP runtime (initialised by torch below) maps them onto 4 hardware queues by default
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # the prover runs five streams; the HIP runtime (initialised by torch below) maps them onto 4 hardware queues by default
     import torch
     dist = None
     if world > 1:
@@ -83,6 +84,23 @@ def main():
         for i in range(nx): zk.GenSendProof(*w.send_args(insts[i % n_inst]))
         ms_abi = 1e3 * (time.perf_counter() - t0) / nx
 
+    # ---- not part of `value`: K proofs in flight per GPU (K prover objects on their own stream sets, one host thread each): what a batch of independent
+    # proofs (BASELINE.json configs[2]) or concurrent cgo calls get
+    inflight = None
+    if not shard and args.inflight > 1:
+        import threading
+        provers = [prover] + [e.Prover(pk_path) for _ in range(args.inflight - 1)]
+        for k, pv in enumerate(provers): pv.set_witness(zs[k % n_inst]); pv.prove_resident()
+        per = max(4, args.steps)
+        def worker(pv):
+            for _ in range(per): pv.prove_resident()
+        ths = [threading.Thread(target=worker, args=(pv,)) for pv in provers]; t0 = time.perf_counter()
+        for t in ths: t.start()
+        for t in ths: t.join()
+        dti = time.perf_counter() - t0; inflight = {"provers": args.inflight, "proofs": per * args.inflight, "proofs_per_s": round(per * args.inflight / dti, 2), "ms_per_proof": round(1e3 * dti / (per * args.inflight), 4)}
+        for pv in provers[1:]: pv.close()
+        prover.set_witness(zs[0])
+
     # ---- roofline leg: HIP-event time of the dominant kernel, same stream, after the timed region --------------------------
     e.profile_enable(True); nprof = max(3, min(args.steps, 10))
     for i in range(nprof): one_proof(i)
@@ -122,7 +140,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery)", "data": "synthetic",
             "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
                        "includes": "R1CS rows + 7 NTT + 5 MSM + host proof assembly + hex serialisation, assignment resident in HBM; excludes witness generation and key load"},
-            "ms_per_proof_host_buffer_in": ms_pcie and round(ms_pcie, 4), "ms_per_proof_through_genSendproof": ms_abi and round(ms_abi, 4),
+            "proofs_in_flight": inflight, "ms_per_proof_host_buffer_in": ms_pcie and round(ms_pcie, 4), "ms_per_proof_through_genSendproof": ms_abi and round(ms_abi, 4),
             "roofline": roofline, "cpu_baseline": cpu,
             "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2)}}))
     prover.close()

@@ -91,6 +91,11 @@ template <class Fn> static int guarded(Fn fn) {
   catch (const std::exception &e) { zkgpu_set_error(e.what()); return ZKGPU_ERR_RUNTIME; } catch (...) { zkgpu_set_error("unknown error"); return ZKGPU_ERR_RUNTIME; } }
 template <class Fn> static int guarded_host(Fn fn) { try { return fn(); } catch (const std::exception &e) { zkgpu_set_error(e.what()); return ZKGPU_ERR_RUNTIME; } catch (...) { zkgpu_set_error("unknown error"); return ZKGPU_ERR_RUNTIME; } }
 
+struct zkgpu_prover { std::shared_ptr<Prover> p; std::mutex m; };   // proofs on different prover objects may run concurrently (each has its own streams); one object is used by one thread at a time
+template <class Fn> static int guarded_prover(zkgpu_prover *h, Fn fn) {
+  try { if (!gpu_available()) { zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback"); return ZKGPU_ERR_NO_DEVICE; } if (!h) return ZKGPU_ERR_ARG; std::lock_guard<std::mutex> lk(h->m); return fn(); }
+  catch (const std::exception &e) { zkgpu_set_error(e.what()); return ZKGPU_ERR_RUNTIME; } catch (...) { zkgpu_set_error("unknown error"); return ZKGPU_ERR_RUNTIME; } }
+
 extern "C" {
 char *zkgpu_abi_genCMT(uint64_t value, char *sn_string, char *r_string) { return hash_out(note_cm(value, blob256_from_hex(sn_string), blob256_from_hex(r_string))); }
 char *zkgpu_abi_genCMTS(uint64_t value_s, char *pk_string, char *r_s_string, char *sn_old_string) { return hash_out(note_s_cm(value_s, blob160_from_hex(pk_string), blob256_from_hex(r_s_string), blob256_from_hex(sn_old_string))); }
@@ -140,8 +145,6 @@ bool zkgpu_abi_verifyDepositproof(char *data, char *RT, char *pk, char *cmtb_old
   append(bits, blob_bits(blob256_from_hex(cmtb).b, 32)); append(bits, blob_bits(blob256_from_hex(sns).b, 32)); return verify(CircuitKind::Deposit, data, bits); }
 
 // ---- engine-level entry points for keys, circuits and the resident prover (include/zkgpu.h) ---------------------------
-struct zkgpu_prover { std::shared_ptr<Prover> p; };
-
 static void write_r1cs_file(const char *path, const R1csHost &cs) { FILE *f = fopen(path, "wb"); if (!f) throw std::runtime_error(std::string("cannot write ") + path);
   uint64_t hdr[3] = {cs.n_inputs, cs.n_vars, cs.n_cons}; fwrite("R1CSBM01", 1, 8, f); fwrite(hdr, 8, 3, f);
   for (int m = 0; m < 3; m++) { uint64_t nnz = cs.col[m].size(); fwrite(&nnz, 8, 1, f); fwrite(cs.rowptr[m].data(), 4, cs.rowptr[m].size(), f); fwrite(cs.col[m].data(), 4, nnz, f); fwrite(cs.coeff[m].data(), 32, nnz, f); } fclose(f); }
@@ -178,15 +181,15 @@ int zkgpu_keygen(int kind, int tree_depth, uint64_t seed, const char *pk_path, c
 
 zkgpu_prover *zkgpu_prover_load_shard(const char *pk_path, size_t shard_rank, size_t shard_world) { zkgpu_prover *h = nullptr; guarded([&] { ProvingKeyHost pk = load_proving_key(pk_path); std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(pk, shard_rank, shard_world)); h = p.release(); return ZKGPU_OK; }); return h; }
 zkgpu_prover *zkgpu_prover_load(const char *pk_path) { return zkgpu_prover_load_shard(pk_path, 0, 1); }
-int zkgpu_prover_prove_partial(zkgpu_prover *h, uint8_t out[384]) { return guarded([&] { if (!h) return ZKGPU_ERR_ARG; if (!h->p->prove_partial(out)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } return ZKGPU_OK; }); }
+int zkgpu_prover_prove_partial(zkgpu_prover *h, uint8_t out[384]) { return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; if (!h->p->prove_partial(out)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } return ZKGPU_OK; }); }
 int zkgpu_prover_finish(zkgpu_prover *h, const uint8_t *records, size_t n, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_host([&] { if (!h) return ZKGPU_ERR_ARG; Proof p; h->p->finish_from_partials(records, n, (const Fe32 *)r, (const Fe32 *)s, p);
   std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
 void zkgpu_prover_destroy(zkgpu_prover *h) { guarded([&] { delete h; return ZKGPU_OK; }); }
 int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]) { if (!h) return ZKGPU_ERR_ARG; out[0] = h->p->num_variables(); out[1] = h->p->num_inputs(); out[2] = h->p->domain_size(); return ZKGPU_OK; }
-int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded([&] { if (!h) return ZKGPU_ERR_ARG; Proof p;
+int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; Proof p;
   if (!h->p->prove((const Fe32 *)z, (const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
-int zkgpu_prover_set_witness(zkgpu_prover *h, const uint8_t *z) { return guarded([&] { if (!h) return ZKGPU_ERR_ARG; h->p->set_witness((const Fe32 *)z, false); gpu_sync(); return ZKGPU_OK; }); }
-int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded([&] { if (!h) return ZKGPU_ERR_ARG; Proof p;
+int zkgpu_prover_set_witness(zkgpu_prover *h, const uint8_t *z) { return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; h->p->set_witness((const Fe32 *)z, false); gpu_sync(); return ZKGPU_OK; }); }
+int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; Proof p;
   if (!h->p->prove_resident((const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
 int zkgpu_prover_timings(zkgpu_prover *h, double out[5]) { if (!h) return ZKGPU_ERR_ARG; out[0] = h->p->last.upload_ms; out[1] = h->p->last.qap_ms; out[2] = h->p->last.msm_ms; out[3] = h->p->last.finish_ms; out[4] = h->p->last.total_ms; return ZKGPU_OK; }
 int zkgpu_profile_enable(int on) { return guarded([&] { profile_enable(on != 0); return ZKGPU_OK; }); }

@@ -5,12 +5,25 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <atomic>
+#include <mutex>
 #include "gpu_internal.hpp"
 #include "ntt.cuh"
 
 namespace zk {
 
-GpuContext &gpu() { static GpuContext ctx; hipSetDevice(ctx.device); return ctx; }
+// Lanes: independent sets of streams (one main + four auxiliary) so that several provers can have a proof in flight at the same time; a thread works on the lane it
+// selected with LaneScope (lane 0 unless told otherwise).  Contexts are created on first use and live for the life of the process.
+constexpr int MAX_LANES = 8;
+static std::atomic<GpuContext *> g_lanes[MAX_LANES]; static std::mutex g_lane_mutex; static thread_local int t_lane = 0; static std::atomic<unsigned> g_next_lane{0};
+GpuContext &gpu() {
+  GpuContext *c = g_lanes[t_lane].load(std::memory_order_acquire);
+  if (!c) { std::lock_guard<std::mutex> lk(g_lane_mutex); c = g_lanes[t_lane].load(std::memory_order_acquire); if (!c) { c = new GpuContext; g_lanes[t_lane].store(c, std::memory_order_release); } }
+  hipSetDevice(c->device); return *c;
+}
+int gpu_lane_acquire() { return 1 + (int)(g_next_lane.fetch_add(1) % (MAX_LANES - 1)); }      // lanes 1..7 round robin for provers; lane 0 stays with everything else
+int gpu_lane_current() { return t_lane; }
+void gpu_lane_select(int lane) { t_lane = lane < 0 || lane >= MAX_LANES ? 0 : lane; }
 bool gpu_available() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0; }
 void gpu_sync() { HIP_CHECK(hipStreamSynchronize(gpu().stream)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamSynchronize(gpu().aux[i])); }
 void gpu_join_aux() { GpuContext &g = gpu(); for (int i = 0; i < 4; i++) { HIP_CHECK(hipEventRecord(g.join_event[i], g.aux[i])); HIP_CHECK(hipStreamWaitEvent(g.stream, g.join_event[i], 0)); } }

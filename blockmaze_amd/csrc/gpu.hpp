@@ -23,6 +23,8 @@ struct G2AffineRaw { Fe32 x0, x1, y0, y1; };  // 128 B
 class GpuContext;
 GpuContext &gpu();                             // lazily initialised process-wide context (device from ZK_DEVICE / LOCAL_RANK)
 bool gpu_available();                          // false if no HIP device is visible
+int gpu_lane_acquire(); int gpu_lane_current(); void gpu_lane_select(int lane);   // independent stream sets (gpu.hip)
+struct LaneScope { int prev; explicit LaneScope(int lane) : prev(gpu_lane_current()) { gpu_lane_select(lane); } ~LaneScope() { gpu_lane_select(prev); } LaneScope(const LaneScope &) = delete; };
 
 template <class T> class DevBuf {              // RAII device allocation
  public:

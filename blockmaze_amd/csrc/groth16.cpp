@@ -185,6 +185,7 @@ void generate_keys(const R1csHost &cs_in, const ToxicWaste &tw, ProvingKeyHost &
 // prover
 // ======================================================================================================================
 struct Prover::Impl {
+  int lane = 0;                                                // this prover's stream set: provers on different lanes overlap on the device
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
   std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; PinnedBuf<Fe32> z_host; GpuGraph *graph = nullptr; bool graph_failed = false;
@@ -193,7 +194,7 @@ struct Prover::Impl {
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &e) { size_t base = n / world, rem = n % world; b = rank * base + (rank < rem ? rank : rem); e = b + base + (rank < rem ? 1 : 0); }
 Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) : impl(new Impl) {
-  Impl &p = *impl; p.nv = pk.cs.n_vars; p.ni = pk.cs.n_inputs; if (shard_world == 0 || shard_rank >= shard_world) throw std::runtime_error("prover: bad shard"); p.cs.reset(new R1csDev(pk.cs)); p.dom.reset(new Domain(pk.cs.n_cons + p.ni + 1)); p.m = p.dom->m();
+  Impl &p = *impl; p.lane = gpu_lane_acquire(); LaneScope lane_scope(p.lane); p.nv = pk.cs.n_vars; p.ni = pk.cs.n_inputs; if (shard_world == 0 || shard_rank >= shard_world) throw std::runtime_error("prover: bad shard"); p.cs.reset(new R1csDev(pk.cs)); p.dom.reset(new Domain(pk.cs.n_cons + p.ni + 1)); p.m = p.dom->m();
   if (pk.A.size() != p.nv + 1 || pk.H.size() != p.m - 1 || pk.L.size() != p.nv - p.ni) throw std::runtime_error("proving key: query sizes do not match the constraint system");
   p.alpha_g1 = g1_of(pk.alpha_g1); p.beta_g1 = g1_of(pk.beta_g1); p.delta_g1 = g1_of(pk.delta_g1); p.beta_g2 = g2_of(pk.beta_g2); p.delta_g2 = g2_of(pk.delta_g2);
   int cw = env_int("ZK_MSM_WITNESS_WINDOW", 8), ch = env_int("ZK_MSM_H_WINDOW", 16);
@@ -206,13 +207,13 @@ Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) 
   p.B_idx = DevBuf<uint32_t>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx.upload(pk.B_idx.data(), pk.B_idx.size());
   p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host = PinnedBuf<Fe32>(p.nv + 1);
 }
-Prover::~Prover() = default;
+Prover::~Prover() { if (impl) { LaneScope lane_scope(impl->lane); try { gpu_sync(); } catch (...) {} impl.reset(); } }
 size_t Prover::num_variables() const { return impl->nv; }
 size_t Prover::num_inputs() const { return impl->ni; }
 size_t Prover::domain_size() const { return impl->m; }
 
 void Prover::set_witness(const Fe32 *z, bool montgomery) {
-  Impl &p = *impl; double t0 = now_ms(); Fe32 *h = p.z_host.get();
+  Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); Fe32 *h = p.z_host.get();
   if (montgomery) memcpy(&h[0], FrParams::R1, 32); else { memset(&h[0], 0, 32); h[0].l[0] = 1; }
   memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * (p.nv + 1)); if (!montgomery) fr_to_mont_dev(p.z.get(), p.nv + 1);
   last.upload_ms = now_ms() - t0;
@@ -231,7 +232,7 @@ static void enqueue_all(Prover::Impl &p) {
   int nh = (gpu_capturing() || profiling_enabled()) ? 0 : n_helpers;   // (the stage timers are not thread-safe: profiling runs submit from one thread)
   std::exception_ptr aux_error[4]; std::thread helpers[4];
   struct Joiner { std::thread *t; ~Joiner() { for (int i = 0; i < 4; i++) if (t[i].joinable()) t[i].join(); } } joiner{helpers};
-  for (int h = 0; h < nh; h++) helpers[h] = std::thread([&, h] { try { for (int j = h; j < 4; j += nh) jobs[j](); } catch (...) { aux_error[h] = std::current_exception(); } });
+  for (int h = 0; h < nh; h++) helpers[h] = std::thread([&, h] { LaneScope lane_scope(p.lane); try { for (int j = h; j < 4; j += nh) jobs[j](); } catch (...) { aux_error[h] = std::current_exception(); } });
   if (!nh) for (auto &j : jobs) j();
   p.cs->eval(p.z.get(), p.abc.get(), p.m);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
@@ -256,7 +257,7 @@ static void assemble(const Prover::Impl &p, const RsTerms &t, const HG1 &eA, con
   HG1 gC = eH.add(eL).add(gA.mul(t.s.l)).add(gB1.mul(t.r.l)).add(t.rs_delta_neg);                                       // :495
   out.A = raw_of(gA); out.B = raw_of(gB2); out.C = raw_of(gC); }
 bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
-  Impl &p = *impl; double t1 = now_ms(); run_device(p);
+  Impl &p = *impl; LaneScope lane_scope(p.lane); double t1 = now_ms(); run_device(p);
   RsTerms t = rs_terms(r_in, s_in, p.delta_g1, p.delta_g2);                                                              // host work overlapped with the kernels
   double t2 = now_ms();
   // The witness MSMs finish well before the H chain (row products, 7 transforms, the largest MSM).  Their Horner combines, the two scalar multiples and the
@@ -275,7 +276,7 @@ bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
 static void put_canon_g1(const HG1 &p, uint8_t *o) { HFq x, y; p.to_affine(x, y); x = x.from_mont(); y = y.from_mont(); memcpy(o, x.l, 32); memcpy(o + 32, y.l, 32); }
 static HG1 get_canon_g1(const uint8_t *o) { HFq x, y; memcpy(x.l, o, 32); memcpy(y.l, o + 32, 32); if (x.is_zero() && y.is_zero()) return HG1::inf(); return HG1::from_affine(x.to_mont(), y.to_mont()); }
 bool Prover::prove_partial(uint8_t out[PARTIAL_BYTES]) {
-  Impl &p = *impl; run_device(p); gpu_sync(); if (!p.cs->check_result()) return false;
+  Impl &p = *impl; LaneScope lane_scope(p.lane); run_device(p); gpu_sync(); if (!p.cs->check_result()) return false;
   put_canon_g1(p.A->result(), out); put_canon_g1(p.B1->result(), out + 64); put_canon_g1(p.H->result(), out + 128); put_canon_g1(p.L->result(), out + 192);
   HFq2 x, y; p.B2->result().to_affine(x, y); HFq v[4] = {x.c0.from_mont(), x.c1.from_mont(), y.c0.from_mont(), y.c1.from_mont()}; for (int k = 0; k < 4; k++) memcpy(out + 256 + 32 * k, v[k].l, 32); return true;
 }
