@@ -25,7 +25,7 @@ HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2, help="extra leg (not `value`): this many prover objects per GPU, one host thread each, proofs overlapping on the device; 0/1 = skip")
+    ap.add_argument("--inflight", type=int, default=4, help="extra leg (not `value`): this many prover objects per GPU, one host thread each, proofs overlapping on the device; 0/1 = skip")
     ap.add_argument("--shard-msm", action="store_true", help="N > 1 only: all ranks prove ONE proof per step together, each holding 1/N of every query; one all-gather of 384-byte partial records per proof (strong scaling)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -75,14 +75,22 @@ def main():
 
     # ---- not part of `value`: the same proofs with the witness handed over as a host buffer each time (PCIe inclusive), and through the
     # drop-in cgo symbol genSendproof (adds witness generation on the host and hex marshalling)
-    nx = max(3, min(args.steps, 10)); ms_pcie = ms_abi = None
+    nx = max(3, min(args.steps, 10)); ms_pcie = ms_abi = abi_conc = None
     if not shard:
         t0 = time.perf_counter()
         for i in range(nx): prover.prove(zs[i % n_inst])
         ms_pcie = 1e3 * (time.perf_counter() - t0) / nx
-        os.environ["ZK_PRFKEY_DIR"] = tmp; zk = e.Zk(); zk.GenSendProof(*w.send_args(insts[0])); t0 = time.perf_counter()
+        os.environ["ZK_PRFKEY_DIR"] = tmp; os.environ.setdefault("ZK_PROVERS_PER_KEY", str(max(2, args.inflight))); zk = e.Zk(); zk.GenSendProof(*w.send_args(insts[0])); t0 = time.perf_counter()
         for i in range(nx): zk.GenSendProof(*w.send_args(insts[i % n_inst]))
         ms_abi = 1e3 * (time.perf_counter() - t0) / nx
+        if args.inflight > 1:                                                  # the same symbol called from several threads at once, as go-ethereum's goroutines do
+            import threading
+            def caller(k):
+                for i in range(nx): zk.GenSendProof(*w.send_args(insts[(i + k) % n_inst]))
+            ths = [threading.Thread(target=caller, args=(k,)) for k in range(args.inflight)]; t0 = time.perf_counter()
+            for t in ths: t.start()
+            for t in ths: t.join()
+            abi_conc = round(nx * args.inflight / (time.perf_counter() - t0), 2)
 
     # ---- not part of `value`: K proofs in flight per GPU (K prover objects on their own stream sets, one host thread each): what a batch of independent
     # proofs (BASELINE.json configs[2]) or concurrent cgo calls get
@@ -140,7 +148,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery)", "data": "synthetic",
             "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
                        "includes": "R1CS rows + 7 NTT + 5 MSM + host proof assembly + hex serialisation, assignment resident in HBM; excludes witness generation and key load"},
-            "proofs_in_flight": inflight, "ms_per_proof_host_buffer_in": ms_pcie and round(ms_pcie, 4), "ms_per_proof_through_genSendproof": ms_abi and round(ms_abi, 4),
+            "proofs_in_flight": inflight, "ms_per_proof_host_buffer_in": ms_pcie and round(ms_pcie, 4), "ms_per_proof_through_genSendproof": ms_abi and round(ms_abi, 4), "proofs_per_s_through_genSendproof_concurrent_callers": abi_conc,
             "roofline": roofline, "cpu_baseline": cpu,
             "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2)}}))
     prover.close()

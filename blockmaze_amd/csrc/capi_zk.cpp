@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -36,20 +37,30 @@ std::string key_path(CircuitKind k, bool pk) { return key_dir() + "/" + circuit_
 struct FileStamp { off_t size = -1; time_t mtime = 0; long mtime_ns = 0; bool operator==(const FileStamp &o) const { return size == o.size && mtime == o.mtime && mtime_ns == o.mtime_ns; } };
 bool stamp_of(const std::string &p, FileStamp &s) { struct stat st; if (stat(p.c_str(), &st)) return false; s.size = st.st_size; s.mtime = st.st_mtim.tv_sec; s.mtime_ns = st.st_mtim.tv_nsec; return true; }
 
-struct ProverSlot { FileStamp stamp; std::shared_ptr<Prover> prover; std::unique_ptr<Circuit> circuit; };
+// One proving key = a small pool of provers (ZK_PROVERS_PER_KEY, default 2), each with its own circuit board, device buffers and stream set: cgo calls
+// that arrive concurrently (tx pool, RPC goroutines, block processing) overlap on the GPU instead of queueing behind one mutex.
+struct ProverUnit { std::shared_ptr<Prover> prover; std::unique_ptr<Circuit> circuit; std::mutex busy; };
+struct ProverSlot { FileStamp stamp; std::vector<std::unique_ptr<ProverUnit>> units; std::atomic<unsigned> next{0}; };
 struct VkSlot { FileStamp stamp; std::shared_ptr<VerifyingKeyHost> vk; };
 std::mutex g_cache_mutex; std::map<std::string, ProverSlot> g_provers; std::map<std::string, VkSlot> g_vks;
 
 std::unique_ptr<Circuit> make_circuit(CircuitKind k, bool emit) {
   switch (k) { case CircuitKind::Mint: return make_mint_circuit(emit); case CircuitKind::Send: return make_send_circuit(emit); case CircuitKind::Redeem: return make_redeem_circuit(emit); default: return make_deposit_circuit(emit, 8); } }
 
-// caller holds g_gpu_mutex
-ProverSlot &prover_for(CircuitKind k) {
+// returns a locked unit of the key's pool (loads the key on first use or when the file changed; loading is serialised by g_gpu_mutex)
+ProverUnit &acquire_prover(CircuitKind k, std::unique_lock<std::mutex> &held) {
   std::string path = key_path(k, true); FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("proving key not found: " + path);
-  ProverSlot &slot = g_provers[path];
-  if (!slot.prover || !(slot.stamp == st)) { ProvingKeyHost pk = load_proving_key(path); slot.prover.reset(new Prover(pk)); slot.stamp = st; slot.circuit = make_circuit(k, false);
-    if (slot.circuit->board.num_variables() != slot.prover->num_variables() || slot.circuit->num_inputs() != slot.prover->num_inputs()) { slot.prover.reset(); throw std::runtime_error("proving key does not belong to the " + std::string(circuit_name(k)) + " circuit"); } }
-  return slot;
+  ProverSlot *slot;
+  { std::lock_guard<std::mutex> lk(g_gpu_mutex); slot = &g_provers[path];
+    if (slot->units.empty() || !(slot->stamp == st)) {
+      for (auto &u : slot->units) { std::lock_guard<std::mutex> wait(u->busy); }                        // proofs still running on the old key finish first
+      slot->units.clear(); ProvingKeyHost pk = load_proving_key(path); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 2; if (n < 1) n = 1; if (n > 7) n = 7;
+      for (int i = 0; i < n; i++) { std::unique_ptr<ProverUnit> u(new ProverUnit); u->prover.reset(new Prover(pk)); u->circuit = make_circuit(k, false);
+        if (u->circuit->board.num_variables() != u->prover->num_variables() || u->circuit->num_inputs() != u->prover->num_inputs()) throw std::runtime_error("proving key does not belong to the " + std::string(circuit_name(k)) + " circuit: " + path);
+        slot->units.push_back(std::move(u)); }
+      slot->stamp = st; } }
+  for (auto &u : slot->units) { std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) { held = std::move(lk); return *u; } }
+  ProverUnit &u = *slot->units[slot->next.fetch_add(1) % slot->units.size()]; held = std::unique_lock<std::mutex>(u.busy); return u;
 }
 std::shared_ptr<VerifyingKeyHost> vk_for(CircuitKind k) {
   std::string path = key_path(k, false); FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("verification key not found: " + path);
@@ -67,8 +78,7 @@ bool parse_fixed_rs(Fe32 &r, Fe32 &s) {   // test hook: ZK_FIXED_RS="<r hex>:<s 
 template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
   try {
     if (!gpu_available()) { zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback"); fprintf(stderr, "libzkgpu: no HIP device visible, cannot generate %s proof\n", circuit_name(k)); return dup_string(proof_to_hex(default_proof())); }
-    std::lock_guard<std::mutex> lk(g_gpu_mutex);
-    ProverSlot &slot = prover_for(k); assign(*slot.circuit);
+    std::unique_lock<std::mutex> held; ProverUnit &slot = acquire_prover(k, held); assign(*slot.circuit);
     printf("Trying to generate %s proof...\n", circuit_name(k)); fflush(stdout);
     Fe32 r, s; bool fixed = parse_fixed_rs(r, s); Proof proof;
     slot.prover->set_witness(reinterpret_cast<const Fe32 *>(slot.circuit->board.val.data() + 1), true);   // the board holds Montgomery values: no conversion on either side

@@ -2,7 +2,7 @@
 #include "msm_impl.hpp"
 namespace zk {
 struct MsmG1::Impl : MsmImpl<Fq, G1AffineRaw> { using MsmImpl::MsmImpl; };
-MsmG1::MsmG1(const G1AffineRaw *p, size_t n, int c, bool fo) : impl(new Impl(p, n, c, fo)) {}
+MsmG1::MsmG1(const G1AffineRaw *p, size_t n, int c, bool fo, bool tables) : impl(new Impl(p, n, c, fo, tables)) {}
 MsmG1::~MsmG1() = default;
 void MsmG1::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
 void MsmG1::set_label(const char *l) { impl->label = l; }

@@ -29,8 +29,8 @@ struct MsmImpl {
   static bool use_precompute(size_t n_, int W_) { static const bool on = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE"); return !e || atoi(e) != 0; }();
     static const size_t cap = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE_MAX_MB"); return (size_t)(e ? atol(e) : 768) << 20; }();
     return on && n_ > 0 && W_ > 1 && n_ * (size_t)W_ < (1ull << 31) && n_ * (size_t)W_ * sizeof(RawAffine) <= cap; }
-  MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo)
-      : n(n_), c(c_), W(msm_num_windows(c_)), WB(use_precompute(n_, msm_num_windows(c_)) ? 1 : msm_num_windows(c_)), NB(1u << (c_ - 1)), filter_ones(fo), points((n_ ? n_ : 1) * (size_t)(WB == 1 ? W : 1)), inf(n_ ? n_ : 1),
+  MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true)
+      : n(n_), c(c_), W(msm_num_windows(c_)), WB(tables && use_precompute(n_, msm_num_windows(c_)) ? 1 : msm_num_windows(c_)), NB(1u << (c_ - 1)), filter_ones(fo), points((n_ ? n_ : 1) * (size_t)(WB == 1 ? W : 1)), inf(n_ ? n_ : 1),
         zeroed(2 * (size_t)WB * NB + sizeof(MsmCounters) / 4), offsets((size_t)WB * NB), entries((n_ ? n_ : 1) * (size_t)W), ones(n_ ? n_ : 1), ntasks((size_t)WB * NB + 1), task_off((size_t)WB * NB + 1), cls_start(BSORT_CLASSES),
         scanner((size_t)WB * NB), task_scanner((size_t)WB * NB + 1) {
     if (c < 6 || c > 20 || W > MSM_MAX_WINDOWS) throw GpuError("msm: unsupported window size");

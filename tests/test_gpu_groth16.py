@@ -167,3 +167,27 @@ def test_deposit_depth32_single_gpu(tmp_path):
     proof = p.prove(z, 5, 7); assert p.prove(z, 5, 7) == proof; print("timings", p.timings()); p.close()
     assert e.verify(vk_path, proof, inputs) and not e.verify(vk_path, proof, inputs[::-1])
     assert e.verify_batch(vk_path, [proof, proof], [inputs, inputs[::-1]]) == [True, False]
+
+def test_concurrent_cgo_calls_overlap_and_stay_correct(all_keys, monkeypatch):
+    """cgo calls arrive on arbitrary OS threads (threading): 8 threads call genSendproof / genMintproof / genRedeemproof at the same time (pool of
+    provers per key, each on its own stream set); every proof must verify against its own public inputs and none against its neighbour's"""
+    import threading
+    monkeypatch.setenv("ZK_PRFKEY_DIR", str(all_keys)); zk = e.Zk(); out = {}; errs = []
+    def send_job(i):
+        try:
+            for j in range(3): s = w.send_instance(100 + 10 * i + j); out[("send", i, j)] = (s, zk.GenSendProof(*w.send_args(s)))
+        except Exception as ex: errs.append(ex)
+    def mint_job(i, redeem):
+        try:
+            for j in range(3): m = w.mint_instance(200 + 10 * i + j, redeem=redeem); out[("redeem" if redeem else "mint", i, j)] = (m, (zk.GenRedeemProof if redeem else zk.GenMintProof)(*w.mint_args(m)))
+        except Exception as ex: errs.append(ex)
+    ths = [threading.Thread(target=send_job, args=(i,)) for i in range(4)] + [threading.Thread(target=mint_job, args=(i, i % 2 == 1)) for i in range(4)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not errs and len(out) == 24
+    for (kind, i, j), (d, p) in out.items():
+        assert len(p) == 512 and not p.startswith("0000000000"), (kind, i, j)
+        if kind == "send": assert zk.VerifySendProof(p, d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"])
+        elif kind == "mint": assert zk.VerifyMintProof(p, d["cmtA_old"], d["sn_old"], d["cmtA"], d["value_s"])
+        else: assert zk.VerifyRedeemProof(p, d["cmtA_old"], d["sn_old"], d["cmtA"], d["value_s"])
+    (d0, p0), (d1, p1) = out[("send", 0, 0)], out[("send", 1, 0)]; assert not zk.VerifySendProof(p0, d1["cmtA_old"], d1["sn_old"], d1["cmtS"], d1["cmtA"])

@@ -20,10 +20,10 @@ out = {"units": "bytes per launch; hbm_bytes = 2 * FETCH_SIZE[KB] * 1024 + WRITE
 for k in sorted(set(fetch) | set(write), key=lambda k: (short(k[0]), k[1])):
     f = fetch.get(k, (0.0, 0)); w = write.get(k, (0.0, 0))
     out["kernels"]["%s grid=%d" % (short(k[0]), k[1])] = {"launches": max(f[1], w[1]), "FETCH_SIZE_KB_raw": round(f[0], 2), "WRITE_SIZE_KB": round(w[0], 2), "hbm_bytes_per_launch": int(2 * f[0] * 1024 + w[0] * 1024)}
-# the dominant kernel: bucket accumulation of the H-query MSM = the k_msm_accumulate_tasks<Fq> launch with the largest grid
+# the dominant kernel: bucket accumulation of the H-query MSM = the k_msm_accumulate_tasks<Fq> launch that moves the most bytes (4.2 M point gathers; the witness MSMs have a few 10^4)
 acc = [(k, v) for k, v in out["kernels"].items() if k.startswith("k_msm_accumulate_tasks<Fq") and not k.startswith("k_msm_accumulate_tasks<Fq2")]
 if acc:
-    name, v = max(acc, key=lambda kv: int(kv[0].split("grid=")[1])); out["k_msm_accumulate_H"] = dict(v, kernel=name)
+    name, v = max(acc, key=lambda kv: kv[1]["hbm_bytes_per_launch"]); out["k_msm_accumulate_H"] = dict(v, kernel=name)
 pw = [(k, v) for k, v in out["kernels"].items() if k.startswith("k_qap_pointwise")]
 if pw:
     name, v = pw[0]; m = int(name.split("grid=")[1]); exp_r, exp_w = 3 * m * 32, m * 32
