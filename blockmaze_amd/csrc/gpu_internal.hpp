@@ -16,7 +16,7 @@ class GpuContext {
   GpuContext() {
     // five streams run concurrently (the critical chain + four witness MSMs); the runtime's default of 4 hardware queues makes two of them share one and
     // serialises them (measured: the B1 MSM finished at 2.7 ms instead of 1.4 ms).  Only effective if this is the first HIP call of the process.
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n = 0; if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
     const char *e = getenv("ZK_DEVICE"); if (!e) e = getenv("LOCAL_RANK"); device = e ? atoi(e) % n : 0;
     HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipGetDeviceProperties(&prop, device)); HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
