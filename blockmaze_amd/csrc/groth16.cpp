@@ -223,8 +223,10 @@ static RsTerms rs_terms(const Fe32 *r_in, const Fe32 *s_in, const HG1 &delta_g1,
   RsTerms t; t.r = r_in ? fr_of(*r_in) : random_fr().from_mont(); t.s = s_in ? fr_of(*s_in) : random_fr().from_mont(); HFr rs = (t.r.to_mont() * t.s.to_mont()).from_mont();   // canonical scalars
   t.r_delta = delta_g1.mul(t.r.l); t.s_delta = delta_g1.mul(t.s.l); t.rs_delta_neg = delta_g1.mul(rs.l).neg(); t.s_delta2 = delta_g2.mul(t.s.l); return t; }
 static void enqueue_all(Prover::Impl &p) {
-  gpu_fork_aux();
-  // about 170 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
+  // ZK_WITNESS_MSM_START: where the four witness MSMs (auxiliary streams) are released relative to the critical chain: 0 = at once, 1 = after the row kernels,
+  // 2 = after the three inverse transforms, 3 = after the coset transforms, 4 = after all transforms (they then overlap the H-query MSM only)
+  static const int aux_start = env_int("ZK_WITNESS_MSM_START", 2);   // measured (send): 0: 2.85 ms, 1: 2.65-2.77, 2: 2.69-2.72, 3: 2.83, 4: 3.01 — at the very start the five classify kernels fight the row and transform kernels of the critical chain for the CUs
+  // about 80 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
   // (auxiliary streams) while this one submits the critical chain
   static const int n_helpers = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); int v = e ? atoi(e) : 4; return v < 0 ? 0 : v > 4 ? 4 : v; }();
   std::function<void()> jobs[4] = { [&] { p.B2->run(p.z.get(), p.B_idx.get() + p.b0); }, [&] { p.L->run(p.z.get() + p.ni + 1 + p.l0, nullptr); },       // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
@@ -232,11 +234,17 @@ static void enqueue_all(Prover::Impl &p) {
   int nh = (gpu_capturing() || profiling_enabled()) ? 0 : n_helpers;   // (the stage timers are not thread-safe: profiling runs submit from one thread)
   std::exception_ptr aux_error[4]; std::thread helpers[4];
   struct Joiner { std::thread *t; ~Joiner() { for (int i = 0; i < 4; i++) if (t[i].joinable()) t[i].join(); } } joiner{helpers};
-  for (int h = 0; h < nh; h++) helpers[h] = std::thread([&, h] { LaneScope lane_scope(p.lane); try { for (int j = h; j < 4; j += nh) jobs[j](); } catch (...) { aux_error[h] = std::current_exception(); } });
-  if (!nh) for (auto &j : jobs) j();
+  auto release_aux = [&] { gpu_fork_aux();
+    for (int h = 0; h < nh; h++) helpers[h] = std::thread([&, h] { LaneScope lane_scope(p.lane); try { for (int j = h; j < 4; j += nh) jobs[j](); } catch (...) { aux_error[h] = std::current_exception(); } });
+    if (!nh) for (auto &j : jobs) j(); };
+  if (aux_start <= 0) release_aux();
   p.cs->eval(p.z.get(), p.abc.get(), p.m);
+  if (aux_start == 1) release_aux();
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
-  p.dom->ifft(p.abc.get(), 3, p.m); p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); p.dom->icoset_fft(p.abc.get(), 1, p.m);
+  p.dom->ifft(p.abc.get(), 3, p.m); if (aux_start == 2) release_aux();
+  p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); if (aux_start == 3) release_aux();
+  p.dom->icoset_fft(p.abc.get(), 1, p.m);
+  if (aux_start >= 4) release_aux();
   p.H->run(p.abc.get() + p.h0, nullptr);                                                                                  // :466-473
   for (int h = 0; h < nh; h++) { helpers[h].join(); if (aux_error[h]) std::rethrow_exception(aux_error[h]); }
 }

@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(256) k_r1cs_rows3(R1csMatrices M, const Fr *__
 }
 __global__ void __launch_bounds__(64) k_r1cs_long_rows3(const uint32_t *__restrict__ rows, R1csMatrices M, const Fr *__restrict__ ctab, const Fr *__restrict__ z, uint32_t m, Fr *__restrict__ abc, uint32_t seq, uint32_t *fail) {
   uint32_t r = rows[blockIdx.x], lane = threadIdx.x; Fr v[3];
+#pragma unroll
   for (int mm = 0; mm < 3; mm++) { Fr acc = Fr::zero(); const uint32_t *col = M.col[mm], *cid = M.cid[mm];
     for (uint32_t k = M.rowptr[mm][r] + lane, e = M.rowptr[mm][r + 1]; k < e; k += 64) { uint32_t ci = cid[k]; Fr x = z[col[k]]; if (ci == 0) acc = acc + x; else if (ci == 1) acc = acc - x; else acc = acc + ctab[ci] * x; }
     const uint32_t len = M.rowptr[mm][r + 1] - M.rowptr[mm][r];      // (wave-uniform) the long matrix of a packing constraint has 32..35 terms, the other two have one: no tree for those
