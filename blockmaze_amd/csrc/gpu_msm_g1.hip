@@ -2,12 +2,12 @@
 #include "msm_impl.hpp"
 namespace zk {
 struct MsmG1::Impl : MsmImpl<Fq, G1AffineRaw> { using MsmImpl::MsmImpl; };
-MsmG1::MsmG1(const G1AffineRaw *p, size_t n, int c, bool fo, bool tables) : impl(new Impl(p, n, c, fo, tables)) {}
+MsmG1::MsmG1(const G1AffineRaw *p, size_t n, int c, bool fo, bool tables, bool uniform) : impl(new Impl(p, n, c, fo, tables, uniform)) {}
 MsmG1::~MsmG1() = default;
 void MsmG1::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
 void MsmG1::set_label(const char *l) { impl->label = l; }
 void MsmG1::set_stream(int aux) { impl->stream_id = aux; }
-host::HG1 MsmG1::result() { HIP_CHECK(hipStreamSynchronize(impl->stream())); return combine<host::HFq, Fq>(impl->host_sums(), impl->WB, impl->c); }
+host::HG1 MsmG1::result() { impl->finish_sync(); return combine<host::HFq, Fq>(impl->host_sums(), impl->WB, impl->c); }
 size_t MsmG1::size() const { return impl->n; }
 const G1AffineRaw *MsmG1::points_dev() const { return impl->points.get(); }
 }  // namespace zk

@@ -4,8 +4,8 @@ namespace zk {
 struct MsmG2::Impl : MsmImpl<Fq2, G2AffineRaw> { using MsmImpl::MsmImpl; };
 void MsmG2::set_label(const char *l) { impl->label = l; }
 void MsmG2::set_stream(int aux) { impl->stream_id = aux; }
-MsmG2::MsmG2(const G2AffineRaw *p, size_t n, int c, bool fo, bool tables) : impl(new Impl(p, n, c, fo, tables)) {}
+MsmG2::MsmG2(const G2AffineRaw *p, size_t n, int c, bool fo, bool tables, bool uniform) : impl(new Impl(p, n, c, fo, tables, uniform)) {}
 MsmG2::~MsmG2() = default;
 void MsmG2::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
-host::HG2 MsmG2::result() { HIP_CHECK(hipStreamSynchronize(impl->stream())); return combine<host::HFq2, Fq2>(impl->host_sums(), impl->WB, impl->c); }
+host::HG2 MsmG2::result() { impl->finish_sync(); return combine<host::HFq2, Fq2>(impl->host_sums(), impl->WB, impl->c); }
 }  // namespace zk

@@ -68,6 +68,22 @@ __global__ void k_msm_scatter(const Fr *__restrict__ scalars, const uint32_t *__
     entries[offsets[key] + atomicAdd(&fill[key], 1u)] = (i + (uint32_t)w * point_stride) | (d < 0 ? 0x80000000u : 0u); }   // point_stride = n: the entry addresses 2^(cw) P_i in the precomputed table
 }
 
+// One-pass sort for scalars known to be uniform (the H query: coefficients of the quotient polynomial) with all windows sharing one bucket array: every bucket owns
+// `cap` slots (about twice its expected load), an entry goes to slot atomicAdd(count[b]) of its bucket — no histogram pass, no prefix scan.  A bucket that would
+// overflow sets counters->pad[0]; the host then repeats the MSM on the two-pass path (any input stays correct, only uniform ones are fast).
+template <int DUMMY = 0>
+__global__ void k_msm_scatter_direct(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf, uint32_t n, int c, int W, uint32_t point_stride,
+                                     uint32_t cap, uint32_t *__restrict__ counts, uint32_t *__restrict__ entries, MsmCounters *cnt) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+  if (point_is_inf && point_is_inf[i]) return;
+  Fr k = scalars[scalar_index ? scalar_index[i] : i].from_mont();
+  if (k.is_zero()) return;
+  int dig[MSM_MAX_WINDOWS]; signed_digits(k.l, c, W, dig); bool over = false;
+  for (int w = 0; w < W; w++) { int d = dig[w]; if (!d) continue; uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, slot = atomicAdd(&counts[key], 1u);
+    if (slot < cap) entries[(size_t)key * cap + slot] = (i + (uint32_t)w * point_stride) | (d < 0 ? 0x80000000u : 0u); else over = true; }
+  if (over) atomicOr(&cnt->pad[0], 1u);
+}
+
 // ---- exclusive scan over uint32 (three small kernels; the arrays are <= 2^21 entries) ------------------------------
 constexpr int SCAN_BLOCK = 1024, SCAN_ITEMS = 4;   // 4096 items per block
 static __global__ void k_scan_local(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums, uint32_t n) {
@@ -114,9 +130,9 @@ constexpr uint32_t MSM_TASK = 16;
 // bucket sizes the longest of 64 random buckets is about twice the mean, and every lane of the wave would wait for it.
 constexpr uint32_t BSORT_CLASSES = 64, BSORT_BLOCK = 256;
 __device__ __forceinline__ uint32_t bsort_class(uint32_t count) { return BSORT_CLASSES - 1 - min(count, BSORT_CLASSES - 1); }   // class 0 = the fullest buckets
-static __global__ void __launch_bounds__(BSORT_BLOCK) k_bsort_hist(const uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t n_blocks, uint32_t *__restrict__ block_hist) {
+static __global__ void __launch_bounds__(BSORT_BLOCK) k_bsort_hist(uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t n_blocks, uint32_t *__restrict__ block_hist, uint32_t clip) {
   __shared__ uint32_t h[BSORT_CLASSES]; if (threadIdx.x < BSORT_CLASSES) h[threadIdx.x] = 0; __syncthreads();
-  uint32_t b = blockIdx.x * BSORT_BLOCK + threadIdx.x; if (b < n_buckets) atomicAdd(&h[bsort_class(counts[b])], 1u); __syncthreads();
+  uint32_t b = blockIdx.x * BSORT_BLOCK + threadIdx.x; if (b < n_buckets) { uint32_t cv = counts[b]; if (clip && cv > clip) { cv = clip; counts[b] = cv; } atomicAdd(&h[bsort_class(cv)], 1u); } __syncthreads();   // clip: slot capacity of the one-pass sort (an overflow is flagged there)
   if (threadIdx.x < BSORT_CLASSES) block_hist[threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];          // class-major, so one exclusive scan yields every (class, block) base
 }
 static __global__ void __launch_bounds__(BSORT_BLOCK) k_bsort_scatter(const uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t n_blocks, const uint32_t *__restrict__ block_off,

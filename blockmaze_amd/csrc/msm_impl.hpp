@@ -10,6 +10,7 @@ struct MsmImpl {
   size_t n; int c, W, WB; uint32_t NB;   // W digit windows; WB bucket arrays (1 when the multiples 2^(cw) P are precomputed, else W)
    bool filter_ones; uint32_t seg, n_ones_quads; std::string label = "msm"; int stream_id = -1;   // -1: main stream, 0..3: auxiliary stream
   DevBuf<RawAffine> points; DevBuf<uint8_t> inf; bool any_inf = false;
+  bool direct = false, offsets_direct = false; uint32_t cap = 0; const Fe32 *last_scalars = nullptr; const uint32_t *last_index = nullptr;   // one-pass sort (k_msm_scatter_direct) for uniform scalars
   DevBuf<uint32_t> zeroed;                                          // [hist | fill | counters]: cleared by one memset per run
   DevBuf<uint32_t> offsets, entries, ones, ntasks, task_off, order, rank_of, block_hist, block_off, cls_start; uint32_t bsort_blocks; std::unique_ptr<Scanner> bsort_scanner; Scanner scanner, task_scanner; uint32_t max_tasks;
   DevBuf<uint8_t> buckets, partials, seg_out, seg_l2, ones_partial, ones_l2, result;   // XYZZ<F> arrays, kept as bytes to stay out of the header; result = W window sums, the ones sum, the counters
@@ -29,7 +30,7 @@ struct MsmImpl {
   static bool use_precompute(size_t n_, int W_) { static const bool on = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE"); return !e || atoi(e) != 0; }();
     static const size_t cap = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE_MAX_MB"); return (size_t)(e ? atol(e) : 768) << 20; }();
     return on && n_ > 0 && W_ > 1 && n_ * (size_t)W_ < (1ull << 31) && n_ * (size_t)W_ * sizeof(RawAffine) <= cap; }
-  MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true)
+  MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true, bool uniform_hint = false)
       : n(n_), c(c_), W(msm_num_windows(c_)), WB(tables && use_precompute(n_, msm_num_windows(c_)) ? 1 : msm_num_windows(c_)), NB(1u << (c_ - 1)), filter_ones(fo), points((n_ ? n_ : 1) * (size_t)(WB == 1 ? W : 1)), inf(n_ ? n_ : 1),
         zeroed(2 * (size_t)WB * NB + sizeof(MsmCounters) / 4), offsets((size_t)WB * NB), entries((n_ ? n_ : 1) * (size_t)W), ones(n_ ? n_ : 1), ntasks((size_t)WB * NB + 1), task_off((size_t)WB * NB + 1), cls_start(BSORT_CLASSES),
         scanner((size_t)WB * NB), task_scanner((size_t)WB * NB + 1) {
@@ -45,6 +46,9 @@ struct MsmImpl {
       HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream));
     }
     max_tasks = (uint32_t)((n * (size_t)W) / MSM_TASK + (size_t)WB * NB + 1);
+    if (uniform_hint && WB == 1 && !filter_ones && n && getenv("ZK_MSM_NO_DIRECT_SORT") == nullptr) {   // slots per bucket: twice the expected load (+64), a power of two
+      size_t lam = (n * (size_t)W) / NB, want = 2 * lam + 64; cap = 64; while (cap < want) cap <<= 1;
+      if ((size_t)NB * cap <= (1ull << 28)) { direct = true; entries = DevBuf<uint32_t>((size_t)NB * cap); } }
     { size_t nbk = (size_t)WB * NB; bsort_blocks = cdiv(nbk, BSORT_BLOCK); order = DevBuf<uint32_t>(nbk); rank_of = DevBuf<uint32_t>(nbk); block_hist = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); block_off = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); bsort_scanner.reset(new Scanner((size_t)bsort_blocks * BSORT_CLASSES)); }
     buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>((size_t)max_tasks * sizeof(XYZZ<F>));
     seg_out = DevBuf<uint8_t>((size_t)WB * (NB / seg) * sizeof(XYZZ<F>)); seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
@@ -54,18 +58,30 @@ struct MsmImpl {
   }
   ~MsmImpl() { if (h_result) hipHostFree(h_result); }
   hipStream_t stream() { return stream_id < 0 ? gpu().stream : gpu().aux[stream_id & 3]; }
+  // after the stream has been synchronised: did a bucket of the one-pass sort overflow?  Then repeat the last run on the two-pass path (synchronously).
+  void finish_sync() { HIP_CHECK(hipStreamSynchronize(stream()));
+    if (direct && host_counters()->pad[0]) { direct = false; offsets_direct = false; run(last_scalars, last_index); HIP_CHECK(hipStreamSynchronize(stream())); direct = true; } }
 
   void run(const Fe32 *scalars, const uint32_t *scalar_index) {
     hipStream_t s = stream(); size_t nbk = (size_t)WB * NB; const uint32_t hist_stride = WB == 1 ? 0 : NB, point_stride = WB == 1 && W > 1 ? (uint32_t)n : 0; const uint8_t *infp = any_inf ? inf.get() : nullptr; MsmCounters *cnt = counters();
     const uint32_t bucket_u4 = sizeof(XYZZ<F>) / 16; XYZZ<F> *res = (XYZZ<F> *)result.get();
     HIP_CHECK(hipMemsetAsync(zeroed.get(), 0, zeroed.size() * 4, s));
+    last_scalars = scalars; last_index = scalar_index;
+    if (direct) { Stage st((label + ".sort").c_str(), s);
+      if (!offsets_direct) { std::vector<uint32_t> o(nbk); for (size_t b = 0; b < nbk; b++) o[b] = (uint32_t)(b * cap); offsets.upload(o.data(), nbk); offsets_direct = true; }
+      hipLaunchKernelGGL(k_msm_scatter_direct<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, point_stride, cap, hist(), entries.get(), cnt);
+      hipLaunchKernelGGL(k_bsort_hist, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_hist.get(), cap);
+      bsort_scanner->run(block_hist.get(), block_off.get(), (size_t)bsort_blocks * BSORT_CLASSES, s);
+      hipLaunchKernelGGL(k_bsort_scatter, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_off.get(), order.get(), rank_of.get(), ntasks.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
+      task_scanner.run(ntasks.get(), task_off.get(), nbk + 1, s);
+    } else
     { Stage st((label + ".sort").c_str(), s);
       if (n) hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, hist(), ones.get(), cnt);
       if (nbk <= PLAN_SMALL_MAX) {
         hipLaunchKernelGGL(k_msm_plan_small, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, offsets.get(), order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
       } else {
         scanner.run(hist(), offsets.get(), nbk, s);
-        hipLaunchKernelGGL(k_bsort_hist, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_hist.get());
+        hipLaunchKernelGGL(k_bsort_hist, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_hist.get(), 0u);
         bsort_scanner->run(block_hist.get(), block_off.get(), (size_t)bsort_blocks * BSORT_CLASSES, s);
         hipLaunchKernelGGL(k_bsort_scatter, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_off.get(), order.get(), rank_of.get(), ntasks.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
         task_scanner.run(ntasks.get(), task_off.get(), nbk + 1, s);

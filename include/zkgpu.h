@@ -46,7 +46,8 @@ int zkgpu_test_fq2_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out, 
 int zkgpu_test_group_op(int group, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
 
 /* ---- multi-scalar multiplication ------------------------------------------------------------------------------------ */
-/* window_bits 0 = choose from n.  filter_ones != 0 = treat scalars 0 / 1 specially like multi_exp_with_mixed_addition. */
+/* window_bits 0 = choose from n.  filter_ones: bit 0 = treat scalars 0 / 1 specially like multi_exp_with_mixed_addition; bit 1 = the scalars are known to be
+   uniform (H query): one-pass sort with fixed slots per bucket, falling back to the two-pass sort if a bucket overflows (results are the same either way). */
 int zkgpu_msm_g1(const uint8_t *points, const uint8_t *scalars, size_t n, int window_bits, int filter_ones, uint8_t out[64]);
 int zkgpu_msm_g2(const uint8_t *points, const uint8_t *scalars, size_t n, int window_bits, int filter_ones, uint8_t out[128]);
 

@@ -72,6 +72,15 @@ def test_msm_g2_matches_oracle(n, c):
     assert o.g2_from(e.msm(2, P, K, c))[0] == o.msm_g2(P, K)
     assert o.g2_from(e.msm(2, P, Z, c, filter_ones=True))[0] == o.msm_g2(P, Z, mixed=True)
 
+def test_msm_one_pass_sort_and_its_overflow_fallback():
+    """uniform-scalar hint (the H query): slots of fixed capacity per bucket; a scalar vector that piles everything into a few buckets overflows them and must
+    come out right through the two-pass fallback, and the object must keep working afterwards"""
+    n = 6000; g = o.SplitMix64(77); P = o.g1_consecutive(g.field(), n); m = e.ResidentMsm(1, P, 10, filter_ones=2)
+    K = rand_field_arr(4242, n); m.set_scalars(K); assert o.g1_from(m.run())[0] == o.msm_g1(P, K)
+    same = o.to_arr([0x1234567 << 40 | 3] * n); m.set_scalars(same); assert o.g1_from(m.run())[0] == o.msm_g1(P, same)          # every digit equal: overflow
+    K2 = rand_field_arr(4243, n); m.set_scalars(K2); assert o.g1_from(m.run())[0] == o.msm_g1(P, K2)
+    m.close()
+
 def test_msm_degenerate_inputs():
     assert o.g1_from(e.msm(1, np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)))[0] is None         # empty
     P = o.g1_consecutive(5, 64); assert o.g1_from(e.msm(1, P, np.zeros((64, 4), np.uint64), filter_ones=True))[0] is None   # all-zero scalars
