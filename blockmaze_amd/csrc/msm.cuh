@@ -208,6 +208,21 @@ template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<
 // buckets that were cut into several tasks: add up the partial sums.  Buckets are ranked by decreasing size (order[], cls_start[]).  One quad per bucket adds up
 // to COMBINE_QUAD_MAX partials serially (with precomputed tables every bucket of the H query holds ~8 of them); buckets with more get a whole workgroup each
 // (the first `heavy_blocks` workgroups walk the ranks of the fullest size class and pick those).
+// Planning for the one-pass sort in ONE single-workgroup launch: with uniform scalars every bucket holds about the same number of entries, so the size ordering
+// is pointless (order = identity); counts are clipped to the slot capacity, task_off = exclusive scan of the task counts, empty buckets are set to infinity.
+// cls_start[] = n_buckets for every class: the combine kernel then looks at every bucket's task count itself.
+constexpr uint32_t PLAN_DIRECT_MAX = 65536;
+static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_direct(uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t clip, uint32_t *__restrict__ order, uint32_t *__restrict__ rank_of,
+                                                                   uint32_t *__restrict__ task_off, uint32_t *__restrict__ cls_start, uint4 *__restrict__ bucket_mem, uint32_t bucket_u4) {
+  __shared__ uint32_t sh[PLAN_THREADS]; const uint32_t per = (n_buckets + PLAN_THREADS - 1) / PLAN_THREADS, lo = threadIdx.x * per; uint32_t s = 0, total;
+  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) { uint32_t b = lo + j, cnt = counts[b]; if (cnt > clip) { cnt = clip; counts[b] = cnt; } order[b] = b; rank_of[b] = b; s += (cnt + MSM_TASK - 1) / MSM_TASK;
+    if (cnt == 0) for (uint32_t q = 0; q < bucket_u4; q++) bucket_mem[(size_t)b * bucket_u4 + q] = make_uint4(0, 0, 0, 0); }
+  uint32_t ex = block_exclusive_scan_1024(s, sh, &total);
+  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) { task_off[lo + j] = ex; ex += (min(counts[lo + j], clip) + MSM_TASK - 1) / MSM_TASK; }
+  if (threadIdx.x == 0) task_off[n_buckets] = total;
+  if (threadIdx.x < BSORT_CLASSES) cls_start[threadIdx.x] = n_buckets;
+}
+
 constexpr uint32_t COMBINE_QUAD_MAX = 24;
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, const uint32_t *__restrict__ cls_start, uint32_t heavy_blocks,
@@ -216,11 +231,11 @@ __global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__res
   const uint32_t n_big = cls_start[1], n_multi = cls_start[BSORT_CLASSES - 1 - MSM_TASK];   // ranks below: count >= 63 (the only class that can hold more than COMBINE_QUAD_MAX tasks), count > 16
   if (blockIdx.x < heavy_blocks) {
     for (uint32_t r = blockIdx.x; r < n_big; r += heavy_blocks) { uint32_t beg = task_off[r], nt = task_off[r + 1] - beg; if (nt <= COMBINE_QUAD_MAX) continue;
-      XYZZ<F> acc = block_quad_sum(partials + beg, nt, lds); if (threadIdx.x == 0) buckets[order[r]] = acc; __syncthreads(); }
+      XYZZ<F> acc = block_quad_sum(partials + beg, nt, lds); if (threadIdx.x == 0) buckets[order[r]] = acc; __syncthreads(); }   // (nt is the same for the whole workgroup)
     return;
   }
   uint32_t r = (blockIdx.x - heavy_blocks) * 64 + (threadIdx.x >> 2); int k = threadIdx.x & 3; if (r >= n_multi) return;
-  uint32_t beg = task_off[r], nt = task_off[r + 1] - beg; if (nt > COMBINE_QUAD_MAX) return; XYZZ<F> acc = partials[beg];
+  uint32_t beg = task_off[r], nt = task_off[r + 1] - beg; if (nt < 2 || nt > COMBINE_QUAD_MAX) return; XYZZ<F> acc = partials[beg];   // (one task: the accumulation wrote the bucket itself)
 #pragma unroll 1
   for (uint32_t j = 1; j < nt; j++) acc = quad_add(acc, partials[beg + j], k);
   if (k == 0) buckets[order[r]] = acc;
