@@ -103,7 +103,7 @@ static void radix2_transform(Fe32 *data, Fe32 *scratch, const Fe32 *tw, int logn
   hipStream_t s = gpu().stream; size_t n = (size_t)1 << logn;
   static const int rl = [] { const char *e = getenv("ZK_NTT_RADIX_LOG"); int x = e ? atoi(e) : 3; return x < 1 ? 1 : x > 3 ? 3 : x; }();   // radix-8 passes measured best with three vectors per launch
   auto threads_for = [](int logN, int logC) { int g = logN + logC - rl; unsigned t = 1u << (g < 6 ? 6 : g > 8 ? 8 : g); return t; };   // one butterfly group per thread and pass, 64..256 threads
-  auto lds_for = [](int logN, int logC) { return (sizeof(Fr) << (logN + logC)) + (sizeof(Fr) << logN) / 2; };                            // tile + twiddle table
+  auto lds_for = [](int logN, int logC) { size_t e = (size_t)1 << (logN + logC); return sizeof(Fr) * (e + (e >> 4) + 1) + (sizeof(Fr) << logN) / 2; };   // padded tile (ntt_pad) + twiddle table
   if (logn <= NTT_TILE_LOG) {          // n2 = 1: the column pass alone is the whole transform
     if (post_scale) throw GpuError("ntt: post scale on a single-pass transform");
     hipLaunchKernelGGL(k_ntt_cols, dim3(1, batch), dim3(threads_for(logn, 0)), lds_for(logn, 0), s, (const Fr *)data, (Fr *)data, (const Fr *)pre_scale, (const Fr *)tw, logn, logn, 0, rl, stride, stride);

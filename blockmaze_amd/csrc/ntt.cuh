@@ -67,12 +67,15 @@ __device__ __forceinline__ Fr ntt_twiddle(const Fr *__restrict__ tw, uint32_t e,
 
 // R decimation-in-frequency stages (s, s-1, ..., s-R+1) of the N-point transforms over the rows of tile[N][C] (element i of column c at tile[i*C + c]) with the
 // 2^R values of a butterfly group held in registers: one LDS round trip and one barrier per R stages.  twl[j] = w_N^j (j < N/2) is an LDS copy of the twiddles.
+// LDS layout of a tile: element e sits at e + (e >> 4) (one 32-byte pad per 16 elements).  Without it the last radix-8 pass (each lane owns 8 consecutive elements, so
+// lanes are 16 elements = 512 bytes apart) and the bit-reversed read-out put all 64 lanes of an access on the same 8 banks.
+__device__ __forceinline__ uint32_t ntt_pad(uint32_t e) { return e + (e >> 4); }
 template <int R> __device__ __forceinline__ void ntt_lds_pass(Fr *tile, const Fr *twl, int logN, int logC, int s) {
   const uint32_t groups = (1u << (logN - R)) << logC, cmask = (1u << logC) - 1; const int sh = s - R;
   for (uint32_t w = threadIdx.x; w < groups; w += blockDim.x) {
     const uint32_t g = w >> logC, c = w & cmask, base = ((g >> sh) << s) | (g & ((1u << sh) - 1)); Fr x[1 << R];
 #pragma unroll
-    for (int q = 0; q < (1 << R); q++) x[q] = tile[((base + ((uint32_t)q << sh)) << logC) + c];
+    for (int q = 0; q < (1 << R); q++) x[q] = tile[ntt_pad(((base + ((uint32_t)q << sh)) << logC) + c)];
 #pragma unroll
     for (int t = 0; t < R; t++) { const int st = s - t, hx = 1 << (R - 1 - t);
 #pragma unroll
@@ -80,7 +83,7 @@ template <int R> __device__ __forceinline__ void ntt_lds_pass(Fr *tile, const Fr
         uint32_t j = (base + ((uint32_t)q << sh)) & ((1u << (st - 1)) - 1); Fr u = x[q], v = x[q + hx]; x[q] = u + v; Fr d = u - v; if (j) d = d * twl[j << (logN - st)]; x[q + hx] = d; }
     }
 #pragma unroll
-    for (int q = 0; q < (1 << R); q++) tile[((base + ((uint32_t)q << sh)) << logC) + c] = x[q];
+    for (int q = 0; q < (1 << R); q++) tile[ntt_pad(((base + ((uint32_t)q << sh)) << logC) + c)] = x[q];
   }
   __syncthreads();
 }
@@ -98,11 +101,11 @@ __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(const Fr *__restr
   extern __shared__ uint32_t lds_raw[]; Fr *tile = reinterpret_cast<Fr *>(lds_raw);
   const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, c0 = blockIdx.x << logC, elems = (1u << log_n1) << logC, half_n = 1u << (logn - 1);
   const Fr *s = src + blockIdx.y * stride_in; Fr *d = dst + blockIdx.y * stride_out;
-  for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t g = ((w >> logC) << log_n2) + c0 + (w & (C - 1)); Fr v = s[g]; if (pre) v = v * pre[g]; tile[w] = v; }
+  for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t g = ((w >> logC) << log_n2) + c0 + (w & (C - 1)); Fr v = s[g]; if (pre) v = v * pre[g]; tile[ntt_pad(w)] = v; }
   __syncthreads();
-  ntt_lds_dif(tile, tile + elems, log_n1, logC, tw, n2, radix_log);
+  ntt_lds_dif(tile, tile + ntt_pad(elems), log_n1, logC, tw, n2, radix_log);
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
-    uint32_t k1 = w >> logC, c = w & (C - 1), i2 = c0 + c, p = log_n1 ? bitrev32(k1, log_n1) : 0; Fr v = tile[(p << logC) + c];
+    uint32_t k1 = w >> logC, c = w & (C - 1), i2 = c0 + c, p = log_n1 ? bitrev32(k1, log_n1) : 0; Fr v = tile[ntt_pad((p << logC) + c)];
     uint32_t e = i2 * k1; if (e) v = v * ntt_twiddle(tw, e, half_n);
     d[(k1 << log_n2) + i2] = v;
   }
@@ -112,11 +115,11 @@ __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_rows(const Fr *__restr
   extern __shared__ uint32_t lds_raw[]; Fr *tile = reinterpret_cast<Fr *>(lds_raw);
   const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, r0 = blockIdx.x << logC, elems = n2 << logC;
   const Fr *s = src + blockIdx.y * stride_in; Fr *d = dst + blockIdx.y * stride_out;
-  for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t c = w >> log_n2, i2 = w & (n2 - 1); tile[(i2 << logC) + c] = s[((size_t)(r0 + c) << log_n2) + i2]; }
+  for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t c = w >> log_n2, i2 = w & (n2 - 1); tile[ntt_pad((i2 << logC) + c)] = s[((size_t)(r0 + c) << log_n2) + i2]; }
   __syncthreads();
-  ntt_lds_dif(tile, tile + elems, log_n2, logC, tw, 1u << log_n1, radix_log);
+  ntt_lds_dif(tile, tile + ntt_pad(elems), log_n2, logC, tw, 1u << log_n1, radix_log);
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
-    uint32_t k2 = w >> logC, c = w & (C - 1), p = bitrev32(k2, log_n2), o = (k2 << log_n1) + r0 + c; Fr v = tile[(p << logC) + c];
+    uint32_t k2 = w >> logC, c = w & (C - 1), p = bitrev32(k2, log_n2), o = (k2 << log_n1) + r0 + c; Fr v = tile[ntt_pad((p << logC) + c)];
     if (post) v = v * post[o];
     d[o] = v;
   }
