@@ -60,7 +60,7 @@ __global__ void k_ntt_stage(Fr *__restrict__ data, const Fr *__restrict__ tw, in
 //   decimation-in-frequency stages in LDS, multiplies by the step twiddles and stores Y[k1*n2 + i2] to the same positions (safe in place).
 // k_ntt_rows: the outer sums — C adjacent rows k1 (contiguous loads), log2(n2) stages in LDS, stores X[k1 + n1*k2] in runs of C.
 // tw[j] = w_n^j for j < n/2.  Optional tables: `pre` multiplies the input (natural index), `post` the output (natural index).
-constexpr int NTT_TILE_LOG = 10;             // at most 1024 elements per workgroup: 32 KiB of LDS for the tile + 16 KiB for its twiddles
+constexpr int NTT_TILE_LOG = 11;             // at most 2048 elements per workgroup: 68 KiB of LDS for the padded tile + up to 32 KiB for its twiddles (the launch raises the dynamic LDS limit)
 constexpr int NTT_TILE_THREADS = 256;
 
 __device__ __forceinline__ Fr ntt_twiddle(const Fr *__restrict__ tw, uint32_t e, uint32_t half_n) { return e < half_n ? tw[e] : tw[e - half_n].neg(); }   // w^(n/2) = -1
