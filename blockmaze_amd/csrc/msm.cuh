@@ -211,14 +211,18 @@ template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<
 // Planning for the one-pass sort in ONE single-workgroup launch: with uniform scalars every bucket holds about the same number of entries, so the size ordering
 // is pointless (order = identity); counts are clipped to the slot capacity, task_off = exclusive scan of the task counts, empty buckets are set to infinity.
 // cls_start[] = n_buckets for every class: the combine kernel then looks at every bucket's task count itself.
-constexpr uint32_t PLAN_DIRECT_MAX = 65536;
+constexpr uint32_t PLAN_DIRECT_MAX = 32768;    // task counts of all buckets are staged in LDS as bytes (clip <= 4080 entries, i.e. at most 255 tasks per bucket)
 static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_direct(uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t clip, uint32_t *__restrict__ order, uint32_t *__restrict__ rank_of,
                                                                    uint32_t *__restrict__ task_off, uint32_t *__restrict__ cls_start, uint4 *__restrict__ bucket_mem, uint32_t bucket_u4) {
-  __shared__ uint32_t sh[PLAN_THREADS]; const uint32_t per = (n_buckets + PLAN_THREADS - 1) / PLAN_THREADS, lo = threadIdx.x * per; uint32_t s = 0, total;
-  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) { uint32_t b = lo + j, cnt = counts[b]; if (cnt > clip) { cnt = clip; counts[b] = cnt; } order[b] = b; rank_of[b] = b; s += (cnt + MSM_TASK - 1) / MSM_TASK;
+  __shared__ uint32_t sh[PLAN_THREADS]; __shared__ uint8_t nt_lds[PLAN_DIRECT_MAX];
+  for (uint32_t b = threadIdx.x; b < n_buckets; b += PLAN_THREADS) {                                       // coalesced pass over the buckets
+    uint32_t cnt = counts[b]; if (cnt > clip) { cnt = clip; counts[b] = cnt; } order[b] = b; rank_of[b] = b; nt_lds[b] = (uint8_t)((cnt + MSM_TASK - 1) / MSM_TASK);
     if (cnt == 0) for (uint32_t q = 0; q < bucket_u4; q++) bucket_mem[(size_t)b * bucket_u4 + q] = make_uint4(0, 0, 0, 0); }
+  __syncthreads();
+  const uint32_t per = (n_buckets + PLAN_THREADS - 1) / PLAN_THREADS, lo = threadIdx.x * per; uint32_t s = 0, total;
+  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) s += nt_lds[lo + j];
   uint32_t ex = block_exclusive_scan_1024(s, sh, &total);
-  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) { task_off[lo + j] = ex; ex += (min(counts[lo + j], clip) + MSM_TASK - 1) / MSM_TASK; }
+  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) { task_off[lo + j] = ex; ex += nt_lds[lo + j]; }
   if (threadIdx.x == 0) task_off[n_buckets] = total;
   if (threadIdx.x < BSORT_CLASSES) cls_start[threadIdx.x] = n_buckets;
 }

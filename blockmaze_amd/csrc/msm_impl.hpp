@@ -70,7 +70,7 @@ struct MsmImpl {
     if (direct) { Stage st((label + ".sort").c_str(), s);
       if (!offsets_direct) { std::vector<uint32_t> o(nbk); for (size_t b = 0; b < nbk; b++) o[b] = (uint32_t)(b * cap); offsets.upload(o.data(), nbk); offsets_direct = true; }
       hipLaunchKernelGGL(k_msm_scatter_direct<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, point_stride, cap, hist(), entries.get(), cnt);
-      if (nbk <= PLAN_DIRECT_MAX) hipLaunchKernelGGL(k_msm_plan_direct, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, cap, order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
+      if (nbk <= PLAN_DIRECT_MAX && cap <= 4080) hipLaunchKernelGGL(k_msm_plan_direct, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, cap, order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
       else {
         hipLaunchKernelGGL(k_bsort_hist, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_hist.get(), cap);
         bsort_scanner->run(block_hist.get(), block_off.get(), (size_t)bsort_blocks * BSORT_CLASSES, s);
