@@ -225,7 +225,7 @@ static RsTerms rs_terms(const Fe32 *r_in, const Fe32 *s_in, const HG1 &delta_g1,
 static void enqueue_all(Prover::Impl &p) {
   // ZK_WITNESS_MSM_START: where the four witness MSMs (auxiliary streams) are released relative to the critical chain: 0 = at once, 1 = after the row kernels,
   // 2 = after the three inverse transforms, 3 = after the coset transforms, 4 = after all transforms (they then overlap the H-query MSM only)
-  static const int aux_start = env_int("ZK_WITNESS_MSM_START", 2);   // measured (send): 0: 2.85 ms, 1: 2.65-2.77, 2: 2.69-2.72, 3: 2.83, 4: 3.01 — at the very start the five classify kernels fight the row and transform kernels of the critical chain for the CUs
+  static const int aux_start = env_int("ZK_WITNESS_MSM_START", 1);   // measured (send, earlier build): 0: 2.85 ms, 1: 2.65-2.77, 2: 2.69-2.72, 3: 2.83, 4: 3.01; current build 1: 2.38-2.44, 2: 2.47-2.50, 3: 2.62-2.66 — at the very start the five classify kernels fight the row and transform kernels of the critical chain for the CUs
   // about 80 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
   // (auxiliary streams) while this one submits the critical chain
   static const int n_helpers = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); int v = e ? atoi(e) : 4; return v < 0 ? 0 : v > 4 ? 4 : v; }();
