@@ -96,7 +96,8 @@ struct MsmImpl {
                          (XYZZ<F> *)buckets.get(), (XYZZ<F> *)partials.get());
     }
     { Stage st((label + ".combine").c_str(), s);
-      hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(HEAVY_BLOCKS + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), HEAVY_BLOCKS, (const XYZZ<F> *)partials.get(), (XYZZ<F> *)buckets.get());
+      const uint32_t heavy = direct && cap <= COMBINE_QUAD_MAX * MSM_TASK ? 0u : HEAVY_BLOCKS;   // one-pass sort: no bucket can hold more than `cap` entries, so none needs a whole workgroup
+      hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(heavy + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), heavy, (const XYZZ<F> *)partials.get(), (XYZZ<F> *)buckets.get());
     }
     { Stage st_red((label + ".reduce").c_str(), s);
       uint32_t spw = NB / seg, nseg = (uint32_t)WB * spw; const uint4 *csrc = (const uint4 *)cnt; uint4 *cdst = (uint4 *)(res + WB + 1);
