@@ -35,7 +35,9 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank); dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")             # "gloo": lets the N > 1 code path run on a box with fewer GPUs than ranks (ranks share devices)
+        if backend == "nccl": torch.cuda.set_device(local_rank); dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else: torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count())); dist.init_process_group(backend)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     from blockmaze_amd import engine as e
@@ -57,10 +59,11 @@ def main():
         if torch.cuda.is_available(): torch.cuda.synchronize()
 
     from blockmaze_amd import sharding
+    coll_dev = None if dist is None else ("cuda" if os.environ.get("ZK_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
     prover.set_witness(zs[0])                                                  # the assignment is resident in HBM before the timed region starts
     if shard:
         def one_proof(i):                                                      # every rank runs the device pipeline on its slice; 384 B per rank are exchanged; rank 0 assembles
-            recs = sharding.gather_partials(prover.prove_partial(), dist, "cuda")
+            recs = sharding.gather_partials(prover.prove_partial(), dist, coll_dev)
             return prover.finish(recs, 0x1234567 + i, 0x7654321 + i) if rank == 0 else None
     else:
         def one_proof(i): return prover.prove_resident()                        # synchronous: fresh (r, s), returns the serialized proof
@@ -69,7 +72,7 @@ def main():
     last = None
     for i in range(args.steps): last = one_proof(i)
     barrier(); dt = time.perf_counter() - t0
-    rate, dt = sharding.aggregate_throughput((args.steps if rank == 0 else 0) if shard else args.steps, dt, dist, "cuda" if dist is not None else None)      # max over ranks, units summed
+    rate, dt = sharding.aggregate_throughput((args.steps if rank == 0 else 0) if shard else args.steps, dt, dist, coll_dev)      # max over ranks, units summed
     d = insts[0]
     assert last is None or e.verify(vk_path, last, w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]])), "proof from the timed region does not verify"
 
