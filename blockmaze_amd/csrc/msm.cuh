@@ -176,18 +176,18 @@ static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_small(const ui
 // task_off: exclusive scan of ntasks over the SORTED bucket list (n_buckets + 1 entries, the last one = total)
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
-                                                              const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, uint32_t n_buckets, uint32_t max_tasks, XYZZ<F> *__restrict__ buckets, XYZZ<F> *__restrict__ partials) {
+                                                              const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, uint32_t n_buckets, uint32_t max_tasks, uint32_t task, XYZZ<F> *__restrict__ buckets, XYZZ<F> *__restrict__ partials) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= max_tasks || t >= task_off[n_buckets]) return;
   uint32_t lo = 0, hi = n_buckets;                         // largest i with task_off[i] <= t
   while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (task_off[mid] <= t) lo = mid; else hi = mid; }
-  uint32_t b = order[lo], j = t - task_off[lo], cnt = counts[b], beg = offsets[b] + j * MSM_TASK, end = offsets[b] + min(cnt, (j + 1) * MSM_TASK);
+  uint32_t b = order[lo], j = t - task_off[lo], cnt = counts[b], beg = offsets[b] + j * task, end = offsets[b] + min(cnt, (j + 1) * task);
   XYZZ<F> acc = XYZZ<F>::inf();
   uint32_t v = entries[beg]; Affine<F> p = points[v & 0x7fffffffu];                         // (beg < end: tasks exist only for non-empty slices)
 #pragma unroll 1
   for (uint32_t e = beg; e < end; e++) {                                                       // the next point is in flight while this one is added: the table gathers are random HBM reads
     uint32_t vn = e + 1 < end ? entries[e + 1] : v; Affine<F> pn = points[vn & 0x7fffffffu];
     if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; }
-  if (cnt <= MSM_TASK) buckets[b] = acc; else partials[t] = acc;
+  if (cnt <= task) buckets[b] = acc; else partials[t] = acc;
 }
 // ---- sums by the 64 quads of a 256-thread workgroup ------------------------------------------------------------------------
 // quad q adds elements q, q+64, ...; then a tree over the 16 quads of each wave (shuffles) and over the 4 waves (LDS).  The result is valid in lanes 0..3.
@@ -212,11 +212,11 @@ template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<
 // is pointless (order = identity); counts are clipped to the slot capacity, task_off = exclusive scan of the task counts, empty buckets are set to infinity.
 // cls_start[] = n_buckets for every class: the combine kernel then looks at every bucket's task count itself.
 constexpr uint32_t PLAN_DIRECT_MAX = 32768;    // task counts of all buckets are staged in LDS as bytes (clip <= 4080 entries, i.e. at most 255 tasks per bucket)
-static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_direct(uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t clip, uint32_t *__restrict__ order, uint32_t *__restrict__ rank_of,
+static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_direct(uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t clip, uint32_t task, uint32_t *__restrict__ order, uint32_t *__restrict__ rank_of,
                                                                    uint32_t *__restrict__ task_off, uint32_t *__restrict__ cls_start, uint4 *__restrict__ bucket_mem, uint32_t bucket_u4) {
   __shared__ uint32_t sh[PLAN_THREADS]; __shared__ uint8_t nt_lds[PLAN_DIRECT_MAX];
   for (uint32_t b = threadIdx.x; b < n_buckets; b += PLAN_THREADS) {                                       // coalesced pass over the buckets
-    uint32_t cnt = counts[b]; if (cnt > clip) { cnt = clip; counts[b] = cnt; } order[b] = b; rank_of[b] = b; nt_lds[b] = (uint8_t)((cnt + MSM_TASK - 1) / MSM_TASK);
+    uint32_t cnt = counts[b]; if (cnt > clip) { cnt = clip; counts[b] = cnt; } order[b] = b; rank_of[b] = b; nt_lds[b] = (uint8_t)((cnt + task - 1) / task);
     if (cnt == 0) for (uint32_t q = 0; q < bucket_u4; q++) bucket_mem[(size_t)b * bucket_u4 + q] = make_uint4(0, 0, 0, 0); }
   __syncthreads();
   const uint32_t per = (n_buckets + PLAN_THREADS - 1) / PLAN_THREADS, lo = threadIdx.x * per; uint32_t s = 0, total;

@@ -10,7 +10,8 @@ struct MsmImpl {
   size_t n; int c, W, WB; uint32_t NB;   // W digit windows; WB bucket arrays (1 when the multiples 2^(cw) P are precomputed, else W)
    bool filter_ones; uint32_t seg, n_ones_quads; std::string label = "msm"; int stream_id = -1;   // -1: main stream, 0..3: auxiliary stream
   DevBuf<RawAffine> points; DevBuf<uint8_t> inf; bool any_inf = false;
-  bool direct = false, offsets_direct = false; uint32_t cap = 0; const Fe32 *last_scalars = nullptr; const uint32_t *last_index = nullptr;   // one-pass sort (k_msm_scatter_direct) for uniform scalars
+  bool direct = false, offsets_direct = false; uint32_t cap = 0, task = MSM_TASK;   // task: sorted entries per accumulation lane
+  const Fe32 *last_scalars = nullptr; const uint32_t *last_index = nullptr;   // one-pass sort (k_msm_scatter_direct) for uniform scalars
   DevBuf<uint32_t> zeroed;                                          // [hist | fill | counters]: cleared by one memset per run
   DevBuf<uint32_t> offsets, entries, ones, ntasks, task_off, order, rank_of, block_hist, block_off, cls_start; uint32_t bsort_blocks; std::unique_ptr<Scanner> bsort_scanner; Scanner scanner, task_scanner; uint32_t max_tasks;
   DevBuf<uint8_t> buckets, partials, seg_out, seg_l2, ones_partial, ones_l2, result;   // XYZZ<F> arrays, kept as bytes to stay out of the header; result = W window sums, the ones sum, the counters
@@ -48,7 +49,8 @@ struct MsmImpl {
     max_tasks = (uint32_t)((n * (size_t)W) / MSM_TASK + (size_t)WB * NB + 1);
     if (uniform_hint && WB == 1 && !filter_ones && n && getenv("ZK_MSM_NO_DIRECT_SORT") == nullptr) {   // slots per bucket: twice the expected load (+64), a power of two
       size_t lam = (n * (size_t)W) / NB, want = 2 * lam + 64; cap = 64; while (cap < want) cap <<= 1;
-      if ((size_t)NB * cap <= (1ull << 28)) { direct = true; entries = DevBuf<uint32_t>((size_t)NB * cap); } }
+      if ((size_t)NB * cap <= (1ull << 28)) { direct = true; entries = DevBuf<uint32_t>((size_t)NB * cap);
+        const char *e = getenv("ZK_MSM_DIRECT_TASK"); int tv = e ? atoi(e) : 16; if (lam >= 64 && (tv == 16 || tv == 32 || tv == 64)) task = (uint32_t)tv; } }   // (measured: 32 halves the combine but costs as much in the accumulation, which then has too few lanes)
     { size_t nbk = (size_t)WB * NB; bsort_blocks = cdiv(nbk, BSORT_BLOCK); order = DevBuf<uint32_t>(nbk); rank_of = DevBuf<uint32_t>(nbk); block_hist = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); block_off = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); bsort_scanner.reset(new Scanner((size_t)bsort_blocks * BSORT_CLASSES)); }
     buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>((size_t)max_tasks * sizeof(XYZZ<F>));
     seg_out = DevBuf<uint8_t>((size_t)WB * (NB / seg) * sizeof(XYZZ<F>)); seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
@@ -70,7 +72,7 @@ struct MsmImpl {
     if (direct) { Stage st((label + ".sort").c_str(), s);
       if (!offsets_direct) { std::vector<uint32_t> o(nbk); for (size_t b = 0; b < nbk; b++) o[b] = (uint32_t)(b * cap); offsets.upload(o.data(), nbk); offsets_direct = true; }
       hipLaunchKernelGGL(k_msm_scatter_direct<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, point_stride, cap, hist(), entries.get(), cnt);
-      if (nbk <= PLAN_DIRECT_MAX && cap <= 4080) hipLaunchKernelGGL(k_msm_plan_direct, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, cap, order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
+      if (nbk <= PLAN_DIRECT_MAX && cap <= 4080) hipLaunchKernelGGL(k_msm_plan_direct, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, cap, task, order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
       else {
         hipLaunchKernelGGL(k_bsort_hist, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_hist.get(), cap);
         bsort_scanner->run(block_hist.get(), block_off.get(), (size_t)bsort_blocks * BSORT_CLASSES, s);
@@ -92,11 +94,11 @@ struct MsmImpl {
       if (n) hipLaunchKernelGGL(k_msm_scatter<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, point_stride, offsets.get(), fill(), entries.get());
     }
     { Stage st((label + ".accumulate").c_str(), s);
-      hipLaunchKernelGGL((k_msm_accumulate_tasks<F>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), order.get(), task_off.get(), (uint32_t)nbk, max_tasks,
+      hipLaunchKernelGGL((k_msm_accumulate_tasks<F>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), order.get(), task_off.get(), (uint32_t)nbk, max_tasks, direct ? task : MSM_TASK,
                          (XYZZ<F> *)buckets.get(), (XYZZ<F> *)partials.get());
     }
     { Stage st((label + ".combine").c_str(), s);
-      const uint32_t heavy = direct && cap <= COMBINE_QUAD_MAX * MSM_TASK ? 0u : HEAVY_BLOCKS;   // one-pass sort: no bucket can hold more than `cap` entries, so none needs a whole workgroup
+      const uint32_t heavy = direct && cap <= COMBINE_QUAD_MAX * task ? 0u : HEAVY_BLOCKS;   // one-pass sort: no bucket can hold more than `cap` entries, so none needs a whole workgroup
       hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(heavy + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), heavy, (const XYZZ<F> *)partials.get(), (XYZZ<F> *)buckets.get());
     }
     { Stage st_red((label + ".reduce").c_str(), s);
