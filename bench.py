@@ -127,6 +127,11 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_msm_accumulate<Fq> (H query)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic, "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": H_PAIRS * BYTES_PER_G1_PAIR}
 
+    # what actually bounds that kernel: 254-bit field products on the integer VALU.  One mixed addition = 10 products; the H accumulation does one per
+    # non-zero signed 16-bit digit (262,143 scalars x 16 windows, a digit is zero with probability 2^-16); ceiling = tools/fmul_bench.hip on the same chip
+    madds = H_PAIRS * 16 * (1.0 - 2.0 ** -16); gprod = madds * 10 / (dom_ms * 1e-3) / 1e9
+    roofline_valu = {"bound": "valu-int (not part of the contract: the number that tracks this kernel's quality)", "kernel": roofline["kernel"], "achieved": round(gprod, 2), "peak": 126.0, "unit": "G field products/s", "frac": round(gprod / 126.0, 4)}
+
     # ---- CPU baseline leg (rank 0, N = 1 only): the reference prover on one send proof ------------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -152,7 +157,7 @@ def main():
             "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
                        "includes": "R1CS rows + 7 NTT + 5 MSM + host proof assembly + hex serialisation, assignment resident in HBM; excludes witness generation and key load"},
             "proofs_in_flight": inflight, "ms_per_proof_host_buffer_in": ms_pcie and round(ms_pcie, 4), "ms_per_proof_through_genSendproof": ms_abi and round(ms_abi, 4), "proofs_per_s_through_genSendproof_concurrent_callers": abi_conc,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
             "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2)}}))
     prover.close()
     if dist is not None: dist.destroy_process_group()
