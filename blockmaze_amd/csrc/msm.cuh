@@ -182,11 +182,11 @@ __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *_
   while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (task_off[mid] <= t) lo = mid; else hi = mid; }
   uint32_t b = order[lo], j = t - task_off[lo], cnt = counts[b], beg = offsets[b] + j * task, end = offsets[b] + min(cnt, (j + 1) * task);
   XYZZ<F> acc = XYZZ<F>::inf();
-  uint32_t v = entries[beg]; Affine<F> p = points[v & 0x7fffffffu];                         // (beg < end: tasks exist only for non-empty slices)
+  uint32_t v = entries[beg], vn = beg + 1 < end ? entries[beg + 1] : v; Affine<F> p = points[v & 0x7fffffffu];   // (beg < end: tasks exist only for non-empty slices)
 #pragma unroll 1
-  for (uint32_t e = beg; e < end; e++) {                                                       // the next point is in flight while this one is added: the table gathers are random HBM reads
-    uint32_t vn = e + 1 < end ? entries[e + 1] : v; Affine<F> pn = points[vn & 0x7fffffffu];
-    if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; }
+  for (uint32_t e = beg; e < end; e++) {                 // software pipeline: the next point and the entry after it are in flight while this point is added (random table gathers)
+    Affine<F> pn = points[vn & 0x7fffffffu]; uint32_t vnn = e + 2 < end ? entries[e + 2] : vn;
+    if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; vn = vnn; }
   if (cnt <= task) buckets[b] = acc; else partials[t] = acc;
 }
 // ---- sums by the 64 quads of a 256-thread workgroup ------------------------------------------------------------------------
