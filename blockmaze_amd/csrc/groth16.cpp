@@ -4,6 +4,7 @@
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
+#include <array>
 #include <functional>
 #include <thread>
 #include "groth16.hpp"
@@ -223,30 +224,30 @@ static RsTerms rs_terms(const Fe32 *r_in, const Fe32 *s_in, const HG1 &delta_g1,
   RsTerms t; t.r = r_in ? fr_of(*r_in) : random_fr().from_mont(); t.s = s_in ? fr_of(*s_in) : random_fr().from_mont(); HFr rs = (t.r.to_mont() * t.s.to_mont()).from_mont();   // canonical scalars
   t.r_delta = delta_g1.mul(t.r.l); t.s_delta = delta_g1.mul(t.s.l); t.rs_delta_neg = delta_g1.mul(rs.l).neg(); t.s_delta2 = delta_g2.mul(t.s.l); return t; }
 static void enqueue_all(Prover::Impl &p) {
-  // ZK_WITNESS_MSM_START: where the four witness MSMs (auxiliary streams) are released relative to the critical chain: 0 = at once, 1 = after the row kernels,
-  // 2 = after the three inverse transforms, 3 = after the coset transforms, 4 = after all transforms (they then overlap the H-query MSM only)
-  static const int aux_start = env_int("ZK_WITNESS_MSM_START", 1);   // measured (send, earlier build): 0: 2.85 ms, 1: 2.65-2.77, 2: 2.69-2.72, 3: 2.83, 4: 3.01; current build 1: 2.38-2.44, 2: 2.47-2.50, 3: 2.62-2.66 — at the very start the five classify kernels fight the row and transform kernels of the critical chain for the CUs
+  // ZK_WITNESS_MSM_START: where each witness MSM (auxiliary streams; order B2, L, A, B1) is released relative to the critical chain, one digit per MSM or one for all:
+  // 0 = at once, 1 = after the row kernels, 2 = after the three inverse transforms, 3 = after the coset transforms, 4 = after all transforms (overlapping the H-query MSM only).
+  // Measured (send): all 0: 2.85 ms, 1: 2.38-2.44, 2: 2.47-2.50, 3: 2.62, 4: 3.0 — at time 0 the five full-chip classify kernels fight the row and transform kernels for the CUs.
+  static const std::array<int, 4> start = [] { std::array<int, 4> a{1, 1, 1, 1}; const char *e = getenv("ZK_WITNESS_MSM_START"); size_t n = e ? strlen(e) : 0;
+    for (int j = 0; j < 4 && n; j++) { char ch = e[n == 1 ? 0 : (size_t)j < n ? j : n - 1]; a[j] = ch >= '0' && ch <= '4' ? ch - '0' : 1; } return a; }();
   // about 80 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
   // (auxiliary streams) while this one submits the critical chain
-  static const int n_helpers = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); int v = e ? atoi(e) : 4; return v < 0 ? 0 : v > 4 ? 4 : v; }();
+  static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
   std::function<void()> jobs[4] = { [&] { p.B2->run(p.z.get(), p.B_idx.get() + p.b0); }, [&] { p.L->run(p.z.get() + p.ni + 1 + p.l0, nullptr); },       // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
                                     [&] { p.A->run(p.z.get() + p.a0, nullptr); }, [&] { p.B1->run(p.z.get(), p.B_idx.get() + p.b0); } };
-  int nh = (gpu_capturing() || profiling_enabled()) ? 0 : n_helpers;   // (the stage timers are not thread-safe: profiling runs submit from one thread)
+  const int job_stream[4] = {3, 1, 0, 2};                       // the auxiliary stream each MSM was bound to in the constructor (set_stream)
+  const bool use_threads = threaded && !gpu_capturing() && !profiling_enabled();   // (the stage timers are not thread-safe: profiling runs submit from one thread)
   std::exception_ptr aux_error[4]; std::thread helpers[4];
   struct Joiner { std::thread *t; ~Joiner() { for (int i = 0; i < 4; i++) if (t[i].joinable()) t[i].join(); } } joiner{helpers};
-  auto release_aux = [&] { gpu_fork_aux();
-    for (int h = 0; h < nh; h++) helpers[h] = std::thread([&, h] { LaneScope lane_scope(p.lane); try { for (int j = h; j < 4; j += nh) jobs[j](); } catch (...) { aux_error[h] = std::current_exception(); } });
-    if (!nh) for (auto &j : jobs) j(); };
-  if (aux_start <= 0) release_aux();
-  p.cs->eval(p.z.get(), p.abc.get(), p.m);
-  if (aux_start == 1) release_aux();
+  auto release = [&](int point) { for (int j = 0; j < 4; j++) if (start[j] == point) { gpu_fork_one(job_stream[j]);
+      if (use_threads) helpers[j] = std::thread([&, j] { LaneScope lane_scope(p.lane); try { jobs[j](); } catch (...) { aux_error[j] = std::current_exception(); } }); else jobs[j](); } };
+  release(0);
+  p.cs->eval(p.z.get(), p.abc.get(), p.m); release(1);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
-  p.dom->ifft(p.abc.get(), 3, p.m); if (aux_start == 2) release_aux();
-  p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); if (aux_start == 3) release_aux();
-  p.dom->icoset_fft(p.abc.get(), 1, p.m);
-  if (aux_start >= 4) release_aux();
+  p.dom->ifft(p.abc.get(), 3, p.m); release(2);
+  p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); release(3);
+  p.dom->icoset_fft(p.abc.get(), 1, p.m); release(4);
   p.H->run(p.abc.get() + p.h0, nullptr);                                                                                  // :466-473
-  for (int h = 0; h < nh; h++) { helpers[h].join(); if (aux_error[h]) std::rethrow_exception(aux_error[h]); }
+  for (int j = 0; j < 4; j++) if (helpers[j].joinable()) { helpers[j].join(); if (aux_error[j]) std::rethrow_exception(aux_error[j]); }
 }
 // one proof's device work: replayed from a captured hipGraph (about 70 launches on 5 streams collapse into one submission); opt-in with ZK_USE_GRAPH=1
 static void run_device(Prover::Impl &p) {
