@@ -19,14 +19,24 @@ struct BatchVerifier::Impl {
 
 // registers of the program
 enum { rF = 0, rT = 1, r2 = 2, r3 = 3, r4 = 4, r5 = 5, r6 = 6, r7 = 7, r8 = 8, r9 = 9, rONE = 10 };
-static void emit_exp_neg_z(std::vector<uint32_t> &p, uint32_t dst, uint32_t src) {   // exp_by_neg_z :84-96: conj(src^z), square-and-multiply from the top bit of z
-  bool found = false;
-  for (int i = 63; i >= 0; i--) { bool bit = (BN_Z >> i) & 1; if (found) p.push_back(vm_ins(VM_MUL, r9, r9, r9)); if (bit) { if (!found) p.push_back(vm_ins(VM_MUL, r9, rONE, src)); else p.push_back(vm_ins(VM_MUL, r9, r9, src)); found = true; } }
+// exp_by_neg_z (alt_bn128_pairing.cpp:84-96): conj(src^z) for src in the cyclotomic subgroup.  Width-3 NAF of z (18 non-zero digits in {+-1, +-3} instead of 28
+// one bits; a negative digit costs nothing because the inverse in the cyclotomic subgroup is the conjugate) over cyclotomic squarings; any addition chain gives
+// the same group element as libff's binary cyclotomic_exp (fp12_2over3over2.tcc:337-365).  Uses r9 (accumulator), r11 (src^3), rT (scratch).
+enum { r11 = 11 };
+static void emit_exp_neg_z(std::vector<uint32_t> &p, uint32_t dst, uint32_t src) {
+  std::vector<int> dig; for (uint64_t k = BN_Z; k;) { int t = 0; if (k & 1) { t = (int)(k & 7); if (t >= 4) t -= 8; k -= (uint64_t)(int64_t)t; } dig.push_back(t); k >>= 1; }
+  p.push_back(vm_ins(VM_CYCSQR, rT, src, 0)); p.push_back(vm_ins(VM_MUL, r11, rT, src)); bool started = false;
+  for (size_t i = dig.size(); i-- > 0;) { int d = dig[i];
+    if (started) p.push_back(vm_ins(VM_CYCSQR, r9, r9, 0));
+    if (!d) continue; uint32_t reg = (d == 1 || d == -1) ? src : r11;
+    if (!started) { if (d < 0) throw GpuError("verify: leading NAF digit"); p.push_back(vm_ins(VM_MUL, r9, rONE, reg)); started = true; continue; }
+    if (d < 0) { p.push_back(vm_ins(VM_CONJ, rT, reg, 0)); reg = rT; }
+    p.push_back(vm_ins(VM_MUL, r9, r9, reg)); }
   p.push_back(vm_ins(VM_CONJ, dst, r9, 0));
 }
 static std::vector<uint32_t> assemble_program(size_t n_lines) {
   std::vector<uint32_t> p; uint32_t idx = 0; bool found = false;
-  auto lines = [&] { p.push_back(vm_ins(VM_MUL, rF, rF, rT)); p.push_back(vm_ins(VM_LINE, rT, 1, idx)); p.push_back(vm_ins(VM_MUL, rF, rF, rT)); p.push_back(vm_ins(VM_LINE, rT, 2, idx)); p.push_back(vm_ins(VM_MUL, rF, rF, rT)); idx++; };
+  auto lines = [&] { p.push_back(vm_ins(VM_MUL024, rF, rF, rT)); p.push_back(vm_ins(VM_LINE, rT, 1, idx)); p.push_back(vm_ins(VM_MUL024, rF, rF, rT)); p.push_back(vm_ins(VM_LINE, rT, 2, idx)); p.push_back(vm_ins(VM_MUL024, rF, rF, rT)); idx++; };
   p.push_back(vm_ins(VM_ONE, rF, 0, 0)); p.push_back(vm_ins(VM_ONE, rONE, 0, 0));
   for (int i = 127; i >= 0; i--) { bool bit = (ATE_LOOP[i / 64] >> (i % 64)) & 1; if (!found) { found |= bit; continue; }                      // miller_loop :368-418 / precomputation :305-366
     p.push_back(vm_ins(VM_MUL, rF, rF, rF)); p.push_back(vm_ins(VM_DBL, rT, 0, 0)); lines();
@@ -37,9 +47,9 @@ static std::vector<uint32_t> assemble_program(size_t n_lines) {
   p.push_back(vm_ins(VM_CONJ, r3, rF, 0)); p.push_back(vm_ins(VM_INV, r4, rF, 0)); p.push_back(vm_ins(VM_MUL, r3, r3, r4));                 // C0 = conj(f) * f^-1
   p.push_back(vm_ins(VM_FROB, r4, r3, 2)); p.push_back(vm_ins(VM_MUL, r2, r4, r3));                                                          // first = C0^(q^2) * C0
   emit_exp_neg_z(p, r3, r2);                                                                                                                   // A
-  p.push_back(vm_ins(VM_MUL, r4, r3, r3)); p.push_back(vm_ins(VM_MUL, r5, r4, r4)); p.push_back(vm_ins(VM_MUL, r6, r5, r4));                  // B = A^2, C = B^2, D = C*B
+  p.push_back(vm_ins(VM_CYCSQR, r4, r3, 0)); p.push_back(vm_ins(VM_CYCSQR, r5, r4, 0)); p.push_back(vm_ins(VM_MUL, r6, r5, r4));                  // B = A^2, C = B^2, D = C*B
   emit_exp_neg_z(p, r7, r6);                                                                                                                   // E
-  p.push_back(vm_ins(VM_MUL, r5, r7, r7)); emit_exp_neg_z(p, r8, r5);                                                                          // F = E^2, G
+  p.push_back(vm_ins(VM_CYCSQR, r5, r7, 0)); emit_exp_neg_z(p, r8, r5);                                                                          // F = E^2, G
   p.push_back(vm_ins(VM_CONJ, r6, r6, 0)); p.push_back(vm_ins(VM_CONJ, r8, r8, 0));                                                            // H = conj(D), I = conj(G)
   p.push_back(vm_ins(VM_MUL, r8, r8, r7)); p.push_back(vm_ins(VM_MUL, r8, r8, r6));                                                            // J = I*E, K = J*H
   p.push_back(vm_ins(VM_MUL, r6, r8, r4)); p.push_back(vm_ins(VM_MUL, r7, r8, r7)); p.push_back(vm_ins(VM_MUL, r7, r7, r2));                  // L = K*B, M = K*E, N = M*first

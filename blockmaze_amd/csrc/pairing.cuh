@@ -36,7 +36,7 @@ struct FrobeniusDev { Fq2 fq6_c1[6], fq6_c2[6], fq12_c1[12], twist_mul_by_q_x, t
 struct EllCoeffsDev { Fq2 ell_0, ell_VW, ell_VV; };
 struct VerifyItem { Affine<Fq> A; Affine<Fq2> B; Affine<Fq> C; };                                        // Montgomery form, as parsed from the 512 hex characters
 
-enum VmOp : uint32_t { VM_MUL = 0, VM_CONJ, VM_FROB, VM_INV, VM_ONE, VM_DBL, VM_ADD, VM_LINE, VM_END };
+enum VmOp : uint32_t { VM_MUL = 0, VM_CONJ, VM_FROB, VM_INV, VM_ONE, VM_DBL, VM_ADD, VM_LINE, VM_END, VM_MUL024, VM_CYCSQR };
 __host__ __device__ inline uint32_t vm_ins(uint32_t op, uint32_t d, uint32_t a, uint32_t b) { return op | d << 8 | a << 16 | b << 24; }
 constexpr int VM_REGS = 12;
 
@@ -74,6 +74,24 @@ __global__ void __launch_bounds__(64) k_verify_batch(const uint32_t *__restrict_
     const uint32_t ins = prog[pc], op = ins & 0xff, d = (ins >> 8) & 0xff, a = (ins >> 16) & 0xff, b = ins >> 24;
     if (op == VM_END) break;
     if (op == VM_MUL) { const Fq12 x = R[a], y = R[b]; Fq6 aA = x.c0 * y.c0, bB = x.c1 * y.c1; R[d] = {aA + bB.mul_by_v(), (x.c0 + x.c1) * (y.c0 + y.c1) - aA - bB}; }   // fp12_2over3over2.tcc:91-104
+    else if (op == VM_MUL024) {                                                                                                                                      // mul_by_024 (fp12_2over3over2.tcc:240-335): R[b] = (a, 0, c | 0, e, 0)
+      const Fq12 x = R[a]; const Fq2 la = R[b].c0.c0, lc = R[b].c0.c2, le = R[b].c1.c1;
+      // t0 = x.c0 * (a, 0, c): 5 products;  t1 = x.c1 * (0, e, 0): 3 products;  t2 = (x.c0 + x.c1) * (a, e, c): 6 products (Karatsuba)  -> 14 Fq2 products instead of 18
+      Fq2 p0 = x.c0.c0 * la, p2 = x.c0.c2 * lc, p1c = x.c0.c1 * lc, p1a = x.c0.c1 * la, pm = (x.c0.c0 + x.c0.c2) * (la + lc);
+      Fq6 t0 = {p0 + p1c.mul_xi(), p1a + p2.mul_xi(), pm - p0 - p2};                                                   // (u0 a + xi u1 c, u1 a + xi u2 c, u2 a + u0 c)
+      Fq6 t1 = {(x.c1.c2 * le).mul_xi(), x.c1.c0 * le, x.c1.c1 * le};
+      Fq6 sx = x.c0 + x.c1, sl = {la, le, lc}, t2 = sx * sl;
+      R[d] = {t0 + t1.mul_by_v(), t2 - t0 - t1};
+    }
+    else if (op == VM_CYCSQR) {                                                                                                                                      // cyclotomic_squared :173-238 (Granger-Scott: three Fq4 squarings)
+      const Fq12 x = R[a]; Fq2 z0 = x.c0.c0, z4 = x.c0.c1, z3 = x.c0.c2, z2 = x.c1.c0, z1 = x.c1.c1, z5 = x.c1.c2, tmp, t0, t1, t2, t3, t4, t5;
+      tmp = z0 * z1; t0 = (z0 + z1) * (z0 + z1.mul_xi()) - tmp - tmp.mul_xi(); t1 = tmp + tmp;
+      tmp = z2 * z3; t2 = (z2 + z3) * (z2 + z3.mul_xi()) - tmp - tmp.mul_xi(); t3 = tmp + tmp;
+      tmp = z4 * z5; t4 = (z4 + z5) * (z4 + z5.mul_xi()) - tmp - tmp.mul_xi(); t5 = tmp + tmp;
+      z0 = t0 - z0; z0 = z0 + z0 + t0; z1 = t1 + z1; z1 = z1 + z1 + t1; tmp = t5.mul_xi(); z2 = tmp + z2; z2 = z2 + z2 + tmp;
+      z3 = t4 - z3; z3 = z3 + z3 + t4; z4 = t2 - z4; z4 = z4 + z4 + t2; z5 = t3 + z5; z5 = z5 + z5 + t3;
+      R[d] = {{z0, z4, z3}, {z2, z1, z5}};
+    }
     else if (op == VM_CONJ) { const Fq12 x = R[a]; R[d] = {x.c0, x.c1.neg()}; }                                                                                    // unitary_inverse
     else if (op == VM_FROB) { const Fq12 x = R[a]; R[d] = {fq6_frob(x.c0, b, T), fq6_mul_fq2(fq6_frob(x.c1, b, T), T.fq12_c1[b % 12])}; }
     else if (op == VM_INV) {                                                                                                                                          // fp12 :128-137 over fp6 :128-146
