@@ -23,7 +23,7 @@ BYTES_PER_G1_PAIR = 96                 # 64 B affine point + 32 B scalar, each r
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3)
+    ap = argparse.ArgumentParser(); ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=4, help="extra leg (not `value`): this many prover objects per GPU, one host thread each, proofs overlapping on the device; 0/1 = skip")
     ap.add_argument("--shard-msm", action="store_true", help="N > 1 only: all ranks prove ONE proof per step together, each holding 1/N of every query; one all-gather of 384-byte partial records per proof (strong scaling)")
@@ -124,7 +124,7 @@ def main():
     if os.path.exists(pmc):
         try: traffic = json.load(open(pmc)).get("k_msm_accumulate_H", {}).get("hbm_bytes_per_launch")
         except Exception: traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_msm_accumulate<Fq> (H query)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+    roofline = {"bound": "hbm", "kernel": "k_msm_accumulate_tasks<Fq> (H query)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic, "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": H_PAIRS * BYTES_PER_G1_PAIR}
 
     # what actually bounds that kernel: 254-bit field products on the integer VALU.  One mixed addition = 10 products; the H accumulation does one per
