@@ -42,30 +42,49 @@ struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; };
 
 // scalars: Fr in Montgomery form.  scalar_index (optional): scalar for point i is scalars[scalar_index[i]] (sparse
 // B-query, kc_multiexp.tcc:52-56); otherwise scalars[i].  point_is_inf (optional): byte flags of key points at infinity.
+// Bucket arrays of at most MSM_LDS_HIST counters (the witness MSMs: 128 buckets once all windows share one array) are histogrammed / ranked in LDS per workgroup and
+// touch the global counters once per non-empty bucket and workgroup: with ~60,000 entries on 128 counters the global atomics would serialise.
+constexpr uint32_t MSM_LDS_HIST = 4096;
 template <int DUMMY = 0>
-__global__ void k_msm_classify(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
-                               uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t *__restrict__ hist, uint32_t *__restrict__ ones, MsmCounters *cnt) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
-  if (point_is_inf && point_is_inf[i]) return;
-  Fr k = scalars[scalar_index ? scalar_index[i] : i].from_mont();
-  if (k.is_zero()) return;
-  if (filter_ones) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; if (o == 0) { ones[atomicAdd(&cnt->n_ones, 1u)] = i; return; } }
-  int dig[MSM_MAX_WINDOWS]; signed_digits(k.l, c, W, dig); const uint32_t NB = 1u << (c - 1);
-  for (int w = 0; w < W; w++) { int d = dig[w]; if (d) atomicAdd(&hist[(uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1], 1u); }   // hist_stride = 2^(c-1): buckets per window; 0: all windows share one bucket array (precomputed 2^(cw) P)
-  atomicAdd(&cnt->n_other, 1u);
+__global__ void __launch_bounds__(256) k_msm_classify(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
+                               uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t n_hist, uint32_t *__restrict__ hist, uint32_t *__restrict__ ones, MsmCounters *cnt) {
+  __shared__ uint32_t lh[MSM_LDS_HIST]; const bool use_lds = n_hist <= MSM_LDS_HIST;
+  if (use_lds) { for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) lh[b] = 0; __syncthreads(); }
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; bool live = i < n && !(point_is_inf && point_is_inf[i]); Fr k = Fr::zero();
+  if (live) { k = scalars[scalar_index ? scalar_index[i] : i].from_mont(); live = !k.is_zero(); }
+  bool is_one = false; if (live && filter_ones) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; is_one = o == 0; }
+  { // the compacted list of scalar-one indices: one atomic per wave instead of one per lane (46 % of a witness are ones, all on the same counter)
+    uint64_t m = __ballot(is_one); if (m) { uint32_t lane = threadIdx.x & 63, base = 0; if (lane == (uint32_t)__ffsll((long long)m) - 1) base = atomicAdd(&cnt->n_ones, (uint32_t)__popcll(m));
+      base = __shfl(base, __ffsll((long long)m) - 1, 64); if (is_one) ones[base + __popcll(m & ((1ull << lane) - 1))] = i; } }
+  if (live && !is_one) {
+    int dig[MSM_MAX_WINDOWS]; signed_digits(k.l, c, W, dig);
+    for (int w = 0; w < W; w++) { int d = dig[w]; if (d) { uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; atomicAdd(use_lds ? &lh[key] : &hist[key], 1u); } }   // hist_stride = 2^(c-1): buckets per window; 0: all windows share one bucket array (precomputed 2^(cw) P)
+  }
+  { uint64_t m = __ballot(live && !is_one); if (m && (threadIdx.x & 63) == (uint32_t)__ffsll((long long)m) - 1) atomicAdd(&cnt->n_other, (uint32_t)__popcll(m)); }
+  if (use_lds) { __syncthreads(); for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) if (lh[b]) atomicAdd(&hist[b], lh[b]); }
 }
 
 template <int DUMMY = 0>
-__global__ void k_msm_scatter(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
-                              uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t point_stride, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ fill, uint32_t *__restrict__ entries) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
-  if (point_is_inf && point_is_inf[i]) return;
-  Fr k = scalars[scalar_index ? scalar_index[i] : i].from_mont();
-  if (k.is_zero()) return;
-  if (filter_ones) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; if (o == 0) return; }
-  int dig[MSM_MAX_WINDOWS]; signed_digits(k.l, c, W, dig); const uint32_t NB = 1u << (c - 1);
-  for (int w = 0; w < W; w++) { int d = dig[w]; if (!d) continue; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1;
-    entries[offsets[key] + atomicAdd(&fill[key], 1u)] = (i + (uint32_t)w * point_stride) | (d < 0 ? 0x80000000u : 0u); }   // point_stride = n: the entry addresses 2^(cw) P_i in the precomputed table
+__global__ void __launch_bounds__(256) k_msm_scatter(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
+                              uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t point_stride, uint32_t n_hist, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ fill, uint32_t *__restrict__ entries) {
+  __shared__ uint32_t lcnt[MSM_LDS_HIST], lbase[MSM_LDS_HIST]; const bool use_lds = n_hist <= MSM_LDS_HIST;
+  if (use_lds) { for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) lcnt[b] = 0; __syncthreads(); }
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; bool live = i < n && !(point_is_inf && point_is_inf[i]); Fr k = Fr::zero();
+  if (live) { k = scalars[scalar_index ? scalar_index[i] : i].from_mont(); live = !k.is_zero(); }
+  if (live && filter_ones) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; if (o == 0) live = false; }
+  int dig[MSM_MAX_WINDOWS]; if (live) signed_digits(k.l, c, W, dig);
+  if (!use_lds) {
+    if (live) for (int w = 0; w < W; w++) { int d = dig[w]; if (!d) continue; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1;
+      entries[offsets[key] + atomicAdd(&fill[key], 1u)] = (i + (uint32_t)w * point_stride) | (d < 0 ? 0x80000000u : 0u); }   // point_stride = n: the entry addresses 2^(cw) P_i in the precomputed table
+    return;
+  }
+  uint32_t rank[MSM_MAX_WINDOWS];                                                           // position inside this workgroup's share of the bucket
+  if (live) for (int w = 0; w < W; w++) { int d = dig[w]; if (d) rank[w] = atomicAdd(&lcnt[(uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1], 1u); }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) if (lcnt[b]) lbase[b] = offsets[b] + atomicAdd(&fill[b], lcnt[b]);
+  __syncthreads();
+  if (live) for (int w = 0; w < W; w++) { int d = dig[w]; if (!d) continue; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1;
+    entries[lbase[key] + rank[w]] = (i + (uint32_t)w * point_stride) | (d < 0 ? 0x80000000u : 0u); }
 }
 
 // One-pass sort for scalars known to be uniform (the H query: coefficients of the quotient polynomial) with all windows sharing one bucket array: every bucket owns

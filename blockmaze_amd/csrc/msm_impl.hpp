@@ -81,7 +81,7 @@ struct MsmImpl {
       }
     } else
     { Stage st((label + ".sort").c_str(), s);
-      if (n) hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, hist(), ones.get(), cnt);
+      if (n) hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, (uint32_t)nbk, hist(), ones.get(), cnt);
       if (nbk <= PLAN_SMALL_MAX) {
         hipLaunchKernelGGL(k_msm_plan_small, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, offsets.get(), order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
       } else {
@@ -91,7 +91,7 @@ struct MsmImpl {
         hipLaunchKernelGGL(k_bsort_scatter, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_off.get(), order.get(), rank_of.get(), ntasks.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
         task_scanner.run(ntasks.get(), task_off.get(), nbk + 1, s);
       }
-      if (n) hipLaunchKernelGGL(k_msm_scatter<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, point_stride, offsets.get(), fill(), entries.get());
+      if (n) hipLaunchKernelGGL(k_msm_scatter<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, point_stride, (uint32_t)nbk, offsets.get(), fill(), entries.get());
     }
     { Stage st((label + ".accumulate").c_str(), s);
       hipLaunchKernelGGL((k_msm_accumulate_tasks<F>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), order.get(), task_off.get(), (uint32_t)nbk, max_tasks, direct ? task : MSM_TASK,
