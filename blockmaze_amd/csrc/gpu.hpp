@@ -55,7 +55,7 @@ class MsmG1 {
   // Enqueues the kernels; result() synchronises and finishes the combine on the host.
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
   host::HG1 result();
-  size_t size() const; const G1AffineRaw *points_dev() const; void set_label(const char *l); void set_stream(int aux /* -1 main, 0..3 auxiliary */);
+  size_t size() const; const G1AffineRaw *points_dev() const; void set_label(const char *l); void set_stream(int aux /* -1 main, 0..3 auxiliary */); void split_ones_path();   // split: the scalar-one sum runs on a stream of its own beside the bucket path
   struct Impl; std::unique_ptr<Impl> impl;
 };
 class MsmG2 {
@@ -63,7 +63,7 @@ class MsmG2 {
   MsmG2(const G2AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false);
   ~MsmG2();
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
-  host::HG2 result(); void set_label(const char *l); void set_stream(int aux);
+  host::HG2 result(); void set_label(const char *l); void set_stream(int aux); void split_ones_path();
   struct Impl; std::unique_ptr<Impl> impl;
 };
 

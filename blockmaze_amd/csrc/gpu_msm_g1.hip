@@ -7,6 +7,7 @@ MsmG1::~MsmG1() = default;
 void MsmG1::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
 void MsmG1::set_label(const char *l) { impl->label = l; }
 void MsmG1::set_stream(int aux) { impl->stream_id = aux; }
+void MsmG1::split_ones_path() { impl->enable_split_ones(); }
 host::HG1 MsmG1::result() { impl->finish_sync(); return combine<host::HFq, Fq>(impl->host_sums(), impl->WB, impl->c); }
 size_t MsmG1::size() const { return impl->n; }
 const G1AffineRaw *MsmG1::points_dev() const { return impl->points.get(); }
