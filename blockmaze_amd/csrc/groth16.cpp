@@ -5,7 +5,9 @@
 #include <fstream>
 #include <stdexcept>
 #include <array>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include "groth16.hpp"
 
@@ -185,12 +187,27 @@ void generate_keys(const R1csHost &cs_in, const ToxicWaste &tw, ProvingKeyHost &
 // ======================================================================================================================
 // prover
 // ======================================================================================================================
+// A helper thread that lives as long as its prover: submitting a witness MSM (about a dozen launches, several microseconds of host time each) must not cost a
+// thread creation per proof on the critical path.  post() hands over a job, wait() blocks until it has run and rethrows what it threw.
+class SubmitWorker {
+ public:
+  explicit SubmitWorker(int lane) : lane_(lane), th_([this] { loop(); }) {}
+  ~SubmitWorker() { { std::lock_guard<std::mutex> lk(m_); quit_ = true; } cv_.notify_all(); th_.join(); }
+  void post(std::function<void()> job) { { std::lock_guard<std::mutex> lk(m_); job_ = std::move(job); busy_ = true; err_ = nullptr; } cv_.notify_all(); }
+  void wait() { std::unique_lock<std::mutex> lk(m_); done_.wait(lk, [this] { return !busy_; }); if (err_) { std::exception_ptr e = err_; err_ = nullptr; std::rethrow_exception(e); } }
+ private:
+  void loop() { LaneScope lane_scope(lane_); std::unique_lock<std::mutex> lk(m_);
+    for (;;) { cv_.wait(lk, [this] { return quit_ || (busy_ && job_); }); if (quit_) return; std::function<void()> j = std::move(job_); job_ = nullptr; lk.unlock();
+      std::exception_ptr e; try { j(); } catch (...) { e = std::current_exception(); } lk.lock(); err_ = e; busy_ = false; done_.notify_all(); } }
+  int lane_; std::mutex m_; std::condition_variable cv_, done_; std::function<void()> job_; bool busy_ = false, quit_ = false; std::exception_ptr err_; std::thread th_;
+};
 struct Prover::Impl {
   int lane = 0;                                                // this prover's stream set: provers on different lanes overlap on the device
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
   std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; PinnedBuf<Fe32> z_host; GpuGraph *graph = nullptr; bool graph_failed = false;
-  ~Impl() { gpu_graph_destroy(graph); }
+  std::unique_ptr<SubmitWorker> workers[4];
+  ~Impl() { for (auto &w : workers) w.reset(); gpu_graph_destroy(graph); }
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &e) { size_t base = n / world, rem = n % world; b = rank * base + (rank < rem ? rank : rem); e = b + base + (rank < rem ? 1 : 0); }
@@ -236,10 +253,10 @@ static void enqueue_all(Prover::Impl &p) {
                                     [&] { p.A->run(p.z.get() + p.a0, nullptr); }, [&] { p.B1->run(p.z.get(), p.B_idx.get() + p.b0); } };
   const int job_stream[4] = {3, 1, 0, 2};                       // the auxiliary stream each MSM was bound to in the constructor (set_stream)
   const bool use_threads = threaded && !gpu_capturing() && !profiling_enabled();   // (the stage timers are not thread-safe: profiling runs submit from one thread)
-  std::exception_ptr aux_error[4]; std::thread helpers[4];
-  struct Joiner { std::thread *t; ~Joiner() { for (int i = 0; i < 4; i++) if (t[i].joinable()) t[i].join(); } } joiner{helpers};
+  bool posted[4] = {false, false, false, false};
+  struct Waiter { Prover::Impl &p; bool *posted; ~Waiter() { for (int j = 0; j < 4; j++) if (posted[j]) { try { p.workers[j]->wait(); } catch (...) {} } } } waiter{p, posted};   // never leave a job running behind an exception
   auto release = [&](int point) { for (int j = 0; j < 4; j++) if (start[j] == point) { gpu_fork_one(job_stream[j]);
-      if (use_threads) helpers[j] = std::thread([&, j] { LaneScope lane_scope(p.lane); try { jobs[j](); } catch (...) { aux_error[j] = std::current_exception(); } }); else jobs[j](); } };
+      if (use_threads) { if (!p.workers[j]) p.workers[j].reset(new SubmitWorker(p.lane)); p.workers[j]->post(jobs[j]); posted[j] = true; } else jobs[j](); } };
   release(0);
   p.cs->eval(p.z.get(), p.abc.get(), p.m); release(1);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
@@ -247,7 +264,7 @@ static void enqueue_all(Prover::Impl &p) {
   p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); release(3);
   p.dom->icoset_fft(p.abc.get(), 1, p.m); release(4);
   p.H->run(p.abc.get() + p.h0, nullptr);                                                                                  // :466-473
-  for (int j = 0; j < 4; j++) if (helpers[j].joinable()) { helpers[j].join(); if (aux_error[j]) std::rethrow_exception(aux_error[j]); }
+  for (int j = 0; j < 4; j++) if (posted[j]) { posted[j] = false; p.workers[j]->wait(); }
 }
 // one proof's device work: replayed from a captured hipGraph (about 70 launches on 5 streams collapse into one submission); opt-in with ZK_USE_GRAPH=1
 static void run_device(Prover::Impl &p) {
