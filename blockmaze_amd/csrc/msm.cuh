@@ -4,17 +4,18 @@
 // :443-496) and libsnark's kc_multi_exp_with_mixed_addition (SNARK/knowledge_commitment/kc_multiexp.tcc:21-85).
 // Like the reference it splits the scalars three ways — zero: skipped; one: plain point sum; anything else: Pippenger
 // buckets — but the structure is a GPU one:
-//   classify   one thread per (point, scalar): leave Montgomery form, drop zeros / points at infinity, append "ones" to
-//              a compacted index list, histogram the signed c-bit digits of the rest per window
-//   scan       exclusive prefix sum of the histogram -> bucket offsets
-//   scatter    counting sort of (point index, sign) by (window, |digit|)
-//   accumulate LANES lanes per bucket walk the bucket's slice of the sorted list with mixed additions (XYZZ accumulator
-//              in VGPRs), then combine across lanes with wave shuffles
-//   reduce     per window, sum_b b*B_b by segment: running sums inside a segment, a small scalar multiple for the
-//              segment offset, then a wave-per-window tree
-//   ones       strided partial sums over the compacted list + the same tree
-// The W window sums and the ones-sum go back to the host, which does the c*W doublings of the Horner combine (254
-// dependent doublings are faster on one CPU core than on one GPU lane).
+//   tables     (key load, optional) 2^(cw) P for every window w: all windows then share ONE array of 2^(c-1) buckets (k_msm_precompute)
+//   classify   one thread per (point, scalar): leave Montgomery form, drop zeros / points at infinity, append "ones" to a compacted index list (one atomic per
+//              wave), histogram the signed c-bit digits (in LDS first when the bucket array is small)
+//   plan       bucket offsets (scan), buckets ranked by decreasing size, tasks of at most 16 entries; one single-workgroup launch for small bucket arrays
+//   scatter    counting sort of (table index, sign) by bucket.  H query (uniform scalars): classify + scan + scatter collapse into ONE pass with fixed slots per
+//              bucket (k_msm_scatter_direct), falling back to the two-pass sort if a bucket overflows
+//   accumulate one lane per task walks its slice of the sorted list with mixed additions (XYZZ accumulator in VGPRs, next point's gather in flight)
+//   combine    buckets cut into several tasks: a quad (or a workgroup for very full buckets) adds the partial sums
+//   reduce     sum_b b*B_b by segments: running sums inside a segment, a small scalar multiple for the segment offset, then workgroup-level trees — all with
+//              quad-cooperative additions (curve.cuh): four lanes share one addition, so the dependent chain is 4 products long instead of 14
+//   ones       one quad per strided partial sum over the compacted list + the same trees
+// The bucket-array sums (one with tables, W otherwise) and the ones-sum go back to the host, which does the remaining c*W Horner doublings if there are any.
 // Signed digits halve the bucket count: digit d in [-2^(c-1), 2^(c-1)], bucket |d|, sign applied to y on load.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -5,11 +5,12 @@
 // (FQFFT/evaluation_domain/domains/basic_radix2_domain.tcc:48-112, basic_radix2_domain_aux.tcc:44-79,171-180) and, via
 // the pre/post passes in step_domain kernels, step_radix2_domain (domains/step_radix2_domain.tcc:39-153,242-260).
 // Field arithmetic is exact, so any butterfly schedule gives bit-identical vectors; the schedule here is the GPU one:
-//   * bit-reversal gather, then log2(n) decimation-in-time stages
-//   * the first LOCAL_LOG stages run inside one workgroup on a tile held in LDS (wavefront-level butterflies,
-//     twiddles read through a strided table), the remaining stages stream the vector once per stage
+//   * n = n1 * n2: a column pass (k_ntt_cols) and a row pass (k_ntt_rows), each holding its tile in LDS — natural order in and out, no bit-reversal pass over HBM
+//   * inside a tile: decimation-in-frequency stages three at a time with the eight values of a butterfly group in registers (one LDS round trip and one barrier
+//     per three stages), stage twiddles staged in LDS, tile padded against bank conflicts
 //   * `batch` independent vectors per launch (the witness map transforms A, B, C together)
-//   * scaling by 1/n and the coset shift g^i are folded into one table multiply
+//   * scaling by 1/n and the coset shift g^i are folded into the load of the column pass or the store of the row pass
+//   * beyond 2^22 points: bit-reversal gather + one launch per stage (k_ntt_bitrev_scale, k_ntt_local, k_ntt_stage)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "field.cuh"
@@ -136,28 +137,11 @@ __global__ void k_qap_pointwise(Fr *__restrict__ a, const Fr *__restrict__ b, co
 __global__ void k_fr_to_mont(Fr *__restrict__ a, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = a[i].to_mont(); }
 __global__ void k_fr_from_mont(Fr *__restrict__ a, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = a[i].from_mont(); }
 
-constexpr uint32_t R1CS_LONG_ROW = 16;   // rows with more terms than this get a whole wave (k_r1cs_long_rows)
+constexpr uint32_t R1CS_LONG_ROW = 16;   // rows with more terms than this get a whole wave (k_r1cs_long_rows3)
 // ---- R1CS rows times assignment (kernel K1; r1cs_to_qap.tcc:224-236,281-285; linear_combination::evaluate) ---------
-// CSR with coefficient *indices* into a small table (the circuits use a few hundred distinct coefficients: +-1, +-2^k).
-// out[row] = sum coeff[cid] * z[col]   for row < n_rows; rows are per matrix, one thread per row.
-__global__ void k_r1cs_rows(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col, const uint32_t *__restrict__ cid, const Fr *__restrict__ ctab,
-                            const Fr *__restrict__ z, uint32_t n_rows, Fr *__restrict__ out) {
-  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= n_rows) return; Fr acc = Fr::zero();
-  if (rowptr[r + 1] - rowptr[r] > R1CS_LONG_ROW) return;                        // handled by k_r1cs_long_rows
-  for (uint32_t k = rowptr[r]; k < rowptr[r + 1]; k++) { uint32_t ci = cid[k]; Fr v = z[col[k]];
-    if (ci == 0) acc = acc + v; else if (ci == 1) acc = acc - v; else acc = acc + ctab[ci] * v; }   // table slots 0 / 1 are +1 / -1
-  out[r] = acc;
-}
-// rows with many terms (bit-packing constraints: 32 ... 253 terms) get one wave each: lanes stride over the terms, then a shuffle tree over the partial sums
-__global__ void __launch_bounds__(64) k_r1cs_long_rows(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col, const uint32_t *__restrict__ cid, const Fr *__restrict__ ctab,
-                                                        const Fr *__restrict__ z, Fr *__restrict__ out) {
-  uint32_t r = rows[blockIdx.x], lane = threadIdx.x; Fr acc = Fr::zero();
-  for (uint32_t k = rowptr[r] + lane; k < rowptr[r + 1]; k += 64) { uint32_t ci = cid[k]; Fr v = z[col[k]]; if (ci == 0) acc = acc + v; else if (ci == 1) acc = acc - v; else acc = acc + ctab[ci] * v; }
-#pragma unroll 1
-  for (int d = 32; d >= 1; d >>= 1) { Fr o; for (int i = 0; i < 8; i++) o.l[i] = __shfl_down(acc.l[i], d, 64); acc = acc + o; }
-  if (lane == 0) out[r] = acc;
-}
-// The prover's form of the two kernels above: all three matrices in one launch, the evaluation vectors completed (input-consistency rows
+// CSR with coefficient *indices* into a small table (the circuits use a few hundred distinct coefficients: +-1, +-2^k; table slots 0 / 1 are +1 / -1 and skip the
+// multiply).  Rows with more than R1CS_LONG_ROW terms in any matrix (bit-packing constraints: 32 ... 253 terms) get one wave each (k_r1cs_long_rows3), the rest one lane.
+// All three matrices in one launch, the evaluation vectors completed (input-consistency rows
 // r1cs_to_qap.tcc:227-230, zero padding up to the domain size) and the satisfiability test a*b == c (protoboard::is_satisfied, sendcgo.cpp:209) done on the
 // values while they are in registers.  A violated row stores `seq` (the number of this evaluation) to *fail, a word in mapped host memory: no reset, no copy.
 struct R1csMatrices { const uint32_t *rowptr[3], *col[3], *cid[3]; };
