@@ -1,0 +1,39 @@
+// Key-load transform of the H query into the Lagrange basis of the coset: an inverse NTT over group elements (see below).  Included by gpu.hip only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "curve.cuh"
+
+namespace zk {
+
+// ---- H query in the Lagrange basis of the coset (key load) ---------------------------------------------------------------
+// The prover needs sum_i h_i H_i where h = icosetFFT(v) are the coefficients of the quotient polynomial and v its values on the coset (r1cs_to_qap.tcc:310-322,
+// r1cs_gg_ppzksnark.tcc:466-473).  h_i = (g^-i / m) sum_j v_j w^(-ij), hence  sum_i h_i H_i = sum_j v_j P_j  with  P_j = sum_i w^(-ij) * ((g^-i / m) H_i):
+// the inverse DFT, over GROUP ELEMENTS, of the scaled query (H_(m-1) := 0, its coefficient is zero anyway).  Computing P once per key (m/2 * log m point
+// multiplications by twiddles) removes the seventh transform from every proof; the group element, and so the proof bytes, are the same.
+template <class F> __device__ __forceinline__ XYZZ<F> xyzz_mul_fr(const XYZZ<F> &p, const Fr &k_mont) {     // k * p, MSB-first double-and-add over the canonical bits of k
+  const Fr k = k_mont.from_mont(); XYZZ<F> r = XYZZ<F>::inf(); bool started = false;
+#pragma unroll 1
+  for (int i = 255; i >= 0; i--) { if (started) r = r.dbl_inl(); if ((k.l[i >> 5] >> (i & 31)) & 1) { if (started) r.add_inl(p); else { r = p; started = true; } } }
+  return r;
+}
+// data[i] = scale[i] * H_i for i < n_in, infinity for n_in <= i < m
+__global__ void __launch_bounds__(64) k_ecntt_prescale(const Affine<Fq> *__restrict__ h, uint32_t n_in, const Fr *__restrict__ scale, uint32_t m, XYZZ<Fq> *__restrict__ data) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= m) return;
+  data[i] = i < n_in ? xyzz_mul_fr(XYZZ<Fq>::from_affine(h[i]), scale[i]) : XYZZ<Fq>::inf();
+}
+// one decimation-in-frequency stage s (s = log m ... 1): (u, v) -> (u + v, w^j (u - v)); tw[j] = w^j for j < m/2 (here the inverse root's table); natural order in, bit-reversed out
+__global__ void __launch_bounds__(64) k_ecntt_stage(XYZZ<Fq> *__restrict__ data, const Fr *__restrict__ tw, int logm, int s) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x, half_m = 1u << (logm - 1); if (b >= half_m) return;
+  const uint32_t half = 1u << (s - 1), j = b & (half - 1), i0 = ((b >> (s - 1)) << s) + j, i1 = i0 + half;
+  XYZZ<Fq> u = data[i0], v = data[i1], sum = u; sum.add_inl(v); XYZZ<Fq> d = u; d.add_inl(v.neg());
+  if (j) d = xyzz_mul_fr(d, tw[j << (logm - s)]);
+  data[i0] = sum; data[i1] = d;
+}
+// out[bitrev(p)] = affine(data[p])
+__global__ void __launch_bounds__(64) k_ecntt_finish(const XYZZ<Fq> *__restrict__ data, int logm, Affine<Fq> *__restrict__ out) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; if (p >= (1u << logm)) return; const XYZZ<Fq> q = data[p]; const uint32_t r = __brev(p) >> (32 - logm);
+  if (q.is_inf()) { out[r] = Affine<Fq>::inf(); return; }
+  Fq t = (q.ZZ * q.ZZZ).inv(); out[r] = {q.X * (t * q.ZZZ), q.Y * (t * q.ZZ)};
+}
+
+}  // namespace zk

@@ -9,6 +9,7 @@
 #include <mutex>
 #include "gpu_internal.hpp"
 #include "ntt.cuh"
+#include "ecntt.cuh"
 
 namespace zk {
 
@@ -226,6 +227,16 @@ void Domain::icoset_fft(Fe32 *data, int batch, size_t stride) {
     else radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, nullptr, d.coset_inv.get(), batch, stride, d.scratch_stride);
     return; }
   ifft(data, batch, stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride);
+}
+// see ecntt.cuh: the H query (m - 1 points) in the Lagrange basis of the coset (m points).  Basic radix-2 domains only.
+bool Domain::supports_h_lagrange() const { return !impl->step; }
+void Domain::h_query_to_coset_lagrange(const G1AffineRaw *h, size_t n_in, G1AffineRaw *out) {
+  Impl &d = *impl; if (d.step || n_in > d.m) throw GpuError("domain: h_query_to_coset_lagrange"); hipStream_t s = gpu().stream; const int logm = d.big->logn; const size_t m = d.m;
+  DevBuf<G1AffineRaw> din(n_in ? n_in : 1), dout(m); DevBuf<uint8_t> data(m * sizeof(XYZZ<Fq>)); if (n_in) din.upload(h, n_in);
+  hipLaunchKernelGGL(k_ecntt_prescale, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)din.get(), (uint32_t)n_in, (const Fr *)d.coset_inv.get(), (uint32_t)m, (XYZZ<Fq> *)data.get());   // coset_inv[i] = g^-i / m
+  for (int st = logm; st >= 1; st--) hipLaunchKernelGGL(k_ecntt_stage, dim3(cdiv(m / 2, 64)), dim3(64), 0, s, (XYZZ<Fq> *)data.get(), (const Fr *)d.big->itw.get(), logm, st);
+  hipLaunchKernelGGL(k_ecntt_finish, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)data.get(), logm, (Affine<Fq> *)dout.get());
+  HIP_CHECK(hipGetLastError()); dout.download(out, m);
 }
 void Domain::qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c) {
   hipLaunchKernelGGL(k_qap_pointwise, dim3(cdiv(impl->m, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (const Fr *)b, (const Fr *)c, (const Fr *)impl->zinv.get(), impl->step ? 1 : 0, (uint32_t)impl->m);

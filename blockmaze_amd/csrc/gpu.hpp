@@ -87,6 +87,8 @@ class Domain {
   // in place on `batch` device vectors of m elements each, `stride` elements apart (Montgomery form)
   void fft(Fe32 *data, int batch, size_t stride); void ifft(Fe32 *data, int batch, size_t stride);
   void coset_fft(Fe32 *data, int batch, size_t stride); void icoset_fft(Fe32 *data, int batch, size_t stride);
+  // key load: the H query (n_in = m - 1 affine points) re-expressed so that sum_j v_j out_j = sum_i icosetFFT(v)_i h_i: the prover then skips the last transform (ecntt.cuh)
+  bool supports_h_lagrange() const; void h_query_to_coset_lagrange(const G1AffineRaw *h, size_t n_in, G1AffineRaw *out /* m points */);
   // a = (a*b - c) / Z on the coset
   void qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c);
   struct Impl; std::unique_ptr<Impl> impl;

@@ -202,6 +202,7 @@ class SubmitWorker {
   int lane_; std::mutex m_; std::condition_variable cv_, done_; std::function<void()> job_; bool busy_ = false, quit_ = false; std::exception_ptr err_; std::thread th_;
 };
 struct Prover::Impl {
+  bool h_lagrange = false;                                     // the H query is held in the coset's Lagrange basis: no inverse coset transform per proof
   int lane = 0;                                                // this prover's stream set: provers on different lanes overlap on the device
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
@@ -217,9 +218,12 @@ Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) 
   p.alpha_g1 = g1_of(pk.alpha_g1); p.beta_g1 = g1_of(pk.beta_g1); p.delta_g1 = g1_of(pk.delta_g1); p.beta_g2 = g2_of(pk.beta_g2); p.delta_g2 = g2_of(pk.delta_g2);
   int cw = env_int("ZK_MSM_WITNESS_WINDOW", 8), ch = env_int("ZK_MSM_H_WINDOW", 16);
   size_t e; shard_range(pk.A.size(), shard_rank, shard_world, p.a0, e); size_t nA = e - p.a0; shard_range(pk.L.size(), shard_rank, shard_world, p.l0, e); size_t nL = e - p.l0;
-  shard_range(pk.B_idx.size(), shard_rank, shard_world, p.b0, e); size_t nB = e - p.b0; shard_range(pk.H.size(), shard_rank, shard_world, p.h0, e); size_t nH = e - p.h0;
+  shard_range(pk.B_idx.size(), shard_rank, shard_world, p.b0, e); size_t nB = e - p.b0; // H query: in the coset's Lagrange basis when the domain allows it (then the seventh transform of every proof is skipped, ecntt.cuh); computed once per key object
+  const std::vector<G1AffineRaw> *Hq = &pk.H; p.h_lagrange = env_int("ZK_H_LAGRANGE", 1) != 0 && p.dom->supports_h_lagrange();
+  if (p.h_lagrange) { if (pk.H_lagrange.size() != p.m) { pk.H_lagrange.resize(p.m); p.dom->h_query_to_coset_lagrange(pk.H.data(), pk.H.size(), pk.H_lagrange.data()); } Hq = &pk.H_lagrange; }
+  shard_range(Hq->size(), shard_rank, shard_world, p.h0, e); size_t nH = e - p.h0;
   p.A.reset(new MsmG1(pk.A.data() + p.a0, nA, cw, true)); p.L.reset(new MsmG1(pk.L.data() + p.l0, nL, cw, true));
-  p.B1.reset(new MsmG1(pk.B_g1.data() + p.b0, nB, cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data() + p.b0, nB, cw, true)); p.H.reset(new MsmG1(pk.H.data() + p.h0, nH, ch, false, env_int("ZK_MSM_H_TABLES", 1) != 0, true));   // (with tables the H accumulation gathers from a table 16x larger and slows from 0.40 to 0.51 ms, but the reduction drops from 0.53 to 0.23 ms: measured 3 % better per proof, 10 % better with four proofs in flight)
+  p.B1.reset(new MsmG1(pk.B_g1.data() + p.b0, nB, cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data() + p.b0, nB, cw, true)); p.H.reset(new MsmG1(Hq->data() + p.h0, nH, ch, false, env_int("ZK_MSM_H_TABLES", 1) != 0, true));   // (with tables the H accumulation gathers from a table 16x larger and slows from 0.40 to 0.51 ms, but the reduction drops from 0.53 to 0.23 ms: measured 3 % better per proof, 10 % better with four proofs in flight)
   p.A->set_stream(0); p.L->set_stream(1); p.B1->set_stream(2); p.B2->set_stream(3); if (env_int("ZK_MSM_SPLIT_ONES", 1)) p.B2->split_ones_path();   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
   p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
   p.B_idx = DevBuf<uint32_t>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx.upload(pk.B_idx.data(), pk.B_idx.size());
@@ -262,7 +266,8 @@ static void enqueue_all(Prover::Impl &p) {
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
   p.dom->ifft(p.abc.get(), 3, p.m); release(2);
   p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); release(3);
-  p.dom->icoset_fft(p.abc.get(), 1, p.m); release(4);
+  if (!p.h_lagrange) p.dom->icoset_fft(p.abc.get(), 1, p.m);
+  release(4);
   p.H->run(p.abc.get() + p.h0, nullptr);                                                                                  // :466-473
   for (int j = 0; j < 4; j++) if (posted[j]) { posted[j] = false; p.workers[j]->wait(); }
 }
