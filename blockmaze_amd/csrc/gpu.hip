@@ -38,6 +38,8 @@ GpuGraph *gpu_graph_end() { g_capturing = false; std::unique_ptr<GpuGraph> g(new
 void gpu_graph_abort() { g_capturing = false; hipGraph_t g = nullptr; hipStreamEndCapture(gpu().stream, &g); if (g) hipGraphDestroy(g); (void)hipGetLastError(); }
 void gpu_graph_launch(GpuGraph *g) { HIP_CHECK(hipGraphLaunch(g->exec, gpu().stream)); }
 void gpu_graph_destroy(GpuGraph *g) { if (!g) return; if (g->exec) hipGraphExecDestroy(g->exec); if (g->graph) hipGraphDestroy(g->graph); delete g; }
+void gpu_fork_record() { GpuContext &g = gpu(); HIP_CHECK(hipEventRecord(g.fork_event, g.stream)); }
+void gpu_fork_wait(int i) { GpuContext &g = gpu(); HIP_CHECK(hipStreamWaitEvent(g.aux[i & 3], g.fork_event, 0)); }   // may be called from the thread that submits to that stream
 void gpu_fork_one(int i) { GpuContext &g = gpu(); HIP_CHECK(hipEventRecord(g.join_event[i & 3], g.stream)); HIP_CHECK(hipStreamWaitEvent(g.aux[i & 3], g.join_event[i & 3], 0)); }   // (the stream's join event is free at this point of a proof)
 void gpu_fork_aux() { GpuContext &g = gpu(); HIP_CHECK(hipEventRecord(g.fork_event, g.stream)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(g.aux[i], g.fork_event, 0)); }
 hipStream_t gpu_stream() { return gpu().stream; }

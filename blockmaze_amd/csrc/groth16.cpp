@@ -259,8 +259,9 @@ static void enqueue_all(Prover::Impl &p) {
   const bool use_threads = threaded && !gpu_capturing() && !profiling_enabled();   // (the stage timers are not thread-safe: profiling runs submit from one thread)
   bool posted[4] = {false, false, false, false};
   struct Waiter { Prover::Impl &p; bool *posted; ~Waiter() { for (int j = 0; j < 4; j++) if (posted[j]) { try { p.workers[j]->wait(); } catch (...) {} } } } waiter{p, posted};   // never leave a job running behind an exception
-  auto release = [&](int point) { for (int j = 0; j < 4; j++) if (start[j] == point) { gpu_fork_one(job_stream[j]);
-      if (use_threads) { if (!p.workers[j]) p.workers[j].reset(new SubmitWorker(p.lane)); p.workers[j]->post(jobs[j]); posted[j] = true; } else jobs[j](); } };
+  auto release = [&](int point) { bool any = false; for (int j = 0; j < 4; j++) any |= start[j] == point; if (!any) return; gpu_fork_record();      // one event; each stream's wait is issued by the thread that feeds it
+    for (int j = 0; j < 4; j++) if (start[j] == point) { const int sj = job_stream[j]; std::function<void()> job = jobs[j];
+      if (use_threads) { if (!p.workers[j]) p.workers[j].reset(new SubmitWorker(p.lane)); p.workers[j]->post([sj, job] { gpu_fork_wait(sj); job(); }); posted[j] = true; } else { gpu_fork_wait(sj); job(); } } };
   release(0);
   p.cs->eval(p.z.get(), p.abc.get(), p.m); release(1);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
