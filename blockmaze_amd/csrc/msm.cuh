@@ -48,8 +48,9 @@ struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; };
 constexpr uint32_t MSM_LDS_HIST = 4096;
 template <int DUMMY = 0>
 __global__ void __launch_bounds__(256) k_msm_classify(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
-                               uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t n_hist, uint32_t *__restrict__ hist, uint32_t *__restrict__ ones, MsmCounters *cnt) {
+                               uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t n_hist, uint32_t *__restrict__ hist, uint32_t *__restrict__ ones, MsmCounters *cnt, MsmCounters *cnt_next) {
   __shared__ uint32_t lh[MSM_LDS_HIST]; const bool use_lds = n_hist <= MSM_LDS_HIST;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = MsmCounters{0, 0, {0, 0}};   // the counters alternate between two slots: this run clears the next run's
   if (use_lds) { for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) lh[b] = 0; __syncthreads(); }
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; bool live = i < n && !(point_is_inf && point_is_inf[i]); Fr k = Fr::zero();
   if (live) { k = scalars[scalar_index ? scalar_index[i] : i].from_mont(); live = !k.is_zero(); }
@@ -93,8 +94,8 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const Fr *__restrict__ scal
 // overflow sets counters->pad[0]; the host then repeats the MSM on the two-pass path (any input stays correct, only uniform ones are fast).
 template <int DUMMY = 0>
 __global__ void k_msm_scatter_direct(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf, uint32_t n, int c, int W, uint32_t point_stride,
-                                     uint32_t cap, uint32_t *__restrict__ counts, uint32_t *__restrict__ entries, MsmCounters *cnt) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+                                     uint32_t cap, uint32_t *__restrict__ counts, uint32_t *__restrict__ entries, MsmCounters *cnt, MsmCounters *cnt_next) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i == 0) *cnt_next = MsmCounters{0, 0, {0, 0}}; if (i >= n) return;
   if (point_is_inf && point_is_inf[i]) return;
   Fr k = scalars[scalar_index ? scalar_index[i] : i].from_mont();
   if (k.is_zero()) return;
@@ -250,8 +251,9 @@ static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_direct(uint32_
 constexpr uint32_t COMBINE_QUAD_MAX = 24;
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, const uint32_t *__restrict__ cls_start, uint32_t heavy_blocks,
-                                                           const XYZZ<F> *__restrict__ partials, XYZZ<F> *__restrict__ buckets) {
+                                                           const XYZZ<F> *__restrict__ partials, XYZZ<F> *__restrict__ buckets, uint32_t *__restrict__ zero_words, uint32_t n_zero) {
   __shared__ XYZZ<F> lds[4];
+  { uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; if (gid < n_zero) zero_words[gid] = 0; }   // the histogram / slot counters are not needed any more: leave them cleared for the next run (saves a memset launch at the head of every MSM)
   const uint32_t n_big = cls_start[1], n_multi = cls_start[BSORT_CLASSES - 1 - MSM_TASK];   // ranks below: count >= 63 (the only class that can hold more than COMBINE_QUAD_MAX tasks), count > 16
   if (blockIdx.x < heavy_blocks) {
     for (uint32_t r = blockIdx.x; r < n_big; r += heavy_blocks) { uint32_t beg = task_off[r], nt = task_off[r + 1] - beg; if (nt <= COMBINE_QUAD_MAX) continue;
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(64) k_msm_reduce_segments(const XYZZ<F> *__res
 // ---- generic grouped sum: out[g] = sum_{j<len} in[g*len + j] (the last group may be short: n_in elements in total), one 256-thread workgroup per group.
 // copy_src/copy_dst (optional): 16 bytes carried along by block 0 (the MSM counters travel to the host next to the result)
 template <class F>
-__global__ void __launch_bounds__(256) k_xyzz_group_sum(const XYZZ<F> *__restrict__ in, uint32_t len, uint32_t n_in, XYZZ<F> *__restrict__ out, const uint4 *copy_src, uint4 *copy_dst) {
+__global__ void __launch_bounds__(256) k_xyzz_group_sum(const XYZZ<F> *__restrict__ in, uint32_t len, uint32_t n_in, XYZZ<F> *__restrict__ out, uint4 *copy_src, uint4 *copy_dst) {
   __shared__ XYZZ<F> lds[4]; uint32_t g = blockIdx.x, beg = g * len, l = beg >= n_in ? 0 : min(len, n_in - beg);
   XYZZ<F> acc = block_quad_sum(in + beg, l, lds);
   if (threadIdx.x == 0) { out[g] = acc; if (copy_src && g == 0) *copy_dst = *copy_src; }

@@ -21,7 +21,9 @@ struct MsmImpl {
 
   uint32_t *hist() { return zeroed.get(); }
   uint32_t *fill() { return zeroed.get() + (size_t)WB * NB; }
-  MsmCounters *counters() { return (MsmCounters *)(zeroed.get() + 2 * (size_t)WB * NB); }
+  int parity = 0;                                                   // which of the two counter slots the current run uses
+  MsmCounters *counters() { return (MsmCounters *)(zeroed.get() + 2 * (size_t)WB * NB) + parity; }
+  MsmCounters *counters_next() { return (MsmCounters *)(zeroed.get() + 2 * (size_t)WB * NB) + (parity ^ 1); }
   size_t result_bytes() const { return (size_t)(WB + 1) * sizeof(XYZZ<F>) + sizeof(MsmCounters); }
   const XYZZ<F> *host_sums() const { return (const XYZZ<F> *)h_result; }
   const MsmCounters *host_counters() const { return (const MsmCounters *)(h_result + (size_t)(WB + 1) * sizeof(XYZZ<F>)); }
@@ -34,7 +36,7 @@ struct MsmImpl {
     return on && n_ > 0 && W_ > 1 && n_ * (size_t)W_ < (1ull << 31) && n_ * (size_t)W_ * sizeof(RawAffine) <= cap; }
   MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true, bool uniform_hint = false)
       : n(n_), c(c_), W(msm_num_windows(c_)), WB(tables && use_precompute(n_, msm_num_windows(c_)) ? 1 : msm_num_windows(c_)), NB(1u << (c_ - 1)), filter_ones(fo), points((n_ ? n_ : 1) * (size_t)(WB == 1 ? W : 1)), inf(n_ ? n_ : 1),
-        zeroed(2 * (size_t)WB * NB + sizeof(MsmCounters) / 4), offsets((size_t)WB * NB), entries((n_ ? n_ : 1) * (size_t)W), ones(n_ ? n_ : 1), ntasks((size_t)WB * NB + 1), task_off((size_t)WB * NB + 1), cls_start(BSORT_CLASSES),
+        zeroed(2 * (size_t)WB * NB + 2 * sizeof(MsmCounters) / 4), offsets((size_t)WB * NB), entries((n_ ? n_ : 1) * (size_t)W), ones(n_ ? n_ : 1), ntasks((size_t)WB * NB + 1), task_off((size_t)WB * NB + 1), cls_start(BSORT_CLASSES),
         scanner((size_t)WB * NB), task_scanner((size_t)WB * NB + 1) {
     if (c < 6 || c > 20 || W > MSM_MAX_WINDOWS) throw GpuError("msm: unsupported window size");
     { const char *e = getenv("ZK_MSM_SEG"); uint32_t big = e ? (uint32_t)atoi(e) : 16; if (big < 2 || big > 256 || (big & (big - 1))) big = 16; seg = NB >= 4096 ? (WB == 1 ? 4 : big) : 4; }   // one bucket array: few segments, keep the dependent chain short
@@ -56,7 +58,7 @@ struct MsmImpl {
     buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>((size_t)max_tasks * sizeof(XYZZ<F>));
     seg_out = DevBuf<uint8_t>((size_t)WB * (NB / seg) * sizeof(XYZZ<F>)); seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
     ones_partial = DevBuf<uint8_t>((size_t)n_ones_quads * sizeof(XYZZ<F>)); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
-    result = DevBuf<uint8_t>(result_bytes()); result.zero();          // the ones slot stays the point at infinity when the ones path is off
+    zeroed.zero(); result = DevBuf<uint8_t>(result_bytes()); result.zero();          // the ones slot stays the point at infinity when the ones path is off
     HIP_CHECK(hipHostMalloc((void **)&h_result, result_bytes())); HIP_CHECK(hipStreamSynchronize(gpu().stream));
   }
   ~MsmImpl() { if (h_result) hipHostFree(h_result); if (ones_stream) hipStreamDestroy(ones_stream); if (ev_classified) hipEventDestroy(ev_classified); if (ev_ones) hipEventDestroy(ev_ones); }
@@ -69,16 +71,17 @@ struct MsmImpl {
   void run(const Fe32 *scalars, const uint32_t *scalar_index) {
     hipStream_t s = stream(); size_t nbk = (size_t)WB * NB; const uint32_t hist_stride = WB == 1 ? 0 : NB, point_stride = WB == 1 && W > 1 ? (uint32_t)n : 0; const uint8_t *infp = any_inf ? inf.get() : nullptr; MsmCounters *cnt = counters();
     const uint32_t bucket_u4 = sizeof(XYZZ<F>) / 16; XYZZ<F> *res = (XYZZ<F> *)result.get();
-    HIP_CHECK(hipMemsetAsync(zeroed.get(), 0, zeroed.size() * 4, s));
+    // (histogram and slot counters were cleared by the constructor and are left cleared by every run (k_msm_combine_tasks); the MsmCounters alternate between two slots)
+    parity ^= 1; cnt = counters();
     bool ones_forked = false;
     auto ones_path = [&](hipStream_t os) { Stage st((label + ".ones").c_str(), os); uint32_t g = cdiv(n_ones_quads, GROUP);
       hipLaunchKernelGGL((k_msm_sum_ones<F>), dim3(cdiv((size_t)n_ones_quads * 4, 256)), dim3(256), 0, os, (const Affine<F> *)points.get(), ones.get(), cnt, n_ones_quads, (XYZZ<F> *)ones_partial.get());
-      hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(g), dim3(256), 0, os, (const XYZZ<F> *)ones_partial.get(), GROUP, n_ones_quads, (XYZZ<F> *)ones_l2.get(), (const uint4 *)nullptr, (uint4 *)nullptr);
-      hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(256), 0, os, (const XYZZ<F> *)ones_l2.get(), g, g, res + WB, (const uint4 *)nullptr, (uint4 *)nullptr); };
+      hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(g), dim3(256), 0, os, (const XYZZ<F> *)ones_partial.get(), GROUP, n_ones_quads, (XYZZ<F> *)ones_l2.get(), (uint4 *)nullptr, (uint4 *)nullptr);
+      hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(256), 0, os, (const XYZZ<F> *)ones_l2.get(), g, g, res + WB, (uint4 *)nullptr, (uint4 *)nullptr); };
     last_scalars = scalars; last_index = scalar_index;
     if (direct) { Stage st((label + ".sort").c_str(), s);
       if (!offsets_direct) { std::vector<uint32_t> o(nbk); for (size_t b = 0; b < nbk; b++) o[b] = (uint32_t)(b * cap); offsets.upload(o.data(), nbk); offsets_direct = true; }
-      hipLaunchKernelGGL(k_msm_scatter_direct<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, point_stride, cap, hist(), entries.get(), cnt);
+      hipLaunchKernelGGL(k_msm_scatter_direct<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, point_stride, cap, hist(), entries.get(), cnt, counters_next());
       if (nbk <= PLAN_DIRECT_MAX && cap <= 4080) hipLaunchKernelGGL(k_msm_plan_direct, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, cap, task, order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
       else {
         hipLaunchKernelGGL(k_bsort_hist, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_hist.get(), cap);
@@ -88,7 +91,7 @@ struct MsmImpl {
       }
     } else
     { Stage st((label + ".sort").c_str(), s);
-      if (n) hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, (uint32_t)nbk, hist(), ones.get(), cnt);
+      if (n) hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, (uint32_t)nbk, hist(), ones.get(), cnt, counters_next());
       if (filter_ones && n && split_ones && !profiling_enabled()) { HIP_CHECK(hipEventRecord(ev_classified, s)); HIP_CHECK(hipStreamWaitEvent(ones_stream, ev_classified, 0)); ones_path(ones_stream); HIP_CHECK(hipEventRecord(ev_ones, ones_stream)); ones_forked = true; }
       if (nbk <= PLAN_SMALL_MAX) {
         hipLaunchKernelGGL(k_msm_plan_small, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, offsets.get(), order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
@@ -107,13 +110,13 @@ struct MsmImpl {
     }
     { Stage st((label + ".combine").c_str(), s);
       const uint32_t heavy = direct && cap <= COMBINE_QUAD_MAX * task ? 0u : HEAVY_BLOCKS;   // one-pass sort: no bucket can hold more than `cap` entries, so none needs a whole workgroup
-      hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(heavy + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), heavy, (const XYZZ<F> *)partials.get(), (XYZZ<F> *)buckets.get());
+      hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(heavy + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), heavy, (const XYZZ<F> *)partials.get(), (XYZZ<F> *)buckets.get(), zeroed.get(), (uint32_t)(2 * nbk));
     }
     { Stage st_red((label + ".reduce").c_str(), s);
-      uint32_t spw = NB / seg, nseg = (uint32_t)WB * spw; const uint4 *csrc = (const uint4 *)cnt; uint4 *cdst = (uint4 *)(res + WB + 1);
+      uint32_t spw = NB / seg, nseg = (uint32_t)WB * spw; uint4 *csrc = (uint4 *)cnt; uint4 *cdst = (uint4 *)(res + WB + 1);
       hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3(cdiv(nseg, 16)), dim3(64), 0, s, (const XYZZ<F> *)buckets.get(), NB, seg, nseg, (XYZZ<F> *)seg_out.get());
       if (spw > GROUP) { uint32_t g = spw / GROUP;   // two-level tree per window keeps the dependent chain short (spw is a power of two)
-        hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(WB * g), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), GROUP, nseg, (XYZZ<F> *)seg_l2.get(), (const uint4 *)nullptr, (uint4 *)nullptr);
+        hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(WB * g), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), GROUP, nseg, (XYZZ<F> *)seg_l2.get(), (uint4 *)nullptr, (uint4 *)nullptr);
         hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(WB), dim3(256), 0, s, (const XYZZ<F> *)seg_l2.get(), g, (uint32_t)WB * g, res, csrc, cdst);
       } else hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(WB), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), spw, nseg, res, csrc, cdst);
     }
