@@ -29,8 +29,22 @@ __global__ void __launch_bounds__(64) k_ecntt_stage(XYZZ<Fq> *__restrict__ data,
   if (j) d = xyzz_mul_fr(d, tw[j << (logm - s)]);
   data[i0] = sum; data[i1] = d;
 }
+// Step-radix-2 domains (m = B + S, step_radix2_domain.tcc:79-140): the inverse transform is  Post . (iFFT_B (+) iFFT_S)  with the recombination pass
+//   u1' = w^-i (U1[i] - sum_{k>=1} w^(i+kS) U0[i+kS]);  out[i] = (U0[i] + u1')/2;  out[B+i] = (U0[i] - u1')/2  (i < S);  out[i] = U0[i]  (S <= i < B),
+// so the query needs the TRANSPOSE applied to its (coset-scaled) points Q: first Post^T below, with the 1/B and 1/S of the two inverse transforms folded in,
+// then the two inverse DFTs over group elements (k_ecntt_stage on each part).
+//   R0[j] = (Q[j] + Q[B+j]) / (2B)                                  j < S
+//   R0[j] = Q[j] / B + (w^(j-i) / (2B)) (Q[B+i] - Q[i])              S <= j < B, i = j mod S
+//   R1[i] = (w^-i / (2S)) (Q[i] - Q[B+i])                            i < S
+__global__ void __launch_bounds__(64) k_ecntt_step_pre(const XYZZ<Fq> *__restrict__ Q, XYZZ<Fq> *__restrict__ R, const Fr *__restrict__ wpow, const Fr *__restrict__ winvpow, Fr half_inv_b, Fr inv_b, Fr half_inv_s, uint32_t B, uint32_t S) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= B + S) return;
+  if (t < B) { const uint32_t j = t, i = j % S;
+    if (j < S) { XYZZ<Fq> a = Q[j]; a.add_inl(Q[B + j]); R[j] = xyzz_mul_fr(a, half_inv_b); }
+    else { XYZZ<Fq> d = Q[B + i]; d.add_inl(Q[i].neg()); XYZZ<Fq> r = xyzz_mul_fr(Q[j], inv_b); r.add_inl(xyzz_mul_fr(d, wpow[j - i] * half_inv_b)); R[j] = r; }
+  } else { const uint32_t i = t - B; XYZZ<Fq> d = Q[i]; d.add_inl(Q[B + i].neg()); R[B + i] = xyzz_mul_fr(d, winvpow[i] * half_inv_s); }
+}
 // out[bitrev(p)] = affine(data[p])
-__global__ void __launch_bounds__(64) k_ecntt_finish(const XYZZ<Fq> *__restrict__ data, int logm, Affine<Fq> *__restrict__ out) {
+__global__ void __launch_bounds__(64) k_ecntt_finish(const XYZZ<Fq> *__restrict__ data, int logm, Affine<Fq> *__restrict__ out) {   // (data / out already offset to the sub-transform)
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; if (p >= (1u << logm)) return; const XYZZ<Fq> q = data[p]; const uint32_t r = __brev(p) >> (32 - logm);
   if (q.is_inf()) { out[r] = Affine<Fq>::inf(); return; }
   Fq t = (q.ZZ * q.ZZZ).inv(); out[r] = {q.X * (t * q.ZZZ), q.Y * (t * q.ZZ)};

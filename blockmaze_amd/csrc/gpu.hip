@@ -230,14 +230,22 @@ void Domain::icoset_fft(Fe32 *data, int batch, size_t stride) {
     return; }
   ifft(data, batch, stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride);
 }
-// see ecntt.cuh: the H query (m - 1 points) in the Lagrange basis of the coset (m points).  Basic radix-2 domains only.
-bool Domain::supports_h_lagrange() const { return !impl->step; }
+// see ecntt.cuh: the H query (m - 1 points) in the Lagrange basis of the coset (m points), for both kinds of domain
+bool Domain::supports_h_lagrange() const { return true; }
 void Domain::h_query_to_coset_lagrange(const G1AffineRaw *h, size_t n_in, G1AffineRaw *out) {
-  Impl &d = *impl; if (d.step || n_in > d.m) throw GpuError("domain: h_query_to_coset_lagrange"); hipStream_t s = gpu().stream; const int logm = d.big->logn; const size_t m = d.m;
-  DevBuf<G1AffineRaw> din(n_in ? n_in : 1), dout(m); DevBuf<uint8_t> data(m * sizeof(XYZZ<Fq>)); if (n_in) din.upload(h, n_in);
-  hipLaunchKernelGGL(k_ecntt_prescale, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)din.get(), (uint32_t)n_in, (const Fr *)d.coset_inv.get(), (uint32_t)m, (XYZZ<Fq> *)data.get());   // coset_inv[i] = g^-i / m
-  for (int st = logm; st >= 1; st--) hipLaunchKernelGGL(k_ecntt_stage, dim3(cdiv(m / 2, 64)), dim3(64), 0, s, (XYZZ<Fq> *)data.get(), (const Fr *)d.big->itw.get(), logm, st);
-  hipLaunchKernelGGL(k_ecntt_finish, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)data.get(), logm, (Affine<Fq> *)dout.get());
+  Impl &d = *impl; if (n_in > d.m) throw GpuError("domain: h_query_to_coset_lagrange"); hipStream_t s = gpu().stream; const size_t m = d.m;
+  DevBuf<G1AffineRaw> din(n_in ? n_in : 1), dout(m); DevBuf<uint8_t> data(m * sizeof(XYZZ<Fq>)); if (n_in) din.upload(h, n_in); XYZZ<Fq> *X = (XYZZ<Fq> *)data.get();
+  auto idft = [&](XYZZ<Fq> *part, const Radix2Tables &t, Affine<Fq> *o) {   // unscaled inverse DFT over group elements, natural order in, natural order out (bit reversal in the final conversion)
+    for (int st = t.logn; st >= 1; st--) hipLaunchKernelGGL(k_ecntt_stage, dim3(cdiv(t.n / 2, 64)), dim3(64), 0, s, part, (const Fr *)t.itw.get(), t.logn, st);
+    hipLaunchKernelGGL(k_ecntt_finish, dim3(cdiv(t.n, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)part, t.logn, o); };
+  hipLaunchKernelGGL(k_ecntt_prescale, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)din.get(), (uint32_t)n_in, (const Fr *)d.coset_inv.get(), (uint32_t)m, X);   // basic: g^-i / m; step: g^-i
+  if (!d.step) idft(X, *d.big, (Affine<Fq> *)dout.get());
+  else {
+    DevBuf<uint8_t> data2(m * sizeof(XYZZ<Fq>)); XYZZ<Fq> *R = (XYZZ<Fq> *)data2.get();
+    HFr ib = HFr::from_u64(d.B).inv(), is = HFr::from_u64(d.S).inv(), hib = d.half * ib, his = d.half * is; Fr f_hib, f_ib, f_his; memcpy(&f_hib, hib.l, 32); memcpy(&f_ib, ib.l, 32); memcpy(&f_his, his.l, 32);
+    hipLaunchKernelGGL(k_ecntt_step_pre, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, R, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), f_hib, f_ib, f_his, (uint32_t)d.B, (uint32_t)d.S);
+    idft(R, *d.big, (Affine<Fq> *)dout.get()); idft(R + d.B, *d.small, (Affine<Fq> *)dout.get() + d.B);
+  }
   HIP_CHECK(hipGetLastError()); dout.download(out, m);
 }
 void Domain::qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c) {
