@@ -50,4 +50,36 @@ __global__ void __launch_bounds__(64) k_ecntt_finish(const XYZZ<Fq> *__restrict_
   Fq t = (q.ZZ * q.ZZZ).inv(); out[r] = {q.X * (t * q.ZZZ), q.Y * (t * q.ZZ)};
 }
 
+// ---- the C polynomial folded into the L query (key load, radix-2 domains) -----------------------------------------------
+// With P the coset-Lagrange H query, the H term of the proof is  sum_j zinv (A_j B_j - C_j) P_j  (A_j, B_j, C_j: values on the coset).  The C part is LINEAR in the
+// assignment: C_j = (cosetFFT . iFFT)(c)_j with c_k = <C_k, z>, so  sum_j zinv C_j P_j = sum_k c_k U_k = sum_v z_v (sum_k C_kv U_k)  with
+// U = iFFT^T cosetFFT^T (zinv P) — two more DFTs over group elements and one sparse pass at key load.  Subtracting the per-variable points from the L query
+// (extended to all variables) removes the two transforms of C, and the C rows, from every proof; the proof's C element is the same group element.
+__device__ __forceinline__ XYZZ<Fq> xyzz_mul_canon(const XYZZ<Fq> &p, const Fr &k) {   // like xyzz_mul_fr for a canonical (non-Montgomery) scalar
+  XYZZ<Fq> r = XYZZ<Fq>::inf(); bool started = false;
+#pragma unroll 1
+  for (int i = 255; i >= 0; i--) { if (started) r = r.dbl_inl(); if ((k.l[i >> 5] >> (i & 31)) & 1) { if (started) r.add_inl(p); else { r = p; started = true; } } }
+  return r;
+}
+// data[i] = k * P_i (one scalar for all)
+__global__ void __launch_bounds__(64) k_ecntt_scale_const(const Affine<Fq> *__restrict__ pts, Fr k_mont, uint32_t m, XYZZ<Fq> *__restrict__ data) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= m) return; data[i] = xyzz_mul_fr(XYZZ<Fq>::from_affine(pts[i]), k_mont);
+}
+// out[bitrev(p)] = scale[bitrev(p)] * in[p]: back to natural order between two transforms, with the diagonal factor in between
+__global__ void __launch_bounds__(64) k_ecntt_permute_scale(const XYZZ<Fq> *__restrict__ in, const Fr *__restrict__ scale, int logm, XYZZ<Fq> *__restrict__ out) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; if (p >= (1u << logm)) return; const uint32_t r = __brev(p) >> (32 - logm); out[r] = xyzz_mul_fr(in[p], scale[r]);
+}
+// Lstar[v] = (v > n_inputs ? L[v - n_inputs - 1] : 0) - sum over the entries (k, coefficient) of column v of C of coefficient * U[k]; U is held bit-reversed.
+// kind[e]: 0 = +1, 1 = -1, 2 = general (coef[e], canonical)
+__global__ void __launch_bounds__(64) k_fold_c_columns(const uint32_t *__restrict__ colptr, const uint32_t *__restrict__ rowidx, const uint8_t *__restrict__ kind, const Fr *__restrict__ coef,
+                                                       const XYZZ<Fq> *__restrict__ U_bitrev, int logm, const Affine<Fq> *__restrict__ L, uint32_t n_inputs, uint32_t n_all, Affine<Fq> *__restrict__ out) {
+  uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; if (v >= n_all) return; XYZZ<Fq> acc = XYZZ<Fq>::inf();
+#pragma unroll 1
+  for (uint32_t e = colptr[v]; e < colptr[v + 1]; e++) { XYZZ<Fq> u = U_bitrev[__brev(rowidx[e]) >> (32 - logm)]; uint8_t kd = kind[e];
+    if (kd == 2) u = xyzz_mul_canon(u, coef[e]); else if (kd == 1) u = u.neg(); acc.add_inl(u); }
+  acc = acc.neg(); if (v > n_inputs) acc.madd_inl(L[v - n_inputs - 1]);
+  if (acc.is_inf()) { out[v] = Affine<Fq>::inf(); return; }
+  Fq t = (acc.ZZ * acc.ZZZ).inv(); out[v] = {acc.X * (t * acc.ZZZ), acc.Y * (t * acc.ZZ)};
+}
+
 }  // namespace zk

@@ -248,6 +248,32 @@ void Domain::h_query_to_coset_lagrange(const G1AffineRaw *h, size_t n_in, G1Affi
   }
   HIP_CHECK(hipGetLastError()); dout.download(out, m);
 }
+// see ecntt.cuh: Lstar (n_vars + 1 points) = L extended to all variables minus the C polynomial's share of the H term
+bool Domain::supports_c_fold() const { return !impl->step; }
+void Domain::fold_c_into_l(const G1AffineRaw *h_lagrange, const R1csHost &cs, const G1AffineRaw *L, G1AffineRaw *out) {
+  Impl &d = *impl; if (d.step) throw GpuError("domain: fold_c_into_l on a step domain"); hipStream_t s = gpu().stream; const size_t m = d.m, n_all = cs.n_vars + 1; const int logm = d.big->logn;
+  // column form of C; coefficients classified so that +-1 cost an addition only
+  std::vector<uint32_t> colptr(n_all + 1, 0); const std::vector<uint32_t> &rp = cs.rowptr[2], &cl = cs.col[2]; size_t nnz = cl.size();
+  for (size_t e = 0; e < nnz; e++) colptr[cl[e] + 1]++; for (size_t v = 0; v < n_all; v++) colptr[v + 1] += colptr[v];
+  std::vector<uint32_t> rowidx(nnz ? nnz : 1), fillp(colptr.begin(), colptr.end() - 1); std::vector<uint8_t> kind(nnz ? nnz : 1); std::vector<Fe32> coef(nnz ? nnz : 1);
+  Fe32 one{}; one.l[0] = 1; Fe32 minus_one; { HFr mo = HFr::one().neg().from_mont(); memcpy(&minus_one, mo.l, 32); }
+  for (size_t k = 0; k < cs.n_cons; k++) for (uint32_t e = rp[k]; e < rp[k + 1]; e++) { uint32_t pos = fillp[cl[e]]++; rowidx[pos] = (uint32_t)k; coef[pos] = cs.coeff[2][e];
+    kind[pos] = !memcmp(&cs.coeff[2][e], &one, 32) ? 0 : !memcmp(&cs.coeff[2][e], &minus_one, 32) ? 1 : 2; }
+  DevBuf<uint32_t> d_colptr(n_all + 1), d_rowidx(rowidx.size()); DevBuf<uint8_t> d_kind(kind.size()); DevBuf<Fe32> d_coef(coef.size());
+  d_colptr.upload(colptr.data(), colptr.size()); d_rowidx.upload(rowidx.data(), rowidx.size()); d_kind.upload(kind.data(), kind.size()); d_coef.upload(coef.data(), coef.size());
+  DevBuf<G1AffineRaw> dp(m), dl(cs.n_vars - cs.n_inputs ? cs.n_vars - cs.n_inputs : 1), dout(n_all); dp.upload(h_lagrange, m); if (cs.n_vars > cs.n_inputs) dl.upload(L, cs.n_vars - cs.n_inputs);
+  DevBuf<uint8_t> b0(m * sizeof(XYZZ<Fq>)), b1(m * sizeof(XYZZ<Fq>)); XYZZ<Fq> *X = (XYZZ<Fq> *)b0.get(), *Y = (XYZZ<Fq> *)b1.get();
+  HFr zinv; { Fe32 z; d.zinv.download(&z, 1); memcpy(zinv.l, &z, 32); } Fr fz; memcpy(&fz, zinv.l, 32);
+  std::vector<Fe32> gm = geometric_table(m, HFr::from_u64(m).inv(), fr_coset_gen()); DevBuf<Fe32> d_gm(m); d_gm.upload(gm.data(), m);                              // g^i / m
+  auto dft = [&](XYZZ<Fq> *x, const Fe32 *tw) { for (int st = logm; st >= 1; st--) hipLaunchKernelGGL(k_ecntt_stage, dim3(cdiv(m / 2, 64)), dim3(64), 0, s, x, (const Fr *)tw, logm, st); };
+  hipLaunchKernelGGL(k_ecntt_scale_const, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)dp.get(), fz, (uint32_t)m, X);                                    // zinv * P
+  dft(X, d.big->tw.get());                                                                                                                                         // cosetFFT^T = D_g . DFT_w: the DFT ...
+  hipLaunchKernelGGL(k_ecntt_permute_scale, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, (const Fr *)d_gm.get(), logm, Y);                              // ... then g^i, with the 1/m of the inverse transform
+  dft(Y, d.big->itw.get());                                                                                                                                        // iFFT^T = (1/m) DFT_(1/w); result bit-reversed
+  hipLaunchKernelGGL(k_fold_c_columns, dim3(cdiv(n_all, 64)), dim3(64), 0, s, d_colptr.get(), d_rowidx.get(), d_kind.get(), (const Fr *)d_coef.get(), (const XYZZ<Fq> *)Y, logm,
+                     (const Affine<Fq> *)dl.get(), (uint32_t)cs.n_inputs, (uint32_t)n_all, (Affine<Fq> *)dout.get());
+  HIP_CHECK(hipGetLastError()); dout.download(out, n_all);
+}
 void Domain::qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c) {
   hipLaunchKernelGGL(k_qap_pointwise, dim3(cdiv(impl->m, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (const Fr *)b, (const Fr *)c, (const Fr *)impl->zinv.get(), impl->step ? 1 : 0, (uint32_t)impl->m);
 }

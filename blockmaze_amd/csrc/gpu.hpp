@@ -80,6 +80,7 @@ class BatchVerifier {
 
 // Evaluation domain of size m = 2^k or 2^k + 2^r (libfqfft get_evaluation_domain, get_evaluation_domain.tcc:33-52) with
 // its twiddle / coset tables resident in HBM.
+struct R1csHost;
 class Domain {
  public:
   explicit Domain(size_t min_size); ~Domain();
@@ -89,7 +90,9 @@ class Domain {
   void coset_fft(Fe32 *data, int batch, size_t stride); void icoset_fft(Fe32 *data, int batch, size_t stride);
   // key load: the H query (n_in = m - 1 affine points) re-expressed so that sum_j v_j out_j = sum_i icosetFFT(v)_i h_i: the prover then skips the last transform (ecntt.cuh)
   bool supports_h_lagrange() const; void h_query_to_coset_lagrange(const G1AffineRaw *h, size_t n_in, G1AffineRaw *out /* m points */);
-  // a = (a*b - c) / Z on the coset
+  // key load, radix-2 domains: out (n_vars + 1 points) = the L query extended to all variables minus the C polynomial's share of the H term; the prover then transforms A and B only (ecntt.cuh)
+  bool supports_c_fold() const; void fold_c_into_l(const G1AffineRaw *h_lagrange /* m */, const R1csHost &cs, const G1AffineRaw *L /* n_vars - n_inputs */, G1AffineRaw *out);
+  // a = (a*b - c) / Z on the coset (c may be null: a = a*b / Z)
   void qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c);
   struct Impl; std::unique_ptr<Impl> impl;
 };

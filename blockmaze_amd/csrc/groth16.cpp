@@ -203,6 +203,7 @@ class SubmitWorker {
 };
 struct Prover::Impl {
   bool h_lagrange = false;                                     // the H query is held in the coset's Lagrange basis: no inverse coset transform per proof
+  bool c_fold = false;                                         // the C polynomial's share of the H term lives in the (extended) L query: A and B are the only vectors transformed
   int lane = 0;                                                // this prover's stream set: provers on different lanes overlap on the device
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
@@ -217,12 +218,16 @@ Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) 
   if (pk.A.size() != p.nv + 1 || pk.H.size() != p.m - 1 || pk.L.size() != p.nv - p.ni) throw std::runtime_error("proving key: query sizes do not match the constraint system");
   p.alpha_g1 = g1_of(pk.alpha_g1); p.beta_g1 = g1_of(pk.beta_g1); p.delta_g1 = g1_of(pk.delta_g1); p.beta_g2 = g2_of(pk.beta_g2); p.delta_g2 = g2_of(pk.delta_g2);
   int cw = env_int("ZK_MSM_WITNESS_WINDOW", 8), ch = env_int("ZK_MSM_H_WINDOW", 16);
-  size_t e; shard_range(pk.A.size(), shard_rank, shard_world, p.a0, e); size_t nA = e - p.a0; shard_range(pk.L.size(), shard_rank, shard_world, p.l0, e); size_t nL = e - p.l0;
+  size_t e; shard_range(pk.A.size(), shard_rank, shard_world, p.a0, e); size_t nA = e - p.a0;
   shard_range(pk.B_idx.size(), shard_rank, shard_world, p.b0, e); size_t nB = e - p.b0; // H query: in the coset's Lagrange basis when the domain allows it (then the seventh transform of every proof is skipped, ecntt.cuh); computed once per key object
   const std::vector<G1AffineRaw> *Hq = &pk.H; p.h_lagrange = env_int("ZK_H_LAGRANGE", 1) != 0 && p.dom->supports_h_lagrange();
   if (p.h_lagrange) { if (pk.H_lagrange.size() != p.m) { pk.H_lagrange.resize(p.m); p.dom->h_query_to_coset_lagrange(pk.H.data(), pk.H.size(), pk.H_lagrange.data()); } Hq = &pk.H_lagrange; }
   shard_range(Hq->size(), shard_rank, shard_world, p.h0, e); size_t nH = e - p.h0;
-  p.A.reset(new MsmG1(pk.A.data() + p.a0, nA, cw, true)); p.L.reset(new MsmG1(pk.L.data() + p.l0, nL, cw, true));
+  // L query: extended to all variables with the C polynomial folded in when the domain allows it (ecntt.cuh); computed once per key object
+  const std::vector<G1AffineRaw> *Lq = &pk.L; p.c_fold = p.h_lagrange && env_int("ZK_FOLD_C", 1) != 0 && p.dom->supports_c_fold();
+  if (p.c_fold) { if (pk.L_star.size() != p.nv + 1) { pk.L_star.resize(p.nv + 1); p.dom->fold_c_into_l(pk.H_lagrange.data(), pk.cs, pk.L.data(), pk.L_star.data()); } Lq = &pk.L_star; }
+  shard_range(Lq->size(), shard_rank, shard_world, p.l0, e); size_t nL = e - p.l0;
+  p.A.reset(new MsmG1(pk.A.data() + p.a0, nA, cw, true)); p.L.reset(new MsmG1(Lq->data() + p.l0, nL, cw, true));
   p.B1.reset(new MsmG1(pk.B_g1.data() + p.b0, nB, cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data() + p.b0, nB, cw, true)); p.H.reset(new MsmG1(Hq->data() + p.h0, nH, ch, false, env_int("ZK_MSM_H_TABLES", 1) != 0, true));   // (with tables the H accumulation gathers from a table 16x larger and slows from 0.40 to 0.51 ms, but the reduction drops from 0.53 to 0.23 ms: measured 3 % better per proof, 10 % better with four proofs in flight)
   p.A->set_stream(0); p.L->set_stream(1); p.B1->set_stream(2); p.B2->set_stream(3); if (env_int("ZK_MSM_SPLIT_ONES", 1)) p.B2->split_ones_path();   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
   p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
@@ -253,7 +258,7 @@ static void enqueue_all(Prover::Impl &p) {
   // about 80 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
   // (auxiliary streams) while this one submits the critical chain
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
-  std::function<void()> jobs[4] = { [&] { p.B2->run(p.z.get(), p.B_idx.get() + p.b0); }, [&] { p.L->run(p.z.get() + p.ni + 1 + p.l0, nullptr); },       // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
+  std::function<void()> jobs[4] = { [&] { p.B2->run(p.z.get(), p.B_idx.get() + p.b0); }, [&] { p.L->run(p.z.get() + (p.c_fold ? 0 : p.ni + 1) + p.l0, nullptr); },       // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
                                     [&] { p.A->run(p.z.get() + p.a0, nullptr); }, [&] { p.B1->run(p.z.get(), p.B_idx.get() + p.b0); } };
   const int job_stream[4] = {3, 1, 0, 2};                       // the auxiliary stream each MSM was bound to in the constructor (set_stream)
   const bool use_threads = threaded && !gpu_capturing() && !profiling_enabled();   // (the stage timers are not thread-safe: profiling runs submit from one thread)
@@ -265,8 +270,9 @@ static void enqueue_all(Prover::Impl &p) {
   release(0);
   p.cs->eval(p.z.get(), p.abc.get(), p.m); release(1);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
-  p.dom->ifft(p.abc.get(), 3, p.m); release(2);
-  p.dom->coset_fft(p.abc.get(), 3, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.abc.get() + 2 * p.m); release(3);
+  const int nvec = p.c_fold ? 2 : 3;                          // A, B (and C unless it is folded into the L query)
+  p.dom->ifft(p.abc.get(), nvec, p.m); release(2);
+  p.dom->coset_fft(p.abc.get(), nvec, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.c_fold ? nullptr : p.abc.get() + 2 * p.m); release(3);
   if (!p.h_lagrange) p.dom->icoset_fft(p.abc.get(), 1, p.m);
   release(4);
   p.H->run(p.abc.get() + p.h0, nullptr);                                                                                  // :466-473

@@ -16,6 +16,7 @@ struct ProvingKeyHost {                           // r1cs_gg_ppzksnark.hpp:72-11
   std::vector<G1AffineRaw> A;                     // n_vars + 1 (entries may be infinity)
   std::vector<uint32_t> B_idx; std::vector<G2AffineRaw> B_g2; std::vector<G1AffineRaw> B_g1;   // sparse knowledge-commitment vector
   std::vector<G1AffineRaw> H;                     // m - 1
+  mutable std::vector<G1AffineRaw> L_star;        // likewise: n_vars + 1 points, the L query extended to all variables minus the C polynomial's share of the H term (ecntt.cuh)
   mutable std::vector<G1AffineRaw> H_lagrange;    // filled by the first Prover built on this key: H in the Lagrange basis of the coset, m points (ecntt.cuh)
   std::vector<G1AffineRaw> L;                     // n_vars - n_inputs
   R1csHost cs;                                    // as stored in the key (A/B already swapped if the generator found it beneficial)

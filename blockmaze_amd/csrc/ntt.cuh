@@ -132,7 +132,7 @@ __global__ void k_fr_mul_table(Fr *__restrict__ a, const Fr *__restrict__ table,
 }
 // h[i] = (a[i]*b[i] - c[i]) * zinv[i or 0]   (r1cs_to_qap.tcc:281-310: H_tmp = A*B - C, then divide_by_Z_on_coset)
 __global__ void k_qap_pointwise(Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ c, const Fr *__restrict__ zinv, int zinv_is_table, uint32_t n) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; a[i] = (a[i] * b[i] - c[i]) * zinv[zinv_is_table ? i : 0];
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; Fr t = a[i] * b[i]; if (c) t = t - c[i]; a[i] = t * zinv[zinv_is_table ? i : 0];   // c == nullptr: the C polynomial is folded into the L query (ecntt.cuh)
 }
 __global__ void k_fr_to_mont(Fr *__restrict__ a, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = a[i].to_mont(); }
 __global__ void k_fr_from_mont(Fr *__restrict__ a, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) a[i] = a[i].from_mont(); }
