@@ -69,13 +69,31 @@ __global__ void __launch_bounds__(64) k_ecntt_scale_const(const Affine<Fq> *__re
 __global__ void __launch_bounds__(64) k_ecntt_permute_scale(const XYZZ<Fq> *__restrict__ in, const Fr *__restrict__ scale, int logm, XYZZ<Fq> *__restrict__ out) {
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; if (p >= (1u << logm)) return; const uint32_t r = __brev(p) >> (32 - logm); out[r] = xyzz_mul_fr(in[p], scale[r]);
 }
+// Step domains: the forward transform is  (DFT_B (+) DFT_S) . Pre  with  c[i] = a[i] + [i<S] a[i+B],  d[t] = w^t (a[t] - [t<S] a[t+B]),  e[i] = sum_j d[i + jS]
+// (step_radix2_domain.tcc:39-77), preceded by the coset factor g^i.  Its transpose on points: the two DFTs of the parts, then
+//   T[t] = g^t (C'[t] + w^t E'[t mod S])  (t < B),      T[B+t] = g^(B+t) (C'[t] - w^t E'[t])  (t < S),
+// C' / E' being the transformed parts (held bit-reversed after the DIF stages).
+__global__ void __launch_bounds__(64) k_ecntt_step_fwd_T(const XYZZ<Fq> *__restrict__ Cb, const XYZZ<Fq> *__restrict__ Eb, int logB, int logS, const Fr *__restrict__ wpow, const Fr *__restrict__ gpow, XYZZ<Fq> *__restrict__ T) {
+  const uint32_t B = 1u << logB, S = 1u << logS; uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= B) return;
+  const XYZZ<Fq> c = Cb[__brev(t) >> (32 - logB)]; XYZZ<Fq> we = xyzz_mul_fr(Eb[__brev(t % S) >> (32 - logS)], wpow[t]);
+  XYZZ<Fq> lo = c; lo.add_inl(we); T[t] = xyzz_mul_fr(lo, gpow[t]);
+  if (t < S) { XYZZ<Fq> hi = c; hi.add_inl(we.neg()); T[B + t] = xyzz_mul_fr(hi, gpow[B + t]); }
+}
+// data[i] = scale[i] * P_i
+__global__ void __launch_bounds__(64) k_ecntt_scale_table(const Affine<Fq> *__restrict__ pts, const Fr *__restrict__ scale, uint32_t m, XYZZ<Fq> *__restrict__ data) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= m) return; data[i] = xyzz_mul_fr(XYZZ<Fq>::from_affine(pts[i]), scale[i]);
+}
+// natural-order copy of a bit-reversed array
+__global__ void __launch_bounds__(64) k_ecntt_unpermute(const XYZZ<Fq> *__restrict__ in, int logm, XYZZ<Fq> *__restrict__ out) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; if (p >= (1u << logm)) return; out[__brev(p) >> (32 - logm)] = in[p];
+}
 // Lstar[v] = (v > n_inputs ? L[v - n_inputs - 1] : 0) - sum over the entries (k, coefficient) of column v of C of coefficient * U[k]; U is held bit-reversed.
 // kind[e]: 0 = +1, 1 = -1, 2 = general (coef[e], canonical)
 __global__ void __launch_bounds__(64) k_fold_c_columns(const uint32_t *__restrict__ colptr, const uint32_t *__restrict__ rowidx, const uint8_t *__restrict__ kind, const Fr *__restrict__ coef,
-                                                       const XYZZ<Fq> *__restrict__ U_bitrev, int logm, const Affine<Fq> *__restrict__ L, uint32_t n_inputs, uint32_t n_all, Affine<Fq> *__restrict__ out) {
+                                                       const XYZZ<Fq> *__restrict__ U_bitrev, int logm /* 0: U is in natural order */, const Affine<Fq> *__restrict__ L, uint32_t n_inputs, uint32_t n_all, Affine<Fq> *__restrict__ out) {
   uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; if (v >= n_all) return; XYZZ<Fq> acc = XYZZ<Fq>::inf();
 #pragma unroll 1
-  for (uint32_t e = colptr[v]; e < colptr[v + 1]; e++) { XYZZ<Fq> u = U_bitrev[__brev(rowidx[e]) >> (32 - logm)]; uint8_t kd = kind[e];
+  for (uint32_t e = colptr[v]; e < colptr[v + 1]; e++) { XYZZ<Fq> u = U_bitrev[logm ? __brev(rowidx[e]) >> (32 - logm) : rowidx[e]]; uint8_t kd = kind[e];
     if (kd == 2) u = xyzz_mul_canon(u, coef[e]); else if (kd == 1) u = u.neg(); acc.add_inl(u); }
   acc = acc.neg(); if (v > n_inputs) acc.madd_inl(L[v - n_inputs - 1]);
   if (acc.is_inf()) { out[v] = Affine<Fq>::inf(); return; }

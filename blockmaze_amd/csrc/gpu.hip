@@ -249,9 +249,9 @@ void Domain::h_query_to_coset_lagrange(const G1AffineRaw *h, size_t n_in, G1Affi
   HIP_CHECK(hipGetLastError()); dout.download(out, m);
 }
 // see ecntt.cuh: Lstar (n_vars + 1 points) = L extended to all variables minus the C polynomial's share of the H term
-bool Domain::supports_c_fold() const { return !impl->step; }
+bool Domain::supports_c_fold() const { return true; }
 void Domain::fold_c_into_l(const G1AffineRaw *h_lagrange, const R1csHost &cs, const G1AffineRaw *L, G1AffineRaw *out) {
-  Impl &d = *impl; if (d.step) throw GpuError("domain: fold_c_into_l on a step domain"); hipStream_t s = gpu().stream; const size_t m = d.m, n_all = cs.n_vars + 1; const int logm = d.big->logn;
+  Impl &d = *impl; hipStream_t s = gpu().stream; const size_t m = d.m, n_all = cs.n_vars + 1; const int logm = d.big->logn;   // (step domains: logm is the size of the big part)
   // column form of C; coefficients classified so that +-1 cost an addition only
   std::vector<uint32_t> colptr(n_all + 1, 0); const std::vector<uint32_t> &rp = cs.rowptr[2], &cl = cs.col[2]; size_t nnz = cl.size();
   for (size_t e = 0; e < nnz; e++) colptr[cl[e] + 1]++; for (size_t v = 0; v < n_all; v++) colptr[v + 1] += colptr[v];
@@ -263,15 +263,29 @@ void Domain::fold_c_into_l(const G1AffineRaw *h_lagrange, const R1csHost &cs, co
   d_colptr.upload(colptr.data(), colptr.size()); d_rowidx.upload(rowidx.data(), rowidx.size()); d_kind.upload(kind.data(), kind.size()); d_coef.upload(coef.data(), coef.size());
   DevBuf<G1AffineRaw> dp(m), dl(cs.n_vars - cs.n_inputs ? cs.n_vars - cs.n_inputs : 1), dout(n_all); dp.upload(h_lagrange, m); if (cs.n_vars > cs.n_inputs) dl.upload(L, cs.n_vars - cs.n_inputs);
   DevBuf<uint8_t> b0(m * sizeof(XYZZ<Fq>)), b1(m * sizeof(XYZZ<Fq>)); XYZZ<Fq> *X = (XYZZ<Fq> *)b0.get(), *Y = (XYZZ<Fq> *)b1.get();
-  HFr zinv; { Fe32 z; d.zinv.download(&z, 1); memcpy(zinv.l, &z, 32); } Fr fz; memcpy(&fz, zinv.l, 32);
-  std::vector<Fe32> gm = geometric_table(m, HFr::from_u64(m).inv(), fr_coset_gen()); DevBuf<Fe32> d_gm(m); d_gm.upload(gm.data(), m);                              // g^i / m
-  auto dft = [&](XYZZ<Fq> *x, const Fe32 *tw) { for (int st = logm; st >= 1; st--) hipLaunchKernelGGL(k_ecntt_stage, dim3(cdiv(m / 2, 64)), dim3(64), 0, s, x, (const Fr *)tw, logm, st); };
-  hipLaunchKernelGGL(k_ecntt_scale_const, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)dp.get(), fz, (uint32_t)m, X);                                    // zinv * P
-  dft(X, d.big->tw.get());                                                                                                                                         // cosetFFT^T = D_g . DFT_w: the DFT ...
-  hipLaunchKernelGGL(k_ecntt_permute_scale, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, (const Fr *)d_gm.get(), logm, Y);                              // ... then g^i, with the 1/m of the inverse transform
-  dft(Y, d.big->itw.get());                                                                                                                                        // iFFT^T = (1/m) DFT_(1/w); result bit-reversed
-  hipLaunchKernelGGL(k_fold_c_columns, dim3(cdiv(n_all, 64)), dim3(64), 0, s, d_colptr.get(), d_rowidx.get(), d_kind.get(), (const Fr *)d_coef.get(), (const XYZZ<Fq> *)Y, logm,
-                     (const Affine<Fq> *)dl.get(), (uint32_t)cs.n_inputs, (uint32_t)n_all, (Affine<Fq> *)dout.get());
+  auto stages = [&](XYZZ<Fq> *x, const Fe32 *tw, int lg) { for (int st = lg; st >= 1; st--) hipLaunchKernelGGL(k_ecntt_stage, dim3(cdiv(((size_t)1 << lg) / 2, 64)), dim3(64), 0, s, x, (const Fr *)tw, lg, st); };
+  auto columns = [&](const XYZZ<Fq> *U, int lg) { hipLaunchKernelGGL(k_fold_c_columns, dim3(cdiv(n_all, 64)), dim3(64), 0, s, d_colptr.get(), d_rowidx.get(), d_kind.get(), (const Fr *)d_coef.get(), U, lg,
+                     (const Affine<Fq> *)dl.get(), (uint32_t)cs.n_inputs, (uint32_t)n_all, (Affine<Fq> *)dout.get()); };
+  if (!d.step) {
+    HFr zinv; { Fe32 z; d.zinv.download(&z, 1); memcpy(zinv.l, &z, 32); } Fr fz; memcpy(&fz, zinv.l, 32);
+    std::vector<Fe32> gm = geometric_table(m, HFr::from_u64(m).inv(), fr_coset_gen()); DevBuf<Fe32> d_gm(m); d_gm.upload(gm.data(), m);                            // g^i / m
+    hipLaunchKernelGGL(k_ecntt_scale_const, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)dp.get(), fz, (uint32_t)m, X);                                  // zinv * P
+    stages(X, d.big->tw.get(), logm);                                                                                                                              // cosetFFT^T = D_g . DFT_w: the DFT ...
+    hipLaunchKernelGGL(k_ecntt_permute_scale, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, (const Fr *)d_gm.get(), logm, Y);                            // ... then g^i, with the 1/m of the inverse transform
+    stages(Y, d.big->itw.get(), logm);                                                                                                                             // iFFT^T = (1/m) DFT_(1/w); result bit-reversed
+    columns(Y, logm);
+  } else {
+    const int lb = d.big->logn, ls = d.small->logn;
+    hipLaunchKernelGGL(k_ecntt_scale_table, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)dp.get(), (const Fr *)d.zinv.get(), (uint32_t)m, X);             // zinv[j] * P_j (divide_by_Z_on_coset is a table here)
+    stages(X, d.big->tw.get(), lb); stages(X + d.B, d.small->tw.get(), ls);                                                                                        // the two DFTs of the forward transform's transpose
+    hipLaunchKernelGGL(k_ecntt_step_fwd_T, dim3(cdiv(d.B, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, (const XYZZ<Fq> *)(X + d.B), lb, ls, (const Fr *)d.wpow.get(), (const Fr *)d.coset_fwd.get(), Y);   // Pre^T and g^i
+    // the inverse transform's transpose, as for the H query: Post^T with 1/B, 1/S, then the inverse DFTs of the parts
+    HFr ib = HFr::from_u64(d.B).inv(), is = HFr::from_u64(d.S).inv(), hib = d.half * ib, his = d.half * is; Fr f_hib, f_ib, f_his; memcpy(&f_hib, hib.l, 32); memcpy(&f_ib, ib.l, 32); memcpy(&f_his, his.l, 32);
+    hipLaunchKernelGGL(k_ecntt_step_pre, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)Y, X, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), f_hib, f_ib, f_his, (uint32_t)d.B, (uint32_t)d.S);
+    stages(X, d.big->itw.get(), lb); stages(X + d.B, d.small->itw.get(), ls);
+    hipLaunchKernelGGL(k_ecntt_unpermute, dim3(cdiv(d.B, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, lb, Y); hipLaunchKernelGGL(k_ecntt_unpermute, dim3(cdiv(d.S, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)(X + d.B), ls, Y + d.B);
+    columns(Y, 0);
+  }
   HIP_CHECK(hipGetLastError()); dout.download(out, n_all);
 }
 void Domain::qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c) {
