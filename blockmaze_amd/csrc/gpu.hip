@@ -47,13 +47,14 @@ hipStream_t gpu_stream() { return gpu().stream; }
 // ---- optional per-stage timing with HIP events on the compute stream (bench.py's roofline leg; off by default) ----------
 struct StageTimer {
   struct Span { std::string name; hipEvent_t a, b; };
-  bool enabled = false; std::vector<Span> open; std::vector<hipEvent_t> pool; std::map<std::string, std::pair<double, long>> acc;
+  bool enabled = false; std::mutex mu;   // (stages are opened from the prover's submit threads as well)
+  std::vector<Span> open; std::vector<hipEvent_t> pool; std::map<std::string, std::pair<double, long>> acc;
   hipEvent_t get() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; } hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e; }
   struct Open { hipStream_t st; };
   std::vector<hipStream_t> open_streams;
-  size_t begin(const char *name, hipStream_t st) { if (!enabled) return (size_t)-1; Span s{name, get(), get()}; HIP_CHECK(hipEventRecord(s.a, st)); open.push_back(s); open_streams.push_back(st); return open.size() - 1; }
-  void end(size_t id) { if (id == (size_t)-1) return; HIP_CHECK(hipEventRecord(open[id].b, open_streams[id])); }
-  void collect() { if (open.empty()) return; HIP_CHECK(hipDeviceSynchronize());
+  size_t begin(const char *name, hipStream_t st) { if (!enabled) return (size_t)-1; std::lock_guard<std::mutex> lk(mu); Span s{name, get(), get()}; HIP_CHECK(hipEventRecord(s.a, st)); open.push_back(s); open_streams.push_back(st); return open.size() - 1; }
+  void end(size_t id) { if (id == (size_t)-1) return; std::lock_guard<std::mutex> lk(mu); HIP_CHECK(hipEventRecord(open[id].b, open_streams[id])); }
+  void collect() { std::lock_guard<std::mutex> lk(mu); if (open.empty()) return; HIP_CHECK(hipDeviceSynchronize());
     for (Span &s : open) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { auto &e = acc[s.name]; e.first += ms; e.second++; } pool.push_back(s.a); pool.push_back(s.b); } open.clear(); open_streams.clear(); }
 };
 static StageTimer g_timer;

@@ -261,7 +261,7 @@ static void enqueue_all(Prover::Impl &p) {
   std::function<void()> jobs[4] = { [&] { p.B2->run(p.z.get(), p.B_idx.get() + p.b0); }, [&] { p.L->run(p.z.get() + (p.c_fold ? 0 : p.ni + 1) + p.l0, nullptr); },       // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
                                     [&] { p.A->run(p.z.get() + p.a0, nullptr); }, [&] { p.B1->run(p.z.get(), p.B_idx.get() + p.b0); } };
   const int job_stream[4] = {3, 1, 0, 2};                       // the auxiliary stream each MSM was bound to in the constructor (set_stream)
-  const bool use_threads = threaded && !gpu_capturing() && !profiling_enabled();   // (the stage timers are not thread-safe: profiling runs submit from one thread)
+  const bool use_threads = threaded && !gpu_capturing();
   bool posted[4] = {false, false, false, false};
   struct Waiter { Prover::Impl &p; bool *posted; ~Waiter() { for (int j = 0; j < 4; j++) if (posted[j]) { try { p.workers[j]->wait(); } catch (...) {} } } } waiter{p, posted};   // never leave a job running behind an exception
   auto release = [&](int point) { bool any = false; for (int j = 0; j < 4; j++) any |= start[j] == point; if (!any) return; gpu_fork_record();      // one event; each stream's wait is issued by the thread that feeds it
