@@ -2,7 +2,7 @@
 """Benchmark of the hot path: Groth16 proofs/sec for BlockMaze's send circuit on MI355X.
 
 A step = one send proof per rank through libzkgpu.so's resident prover (the r1cs_gg_ppzksnark_prover equivalent:
-R1CS rows -> 7 NTTs (6 on the device, the 7th folded into the key) -> 5 MSMs -> proof assembly; reference r1cs_gg_ppzksnark.tcc:391-506), witness vector handed over as a
+R1CS rows -> 7 NTTs (4 on the device per proof, 3 folded into the key) -> 5 MSMs -> proof assembly; reference r1cs_gg_ppzksnark.tcc:391-506), witness vector handed over as a
 host buffer.  N ranks prove independent seeded instances (proofs are independent units: no data-path collective), so
 value = N*K proofs / max-over-ranks wall time ("weak" scaling).
 
@@ -155,7 +155,7 @@ def main():
             "metric": "Groth16 proofs/sec (send circuit, alt_bn128)", "value": round(rate, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery)", "data": "synthetic",
             "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
-                       "includes": "R1CS rows + the 7 NTTs of the witness map (6 run per proof, the last one is folded into the H query at key load) + 5 MSM + host proof assembly + hex serialisation, assignment resident in HBM; excludes witness generation and key load"},
+                       "includes": "R1CS rows + the 7 NTTs of the witness map (4 run per proof; both transforms of C and the final inverse are folded into the L and H queries at key load) + 5 MSM + host proof assembly + hex serialisation, assignment resident in HBM; excludes witness generation and key load"},
             "proofs_in_flight": inflight, "ms_per_proof_host_buffer_in": ms_pcie and round(ms_pcie, 4), "ms_per_proof_through_genSendproof": ms_abi and round(ms_abi, 4), "proofs_per_s_through_genSendproof_concurrent_callers": abi_conc,
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
             "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2)}}))
