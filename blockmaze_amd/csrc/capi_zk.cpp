@@ -78,12 +78,16 @@ bool parse_fixed_rs(Fe32 &r, Fe32 &s) {   // test hook: ZK_FIXED_RS="<r hex>:<s 
 template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
   try {
     if (!gpu_available()) { zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback"); fprintf(stderr, "libzkgpu: no HIP device visible, cannot generate %s proof\n", circuit_name(k)); return dup_string(proof_to_hex(default_proof())); }
-    std::unique_lock<std::mutex> held; ProverUnit &slot = acquire_prover(k, held); assign(*slot.circuit);
+    static const bool trace = getenv("ZK_TRACE_TIMES") != nullptr; auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now(); std::unique_lock<std::mutex> held; ProverUnit &slot = acquire_prover(k, held); double t1 = now(); assign(*slot.circuit); double t2 = now();
     printf("Trying to generate %s proof...\n", circuit_name(k)); fflush(stdout);
     Fe32 r, s; bool fixed = parse_fixed_rs(r, s); Proof proof;
     slot.prover->set_witness(reinterpret_cast<const Fe32 *>(slot.circuit->board.val.data() + 1), true);   // the board holds Montgomery values: no conversion on either side
+    double t3 = now();
     if (!slot.prover->prove_resident(fixed ? &r : nullptr, fixed ? &s : nullptr, proof)) { printf("can not generate %s proof\n", circuit_name(k)); fflush(stdout); proof = default_proof(); }
-    return dup_string(proof_to_hex(proof));
+    double t4 = now(); char *out = dup_string(proof_to_hex(proof));
+    if (trace) fprintf(stderr, "trace-abi: acquire %.3f witness %.3f upload %.3f prove %.3f hex %.3f ms\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3, now() - t4);
+    return out;
   } catch (const std::exception &e) { zkgpu_set_error(e.what()); fprintf(stderr, "libzkgpu: %s\n", e.what()); return dup_string(proof_to_hex(default_proof())); }
   catch (...) { zkgpu_set_error("unknown error"); return dup_string(proof_to_hex(default_proof())); }
 }

@@ -207,7 +207,7 @@ struct Prover::Impl {
   int lane = 0;                                                // this prover's stream set: provers on different lanes overlap on the device
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
-  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; PinnedBuf<Fe32> z_host; GpuGraph *graph = nullptr; bool graph_failed = false;
+  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; DevBuf<uint8_t> packed; PinnedBuf<Fe32> z_host; GpuGraph *graph = nullptr; bool graph_failed = false;
   std::unique_ptr<SubmitWorker> workers[4];
   ~Impl() { for (auto &w : workers) w.reset(); gpu_graph_destroy(graph); }
 };
@@ -232,7 +232,7 @@ Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) 
   p.A->set_stream(0); p.L->set_stream(1); p.B1->set_stream(2); p.B2->set_stream(3); if (env_int("ZK_MSM_SPLIT_ONES", 1)) p.B2->split_ones_path();   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
   p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
   p.B_idx = DevBuf<uint32_t>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx.upload(pk.B_idx.data(), pk.B_idx.size());
-  p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host = PinnedBuf<Fe32>(p.nv + 1);
+  p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host = PinnedBuf<Fe32>(p.nv + 1 + 8); p.packed = DevBuf<uint8_t>(32 * (p.nv + 1 + 8));
 }
 Prover::~Prover() { if (impl) { LaneScope lane_scope(impl->lane); try { gpu_sync(); } catch (...) {} impl.reset(); } }
 size_t Prover::num_variables() const { return impl->nv; }
@@ -240,9 +240,22 @@ size_t Prover::num_inputs() const { return impl->ni; }
 size_t Prover::domain_size() const { return impl->m; }
 
 void Prover::set_witness(const Fe32 *z, bool montgomery) {
-  Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); Fe32 *h = p.z_host.get();
-  if (montgomery) memcpy(&h[0], FrParams::R1, 32); else { memset(&h[0], 0, 32); h[0].l[0] = 1; }
-  memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * (p.nv + 1)); if (!montgomery) fr_to_mont_dev(p.z.get(), p.nv + 1);
+  Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); const size_t n = p.nv + 1, words = (n + 63) / 64;
+  Fe32 one; if (montgomery) memcpy(&one, FrParams::R1, 32); else { memset(&one, 0, 32); one.l[0] = 1; }
+  // compact form (k_expand_witness): bitmaps of the entries equal to one / to anything else than 0 and 1, offsets, and the "anything else" values only
+  uint8_t *pk = reinterpret_cast<uint8_t *>(p.z_host.get()); uint64_t *ones = (uint64_t *)pk, *other = ones + words; uint32_t *off = (uint32_t *)(other + words);
+  const size_t vals_at = ((words * 20 + 31) / 32) * 32; Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4; size_t n_other = 0; bool compact = true;
+  uint64_t o1[4]; memcpy(o1, &one, 32); const uint64_t *zz = reinterpret_cast<const uint64_t *>(z) - 4;   // zz + 4 i = entry i of [ONE, z_1 .. z_n]; entry 0 is handled apart
+  for (size_t w = 0; w < words && compact; w++) { uint64_t mo = 0, mx = 0; const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; off[w] = (uint32_t)n_other;
+    for (size_t i = lo ? lo : 1; i < hi; i++) { const uint64_t *v = zz + 4 * i;                                // branch-free classification of the block
+      const uint64_t nz = (v[0] | v[1] | v[2] | v[3]) != 0, is1 = ((v[0] ^ o1[0]) | (v[1] ^ o1[1]) | (v[2] ^ o1[2]) | (v[3] ^ o1[3])) == 0; mo |= is1 << (i - lo); mx |= (nz & (is1 ^ 1)) << (i - lo); }
+    if (!lo) mo |= 1;                                                                                          // the constant ONE
+    const size_t cnt = (size_t)__builtin_popcountll(mx); if (n_other + cnt > max_other) { compact = false; break; }
+    for (uint64_t m = mx; m; m &= m - 1) memcpy(&vals[n_other++], zz + 4 * (lo + (size_t)__builtin_ctzll(m)), 32);
+    ones[w] = mo; other[w] = mx; }
+  if (compact) { size_t bytes = vals_at + 32 * n_other; upload_async(p.packed.get(), pk, bytes); expand_witness_dev(p.packed.get(), words, one, n, p.z.get()); }
+  else { Fe32 *h = p.z_host.get(); h[0] = one; memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * n); }      // dense assignment: plain copy
+  if (!montgomery) fr_to_mont_dev(p.z.get(), n);
   last.upload_ms = now_ms() - t0;
 }
 struct RsTerms { HFr r, s; HG1 r_delta, s_delta, rs_delta_neg; HG2 s_delta2; };
