@@ -289,6 +289,8 @@ void Domain::fold_c_into_l(const G1AffineRaw *h_lagrange, const R1csHost &cs, co
   }
   HIP_CHECK(hipGetLastError()); dout.download(out, n_all);
 }
+const Fe32 *Domain::zinv_dev() const { return impl->zinv.get(); }
+bool Domain::zinv_is_table() const { return impl->step; }
 void Domain::qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c) {
   hipLaunchKernelGGL(k_qap_pointwise, dim3(cdiv(impl->m, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (const Fr *)b, (const Fr *)c, (const Fr *)impl->zinv.get(), impl->step ? 1 : 0, (uint32_t)impl->m);
 }

@@ -54,6 +54,8 @@ class MsmG1 {
   // scalars_dev: Fr (Montgomery) on the device.  scalar_index_dev: optional gather map (point i uses scalars[index[i]]).
   // Enqueues the kernels; result() synchronises and finishes the combine on the host.
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
+  // scalars a_i * b_i * z (z: one element, or a table of n) formed inside the sort kernel; only when one_pass_sort() (uniform-scalar MSM with fixed-base tables)
+  bool one_pass_sort() const; void run_product(const Fe32 *a_dev, const Fe32 *b_dev, const Fe32 *z_dev, bool z_is_table);
   host::HG1 result();
   size_t size() const; const G1AffineRaw *points_dev() const; void set_label(const char *l); void set_stream(int aux /* -1 main, 0..3 auxiliary */); void split_ones_path();   // split: the scalar-one sum runs on a stream of its own beside the bucket path
   struct Impl; std::unique_ptr<Impl> impl;
@@ -92,7 +94,8 @@ class Domain {
   bool supports_h_lagrange() const; void h_query_to_coset_lagrange(const G1AffineRaw *h, size_t n_in, G1AffineRaw *out /* m points */);
   // key load, radix-2 domains: out (n_vars + 1 points) = the L query extended to all variables minus the C polynomial's share of the H term; the prover then transforms A and B only (ecntt.cuh)
   bool supports_c_fold() const; void fold_c_into_l(const G1AffineRaw *h_lagrange /* m */, const R1csHost &cs, const G1AffineRaw *L /* n_vars - n_inputs */, G1AffineRaw *out);
-  // a = (a*b - c) / Z on the coset (c may be null: a = a*b / Z)
+  // a = (a*b - c) / Z on the coset (c may be null: a = a*b / Z); zinv_dev(): 1/Z on the coset, one element or (step domains) a table of m
+  const Fe32 *zinv_dev() const; bool zinv_is_table() const;
   void qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c);
   struct Impl; std::unique_ptr<Impl> impl;
 };

@@ -5,6 +5,8 @@ struct MsmG1::Impl : MsmImpl<Fq, G1AffineRaw> { using MsmImpl::MsmImpl; };
 MsmG1::MsmG1(const G1AffineRaw *p, size_t n, int c, bool fo, bool tables, bool uniform) : impl(new Impl(p, n, c, fo, tables, uniform)) {}
 MsmG1::~MsmG1() = default;
 void MsmG1::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
+bool MsmG1::one_pass_sort() const { return impl->direct; }
+void MsmG1::run_product(const Fe32 *a, const Fe32 *b, const Fe32 *z, bool z_is_table) { impl->run_product(a, b, z, z_is_table); }
 void MsmG1::set_label(const char *l) { impl->label = l; }
 void MsmG1::set_stream(int aux) { impl->stream_id = aux; }
 void MsmG1::split_ones_path() { impl->enable_split_ones(); }

@@ -285,10 +285,12 @@ static void enqueue_all(Prover::Impl &p) {
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
   const int nvec = p.c_fold ? 2 : 3;                          // A, B (and C unless it is folded into the L query)
   p.dom->ifft(p.abc.get(), nvec, p.m); release(2);
-  p.dom->coset_fft(p.abc.get(), nvec, p.m); p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.c_fold ? nullptr : p.abc.get() + 2 * p.m); release(3);
+  const bool fuse_pointwise = p.c_fold && p.H->one_pass_sort();   // zinv*a*b is then formed inside the H query's sort kernel
+  p.dom->coset_fft(p.abc.get(), nvec, p.m); if (!fuse_pointwise) p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.c_fold ? nullptr : p.abc.get() + 2 * p.m); release(3);
   if (!p.h_lagrange) p.dom->icoset_fft(p.abc.get(), 1, p.m);
   release(4);
-  p.H->run(p.abc.get() + p.h0, nullptr);                                                                                  // :466-473
+  if (fuse_pointwise) p.H->run_product(p.abc.get() + p.h0, p.abc.get() + p.m + p.h0, p.dom->zinv_dev() + (p.dom->zinv_is_table() ? p.h0 : 0), p.dom->zinv_is_table());
+  else p.H->run(p.abc.get() + p.h0, nullptr);                                                                             // :466-473
   for (int j = 0; j < 4; j++) if (posted[j]) { posted[j] = false; p.workers[j]->wait(); }
 }
 // one proof's device work: replayed from a captured hipGraph (about 70 launches on 5 streams collapse into one submission); opt-in with ZK_USE_GRAPH=1

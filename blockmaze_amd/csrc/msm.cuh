@@ -94,15 +94,21 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const Fr *__restrict__ scal
 // overflow sets counters->pad[0]; the host then repeats the MSM on the two-pass path (any input stays correct, only uniform ones are fast).
 template <int DUMMY = 0>
 __global__ void k_msm_scatter_direct(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf, uint32_t n, int c, int W, uint32_t point_stride,
-                                     uint32_t cap, uint32_t *__restrict__ counts, uint32_t *__restrict__ entries, MsmCounters *cnt, MsmCounters *cnt_next) {
+                                     uint32_t cap, uint32_t *__restrict__ counts, uint32_t *__restrict__ entries, MsmCounters *cnt, MsmCounters *cnt_next,
+                                     const Fr *__restrict__ mul_b, const Fr *__restrict__ mul_z, int z_is_table) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i == 0) *cnt_next = MsmCounters{0, 0, {0, 0}}; if (i >= n) return;
   if (point_is_inf && point_is_inf[i]) return;
-  Fr k = scalars[scalar_index ? scalar_index[i] : i].from_mont();
+  Fr k = scalars[scalar_index ? scalar_index[i] : i]; if (mul_b) k = k * mul_b[i] * mul_z[z_is_table ? i : 0];   // mul_b: the scalar is the product a*b*z (the pointwise step of the witness map, fused)
+  k = k.from_mont();
   if (k.is_zero()) return;
   int dig[MSM_MAX_WINDOWS]; signed_digits(k.l, c, W, dig); bool over = false;
   for (int w = 0; w < W; w++) { int d = dig[w]; if (!d) continue; uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, slot = atomicAdd(&counts[key], 1u);
     if (slot < cap) entries[(size_t)key * cap + slot] = (i + (uint32_t)w * point_stride) | (d < 0 ? 0x80000000u : 0u); else over = true; }
   if (over) atomicOr(&cnt->pad[0], 1u);
+}
+
+static __global__ void k_fr_mul3(const Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ z, int z_is_table, uint32_t n, Fr *__restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = a[i] * b[i] * z[z_is_table ? i : 0];
 }
 
 // ---- exclusive scan over uint32 (three small kernels; the arrays are <= 2^21 entries) ------------------------------

@@ -3,7 +3,7 @@
   * keys made by the GPU key generator are accepted by the oracle's reader, and oracle / engine / (when the compiled
     reference harness travelled with the repo) the real libsnark prover and verifier all agree on them
   * the full-size send circuit: key generation, proof with fixed (r, s), verification, and the drop-in cgo symbols."""
-import json, os, subprocess
+import json, os, subprocess, sys
 import numpy as np
 import pytest
 from oracle import pyoracle as o
@@ -191,3 +191,14 @@ def test_concurrent_cgo_calls_overlap_and_stay_correct(all_keys, monkeypatch):
         elif kind == "mint": assert zk.VerifyMintProof(p, d["cmtA_old"], d["sn_old"], d["cmtA"], d["value_s"])
         else: assert zk.VerifyRedeemProof(p, d["cmtA_old"], d["sn_old"], d["cmtA"], d["value_s"])
     (d0, p0), (d1, p1) = out[("send", 0, 0)], out[("send", 1, 0)]; assert not zk.VerifySendProof(p0, d1["cmtA_old"], d1["sn_old"], d1["cmtS"], d1["cmtA"])
+
+
+def test_one_pass_sort_overflow_inside_the_prover(golden_dir):
+    """ZK_MSM_DIRECT_CAP=1 makes every bucket of the H query's one-pass sort overflow: the prover must notice, redo that MSM on the two-pass path (materialising the
+    fused zinv*a*b product first) and still emit the reference prover's bytes"""
+    code = ("import json, os, sys; sys.path.insert(0, %r); from blockmaze_amd import engine as e; from oracle import pyoracle as o; d = %r; "
+            "meta = json.load(open(os.path.join(d, 'meta.json'))); z = o.load_witness(os.path.join(d, 'wit.bin')); p = e.Prover(os.path.join(d, 'pk.txt')); "
+            "assert p.prove(z, int(meta['r'], 16), int(meta['s'], 16)) == meta['proof']; assert p.prove(z, int(meta['r'], 16), int(meta['s'], 16)) == meta['proof']; print('same bytes')")
+    for name in ("groth16_small", "groth16_step"):
+        r = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(golden_dir, name))], capture_output=True, text=True, env=dict(os.environ, ZK_MSM_DIRECT_CAP="1"), timeout=300)
+        assert "same bytes" in r.stdout, r.stderr[-2000:]
