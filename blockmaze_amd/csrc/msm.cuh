@@ -239,12 +239,10 @@ template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<
 // is pointless (order = identity); counts are clipped to the slot capacity, task_off = exclusive scan of the task counts, empty buckets are set to infinity.
 // cls_start[] = n_buckets for every class: the combine kernel then looks at every bucket's task count itself.
 constexpr uint32_t PLAN_DIRECT_MAX = 32768;    // task counts of all buckets are staged in LDS as bytes (clip <= 4080 entries, i.e. at most 255 tasks per bucket)
-static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_direct(uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t clip, uint32_t task, uint32_t *__restrict__ order, uint32_t *__restrict__ rank_of,
-                                                                   uint32_t *__restrict__ task_off, uint32_t *__restrict__ cls_start, uint4 *__restrict__ bucket_mem, uint32_t bucket_u4) {
+static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_direct(uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t clip, uint32_t task, uint32_t *__restrict__ task_off, uint32_t *__restrict__ cls_start) {
   __shared__ uint32_t sh[PLAN_THREADS]; __shared__ uint8_t nt_lds[PLAN_DIRECT_MAX];
-  for (uint32_t b = threadIdx.x; b < n_buckets; b += PLAN_THREADS) {                                       // coalesced pass over the buckets
-    uint32_t cnt = counts[b]; if (cnt > clip) { cnt = clip; counts[b] = cnt; } order[b] = b; rank_of[b] = b; nt_lds[b] = (uint8_t)((cnt + task - 1) / task);
-    if (cnt == 0) for (uint32_t q = 0; q < bucket_u4; q++) bucket_mem[(size_t)b * bucket_u4 + q] = make_uint4(0, 0, 0, 0); }
+  // (order / rank_of are the identity in this mode and were written once by the host; an empty bucket is set to infinity by the combine kernel)
+  for (uint32_t b = threadIdx.x; b < n_buckets; b += PLAN_THREADS) { uint32_t cnt = counts[b]; if (cnt > clip) { cnt = clip; counts[b] = cnt; } nt_lds[b] = (uint8_t)((cnt + task - 1) / task); }   // coalesced pass over the buckets
   __syncthreads();
   const uint32_t per = (n_buckets + PLAN_THREADS - 1) / PLAN_THREADS, lo = threadIdx.x * per; uint32_t s = 0, total;
   for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) s += nt_lds[lo + j];
@@ -257,7 +255,7 @@ static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_direct(uint32_
 constexpr uint32_t COMBINE_QUAD_MAX = 24;
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, const uint32_t *__restrict__ cls_start, uint32_t heavy_blocks,
-                                                           const XYZZ<F> *__restrict__ partials, XYZZ<F> *__restrict__ buckets, uint32_t *__restrict__ zero_words, uint32_t n_zero) {
+                                                           const XYZZ<F> *__restrict__ partials, XYZZ<F> *__restrict__ buckets, uint32_t *__restrict__ zero_words, uint32_t n_zero, int zero_empty) {
   __shared__ XYZZ<F> lds[4];
   { uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; if (gid < n_zero) zero_words[gid] = 0; }   // the histogram / slot counters are not needed any more: leave them cleared for the next run (saves a memset launch at the head of every MSM)
   const uint32_t n_big = cls_start[1], n_multi = cls_start[BSORT_CLASSES - 1 - MSM_TASK];   // ranks below: count >= 63 (the only class that can hold more than COMBINE_QUAD_MAX tasks), count > 16
@@ -267,7 +265,8 @@ __global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__res
     return;
   }
   uint32_t r = (blockIdx.x - heavy_blocks) * 64 + (threadIdx.x >> 2); int k = threadIdx.x & 3; if (r >= n_multi) return;
-  uint32_t beg = task_off[r], nt = task_off[r + 1] - beg; if (nt < 2 || nt > COMBINE_QUAD_MAX) return; XYZZ<F> acc = partials[beg];   // (one task: the accumulation wrote the bucket itself)
+  uint32_t beg = task_off[r], nt = task_off[r + 1] - beg; if (nt == 0 && zero_empty) { if (k == 0) buckets[order[r]] = XYZZ<F>::inf(); return; }
+  if (nt < 2 || nt > COMBINE_QUAD_MAX) return; XYZZ<F> acc = partials[beg];   // (one task: the accumulation wrote the bucket itself)
 #pragma unroll 1
   for (uint32_t j = 1; j < nt; j++) acc = quad_add(acc, partials[beg + j], k);
   if (k == 0) buckets[order[r]] = acc;

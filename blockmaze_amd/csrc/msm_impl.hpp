@@ -88,9 +88,10 @@ struct MsmImpl {
       hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(256), 0, os, (const XYZZ<F> *)ones_l2.get(), g, g, res + WB, (uint4 *)nullptr, (uint4 *)nullptr); };
     last_scalars = scalars; last_index = scalar_index;
     if (direct) { Stage st((label + ".sort").c_str(), s);
-      if (!offsets_direct) { std::vector<uint32_t> o(nbk); for (size_t b = 0; b < nbk; b++) o[b] = (uint32_t)(b * cap); offsets.upload(o.data(), nbk); offsets_direct = true; }
+      if (!offsets_direct) { std::vector<uint32_t> o(nbk); for (size_t b = 0; b < nbk; b++) o[b] = (uint32_t)(b * cap); offsets.upload(o.data(), nbk);
+        for (size_t b = 0; b < nbk; b++) o[b] = (uint32_t)b; order.upload(o.data(), nbk); rank_of.upload(o.data(), nbk); offsets_direct = true; }   // identity ranking: uniform buckets need no size ordering
       hipLaunchKernelGGL(k_msm_scatter_direct<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, point_stride, cap, hist(), entries.get(), cnt, counters_next(), (const Fr *)prod_b, (const Fr *)prod_z, (int)prod_z_table);
-      if (nbk <= PLAN_DIRECT_MAX && cap <= 4080) hipLaunchKernelGGL(k_msm_plan_direct, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, cap, task, order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
+      if (nbk <= PLAN_DIRECT_MAX && cap <= 4080) hipLaunchKernelGGL(k_msm_plan_direct, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, cap, task, task_off.get(), cls_start.get());
       else {
         hipLaunchKernelGGL(k_bsort_hist, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_hist.get(), cap);
         bsort_scanner->run(block_hist.get(), block_off.get(), (size_t)bsort_blocks * BSORT_CLASSES, s);
@@ -118,7 +119,7 @@ struct MsmImpl {
     }
     { Stage st((label + ".combine").c_str(), s);
       const uint32_t heavy = direct && cap <= COMBINE_QUAD_MAX * task ? 0u : HEAVY_BLOCKS;   // one-pass sort: no bucket can hold more than `cap` entries, so none needs a whole workgroup
-      hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(heavy + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), heavy, (const XYZZ<F> *)partials.get(), (XYZZ<F> *)buckets.get(), zeroed.get(), (uint32_t)(2 * nbk));
+      hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(heavy + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), heavy, (const XYZZ<F> *)partials.get(), (XYZZ<F> *)buckets.get(), zeroed.get(), (uint32_t)(2 * nbk), (int)(direct && nbk <= PLAN_DIRECT_MAX && cap <= 4080));
     }
     { Stage st_red((label + ".reduce").c_str(), s);
       uint32_t spw = NB / seg, nseg = (uint32_t)WB * spw; uint4 *csrc = (uint4 *)cnt; uint4 *cdst = (uint4 *)(res + WB + 1);
