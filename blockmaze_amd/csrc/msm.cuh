@@ -220,8 +220,9 @@ __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *_
 // quad q adds elements q, q+64, ...; then a tree over the 16 quads of each wave (shuffles) and over the 4 waves (LDS).  The result is valid in lanes 0..3.
 template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<F> *__restrict__ src, uint32_t len, XYZZ<F> *lds) {
   const uint32_t q = threadIdx.x >> 2, wq = q & 15, wave = threadIdx.x >> 6; const int k = threadIdx.x & 3; XYZZ<F> acc = XYZZ<F>::inf();
+  if (q < len) { XYZZ<F> nxt = src[q];
 #pragma unroll 1
-  for (uint32_t j = q; j < len; j += 64) acc = quad_add(acc, src[j], k);
+    for (uint32_t j = q; j < len; j += 64) { XYZZ<F> cur = nxt; if (j + 64 < len) nxt = src[j + 64]; acc = quad_add(acc, cur, k); } }
 #pragma unroll 1
   for (int d = 8; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (wq + d < 16) acc = quad_add(acc, o, k); }
   if ((threadIdx.x & 63) == 0) lds[wave] = acc;
@@ -266,9 +267,9 @@ __global__ void __launch_bounds__(256) k_msm_combine_tasks(const uint32_t *__res
   }
   uint32_t r = (blockIdx.x - heavy_blocks) * 64 + (threadIdx.x >> 2); int k = threadIdx.x & 3; if (r >= n_multi) return;
   uint32_t beg = task_off[r], nt = task_off[r + 1] - beg; if (nt == 0 && zero_empty) { if (k == 0) buckets[order[r]] = XYZZ<F>::inf(); return; }
-  if (nt < 2 || nt > COMBINE_QUAD_MAX) return; XYZZ<F> acc = partials[beg];   // (one task: the accumulation wrote the bucket itself)
+  if (nt < 2 || nt > COMBINE_QUAD_MAX) return; XYZZ<F> acc = partials[beg], nxt = partials[beg + 1];   // (one task: the accumulation wrote the bucket itself)
 #pragma unroll 1
-  for (uint32_t j = 1; j < nt; j++) acc = quad_add(acc, partials[beg + j], k);
+  for (uint32_t j = 1; j < nt; j++) { XYZZ<F> cur = nxt; if (j + 1 < nt) nxt = partials[beg + j + 1]; acc = quad_add(acc, cur, k); }   // the next partial sum is in flight during the addition
   if (k == 0) buckets[order[r]] = acc;
 }
 
@@ -281,8 +282,9 @@ __global__ void __launch_bounds__(64) k_msm_reduce_segments(const XYZZ<F> *__res
   uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; int k = threadIdx.x & 3; if (t >= n_seg_total) return;
   uint32_t segs_per_window = NB / SEG, w = t / segs_per_window, s = t % segs_per_window, lo = s * SEG;
   const XYZZ<F> *B = buckets + (size_t)w * NB + lo; XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
+  XYZZ<F> nxt = B[SEG - 1];
 #pragma unroll 1
-  for (int j = (int)SEG - 1; j >= 0; j--) { run = quad_add(run, B[j], k); acc = quad_add(acc, run, k); }
+  for (int j = (int)SEG - 1; j >= 0; j--) { XYZZ<F> cur = nxt; if (j) nxt = B[j - 1]; run = quad_add(run, cur, k); acc = quad_add(acc, run, k); }   // next bucket in flight during the two additions
   if (lo) acc = quad_add(acc, quad_mul_small(run, lo, k), k);
   if (k == 0) seg_out[t] = acc;
 }
