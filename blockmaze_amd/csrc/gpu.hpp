@@ -49,7 +49,7 @@ void upload_async(void *dev, const void *pinned_host, size_t bytes);   // on the
 // A fixed set of base points resident in HBM (one query of a proving key) plus the reusable MSM workspace for it.
 class MsmG1 {
  public:
-  MsmG1(const G1AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false);   // tables: precompute 2^(cw) P if the size cap allows; uniform: one-pass sort with overflow fallback (msm_impl.hpp)
+  MsmG1(const G1AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false, bool glv = false);   // glv: halve the scalars with the curve's endomorphism (needs tables + uniform); tables: precompute 2^(cw) P if the size cap allows; uniform: one-pass sort with overflow fallback (msm_impl.hpp)
   ~MsmG1();
   // scalars_dev: Fr (Montgomery) on the device.  scalar_index_dev: optional gather map (point i uses scalars[index[i]]).
   // Enqueues the kernels; result() synchronises and finishes the combine on the host.
@@ -62,7 +62,7 @@ class MsmG1 {
 };
 class MsmG2 {
  public:
-  MsmG2(const G2AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false);
+  MsmG2(const G2AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false, bool glv = false);   // (glv is ignored for G2)
   ~MsmG2();
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
   host::HG2 result(); void set_label(const char *l); void set_stream(int aux); void split_ones_path();

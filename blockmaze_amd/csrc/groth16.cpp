@@ -228,7 +228,7 @@ Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) 
   if (p.c_fold) { if (pk.L_star.size() != p.nv + 1) { pk.L_star.resize(p.nv + 1); p.dom->fold_c_into_l(pk.H_lagrange.data(), pk.cs, pk.L.data(), pk.L_star.data()); } Lq = &pk.L_star; }
   shard_range(Lq->size(), shard_rank, shard_world, p.l0, e); size_t nL = e - p.l0;
   p.A.reset(new MsmG1(pk.A.data() + p.a0, nA, cw, true)); p.L.reset(new MsmG1(Lq->data() + p.l0, nL, cw, true));
-  p.B1.reset(new MsmG1(pk.B_g1.data() + p.b0, nB, cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data() + p.b0, nB, cw, true)); p.H.reset(new MsmG1(Hq->data() + p.h0, nH, ch, false, env_int("ZK_MSM_H_TABLES", 1) != 0, true));   // (with tables the H accumulation gathers from a table 16x larger and slows from 0.40 to 0.51 ms, but the reduction drops from 0.53 to 0.23 ms: measured 3 % better per proof, 10 % better with four proofs in flight)
+  p.B1.reset(new MsmG1(pk.B_g1.data() + p.b0, nB, cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data() + p.b0, nB, cw, true)); p.H.reset(new MsmG1(Hq->data() + p.h0, nH, ch, false, env_int("ZK_MSM_H_TABLES", 1) != 0, true, env_int("ZK_MSM_GLV", 0) != 0));   // GLV (msm.cuh) is implemented and tested but off: measured, the accumulation does not get faster on the 151 MB table (0.56 vs 0.53 ms) and the decomposition costs 0.1 ms in the sort   // (with tables the H accumulation gathers from a table 16x larger and slows from 0.40 to 0.51 ms, but the reduction drops from 0.53 to 0.23 ms: measured 3 % better per proof, 10 % better with four proofs in flight)
   p.A->set_stream(0); p.L->set_stream(1); p.B1->set_stream(2); p.B2->set_stream(3); if (env_int("ZK_MSM_SPLIT_ONES", 1)) p.B2->split_ones_path();   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
   p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
   p.B_idx = DevBuf<uint32_t>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx.upload(pk.B_idx.data(), pk.B_idx.size());

@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "curve.cuh"
+#include "glv_params.h"
 
 namespace zk {
 
@@ -39,6 +40,39 @@ __device__ __forceinline__ void signed_digits(const uint32_t k[8], int c, int W,
   }
 }
 
+// ---- GLV: k = k1 + k2*lambda with |k1|, |k2| < 2^128, lambda*(x, y) = (beta*x, y) ------------------------------------------
+// Halves the windows an MSM with fixed-base tables needs (9 of 16 bits instead of 16): the H query's table shrinks from 268 MB to 151 MB and fits the Infinity Cache.
+// An entry of the second half carries bit 30; the accumulation kernel multiplies x by beta for it.  Any integers c1, c2 give a correct decomposition (the basis
+// vectors are multiples of r under (x, y) -> x + y*lambda), so the truncated quotients below are fine.
+__device__ __forceinline__ void mp_mul_lo8(const uint32_t *x, int nx, const uint32_t *y, int ny, uint32_t out[8]) {   // low 256 bits of x*y
+  for (int i = 0; i < 8; i++) out[i] = 0;
+  for (int i = 0; i < nx && i < 8; i++) { uint64_t c = 0; for (int j = 0; j < ny && i + j < 8; j++) { uint64_t t = (uint64_t)x[i] * y[j] + out[i + j] + c; out[i + j] = (uint32_t)t; c = t >> 32; }
+    for (int t = i + ny; c && t < 8; t++) { uint64_t u = (uint64_t)out[t] + c; out[t] = (uint32_t)u; c = u >> 32; } }
+}
+template <int NY> __device__ __forceinline__ void mp_mul_hi(const uint32_t k[8], const uint32_t (&y)[NY], uint32_t out[NY]) {   // floor(k*y / 2^256), NY limbs
+  uint32_t p[8 + NY]; for (int i = 0; i < 8 + NY; i++) p[i] = 0;
+  for (int i = 0; i < 8; i++) { uint64_t c = 0; for (int j = 0; j < NY; j++) { uint64_t t = (uint64_t)k[i] * y[j] + p[i + j] + c; p[i + j] = (uint32_t)t; c = t >> 32; } p[i + NY] = (uint32_t)c; }
+  for (int j = 0; j < NY; j++) out[j] = p[8 + j];
+}
+__device__ __forceinline__ void mp_sub8(uint32_t a[8], const uint32_t b[8]) { uint64_t br = 0; for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)a[i] - b[i] - br; a[i] = (uint32_t)t; br = (t >> 32) & 1; } }
+__device__ __forceinline__ bool mp_abs8(uint32_t a[8]) { if (!(a[7] >> 31)) return false; uint64_t c = 1; for (int i = 0; i < 8; i++) { c += (uint32_t)~a[i]; a[i] = (uint32_t)c; c >>= 32; } return true; }   // two's complement -> magnitude; true if it was negative
+__device__ __forceinline__ void glv_decompose(const uint32_t k[8], uint32_t k1[8], bool &neg1, uint32_t k2[8], bool &neg2) {
+  uint32_t c1[3], c2[5], t[8]; mp_mul_hi<3>(k, GLV_G1, c1); mp_mul_hi<5>(k, GLV_G2, c2);
+  for (int i = 0; i < 8; i++) k1[i] = k[i];
+  mp_mul_lo8(c1, 3, GLV_A1, 2, t); mp_sub8(k1, t); mp_mul_lo8(c2, 5, GLV_A2, 4, t); mp_sub8(k1, t);           // k1 = k - c1 a1 - c2 a2
+  mp_mul_lo8(c1, 3, GLV_NB1, 4, k2); mp_mul_lo8(c2, 5, GLV_B2, 2, t); mp_sub8(k2, t);                          // k2 = c1 (-b1) - c2 b2
+  neg1 = mp_abs8(k1); neg2 = mp_abs8(k2);
+}
+// signed digits of k for the sort kernels: W digits, or with GLV the W digits of |k1| followed by the W digits of |k2| (signs applied)
+__device__ __forceinline__ int msm_digits(const uint32_t k[8], int c, int W, int glv, int *dig) {
+  if (!glv) { signed_digits(k, c, W, dig); return W; }
+  uint32_t k1[8], k2[8]; bool n1, n2; glv_decompose(k, k1, n1, k2, n2); signed_digits(k1, c, W, dig); signed_digits(k2, c, W, dig + W);
+  if (n1) for (int w = 0; w < W; w++) dig[w] = -dig[w];
+  if (n2) for (int w = 0; w < W; w++) dig[W + w] = -dig[W + w];
+  return 2 * W;
+}
+constexpr uint32_t MSM_ENTRY_SIGN = 0x80000000u, MSM_ENTRY_PHI = 0x40000000u;   // entry = table index | sign | second GLV half
+
 struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; };
 
 // scalars: Fr in Montgomery form.  scalar_index (optional): scalar for point i is scalars[scalar_index[i]] (sparse
@@ -48,7 +82,7 @@ struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; };
 constexpr uint32_t MSM_LDS_HIST = 4096;
 template <int DUMMY = 0>
 __global__ void __launch_bounds__(256) k_msm_classify(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
-                               uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t n_hist, uint32_t *__restrict__ hist, uint32_t *__restrict__ ones, MsmCounters *cnt, MsmCounters *cnt_next) {
+                               uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t n_hist, int glv, uint32_t *__restrict__ hist, uint32_t *__restrict__ ones, MsmCounters *cnt, MsmCounters *cnt_next) {
   __shared__ uint32_t lh[MSM_LDS_HIST]; const bool use_lds = n_hist <= MSM_LDS_HIST;
   if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = MsmCounters{0, 0, {0, 0}};   // the counters alternate between two slots: this run clears the next run's
   if (use_lds) { for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) lh[b] = 0; __syncthreads(); }
@@ -59,8 +93,8 @@ __global__ void __launch_bounds__(256) k_msm_classify(const Fr *__restrict__ sca
     uint64_t m = __ballot(is_one); if (m) { uint32_t lane = threadIdx.x & 63, base = 0; if (lane == (uint32_t)__ffsll((long long)m) - 1) base = atomicAdd(&cnt->n_ones, (uint32_t)__popcll(m));
       base = __shfl(base, __ffsll((long long)m) - 1, 64); if (is_one) ones[base + __popcll(m & ((1ull << lane) - 1))] = i; } }
   if (live && !is_one) {
-    int dig[MSM_MAX_WINDOWS]; signed_digits(k.l, c, W, dig);
-    for (int w = 0; w < W; w++) { int d = dig[w]; if (d) { uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; atomicAdd(use_lds ? &lh[key] : &hist[key], 1u); } }   // hist_stride = 2^(c-1): buckets per window; 0: all windows share one bucket array (precomputed 2^(cw) P)
+    int dig[MSM_MAX_WINDOWS]; const int nd = msm_digits(k.l, c, W, glv, dig);
+    for (int e = 0; e < nd; e++) { int d = dig[e]; const int w = e < W ? e : e - W; if (d) { uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; atomicAdd(use_lds ? &lh[key] : &hist[key], 1u); } }   // hist_stride = 2^(c-1): buckets per window; 0: all windows share one bucket array (precomputed 2^(cw) P)
   }
   { uint64_t m = __ballot(live && !is_one); if (m && (threadIdx.x & 63) == (uint32_t)__ffsll((long long)m) - 1) atomicAdd(&cnt->n_other, (uint32_t)__popcll(m)); }
   if (use_lds) { __syncthreads(); for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) if (lh[b]) atomicAdd(&hist[b], lh[b]); }
@@ -68,25 +102,25 @@ __global__ void __launch_bounds__(256) k_msm_classify(const Fr *__restrict__ sca
 
 template <int DUMMY = 0>
 __global__ void __launch_bounds__(256) k_msm_scatter(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
-                              uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t point_stride, uint32_t n_hist, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ fill, uint32_t *__restrict__ entries) {
+                              uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t point_stride, uint32_t n_hist, int glv, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ fill, uint32_t *__restrict__ entries) {
   __shared__ uint32_t lcnt[MSM_LDS_HIST], lbase[MSM_LDS_HIST]; const bool use_lds = n_hist <= MSM_LDS_HIST;
   if (use_lds) { for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) lcnt[b] = 0; __syncthreads(); }
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; bool live = i < n && !(point_is_inf && point_is_inf[i]); Fr k = Fr::zero();
   if (live) { k = scalars[scalar_index ? scalar_index[i] : i].from_mont(); live = !k.is_zero(); }
   if (live && filter_ones) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; if (o == 0) live = false; }
-  int dig[MSM_MAX_WINDOWS]; if (live) signed_digits(k.l, c, W, dig);
+  int dig[MSM_MAX_WINDOWS]; int nd = 0; if (live) nd = msm_digits(k.l, c, W, glv, dig);
   if (!use_lds) {
-    if (live) for (int w = 0; w < W; w++) { int d = dig[w]; if (!d) continue; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1;
-      entries[offsets[key] + atomicAdd(&fill[key], 1u)] = (i + (uint32_t)w * point_stride) | (d < 0 ? 0x80000000u : 0u); }   // point_stride = n: the entry addresses 2^(cw) P_i in the precomputed table
+    for (int e = 0; e < nd; e++) { int d = dig[e]; if (!d) continue; const int w = e < W ? e : e - W; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1;
+      entries[offsets[key] + atomicAdd(&fill[key], 1u)] = (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u) | (e >= W ? MSM_ENTRY_PHI : 0u); }   // point_stride = n: the entry addresses 2^(cw) P_i in the precomputed table
     return;
   }
   uint32_t rank[MSM_MAX_WINDOWS];                                                           // position inside this workgroup's share of the bucket
-  if (live) for (int w = 0; w < W; w++) { int d = dig[w]; if (d) rank[w] = atomicAdd(&lcnt[(uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1], 1u); }
+  for (int e = 0; e < nd; e++) { int d = dig[e]; const int w = e < W ? e : e - W; if (d) rank[e] = atomicAdd(&lcnt[(uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1], 1u); }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) if (lcnt[b]) lbase[b] = offsets[b] + atomicAdd(&fill[b], lcnt[b]);
   __syncthreads();
-  if (live) for (int w = 0; w < W; w++) { int d = dig[w]; if (!d) continue; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1;
-    entries[lbase[key] + rank[w]] = (i + (uint32_t)w * point_stride) | (d < 0 ? 0x80000000u : 0u); }
+  for (int e = 0; e < nd; e++) { int d = dig[e]; if (!d) continue; const int w = e < W ? e : e - W; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1;
+    entries[lbase[key] + rank[e]] = (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u) | (e >= W ? MSM_ENTRY_PHI : 0u); }
 }
 
 // One-pass sort for scalars known to be uniform (the H query: coefficients of the quotient polynomial) with all windows sharing one bucket array: every bucket owns
@@ -95,15 +129,15 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const Fr *__restrict__ scal
 template <int DUMMY = 0>
 __global__ void k_msm_scatter_direct(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf, uint32_t n, int c, int W, uint32_t point_stride,
                                      uint32_t cap, uint32_t *__restrict__ counts, uint32_t *__restrict__ entries, MsmCounters *cnt, MsmCounters *cnt_next,
-                                     const Fr *__restrict__ mul_b, const Fr *__restrict__ mul_z, int z_is_table) {
+                                     const Fr *__restrict__ mul_b, const Fr *__restrict__ mul_z, int z_is_table, int glv) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i == 0) *cnt_next = MsmCounters{0, 0, {0, 0}}; if (i >= n) return;
   if (point_is_inf && point_is_inf[i]) return;
   Fr k = scalars[scalar_index ? scalar_index[i] : i]; if (mul_b) k = k * mul_b[i] * mul_z[z_is_table ? i : 0];   // mul_b: the scalar is the product a*b*z (the pointwise step of the witness map, fused)
   k = k.from_mont();
   if (k.is_zero()) return;
-  int dig[MSM_MAX_WINDOWS]; signed_digits(k.l, c, W, dig); bool over = false;
-  for (int w = 0; w < W; w++) { int d = dig[w]; if (!d) continue; uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, slot = atomicAdd(&counts[key], 1u);
-    if (slot < cap) entries[(size_t)key * cap + slot] = (i + (uint32_t)w * point_stride) | (d < 0 ? 0x80000000u : 0u); else over = true; }
+  int dig[MSM_MAX_WINDOWS]; const int nd = msm_digits(k.l, c, W, glv, dig); bool over = false;
+  for (int e = 0; e < nd; e++) { int d = dig[e]; if (!d) continue; const int w = e < W ? e : e - W; uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, slot = atomicAdd(&counts[key], 1u);
+    if (slot < cap) entries[(size_t)key * cap + slot] = (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u) | (e >= W ? MSM_ENTRY_PHI : 0u); else over = true; }
   if (over) atomicOr(&cnt->pad[0], 1u);
 }
 
@@ -203,16 +237,18 @@ static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_small(const ui
 // task_off: exclusive scan of ntasks over the SORTED bucket list (n_buckets + 1 entries, the last one = total)
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
-                                                              const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, uint32_t n_buckets, uint32_t max_tasks, uint32_t task, XYZZ<F> *__restrict__ buckets, XYZZ<F> *__restrict__ partials) {
+                                                              const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, uint32_t n_buckets, uint32_t max_tasks, uint32_t task, const F *__restrict__ beta, XYZZ<F> *__restrict__ buckets, XYZZ<F> *__restrict__ partials) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= max_tasks || t >= task_off[n_buckets]) return;
   uint32_t lo = 0, hi = n_buckets;                         // largest i with task_off[i] <= t
   while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (task_off[mid] <= t) lo = mid; else hi = mid; }
   uint32_t b = order[lo], j = t - task_off[lo], cnt = counts[b], beg = offsets[b] + j * task, end = offsets[b] + min(cnt, (j + 1) * task);
   XYZZ<F> acc = XYZZ<F>::inf();
-  uint32_t v = entries[beg], vn = beg + 1 < end ? entries[beg + 1] : v; Affine<F> p = points[v & 0x7fffffffu];   // (beg < end: tasks exist only for non-empty slices)
+  const uint32_t imask = beta ? ~(MSM_ENTRY_SIGN | MSM_ENTRY_PHI) : ~MSM_ENTRY_SIGN; F bt = F::zero(); if (beta) bt = *beta;
+  uint32_t v = entries[beg], vn = beg + 1 < end ? entries[beg + 1] : v; Affine<F> p = points[v & imask];   // (beg < end: tasks exist only for non-empty slices)
 #pragma unroll 1
   for (uint32_t e = beg; e < end; e++) {                 // software pipeline: the next point and the entry after it are in flight while this point is added (random table gathers)
-    Affine<F> pn = points[vn & 0x7fffffffu]; uint32_t vnn = e + 2 < end ? entries[e + 2] : vn;
+    Affine<F> pn = points[vn & imask]; uint32_t vnn = e + 2 < end ? entries[e + 2] : vn;
+    if (beta && (v & MSM_ENTRY_PHI)) p.x = p.x * bt;     // second GLV half: lambda*(x, y) = (beta*x, y)
     if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; vn = vnn; }
   if (cnt <= task) buckets[b] = acc; else partials[t] = acc;
 }

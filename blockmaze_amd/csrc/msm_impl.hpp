@@ -35,11 +35,16 @@ struct MsmImpl {
   static bool use_precompute(size_t n_, int W_) { static const bool on = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE"); return !e || atoi(e) != 0; }();
     static const size_t cap = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE_MAX_MB"); return (size_t)(e ? atol(e) : 768) << 20; }();
     return on && n_ > 0 && W_ > 1 && n_ * (size_t)W_ < (1ull << 31) && n_ * (size_t)W_ * sizeof(RawAffine) <= cap; }
-  MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true, bool uniform_hint = false)
-      : n(n_), c(c_), W(msm_num_windows(c_)), WB(tables && use_precompute(n_, msm_num_windows(c_)) ? 1 : msm_num_windows(c_)), NB(1u << (c_ - 1)), filter_ones(fo), points((n_ ? n_ : 1) * (size_t)(WB == 1 ? W : 1)), inf(n_ ? n_ : 1),
-        zeroed(2 * (size_t)WB * NB + 2 * sizeof(MsmCounters) / 4), offsets((size_t)WB * NB), entries((n_ ? n_ : 1) * (size_t)W), ones(n_ ? n_ : 1), ntasks((size_t)WB * NB + 1), task_off((size_t)WB * NB + 1), cls_start(BSORT_CLASSES),
+  static int windows_for(int c_, bool glv_) { return glv_ ? 132 / c_ + 1 : msm_num_windows(c_); }   // GLV halves are below 2^128 (measured bound 2^127; four spare bits)
+  static bool glv_possible(size_t n_, int c_, bool fo, bool tables, bool uniform_hint, bool glv_hint) { return glv_hint && uniform_hint && tables && !fo && sizeof(F) == 32 && use_precompute(n_, windows_for(c_, true)) && getenv("ZK_MSM_NO_GLV") == nullptr; }
+  bool glv = false; DevBuf<Fe32> beta;   // GLV: two half-length scalars per point, the second half addresses lambda*P = (beta*x, y)
+  MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true, bool uniform_hint = false, bool glv_hint = false)
+      : n(n_), c(c_), W(windows_for(c_, glv_possible(n_, c_, fo, tables, uniform_hint, glv_hint))), WB(tables && use_precompute(n_, windows_for(c_, glv_possible(n_, c_, fo, tables, uniform_hint, glv_hint))) ? 1 : windows_for(c_, glv_possible(n_, c_, fo, tables, uniform_hint, glv_hint))), NB(1u << (c_ - 1)), filter_ones(fo), points((n_ ? n_ : 1) * (size_t)(WB == 1 ? W : 1)), inf(n_ ? n_ : 1),
+        zeroed(2 * (size_t)WB * NB + 2 * sizeof(MsmCounters) / 4), offsets((size_t)WB * NB), entries((n_ ? n_ : 1) * (size_t)W * 2), ones(n_ ? n_ : 1), ntasks((size_t)WB * NB + 1), task_off((size_t)WB * NB + 1), cls_start(BSORT_CLASSES),
         scanner((size_t)WB * NB), task_scanner((size_t)WB * NB + 1) {
     if (c < 6 || c > 20 || W > MSM_MAX_WINDOWS) throw GpuError("msm: unsupported window size");
+    glv = glv_possible(n_, c_, fo, tables, uniform_hint, glv_hint); if (glv && (WB != 1 || n * (size_t)W >= (1ull << 30))) glv = false;
+    if (glv) { DevBuf<Fe32> b(1); Fe32 bm; memcpy(&bm, GLV_BETA_MONT, 32); b.upload(&bm, 1); beta = std::move(b); }
     { const char *e = getenv("ZK_MSM_SEG"); uint32_t big = e ? (uint32_t)atoi(e) : 16; if (big < 2 || big > 256 || (big & (big - 1))) big = 16; seg = NB >= 4096 ? (WB == 1 ? 4 : big) : 4; }   // one bucket array: few segments, keep the dependent chain short
     n_ones_quads = 16384;
     std::vector<uint8_t> flags(n ? n : 1, 0); const uint8_t zero[sizeof(RawAffine)] = {0};
@@ -50,9 +55,9 @@ struct MsmImpl {
       hipLaunchKernelGGL((k_msm_precompute<F>), dim3(cdiv(n, 64)), dim3(64), 0, gpu().stream, (Affine<F> *)points.get(), (uint32_t)n, c, W, (XYZZ<F> *)tmp.get(), (F *)pref.get());
       HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream));
     }
-    max_tasks = (uint32_t)((n * (size_t)W) / MSM_TASK + (size_t)WB * NB + 1);
+    max_tasks = (uint32_t)((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1);
     if (uniform_hint && WB == 1 && !filter_ones && n && getenv("ZK_MSM_NO_DIRECT_SORT") == nullptr) {   // slots per bucket: twice the expected load (+64), a power of two
-      size_t lam = (n * (size_t)W) / NB, want = 2 * lam + 64; cap = 64; while (cap < want) cap <<= 1;
+      size_t lam = (n * (size_t)msm_num_windows(c)) / NB, want = 2 * lam + 64; cap = 64; while (cap < want) cap <<= 1;
       if (const char *e = getenv("ZK_MSM_DIRECT_CAP")) { int v = atoi(e); if (v >= 1 && v <= 4080) cap = (uint32_t)v; }   // test hook: a tiny capacity forces the overflow fallback
       if ((size_t)NB * cap <= (1ull << 28)) { direct = true; entries = DevBuf<uint32_t>((size_t)NB * cap);
         const char *e = getenv("ZK_MSM_DIRECT_TASK"); int tv = e ? atoi(e) : 16; if (lam >= 64 && (tv == 16 || tv == 32 || tv == 64)) task = (uint32_t)tv; } }   // (measured: 32 halves the combine but costs as much in the accumulation, which then has too few lanes)
@@ -90,7 +95,7 @@ struct MsmImpl {
     if (direct) { Stage st((label + ".sort").c_str(), s);
       if (!offsets_direct) { std::vector<uint32_t> o(nbk); for (size_t b = 0; b < nbk; b++) o[b] = (uint32_t)(b * cap); offsets.upload(o.data(), nbk);
         for (size_t b = 0; b < nbk; b++) o[b] = (uint32_t)b; order.upload(o.data(), nbk); rank_of.upload(o.data(), nbk); offsets_direct = true; }   // identity ranking: uniform buckets need no size ordering
-      hipLaunchKernelGGL(k_msm_scatter_direct<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, point_stride, cap, hist(), entries.get(), cnt, counters_next(), (const Fr *)prod_b, (const Fr *)prod_z, (int)prod_z_table);
+      hipLaunchKernelGGL(k_msm_scatter_direct<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, point_stride, cap, hist(), entries.get(), cnt, counters_next(), (const Fr *)prod_b, (const Fr *)prod_z, (int)prod_z_table, (int)glv);
       if (nbk <= PLAN_DIRECT_MAX && cap <= 4080) hipLaunchKernelGGL(k_msm_plan_direct, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, cap, task, task_off.get(), cls_start.get());
       else {
         hipLaunchKernelGGL(k_bsort_hist, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_hist.get(), cap);
@@ -100,7 +105,7 @@ struct MsmImpl {
       }
     } else
     { Stage st((label + ".sort").c_str(), s);
-      if (n) hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, (uint32_t)nbk, hist(), ones.get(), cnt, counters_next());
+      if (n) hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, (uint32_t)nbk, (int)glv, hist(), ones.get(), cnt, counters_next());
       if (filter_ones && n && split_ones) { HIP_CHECK(hipEventRecord(ev_classified, s)); HIP_CHECK(hipStreamWaitEvent(ones_stream, ev_classified, 0)); ones_path(ones_stream); HIP_CHECK(hipEventRecord(ev_ones, ones_stream)); ones_forked = true; }
       if (nbk <= PLAN_SMALL_MAX) {
         hipLaunchKernelGGL(k_msm_plan_small, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, offsets.get(), order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
@@ -111,10 +116,10 @@ struct MsmImpl {
         hipLaunchKernelGGL(k_bsort_scatter, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_off.get(), order.get(), rank_of.get(), ntasks.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
         task_scanner.run(ntasks.get(), task_off.get(), nbk + 1, s);
       }
-      if (n) hipLaunchKernelGGL(k_msm_scatter<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, point_stride, (uint32_t)nbk, offsets.get(), fill(), entries.get());
+      if (n) hipLaunchKernelGGL(k_msm_scatter<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, point_stride, (uint32_t)nbk, (int)glv, offsets.get(), fill(), entries.get());
     }
     { Stage st((label + ".accumulate").c_str(), s);
-      hipLaunchKernelGGL((k_msm_accumulate_tasks<F>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), order.get(), task_off.get(), (uint32_t)nbk, max_tasks, direct ? task : MSM_TASK,
+      hipLaunchKernelGGL((k_msm_accumulate_tasks<F>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), order.get(), task_off.get(), (uint32_t)nbk, max_tasks, direct ? task : MSM_TASK, glv ? (const F *)beta.get() : (const F *)nullptr,
                          (XYZZ<F> *)buckets.get(), (XYZZ<F> *)partials.get());
     }
     { Stage st((label + ".combine").c_str(), s);

@@ -81,6 +81,17 @@ def test_msm_one_pass_sort_and_its_overflow_fallback():
     K2 = rand_field_arr(4243, n); m.set_scalars(K2); assert o.g1_from(m.run())[0] == o.msm_g1(P, K2)
     m.close()
 
+def test_msm_glv_halves_match_oracle():
+    """GLV (k = k1 + k2*lambda, second half on (beta*x, y)) on top of the tables and the one-pass sort: uniform scalars, the edge scalars of the decomposition, and
+    the overflow fallback (which has to decompose the same way on the two-pass path)"""
+    n = 5000; g = o.SplitMix64(91); P = o.g1_consecutive(g.field(), n); P[17] = 0; m = e.ResidentMsm(1, P, 12, filter_ones=2 | 4)
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    K = rand_field_arr(777, n); edge = [0, 1, 2, o.R_MOD - 1, o.R_MOD - 2, lam, lam + 1, lam - 1, (lam * lam) % o.R_MOD, (o.R_MOD - 1) // 2, 1 << 127, (1 << 128) - 1, 1 << 253]
+    K[:len(edge)] = o.to_arr(edge); m.set_scalars(K); assert o.g1_from(m.run())[0] == o.msm_g1(P, K)
+    same = o.to_arr([lam * 12345 % o.R_MOD] * n); m.set_scalars(same); assert o.g1_from(m.run())[0] == o.msm_g1(P, same)          # every digit equal: overflow -> two-pass path
+    K2 = rand_field_arr(778, n); m.set_scalars(K2); assert o.g1_from(m.run())[0] == o.msm_g1(P, K2)
+    m.close()
+
 def test_msm_degenerate_inputs():
     assert o.g1_from(e.msm(1, np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)))[0] is None         # empty
     P = o.g1_consecutive(5, 64); assert o.g1_from(e.msm(1, P, np.zeros((64, 4), np.uint64), filter_ones=True))[0] is None   # all-zero scalars
