@@ -5,7 +5,8 @@
 
 Corrections (MI355X_MICROARCH.md, HBM section): both counters are reported in KB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes for wide
 coalesced reads, so it is doubled; WRITE_SIZE is taken as is.  Both are checked in the same run on k_qap_pointwise, a pure streaming kernel with a known
-byte count (reads 3 vectors and writes 1 vector of m field elements of 32 bytes): the `calibration` entry holds measured/expected for both.
+byte count (reads 3 vectors and writes 1 vector of m field elements of 32 bytes) or, in builds where that step is fused into the MSM sort, on k_fr_to_mont (the in-place
+conversion of the assignment: n x 32 bytes read and written): the `calibration` entry holds measured/expected for both.
 """
 import csv, glob, json, os, sys, collections
 def load(d, counter):
@@ -25,7 +26,9 @@ acc = [(k, v) for k, v in out["kernels"].items() if k.startswith("k_msm_accumula
 if acc:
     name, v = max(acc, key=lambda kv: kv[1]["hbm_bytes_per_launch"]); out["k_msm_accumulate_H"] = dict(v, kernel=name)
 pw = [(k, v) for k, v in out["kernels"].items() if k.startswith("k_qap_pointwise")]
-if pw:
-    name, v = pw[0]; m = int(name.split("grid=")[1]); exp_r, exp_w = 3 * m * 32, m * 32
+fm = [(k, v) for k, v in out["kernels"].items() if k.startswith("k_fr_to_mont")]
+if pw or fm:
+    if pw: name, v = pw[0]; m = int(name.split("grid=")[1]); exp_r, exp_w = 3 * m * 32, m * 32       # reads a, b, c, writes a
+    else: name, v = max(fm, key=lambda kv: int(kv[0].split("grid=")[1])); m = int(name.split("grid=")[1]); exp_r, exp_w = m * 32, m * 32   # in-place conversion of the assignment (grid = n rounded up to 256)
     out["calibration"] = {"kernel": name, "expected_read_bytes": exp_r, "expected_write_bytes": exp_w, "corrected_read_over_expected": round(2 * v["FETCH_SIZE_KB_raw"] * 1024 / exp_r, 3), "write_over_expected": round(v["WRITE_SIZE_KB"] * 1024 / exp_w, 3)}
 print(json.dumps(out, indent=1))
