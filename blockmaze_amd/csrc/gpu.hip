@@ -103,10 +103,10 @@ static std::vector<Fe32> geometric_table(size_t n, const HFr &first, const HFr &
 
 // in-place radix-2 transform of `batch` vectors: data = post * NTT(pre * data), natural order in and out.  Up to 2^22 points: two LDS-tiled passes
 // (k_ntt_cols: data -> scratch, k_ntt_rows: scratch -> data; one pass in place when the whole vector fits a tile); beyond that the stage-per-launch path.
-static int ntt_pref_log_c() { static const int v = [] { const char *e = getenv("ZK_NTT_LOGC"); int x = e ? atoi(e) : 1; return x < 0 ? 0 : x > 3 ? 3 : x; }(); return v; }
+static int ntt_pref_log_c() { static const int v = [] { const char *e = getenv("ZK_NTT_LOGC"); int x = e ? atoi(e) : 0; return x < 0 ? 0 : x > 3 ? 3 : x; }(); return v; }
 static void radix2_transform(Fe32 *data, Fe32 *scratch, const Fe32 *tw, int logn, const Fe32 *pre_scale, const Fe32 *post_scale, int batch, size_t stride, size_t scratch_stride) {
   hipStream_t s = gpu().stream; size_t n = (size_t)1 << logn;
-  static const int rl = [] { const char *e = getenv("ZK_NTT_RADIX_LOG"); int x = e ? atoi(e) : 3; return x < 1 ? 1 : x > 3 ? 3 : x; }();   // radix-8 passes measured best with three vectors per launch
+  static const int rl = [] { const char *e = getenv("ZK_NTT_RADIX_LOG"); int x = e ? atoi(e) : 2; return x < 1 ? 1 : x > 3 ? 3 : x; }();   // radix-4 passes on one-column tiles measured best with two vectors per launch (twice the waves of radix 8: the passes are latency bound), radix 8 with three
   static const bool lds_raised = [] { HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_cols, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); return true; }(); (void)lds_raised;
   auto threads_for = [](int logN, int logC) { int g = logN + logC - rl; unsigned t = 1u << (g < 6 ? 6 : g > 8 ? 8 : g); return t; };   // one butterfly group per thread and pass, 64..256 threads
   auto lds_for = [](int logN, int logC) { size_t e = (size_t)1 << (logN + logC); return sizeof(Fr) * (e + (e >> 4) + 1) + (sizeof(Fr) << logN) / 2; };   // padded tile (ntt_pad) + twiddle table
