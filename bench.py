@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: Groth16 proofs/sec for BlockMaze's send circuit on MI355X.
 
-A step = one send proof per rank through libzkgpu.so's resident prover (the r1cs_gg_ppzksnark_prover equivalent:
-R1CS rows -> 7 NTTs (4 on the device per proof, 3 folded into the key) -> 5 MSMs -> proof assembly; reference r1cs_gg_ppzksnark.tcc:391-506), witness vector handed over as a
-host buffer.  N ranks prove independent seeded instances (proofs are independent units: no data-path collective), so
-value = N*K proofs / max-over-ranks wall time ("weak" scaling).
+A step = one send proof per rank through libzkgpu.so's prover entry point `zkgpu_prover_prove` — the equivalent of one
+`r1cs_gg_ppzksnark_prover(pk, primary, auxiliary)` call (reference r1cs_gg_ppzksnark.tcc:391-506): the full assignment
+arrives as a HOST buffer, a different one every step, and the serialized proof comes back.  N ranks prove independent
+seeded instances (proofs are independent units: no data-path collective), so value = N*K proofs / max-over-ranks wall
+time ("weak" scaling).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+        N > 1 without a launcher: this script starts the N ranks itself (child processes, one per GPU, created before
+        anything in the parent touches the GPU) and exits with their status.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+        (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; --gpus must equal WORLD_SIZE)
 
-Prints ONE JSON line on rank 0.  `roofline` times the dominant kernel (bucket accumulation of the H-query MSM) with HIP
-events on the library's compute stream; `cpu_baseline` times the reference's own prover (oracle/_ref, kind "reference") or,
-where that binary is absent, the plain-C oracle (kind "port") on one send proof on the host cores.
+Prints ONE JSON line on rank 0's stdout (everything else, including the reference-style chatter of the cgo symbols,
+goes to stderr).  `roofline` times the dominant kernel (bucket accumulation of the H-query MSM) with HIP events on the
+library's compute stream; `cpu_baseline` times the reference's own prover (oracle/_ref, kind "reference") on the host
+cores, or the plain-C oracle (kind "port") where that binary is absent.
 """
-import argparse, json, os, subprocess, sys, tempfile, time
+import argparse, json, os, socket, subprocess, sys, tempfile, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -21,96 +26,152 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 H_PAIRS = 262143                       # H-query size of the send circuit (m - 1, m = 2^18)
 BYTES_PER_G1_PAIR = 96                 # 64 B affine point + 32 B scalar, each read once
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s
+MAX_DISTINCT_WITNESSES = 64            # host memory bound (7.3 MB each); longer runs cycle through them, consecutive steps still differ
 
-def main():
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+def parse_args():
     ap = argparse.ArgumentParser(); ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="only the timed region and the roofline leg (what the N > 1 scaling runs need)")
     ap.add_argument("--inflight", type=int, default=4, help="extra leg (not `value`): this many prover objects per GPU, one host thread each, proofs overlapping on the device; 0/1 = skip")
+    ap.add_argument("--batch", type=int, default=16, help="extra leg (not `value`): zkgpu_prover_prove_batch with this many witnesses per call (BASELINE.json configs[2]); 0/1 = skip")
     ap.add_argument("--shard-msm", action="store_true", help="N > 1 only: all ranks prove ONE proof per step together, each holding 1/N of every query; one all-gather of 384-byte partial records per proof (strong scaling)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+def launch(args):
+    """--gpus N without a launcher: start the N ranks as child processes.  Nothing here imports torch or touches HIP, so no process that initialised the GPU is ever
+    replaced or forked; a rank that fails takes the whole run down with a non-zero status."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ZK_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0; pending = set(range(args.gpus))
+    while pending:
+        for r in list(pending):
+            c = procs[r].poll()
+            if c is None: continue
+            pending.discard(r)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1; log("bench: rank %d exited with status %d, stopping the other ranks" % (r, c))
+                for q in pending: procs[q].terminate()                       # exact child PIDs only
+        time.sleep(0.05)
+    return rc
+
+def read_witness(path):
+    """[u64 n | n * 32 bytes] as written by libzkgpu's witness generators -> (n, 4) uint64 canonical values"""
+    import numpy as np
+    b = open(path, "rb").read(); n = int(np.frombuffer(b, dtype=np.uint64, count=1)[0]); return np.frombuffer(b, dtype=np.uint64, count=4 * n, offset=8).reshape(n, 4).copy()
+
+def harness_kv(harness, *cmd):
+    out = subprocess.run([harness, *cmd], capture_output=True, text=True).stdout; kv = {}
+    for line in out.splitlines():
+        tok = line.split()
+        for a, b in zip(tok[0::2], tok[1::2]): kv[a] = b
+    return kv
+
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("bench: --gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world)); return 2
+    # the cgo symbols print the reference's progress lines on stdout (sendcgo.cpp:352,458): keep fd 1 for the JSON line only
+    sys.stdout.flush(); real_stdout = os.fdopen(os.dup(1), "w"); os.dup2(2, 1)
     os.environ.setdefault("ZK_DEVICE", str(local_rank))
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # the prover runs five streams; the HIP runtime (initialised by torch below) maps them onto 4 hardware queues by default
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # torch initialises the HIP runtime before libzkgpu.so is loaded, so the library's own load-time default would come too late here
     import torch
+    backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")                 # "gloo": lets the N > 1 code path run on a box with fewer GPUs than ranks (ranks share devices)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")             # "gloo": lets the N > 1 code path run on a box with fewer GPUs than ranks (ranks share devices)
         if backend == "nccl": torch.cuda.set_device(local_rank); dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else: torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count())); dist.init_process_group(backend)
+        else: dist.init_process_group(backend)
+        log("bench: rank %d of %d joined the process group (backend %s)" % (dist.get_rank(), dist.get_world_size(), backend))
+        assert dist.get_world_size() == args.gpus
+        if backend != "nccl" and torch.cuda.is_available(): torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count())); os.environ["ZK_DEVICE"] = str(local_rank % max(1, torch.cuda.device_count()))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     from blockmaze_amd import engine as e
-    from oracle import pyoracle as o      # used ONLY to read witness files back and for the cpu_baseline leg
     import workload as w
+    hx = lambda a: [("0x" + x.hex()) if isinstance(x, bytes) else x for x in a]
+    e.init()                                                                 # raises "no HIP device visible" on a box without a GPU: there is no CPU path to fall back to
 
-    # ---- untimed setup: test keys for the send circuit (seeded toxic waste), resident prover, witnesses -----------------
+    # ---- untimed setup: test keys for the send circuit (seeded toxic waste), resident prover, one witness per step -----------------
     tmp = tempfile.mkdtemp(prefix="zkbench_%d_" % rank); pk_path, vk_path = os.path.join(tmp, "sendpk.txt"), os.path.join(tmp, "sendvk.txt")
     t0 = time.time(); e.keygen("send", pk_path, vk_path, seed=0xB10C4A2E); t_keygen = time.time() - t0
     shard = args.shard_msm and world > 1
     t0 = time.time(); prover = e.Prover(pk_path, rank, world) if shard else e.Prover(pk_path); t_load = time.time() - t0
-    n_inst = 4; insts, zs = [], []
+    n_inst = max(2, min(args.steps + args.warmup, MAX_DISTINCT_WITNESSES)); insts, zs = [], []; wp = os.path.join(tmp, "w.bin")
     for i in range(n_inst):
-        d = w.send_instance(i if shard else rank + i * world); wp = os.path.join(tmp, "w%d.bin" % i)
-        e.witness_send(*[("0x" + a.hex()) if isinstance(a, bytes) else a for a in w.send_args(d)], wp); insts.append(d); zs.append(o.load_witness(wp))
+        d = w.send_instance(i if shard else rank + i * world); e.witness_send(*hx(w.send_args(d)), wp); insts.append(d); zs.append(read_witness(wp))
+    e.witness_send(*hx(w.send_args(insts[0])), os.path.join(tmp, "w0.bin"))            # kept on disk for the CPU baseline
 
     def barrier():
         if dist is not None: dist.barrier()
         if torch.cuda.is_available(): torch.cuda.synchronize()
 
     from blockmaze_amd import sharding
-    coll_dev = None if dist is None else ("cuda" if os.environ.get("ZK_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
-    prover.set_witness(zs[0])                                                  # the assignment is resident in HBM before the timed region starts
+    coll_dev = None if dist is None else ("cuda" if backend == "nccl" else "cpu")
     if shard:
         def one_proof(i):                                                      # every rank runs the device pipeline on its slice; 384 B per rank are exchanged; rank 0 assembles
-            recs = sharding.gather_partials(prover.prove_partial(), dist, coll_dev)
+            prover.set_witness(zs[i % n_inst]); recs = sharding.gather_partials(prover.prove_partial(), dist, coll_dev)
             return prover.finish(recs, 0x1234567 + i, 0x7654321 + i) if rank == 0 else None
     else:
-        def one_proof(i): return prover.prove_resident()                        # synchronous: fresh (r, s), returns the serialized proof
+        def one_proof(i): return prover.prove(zs[i % n_inst])                   # host buffer in, fresh (r, s), serialized proof out; synchronous
     for i in range(args.warmup): one_proof(i)
     barrier(); t0 = time.perf_counter()
     last = None
-    for i in range(args.steps): last = one_proof(i)
+    for i in range(args.steps): last = one_proof(args.warmup + i)
     barrier(); dt = time.perf_counter() - t0
     rate, dt = sharding.aggregate_throughput((args.steps if rank == 0 else 0) if shard else args.steps, dt, dist, coll_dev)      # max over ranks, units summed
-    d = insts[0]
+    d = insts[(args.warmup + args.steps - 1) % n_inst]
     assert last is None or e.verify(vk_path, last, w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]])), "proof from the timed region does not verify"
 
-    # ---- not part of `value`: the same proofs with the witness handed over as a host buffer each time (PCIe inclusive), and through the
-    # drop-in cgo symbol genSendproof (adds witness generation on the host and hex marshalling)
-    nx = max(3, min(args.steps, 10)); ms_pcie = ms_abi = abi_conc = None
-    if not shard:
-        t0 = time.perf_counter()
-        for i in range(nx): prover.prove(zs[i % n_inst])
-        ms_pcie = 1e3 * (time.perf_counter() - t0) / nx
+    extra = {}
+    if not shard and not args.no_extra_legs:
+        nx = max(3, min(args.steps, 10))
+        # the device pipeline alone: the assignment already resident in HBM (no host hand-over per proof)
+        prover.set_witness(zs[0]); prover.prove_resident(); t0 = time.perf_counter()
+        for i in range(nx): prover.prove_resident()
+        ms_res = 1e3 * (time.perf_counter() - t0) / nx; extra["witness_resident_in_hbm"] = {"ms_per_proof": round(ms_res, 4), "proofs_per_s": round(1e3 / ms_res, 2)}
+        # through the drop-in cgo symbol genSendproof (adds witness generation on the host and hex marshalling), one caller and several at once as go-ethereum's goroutines do
         os.environ["ZK_PRFKEY_DIR"] = tmp; os.environ.setdefault("ZK_PROVERS_PER_KEY", str(max(2, args.inflight))); zk = e.Zk(); zk.GenSendProof(*w.send_args(insts[0])); t0 = time.perf_counter()
         for i in range(nx): zk.GenSendProof(*w.send_args(insts[i % n_inst]))
-        ms_abi = 1e3 * (time.perf_counter() - t0) / nx
-        if args.inflight > 1:                                                  # the same symbol called from several threads at once, as go-ethereum's goroutines do
-            import threading
+        ms_abi = 1e3 * (time.perf_counter() - t0) / nx; extra["through_genSendproof"] = {"ms_per_proof": round(ms_abi, 4), "proofs_per_s": round(1e3 / ms_abi, 2)}
+        import threading
+        if args.inflight > 1:
             def caller(k):
                 for i in range(nx): zk.GenSendProof(*w.send_args(insts[(i + k) % n_inst]))
             ths = [threading.Thread(target=caller, args=(k,)) for k in range(args.inflight)]; t0 = time.perf_counter()
             for t in ths: t.start()
             for t in ths: t.join()
-            abi_conc = round(nx * args.inflight / (time.perf_counter() - t0), 2)
-
-    # ---- not part of `value`: K proofs in flight per GPU (K prover objects on their own stream sets, one host thread each): what a batch of independent
-    # proofs (BASELINE.json configs[2]) or concurrent cgo calls get
-    inflight = None
-    if not shard and args.inflight > 1:
-        import threading
-        provers = [prover] + [e.Prover(pk_path) for _ in range(args.inflight - 1)]
-        for k, pv in enumerate(provers): pv.set_witness(zs[k % n_inst]); pv.prove_resident()
-        per = max(4, args.steps)
-        def worker(pv):
-            for _ in range(per): pv.prove_resident()
-        ths = [threading.Thread(target=worker, args=(pv,)) for pv in provers]; t0 = time.perf_counter()
-        for t in ths: t.start()
-        for t in ths: t.join()
-        dti = time.perf_counter() - t0; inflight = {"provers": args.inflight, "proofs": per * args.inflight, "proofs_per_s": round(per * args.inflight / dti, 2), "ms_per_proof": round(1e3 * dti / (per * args.inflight), 4)}
-        for pv in provers[1:]: pv.close()
-        prover.set_witness(zs[0])
+            extra["through_genSendproof"]["concurrent_callers"] = args.inflight; extra["through_genSendproof"]["proofs_per_s_concurrent"] = round(nx * args.inflight / (time.perf_counter() - t0), 2)
+            # K prover objects on their own stream sets, one host thread each, host-buffer witnesses
+            provers = [prover] + [e.Prover(pk_path) for _ in range(args.inflight - 1)]
+            for k, pv in enumerate(provers): pv.prove(zs[k % n_inst])
+            per = max(4, args.steps)
+            def worker(k):
+                for i in range(per): provers[k].prove(zs[(i + k) % n_inst])
+            ths = [threading.Thread(target=worker, args=(k,)) for k in range(len(provers))]; t0 = time.perf_counter()
+            for t in ths: t.start()
+            for t in ths: t.join()
+            dti = time.perf_counter() - t0; extra["proofs_in_flight"] = {"provers": args.inflight, "proofs": per * args.inflight, "proofs_per_s": round(per * args.inflight / dti, 2), "ms_per_proof": round(1e3 * dti / (per * args.inflight), 4)}
+            for pv in provers[1:]: pv.close()
+        # B witnesses against one resident key in one call (BASELINE.json configs[2]: a batch of independent send proofs)
+        if args.batch > 1 and hasattr(prover, "prove_batch"):
+            B = args.batch; batch = [zs[i % n_inst] for i in range(B)]; proofs = prover.prove_batch(batch); reps = max(2, min(6, 128 // B)); t0 = time.perf_counter()
+            for _ in range(reps): proofs = prover.prove_batch(batch)
+            dtb = time.perf_counter() - t0
+            ok = all(e.verify(vk_path, proofs[k], w.pack_public([insts[k % n_inst][x] for x in ("cmtA_old", "sn_old", "cmtS", "cmtA")])) for k in (0, B - 1))
+            extra["prove_batch"] = {"batch": B, "proofs_per_s": round(B * reps / dtb, 2), "ms_per_proof": round(1e3 * dtb / (B * reps), 4), "verified": ok}
+        # BASELINE.json configs[0] beside it: one mint proof (step domain 196,608) on the GPU; its CPU time is in cpu_baseline
+        mpk, mvk = os.path.join(tmp, "mintpk.txt"), os.path.join(tmp, "mintvk.txt"); e.keygen("mint", mpk, mvk, seed=0xB10C4A2F); mp = e.Prover(mpk); md = w.mint_instance(0); mw = os.path.join(tmp, "mint_w.bin")
+        e.witness_mint_redeem(False, *hx(w.mint_args(md)), mw); mz = read_witness(mw); mp.prove(mz); t0 = time.perf_counter()
+        for i in range(nx): mproof = mp.prove(mz)
+        ms_mint = 1e3 * (time.perf_counter() - t0) / nx; mp.close()
+        assert e.verify(mvk, mproof, w.pack_public([md["cmtA_old"], md["sn_old"], md["cmtA"]], md["value_s"]))
+        extra["mint_single_proof"] = {"ms_per_proof": round(ms_mint, 4), "proofs_per_s": round(1e3 / ms_mint, 2)}
 
     # ---- roofline leg: HIP-event time of the dominant kernel, same stream, after the timed region --------------------------
     e.profile_enable(True); nprof = max(3, min(args.steps, 10))
@@ -119,48 +180,62 @@ def main():
     per_proof = {k: v["ms_total"] / nprof for k, v in stages.items()}
     dom = "msm_H.accumulate"; dom_ms = stages[dom]["ms_total"] / stages[dom]["count"]
     achieved = H_PAIRS * BYTES_PER_G1_PAIR / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    traffic = traffic_src = None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc):
-        try: traffic = json.load(open(pmc)).get("k_msm_accumulate_H", {}).get("hbm_bytes_per_launch")
+        try: j = json.load(open(pmc)); traffic = j.get("k_msm_accumulate_H", {}).get("hbm_bytes_per_launch"); traffic_src = "profiles/pmc_summary.json (%s)" % j.get("tag", "untagged")
         except Exception: traffic = None
     roofline = {"bound": "hbm", "kernel": "k_msm_accumulate_tasks<Fq> (H query)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": traffic, "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": H_PAIRS * BYTES_PER_G1_PAIR}
-
+                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": H_PAIRS * BYTES_PER_G1_PAIR}
     # what actually bounds that kernel: 254-bit field products on the integer VALU.  One mixed addition = 10 products; the H accumulation does one per
     # non-zero signed 16-bit digit (262,143 scalars x 16 windows, a digit is zero with probability 2^-16); ceiling = tools/fmul_bench.hip on the same chip
     madds = H_PAIRS * 16 * (1.0 - 2.0 ** -16); gprod = madds * 10 / (dom_ms * 1e-3) / 1e9
     roofline_valu = {"bound": "valu-int (not part of the contract: the number that tracks this kernel's quality)", "kernel": roofline["kernel"], "achieved": round(gprod, 2), "peak": 126.0, "unit": "G field products/s", "frac": round(gprod / 126.0, 4)}
 
-    # ---- CPU baseline leg (rank 0, N = 1 only): the reference prover on one send proof ------------------------------------
-    cpu = None
+    # ---- CPU baseline legs (rank 0, N = 1 only): the reference's own code on the host cores -------------------------------
+    cpu = None; cpu_more = {}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness"); r1cs_path = os.path.join(tmp, "send_r1cs.bin"); e.circuit_export("send", r1cs_path)
+        harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness"); harness_mt = harness + "_mt"; r1cs_path = os.path.join(tmp, "send_r1cs.bin"); e.circuit_export("send", r1cs_path); w0 = os.path.join(tmp, "w0.bin")
         if os.path.exists(harness):
-            out = subprocess.run([harness, "bench_prover", r1cs_path, os.path.join(tmp, "w0.bin")], capture_output=True, text=True).stdout
-            kv = dict(zip(out.split()[0::2], out.split()[1::2])) if False else {}
-            for line in out.splitlines():
-                tok = line.split()
-                for a, b in zip(tok[0::2], tok[1::2]): kv[a] = b
+            kv = harness_kv(harness, "bench_prover", r1cs_path, w0)
             if "prover_total_s" in kv:
                 cpu = {"value": round(1.0 / float(kv["prover_total_s"]), 5), "unit": "proofs/s", "cores": 1, "kind": "reference",
                        "sample": "1 send proof by libsnark's r1cs_gg_ppzksnark_prover (oracle/_ref), key of the send circuit's shape with synthetic points; %.2f s" % float(kv["prover_total_s"])}
+            if os.path.exists(harness_mt):                                   # the reference's -DMULTICORE build (OpenMP over FFT butterflies and multi_exp chunks) on all host cores
+                ncores = os.cpu_count() or 1; kv = harness_kv(harness_mt, "bench_prover", r1cs_path, w0)
+                if "prover_total_s" in kv: cpu_more["multicore"] = {"value": round(1.0 / float(kv["prover_total_s"]), 5), "unit": "proofs/s", "cores": int(kv.get("threads", ncores)), "kind": "reference", "sample": "same proof, libsnark built with -DMULTICORE -fopenmp; %.2f s" % float(kv["prover_total_s"])}
+            if not args.no_extra_legs:
+                # what one genSendproof call costs in the reference: the key file is parsed and its 943k points decompressed on EVERY call (sendcgo.cpp:345), then the prover runs
+                kv = harness_kv(harness, "prove", pk_path, w0, "5", "1234", "5678")
+                if "load_pk_s" in kv and "prove_s" in kv:
+                    tot = float(kv["load_pk_s"]) + float(kv["prove_s"]); cpu_more["per_call_incl_key_load"] = {"value": round(1.0 / tot, 5), "unit": "proofs/s", "cores": 1, "kind": "reference", "key_load_s": float(kv["load_pk_s"]), "prove_s": float(kv["prove_s"]),
+                                                              "sample": "reference operator>> on the 77 MB send key + prover, as every genSendproof call of the reference does; %.1f s" % tot}
+                mr = os.path.join(tmp, "mint_r1cs.bin"); e.circuit_export("mint", mr); kv = harness_kv(harness, "bench_prover", mr, os.path.join(tmp, "mint_w.bin"))
+                if "prover_total_s" in kv: cpu_more["mint_single_proof"] = {"value": round(1.0 / float(kv["prover_total_s"]), 5), "unit": "proofs/s", "cores": 1, "kind": "reference", "sample": "BASELINE.json configs[0]: 1 mint proof by libsnark's prover; %.2f s" % float(kv["prover_total_s"])}
         if cpu is None:
+            from oracle import pyoracle as o      # checker code, used here ONLY as the timed CPU baseline
             cs = o.R1CS.load(r1cs_path); cs = cs.swapped() if cs.swap_ab_beneficial() else cs; pk, _ = o.parse_pk(pk_path); t0 = time.time(); o.prove(cs, zs[0], pk, 12345, 67890); t = time.time() - t0
             cpu = {"value": round(1.0 / t, 5), "unit": "proofs/s", "cores": 1, "kind": "port", "sample": "1 send proof by the plain-C oracle prover; %.2f s" % t}
 
     if rank == 0:
-        total = args.steps * world
-        print(json.dumps({
+        line = {
             "metric": "Groth16 proofs/sec (send circuit, alt_bn128)", "value": round(rate, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery)", "data": "synthetic",
-            "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
-                       "includes": "R1CS rows + the 7 NTTs of the witness map (4 run per proof; both transforms of C and the final inverse are folded into the L and H queries at key load) + 5 MSM + host proof assembly + hex serialisation, assignment resident in HBM; excludes witness generation and key load"},
-            "proofs_in_flight": inflight, "ms_per_proof_host_buffer_in": ms_pcie and round(ms_pcie, 4), "ms_per_proof_through_genSendproof": ms_abi and round(ms_abi, 4), "proofs_per_s_through_genSendproof_concurrent_callers": abi_conc,
-            "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu,
-            "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2)}}))
+            "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "distinct_witnesses": n_inst,
+                       "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
+                       "includes": "one prover call per step on a fresh HOST-buffer assignment (a different witness every step): hand-over to the device, R1CS rows, the 7 NTTs of the witness map (4 run per proof; both transforms of C and the final inverse are folded into the L and H queries at key load), 5 MSM, host proof assembly, hex serialisation; excludes witness generation and key load"},
+            "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "cpu_baseline_variants": cpu_more or None, "extra_legs": extra or None,
+            "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2)}}
+        real_stdout.write(json.dumps(line) + "\n"); real_stdout.flush()
     prover.close()
     if dist is not None: dist.destroy_process_group()
+    return 0
+
+def main():
+    args = parse_args()
+    if args.gpus < 1: log("bench: --gpus must be >= 1"); return 2
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ: return launch(args)
+    return run_rank(args)
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

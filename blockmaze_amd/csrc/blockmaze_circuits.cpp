@@ -260,6 +260,26 @@ std::unique_ptr<Circuit> make_mint_circuit(bool emit) { return std::unique_ptr<C
 void assign_mint(Circuit &c, const MintInputs &in) { static_cast<MintRedeemCircuit &>(c).assign(in); }
 std::unique_ptr<Circuit> make_redeem_circuit(bool emit) { return std::unique_ptr<Circuit>(new MintRedeemCircuit(emit, true)); }
 void assign_redeem(Circuit &c, const RedeemInputs &in) { static_cast<MintRedeemCircuit &>(c).assign(in); }
+// test circuit: the "value_s <= value_old" block of send's and redeem's note gadgets on its own (note.tcc:35-59,78-83 + less_cmp.tcc:23-34): compared with the
+// reference's comparison.tcc compiled for real (oracle/ref_harness.cpp cmd_lesscmp)
+struct LessCmpTestCircuit : Circuit {
+  VarArray value_old, value_s; Var value_old_packed, value_s_packed; std::unique_ptr<LessCmp> less;
+  explicit LessCmpTestCircuit(bool emit) : Circuit(emit) { Board &b = board; value_old = b.alloc_array(64); value_s = b.alloc_array(64); value_old_packed = b.alloc(); value_s_packed = b.alloc();
+    less.reset(new LessCmp(b, LC(value_s_packed), LC(value_old_packed))); if (emit) { bool64(b, value_old); bool64(b, value_s); less->constraints(); } b.finish(); }
+  void assign(uint64_t v_old, uint64_t v_s) { Board &b = board; fill(b, value_old, u64_bits(v_old)); b.val[value_old_packed] = value_by_order(b, value_old); fill(b, value_s, u64_bits(v_s)); b.val[value_s_packed] = value_by_order(b, value_s); less->witness(); }
+};
+// test circuit: one sha256_CMTA_gadget (commitment.tcc:12-110) on its own — ZERO, value, sn, r, output digest, then the gadget; compared with the same composition
+// built from libsnark's own classes (oracle/ref_harness.cpp cmd_cmta)
+struct CmtaTestCircuit : Circuit {
+  Var ZERO; VarArray v, sn, r; std::unique_ptr<Digest> out; std::unique_ptr<ShaTwoBlock> g;
+  explicit CmtaTestCircuit(bool emit) : Circuit(emit) { Board &b = board; ZERO = b.alloc(); v = b.alloc_array(64); sn = b.alloc_array(256); r = b.alloc_array(256); out.reset(new Digest(b, 256)); g = make_cmta(b, ZERO, v, sn, r, out->bits);
+    if (emit) { b.constraint(ONE_LC, LC(ZERO), LC()); g->constraints(); } b.finish(); }
+  void assign(const std::vector<bool> &bv, const std::vector<bool> &bsn, const std::vector<bool> &br) { Board &b = board; b.val[ZERO] = HFr::zero(); fill(b, v, bv); fill(b, sn, bsn); fill(b, r, br); g->witness(); }
+};
+std::unique_ptr<Circuit> make_cmta_test_circuit(bool emit) { return std::unique_ptr<Circuit>(new CmtaTestCircuit(emit)); }
+void assign_cmta_test(Circuit &c, const std::vector<bool> &v, const std::vector<bool> &sn, const std::vector<bool> &r) { static_cast<CmtaTestCircuit &>(c).assign(v, sn, r); }
+std::unique_ptr<Circuit> make_lesscmp_test_circuit(bool emit) { return std::unique_ptr<Circuit>(new LessCmpTestCircuit(emit)); }
+void assign_lesscmp_test(Circuit &c, uint64_t value_old, uint64_t value_s) { static_cast<LessCmpTestCircuit &>(c).assign(value_old, value_s); }
 std::unique_ptr<Circuit> make_sha256_two_to_one(bool emit) { return std::unique_ptr<Circuit>(new Sha256TwoToOne(emit)); }
 void assign_sha256_two_to_one(Circuit &c, const std::vector<bool> &l, const std::vector<bool> &r) { auto &s = static_cast<Sha256TwoToOne &>(c); s.left->fill(l); s.right->fill(r); s.f->witness(); }
 

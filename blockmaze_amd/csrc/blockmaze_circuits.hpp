@@ -61,6 +61,14 @@ void assign_deposit(Circuit &c, const DepositInputs &in);
 std::unique_ptr<Circuit> make_sha256_two_to_one(bool emit);
 void assign_sha256_two_to_one(Circuit &c, const std::vector<bool> &left, const std::vector<bool> &right);
 
+// test circuit: BlockMaze's less_comparison_gadget block (send/circuit/comparison.tcc:5-96 as composed by note.tcc / less_cmp.tcc)
+std::unique_ptr<Circuit> make_lesscmp_test_circuit(bool emit);
+void assign_lesscmp_test(Circuit &c, uint64_t value_old, uint64_t value_s);
+
+// test circuit: one sha256_CMTA_gadget (send/circuit/commitment.tcc:12-110): two chained compressions with hard-wired padding; bit vectors of 64 / 256 / 256 entries
+std::unique_ptr<Circuit> make_cmta_test_circuit(bool emit);
+void assign_cmta_test(Circuit &c, const std::vector<bool> &v, const std::vector<bool> &sn, const std::vector<bool> &r);
+
 // test circuit: libsnark's merkle_tree_check_read_gadget as its self-test composes it (merkle_tree_check_read_gadget.tcc:131-196)
 std::unique_ptr<Circuit> make_merkle_test_circuit(bool emit, size_t depth);
 void assign_merkle_test(Circuit &c, const Blob256 &leaf, const std::vector<Blob256> &path /* leaf level first */, const std::vector<bool> &index_bits, const Blob256 &root);

@@ -40,27 +40,33 @@ bool stamp_of(const std::string &p, FileStamp &s) { struct stat st; if (stat(p.c
 // One proving key = a small pool of provers (ZK_PROVERS_PER_KEY, default 2), each with its own circuit board, device buffers and stream set: cgo calls
 // that arrive concurrently (tx pool, RPC goroutines, block processing) overlap on the GPU instead of queueing behind one mutex.
 struct ProverUnit { std::shared_ptr<Prover> prover; std::unique_ptr<Circuit> circuit; std::mutex busy; };
-struct ProverSlot { FileStamp stamp; std::vector<std::unique_ptr<ProverUnit>> units; std::atomic<unsigned> next{0}; };
+typedef std::vector<std::shared_ptr<ProverUnit>> UnitList;
+// A reload (the key file's size or mtime changed) never touches the old list: it publishes a NEW one, and the old units die when the last proof running on them lets
+// go of its reference — a caller can therefore never see a destroyed unit or mutex, however the reload interleaves with proofs in flight.
+struct ProverSlot { FileStamp stamp; std::shared_ptr<const UnitList> units; std::atomic<unsigned> next{0}; };
 struct VkSlot { FileStamp stamp; std::shared_ptr<VerifyingKeyHost> vk; };
 std::mutex g_cache_mutex; std::map<std::string, ProverSlot> g_provers; std::map<std::string, VkSlot> g_vks;
 
 std::unique_ptr<Circuit> make_circuit(CircuitKind k, bool emit) {
   switch (k) { case CircuitKind::Mint: return make_mint_circuit(emit); case CircuitKind::Send: return make_send_circuit(emit); case CircuitKind::Redeem: return make_redeem_circuit(emit); default: return make_deposit_circuit(emit, 8); } }
 
-// returns a locked unit of the key's pool (loads the key on first use or when the file changed; loading is serialised by g_gpu_mutex)
-ProverUnit &acquire_prover(CircuitKind k, std::unique_lock<std::mutex> &held) {
+// A unit of the key's pool, locked for the caller (the reference keeps the unit alive, the lock is released first: members are destroyed in reverse order)
+struct HeldUnit { std::shared_ptr<ProverUnit> unit; std::unique_lock<std::mutex> lock; };
+// loads the key on first use or when the file changed; loading is serialised by g_gpu_mutex, which also guards the slot table
+HeldUnit acquire_prover(CircuitKind k) {
   std::string path = key_path(k, true); FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("proving key not found: " + path);
-  ProverSlot *slot;
-  { std::lock_guard<std::mutex> lk(g_gpu_mutex); slot = &g_provers[path];
-    if (slot->units.empty() || !(slot->stamp == st)) {
-      for (auto &u : slot->units) { std::lock_guard<std::mutex> wait(u->busy); }                        // proofs still running on the old key finish first
-      slot->units.clear(); ProvingKeyHost pk = load_proving_key(path); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 2; if (n < 1) n = 1; if (n > 7) n = 7;
-      for (int i = 0; i < n; i++) { std::unique_ptr<ProverUnit> u(new ProverUnit); u->prover.reset(new Prover(pk)); u->circuit = make_circuit(k, false);
+  std::shared_ptr<const UnitList> units; unsigned turn = 0;
+  { std::lock_guard<std::mutex> lk(g_gpu_mutex); ProverSlot &slot = g_provers[path];
+    if (!slot.units || !(slot.stamp == st)) {
+      ProvingKeyHost pk = load_proving_key(path); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 2; if (n < 1) n = 1; if (n > 7) n = 7;
+      auto fresh = std::make_shared<UnitList>();
+      for (int i = 0; i < n; i++) { auto u = std::make_shared<ProverUnit>(); u->prover.reset(new Prover(pk)); u->circuit = make_circuit(k, false);
         if (u->circuit->board.num_variables() != u->prover->num_variables() || u->circuit->num_inputs() != u->prover->num_inputs()) throw std::runtime_error("proving key does not belong to the " + std::string(circuit_name(k)) + " circuit: " + path);
-        slot->units.push_back(std::move(u)); }
-      slot->stamp = st; } }
-  for (auto &u : slot->units) { std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) { held = std::move(lk); return *u; } }
-  ProverUnit &u = *slot->units[slot->next.fetch_add(1) % slot->units.size()]; held = std::unique_lock<std::mutex>(u.busy); return u;
+        fresh->push_back(std::move(u)); }
+      slot.units = std::move(fresh); slot.stamp = st; }
+    units = slot.units; turn = slot.next.fetch_add(1); }
+  for (const auto &u : *units) { std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) return HeldUnit{u, std::move(lk)}; }
+  const std::shared_ptr<ProverUnit> &u = (*units)[turn % units->size()]; return HeldUnit{u, std::unique_lock<std::mutex>(u->busy)};
 }
 std::shared_ptr<VerifyingKeyHost> vk_for(CircuitKind k) {
   std::string path = key_path(k, false); FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("verification key not found: " + path);
@@ -68,18 +74,24 @@ std::shared_ptr<VerifyingKeyHost> vk_for(CircuitKind k) {
   if (!slot.vk || !(slot.stamp == st)) { slot.vk.reset(new VerifyingKeyHost(load_verifying_key(path))); slot.stamp = st; }
   return slot.vk;
 }
-bool parse_fixed_rs(Fe32 &r, Fe32 &s) {   // test hook: ZK_FIXED_RS="<r hex>:<s hex>" makes proofs reproducible (the reference draws r, s from std::random_device)
+#ifdef ZKGPU_TEST_HOOKS
+// test builds only (make TEST_HOOKS=1): ZK_FIXED_RS="<r hex>:<s hex>" makes proofs reproducible.  The release library does not contain this code: an environment
+// variable must never be able to remove the zero-knowledge property (the reference draws r, s from std::random_device, r1cs_gg_ppzksnark.tcc:418-419).
+bool parse_fixed_rs(Fe32 &r, Fe32 &s) {
   const char *e = getenv("ZK_FIXED_RS"); if (!e) return false; const char *colon = strchr(e, ':'); if (!colon) return false;
   auto parse = [](const char *b, const char *en, Fe32 &o) { memset(&o, 0, sizeof o); int n = 0; for (const char *p = en; p-- > b;) { char ch = *p; int d = ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : -1; if (d < 0 || n >= 64) return false; o.l[n / 8] |= (uint32_t)d << (4 * (n % 8)); n++; } return n > 0; };
   return parse(e, colon, r) && parse(colon + 1, e + strlen(e), s);
 }
+#else
+inline bool parse_fixed_rs(Fe32 &, Fe32 &) { return false; }
+#endif
 
 // shared tail of the gen*proof functions: assign() has filled the circuit's board
 template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
   try {
     if (!gpu_available()) { zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback"); fprintf(stderr, "libzkgpu: no HIP device visible, cannot generate %s proof\n", circuit_name(k)); return dup_string(proof_to_hex(default_proof())); }
     static const bool trace = getenv("ZK_TRACE_TIMES") != nullptr; auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = now(); std::unique_lock<std::mutex> held; ProverUnit &slot = acquire_prover(k, held); double t1 = now(); assign(*slot.circuit); double t2 = now();
+    double t0 = now(); HeldUnit held = acquire_prover(k); ProverUnit &slot = *held.unit; double t1 = now(); assign(*slot.circuit); double t2 = now();
     printf("Trying to generate %s proof...\n", circuit_name(k)); fflush(stdout);
     Fe32 r, s; bool fixed = parse_fixed_rs(r, s); Proof proof;
     slot.prover->set_witness(reinterpret_cast<const Fe32 *>(slot.circuit->board.val.data() + 1), true);   // the board holds Montgomery values: no conversion on either side
@@ -168,7 +180,10 @@ static R1csHost read_r1cs_file(const char *path) { FILE *f = fopen(path, "rb"); 
     if (fread(cs.rowptr[m].data(), 4, cs.n_cons + 1, f) != cs.n_cons + 1 || fread(cs.col[m].data(), 4, nnz, f) != nnz || fread(cs.coeff[m].data(), 32, nnz, f) != nnz) { fclose(f); throw std::runtime_error("truncated R1CS file"); } } fclose(f); return cs; }
 static void write_witness_file(const char *path, const std::vector<Fe32> &z) { FILE *f = fopen(path, "wb"); if (!f) throw std::runtime_error(std::string("cannot write ") + path); uint64_t n = z.size(); fwrite(&n, 8, 1, f); fwrite(z.data(), 32, n, f); fclose(f); }
 
-int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path) { return guarded_host([&] { std::unique_ptr<Circuit> c = kind == 100 ? make_sha256_two_to_one(true) : kind == 101 ? make_merkle_test_circuit(true, tree_depth) : kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true); write_r1cs_file(r1cs_path, c->r1cs()); return ZKGPU_OK; }); }
+int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path) { return guarded_host([&] { std::unique_ptr<Circuit> c = kind == 100 ? make_sha256_two_to_one(true) : kind == 101 ? make_merkle_test_circuit(true, tree_depth) : kind == 102 ? make_lesscmp_test_circuit(true) : kind == 103 ? make_cmta_test_circuit(true) : kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true); write_r1cs_file(r1cs_path, c->r1cs()); return ZKGPU_OK; }); }
+/* bits: 64 + 256 + 256 bytes, each 0 or 1, in the circuit's bit order */
+int zkgpu_witness_cmta(const uint8_t *bits, const char *wit_path) { return guarded_host([&] { auto c = make_cmta_test_circuit(false); std::vector<bool> v(bits, bits + 64), sn(bits + 64, bits + 320), r(bits + 320, bits + 576); assign_cmta_test(*c, v, sn, r); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
+int zkgpu_witness_lesscmp(uint64_t value_old, uint64_t value_s, const char *wit_path) { return guarded_host([&] { auto c = make_lesscmp_test_circuit(false); assign_lesscmp_test(*c, value_old, value_s); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
 int zkgpu_witness_sha256(const uint8_t left[32], const uint8_t right[32], const char *wit_path) { return guarded_host([&] { auto c = make_sha256_two_to_one(false); assign_sha256_two_to_one(*c, blob_bits(left, 32), blob_bits(right, 32)); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
 /* Merkle test circuit: leaf and depth siblings (leaf level first, 32 bytes each, in hashing byte order), position of the leaf; the root is computed */
 int zkgpu_witness_merkle(int depth, const uint8_t leaf[32], const uint8_t *siblings, uint64_t position, const char *wit_path) { return guarded_host([&] { auto c = make_merkle_test_circuit(false, depth);

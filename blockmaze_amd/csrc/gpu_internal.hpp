@@ -14,9 +14,7 @@ class GpuContext {
  public:
   int device = 0; hipStream_t stream = nullptr; hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t fork_event = nullptr; hipEvent_t join_event[4] = {nullptr, nullptr, nullptr, nullptr}; hipDeviceProp_t prop;
   GpuContext() {
-    // five streams run concurrently (the critical chain + four witness MSMs); the runtime's default of 4 hardware queues makes two of them share one and
-    // serialises them (measured: the B1 MSM finished at 2.7 ms instead of 1.4 ms).  Only effective if this is the first HIP call of the process.
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // (GPU_MAX_HW_QUEUES is raised by the library constructor in gpu.hip, before any HIP call of this process can have read it)
     int n = 0; if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
     const char *e = getenv("ZK_DEVICE"); if (!e) e = getenv("LOCAL_RANK"); device = e ? atoi(e) % n : 0;
     HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipGetDeviceProperties(&prop, device)); HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));   // (a high-priority main stream was measured: no gain for one proof, 15 % loss with four in flight)

@@ -1,4 +1,6 @@
 // see groth16.hpp
+#include <sys/random.h>
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -37,7 +39,7 @@ struct Cursor {
   void dec(uint32_t out[8]) { skip_ws(); memset(out, 0, 32); int nd = 0;
     while (p < end && *p >= '0' && *p <= '9') { uint64_t carry = *p - '0'; for (int i = 0; i < 8; i++) { uint64_t v = (uint64_t)out[i] * 10 + carry; out[i] = (uint32_t)v; carry = v >> 32; } p++; nd++; }
     if (!nd) fail("expected a decimal number"); }
-  size_t size() { uint32_t v[8]; dec(v); return (size_t)v[0] | ((size_t)v[1] << 32); }
+  size_t size() { uint32_t v[8]; dec(v); for (int i = 2; i < 8; i++) if (v[i]) fail("count or index does not fit 64 bits"); size_t r = (size_t)v[0] | ((size_t)v[1] << 32); if (r >> 40) fail("implausible count or index"); return r; }
   void eat(char c) { if (p < end && *p == (uint8_t)c) p++; else fail("unexpected byte"); }
   // compressed points: ASCII is_zero, raw Montgomery X, ASCII lsb(Y)   (alt_bn128_g1.cpp:404-418, alt_bn128_g2.cpp:418-431)
   void g1(std::vector<Fe32> &xs, std::vector<uint8_t> &flags) { if (end - p < 34) fail("truncated G1"); uint8_t z = *p++ - '0'; Fe32 x; memcpy(&x, p, 32); p += 32; uint8_t lsb = *p++ - '0'; if (z > 1 || lsb > 1) fail("bad G1 flag"); xs.push_back(x); flags.push_back((uint8_t)(lsb | (z << 1))); }
@@ -57,12 +59,14 @@ void put_g2(std::string &o, const G2AffineRaw &p) { bool z = is_zero_raw(&p, siz
 void put_g1_vec(std::string &o, const std::vector<G1AffineRaw> &v) { put_size(o, v.size()); o.push_back('\n'); for (auto &p : v) put_g1(o, p); }   // vector<G1> operator of libff.so: no per-element newline
 }  // namespace
 
+static size_t domain_size_for(size_t min_size);
 ProvingKeyHost load_proving_key(const std::string &path) {
   std::vector<uint8_t> buf = slurp(path); Cursor c{buf.data(), buf.data() + buf.size(), "proving key"}; ProvingKeyHost pk;
   std::vector<Fe32> x1, x2; std::vector<uint8_t> f1, f2;     // every G1 / G2 of the file, decompressed in one batch each
   c.g1(x1, f1); c.eat('\n'); c.g1(x1, f1); c.eat('\n'); c.g2(x2, f2); c.eat('\n'); c.g1(x1, f1); c.eat('\n'); c.g2(x2, f2); c.eat('\n');   // alpha_g1 beta_g1 beta_g2 delta_g1 delta_g2 (r1cs_gg_ppzksnark.tcc:52-66)
   size_t nA = c.size(); c.eat('\n'); for (size_t i = 0; i < nA; i++) c.g1(x1, f1);
-  size_t dom = c.size(); size_t ni = c.size(); pk.B_idx.resize(ni); for (size_t i = 0; i < ni; i++) pk.B_idx[i] = (uint32_t)c.size();             // sparse_vector.tcc:272-288
+  size_t dom = c.size(); size_t ni = c.size(); if (ni > nA) c.fail("B query has more entries than variables"); pk.B_idx.resize(ni);
+  for (size_t i = 0; i < ni; i++) { size_t idx = c.size(); if (idx >= nA) c.fail("B query index out of range"); if (i && idx <= pk.B_idx[i - 1]) c.fail("B query indices are not increasing"); pk.B_idx[i] = (uint32_t)idx; }   // sparse_vector.tcc:272-288; the device gathers z[B_idx[i]]
   size_t nB = c.size(); c.eat('\n'); if (nB != ni || dom != nA) c.fail("inconsistent B query");
   for (size_t i = 0; i < nB; i++) { c.g2(x2, f2); c.eat(' '); c.g1(x1, f1); c.eat('\n'); }                                                          // knowledge_commitment.tcc:121-125
   size_t nH = c.size(); c.eat('\n'); for (size_t i = 0; i < nH; i++) c.g1(x1, f1);
@@ -72,7 +76,8 @@ ProvingKeyHost load_proving_key(const std::string &path) {
   for (size_t i = 0; i < cs.n_cons; i++) for (int m = 0; m < 3; m++) { size_t nt = c.size();
     for (size_t k = 0; k < nt; k++) { size_t idx = c.size(); if (idx > cs.n_vars) c.fail("variable index out of range"); Fe32 co; c.dec(co.l); cs.col[m].push_back((uint32_t)idx); cs.coeff[m].push_back(co); }
     cs.rowptr[m].push_back((uint32_t)cs.col[m].size()); }
-  if (nA != cs.n_vars + 1 || nL != cs.n_vars - cs.n_inputs) c.fail("query sizes do not match the constraint system");
+  if (cs.n_inputs > cs.n_vars || nA != cs.n_vars + 1 || nL != cs.n_vars - cs.n_inputs) c.fail("query sizes do not match the constraint system");
+  if (nH + 1 != domain_size_for(cs.n_cons + cs.n_inputs + 1)) c.fail("H query size does not match the evaluation domain");                           // r1cs_gg_ppzksnark.tcc:281: m - 1 powers
   std::vector<G1AffineRaw> p1(x1.size()); std::vector<G2AffineRaw> p2(f2.size());
   decompress_g1(x1.data(), f1.data(), x1.size(), p1.data()); decompress_g2(x2.data(), f2.data(), f2.size(), p2.data());
   size_t i1 = 0, i2 = 0; pk.alpha_g1 = p1[i1++]; pk.beta_g1 = p1[i1++]; pk.beta_g2 = p2[i2++]; pk.delta_g1 = p1[i1++]; pk.delta_g2 = p2[i2++];
@@ -127,7 +132,8 @@ void save_verifying_key(const std::string &path, const VerifyingKeyHost &vk) {
 // ======================================================================================================================
 // generator
 // ======================================================================================================================
-static void urandom(void *p, size_t n) { FILE *f = fopen("/dev/urandom", "rb"); if (!f || fread(p, 1, n, f) != n) { if (f) fclose(f); throw std::runtime_error("cannot read /dev/urandom"); } fclose(f); }
+static void urandom(void *p, size_t n) {   // the kernel's CSPRNG through getrandom(2): no file descriptor, no open() per proof
+  uint8_t *b = (uint8_t *)p; while (n) { ssize_t k = getrandom(b, n, 0); if (k < 0) { if (errno == EINTR) continue; throw std::runtime_error("getrandom failed"); } b += k; n -= (size_t)k; } }
 static HFr random_fr() { for (;;) { HFr v; urandom(v.l, 32); v.l[3] &= (1ull << 62) - 1; if (!HFr::geq_mod(v.l)) return v.to_mont(); } }   // uniform in [0, r) by rejection (bigint.tcc:167-179 / fp.tcc:695-721)
 static uint64_t splitmix(uint64_t &s) { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 ToxicWaste ToxicWaste::random() { ToxicWaste t; HFr *f = &t.t; for (int i = 0; i < 7; i++) { do f[i] = random_fr(); while (f[i].is_zero()); } return t; }
@@ -145,6 +151,7 @@ static std::vector<HFr> radix2_lagrange(size_t m, const HFr &t) {
 struct DomainShape { size_t m; bool step; size_t B, S; };
 static DomainShape domain_shape(size_t min_size) { DomainShape d{0, false, 0, 0}; size_t lg = ceil_log2(min_size); if (min_size == ((size_t)1 << lg)) { d.m = min_size; return d; }
   size_t big = (size_t)1 << (lg - 1), small = min_size - big, rs = (size_t)1 << ceil_log2(small); d.m = small == rs ? min_size : big + rs; if (d.m != ((size_t)1 << ceil_log2(d.m))) { d.step = true; d.B = (size_t)1 << (ceil_log2(d.m) - 1); d.S = d.m - d.B; } return d; }
+static size_t domain_size_for(size_t min_size) { return domain_shape(min_size).m; }
 // all Lagrange polynomials at t and Z(t)  (basic_radix2_domain.tcc:90-101; step_radix2_domain.tcc:169-215)
 static std::vector<HFr> domain_lagrange(const DomainShape &d, const HFr &t, HFr &Zt) { HFr one = HFr::one();
   if (!d.step) { Zt = t.pow_u64(d.m) - one; return radix2_lagrange(d.m, t); }

@@ -12,6 +12,10 @@ possible in the build container, where /root/reference exists) and stores its OU
   sha256_gadget.json         constraint / variable counts, digest and SHA-256 of the R1CS / witness dumps of libsnark's
                              sha256_two_to_one_hash_gadget on the reference's own KAT input and on seeded inputs
   merkle_gadget.json         same for merkle_tree_check_read_gadget (depth 2 and 8)
+  lesscmp_gadget.json        BlockMaze's less_comparison_gadget block (send/circuit/comparison.tcc compiled for real): canonical R1CS
+                             hash and the witness digests for seven (value_old, value_s) pairs
+  cmta_gadget.json           two chained compression gadgets with hard-wired padding, composed like sha256_CMTA_gadget (commitment.tcc:12-110)
+  note_hashes.txt            Note::cm / NoteS::cm / Compute_PRF / Compute_CRH of send/Note.h and util.h on seeded hex strings
 
 Fixtures are data only; no reference source is copied.
 """
@@ -57,11 +61,34 @@ def gadget_fixture():
             res["depth%d" % depth] = {"canonical_r1cs_sha256": canonical_hash(o.R1CS.load(t + "/r.bin")), "seed": seed, "constraints": int(kv["constraints"]), "variables": int(kv["variables"]), "address": int(kv["address"]), "r1cs_sha256": sha(t + "/r.bin"), "witness_sha256": sha(t + "/w.bin")}
         json.dump(res, open(os.path.join(GOLD, "merkle_gadget.json"), "w"), indent=1)
 
+LESSCMP_PAIRS = [(22, 8), (8, 8), (2 ** 64 - 1, 0), (5, 9), (0, 0), (1 << 63, (1 << 63) - 1), (0x0123456789abcdef, 0x00ffeeddccbbaa99)]
+def blockmaze_fixture():
+    """BlockMaze's own sources compiled for real (the ones that need no boost): comparison.tcc's gadget block and the host note hashes"""
+    from test_circuits_cpu import canonical_hash
+    res = {"pairs": []}
+    with tempfile.TemporaryDirectory() as t:
+        for vo, vs in LESSCMP_PAIRS:
+            out = run("lesscmp", str(vo), str(vs), t + "/r.bin", t + "/w.bin"); kv = dict(p.split("=") for p in out.split()[1:])
+            res["canonical_r1cs_sha256"] = canonical_hash(o.R1CS.load(t + "/r.bin")); res["constraints"] = int(kv["constraints"]); res["variables"] = int(kv["variables"])
+            res["pairs"].append({"value_old": vo, "value_s": vs, "satisfied": int(kv["satisfied"]), "witness_sha256": sha(t + "/w.bin")})
+    json.dump(res, open(os.path.join(GOLD, "lesscmp_gadget.json"), "w"), indent=1)
+    open(os.path.join(GOLD, "note_hashes.txt"), "w").write(run("notehashes", "20241002", "12"))
+    res = {}
+    with tempfile.TemporaryDirectory() as t:
+        for seed in (3, 4):
+            out = run("cmta", str(seed), t + "/r.bin", t + "/w.bin"); kv = dict(p.split("=") for p in out.split()[1:])
+            res["canonical_r1cs_sha256"] = canonical_hash(o.R1CS.load(t + "/r.bin")); res["constraints"] = int(kv["constraints"]); res["variables"] = int(kv["variables"])
+            res["terms"] = [int(x) for x in kv["terms"].split(",")]; res["zero_coefficient_terms"] = [int(x) for x in kv["zero_terms"].split(",")]     # libsnark keeps terms with coefficient 0 (e.g. `c = 0`, IV bits that are 0)
+            res["seed%d" % seed] = {"digest_bits": kv["digest"], "witness_sha256": sha(t + "/w.bin")}
+        run("sha256gadget", t + "/r.bin", t + "/w.bin", "0"); cs = o.R1CS.load(t + "/r.bin")
+        res["two_to_one_zero_coefficient_terms"] = [int((cs.coeff[m] == 0).all(axis=1).sum()) for m in range(3)]
+    json.dump(res, open(os.path.join(GOLD, "cmta_gadget.json"), "w"), indent=1)
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if "--gadgets-only" not in sys.argv:      # the key fixtures come from the reference generator's std::random_device: regenerating them changes pk/vk/proof (consistently)
         run("vectors", os.path.join(GOLD, "ref_vectors.txt"))
         groth16_fixture("groth16_small", 7, 3, 40, 60, 99)
         groth16_fixture("groth16_step", 8, 4, 30, 40, 100)
-    gadget_fixture()
+    gadget_fixture(); blockmaze_fixture()
     print("golden fixtures written to", GOLD)

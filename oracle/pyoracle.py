@@ -243,3 +243,7 @@ def proof_hex(proof_words):
     """A.x A.y B.x.c1 B.x.c0 B.y.c1 B.y.c0 C.x C.y, 64 lowercase hex each (sendcgo.cpp:113-188)."""
     v = from_arr(proof_words); order = [v[0], v[1], v[3], v[2], v[5], v[4], v[6], v[7]]
     return "".join("%064x" % x for x in order)
+
+def proof_words_from_hex(h):
+    """inverse of proof_hex: 512 hex characters -> the 32 words verify() takes (values are taken as they are, like sendcgo.cpp:388-448)"""
+    v = [int(h[64 * k:64 * k + 64], 16) for k in range(8)]; return to_arr([v[0], v[1], v[3], v[2], v[5], v[4], v[6], v[7]]).reshape(-1)

@@ -18,6 +18,9 @@
 //   vectors <out.txt>                                   field / curve / domain / MSM / pairing known-answer vectors
 //   sha256gadget <out_r1cs.bin> <out_wit.bin> <seed>    libsnark sha256_compression_function_gadget R1CS + witness
 //   merklegadget <depth> <out_r1cs.bin> <out_wit.bin> <seed>
+//   lesscmp <value_old> <value_s> <out_r1cs.bin> <out_wit.bin>   BlockMaze's less_comparison_gadget block (send/circuit/comparison.tcc) R1CS + witness
+//   cmta <seed> <out_r1cs.bin> <out_wit.bin>            two chained compression gadgets + hard-wired padding, composed like sha256_CMTA_gadget (commitment.tcc:12-110)
+//   notehashes <seed> <count>                           Note::cm / NoteS::cm / Compute_PRF / Compute_CRH on seeded hex inputs (send/Note.h, util.h)
 //   e2e <r1cs.bin> <wit.bin> <r_hex> <s_hex> <outdir>   is_satisfied, generator, write pk.txt/vk.txt, prove(r,s),
 //                                                       verify; prints "proof <hex>"
 //   prove <pk.txt> <wit.bin> <n_inputs> <r_hex> <s_hex> load pk with the reference operator>>, prove(r,s)
@@ -33,6 +36,9 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#ifdef MULTICORE
+#include <omp.h>
+#endif
 
 #include "libsnark/zk_proof_systems/ppzksnark/r1cs_gg_ppzksnark/r1cs_gg_ppzksnark.hpp"
 #include "libsnark/common/default_types/r1cs_gg_ppzksnark_pp.hpp"
@@ -40,9 +46,14 @@
 #include <libsnark/gadgetlib1/gadgets/merkle_tree/merkle_tree_check_read_gadget.hpp>
 #include <libfqfft/evaluation_domain/get_evaluation_domain.hpp>
 #include <libff/algebra/scalar_multiplication/multiexp.hpp>
+// BlockMaze's own sources that need no boost (the Makefile adds -I libsnark-vnt/src/send): the host note hashing (Note.h -> deps/sha256.h, uint256.h, util.h) and,
+// further down, the comparison gadget (circuit/comparison.tcc; redeem/circuit/comparison.tcc is the same file).  circuit/utils.tcc — and with it note.tcc,
+// commitment.tcc and gadget.tcc, which call into it — needs BOOST_FOREACH and stays unbuilt.
+#include "Note.h"
 
 using namespace libsnark;
 using namespace libff;
+#include "circuit/comparison.tcc"   // less_comparison_gadget (unqualified gadgetlib1 names: after the using-directives, as in send/main.cpp:17-20)
 typedef alt_bn128_pp ppT;
 typedef Fr<ppT> FrT;
 typedef Fq<ppT> FqT;
@@ -280,6 +291,57 @@ static int cmd_merklegadget(size_t depth, const char *r1cs_out, const char *wit_
   save_r1cs(r1cs_out, pb.get_constraint_system()); save_wit(wit_out, pb.full_variable_assignment());
   printf("merklegadget depth=%zu constraints=%zu variables=%zu address=%zu\n", depth, pb.num_constraints(), pb.num_variables(), address); return 0; }
 
+// ---- BlockMaze's comparison gadget and bit-order helpers, compiled from libsnark-vnt/src/send ------------------------------
+// The block of send's / redeem's note gadgets that proves value_s <= value_old, rebuilt from the reference's own pieces exactly as note.tcc:35-59,78-83 +
+// less_cmp.tcc:23-34 compose them (those two files cannot be included: they call into utils.tcc): 64 + 64 bit variables, the two packed values,
+// less_comparison_gadget(value_s_packed, value_old_packed); booleanity of the bits, the gadget's constraints; the bits filled in the order of
+// uint64_to_bool_vector (utils.tcc:47-53 = convertIntToVectorLE + convertBytesVectorToVector of util.h, both called here), the packed values by BlockMaze's
+// get_field_element_from_bits_by_order (pb_variable.tcc:119-133).
+static int cmd_lesscmp(uint64_t v_old, uint64_t v_s, const char *r1cs_out, const char *wit_out) {
+  protoboard<FrT> pb; pb_variable_array<FrT> value_old, value_s; value_old.allocate(pb, 64, "value_old"); value_s.allocate(pb, 64, "value_s");
+  pb_variable<FrT> value_old_packed, value_s_packed; value_old_packed.allocate(pb, "value_old_packed"); value_s_packed.allocate(pb, "value_s_packed");
+  less_comparison_gadget<FrT> less_cmp(pb, value_s_packed, value_old_packed, " less_cmp");
+  for (size_t i = 0; i < 64; i++) generate_boolean_r1cs_constraint<FrT>(pb, value_old[i], "boolean_value_old");
+  for (size_t i = 0; i < 64; i++) generate_boolean_r1cs_constraint<FrT>(pb, value_s[i], "boolean_value_s");
+  less_cmp.generate_r1cs_constraints();
+  auto bits_of = [](uint64_t v) { std::vector<unsigned char> le = convertIntToVectorLE(v); std::vector<bool> b(64, 0); convertBytesVectorToVector(le, b); return b; };
+  value_old.fill_with_bits(pb, bits_of(v_old)); pb.lc_val(value_old_packed) = value_old.get_field_element_from_bits_by_order(pb);
+  value_s.fill_with_bits(pb, bits_of(v_s)); pb.lc_val(value_s_packed) = value_s.get_field_element_from_bits_by_order(pb);
+  less_cmp.generate_r1cs_witness();
+  save_r1cs(r1cs_out, pb.get_constraint_system()); save_wit(wit_out, pb.full_variable_assignment());
+  printf("lesscmp constraints=%zu variables=%zu satisfied=%d packed_old=%s packed_s=%s\n", pb.num_constraints(), pb.num_variables(), pb.is_satisfied() ? 1 : 0, hex_of(pb.val(value_old_packed)).c_str(), hex_of(pb.val(value_s_packed)).c_str()); return 0; }
+
+// Two chained libsnark compression gadgets composed the way BlockMaze's sha256_CMTA_gadget composes them (send/circuit/commitment.tcc:12-110, which itself cannot be
+// included: its padding comes from utils.tcc's from_bits): ZERO, value[64], sn[256], r[256], the output digest; then the intermediate digest, block1 = value | sn |
+// r[0..192), block2 = r[192..256) | padding for a 576-bit message made of the constant ONE and the variable ZERO, hasher1 from SHA256_default_IV, hasher2 from the
+// intermediate digest's bits.  Constraints: ZERO = 0, intermediate booleanity, hasher1, hasher2.  Pins the chained (non-IV) use of the compression gadget and the
+// zero-coefficient bookkeeping of both kinds.
+static int cmd_cmta(uint64_t seed, const char *r1cs_out, const char *wit_out) {
+  protoboard<FrT> pb; pb_variable<FrT> ZERO; ZERO.allocate(pb, "zero"); pb_variable_array<FrT> v, sn, r; v.allocate(pb, 64, "v"); sn.allocate(pb, 256, "sn"); r.allocate(pb, 256, "r");
+  digest_variable<FrT> cmtA(pb, 256, "cmtA"), inter(pb, 256, "");
+  pb_variable_array<FrT> first_of_r(r.begin(), r.begin() + 192), last_of_r(r.begin() + 192, r.end()), padding;
+  for (size_t i = 0; i < 448; i++) { bool bit = i == 0 || (i >= 384 && ((576ull >> (447 - i)) & 1)); padding.emplace_back(bit ? pb_variable<FrT>(0) : ZERO); }   // from_bits (utils.tcc:3-12): ONE is variable 0
+  block_variable<FrT> block1(pb, {v, sn, first_of_r}, "b1"), block2(pb, {last_of_r, padding}, "b2");
+  sha256_compression_function_gadget<FrT> h1(pb, SHA256_default_IV<FrT>(pb), block1.bits, inter, "h1"), h2(pb, pb_linear_combination_array<FrT>(inter.bits), block2.bits, cmtA, "h2");
+  pb.add_r1cs_constraint(r1cs_constraint<FrT>(1, ZERO, 0), "zero"); inter.generate_r1cs_constraints(); h1.generate_r1cs_constraints(); h2.generate_r1cs_constraints();
+  SplitMix g(seed); bit_vector bv(64), bsn(256), br(256); for (auto &&b : bv) b = g.next() & 1; for (auto &&b : bsn) b = g.next() & 1; for (auto &&b : br) b = g.next() & 1;
+  pb.val(ZERO) = FrT::zero(); v.fill_with_bits(pb, bv); sn.fill_with_bits(pb, bsn); r.fill_with_bits(pb, br); h1.generate_r1cs_witness(); h2.generate_r1cs_witness();
+  if (!pb.is_satisfied()) { fprintf(stderr, "unsatisfied\n"); return 1; }
+  save_r1cs(r1cs_out, pb.get_constraint_system()); save_wit(wit_out, pb.full_variable_assignment());
+  size_t terms[3] = {0, 0, 0}, zeros[3] = {0, 0, 0};
+  for (auto &c : pb.get_constraint_system().constraints) { const linear_combination<FrT> *l[3] = {&c.a, &c.b, &c.c}; for (int m = 0; m < 3; m++) for (auto &t : l[m]->terms) { terms[m]++; if (t.coeff.is_zero()) zeros[m]++; } }
+  printf("cmta constraints=%zu variables=%zu terms=%zu,%zu,%zu zero_terms=%zu,%zu,%zu digest=", pb.num_constraints(), pb.num_variables(), terms[0], terms[1], terms[2], zeros[0], zeros[1], zeros[2]);
+  for (bool b : cmtA.get_digest()) printf("%d", b ? 1 : 0); printf("\n"); return 0; }
+
+// host note hashing through the reference's own classes (send/Note.h:14-80, util.h:233-258, uint256.h:222-248 via uint256S / uint160S)
+static int cmd_notehashes(uint64_t seed, int count) {
+  SplitMix g(seed); auto hex = [&](int nbytes) { std::string s = "0x"; char b[3]; for (int i = 0; i < nbytes; i++) { snprintf(b, 3, "%02x", (unsigned)(g.next() & 0xff)); s += b; } return s; };
+  for (int i = 0; i < count; i++) { std::string sk = hex(32), r = hex(32), sn = hex(32), pk = hex(20); uint64_t v = g.next(); if (i == 0) v = 0; if (i == 1) { sk = "0x1"; r = "0x123456"; }   // short strings: zero-extension
+    uint256 sk_ = uint256S(sk), r_ = uint256S(r), sn_ = uint256S(sn); uint160 pk_ = uint160S(pk);
+    printf("notehash v=%llu sk=%s r=%s sn=%s pk=%s prf=%s crh=%s cm=%s cms=%s\n", (unsigned long long)v, sk.c_str(), r.c_str(), sn.c_str(), pk.c_str(), Compute_PRF(sk_, r_).GetHex().c_str(), Compute_CRH(pk_, r_).GetHex().c_str(),
+           Note(v, sn_, r_).cm().GetHex().c_str(), NoteS(v, pk_, r_, sn_).cm().GetHex().c_str()); }
+  return 0; }
+
 // ---- Groth16 over an R1CS supplied by the caller ---------------------------------------------------------------
 static int cmd_e2e(const char *r1cs_path, const char *wit_path, const char *r_hex, const char *s_hex, const std::string &outdir) {
   double t0 = now_s(); r1cs_constraint_system<FrT> cs = load_r1cs(r1cs_path); std::vector<FrT> w = load_wit(wit_path);
@@ -328,7 +390,11 @@ static int cmd_bench_prover(const char *r1cs_path, const char *wit_path) {
   printf("bench_prover constraints=%zu variables=%zu domain=%zu b_nonzero=%zu\n", pk.constraint_system.num_constraints(), nv, m, bidx.size());
   double t0 = now_s(); auto qw = r1cs_to_qap_witness_map(pk.constraint_system, primary, aux, FrT::zero(), FrT::zero(), FrT::zero()); double t_wm = now_s() - t0;
   t0 = now_s(); auto pr = r1cs_gg_ppzksnark_prover<ppT>(pk, primary, aux); double t_total = now_s() - t0;
-  printf("witness_map_s %.3f prover_total_s %.3f proofs_per_s %.5f\n", t_wm, t_total, 1.0 / t_total); (void)pr; (void)qw; return 0; }
+  int threads = 1;
+#ifdef MULTICORE
+  threads = omp_get_max_threads();
+#endif
+  printf("witness_map_s %.3f prover_total_s %.3f proofs_per_s %.5f threads %d\n", t_wm, t_total, 1.0 / t_total, threads); (void)pr; (void)qw; return 0; }
 
 int main(int argc, char **argv) {
   ppT::init_public_params(); libff::inhibit_profiling_info = true; libff::inhibit_profiling_counters = true;
@@ -337,6 +403,9 @@ int main(int argc, char **argv) {
   if (m == "vectors" && argc == 3) return cmd_vectors(argv[2]);
   if (m == "sha256gadget" && argc == 5) return cmd_sha256gadget(argv[2], argv[3], strtoull(argv[4], 0, 0));
   if (m == "merklegadget" && argc == 6) return cmd_merklegadget(atoi(argv[2]), argv[3], argv[4], strtoull(argv[5], 0, 0));
+  if (m == "lesscmp" && argc == 6) return cmd_lesscmp(strtoull(argv[2], 0, 0), strtoull(argv[3], 0, 0), argv[4], argv[5]);
+  if (m == "cmta" && argc == 5) return cmd_cmta(strtoull(argv[2], 0, 0), argv[3], argv[4]);
+  if (m == "notehashes" && argc == 4) return cmd_notehashes(strtoull(argv[2], 0, 0), atoi(argv[3]));
   if (m == "e2e" && argc == 7) return cmd_e2e(argv[2], argv[3], argv[4], argv[5], argv[6]);
   if (m == "prove" && argc == 7) return cmd_prove(argv[2], argv[3], atoi(argv[4]), argv[5], argv[6]);
   if (m == "verify" && argc >= 5) return cmd_verify(argc, argv);

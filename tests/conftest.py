@@ -18,3 +18,10 @@ def golden_dir():
 def ref_vectors():
     """tests/golden/ref_vectors.txt (outputs of the real reference, see oracle/make_golden.py) as token lists."""
     return [l.split() for l in open(os.path.join(GOLDEN, "ref_vectors.txt"))]
+
+# Which optional legs of the parity tests really ran (e.g. the real libsnark prover on the full-size send key): tests add to LEGS, the summary is printed at the very
+# end of the run so that it shows in the tail of `pytest -q` that the driver records.
+LEGS = {}
+def record_leg(name, seconds=None): LEGS[name] = seconds
+def pytest_terminal_summary(terminalreporter):
+    if LEGS: terminalreporter.write_line("reference legs run: " + ", ".join("%s%s" % (k, "" if v is None else " (%.1f s)" % v) for k, v in sorted(LEGS.items())))

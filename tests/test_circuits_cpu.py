@@ -131,3 +131,130 @@ def test_deposit_circuit(tmp_path):
     bad = dict(d); bad["leaves"] = list(d["leaves"]); bad["leaves"][3] = bytes(32)                                              # same leaf, different tree: root no longer matches the claimed rt? (rt is recomputed, so still valid)
     bad = dict(d); bad["sn_s"] = w.prf(d["sk"], (345).to_bytes(32, "big"))                                                       # wrong_sn_s (deposit/main.cpp:201-216)
     arr = "".join(H(x) for x in d["leaves"]); e.witness_deposit(*[H(a) if isinstance(a, bytes) else a for a in w.deposit_args(bad)], arr, 16, H(d["sk"]), wp); assert not o.r1cs_is_satisfied(cs, o.load_witness(wp))
+
+def test_lesscmp_block_matches_the_reference_gadget(tmp_path, golden_dir):
+    """BlockMaze's less_comparison_gadget (send/circuit/comparison.tcc:5-96 = redeem's copy) as note.tcc / less_cmp.tcc compose it, compiled from the reference
+    sources by oracle/ref_harness.cpp (cmd_lesscmp): same canonical R1CS, bit-identical assignment for every pair — including value_s > value_old, where the
+    reference's witness generator still runs and the system is unsatisfied"""
+    gold = json.load(open(os.path.join(golden_dir, "lesscmp_gadget.json"))); p = str(tmp_path / "lc.bin"); e.circuit_export("lesscmp", p); cs = o.R1CS.load(p)
+    assert (cs.n_cons, cs.n_vars) == (gold["constraints"], gold["variables"]) == (199, 197) and canonical_hash(cs) == gold["canonical_r1cs_sha256"]
+    for pr in gold["pairs"]:
+        wp = str(tmp_path / "w.bin"); e.witness_lesscmp(pr["value_old"], pr["value_s"], wp)
+        assert hashlib.sha256(open(wp, "rb").read()).hexdigest() == pr["witness_sha256"], pr
+        assert o.r1cs_is_satisfied(cs, o.load_witness(wp)) == bool(pr["satisfied"]) == (pr["value_s"] <= pr["value_old"])
+
+def test_note_hashes_match_the_reference_classes(zk, golden_dir):
+    """Note::cm, NoteS::cm, Compute_PRF, Compute_CRH (send/Note.h:14-80, util.h:233-258) and uint256S / uint160S parsing, run from the reference's own headers by
+    oracle/ref_harness.cpp (cmd_notehashes): the drop-in symbols return the same hex for the same "0x…" strings, short strings included"""
+    n = 0
+    for line in open(os.path.join(golden_dir, "note_hashes.txt")):
+        kv = dict(t.split("=") for t in line.split()[1:]); v = int(kv["v"]); L = zk.L; n += 1
+        assert L.computePRF(kv["sk"].encode(), kv["r"].encode()).decode() == kv["prf"] and L.computeCRH(kv["pk"].encode(), kv["r"].encode()).decode() == kv["crh"]
+        assert L.genCMT(ctypes.c_uint64(v), kv["sn"].encode(), kv["r"].encode()).decode() == kv["cm"] and L.genCMTS(ctypes.c_uint64(v), kv["pk"].encode(), kv["r"].encode(), kv["sn"].encode()).decode() == kv["cms"]
+    assert n == 12
+
+# ---- SURVEY.md Appendix C: the variable / constraint layout of the send circuit as dumped from the compiled reference (protoboard annotations) ----------------
+def _bits_of_blob(be):   # uint256_to_bool_vector on the blob (= reversed big-endian bytes), MSB first inside a byte
+    return [(byte >> (7 - j)) & 1 for byte in w.rev(be) for j in range(8)]
+def _bits_of_u64(v): return [(byte >> (7 - j)) & 1 for byte in v.to_bytes(8, "little") for j in range(8)]
+def _sha_rounds(state, block):
+    """FIPS 180-4 compression, returning the message schedule W[0..63], the working variables a and e after every round, and the new state"""
+    import struct
+    M = 0xFFFFFFFF; rotr = lambda x, n: ((x >> n) | (x << (32 - n))) & M; W = list(struct.unpack(">16I", block))
+    for i in range(16, 64):
+        s0 = rotr(W[i - 15], 7) ^ rotr(W[i - 15], 18) ^ (W[i - 15] >> 3); s1 = rotr(W[i - 2], 17) ^ rotr(W[i - 2], 19) ^ (W[i - 2] >> 10); W.append((W[i - 16] + s0 + W[i - 7] + s1) & M)
+    a, b, c, d, e_, f, g, h = state; As, Es = [], []
+    for i in range(64):
+        t1 = (h + (rotr(e_, 6) ^ rotr(e_, 11) ^ rotr(e_, 25)) + ((e_ & f) ^ (~e_ & g)) + w._K[i] + W[i]) & M; t2 = ((rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c))) & M
+        h, g, f, e_, d, c, b, a = g, f, e_, (d + t1) & M, c, b, a, (t1 + t2) & M; As.append(a); Es.append(e_)
+    return W, As, Es, [(x + y) & M for x, y in zip(state, [a, b, c, d, e_, f, g, h])]
+IV = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+def _pad(msg):   # SHA-256 padding to whole blocks
+    l = len(msg) * 8; msg += b"\x80"; msg += bytes((56 - len(msg)) % 64); return msg + l.to_bytes(8, "big")
+
+def test_send_circuit_layout_is_appendix_c(send_cs, tmp_path):
+    """every variable range of SURVEY.md Appendix C holds what the reference puts there for its own send fixture (send/main.cpp:123-142), and inside each of the nine
+    SHA-256 compression gadgets (24,792 variables each) the packed message schedule and the packed working variables a, e of all 64 rounds sit at the dumped offsets"""
+    import struct
+    d = w.reference_send_fixture(); wp = str(tmp_path / "w.bin"); e.witness_send(*[("0x" + a.hex()) if isinstance(a, bytes) else a for a in w.send_args(d)], wp)
+    z = [1] + o.from_arr(o.load_witness(wp)); assert len(z) == 227047                                     # z[i] = variable i, z[0] = ONE
+    rng = lambda a, b: z[a:b + 1]
+    assert rng(1, 5) == w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]])                  # zk_packed_inputs (gadget.tcc:87-88)
+    assert rng(6, 1029) == sum((_bits_of_blob(d[k]) for k in ("cmtA_old", "sn_old", "cmtS", "cmtA")), [])  # unpacked public bits (:90-93)
+    assert z[1030] == 0                                                                                     # ZERO (:108)
+    assert rng(1031, 1094) == _bits_of_u64(22) and rng(1095, 1350) == _bits_of_blob(d["r_old"])            # value_old, r_old (:110-111)
+    assert rng(1351, 1414) == _bits_of_u64(8) and rng(1415, 1574) == _bits_of_blob(d["pk_recv"]) and rng(1575, 1734) == _bits_of_blob(d["pk_sender"]) and rng(1735, 1990) == _bits_of_blob(d["r_s"])   # :114-117
+    assert rng(1991, 2054) == _bits_of_u64(14) and rng(2055, 2310) == _bits_of_blob(d["sn"]) and rng(2311, 2566) == _bits_of_blob(d["r"]) and rng(2567, 2822) == _bits_of_blob(d["sk"])                 # :119-123
+    assert rng(2823, 2824) == [22, 8]                                                                       # lessCMP's value_old_packed, value_s_packed (note.tcc:35-37)
+    ap = (1 << 64) + 22 - 8; assert rng(2825, 2888) == [(ap >> i) & 1 for i in range(64)] and z[2889] == ap and z[2890] == 1 and z[2891] == pow(3, -1, o.R_MOD)   # alpha[64], alpha_packed, not_all_zeros, disjunction inv (comparison.tcc:24-39)
+    assert rng(2892, 2894) == [22, 8, 14]                                                                   # noteSUB's second copies + value_packed (note.tcc:35-37,116)
+    rb = lambda k: w.rev(d[k])                                                                              # blob bytes = what the reference hashes
+    v64 = lambda v: struct.pack("<Q", v)
+    msgs = [("crh", rb("pk_sender") + rb("r"), 2895, None), ("prf", rb("sk") + rb("r"), 27943, 27687), ("cmtA_old", v64(22) + rb("sn_old") + rb("r_old"), 77783, 77527),
+            ("cmtS", v64(8) + rb("pk_recv") + rb("r_s") + rb("sn_old"), 127623, 127367), ("cmtA", v64(14) + rb("sn") + rb("r"), 177463, 177207)]
+    end = None
+    for name, msg, first, inter in msgs:
+        blocks = _pad(bytearray(msg)); nb = len(blocks) // 64; assert nb == (1 if name == "crh" else 2); state = IV; base = first
+        for k in range(nb):
+            W, As, Es, new_state = _sha_rounds(state, bytes(blocks[64 * k:64 * k + 64]))
+            assert rng(base, base + 63) == W, (name, k)                                                     # packed_W[64] (sha256_gadget.tcc:31-82)
+            for i in range(64):                                                                             # round i: 272 variables from offset 7360; packed_new_a / packed_new_e at +264 / +265
+                assert z[base + 7360 + 272 * i + 264] == As[i] and z[base + 7360 + 272 * i + 265] == Es[i], (name, k, i)
+            assert rng(base + 24776, base + 24783) == new_state, (name, k)                                  # reduced_output[8]
+            if k == 0 and inter is not None:                                                                # the intermediate digest variable sits BEFORE the two compressions
+                assert rng(inter, inter + 255) == [(wd >> (31 - j)) & 1 for wd in new_state for j in range(32)], name
+            state = new_state; base += 24792
+        end = base - 1
+    assert end == 227046
+
+def _bool_var(cs, i):
+    """variable v if constraint i is libsnark's booleanity constraint  v * (1 - v) = 0  (basic_gadgets.tcc:17-22), else None"""
+    A, B, C = [[(int(cs.col[m][k]), o.from_arr(cs.coeff[m][k:k + 1])[0]) for k in range(int(cs.rowptr[m][i]), int(cs.rowptr[m][i + 1]))] for m in range(3)]
+    if len(A) == 1 and A[0][1] == 1 and not C and sorted(B) == sorted([(0, 1), (A[0][0], o.R_MOD - 1)]): return A[0][0]
+    return None
+
+def test_send_constraint_order_is_appendix_c(send_cs):
+    """the blocks of SURVEY.md Appendix C's constraint order, located by the variables their booleanity constraints bind (duplicates kept, as in the reference)"""
+    cs = send_cs; R = lambda a, b: list(range(a, b + 1)); pos = 0
+    def expect_bools(vars_, what):
+        nonlocal pos
+        got = [_bool_var(cs, pos + k) for k in range(len(vars_))]; assert got == vars_, (what, pos); pos += len(vars_)
+    for k in range(5): pos += 1; expect_bools(R(6 + 253 * k, min(6 + 253 * k + 252, 1029)), "unpacker chunk %d" % k)   # multipacking_gadget: per 253-bit chunk the packing constraint, then its bitness constraints (basic_gadgets.tcc:31-58)
+    sn_old, r_old, pk_recv, r_s = R(262, 517), R(1095, 1350), R(1415, 1574), R(1735, 1990)
+    note = R(1031, 1094) + R(1351, 1414) + sn_old + r_old + pk_recv + r_s                                     # note_gadget_with_packing::generate_r1cs_constraints (note.tcc:40-62)
+    expect_bools(note, "lessCMP note"); expect_bools([2890], "not_all_zeros"); pos += 1; expect_bools(R(2825, 2888), "alpha bitness"); assert [int(c) for c in cs.col[0][int(cs.rowptr[0][pos]):int(cs.rowptr[0][pos + 1])]] == [0]; pos += 1 + 1 + 2 + 1   # alpha[64] is the constant ONE: its "bitness" row is 1 * (1 - 1) = 0;   # pack_alpha's packing constraint before its bitness; main, disjunction x2, less_or_eq
+    assert pos == 1029 + 1056 + 71
+    expect_bools(note + R(1991, 2054) + R(2055, 2310) + R(2311, 2566) + R(2567, 2822) + R(1575, 1734), "noteSUB"); pos += 1 + 1      # `equal`, ZERO
+    expect_bools(r_s, "r_s digest"); pos += 27280                                                             # CRH
+    expect_bools(R(2055, 2310), "sn digest"); expect_bools(R(27687, 27942), "PRF intermediate"); pos += 2 * 27280
+    expect_bools(sn_old + R(6, 261) + R(77527, 77782), "sn_old, cmtA_old, intermediate"); pos += 2 * 27280
+    expect_bools(R(518, 773) + R(127367, 127622), "cmtS, intermediate"); pos += 2 * 27280
+    expect_bools(R(774, 1029) + R(177207, 177462), "cmtA, intermediate"); pos += 2 * 27280
+    assert pos == cs.n_cons == 252286
+
+def test_send_r1cs_density_is_the_reference_s(send_cs, golden_dir):
+    """SURVEY.md §6, measured on the compiled reference before the A/B swap: A 307,103 · B 677,133 · C 515,184 terms.  libsnark keeps terms whose coefficient is 0
+    (`c = 0` is the term 0*ONE; IV bits that are 0); this engine's boards drop them (same polynomial, same canonical system).  Their number follows from libsnark's own
+    gadgets as dumped in tests/golden: per compression from the default IV, per chained compression, one per `c = 0` row outside the hashes, one for the bitness row of alpha[64] = ONE."""
+    import numpy as np
+    cs = send_cs; g = json.load(open(os.path.join(golden_dir, "cmta_gadget.json"))); iv = g["two_to_one_zero_coefficient_terms"]; both = g["zero_coefficient_terms"]
+    chain = [both[m] - iv[m] - (257 if m == 2 else 0) for m in range(3)]                                       # the CMTA dump adds 256 booleanity rows and ZERO = 0 (all `c = 0`)
+    assert iv == [74, 154, 10569] and chain == [0, 0, 10472]
+    sha_rows = 9 * 27280; first_sha = [1029 + 1056 + 71 + 2048 + 2 + 256]                                      # CRH starts after unpacker, lessCMP, noteSUB (+ equal, ZERO), r_s digest
+    empty_c = np.diff(cs.rowptr[2]) == 0; in_sha = np.zeros(cs.n_cons, dtype=bool); pos = first_sha[0]
+    for blocks, gap in ((1, 512), (2, 768), (2, 512), (2, 512), (2, 0)): in_sha[pos:pos + blocks * 27280] = True; pos += blocks * 27280 + gap
+    assert int(in_sha.sum()) == sha_rows and pos == cs.n_cons
+    outside = int((empty_c & ~in_sha).sum()); assert outside == 6756
+    mine = [len(cs.col[m]) for m in range(3)]; ref_raw = [mine[0] + 5 * iv[0], mine[1] + 5 * iv[1] + 1, mine[2] + 5 * iv[2] + 4 * chain[2] + outside]
+    assert ref_raw == [307103, 677133, 515184]
+
+def test_cmta_block_matches_libsnark_composition(tmp_path, golden_dir):
+    """one sha256_CMTA_gadget (send/circuit/commitment.tcc:12-110: compression from the default IV chained into a second one, hard-wired padding of ONE / ZERO), built in
+    oracle/ref_harness.cpp (cmd_cmta) from libsnark's own block_variable / digest_variable / sha256_compression_function_gadget: same canonical R1CS, bit-identical witness"""
+    gold = json.load(open(os.path.join(golden_dir, "cmta_gadget.json"))); p = str(tmp_path / "c.bin"); e.circuit_export("cmta", p); cs = o.R1CS.load(p)
+    assert (cs.n_cons, cs.n_vars) == (gold["constraints"], gold["variables"]) == (2 * 27280 + 257, 2 * 24792 + 1089) and canonical_hash(cs) == gold["canonical_r1cs_sha256"]
+    for seed in (3, 4):
+        g = o.SplitMix64(seed); bits = [g.next() & 1 for _ in range(576)]; wp = str(tmp_path / "w.bin"); e.witness_cmta(bits, wp)
+        assert hashlib.sha256(open(wp, "rb").read()).hexdigest() == gold["seed%d" % seed]["witness_sha256"]
+        z = o.load_witness(wp); assert o.r1cs_is_satisfied(cs, z)
+        msg = bytes(sum(b << (7 - j) for j, b in enumerate(bits[8 * i:8 * i + 8])) for i in range(72)); assert "".join(str(int(v)) for v in o.from_arr(z[577:833])) == "".join(format(x, "08b") for x in hashlib.sha256(msg).digest()) == gold["seed%d" % seed]["digest_bits"]

@@ -3,7 +3,18 @@ pk_recv (20 B), value_old in [1, 2^63), value_s in [0, value_old]; dependent has
 the byte order of the reference (send/Note.h:30-78, util.h:233-258): blobs are hashed in their in-memory order, which is
 the reverse of the big-endian bytes go-ethereum passes as hex."""
 import hashlib, struct
-from oracle.pyoracle import SplitMix64
+
+class SplitMix64:
+    """the PRNG shared by the tests, the oracle (oracle/pyoracle.py has the same class) and oracle/ref_harness.cpp; restated here so that this module
+    (used by bench.py's setup) does not import the checker"""
+    def __init__(self, seed): self.s = seed & 0xFFFFFFFFFFFFFFFF
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF; z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF; z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+    def field(self):
+        l = [self.next() for _ in range(4)]; l[3] &= (1 << 61) - 1
+        return l[0] | l[1] << 64 | l[2] << 128 | l[3] << 192
 
 def rev(b): return bytes(b)[::-1]
 def sha(b): return hashlib.sha256(b).digest()
@@ -52,7 +63,6 @@ def pack_public(bits_be_blobs, extra_u64=None):
 
 def merkle_root_and_path(leaves_be, index, depth=8):
     """tree of 2^depth leaves padded with zero leaves, nodes = SHA-256 compression of left||right (no padding) in blob byte order; returns (root, siblings leaf level first), big-endian like everything else here"""
-    from oracle.pyoracle import lib as _unused  # noqa: F401  (keeps the import graph explicit: the hash below is local)
     def comp(l, r): return _sha256_compress(l + r)
     level = [rev(x) for x in leaves_be]; empty = bytes(32); sibs = []; pos = index
     for d in range(depth):
