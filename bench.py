@@ -65,8 +65,22 @@ def read_witness(path):
     import numpy as np
     b = open(path, "rb").read(); n = int(np.frombuffer(b, dtype=np.uint64, count=1)[0]); return np.frombuffer(b, dtype=np.uint64, count=4 * n, offset=8).reshape(n, 4).copy()
 
-def harness_kv(harness, *cmd):
-    out = subprocess.run([harness, *cmd], capture_output=True, text=True).stdout; kv = {}
+def usable_cores():
+    """host cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a pod that sees 256 CPUs may own far fewer; oversubscribed OpenMP
+    threads make the multi-core baseline slower than one thread)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max": n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0: n = max(1, min(n, q // per))
+        except Exception: pass
+    return min(n, 64)
+
+def harness_kv(harness, *cmd, env=None):
+    out = subprocess.run([harness, *cmd], capture_output=True, text=True, env=env).stdout; kv = {}
     for line in out.splitlines():
         tok = line.split()
         for a, b in zip(tok[0::2], tok[1::2]): kv[a] = b
@@ -202,7 +216,7 @@ def run_rank(args):
                 cpu = {"value": round(1.0 / float(kv["prover_total_s"]), 5), "unit": "proofs/s", "cores": 1, "kind": "reference",
                        "sample": "1 send proof by libsnark's r1cs_gg_ppzksnark_prover (oracle/_ref), key of the send circuit's shape with synthetic points; %.2f s" % float(kv["prover_total_s"])}
             if os.path.exists(harness_mt):                                   # the reference's -DMULTICORE build (OpenMP over FFT butterflies and multi_exp chunks) on all host cores
-                ncores = os.cpu_count() or 1; kv = harness_kv(harness_mt, "bench_prover", r1cs_path, w0)
+                ncores = usable_cores(); kv = harness_kv(harness_mt, "bench_prover", r1cs_path, w0, env=dict(os.environ, OMP_NUM_THREADS=str(ncores)))
                 if "prover_total_s" in kv: cpu_more["multicore"] = {"value": round(1.0 / float(kv["prover_total_s"]), 5), "unit": "proofs/s", "cores": int(kv.get("threads", ncores)), "kind": "reference", "sample": "same proof, libsnark built with -DMULTICORE -fopenmp; %.2f s" % float(kv["prover_total_s"])}
             if not args.no_extra_legs:
                 # what one genSendproof call costs in the reference: the key file is parsed and its 943k points decompressed on EVERY call (sendcgo.cpp:345), then the prover runs

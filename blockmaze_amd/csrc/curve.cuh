@@ -142,6 +142,13 @@ template <class F> __device__ __forceinline__ XYZZ<F> quad_mul_small(const XYZZ<
   for (int i = 31 - __clz(n); i >= 0; i--) { r = quad_dbl_inl(r, k); if ((n >> i) & 1) r = quad_add(r, a, k); }
   return r;
 }
+// n * p for an affine point and a small scalar n >= 1, MSB first: the top bit lifts p, every further bit costs a doubling and, if set, a mixed addition
+template <class F> __device__ __forceinline__ XYZZ<F> quad_mul_small_affine(const Affine<F> &p, uint32_t n, int k) {
+  XYZZ<F> r = XYZZ<F>::from_affine(p);
+#pragma unroll 1
+  for (int i = 30 - __clz(n); i >= 0; i--) { r = quad_dbl_inl(r, k); if ((n >> i) & 1) r = quad_madd(r, p, k); }
+  return r;
+}
 #endif
 
 using G1Affine = Affine<Fq>;

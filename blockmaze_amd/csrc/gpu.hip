@@ -35,16 +35,7 @@ void gpu_lane_select(int lane) { t_lane = lane < 0 || lane >= MAX_LANES ? 0 : la
 bool gpu_available() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0; }
 void gpu_sync() { HIP_CHECK(hipStreamSynchronize(gpu().stream)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamSynchronize(gpu().aux[i])); }
 void gpu_join_aux() { GpuContext &g = gpu(); for (int i = 0; i < 4; i++) { HIP_CHECK(hipEventRecord(g.join_event[i], g.aux[i])); HIP_CHECK(hipStreamWaitEvent(g.stream, g.join_event[i], 0)); } }
-// the whole device side of one proof is a fixed sequence of launches on fixed buffers: capture it once, replay it with one call
-struct GpuGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
 bool profiling_enabled();
-static bool g_capturing = false;
-bool gpu_capturing() { return g_capturing; }
-void gpu_graph_begin() { HIP_CHECK(hipStreamBeginCapture(gpu().stream, hipStreamCaptureModeThreadLocal)); g_capturing = true; }
-GpuGraph *gpu_graph_end() { g_capturing = false; std::unique_ptr<GpuGraph> g(new GpuGraph); HIP_CHECK(hipStreamEndCapture(gpu().stream, &g->graph)); HIP_CHECK(hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0)); return g.release(); }
-void gpu_graph_abort() { g_capturing = false; hipGraph_t g = nullptr; hipStreamEndCapture(gpu().stream, &g); if (g) hipGraphDestroy(g); (void)hipGetLastError(); }
-void gpu_graph_launch(GpuGraph *g) { HIP_CHECK(hipGraphLaunch(g->exec, gpu().stream)); }
-void gpu_graph_destroy(GpuGraph *g) { if (!g) return; if (g->exec) hipGraphExecDestroy(g->exec); if (g->graph) hipGraphDestroy(g->graph); delete g; }
 void gpu_fork_record() { GpuContext &g = gpu(); HIP_CHECK(hipEventRecord(g.fork_event, g.stream)); }
 void gpu_fork_wait(int i) { GpuContext &g = gpu(); HIP_CHECK(hipStreamWaitEvent(g.aux[i & 3], g.fork_event, 0)); }   // may be called from the thread that submits to that stream
 void gpu_fork_one(int i) { GpuContext &g = gpu(); HIP_CHECK(hipEventRecord(g.join_event[i & 3], g.stream)); HIP_CHECK(hipStreamWaitEvent(g.aux[i & 3], g.join_event[i & 3], 0)); }   // (the stream's join event is free at this point of a proof)

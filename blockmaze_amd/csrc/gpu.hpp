@@ -129,7 +129,7 @@ void gpu_fork_aux();        // auxiliary streams wait for everything queued on t
 void gpu_fork_one(int aux); // the same for one auxiliary stream
 void gpu_fork_record(); void gpu_fork_wait(int aux);   // the two halves of a fork: record the point on the main stream once, let each auxiliary stream wait for it (from any thread)
 void gpu_join_aux();        // the main stream waits for everything queued on the auxiliary streams
-struct GpuGraph; void gpu_graph_begin(); GpuGraph *gpu_graph_end(); void gpu_graph_abort(); void gpu_graph_launch(GpuGraph *g); void gpu_graph_destroy(GpuGraph *g); bool profiling_enabled(); bool gpu_capturing();
+bool profiling_enabled();
 // per-stage device timing (HIP events on the compute stream); report = JSON object {stage: {ms_total, count}}
 void profile_enable(bool on); std::string profile_report();
 

@@ -214,9 +214,9 @@ struct Prover::Impl {
   int lane = 0;                                                // this prover's stream set: provers on different lanes overlap on the device
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
-  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; DevBuf<uint8_t> packed; PinnedBuf<Fe32> z_host; GpuGraph *graph = nullptr; bool graph_failed = false;
+  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; DevBuf<uint8_t> packed; PinnedBuf<Fe32> z_host;
   std::unique_ptr<SubmitWorker> workers[4];
-  ~Impl() { for (auto &w : workers) w.reset(); gpu_graph_destroy(graph); }
+  ~Impl() { for (auto &w : workers) w.reset(); }
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &e) { size_t base = n / world, rem = n % world; b = rank * base + (rank < rem ? rank : rem); e = b + base + (rank < rem ? 1 : 0); }
@@ -236,7 +236,8 @@ Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) 
   shard_range(Lq->size(), shard_rank, shard_world, p.l0, e); size_t nL = e - p.l0;
   p.A.reset(new MsmG1(pk.A.data() + p.a0, nA, cw, true)); p.L.reset(new MsmG1(Lq->data() + p.l0, nL, cw, true));
   p.B1.reset(new MsmG1(pk.B_g1.data() + p.b0, nB, cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data() + p.b0, nB, cw, true)); p.H.reset(new MsmG1(Hq->data() + p.h0, nH, ch, false, env_int("ZK_MSM_H_TABLES", 1) != 0, true, env_int("ZK_MSM_GLV", 0) != 0));   // GLV (msm.cuh) is implemented and tested but off: measured, the accumulation does not get faster on the 151 MB table (0.56 vs 0.53 ms) and the decomposition costs 0.1 ms in the sort   // (with tables the H accumulation gathers from a table 16x larger and slows from 0.40 to 0.51 ms, but the reduction drops from 0.53 to 0.23 ms: measured 3 % better per proof, 10 % better with four proofs in flight)
-  p.A->set_stream(0); p.L->set_stream(1); p.B1->set_stream(2); p.B2->set_stream(3); if (env_int("ZK_MSM_SPLIT_ONES", 1)) p.B2->split_ones_path();   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
+  const bool one_stream = env_int("ZK_MSM_ONE_STREAM", 0) != 0;   // diagnostic: everything on the main stream, so that a kernel trace shows every kernel's stand-alone duration
+  if (!one_stream) { p.A->set_stream(0); p.L->set_stream(1); p.B1->set_stream(2); p.B2->set_stream(3); if (env_int("ZK_MSM_SPLIT_ONES", 1)) p.B2->split_ones_path(); }   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
   p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
   p.B_idx = DevBuf<uint32_t>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx.upload(pk.B_idx.data(), pk.B_idx.size());
   p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host = PinnedBuf<Fe32>(p.nv + 1 + 8); p.packed = DevBuf<uint8_t>(32 * (p.nv + 1 + 8));
@@ -281,7 +282,7 @@ static void enqueue_all(Prover::Impl &p) {
   std::function<void()> jobs[4] = { [&] { p.B2->run(p.z.get(), p.B_idx.get() + p.b0); }, [&] { p.L->run(p.z.get() + (p.c_fold ? 0 : p.ni + 1) + p.l0, nullptr); },       // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
                                     [&] { p.A->run(p.z.get() + p.a0, nullptr); }, [&] { p.B1->run(p.z.get(), p.B_idx.get() + p.b0); } };
   const int job_stream[4] = {3, 1, 0, 2};                       // the auxiliary stream each MSM was bound to in the constructor (set_stream)
-  const bool use_threads = threaded && !gpu_capturing();
+  const bool use_threads = threaded;
   bool posted[4] = {false, false, false, false};
   struct Waiter { Prover::Impl &p; bool *posted; ~Waiter() { for (int j = 0; j < 4; j++) if (posted[j]) { try { p.workers[j]->wait(); } catch (...) {} } } } waiter{p, posted};   // never leave a job running behind an exception
   auto release = [&](int point) { bool any = false; for (int j = 0; j < 4; j++) any |= start[j] == point; if (!any) return; gpu_fork_record();      // one event; each stream's wait is issued by the thread that feeds it
@@ -300,16 +301,9 @@ static void enqueue_all(Prover::Impl &p) {
   else p.H->run(p.abc.get() + p.h0, nullptr);                                                                             // :466-473
   for (int j = 0; j < 4; j++) if (posted[j]) { posted[j] = false; p.workers[j]->wait(); }
 }
-// one proof's device work: replayed from a captured hipGraph (about 70 launches on 5 streams collapse into one submission); opt-in with ZK_USE_GRAPH=1
-static void run_device(Prover::Impl &p) {
-  static const bool no_graph = getenv("ZK_USE_GRAPH") == nullptr;   // measured on ROCm 7.2 / MI355X: replay of this 5-stream graph is slower than eager submission (5.9 vs 5.2 ms per proof), so it is opt-in
-  if (no_graph || p.graph_failed || profiling_enabled()) { enqueue_all(p); return; }
-  if (!p.graph) {
-    try { gpu_graph_begin(); enqueue_all(p); gpu_join_aux(); p.graph = gpu_graph_end(); }   // (enqueue_all stays single-threaded while capturing)
-    catch (const std::exception &) { gpu_graph_abort(); p.graph_failed = true; p.graph = nullptr; enqueue_all(p); return; }
-  }
-  gpu_graph_launch(p.graph);
-}
+// one proof's device work.  (Replaying the five-stream DAG from a captured hipGraph was measured slower than eager submission from the five submit threads on
+// ROCm 7.2 / MI355X — 4.65 vs 3.70 ms per proof in round 1 — and was removed.)
+static void run_device(Prover::Impl &p) { enqueue_all(p); }
 // proof assembly (r1cs_gg_ppzksnark.tcc:487-495)
 static void assemble(const Prover::Impl &p, const RsTerms &t, const HG1 &eA, const HG1 &eB1, const HG2 &eB2, const HG1 &eH, const HG1 &eL, Proof &out) {
   HG1 gA = p.alpha_g1.add(eA).add(t.r_delta);                                                                            // :488

@@ -40,6 +40,19 @@ __device__ __forceinline__ void signed_digits(const uint32_t k[8], int c, int W,
   }
 }
 
+// The same digits for a compile-time window size, handed to fn(w, digit) one by one: after unrolling every limb index is a constant and the scalar stays in registers.
+// (With a runtime window size k[] is indexed dynamically and, like the digit array above, lives in scratch memory: 300-560 bytes per lane in the first version of the
+// sort kernels.)  C = 0 selects the runtime path in the kernels below.
+template <int C, class Fn> __device__ __forceinline__ void for_each_digit(const uint32_t (&k)[8], Fn &&fn) {
+  constexpr int W = 254 / (C ? C : 1) + 1; constexpr uint32_t half = 1u << ((C ? C : 1) - 1), full = 1u << (C ? C : 1), mask = full - 1; uint32_t carry = 0;
+#pragma unroll
+  for (int w = 0; w < W; w++) {
+    const int bit = w * C, word = bit >> 5, sh = bit & 31;
+    uint32_t v = word < 8 ? k[word] >> sh : 0u; if (sh + C > 32 && word + 1 < 8) v |= k[word + 1] << (32 - sh);
+    const uint32_t d = (v & mask) + carry; int dg; if (d > half) { dg = (int)d - (int)full; carry = 1; } else { dg = (int)d; carry = 0; }
+    fn(w, dg);
+  }
+}
 // ---- GLV: k = k1 + k2*lambda with |k1|, |k2| < 2^128, lambda*(x, y) = (beta*x, y) ------------------------------------------
 // Halves the windows an MSM with fixed-base tables needs (9 of 16 bits instead of 16): the H query's table shrinks from 268 MB to 151 MB and fits the Infinity Cache.
 // An entry of the second half carries bit 30; the accumulation kernel multiplies x by beta for it.  Any integers c1, c2 give a correct decomposition (the basis
@@ -71,6 +84,10 @@ __device__ __forceinline__ int msm_digits(const uint32_t k[8], int c, int W, int
   if (n2) for (int w = 0; w < W; w++) dig[W + w] = -dig[W + w];
   return 2 * W;
 }
+template <int C, class Fn> __device__ __forceinline__ void msm_walk_digits(const uint32_t (&k)[8], int c, int W, int glv, Fn &&fn) {   // fn(e, w, digit): e = entry number (w, or W + w for the second GLV half)
+  if constexpr (C > 0) { for_each_digit<C>(k, [&](int w, int d) { fn(w, w, d); }); }
+  else { int dig[MSM_MAX_WINDOWS]; const int nd = msm_digits(k, c, W, glv, dig); for (int e = 0; e < nd; e++) fn(e, e < W ? e : e - W, dig[e]); }
+}
 constexpr uint32_t MSM_ENTRY_SIGN = 0x80000000u, MSM_ENTRY_PHI = 0x40000000u;   // entry = table index | sign | second GLV half
 
 struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; };
@@ -80,7 +97,7 @@ struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; };
 // Bucket arrays of at most MSM_LDS_HIST counters (the witness MSMs: 128 buckets once all windows share one array) are histogrammed / ranked in LDS per workgroup and
 // touch the global counters once per non-empty bucket and workgroup: with ~60,000 entries on 128 counters the global atomics would serialise.
 constexpr uint32_t MSM_LDS_HIST = 4096;
-template <int DUMMY = 0>
+template <int C>
 __global__ void __launch_bounds__(256) k_msm_classify(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
                                uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t n_hist, int glv, uint32_t *__restrict__ hist, uint32_t *__restrict__ ones, MsmCounters *cnt, MsmCounters *cnt_next) {
   __shared__ uint32_t lh[MSM_LDS_HIST]; const bool use_lds = n_hist <= MSM_LDS_HIST;
@@ -92,15 +109,13 @@ __global__ void __launch_bounds__(256) k_msm_classify(const Fr *__restrict__ sca
   { // the compacted list of scalar-one indices: one atomic per wave instead of one per lane (46 % of a witness are ones, all on the same counter)
     uint64_t m = __ballot(is_one); if (m) { uint32_t lane = threadIdx.x & 63, base = 0; if (lane == (uint32_t)__ffsll((long long)m) - 1) base = atomicAdd(&cnt->n_ones, (uint32_t)__popcll(m));
       base = __shfl(base, __ffsll((long long)m) - 1, 64); if (is_one) ones[base + __popcll(m & ((1ull << lane) - 1))] = i; } }
-  if (live && !is_one) {
-    int dig[MSM_MAX_WINDOWS]; const int nd = msm_digits(k.l, c, W, glv, dig);
-    for (int e = 0; e < nd; e++) { int d = dig[e]; const int w = e < W ? e : e - W; if (d) { uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; atomicAdd(use_lds ? &lh[key] : &hist[key], 1u); } }   // hist_stride = 2^(c-1): buckets per window; 0: all windows share one bucket array (precomputed 2^(cw) P)
-  }
+  if (live && !is_one)
+    msm_walk_digits<C>(k.l, c, W, glv, [&](int, int w, int d) { if (d) { uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; atomicAdd(use_lds ? &lh[key] : &hist[key], 1u); } });   // hist_stride = 2^(c-1): buckets per window; 0: all windows share one bucket array (precomputed 2^(cw) P)
   { uint64_t m = __ballot(live && !is_one); if (m && (threadIdx.x & 63) == (uint32_t)__ffsll((long long)m) - 1) atomicAdd(&cnt->n_other, (uint32_t)__popcll(m)); }
   if (use_lds) { __syncthreads(); for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) if (lh[b]) atomicAdd(&hist[b], lh[b]); }
 }
 
-template <int DUMMY = 0>
+template <int C>
 __global__ void __launch_bounds__(256) k_msm_scatter(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
                               uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t point_stride, uint32_t n_hist, int glv, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ fill, uint32_t *__restrict__ entries) {
   __shared__ uint32_t lcnt[MSM_LDS_HIST], lbase[MSM_LDS_HIST]; const bool use_lds = n_hist <= MSM_LDS_HIST;
@@ -108,19 +123,18 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const Fr *__restrict__ scal
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; bool live = i < n && !(point_is_inf && point_is_inf[i]); Fr k = Fr::zero();
   if (live) { k = scalars[scalar_index ? scalar_index[i] : i].from_mont(); live = !k.is_zero(); }
   if (live && filter_ones) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; if (o == 0) live = false; }
-  int dig[MSM_MAX_WINDOWS]; int nd = 0; if (live) nd = msm_digits(k.l, c, W, glv, dig);
+  auto entry_of = [&](int e, int w, int d) { return (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u) | (e >= W ? MSM_ENTRY_PHI : 0u); };   // point_stride = n: the entry addresses 2^(cw) P_i in the precomputed table
   if (!use_lds) {
-    for (int e = 0; e < nd; e++) { int d = dig[e]; if (!d) continue; const int w = e < W ? e : e - W; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1;
-      entries[offsets[key] + atomicAdd(&fill[key], 1u)] = (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u) | (e >= W ? MSM_ENTRY_PHI : 0u); }   // point_stride = n: the entry addresses 2^(cw) P_i in the precomputed table
+    if (live) msm_walk_digits<C>(k.l, c, W, glv, [&](int e, int w, int d) { if (!d) return; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; entries[offsets[key] + atomicAdd(&fill[key], 1u)] = entry_of(e, w, d); });
     return;
   }
-  uint32_t rank[MSM_MAX_WINDOWS];                                                           // position inside this workgroup's share of the bucket
-  for (int e = 0; e < nd; e++) { int d = dig[e]; const int w = e < W ? e : e - W; if (d) rank[e] = atomicAdd(&lcnt[(uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1], 1u); }
+  // small bucket arrays: the workgroup counts its entries per bucket in LDS, reserves its share of every bucket with one global atomic, then walks the digits a second
+  // time to place them (ranks come from the LDS counters; nothing per entry is kept in registers or scratch between the two walks)
+  if (live) msm_walk_digits<C>(k.l, c, W, glv, [&](int, int w, int d) { if (d) atomicAdd(&lcnt[(uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1], 1u); });
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) if (lcnt[b]) lbase[b] = offsets[b] + atomicAdd(&fill[b], lcnt[b]);
+  for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) { const uint32_t m = lcnt[b]; lbase[b] = m ? offsets[b] + atomicAdd(&fill[b], m) : 0; lcnt[b] = 0; }
   __syncthreads();
-  for (int e = 0; e < nd; e++) { int d = dig[e]; if (!d) continue; const int w = e < W ? e : e - W; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1;
-    entries[lbase[key] + rank[e]] = (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u) | (e >= W ? MSM_ENTRY_PHI : 0u); }
+  if (live) msm_walk_digits<C>(k.l, c, W, glv, [&](int e, int w, int d) { if (!d) return; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; entries[lbase[key] + atomicAdd(&lcnt[key], 1u)] = entry_of(e, w, d); });
 }
 
 // One-pass sort for scalars known to be uniform (the H query: coefficients of the quotient polynomial) with all windows sharing one bucket array: every bucket owns
@@ -139,6 +153,77 @@ __global__ void k_msm_scatter_direct(const Fr *__restrict__ scalars, const uint3
   for (int e = 0; e < nd; e++) { int d = dig[e]; if (!d) continue; const int w = e < W ? e : e - W; uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, slot = atomicAdd(&counts[key], 1u);
     if (slot < cap) entries[(size_t)key * cap + slot] = (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u) | (e >= W ? MSM_ENTRY_PHI : 0u); else over = true; }
   if (over) atomicOr(&cnt->pad[0], 1u);
+}
+
+// ---- H query, second generation of the one-pass sort: workgroup-local binning ------------------------------------------------
+// k_msm_scatter_direct above pays one device-scope atomic and one isolated 4-byte store per digit (4.2 M of each for the send circuit: 0.34 ms, 13.6x the algorithmic
+// traffic).  Here the 2^(c-1) buckets are cut into HSORT_GROUPS groups by their high bits, and the sort runs in two short kernels whose atomics are all in LDS:
+//   k_hsort_bin    a workgroup takes HSORT_TILE scalars (forming a*b*z on the way), counts its digits per group in LDS, reserves its share of every group's region
+//                  with ONE device-scope atomic per group (65 K per MSM instead of 4.2 M), then writes each entry next to its workgroup-mates of the same group:
+//                  runs of ~128 bytes per group and workgroup instead of isolated words.  Entry = low bucket bits | sign | table index.
+//   k_hsort_group  one workgroup per group: the group's entries (16 K for send) are counted per bucket in LDS, the counts are scanned, and every entry moves to its
+//                  final place inside the group's region of the output (a 64 KB window that lives in this XCD's L2 while it is written).  Emits counts[] / offsets[].
+// Uniform scalars fill every group to within a few per cent of n*W/G, so a region holds 1.25x that; a region that would overflow raises the same flag as before
+// and the host repeats the MSM on the two-pass path (any input stays correct).  With every bucket holding lambda +- 3 sqrt(lambda) entries there is also no need
+// for a task plan: each bucket is cut into HSORT_SLICES equal slices (k_msm_accumulate_slices), whose partial sums one quad adds up (k_msm_combine_slices).
+constexpr uint32_t HSORT_GROUPS = 1024 /* at most; the shape says how many are used */, HSORT_BIN_THREADS = 256, HSORT_PER_THREAD = 2, HSORT_TILE = HSORT_BIN_THREADS * HSORT_PER_THREAD, HSORT_GROUP_THREADS = 512, HSORT_MAX_PER_THREAD = 48, HSORT_SLICES = 8, HSORT_STAGE_W = 20 /* staged entries per scalar: at most 254 / c + 1 digits, c >= 13 */;
+struct HsortShape { uint32_t groups, low_bits, idx_bits, region; };     // groups * 2^low_bits = buckets; bucket = group << low_bits | low; entry = low << (idx_bits + 1) | sign << idx_bits | index; region: entry slots per group
+template <int C>
+__global__ void __launch_bounds__(HSORT_BIN_THREADS) k_hsort_bin(const Fr *__restrict__ scalars, const Fr *__restrict__ mul_b, const Fr *__restrict__ mul_z, int z_is_table, const uint8_t *__restrict__ point_is_inf,
+                                                                 uint32_t n, int c, int W, uint32_t point_stride, HsortShape sh, uint32_t *__restrict__ group_fill, uint32_t *__restrict__ mid, MsmCounters *cnt, MsmCounters *cnt_next) {
+  __shared__ uint32_t lcnt[HSORT_GROUPS], lpos[HSORT_GROUPS], gbase[HSORT_GROUPS]; __shared__ uint32_t stage[HSORT_TILE * HSORT_STAGE_W]; __shared__ uint16_t stage_g[HSORT_TILE * HSORT_STAGE_W]; __shared__ uint32_t wave_tot[HSORT_BIN_THREADS / 64];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = MsmCounters{0, 0, {0, 0}};
+  for (uint32_t g = threadIdx.x; g < sh.groups; g += blockDim.x) lcnt[g] = 0;
+  __syncthreads();
+  Fr k[HSORT_PER_THREAD]; bool live[HSORT_PER_THREAD];
+#pragma unroll
+  for (int q = 0; q < (int)HSORT_PER_THREAD; q++) { const uint32_t i = blockIdx.x * HSORT_TILE + q * HSORT_BIN_THREADS + threadIdx.x; live[q] = i < n && !(point_is_inf && point_is_inf[i]); k[q] = Fr::zero();
+    if (live[q]) { Fr v = scalars[i]; if (mul_b) v = v * mul_b[i] * mul_z[z_is_table ? i : 0]; k[q] = v.from_mont(); live[q] = !k[q].is_zero(); } }
+  const uint32_t low_mask = (1u << sh.low_bits) - 1;
+#pragma unroll
+  for (int q = 0; q < (int)HSORT_PER_THREAD; q++) if (live[q]) msm_walk_digits<C>(k[q].l, c, W, 0, [&](int, int, int d) { if (d) atomicAdd(&lcnt[((uint32_t)(d < 0 ? -d : d) - 1) >> sh.low_bits], 1u); });
+  __syncthreads();
+  // exclusive scan of the group counts (where each group's run starts in the staging tile) and the reservation of the runs in the groups' regions
+  { uint32_t s = 0; const uint32_t per = (sh.groups + HSORT_BIN_THREADS - 1) / HSORT_BIN_THREADS, lo = threadIdx.x * per; for (uint32_t j = 0; j < per; j++) if (lo + j < sh.groups) s += lcnt[lo + j];
+    uint32_t inc = s; for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(inc, d, 64); if ((int)(threadIdx.x & 63) >= d) inc += t; }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t ex = inc - s; for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) ex += wave_tot[wv];
+    bool over = false;
+    for (uint32_t j = 0; j < per; j++) if (lo + j < sh.groups) { const uint32_t g = lo + j, m = lcnt[g]; lpos[g] = ex; ex += m; const uint32_t b = m ? atomicAdd(&group_fill[g], m) : 0; if (b + m > sh.region) over = true; gbase[g] = b; }
+    if (over) atomicOr(&cnt->pad[0], 1u); }
+  __syncthreads();
+  for (uint32_t g = threadIdx.x; g < sh.groups; g += blockDim.x) lcnt[g] = lpos[g];       // running write position of every group inside the staging tile
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < (int)HSORT_PER_THREAD; q++) if (live[q]) { const uint32_t i = blockIdx.x * HSORT_TILE + q * HSORT_BIN_THREADS + threadIdx.x;
+    msm_walk_digits<C>(k[q].l, c, W, 0, [&](int, int w, int d) { if (!d) return; const uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, g = key >> sh.low_bits, p = atomicAdd(&lcnt[g], 1u);
+      if (p < HSORT_TILE * HSORT_STAGE_W) { stage[p] = ((key & low_mask) << (sh.idx_bits + 1)) | ((d < 0 ? 1u : 0u) << sh.idx_bits) | (i + (uint32_t)w * point_stride); stage_g[p] = (uint16_t)g; } }); }
+  __syncthreads();
+  // copy-out: consecutive lanes write consecutive words of a group's run (about 128 bytes per group and workgroup) instead of one isolated word per digit
+  const uint32_t total = min(lcnt[sh.groups - 1], HSORT_TILE * HSORT_STAGE_W);
+  for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) { const uint32_t g = stage_g[p], pos = gbase[g] + (p - lpos[g]); if (pos < sh.region) mid[(size_t)g * sh.region + pos] = stage[p]; }
+}
+static __global__ void __launch_bounds__(HSORT_GROUP_THREADS) k_hsort_group(const uint32_t *__restrict__ mid, uint32_t *__restrict__ group_fill, HsortShape sh, uint32_t *__restrict__ entries, uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets) {
+  __shared__ uint32_t lcnt[1024], lpre[1024];                        // 2^low_bits <= 1024 buckets per group
+  const uint32_t g = blockIdx.x, nb = 1u << sh.low_bits, n_g = min(group_fill[g], sh.region), idx_mask = (1u << sh.idx_bits) - 1; const uint32_t *src = mid + (size_t)g * sh.region;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lcnt[b] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) group_fill[g] = 0;                           // (read above by every thread of this workgroup only, before the barrier) cleared for the next run
+  uint32_t e[HSORT_MAX_PER_THREAD]; int ne = 0;
+#pragma unroll
+  for (int j = 0; j < (int)HSORT_MAX_PER_THREAD; j++) { const uint32_t p = (uint32_t)j * HSORT_GROUP_THREADS + threadIdx.x; if (p < n_g) { e[j] = src[p]; atomicAdd(&lcnt[e[j] >> (sh.idx_bits + 1)], 1u); ne = j + 1; } }
+  __syncthreads();
+  if (threadIdx.x < 64) {                                           // exclusive scan of the bucket counts by one wave (nb / 64 consecutive buckets per lane)
+    const uint32_t per = (nb + 63) / 64, lo = threadIdx.x * per; uint32_t s = 0; for (uint32_t j = 0; j < per; j++) if (lo + j < nb) s += lcnt[lo + j];
+    uint32_t inc = s; for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(inc, d, 64); if ((int)threadIdx.x >= d) inc += t; }
+    uint32_t ex = inc - s; for (uint32_t j = 0; j < per; j++) if (lo + j < nb) { lpre[lo + j] = ex; ex += lcnt[lo + j]; } }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) { const uint32_t bucket = (g << sh.low_bits) | b; counts[bucket] = lcnt[b]; offsets[bucket] = g * sh.region + lpre[b]; lcnt[b] = 0; }
+  __syncthreads();
+  uint32_t *dst = entries + (size_t)g * sh.region;
+#pragma unroll
+  for (int j = 0; j < (int)HSORT_MAX_PER_THREAD; j++) if (j < ne) { const uint32_t v = e[j], b = v >> (sh.idx_bits + 1), r = atomicAdd(&lcnt[b], 1u); dst[lpre[b] + r] = (v & idx_mask) | (((v >> sh.idx_bits) & 1u) ? MSM_ENTRY_SIGN : 0u); }
 }
 
 static __global__ void k_fr_mul3(const Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ z, int z_is_table, uint32_t n, Fr *__restrict__ out) {
@@ -252,13 +337,35 @@ __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *_
     if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; vn = vnn; }
   if (cnt <= task) buckets[b] = acc; else partials[t] = acc;
 }
+// The same accumulation for the group-sorted H query: no plan, lane t takes slice t % S of bucket t / S — the entries [cnt*j/S, cnt*(j+1)/S) of the bucket.  With
+// uniform scalars every slice of a wave is within an entry or two of the same length.
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_accumulate_slices(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
+                                                               uint32_t n_buckets, XYZZ<F> *__restrict__ partials) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= n_buckets * HSORT_SLICES) return;
+  const uint32_t b = t / HSORT_SLICES, j = t % HSORT_SLICES, cnt = counts[b], beg = offsets[b] + (cnt * j) / HSORT_SLICES, end = offsets[b] + (cnt * (j + 1)) / HSORT_SLICES;
+  XYZZ<F> acc = XYZZ<F>::inf();
+  if (beg < end) {
+    uint32_t v = entries[beg], vn = beg + 1 < end ? entries[beg + 1] : v; Affine<F> p = points[v & ~MSM_ENTRY_SIGN];
+#pragma unroll 1
+    for (uint32_t e = beg; e < end; e++) {                 // software pipeline as in k_msm_accumulate_tasks
+      Affine<F> pn = points[vn & ~MSM_ENTRY_SIGN]; uint32_t vnn = e + 2 < end ? entries[e + 2] : vn;
+      if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; vn = vnn; } }
+  partials[t] = acc;
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_combine_slices(const XYZZ<F> *__restrict__ partials, uint32_t n_buckets, XYZZ<F> *__restrict__ buckets) {
+  const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; const int k = threadIdx.x & 3; if (b >= n_buckets) return;
+  const XYZZ<F> *src = partials + (size_t)b * HSORT_SLICES; XYZZ<F> acc = src[0], nxt = src[1];
+#pragma unroll 1
+  for (uint32_t j = 1; j < HSORT_SLICES; j++) { XYZZ<F> cur = nxt; if (j + 1 < HSORT_SLICES) nxt = src[j + 1]; acc = quad_add(acc, cur, k); }
+  if (k == 0) buckets[b] = acc;
+}
 // ---- sums by the 64 quads of a 256-thread workgroup ------------------------------------------------------------------------
 // quad q adds elements q, q+64, ...; then a tree over the 16 quads of each wave (shuffles) and over the 4 waves (LDS).  The result is valid in lanes 0..3.
-template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<F> *__restrict__ src, uint32_t len, XYZZ<F> *lds) {
-  const uint32_t q = threadIdx.x >> 2, wq = q & 15, wave = threadIdx.x >> 6; const int k = threadIdx.x & 3; XYZZ<F> acc = XYZZ<F>::inf();
-  if (q < len) { XYZZ<F> nxt = src[q];
-#pragma unroll 1
-    for (uint32_t j = q; j < len; j += 64) { XYZZ<F> cur = nxt; if (j + 64 < len) nxt = src[j + 64]; acc = quad_add(acc, cur, k); } }
+// tree over the 64 quads of a 256-thread workgroup: 16 quads per wave by shuffles, the 4 waves through LDS.  Every quad brings `acc`; the sum is valid in lanes 0..3.
+template <class F> __device__ __forceinline__ XYZZ<F> block_quad_tree(XYZZ<F> acc, XYZZ<F> *lds) {
+  const uint32_t q = threadIdx.x >> 2, wq = q & 15, wave = threadIdx.x >> 6; const int k = threadIdx.x & 3;
 #pragma unroll 1
   for (int d = 8; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (wq + d < 16) acc = quad_add(acc, o, k); }
   if ((threadIdx.x & 63) == 0) lds[wave] = acc;
@@ -267,6 +374,13 @@ template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<
 #pragma unroll 1
     for (int d = 2; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (q + d < 4) acc = quad_add(acc, o, k); } }
   return acc;
+}
+template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<F> *__restrict__ src, uint32_t len, XYZZ<F> *lds) {
+  const uint32_t q = threadIdx.x >> 2; const int k = threadIdx.x & 3; XYZZ<F> acc = XYZZ<F>::inf();
+  if (q < len) { XYZZ<F> nxt = src[q];
+#pragma unroll 1
+    for (uint32_t j = q; j < len; j += 64) { XYZZ<F> cur = nxt; if (j + 64 < len) nxt = src[j + 64]; acc = quad_add(acc, cur, k); } }
+  return block_quad_tree(acc, lds);
 }
 
 // buckets that were cut into several tasks: add up the partial sums.  Buckets are ranked by decreasing size (order[], cls_start[]).  One quad per bucket adds up
@@ -342,6 +456,47 @@ __global__ void __launch_bounds__(256) k_msm_sum_ones(const Affine<F> *__restric
 #pragma unroll 1
   for (uint32_t j = t; j < n; j += n_quads) acc = quad_madd(acc, points[ones[j]], k);
   if (k == 0) partial[t] = acc;
+}
+
+// ---- witness MSMs without buckets -------------------------------------------------------------------------------------------
+// 97 % of a BlockMaze assignment is 0 or 1 and most of the rest are 32-bit words (7,574 of 227,047 scalars of the send circuit are neither, with 36 K
+// non-zero 8-bit digits between them).  Pippenger's machinery — histogram, plan, counting sort, bucket accumulation, combine, weighted bucket reduction, six launches
+// of mostly dependent additions — is the wrong tool for that: with the fixed-base table T[w][i] = 2^(cw) P_i resident, every non-zero digit d of a scalar is simply one
+// more term d * T[w][i] of a plain point sum.  So:
+//   k_wmsm_classify   one pass over the scalars: indices of the ones and (table index, digit) pairs of everything else, both appended with one atomic per wave
+//   k_wmsm_sum        one quad per strided share of both lists: small multiples by double-and-add (at most c - 1 doublings), mixed additions for the ones, then the
+//                     workgroup's tree; one partial sum per workgroup
+//   k_xyzz_group_sum  the partial sums
+// The same group element as multi_exp_with_mixed_addition (multiexp.tcc:443-496) computes, with chains of ~25 dependent additions instead of ~150.
+template <int C>
+__global__ void __launch_bounds__(256) k_wmsm_classify(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf, uint32_t n, int c, int W, uint32_t point_stride,
+                                                       uint32_t *__restrict__ ones, uint2 *__restrict__ others, uint32_t others_cap, MsmCounters *cnt, MsmCounters *cnt_next) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = MsmCounters{0, 0, {0, 0}};
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63; bool live = i < n && !(point_is_inf && point_is_inf[i]); Fr k = Fr::zero();
+  if (live) { k = scalars[scalar_index ? scalar_index[i] : i].from_mont(); live = !k.is_zero(); }
+  bool is_one = false; if (live) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; is_one = o == 0; }
+  { uint64_t m = __ballot(is_one); if (m) { uint32_t base = 0; const int first = __ffsll((long long)m) - 1; if ((int)lane == first) base = atomicAdd(&cnt->n_ones, (uint32_t)__popcll(m));
+      base = __shfl(base, first, 64); if (is_one) ones[base + __popcll(m & ((1ull << lane) - 1))] = i; } }
+  const bool other = live && !is_one; uint32_t nd = 0;
+  if (other) msm_walk_digits<C>(k.l, c, W, 0, [&](int, int, int d) { nd += d != 0; });
+  if (__ballot(other)) {                                               // wave-level exclusive scan of the digit counts, one atomic for the whole wave
+    uint32_t inc = nd; for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += t; }
+    const uint32_t total = __shfl(inc, 63, 64); uint32_t base = 0; if (lane == 63) base = atomicAdd(&cnt->n_other, total); base = __shfl(base, 63, 64);
+    uint32_t pos = base + inc - nd;
+    if (other) msm_walk_digits<C>(k.l, c, W, 0, [&](int, int w, int d) { if (!d) return; if (pos < others_cap) others[pos] = make_uint2(i + (uint32_t)w * point_stride, (uint32_t)(d < 0 ? -d : d) | (d < 0 ? 0x80000000u : 0u)); else atomicOr(&cnt->pad[0], 1u); pos++; });
+  }
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_wmsm_sum(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ ones, const uint2 *__restrict__ others, uint32_t others_cap, const MsmCounters *cnt, uint32_t n_quads, XYZZ<F> *__restrict__ partial) {
+  __shared__ XYZZ<F> lds[4];
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; const int k = threadIdx.x & 3; const uint32_t n1 = cnt->n_ones, n2 = min(cnt->n_other, others_cap); XYZZ<F> acc = XYZZ<F>::inf();
+#pragma unroll 1
+  for (uint32_t j = t; j < n2; j += n_quads) { const uint2 e = others[j]; Affine<F> p = points[e.x]; if (e.y >> 31) p.y = p.y.neg(); acc = quad_add(acc, quad_mul_small_affine(p, e.y & 0x7fffffffu, k), k); }
+  if (t < n1) { Affine<F> nxt = points[ones[t]];
+#pragma unroll 1
+    for (uint32_t j = t; j < n1; j += n_quads) { Affine<F> cur = nxt; if (j + n_quads < n1) nxt = points[ones[j + n_quads]]; acc = quad_madd(acc, cur, k); } }   // the next point's gather is in flight during the addition
+  acc = block_quad_tree(acc, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
 // ---- fixed-base precomputation: table[w*n + i] = 2^(c*w) * P_i, affine ------------------------------------------------

@@ -4,6 +4,9 @@
 #include <memory>
 #include "gpu_internal.hpp"
 
+// window sizes with a compiled-in digit walk (msm.cuh: for_each_digit); every other size takes the runtime path (C = 0)
+#define ZK_MSM_DISPATCH_C(cval, glvval, CALL) do { if (!(glvval) && (cval) == 8) { CALL(8); } else if (!(glvval) && (cval) == 16) { CALL(16); } else { CALL(0); } } while (0)
+
 namespace zk {
 template <class F, class RawAffine>
 struct MsmImpl {
@@ -13,6 +16,8 @@ struct MsmImpl {
   bool direct = false, offsets_direct = false; uint32_t cap = 0, task = MSM_TASK;   // task: sorted entries per accumulation lane
   bool split_ones = false; hipStream_t ones_stream = nullptr; hipEvent_t ev_classified = nullptr, ev_ones = nullptr;   // the ones path on a stream of its own, beside the bucket path (the G2 MSM: both are long chains)
   const Fe32 *prod_b = nullptr, *prod_z = nullptr; bool prod_z_table = false; DevBuf<Fe32> prod_tmp;   // scalars given as a product a*b*z (run_product)
+  bool sparse = false; DevBuf<uint8_t> others; uint32_t others_cap = 0;   // witness MSMs without buckets (k_wmsm_classify / k_wmsm_sum, msm.cuh): needs the fixed-base tables
+  bool hsort = false; HsortShape hs{0, 0, 0, 0}; DevBuf<uint32_t> group_fill, mid;   // group-binned one-pass sort (k_hsort_bin / k_hsort_group, msm.cuh)
   const Fe32 *last_scalars = nullptr; const uint32_t *last_index = nullptr;   // one-pass sort (k_msm_scatter_direct) for uniform scalars
   DevBuf<uint32_t> zeroed;                                          // [hist | fill | counters]: cleared by one memset per run
   DevBuf<uint32_t> offsets, entries, ones, ntasks, task_off, order, rank_of, block_hist, block_off, cls_start; uint32_t bsort_blocks; std::unique_ptr<Scanner> bsort_scanner; Scanner scanner, task_scanner; uint32_t max_tasks;
@@ -55,11 +60,18 @@ struct MsmImpl {
       hipLaunchKernelGGL((k_msm_precompute<F>), dim3(cdiv(n, 64)), dim3(64), 0, gpu().stream, (Affine<F> *)points.get(), (uint32_t)n, c, W, (XYZZ<F> *)tmp.get(), (F *)pref.get());
       HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream));
     }
-    max_tasks = (uint32_t)((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1);
+    if (filter_ones && WB == 1 && n && getenv("ZK_MSM_SPARSE") != nullptr && atoi(getenv("ZK_MSM_SPARSE")) != 0) {   // opt-in (measured: chains 2-3x shorter, but 3x the field products of the bucket path, which the other streams then miss: 1.82 vs 1.74 ms per send proof)
+      sparse = true; others_cap = (uint32_t)std::min<size_t>((size_t)n * W, std::max<size_t>((size_t)n * 2, 1u << 16)); others = DevBuf<uint8_t>((size_t)others_cap * sizeof(uint2)); }   // room for two non-zero digits per scalar on average (a witness has ~0.16); more raises the overflow flag and the bucket path below runs instead
+    max_tasks = (uint32_t)std::max((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1, (size_t)WB * NB * HSORT_SLICES);
     if (uniform_hint && WB == 1 && !filter_ones && n && getenv("ZK_MSM_NO_DIRECT_SORT") == nullptr) {   // slots per bucket: twice the expected load (+64), a power of two
       size_t lam = (n * (size_t)msm_num_windows(c)) / NB, want = 2 * lam + 64; cap = 64; while (cap < want) cap <<= 1;
       if (const char *e = getenv("ZK_MSM_DIRECT_CAP")) { int v = atoi(e); if (v >= 1 && v <= 4080) cap = (uint32_t)v; }   // test hook: a tiny capacity forces the overflow fallback
-      if ((size_t)NB * cap <= (1ull << 28)) { direct = true; entries = DevBuf<uint32_t>((size_t)NB * cap);
+      // group-binned variant: G groups of 2^low buckets, about 16 K entries per group (one workgroup sorts a group in registers + LDS)
+      { size_t total = n * (size_t)W; uint32_t G = 256; while (G < HSORT_GROUPS && total / G > 16384) G <<= 1; uint32_t low = 0; while ((G << low) < NB) low++; uint32_t ib = 1; while (((size_t)1 << ib) < total) ib++;
+        size_t region = ((total / G) * 5 / 4 + 1024 + 255) & ~(size_t)255; if (getenv("ZK_MSM_DIRECT_CAP")) region = 256;   // (test hook: regions far too small force the overflow fallback)
+        if (!glv && W <= (int)HSORT_STAGE_W && getenv("ZK_MSM_NO_HSORT") == nullptr && (G << low) == NB && low >= 1 && low <= 10 && low + 1 + ib <= 32 && region <= (size_t)HSORT_GROUP_THREADS * HSORT_MAX_PER_THREAD) {
+          hsort = true; hs = HsortShape{G, low, ib, (uint32_t)region}; group_fill = DevBuf<uint32_t>(G); group_fill.zero(); mid = DevBuf<uint32_t>((size_t)G * region); direct = true; entries = DevBuf<uint32_t>((size_t)G * region); } }
+      if (!hsort && (size_t)NB * cap <= (1ull << 28)) { direct = true; entries = DevBuf<uint32_t>((size_t)NB * cap);
         const char *e = getenv("ZK_MSM_DIRECT_TASK"); int tv = e ? atoi(e) : 16; if (lam >= 64 && (tv == 16 || tv == 32 || tv == 64)) task = (uint32_t)tv; } }   // (measured: 32 halves the combine but costs as much in the accumulation, which then has too few lanes)
     { size_t nbk = (size_t)WB * NB; bsort_blocks = cdiv(nbk, BSORT_BLOCK); order = DevBuf<uint32_t>(nbk); rank_of = DevBuf<uint32_t>(nbk); block_hist = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); block_off = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); bsort_scanner.reset(new Scanner((size_t)bsort_blocks * BSORT_CLASSES)); }
     buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>((size_t)max_tasks * sizeof(XYZZ<F>));
@@ -73,10 +85,12 @@ struct MsmImpl {
   hipStream_t stream() { return stream_id < 0 ? gpu().stream : gpu().aux[stream_id & 3]; }
   // after the stream has been synchronised: did a bucket of the one-pass sort overflow?  Then repeat the last run on the two-pass path (synchronously).
   void finish_sync() { HIP_CHECK(hipStreamSynchronize(stream()));
-    if (direct && host_counters()->pad[0]) { direct = false; offsets_direct = false; const Fe32 *sc = last_scalars;
+    if (sparse && host_counters()->pad[0]) { sparse = false; run_impl(last_scalars, last_index); HIP_CHECK(hipStreamSynchronize(stream())); sparse = true; }   // more digits than the list holds: the bucket path handles any input
+    if (direct && host_counters()->pad[0]) { direct = false; offsets_direct = false; const Fe32 *sc = last_scalars; const bool was_hsort = hsort; hsort = false;
+      if (was_hsort) { HIP_CHECK(hipMemsetAsync(zeroed.get(), 0, 2 * (size_t)WB * NB * sizeof(uint32_t), stream())); HIP_CHECK(hipMemsetAsync(group_fill.get(), 0, hs.groups * sizeof(uint32_t), stream())); }   // hist() held the bucket counts of the group sort; the two-pass path wants it cleared
       if (prod_b) { if (prod_tmp.size() < n) prod_tmp = DevBuf<Fe32>(n);   // materialise the product for the two-pass path
         hipLaunchKernelGGL(k_fr_mul3, dim3(cdiv(n, 256)), dim3(256), 0, stream(), (const Fr *)last_scalars, (const Fr *)prod_b, (const Fr *)prod_z, (int)prod_z_table, (uint32_t)n, (Fr *)prod_tmp.get()); sc = prod_tmp.get(); }
-      const Fe32 *pb = prod_b; prod_b = nullptr; run_impl(sc, last_index); HIP_CHECK(hipStreamSynchronize(stream())); prod_b = pb; direct = true; } }
+      const Fe32 *pb = prod_b; prod_b = nullptr; run_impl(sc, last_index); HIP_CHECK(hipStreamSynchronize(stream())); prod_b = pb; direct = true; hsort = was_hsort; } }
   // sum_i (a_i b_i z) P_i; only with the one-pass sort (is_direct()), where the product is formed inside the sort kernel
   void run_product(const Fe32 *a, const Fe32 *b, const Fe32 *z, bool z_is_table) { if (!direct) throw GpuError("msm: run_product needs the one-pass sort"); prod_b = b; prod_z = z; prod_z_table = z_is_table; run_impl(a, nullptr); }
   void run(const Fe32 *scalars, const uint32_t *scalar_index) { prod_b = nullptr; run_impl(scalars, scalar_index); }
@@ -92,7 +106,26 @@ struct MsmImpl {
       hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(g), dim3(256), 0, os, (const XYZZ<F> *)ones_partial.get(), GROUP, n_ones_quads, (XYZZ<F> *)ones_l2.get(), (uint4 *)nullptr, (uint4 *)nullptr);
       hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(256), 0, os, (const XYZZ<F> *)ones_l2.get(), g, g, res + WB, (uint4 *)nullptr, (uint4 *)nullptr); };
     last_scalars = scalars; last_index = scalar_index;
+    if (sparse) {
+      const uint32_t nq = 16384, nblk = nq / 64; uint4 *csrc = (uint4 *)cnt; uint4 *cdst = (uint4 *)(res + WB + 1);
+      { Stage st((label + ".sort").c_str(), s);
+#define ZK_CALL(CC) hipLaunchKernelGGL(k_wmsm_classify<CC>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, point_stride, ones.get(), (uint2 *)others.get(), others_cap, cnt, counters_next())
+        ZK_MSM_DISPATCH_C(c, false, ZK_CALL);
+#undef ZK_CALL
+      }
+      { Stage st((label + ".accumulate").c_str(), s); hipLaunchKernelGGL((k_wmsm_sum<F>), dim3(nblk), dim3(256), 0, s, (const Affine<F> *)points.get(), ones.get(), (const uint2 *)others.get(), others_cap, cnt, nq, (XYZZ<F> *)ones_partial.get()); }
+      { Stage st((label + ".reduce").c_str(), s); hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(256), 0, s, (const XYZZ<F> *)ones_partial.get(), nblk, nblk, res, csrc, cdst); }
+      HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s)); return;
+    }
+    const bool hs_run = direct && hsort && scalar_index == nullptr;
+    if (hs_run) { Stage st((label + ".sort").c_str(), s);
+#define ZK_CALL(CC) hipLaunchKernelGGL(k_hsort_bin<CC>, dim3(cdiv(n, HSORT_TILE)), dim3(HSORT_BIN_THREADS), 0, s, (const Fr *)scalars, (const Fr *)prod_b, (const Fr *)prod_z, (int)prod_z_table, infp, (uint32_t)n, c, W, point_stride, hs, group_fill.get(), mid.get(), cnt, counters_next())
+      ZK_MSM_DISPATCH_C(c, false, ZK_CALL);
+#undef ZK_CALL
+      hipLaunchKernelGGL(k_hsort_group, dim3(hs.groups), dim3(HSORT_GROUP_THREADS), 0, s, (const uint32_t *)mid.get(), group_fill.get(), hs, entries.get(), hist(), offsets.get());
+    } else
     if (direct) { Stage st((label + ".sort").c_str(), s);
+      if (hsort) throw GpuError("msm: the group-binned sort takes no scalar index");
       if (!offsets_direct) { std::vector<uint32_t> o(nbk); for (size_t b = 0; b < nbk; b++) o[b] = (uint32_t)(b * cap); offsets.upload(o.data(), nbk);
         for (size_t b = 0; b < nbk; b++) o[b] = (uint32_t)b; order.upload(o.data(), nbk); rank_of.upload(o.data(), nbk); offsets_direct = true; }   // identity ranking: uniform buckets need no size ordering
       hipLaunchKernelGGL(k_msm_scatter_direct<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, point_stride, cap, hist(), entries.get(), cnt, counters_next(), (const Fr *)prod_b, (const Fr *)prod_z, (int)prod_z_table, (int)glv);
@@ -105,7 +138,9 @@ struct MsmImpl {
       }
     } else
     { Stage st((label + ".sort").c_str(), s);
-      if (n) hipLaunchKernelGGL(k_msm_classify<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, (uint32_t)nbk, (int)glv, hist(), ones.get(), cnt, counters_next());
+#define ZK_CALL(CC) hipLaunchKernelGGL(k_msm_classify<CC>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, (uint32_t)nbk, (int)glv, hist(), ones.get(), cnt, counters_next())
+      if (n) ZK_MSM_DISPATCH_C(c, glv, ZK_CALL);
+#undef ZK_CALL
       if (filter_ones && n && split_ones) { HIP_CHECK(hipEventRecord(ev_classified, s)); HIP_CHECK(hipStreamWaitEvent(ones_stream, ev_classified, 0)); ones_path(ones_stream); HIP_CHECK(hipEventRecord(ev_ones, ones_stream)); ones_forked = true; }
       if (nbk <= PLAN_SMALL_MAX) {
         hipLaunchKernelGGL(k_msm_plan_small, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, offsets.get(), order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
@@ -116,8 +151,14 @@ struct MsmImpl {
         hipLaunchKernelGGL(k_bsort_scatter, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_off.get(), order.get(), rank_of.get(), ntasks.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
         task_scanner.run(ntasks.get(), task_off.get(), nbk + 1, s);
       }
-      if (n) hipLaunchKernelGGL(k_msm_scatter<0>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, point_stride, (uint32_t)nbk, (int)glv, offsets.get(), fill(), entries.get());
+#define ZK_CALL(CC) hipLaunchKernelGGL(k_msm_scatter<CC>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, point_stride, (uint32_t)nbk, (int)glv, offsets.get(), fill(), entries.get())
+      if (n) ZK_MSM_DISPATCH_C(c, glv, ZK_CALL);
+#undef ZK_CALL
     }
+    if (hs_run) {
+      { Stage st((label + ".accumulate").c_str(), s); hipLaunchKernelGGL((k_msm_accumulate_slices<F>), dim3(cdiv(nbk * HSORT_SLICES, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), (uint32_t)nbk, (XYZZ<F> *)partials.get()); }
+      { Stage st((label + ".combine").c_str(), s); hipLaunchKernelGGL((k_msm_combine_slices<F>), dim3(cdiv(nbk * 4, 256)), dim3(256), 0, s, (const XYZZ<F> *)partials.get(), (uint32_t)nbk, (XYZZ<F> *)buckets.get()); }
+    } else {
     { Stage st((label + ".accumulate").c_str(), s);
       hipLaunchKernelGGL((k_msm_accumulate_tasks<F>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), order.get(), task_off.get(), (uint32_t)nbk, max_tasks, direct ? task : MSM_TASK, glv ? (const F *)beta.get() : (const F *)nullptr,
                          (XYZZ<F> *)buckets.get(), (XYZZ<F> *)partials.get());
@@ -125,6 +166,7 @@ struct MsmImpl {
     { Stage st((label + ".combine").c_str(), s);
       const uint32_t heavy = direct && cap <= COMBINE_QUAD_MAX * task ? 0u : HEAVY_BLOCKS;   // one-pass sort: no bucket can hold more than `cap` entries, so none needs a whole workgroup
       hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(heavy + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), heavy, (const XYZZ<F> *)partials.get(), (XYZZ<F> *)buckets.get(), zeroed.get(), (uint32_t)(2 * nbk), (int)(direct && nbk <= PLAN_DIRECT_MAX && cap <= 4080));
+    }
     }
     { Stage st_red((label + ".reduce").c_str(), s);
       uint32_t spw = NB / seg, nseg = (uint32_t)WB * spw; uint4 *csrc = (uint4 *)cnt; uint4 *cdst = (uint4 *)(res + WB + 1);

@@ -5,8 +5,8 @@ tag=${1:-r01}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $root/gpurun_out/pmc_${tag}_$c -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $root/gpurun_out/pmc_${tag}_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $root/gpurun_out/pmc_${tag}_$c -- python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs > $root/gpurun_out/pmc_${tag}_$c.log 2>&1
 done
 cd $root
-python3 tools/pmc_summarize.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE > gpurun_out/pmc_${tag}_summary.json
+python3 tools/pmc_summarize.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE ${tag} > gpurun_out/pmc_${tag}_summary.json
 find gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE -name "*.csv" -size +2M -delete

@@ -17,12 +17,12 @@ def load(d, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 fetch = load(sys.argv[1], "FETCH_SIZE"); write = load(sys.argv[2], "WRITE_SIZE")
 def short(n): return n.replace("zk::", "").replace("Fp<FqParams>", "Fq").replace("Fp<FrParams>", "Fr").split("(")[0].replace("void ", "")
-out = {"units": "bytes per launch; hbm_bytes = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950 correction for FETCH_SIZE, MI355X_MICROARCH.md)", "kernels": {}}
+out = {"tag": sys.argv[3] if len(sys.argv) > 3 else "untagged", "units": "bytes per launch; hbm_bytes = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950 correction for FETCH_SIZE, MI355X_MICROARCH.md)", "kernels": {}}
 for k in sorted(set(fetch) | set(write), key=lambda k: (short(k[0]), k[1])):
     f = fetch.get(k, (0.0, 0)); w = write.get(k, (0.0, 0))
     out["kernels"]["%s grid=%d" % (short(k[0]), k[1])] = {"launches": max(f[1], w[1]), "FETCH_SIZE_KB_raw": round(f[0], 2), "WRITE_SIZE_KB": round(w[0], 2), "hbm_bytes_per_launch": int(2 * f[0] * 1024 + w[0] * 1024)}
 # the dominant kernel: bucket accumulation of the H-query MSM = the k_msm_accumulate_tasks<Fq> launch that moves the most bytes (4.2 M point gathers; the witness MSMs have a few 10^4)
-acc = [(k, v) for k, v in out["kernels"].items() if k.startswith("k_msm_accumulate_tasks<Fq") and not k.startswith("k_msm_accumulate_tasks<Fq2")]
+acc = [(k, v) for k, v in out["kernels"].items() if (k.startswith("k_msm_accumulate_tasks<Fq") or k.startswith("k_msm_accumulate_slices<Fq")) and "<Fq2" not in k]
 if acc:
     name, v = max(acc, key=lambda kv: kv[1]["hbm_bytes_per_launch"]); out["k_msm_accumulate_H"] = dict(v, kernel=name)
 pw = [(k, v) for k, v in out["kernels"].items() if k.startswith("k_qap_pointwise")]
