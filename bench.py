@@ -162,7 +162,7 @@ def run_rank(args):
             for t in ths: t.join()
             extra["through_genSendproof"]["concurrent_callers"] = args.inflight; extra["through_genSendproof"]["proofs_per_s_concurrent"] = round(nx * args.inflight / (time.perf_counter() - t0), 2)
             # K prover objects on their own stream sets, one host thread each, host-buffer witnesses
-            provers = [prover] + [e.Prover(pk_path) for _ in range(args.inflight - 1)]
+            provers = [prover] + [prover.clone() for _ in range(args.inflight - 1)]                                   # share the key's device tables
             for k, pv in enumerate(provers): pv.prove(zs[k % n_inst])
             per = max(4, args.steps)
             def worker(k):
@@ -174,7 +174,8 @@ def run_rank(args):
             for pv in provers[1:]: pv.close()
         # B witnesses against one resident key in one call (BASELINE.json configs[2]: a batch of independent send proofs)
         if args.batch > 1 and hasattr(prover, "prove_batch"):
-            B = args.batch; batch = [zs[i % n_inst] for i in range(B)]; proofs = prover.prove_batch(batch); reps = max(2, min(6, 128 // B)); t0 = time.perf_counter()
+            import numpy as np
+            B = args.batch; batch = np.ascontiguousarray(np.stack([zs[i % n_inst] for i in range(B)])); proofs = prover.prove_batch(batch); reps = max(2, min(6, 128 // B)); t0 = time.perf_counter()   # the B assignments back to back in one host buffer
             for _ in range(reps): proofs = prover.prove_batch(batch)
             dtb = time.perf_counter() - t0
             ok = all(e.verify(vk_path, proofs[k], w.pack_public([insts[k % n_inst][x] for x in ("cmtA_old", "sn_old", "cmtS", "cmtA")])) for k in (0, B - 1))

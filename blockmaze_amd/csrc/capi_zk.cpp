@@ -16,10 +16,13 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 #include "../../include/zk_deposit.h"
 #include "../../include/zk_mint.h"
 #include "../../include/zk_redeem.h"
 #include "../../include/zk_send.h"
+#include "../../include/zk_batch.h"
 #include "../../include/zkgpu.h"
 #include "blockmaze_circuits.hpp"
 #include "groth16.hpp"
@@ -44,7 +47,7 @@ typedef std::vector<std::shared_ptr<ProverUnit>> UnitList;
 // A reload (the key file's size or mtime changed) never touches the old list: it publishes a NEW one, and the old units die when the last proof running on them lets
 // go of its reference — a caller can therefore never see a destroyed unit or mutex, however the reload interleaves with proofs in flight.
 struct ProverSlot { FileStamp stamp; std::shared_ptr<const UnitList> units; std::atomic<unsigned> next{0}; };
-struct VkSlot { FileStamp stamp; std::shared_ptr<VerifyingKeyHost> vk; };
+struct VkSlot { FileStamp stamp; std::shared_ptr<PreparedVerifyingKey> vk; std::shared_ptr<BatchVerifier> gpu; };
 std::mutex g_cache_mutex; std::map<std::string, ProverSlot> g_provers; std::map<std::string, VkSlot> g_vks;
 
 std::unique_ptr<Circuit> make_circuit(CircuitKind k, bool emit) {
@@ -58,9 +61,9 @@ HeldUnit acquire_prover(CircuitKind k) {
   std::shared_ptr<const UnitList> units; unsigned turn = 0;
   { std::lock_guard<std::mutex> lk(g_gpu_mutex); ProverSlot &slot = g_provers[path];
     if (!slot.units || !(slot.stamp == st)) {
-      ProvingKeyHost pk = load_proving_key(path); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 2; if (n < 1) n = 1; if (n > 7) n = 7;
+      ProvingKeyHost pk = load_proving_key(path); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 4; if (n < 1) n = 1; if (n > 7) n = 7;
       auto fresh = std::make_shared<UnitList>();
-      for (int i = 0; i < n; i++) { auto u = std::make_shared<ProverUnit>(); u->prover.reset(new Prover(pk)); u->circuit = make_circuit(k, false);
+      for (int i = 0; i < n; i++) { auto u = std::make_shared<ProverUnit>(); if (i == 0) u->prover.reset(new Prover(pk)); else u->prover.reset(new Prover(*fresh->front()->prover)); u->circuit = make_circuit(k, false);   // members beyond the first share its device tables
         if (u->circuit->board.num_variables() != u->prover->num_variables() || u->circuit->num_inputs() != u->prover->num_inputs()) throw std::runtime_error("proving key does not belong to the " + std::string(circuit_name(k)) + " circuit: " + path);
         fresh->push_back(std::move(u)); }
       slot.units = std::move(fresh); slot.stamp = st; }
@@ -68,11 +71,18 @@ HeldUnit acquire_prover(CircuitKind k) {
   for (const auto &u : *units) { std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) return HeldUnit{u, std::move(lk)}; }
   const std::shared_ptr<ProverUnit> &u = (*units)[turn % units->size()]; return HeldUnit{u, std::unique_lock<std::mutex>(u->busy)};
 }
-std::shared_ptr<VerifyingKeyHost> vk_for(CircuitKind k) {
-  std::string path = key_path(k, false); FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("verification key not found: " + path);
+std::shared_ptr<PreparedVerifyingKey> vk_for_path(const std::string &path) {
+  FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("verification key not found: " + path);
   std::lock_guard<std::mutex> lk(g_cache_mutex); VkSlot &slot = g_vks[path];
-  if (!slot.vk || !(slot.stamp == st)) { slot.vk.reset(new VerifyingKeyHost(load_verifying_key(path))); slot.stamp = st; }
+  if (!slot.vk || !(slot.stamp == st)) { slot.vk = prepare_verifying_key(load_verifying_key(path)); slot.gpu.reset(); slot.stamp = st; }
   return slot.vk;
+}
+std::shared_ptr<PreparedVerifyingKey> vk_for(CircuitKind k) { return vk_for_path(key_path(k, false)); }
+// the key's batched GPU verifier (kernel K9), built on first use; the caller holds g_gpu_mutex
+std::shared_ptr<BatchVerifier> gpu_verifier_for_path(const std::string &path) {
+  std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(path); std::lock_guard<std::mutex> lk(g_cache_mutex); VkSlot &slot = g_vks[path];
+  if (!slot.gpu) slot.gpu = std::shared_ptr<BatchVerifier>(make_batch_verifier(vk->vk).release());
+  return slot.gpu;
 }
 #ifdef ZKGPU_TEST_HOOKS
 // test builds only (make TEST_HOOKS=1): ZK_FIXED_RS="<r hex>:<s hex>" makes proofs reproducible.  The release library does not contain this code: an environment
@@ -110,6 +120,15 @@ bool verify(CircuitKind k, const char *data, const std::vector<bool> &public_bit
   printf("Verifying %s proof %s!!!\n", circuit_name(k), ok ? "successfully" : "unsuccessfully"); fflush(stdout); return ok;
 }
 void append(std::vector<bool> &v, const std::vector<bool> &w) { v.insert(v.end(), w.begin(), w.end()); }
+// the statement of a proof as the verifier packs it (X_gadget::witness_map): args in the order of the kind's verifyXproof symbol
+std::vector<bool> public_bits(CircuitKind k, const char *const *a, uint64_t value_s) {
+  std::vector<bool> bits; auto h256 = [&](const char *s) { append(bits, blob_bits(blob256_from_hex(s ? s : "").b, 32)); };
+  switch (k) {
+    case CircuitKind::Mint: case CircuitKind::Redeem: h256(a[0]); h256(a[1]); h256(a[2]); append(bits, u64_bits(value_s)); break;                        // cmtA_old, sn_old, cmtA, value_s (mint/circuit/gadget.tcc:252-269)
+    case CircuitKind::Send: h256(a[0]); h256(a[1]); h256(a[2]); h256(a[3]); break;                                                                       // cmtA_old, sn_old, cmtS, cmtA_new (send/circuit/gadget.tcc:274-291)
+    default: h256(a[0]); append(bits, blob_bits(blob160_from_hex(a[1] ? a[1] : "").b, 20)); h256(a[2]); h256(a[3]); h256(a[4]); h256(a[5]); break;      // RT, pk, cmtb_old, sn_old, cmtb, sns (deposit/circuit/gadget.tcc:301-323)
+  }
+  return bits; }
 }  // namespace
 
 template <class Fn> static int guarded(Fn fn) {
@@ -117,7 +136,7 @@ template <class Fn> static int guarded(Fn fn) {
   catch (const std::exception &e) { zkgpu_set_error(e.what()); return ZKGPU_ERR_RUNTIME; } catch (...) { zkgpu_set_error("unknown error"); return ZKGPU_ERR_RUNTIME; } }
 template <class Fn> static int guarded_host(Fn fn) { try { return fn(); } catch (const std::exception &e) { zkgpu_set_error(e.what()); return ZKGPU_ERR_RUNTIME; } catch (...) { zkgpu_set_error("unknown error"); return ZKGPU_ERR_RUNTIME; } }
 
-struct zkgpu_prover { std::shared_ptr<Prover> p; std::mutex m; };   // proofs on different prover objects may run concurrently (each has its own streams); one object is used by one thread at a time
+struct zkgpu_prover { std::shared_ptr<Prover> p; std::mutex m; std::vector<std::shared_ptr<Prover>> lanes; };   // lanes: the extra prover objects of prove_batch (share p's tables), created on first use   // proofs on different prover objects may run concurrently (each has its own streams); one object is used by one thread at a time
 template <class Fn> static int guarded_prover(zkgpu_prover *h, Fn fn) {
   try { if (!gpu_available()) { zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback"); return ZKGPU_ERR_NO_DEVICE; } if (!h) return ZKGPU_ERR_ARG; std::lock_guard<std::mutex> lk(h->m); return fn(); }
   catch (const std::exception &e) { zkgpu_set_error(e.what()); return ZKGPU_ERR_RUNTIME; } catch (...) { zkgpu_set_error("unknown error"); return ZKGPU_ERR_RUNTIME; } }
@@ -135,14 +154,12 @@ char *zkgpu_abi_genMintproof(uint64_t value, uint64_t value_old, char *sn_old, c
   MintInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn), blob256_from_hex(r), blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
   return generate(CircuitKind::Mint, [&](Circuit &c) { assign_mint(c, in); }); }
 bool zkgpu_abi_verifyMintproof(char *data, char *cmtA_old, char *sn_old, char *cmtA, uint64_t value_s) {   // mint_gadget::witness_map (mint/circuit/gadget.tcc:252-269)
-  std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(cmtA_old).b, 32)); append(bits, blob_bits(blob256_from_hex(sn_old).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtA).b, 32)); append(bits, u64_bits(value_s));
-  return verify(CircuitKind::Mint, data, bits); }
+  const char *a[3] = {cmtA_old, sn_old, cmtA}; return verify(CircuitKind::Mint, data, public_bits(CircuitKind::Mint, a, value_s)); }
 char *zkgpu_abi_genRedeemproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk) {
   RedeemInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn), blob256_from_hex(r), blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
   return generate(CircuitKind::Redeem, [&](Circuit &c) { assign_redeem(c, in); }); }
 bool zkgpu_abi_verifyRedeemproof(char *data, char *cmtA_old, char *sn_old, char *cmtA, uint64_t value_s) {
-  std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(cmtA_old).b, 32)); append(bits, blob_bits(blob256_from_hex(sn_old).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtA).b, 32)); append(bits, u64_bits(value_s));
-  return verify(CircuitKind::Redeem, data, bits); }
+  const char *a[3] = {cmtA_old, sn_old, cmtA}; return verify(CircuitKind::Redeem, data, public_bits(CircuitKind::Redeem, a, value_s)); }
 
 static SendInputs send_inputs(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender) {
   SendInputs in;   // sendcgo.cpp:317-333: note_old = (value_A, sn, r), notes = (value_s, pk_recv, r_s, sn), note_new = (value_A_new, sn_A_new, r_A_new)
@@ -152,8 +169,7 @@ char *zkgpu_abi_genSendproof(uint64_t value_A, char *r_s, char *sn, char *r, cha
   SendInputs in = send_inputs(value_A, r_s, sn, r, cmt_s, cmtA, value_s, pk_recv, value_A_new, sn_A_new, r_A_new, cmt_A_new, sk, pk_sender);
   return generate(CircuitKind::Send, [&](Circuit &c) { assign_send(c, in); }); }
 bool zkgpu_abi_verifySendproof(char *data, char *cmtA_old, char *sn_old, char *cmtS, char *cmtA_new) {   // send_gadget::witness_map (send/circuit/gadget.tcc:274-291)
-  std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(cmtA_old).b, 32)); append(bits, blob_bits(blob256_from_hex(sn_old).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtS).b, 32)); append(bits, blob_bits(blob256_from_hex(cmtA_new).b, 32));
-  return verify(CircuitKind::Send, data, bits); }
+  const char *a[4] = {cmtA_old, sn_old, cmtS, cmtA_new}; return verify(CircuitKind::Send, data, public_bits(CircuitKind::Send, a, 0)); }
 
 // depositcgo.cpp:327-444: the Merkle path of cmtS is rebuilt from cmtarray (the tree holds the leaves up to and including the first occurrence of cmtS plus
 // everything appended afterwards, i.e. all n leaves); RT is ignored and the root recomputed
@@ -167,8 +183,7 @@ static DepositInputs deposit_inputs(uint64_t value, uint64_t value_old, char *sn
 char *zkgpu_abi_genDepositproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old, char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *RT, char *sk) {
   (void)RT; return generate(CircuitKind::Deposit, [&](Circuit &c) { assign_deposit(c, deposit_inputs(value, value_old, sn_old, r_old, sn, r, sns, rs, cmtB_old, cmtB, value_s, pk, sn_A_old, cmtS, cmtarray, n, sk, 8)); }); }
 bool zkgpu_abi_verifyDepositproof(char *data, char *RT, char *pk, char *cmtb_old, char *snold, char *cmtb, char *sns) {   // deposit_gadget::witness_map (deposit/circuit/gadget.tcc:301-323)
-  std::vector<bool> bits; append(bits, blob_bits(blob256_from_hex(RT).b, 32)); append(bits, blob_bits(blob160_from_hex(pk).b, 20)); append(bits, blob_bits(blob256_from_hex(cmtb_old).b, 32)); append(bits, blob_bits(blob256_from_hex(snold).b, 32));
-  append(bits, blob_bits(blob256_from_hex(cmtb).b, 32)); append(bits, blob_bits(blob256_from_hex(sns).b, 32)); return verify(CircuitKind::Deposit, data, bits); }
+  const char *a[6] = {RT, pk, cmtb_old, snold, cmtb, sns}; return verify(CircuitKind::Deposit, data, public_bits(CircuitKind::Deposit, a, 0)); }
 
 // ---- engine-level entry points for keys, circuits and the resident prover (include/zkgpu.h) ---------------------------
 static void write_r1cs_file(const char *path, const R1csHost &cs) { FILE *f = fopen(path, "wb"); if (!f) throw std::runtime_error(std::string("cannot write ") + path);
@@ -213,6 +228,22 @@ zkgpu_prover *zkgpu_prover_load(const char *pk_path) { return zkgpu_prover_load_
 int zkgpu_prover_prove_partial(zkgpu_prover *h, uint8_t out[384]) { return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; if (!h->p->prove_partial(out)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } return ZKGPU_OK; }); }
 int zkgpu_prover_finish(zkgpu_prover *h, const uint8_t *records, size_t n, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_host([&] { if (!h) return ZKGPU_ERR_ARG; Proof p; h->p->finish_from_partials(records, n, (const Fe32 *)r, (const Fe32 *)s, p);
   std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
+zkgpu_prover *zkgpu_prover_clone(zkgpu_prover *h) { zkgpu_prover *out = nullptr; guarded([&] { if (!h) return ZKGPU_ERR_ARG; std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(*h->p)); out = p.release(); return ZKGPU_OK; }); return out; }
+int zkgpu_prover_prove_batch(zkgpu_prover *h, const uint8_t *zs, size_t n, const uint8_t *rs, char *proofs_hex) { return guarded_prover(h, [&] {
+  if (!h || (n && (!zs || !proofs_hex))) return ZKGPU_ERR_ARG; if (!n) return ZKGPU_OK;
+  static const size_t want = [] { const char *e = getenv("ZK_BATCH_LANES"); long v = e ? atol(e) : 4; return (size_t)(v < 1 ? 1 : v > 7 ? 7 : v); }();
+  const size_t K = std::min(want, n); { std::lock_guard<std::mutex> lk(g_gpu_mutex); while (h->lanes.size() + 1 < K) h->lanes.push_back(std::make_shared<Prover>(*h->p)); }
+  const size_t zbytes = 32 * h->p->num_variables(); std::vector<uint8_t> bad(n, 0); std::vector<std::string> errs(K); std::vector<std::thread> th;
+  auto work = [&](size_t lane) { Prover &pv = lane ? *h->lanes[lane - 1] : *h->p;
+    try { for (size_t i = lane; i < n; i += K) { Proof pr; const Fe32 *r = rs ? (const Fe32 *)(rs + 64 * i) : nullptr, *s_ = rs ? (const Fe32 *)(rs + 64 * i + 32) : nullptr;
+        if (!pv.prove((const Fe32 *)(zs + zbytes * i), r, s_, pr)) { bad[i] = 1; pr = default_proof(); } std::string hx = proof_to_hex(pr); memcpy(proofs_hex + 513 * i, hx.c_str(), 513); } }
+    catch (const std::exception &e) { errs[lane] = e.what(); } catch (...) { errs[lane] = "unknown error"; } };
+  for (size_t lane = 1; lane < K; lane++) th.emplace_back(work, lane);
+  work(0); for (auto &t : th) t.join();
+  for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
+  std::string which; for (size_t i = 0; i < n; i++) if (bad[i]) which += (which.empty() ? "" : ", ") + std::to_string(i);
+  if (!which.empty()) { zkgpu_set_error("assignment does not satisfy the constraint system: batch record(s) " + which); return ZKGPU_ERR_UNSATISFIED; }
+  return ZKGPU_OK; }); }
 void zkgpu_prover_destroy(zkgpu_prover *h) { guarded([&] { delete h; return ZKGPU_OK; }); }
 int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]) { if (!h) return ZKGPU_ERR_ARG; out[0] = h->p->num_variables(); out[1] = h->p->num_inputs(); out[2] = h->p->domain_size(); return ZKGPU_OK; }
 int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; Proof p;
@@ -223,19 +254,42 @@ int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t
 int zkgpu_prover_timings(zkgpu_prover *h, double out[5]) { if (!h) return ZKGPU_ERR_ARG; out[0] = h->p->last.upload_ms; out[1] = h->p->last.qap_ms; out[2] = h->p->last.msm_ms; out[3] = h->p->last.finish_ms; out[4] = h->p->last.total_ms; return ZKGPU_OK; }
 int zkgpu_profile_enable(int on) { return guarded([&] { profile_enable(on != 0); return ZKGPU_OK; }); }
 int zkgpu_profile_report(char *buf, size_t cap) { return guarded([&] { std::string r = profile_report(); if (r.size() + 1 > cap) return ZKGPU_ERR_ARG; memcpy(buf, r.c_str(), r.size() + 1); return ZKGPU_OK; }); }
-int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs) { int res = 0; int rc = guarded_host([&] { VerifyingKeyHost vk = load_verifying_key(vk_path); Proof p;
-  if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK; } res = verify_proof(vk, (const Fe32 *)inputs, n_inputs, p) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
+int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs) { int res = 0; int rc = guarded_host([&] { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(vk_path); Proof p;   // host verifier on the prepared key (cached by the file's size and mtime)
+  if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK; } res = verify_proof(*vk, (const Fe32 *)inputs, n_inputs, p) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
 // batched verification on the GPU (kernel K9).  proofs_hex: n * 512 characters; inputs: n * n_inputs canonical field elements; ok[i] = 1 accept / 0 reject
 // (a record that is not 512 hex digits of values below q is rejected without reaching the device, like proof_from_hex in zkgpu_verify)
 int zkgpu_verify_batch(const char *vk_path, const char *proofs_hex, const uint8_t *inputs, size_t n_inputs, size_t n, uint8_t *ok) { return guarded([&] {
   if (!vk_path || (!proofs_hex && n) || !ok) return ZKGPU_ERR_ARG;
-  struct Slot { FileStamp stamp; std::unique_ptr<BatchVerifier> v; }; static std::map<std::string, Slot> cache;        // caller holds the device mutex (guarded)
-  FileStamp st; if (!stamp_of(vk_path, st)) throw std::runtime_error(std::string("verification key not found: ") + vk_path);
-  Slot &slot = cache[vk_path]; if (!slot.v || !(slot.stamp == st)) { VerifyingKeyHost vk = load_verifying_key(vk_path); slot.v = make_batch_verifier(vk); slot.stamp = st; }
+  struct { std::shared_ptr<BatchVerifier> v; } slot{gpu_verifier_for_path(vk_path)};                                  // caller holds the device mutex (guarded)
   if (slot.v->num_inputs() != n_inputs) { for (size_t i = 0; i < n; i++) ok[i] = 0; return ZKGPU_OK; }                // strong IC: wrong input count rejects (r1cs_gg_ppzksnark.tcc:584-590)
   std::vector<Proof> ps(n); std::vector<uint8_t> parsed(n);
   for (size_t i = 0; i < n; i++) { parsed[i] = strnlen(proofs_hex + 512 * i, 512) == 512 && proof_from_hex(proofs_hex + 512 * i, ps[i]); if (!parsed[i]) memset(&ps[i], 0, sizeof(Proof)); }
   slot.v->verify(ps.data(), (const Fe32 *)inputs, n, ok); for (size_t i = 0; i < n; i++) if (!parsed[i]) ok[i] = 0; return ZKGPU_OK; }); }
+// ---- verifyBatch: the optional batch entry of include/zk_batch.h ---------------------------------------------------
+// go-ethereum checks every ZK transaction twice, once in the pool and once in the block (core/tx_pool.go:612-645, core/state_processor.go:106-163), one cgo call
+// and one key load per proof.  A block's worth of proofs in ONE call is what the GPU verifier (kernel K9, one lane per proof) is for: from ZK_VERIFY_GPU_MIN
+// proofs of a kind on (default 24: the break-even against the prepared host verifier) the kind's records go to the device in one launch, smaller groups are checked
+// on the host.  Decisions are exactly those of the kind's verifyXproof symbol.
+int verifyBatch(const zk_verify_item *items, int n, unsigned char *ok) {
+  if (n < 0 || (n && (!items || !ok))) return -1;
+  try {
+    static const size_t gpu_min = [] { const char *e = getenv("ZK_VERIFY_GPU_MIN"); long v = e ? atol(e) : 24; return (size_t)(v < 1 ? 1 : v); }();
+    int accepted = 0; std::vector<int> idx[4];
+    for (int i = 0; i < n; i++) { ok[i] = 0; if (items[i].kind >= 0 && items[i].kind <= 3) idx[items[i].kind].push_back(i); }
+    for (int k = 0; k < 4; k++) { if (idx[k].empty()) continue; const CircuitKind kind = (CircuitKind)k; const size_t m = idx[k].size();
+      std::vector<Proof> ps(m); std::vector<uint8_t> parsed(m), res(m, 0); std::vector<Fe32> inputs; size_t ni = 0;
+      for (size_t j = 0; j < m; j++) { const zk_verify_item &it = items[idx[k][j]]; parsed[j] = it.proof && strnlen(it.proof, 512) == 512 && proof_from_hex(it.proof, ps[j]); if (!parsed[j]) memset(&ps[j], 0, sizeof(Proof));
+        std::vector<Fe32> in = pack_public_bits(public_bits(kind, it.args, it.value_s)); ni = in.size(); inputs.insert(inputs.end(), in.begin(), in.end()); }
+      const std::string path = key_path(kind, false);
+      if (m >= gpu_min && gpu_available()) { std::lock_guard<std::mutex> lk(g_gpu_mutex); std::shared_ptr<BatchVerifier> v = gpu_verifier_for_path(path);
+        if (v->num_inputs() == ni) v->verify(ps.data(), inputs.data(), m, res.data()); }
+      else { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(path); for (size_t j = 0; j < m; j++) res[j] = parsed[j] && verify_proof(*vk, inputs.data() + j * ni, ni, ps[j]); }
+      for (size_t j = 0; j < m; j++) { ok[idx[k][j]] = parsed[j] && res[j]; accepted += ok[idx[k][j]]; } }
+    return accepted;
+  } catch (const std::exception &e) { zkgpu_set_error(e.what()); fprintf(stderr, "libzkgpu: verifyBatch: %s\n", e.what()); for (int i = 0; i < n; i++) ok[i] = 0; return -1; }
+  catch (...) { for (int i = 0; i < n; i++) ok[i] = 0; return -1; }
+}
+
 // the reference's symbol names, exported by libzkgpu.so itself (the four libzk_*.so forward to the zkgpu_abi_* names above)
 char *genCMT(uint64_t v, char *a, char *b) { return zkgpu_abi_genCMT(v, a, b); }
 char *genCMTS(uint64_t v, char *a, char *b, char *c) { return zkgpu_abi_genCMTS(v, a, b, c); }

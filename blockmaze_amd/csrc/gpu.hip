@@ -22,7 +22,7 @@ namespace zk {
 
 // Lanes: independent sets of streams (one main + four auxiliary) so that several provers can have a proof in flight at the same time; a thread works on the lane it
 // selected with LaneScope (lane 0 unless told otherwise).  Contexts are created on first use and live for the life of the process.
-constexpr int MAX_LANES = 8;
+constexpr int MAX_LANES = 32;   // lanes beyond the hardware queues share queues; provers sharing a lane share its streams (still correct, merely serialised)
 static std::atomic<GpuContext *> g_lanes[MAX_LANES]; static std::mutex g_lane_mutex; static thread_local int t_lane = 0; static std::atomic<unsigned> g_next_lane{0};
 GpuContext &gpu() {
   GpuContext *c = g_lanes[t_lane].load(std::memory_order_acquire);
@@ -147,17 +147,23 @@ __global__ void k_step_inv_post(Fr *a_all, const Fr *__restrict__ wpow, const Fr
   u1 = u1 * winvpow[i]; Fr u0 = a[i]; a[i] = (u0 + u1) * half; a[B + i] = (u0 - u1) * half;
 }
 
-struct Domain::Impl {
+struct DomainTables {                                            // immutable per key: shared by every Domain object copied from the first
   size_t m = 0; bool step = false; size_t B = 0, S = 0;           // step: m = B + S
   std::unique_ptr<Radix2Tables> big, small;                       // basic: only `big` (size m)
-  DevBuf<Fe32> inv_n_big, inv_n_small;                            // constant tables 1/n folded into pre-scales where possible
-  DevBuf<Fe32> coset_fwd, coset_inv, zinv, wpow, winvpow, scratch;
-  DevBuf<Fe32> scale_big, scale_small;                            // 1/B, 1/S as m-long constant tables are avoided: k_fr_mul_table with per-element tables below
+  DevBuf<Fe32> coset_fwd, coset_inv, zinv, wpow, winvpow;
+  DevBuf<Fe32> scale_big, scale_small;                            // 1/n folded into the loads of the inverse transforms
   HFr half;
-  size_t scratch_stride = 0;
 };
+struct Domain::Impl {
+  std::shared_ptr<DomainTables> t; DomainTables &d_;              // (d_ keeps the code below unchanged: every table is reached through it)
+  size_t &m; bool &step; size_t &B, &S; std::unique_ptr<Radix2Tables> &big, &small; DevBuf<Fe32> &coset_fwd, &coset_inv, &zinv, &wpow, &winvpow, &scale_big, &scale_small; HFr &half;
+  DevBuf<Fe32> scratch; size_t scratch_stride = 0;                // per object
+  explicit Impl(std::shared_ptr<DomainTables> tt) : t(tt), d_(*t), m(d_.m), step(d_.step), B(d_.B), S(d_.S), big(d_.big), small(d_.small), coset_fwd(d_.coset_fwd), coset_inv(d_.coset_inv), zinv(d_.zinv), wpow(d_.wpow), winvpow(d_.winvpow),
+                                                        scale_big(d_.scale_big), scale_small(d_.scale_small), half(d_.half) {}
+};
+Domain::Domain(const Domain &peer) : impl(new Impl(peer.impl->t)) { Impl &d = *impl; d.scratch_stride = d.m; d.scratch = DevBuf<Fe32>(d.step ? 6 * d.B : 3 * d.m); }
 
-Domain::Domain(size_t min_size) : impl(new Impl) {
+Domain::Domain(size_t min_size) : impl(new Impl(std::make_shared<DomainTables>())) {
   Impl &d = *impl; if (min_size <= 1) throw GpuError("domain: size");
   size_t lg = ceil_log2(min_size);
   if (min_size == ((size_t)1 << lg)) { d.m = min_size; }
@@ -305,12 +311,16 @@ void fr_from_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_from_m
 // ======================================================================================================================
 // R1CS rows
 // ======================================================================================================================
+struct R1csArrays { size_t n_inputs, n_vars, n_cons; DevBuf<uint32_t> rowptr[3], col[3], cid[3], long_rows[3]; size_t n_long[3] = {0, 0, 0}; DevBuf<Fe32> ctab; DevBuf<uint32_t> long_any; size_t n_long_any = 0; };   // immutable per key
 struct R1csDev::Impl {
-  size_t n_inputs, n_vars, n_cons; DevBuf<uint32_t> rowptr[3], col[3], cid[3], long_rows[3]; size_t n_long[3] = {0, 0, 0}; DevBuf<Fe32> ctab; DevBuf<uint32_t> flag; uint32_t *h_flag = nullptr;
-  DevBuf<uint32_t> long_any; size_t n_long_any = 0; uint32_t *h_fail = nullptr, *d_fail = nullptr, seq = 0;   // h_fail: mapped host word the prover's row kernels store the evaluation number to when a constraint is violated
+  std::shared_ptr<R1csArrays> a; size_t &n_inputs, &n_vars, &n_cons; DevBuf<uint32_t> (&rowptr)[3], (&col)[3], (&cid)[3], (&long_rows)[3]; size_t (&n_long)[3]; DevBuf<Fe32> &ctab; DevBuf<uint32_t> &long_any; size_t &n_long_any;
+  DevBuf<uint32_t> flag; uint32_t *h_flag = nullptr; uint32_t *h_fail = nullptr, *d_fail = nullptr, seq = 0;   // per object.  h_fail: mapped host word the prover's row kernels store the evaluation number to when a constraint is violated
+  explicit Impl(std::shared_ptr<R1csArrays> aa) : a(aa), n_inputs(a->n_inputs), n_vars(a->n_vars), n_cons(a->n_cons), rowptr(a->rowptr), col(a->col), cid(a->cid), long_rows(a->long_rows), n_long(a->n_long), ctab(a->ctab), long_any(a->long_any), n_long_any(a->n_long_any) {}
+  void own_words() { flag = DevBuf<uint32_t>(1); HIP_CHECK(hipHostMalloc((void **)&h_flag, 4)); HIP_CHECK(hipHostMalloc((void **)&h_fail, 4, hipHostMallocMapped)); *h_fail = 0; HIP_CHECK(hipHostGetDevicePointer((void **)&d_fail, h_fail, 0)); }
   ~Impl() { if (h_flag) hipHostFree(h_flag); if (h_fail) hipHostFree(h_fail); }
 };
-R1csDev::R1csDev(const R1csHost &h) : impl(new Impl) {
+R1csDev::R1csDev(const R1csDev &peer) : impl(new Impl(peer.impl->a)) { impl->own_words(); }
+R1csDev::R1csDev(const R1csHost &h) : impl(new Impl(std::make_shared<R1csArrays>())) {
   Impl &d = *impl; d.n_inputs = h.n_inputs; d.n_vars = h.n_vars; d.n_cons = h.n_cons;
   // coefficient table: slot 0 = +1, slot 1 = -1 (handled without a multiply), the rest in order of first appearance
   std::vector<Fe32> tab(2); { HFr one = HFr::one(), m1 = one.neg(); memcpy(&tab[0], one.l, 32); memcpy(&tab[1], m1.l, 32); }
@@ -336,8 +346,7 @@ R1csDev::R1csDev(const R1csHost &h) : impl(new Impl) {
   }
   { std::vector<uint32_t> lr; for (size_t i = 0; i < h.n_cons; i++) { bool lg = false; for (int m = 0; m < 3; m++) lg |= h.rowptr[m][i + 1] - h.rowptr[m][i] > R1CS_LONG_ROW; if (lg) lr.push_back((uint32_t)i); }
     d.n_long_any = lr.size(); d.long_any = DevBuf<uint32_t>(lr.size() + 1); if (!lr.empty()) d.long_any.upload(lr.data(), lr.size()); }
-  d.ctab = DevBuf<Fe32>(tab.size()); d.ctab.upload(tab.data(), tab.size()); d.flag = DevBuf<uint32_t>(1); HIP_CHECK(hipHostMalloc((void **)&d.h_flag, 4));
-  HIP_CHECK(hipHostMalloc((void **)&d.h_fail, 4, hipHostMallocMapped)); *d.h_fail = 0; HIP_CHECK(hipHostGetDevicePointer((void **)&d.d_fail, d.h_fail, 0));
+  d.ctab = DevBuf<Fe32>(tab.size()); d.ctab.upload(tab.data(), tab.size()); d.own_words();
 }
 R1csDev::~R1csDev() = default;
 void R1csDev::eval(const Fe32 *z, Fe32 *abc, size_t m) {

@@ -50,6 +50,7 @@ void upload_async(void *dev, const void *pinned_host, size_t bytes);   // on the
 class MsmG1 {
  public:
   MsmG1(const G1AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false, bool glv = false);   // glv: halve the scalars with the curve's endomorphism (needs tables + uniform); tables: precompute 2^(cw) P if the size cap allows; uniform: one-pass sort with overflow fallback (msm_impl.hpp)
+  MsmG1(const MsmG1 &peer, bool filter_ones, bool uniform_scalars);   // shares the peer's resident points / fixed-base table (immutable); owns only its workspace
   ~MsmG1();
   // scalars_dev: Fr (Montgomery) on the device.  scalar_index_dev: optional gather map (point i uses scalars[index[i]]).
   // Enqueues the kernels; result() synchronises and finishes the combine on the host.
@@ -63,6 +64,7 @@ class MsmG1 {
 class MsmG2 {
  public:
   MsmG2(const G2AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false, bool glv = false);   // (glv is ignored for G2)
+  MsmG2(const MsmG2 &peer, bool filter_ones, bool uniform_scalars);
   ~MsmG2();
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
   host::HG2 result(); void set_label(const char *l); void set_stream(int aux); void split_ones_path();
@@ -85,7 +87,7 @@ class BatchVerifier {
 struct R1csHost;
 class Domain {
  public:
-  explicit Domain(size_t min_size); ~Domain();
+  explicit Domain(size_t min_size); explicit Domain(const Domain &peer); ~Domain();   // the copy shares the twiddle / coset tables and owns its scratch space
   size_t m() const; bool is_step() const;
   // in place on `batch` device vectors of m elements each, `stride` elements apart (Montgomery form)
   void fft(Fe32 *data, int batch, size_t stride); void ifft(Fe32 *data, int batch, size_t stride);
@@ -107,7 +109,7 @@ struct R1csHost {                               // as parsed from a key file or 
 };
 class R1csDev {
  public:
-  explicit R1csDev(const R1csHost &h); ~R1csDev();
+  explicit R1csDev(const R1csHost &h); explicit R1csDev(const R1csDev &peer); ~R1csDev();   // the copy shares the CSR arrays and owns its failure word
   // z_dev: n_vars+1 Fr (Montgomery, z[0] = 1).  abc: 3 vectors of m (zero padded, aA[n_cons + i] = z_i for i <= n_inputs; r1cs_to_qap.tcc:227-230)
   void eval(const Fe32 *z_dev, Fe32 *abc, size_t m);
   bool satisfied(const Fe32 *abc, size_t m);    // synchronises

@@ -3,6 +3,7 @@
 namespace zk {
 struct MsmG1::Impl : MsmImpl<Fq, G1AffineRaw> { using MsmImpl::MsmImpl; };
 MsmG1::MsmG1(const G1AffineRaw *p, size_t n, int c, bool fo, bool tables, bool uniform, bool glv) : impl(new Impl(p, n, c, fo, tables, uniform, glv)) {}
+MsmG1::MsmG1(const MsmG1 &peer, bool fo, bool uniform) : impl(new Impl(peer.impl->bases, fo, uniform)) {}
 MsmG1::~MsmG1() = default;
 void MsmG1::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
 bool MsmG1::one_pass_sort() const { return impl->direct; }

@@ -214,12 +214,19 @@ struct Prover::Impl {
   int lane = 0;                                                // this prover's stream set: provers on different lanes overlap on the device
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
-  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; DevBuf<uint32_t> B_idx; DevBuf<Fe32> z, abc; DevBuf<uint8_t> packed; PinnedBuf<Fe32> z_host;
+  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; std::shared_ptr<DevBuf<uint32_t>> B_idx; DevBuf<Fe32> z, abc; DevBuf<uint8_t> packed; PinnedBuf<Fe32> z_host;
   std::unique_ptr<SubmitWorker> workers[4];
   ~Impl() { for (auto &w : workers) w.reset(); }
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &e) { size_t base = n / world, rem = n % world; b = rank * base + (rank < rem ? rank : rem); e = b + base + (rank < rem ? 1 : 0); }
+// streams, labels and the per-object vectors (everything that is not shared between the provers of one key)
+static void finish_setup(Prover::Impl &p) {
+  const bool one_stream = env_int("ZK_MSM_ONE_STREAM", 0) != 0;   // diagnostic: everything on the main stream, so that a kernel trace shows every kernel's stand-alone duration
+  if (!one_stream) { p.A->set_stream(0); p.L->set_stream(1); p.B1->set_stream(2); p.B2->set_stream(3); if (env_int("ZK_MSM_SPLIT_ONES", 1)) p.B2->split_ones_path(); }   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
+  p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
+  p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host = PinnedBuf<Fe32>(p.nv + 1 + 8); p.packed = DevBuf<uint8_t>(32 * (p.nv + 1 + 8));
+}
 Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) : impl(new Impl) {
   Impl &p = *impl; p.lane = gpu_lane_acquire(); LaneScope lane_scope(p.lane); p.nv = pk.cs.n_vars; p.ni = pk.cs.n_inputs; if (shard_world == 0 || shard_rank >= shard_world) throw std::runtime_error("prover: bad shard"); p.cs.reset(new R1csDev(pk.cs)); p.dom.reset(new Domain(pk.cs.n_cons + p.ni + 1)); p.m = p.dom->m();
   if (pk.A.size() != p.nv + 1 || pk.H.size() != p.m - 1 || pk.L.size() != p.nv - p.ni) throw std::runtime_error("proving key: query sizes do not match the constraint system");
@@ -236,11 +243,16 @@ Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) 
   shard_range(Lq->size(), shard_rank, shard_world, p.l0, e); size_t nL = e - p.l0;
   p.A.reset(new MsmG1(pk.A.data() + p.a0, nA, cw, true)); p.L.reset(new MsmG1(Lq->data() + p.l0, nL, cw, true));
   p.B1.reset(new MsmG1(pk.B_g1.data() + p.b0, nB, cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data() + p.b0, nB, cw, true)); p.H.reset(new MsmG1(Hq->data() + p.h0, nH, ch, false, env_int("ZK_MSM_H_TABLES", 1) != 0, true, env_int("ZK_MSM_GLV", 0) != 0));   // GLV (msm.cuh) is implemented and tested but off: measured, the accumulation does not get faster on the 151 MB table (0.56 vs 0.53 ms) and the decomposition costs 0.1 ms in the sort   // (with tables the H accumulation gathers from a table 16x larger and slows from 0.40 to 0.51 ms, but the reduction drops from 0.53 to 0.23 ms: measured 3 % better per proof, 10 % better with four proofs in flight)
-  const bool one_stream = env_int("ZK_MSM_ONE_STREAM", 0) != 0;   // diagnostic: everything on the main stream, so that a kernel trace shows every kernel's stand-alone duration
-  if (!one_stream) { p.A->set_stream(0); p.L->set_stream(1); p.B1->set_stream(2); p.B2->set_stream(3); if (env_int("ZK_MSM_SPLIT_ONES", 1)) p.B2->split_ones_path(); }   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
-  p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
-  p.B_idx = DevBuf<uint32_t>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx.upload(pk.B_idx.data(), pk.B_idx.size());
-  p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host = PinnedBuf<Fe32>(p.nv + 1 + 8); p.packed = DevBuf<uint8_t>(32 * (p.nv + 1 + 8));
+  finish_setup(p);
+  p.B_idx = std::make_shared<DevBuf<uint32_t>>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx->upload(pk.B_idx.data(), pk.B_idx.size());
+}
+Prover::Prover(const Prover &peer) : impl(new Impl) {
+  Impl &p = *impl; const Impl &o = *peer.impl; p.lane = gpu_lane_acquire(); LaneScope lane_scope(p.lane);
+  p.h_lagrange = o.h_lagrange; p.c_fold = o.c_fold; p.nv = o.nv; p.ni = o.ni; p.m = o.m; p.a0 = o.a0; p.l0 = o.l0; p.b0 = o.b0; p.h0 = o.h0;
+  p.alpha_g1 = o.alpha_g1; p.beta_g1 = o.beta_g1; p.delta_g1 = o.delta_g1; p.beta_g2 = o.beta_g2; p.delta_g2 = o.delta_g2;
+  p.cs.reset(new R1csDev(*o.cs)); p.dom.reset(new Domain(*o.dom)); p.B_idx = o.B_idx;
+  p.A.reset(new MsmG1(*o.A, true, false)); p.L.reset(new MsmG1(*o.L, true, false)); p.B1.reset(new MsmG1(*o.B1, true, false)); p.B2.reset(new MsmG2(*o.B2, true, false)); p.H.reset(new MsmG1(*o.H, false, true));
+  finish_setup(p);
 }
 Prover::~Prover() { if (impl) { LaneScope lane_scope(impl->lane); try { gpu_sync(); } catch (...) {} impl.reset(); } }
 size_t Prover::num_variables() const { return impl->nv; }
@@ -279,8 +291,8 @@ static void enqueue_all(Prover::Impl &p) {
   // about 80 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
   // (auxiliary streams) while this one submits the critical chain
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
-  std::function<void()> jobs[4] = { [&] { p.B2->run(p.z.get(), p.B_idx.get() + p.b0); }, [&] { p.L->run(p.z.get() + (p.c_fold ? 0 : p.ni + 1) + p.l0, nullptr); },       // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
-                                    [&] { p.A->run(p.z.get() + p.a0, nullptr); }, [&] { p.B1->run(p.z.get(), p.B_idx.get() + p.b0); } };
+  std::function<void()> jobs[4] = { [&] { p.B2->run(p.z.get(), p.B_idx->get() + p.b0); }, [&] { p.L->run(p.z.get() + (p.c_fold ? 0 : p.ni + 1) + p.l0, nullptr); },       // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
+                                    [&] { p.A->run(p.z.get() + p.a0, nullptr); }, [&] { p.B1->run(p.z.get(), p.B_idx->get() + p.b0); } };
   const int job_stream[4] = {3, 1, 0, 2};                       // the auxiliary stream each MSM was bound to in the constructor (set_stream)
   const bool use_threads = threaded;
   bool posted[4] = {false, false, false, false};
@@ -344,18 +356,30 @@ void Prover::finish_from_partials(const uint8_t *records, size_t n, const Fe32 *
 // ======================================================================================================================
 // verifier and proof encoding
 // ======================================================================================================================
-bool verify_proof(const VerifyingKeyHost &vk, const Fe32 *inputs, size_t n_inputs, const Proof &proof) {
-  if (vk.IC.size() != n_inputs + 1) return false;                                                                       // strong IC (:584-590)
-  HG1 acc = g1_of(vk.IC[0]); for (size_t i = 0; i < n_inputs; i++) { HFr k = fr_of(inputs[i]); acc = acc.add(g1_of(vk.IC[i + 1]).mul(k.l)); }
+bool verify_proof(const VerifyingKeyHost &vk, const Fe32 *inputs, size_t n_inputs, const Proof &proof) { return verify_proof(*prepare_verifying_key(vk), inputs, n_inputs, proof); }   // one-off use; callers that verify more than once keep the prepared key
+
+std::shared_ptr<PreparedVerifyingKey> prepare_verifying_key(const VerifyingKeyHost &vk) {
+  auto p = std::make_shared<PreparedVerifyingKey>(); p->vk = vk;
+  p->gamma = precompute_g2(fq2_of(vk.gamma_g2.x0, vk.gamma_g2.x1), fq2_of(vk.gamma_g2.y0, vk.gamma_g2.y1)); p->delta = precompute_g2(fq2_of(vk.delta_g2.x0, vk.delta_g2.x1), fq2_of(vk.delta_g2.y0, vk.delta_g2.y1));
+  const size_t ni = vk.IC.size() ? vk.IC.size() - 1 : 0; p->ic_x.assign(ni * 32 * 255, HFq::zero()); p->ic_y.assign(ni * 32 * 255, HFq::zero());
+  for (size_t j = 0; j < ni; j++) { HG1 wbase = is_zero_raw(&vk.IC[j + 1], sizeof(G1AffineRaw)) ? HG1::inf() : g1_of(vk.IC[j + 1]); std::vector<HG1> pts(32 * 255);
+    for (int w = 0; w < 32; w++) { HG1 acc = wbase; for (int d = 1; d <= 255; d++) { pts[w * 255 + d - 1] = acc; acc = acc.add(wbase); } wbase = acc; }
+    std::vector<HFq> pre(pts.size()); HFq run = HFq::one(); for (size_t k = 0; k < pts.size(); k++) { pre[k] = run; if (!pts[k].is_inf()) run = run * pts[k].Z; }     // one inversion for the whole table
+    HFq inv = run.inv();
+    for (size_t k = pts.size(); k-- > 0;) { if (pts[k].is_inf()) continue; HFq zi = inv * pre[k]; inv = inv * pts[k].Z; HFq z2 = zi.sqr(); p->ic_x[j * 32 * 255 + k] = pts[k].X * z2; p->ic_y[j * 32 * 255 + k] = pts[k].Y * z2 * zi; } }
+  return p;
+}
+bool verify_proof(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof) {
+  const VerifyingKeyHost &vk = pvk.vk; if (vk.IC.size() != n_inputs + 1) return false;                                     // strong IC (:584-590)
+  HG1 acc = g1_of(vk.IC[0]);
+  for (size_t j = 0; j < n_inputs; j++) { const uint8_t *b = reinterpret_cast<const uint8_t *>(&inputs[j]);
+    for (int w = 0; w < 32; w++) if (b[w]) { const size_t k = j * 32 * 255 + (size_t)w * 255 + b[w] - 1; if (!(pvk.ic_x[k].is_zero() && pvk.ic_y[k].is_zero())) acc = acc.add(HG1::from_affine(pvk.ic_x[k], pvk.ic_y[k])); } }
   HFq ax = fq_of(proof.A.x), ay = fq_of(proof.A.y), cx = fq_of(proof.C.x), cy = fq_of(proof.C.y); HFq2 bx = fq2_of(proof.B.x0, proof.B.x1), by = fq2_of(proof.B.y0, proof.B.y1);
-  bool well_formed = g1_on_curve(ax, ay) && g2_on_curve(bx, by) && g1_on_curve(cx, cy);                                 // is_well_formed: on-curve only
-  if (is_zero_raw(&proof.A, sizeof proof.A) || is_zero_raw(&proof.B, sizeof proof.B) || is_zero_raw(&proof.C, sizeof proof.C)) return false;   // a proof read from hex has Z = 1, so these are (0,0): off-curve in the reference as well
-  if (!well_formed) return false;
+  if (is_zero_raw(&proof.A, sizeof proof.A) || is_zero_raw(&proof.B, sizeof proof.B) || is_zero_raw(&proof.C, sizeof proof.C)) return false;
+  if (!(g1_on_curve(ax, ay) && g2_on_curve(bx, by) && g1_on_curve(cx, cy))) return false;                                    // is_well_formed: on-curve only
   HFq accx, accy; acc.to_affine(accx, accy);
-  HFq12 q1 = miller_loop(ax, ay, precompute_g2(bx, by));
-  HFq12 q2 = acc.is_inf() ? HFq12::one() : miller_loop(accx, accy, precompute_g2(fq2_of(vk.gamma_g2.x0, vk.gamma_g2.x1), fq2_of(vk.gamma_g2.y0, vk.gamma_g2.y1)));
-  HFq12 q3 = miller_loop(cx, cy, precompute_g2(fq2_of(vk.delta_g2.x0, vk.delta_g2.x1), fq2_of(vk.delta_g2.y0, vk.delta_g2.y1)));
-  return final_exponentiation(q1 * (q2 * q3).conj()) == vk.alpha_g1_beta_g2;                                            // :556-560
+  HFq12 q1 = miller_loop(ax, ay, precompute_g2(bx, by)), q2 = acc.is_inf() ? HFq12::one() : miller_loop(accx, accy, pvk.gamma), q3 = miller_loop(cx, cy, pvk.delta);
+  return final_exponentiation(q1 * (q2 * q3).conj()) == vk.alpha_g1_beta_g2;                                               // :556-560
 }
 
 std::unique_ptr<BatchVerifier> make_batch_verifier(const VerifyingKeyHost &vk) { return std::unique_ptr<BatchVerifier>(new BatchVerifier(vk.alpha_g1_beta_g2, vk.gamma_g2, vk.delta_g2, vk.IC.data(), vk.IC.size())); }

@@ -42,6 +42,9 @@ class Prover {                                    // a proving key resident in H
   // shard_rank / shard_world: this object holds only the contiguous slice [n*rank/world, n*(rank+1)/world) of every query (kernel K7);
   // a sharded prover produces partial sums (prove_partial), any process then adds the ranks' partials and assembles the proof (finish_from_partials)
   explicit Prover(const ProvingKeyHost &pk, size_t shard_rank = 0, size_t shard_world = 1); ~Prover();
+  // a second prover on the same key: shares the peer's immutable device state (query tables, twiddles, constraint system: 1.8 GB for send) and owns only its
+  // streams, sort / bucket workspaces and vectors (about 0.25 GB), so a pool of provers per key costs little HBM and no second key load
+  explicit Prover(const Prover &peer);
   size_t num_variables() const; size_t num_inputs() const; size_t domain_size() const;
   // z: full assignment without ONE (canonical).  r, s: prover randomness (canonical; nullptr = fresh CSPRNG values).
   // Returns false if z does not satisfy the constraint system (the reference then emits its default proof, sendcgo.cpp:209-214).
@@ -60,6 +63,12 @@ class Prover {                                    // a proving key resident in H
 
 // ---- verifier (r1cs_gg_ppzksnark.tcc:509-623) -------------------------------------------------------------------------------
 bool verify_proof(const VerifyingKeyHost &vk, const Fe32 *inputs /* canonical */, size_t n_inputs, const Proof &proof);
+// The key-dependent half of the check done once (libsnark's r1cs_gg_ppzksnark_verifier_process_vk, :509-522, plus window tables of the IC points): the line
+// coefficients of gamma_g2 and delta_g2, and 2^(8w) d IC_j for every byte value d.  A call then costs three Miller loops, one final exponentiation and 32
+// mixed additions per public input instead of a 254-bit scalar multiplication each — 2.5 -> about 1.3 ms per proof on the host.
+struct PreparedVerifyingKey { VerifyingKeyHost vk; host::G2Precomp gamma, delta; std::vector<host::HFq> ic_x, ic_y; /* [j][w*255 + d-1], affine; (0,0) = infinity */ };
+std::shared_ptr<PreparedVerifyingKey> prepare_verifying_key(const VerifyingKeyHost &vk);
+bool verify_proof(const PreparedVerifyingKey &pvk, const Fe32 *inputs /* canonical */, size_t n_inputs, const Proof &proof);
 
 // the same decision for n proofs at once on the GPU (kernel K9): one BatchVerifier per verifying key
 std::unique_ptr<BatchVerifier> make_batch_verifier(const VerifyingKeyHost &vk);

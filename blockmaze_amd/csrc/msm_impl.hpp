@@ -12,7 +12,9 @@ template <class F, class RawAffine>
 struct MsmImpl {
   size_t n; int c, W, WB; uint32_t NB;   // W digit windows; WB bucket arrays (1 when the multiples 2^(cw) P are precomputed, else W)
    bool filter_ones; uint32_t seg, n_ones_quads; std::string label = "msm"; int stream_id = -1;   // -1: main stream, 0..3: auxiliary stream
-  DevBuf<RawAffine> points; DevBuf<uint8_t> inf; bool any_inf = false;
+  // the key's points (with the fixed-base table when there is one) are immutable and shared by every prover object of the key on this device; everything else below is per-object workspace
+  struct Bases { size_t n = 0; int c = 0, W = 0, WB = 0; bool glv = false, any_inf = false; DevBuf<RawAffine> points; DevBuf<uint8_t> inf; };
+  std::shared_ptr<const Bases> bases; const DevBuf<RawAffine> &points; const DevBuf<uint8_t> &inf; bool any_inf = false;
   bool direct = false, offsets_direct = false; uint32_t cap = 0, task = MSM_TASK;   // task: sorted entries per accumulation lane
   bool split_ones = false; hipStream_t ones_stream = nullptr; hipEvent_t ev_classified = nullptr, ev_ones = nullptr;   // the ones path on a stream of its own, beside the bucket path (the G2 MSM: both are long chains)
   const Fe32 *prod_b = nullptr, *prod_z = nullptr; bool prod_z_table = false; DevBuf<Fe32> prod_tmp;   // scalars given as a product a*b*z (run_product)
@@ -43,23 +45,30 @@ struct MsmImpl {
   static int windows_for(int c_, bool glv_) { return glv_ ? 132 / c_ + 1 : msm_num_windows(c_); }   // GLV halves are below 2^128 (measured bound 2^127; four spare bits)
   static bool glv_possible(size_t n_, int c_, bool fo, bool tables, bool uniform_hint, bool glv_hint) { return glv_hint && uniform_hint && tables && !fo && sizeof(F) == 32 && use_precompute(n_, windows_for(c_, true)) && getenv("ZK_MSM_NO_GLV") == nullptr; }
   bool glv = false; DevBuf<Fe32> beta;   // GLV: two half-length scalars per point, the second half addresses lambda*P = (beta*x, y)
-  MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true, bool uniform_hint = false, bool glv_hint = false)
-      : n(n_), c(c_), W(windows_for(c_, glv_possible(n_, c_, fo, tables, uniform_hint, glv_hint))), WB(tables && use_precompute(n_, windows_for(c_, glv_possible(n_, c_, fo, tables, uniform_hint, glv_hint))) ? 1 : windows_for(c_, glv_possible(n_, c_, fo, tables, uniform_hint, glv_hint))), NB(1u << (c_ - 1)), filter_ones(fo), points((n_ ? n_ : 1) * (size_t)(WB == 1 ? W : 1)), inf(n_ ? n_ : 1),
-        zeroed(2 * (size_t)WB * NB + 2 * sizeof(MsmCounters) / 4), offsets((size_t)WB * NB), entries((n_ ? n_ : 1) * (size_t)W * 2), ones(n_ ? n_ : 1), ntasks((size_t)WB * NB + 1), task_off((size_t)WB * NB + 1), cls_start(BSORT_CLASSES),
+  static std::shared_ptr<const Bases> make_bases(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables, bool uniform_hint, bool glv_hint) {
+    auto b = std::make_shared<Bases>(); b->n = n_; b->c = c_; b->glv = glv_possible(n_, c_, fo, tables, uniform_hint, glv_hint); b->W = windows_for(c_, b->glv); b->WB = tables && use_precompute(n_, b->W) ? 1 : b->W;
+    if (c_ < 6 || c_ > 20 || b->W > MSM_MAX_WINDOWS) throw GpuError("msm: unsupported window size");
+    if (b->glv && (b->WB != 1 || n_ * (size_t)b->W >= (1ull << 30))) { b->glv = false; b->W = windows_for(c_, false); b->WB = tables && use_precompute(n_, b->W) ? 1 : b->W; }
+    b->points = DevBuf<RawAffine>((n_ ? n_ : 1) * (size_t)(b->WB == 1 ? b->W : 1)); b->inf = DevBuf<uint8_t>(n_ ? n_ : 1);
+    std::vector<uint8_t> flags(n_ ? n_ : 1, 0); const uint8_t zero[sizeof(RawAffine)] = {0};
+    for (size_t i = 0; i < n_; i++) if (!memcmp(&host_points[i], zero, sizeof(RawAffine))) { flags[i] = 1; b->any_inf = true; }
+    if (n_) { b->points.upload(host_points, n_); b->inf.upload(flags.data(), n_); }
+    if (b->WB == 1 && b->W > 1 && n_) {   // table[w*n + i] = 2^(c*w) * P_i (k_msm_precompute); the scratch arrays live only for this launch
+      DevBuf<uint8_t> tmp((size_t)(b->W - 1) * n_ * sizeof(XYZZ<F>)), pref((size_t)(b->W - 1) * n_ * sizeof(F));
+      hipLaunchKernelGGL((k_msm_precompute<F>), dim3(cdiv(n_, 64)), dim3(64), 0, gpu().stream, (Affine<F> *)b->points.get(), (uint32_t)n_, c_, b->W, (XYZZ<F> *)tmp.get(), (F *)pref.get());
+      HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream));
+    }
+    return b;
+  }
+  MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true, bool uniform_hint = false, bool glv_hint = false) : MsmImpl(make_bases(host_points, n_, c_, fo, tables, uniform_hint, glv_hint), fo, uniform_hint) {}
+  MsmImpl(std::shared_ptr<const Bases> shared, bool fo, bool uniform_hint)
+      : n(shared->n), c(shared->c), W(shared->W), WB(shared->WB), NB(1u << (shared->c - 1)), filter_ones(fo), bases(shared), points(shared->points), inf(shared->inf), any_inf(shared->any_inf),
+        zeroed(2 * (size_t)WB * NB + 2 * sizeof(MsmCounters) / 4), offsets((size_t)WB * NB), entries((n ? n : 1) * (size_t)W * 2), ones(n ? n : 1), ntasks((size_t)WB * NB + 1), task_off((size_t)WB * NB + 1), cls_start(BSORT_CLASSES),
         scanner((size_t)WB * NB), task_scanner((size_t)WB * NB + 1) {
-    if (c < 6 || c > 20 || W > MSM_MAX_WINDOWS) throw GpuError("msm: unsupported window size");
-    glv = glv_possible(n_, c_, fo, tables, uniform_hint, glv_hint); if (glv && (WB != 1 || n * (size_t)W >= (1ull << 30))) glv = false;
+    glv = shared->glv;
     if (glv) { DevBuf<Fe32> b(1); Fe32 bm; memcpy(&bm, GLV_BETA_MONT, 32); b.upload(&bm, 1); beta = std::move(b); }
     { const char *e = getenv("ZK_MSM_SEG"); uint32_t big = e ? (uint32_t)atoi(e) : 16; if (big < 2 || big > 256 || (big & (big - 1))) big = 16; seg = NB >= 4096 ? (WB == 1 ? 4 : big) : 4; }   // one bucket array: few segments, keep the dependent chain short
     n_ones_quads = 16384;
-    std::vector<uint8_t> flags(n ? n : 1, 0); const uint8_t zero[sizeof(RawAffine)] = {0};
-    for (size_t i = 0; i < n; i++) if (!memcmp(&host_points[i], zero, sizeof(RawAffine))) { flags[i] = 1; any_inf = true; }
-    if (n) { points.upload(host_points, n); inf.upload(flags.data(), n); }
-    if (WB == 1 && W > 1 && n) {   // table[w*n + i] = 2^(c*w) * P_i (k_msm_precompute); the scratch arrays live only for this launch
-      DevBuf<uint8_t> tmp((size_t)(W - 1) * n * sizeof(XYZZ<F>)), pref((size_t)(W - 1) * n * sizeof(F));
-      hipLaunchKernelGGL((k_msm_precompute<F>), dim3(cdiv(n, 64)), dim3(64), 0, gpu().stream, (Affine<F> *)points.get(), (uint32_t)n, c, W, (XYZZ<F> *)tmp.get(), (F *)pref.get());
-      HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream));
-    }
     if (filter_ones && WB == 1 && n && getenv("ZK_MSM_SPARSE") != nullptr && atoi(getenv("ZK_MSM_SPARSE")) != 0) {   // opt-in (measured: chains 2-3x shorter, but 3x the field products of the bucket path, which the other streams then miss: 1.82 vs 1.74 ms per send proof)
       sparse = true; others_cap = (uint32_t)std::min<size_t>((size_t)n * W, std::max<size_t>((size_t)n * 2, 1u << 16)); others = DevBuf<uint8_t>((size_t)others_cap * sizeof(uint2)); }   // room for two non-zero digits per scalar on average (a witness has ~0.16); more raises the overflow flag and the bucket path below runs instead
     max_tasks = (uint32_t)std::max((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1, (size_t)WB * NB * HSORT_SLICES);

@@ -141,6 +141,18 @@ class Prover:
         """add the shard records (list of 384-byte strings, any order) and assemble the proof with the given randomness"""
         buf = b"".join(records); out = ctypes.create_string_buffer(513)
         _check(lib().zkgpu_prover_finish(ctypes.c_void_p(self.h), buf, ctypes.c_size_t(len(records)), int(r).to_bytes(32, "little"), int(s).to_bytes(32, "little"), out)); return out.value.decode()
+    def clone(self):
+        """another prover object on the same resident key (shares the device tables, owns its streams and workspaces)"""
+        lib().zkgpu_prover_clone.restype = ctypes.c_void_p; h = lib().zkgpu_prover_clone(ctypes.c_void_p(self.h))
+        if not h: raise ZkGpuError(lib().zkgpu_last_error().decode())
+        c = object.__new__(Prover); c.h = h; c.n_vars, c.n_inputs, c.m = self.n_vars, self.n_inputs, self.m; return c
+    def prove_batch(self, zs, rs=None):
+        """zs: list of (n_vars, 4) uint64 assignments; rs: list of (r, s) int pairs or None.  One call, len(zs) proofs (512-character hex each)."""
+        if isinstance(zs, np.ndarray) and zs.ndim == 3: Z = np.ascontiguousarray(zs, dtype=np.uint64); n = Z.shape[0]; assert Z.shape[1:] == (self.n_vars, 4)   # already back to back: no copy
+        else: n = len(zs); Z = np.ascontiguousarray(np.stack([np.ascontiguousarray(z, dtype=np.uint64).reshape(self.n_vars, 4) for z in zs])) if n else np.zeros((0, self.n_vars, 4), dtype=np.uint64)
+        R = b"".join(int(r).to_bytes(32, "little") + int(s).to_bytes(32, "little") for r, s in rs) if rs is not None else None
+        out = ctypes.create_string_buffer(513 * max(1, n)); _check(lib().zkgpu_prover_prove_batch(ctypes.c_void_p(self.h), _bytes(Z), ctypes.c_size_t(n), R, out))
+        return [out.raw[513 * i:513 * i + 512].decode() for i in range(n)]
     def timings(self):
         t = (ctypes.c_double * 5)(); _check(lib().zkgpu_prover_timings(ctypes.c_void_p(self.h), t)); return dict(zip(("upload_ms", "enqueue_ms", "device_ms", "finish_ms", "total_ms"), (float(x) for x in t)))
     def close(self):
@@ -194,6 +206,14 @@ class Zk:
     def GenMintProof(self, value, value_old, sn_old, r_old, sn, r, cmtA_old, cmtA, value_s, sk):
         return self.L.genMintproof(ctypes.c_uint64(value), ctypes.c_uint64(value_old), self.hx(sn_old), self.hx(r_old), self.hx(sn), self.hx(r), self.hx(cmtA_old), self.hx(cmtA), ctypes.c_uint64(value_s), self.hx(sk)).decode()
     def VerifyMintProof(self, proof, cmtA_old, sn_old, cmtA, value_s): return bool(self.L.verifyMintproof(proof.encode(), self.hx(cmtA_old), self.hx(sn_old), self.hx(cmtA), ctypes.c_uint64(value_s)))
+    def VerifyBatch(self, items):
+        """include/zk_batch.h: items = list of (kind, proof_hex, [big-endian byte strings in the order of the kind's verify symbol], value_s) -> (accepted, [bool])"""
+        class Item(ctypes.Structure): _fields_ = [("kind", ctypes.c_int), ("proof", ctypes.c_char_p), ("args", ctypes.c_char_p * 6), ("value_s", ctypes.c_uint64)]
+        arr = (Item * max(1, len(items)))(); keep = []
+        for i, (kind, proof, args, value_s) in enumerate(items):
+            arr[i].kind = KIND[kind] if isinstance(kind, str) else int(kind); pb = proof.encode() if isinstance(proof, str) else proof; keep.append(pb); arr[i].proof = pb; arr[i].value_s = int(value_s or 0)
+            for j, a in enumerate(args): hb = self.hx(a); keep.append(hb); arr[i].args[j] = hb
+        ok = (ctypes.c_ubyte * max(1, len(items)))(); self.L.verifyBatch.restype = ctypes.c_int; rc = self.L.verifyBatch(arr, len(items), ok); return rc, [bool(ok[i]) for i in range(len(items))]
     def GenRedeemProof(self, value, value_old, sn_old, r_old, sn, r, cmtA_old, cmtA, value_s, sk):
         return self.L.genRedeemproof(ctypes.c_uint64(value), ctypes.c_uint64(value_old), self.hx(sn_old), self.hx(r_old), self.hx(sn), self.hx(r), self.hx(cmtA_old), self.hx(cmtA), ctypes.c_uint64(value_s), self.hx(sk)).decode()
     def VerifyRedeemProof(self, proof, cmtA_old, sn_old, cmtA, value_s): return bool(self.L.verifyRedeemproof(proof.encode(), self.hx(cmtA_old), self.hx(sn_old), self.hx(cmtA), ctypes.c_uint64(value_s)))

@@ -106,6 +106,15 @@ int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, cons
 /* the two halves of zkgpu_prover_prove: upload the assignment into HBM (returns when it is resident), then prove from there any number of times */
 int zkgpu_prover_set_witness(zkgpu_prover *h, const uint8_t *z);
 int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t *s, char proof_hex[513]);
+/* A second prover object on the same resident key: shares the immutable device tables of `h` (1.8 GB for send), owns its streams and workspaces (about 0.25 GB).
+ * Objects may be used from different threads at the same time; their proofs overlap on the device. */
+zkgpu_prover *zkgpu_prover_clone(zkgpu_prover *h);
+/* n proofs against one resident key in one call (BASELINE.json configs[2]: a batch of independent statements).  zs: n assignments of n_vars 32-byte canonical values each,
+ * back to back; rs: n pairs (r, s) of 32-byte canonical values, or NULL for fresh randomness; proofs_hex: n records of 513 bytes.  The proofs are spread over
+ * ZK_BATCH_LANES (default 4) prover objects sharing the key's tables, one host thread each, so that the packing of witness i+1 and the latency-bound tails of proof i
+ * overlap the kernels of the others.  Every proof is byte-identical to what zkgpu_prover_prove returns for the same (z, r, s).  ZKGPU_ERR_UNSATISFIED if any assignment
+ * violates the constraint system (the error text lists which); the other records are still filled. */
+int zkgpu_prover_prove_batch(zkgpu_prover *h, const uint8_t *zs, size_t n, const uint8_t *rs, char *proofs_hex);
 int zkgpu_prover_timings(zkgpu_prover *h, double out[5]);       /* ms of the last prove(): upload+rows, (unused), device kernels, host finish, total */
 /* per-stage device timing with HIP events on the compute stream (for the benchmark's roofline leg).  report: JSON {"stage": {"ms_total": x, "count": n}, ...} */
 int zkgpu_profile_enable(int on);

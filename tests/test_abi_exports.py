@@ -23,6 +23,9 @@ def test_engine_header_symbols_exported(zkgpu):
     syms = declared_symbols("zkgpu.h"); assert len(syms) >= 18
     for s in syms: assert hasattr(zkgpu, s), s
 
+def test_batch_header_symbol_exported(zkgpu):
+    assert declared_symbols("zk_batch.h") == ["verifyBatch"] and hasattr(zkgpu, "verifyBatch")
+
 def test_no_cpu_fallback(zkgpu):
     import torch
     if torch.cuda.is_available(): pytest.skip("GPU present")

@@ -221,3 +221,33 @@ def test_one_pass_sort_overflow_inside_the_prover(golden_dir):
     for name in ("groth16_small", "groth16_step"):
         r = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(golden_dir, name))], capture_output=True, text=True, env=dict(os.environ, ZK_MSM_DIRECT_CAP="1"), timeout=300)
         assert "same bytes" in r.stdout, r.stderr[-2000:]
+
+def test_gpu_verifier_reproduces_reference_pairing_values(ref_vectors, tmp_path):
+    """K9 against libff's reduced_pairing VALUES (tests/golden/ref_vectors.txt), not against another verifier: keys crafted as in tests/test_verifier_cpu.py, whose
+    alpha_g1_beta_g2 is the reference's GT value of e(aG1, bG2) and whose other two pairings cancel"""
+    from test_verifier_cpu import write_vk, proof_hex, H
+    G1, G2 = o.g1_gen(), o.g2_gen(); neg_g2 = (G2[0], ((o.Q_MOD - G2[1][0]) % o.Q_MOD, (o.Q_MOD - G2[1][1]) % o.Q_MOD)); C = o.g1_op("mul", G1, k=77); n = 0
+    for l in ref_vectors:
+        if l[0] != "pairing": continue
+        a, b = H(l[1].split("=")[1]), H(l[2].split("=")[1]); gt = [int(l[3].split("=")[1])] + [int(x) for x in l[4:]]; A, B = o.g1_op("mul", G1, k=a), o.g2_op("mul", G2, k=b)
+        vk = str(tmp_path / ("vk%d.txt" % n)); write_vk(vk, gt, G2, neg_g2, [C]); n += 1
+        assert e.verify_batch(vk, [proof_hex(A, B, C), proof_hex(o.g1_op("dbl", A), B, C), proof_hex(A, B, o.g1_op("dbl", C))], [[], [], []]) == [True, False, False]
+    assert n == 3
+
+def test_verify_batch_symbol_mixed_block(all_keys, monkeypatch, tmp_path):
+    """include/zk_batch.h: one call with a block's worth of proofs — 40 send records (above the GPU threshold: one K9 launch), 3 mint and 2 redeem (host) and junk —
+    decided exactly like the per-proof verify symbols"""
+    monkeypatch.setenv("ZK_PRFKEY_DIR", str(all_keys)); zk = e.Zk(); items, exp = [], []
+    sends = [w.send_instance(500 + i) for i in range(4)]; sp = [zk.GenSendProof(*w.send_args(d)) for d in sends]
+    for i in range(40):
+        d = sends[i % 4]; pr = sp[i % 4]; args = [d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]]
+        if i % 5 == 1: pr = pr[:200] + ("7" if pr[200] != "7" else "8") + pr[201:]
+        if i % 5 == 2: args = [d["cmtA"], d["sn_old"], d["cmtS"], d["cmtA_old"]]
+        items.append(("send", pr, args, 0)); exp.append(i % 5 not in (1, 2))
+    for i in range(3):
+        m = w.mint_instance(600 + i); pr = zk.GenMintProof(*w.mint_args(m)); items.append(("mint", pr, [m["cmtA_old"], m["sn_old"], m["cmtA"]], m["value_s"] + (1 if i == 1 else 0))); exp.append(i != 1)
+    for i in range(2):
+        r = w.mint_instance(700 + i, redeem=True); pr = zk.GenRedeemProof(*w.mint_args(r)); items.append(("redeem", pr, [r["cmtA_old"], r["sn_old"], r["cmtA"]], r["value_s"])); exp.append(True)
+    items.append(("send", "xyz", [bytes(32)] * 4, 0)); exp.append(False); items.append((9, sp[0], [bytes(32)] * 4, 0)); exp.append(False)
+    rc, ok = zk.VerifyBatch(items); assert ok == exp and rc == sum(exp)
+    singles = [zk.VerifySendProof(p, *a) for k, p, a, v in items[:40]]; assert singles == exp[:40]

@@ -1,0 +1,55 @@
+"""Host verifier (r1cs_gg_ppzksnark_verifier_strong_IC on a prepared key; the path the verifyXproof symbols take) without a GPU:
+  * the reference prover's proofs on the reference-made verification keys of tests/golden: accepted; every kind of tampering: rejected
+  * the pairing itself against the reference's reduced_pairing VALUES (tests/golden/ref_vectors.txt): a verification key is crafted whose alpha_g1_beta_g2 is the
+    reference's GT value for e(aG1, bG2) and whose other two pairings cancel (delta = -gamma, C = IC[0]); the proof (aG1, bG2, IC[0]) is accepted iff the
+    engine's Miller loop + final exponentiation reproduce that value bit for bit
+  * verifyBatch (include/zk_batch.h) is exported and fails cleanly without keys."""
+import ctypes, json, os
+import pytest
+from oracle import pyoracle as o
+from blockmaze_amd import engine as e
+
+def H(x): return int(x, 16)
+
+def g1_bytes(P):
+    """compressed key-file encoding (alt_bn128_g1.cpp:404-418 under BINARY_OUTPUT / MONTGOMERY_OUTPUT): '0'|'1' is_zero, 32 bytes of Montgomery X (LE), '0'|'1' lsb of canonical Y"""
+    if P is None: return b"1" + bytes(32) + b"1"
+    return b"0" + o.to_mont(o.FQ, [P[0]])[0].to_bytes(32, "little") + (b"1" if P[1] & 1 else b"0")
+def g2_bytes(Q):
+    if Q is None: return b"1" + bytes(64) + b"1"
+    (x0, x1), (y0, y1) = Q; m = o.to_mont(o.FQ, [x0, x1]); return b"0" + m[0].to_bytes(32, "little") + m[1].to_bytes(32, "little") + (b"1" if y0 & 1 else b"0")
+def write_vk(path, gt12, gamma, delta, ic):
+    """r1cs_gg_ppzksnark.tcc:100-108 + accumulation_vector.tcc:63-69"""
+    n = len(ic) - 1; b = " ".join(str(c) for c in gt12).encode() + b"\n" + g2_bytes(gamma) + b"\n" + g2_bytes(delta) + b"\n" + g1_bytes(ic[0]) + b"\n"
+    b += b"%d\n%d\n" % (n, n) + b"".join(b"%d\n" % i for i in range(n)) + b"%d\n" % n + b"".join(g1_bytes(p) + b"\n" for p in ic[1:]) + b"\n\n"
+    open(path, "wb").write(b)
+def proof_hex(A, B, C): return o.proof_hex(o.to_arr([A[0], A[1], B[0][0], B[0][1], B[1][0], B[1][1], C[0], C[1]]).reshape(-1))
+
+@pytest.mark.parametrize("name", ["groth16_small", "groth16_step"])
+def test_reference_proofs_on_reference_keys(golden_dir, name):
+    d = os.path.join(golden_dir, name); meta = json.load(open(os.path.join(d, "meta.json"))); z = o.load_witness(os.path.join(d, "wit.bin")); vk = os.path.join(d, "vk.txt")
+    inputs = o.from_arr(z[:meta["n_inputs"]]); proof = meta["proof"]; assert e.verify(vk, proof, inputs)
+    for j in range(len(inputs)): bad = list(inputs); bad[j] = (bad[j] + 1) % o.R_MOD; assert not e.verify(vk, proof, bad)
+    assert not e.verify(vk, proof, inputs[:-1]) and not e.verify(vk, proof, inputs + [0])                  # strong IC: the input count must match
+    for k in range(8): pos = 64 * k + 21; assert not e.verify(vk, proof[:pos] + ("0" if proof[pos] != "0" else "1") + proof[pos + 1:], inputs)
+    assert not e.verify(vk, "0" * 512, inputs) and not e.verify(vk, "zz" + proof[2:], inputs) and not e.verify(vk, "%064x" % o.Q_MOD + proof[64:], inputs)   # (0,0), non-hex, coordinate >= q
+    ovk = o.parse_vk(vk); assert o.verify(ovk, inputs, o.proof_words_from_hex(proof))                      # and the oracle agrees
+
+def test_pairing_values_of_the_reference(ref_vectors, tmp_path):
+    G1, G2 = o.g1_gen(), o.g2_gen(); neg_g2 = (G2[0], ((o.Q_MOD - G2[1][0]) % o.Q_MOD, (o.Q_MOD - G2[1][1]) % o.Q_MOD)); n = 0; gts = []
+    for l in ref_vectors:
+        if l[0] != "pairing": continue
+        a, b = H(l[1].split("=")[1]), H(l[2].split("=")[1]); gt = [int(l[3].split("=")[1])] + [int(x) for x in l[4:]]; assert len(gt) == 12; gts.append(gt)
+        A, B = o.g1_op("mul", G1, k=a), o.g2_op("mul", G2, k=b); C = o.g1_op("mul", G1, k=77)
+        vk = str(tmp_path / ("vk%d.txt" % n)); write_vk(vk, gt, G2, neg_g2, [C]); n += 1
+        assert e.verify(vk, proof_hex(A, B, C), [])                                                        # e(A,B) * e(-C,gamma) * e(-C,-gamma) = e(A,B) == the reference's value
+        assert not e.verify(vk, proof_hex(o.g1_op("dbl", A), B, C), [])
+    assert n == 3
+    vk = str(tmp_path / "vkx.txt"); write_vk(vk, gts[1], G2, neg_g2, [o.g1_op("mul", G1, k=77)])          # the GT value of another pair: rejected
+    assert not e.verify(vk, proof_hex(G1, G2, o.g1_op("mul", G1, k=77)), [])
+
+def test_verify_batch_symbol(tmp_path, monkeypatch):
+    zk = e.Zk(); assert hasattr(zk.L, "verifyBatch")
+    monkeypatch.setenv("ZK_PRFKEY_DIR", str(tmp_path))                                                     # no key files there: no decision can be made
+    rc, ok = zk.VerifyBatch([("send", "0" * 512, [bytes(32)] * 4, 0), (7, "0" * 512, [], 0)]); assert rc == -1 and ok == [False, False]
+    assert zk.VerifyBatch([]) == (0, [])
