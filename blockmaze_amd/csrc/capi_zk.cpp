@@ -7,6 +7,7 @@
 //     and kept resident in HBM, re-read only when the file's size or mtime changes;
 //   * no exception, abort or signal handler ever crosses this boundary; calls may arrive concurrently on any thread.
 #include <sys/stat.h>
+#include <unistd.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +54,10 @@ std::mutex g_cache_mutex; std::map<std::string, ProverSlot> g_provers; std::map<
 std::unique_ptr<Circuit> make_circuit(CircuitKind k, bool emit) {
   switch (k) { case CircuitKind::Mint: return make_mint_circuit(emit); case CircuitKind::Send: return make_send_circuit(emit); case CircuitKind::Redeem: return make_redeem_circuit(emit); default: return make_deposit_circuit(emit, 8); } }
 
+// after the first load from text: leave the container behind for the next process start (a read-only key directory simply goes without)
+void write_container_quietly(const std::string &pk_path, const ProvingKeyHost &pk) {
+  std::string cp = key_container_path(pk_path); KeyStamp ks; if (cp.empty() || pk.H_lagrange.empty() || pk.L_star.empty() || !key_stamp_of(pk_path, ks)) return;
+  try { save_key_container(cp, pk, ks); } catch (const std::exception &) {} }
 // A unit of the key's pool, locked for the caller (the reference keeps the unit alive, the lock is released first: members are destroyed in reverse order)
 struct HeldUnit { std::shared_ptr<ProverUnit> unit; std::unique_lock<std::mutex> lock; };
 // loads the key on first use or when the file changed; loading is serialised by g_gpu_mutex, which also guards the slot table
@@ -61,12 +66,13 @@ HeldUnit acquire_prover(CircuitKind k) {
   std::shared_ptr<const UnitList> units; unsigned turn = 0;
   { std::lock_guard<std::mutex> lk(g_gpu_mutex); ProverSlot &slot = g_provers[path];
     if (!slot.units || !(slot.stamp == st)) {
-      ProvingKeyHost pk = load_proving_key(path); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 4; if (n < 1) n = 1; if (n > 7) n = 7;
+      bool cached = false; ProvingKeyHost pk = load_proving_key_fast(path, cached); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 4; if (n < 1) n = 1; if (n > 7) n = 7;
       auto fresh = std::make_shared<UnitList>();
       for (int i = 0; i < n; i++) { auto u = std::make_shared<ProverUnit>(); if (i == 0) u->prover.reset(new Prover(pk)); else u->prover.reset(new Prover(*fresh->front()->prover)); u->circuit = make_circuit(k, false);   // members beyond the first share its device tables
         if (u->circuit->board.num_variables() != u->prover->num_variables() || u->circuit->num_inputs() != u->prover->num_inputs()) throw std::runtime_error("proving key does not belong to the " + std::string(circuit_name(k)) + " circuit: " + path);
         fresh->push_back(std::move(u)); }
-      slot.units = std::move(fresh); slot.stamp = st; }
+      slot.units = std::move(fresh); slot.stamp = st;
+      if (!cached) write_container_quietly(path, pk); }
     units = slot.units; turn = slot.next.fetch_add(1); }
   for (const auto &u : *units) { std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) return HeldUnit{u, std::move(lk)}; }
   const std::shared_ptr<ProverUnit> &u = (*units)[turn % units->size()]; return HeldUnit{u, std::unique_lock<std::mutex>(u->busy)};
@@ -223,7 +229,30 @@ int zkgpu_keygen_from_r1cs(const char *r1cs_path, uint64_t seed, const char *pk_
 int zkgpu_keygen(int kind, int tree_depth, uint64_t seed, const char *pk_path, const char *vk_path) { return guarded([&] { std::unique_ptr<Circuit> c = kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true);
   ProvingKeyHost pk; VerifyingKeyHost vk; generate_keys(c->r1cs(), seed ? ToxicWaste::from_seed(seed) : ToxicWaste::random(), pk, vk); save_proving_key(pk_path, pk); save_verifying_key(vk_path, vk); return ZKGPU_OK; }); }
 
-zkgpu_prover *zkgpu_prover_load_shard(const char *pk_path, size_t shard_rank, size_t shard_world) { zkgpu_prover *h = nullptr; guarded([&] { ProvingKeyHost pk = load_proving_key(pk_path); std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(pk, shard_rank, shard_world)); h = p.release(); return ZKGPU_OK; }); return h; }
+zkgpu_prover *zkgpu_prover_load_shard(const char *pk_path, size_t shard_rank, size_t shard_world) { zkgpu_prover *h = nullptr; guarded([&] { bool cached = false; ProvingKeyHost pk = load_proving_key_fast(pk_path, cached); std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(pk, shard_rank, shard_world));
+  if (!cached) write_container_quietly(pk_path, pk); h = p.release(); return ZKGPU_OK; }); return h; }
+/* host-only self-test of the container code (tests/test_key_container_cpu.py): a synthetic transformed key of the given shape is written, mapped back and compared; then the
+ * file is truncated, a payload byte is flipped, and the source stamp is changed — each must make the loader refuse.  Returns 0 if every step behaved. */
+int zkgpu_test_key_container(const char *path, size_t n_vars, size_t n_cons, size_t m) { int rc = -1; guarded_host([&] {
+  ProvingKeyHost pk; uint64_t s = 0x1234; auto rnd = [&](void *p, size_t n) { uint8_t *b = (uint8_t *)p; for (size_t i = 0; i < n; i++) { s = s * 6364136223846793005ull + 1442695040888963407ull; b[i] = (uint8_t)(s >> 56); } };
+  pk.cs.n_inputs = 3; pk.cs.n_vars = n_vars; pk.cs.n_cons = n_cons; pk.A.resize(n_vars + 1); pk.L_star.resize(n_vars + 1); pk.H_lagrange.resize(m); size_t nB = n_vars / 2 + 1; pk.B_idx.resize(nB); pk.B_g1.resize(nB); pk.B_g2.resize(nB);
+  rnd(&pk.alpha_g1, 64); rnd(&pk.beta_g1, 64); rnd(&pk.delta_g1, 64); rnd(&pk.beta_g2, 128); rnd(&pk.delta_g2, 128); rnd(pk.A.data(), pk.A.size() * 64); rnd(pk.L_star.data(), pk.L_star.size() * 64); rnd(pk.H_lagrange.data(), m * 64); rnd(pk.B_g1.data(), nB * 64); rnd(pk.B_g2.data(), nB * 128);
+  for (size_t i = 0; i < nB; i++) pk.B_idx[i] = (uint32_t)(2 * i);
+  for (int k = 0; k < 3; k++) { pk.cs.rowptr[k].resize(n_cons + 1); pk.cs.rowptr[k][0] = 0; for (size_t i = 0; i < n_cons; i++) pk.cs.rowptr[k][i + 1] = pk.cs.rowptr[k][i] + (uint32_t)((i + k) % 3); size_t nnz = pk.cs.rowptr[k][n_cons]; pk.cs.col[k].resize(nnz); pk.cs.coeff[k].resize(nnz); for (size_t e = 0; e < nnz; e++) pk.cs.col[k][e] = (uint32_t)(e % (n_vars + 1)); rnd(pk.cs.coeff[k].data(), nnz * 32); }
+  KeyStamp st{12345, 1700000000, 42}; save_key_container(path, pk, st); ProvingKeyHost q;
+  auto same = [&](const ProvingKeyHost &a, const ProvingKeyHost &b) { bool ok = !memcmp(&a.alpha_g1, &b.alpha_g1, 64) && !memcmp(&a.delta_g2, &b.delta_g2, 128) && a.B_idx == b.B_idx && a.cs.n_cons == b.cs.n_cons && a.cs.n_vars == b.cs.n_vars && a.cs.n_inputs == b.cs.n_inputs;
+    ok = ok && a.A.size() == b.A.size() && !memcmp(a.A.data(), b.A.data(), a.A.size() * 64) && a.L_star.size() == b.L_star.size() && !memcmp(a.L_star.data(), b.L_star.data(), a.L_star.size() * 64) && a.H_lagrange.size() == b.H_lagrange.size() && !memcmp(a.H_lagrange.data(), b.H_lagrange.data(), a.H_lagrange.size() * 64);
+    ok = ok && a.B_g2.size() == b.B_g2.size() && !memcmp(a.B_g2.data(), b.B_g2.data(), a.B_g2.size() * 128) && !memcmp(a.B_g1.data(), b.B_g1.data(), a.B_g1.size() * 64);
+    for (int k = 0; k < 3 && ok; k++) ok = a.cs.rowptr[k] == b.cs.rowptr[k] && a.cs.col[k] == b.cs.col[k] && a.cs.coeff[k].size() == b.cs.coeff[k].size() && !memcmp(a.cs.coeff[k].data(), b.cs.coeff[k].data(), a.cs.coeff[k].size() * 32); return ok; };
+  if (!load_key_container(path, st, q) || !same(pk, q)) { rc = 1; return ZKGPU_OK; }
+  KeyStamp other = st; other.mtime_ns++; if (load_key_container(path, other, q)) { rc = 2; return ZKGPU_OK; }                       // the key file changed: stale
+  struct stat sb; if (stat(path, &sb)) { rc = 3; return ZKGPU_OK; }
+  { FILE *f = fopen(path, "r+b"); fseek(f, (long)(sb.st_size / 2), SEEK_SET); int ch = fgetc(f); fseek(f, (long)(sb.st_size / 2), SEEK_SET); fputc(ch ^ 1, f); fclose(f); if (load_key_container(path, st, q)) { rc = 4; return ZKGPU_OK; }   // bit rot: checksum
+    f = fopen(path, "r+b"); fseek(f, (long)(sb.st_size / 2), SEEK_SET); fputc(ch, f); fclose(f); if (!load_key_container(path, st, q)) { rc = 5; return ZKGPU_OK; } }
+  if (truncate(path, sb.st_size - 64)) { rc = 6; return ZKGPU_OK; } if (load_key_container(path, st, q)) { rc = 7; return ZKGPU_OK; }                                      // truncated
+  rc = 0; return ZKGPU_OK; }); return rc; }
+/* 1 if a valid container exists for this key file (what the next load will use), 0 if not */
+int zkgpu_key_container_valid(const char *pk_path) { int r = 0; guarded_host([&] { KeyStamp ks; ProvingKeyHost pk; std::string cp = key_container_path(pk_path); r = !cp.empty() && key_stamp_of(pk_path, ks) && load_key_container(cp, ks, pk) ? 1 : 0; return ZKGPU_OK; }); return r; }
 zkgpu_prover *zkgpu_prover_load(const char *pk_path) { return zkgpu_prover_load_shard(pk_path, 0, 1); }
 int zkgpu_prover_prove_partial(zkgpu_prover *h, uint8_t out[384]) { return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; if (!h->p->prove_partial(out)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } return ZKGPU_OK; }); }
 int zkgpu_prover_finish(zkgpu_prover *h, const uint8_t *records, size_t n, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_host([&] { if (!h) return ZKGPU_ERR_ARG; Proof p; h->p->finish_from_partials(records, n, (const Fe32 *)r, (const Fe32 *)s, p);

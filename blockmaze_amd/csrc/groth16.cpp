@@ -1,5 +1,9 @@
 // see groth16.hpp
 #include <sys/random.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
@@ -130,6 +134,62 @@ void save_verifying_key(const std::string &path, const VerifyingKeyHost &vk) {
 }
 
 // ======================================================================================================================
+// fast key container
+// ======================================================================================================================
+namespace {
+struct ContainerHeader { char magic[8]; uint32_t version, flags; int64_t src_size, src_mtime_s, src_mtime_ns; uint64_t n_inputs, n_vars, n_cons, m, nA, nB, nH, nL, nnz[3], payload_bytes, checksum; uint8_t pad[256 - 8 - 8 - 24 - 8 * 13]; };
+static_assert(sizeof(ContainerHeader) == 256, "container header");
+const char CONTAINER_MAGIC[8] = {'Z', 'K', 'G', 'P', 'U', 'K', 'C', '1'};
+uint64_t checksum64(const uint8_t *p, size_t n) {   // four independent multiply-xor lanes over 8-byte words (about 10 GB/s): an integrity check against truncation and bit rot, not a MAC
+  uint64_t h[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull}; size_t i = 0;
+  for (; i + 32 <= n; i += 32) { uint64_t w[4]; memcpy(w, p + i, 32); for (int k = 0; k < 4; k++) { h[k] = (h[k] ^ w[k]) * 0x9E3779B97F4A7C15ull; h[k] ^= h[k] >> 29; } }
+  for (; i < n; i++) { h[0] = (h[0] ^ p[i]) * 0x100000001B3ull; }
+  return (h[0] * 3) ^ (h[1] * 5) ^ (h[2] * 7) ^ (h[3] * 11) ^ n; }
+size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
+struct Section { const void *p; size_t bytes; };
+std::vector<Section> sections_of(const ProvingKeyHost &pk) {
+  std::vector<Section> s; s.push_back({&pk.alpha_g1, 64}); s.push_back({&pk.beta_g1, 64}); s.push_back({&pk.delta_g1, 64}); s.push_back({&pk.beta_g2, 128}); s.push_back({&pk.delta_g2, 128});
+  s.push_back({pk.A.data(), pk.A.size() * 64}); s.push_back({pk.B_idx.data(), pk.B_idx.size() * 4}); s.push_back({pk.B_g1.data(), pk.B_g1.size() * 64}); s.push_back({pk.B_g2.data(), pk.B_g2.size() * 128});
+  s.push_back({pk.H_lagrange.data(), pk.H_lagrange.size() * 64}); s.push_back({pk.L_star.data(), pk.L_star.size() * 64});
+  for (int m = 0; m < 3; m++) { s.push_back({pk.cs.rowptr[m].data(), pk.cs.rowptr[m].size() * 4}); s.push_back({pk.cs.col[m].data(), pk.cs.col[m].size() * 4}); s.push_back({pk.cs.coeff[m].data(), pk.cs.coeff[m].size() * 32}); }
+  return s; }
+}  // namespace
+bool key_stamp_of(const std::string &path, KeyStamp &out) { struct stat st; if (stat(path.c_str(), &st)) return false; out.size = st.st_size; out.mtime_s = st.st_mtim.tv_sec; out.mtime_ns = st.st_mtim.tv_nsec; return true; }
+std::string key_container_path(const std::string &pk_path) {
+  const char *on = getenv("ZK_KEY_CACHE"); if (on && atoi(on) == 0) return "";
+  const char *dir = getenv("ZK_KEY_CACHE_DIR"); if (!dir || !*dir) return pk_path + ".gpucache";
+  std::string flat = pk_path; for (char &ch : flat) if (ch == '/') ch = '_'; return std::string(dir) + "/" + flat + ".gpucache"; }
+void save_key_container(const std::string &path, const ProvingKeyHost &pk, const KeyStamp &src) {
+  if (pk.H_lagrange.empty() || pk.L_star.empty()) throw std::runtime_error("key container: the key has not been transformed yet");
+  ContainerHeader h; memset(&h, 0, sizeof h); memcpy(h.magic, CONTAINER_MAGIC, 8); h.version = 1; h.flags = 3; h.src_size = src.size; h.src_mtime_s = src.mtime_s; h.src_mtime_ns = src.mtime_ns;
+  h.n_inputs = pk.cs.n_inputs; h.n_vars = pk.cs.n_vars; h.n_cons = pk.cs.n_cons; h.m = pk.H_lagrange.size(); h.nA = pk.A.size(); h.nB = pk.B_idx.size(); h.nH = pk.H_lagrange.size(); h.nL = pk.L_star.size(); for (int m = 0; m < 3; m++) h.nnz[m] = pk.cs.col[m].size();
+  std::vector<Section> secs = sections_of(pk); size_t total = 0; for (auto &s : secs) total += align64(s.bytes);
+  std::vector<uint8_t> buf(total, 0); size_t off = 0; for (auto &s : secs) { if (s.bytes) memcpy(buf.data() + off, s.p, s.bytes); off += align64(s.bytes); }
+  h.payload_bytes = total; h.checksum = checksum64(buf.data(), total);
+  const std::string tmp = path + ".tmp." + std::to_string((long)getpid()); FILE *f = fopen(tmp.c_str(), "wb"); if (!f) throw std::runtime_error("key container: cannot write " + tmp);
+  bool ok = fwrite(&h, 1, sizeof h, f) == sizeof h && fwrite(buf.data(), 1, total, f) == total; ok = fclose(f) == 0 && ok;
+  if (!ok || rename(tmp.c_str(), path.c_str())) { remove(tmp.c_str()); throw std::runtime_error("key container: cannot write " + path); } }
+bool load_key_container(const std::string &path, const KeyStamp &src, ProvingKeyHost &pk) {
+  int fd = open(path.c_str(), O_RDONLY); if (fd < 0) return false; struct stat st; if (fstat(fd, &st) || (size_t)st.st_size < sizeof(ContainerHeader)) { close(fd); return false; }
+  const size_t len = (size_t)st.st_size; void *map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0); close(fd); if (map == MAP_FAILED) return false;
+  struct Unmap { void *p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, len};
+  const ContainerHeader &h = *(const ContainerHeader *)map; const uint8_t *pay = (const uint8_t *)map + sizeof(ContainerHeader);
+  if (memcmp(h.magic, CONTAINER_MAGIC, 8) || h.version != 1 || h.flags != 3 || h.src_size != src.size || h.src_mtime_s != src.mtime_s || h.src_mtime_ns != src.mtime_ns) return false;
+  if (h.payload_bytes != len - sizeof(ContainerHeader) || checksum64(pay, h.payload_bytes) != h.checksum) return false;
+  if (h.nA != h.n_vars + 1 || h.nL != h.n_vars + 1 || h.nH != h.m || h.n_inputs > h.n_vars || h.nB > h.nA) return false;
+  ProvingKeyHost k; k.A.resize(h.nA); k.B_idx.resize(h.nB); k.B_g1.resize(h.nB); k.B_g2.resize(h.nB); k.H_lagrange.resize(h.nH); k.L_star.resize(h.nL); k.cs.n_inputs = h.n_inputs; k.cs.n_vars = h.n_vars; k.cs.n_cons = h.n_cons;
+  for (int m = 0; m < 3; m++) { k.cs.rowptr[m].resize(h.n_cons + 1); k.cs.col[m].resize(h.nnz[m]); k.cs.coeff[m].resize(h.nnz[m]); }
+  std::vector<Section> secs = sections_of(k); size_t total = 0; for (auto &s : secs) total += align64(s.bytes); if (total != h.payload_bytes) return false;
+  size_t off = 0; for (auto &s : secs) { if (s.bytes) memcpy(const_cast<void *>(s.p), pay + off, s.bytes); off += align64(s.bytes); }
+  for (int m = 0; m < 3; m++) { if (k.cs.rowptr[m][0] != 0 || k.cs.rowptr[m][h.n_cons] != h.nnz[m]) return false; }
+  for (uint32_t i : k.B_idx) if (i >= h.nA) return false;
+  pk = std::move(k); return true; }
+ProvingKeyHost load_proving_key_fast(const std::string &pk_path, bool &from_container) {
+  from_container = false; KeyStamp st; std::string cp = key_container_path(pk_path); ProvingKeyHost pk;
+  if (!cp.empty() && key_stamp_of(pk_path, st) && load_key_container(cp, st, pk)) { from_container = true; return pk; }
+  return load_proving_key(pk_path); }
+
+// ======================================================================================================================
 // generator
 // ======================================================================================================================
 static void urandom(void *p, size_t n) {   // the kernel's CSPRNG through getrandom(2): no file descriptor, no open() per proof
@@ -229,7 +289,9 @@ static void finish_setup(Prover::Impl &p) {
 }
 Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) : impl(new Impl) {
   Impl &p = *impl; p.lane = gpu_lane_acquire(); LaneScope lane_scope(p.lane); p.nv = pk.cs.n_vars; p.ni = pk.cs.n_inputs; if (shard_world == 0 || shard_rank >= shard_world) throw std::runtime_error("prover: bad shard"); p.cs.reset(new R1csDev(pk.cs)); p.dom.reset(new Domain(pk.cs.n_cons + p.ni + 1)); p.m = p.dom->m();
-  if (pk.A.size() != p.nv + 1 || pk.H.size() != p.m - 1 || pk.L.size() != p.nv - p.ni) throw std::runtime_error("proving key: query sizes do not match the constraint system");
+  const bool transformed = pk.H_lagrange.size() == p.m && pk.L_star.size() == p.nv + 1;   // a key from the container carries H and L only in their transformed form
+  if (pk.A.size() != p.nv + 1 || (!transformed && (pk.H.size() != p.m - 1 || pk.L.size() != p.nv - p.ni))) throw std::runtime_error("proving key: query sizes do not match the constraint system");
+  if (transformed && pk.H.empty() && !(env_int("ZK_H_LAGRANGE", 1) != 0 && env_int("ZK_FOLD_C", 1) != 0)) throw std::runtime_error("proving key: loaded from a container of transformed queries, which ZK_H_LAGRANGE=0 / ZK_FOLD_C=0 cannot use (set ZK_KEY_CACHE=0)");
   p.alpha_g1 = g1_of(pk.alpha_g1); p.beta_g1 = g1_of(pk.beta_g1); p.delta_g1 = g1_of(pk.delta_g1); p.beta_g2 = g2_of(pk.beta_g2); p.delta_g2 = g2_of(pk.delta_g2);
   int cw = env_int("ZK_MSM_WITNESS_WINDOW", 8), ch = env_int("ZK_MSM_H_WINDOW", 16);
   size_t e; shard_range(pk.A.size(), shard_rank, shard_world, p.a0, e); size_t nA = e - p.a0;

@@ -32,6 +32,21 @@ VerifyingKeyHost load_verifying_key(const std::string &path);   // host only
 void save_proving_key(const std::string &path, const ProvingKeyHost &pk);
 void save_verifying_key(const std::string &path, const VerifyingKeyHost &vk);
 
+// ---- the fast key container ------------------------------------------------------------------------------
+// The reference parses its key file on every call (sendcgo.cpp:64-81: 54 s for send); this engine parses it once per process — still 0.9 s: 77 MB of decimal text,
+// 1.08 M square roots, and the key transforms of ecntt.cuh.  The container holds the RESULT of all that as raw, 64-byte aligned arrays (uncompressed affine Montgomery
+// points with H already in the coset's Lagrange basis and C folded into L, the constraint system in CSR form), so a later process start maps the file and copies:
+//   header: magic "ZKGPUKC1", flags, the source key file's size and mtime (a stale or foreign container is ignored), shape, payload length, 64-bit checksum
+//   payload: alpha_g1 beta_g1 delta_g1 | beta_g2 delta_g2 | A | B_idx | B_g1 | B_g2 | H_lagrange | L_star | rowptr[3] col[3] coeff[3]
+// Written next to the key file as <key>.gpucache (or under $ZK_KEY_CACHE_DIR) after the first load from text; ZK_KEY_CACHE=0 disables both reading and writing.
+struct KeyStamp { int64_t size = -1, mtime_s = 0, mtime_ns = 0; bool operator==(const KeyStamp &o) const { return size == o.size && mtime_s == o.mtime_s && mtime_ns == o.mtime_ns; } };
+bool key_stamp_of(const std::string &path, KeyStamp &out);
+std::string key_container_path(const std::string &pk_path);            // "" if the cache is disabled
+void save_key_container(const std::string &path, const ProvingKeyHost &pk, const KeyStamp &source);   // pk must carry H_lagrange and L_star (filled by the first Prover built on it); atomic (temporary file + rename)
+bool load_key_container(const std::string &path, const KeyStamp &source, ProvingKeyHost &pk);          // false: missing, stale, truncated, wrong checksum or wrong version — the caller falls back to the text key
+// text key or its container, whichever is valid; `from_container` tells which.  After building the first Prover on a key that came from text, call save_key_container.
+ProvingKeyHost load_proving_key_fast(const std::string &pk_path, bool &from_container);
+
 // ---- generator (r1cs_gg_ppzksnark.tcc:212-388) --------------------------------------------------------------------------
 struct ToxicWaste { host::HFr t, alpha, beta, gamma, delta, g1_scalar, g2_scalar; static ToxicWaste random(); static ToxicWaste from_seed(uint64_t seed); };
 void generate_keys(const R1csHost &cs, const ToxicWaste &tw, ProvingKeyHost &pk, VerifyingKeyHost &vk);

@@ -92,7 +92,9 @@ int zkgpu_keygen(int kind, int tree_depth, uint64_t seed, const char *pk_path, c
 int zkgpu_keygen_from_r1cs(const char *r1cs_path, uint64_t seed, const char *pk_path, const char *vk_path);
 /* resident prover over a reference-format proving key file */
 typedef struct zkgpu_prover zkgpu_prover;
-zkgpu_prover *zkgpu_prover_load(const char *pk_path);
+zkgpu_prover *zkgpu_prover_load(const char *pk_path);   /* parses the reference-format key file, or maps its container <pk_path>.gpucache when that is valid; writes the container after a load from text */
+int zkgpu_key_container_valid(const char *pk_path);
+int zkgpu_test_key_container(const char *path, size_t n_vars, size_t n_cons, size_t m);   /* host-only self-test of the container reader / writer; 0 = passed */     /* 1 if a valid container (matching size / mtime of the key file, checksum) is in place */
 /* MSM sharding across GPUs (one process per GPU): a shard holds the contiguous slice rank/world of every query of the key.  prove_partial() runs the whole
  * device pipeline on the resident witness and returns this shard's five partial sums (affine canonical: eA 64 | eB1 64 | eH 64 | eL 64 | eB2 128 = 384 bytes);
  * the records of all ranks are exchanged by the caller (one all-gather) and zkgpu_prover_finish() adds them and assembles the proof on the host. */

@@ -251,3 +251,18 @@ def test_verify_batch_symbol_mixed_block(all_keys, monkeypatch, tmp_path):
     items.append(("send", "xyz", [bytes(32)] * 4, 0)); exp.append(False); items.append((9, sp[0], [bytes(32)] * 4, 0)); exp.append(False)
     rc, ok = zk.VerifyBatch(items); assert ok == exp and rc == sum(exp)
     singles = [zk.VerifySendProof(p, *a) for k, p, a, v in items[:40]]; assert singles == exp[:40]
+
+def test_key_container_gives_the_same_prover(tmp_path):
+    """the first load of a text key leaves <key>.gpucache behind (post-transform tables as raw aligned arrays); the next load maps it instead of parsing 77 MB
+    of text — same proof bytes, a fraction of the time; a container whose key file changed is ignored and rebuilt"""
+    import time, ctypes
+    pk_path, vk_path, wp = str(tmp_path / "sendpk.txt"), str(tmp_path / "sendvk.txt"), str(tmp_path / "w.bin"); e.keygen("send", pk_path, vk_path, seed=0xC0FFEE)
+    d = w.send_instance(77); e.witness_send(*hexargs(w.send_args(d)), wp); z = o.load_witness(wp); L = e.lib()
+    assert L.zkgpu_key_container_valid(pk_path.encode()) == 0
+    t0 = time.time(); p = e.Prover(pk_path); t_text = time.time() - t0; a = p.prove(z, 11, 22); p.close(); assert L.zkgpu_key_container_valid(pk_path.encode()) == 1
+    t0 = time.time(); p = e.Prover(pk_path); t_cont = time.time() - t0; b = p.prove(z, 11, 22); p.close()
+    print("key load: %.3f s from text, %.3f s from the container (%d MB)" % (t_text, t_cont, os.path.getsize(pk_path + ".gpucache") >> 20)); record_leg("send key load from text / container", None); record_leg("  text %.2f s, container %.2f s" % (t_text, t_cont), None)
+    assert a == b and e.verify(vk_path, a, w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]])) and t_cont < 0.6 * t_text
+    e.keygen("send", pk_path, vk_path, seed=0xC0FFEF)                                   # a different key at the same path: the old container must not be used
+    assert L.zkgpu_key_container_valid(pk_path.encode()) == 0
+    p = e.Prover(pk_path); c = p.prove(z, 11, 22); p.close(); assert c != a and e.verify(vk_path, c, w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]]))
