@@ -67,14 +67,18 @@ HeldUnit acquire_prover(CircuitKind k) {
   { std::lock_guard<std::mutex> lk(g_gpu_mutex); ProverSlot &slot = g_provers[path];
     if (!slot.units || !(slot.stamp == st)) {
       bool cached = false; ProvingKeyHost pk = load_proving_key_fast(path, cached); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 4; if (n < 1) n = 1; if (n > 7) n = 7;
-      auto fresh = std::make_shared<UnitList>();
-      for (int i = 0; i < n; i++) { auto u = std::make_shared<ProverUnit>(); if (i == 0) u->prover.reset(new Prover(pk)); else u->prover.reset(new Prover(*fresh->front()->prover)); u->circuit = make_circuit(k, false);   // members beyond the first share its device tables
+      // per device of the process's list (ZK_DEVICES): one prover built from the key, the rest of that device's members share its tables.  The list is interleaved by
+      // device — d0u0 d1u0 ... d0u1 d1u1 ... — so that callers walking it from a rotating start (below) spread over the GPUs before they double up on one.
+      auto fresh = std::make_shared<UnitList>(); const int D = std::max(1, gpu_device_slots()); std::vector<std::shared_ptr<Prover>> first(D);
+      for (int i = 0; i < n; i++) for (int dslot = 0; dslot < D; dslot++) { auto u = std::make_shared<ProverUnit>();
+        if (i == 0) { u->prover.reset(new Prover(pk, 0, 1, dslot)); first[dslot] = u->prover; } else u->prover.reset(new Prover(*first[dslot]));
+        u->circuit = make_circuit(k, false);
         if (u->circuit->board.num_variables() != u->prover->num_variables() || u->circuit->num_inputs() != u->prover->num_inputs()) throw std::runtime_error("proving key does not belong to the " + std::string(circuit_name(k)) + " circuit: " + path);
         fresh->push_back(std::move(u)); }
       slot.units = std::move(fresh); slot.stamp = st;
       if (!cached) write_container_quietly(path, pk); }
     units = slot.units; turn = slot.next.fetch_add(1); }
-  for (const auto &u : *units) { std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) return HeldUnit{u, std::move(lk)}; }
+  for (size_t j = 0; j < units->size(); j++) { const auto &u = (*units)[(turn + j) % units->size()]; std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) return HeldUnit{u, std::move(lk)}; }   // first free member, starting at a rotating position
   const std::shared_ptr<ProverUnit> &u = (*units)[turn % units->size()]; return HeldUnit{u, std::unique_lock<std::mutex>(u->busy)};
 }
 std::shared_ptr<PreparedVerifyingKey> vk_for_path(const std::string &path) {
@@ -231,6 +235,11 @@ int zkgpu_keygen(int kind, int tree_depth, uint64_t seed, const char *pk_path, c
 
 zkgpu_prover *zkgpu_prover_load_shard(const char *pk_path, size_t shard_rank, size_t shard_world) { zkgpu_prover *h = nullptr; guarded([&] { bool cached = false; ProvingKeyHost pk = load_proving_key_fast(pk_path, cached); std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(pk, shard_rank, shard_world));
   if (!cached) write_container_quietly(pk_path, pk); h = p.release(); return ZKGPU_OK; }); return h; }
+/* pure host logic of the multi-device pool, for the CPU tests: parses `spec` as ZK_DEVICES would be (n_visible devices, `fallback` = ZK_DEVICE / LOCAL_RANK) into out_devices (returns
+ * the count), and writes the device slot of each of the first n_order pool members (ZK_PROVERS_PER_KEY = per_device) into out_order in pool order */
+int zkgpu_test_device_plan(const char *spec, int n_visible, int fallback, int per_device, int *out_devices, int *out_order, int n_order) {
+  std::vector<int> l = parse_device_list(spec, n_visible, fallback); for (size_t i = 0; i < l.size(); i++) out_devices[i] = l[i];
+  const int D = std::max<int>(1, (int)l.size()); int k = 0; for (int i = 0; i < per_device && k < n_order; i++) for (int d = 0; d < D && k < n_order; d++) out_order[k++] = d; return (int)l.size(); }
 /* host-only self-test of the container code (tests/test_key_container_cpu.py): a synthetic transformed key of the given shape is written, mapped back and compared; then the
  * file is truncated, a payload byte is flipped, and the source stamp is changed — each must make the loader refuse.  Returns 0 if every step behaved. */
 int zkgpu_test_key_container(const char *path, size_t n_vars, size_t n_cons, size_t m) { int rc = -1; guarded_host([&] {

@@ -23,13 +23,31 @@ namespace zk {
 // Lanes: independent sets of streams (one main + four auxiliary) so that several provers can have a proof in flight at the same time; a thread works on the lane it
 // selected with LaneScope (lane 0 unless told otherwise).  Contexts are created on first use and live for the life of the process.
 constexpr int MAX_LANES = 32;   // lanes beyond the hardware queues share queues; provers sharing a lane share its streams (still correct, merely serialised)
-static std::atomic<GpuContext *> g_lanes[MAX_LANES]; static std::mutex g_lane_mutex; static thread_local int t_lane = 0; static std::atomic<unsigned> g_next_lane{0};
+static std::atomic<GpuContext *> g_lanes[MAX_LANES]; static std::atomic<int> g_lane_slot[MAX_LANES]; static std::mutex g_lane_mutex; static thread_local int t_lane = 0; static std::atomic<unsigned> g_next_lane{0};
+std::vector<int> parse_device_list(const char *spec, int n_visible, int fallback_device) {
+  std::vector<int> out; if (n_visible <= 0) return out;
+  if (!spec || !*spec) { out.push_back(((fallback_device % n_visible) + n_visible) % n_visible); return out; }
+  if (!strcmp(spec, "all")) { for (int i = 0; i < n_visible; i++) out.push_back(i); return out; }
+  for (const char *p = spec; *p;) { char *end = nullptr; long v = strtol(p, &end, 10); if (end == p) break; if (v >= 0 && v < n_visible) { bool dup = false; for (int x : out) dup |= x == (int)v; if (!dup) out.push_back((int)v); } p = *end == ',' ? end + 1 : end; if (*end && *end != ',') break; }
+  if (out.empty()) out.push_back(0);
+  return out; }
+static const std::vector<int> &device_list() { static const std::vector<int> l = [] { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) n = 0; const char *e = getenv("ZK_DEVICE"); if (!e) e = getenv("LOCAL_RANK");
+    return parse_device_list(getenv("ZK_DEVICES"), n, e ? atoi(e) : 0); }(); return l; }
+int gpu_device_slots() { return (int)device_list().size(); }
+int gpu_slot_of_lane(int lane) { return lane < 0 || lane >= MAX_LANES ? 0 : g_lane_slot[lane].load(); }
 GpuContext &gpu() {
   GpuContext *c = g_lanes[t_lane].load(std::memory_order_acquire);
-  if (!c) { std::lock_guard<std::mutex> lk(g_lane_mutex); c = g_lanes[t_lane].load(std::memory_order_acquire); if (!c) { c = new GpuContext; g_lanes[t_lane].store(c, std::memory_order_release); } }
+  if (!c) { std::lock_guard<std::mutex> lk(g_lane_mutex); c = g_lanes[t_lane].load(std::memory_order_acquire);
+    if (!c) { const std::vector<int> &l = device_list(); if (l.empty()) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
+      c = new GpuContext(l[(size_t)g_lane_slot[t_lane].load() % l.size()]); g_lanes[t_lane].store(c, std::memory_order_release); } }
   hipSetDevice(c->device); return *c;
 }
-int gpu_lane_acquire() { return 1 + (int)(g_next_lane.fetch_add(1) % (MAX_LANES - 1)); }      // lanes 1..7 round robin for provers; lane 0 stays with everything else
+// lanes 1.. round robin for provers; lane 0 (device slot 0) stays with everything else.  A lane keeps the device slot of its first user; asking for a lane on another
+// slot skips lanes bound elsewhere.
+int gpu_lane_acquire(int device_slot) {
+  for (int tries = 0; tries < 2 * MAX_LANES; tries++) { int lane = 1 + (int)(g_next_lane.fetch_add(1) % (MAX_LANES - 1)); std::lock_guard<std::mutex> lk(g_lane_mutex);
+    static bool claimed[MAX_LANES]; if (!claimed[lane]) { claimed[lane] = true; g_lane_slot[lane].store(device_slot); return lane; } if (g_lane_slot[lane].load() == device_slot) return lane; }
+  throw GpuError("no stream lane left for device slot " + std::to_string(device_slot)); }
 int gpu_lane_current() { return t_lane; }
 void gpu_lane_select(int lane) { t_lane = lane < 0 || lane >= MAX_LANES ? 0 : lane; }
 bool gpu_available() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0; }

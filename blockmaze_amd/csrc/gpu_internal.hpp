@@ -13,10 +13,10 @@ namespace zk {
 class GpuContext {
  public:
   int device = 0; hipStream_t stream = nullptr; hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t fork_event = nullptr; hipEvent_t join_event[4] = {nullptr, nullptr, nullptr, nullptr}; hipDeviceProp_t prop;
-  GpuContext() {
+  explicit GpuContext(int device_index) {
     // (GPU_MAX_HW_QUEUES is raised by the library constructor in gpu.hip, before any HIP call of this process can have read it)
     int n = 0; if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
-    const char *e = getenv("ZK_DEVICE"); if (!e) e = getenv("LOCAL_RANK"); device = e ? atoi(e) % n : 0;
+    device = device_index % n;
     HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipGetDeviceProperties(&prop, device)); HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));   // (a high-priority main stream was measured: no gain for one proof, 15 % loss with four in flight)
     for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking)); HIP_CHECK(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming)); for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&join_event[i], hipEventDisableTiming));
   }

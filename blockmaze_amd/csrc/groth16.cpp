@@ -287,8 +287,8 @@ static void finish_setup(Prover::Impl &p) {
   p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
   p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host = PinnedBuf<Fe32>(p.nv + 1 + 8); p.packed = DevBuf<uint8_t>(32 * (p.nv + 1 + 8));
 }
-Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) : impl(new Impl) {
-  Impl &p = *impl; p.lane = gpu_lane_acquire(); LaneScope lane_scope(p.lane); p.nv = pk.cs.n_vars; p.ni = pk.cs.n_inputs; if (shard_world == 0 || shard_rank >= shard_world) throw std::runtime_error("prover: bad shard"); p.cs.reset(new R1csDev(pk.cs)); p.dom.reset(new Domain(pk.cs.n_cons + p.ni + 1)); p.m = p.dom->m();
+Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world, int device_slot) : impl(new Impl) {
+  Impl &p = *impl; p.lane = gpu_lane_acquire(device_slot); LaneScope lane_scope(p.lane); p.nv = pk.cs.n_vars; p.ni = pk.cs.n_inputs; if (shard_world == 0 || shard_rank >= shard_world) throw std::runtime_error("prover: bad shard"); p.cs.reset(new R1csDev(pk.cs)); p.dom.reset(new Domain(pk.cs.n_cons + p.ni + 1)); p.m = p.dom->m();
   const bool transformed = pk.H_lagrange.size() == p.m && pk.L_star.size() == p.nv + 1;   // a key from the container carries H and L only in their transformed form
   if (pk.A.size() != p.nv + 1 || (!transformed && (pk.H.size() != p.m - 1 || pk.L.size() != p.nv - p.ni))) throw std::runtime_error("proving key: query sizes do not match the constraint system");
   if (transformed && pk.H.empty() && !(env_int("ZK_H_LAGRANGE", 1) != 0 && env_int("ZK_FOLD_C", 1) != 0)) throw std::runtime_error("proving key: loaded from a container of transformed queries, which ZK_H_LAGRANGE=0 / ZK_FOLD_C=0 cannot use (set ZK_KEY_CACHE=0)");
@@ -309,7 +309,7 @@ Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world) 
   p.B_idx = std::make_shared<DevBuf<uint32_t>>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx->upload(pk.B_idx.data(), pk.B_idx.size());
 }
 Prover::Prover(const Prover &peer) : impl(new Impl) {
-  Impl &p = *impl; const Impl &o = *peer.impl; p.lane = gpu_lane_acquire(); LaneScope lane_scope(p.lane);
+  Impl &p = *impl; const Impl &o = *peer.impl; p.lane = gpu_lane_acquire(gpu_slot_of_lane(o.lane)); LaneScope lane_scope(p.lane);   // same device as the peer: the shared tables live there
   p.h_lagrange = o.h_lagrange; p.c_fold = o.c_fold; p.nv = o.nv; p.ni = o.ni; p.m = o.m; p.a0 = o.a0; p.l0 = o.l0; p.b0 = o.b0; p.h0 = o.h0;
   p.alpha_g1 = o.alpha_g1; p.beta_g1 = o.beta_g1; p.delta_g1 = o.delta_g1; p.beta_g2 = o.beta_g2; p.delta_g2 = o.delta_g2;
   p.cs.reset(new R1csDev(*o.cs)); p.dom.reset(new Domain(*o.dom)); p.B_idx = o.B_idx;
@@ -317,6 +317,7 @@ Prover::Prover(const Prover &peer) : impl(new Impl) {
   finish_setup(p);
 }
 Prover::~Prover() { if (impl) { LaneScope lane_scope(impl->lane); try { gpu_sync(); } catch (...) {} impl.reset(); } }
+int Prover::device_slot() const { return gpu_slot_of_lane(impl->lane); }
 size_t Prover::num_variables() const { return impl->nv; }
 size_t Prover::num_inputs() const { return impl->ni; }
 size_t Prover::domain_size() const { return impl->m; }

@@ -56,10 +56,11 @@ class Prover {                                    // a proving key resident in H
  public:
   // shard_rank / shard_world: this object holds only the contiguous slice [n*rank/world, n*(rank+1)/world) of every query (kernel K7);
   // a sharded prover produces partial sums (prove_partial), any process then adds the ranks' partials and assembles the proof (finish_from_partials)
-  explicit Prover(const ProvingKeyHost &pk, size_t shard_rank = 0, size_t shard_world = 1); ~Prover();
+  explicit Prover(const ProvingKeyHost &pk, size_t shard_rank = 0, size_t shard_world = 1, int device_slot = 0); ~Prover();   // device_slot: index into the process's device list (ZK_DEVICES)
   // a second prover on the same key: shares the peer's immutable device state (query tables, twiddles, constraint system: 1.8 GB for send) and owns only its
   // streams, sort / bucket workspaces and vectors (about 0.25 GB), so a pool of provers per key costs little HBM and no second key load
   explicit Prover(const Prover &peer);
+  int device_slot() const;
   size_t num_variables() const; size_t num_inputs() const; size_t domain_size() const;
   // z: full assignment without ONE (canonical).  r, s: prover randomness (canonical; nullptr = fresh CSPRNG values).
   // Returns false if z does not satisfy the constraint system (the reference then emits its default proof, sendcgo.cpp:209-214).

@@ -266,3 +266,10 @@ def test_key_container_gives_the_same_prover(tmp_path):
     e.keygen("send", pk_path, vk_path, seed=0xC0FFEF)                                   # a different key at the same path: the old container must not be used
     assert L.zkgpu_key_container_valid(pk_path.encode()) == 0
     p = e.Prover(pk_path); c = p.prove(z, 11, 22); p.close(); assert c != a and e.verify(vk_path, c, w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]]))
+
+def test_key_generation_executables(tmp_path):
+    """the reference's send_key / mint_key (src/X/getpvk.cpp:41-51): write Xpk.txt / Xvk.txt into the directory; the files load and prove"""
+    exe = os.path.join(ROOT, "blockmaze_amd", "bin", "mint_key"); r = subprocess.run([exe], cwd=str(tmp_path), capture_output=True, text=True, env=dict(os.environ, ZK_KEY_SEED="77")); assert r.returncode == 0, r.stderr
+    pk, vk = str(tmp_path / "mintpk.txt"), str(tmp_path / "mintvk.txt"); assert os.path.getsize(pk) > 40e6 and os.path.getsize(vk) > 1000
+    m = w.mint_instance(9); wp = str(tmp_path / "w.bin"); e.witness_mint_redeem(False, *hexargs(w.mint_args(m)), wp); p = e.Prover(pk); proof = p.prove(o.load_witness(wp)); p.close()
+    assert e.verify(vk, proof, w.pack_public([m["cmtA_old"], m["sn_old"], m["cmtA"]], m["value_s"]))
