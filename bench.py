@@ -200,7 +200,7 @@ def run_rank(args):
     if os.path.exists(pmc):
         try: j = json.load(open(pmc)); traffic = j.get("k_msm_accumulate_H", {}).get("hbm_bytes_per_launch"); traffic_src = "profiles/pmc_summary.json (%s)" % j.get("tag", "untagged")
         except Exception: traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_msm_accumulate_tasks<Fq> (H query)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+    roofline = {"bound": "hbm", "kernel": "k_msm_accumulate_slices<Fq> (H query)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": H_PAIRS * BYTES_PER_G1_PAIR}
     # what actually bounds that kernel: 254-bit field products on the integer VALU.  One mixed addition = 10 products; the H accumulation does one per
     # non-zero signed 16-bit digit (262,143 scalars x 16 windows, a digit is zero with probability 2^-16); ceiling = tools/fmul_bench.hip on the same chip

@@ -78,7 +78,8 @@ HeldUnit acquire_prover(CircuitKind k) {
       slot.units = std::move(fresh); slot.stamp = st;
       if (!cached) write_container_quietly(path, pk); }
     units = slot.units; turn = slot.next.fetch_add(1); }
-  for (size_t j = 0; j < units->size(); j++) { const auto &u = (*units)[(turn + j) % units->size()]; std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) return HeldUnit{u, std::move(lk)}; }   // first free member, starting at a rotating position
+  const size_t D = (size_t)std::max(1, gpu_device_slots()), start = turn % D;   // first free member; the walk starts on a rotating DEVICE (the list is interleaved by device), so one device's callers keep reusing its first member — warm circuit board, warm buffers —
+  for (size_t j = 0; j < units->size(); j++) { const auto &u = (*units)[(start + j) % units->size()]; std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) return HeldUnit{u, std::move(lk)}; }   // and only concurrent callers fan out
   const std::shared_ptr<ProverUnit> &u = (*units)[turn % units->size()]; return HeldUnit{u, std::unique_lock<std::mutex>(u->busy)};
 }
 std::shared_ptr<PreparedVerifyingKey> vk_for_path(const std::string &path) {

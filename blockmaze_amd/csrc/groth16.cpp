@@ -154,9 +154,11 @@ std::vector<Section> sections_of(const ProvingKeyHost &pk) {
   for (int m = 0; m < 3; m++) { s.push_back({pk.cs.rowptr[m].data(), pk.cs.rowptr[m].size() * 4}); s.push_back({pk.cs.col[m].data(), pk.cs.col[m].size() * 4}); s.push_back({pk.cs.coeff[m].data(), pk.cs.coeff[m].size() * 32}); }
   return s; }
 }  // namespace
+static int env_int_early(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 bool key_stamp_of(const std::string &path, KeyStamp &out) { struct stat st; if (stat(path.c_str(), &st)) return false; out.size = st.st_size; out.mtime_s = st.st_mtim.tv_sec; out.mtime_ns = st.st_mtim.tv_nsec; return true; }
 std::string key_container_path(const std::string &pk_path) {
   const char *on = getenv("ZK_KEY_CACHE"); if (on && atoi(on) == 0) return "";
+  if (env_int_early("ZK_H_LAGRANGE", 1) == 0 || env_int_early("ZK_FOLD_C", 1) == 0) return "";   // the container holds the TRANSFORMED queries: a run that switches a transform off works from the text key
   const char *dir = getenv("ZK_KEY_CACHE_DIR"); if (!dir || !*dir) return pk_path + ".gpucache";
   std::string flat = pk_path; for (char &ch : flat) if (ch == '/') ch = '_'; return std::string(dir) + "/" + flat + ".gpucache"; }
 void save_key_container(const std::string &path, const ProvingKeyHost &pk, const KeyStamp &src) {
@@ -325,18 +327,28 @@ size_t Prover::domain_size() const { return impl->m; }
 void Prover::set_witness(const Fe32 *z, bool montgomery) {
   Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); const size_t n = p.nv + 1, words = (n + 63) / 64;
   Fe32 one; if (montgomery) memcpy(&one, FrParams::R1, 32); else { memset(&one, 0, 32); one.l[0] = 1; }
-  // compact form (k_expand_witness): bitmaps of the entries equal to one / to anything else than 0 and 1, offsets, and the "anything else" values only
+  // compact form (k_expand_witness): bitmaps of the entries equal to one / to anything else than 0 and 1, offsets, and the "anything else" values only.  The scan of the
+  // 7 MB assignment is memory-bound on one core (0.3 ms for send), so the prover's four submit threads — idle at this point of a proof — take a quarter of the words
+  // each; every thread owns a quarter of the value area, the per-word offsets make the pieces look like one list to the kernel.
   uint8_t *pk = reinterpret_cast<uint8_t *>(p.z_host.get()); uint64_t *ones = (uint64_t *)pk, *other = ones + words; uint32_t *off = (uint32_t *)(other + words);
-  const size_t vals_at = ((words * 20 + 31) / 32) * 32; Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4; size_t n_other = 0; bool compact = true;
+  const size_t vals_at = ((words * 20 + 31) / 32) * 32; Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
   uint64_t o1[4]; memcpy(o1, &one, 32); const uint64_t *zz = reinterpret_cast<const uint64_t *>(z) - 4;   // zz + 4 i = entry i of [ONE, z_1 .. z_n]; entry 0 is handled apart
-  for (size_t w = 0; w < words && compact; w++) { uint64_t mo = 0, mx = 0; const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; off[w] = (uint32_t)n_other;
-    for (size_t i = lo ? lo : 1; i < hi; i++) { const uint64_t *v = zz + 4 * i;                                // branch-free classification of the block
-      const uint64_t nz = (v[0] | v[1] | v[2] | v[3]) != 0, is1 = ((v[0] ^ o1[0]) | (v[1] ^ o1[1]) | (v[2] ^ o1[2]) | (v[3] ^ o1[3])) == 0; mo |= is1 << (i - lo); mx |= (nz & (is1 ^ 1)) << (i - lo); }
-    if (!lo) mo |= 1;                                                                                          // the constant ONE
-    const size_t cnt = (size_t)__builtin_popcountll(mx); if (n_other + cnt > max_other) { compact = false; break; }
-    for (uint64_t m = mx; m; m &= m - 1) memcpy(&vals[n_other++], zz + 4 * (lo + (size_t)__builtin_ctzll(m)), 32);
-    ones[w] = mo; other[w] = mx; }
-  if (compact) { size_t bytes = vals_at + 32 * n_other; upload_async(p.packed.get(), pk, bytes); expand_witness_dev(p.packed.get(), words, one, n, p.z.get()); }
+  constexpr size_t T = 4; const size_t cap_t = max_other / T; size_t used[T] = {0, 0, 0, 0}; bool fits[T] = {true, true, true, true};
+  auto scan = [&](size_t t) { const size_t w0 = words * t / T, w1 = words * (t + 1) / T, base = t * cap_t; size_t n_other = 0;
+    for (size_t w = w0; w < w1; w++) { uint64_t mo = 0, mx = 0; const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; off[w] = (uint32_t)(base + n_other);
+      for (size_t i = lo ? lo : 1; i < hi; i++) { const uint64_t *v = zz + 4 * i;                                // branch-free classification of the block
+        const uint64_t nz = (v[0] | v[1] | v[2] | v[3]) != 0, is1 = ((v[0] ^ o1[0]) | (v[1] ^ o1[1]) | (v[2] ^ o1[2]) | (v[3] ^ o1[3])) == 0; mo |= is1 << (i - lo); mx |= (nz & (is1 ^ 1)) << (i - lo); }
+      if (!lo) mo |= 1;                                                                                          // the constant ONE
+      const size_t cnt = (size_t)__builtin_popcountll(mx); if (n_other + cnt > cap_t) { fits[t] = false; return; }
+      for (uint64_t m = mx; m; m &= m - 1) memcpy(&vals[base + n_other++], zz + 4 * (lo + (size_t)__builtin_ctzll(m)), 32);
+      ones[w] = mo; other[w] = mx; }
+    used[t] = n_other; };
+  static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
+  if (threaded && words >= 512) { for (size_t t = 1; t < T; t++) { if (!p.workers[t]) p.workers[t].reset(new SubmitWorker(p.lane)); p.workers[t]->post([&scan, t] { scan(t); }); } scan(0); for (size_t t = 1; t < T; t++) p.workers[t]->wait(); }
+  else for (size_t t = 0; t < T; t++) scan(t);
+  const bool compact = fits[0] && fits[1] && fits[2] && fits[3];
+  if (compact) { upload_async(p.packed.get(), pk, vals_at); for (size_t t = 0; t < T; t++) if (used[t]) upload_async(p.packed.get() + vals_at + 32 * t * cap_t, pk + vals_at + 32 * t * cap_t, 32 * used[t]);
+    expand_witness_dev(p.packed.get(), words, one, n, p.z.get()); }
   else { Fe32 *h = p.z_host.get(); h[0] = one; memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * n); }      // dense assignment: plain copy
   if (!montgomery) fr_to_mont_dev(p.z.get(), n);
   last.upload_ms = now_ms() - t0;
