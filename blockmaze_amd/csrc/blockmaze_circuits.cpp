@@ -1,6 +1,8 @@
 // BlockMaze statement circuits — see blockmaze_circuits.hpp.  Allocation and constraint order follow the reference's
 // gadget constructors / generate_r1cs_constraints() line by line (cited per class); the code itself is written against
 // circuit::Board.
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include "blockmaze_circuits.hpp"
@@ -118,16 +120,18 @@ struct SendCircuit : Circuit {
     r_s->constraints(); crh->constraints(); sn->constraints(); prf->constraints(); sn_old->constraints();
     cmtA_old->constraints(); cmt_old->constraints(); cmtS->constraints(); cmt_s->constraints(); cmtA->constraints(); cmt_new->constraints(); }
   void assign(const SendInputs &in) { Board &b = board;                                                               // gadget.tcc:228-271
+    static const bool tr = getenv("ZK_TRACE_WITNESS") != nullptr; auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; double t0 = now(), t1 = 0, t2 = 0, t3 = 0;
     auto note_fill = [&](Var vo_packed, Var vs_packed) { fill(b, value_old, u64_bits(in.value_old)); b.val[vo_packed] = value_by_order(b, value_old);
       sn_old->fill(blob_bits(in.sn_old.b, 32)); r_old->fill(blob_bits(in.r_old.b, 32)); fill(b, value_s, u64_bits(in.value_s)); b.val[vs_packed] = value_by_order(b, value_s);
       pk_recv->fill(blob_bits(in.pk_recv.b, 20)); r_s->fill(blob_bits(in.r_s.b, 32)); };
     note_fill(l_value_old_packed, l_value_s_packed); less->witness();
     note_fill(s_value_old_packed, s_value_s_packed); fill(b, value, u64_bits(in.value)); b.val[s_value_packed] = value_by_order(b, value);
     sn->fill(blob_bits(in.sn.b, 32)); r->fill(blob_bits(in.r.b, 32)); sk->fill(blob_bits(in.sk.b, 32)); pk_sender->fill(blob_bits(in.pk_sender.b, 20));
-    b.val[ZERO] = HFr::zero();
-    crh->witness(); prf->witness(); cmt_old->witness(); cmt_s->witness(); cmt_new->witness();
+    b.val[ZERO] = HFr::zero(); t1 = now();
+    // sequential order of the reference: crh (writes r_s), prf (writes sn), cmt_old, cmt_s (reads r_s), cmt_new (reads sn).  Two waves of independent hashers give the same board:
+    run_parallel({[&] { crh->witness(); }, [&] { prf->witness(); }, [&] { cmt_old->witness(); }}); run_parallel({[&] { cmt_s->witness(); }, [&] { cmt_new->witness(); }}); t2 = now();
     cmtA_old->fill(blob_bits(in.cmtA_old.b, 32)); cmtS->fill(blob_bits(in.cmtS.b, 32)); cmtA->fill(blob_bits(in.cmtA.b, 32));
-    unpacker->witness_from_bits(); }
+    unpacker->witness_from_bits(); t3 = now(); if (tr) fprintf(stderr, "trace-witness: fills %.3f hashers %.3f rest %.3f ms\n", t1 - t0, t2 - t1, t3 - t2); }
 };
 
 // ======================================================================================================================
@@ -158,9 +162,11 @@ struct MintRedeemCircuit : Circuit {
     fill(b, value_s, u64_bits(in.value_s)); b.val[value_s_packed] = value_by_order(b, value_s);
     sk->fill(blob_bits(in.sk.b, 32)); r->fill(blob_bits(in.r.b, 32)); r_old->fill(blob_bits(in.r_old.b, 32));
     if (redeem) { sn->fill(blob_bits(in.sn.b, 32)); sn_old->fill(blob_bits(in.sn_old.b, 32)); less->witness(); }
-    b.val[ZERO] = HFr::zero(); prf->witness();
-    if (!redeem) { sn->fill(blob_bits(in.sn.b, 32)); sn_old->fill(blob_bits(in.sn_old.b, 32)); }                        // mint/gadget.tcc:213-221
-    cmt_old->witness(); cmt_new->witness(); cmtA_old->fill(blob_bits(in.cmtA_old.b, 32)); cmtA->fill(blob_bits(in.cmtA.b, 32)); unpacker->witness_from_bits(); }
+    b.val[ZERO] = HFr::zero();
+    if (!redeem) sn_old->fill(blob_bits(in.sn_old.b, 32));                                                              // (no hasher writes sn_old: filling it before the first wave changes nothing)
+    run_parallel({[&] { prf->witness(); }, [&] { cmt_old->witness(); }});                                               // prf writes sn, cmt_old reads sn_old / r_old / value_old
+    if (!redeem) sn->fill(blob_bits(in.sn.b, 32));                                                                      // mint/gadget.tcc:213-221: mint overwrites the computed serial number with the given one
+    cmt_new->witness(); cmtA_old->fill(blob_bits(in.cmtA_old.b, 32)); cmtA->fill(blob_bits(in.cmtA.b, 32)); unpacker->witness_from_bits(); }
 };
 
 
@@ -232,10 +238,11 @@ struct DepositCircuit : Circuit {
     pk_recv->fill(blob_bits(in.pk_recv.b, 20)); r_s->fill(blob_bits(in.r_s.b, 32)); sn_A_old->fill(blob_bits(in.sn_A_old.b, 32)); sn_old->fill(blob_bits(in.sn_old.b, 32)); r_old->fill(blob_bits(in.r_old.b, 32));
     sn->fill(blob_bits(in.sn.b, 32)); r->fill(blob_bits(in.r.b, 32)); sk->fill(blob_bits(in.sk.b, 32));
     b.set_bit(value_enforce, in.value_s != 0); b.val[ZERO] = HFr::zero();
-    prf_sn->witness(); prf_sn_s->witness(); sn_s->fill(blob_bits(in.sn_s.b, 32));
-    cmt_s->witness(); cmt_old->witness(); cmt_new->witness(); cmtS->fill(blob_bits(in.cmtS.b, 32)); cmtB_old->fill(blob_bits(in.cmtB_old.b, 32)); cmtB->fill(blob_bits(in.cmtB.b, 32));
     if (in.path.size() != depth || in.index_bits.size() != depth) throw std::runtime_error("deposit: Merkle path length does not match the tree depth");
-    merkle->witness(in.path, in.index_bits); rt->fill(blob_bits(in.rt.b, 32)); unpacker->witness_from_bits(); }
+    // reference order: prf_sn (writes sn), prf_sn_s (writes sn_s), sn_s := given, cmt_s, cmt_old, cmt_new (reads sn), the three commitments := given, merkle (reads cmtS).
+    run_parallel({[&] { prf_sn->witness(); }, [&] { prf_sn_s->witness(); }, [&] { cmt_s->witness(); }, [&] { cmt_old->witness(); }}); sn_s->fill(blob_bits(in.sn_s.b, 32)); cmtS->fill(blob_bits(in.cmtS.b, 32)); cmtB_old->fill(blob_bits(in.cmtB_old.b, 32));
+    run_parallel({[&] { merkle->witness(in.path, in.index_bits); }, [&] { cmt_new->witness(); }}); cmtB->fill(blob_bits(in.cmtB.b, 32));
+    rt->fill(blob_bits(in.rt.b, 32)); unpacker->witness_from_bits(); }
 };
 
 // libsnark's merkle_tree_check_read_gadget composed as its own self-test does (merkle_tree_check_read_gadget.tcc:131-196): address bits, leaf, root,

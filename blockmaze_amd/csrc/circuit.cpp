@@ -1,6 +1,10 @@
 // gadgetlib1 subset restated on circuit::Board — see circuit.hpp for the source map.
 #include <algorithm>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include "circuit.hpp"
 
 namespace zk { namespace circuit {
@@ -171,5 +175,30 @@ void Sha256Compression::witness_reference() { Impl &s = *impl; s.ms->witness(); 
   for (size_t i = 0; i < 4; i++) { s.b.val[s.unreduced_output[i]] = s.b.val[s.rounds[3 - i]->packed_d] + s.b.val[s.rounds[63 - i]->packed_new_a];
                                    s.b.val[s.unreduced_output[4 + i]] = s.b.val[s.rounds[3 - i]->packed_h] + s.b.val[s.rounds[63 - i]->packed_new_e]; }
   for (auto &r : s.reduce) r.witness(); }
+
+
+// ---- the helper pool of run_parallel ----------------------------------------------------------------------------------------
+namespace {
+struct Batch { std::mutex m; std::condition_variable cv; size_t remaining; std::exception_ptr err; };
+struct Job { std::function<void()> fn; Batch *batch; };
+class TaskPool {
+ public:
+  static TaskPool &instance() { static TaskPool *p = new TaskPool; return *p; }          // (never destroyed: the threads may outlive static destruction of a host process that exits from another thread)
+  void run(std::vector<std::function<void()>> &tasks) {
+    if (tasks.size() <= 1 || threads_.empty()) { for (auto &t : tasks) t(); return; }
+    Batch b; b.remaining = tasks.size();
+    { std::lock_guard<std::mutex> lk(m_); for (auto &t : tasks) q_.push_back(Job{std::move(t), &b}); } cv_.notify_all();
+    for (;;) { Job j; { std::lock_guard<std::mutex> lk(m_); if (q_.empty()) break; j = std::move(q_.front()); q_.pop_front(); } execute(j); }   // the caller works as well (possibly on another caller's tasks)
+    std::unique_lock<std::mutex> lk(b.m); b.cv.wait(lk, [&] { return b.remaining == 0; }); if (b.err) std::rethrow_exception(b.err);
+  }
+ private:
+  TaskPool() { const char *e = getenv("ZK_WITNESS_THREADS"); long n = e ? atol(e) : 3; unsigned hw = std::thread::hardware_concurrency(); if (hw && (long)hw / 2 < n + 1) n = (long)hw / 2 - 1; if (n < 0) n = 0; if (n > 15) n = 15;
+    for (long i = 0; i < n; i++) threads_.emplace_back([this] { loop(); }); for (auto &t : threads_) t.detach(); }
+  static void execute(Job &j) { std::exception_ptr e; try { j.fn(); } catch (...) { e = std::current_exception(); } std::lock_guard<std::mutex> lk(j.batch->m); if (e && !j.batch->err) j.batch->err = e; if (--j.batch->remaining == 0) j.batch->cv.notify_all(); }
+  void loop() { for (;;) { Job j; { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [this] { return !q_.empty(); }); j = std::move(q_.front()); q_.pop_front(); } execute(j); } }
+  std::mutex m_; std::condition_variable cv_; std::deque<Job> q_; std::vector<std::thread> threads_;
+};
+}  // namespace
+void run_parallel(std::vector<std::function<void()>> tasks) { TaskPool::instance().run(tasks); }
 
 }  }  // namespace zk::circuit

@@ -20,6 +20,7 @@
 //                              gadgets/hashes/digest_selector_gadget.tcc
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <vector>
 #include "gpu.hpp"
@@ -93,5 +94,10 @@ struct Sha256Compression {
   void witness_reference();   // gadget-by-gadget evaluation exactly as libsnark does it; kept as the cross-check of the native path
 };
 LCArray sha256_default_iv();          // sha256_components.tcc:38-56
+
+// Witness generation is 9 (send) to 18 (deposit) SHA-256 compression gadgets of 24,792 variables each, most of them independent of one another: run_parallel hands the
+// tasks of one wave to a small process-wide pool of helper threads (the caller works too) and returns when all of them are done.  Tasks of one call must write disjoint
+// variables and read nothing another task of the same call writes — the circuits below order their waves so that this holds and the result equals the sequential order's.
+void run_parallel(std::vector<std::function<void()>> tasks);
 
 }  }  // namespace zk::circuit

@@ -339,18 +339,32 @@ __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *_
 }
 // The same accumulation for the group-sorted H query: no plan, lane t takes slice t % S of bucket t / S — the entries [cnt*j/S, cnt*(j+1)/S) of the bucket.  With
 // uniform scalars every slice of a wave is within an entry or two of the same length.
-template <class F>
+// point gathers of the accumulation kernels: every table entry is read once per MSM, so the loads are marked non-temporal (VARIANT & 1) — they should not evict the
+// sorted entries and partial sums from the L2
+template <int NT, class F> __device__ __forceinline__ Affine<F> load_point(const Affine<F> *p) {
+  if constexpr (NT) { typedef uint32_t v4u __attribute__((ext_vector_type(4))); Affine<F> r; const uint32_t *s = reinterpret_cast<const uint32_t *>(p); uint32_t *d = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(Affine<F>) / 16; i++) { v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(s) + i); d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w; } return r; }
+  else return *p;
+}
+template <int VARIANT, class F>
 __global__ void __launch_bounds__(256) k_msm_accumulate_slices(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                                uint32_t n_buckets, XYZZ<F> *__restrict__ partials) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= n_buckets * HSORT_SLICES) return;
   const uint32_t b = t / HSORT_SLICES, j = t % HSORT_SLICES, cnt = counts[b], beg = offsets[b] + (cnt * j) / HSORT_SLICES, end = offsets[b] + (cnt * (j + 1)) / HSORT_SLICES;
-  XYZZ<F> acc = XYZZ<F>::inf();
+  XYZZ<F> acc = XYZZ<F>::inf(); constexpr int NT = VARIANT & 1;
   if (beg < end) {
-    uint32_t v = entries[beg], vn = beg + 1 < end ? entries[beg + 1] : v; Affine<F> p = points[v & ~MSM_ENTRY_SIGN];
+    if constexpr (VARIANT & 2) {                             // two points in flight
+      uint32_t v0 = entries[beg], v1 = beg + 1 < end ? entries[beg + 1] : v0, v2 = beg + 2 < end ? entries[beg + 2] : v1; Affine<F> p0 = load_point<NT>(points + (v0 & ~MSM_ENTRY_SIGN)), p1 = load_point<NT>(points + (v1 & ~MSM_ENTRY_SIGN));
 #pragma unroll 1
-    for (uint32_t e = beg; e < end; e++) {                 // software pipeline as in k_msm_accumulate_tasks
-      Affine<F> pn = points[vn & ~MSM_ENTRY_SIGN]; uint32_t vnn = e + 2 < end ? entries[e + 2] : vn;
-      if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; vn = vnn; } }
+      for (uint32_t e = beg; e < end; e++) { Affine<F> p2 = load_point<NT>(points + (v2 & ~MSM_ENTRY_SIGN)); uint32_t v3 = e + 3 < end ? entries[e + 3] : v2;
+        if (v0 >> 31) p0.y = p0.y.neg(); acc.madd_inl(p0); v0 = v1; p0 = p1; v1 = v2; p1 = p2; v2 = v3; }
+    } else {
+      uint32_t v = entries[beg], vn = beg + 1 < end ? entries[beg + 1] : v; Affine<F> p = load_point<NT>(points + (v & ~MSM_ENTRY_SIGN));
+#pragma unroll 1
+      for (uint32_t e = beg; e < end; e++) {                 // software pipeline as in k_msm_accumulate_tasks
+        Affine<F> pn = load_point<NT>(points + (vn & ~MSM_ENTRY_SIGN)); uint32_t vnn = e + 2 < end ? entries[e + 2] : vn;
+        if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; vn = vnn; } } }
   partials[t] = acc;
 }
 template <class F>

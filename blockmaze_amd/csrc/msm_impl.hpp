@@ -165,7 +165,11 @@ struct MsmImpl {
 #undef ZK_CALL
     }
     if (hs_run) {
-      { Stage st((label + ".accumulate").c_str(), s); hipLaunchKernelGGL((k_msm_accumulate_slices<F>), dim3(cdiv(nbk * HSORT_SLICES, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), (uint32_t)nbk, (XYZZ<F> *)partials.get()); }
+      { Stage st((label + ".accumulate").c_str(), s); static const int av = [] { const char *e = getenv("ZK_ACC_VARIANT"); return e ? atoi(e) & 3 : 0; }();
+#define ZK_ACC(V) hipLaunchKernelGGL((k_msm_accumulate_slices<V, F>), dim3(cdiv(nbk * HSORT_SLICES, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), (uint32_t)nbk, (XYZZ<F> *)partials.get())
+        if (av == 0) ZK_ACC(0); else if (av == 1) ZK_ACC(1); else if (av == 2) ZK_ACC(2); else ZK_ACC(3);
+#undef ZK_ACC
+      }
       { Stage st((label + ".combine").c_str(), s); hipLaunchKernelGGL((k_msm_combine_slices<F>), dim3(cdiv(nbk * 4, 256)), dim3(256), 0, s, (const XYZZ<F> *)partials.get(), (uint32_t)nbk, (XYZZ<F> *)buckets.get()); }
     } else {
     { Stage st((label + ".accumulate").c_str(), s);
