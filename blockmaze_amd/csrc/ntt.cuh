@@ -100,7 +100,12 @@ __device__ __forceinline__ void ntt_lds_dif(Fr *tile, Fr *twl, int logN, int log
 __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(const Fr *__restrict__ src, Fr *__restrict__ dst, const Fr *__restrict__ pre, const Fr *__restrict__ tw,
                                                                int logn, int log_n1, int logC, int radix_log, size_t stride_in, size_t stride_out) {
   extern __shared__ uint32_t lds_raw[]; Fr *tile = reinterpret_cast<Fr *>(lds_raw);
-  const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, c0 = blockIdx.x << logC, elems = (1u << log_n1) << logC, half_n = 1u << (logn - 1);
+  // XCD-aware tile order.  A one-column tile reads 32 bytes of every 128-byte line it touches; the other three quarters belong to the next three columns.  Workgroup b
+  // runs on XCD b % 8 (MI355X_MICROARCH.md, observed dispatch order), each XCD has its own L2, so with tile = blockIdx.x four different L2s fetched every line: 4.2x the
+  // algorithmic traffic (PMC, profiles/r02e).  Giving XCD x the contiguous columns [x * n_tiles / 8, (x + 1) * n_tiles / 8) in dispatch order lets the four tiles of a
+  // line share one L2 fetch.  (A different placement only costs the extra fetches again: results do not depend on it.)
+  const uint32_t n_tiles = gridDim.x, tile_no = n_tiles >= 8 && n_tiles % 8 == 0 ? (blockIdx.x % 8) * (n_tiles / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, c0 = tile_no << logC, elems = (1u << log_n1) << logC, half_n = 1u << (logn - 1);
   const Fr *s = src + blockIdx.y * stride_in; Fr *d = dst + blockIdx.y * stride_out;
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t g = ((w >> logC) << log_n2) + c0 + (w & (C - 1)); Fr v = s[g]; if (pre) v = v * pre[g]; tile[ntt_pad(w)] = v; }
   __syncthreads();

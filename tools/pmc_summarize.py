@@ -22,7 +22,7 @@ for k in sorted(set(fetch) | set(write), key=lambda k: (short(k[0]), k[1])):
     f = fetch.get(k, (0.0, 0)); w = write.get(k, (0.0, 0))
     out["kernels"]["%s grid=%d" % (short(k[0]), k[1])] = {"launches": max(f[1], w[1]), "FETCH_SIZE_KB_raw": round(f[0], 2), "WRITE_SIZE_KB": round(w[0], 2), "hbm_bytes_per_launch": int(2 * f[0] * 1024 + w[0] * 1024)}
 # the dominant kernel: bucket accumulation of the H-query MSM = the k_msm_accumulate_tasks<Fq> launch that moves the most bytes (4.2 M point gathers; the witness MSMs have a few 10^4)
-acc = [(k, v) for k, v in out["kernels"].items() if (k.startswith("k_msm_accumulate_tasks<Fq") or k.startswith("k_msm_accumulate_slices<Fq")) and "<Fq2" not in k]
+acc = [(k, v) for k, v in out["kernels"].items() if (k.startswith("k_msm_accumulate_tasks<") or k.startswith("k_msm_accumulate_slices<")) and "Fq2" not in k]
 if acc:
     name, v = max(acc, key=lambda kv: kv[1]["hbm_bytes_per_launch"]); out["k_msm_accumulate_H"] = dict(v, kernel=name)
 pw = [(k, v) for k, v in out["kernels"].items() if k.startswith("k_qap_pointwise")]
