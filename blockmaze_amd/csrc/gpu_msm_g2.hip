@@ -9,5 +9,5 @@ MsmG2::MsmG2(const G2AffineRaw *p, size_t n, int c, bool fo, bool tables, bool u
 MsmG2::MsmG2(const MsmG2 &peer, bool fo, bool uniform) : impl(new Impl(peer.impl->bases, fo, uniform)) {}
 MsmG2::~MsmG2() = default;
 void MsmG2::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
-host::HG2 MsmG2::result() { impl->finish_sync(); return combine<host::HFq2, Fq2>(impl->host_sums(), impl->WB, impl->c); }
+host::HG2 MsmG2::result() { impl->finish_sync(); if (impl->tail_mode) return host_tail_sum<host::HFq2, Fq2>(*impl); return combine<host::HFq2, Fq2>(impl->host_sums(), impl->WB, impl->c); }
 }  // namespace zk

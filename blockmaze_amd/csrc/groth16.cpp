@@ -278,7 +278,12 @@ struct Prover::Impl {
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
   std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; std::shared_ptr<DevBuf<uint32_t>> B_idx; DevBuf<Fe32> z, abc; DevBuf<uint8_t> packed; PinnedBuf<Fe32> z_host;
   std::unique_ptr<SubmitWorker> workers[4];
-  ~Impl() { for (auto &w : workers) w.reset(); }
+  // The submit thread of a witness MSM also waits for its stream and finishes the MSM on the host (Horner combine, or the host tail of msm_impl.hpp): four threads do that
+  // side by side while the H chain is still running.  pending[j]: job j (order B2, L, A, B1) was posted and its result slot is not valid before workers[j]->wait().
+  HG2 rB2; HG1 rL, rA, rB1; bool pending[4] = {false, false, false, false}, inline_result[4] = {false, false, false, false};
+  void settle(int j) { if (pending[j]) { pending[j] = false; workers[j]->wait(); } if (inline_result[j]) { inline_result[j] = false; switch (j) { case 0: rB2 = B2->result(); break; case 1: rL = L->result(); break; case 2: rA = A->result(); break; default: rB1 = B1->result(); } } }
+  void settle_all_quietly() { for (int j = 0; j < 4; j++) { try { settle(j); } catch (...) {} } }
+  ~Impl() { settle_all_quietly(); for (auto &w : workers) w.reset(); }
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &e) { size_t base = n / world, rem = n % world; b = rank * base + (rank < rem ? rank : rem); e = b + base + (rank < rem ? 1 : 0); }
@@ -366,15 +371,16 @@ static void enqueue_all(Prover::Impl &p) {
   // about 80 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
   // (auxiliary streams) while this one submits the critical chain
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
-  std::function<void()> jobs[4] = { [&] { p.B2->run(p.z.get(), p.B_idx->get() + p.b0); }, [&] { p.L->run(p.z.get() + (p.c_fold ? 0 : p.ni + 1) + p.l0, nullptr); },       // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
-                                    [&] { p.A->run(p.z.get() + p.a0, nullptr); }, [&] { p.B1->run(p.z.get(), p.B_idx->get() + p.b0); } };
+  Prover::Impl *pp = &p;
+  std::function<void()> jobs[4] = { [pp] { pp->B2->run(pp->z.get(), pp->B_idx->get() + pp->b0); }, [pp] { pp->L->run(pp->z.get() + (pp->c_fold ? 0 : pp->ni + 1) + pp->l0, nullptr); },       // r1cs_gg_ppzksnark.tcc:442-462,477-484; longest first
+                                    [pp] { pp->A->run(pp->z.get() + pp->a0, nullptr); }, [pp] { pp->B1->run(pp->z.get(), pp->B_idx->get() + pp->b0); } };
+  std::function<void()> finish[4] = { [pp] { pp->rB2 = pp->B2->result(); }, [pp] { pp->rL = pp->L->result(); }, [pp] { pp->rA = pp->A->result(); }, [pp] { pp->rB1 = pp->B1->result(); } };
   const int job_stream[4] = {3, 1, 0, 2};                       // the auxiliary stream each MSM was bound to in the constructor (set_stream)
   const bool use_threads = threaded;
-  bool posted[4] = {false, false, false, false};
-  struct Waiter { Prover::Impl &p; bool *posted; ~Waiter() { for (int j = 0; j < 4; j++) if (posted[j]) { try { p.workers[j]->wait(); } catch (...) {} } } } waiter{p, posted};   // never leave a job running behind an exception
+  p.settle_all_quietly();                                       // (nothing is pending unless an earlier proof was abandoned by an exception)
   auto release = [&](int point) { bool any = false; for (int j = 0; j < 4; j++) any |= start[j] == point; if (!any) return; gpu_fork_record();      // one event; each stream's wait is issued by the thread that feeds it
-    for (int j = 0; j < 4; j++) if (start[j] == point) { const int sj = job_stream[j]; std::function<void()> job = jobs[j];
-      if (use_threads) { if (!p.workers[j]) p.workers[j].reset(new SubmitWorker(p.lane)); p.workers[j]->post([sj, job] { gpu_fork_wait(sj); job(); }); posted[j] = true; } else { gpu_fork_wait(sj); job(); } } };
+    for (int j = 0; j < 4; j++) if (start[j] == point) { const int sj = job_stream[j]; std::function<void()> job = jobs[j], fin = finish[j];
+      if (use_threads) { if (!p.workers[j]) p.workers[j].reset(new SubmitWorker(p.lane)); p.workers[j]->post([sj, job, fin] { gpu_fork_wait(sj); job(); fin(); }); p.pending[j] = true; } else { gpu_fork_wait(sj); job(); p.inline_result[j] = true; } } };
   release(0);
   p.cs->eval(p.z.get(), p.abc.get(), p.m); release(1);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
@@ -386,8 +392,7 @@ static void enqueue_all(Prover::Impl &p) {
   release(4);
   if (fuse_pointwise) p.H->run_product(p.abc.get() + p.h0, p.abc.get() + p.m + p.h0, p.dom->zinv_dev() + (p.dom->zinv_is_table() ? p.h0 : 0), p.dom->zinv_is_table());
   else p.H->run(p.abc.get() + p.h0, nullptr);                                                                             // :466-473
-  for (int j = 0; j < 4; j++) if (posted[j]) { posted[j] = false; p.workers[j]->wait(); }
-}
+}   // (the witness MSMs' jobs keep running: Impl::settle(j) waits for job j where its result is needed)
 // one proof's device work.  (Replaying the five-stream DAG from a captured hipGraph was measured slower than eager submission from the five submit threads on
 // ROCm 7.2 / MI355X — 4.65 vs 3.70 ms per proof in round 1 — and was removed.)
 static void run_device(Prover::Impl &p) { enqueue_all(p); }
@@ -404,10 +409,11 @@ bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
   // The witness MSMs finish well before the H chain (row products, 7 transforms, the largest MSM).  Their Horner combines, the two scalar multiples and the
   // affine conversions of A and B run on the host meanwhile, in the order the streams complete (each result() waits for its own stream only).
   static const bool trace = getenv("ZK_TRACE_TIMES") != nullptr;
-  HG1 gA = p.alpha_g1.add(p.A->result()).add(t.r_delta), c_part = gA.mul(t.s.l).add(t.rs_delta_neg); out.A = raw_of(gA); double ta = now_ms();     // :488 and s*A of :495
-  c_part = c_part.add(p.L->result()); double tl = now_ms();
-  HG1 gB1 = p.beta_g1.add(p.B1->result()).add(t.s_delta); c_part = c_part.add(gB1.mul(t.r.l)); double tb1 = now_ms();                                // :491 and r*B1 of :495
-  HG2 gB2 = p.beta_g2.add(p.B2->result()).add(t.s_delta2); out.B = raw_of(gB2); double tb2 = now_ms();                                              // :492
+  struct Settle { Impl &p; ~Settle() { p.settle_all_quietly(); } } settle_guard{p};   // no job outlives this call, whatever throws
+  p.settle(2); HG1 gA = p.alpha_g1.add(p.rA).add(t.r_delta), c_part = gA.mul(t.s.l).add(t.rs_delta_neg); out.A = raw_of(gA); double ta = now_ms();     // :488 and s*A of :495
+  p.settle(1); c_part = c_part.add(p.rL); double tl = now_ms();
+  p.settle(3); HG1 gB1 = p.beta_g1.add(p.rB1).add(t.s_delta); c_part = c_part.add(gB1.mul(t.r.l)); double tb1 = now_ms();                                // :491 and r*B1 of :495
+  p.settle(0); HG2 gB2 = p.beta_g2.add(p.rB2).add(t.s_delta2); out.B = raw_of(gB2); double tb2 = now_ms();                                              // :492
   gpu_sync(); double t3 = now_ms();
   if (trace) fprintf(stderr, "trace: enqueue %.3f A %.3f L %.3f B1 %.3f B2 %.3f sync %.3f\n", t2 - t1, ta - t1, tl - t1, tb1 - t1, tb2 - t1, t3 - t1);
   if (!p.cs->check_result()) return false;
@@ -417,9 +423,9 @@ bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
 static void put_canon_g1(const HG1 &p, uint8_t *o) { HFq x, y; p.to_affine(x, y); x = x.from_mont(); y = y.from_mont(); memcpy(o, x.l, 32); memcpy(o + 32, y.l, 32); }
 static HG1 get_canon_g1(const uint8_t *o) { HFq x, y; memcpy(x.l, o, 32); memcpy(y.l, o + 32, 32); if (x.is_zero() && y.is_zero()) return HG1::inf(); return HG1::from_affine(x.to_mont(), y.to_mont()); }
 bool Prover::prove_partial(uint8_t out[PARTIAL_BYTES]) {
-  Impl &p = *impl; LaneScope lane_scope(p.lane); run_device(p); gpu_sync(); if (!p.cs->check_result()) return false;
-  put_canon_g1(p.A->result(), out); put_canon_g1(p.B1->result(), out + 64); put_canon_g1(p.H->result(), out + 128); put_canon_g1(p.L->result(), out + 192);
-  HFq2 x, y; p.B2->result().to_affine(x, y); HFq v[4] = {x.c0.from_mont(), x.c1.from_mont(), y.c0.from_mont(), y.c1.from_mont()}; for (int k = 0; k < 4; k++) memcpy(out + 256 + 32 * k, v[k].l, 32); return true;
+  Impl &p = *impl; LaneScope lane_scope(p.lane); run_device(p); for (int j = 0; j < 4; j++) p.settle(j); gpu_sync(); if (!p.cs->check_result()) return false;
+  put_canon_g1(p.rA, out); put_canon_g1(p.rB1, out + 64); put_canon_g1(p.H->result(), out + 128); put_canon_g1(p.rL, out + 192);
+  HFq2 x, y; p.rB2.to_affine(x, y); HFq v[4] = {x.c0.from_mont(), x.c1.from_mont(), y.c0.from_mont(), y.c1.from_mont()}; for (int k = 0; k < 4; k++) memcpy(out + 256 + 32 * k, v[k].l, 32); return true;
 }
 void Prover::finish_from_partials(const uint8_t *records, size_t n, const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
   Impl &p = *impl; HG1 eA = HG1::inf(), eB1 = HG1::inf(), eH = HG1::inf(), eL = HG1::inf(); HG2 eB2 = HG2::inf();

@@ -25,6 +25,13 @@ struct MsmImpl {
   DevBuf<uint32_t> offsets, entries, ones, ntasks, task_off, order, rank_of, block_hist, block_off, cls_start; uint32_t bsort_blocks; std::unique_ptr<Scanner> bsort_scanner; Scanner scanner, task_scanner; uint32_t max_tasks;
   DevBuf<uint8_t> buckets, partials, seg_out, seg_l2, ones_partial, ones_l2, result;   // XYZZ<F> arrays, kept as bytes to stay out of the header; result = W window sums, the ones sum, the counters
   uint8_t *h_result = nullptr;                                      // pinned copy of `result`
+  // Host tail (optional, ZK_MSM_HOST_TAIL=1; one bucket array, i.e. fixed-base tables): the last, purely dependent additions of an MSM done by the host, which idles
+  // while the device works (the MSM's submit thread does them, groth16.cpp).  Frees the device of its slowest tiny kernels, but is no faster (see the constructor).  tail = [T0: 256 sums | T1: 64 partial sums of the scalar-one path | counters].  Witness MSMs (at most
+  // 256 buckets): T0 IS the bucket array and the host does the weighted running-sum reduction (2 * 128 additions); H query: T0 holds the sums of 256 segments each.
+  static constexpr uint32_t TAIL_T0 = 256, TAIL_T1 = 64; int tail_mode = 0; uint32_t tail_n0 = 0, tail_n1 = 0; DevBuf<uint8_t> tail; uint8_t *h_tail = nullptr;   // mode 1: weighted buckets, mode 2: plain sums
+  static size_t tail_bytes() { return (size_t)(TAIL_T0 + TAIL_T1) * sizeof(XYZZ<F>) + sizeof(MsmCounters); }
+  XYZZ<F> *bucket_array() { return tail_mode == 1 ? (XYZZ<F> *)tail.get() : reinterpret_cast<XYZZ<F> *>(buckets.get()); }
+  const XYZZ<F> *host_tail0() const { return (const XYZZ<F> *)h_tail; } const XYZZ<F> *host_tail1() const { return (const XYZZ<F> *)h_tail + TAIL_T0; }
   static constexpr uint32_t HEAVY_BLOCKS = 256, GROUP = 256;
 
   uint32_t *hist() { return zeroed.get(); }
@@ -34,7 +41,7 @@ struct MsmImpl {
   MsmCounters *counters_next() { return (MsmCounters *)(zeroed.get() + 2 * (size_t)WB * NB) + (parity ^ 1); }
   size_t result_bytes() const { return (size_t)(WB + 1) * sizeof(XYZZ<F>) + sizeof(MsmCounters); }
   const XYZZ<F> *host_sums() const { return (const XYZZ<F> *)h_result; }
-  const MsmCounters *host_counters() const { return (const MsmCounters *)(h_result + (size_t)(WB + 1) * sizeof(XYZZ<F>)); }
+  const MsmCounters *host_counters() const { return tail_mode ? (const MsmCounters *)(h_tail + (size_t)(TAIL_T0 + TAIL_T1) * sizeof(XYZZ<F>)) : (const MsmCounters *)(h_result + (size_t)(WB + 1) * sizeof(XYZZ<F>)); }
 
   // Precomputed multiples 2^(cw) P unless switched off (ZK_MSM_PRECOMPUTE=0), the table would pass ZK_MSM_PRECOMPUTE_MAX_MB (default 768 MB: measured on MI355X, the
   // random 64-byte gathers from a table far beyond the 256 MB Infinity Cache cost more than the smaller bucket reduction saves — deposit at depth 32: 9.1 ms
@@ -69,8 +76,11 @@ struct MsmImpl {
     if (glv) { DevBuf<Fe32> b(1); Fe32 bm; memcpy(&bm, GLV_BETA_MONT, 32); b.upload(&bm, 1); beta = std::move(b); }
     { const char *e = getenv("ZK_MSM_SEG"); uint32_t big = e ? (uint32_t)atoi(e) : 16; if (big < 2 || big > 256 || (big & (big - 1))) big = 16; seg = NB >= 4096 ? (WB == 1 ? 4 : big) : 4; }   // one bucket array: few segments, keep the dependent chain short
     n_ones_quads = 16384;
+    if (WB == 1 && n && getenv("ZK_MSM_HOST_TAIL") != nullptr && atoi(getenv("ZK_MSM_HOST_TAIL")) != 0) {   // opt-in: measured on the GPU box's host a Jacobian addition costs 1.5 us, so the 320 additions of a witness MSM's tail take 0.5 ms of a thread against 0.15-0.25 ms for the quad kernels
+      tail_mode = NB <= TAIL_T0 ? 1 : (NB / seg) / GROUP <= TAIL_T0 && NB / seg > GROUP ? 2 : 0;
+      if (tail_mode) { tail = DevBuf<uint8_t>(tail_bytes()); tail.zero(); HIP_CHECK(hipHostMalloc((void **)&h_tail, tail_bytes())); memset(h_tail, 0, tail_bytes()); } }
     if (filter_ones && WB == 1 && n && getenv("ZK_MSM_SPARSE") != nullptr && atoi(getenv("ZK_MSM_SPARSE")) != 0) {   // opt-in (measured: chains 2-3x shorter, but 3x the field products of the bucket path, which the other streams then miss: 1.82 vs 1.74 ms per send proof)
-      sparse = true; others_cap = (uint32_t)std::min<size_t>((size_t)n * W, std::max<size_t>((size_t)n * 2, 1u << 16)); others = DevBuf<uint8_t>((size_t)others_cap * sizeof(uint2)); }   // room for two non-zero digits per scalar on average (a witness has ~0.16); more raises the overflow flag and the bucket path below runs instead
+      sparse = true; tail_mode = 0; others_cap = (uint32_t)std::min<size_t>((size_t)n * W, std::max<size_t>((size_t)n * 2, 1u << 16)); others = DevBuf<uint8_t>((size_t)others_cap * sizeof(uint2)); }   // room for two non-zero digits per scalar on average (a witness has ~0.16); more raises the overflow flag and the bucket path below runs instead
     max_tasks = (uint32_t)std::max((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1, (size_t)WB * NB * HSORT_SLICES);
     if (uniform_hint && WB == 1 && !filter_ones && n && getenv("ZK_MSM_NO_DIRECT_SORT") == nullptr) {   // slots per bucket: twice the expected load (+64), a power of two
       size_t lam = (n * (size_t)msm_num_windows(c)) / NB, want = 2 * lam + 64; cap = 64; while (cap < want) cap <<= 1;
@@ -89,7 +99,7 @@ struct MsmImpl {
     zeroed.zero(); result = DevBuf<uint8_t>(result_bytes()); result.zero();          // the ones slot stays the point at infinity when the ones path is off
     HIP_CHECK(hipHostMalloc((void **)&h_result, result_bytes())); HIP_CHECK(hipStreamSynchronize(gpu().stream));
   }
-  ~MsmImpl() { if (h_result) hipHostFree(h_result); if (ones_stream) hipStreamDestroy(ones_stream); if (ev_classified) hipEventDestroy(ev_classified); if (ev_ones) hipEventDestroy(ev_ones); }
+  ~MsmImpl() { if (h_result) hipHostFree(h_result); if (h_tail) hipHostFree(h_tail); if (ones_stream) hipStreamDestroy(ones_stream); if (ev_classified) hipEventDestroy(ev_classified); if (ev_ones) hipEventDestroy(ev_ones); }
   void enable_split_ones() { if (split_ones || !filter_ones) return; HIP_CHECK(hipStreamCreateWithFlags(&ones_stream, hipStreamNonBlocking)); HIP_CHECK(hipEventCreateWithFlags(&ev_classified, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_ones, hipEventDisableTiming)); split_ones = true; }
   hipStream_t stream() { return stream_id < 0 ? gpu().stream : gpu().aux[stream_id & 3]; }
   // after the stream has been synchronised: did a bucket of the one-pass sort overflow?  Then repeat the last run on the two-pass path (synchronously).
@@ -108,10 +118,12 @@ struct MsmImpl {
     hipStream_t s = stream(); size_t nbk = (size_t)WB * NB; const uint32_t hist_stride = WB == 1 ? 0 : NB, point_stride = WB == 1 && W > 1 ? (uint32_t)n : 0; const uint8_t *infp = any_inf ? inf.get() : nullptr; MsmCounters *cnt = counters();
     const uint32_t bucket_u4 = sizeof(XYZZ<F>) / 16; XYZZ<F> *res = (XYZZ<F> *)result.get();
     // (histogram and slot counters were cleared by the constructor and are left cleared by every run (k_msm_combine_tasks); the MsmCounters alternate between two slots)
-    parity ^= 1; cnt = counters();
+    parity ^= 1; cnt = counters(); tail_n1 = 0;
     bool ones_forked = false;
+    XYZZ<F> *const t0 = (XYZZ<F> *)tail.get(), *const t1 = t0 ? t0 + TAIL_T0 : nullptr; uint4 *const tail_cnt = t0 ? (uint4 *)(t0 + TAIL_T0 + TAIL_T1) : nullptr;
     auto ones_path = [&](hipStream_t os) { Stage st((label + ".ones").c_str(), os); uint32_t g = cdiv(n_ones_quads, GROUP);
       hipLaunchKernelGGL((k_msm_sum_ones<F>), dim3(cdiv((size_t)n_ones_quads * 4, 256)), dim3(256), 0, os, (const Affine<F> *)points.get(), ones.get(), cnt, n_ones_quads, (XYZZ<F> *)ones_partial.get());
+      if (tail_mode && g <= TAIL_T1) { tail_n1 = g; hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(g), dim3(256), 0, os, (const XYZZ<F> *)ones_partial.get(), GROUP, n_ones_quads, t1, (uint4 *)cnt, tail_cnt); return; }   // the host adds the g partial sums; block 0 carries the counters along
       hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(g), dim3(256), 0, os, (const XYZZ<F> *)ones_partial.get(), GROUP, n_ones_quads, (XYZZ<F> *)ones_l2.get(), (uint4 *)nullptr, (uint4 *)nullptr);
       hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(256), 0, os, (const XYZZ<F> *)ones_l2.get(), g, g, res + WB, (uint4 *)nullptr, (uint4 *)nullptr); };
     last_scalars = scalars; last_index = scalar_index;
@@ -142,7 +154,7 @@ struct MsmImpl {
       else {
         hipLaunchKernelGGL(k_bsort_hist, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_hist.get(), cap);
         bsort_scanner->run(block_hist.get(), block_off.get(), (size_t)bsort_blocks * BSORT_CLASSES, s);
-        hipLaunchKernelGGL(k_bsort_scatter, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_off.get(), order.get(), rank_of.get(), ntasks.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
+        hipLaunchKernelGGL(k_bsort_scatter, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_off.get(), order.get(), rank_of.get(), ntasks.get(), cls_start.get(), (uint4 *)bucket_array(), bucket_u4);
         task_scanner.run(ntasks.get(), task_off.get(), nbk + 1, s);
       }
     } else
@@ -152,12 +164,12 @@ struct MsmImpl {
 #undef ZK_CALL
       if (filter_ones && n && split_ones) { HIP_CHECK(hipEventRecord(ev_classified, s)); HIP_CHECK(hipStreamWaitEvent(ones_stream, ev_classified, 0)); ones_path(ones_stream); HIP_CHECK(hipEventRecord(ev_ones, ones_stream)); ones_forked = true; }
       if (nbk <= PLAN_SMALL_MAX) {
-        hipLaunchKernelGGL(k_msm_plan_small, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, offsets.get(), order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
+        hipLaunchKernelGGL(k_msm_plan_small, dim3(1), dim3(PLAN_THREADS), 0, s, hist(), (uint32_t)nbk, offsets.get(), order.get(), rank_of.get(), task_off.get(), cls_start.get(), (uint4 *)bucket_array(), bucket_u4);
       } else {
         scanner.run(hist(), offsets.get(), nbk, s);
         hipLaunchKernelGGL(k_bsort_hist, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_hist.get(), 0u);
         bsort_scanner->run(block_hist.get(), block_off.get(), (size_t)bsort_blocks * BSORT_CLASSES, s);
-        hipLaunchKernelGGL(k_bsort_scatter, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_off.get(), order.get(), rank_of.get(), ntasks.get(), cls_start.get(), (uint4 *)buckets.get(), bucket_u4);
+        hipLaunchKernelGGL(k_bsort_scatter, dim3(bsort_blocks), dim3(BSORT_BLOCK), 0, s, hist(), (uint32_t)nbk, bsort_blocks, block_off.get(), order.get(), rank_of.get(), ntasks.get(), cls_start.get(), (uint4 *)bucket_array(), bucket_u4);
         task_scanner.run(ntasks.get(), task_off.get(), nbk + 1, s);
       }
 #define ZK_CALL(CC) hipLaunchKernelGGL(k_msm_scatter<CC>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, (int)filter_ones, hist_stride, point_stride, (uint32_t)nbk, (int)glv, offsets.get(), fill(), entries.get())
@@ -170,28 +182,32 @@ struct MsmImpl {
         if (av == 0) ZK_ACC(0); else if (av == 1) ZK_ACC(1); else if (av == 2) ZK_ACC(2); else ZK_ACC(3);
 #undef ZK_ACC
       }
-      { Stage st((label + ".combine").c_str(), s); hipLaunchKernelGGL((k_msm_combine_slices<F>), dim3(cdiv(nbk * 4, 256)), dim3(256), 0, s, (const XYZZ<F> *)partials.get(), (uint32_t)nbk, (XYZZ<F> *)buckets.get()); }
+      { Stage st((label + ".combine").c_str(), s); hipLaunchKernelGGL((k_msm_combine_slices<F>), dim3(cdiv(nbk * 4, 256)), dim3(256), 0, s, (const XYZZ<F> *)partials.get(), (uint32_t)nbk, bucket_array()); }
     } else {
     { Stage st((label + ".accumulate").c_str(), s);
       hipLaunchKernelGGL((k_msm_accumulate_tasks<F>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), order.get(), task_off.get(), (uint32_t)nbk, max_tasks, direct ? task : MSM_TASK, glv ? (const F *)beta.get() : (const F *)nullptr,
-                         (XYZZ<F> *)buckets.get(), (XYZZ<F> *)partials.get());
+                         bucket_array(), (XYZZ<F> *)partials.get());
     }
     { Stage st((label + ".combine").c_str(), s);
       const uint32_t heavy = direct && cap <= COMBINE_QUAD_MAX * task ? 0u : HEAVY_BLOCKS;   // one-pass sort: no bucket can hold more than `cap` entries, so none needs a whole workgroup
-      hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(heavy + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), heavy, (const XYZZ<F> *)partials.get(), (XYZZ<F> *)buckets.get(), zeroed.get(), (uint32_t)(2 * nbk), (int)(direct && nbk <= PLAN_DIRECT_MAX && cap <= 4080));
+      hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(heavy + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), heavy, (const XYZZ<F> *)partials.get(), bucket_array(), zeroed.get(), (uint32_t)(2 * nbk), (int)(direct && nbk <= PLAN_DIRECT_MAX && cap <= 4080));
     }
     }
-    { Stage st_red((label + ".reduce").c_str(), s);
+    const bool ones_runs = filter_ones && n;
+    if (tail_mode == 1) { tail_n0 = NB; if (!ones_runs) HIP_CHECK(hipMemcpyAsync(tail_cnt, cnt, sizeof(MsmCounters), hipMemcpyDeviceToDevice, s)); }   // the buckets already sit in the tail buffer: nothing left to launch
+    else { Stage st_red((label + ".reduce").c_str(), s);
       uint32_t spw = NB / seg, nseg = (uint32_t)WB * spw; uint4 *csrc = (uint4 *)cnt; uint4 *cdst = (uint4 *)(res + WB + 1);
-      hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3(cdiv(nseg, 16)), dim3(64), 0, s, (const XYZZ<F> *)buckets.get(), NB, seg, nseg, (XYZZ<F> *)seg_out.get());
-      if (spw > GROUP) { uint32_t g = spw / GROUP;   // two-level tree per window keeps the dependent chain short (spw is a power of two)
+      hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3(cdiv(nseg, 16)), dim3(64), 0, s, (const XYZZ<F> *)bucket_array(), NB, seg, nseg, (XYZZ<F> *)seg_out.get());
+      if (tail_mode == 2) { uint32_t g = spw / GROUP; tail_n0 = g; hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(g), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), GROUP, nseg, t0, ones_runs ? (uint4 *)nullptr : csrc, ones_runs ? (uint4 *)nullptr : tail_cnt); }
+      else if (spw > GROUP) { uint32_t g = spw / GROUP;   // two-level tree per window keeps the dependent chain short (spw is a power of two)
         hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(WB * g), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), GROUP, nseg, (XYZZ<F> *)seg_l2.get(), (uint4 *)nullptr, (uint4 *)nullptr);
         hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(WB), dim3(256), 0, s, (const XYZZ<F> *)seg_l2.get(), g, (uint32_t)WB * g, res, csrc, cdst);
       } else hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(WB), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), spw, nseg, res, csrc, cdst);
     }
     if (filter_ones && n && !split_ones) ones_path(s);
     if (ones_forked) HIP_CHECK(hipStreamWaitEvent(s, ev_ones, 0));
-    HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s));
+    if (tail_mode) HIP_CHECK(hipMemcpyAsync(h_tail, tail.get(), tail_bytes(), hipMemcpyDeviceToHost, s));
+    else HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s));
   }
 };
 
@@ -206,6 +222,16 @@ template <class HF, class F> static host::HPoint<HF> combine(const XYZZ<F> *res,
   host::HPoint<HF> acc = host::HPoint<HF>::inf();
   for (int w = W - 1; w >= 0; w--) { if (!acc.is_inf()) for (int i = 0; i < c; i++) acc = acc.dbl(); acc = acc.add(get(w)); }
   return acc.add(get(W));
+}
+
+// the host tail (MsmImpl::tail_mode): mode 1 — sum_b (b + 1) B_b over the bucket array by running sums; mode 2 — plain sum; plus the partial sums of the scalar-one path
+template <class HF, class F, class Impl> static host::HPoint<HF> host_tail_sum(const Impl &m) {
+  auto get = [&](const XYZZ<F> *arr, uint32_t i) { const char *b = (const char *)&arr[i]; size_t fs = sizeof(F); return host::HPoint<HF>::from_xyzz(load_hf<HF>(b), load_hf<HF>(b + fs), load_hf<HF>(b + 2 * fs), load_hf<HF>(b + 3 * fs)); };
+  host::HPoint<HF> acc = host::HPoint<HF>::inf();
+  if (m.tail_mode == 1) { host::HPoint<HF> run = host::HPoint<HF>::inf(); for (uint32_t b = m.tail_n0; b-- > 0;) { run = run.add(get(m.host_tail0(), b)); acc = acc.add(run); } }
+  else for (uint32_t i = 0; i < m.tail_n0; i++) acc = acc.add(get(m.host_tail0(), i));
+  for (uint32_t i = 0; i < m.tail_n1; i++) acc = acc.add(get(m.host_tail1(), i));
+  return acc;
 }
 
 }  // namespace zk
