@@ -258,3 +258,56 @@ def test_cmta_block_matches_libsnark_composition(tmp_path, golden_dir):
         assert hashlib.sha256(open(wp, "rb").read()).hexdigest() == gold["seed%d" % seed]["witness_sha256"]
         z = o.load_witness(wp); assert o.r1cs_is_satisfied(cs, z)
         msg = bytes(sum(b << (7 - j) for j, b in enumerate(bits[8 * i:8 * i + 8])) for i in range(72)); assert "".join(str(int(v)) for v in o.from_arr(z[577:833])) == "".join(format(x, "08b") for x in hashlib.sha256(msg).digest()) == gold["seed%d" % seed]["digest_bits"]
+
+# ---- mint / redeem / deposit: the variable layout as the reference's constructors allocate it (read off the sources cited below; the reference-DUMPED table of SURVEY.md
+# Appendix C exists for send only).  Same kind of check as for send: every range holds what the reference's witness generator puts there, and inside every compression
+# gadget the packed message schedule, the packed working variables of all 64 rounds and the reduced output sit at the gadget's offsets.
+def _check_hasher(z, name, msg, first, inter):
+    blocks = _pad(bytearray(msg)); state = IV; base = first
+    for k in range(len(blocks) // 64):
+        W, As, Es, new_state = _sha_rounds(state, bytes(blocks[64 * k:64 * k + 64])); assert z[base:base + 64] == W, (name, k)
+        for i in range(64): assert z[base + 7360 + 272 * i + 264] == As[i] and z[base + 7360 + 272 * i + 265] == Es[i], (name, k, i)
+        assert z[base + 24776:base + 24784] == new_state, (name, k)
+        if k == 0 and inter is not None: assert z[inter:inter + 256] == [(wd >> (31 - j)) & 1 for wd in new_state for j in range(32)], name
+        state = new_state; base += 24792
+    return base
+
+@pytest.mark.parametrize("kind", ["mint", "redeem"])
+def test_mint_redeem_layout_follows_the_reference_constructors(kind, tmp_path):
+    """mint/circuit/gadget.tcc:71-160 (redeem/circuit/gadget.tcc:70-135 is the same order plus the comparison gadget, sub_cmp.tcc:25-27): packed inputs, unpacked bits
+    cmtA_old | sn_old | cmtA | value_s, ZERO, value, value_old, sk, r, r_old, sn, the three packed values (note.tcc:39-43), [redeem: less_cmp's 67 variables], then the
+    PRF, CMTA_old and CMTA hashers, each with its intermediate digest first (commitment.tcc)"""
+    import struct
+    redeem = kind == "redeem"; d = w.mint_instance(5, redeem=redeem); wp = str(tmp_path / "w.bin"); e.witness_mint_redeem(redeem, *[("0x" + a.hex()) if isinstance(a, bytes) else a for a in w.mint_args(d)], wp)
+    z = [1] + o.from_arr(o.load_witness(wp)); assert len(z) == (151579 if redeem else 151512) + 1; rng = lambda a, b: z[a:b + 1]
+    assert rng(1, 4) == w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtA"]], d["value_s"])
+    assert rng(5, 772) == sum((_bits_of_blob(d[k]) for k in ("cmtA_old", "sn_old", "cmtA")), []) and rng(773, 836) == _bits_of_u64(d["value_s"]) and z[837] == 0
+    assert rng(838, 901) == _bits_of_u64(d["value"]) and rng(902, 965) == _bits_of_u64(d["value_old"])
+    assert rng(966, 1221) == _bits_of_blob(d["sk"]) and rng(1222, 1477) == _bits_of_blob(d["r"]) and rng(1478, 1733) == _bits_of_blob(d["r_old"]) and rng(1734, 1989) == _bits_of_blob(d["sn"])
+    assert rng(1990, 1992) == [d["value"], d["value_old"], d["value_s"]]
+    nxt = 1993
+    if redeem: ap = (1 << 64) + d["value_old"] - d["value_s"]; assert rng(1993, 2056) == [(ap >> i) & 1 for i in range(64)] and z[2057] == ap and z[2058] == (1 if ap & ((1 << 64) - 1) else 0); nxt = 2060
+    rb = lambda k: w.rev(d[k]); v64 = lambda v: struct.pack("<Q", v)
+    for name, msg in (("prf", rb("sk") + rb("r")), ("cmtA_old", v64(d["value_old"]) + rb("sn_old") + rb("r_old")), ("cmtA", v64(d["value"]) + rb("sn") + rb("r"))):
+        nxt = _check_hasher(z, name, msg, nxt + 256, nxt)
+    assert nxt == len(z)
+
+def test_deposit_layout_follows_the_reference_constructor(tmp_path):
+    """deposit/circuit/gadget.tcc:88-190: packed inputs, unpacked bits rt | pk_recv | cmtB_old | sn_old | cmtB | sn_s, value_enforce, ZERO, value_s, r_s, sn_A_old, cmtS,
+    value_old, r_old, value, sn, r, sk, the packed values (deposit/note.tcc:38-40 and the ADD class), the hashers PRF(sn), PRF(sn_s), CMTS, CMTB_old, CMTB, then the
+    Merkle gadget: 8 position bits and the authentication path (merkle.tcc:17-22), whose 8 compression gadgets close the count at 457,127"""
+    import struct
+    d = w.reference_deposit_fixture(); H = lambda b: "0x" + b.hex(); wp = str(tmp_path / "w.bin"); arr = "".join(H(x) for x in d["leaves"])
+    e.witness_deposit(*[H(a) if isinstance(a, bytes) else a for a in w.deposit_args(d)], arr, len(d["leaves"]), H(d["sk"]), wp); z = [1] + o.from_arr(o.load_witness(wp)); assert len(z) == 457128; rng = lambda a, b: z[a:b + 1]
+    assert rng(1, 6) == w.pack_public([d["rt"], d["pk_recv"], d["cmtB_old"], d["sn_old"], d["cmtB"], d["sn_s"]])
+    assert rng(7, 1446) == sum((_bits_of_blob(d[k]) for k in ("rt", "pk_recv", "cmtB_old", "sn_old", "cmtB", "sn_s")), []) and z[1447] == 1 and z[1448] == 0      # value_enforce = (value_s != 0), ZERO
+    pos = 1449
+    for k, nbits in (("value_s", 64), ("r_s", 256), ("sn_A_old", 256), ("cmtS", 256), ("value_old", 64), ("r_old", 256), ("value", 64), ("sn", 256), ("r", 256), ("sk", 256)):
+        assert rng(pos, pos + nbits - 1) == (_bits_of_u64(d[k]) if nbits == 64 else _bits_of_blob(d[k])), k; pos += nbits
+    assert pos == 3433 and sorted(rng(3433, 3435)) == sorted([d["value_s"], d["value_old"], d["value"]]) and rng(3433, 3434) == [d["value_s"], d["value_old"]]
+    rb = lambda k: w.rev(d[k]); v64 = lambda v: struct.pack("<Q", v); nxt = 3436
+    for name, msg in (("prf_sn", rb("sk") + rb("r")), ("prf_sn_s", rb("sk") + rb("r_s")), ("cmtS", v64(d["value_s"]) + rb("pk_recv") + rb("r_s") + rb("sn_A_old")),
+                      ("cmtB_old", v64(d["value_old"]) + rb("sn_old") + rb("r_old")), ("cmtB", v64(d["value"]) + rb("sn") + rb("r"))):
+        nxt = _check_hasher(z, name, msg, nxt + 256, nxt)
+    assert nxt == 252636 and rng(252636, 252643) == [(d["index"] >> i) & 1 for i in range(8)]               # positions: fill_with_bits_of_ulong, little-endian
+    assert len(z) - 1 - 256739 == 8 * 24792 + 7 * 256 + 260                                                  # 8 hashers, 7 internal digests, the selectors' and the root copy's variables
