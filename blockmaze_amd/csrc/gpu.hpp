@@ -52,6 +52,7 @@ template <class T> class PinnedBuf {           // page-locked host staging buffe
 void upload_async(void *dev, const void *pinned_host, size_t bytes);   // on the main stream, no synchronisation
 
 // A fixed set of base points resident in HBM (one query of a proving key) plus the reusable MSM workspace for it.
+struct WsortBuffers;                           // the sorted witness digits an MSM leaves for the MSMs over the same scalar vector (msm_impl.hpp)
 class MsmG1 {
  public:
   MsmG1(const G1AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false, bool glv = false);   // glv: halve the scalars with the curve's endomorphism (needs tables + uniform); tables: precompute 2^(cw) P if the size cap allows; uniform: one-pass sort with overflow fallback (msm_impl.hpp)
@@ -63,6 +64,9 @@ class MsmG1 {
   // scalars a_i * b_i * z (z: one element, or a table of n) formed inside the sort kernel; only when one_pass_sort() (uniform-scalar MSM with fixed-base tables)
   bool one_pass_sort() const; void run_product(const Fe32 *a_dev, const Fe32 *b_dev, const Fe32 *z_dev, bool z_is_table);
   host::HG1 result();
+  // MSMs over the same scalar vector (same length, same window) can share one sort of its digits: the follower must be run after the leader, on the leader's stream
+  // or on another one (it then waits for the leader's event).  false if either side is not on the three-launch witness path.
+  std::shared_ptr<WsortBuffers> sort_handle() const; bool share_sort_with(const std::shared_ptr<WsortBuffers> &leader);
   size_t size() const; const G1AffineRaw *points_dev() const; void set_label(const char *l); void set_stream(int aux /* -1 main, 0..3 auxiliary */); void split_ones_path();   // split: the scalar-one sum runs on a stream of its own beside the bucket path
   struct Impl; std::unique_ptr<Impl> impl;
 };
@@ -72,6 +76,7 @@ class MsmG2 {
   MsmG2(const MsmG2 &peer, bool filter_ones, bool uniform_scalars);
   ~MsmG2();
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
+  bool share_sort_with(const std::shared_ptr<WsortBuffers> &leader);
   host::HG2 result(); void set_label(const char *l); void set_stream(int aux); void split_ones_path();
   struct Impl; std::unique_ptr<Impl> impl;
 };

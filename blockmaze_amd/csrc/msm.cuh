@@ -378,15 +378,16 @@ __global__ void __launch_bounds__(256) k_msm_combine_slices(const XYZZ<F> *__res
 // ---- sums by the 64 quads of a 256-thread workgroup ------------------------------------------------------------------------
 // quad q adds elements q, q+64, ...; then a tree over the 16 quads of each wave (shuffles) and over the 4 waves (LDS).  The result is valid in lanes 0..3.
 // tree over the 64 quads of a 256-thread workgroup: 16 quads per wave by shuffles, the 4 waves through LDS.  Every quad brings `acc`; the sum is valid in lanes 0..3.
-template <class F> __device__ __forceinline__ XYZZ<F> block_quad_tree(XYZZ<F> acc, XYZZ<F> *lds) {
+// `live` = how many of the quads (the first ones) hold something: levels whose partner quads are all empty are skipped (whole waves at a time), so a short list costs a short tree
+template <class F> __device__ __forceinline__ XYZZ<F> block_quad_tree(XYZZ<F> acc, XYZZ<F> *lds, uint32_t live = 64) {
   const uint32_t q = threadIdx.x >> 2, wq = q & 15, wave = threadIdx.x >> 6; const int k = threadIdx.x & 3;
 #pragma unroll 1
-  for (int d = 8; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (wq + d < 16) acc = quad_add(acc, o, k); }
+  for (int d = 8; d >= 1; d >>= 1) { if (wave * 16 + d >= live) continue; XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (wq + d < 16) acc = quad_add(acc, o, k); }
   if ((threadIdx.x & 63) == 0) lds[wave] = acc;
   __syncthreads();
   if (wave == 0) { acc = q < 4 ? lds[q] : XYZZ<F>::inf();
 #pragma unroll 1
-    for (int d = 2; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (q + d < 4) acc = quad_add(acc, o, k); } }
+    for (int d = 2; d >= 1; d >>= 1) { if ((uint32_t)d * 16 >= live) continue; XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (q + d < 4) acc = quad_add(acc, o, k); } }
   return acc;
 }
 template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<F> *__restrict__ src, uint32_t len, XYZZ<F> *lds) {
@@ -394,7 +395,7 @@ template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<
   if (q < len) { XYZZ<F> nxt = src[q];
 #pragma unroll 1
     for (uint32_t j = q; j < len; j += 64) { XYZZ<F> cur = nxt; if (j + 64 < len) nxt = src[j + 64]; acc = quad_add(acc, cur, k); } }
-  return block_quad_tree(acc, lds);
+  return block_quad_tree(acc, lds, min(len, 64u));
 }
 
 // buckets that were cut into several tasks: add up the partial sums.  Buckets are ranked by decreasing size (order[], cls_start[]).  One quad per bucket adds up
@@ -511,6 +512,123 @@ __global__ void __launch_bounds__(256) k_wmsm_sum(const Affine<F> *__restrict__ 
     for (uint32_t j = t; j < n1; j += n_quads) { Affine<F> cur = nxt; if (j + n_quads < n1) nxt = points[ones[j + n_quads]]; acc = quad_madd(acc, cur, k); } }   // the next point's gather is in flight during the addition
   acc = block_quad_tree(acc, lds);
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// ---- witness MSMs in three launches -----------------------------------------------------------------------------------------
+// Measured with several proofs in flight (tools/inflight_probe.py): the four witness MSMs — 5 % of a proof's field products — took as much of the machine as the H query,
+// because the general path above spends ten launches of tiny, dependent kernels on each of them (classify, plan, scatter, accumulate, combine, reduce, three tree
+// levels, the ones sum).  With fixed-base tables all windows share at most 128 buckets, and a workgroup is exactly the right size for one bucket:
+//   k_wsort   one pass over the scalars: the ones go to a compacted list, every non-zero digit to its bucket's REGION (cap slots per bucket; a workgroup counts in LDS,
+//             reserves with one atomic per bucket, walks the digits again to place them).  No histogram pass, no plan.  A bucket that would overflow raises the flag
+//             that sends the MSM back to the general path.
+//   k_wacc_lanes / k_wacc_fold   4,096 lanes share the buckets' entries in equal slices, 8,192 more stride over the list of ones (plain lane-serial mixed additions);
+//             then one workgroup per bucket folds its lanes' partial sums, and 32 more fold the ones lanes to 32 partial sums.
+//   k_wtail   two workgroups: (0) sum_b (b + 1) B_b as sum_k 2^k S_k with S_k the sum of the buckets whose weight has bit k — eight plain sums by eight groups of
+//             eight quads, then a Horner chain of 7 doublings and 7 additions; (1) the tree over the ones' partial sums.  The host adds the two results.
+// The sort only depends on the scalars: MSMs over the same scalar vector (A and L*; B1 and B2) share one k_wsort (msm_impl.hpp: WsortBuffers).
+constexpr uint32_t WFUSED_MAX_BUCKETS = 128;
+template <int C>
+__global__ void __launch_bounds__(256) k_wsort(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf, uint32_t n, int c, int W, uint32_t point_stride, uint32_t NB, uint32_t cap,
+                                               uint32_t *__restrict__ fill, uint32_t *__restrict__ fill_next, uint32_t *__restrict__ entries, uint32_t *__restrict__ ones, MsmCounters *cnt, MsmCounters *cnt_next) {
+  __shared__ uint32_t lcnt[WFUSED_MAX_BUCKETS], lbase[WFUSED_MAX_BUCKETS];
+  if (blockIdx.x == 0) { if (threadIdx.x == 0) *cnt_next = MsmCounters{0, 0, {0, 0}}; if (threadIdx.x < NB) fill_next[threadIdx.x] = 0; }   // the two counter sets alternate: this run clears the next run's
+  if (threadIdx.x < NB) lcnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63; bool live = i < n && !(point_is_inf && point_is_inf[i]); Fr k = Fr::zero();
+  if (live) { k = scalars[scalar_index ? scalar_index[i] : i].from_mont(); live = !k.is_zero(); }
+  bool is_one = false; if (live) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; is_one = o == 0; }
+  { uint64_t m = __ballot(is_one); if (m) { uint32_t base = 0; const int first = __ffsll((long long)m) - 1; if ((int)lane == first) base = atomicAdd(&cnt->n_ones, (uint32_t)__popcll(m));
+      base = __shfl(base, first, 64); if (is_one) ones[base + __popcll(m & ((1ull << lane) - 1))] = i; } }
+  const bool other = live && !is_one;
+  if (other) msm_walk_digits<C>(k.l, c, W, 0, [&](int, int, int d) { if (d) atomicAdd(&lcnt[(uint32_t)(d < 0 ? -d : d) - 1], 1u); });
+  __syncthreads();
+  if (threadIdx.x < NB) { const uint32_t m = lcnt[threadIdx.x]; uint32_t b = m ? atomicAdd(&fill[threadIdx.x], m) : 0; if (b + m > cap) atomicOr(&cnt->pad[0], 1u); lbase[threadIdx.x] = b; lcnt[threadIdx.x] = 0; }
+  __syncthreads();
+  if (other) msm_walk_digits<C>(k.l, c, W, 0, [&](int, int w, int d) { if (!d) return; const uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, pos = lbase[key] + atomicAdd(&lcnt[key], 1u);
+    if (pos < cap) entries[(size_t)key * cap + pos] = (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u); });
+}
+// k_wacc_lanes + k_wacc_fold replace the first version of k_wacc (one workgroup of 64 quads per bucket, measured: 188 us, every SIMD of the chip busy with quad
+// arithmetic and with tree levels in which most quads idle — 0.5 ms of the machine per proof for 5 % of its field products).  Accumulation is lane-serial (10 products per
+// point, no exchange overhead, 160 waves in all); only the trees are cooperative, and they skip the levels a short list does not need.
+constexpr uint32_t WFUSED_BUCKET_LANES = 4096, WFUSED_ONES_LANES = 8192, WFUSED_ONES_GROUPS = WFUSED_ONES_LANES / 256, WFUSED_MIN_SLICE = 8;
+// Lanes are dealt to the buckets in proportion to their fill (a witness puts thousands of equal values into one bucket): slice length T = total / lanes, bucket b gets
+// ceil(fill_b / T) lanes, lane_off[] (NB + 1 prefix sums, recomputed by every workgroup, written out by the first) tells the next kernel where each bucket's partial sums lie.
+template <class F>
+__global__ void __launch_bounds__(256) k_wacc_lanes(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap, uint32_t NB, const uint32_t *__restrict__ ones, const MsmCounters *cnt,
+                                                    XYZZ<F> *__restrict__ partial, uint32_t *__restrict__ lane_off) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; XYZZ<F> acc = XYZZ<F>::inf();
+  if (t >= WFUSED_BUCKET_LANES) { const uint32_t u = t - WFUSED_BUCKET_LANES; if (u >= WFUSED_ONES_LANES) return; const uint32_t n1 = cnt->n_ones;     // (whole workgroups: 4096 is a multiple of 256)
+    if (u < n1) { Affine<F> p = points[ones[u]];
+#pragma unroll 1
+      for (uint32_t i = u; i < n1; i += WFUSED_ONES_LANES) { Affine<F> pn = p; if (i + WFUSED_ONES_LANES < n1) pn = points[ones[i + WFUSED_ONES_LANES]]; acc.madd_inl(p); p = pn; } }
+    partial[t] = acc; return; }
+  __shared__ uint32_t m_of[WFUSED_MAX_BUCKETS], off[WFUSED_MAX_BUCKETS + 1], slice;
+  if (threadIdx.x < NB) m_of[threadIdx.x] = min(fill[threadIdx.x], cap);
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t tot = 0; for (uint32_t b = 0; b < NB; b++) tot += m_of[b];
+    const uint32_t T = max(WFUSED_MIN_SLICE, (tot + (WFUSED_BUCKET_LANES - NB) - 1) / (WFUSED_BUCKET_LANES - NB)); uint32_t o = 0; for (uint32_t b = 0; b < NB; b++) { off[b] = o; o += (m_of[b] + T - 1) / T; } off[NB] = o; slice = T; }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x <= NB) lane_off[threadIdx.x] = off[threadIdx.x];
+  if (t >= off[NB]) return;
+  uint32_t lo = 0, hi = NB;                                                                    // the bucket b with off[b] <= t < off[b + 1]
+  while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (off[mid] <= t) lo = mid; else hi = mid; }
+  const uint32_t b = lo, beg = (t - off[b]) * slice, end = min(m_of[b], beg + slice); const uint32_t *e = entries + (size_t)b * cap;
+  { uint32_t v = e[beg], vn = beg + 1 < end ? e[beg + 1] : v; Affine<F> p = points[v & ~MSM_ENTRY_SIGN];
+#pragma unroll 1
+    for (uint32_t i = beg; i < end; i++) { Affine<F> pn = points[vn & ~MSM_ENTRY_SIGN]; uint32_t vnn = i + 2 < end ? e[i + 2] : vn; if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; vn = vnn; } }
+  partial[t] = acc;
+}
+// workgroup b < NB: bucket b = the sum of its lanes' partial sums; workgroup NB + g: 256 of the ones lanes
+template <class F>
+__global__ void __launch_bounds__(256) k_wacc_fold(const XYZZ<F> *__restrict__ partial, const uint32_t *__restrict__ lane_off, uint32_t NB, XYZZ<F> *__restrict__ out) {
+  __shared__ XYZZ<F> lds[4]; const uint32_t b = blockIdx.x; uint32_t beg, len;
+  if (b < NB) { beg = lane_off[b]; len = lane_off[b + 1] - beg; } else { beg = WFUSED_BUCKET_LANES + (b - NB) * 256; len = 256; }
+  XYZZ<F> acc = block_quad_sum(partial + beg, len, lds); if (threadIdx.x == 0) out[b] = acc;
+}
+// The cooperative form of the two kernels above in one launch, for G2: a lane-serial Fq2 addition keeps ~450 registers alive and runs at 30 us, so there the 64 quads of
+// workgroup b < NB stride over bucket b's entries directly (workgroups NB .. NB + 127 over the list of ones) and the workgroup's tree leaves the sum.
+constexpr uint32_t WFUSED_ONES_BLOCKS = 128;
+template <class F>
+__global__ void __launch_bounds__(256) k_wacc_quads(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap, uint32_t NB, const uint32_t *__restrict__ ones, const MsmCounters *cnt,
+                                                    XYZZ<F> *__restrict__ out) {
+  __shared__ XYZZ<F> lds[4]; const uint32_t q = threadIdx.x >> 2, b = blockIdx.x; const int k = threadIdx.x & 3; XYZZ<F> acc = XYZZ<F>::inf();
+  if (b < NB) { const uint32_t m = min(fill[b], cap); const uint32_t *e = entries + (size_t)b * cap;
+    if (q < m) { uint32_t v = e[q]; Affine<F> p = points[v & ~MSM_ENTRY_SIGN];
+#pragma unroll 1
+      for (uint32_t i = q; i < m; i += 64) { uint32_t vn = v; Affine<F> pn = p; if (i + 64 < m) { vn = e[i + 64]; pn = points[vn & ~MSM_ENTRY_SIGN]; } if (v >> 31) p.y = p.y.neg(); acc = quad_madd(acc, p, k); v = vn; p = pn; } }
+    acc = block_quad_tree(acc, lds, min(m, 64u)); }
+  else { const uint32_t n1 = cnt->n_ones, u = (b - NB) * 64 + q, stride = WFUSED_ONES_BLOCKS * 64;
+    if (u < n1) { Affine<F> p = points[ones[u]];
+#pragma unroll 1
+      for (uint32_t i = u; i < n1; i += stride) { Affine<F> pn = p; if (i + stride < n1) pn = points[ones[i + stride]]; acc = quad_madd(acc, p, k); p = pn; } }
+    acc = block_quad_tree(acc, lds); }
+  if (threadIdx.x == 0) out[b] = acc;
+}
+// sum_b (b + 1) * bucket_b as sum_s 2^s S_s, S_s = the sum of the buckets whose weight has bit s: for s < 7 those are the 64 weights "i with a one inserted at bit s"
+// (i = 0..63), eight per quad of group s and none skipped; S_7 is bucket 127 alone.  Then 2^s S_s pairwise: (S0 + 2 S1) + 4 (S2 + 2 S3) + 16 (...): 7 doublings, 3 additions.
+template <class F>
+__global__ void __launch_bounds__(256) k_wtail(const XYZZ<F> *__restrict__ buckets, uint32_t NB, const XYZZ<F> *__restrict__ ones_partial, uint32_t n_ones_partial, XYZZ<F> *__restrict__ res, uint4 *copy_src, uint4 *copy_dst) {
+  __shared__ XYZZ<F> lds[8]; const uint32_t q = threadIdx.x >> 2; const int k = threadIdx.x & 3;
+  if (blockIdx.x == 1) { XYZZ<F> acc = block_quad_sum(ones_partial, n_ones_partial, lds); if (threadIdx.x == 0) { res[1] = acc; if (copy_src) *copy_dst = *copy_src; } return; }
+  const uint32_t s_ = q >> 3, j = q & 7, half = NB >> 1, per = half >> 3; XYZZ<F> acc = XYZZ<F>::inf();                  // NB is a power of two, 16 <= NB <= 128; top = log2 NB
+  const uint32_t top = 31 - __clz(NB);
+  auto weight = [&](uint32_t i) { return ((i >> s_) << (s_ + 1)) | (1u << s_) | (i & ((1u << s_) - 1)); };
+  if (s_ < top) { XYZZ<F> nxt = buckets[weight(j * per) - 1];
+#pragma unroll 1
+    for (uint32_t i = j * per; i < (j + 1) * per; i++) { XYZZ<F> cur = nxt; if (i + 1 < (j + 1) * per) nxt = buckets[weight(i + 1) - 1]; acc = quad_add(acc, cur, k); } }
+  else if (s_ == top && j == 0) acc = buckets[NB - 1];
+#pragma unroll 1
+  for (int d = 4; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if ((int)j + d < 8) acc = quad_add(acc, o, k); }
+  if (j == 0 && k == 0) lds[s_] = acc;
+  __syncthreads();
+  if (threadIdx.x < 64) {                                // quad q of the first wave: level 1 pairs (2q, 2q+1), level 2 quads (q, q+1), level 3 quads (q, q+2); quad 0 ends with the sum
+    XYZZ<F> R = quad_add(lds[(2 * q) & 7], quad_dbl_inl(lds[(2 * q + 1) & 7], k), k);
+    { XYZZ<F> o = shfl_down_struct(R, 4); o = quad_dbl_inl(quad_dbl_inl(o, k), k); R = quad_add(R, o, k); }
+    { XYZZ<F> o = shfl_down_struct(R, 8);
+#pragma unroll 1
+      for (int t = 0; t < 4; t++) o = quad_dbl_inl(o, k);
+      R = quad_add(R, o, k); }
+    if (threadIdx.x == 0) res[0] = R; }
 }
 
 // ---- fixed-base precomputation: table[w*n + i] = 2^(c*w) * P_i, affine ------------------------------------------------

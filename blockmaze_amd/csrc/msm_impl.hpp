@@ -8,6 +8,10 @@
 #define ZK_MSM_DISPATCH_C(cval, glvval, CALL) do { if (!(glvval) && (cval) == 8) { CALL(8); } else if (!(glvval) && (cval) == 16) { CALL(16); } else { CALL(0); } } while (0)
 
 namespace zk {
+// what k_wsort leaves behind (msm.cuh, "witness MSMs in three launches"): one set per scalar vector, shared by the MSMs over that vector (A and L*; B1 and B2 — different
+// curve groups, hence no template parameter here).  The leader runs the sort; a follower queued behind it on the same stream, or waiting for `sorted`, only accumulates.
+struct WsortBuffers { uint32_t NB = 0, cap = 0; size_t n = 0; DevBuf<uint32_t> fill /* 2 x NB: the runs alternate */, entries /* NB x cap */, ones /* n */, counters /* 2 MsmCounters */; int parity = 0; bool shared = false; hipEvent_t sorted = nullptr; int leader_stream = -1;
+  ~WsortBuffers() { if (sorted) hipEventDestroy(sorted); } };
 template <class F, class RawAffine>
 struct MsmImpl {
   size_t n; int c, W, WB; uint32_t NB;   // W digit windows; WB bucket arrays (1 when the multiples 2^(cw) P are precomputed, else W)
@@ -18,11 +22,13 @@ struct MsmImpl {
   bool direct = false, offsets_direct = false; uint32_t cap = 0, task = MSM_TASK;   // task: sorted entries per accumulation lane
   bool split_ones = false; hipStream_t ones_stream = nullptr; hipEvent_t ev_classified = nullptr, ev_ones = nullptr;   // the ones path on a stream of its own, beside the bucket path (the G2 MSM: both are long chains)
   const Fe32 *prod_b = nullptr, *prod_z = nullptr; bool prod_z_table = false; DevBuf<Fe32> prod_tmp;   // scalars given as a product a*b*z (run_product)
+  bool wfused = false, wacc_quads = false, ws_leader = true; std::shared_ptr<WsortBuffers> ws;   // witness MSMs in three launches (k_wsort / k_wacc / k_wtail); needs the fixed-base tables and at most 128 buckets
   bool sparse = false; DevBuf<uint8_t> others; uint32_t others_cap = 0;   // witness MSMs without buckets (k_wmsm_classify / k_wmsm_sum, msm.cuh): needs the fixed-base tables
   bool hsort = false; HsortShape hs{0, 0, 0, 0}; DevBuf<uint32_t> group_fill, mid;   // group-binned one-pass sort (k_hsort_bin / k_hsort_group, msm.cuh)
   const Fe32 *last_scalars = nullptr; const uint32_t *last_index = nullptr;   // one-pass sort (k_msm_scatter_direct) for uniform scalars
   DevBuf<uint32_t> zeroed;                                          // [hist | fill | counters]: cleared by one memset per run
   DevBuf<uint32_t> offsets, entries, ones, ntasks, task_off, order, rank_of, block_hist, block_off, cls_start; uint32_t bsort_blocks; std::unique_ptr<Scanner> bsort_scanner; Scanner scanner, task_scanner; uint32_t max_tasks;
+  DevBuf<uint32_t> lane_off;   // fused witness path: where each bucket's lanes start
   DevBuf<uint8_t> buckets, partials, seg_out, seg_l2, ones_partial, ones_l2, result;   // XYZZ<F> arrays, kept as bytes to stay out of the header; result = W window sums, the ones sum, the counters
   uint8_t *h_result = nullptr;                                      // pinned copy of `result`
   // Host tail (optional, ZK_MSM_HOST_TAIL=1; one bucket array, i.e. fixed-base tables): the last, purely dependent additions of an MSM done by the host, which idles
@@ -34,6 +40,7 @@ struct MsmImpl {
   const XYZZ<F> *host_tail0() const { return (const XYZZ<F> *)h_tail; } const XYZZ<F> *host_tail1() const { return (const XYZZ<F> *)h_tail + TAIL_T0; }
   static constexpr uint32_t HEAVY_BLOCKS = 256, GROUP = 256;
 
+  void share_sort(const std::shared_ptr<WsortBuffers> &leader_ws) { if (!wfused || !leader_ws || leader_ws->NB != NB || leader_ws->n != n) throw GpuError("msm: this MSM cannot share the sort (different size or path)"); ws = leader_ws; ws_leader = false; ws->shared = true; }
   uint32_t *hist() { return zeroed.get(); }
   uint32_t *fill() { return zeroed.get() + (size_t)WB * NB; }
   int parity = 0;                                                   // which of the two counter slots the current run uses
@@ -76,11 +83,16 @@ struct MsmImpl {
     if (glv) { DevBuf<Fe32> b(1); Fe32 bm; memcpy(&bm, GLV_BETA_MONT, 32); b.upload(&bm, 1); beta = std::move(b); }
     { const char *e = getenv("ZK_MSM_SEG"); uint32_t big = e ? (uint32_t)atoi(e) : 16; if (big < 2 || big > 256 || (big & (big - 1))) big = 16; seg = NB >= 4096 ? (WB == 1 ? 4 : big) : 4; }   // one bucket array: few segments, keep the dependent chain short
     n_ones_quads = 16384;
-    if (WB == 1 && n && getenv("ZK_MSM_HOST_TAIL") != nullptr && atoi(getenv("ZK_MSM_HOST_TAIL")) != 0) {   // opt-in: measured on the GPU box's host a Jacobian addition costs 1.5 us, so the 320 additions of a witness MSM's tail take 0.5 ms of a thread against 0.15-0.25 ms for the quad kernels
+    if (!wfused && WB == 1 && n && getenv("ZK_MSM_HOST_TAIL") != nullptr && atoi(getenv("ZK_MSM_HOST_TAIL")) != 0) {   // opt-in: measured on the GPU box's host a Jacobian addition costs 1.5 us, so the 320 additions of a witness MSM's tail take 0.5 ms of a thread against 0.15-0.25 ms for the quad kernels
       tail_mode = NB <= TAIL_T0 ? 1 : (NB / seg) / GROUP <= TAIL_T0 && NB / seg > GROUP ? 2 : 0;
       if (tail_mode) { tail = DevBuf<uint8_t>(tail_bytes()); tail.zero(); HIP_CHECK(hipHostMalloc((void **)&h_tail, tail_bytes())); memset(h_tail, 0, tail_bytes()); } }
+    if (filter_ones && WB == 1 && n && NB >= 16 && NB <= WFUSED_MAX_BUCKETS && n * (size_t)W < (1ull << 31) && !(getenv("ZK_MSM_WFUSED") && atoi(getenv("ZK_MSM_WFUSED")) == 0)) {
+      wfused = true; tail_mode = 0; { const char *e = getenv("ZK_MSM_WACC"); wacc_quads = e ? !strcmp(e, "quads") : sizeof(F) > 32; }   // G2 accumulates by quads, G1 by lanes (msm.cuh)
+      ws = std::make_shared<WsortBuffers>(); ws->NB = NB; ws->n = n; ws->cap = getenv("ZK_MSM_DIRECT_CAP") ? 2 : 8192;   // (test hook: a tiny region forces the overflow fallback)
+      ws->fill = DevBuf<uint32_t>(2 * NB); ws->fill.zero(); ws->entries = DevBuf<uint32_t>((size_t)NB * ws->cap); ws->ones = DevBuf<uint32_t>(n); ws->counters = DevBuf<uint32_t>(2 * sizeof(MsmCounters) / 4); ws->counters.zero();
+      HIP_CHECK(hipEventCreateWithFlags(&ws->sorted, hipEventDisableTiming)); }
     if (filter_ones && WB == 1 && n && getenv("ZK_MSM_SPARSE") != nullptr && atoi(getenv("ZK_MSM_SPARSE")) != 0) {   // opt-in (measured: chains 2-3x shorter, but 3x the field products of the bucket path, which the other streams then miss: 1.82 vs 1.74 ms per send proof)
-      sparse = true; tail_mode = 0; others_cap = (uint32_t)std::min<size_t>((size_t)n * W, std::max<size_t>((size_t)n * 2, 1u << 16)); others = DevBuf<uint8_t>((size_t)others_cap * sizeof(uint2)); }   // room for two non-zero digits per scalar on average (a witness has ~0.16); more raises the overflow flag and the bucket path below runs instead
+      sparse = true; wfused = false; tail_mode = 0; others_cap = (uint32_t)std::min<size_t>((size_t)n * W, std::max<size_t>((size_t)n * 2, 1u << 16)); others = DevBuf<uint8_t>((size_t)others_cap * sizeof(uint2)); }   // room for two non-zero digits per scalar on average (a witness has ~0.16); more raises the overflow flag and the bucket path below runs instead
     max_tasks = (uint32_t)std::max((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1, (size_t)WB * NB * HSORT_SLICES);
     if (uniform_hint && WB == 1 && !filter_ones && n && getenv("ZK_MSM_NO_DIRECT_SORT") == nullptr) {   // slots per bucket: twice the expected load (+64), a power of two
       size_t lam = (n * (size_t)msm_num_windows(c)) / NB, want = 2 * lam + 64; cap = 64; while (cap < want) cap <<= 1;
@@ -93,9 +105,9 @@ struct MsmImpl {
       if (!hsort && (size_t)NB * cap <= (1ull << 28)) { direct = true; entries = DevBuf<uint32_t>((size_t)NB * cap);
         const char *e = getenv("ZK_MSM_DIRECT_TASK"); int tv = e ? atoi(e) : 16; if (lam >= 64 && (tv == 16 || tv == 32 || tv == 64)) task = (uint32_t)tv; } }   // (measured: 32 halves the combine but costs as much in the accumulation, which then has too few lanes)
     { size_t nbk = (size_t)WB * NB; bsort_blocks = cdiv(nbk, BSORT_BLOCK); order = DevBuf<uint32_t>(nbk); rank_of = DevBuf<uint32_t>(nbk); block_hist = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); block_off = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); bsort_scanner.reset(new Scanner((size_t)bsort_blocks * BSORT_CLASSES)); }
-    buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>((size_t)max_tasks * sizeof(XYZZ<F>));
+    buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>(std::max<size_t>(max_tasks, wfused ? (size_t)WFUSED_BUCKET_LANES + WFUSED_ONES_LANES : 0) * sizeof(XYZZ<F>));
     seg_out = DevBuf<uint8_t>((size_t)WB * (NB / seg) * sizeof(XYZZ<F>)); seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
-    ones_partial = DevBuf<uint8_t>((size_t)n_ones_quads * sizeof(XYZZ<F>)); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
+    ones_partial = DevBuf<uint8_t>(std::max<size_t>(n_ones_quads, wfused ? (size_t)NB + WFUSED_ONES_BLOCKS : 0) * sizeof(XYZZ<F>)); if (wfused) lane_off = DevBuf<uint32_t>(WFUSED_MAX_BUCKETS + 1); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
     zeroed.zero(); result = DevBuf<uint8_t>(result_bytes()); result.zero();          // the ones slot stays the point at infinity when the ones path is off
     HIP_CHECK(hipHostMalloc((void **)&h_result, result_bytes())); HIP_CHECK(hipStreamSynchronize(gpu().stream));
   }
@@ -104,6 +116,7 @@ struct MsmImpl {
   hipStream_t stream() { return stream_id < 0 ? gpu().stream : gpu().aux[stream_id & 3]; }
   // after the stream has been synchronised: did a bucket of the one-pass sort overflow?  Then repeat the last run on the two-pass path (synchronously).
   void finish_sync() { HIP_CHECK(hipStreamSynchronize(stream()));
+    if (wfused && host_counters()->pad[0]) { wfused = false; run_impl(last_scalars, last_index); HIP_CHECK(hipStreamSynchronize(stream())); wfused = true; }   // a bucket's region overflowed: the general path handles any input
     if (sparse && host_counters()->pad[0]) { sparse = false; run_impl(last_scalars, last_index); HIP_CHECK(hipStreamSynchronize(stream())); sparse = true; }   // more digits than the list holds: the bucket path handles any input
     if (direct && host_counters()->pad[0]) { direct = false; offsets_direct = false; const Fe32 *sc = last_scalars; const bool was_hsort = hsort; hsort = false;
       if (was_hsort) { HIP_CHECK(hipMemsetAsync(zeroed.get(), 0, 2 * (size_t)WB * NB * sizeof(uint32_t), stream())); HIP_CHECK(hipMemsetAsync(group_fill.get(), 0, hs.groups * sizeof(uint32_t), stream())); }   // hist() held the bucket counts of the group sort; the two-pass path wants it cleared
@@ -127,6 +140,25 @@ struct MsmImpl {
       hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(g), dim3(256), 0, os, (const XYZZ<F> *)ones_partial.get(), GROUP, n_ones_quads, (XYZZ<F> *)ones_l2.get(), (uint4 *)nullptr, (uint4 *)nullptr);
       hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(256), 0, os, (const XYZZ<F> *)ones_l2.get(), g, g, res + WB, (uint4 *)nullptr, (uint4 *)nullptr); };
     last_scalars = scalars; last_index = scalar_index;
+    if (wfused) {
+      parity ^= 1;   // (undo the flip above: this path has its own counters, and the general path — which may follow as the overflow fallback — relies on strict alternation of its two slots)
+      WsortBuffers &w = *ws; MsmCounters *wc = (MsmCounters *)w.counters.get();
+      if (ws_leader) { w.parity ^= 1; w.leader_stream = stream_id; Stage st((label + ".sort").c_str(), s); const uint8_t *winf = w.shared ? nullptr : infp;   // a shared sort keeps every point: the tables differ in which points are at infinity, and the additions skip those
+#define ZK_CALL(CC) hipLaunchKernelGGL(k_wsort<CC>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, winf, (uint32_t)n, c, W, point_stride, NB, w.cap, w.fill.get() + (size_t)w.parity * NB, w.fill.get() + (size_t)(w.parity ^ 1) * NB, w.entries.get(), w.ones.get(), wc + w.parity, wc + (w.parity ^ 1))
+        ZK_MSM_DISPATCH_C(c, false, ZK_CALL);
+#undef ZK_CALL
+        if (w.shared) HIP_CHECK(hipEventRecord(w.sorted, s)); }
+      else if (w.leader_stream != stream_id) HIP_CHECK(hipStreamWaitEvent(s, w.sorted, 0));   // (a follower on the leader's stream is simply queued behind it)
+      uint4 *csrc = (uint4 *)(wc + w.parity); uint4 *cdst = (uint4 *)(res + WB + 1);
+      XYZZ<F> *l2 = (XYZZ<F> *)ones_partial.get(); uint32_t n_op;                          // l2: [NB bucket sums | n_op partial sums of the ones]
+      { Stage st((label + ".accumulate").c_str(), s); const uint32_t *fl = w.fill.get() + (size_t)w.parity * NB;
+        if (wacc_quads) { n_op = WFUSED_ONES_BLOCKS; hipLaunchKernelGGL((k_wacc_quads<F>), dim3(NB + WFUSED_ONES_BLOCKS), dim3(256), 0, s, (const Affine<F> *)points.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l2); }
+        else { n_op = WFUSED_ONES_GROUPS; XYZZ<F> *l1 = (XYZZ<F> *)partials.get();
+          hipLaunchKernelGGL((k_wacc_lanes<F>), dim3((WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) / 256), dim3(256), 0, s, (const Affine<F> *)points.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l1, lane_off.get());
+          hipLaunchKernelGGL((k_wacc_fold<F>), dim3(NB + WFUSED_ONES_GROUPS), dim3(256), 0, s, (const XYZZ<F> *)l1, (const uint32_t *)lane_off.get(), NB, l2); } }
+      { Stage st((label + ".reduce").c_str(), s); hipLaunchKernelGGL((k_wtail<F>), dim3(2), dim3(256), 0, s, (const XYZZ<F> *)l2, NB, (const XYZZ<F> *)l2 + NB, n_op, res, csrc, cdst); }
+      HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s)); return;
+    }
     if (sparse) {
       const uint32_t nq = 16384, nblk = nq / 64; uint4 *csrc = (uint4 *)cnt; uint4 *cdst = (uint4 *)(res + WB + 1);
       { Stage st((label + ".sort").c_str(), s);
