@@ -35,8 +35,8 @@ def parse_args():
     ap = argparse.ArgumentParser(); ap.add_argument("--gpus", type=int, default=1); ap.add_argument("--steps", type=int, default=50); ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the timed region and the roofline leg (what the N > 1 scaling runs need)")
-    ap.add_argument("--inflight", type=int, default=4, help="extra leg (not `value`): this many prover objects per GPU, one host thread each, proofs overlapping on the device; 0/1 = skip")
-    ap.add_argument("--batch", type=int, default=16, help="extra leg (not `value`): zkgpu_prover_prove_batch with this many witnesses per call (BASELINE.json configs[2]); 0/1 = skip")
+    ap.add_argument("--inflight", type=int, default=6, help="extra leg (not `value`): this many prover objects per GPU, one host thread each, proofs overlapping on the device; 0/1 = skip")
+    ap.add_argument("--batch", type=int, default=32, help="extra leg (not `value`): zkgpu_prover_prove_batch with this many witnesses per call (BASELINE.json configs[2]); 0/1 = skip")
     ap.add_argument("--shard-msm", action="store_true", help="N > 1 only: all ranks prove ONE proof per step together, each holding 1/N of every query; one all-gather of 384-byte partial records per proof (strong scaling)")
     return ap.parse_args()
 

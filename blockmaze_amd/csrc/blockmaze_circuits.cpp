@@ -20,7 +20,7 @@ std::vector<Fe32> pack_public_bits(const std::vector<bool> &bits) {
   for (size_t i = 0; i < n; i++) { memset(&r[i], 0, 32); for (size_t j = 0; j < chunk && i * chunk + j < bits.size(); j++) if (bits[i * chunk + j]) r[i].l[j / 32] |= 1u << (j % 32); }
   return r; }
 
-void Circuit::export_assignment(std::vector<Fe32> &z) const { size_t n = board.val.size() - 1; z.resize(n); for (size_t i = 0; i < n; i++) { HFr c = board.val[i + 1].from_mont(); memcpy(&z[i], c.l, 32); } }
+void Circuit::export_assignment(std::vector<Fe32> &z) const { size_t n = board.num_variables(); z.resize(n); for (size_t i = 0; i < n; i++) { HFr c = board.get(i + 1).from_mont(); memcpy(&z[i], c.l, 32); } }
 
 namespace {
 const LC ONE_LC = LC::constant(HFr::one());
@@ -28,7 +28,7 @@ const LC ONE_LC = LC::constant(HFr::one());
 // value from bits "by order" (pb_variable.tcc:119-133): big-endian bytes, MSB-first bits == the integer itself for a
 // 64-bit value stored as little-endian bytes
 HFr value_by_order(const Board &b, const VarArray &bits) { HFr r = HFr::zero(); size_t n = bits.size();
-  for (size_t i = 0; i < n / 8; i++) for (size_t j = 0; j < 8; j++) { r = r.dbl(); r = r + b.val[bits[n - 1 - i * 8 - (7 - j)]]; } return r; }
+  for (size_t i = 0; i < n / 8; i++) for (size_t j = 0; j < 8; j++) { r = r.dbl(); r = r + b.get(bits[n - 1 - i * 8 - (7 - j)]); } return r; }
 void fill(Board &b, const VarArray &vars, const std::vector<bool> &bits) { for (size_t i = 0; i < vars.size(); i++) b.set_bit(vars[i], bits[i]); }
 
 struct MultiPacking {   // basic_gadgets.tcc:60-108, chunk = Fr capacity = 253 bits
@@ -42,7 +42,7 @@ struct Disjunction {    // basic_gadgets.tcc:197-261
   Board &b; VarArray inputs; Var output, inv;
   Disjunction(Board &b, const VarArray &inputs, Var output) : b(b), inputs(inputs), output(output), inv(b.alloc()) {}
   void constraints() { LC sum; for (Var v : inputs) sum.add(LC(v)); b.constraint(LC(inv), sum, LC(output)); b.constraint(ONE_LC - LC(output), sum, LC()); }
-  void witness() { HFr sum = HFr::zero(); for (Var v : inputs) sum = sum + b.val[v]; if (sum.is_zero()) { b.val[inv] = HFr::zero(); b.val[output] = HFr::zero(); } else { b.val[inv] = sum.inv(); b.val[output] = HFr::one(); } }
+  void witness() { HFr sum = HFr::zero(); for (Var v : inputs) sum = sum + b.get(v); if (sum.is_zero()) { b.set(inv, HFr::zero()); b.set(output, HFr::zero()); } else { b.set(inv, sum.inv()); b.set(output, HFr::one()); } }
 };
 // less_comparison_gadget (src/send/circuit/comparison.tcc:5-96): proves A <= B for 64-bit values.  alpha[64] is the
 // constant ONE (alpha.emplace_back(0) appends variable index 0), so packed(alpha) = 2^64 + B - A forces B - A >= 0.
@@ -52,7 +52,7 @@ struct LessCmp {
     dis.reset(new Disjunction(b, VarArray(alpha.begin(), alpha.begin() + 64), not_all_zeros)); }
   void constraints() { boolean_constraint(b, LC(not_all_zeros)); Packing(b, to_lcs(alpha), alpha_packed).constraints(true);
     b.constraint(ONE_LC, LC::constant(HFr::from_u64(2).pow_u64(64)) + B - A, LC(alpha_packed)); dis->constraints(); b.constraint(ONE_LC, LC(not_all_zeros), LC(not_all_zeros)); }
-  void witness() { b.val[alpha_packed] = HFr::from_u64(2).pow_u64(64) + b.eval(B) - b.eval(A); fill_bits_of_value(b, alpha, b.val[alpha_packed]); dis->witness(); }
+  void witness() { b.set(alpha_packed, HFr::from_u64(2).pow_u64(64) + b.eval(B) - b.eval(A)); fill_bits_of_value(b, alpha, b.get(alpha_packed)); dis->witness(); }
 };
 
 // two-/one-block SHA-256 wrappers with hard-wired padding (src/send/circuit/commitment.tcc); `pad` is the bit pattern of
@@ -121,13 +121,13 @@ struct SendCircuit : Circuit {
     cmtA_old->constraints(); cmt_old->constraints(); cmtS->constraints(); cmt_s->constraints(); cmtA->constraints(); cmt_new->constraints(); }
   void assign(const SendInputs &in) { Board &b = board;                                                               // gadget.tcc:228-271
     static const bool tr = getenv("ZK_TRACE_WITNESS") != nullptr; auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }; double t0 = now(), t1 = 0, t2 = 0, t3 = 0;
-    auto note_fill = [&](Var vo_packed, Var vs_packed) { fill(b, value_old, u64_bits(in.value_old)); b.val[vo_packed] = value_by_order(b, value_old);
-      sn_old->fill(blob_bits(in.sn_old.b, 32)); r_old->fill(blob_bits(in.r_old.b, 32)); fill(b, value_s, u64_bits(in.value_s)); b.val[vs_packed] = value_by_order(b, value_s);
+    auto note_fill = [&](Var vo_packed, Var vs_packed) { fill(b, value_old, u64_bits(in.value_old)); b.set(vo_packed, value_by_order(b, value_old));
+      sn_old->fill(blob_bits(in.sn_old.b, 32)); r_old->fill(blob_bits(in.r_old.b, 32)); fill(b, value_s, u64_bits(in.value_s)); b.set(vs_packed, value_by_order(b, value_s));
       pk_recv->fill(blob_bits(in.pk_recv.b, 20)); r_s->fill(blob_bits(in.r_s.b, 32)); };
     note_fill(l_value_old_packed, l_value_s_packed); less->witness();
-    note_fill(s_value_old_packed, s_value_s_packed); fill(b, value, u64_bits(in.value)); b.val[s_value_packed] = value_by_order(b, value);
+    note_fill(s_value_old_packed, s_value_s_packed); fill(b, value, u64_bits(in.value)); b.set(s_value_packed, value_by_order(b, value));
     sn->fill(blob_bits(in.sn.b, 32)); r->fill(blob_bits(in.r.b, 32)); sk->fill(blob_bits(in.sk.b, 32)); pk_sender->fill(blob_bits(in.pk_sender.b, 20));
-    b.val[ZERO] = HFr::zero(); t1 = now();
+    b.set(ZERO, HFr::zero()); t1 = now();
     // sequential order of the reference: crh (writes r_s), prf (writes sn), cmt_old, cmt_s (reads r_s), cmt_new (reads sn).  Two waves of independent hashers give the same board:
     run_parallel({[&] { crh->witness(); }, [&] { prf->witness(); }, [&] { cmt_old->witness(); }}); run_parallel({[&] { cmt_s->witness(); }, [&] { cmt_new->witness(); }}); t2 = now();
     cmtA_old->fill(blob_bits(in.cmtA_old.b, 32)); cmtS->fill(blob_bits(in.cmtS.b, 32)); cmtA->fill(blob_bits(in.cmtA.b, 32));
@@ -158,11 +158,11 @@ struct MintRedeemCircuit : Circuit {
     b.constraint(ONE_LC, LC(ZERO), LC());
     sn->constraints(); prf->constraints(); sn_old->constraints(); cmtA_old->constraints(); cmt_old->constraints(); cmtA->constraints(); cmt_new->constraints(); }
   template <class In> void assign(const In &in) { Board &b = board;
-    fill(b, value, u64_bits(in.value)); b.val[value_packed] = value_by_order(b, value); fill(b, value_old, u64_bits(in.value_old)); b.val[value_old_packed] = value_by_order(b, value_old);
-    fill(b, value_s, u64_bits(in.value_s)); b.val[value_s_packed] = value_by_order(b, value_s);
+    fill(b, value, u64_bits(in.value)); b.set(value_packed, value_by_order(b, value)); fill(b, value_old, u64_bits(in.value_old)); b.set(value_old_packed, value_by_order(b, value_old));
+    fill(b, value_s, u64_bits(in.value_s)); b.set(value_s_packed, value_by_order(b, value_s));
     sk->fill(blob_bits(in.sk.b, 32)); r->fill(blob_bits(in.r.b, 32)); r_old->fill(blob_bits(in.r_old.b, 32));
     if (redeem) { sn->fill(blob_bits(in.sn.b, 32)); sn_old->fill(blob_bits(in.sn_old.b, 32)); less->witness(); }
-    b.val[ZERO] = HFr::zero();
+    b.set(ZERO, HFr::zero());
     if (!redeem) sn_old->fill(blob_bits(in.sn_old.b, 32));                                                              // (no hasher writes sn_old: filling it before the first wave changes nothing)
     run_parallel({[&] { prf->witness(); }, [&] { cmt_old->witness(); }});                                               // prf writes sn, cmt_old reads sn_old / r_old / value_old
     if (!redeem) sn->fill(blob_bits(in.sn.b, 32));                                                                      // mint/gadget.tcc:213-221: mint overwrites the computed serial number with the given one
@@ -233,11 +233,11 @@ struct DepositCircuit : Circuit {
     cmtS->constraints(); cmt_s->constraints(); cmtB_old->constraints(); cmt_old->constraints(); cmtB->constraints(); cmt_new->constraints();
     rt->constraints(); boolean_constraint(b, LC(value_enforce)); merkle->constraints(); }
   void assign(const DepositInputs &in) { Board &b = board;                                                  // gadget.tcc:235-298
-    fill(b, value_s, u64_bits(in.value_s)); b.val[value_s_packed] = value_by_order(b, value_s); fill(b, value_old, u64_bits(in.value_old)); b.val[value_old_packed] = value_by_order(b, value_old);
-    fill(b, value, u64_bits(in.value)); b.val[value_packed] = value_by_order(b, value);
+    fill(b, value_s, u64_bits(in.value_s)); b.set(value_s_packed, value_by_order(b, value_s)); fill(b, value_old, u64_bits(in.value_old)); b.set(value_old_packed, value_by_order(b, value_old));
+    fill(b, value, u64_bits(in.value)); b.set(value_packed, value_by_order(b, value));
     pk_recv->fill(blob_bits(in.pk_recv.b, 20)); r_s->fill(blob_bits(in.r_s.b, 32)); sn_A_old->fill(blob_bits(in.sn_A_old.b, 32)); sn_old->fill(blob_bits(in.sn_old.b, 32)); r_old->fill(blob_bits(in.r_old.b, 32));
     sn->fill(blob_bits(in.sn.b, 32)); r->fill(blob_bits(in.r.b, 32)); sk->fill(blob_bits(in.sk.b, 32));
-    b.set_bit(value_enforce, in.value_s != 0); b.val[ZERO] = HFr::zero();
+    b.set_bit(value_enforce, in.value_s != 0); b.set(ZERO, HFr::zero());
     if (in.path.size() != depth || in.index_bits.size() != depth) throw std::runtime_error("deposit: Merkle path length does not match the tree depth");
     // reference order: prf_sn (writes sn), prf_sn_s (writes sn_s), sn_s := given, cmt_s, cmt_old, cmt_new (reads sn), the three commitments := given, merkle (reads cmtS).
     run_parallel({[&] { prf_sn->witness(); }, [&] { prf_sn_s->witness(); }, [&] { cmt_s->witness(); }, [&] { cmt_old->witness(); }}); sn_s->fill(blob_bits(in.sn_s.b, 32)); cmtS->fill(blob_bits(in.cmtS.b, 32)); cmtB_old->fill(blob_bits(in.cmtB_old.b, 32));
@@ -273,7 +273,7 @@ struct LessCmpTestCircuit : Circuit {
   VarArray value_old, value_s; Var value_old_packed, value_s_packed; std::unique_ptr<LessCmp> less;
   explicit LessCmpTestCircuit(bool emit) : Circuit(emit) { Board &b = board; value_old = b.alloc_array(64); value_s = b.alloc_array(64); value_old_packed = b.alloc(); value_s_packed = b.alloc();
     less.reset(new LessCmp(b, LC(value_s_packed), LC(value_old_packed))); if (emit) { bool64(b, value_old); bool64(b, value_s); less->constraints(); } b.finish(); }
-  void assign(uint64_t v_old, uint64_t v_s) { Board &b = board; fill(b, value_old, u64_bits(v_old)); b.val[value_old_packed] = value_by_order(b, value_old); fill(b, value_s, u64_bits(v_s)); b.val[value_s_packed] = value_by_order(b, value_s); less->witness(); }
+  void assign(uint64_t v_old, uint64_t v_s) { Board &b = board; fill(b, value_old, u64_bits(v_old)); b.set(value_old_packed, value_by_order(b, value_old)); fill(b, value_s, u64_bits(v_s)); b.set(value_s_packed, value_by_order(b, value_s)); less->witness(); }
 };
 // test circuit: one sha256_CMTA_gadget (commitment.tcc:12-110) on its own — ZERO, value, sn, r, output digest, then the gadget; compared with the same composition
 // built from libsnark's own classes (oracle/ref_harness.cpp cmd_cmta)
@@ -281,7 +281,7 @@ struct CmtaTestCircuit : Circuit {
   Var ZERO; VarArray v, sn, r; std::unique_ptr<Digest> out; std::unique_ptr<ShaTwoBlock> g;
   explicit CmtaTestCircuit(bool emit) : Circuit(emit) { Board &b = board; ZERO = b.alloc(); v = b.alloc_array(64); sn = b.alloc_array(256); r = b.alloc_array(256); out.reset(new Digest(b, 256)); g = make_cmta(b, ZERO, v, sn, r, out->bits);
     if (emit) { b.constraint(ONE_LC, LC(ZERO), LC()); g->constraints(); } b.finish(); }
-  void assign(const std::vector<bool> &bv, const std::vector<bool> &bsn, const std::vector<bool> &br) { Board &b = board; b.val[ZERO] = HFr::zero(); fill(b, v, bv); fill(b, sn, bsn); fill(b, r, br); g->witness(); }
+  void assign(const std::vector<bool> &bv, const std::vector<bool> &bsn, const std::vector<bool> &br) { Board &b = board; b.set(ZERO, HFr::zero()); fill(b, v, bv); fill(b, sn, bsn); fill(b, r, br); g->witness(); }
 };
 std::unique_ptr<Circuit> make_cmta_test_circuit(bool emit) { return std::unique_ptr<Circuit>(new CmtaTestCircuit(emit)); }
 void assign_cmta_test(Circuit &c, const std::vector<bool> &v, const std::vector<bool> &sn, const std::vector<bool> &r) { static_cast<CmtaTestCircuit &>(c).assign(v, sn, r); }

@@ -41,7 +41,7 @@ std::string key_path(CircuitKind k, bool pk) { return key_dir() + "/" + circuit_
 struct FileStamp { off_t size = -1; time_t mtime = 0; long mtime_ns = 0; bool operator==(const FileStamp &o) const { return size == o.size && mtime == o.mtime && mtime_ns == o.mtime_ns; } };
 bool stamp_of(const std::string &p, FileStamp &s) { struct stat st; if (stat(p.c_str(), &st)) return false; s.size = st.st_size; s.mtime = st.st_mtim.tv_sec; s.mtime_ns = st.st_mtim.tv_nsec; return true; }
 
-// One proving key = a small pool of provers (ZK_PROVERS_PER_KEY, default 2), each with its own circuit board, device buffers and stream set: cgo calls
+// One proving key = a small pool of provers (ZK_PROVERS_PER_KEY, default 6), each with its own circuit board, device buffers and stream set: cgo calls
 // that arrive concurrently (tx pool, RPC goroutines, block processing) overlap on the GPU instead of queueing behind one mutex.
 struct ProverUnit { std::shared_ptr<Prover> prover; std::unique_ptr<Circuit> circuit; std::mutex busy; };
 typedef std::vector<std::shared_ptr<ProverUnit>> UnitList;
@@ -66,7 +66,7 @@ HeldUnit acquire_prover(CircuitKind k) {
   std::shared_ptr<const UnitList> units; unsigned turn = 0;
   { std::lock_guard<std::mutex> lk(g_gpu_mutex); ProverSlot &slot = g_provers[path];
     if (!slot.units || !(slot.stamp == st)) {
-      bool cached = false; ProvingKeyHost pk = load_proving_key_fast(path, cached); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 4; if (n < 1) n = 1; if (n > 7) n = 7;
+      bool cached = false; ProvingKeyHost pk = load_proving_key_fast(path, cached); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 6; if (n < 1) n = 1; if (n > 7) n = 7;
       // per device of the process's list (ZK_DEVICES): one prover built from the key, the rest of that device's members share its tables.  The list is interleaved by
       // device — d0u0 d1u0 ... d0u1 d1u1 ... — so that callers walking it from a rotating start (below) spread over the GPUs before they double up on one.
       auto fresh = std::make_shared<UnitList>(); const int D = std::max(1, gpu_device_slots()); std::vector<std::shared_ptr<Prover>> first(D);
@@ -115,7 +115,7 @@ template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
     double t0 = now(); HeldUnit held = acquire_prover(k); ProverUnit &slot = *held.unit; double t1 = now(); assign(*slot.circuit); double t2 = now();
     printf("Trying to generate %s proof...\n", circuit_name(k)); fflush(stdout);
     Fe32 r, s; bool fixed = parse_fixed_rs(r, s); Proof proof;
-    slot.prover->set_witness(reinterpret_cast<const Fe32 *>(slot.circuit->board.val.data() + 1), true);   // the board holds Montgomery values: no conversion on either side
+    slot.prover->set_witness_tagged(slot.circuit->board.tag.data(), reinterpret_cast<const Fe32 *>(slot.circuit->board.wide.data()));   // the board's own form (one byte per 0 / 1, Montgomery values for the rest): no conversion, no scan
     double t3 = now();
     if (!slot.prover->prove_resident(fixed ? &r : nullptr, fixed ? &s : nullptr, proof)) { printf("can not generate %s proof\n", circuit_name(k)); fflush(stdout); proof = default_proof(); }
     double t4 = now(); char *out = dup_string(proof_to_hex(proof));
@@ -270,7 +270,7 @@ int zkgpu_prover_finish(zkgpu_prover *h, const uint8_t *records, size_t n, const
 zkgpu_prover *zkgpu_prover_clone(zkgpu_prover *h) { zkgpu_prover *out = nullptr; guarded([&] { if (!h) return ZKGPU_ERR_ARG; std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(*h->p)); out = p.release(); return ZKGPU_OK; }); return out; }
 int zkgpu_prover_prove_batch(zkgpu_prover *h, const uint8_t *zs, size_t n, const uint8_t *rs, char *proofs_hex) { return guarded_prover(h, [&] {
   if (!h || (n && (!zs || !proofs_hex))) return ZKGPU_ERR_ARG; if (!n) return ZKGPU_OK;
-  static const size_t want = [] { const char *e = getenv("ZK_BATCH_LANES"); long v = e ? atol(e) : 4; return (size_t)(v < 1 ? 1 : v > 7 ? 7 : v); }();
+  static const size_t want = [] { const char *e = getenv("ZK_BATCH_LANES"); long v = e ? atol(e) : 6; return (size_t)(v < 1 ? 1 : v > 7 ? 7 : v); }();
   const size_t K = std::min(want, n); { std::lock_guard<std::mutex> lk(g_gpu_mutex); while (h->lanes.size() + 1 < K) h->lanes.push_back(std::make_shared<Prover>(*h->p)); }
   const size_t zbytes = 32 * h->p->num_variables(); std::vector<uint8_t> bad(n, 0); std::vector<std::string> errs(K); std::vector<std::thread> th;
   auto work = [&](size_t lane) { Prover &pv = lane ? *h->lanes[lane - 1] : *h->p;

@@ -51,19 +51,24 @@ inline LCArray to_lcs(const VarArray &v) { LCArray r; r.reserve(v.size()); for (
 
 class Board {
  public:
-  explicit Board(bool emit_constraints) : emit(emit_constraints) { val.push_back(HFr::one()); for (int m = 0; m < 3; m++) cs.rowptr[m].push_back(0); }
+  explicit Board(bool emit_constraints) : emit(emit_constraints) { tag.push_back(1); wide.push_back(HFr::one()); for (int m = 0; m < 3; m++) cs.rowptr[m].push_back(0); }
   bool emit;                                   // false: witness-only pass (allocation still happens, constraints are skipped)
-  std::vector<HFr> val;                        // val[0] = 1
+  // The assignment, variable 0 = ONE.  97 % of a BlockMaze witness is 0 or 1 (bits of SHA-256 states), so a value is ONE BYTE — tag 0 / 1 — unless it is something
+  // else (tag 2, value in wide[]): a SHA round writes ~900 bytes instead of 28 KB of field elements, and the prover takes tags + wide values as they are
+  // (Prover::set_witness_tagged: no scan of a 7 MB vector to find the zeros and ones again).
+  std::vector<uint8_t> tag; std::vector<HFr> wide;
   R1csHost cs;
-  Var alloc() { val.push_back(HFr::zero()); return (Var)(val.size() - 1); }
+  Var alloc() { tag.push_back(0); wide.push_back(HFr::zero()); return (Var)(tag.size() - 1); }
   VarArray alloc_array(size_t n) { VarArray a(n); for (size_t i = 0; i < n; i++) a[i] = alloc(); return a; }
   void set_input_sizes(size_t n) { cs.n_inputs = n; }
-  size_t num_variables() const { return val.size() - 1; }
+  size_t num_variables() const { return tag.size() - 1; }
   void constraint(const LC &a, const LC &b, const LC &c);
-  HFr eval(const LC &lc) const { if (lc.t.size() == 1 && lc.t[0].one) return val[lc.t[0].v]; HFr s = HFr::zero(); for (const Term &x : lc.t) s = s + (x.one ? val[x.v] : x.c * val[x.v]); return s; }
-  bool eval_bit(const LC &lc) const { if (lc.t.size() == 1 && lc.t[0].one) return !val[lc.t[0].v].is_zero(); if (lc.t.empty()) return false; return !eval(lc).is_zero(); }
-  void set_bit(Var v, bool b) { if (v) val[v] = b ? HFr::one() : HFr::zero(); }   // writes to ONE are dropped (see LessCmp)
-  bool bit(Var v) const { return !val[v].is_zero(); }
+  HFr get(Var v) const { const uint8_t t = tag[v]; return t == 2 ? wide[v] : t ? HFr::one() : HFr::zero(); }
+  void set(Var v, const HFr &x) { if (x.is_zero()) tag[v] = 0; else if (x == HFr::one()) tag[v] = 1; else { wide[v] = x; tag[v] = 2; } }
+  HFr eval(const LC &lc) const { if (lc.t.size() == 1 && lc.t[0].one) return get(lc.t[0].v); HFr s = HFr::zero(); for (const Term &x : lc.t) { const uint8_t t = tag[x.v]; if (t == 0) continue; s = s + (x.one ? get(x.v) : t == 1 ? x.c : x.c * wide[x.v]); } return s; }
+  bool eval_bit(const LC &lc) const { if (lc.t.size() == 1 && lc.t[0].one) return tag[lc.t[0].v] != 0; if (lc.t.empty()) return false; return !eval(lc).is_zero(); }
+  void set_bit(Var v, bool b) { if (v) tag[v] = (uint8_t)b; }   // writes to ONE are dropped (see LessCmp)
+  bool bit(Var v) const { return tag[v] != 0; }
   void finish() { cs.n_vars = num_variables(); cs.n_cons = cs.rowptr[0].size() - 1; }
  private:
   void push(int m, const LC &lc);
@@ -79,7 +84,7 @@ struct Packing {      // packed = sum bits[i] 2^i
   Board &b; LCArray bits; LC packed; bool packed_is_var; Var packed_var;
   Packing(Board &b, const LCArray &bits, Var packed) : b(b), bits(bits), packed(packed), packed_is_var(true), packed_var(packed) {}
   void constraints(bool enforce_bitness);
-  void witness_from_bits() { b.val[packed_var] = pack_bits_value(b, bits); }
+  void witness_from_bits() { b.set(packed_var, pack_bits_value(b, bits)); }
 };
 
 struct Digest { Board &b; VarArray bits; Digest(Board &b, size_t n) : b(b), bits(b.alloc_array(n)) {} void constraints() { for (Var v : bits) boolean_constraint(b, LC(v)); }

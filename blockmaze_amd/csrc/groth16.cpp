@@ -361,6 +361,21 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   if (!montgomery) fr_to_mont_dev(p.z.get(), n);
   last.upload_ms = now_ms() - t0;
 }
+void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
+  Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); const size_t n = p.nv + 1, words = (n + 63) / 64; Fe32 one; memcpy(&one, FrParams::R1, 32);
+  uint8_t *pk = reinterpret_cast<uint8_t *>(p.z_host.get()); uint64_t *ones = (uint64_t *)pk, *other = ones + words; uint32_t *off = (uint32_t *)(other + words);   // the layout set_witness builds
+  const size_t vals_at = ((words * 20 + 31) / 32) * 32; Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4; size_t n_other = 0; bool fits = true;
+  constexpr uint64_t LSB = 0x0101010101010101ull, GATHER = 0x0102040810204080ull;              // (y & LSB) * GATHER >> 56: the low bits of 8 bytes as one byte
+  for (size_t w = 0; w < words && fits; w++) { const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; uint64_t mo = 0, mx = 0; off[w] = (uint32_t)n_other;
+    if (hi - lo == 64) for (size_t k = 0; k < 8; k++) { uint64_t x; memcpy(&x, tag + lo + 8 * k, 8); mo |= (((x & LSB) * GATHER) >> 56) << (8 * k); mx |= ((((x >> 1) & LSB) * GATHER) >> 56) << (8 * k); }
+    else for (size_t i = lo; i < hi; i++) { mo |= (uint64_t)(tag[i] & 1) << (i - lo); mx |= (uint64_t)((tag[i] >> 1) & 1) << (i - lo); }
+    if (n_other + (size_t)__builtin_popcountll(mx) > max_other) { fits = false; break; }
+    for (uint64_t m = mx; m; m &= m - 1) vals[n_other++] = wide[lo + (size_t)__builtin_ctzll(m)];
+    ones[w] = mo; other[w] = mx; }
+  if (fits) { upload_async(p.packed.get(), pk, vals_at + 32 * n_other); expand_witness_dev(p.packed.get(), words, one, n, p.z.get()); }
+  else { Fe32 *h = p.z_host.get(); Fe32 zero; memset(&zero, 0, 32); for (size_t i = 0; i < n; i++) h[i] = tag[i] == 2 ? wide[i] : tag[i] ? one : zero; upload_async(p.z.get(), h, 32 * n); }   // a dense assignment (never a BlockMaze one)
+  last.upload_ms = now_ms() - t0;
+}
 struct RsTerms { HFr r, s; HG1 r_delta, s_delta, rs_delta_neg; HG2 s_delta2; };
 static RsTerms rs_terms(const Fe32 *r_in, const Fe32 *s_in, const HG1 &delta_g1, const HG2 &delta_g2) {   // everything that depends only on (r, s) and the key (:488-495)
   RsTerms t; t.r = r_in ? fr_of(*r_in) : random_fr().from_mont(); t.s = s_in ? fr_of(*s_in) : random_fr().from_mont(); HFr rs = (t.r.to_mont() * t.s.to_mont()).from_mont();   // canonical scalars
