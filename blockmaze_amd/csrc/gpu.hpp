@@ -76,7 +76,7 @@ class MsmG2 {
   MsmG2(const MsmG2 &peer, bool filter_ones, bool uniform_scalars);
   ~MsmG2();
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
-  bool share_sort_with(const std::shared_ptr<WsortBuffers> &leader);
+  std::shared_ptr<WsortBuffers> sort_handle() const; bool share_sort_with(const std::shared_ptr<WsortBuffers> &leader);
   host::HG2 result(); void set_label(const char *l); void set_stream(int aux); void split_ones_path();
   struct Impl; std::unique_ptr<Impl> impl;
 };

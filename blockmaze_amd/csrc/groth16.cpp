@@ -281,7 +281,7 @@ struct Prover::Impl {
   // The submit thread of a witness MSM also waits for its stream and finishes the MSM on the host (Horner combine, or the host tail of msm_impl.hpp): four threads do that
   // side by side while the H chain is still running.  pending[j]: job j (order B2, L, A, B1) was posted and its result slot is not valid before workers[j]->wait().
   HG2 rB2; HG1 rL, rA, rB1; bool pending[4] = {false, false, false, false}, inline_result[4] = {false, false, false, false};
-  bool pair_AL = false, pair_B = false;                       // L* rides on A's sort and job, B2 on B1's (same scalar vectors: msm.cuh, "witness MSMs in three launches")
+  bool pair_AL = false, pair_B = false, b2_first = false;                       // L* rides on A's sort and job, B2 on B1's (same scalar vectors: msm.cuh, "witness MSMs in three launches")
   int owner(int j) const { return j == 1 && pair_AL ? 2 : j == 0 && pair_B ? 3 : j; }
   void settle(int j) { const int o = owner(j); if (pending[o]) { pending[o] = false; workers[o]->wait(); } if (inline_result[j]) { inline_result[j] = false; switch (j) { case 0: rB2 = B2->result(); break; case 1: rL = L->result(); break; case 2: rA = A->result(); break; default: rB1 = B1->result(); } } }
   void settle_all_quietly() { for (int j = 0; j < 4; j++) { try { settle(j); } catch (...) {} } }
@@ -292,7 +292,7 @@ static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &
 // streams, labels and the per-object vectors (everything that is not shared between the provers of one key)
 static void finish_setup(Prover::Impl &p) {
   const bool one_stream = env_int("ZK_MSM_ONE_STREAM", 0) != 0;   // diagnostic: everything on the main stream, so that a kernel trace shows every kernel's stand-alone duration
-  if (env_int("ZK_MSM_SHARE_SORT", 1)) { p.pair_AL = p.c_fold && p.a0 == p.l0 && p.L->share_sort_with(p.A->sort_handle()); p.pair_B = p.B2->share_sort_with(p.B1->sort_handle()); }
+  if (env_int("ZK_MSM_SHARE_SORT", 1)) { p.pair_AL = p.c_fold && p.a0 == p.l0 && p.L->share_sort_with(p.A->sort_handle()); p.b2_first = env_int("ZK_B2_FIRST", 1) != 0; p.pair_B = p.b2_first ? p.B1->share_sort_with(p.B2->sort_handle()) : p.B2->share_sort_with(p.B1->sort_handle()); }
   if (!one_stream) { p.A->set_stream(0); p.L->set_stream(p.pair_AL ? 0 : 1); p.B1->set_stream(2); p.B2->set_stream(p.pair_B ? 2 : 3); if (!p.pair_B && env_int("ZK_MSM_SPLIT_ONES", 1)) p.B2->split_ones_path(); }   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
   p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
   p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host = PinnedBuf<Fe32>(p.nv + 1 + 8); p.packed = DevBuf<uint8_t>(32 * (p.nv + 1 + 8));
@@ -389,13 +389,17 @@ static void enqueue_all(Prover::Impl &p) {
   // about 80 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
   // (auxiliary streams) while this one submits the critical chain
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
-  static const char *dbg_skip = getenv("ZK_DEBUG_SKIP");   // diagnostic only (tools/inflight_probe.py): 'w' drops the witness MSMs, 'h' the H query, 'n' the transforms — the proofs are then WRONG; used to see what share of the machine each part takes
+#ifdef ZKGPU_TEST_HOOKS   // diagnostic builds only (make HOOKS=1; tools/inflight_probe.py): 'w' drops the witness MSMs, 'h' the H query, 'n' the transforms — the proofs are then WRONG; shows what share of the machine each part takes
+  static const char *dbg_skip = getenv("ZK_DEBUG_SKIP");
   const bool skip_w = dbg_skip && strchr(dbg_skip, 'w'), skip_h = dbg_skip && strchr(dbg_skip, 'h'), skip_n = dbg_skip && strchr(dbg_skip, 'n');
+#else
+  constexpr bool skip_w = false, skip_h = false, skip_n = false;
+#endif
   Prover::Impl *pp = &p;
   auto runB2 = [pp] { pp->B2->run(pp->z.get(), pp->B_idx->get() + pp->b0); }; auto runL = [pp] { pp->L->run(pp->z.get() + (pp->c_fold ? 0 : pp->ni + 1) + pp->l0, nullptr); };       // r1cs_gg_ppzksnark.tcc:442-462,477-484
   auto runA = [pp] { pp->A->run(pp->z.get() + pp->a0, nullptr); }; auto runB1 = [pp] { pp->B1->run(pp->z.get(), pp->B_idx->get() + pp->b0); };
   // job order: B2, L, A, B1 (longest first).  A follower of a shared sort is queued behind its leader by the leader's job: its own slot stays empty.
-  std::function<void()> jobs[4] = { runB2, runL, [pp, runA, runL] { runA(); if (pp->pair_AL) runL(); }, [pp, runB1, runB2] { runB1(); if (pp->pair_B) runB2(); } };
+  std::function<void()> jobs[4] = { runB2, runL, [pp, runA, runL] { runA(); if (pp->pair_AL) runL(); }, [pp, runB1, runB2] { if (pp->pair_B && pp->b2_first) { runB2(); runB1(); } else { runB1(); if (pp->pair_B) runB2(); } } };   // the G2 MSM first: its long accumulation then overlaps the transforms, not the H accumulation
   std::function<void()> finish[4] = { [pp] { pp->rB2 = pp->B2->result(); }, [pp] { pp->rL = pp->L->result(); }, [pp] { pp->rA = pp->A->result(); if (pp->pair_AL) pp->rL = pp->L->result(); }, [pp] { pp->rB1 = pp->B1->result(); if (pp->pair_B) pp->rB2 = pp->B2->result(); } };
   const bool job_used[4] = {!p.pair_B, !p.pair_AL, true, true};
   const int job_stream[4] = {3, 1, 0, 2};                       // the auxiliary stream each MSM was bound to in the constructor (set_stream)

@@ -30,7 +30,7 @@ struct MsmImpl {
   DevBuf<uint32_t> offsets, entries, ones, ntasks, task_off, order, rank_of, block_hist, block_off, cls_start; uint32_t bsort_blocks; std::unique_ptr<Scanner> bsort_scanner; Scanner scanner, task_scanner; uint32_t max_tasks;
   DevBuf<uint32_t> lane_off;   // fused witness path: where each bucket's lanes start
   DevBuf<uint8_t> buckets, partials, seg_out, seg_l2, ones_partial, ones_l2, result;   // XYZZ<F> arrays, kept as bytes to stay out of the header; result = W window sums, the ones sum, the counters
-  uint8_t *h_result = nullptr;                                      // pinned copy of `result`
+  uint8_t *h_result = nullptr, *h_result_dev = nullptr;             // pinned host memory the last kernels of an MSM write their sums into (device address of the same pages); only under ZK_MSM_MAPPED_RESULT=1, otherwise `result` is copied
   // Host tail (optional, ZK_MSM_HOST_TAIL=1; one bucket array, i.e. fixed-base tables): the last, purely dependent additions of an MSM done by the host, which idles
   // while the device works (the MSM's submit thread does them, groth16.cpp).  Frees the device of its slowest tiny kernels, but is no faster (see the constructor).  tail = [T0: 256 sums | T1: 64 partial sums of the scalar-one path | counters].  Witness MSMs (at most
   // 256 buckets): T0 IS the bucket array and the host does the weighted running-sum reduction (2 * 128 additions); H query: T0 holds the sums of 256 segments each.
@@ -109,7 +109,9 @@ struct MsmImpl {
     seg_out = DevBuf<uint8_t>((size_t)WB * (NB / seg) * sizeof(XYZZ<F>)); seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
     ones_partial = DevBuf<uint8_t>(std::max<size_t>(n_ones_quads, wfused ? (size_t)NB + WFUSED_ONES_BLOCKS : 0) * sizeof(XYZZ<F>)); if (wfused) lane_off = DevBuf<uint32_t>(WFUSED_MAX_BUCKETS + 1); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
     zeroed.zero(); result = DevBuf<uint8_t>(result_bytes()); result.zero();          // the ones slot stays the point at infinity when the ones path is off
-    HIP_CHECK(hipHostMalloc((void **)&h_result, result_bytes())); HIP_CHECK(hipStreamSynchronize(gpu().stream));
+    HIP_CHECK(hipHostMalloc((void **)&h_result, result_bytes())); memset(h_result, 0, result_bytes());
+    if (getenv("ZK_MSM_MAPPED_RESULT") && atoi(getenv("ZK_MSM_MAPPED_RESULT")) != 0) HIP_CHECK(hipHostGetDevicePointer((void **)&h_result_dev, h_result, 0));   // opt-in: saves the copy's blit kernel (25-40 us on the stream); measured 1.433 vs 1.437 ms per proof, i.e. nothing
+    HIP_CHECK(hipStreamSynchronize(gpu().stream));
   }
   ~MsmImpl() { if (h_result) hipHostFree(h_result); if (h_tail) hipHostFree(h_tail); if (ones_stream) hipStreamDestroy(ones_stream); if (ev_classified) hipEventDestroy(ev_classified); if (ev_ones) hipEventDestroy(ev_ones); }
   void enable_split_ones() { if (split_ones || !filter_ones) return; HIP_CHECK(hipStreamCreateWithFlags(&ones_stream, hipStreamNonBlocking)); HIP_CHECK(hipEventCreateWithFlags(&ev_classified, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ev_ones, hipEventDisableTiming)); split_ones = true; }
@@ -129,7 +131,7 @@ struct MsmImpl {
 
   void run_impl(const Fe32 *scalars, const uint32_t *scalar_index) {
     hipStream_t s = stream(); size_t nbk = (size_t)WB * NB; const uint32_t hist_stride = WB == 1 ? 0 : NB, point_stride = WB == 1 && W > 1 ? (uint32_t)n : 0; const uint8_t *infp = any_inf ? inf.get() : nullptr; MsmCounters *cnt = counters();
-    const uint32_t bucket_u4 = sizeof(XYZZ<F>) / 16; XYZZ<F> *res = (XYZZ<F> *)result.get();
+    const uint32_t bucket_u4 = sizeof(XYZZ<F>) / 16; XYZZ<F> *res = h_result_dev ? (XYZZ<F> *)h_result_dev : (XYZZ<F> *)result.get();
     // (histogram and slot counters were cleared by the constructor and are left cleared by every run (k_msm_combine_tasks); the MsmCounters alternate between two slots)
     parity ^= 1; cnt = counters(); tail_n1 = 0;
     bool ones_forked = false;
@@ -157,7 +159,7 @@ struct MsmImpl {
           hipLaunchKernelGGL((k_wacc_lanes<F>), dim3((WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) / 256), dim3(256), 0, s, (const Affine<F> *)points.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l1, lane_off.get());
           hipLaunchKernelGGL((k_wacc_fold<F>), dim3(NB + WFUSED_ONES_GROUPS), dim3(256), 0, s, (const XYZZ<F> *)l1, (const uint32_t *)lane_off.get(), NB, l2); } }
       { Stage st((label + ".reduce").c_str(), s); hipLaunchKernelGGL((k_wtail<F>), dim3(2), dim3(256), 0, s, (const XYZZ<F> *)l2, NB, (const XYZZ<F> *)l2 + NB, n_op, res, csrc, cdst); }
-      HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s)); return;
+      if (!h_result_dev) HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s)); return;
     }
     if (sparse) {
       const uint32_t nq = 16384, nblk = nq / 64; uint4 *csrc = (uint4 *)cnt; uint4 *cdst = (uint4 *)(res + WB + 1);
@@ -168,7 +170,7 @@ struct MsmImpl {
       }
       { Stage st((label + ".accumulate").c_str(), s); hipLaunchKernelGGL((k_wmsm_sum<F>), dim3(nblk), dim3(256), 0, s, (const Affine<F> *)points.get(), ones.get(), (const uint2 *)others.get(), others_cap, cnt, nq, (XYZZ<F> *)ones_partial.get()); }
       { Stage st((label + ".reduce").c_str(), s); hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(256), 0, s, (const XYZZ<F> *)ones_partial.get(), nblk, nblk, res, csrc, cdst); }
-      HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s)); return;
+      if (!h_result_dev) HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s)); return;
     }
     const bool hs_run = direct && hsort && scalar_index == nullptr;
     if (hs_run) { Stage st((label + ".sort").c_str(), s);
@@ -239,7 +241,7 @@ struct MsmImpl {
     if (filter_ones && n && !split_ones) ones_path(s);
     if (ones_forked) HIP_CHECK(hipStreamWaitEvent(s, ev_ones, 0));
     if (tail_mode) HIP_CHECK(hipMemcpyAsync(h_tail, tail.get(), tail_bytes(), hipMemcpyDeviceToHost, s));
-    else HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s));
+    else if (!h_result_dev) HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s));
   }
 };
 

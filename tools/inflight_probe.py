@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """What bounds the rate with several proofs in flight?  K prover objects (sharing one key's tables), one host thread each, resident witnesses; optionally with parts of the
-pipeline dropped (ZK_DEBUG_SKIP=w / h / n: witness MSMs / H query / transforms — the proofs are wrong then, only the timing means something).
+pipeline dropped (ZK_DEBUG_SKIP=w / h / n: witness MSMs / H query / transforms — the proofs are wrong then, only the timing means something; the switch exists
+only in a diagnostic build of the library: `make -C blockmaze_amd/csrc clean && make -C blockmaze_amd/csrc HOOKS=1`, and rebuild without HOOKS afterwards).
     python tools/inflight_probe.py [K=3] [proofs per thread=60]"""
 import os, sys, tempfile, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
