@@ -22,7 +22,7 @@ struct MsmImpl {
   bool direct = false, offsets_direct = false; uint32_t cap = 0, task = MSM_TASK;   // task: sorted entries per accumulation lane
   bool split_ones = false; hipStream_t ones_stream = nullptr; hipEvent_t ev_classified = nullptr, ev_ones = nullptr;   // the ones path on a stream of its own, beside the bucket path (the G2 MSM: both are long chains)
   const Fe32 *prod_b = nullptr, *prod_z = nullptr; bool prod_z_table = false; DevBuf<Fe32> prod_tmp;   // scalars given as a product a*b*z (run_product)
-  bool wfused = false, wacc_quads = false, ws_leader = true; std::shared_ptr<WsortBuffers> ws;   // witness MSMs in three launches (k_wsort / k_wacc / k_wtail); needs the fixed-base tables and at most 128 buckets
+  bool wfused = false, wacc_quads = false, ws_leader = true, overflow_noted = false; std::shared_ptr<WsortBuffers> ws;   // witness MSMs in three launches (k_wsort / k_wacc / k_wtail); needs the fixed-base tables and at most 128 buckets
   bool sparse = false; DevBuf<uint8_t> others; uint32_t others_cap = 0;   // witness MSMs without buckets (k_wmsm_classify / k_wmsm_sum, msm.cuh): needs the fixed-base tables
   bool hsort = false; HsortShape hs{0, 0, 0, 0}; DevBuf<uint32_t> group_fill, mid;   // group-binned one-pass sort (k_hsort_bin / k_hsort_group, msm.cuh)
   const Fe32 *last_scalars = nullptr; const uint32_t *last_index = nullptr;   // one-pass sort (k_msm_scatter_direct) for uniform scalars
@@ -88,7 +88,7 @@ struct MsmImpl {
       if (tail_mode) { tail = DevBuf<uint8_t>(tail_bytes()); tail.zero(); HIP_CHECK(hipHostMalloc((void **)&h_tail, tail_bytes())); memset(h_tail, 0, tail_bytes()); } }
     if (filter_ones && WB == 1 && n && NB >= 16 && NB <= WFUSED_MAX_BUCKETS && n * (size_t)W < (1ull << 31) && !(getenv("ZK_MSM_WFUSED") && atoi(getenv("ZK_MSM_WFUSED")) == 0)) {
       wfused = true; tail_mode = 0; { const char *e = getenv("ZK_MSM_WACC"); wacc_quads = e ? !strcmp(e, "quads") : sizeof(F) > 32; }   // G2 accumulates by quads, G1 by lanes (msm.cuh)
-      ws = std::make_shared<WsortBuffers>(); ws->NB = NB; ws->n = n; ws->cap = getenv("ZK_MSM_DIRECT_CAP") ? 2 : 8192;   // (test hook: a tiny region forces the overflow fallback)
+      ws = std::make_shared<WsortBuffers>(); ws->NB = NB; ws->n = n; ws->cap = getenv("ZK_MSM_DIRECT_CAP") ? 2 : (uint32_t)std::min<size_t>(std::max<size_t>(8192, n / 8), 1u << 17);   // (test hook: a tiny region forces the overflow fallback)
       ws->fill = DevBuf<uint32_t>(2 * NB); ws->fill.zero(); ws->entries = DevBuf<uint32_t>((size_t)NB * ws->cap); ws->ones = DevBuf<uint32_t>(n); ws->counters = DevBuf<uint32_t>(2 * sizeof(MsmCounters) / 4); ws->counters.zero();
       HIP_CHECK(hipEventCreateWithFlags(&ws->sorted, hipEventDisableTiming)); }
     if (filter_ones && WB == 1 && n && getenv("ZK_MSM_SPARSE") != nullptr && atoi(getenv("ZK_MSM_SPARSE")) != 0) {   // opt-in (measured: chains 2-3x shorter, but 3x the field products of the bucket path, which the other streams then miss: 1.82 vs 1.74 ms per send proof)
@@ -118,7 +118,8 @@ struct MsmImpl {
   hipStream_t stream() { return stream_id < 0 ? gpu().stream : gpu().aux[stream_id & 3]; }
   // after the stream has been synchronised: did a bucket of the one-pass sort overflow?  Then repeat the last run on the two-pass path (synchronously).
   void finish_sync() { HIP_CHECK(hipStreamSynchronize(stream()));
-    if (wfused && host_counters()->pad[0]) { wfused = false; run_impl(last_scalars, last_index); HIP_CHECK(hipStreamSynchronize(stream())); wfused = true; }   // a bucket's region overflowed: the general path handles any input
+    if (wfused && host_counters()->pad[0]) { if (!overflow_noted) { overflow_noted = true; fprintf(stderr, "libzkgpu: %s: a bucket of the witness sort overflowed (%u slots), general MSM path used\n", label.c_str(), ws->cap); }
+      wfused = false; run_impl(last_scalars, last_index); HIP_CHECK(hipStreamSynchronize(stream())); wfused = true; }   // a bucket's region overflowed: the general path handles any input
     if (sparse && host_counters()->pad[0]) { sparse = false; run_impl(last_scalars, last_index); HIP_CHECK(hipStreamSynchronize(stream())); sparse = true; }   // more digits than the list holds: the bucket path handles any input
     if (direct && host_counters()->pad[0]) { direct = false; offsets_direct = false; const Fe32 *sc = last_scalars; const bool was_hsort = hsort; hsort = false;
       if (was_hsort) { HIP_CHECK(hipMemsetAsync(zeroed.get(), 0, 2 * (size_t)WB * NB * sizeof(uint32_t), stream())); HIP_CHECK(hipMemsetAsync(group_fill.get(), 0, hs.groups * sizeof(uint32_t), stream())); }   // hist() held the bucket counts of the group sort; the two-pass path wants it cleared
