@@ -17,8 +17,9 @@ class GpuContext {
     // (GPU_MAX_HW_QUEUES is raised by the library constructor in gpu.hip, before any HIP call of this process can have read it)
     int n = 0; if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
     device = device_index % n;
-    HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipGetDeviceProperties(&prop, device)); HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));   // (a high-priority main stream was measured: no gain for one proof, 15 % loss with four in flight)
-    for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking)); HIP_CHECK(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming)); for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&join_event[i], hipEventDisableTiming));
+    HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipGetDeviceProperties(&prop, device)); const char *pe = getenv("ZK_STREAM_PRIORITY"); const int pm = pe ? atoi(pe) : 0; int lo = 0, hi = 0; HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (lo = least urgent; numerically greater)
+    if (pm & 1) HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi)); else HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));   // (round 1: a high-priority main stream gave nothing for one proof and cost 15 % with four in flight)
+    for (int i = 0; i < 4; i++) { if (pm & 2) HIP_CHECK(hipStreamCreateWithPriority(&aux[i], hipStreamNonBlocking, lo)); else HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking)); } HIP_CHECK(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming)); for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&join_event[i], hipEventDisableTiming));
   }
 };
 GpuContext &gpu();

@@ -165,7 +165,7 @@ __global__ void k_msm_scatter_direct(const Fr *__restrict__ scalars, const uint3
 //                  final place inside the group's region of the output (a 64 KB window that lives in this XCD's L2 while it is written).  Emits counts[] / offsets[].
 // Uniform scalars fill every group to within a few per cent of n*W/G, so a region holds 1.25x that; a region that would overflow raises the same flag as before
 // and the host repeats the MSM on the two-pass path (any input stays correct).  With every bucket holding lambda +- 3 sqrt(lambda) entries there is also no need
-// for a task plan: each bucket is cut into HSORT_SLICES equal slices (k_msm_accumulate_slices), whose partial sums one quad adds up (k_msm_combine_slices).
+// for a task plan: each bucket is cut into equal slices (k_msm_accumulate_slices; how many: msm_impl.hpp, h_slices), whose partial sums one quad adds up (k_msm_combine_slices).
 constexpr uint32_t HSORT_GROUPS = 1024 /* at most; the shape says how many are used */, HSORT_BIN_THREADS = 256, HSORT_PER_THREAD = 2, HSORT_TILE = HSORT_BIN_THREADS * HSORT_PER_THREAD, HSORT_GROUP_THREADS = 512, HSORT_MAX_PER_THREAD = 48, HSORT_SLICES = 8, HSORT_STAGE_W = 20 /* staged entries per scalar: at most 254 / c + 1 digits, c >= 13 */;
 struct HsortShape { uint32_t groups, low_bits, idx_bits, region; };     // groups * 2^low_bits = buckets; bucket = group << low_bits | low; entry = low << (idx_bits + 1) | sign << idx_bits | index; region: entry slots per group
 template <int C>
@@ -349,9 +349,9 @@ template <int NT, class F> __device__ __forceinline__ Affine<F> load_point(const
 }
 template <int VARIANT, class F>
 __global__ void __launch_bounds__(256) k_msm_accumulate_slices(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
-                                                               uint32_t n_buckets, XYZZ<F> *__restrict__ partials) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= n_buckets * HSORT_SLICES) return;
-  const uint32_t b = t / HSORT_SLICES, j = t % HSORT_SLICES, cnt = counts[b], beg = offsets[b] + (cnt * j) / HSORT_SLICES, end = offsets[b] + (cnt * (j + 1)) / HSORT_SLICES;
+                                                               uint32_t n_buckets, uint32_t slices, XYZZ<F> *__restrict__ partials) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= n_buckets * slices) return;
+  const uint32_t b = t / slices, j = t - b * slices, cnt = counts[b], beg = offsets[b] + (cnt * j) / slices, end = offsets[b] + (cnt * (j + 1)) / slices;
   XYZZ<F> acc = XYZZ<F>::inf(); constexpr int NT = VARIANT & 1;
   if (beg < end) {
     if constexpr (VARIANT & 2) {                             // two points in flight
@@ -368,12 +368,15 @@ __global__ void __launch_bounds__(256) k_msm_accumulate_slices(const Affine<F> *
   partials[t] = acc;
 }
 template <class F>
-__global__ void __launch_bounds__(256) k_msm_combine_slices(const XYZZ<F> *__restrict__ partials, uint32_t n_buckets, XYZZ<F> *__restrict__ buckets) {
-  const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; const int k = threadIdx.x & 3; if (b >= n_buckets) return;
-  const XYZZ<F> *src = partials + (size_t)b * HSORT_SLICES; XYZZ<F> acc = src[0], nxt = src[1];
+__global__ void __launch_bounds__(256) k_msm_combine_slices(const XYZZ<F> *__restrict__ partials, uint32_t n_buckets, uint32_t slices, uint32_t lq, XYZZ<F> *__restrict__ buckets) {
+  // 2^lq quads per bucket (slices divisible by it): each adds its share of the bucket's partial sums serially, then lq shuffle levels
+  const uint32_t per = slices >> lq, q = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, b = q >> lq, sub = q & ((1u << lq) - 1); const int k = threadIdx.x & 3;
+  const bool live = b < n_buckets; const XYZZ<F> *src = partials + (size_t)(live ? b : 0) * slices + sub * per; XYZZ<F> acc = src[0], nxt = per > 1 ? src[1] : acc;
 #pragma unroll 1
-  for (uint32_t j = 1; j < HSORT_SLICES; j++) { XYZZ<F> cur = nxt; if (j + 1 < HSORT_SLICES) nxt = src[j + 1]; acc = quad_add(acc, cur, k); }
-  if (k == 0) buckets[b] = acc;
+  for (uint32_t j = 1; j < per; j++) { XYZZ<F> cur = nxt; if (j + 1 < per) nxt = src[j + 1]; acc = quad_add(acc, cur, k); }
+#pragma unroll 1
+  for (uint32_t d = (1u << lq) >> 1; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (sub + d < (1u << lq)) acc = quad_add(acc, o, k); }   // (the quads of a bucket are neighbours in one wave: 2^lq <= 16)
+  if (live && sub == 0 && k == 0) buckets[b] = acc;
 }
 // ---- sums by the 64 quads of a 256-thread workgroup ------------------------------------------------------------------------
 // quad q adds elements q, q+64, ...; then a tree over the 16 quads of each wave (shuffles) and over the 4 waves (LDS).  The result is valid in lanes 0..3.

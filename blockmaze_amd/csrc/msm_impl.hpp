@@ -22,6 +22,8 @@ struct MsmImpl {
   bool direct = false, offsets_direct = false; uint32_t cap = 0, task = MSM_TASK;   // task: sorted entries per accumulation lane
   bool split_ones = false; hipStream_t ones_stream = nullptr; hipEvent_t ev_classified = nullptr, ev_ones = nullptr;   // the ones path on a stream of its own, beside the bucket path (the G2 MSM: both are long chains)
   const Fe32 *prod_b = nullptr, *prod_z = nullptr; bool prod_z_table = false; DevBuf<Fe32> prod_tmp;   // scalars given as a product a*b*z (run_product)
+  uint32_t h_slices = [] { const char *e = getenv("ZK_MSM_H_SLICES"); int v = e ? atoi(e) : 12; return (uint32_t)(v < 1 ? 1 : v > 64 ? 64 : v); }();   // slices per bucket of the H query's accumulation (measured, accumulate + combine inside a proof: 5: 0.66, 6: 0.69, 8: 0.67, 12: 0.64, 16: 0.655, 32: 0.74, 64: 1.0 ms)
+  uint32_t h_combine_lq = [] { const char *e = getenv("ZK_MSM_H_COMBINE_LQ"); return (uint32_t)(e ? atoi(e) & 3 : 0); }();      // 2^lq quads per bucket in the combine (slices must be divisible by it)
   bool wfused = false, wacc_quads = false, ws_leader = true, overflow_noted = false; std::shared_ptr<WsortBuffers> ws;   // witness MSMs in three launches (k_wsort / k_wacc / k_wtail); needs the fixed-base tables and at most 128 buckets
   bool sparse = false; DevBuf<uint8_t> others; uint32_t others_cap = 0;   // witness MSMs without buckets (k_wmsm_classify / k_wmsm_sum, msm.cuh): needs the fixed-base tables
   bool hsort = false; HsortShape hs{0, 0, 0, 0}; DevBuf<uint32_t> group_fill, mid;   // group-binned one-pass sort (k_hsort_bin / k_hsort_group, msm.cuh)
@@ -93,7 +95,7 @@ struct MsmImpl {
       HIP_CHECK(hipEventCreateWithFlags(&ws->sorted, hipEventDisableTiming)); }
     if (filter_ones && WB == 1 && n && getenv("ZK_MSM_SPARSE") != nullptr && atoi(getenv("ZK_MSM_SPARSE")) != 0) {   // opt-in (measured: chains 2-3x shorter, but 3x the field products of the bucket path, which the other streams then miss: 1.82 vs 1.74 ms per send proof)
       sparse = true; wfused = false; tail_mode = 0; others_cap = (uint32_t)std::min<size_t>((size_t)n * W, std::max<size_t>((size_t)n * 2, 1u << 16)); others = DevBuf<uint8_t>((size_t)others_cap * sizeof(uint2)); }   // room for two non-zero digits per scalar on average (a witness has ~0.16); more raises the overflow flag and the bucket path below runs instead
-    max_tasks = (uint32_t)std::max((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1, (size_t)WB * NB * HSORT_SLICES);
+    max_tasks = (uint32_t)std::max((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1, (size_t)WB * NB * h_slices);
     if (uniform_hint && WB == 1 && !filter_ones && n && getenv("ZK_MSM_NO_DIRECT_SORT") == nullptr) {   // slots per bucket: twice the expected load (+64), a power of two
       size_t lam = (n * (size_t)msm_num_windows(c)) / NB, want = 2 * lam + 64; cap = 64; while (cap < want) cap <<= 1;
       if (const char *e = getenv("ZK_MSM_DIRECT_CAP")) { int v = atoi(e); if (v >= 1 && v <= 4080) cap = (uint32_t)v; }   // test hook: a tiny capacity forces the overflow fallback
@@ -213,11 +215,11 @@ struct MsmImpl {
     }
     if (hs_run) {
       { Stage st((label + ".accumulate").c_str(), s); static const int av = [] { const char *e = getenv("ZK_ACC_VARIANT"); return e ? atoi(e) & 3 : 0; }();
-#define ZK_ACC(V) hipLaunchKernelGGL((k_msm_accumulate_slices<V, F>), dim3(cdiv(nbk * HSORT_SLICES, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), (uint32_t)nbk, (XYZZ<F> *)partials.get())
+#define ZK_ACC(V) hipLaunchKernelGGL((k_msm_accumulate_slices<V, F>), dim3(cdiv(nbk * h_slices, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), (uint32_t)nbk, h_slices, (XYZZ<F> *)partials.get())
         if (av == 0) ZK_ACC(0); else if (av == 1) ZK_ACC(1); else if (av == 2) ZK_ACC(2); else ZK_ACC(3);
 #undef ZK_ACC
       }
-      { Stage st((label + ".combine").c_str(), s); hipLaunchKernelGGL((k_msm_combine_slices<F>), dim3(cdiv(nbk * 4, 256)), dim3(256), 0, s, (const XYZZ<F> *)partials.get(), (uint32_t)nbk, bucket_array()); }
+      { Stage st((label + ".combine").c_str(), s); hipLaunchKernelGGL((k_msm_combine_slices<F>), dim3(cdiv((nbk * 4) << h_combine_lq, 256)), dim3(256), 0, s, (const XYZZ<F> *)partials.get(), (uint32_t)nbk, h_slices, h_combine_lq, bucket_array()); }
     } else {
     { Stage st((label + ".accumulate").c_str(), s);
       hipLaunchKernelGGL((k_msm_accumulate_tasks<F>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), order.get(), task_off.get(), (uint32_t)nbk, max_tasks, direct ? task : MSM_TASK, glv ? (const F *)beta.get() : (const F *)nullptr,
