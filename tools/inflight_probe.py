@@ -19,6 +19,7 @@ def run(p, n):
         try: p.prove_resident()
         except e.ZkGpuError: pass
 for p in provers: p.set_witness(z); run(p, 3)
+if os.environ.get("ZK_PROBE_START"): time.sleep(max(0.0, float(os.environ["ZK_PROBE_START"]) - time.time()))   # several processes on one GPU: start the timed part together
 ths = [threading.Thread(target=run, args=(p, per)) for p in provers]; t0 = time.perf_counter()
 for t in ths: t.start()
 for t in ths: t.join()
