@@ -72,6 +72,22 @@ def test_msm_g2_matches_oracle(n, c):
     assert o.g2_from(e.msm(2, P, K, c))[0] == o.msm_g2(P, K)
     assert o.g2_from(e.msm(2, P, Z, c, filter_ones=True))[0] == o.msm_g2(P, Z, mixed=True)
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_witness_msm_fast_path_edge_cases(group):
+    """the three-launch witness path (k_wsort / k_wacc_* / k_wtail, window 8 = 128 buckets) on the shapes that stress it: nothing but ones, nothing but zeros, no
+    ones at all, one value repeated (every digit lands in the same bucket of its window: lanes are dealt by fill, and past the region size the general path must take
+    over), a single non-trivial scalar, and ordinary witness-like vectors before and after on the same resident object"""
+    n = 3000 if group == 1 else 600; g = o.SplitMix64(500 + group); P = (o.g1_consecutive if group == 1 else o.g2_consecutive)(g.field(), n)
+    ref = (lambda K: o.msm_g1(P, K, mixed=True)) if group == 1 else (lambda K: o.msm_g2(P, K, mixed=True)); dec = o.g1_from if group == 1 else o.g2_from
+    m = e.ResidentMsm(group, P, 8, filter_ones=True)
+    def check(K): m.set_scalars(K); assert dec(m.run())[0] == ref(K)
+    check(witness_like_scalars(77, n))
+    check(o.to_arr([1] * n)); check(o.to_arr([0] * n)); check(o.to_arr([2 + (i % 251) for i in range(n)]))
+    check(o.to_arr([0x0101010101010101] * n))                                                      # eight digits equal to 1: one bucket holds 8 n entries
+    one = [0] * n; one[n // 2] = o.R_MOD - 1; check(o.to_arr(one))
+    check(o.to_arr([o.R_MOD - 1 - i for i in range(n)]))                                           # full-width values only: 32 digits each
+    check(witness_like_scalars(78, n)); m.close()
+
 def test_msm_one_pass_sort_and_its_overflow_fallback():
     """uniform-scalar hint (the H query): slots of fixed capacity per bucket; a scalar vector that piles everything into a few buckets overflows them and must
     come out right through the two-pass fallback, and the object must keep working afterwards"""
