@@ -354,7 +354,8 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
   if (threaded && words >= 512) { for (size_t t = 1; t < T; t++) { if (!p.workers[t]) p.workers[t].reset(new SubmitWorker(p.lane)); p.workers[t]->post([&scan, t] { scan(t); }); } scan(0); for (size_t t = 1; t < T; t++) p.workers[t]->wait(); }
   else for (size_t t = 0; t < T; t++) scan(t);
-  const bool compact = fits[0] && fits[1] && fits[2] && fits[3];
+  static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;   // (test switch: the plain-copy branch below, which no BlockMaze assignment reaches on its own)
+  const bool compact = fits[0] && fits[1] && fits[2] && fits[3] && !force_dense;
   if (compact) { upload_async(p.packed.get(), pk, vals_at); for (size_t t = 0; t < T; t++) if (used[t]) upload_async(p.packed.get() + vals_at + 32 * t * cap_t, pk + vals_at + 32 * t * cap_t, 32 * used[t]);
     expand_witness_dev(p.packed.get(), words, one, n, p.z.get()); }
   else { Fe32 *h = p.z_host.get(); h[0] = one; memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * n); }      // dense assignment: plain copy
@@ -372,7 +373,8 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
     if (n_other + (size_t)__builtin_popcountll(mx) > max_other) { fits = false; break; }
     for (uint64_t m = mx; m; m &= m - 1) vals[n_other++] = wide[lo + (size_t)__builtin_ctzll(m)];
     ones[w] = mo; other[w] = mx; }
-  if (fits) { upload_async(p.packed.get(), pk, vals_at + 32 * n_other); expand_witness_dev(p.packed.get(), words, one, n, p.z.get()); }
+  static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;
+  if (fits && !force_dense) { upload_async(p.packed.get(), pk, vals_at + 32 * n_other); expand_witness_dev(p.packed.get(), words, one, n, p.z.get()); }
   else { Fe32 *h = p.z_host.get(); Fe32 zero; memset(&zero, 0, 32); for (size_t i = 0; i < n; i++) h[i] = tag[i] == 2 ? wide[i] : tag[i] ? one : zero; upload_async(p.z.get(), h, 32 * n); }   // a dense assignment (never a BlockMaze one)
   last.upload_ms = now_ms() - t0;
 }
