@@ -187,13 +187,15 @@ def test_deposit_depth32_single_gpu(tmp_path):
     assert e.verify(vk_path, proof, inputs) and not e.verify(vk_path, proof, inputs[::-1])
     assert e.verify_batch(vk_path, [proof, proof], [inputs, inputs[::-1]]) == [True, False]
 
-def test_dense_witness_handover_through_the_cgo_symbols(all_keys):
-    """the cgo path hands the circuit board's tagged assignment to the prover in compact form; an assignment with too many values other than 0 / 1 would go as a plain
+@pytest.mark.parametrize("env", [{"ZK_WITNESS_DENSE": "1"}, {"ZK_DEVICES": "all", "ZK_PROVERS_PER_KEY": "2"}, {"ZK_PROVERS_PER_KEY": "1", "ZK_WITNESS_THREADS": "0", "ZK_SUBMIT_THREADS": "0"}], ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+def test_cgo_symbols_under_process_wide_switches(all_keys, env):
+    """switches that only the cgo layer reads (a fresh process each: they are read once).  ZK_DEVICES=all: the prover pool spread over every visible GPU (one here);
+    one prover per key with no helper threads at all; and the dense hand-over: the cgo path hands the circuit board's tagged assignment to the prover in compact form; an assignment with too many values other than 0 / 1 would go as a plain
     vector instead — a branch no BlockMaze circuit reaches, forced here by ZK_WITNESS_DENSE=1 (a fresh process: the switch is read once): proofs must still verify"""
     code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nfrom blockmaze_amd import engine as e\nimport workload as w\nzk = e.Zk()\n"
             "s = w.send_instance(41); p = zk.GenSendProof(*w.send_args(s)); m = w.mint_instance(42); q = zk.GenMintProof(*w.mint_args(m))\n"
             "print('DENSE', zk.VerifySendProof(p, s['cmtA_old'], s['sn_old'], s['cmtS'], s['cmtA']), zk.VerifyMintProof(q, m['cmtA_old'], m['sn_old'], m['cmtA'], m['value_s']))\n") % (ROOT, os.path.join(ROOT, "tests"))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ZK_PRFKEY_DIR=str(all_keys), ZK_WITNESS_DENSE="1"), timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ZK_PRFKEY_DIR=str(all_keys), **env), timeout=600)
     assert "DENSE True True" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 def test_concurrent_cgo_calls_overlap_and_stay_correct(all_keys, monkeypatch):
