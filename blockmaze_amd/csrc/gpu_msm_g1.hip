@@ -13,7 +13,7 @@ void MsmG1::run_product(const Fe32 *a, const Fe32 *b, const Fe32 *z, bool z_is_t
 void MsmG1::set_label(const char *l) { impl->label = l; }
 void MsmG1::set_stream(int aux) { impl->stream_id = aux; }
 void MsmG1::split_ones_path() { impl->enable_split_ones(); }
-host::HG1 MsmG1::result() { impl->finish_sync(); if (impl->tail_mode) return host_tail_sum<host::HFq, Fq>(*impl); return combine<host::HFq, Fq>(impl->host_sums(), impl->WB, impl->c); }
+host::HG1 MsmG1::result() { impl->finish_sync(); if (impl->tail_mode) return host_tail_sum<host::HFq, Fq>(*impl); return combine<host::HFq, Fq>(impl->host_sums(), impl->RS, impl->bitsum ? 1 : impl->c); }
 size_t MsmG1::size() const { return impl->n; }
 const G1AffineRaw *MsmG1::points_dev() const { return impl->points.get(); }
 }  // namespace zk

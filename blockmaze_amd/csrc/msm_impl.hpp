@@ -48,9 +48,11 @@ struct MsmImpl {
   int parity = 0;                                                   // which of the two counter slots the current run uses
   MsmCounters *counters() { return (MsmCounters *)(zeroed.get() + 2 * (size_t)WB * NB) + parity; }
   MsmCounters *counters_next() { return (MsmCounters *)(zeroed.get() + 2 * (size_t)WB * NB) + (parity ^ 1); }
-  size_t result_bytes() const { return (size_t)(WB + 1) * sizeof(XYZZ<F>) + sizeof(MsmCounters); }
+  int RS = 0;   // result slots before the ones slot: WB window sums, or (bitsum) log2(NB) + 1 sums by weight bit
+  bool bitsum = false;
+  size_t result_bytes() const { return (size_t)(RS + 1) * sizeof(XYZZ<F>) + sizeof(MsmCounters); }
   const XYZZ<F> *host_sums() const { return (const XYZZ<F> *)h_result; }
-  const MsmCounters *host_counters() const { return tail_mode ? (const MsmCounters *)(h_tail + (size_t)(TAIL_T0 + TAIL_T1) * sizeof(XYZZ<F>)) : (const MsmCounters *)(h_result + (size_t)(WB + 1) * sizeof(XYZZ<F>)); }
+  const MsmCounters *host_counters() const { return tail_mode ? (const MsmCounters *)(h_tail + (size_t)(TAIL_T0 + TAIL_T1) * sizeof(XYZZ<F>)) : (const MsmCounters *)(h_result + (size_t)(RS + 1) * sizeof(XYZZ<F>)); }
 
   // Precomputed multiples 2^(cw) P unless switched off (ZK_MSM_PRECOMPUTE=0), the table would pass ZK_MSM_PRECOMPUTE_MAX_MB (default 768 MB: measured on MI355X, the
   // random 64-byte gathers from a table far beyond the 256 MB Infinity Cache cost more than the smaller bucket reduction saves — deposit at depth 32: 9.1 ms
@@ -108,8 +110,9 @@ struct MsmImpl {
         const char *e = getenv("ZK_MSM_DIRECT_TASK"); int tv = e ? atoi(e) : 16; if (lam >= 64 && (tv == 16 || tv == 32 || tv == 64)) task = (uint32_t)tv; } }   // (measured: 32 halves the combine but costs as much in the accumulation, which then has too few lanes)
     { size_t nbk = (size_t)WB * NB; bsort_blocks = cdiv(nbk, BSORT_BLOCK); order = DevBuf<uint32_t>(nbk); rank_of = DevBuf<uint32_t>(nbk); block_hist = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); block_off = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); bsort_scanner.reset(new Scanner((size_t)bsort_blocks * BSORT_CLASSES)); }
     buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>(std::max<size_t>(max_tasks, wfused ? (size_t)WFUSED_BUCKET_LANES + WFUSED_ONES_LANES : 0) * sizeof(XYZZ<F>));
-    seg_out = DevBuf<uint8_t>((size_t)WB * (NB / seg) * sizeof(XYZZ<F>)); seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
+    seg_out = DevBuf<uint8_t>(std::max<size_t>((size_t)WB * (NB / seg), (size_t)32 * cdiv(NB, 512)) * sizeof(XYZZ<F>)); /* (also the chunk sums of the bit-sum tail: log2(NB) x NB/512) */ seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
     ones_partial = DevBuf<uint8_t>(std::max<size_t>(n_ones_quads, wfused ? (size_t)NB + WFUSED_ONES_BLOCKS : 0) * sizeof(XYZZ<F>)); if (wfused) lane_off = DevBuf<uint32_t>(WFUSED_MAX_BUCKETS + 1); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
+    RS = WB; if (hsort && WB == 1 && NB >= 512 && !(getenv("ZK_MSM_H_BITSUM") && atoi(getenv("ZK_MSM_H_BITSUM")) == 0)) { bitsum = true; RS = 1; while ((1u << (RS - 1)) < NB) RS++; }   // RS = log2(NB) + 1
     zeroed.zero(); result = DevBuf<uint8_t>(result_bytes()); result.zero();          // the ones slot stays the point at infinity when the ones path is off
     HIP_CHECK(hipHostMalloc((void **)&h_result, result_bytes())); memset(h_result, 0, result_bytes());
     if (getenv("ZK_MSM_MAPPED_RESULT") && atoi(getenv("ZK_MSM_MAPPED_RESULT")) != 0) HIP_CHECK(hipHostGetDevicePointer((void **)&h_result_dev, h_result, 0));   // opt-in: saves the copy's blit kernel (25-40 us on the stream); measured 1.433 vs 1.437 ms per proof, i.e. nothing
@@ -143,7 +146,7 @@ struct MsmImpl {
       hipLaunchKernelGGL((k_msm_sum_ones<F>), dim3(cdiv((size_t)n_ones_quads * 4, 256)), dim3(256), 0, os, (const Affine<F> *)points.get(), ones.get(), cnt, n_ones_quads, (XYZZ<F> *)ones_partial.get());
       if (tail_mode && g <= TAIL_T1) { tail_n1 = g; hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(g), dim3(256), 0, os, (const XYZZ<F> *)ones_partial.get(), GROUP, n_ones_quads, t1, (uint4 *)cnt, tail_cnt); return; }   // the host adds the g partial sums; block 0 carries the counters along
       hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(g), dim3(256), 0, os, (const XYZZ<F> *)ones_partial.get(), GROUP, n_ones_quads, (XYZZ<F> *)ones_l2.get(), (uint4 *)nullptr, (uint4 *)nullptr);
-      hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(256), 0, os, (const XYZZ<F> *)ones_l2.get(), g, g, res + WB, (uint4 *)nullptr, (uint4 *)nullptr); };
+      hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(1), dim3(256), 0, os, (const XYZZ<F> *)ones_l2.get(), g, g, res + RS, (uint4 *)nullptr, (uint4 *)nullptr); };
     last_scalars = scalars; last_index = scalar_index;
     if (wfused) {
       parity ^= 1;   // (undo the flip above: this path has its own counters, and the general path — which may follow as the overflow fallback — relies on strict alternation of its two slots)
@@ -154,7 +157,7 @@ struct MsmImpl {
 #undef ZK_CALL
         if (w.shared) HIP_CHECK(hipEventRecord(w.sorted, s)); }
       else if (w.leader_stream != stream_id) HIP_CHECK(hipStreamWaitEvent(s, w.sorted, 0));   // (a follower on the leader's stream is simply queued behind it)
-      uint4 *csrc = (uint4 *)(wc + w.parity); uint4 *cdst = (uint4 *)(res + WB + 1);
+      uint4 *csrc = (uint4 *)(wc + w.parity); uint4 *cdst = (uint4 *)(res + RS + 1);
       XYZZ<F> *l2 = (XYZZ<F> *)ones_partial.get(); uint32_t n_op;                          // l2: [NB bucket sums | n_op partial sums of the ones]
       { Stage st((label + ".accumulate").c_str(), s); const uint32_t *fl = w.fill.get() + (size_t)w.parity * NB;
         if (wacc_quads) { n_op = WFUSED_ONES_BLOCKS; hipLaunchKernelGGL((k_wacc_quads<F>), dim3(NB + WFUSED_ONES_BLOCKS), dim3(256), 0, s, (const Affine<F> *)points.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l2); }
@@ -165,7 +168,7 @@ struct MsmImpl {
       if (!h_result_dev) HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s)); return;
     }
     if (sparse) {
-      const uint32_t nq = 16384, nblk = nq / 64; uint4 *csrc = (uint4 *)cnt; uint4 *cdst = (uint4 *)(res + WB + 1);
+      const uint32_t nq = 16384, nblk = nq / 64; uint4 *csrc = (uint4 *)cnt; uint4 *cdst = (uint4 *)(res + RS + 1);
       { Stage st((label + ".sort").c_str(), s);
 #define ZK_CALL(CC) hipLaunchKernelGGL(k_wmsm_classify<CC>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, infp, (uint32_t)n, c, W, point_stride, ones.get(), (uint2 *)others.get(), others_cap, cnt, counters_next())
         ZK_MSM_DISPATCH_C(c, false, ZK_CALL);
@@ -232,8 +235,12 @@ struct MsmImpl {
     }
     const bool ones_runs = filter_ones && n;
     if (tail_mode == 1) { tail_n0 = NB; if (!ones_runs) HIP_CHECK(hipMemcpyAsync(tail_cnt, cnt, sizeof(MsmCounters), hipMemcpyDeviceToDevice, s)); }   // the buckets already sit in the tail buffer: nothing left to launch
+    else if (bitsum && hs_run) { Stage st_red((label + ".reduce").c_str(), s); const uint32_t top = (uint32_t)RS - 1, chunks = NB / 512;   // sums by weight bit; the host's Horner rule does the rest (combine() with c = 1)
+      hipLaunchKernelGGL((k_bitsum_chunks<F>), dim3(chunks, top), dim3(256), 0, s, (const XYZZ<F> *)bucket_array(), (XYZZ<F> *)seg_out.get());
+      hipLaunchKernelGGL((k_bitsum_final<F>), dim3(top + 1), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), chunks, top, (const XYZZ<F> *)bucket_array(), NB, res, (uint4 *)cnt, (uint4 *)(res + RS + 1)); }
     else { Stage st_red((label + ".reduce").c_str(), s);
-      uint32_t spw = NB / seg, nseg = (uint32_t)WB * spw; uint4 *csrc = (uint4 *)cnt; uint4 *cdst = (uint4 *)(res + WB + 1);
+      if (RS > WB) HIP_CHECK(hipMemsetAsync(res + WB, 0, (size_t)(RS - WB) * sizeof(XYZZ<F>), s));   // (a bit-sum MSM on its fallback path: one window sum in slot 0, the other slots at infinity)
+      uint32_t spw = NB / seg, nseg = (uint32_t)WB * spw; uint4 *csrc = (uint4 *)cnt; uint4 *cdst = (uint4 *)(res + RS + 1);
       hipLaunchKernelGGL((k_msm_reduce_segments<F>), dim3(cdiv(nseg, 16)), dim3(64), 0, s, (const XYZZ<F> *)bucket_array(), NB, seg, nseg, (XYZZ<F> *)seg_out.get());
       if (tail_mode == 2) { uint32_t g = spw / GROUP; tail_n0 = g; hipLaunchKernelGGL((k_xyzz_group_sum<F>), dim3(g), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), GROUP, nseg, t0, ones_runs ? (uint4 *)nullptr : csrc, ones_runs ? (uint4 *)nullptr : tail_cnt); }
       else if (spw > GROUP) { uint32_t g = spw / GROUP;   // two-level tree per window keeps the dependent chain short (spw is a power of two)
