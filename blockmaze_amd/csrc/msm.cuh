@@ -636,16 +636,16 @@ __global__ void __launch_bounds__(256) k_wtail(const XYZZ<F> *__restrict__ bucke
 
 // ---- weighted bucket sum of the H query by weight bits ----------------------------------------------------------------------------------------------------------
 // sum_b (b + 1) S_b over NB = 2^top buckets as sum_s 2^s T_s, T_s = the sum of the buckets whose weight has bit s (k_wtail's idea at full size).  For s < top those
-// are the NB / 2 weights "i with a one inserted at bit s"; weight NB itself (bucket NB - 1) is T_top.  k_bitsum_chunks: workgroup (chunk, s) adds 256 of them (four per
-// quad, then the workgroup tree); k_bitsum_final: workgroup s adds the chunks' partial sums.  The host finishes with the Horner rule it already has (combine() with
+// are the NB / 2 weights "i with a one inserted at bit s"; weight NB itself (bucket NB - 1) is T_top.  k_bitsum_chunks: workgroup (chunk, s) adds 512 of them (eight per
+// quad, then the workgroup tree: 480 workgroups, one round of the chip; with 256 per workgroup the 960 workgroups ran in two rounds, 147 us); k_bitsum_final: workgroup s adds the chunks' partial sums.  The host finishes with the Horner rule it already has (combine() with
 // one-bit "windows": top doublings and additions).  Chain: 12 + 7 dependent quad additions instead of the 27 + 12 + 6 of k_msm_reduce_segments and its two group sums.
 template <class F>
-__global__ void __launch_bounds__(256) k_bitsum_chunks(const XYZZ<F> *__restrict__ buckets, XYZZ<F> *__restrict__ out) {
-  __shared__ XYZZ<F> lds[4]; const uint32_t s_ = blockIdx.y, q = threadIdx.x >> 2, base = blockIdx.x * 256 + q; const int k = threadIdx.x & 3;
+__global__ void __launch_bounds__(256) k_bitsum_chunks(const XYZZ<F> *__restrict__ buckets, uint32_t per, XYZZ<F> *__restrict__ out) {   // `per` elements per quad, 64 * per per workgroup
+  __shared__ XYZZ<F> lds[4]; const uint32_t s_ = blockIdx.y, q = threadIdx.x >> 2, base = blockIdx.x * 64 * per + q; const int k = threadIdx.x & 3;
   auto bucket_of = [&](uint32_t i) { return (((i >> s_) << (s_ + 1)) | (1u << s_) | (i & ((1u << s_) - 1))) - 1; };
   XYZZ<F> acc = XYZZ<F>::inf(), nxt = buckets[bucket_of(base)];
 #pragma unroll 1
-  for (uint32_t j = 0; j < 4; j++) { XYZZ<F> cur = nxt; if (j < 3) nxt = buckets[bucket_of(base + 64 * (j + 1))]; acc = quad_add(acc, cur, k); }
+  for (uint32_t j = 0; j < per; j++) { XYZZ<F> cur = nxt; if (j + 1 < per) nxt = buckets[bucket_of(base + 64 * (j + 1))]; acc = quad_add(acc, cur, k); }
   acc = block_quad_tree(acc, lds); if (threadIdx.x == 0) out[s_ * gridDim.x + blockIdx.x] = acc;
 }
 template <class F>

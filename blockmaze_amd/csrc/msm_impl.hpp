@@ -235,8 +235,9 @@ struct MsmImpl {
     }
     const bool ones_runs = filter_ones && n;
     if (tail_mode == 1) { tail_n0 = NB; if (!ones_runs) HIP_CHECK(hipMemcpyAsync(tail_cnt, cnt, sizeof(MsmCounters), hipMemcpyDeviceToDevice, s)); }   // the buckets already sit in the tail buffer: nothing left to launch
-    else if (bitsum && hs_run) { Stage st_red((label + ".reduce").c_str(), s); const uint32_t top = (uint32_t)RS - 1, chunks = NB / 512;   // sums by weight bit; the host's Horner rule does the rest (combine() with c = 1)
-      hipLaunchKernelGGL((k_bitsum_chunks<F>), dim3(chunks, top), dim3(256), 0, s, (const XYZZ<F> *)bucket_array(), (XYZZ<F> *)seg_out.get());
+    else if (bitsum && hs_run) { Stage st_red((label + ".reduce").c_str(), s); static const uint32_t per_env = [] { const char *e = getenv("ZK_MSM_BITSUM_PER"); int v = e ? atoi(e) : 8; return (uint32_t)(v == 4 || v == 8 || v == 16 || v == 32 ? v : 8); }();
+      uint32_t per = per_env; while (per > 4 && (NB / 2) % (64 * per)) per >>= 1; const uint32_t top = (uint32_t)RS - 1, chunks = (NB / 2) / (64 * per);   // sums by weight bit; the host's Horner rule does the rest (combine() with c = 1)
+      hipLaunchKernelGGL((k_bitsum_chunks<F>), dim3(chunks, top), dim3(256), 0, s, (const XYZZ<F> *)bucket_array(), per, (XYZZ<F> *)seg_out.get());
       hipLaunchKernelGGL((k_bitsum_final<F>), dim3(top + 1), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), chunks, top, (const XYZZ<F> *)bucket_array(), NB, res, (uint4 *)cnt, (uint4 *)(res + RS + 1)); }
     else { Stage st_red((label + ".reduce").c_str(), s);
       if (RS > WB) HIP_CHECK(hipMemsetAsync(res + WB, 0, (size_t)(RS - WB) * sizeof(XYZZ<F>), s));   // (a bit-sum MSM on its fallback path: one window sum in slot 0, the other slots at infinity)
