@@ -608,11 +608,14 @@ __global__ void __launch_bounds__(256) k_wacc_quads(const Affine<F> *__restrict_
   if (threadIdx.x == 0) out[b] = acc;
 }
 // sum_b (b + 1) * bucket_b as sum_s 2^s S_s, S_s = the sum of the buckets whose weight has bit s: for s < 7 those are the 64 weights "i with a one inserted at bit s"
-// (i = 0..63), eight per quad of group s and none skipped; S_7 is bucket 127 alone.  Then 2^s S_s pairwise: (S0 + 2 S1) + 4 (S2 + 2 S3) + 16 (...): 7 doublings, 3 additions.
+// (i = 0..63), eight per quad of group s and none skipped; S_7 is bucket 127 alone.  The eight S_s go to the host as they are (res[0..7]; res[8] = the sum of the ones):
+// its Horner rule for window sums finishes with one-bit windows on the MSM's submit thread (7 doublings, 8 additions) — on the device that was 10 more dependent quad
+// operations, 150 us of the G2 chain.
+constexpr int WTAIL_SLOTS = 8;
 template <class F>
 __global__ void __launch_bounds__(256) k_wtail(const XYZZ<F> *__restrict__ buckets, uint32_t NB, const XYZZ<F> *__restrict__ ones_partial, uint32_t n_ones_partial, XYZZ<F> *__restrict__ res, uint4 *copy_src, uint4 *copy_dst) {
-  __shared__ XYZZ<F> lds[8]; const uint32_t q = threadIdx.x >> 2; const int k = threadIdx.x & 3;
-  if (blockIdx.x == 1) { XYZZ<F> acc = block_quad_sum(ones_partial, n_ones_partial, lds); if (threadIdx.x == 0) { res[1] = acc; if (copy_src) *copy_dst = *copy_src; } return; }
+  __shared__ XYZZ<F> lds[4]; const uint32_t q = threadIdx.x >> 2; const int k = threadIdx.x & 3;
+  if (blockIdx.x == 1) { XYZZ<F> acc = block_quad_sum(ones_partial, n_ones_partial, lds); if (threadIdx.x == 0) { res[WTAIL_SLOTS] = acc; if (copy_src) *copy_dst = *copy_src; } return; }
   const uint32_t s_ = q >> 3, j = q & 7, half = NB >> 1, per = half >> 3; XYZZ<F> acc = XYZZ<F>::inf();                  // NB is a power of two, 16 <= NB <= 128; top = log2 NB
   const uint32_t top = 31 - __clz(NB);
   auto weight = [&](uint32_t i) { return ((i >> s_) << (s_ + 1)) | (1u << s_) | (i & ((1u << s_) - 1)); };
@@ -622,16 +625,7 @@ __global__ void __launch_bounds__(256) k_wtail(const XYZZ<F> *__restrict__ bucke
   else if (s_ == top && j == 0) acc = buckets[NB - 1];
 #pragma unroll 1
   for (int d = 4; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if ((int)j + d < 8) acc = quad_add(acc, o, k); }
-  if (j == 0 && k == 0) lds[s_] = acc;
-  __syncthreads();
-  if (threadIdx.x < 64) {                                // quad q of the first wave: level 1 pairs (2q, 2q+1), level 2 quads (q, q+1), level 3 quads (q, q+2); quad 0 ends with the sum
-    XYZZ<F> R = quad_add(lds[(2 * q) & 7], quad_dbl_inl(lds[(2 * q + 1) & 7], k), k);
-    { XYZZ<F> o = shfl_down_struct(R, 4); o = quad_dbl_inl(quad_dbl_inl(o, k), k); R = quad_add(R, o, k); }
-    { XYZZ<F> o = shfl_down_struct(R, 8);
-#pragma unroll 1
-      for (int t = 0; t < 4; t++) o = quad_dbl_inl(o, k);
-      R = quad_add(R, o, k); }
-    if (threadIdx.x == 0) res[0] = R; }
+  if (j == 0 && k == 0) res[s_] = acc;                                                                                      // (groups above `top` hold the point at infinity)
 }
 
 // ---- weighted bucket sum of the H query by weight bits ----------------------------------------------------------------------------------------------------------

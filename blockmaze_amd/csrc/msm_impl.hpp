@@ -112,7 +112,8 @@ struct MsmImpl {
     buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>(std::max<size_t>(max_tasks, wfused ? (size_t)WFUSED_BUCKET_LANES + WFUSED_ONES_LANES : 0) * sizeof(XYZZ<F>));
     seg_out = DevBuf<uint8_t>(std::max<size_t>((size_t)WB * (NB / seg), (size_t)32 * cdiv(NB, 512)) * sizeof(XYZZ<F>)); /* (also the chunk sums of the bit-sum tail: log2(NB) x NB/512) */ seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
     ones_partial = DevBuf<uint8_t>(std::max<size_t>(n_ones_quads, wfused ? (size_t)NB + WFUSED_ONES_BLOCKS : 0) * sizeof(XYZZ<F>)); if (wfused) lane_off = DevBuf<uint32_t>(WFUSED_MAX_BUCKETS + 1); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
-    RS = WB; if (hsort && WB == 1 && NB >= 512 && tail_mode == 0 && !(getenv("ZK_MSM_H_BITSUM") && atoi(getenv("ZK_MSM_H_BITSUM")) == 0)) { bitsum = true; RS = 1; while ((1u << (RS - 1)) < NB) RS++; }   // RS = log2(NB) + 1
+    RS = WB; if (wfused) { bitsum = true; RS = WTAIL_SLOTS; }   // k_wtail leaves eight sums by weight bit
+    else if (hsort && WB == 1 && NB >= 512 && tail_mode == 0 && !(getenv("ZK_MSM_H_BITSUM") && atoi(getenv("ZK_MSM_H_BITSUM")) == 0)) { bitsum = true; RS = 1; while ((1u << (RS - 1)) < NB) RS++; }   // RS = log2(NB) + 1
     zeroed.zero(); result = DevBuf<uint8_t>(result_bytes()); result.zero();          // the ones slot stays the point at infinity when the ones path is off
     HIP_CHECK(hipHostMalloc((void **)&h_result, result_bytes())); memset(h_result, 0, result_bytes());
     if (getenv("ZK_MSM_MAPPED_RESULT") && atoi(getenv("ZK_MSM_MAPPED_RESULT")) != 0) HIP_CHECK(hipHostGetDevicePointer((void **)&h_result_dev, h_result, 0));   // opt-in: saves the copy's blit kernel (25-40 us on the stream); measured 1.433 vs 1.437 ms per proof, i.e. nothing
