@@ -181,6 +181,29 @@ __global__ void k_expand_witness(const uint64_t *__restrict__ ones_bm, const uin
   if ((ob >> bit) & 1) out[i] = values[block_off[wd] + (uint32_t)__popcll(ob & ((1ull << bit) - 1))];
   else out[i] = ((ones_bm[wd] >> bit) & 1) ? one_value : Fr::zero();
 }
+// both of the above in ONE launch (the two are independent and each too small to fill the chip for long: 27 + 25 us one after the other at the head of every proof's
+// critical chain): the first `short_blocks` workgroups take the one-lane rows, the others four long rows each, one per wave
+__global__ void __launch_bounds__(256) k_r1cs_rows_all(R1csMatrices M, const Fr *__restrict__ ctab, const Fr *__restrict__ z, uint32_t n_rows, uint32_t n_inputs, uint32_t m, const uint32_t *__restrict__ long_rows, uint32_t n_long, uint32_t short_blocks,
+                                                       Fr *__restrict__ abc, uint32_t seq, uint32_t *fail) {
+  if (blockIdx.x < short_blocks) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= m) return;
+    if (r >= n_rows) { abc[r] = r <= n_rows + n_inputs ? z[r - n_rows] : Fr::zero(); abc[m + r] = Fr::zero(); abc[2 * (size_t)m + r] = Fr::zero(); return; }
+    if (M.rowptr[0][r + 1] - M.rowptr[0][r] > R1CS_LONG_ROW || M.rowptr[1][r + 1] - M.rowptr[1][r] > R1CS_LONG_ROW || M.rowptr[2][r + 1] - M.rowptr[2][r] > R1CS_LONG_ROW) return;
+    Fr a = r1cs_row_dot(M, 0, r, ctab, z), b = r1cs_row_dot(M, 1, r, ctab, z), c = r1cs_row_dot(M, 2, r, ctab, z);
+    abc[r] = a; abc[m + r] = b; abc[2 * (size_t)m + r] = c;
+    if (a * b != c) *fail = seq;
+    return; }
+  const uint32_t w = (blockIdx.x - short_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63; if (w >= n_long) return;
+  const uint32_t r = long_rows[w]; Fr v[3];
+#pragma unroll
+  for (int mm = 0; mm < 3; mm++) { Fr acc = Fr::zero(); const uint32_t *col = M.col[mm], *cid = M.cid[mm];
+    for (uint32_t k = M.rowptr[mm][r] + lane, e = M.rowptr[mm][r + 1]; k < e; k += 64) { uint32_t ci = cid[k]; Fr x = z[col[k]]; if (ci == 0) acc = acc + x; else if (ci == 1) acc = acc - x; else acc = acc + ctab[ci] * x; }
+    const uint32_t len = M.rowptr[mm][r + 1] - M.rowptr[mm][r];
+#pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) { if ((uint32_t)d >= len) continue; Fr o; for (int i = 0; i < 8; i++) o.l[i] = __shfl_down(acc.l[i], d, 64); acc = acc + o; }
+    v[mm] = acc; }
+  if (lane == 0) { abc[r] = v[0]; abc[m + r] = v[1]; abc[2 * (size_t)m + r] = v[2]; if (v[0] * v[1] != v[2]) *fail = seq; }
+}
 // satisfiability: flag[0] |= (a[i]*b[i] != c[i]) over the constraint rows (protoboard::is_satisfied, sendcgo.cpp:209)
 __global__ void k_r1cs_check(const Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ c, uint32_t n_rows, uint32_t *flag) {
   uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= n_rows) return; if (a[r] * b[r] != c[r]) atomicOr(flag, 1u);
