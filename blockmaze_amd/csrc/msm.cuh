@@ -401,6 +401,19 @@ template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<
   return block_quad_tree(acc, lds, min(len, 64u));
 }
 
+// The same combine with plain lanes: 2^ll lanes per bucket (neighbours in a wave) add slices / 2^ll partial sums each with the lane-serial addition (14 products,
+// none of the quad form's exchange instructions), then ll shuffle levels.  Fewer issue slots than one quad per bucket adding all of them; the chain is about as long.
+template <class F>
+__global__ void __launch_bounds__(256) k_msm_combine_lanes(const XYZZ<F> *__restrict__ partials, uint32_t n_buckets, uint32_t slices, uint32_t ll, XYZZ<F> *__restrict__ buckets) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = t >> ll, sub = t & ((1u << ll) - 1), per = slices >> ll; const bool live = b < n_buckets;
+  const XYZZ<F> *src = partials + (size_t)(live ? b : 0) * slices + sub * per; XYZZ<F> acc = src[0], nxt = per > 1 ? src[1] : acc;
+#pragma unroll 1
+  for (uint32_t j = 1; j < per; j++) { XYZZ<F> cur = nxt; if (j + 1 < per) nxt = src[j + 1]; acc.add_inl(cur); }
+#pragma unroll 1
+  for (uint32_t d = (1u << ll) >> 1; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); if (sub + d < (1u << ll)) acc.add_inl(o); }
+  if (live && sub == 0) buckets[b] = acc;
+}
+
 // buckets that were cut into several tasks: add up the partial sums.  Buckets are ranked by decreasing size (order[], cls_start[]).  One quad per bucket adds up
 // to COMBINE_QUAD_MAX partials serially (with precomputed tables every bucket of the H query holds ~8 of them); buckets with more get a whole workgroup each
 // (the first `heavy_blocks` workgroups walk the ranks of the fullest size class and pick those).

@@ -223,6 +223,9 @@ struct MsmImpl {
         if (av == 0) ZK_ACC(0); else if (av == 1) ZK_ACC(1); else if (av == 2) ZK_ACC(2); else ZK_ACC(3);
 #undef ZK_ACC
       }
+      static const int comb_ll = [] { const char *e = getenv("ZK_MSM_H_COMBINE_LANES"); return e ? atoi(e) : 1; }();   // >= 0: lane-serial combine with 2^ll lanes per bucket (default two lanes: 77 vs 103 us inside a proof for the quad form, which -1 selects)
+      if (comb_ll >= 0 && comb_ll <= 4 && h_slices % (1u << comb_ll) == 0) { Stage st((label + ".combine").c_str(), s); hipLaunchKernelGGL((k_msm_combine_lanes<F>), dim3(cdiv(nbk << comb_ll, 256)), dim3(256), 0, s, (const XYZZ<F> *)partials.get(), (uint32_t)nbk, h_slices, (uint32_t)comb_ll, bucket_array()); }
+      else
       { Stage st((label + ".combine").c_str(), s); hipLaunchKernelGGL((k_msm_combine_slices<F>), dim3(cdiv((nbk * 4) << h_combine_lq, 256)), dim3(256), 0, s, (const XYZZ<F> *)partials.get(), (uint32_t)nbk, h_slices, h_combine_lq, bucket_array()); }
     } else {
     { Stage st((label + ".accumulate").c_str(), s);

@@ -42,7 +42,7 @@ def test_witness_map_of_the_send_circuit_matches_oracle(tmp_path):
     assert got.shape == exp.shape == (262145, 4) and np.array_equal(got, exp)
 
 SWITCHES = [{"ZK_FOLD_C": "0"}, {"ZK_H_LAGRANGE": "0"}, {"ZK_MSM_PRECOMPUTE": "0"}, {"ZK_MSM_H_TABLES": "0"}, {"ZK_NTT_RADIX_LOG": "1"}, {"ZK_NTT_RADIX_LOG": "3"}, {"ZK_NTT_LOGC": "1"},
-            {"ZK_NTT_LOGC": "2", "ZK_NTT_RADIX_LOG": "3"}, {"ZK_SUBMIT_THREADS": "0"}, {"ZK_MSM_SPLIT_ONES": "0"}, {"ZK_WITNESS_MSM_START": "0213"}, {"ZK_MSM_NO_DIRECT_SORT": "1"}, {"ZK_MSM_NO_HSORT": "1"}, {"ZK_MSM_SPARSE": "1"}, {"ZK_MSM_ONE_STREAM": "1"}, {"ZK_MSM_HOST_TAIL": "1", "ZK_MSM_WFUSED": "0"}, {"ZK_MSM_WFUSED": "0"}, {"ZK_MSM_SHARE_SORT": "0"}, {"ZK_B2_FIRST": "0"}, {"ZK_MSM_MAPPED_RESULT": "1"}, {"ZK_MSM_H_SLICES": "8"}, {"ZK_MSM_H_SLICES": "16", "ZK_MSM_H_COMBINE_LQ": "1"}, {"ZK_MSM_WACC": "quads"}, {"ZK_MSM_WACC": "lanes"}, {"ZK_WITNESS_THREADS": "0"}, {"ZK_WITNESS_DENSE": "1"}, {"ZK_MSM_H_BITSUM": "0"}, {"ZK_R1CS_MERGED": "0"}, {"ZK_MSM_GLV": "1"}]
+            {"ZK_NTT_LOGC": "2", "ZK_NTT_RADIX_LOG": "3"}, {"ZK_SUBMIT_THREADS": "0"}, {"ZK_MSM_SPLIT_ONES": "0"}, {"ZK_WITNESS_MSM_START": "0213"}, {"ZK_MSM_NO_DIRECT_SORT": "1"}, {"ZK_MSM_NO_HSORT": "1"}, {"ZK_MSM_SPARSE": "1"}, {"ZK_MSM_ONE_STREAM": "1"}, {"ZK_MSM_HOST_TAIL": "1", "ZK_MSM_WFUSED": "0"}, {"ZK_MSM_WFUSED": "0"}, {"ZK_MSM_SHARE_SORT": "0"}, {"ZK_B2_FIRST": "0"}, {"ZK_MSM_MAPPED_RESULT": "1"}, {"ZK_MSM_H_SLICES": "8"}, {"ZK_MSM_H_SLICES": "16", "ZK_MSM_H_COMBINE_LQ": "1"}, {"ZK_MSM_WACC": "quads"}, {"ZK_MSM_WACC": "lanes"}, {"ZK_WITNESS_THREADS": "0"}, {"ZK_WITNESS_DENSE": "1"}, {"ZK_MSM_H_BITSUM": "0"}, {"ZK_R1CS_MERGED": "0"}, {"ZK_MSM_H_COMBINE_LANES": "-1"}, {"ZK_MSM_H_COMBINE_LANES": "2"}, {"ZK_MSM_GLV": "1"}]
 PROVE_CODE = """
 import json, os, sys
 sys.path.insert(0, %r)
