@@ -25,49 +25,53 @@ struct Fp {
   static ZK_HD Fp zero() { Fp r; for (int i = 0; i < 8; i++) r.l[i] = 0; return r; }
   static ZK_HD Fp one() { Fp r; for (int i = 0; i < 8; i++) r.l[i] = P::R1[i]; return r; }
   static ZK_HD Fp r2() { Fp r; for (int i = 0; i < 8; i++) r.l[i] = P::R2[i]; return r; }
+  static ZK_HD uint32_t modulus_limb0() { return P::MOD[0]; }
+  static ZK_HD uint32_t modulus_limb(int i) { return P::MOD[i]; }
 
   ZK_HD bool is_zero() const { uint32_t o = 0; for (int i = 0; i < 8; i++) o |= l[i]; return o == 0; }
   ZK_HD bool operator==(const Fp &b) const { uint32_t o = 0; for (int i = 0; i < 8; i++) o |= l[i] ^ b.l[i]; return o == 0; }
   ZK_HD bool operator!=(const Fp &b) const { return !(*this == b); }
 
+  // Device code: every carry chain is one v_addc / v_subb per limb (field_mul_gfx950.inc, generated); hipcc lowers the limb loops of the host versions below to 64-bit
+  // adds and sign extensions, about five instructions per limb (measured in the H-query accumulation: 1,100 of 4,215 instructions per mixed addition were such code).
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "field_mul_gfx950.inc"   // mul_raw / sqr_raw / add_raw / sub_fix / cond_sub / cond_neg / neg_masked (gen_field_mul.py)
+  static __device__ __forceinline__ Fp reduce_once(const Fp &a) { Fp r = a; cond_sub<1>(r); return r; }          // r = a - p if a >= p (a < 2p)
+  friend __device__ __forceinline__ Fp operator+(const Fp &a, const Fp &b) { Fp s = a; add_raw(s, b); cond_sub<1>(s); return s; }   // no carry out: 2p < 2^256
+  friend __device__ __forceinline__ Fp operator-(const Fp &a, const Fp &b) { Fp d = a; sub_fix<1>(d, b); return d; }
+  friend __device__ __forceinline__ Fp operator*(const Fp &a, const Fp &b) { Fp r = mul_raw(a, b); cond_sub<1>(r); return r; }
+  __device__ __forceinline__ Fp sqr() const { Fp r = sqr_raw(*this); cond_sub<1>(r); return r; }                   // dedicated squaring: 36 limb products instead of 64 (fp.tcc:594 squared())
+  // ---- the lazy domain: values in [0, 2p) ----------------------------------------------------------------------------------------------------------------------
+  // Both moduli leave two spare bits (p < 2^254).  A Montgomery product of a, b < 2p is (ab + mp)/R < (4p^2 + Rp)/R < 2p because R = 2^256 > 4p, so products need no final
+  // subtraction when they feed further products; a difference stays in [0, 2p) when 2p is added after a borrow.  normalize() brings a value back to [0, p).  The bucket
+  // accumulation's mixed addition (curve.cuh: madd_lazy) lives in this domain: 7 differences at 25 instructions, no reduction after any of the 10 products.
+  static __device__ __forceinline__ Fp mul_lazy(const Fp &a, const Fp &b) { return mul_raw(a, b); }
+  static __device__ __forceinline__ Fp sqr_lazy(const Fp &a) { return sqr_raw(a); }
+  static __device__ __forceinline__ Fp sub_lazy(const Fp &a, const Fp &b) { Fp d = a; sub_fix<2>(d, b); return d; }
+  __device__ __forceinline__ Fp normalize() const { return reduce_once(*this); }
+  __device__ __forceinline__ bool is_zero_lazy() const { uint32_t o = 0, q = 0; for (int i = 0; i < 8; i++) { o |= l[i]; q |= l[i] ^ P::MOD[i]; } return o == 0 || q == 0; }   // 0 or p
+#else
   // r = a - MOD if a >= MOD (a < 2*MOD)
   static ZK_HD Fp reduce_once(const Fp &a) {
     Fp d; uint64_t br = 0;
-#pragma unroll
     for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)a.l[i] - P::MOD[i] - br; d.l[i] = (uint32_t)t; br = (t >> 32) & 1; }
     Fp r;
-#pragma unroll
     for (int i = 0; i < 8; i++) r.l[i] = br ? a.l[i] : d.l[i];
     return r;
   }
   friend ZK_HD Fp operator+(const Fp &a, const Fp &b) {
     Fp s; uint64_t c = 0;
-#pragma unroll
     for (int i = 0; i < 8; i++) { c += (uint64_t)a.l[i] + b.l[i]; s.l[i] = (uint32_t)c; c >>= 32; }
     return reduce_once(s);   // no carry out: 2*MOD < 2^256
   }
   friend ZK_HD Fp operator-(const Fp &a, const Fp &b) {
     Fp d; uint64_t br = 0;
-#pragma unroll
     for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)a.l[i] - b.l[i] - br; d.l[i] = (uint32_t)t; br = (t >> 32) & 1; }
     uint32_t mask = (uint32_t)0 - (uint32_t)br; uint64_t c = 0;
-#pragma unroll
     for (int i = 0; i < 8; i++) { c += (uint64_t)d.l[i] + (P::MOD[i] & mask); d.l[i] = (uint32_t)c; c >>= 32; }
     return d;
   }
-  ZK_HD Fp neg() const { return zero() - *this; }   // 0 - 0 borrows nothing, so zero stays zero; (a `cond ? *this : ...` here makes the compiler select between two memory copies and pins the operand in scratch)
-  ZK_HD Fp dbl() const { return *this + *this; }
-
-  // Montgomery product a*b/R mod p.
-  // Device: product scanning (columns of a*b and of m*p interleaved, FIPS order) on a 96-bit column accumulator.  Every 32x32 multiply-accumulate is ONE
-  // v_mad_u64_u32 whose carry-out goes into the third accumulator word with one v_addc: 128 + 128 instructions for the 128 products (the 64 a_i*b_j and the 64 m_i*p_j).  The compiler's own
-  // lowering of the C++ below (row-wise CIOS) needs ~600 instructions per product, mostly zero-extensions and 64-bit adds around the same 128 mads;
-  // measured on MI355X: 97 -> 126 G products/s chip-wide, single-wave latency 889 -> 620 ns (tools/fmul_bench.hip).
-  // Host (and the reference point for the above): coarsely integrated operand scanning, one row of a*b_i followed by one reduction row m*p.
-#if defined(__HIP_DEVICE_COMPILE__)
-#include "field_mul_gfx950.inc"   // mul_columns(): the same schedule fully unrolled, one asm statement per column half (gen_field_mul.py)
-  friend __device__ __forceinline__ Fp operator*(const Fp &a, const Fp &b) { return mul_columns(a, b); }
-#else
+  // Montgomery product a*b/R mod p, host reference of the device's column product: coarsely integrated operand scanning, one row of a*b_i followed by one reduction row m*p.
   friend ZK_HD Fp operator*(const Fp &a, const Fp &b) {
     uint32_t t[8];
     for (int j = 0; j < 8; j++) t[j] = 0;
@@ -84,8 +88,18 @@ struct Fp {
     for (int j = 0; j < 8; j++) r.l[j] = t[j];
     return reduce_once(r);
   }
-#endif
   ZK_HD Fp sqr() const { return (*this) * (*this); }
+  // (host pass of hipcc and plain g++: the lazy-domain entry points exist so that kernel bodies parse; canonical values are lazy values)
+  static ZK_HD Fp mul_lazy(const Fp &a, const Fp &b) { return a * b; }
+  static ZK_HD Fp sqr_lazy(const Fp &a) { return a * a; }
+  static ZK_HD Fp sub_lazy(const Fp &a, const Fp &b) { return a - b; }
+  static ZK_HD void neg_masked(Fp &a, uint32_t m) { if (m) a = zero() - a; }
+  static ZK_HD void add_raw(Fp &a, const Fp &b) { a = a + b; }
+  ZK_HD Fp normalize() const { return *this; }
+  ZK_HD bool is_zero_lazy() const { return is_zero(); }
+#endif
+  ZK_HD Fp neg() const { return zero() - *this; }   // 0 - 0 borrows nothing, so zero stays zero; (a `cond ? *this : ...` here makes the compiler select between two memory copies and pins the operand in scratch)
+  ZK_HD Fp dbl() const { return *this + *this; }
 
   ZK_HD Fp to_mont() const { return (*this) * r2(); }              // canonical -> Montgomery
   ZK_HD Fp from_mont() const { Fp o = zero(); o.l[0] = 1; return (*this) * o; }   // Montgomery -> canonical

@@ -204,12 +204,13 @@ __global__ void __launch_bounds__(HSORT_BIN_THREADS) k_hsort_bin(const Fr *__res
   const uint32_t total = min(lcnt[sh.groups - 1], HSORT_TILE * HSORT_STAGE_W);
   for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) { const uint32_t g = stage_g[p], pos = gbase[g] + (p - lpos[g]); if (pos < sh.region) mid[(size_t)g * sh.region + pos] = stage[p]; }
 }
-static __global__ void __launch_bounds__(HSORT_GROUP_THREADS) k_hsort_group(const uint32_t *__restrict__ mid, uint32_t *__restrict__ group_fill, HsortShape sh, uint32_t *__restrict__ entries, uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets) {
+static __global__ void __launch_bounds__(HSORT_GROUP_THREADS) k_hsort_group(const uint32_t *__restrict__ mid, uint32_t *__restrict__ group_fill, HsortShape sh, uint32_t *__restrict__ entries, uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets,
+                                                                            uint32_t *__restrict__ group_n, int keep_low) {   // keep_low: entries stay in the staging format (low bucket bits | sign | index) — what k_hacc_runs walks; group_n[g] = entries of group g
   __shared__ uint32_t lcnt[1024], lpre[1024];                        // 2^low_bits <= 1024 buckets per group
   const uint32_t g = blockIdx.x, nb = 1u << sh.low_bits, n_g = min(group_fill[g], sh.region), idx_mask = (1u << sh.idx_bits) - 1; const uint32_t *src = mid + (size_t)g * sh.region;
   for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lcnt[b] = 0;
   __syncthreads();
-  if (threadIdx.x == 0) group_fill[g] = 0;                           // (read above by every thread of this workgroup only, before the barrier) cleared for the next run
+  if (threadIdx.x == 0) { group_fill[g] = 0; group_n[g] = n_g; }     // (read above by every thread of this workgroup only, before the barrier) cleared for the next run
   uint32_t e[HSORT_MAX_PER_THREAD]; int ne = 0;
 #pragma unroll
   for (int j = 0; j < (int)HSORT_MAX_PER_THREAD; j++) { const uint32_t p = (uint32_t)j * HSORT_GROUP_THREADS + threadIdx.x; if (p < n_g) { e[j] = src[p]; atomicAdd(&lcnt[e[j] >> (sh.idx_bits + 1)], 1u); ne = j + 1; } }
@@ -223,7 +224,7 @@ static __global__ void __launch_bounds__(HSORT_GROUP_THREADS) k_hsort_group(cons
   __syncthreads();
   uint32_t *dst = entries + (size_t)g * sh.region;
 #pragma unroll
-  for (int j = 0; j < (int)HSORT_MAX_PER_THREAD; j++) if (j < ne) { const uint32_t v = e[j], b = v >> (sh.idx_bits + 1), r = atomicAdd(&lcnt[b], 1u); dst[lpre[b] + r] = (v & idx_mask) | (((v >> sh.idx_bits) & 1u) ? MSM_ENTRY_SIGN : 0u); }
+  for (int j = 0; j < (int)HSORT_MAX_PER_THREAD; j++) if (j < ne) { const uint32_t v = e[j], b = v >> (sh.idx_bits + 1), r = atomicAdd(&lcnt[b], 1u); dst[lpre[b] + r] = keep_low ? v : (v & idx_mask) | (((v >> sh.idx_bits) & 1u) ? MSM_ENTRY_SIGN : 0u); }
 }
 
 static __global__ void k_fr_mul3(const Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ z, int z_is_table, uint32_t n, Fr *__restrict__ out) {
@@ -377,6 +378,186 @@ __global__ void __launch_bounds__(256) k_msm_combine_slices(const XYZZ<F> *__res
 #pragma unroll 1
   for (uint32_t d = (1u << lq) >> 1; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (sub + d < (1u << lq)) acc = quad_add(acc, o, k); }   // (the quads of a bucket are neighbours in one wave: 2^lq <= 16)
   if (live && sub == 0 && k == 0) buckets[b] = acc;
+}
+// ---- H query accumulation over fixed-length runs (round 3) ---------------------------------------------------------------------------------------------------------
+// k_msm_accumulate_slices above cuts every bucket into the same NUMBER of slices; bucket sizes are Poisson (128 +- 11 for send), so the 64 lanes of a wave hold slices of
+// different lengths and the wave runs for the longest (+12 % measured).  Here a lane takes a RUN of `run` consecutive entries of its group's sorted list, wherever the
+// bucket boundaries fall: every lane of the chip does the same number of additions.  The entries keep their low bucket bits (k_hsort_group, keep_low), so a lane sees a
+// boundary as a change of those bits: it stores the sum so far as piece (this run - the bucket's first run) of the old bucket, and starts over.  Bucket b's pieces sit at
+// partials[b * maxp + 0 .. np): no plan, no atomics; a bucket with more than maxp pieces (non-uniform scalars) raises the overflow flag of the one-pass sort and the host
+// repeats the MSM on the two-pass path.  The additions run in the lazy domain (curve.cuh: madd_lazy; field.cuh), the infinity flag beside the accumulator; pieces are
+// stored as they are, in [0, 2p) — k_hacc_combine normalizes what it loads.
+template <class F> __device__ __forceinline__ void hacc_flush(const XYZZ<F> &acc, bool inf, uint32_t bucket, uint32_t t, uint32_t g, const uint32_t *__restrict__ offsets, const HsortShape &sh, uint32_t run, uint32_t maxp, XYZZ<F> *__restrict__ partials, MsmCounters *cnt) {
+  const uint32_t piece = t - (offsets[bucket] - g * sh.region) / run;
+  if (piece >= maxp) { atomicOr(&cnt->pad[0], 1u); return; }
+  XYZZ<F> *dst = partials + (size_t)bucket * maxp + piece;
+  if (inf) *dst = XYZZ<F>::inf(); else *dst = acc;
+}
+// The grid is one-dimensional over the runs of all groups: every workgroup scans the groups' run counts in LDS (at most 1024 of them) and finds its lanes' (group, run)
+// pairs itself.  A grid of groups x (region / run) left a third of the workgroups without work, and the dispatcher — which cannot tell them apart — then gave some CUs
+// five working workgroups and others three: 0.46 ms instead of 0.34 for the same additions (profiles/r03a_ab_hacc.txt).
+template <int ANY_INF, class F>
+__global__ void __launch_bounds__(256) k_hacc_runs(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ group_n, const uint32_t *__restrict__ offsets, HsortShape sh, uint32_t run, uint32_t maxp,
+                                                   XYZZ<F> *__restrict__ partials, MsmCounters *cnt) {
+  __shared__ uint32_t base[HSORT_GROUPS + 1], wave_tot[4];
+  { const uint32_t per = (sh.groups + 255) / 256, lo = threadIdx.x * per; uint32_t s = 0;                       // exclusive scan of ceil(n_g / run) over the groups
+    for (uint32_t j = 0; j < per; j++) if (lo + j < sh.groups) s += (min(group_n[lo + j], sh.region) + run - 1) / run;
+    uint32_t inc = s; for (int d = 1; d < 64; d <<= 1) { uint32_t u = __shfl_up(inc, d, 64); if ((int)(threadIdx.x & 63) >= d) inc += u; }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t ex = inc - s; for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) ex += wave_tot[wv];
+    for (uint32_t j = 0; j < per; j++) if (lo + j < sh.groups) { base[lo + j] = ex; ex += (min(group_n[lo + j], sh.region) + run - 1) / run; }
+    if (threadIdx.x == 255) base[sh.groups] = ex;
+    __syncthreads(); }
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= base[sh.groups]) return;
+  uint32_t glo = 0, ghi = sh.groups; while (ghi - glo > 1) { const uint32_t mid = (glo + ghi) >> 1; if (base[mid] <= r) glo = mid; else ghi = mid; }   // the group g with base[g] <= r < base[g + 1]
+  const uint32_t g = glo, t = r - base[g], n_g = min(group_n[g], sh.region), beg = t * run;
+  const uint32_t end = min(beg + run, n_g), idx_mask = (1u << sh.idx_bits) - 1, shift = sh.idx_bits + 1; const uint32_t *e = entries + (size_t)g * sh.region;
+  uint32_t v = e[beg], vn = beg + 1 < end ? e[beg + 1] : v; Affine<F> p = points[v & idx_mask];
+  uint32_t cur = v >> shift; bool inf = true; XYZZ<F> acc = XYZZ<F>::inf();
+#pragma unroll 1
+  for (uint32_t i = beg; i < end; i++) {                   // software pipeline: the next point and the entry after it are in flight while this point is added (random table gathers)
+    Affine<F> pn = points[vn & idx_mask]; const uint32_t vnn = i + 2 < end ? e[i + 2] : vn;
+    const uint32_t low = v >> shift;
+    if (low != cur) { hacc_flush(acc, inf, (g << sh.low_bits) | cur, t, g, offsets, sh, run, maxp, partials, cnt); cur = low; inf = true; }
+    F py = p.y; F::neg_masked(py, 0u - ((v >> sh.idx_bits) & 1u));
+    if (ANY_INF && p.is_inf()) { }                         // a key point at infinity adds nothing
+    else if (inf) { acc.X = p.x; acc.Y = py; acc.ZZ = F::one(); acc.ZZZ = F::one(); inf = false; }
+    else if (!acc.madd_lazy(p.x, py)) atomicOr(&cnt->pad[0], 1u);   // operand = +-acc (a key with repeated points; never for random ones): the complete formulas are not in this loop — they would cost it a wave
+                                                                     // of occupancy in registers — so the MSM is repeated on the general path, like after an overflow of the sort
+    v = vn; p = pn; vn = vnn;
+  }
+  hacc_flush(acc, inf, (g << sh.low_bits) | cur, t, g, offsets, sh, run, maxp, partials, cnt);
+}
+// ---- the same accumulation on nine 29-bit limbs ---------------------------------------------------------------------------------------------------------------
+// v_addc_co_u32 / v_subb_co_u32 issue at the rate of v_mad_u64_u32 on gfx950 (tools/valu_probe.hip: 32 T lane-ops/s, v_add_u32 61 T), so in k_hacc_runs the carry
+// additions cost as much as the multiplications: 12.3 k issue cycles per mixed addition, which is what the kernel measures (0.38 ms for 3.8 M additions).  On 29-bit limbs
+// (field29_gfx950.inc: Montgomery radix 2^261) a product is 162 v_mad_u64_u32 and NO carry instruction, a difference nine 32-bit operations and a parallel carry step.
+// The table this kernel gathers from holds the same points as the fixed-base table with coordinates x * 2^261 instead of x * 2^256 (k_table_to_r261 at key load: one
+// product per coordinate; canonical, 8 words each, so the record size and the gather pattern do not change); limbs are unpacked after the load.  A piece is converted
+// back (one product per coordinate with 2^256 mod p) when it is stored, so everything downstream sees the lazy 8 x 32-bit form it saw before.  Operand = +-accumulator
+// (P = 0) is not looked for in the loop: it leaves ZZ = 0 (mod p) for good, which the store notices and reports like an overflow of the sort.
+#include "field29_gfx950.inc"
+struct XYZZ29 { Fq29 X, Y, ZZ, ZZZ;
+  // madd-2008-s in two steps, so that the caller can start the NEXT point's gather between them, into the registers this point's coordinates just left (its words are
+  // dead after the first two products; loading the next point at the top of the loop instead cost 16 registers and with them the fourth wave per SIMD).
+  // px normalized, py possibly K_2 - y (limbs below 2^31); bounds: gen_field29.py
+  __device__ __forceinline__ void madd_head(const Fq29 &px, const Fq29 &py, Fq29 &Pv, Fq29 &Rv) const { Pv = Fq29::sub<6>(Fq29::mul(px, ZZ), X); Rv = Fq29::sub<4>(Fq29::mul(py, ZZZ), Y); }
+  __device__ __forceinline__ void madd_tail(const Fq29 &Pv, const Fq29 &Rv) {
+    const Fq29 PP = Fq29::sqr(Pv), PPP = Fq29::mul(Pv, PP), Q = Fq29::mul(X, PP);
+    Fq29 s;
+#pragma unroll
+    for (int i = 0; i < 9; i++) s.l[i] = PPP.l[i] + 2u * Q.l[i];
+    const Fq29 X3 = Fq29::sub<4>(Fq29::sqr(Rv), s);
+    Y = Fq29::sub<2>(Fq29::mul(Rv, Fq29::sub<6>(Q, X3)), Fq29::mul(Y, PPP)); X = X3; ZZ = Fq29::mul(ZZ, PP); ZZZ = Fq29::mul(ZZZ, PPP);
+  }
+};
+// add-2008-s on two accumulators within the invariant of madd (gen_field29.py: check_bounds_add); neither at infinity, and not +-each other (that leaves ZZ = 0 mod p)
+__device__ __forceinline__ XYZZ29 xyzz29_add(const XYZZ29 &a, const XYZZ29 &b) {
+  const Fq29 U1 = Fq29::mul(a.X, b.ZZ), S1 = Fq29::mul(a.Y, b.ZZZ), Pv = Fq29::sub<2>(Fq29::mul(b.X, a.ZZ), U1), Rv = Fq29::sub<2>(Fq29::mul(b.Y, a.ZZZ), S1);
+  const Fq29 PP = Fq29::sqr(Pv), PPP = Fq29::mul(Pv, PP), Q = Fq29::mul(U1, PP);
+  Fq29 s;
+#pragma unroll
+  for (int i = 0; i < 9; i++) s.l[i] = PPP.l[i] + 2u * Q.l[i];
+  XYZZ29 r; r.X = Fq29::sub<4>(Fq29::sqr(Rv), s); r.Y = Fq29::sub<2>(Fq29::mul(Rv, Fq29::sub<6>(Q, r.X)), Fq29::mul(S1, PPP));
+  r.ZZ = Fq29::mul(Fq29::mul(a.ZZ, b.ZZ), PP); r.ZZZ = Fq29::mul(Fq29::mul(a.ZZZ, b.ZZZ), PPP); return r;
+}
+// A piece is stored as it is — 36 limbs; all-zero ZZ limbs mark the point at infinity — and converted by k_hacc_combine29 after the pieces of a bucket have been added
+// up.  (Converting here, four products per piece, looked cheap per lane and was not per wave: with 64 lanes and buckets of ~11 runs some lane reaches a bucket boundary
+// in nearly every iteration, so the whole wave walked the conversion code every time: 0.366 ms, no faster than the 32-bit loop.)
+struct Piece29 { uint32_t w[36]; };
+__device__ __forceinline__ void hacc_flush29(const XYZZ29 &acc, bool inf, uint32_t bucket, uint32_t t, uint32_t g, const uint32_t *__restrict__ offsets, const HsortShape &sh, uint32_t run, uint32_t maxp, Piece29 *__restrict__ partials, MsmCounters *cnt) {
+  const uint32_t piece = t - (offsets[bucket] - g * sh.region) / run;
+  if (piece >= maxp) { atomicOr(&cnt->pad[0], 1u); return; }
+  uint4 *dst = reinterpret_cast<uint4 *>(partials + (size_t)bucket * maxp + piece); const uint32_t z = inf ? 0u : ~0u;
+  dst[0] = make_uint4(acc.X.l[0], acc.X.l[1], acc.X.l[2], acc.X.l[3]); dst[1] = make_uint4(acc.X.l[4], acc.X.l[5], acc.X.l[6], acc.X.l[7]); dst[2] = make_uint4(acc.X.l[8], acc.Y.l[0], acc.Y.l[1], acc.Y.l[2]);
+  dst[3] = make_uint4(acc.Y.l[3], acc.Y.l[4], acc.Y.l[5], acc.Y.l[6]); dst[4] = make_uint4(acc.Y.l[7], acc.Y.l[8], acc.ZZ.l[0] & z, acc.ZZ.l[1] & z); dst[5] = make_uint4(acc.ZZ.l[2] & z, acc.ZZ.l[3] & z, acc.ZZ.l[4] & z, acc.ZZ.l[5] & z);
+  dst[6] = make_uint4(acc.ZZ.l[6] & z, acc.ZZ.l[7] & z, acc.ZZ.l[8] & z, acc.ZZZ.l[0]); dst[7] = make_uint4(acc.ZZZ.l[1], acc.ZZZ.l[2], acc.ZZZ.l[3], acc.ZZZ.l[4]); dst[8] = make_uint4(acc.ZZZ.l[5], acc.ZZZ.l[6], acc.ZZZ.l[7], acc.ZZZ.l[8]);
+}
+__device__ __forceinline__ XYZZ29 piece29_load(const Piece29 *p, bool &inf) {
+  const uint4 *s = reinterpret_cast<const uint4 *>(p); uint32_t w[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { const uint4 v = s[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+  XYZZ29 r; uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { r.X.l[i] = w[i]; r.Y.l[i] = w[9 + i]; r.ZZ.l[i] = w[18 + i]; r.ZZZ.l[i] = w[27 + i]; o |= w[18 + i]; }
+  inf = o == 0; return r;
+}
+template <int ANY_INF>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_hacc_runs29(const Affine<Fq> *__restrict__ points261, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ group_n, const uint32_t *__restrict__ offsets, HsortShape sh, uint32_t run, uint32_t maxp,
+                                                     Piece29 *__restrict__ partials, MsmCounters *cnt) {
+  __shared__ uint32_t base[HSORT_GROUPS + 1], wave_tot[4];
+  { const uint32_t per = (sh.groups + 255) / 256, lo = threadIdx.x * per; uint32_t s = 0;                       // exclusive scan of ceil(n_g / run) over the groups (as in k_hacc_runs)
+    for (uint32_t j = 0; j < per; j++) if (lo + j < sh.groups) s += (min(group_n[lo + j], sh.region) + run - 1) / run;
+    uint32_t inc = s; for (int d = 1; d < 64; d <<= 1) { uint32_t u = __shfl_up(inc, d, 64); if ((int)(threadIdx.x & 63) >= d) inc += u; }
+    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t ex = inc - s; for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) ex += wave_tot[wv];
+    for (uint32_t j = 0; j < per; j++) if (lo + j < sh.groups) { base[lo + j] = ex; ex += (min(group_n[lo + j], sh.region) + run - 1) / run; }
+    if (threadIdx.x == 255) base[sh.groups] = ex;
+    __syncthreads(); }
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= base[sh.groups]) return;
+  uint32_t glo = 0, ghi = sh.groups; while (ghi - glo > 1) { const uint32_t mid = (glo + ghi) >> 1; if (base[mid] <= r) glo = mid; else ghi = mid; }
+  const uint32_t g = glo, t = r - base[g], n_g = min(group_n[g], sh.region), beg = t * run;
+  const uint32_t end = min(beg + run, n_g), idx_mask = (1u << sh.idx_bits) - 1, shift = sh.idx_bits + 1; const uint32_t *e = entries + (size_t)g * sh.region;
+  uint32_t v = e[beg], vn = beg + 1 < end ? e[beg + 1] : v; Affine<Fq> p = points261[v & idx_mask];
+  uint32_t cur = v >> shift; bool inf = true; XYZZ29 acc;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { acc.X.l[i] = 0; acc.Y.l[i] = 0; acc.ZZ.l[i] = 0; acc.ZZZ.l[i] = 0; }
+#pragma unroll 1
+  for (uint32_t i = beg; i < end; i++) {
+    Affine<Fq> pn = points261[vn & idx_mask]; const uint32_t vnn = i + 2 < end ? e[i + 2] : vn, low = v >> shift;   // software pipeline: the next point's gather is in flight during this addition
+    if (low != cur) { hacc_flush29(acc, inf, (g << sh.low_bits) | cur, t, g, offsets, sh, run, maxp, partials, cnt); cur = low; inf = true; }
+    if (ANY_INF && p.is_inf()) { }                         // a key point at infinity adds nothing
+    else { const Fq29 px = Fq29::unpack(p.x.l), py = Fq29::cond_neg(Fq29::unpack(p.y.l), (v >> sh.idx_bits) & 1u);
+      if (inf) { acc.X = px; acc.Y = py.norm(); acc.ZZ = Fq29::one(); acc.ZZZ = Fq29::one(); inf = false; } else { Fq29 Pv, Rv; acc.madd_head(px, py, Pv, Rv); acc.madd_tail(Pv, Rv); } }
+    v = vn; p = pn; vn = vnn;
+  }
+  hacc_flush29(acc, inf, (g << sh.low_bits) | cur, t, g, offsets, sh, run, maxp, partials, cnt);
+}
+// bucket b = the sum of its pieces, still on 29-bit limbs (14 products of 162 multiply-adds); 2^ll neighbouring lanes share the pieces, the first of them converts the
+// sum to the lazy 8 x 32-bit form (one product per coordinate with 2^256 mod p) that the weighted bucket sum reads.  ZZ = 0 (mod p) in a sum — two pieces were +-each
+// other somewhere, or an operand of the accumulation was +-its accumulator — raises the flag that sends the MSM to the general path.
+static __global__ void __launch_bounds__(256) k_hacc_combine29(const Piece29 *__restrict__ partials, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts, HsortShape sh, uint32_t run, uint32_t maxp, uint32_t n_buckets, uint32_t ll,
+                                                        XYZZ<Fq> *__restrict__ buckets, MsmCounters *cnt) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = t >> ll, sub = t & ((1u << ll) - 1), step = 1u << ll; const bool live = b < n_buckets; uint32_t np = 0;
+  if (live) { const uint32_t c = counts[b], off = offsets[b] - (b >> sh.low_bits) * sh.region; if (c) np = min((off + c - 1) / run - off / run + 1, maxp); }
+  const Piece29 *src = partials + (size_t)(live ? b : 0) * maxp; XYZZ29 acc; bool inf = true;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { acc.X.l[i] = 0; acc.Y.l[i] = 0; acc.ZZ.l[i] = 0; acc.ZZZ.l[i] = 0; }
+#pragma unroll 1
+  for (uint32_t j = sub; j < np; j += step) { bool pinf; const XYZZ29 cur = piece29_load(src + j, pinf); if (pinf) continue; if (inf) { acc = cur; inf = false; } else acc = xyzz29_add(acc, cur); }
+#pragma unroll 1
+  for (uint32_t d = step >> 1; d >= 1; d >>= 1) {
+    XYZZ29 o; const bool oinf = __shfl_down((int)inf, d, 64) != 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { o.X.l[i] = __shfl_down(acc.X.l[i], d, 64); o.Y.l[i] = __shfl_down(acc.Y.l[i], d, 64); o.ZZ.l[i] = __shfl_down(acc.ZZ.l[i], d, 64); o.ZZZ.l[i] = __shfl_down(acc.ZZZ.l[i], d, 64); }
+    if (sub + d < step && !oinf) { if (inf) { acc = o; inf = false; } else acc = xyzz29_add(acc, o); } }
+  if (live && sub == 0) { XYZZ<Fq> o = XYZZ<Fq>::inf();
+    if (!inf) { acc.X.to_words(o.X.l); acc.Y.to_words(o.Y.l); acc.ZZ.to_words(o.ZZ.l); acc.ZZZ.to_words(o.ZZZ.l); if (o.ZZ.is_zero_lazy()) atomicOr(&cnt->pad[0], 1u);
+      o = XYZZ<Fq>{o.X.normalize(), o.Y.normalize(), o.ZZ.normalize(), o.ZZZ.normalize()}; }
+    buckets[b] = o; }
+}
+// table of the 29-bit kernel: coordinates x * 2^261 (mod p) from x * 2^256 — a Montgomery product with the plain integer 2^261 mod p; (0, 0) stays the point at infinity
+static __global__ void k_table_to_r261(const Affine<Fq> *__restrict__ in, Affine<Fq> *__restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; Fq c;
+#pragma unroll
+  for (int j = 0; j < 8; j++) c.l[j] = FQ_TWO261[j];
+  const Affine<Fq> p = in[i]; out[i] = {p.x * c, p.y * c};
+}
+// bucket b = the sum of its pieces: 2^ll neighbouring lanes share them (lane-serial additions, ll shuffle levels); an empty bucket becomes the point at infinity
+template <class F> __device__ __forceinline__ XYZZ<F> xyzz_normalize(const XYZZ<F> &a) { return {a.X.normalize(), a.Y.normalize(), a.ZZ.normalize(), a.ZZZ.normalize()}; }
+template <class F>
+__global__ void __launch_bounds__(256) k_hacc_combine(const XYZZ<F> *__restrict__ partials, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts, HsortShape sh, uint32_t run, uint32_t maxp, uint32_t n_buckets, uint32_t ll, XYZZ<F> *__restrict__ buckets) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = t >> ll, sub = t & ((1u << ll) - 1), step = 1u << ll; const bool live = b < n_buckets; uint32_t np = 0;
+  if (live) { const uint32_t cnt = counts[b], off = offsets[b] - (b >> sh.low_bits) * sh.region; if (cnt) np = min((off + cnt - 1) / run - off / run + 1, maxp); }
+  const XYZZ<F> *src = partials + (size_t)(live ? b : 0) * maxp; XYZZ<F> acc = XYZZ<F>::inf();
+  if (sub < np) { XYZZ<F> nxt = src[sub];
+#pragma unroll 1
+    for (uint32_t j = sub; j < np; j += step) { XYZZ<F> cur = xyzz_normalize(nxt); if (j + step < np) nxt = src[j + step]; acc.add_inl(cur); } }
+#pragma unroll 1
+  for (uint32_t d = step >> 1; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); if (sub + d < step) acc.add_inl(o); }
+  if (live && sub == 0) buckets[b] = acc;
 }
 // ---- sums by the 64 quads of a 256-thread workgroup ------------------------------------------------------------------------
 // quad q adds elements q, q+64, ...; then a tree over the 16 quads of each wave (shuffles) and over the 4 waves (LDS).  The result is valid in lanes 0..3.

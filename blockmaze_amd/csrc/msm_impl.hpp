@@ -17,7 +17,7 @@ struct MsmImpl {
   size_t n; int c, W, WB; uint32_t NB;   // W digit windows; WB bucket arrays (1 when the multiples 2^(cw) P are precomputed, else W)
    bool filter_ones; uint32_t seg, n_ones_quads; std::string label = "msm"; int stream_id = -1;   // -1: main stream, 0..3: auxiliary stream
   // the key's points (with the fixed-base table when there is one) are immutable and shared by every prover object of the key on this device; everything else below is per-object workspace
-  struct Bases { size_t n = 0; int c = 0, W = 0, WB = 0; bool glv = false, any_inf = false; DevBuf<RawAffine> points; DevBuf<uint8_t> inf; };
+  struct Bases { size_t n = 0; int c = 0, W = 0, WB = 0; bool glv = false, any_inf = false; DevBuf<RawAffine> points, points261 /* the same table with coordinates x 2^261: what k_hacc_runs29 gathers from (G1, uniform scalars, fixed-base table) */; DevBuf<uint8_t> inf; };
   std::shared_ptr<const Bases> bases; const DevBuf<RawAffine> &points; const DevBuf<uint8_t> &inf; bool any_inf = false;
   bool direct = false, offsets_direct = false; uint32_t cap = 0, task = MSM_TASK;   // task: sorted entries per accumulation lane
   bool split_ones = false; hipStream_t ones_stream = nullptr; hipEvent_t ev_classified = nullptr, ev_ones = nullptr;   // the ones path on a stream of its own, beside the bucket path (the G2 MSM: both are long chains)
@@ -26,7 +26,8 @@ struct MsmImpl {
   uint32_t h_combine_lq = [] { const char *e = getenv("ZK_MSM_H_COMBINE_LQ"); return (uint32_t)(e ? atoi(e) & 3 : 0); }();      // 2^lq quads per bucket in the combine (slices must be divisible by it)
   bool wfused = false, wacc_quads = false, ws_leader = true, overflow_noted = false; std::shared_ptr<WsortBuffers> ws;   // witness MSMs in three launches (k_wsort / k_wacc / k_wtail); needs the fixed-base tables and at most 128 buckets
   bool sparse = false; DevBuf<uint8_t> others; uint32_t others_cap = 0;   // witness MSMs without buckets (k_wmsm_classify / k_wmsm_sum, msm.cuh): needs the fixed-base tables
-  bool hsort = false; HsortShape hs{0, 0, 0, 0}; DevBuf<uint32_t> group_fill, mid;   // group-binned one-pass sort (k_hsort_bin / k_hsort_group, msm.cuh)
+  bool hsort = false; HsortShape hs{0, 0, 0, 0}; DevBuf<uint32_t> group_fill, mid, group_n; bool hruns = false; uint32_t h_run = 16, h_maxp = 16;   // hruns: accumulation over fixed-length runs (k_hacc_runs), h_run entries per lane, at most h_maxp pieces per bucket
+    // group-binned one-pass sort (k_hsort_bin / k_hsort_group, msm.cuh)
   const Fe32 *last_scalars = nullptr; const uint32_t *last_index = nullptr;   // one-pass sort (k_msm_scatter_direct) for uniform scalars
   DevBuf<uint32_t> zeroed;                                          // [hist | fill | counters]: cleared by one memset per run
   DevBuf<uint32_t> offsets, entries, ones, ntasks, task_off, order, rank_of, block_hist, block_off, cls_start; uint32_t bsort_blocks; std::unique_ptr<Scanner> bsort_scanner; Scanner scanner, task_scanner; uint32_t max_tasks;
@@ -76,6 +77,8 @@ struct MsmImpl {
       hipLaunchKernelGGL((k_msm_precompute<F>), dim3(cdiv(n_, 64)), dim3(64), 0, gpu().stream, (Affine<F> *)b->points.get(), (uint32_t)n_, c_, b->W, (XYZZ<F> *)tmp.get(), (F *)pref.get());
       HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream));
     }
+    if constexpr (sizeof(F) == 32) if (uniform_hint && !fo && b->WB == 1 && n_ && !b->glv && !(getenv("ZK_MSM_HACC") && strcmp(getenv("ZK_MSM_HACC"), "runs29"))) { const size_t tn = n_ * (size_t)b->W; b->points261 = DevBuf<RawAffine>(tn);
+      hipLaunchKernelGGL(k_table_to_r261, dim3(cdiv(tn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq> *)b->points.get(), (Affine<Fq> *)b->points261.get(), tn); HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
     return b;
   }
   MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true, bool uniform_hint = false, bool glv_hint = false) : MsmImpl(make_bases(host_points, n_, c_, fo, tables, uniform_hint, glv_hint), fo, uniform_hint) {}
@@ -105,11 +108,13 @@ struct MsmImpl {
       { size_t total = n * (size_t)W; uint32_t G = 256; while (G < HSORT_GROUPS && total / G > 16384) G <<= 1; uint32_t low = 0; while ((G << low) < NB) low++; uint32_t ib = 1; while (((size_t)1 << ib) < total) ib++;
         size_t region = ((total / G) * 5 / 4 + 1024 + 255) & ~(size_t)255; if (getenv("ZK_MSM_DIRECT_CAP")) region = 256;   // (test hook: regions far too small force the overflow fallback)
         if (!glv && W <= (int)HSORT_STAGE_W && getenv("ZK_MSM_NO_HSORT") == nullptr && (G << low) == NB && low >= 1 && low <= 10 && low + 1 + ib <= 32 && region <= (size_t)HSORT_GROUP_THREADS * HSORT_MAX_PER_THREAD) {
-          hsort = true; hs = HsortShape{G, low, ib, (uint32_t)region}; group_fill = DevBuf<uint32_t>(G); group_fill.zero(); mid = DevBuf<uint32_t>((size_t)G * region); direct = true; entries = DevBuf<uint32_t>((size_t)G * region); } }
+          hsort = true; hs = HsortShape{G, low, ib, (uint32_t)region}; group_fill = DevBuf<uint32_t>(G); group_fill.zero(); group_n = DevBuf<uint32_t>(G); group_n.zero(); mid = DevBuf<uint32_t>((size_t)G * region); direct = true; entries = DevBuf<uint32_t>((size_t)G * region);
+          if (sizeof(F) == 32 && !(getenv("ZK_MSM_HACC") && !strcmp(getenv("ZK_MSM_HACC"), "slices"))) { hruns = true; const char *e = getenv("ZK_MSM_H_RUN"); int v = e ? atoi(e) : 12; h_run = (uint32_t)(v < 4 ? 4 : v > 64 ? 64 : v);
+            const size_t lam = total / NB; h_maxp = (uint32_t)((lam + lam / 2 + 32 + h_run - 1) / h_run + 2); } } }   // pieces per bucket: room for 1.5x the expected load + 32 entries
       if (!hsort && (size_t)NB * cap <= (1ull << 28)) { direct = true; entries = DevBuf<uint32_t>((size_t)NB * cap);
         const char *e = getenv("ZK_MSM_DIRECT_TASK"); int tv = e ? atoi(e) : 16; if (lam >= 64 && (tv == 16 || tv == 32 || tv == 64)) task = (uint32_t)tv; } }   // (measured: 32 halves the combine but costs as much in the accumulation, which then has too few lanes)
     { size_t nbk = (size_t)WB * NB; bsort_blocks = cdiv(nbk, BSORT_BLOCK); order = DevBuf<uint32_t>(nbk); rank_of = DevBuf<uint32_t>(nbk); block_hist = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); block_off = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); bsort_scanner.reset(new Scanner((size_t)bsort_blocks * BSORT_CLASSES)); }
-    buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>(std::max<size_t>(max_tasks, wfused ? (size_t)WFUSED_BUCKET_LANES + WFUSED_ONES_LANES : 0) * sizeof(XYZZ<F>));
+    buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>)); partials = DevBuf<uint8_t>(std::max<size_t>(std::max<size_t>(max_tasks, hruns ? ((size_t)NB * h_maxp * 144 + sizeof(XYZZ<F>) - 1) / sizeof(XYZZ<F>) : 0), wfused ? (size_t)WFUSED_BUCKET_LANES + WFUSED_ONES_LANES : 0) * sizeof(XYZZ<F>));
     seg_out = DevBuf<uint8_t>(std::max<size_t>((size_t)WB * (NB / seg), (size_t)32 * cdiv(NB, 512)) * sizeof(XYZZ<F>)); /* (also the chunk sums of the bit-sum tail: log2(NB) x NB/512) */ seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
     ones_partial = DevBuf<uint8_t>(std::max<size_t>(n_ones_quads, wfused ? (size_t)NB + WFUSED_ONES_BLOCKS : 0) * sizeof(XYZZ<F>)); if (wfused) lane_off = DevBuf<uint32_t>(WFUSED_MAX_BUCKETS + 1); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
     RS = WB; if (wfused) { bitsum = true; RS = WTAIL_SLOTS; }   // k_wtail leaves eight sums by weight bit
@@ -184,7 +189,7 @@ struct MsmImpl {
 #define ZK_CALL(CC) hipLaunchKernelGGL(k_hsort_bin<CC>, dim3(cdiv(n, HSORT_TILE)), dim3(HSORT_BIN_THREADS), 0, s, (const Fr *)scalars, (const Fr *)prod_b, (const Fr *)prod_z, (int)prod_z_table, infp, (uint32_t)n, c, W, point_stride, hs, group_fill.get(), mid.get(), cnt, counters_next())
       ZK_MSM_DISPATCH_C(c, false, ZK_CALL);
 #undef ZK_CALL
-      hipLaunchKernelGGL(k_hsort_group, dim3(hs.groups), dim3(HSORT_GROUP_THREADS), 0, s, (const uint32_t *)mid.get(), group_fill.get(), hs, entries.get(), hist(), offsets.get());
+      hipLaunchKernelGGL(k_hsort_group, dim3(hs.groups), dim3(HSORT_GROUP_THREADS), 0, s, (const uint32_t *)mid.get(), group_fill.get(), hs, entries.get(), hist(), offsets.get(), group_n.get(), (int)hruns);
     } else
     if (direct) { Stage st((label + ".sort").c_str(), s);
       if (hsort) throw GpuError("msm: the group-binned sort takes no scalar index");
@@ -217,6 +222,18 @@ struct MsmImpl {
       if (n) ZK_MSM_DISPATCH_C(c, glv, ZK_CALL);
 #undef ZK_CALL
     }
+    if (hs_run && hruns) {
+      if constexpr (sizeof(F) == 32) {
+      { Stage st((label + ".accumulate").c_str(), s); const dim3 grid(cdiv(cdiv(n * (size_t)W, h_run) + hs.groups, 256));   // one lane per run: at most ceil(entries / run) + one short run per group
+        if (bases->points261.size()) { if (any_inf) hipLaunchKernelGGL(k_hacc_runs29<1>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(), offsets.get(), hs, h_run, h_maxp, (Piece29 *)partials.get(), cnt);
+          else hipLaunchKernelGGL(k_hacc_runs29<0>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(), offsets.get(), hs, h_run, h_maxp, (Piece29 *)partials.get(), cnt); }
+        else if (any_inf) hipLaunchKernelGGL((k_hacc_runs<1, F>), grid, dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), group_n.get(), offsets.get(), hs, h_run, h_maxp, (XYZZ<F> *)partials.get(), cnt);
+        else hipLaunchKernelGGL((k_hacc_runs<0, F>), grid, dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), group_n.get(), offsets.get(), hs, h_run, h_maxp, (XYZZ<F> *)partials.get(), cnt); }
+      { Stage st((label + ".combine").c_str(), s); static const uint32_t ll = [] { const char *e = getenv("ZK_MSM_H_COMBINE_LANES"); int v = e ? atoi(e) : 1; return (uint32_t)(v < 0 ? 0 : v > 3 ? 3 : v); }();
+        if (bases->points261.size()) hipLaunchKernelGGL(k_hacc_combine29, dim3(cdiv(nbk << ll, 256)), dim3(256), 0, s, (const Piece29 *)partials.get(), offsets.get(), hist(), hs, h_run, h_maxp, (uint32_t)nbk, ll, (XYZZ<Fq> *)bucket_array(), cnt);
+        else hipLaunchKernelGGL((k_hacc_combine<F>), dim3(cdiv(nbk << ll, 256)), dim3(256), 0, s, (const XYZZ<F> *)partials.get(), offsets.get(), hist(), hs, h_run, h_maxp, (uint32_t)nbk, ll, bucket_array()); }
+      }
+    } else
     if (hs_run) {
       { Stage st((label + ".accumulate").c_str(), s); static const int av = [] { const char *e = getenv("ZK_ACC_VARIANT"); return e ? atoi(e) & 3 : 0; }();
 #define ZK_ACC(V) hipLaunchKernelGGL((k_msm_accumulate_slices<V, F>), dim3(cdiv(nbk * h_slices, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(), offsets.get(), hist(), (uint32_t)nbk, h_slices, (XYZZ<F> *)partials.get())

@@ -40,9 +40,10 @@ int zkgpu_init(void);                               /* create the device context
 /* ---- device arithmetic probes (parity tests of the __device__ field / curve code) ---------------------------------- */
 /* field: 0 = Fr, 1 = Fq.  op: 0 mul, 1 add, 2 sub, 3 inverse(a), 4 square(a), 5 negate(a) */
 int zkgpu_test_field_op(int field, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
+/* (field ops 6..9 probe the lazy domain of field.cuh: 6 mul, 7 square, 8 sub on operands pushed towards 2p, 9 masked negation; results normalized) */
 /* op: 0 mul, 1 square(a), 2 inverse(a) on Fq2 (64-byte elements c0 | c1) */
 int zkgpu_test_fq2_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
-/* group: 1 = G1, 2 = G2.  op: 0 general add, 1 double(a), 2 mixed add (b affine), 3 a*k for 32-bit k (k in b's first 4 bytes) */
+/* group: 1 = G1, 2 = G2.  op: 0 general add, 1 double(a), 2 mixed add (b affine), 3 a*k for 32-bit k (k in b's first 4 bytes), 4 (G1) 2a + b - b + b through the lazy-domain mixed addition */
 int zkgpu_test_group_op(int group, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
 
 /* ---- multi-scalar multiplication ------------------------------------------------------------------------------------ */

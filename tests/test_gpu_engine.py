@@ -21,6 +21,12 @@ def test_field_ops_match_oracle(field):
     for op in ("sqr", "neg"):
         assert o.from_arr(e.field_op(field, op, a)) == o.field_op(field, op, o.from_arr(a)), op
     nz = a[8:40]; assert o.from_arr(e.field_op(field, "inv", nz)) == o.field_op(field, "inv", o.from_arr(nz))
+    # the lazy domain [0, 2p) of the bucket accumulation (field.cuh): products without the final subtraction on operands pushed towards 2p, differences that add 2p after a
+    # borrow, the masked negation — all normalized before they come back
+    for lazy, op in (("mul_lazy", "mul"), ("sub_lazy", "sub")):
+        assert o.from_arr(e.field_op(field, lazy, a, b)) == o.field_op(field, op, o.from_arr(a), o.from_arr(b)), lazy
+    assert o.from_arr(e.field_op(field, "sqr_lazy", a)) == o.field_op(field, "sqr", o.from_arr(a))
+    assert o.from_arr(e.field_op(field, "neg_masked", a)) == o.field_op(field, "neg", o.from_arr(a))
 
 def test_fq2_ops_match_oracle():
     n = 64; a = rand_field_arr(5, 2 * n).reshape(n, 8); b = rand_field_arr(6, 2 * n).reshape(n, 8)
@@ -41,6 +47,16 @@ def test_g1_group_law_matches_oracle():
         p, q = o.g1_from(P[i])[0], o.g1_from(Q[i])[0]; exp = o.g1_op("add", p, q)
         assert o.g1_from(add[i])[0] == exp and o.g1_from(madd[i])[0] == exp, i
         assert o.g1_from(dbl[i])[0] == o.g1_op("dbl", p) and o.g1_from(mul[i])[0] == o.g1_op("mul", p, k=ks[i]), i
+
+def test_g1_lazy_mixed_addition_matches_oracle():
+    """curve.cuh madd_lazy (the H query's inner loop): 2a + b - b + b in the lazy domain == 2a + b; operand = +-accumulator is reported, not computed"""
+    n = 64; g = o.SplitMix64(79); P = o.g1_consecutive(g.field(), n); Q = o.g1_consecutive(g.field(), n)
+    Q[3] = o.g1_arr([o.g1_op("dbl", o.g1_from(P[3])[0])])[0]                               # b = 2a: P = 0, R = 0
+    Q[4] = o.g1_arr([o.g1_op("neg", o.g1_op("dbl", o.g1_from(P[4])[0]))])[0]              # b = -2a: P = 0
+    got = e.group_op(1, "madd_lazy", P, Q)
+    for i in range(n):
+        p, q = o.g1_from(P[i])[0], o.g1_from(Q[i])[0]; exp = None if i in (3, 4) else o.g1_op("add", o.g1_op("dbl", p), q)
+        assert o.g1_from(got[i])[0] == exp, i
 
 def test_g2_group_law_matches_oracle():
     n = 16; g = o.SplitMix64(78); P = o.g2_consecutive(g.field(), n); Q = o.g2_consecutive(g.field(), n); Q[3] = P[3]; P[5] = 0
