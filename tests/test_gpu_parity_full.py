@@ -33,6 +33,16 @@ def test_msm_g1_at_h_query_size_matches_oracle():
     assert o.g1_from(e.msm(1, P[:n2], Z, filter_ones=True))[0] == exp2
     record_leg("oracle MSM at n = 2^18 and 227,047", t_o)
 
+def test_msm_g2_at_b_query_size_matches_oracle():
+    """the G2 half of the B query at its full size (136,316 pairs for send) with the witness mix, against the oracle's restatement of
+    kc_multi_exp_with_mixed_addition (kc_multiexp.tcc:21-85) — at this size the fused witness path (k_wsort / k_wacc_quads / k_wtail over Fq2) runs on its fixed-base table"""
+    n = 136316; g = o.SplitMix64(0xB2); P = o.g2_consecutive(g.field(), n); rng = np.random.default_rng(36)
+    Z = np.zeros((n, 4), dtype=np.uint64); Z[:] = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(n, 4), dtype=np.uint64); Z[:, 3] &= np.uint64((1 << 61) - 1)
+    sel = rng.integers(0, 1000, size=n); Z[sel < 509] = 0; ones = (sel >= 509) & (sel < 967); Z[ones] = 0; Z[ones, 0] = 1; small = (sel >= 967) & (sel < 995); Z[small, 1:] = 0; Z[small, 0] &= np.uint64(0xffffffff)
+    t0 = time.time(); exp = o.msm_g2(P, Z, mixed=True); t_o = time.time() - t0
+    assert o.g2_from(e.msm(2, P, Z, filter_ones=True))[0] == exp
+    record_leg("oracle G2 MSM at n = 136,316", t_o)
+
 def test_witness_map_of_the_send_circuit_matches_oracle(tmp_path):
     """all m + 1 = 262,145 coefficients of H for a real send witness: device rows + transforms + pointwise step vs the oracle's r1cs_to_qap_witness_map restatement"""
     rp = str(tmp_path / "send.bin"); e.circuit_export("send", rp); cs = o.R1CS.load(rp); assert cs.domain_m == 262144
