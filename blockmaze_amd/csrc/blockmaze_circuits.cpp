@@ -283,6 +283,19 @@ struct CmtaTestCircuit : Circuit {
     if (emit) { b.constraint(ONE_LC, LC(ZERO), LC()); g->constraints(); } b.finish(); }
   void assign(const std::vector<bool> &bv, const std::vector<bool> &bsn, const std::vector<bool> &br) { Board &b = board; b.set(ZERO, HFr::zero()); fill(b, v, bv); fill(b, sn, bsn); fill(b, r, br); g->witness(); }
 };
+// test circuits: the CMTS / PRF / CRH blocks on their own (commitment.tcc:100-320) — ZERO, the inputs, the output digest, then the gadget; compared with the same
+// compositions built from libsnark's own classes (oracle/ref_harness.cpp cmd_hashblock).  which: 0 CMTS (64 | 160 | 256 | 256 bits), 1 PRF (256 | 256), 2 CRH (160 | 256)
+struct HashBlockTestCircuit : Circuit {
+  int which; Var ZERO; std::vector<VarArray> in; std::unique_ptr<Digest> out; std::unique_ptr<ShaTwoBlock> g2; std::unique_ptr<ShaOneBlock> g1;
+  static std::vector<size_t> widths(int which) { return which == 0 ? std::vector<size_t>{64, 160, 256, 256} : which == 1 ? std::vector<size_t>{256, 256} : std::vector<size_t>{160, 256}; }
+  HashBlockTestCircuit(bool emit, int which) : Circuit(emit), which(which) { Board &b = board; ZERO = b.alloc(); for (size_t w : widths(which)) in.push_back(b.alloc_array(w)); out.reset(new Digest(b, 256));
+    if (which == 0) g2 = make_cmts(b, ZERO, in[0], in[1], in[2], in[3], out->bits); else if (which == 1) g2 = make_prf(b, ZERO, in[0], in[1], out->bits); else g1 = make_crh(b, ZERO, in[0], in[1], out->bits);
+    if (emit) { b.constraint(ONE_LC, LC(ZERO), LC()); if (g2) g2->constraints(); else g1->constraints(); } b.finish(); }
+  void assign(const std::vector<bool> &bits) { Board &b = board; b.set(ZERO, HFr::zero()); size_t pos = 0; for (auto &a : in) { fill(b, a, std::vector<bool>(bits.begin() + pos, bits.begin() + pos + a.size())); pos += a.size(); } if (g2) g2->witness(); else g1->witness(); }
+};
+std::unique_ptr<Circuit> make_hashblock_test_circuit(bool emit, int which) { return std::unique_ptr<Circuit>(new HashBlockTestCircuit(emit, which)); }
+size_t hashblock_input_bits(int which) { size_t n = 0; for (size_t w : HashBlockTestCircuit::widths(which)) n += w; return n; }
+void assign_hashblock_test(Circuit &c, const std::vector<bool> &bits) { static_cast<HashBlockTestCircuit &>(c).assign(bits); }
 std::unique_ptr<Circuit> make_cmta_test_circuit(bool emit) { return std::unique_ptr<Circuit>(new CmtaTestCircuit(emit)); }
 void assign_cmta_test(Circuit &c, const std::vector<bool> &v, const std::vector<bool> &sn, const std::vector<bool> &r) { static_cast<CmtaTestCircuit &>(c).assign(v, sn, r); }
 std::unique_ptr<Circuit> make_lesscmp_test_circuit(bool emit) { return std::unique_ptr<Circuit>(new LessCmpTestCircuit(emit)); }

@@ -67,6 +67,7 @@ void assign_lesscmp_test(Circuit &c, uint64_t value_old, uint64_t value_s);
 
 // test circuit: one sha256_CMTA_gadget (send/circuit/commitment.tcc:12-110): two chained compressions with hard-wired padding; bit vectors of 64 / 256 / 256 entries
 std::unique_ptr<Circuit> make_cmta_test_circuit(bool emit);
+std::unique_ptr<Circuit> make_hashblock_test_circuit(bool emit, int which /* 0 CMTS, 1 PRF, 2 CRH */); size_t hashblock_input_bits(int which); void assign_hashblock_test(Circuit &c, const std::vector<bool> &bits);
 void assign_cmta_test(Circuit &c, const std::vector<bool> &v, const std::vector<bool> &sn, const std::vector<bool> &r);
 
 // test circuit: libsnark's merkle_tree_check_read_gadget as its self-test composes it (merkle_tree_check_read_gadget.tcc:131-196)

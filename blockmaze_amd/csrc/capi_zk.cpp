@@ -206,9 +206,12 @@ static R1csHost read_r1cs_file(const char *path) { FILE *f = fopen(path, "rb"); 
     if (fread(cs.rowptr[m].data(), 4, cs.n_cons + 1, f) != cs.n_cons + 1 || fread(cs.col[m].data(), 4, nnz, f) != nnz || fread(cs.coeff[m].data(), 32, nnz, f) != nnz) { fclose(f); throw std::runtime_error("truncated R1CS file"); } } fclose(f); return cs; }
 static void write_witness_file(const char *path, const std::vector<Fe32> &z) { FILE *f = fopen(path, "wb"); if (!f) throw std::runtime_error(std::string("cannot write ") + path); uint64_t n = z.size(); fwrite(&n, 8, 1, f); fwrite(z.data(), 32, n, f); fclose(f); }
 
-int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path) { return guarded_host([&] { std::unique_ptr<Circuit> c = kind == 100 ? make_sha256_two_to_one(true) : kind == 101 ? make_merkle_test_circuit(true, tree_depth) : kind == 102 ? make_lesscmp_test_circuit(true) : kind == 103 ? make_cmta_test_circuit(true) : kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true); write_r1cs_file(r1cs_path, c->r1cs()); return ZKGPU_OK; }); }
+int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path) { return guarded_host([&] { std::unique_ptr<Circuit> c = kind == 100 ? make_sha256_two_to_one(true) : kind == 101 ? make_merkle_test_circuit(true, tree_depth) : kind == 102 ? make_lesscmp_test_circuit(true) : kind == 103 ? make_cmta_test_circuit(true) : kind >= 104 && kind <= 106 ? make_hashblock_test_circuit(true, kind - 104) : kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true); write_r1cs_file(r1cs_path, c->r1cs()); return ZKGPU_OK; }); }
 /* bits: 64 + 256 + 256 bytes, each 0 or 1, in the circuit's bit order */
 int zkgpu_witness_cmta(const uint8_t *bits, const char *wit_path) { return guarded_host([&] { auto c = make_cmta_test_circuit(false); std::vector<bool> v(bits, bits + 64), sn(bits + 64, bits + 320), r(bits + 320, bits + 576); assign_cmta_test(*c, v, sn, r); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
+/* which: 0 CMTS (736 input bits), 1 PRF (512), 2 CRH (416); bits: one byte (0 / 1) per input bit, in the block's message order */
+int zkgpu_witness_hashblock(int which, const uint8_t *bits, const char *wit_path) { return guarded_host([&] { if (which < 0 || which > 2) throw std::runtime_error("hashblock: which must be 0, 1 or 2"); auto c = make_hashblock_test_circuit(false, which);
+  assign_hashblock_test(*c, std::vector<bool>(bits, bits + hashblock_input_bits(which))); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
 int zkgpu_witness_lesscmp(uint64_t value_old, uint64_t value_s, const char *wit_path) { return guarded_host([&] { auto c = make_lesscmp_test_circuit(false); assign_lesscmp_test(*c, value_old, value_s); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
 int zkgpu_witness_sha256(const uint8_t left[32], const uint8_t right[32], const char *wit_path) { return guarded_host([&] { auto c = make_sha256_two_to_one(false); assign_sha256_two_to_one(*c, blob_bits(left, 32), blob_bits(right, 32)); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
 /* Merkle test circuit: leaf and depth siblings (leaf level first, 32 bytes each, in hashing byte order), position of the leaf; the root is computed */

@@ -79,6 +79,7 @@ int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path);
 /* witness files: u64 n, then n 32-byte canonical values (the full assignment without ONE).  Same arguments as the gen*proof symbols. */
 int zkgpu_witness_sha256(const uint8_t left[32], const uint8_t right[32], const char *wit_path);
 int zkgpu_witness_lesscmp(uint64_t value_old, uint64_t value_s, const char *wit_path);
+int zkgpu_witness_hashblock(int which /* 0 CMTS, 1 PRF, 2 CRH: circuit kinds 104..106 of zkgpu_circuit_export */, const uint8_t *bits /* 736 / 512 / 416 bytes of 0 / 1 */, const char *wit_path);
 int zkgpu_witness_cmta(const uint8_t *bits /* 576 bytes of 0 / 1: value[64], sn[256], r[256] */, const char *wit_path);
 int zkgpu_witness_send(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new,
                        char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender, const char *wit_path);

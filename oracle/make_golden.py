@@ -14,6 +14,7 @@ possible in the build container, where /root/reference exists) and stores its OU
   merkle_gadget.json         same for merkle_tree_check_read_gadget (depth 2 and 8)
   lesscmp_gadget.json        BlockMaze's less_comparison_gadget block (send/circuit/comparison.tcc compiled for real): canonical R1CS
                              hash and the witness digests for seven (value_old, value_s) pairs
+  hash_blocks.json           the CMTS (736 bits), PRF (512 bits) and CRH (416 bits, one block) gadgets composed like commitment.tcc:100-320
   cmta_gadget.json           two chained compression gadgets with hard-wired padding, composed like sha256_CMTA_gadget (commitment.tcc:12-110)
   note_hashes.txt            Note::cm / NoteS::cm / Compute_PRF / Compute_CRH of send/Note.h and util.h on seeded hex strings
 
@@ -83,6 +84,17 @@ def blockmaze_fixture():
         run("sha256gadget", t + "/r.bin", t + "/w.bin", "0"); cs = o.R1CS.load(t + "/r.bin")
         res["two_to_one_zero_coefficient_terms"] = [int((cs.coeff[m] == 0).all(axis=1).sum()) for m in range(3)]
     json.dump(res, open(os.path.join(GOLD, "cmta_gadget.json"), "w"), indent=1)
+    res = {}                                                                           # the CMTS / PRF / CRH blocks composed like commitment.tcc:100-320 (ref_harness hashblock)
+    with tempfile.TemporaryDirectory() as t:
+        for kind in ("cmts", "prf", "crh"):
+            r = {}
+            for seed in (3, 4):
+                out = run("hashblock", kind, str(seed), t + "/r.bin", t + "/w.bin"); kv = dict(p.split("=") for p in out.split()[1:])
+                r["canonical_r1cs_sha256"] = canonical_hash(o.R1CS.load(t + "/r.bin")); r["constraints"] = int(kv["constraints"]); r["variables"] = int(kv["variables"])
+                r["terms"] = [int(x) for x in kv["terms"].split(",")]; r["zero_coefficient_terms"] = [int(x) for x in kv["zero_terms"].split(",")]
+                r["seed%d" % seed] = {"digest_bits": kv["digest"], "witness_sha256": sha(t + "/w.bin")}
+            res[kind] = r
+    json.dump(res, open(os.path.join(GOLD, "hash_blocks.json"), "w"), indent=1)
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

@@ -19,6 +19,7 @@
 //   sha256gadget <out_r1cs.bin> <out_wit.bin> <seed>    libsnark sha256_compression_function_gadget R1CS + witness
 //   merklegadget <depth> <out_r1cs.bin> <out_wit.bin> <seed>
 //   lesscmp <value_old> <value_s> <out_r1cs.bin> <out_wit.bin>   BlockMaze's less_comparison_gadget block (send/circuit/comparison.tcc) R1CS + witness
+//   hashblock cmts|prf|crh <seed> <out_r1cs.bin> <out_wit.bin>   the CMTS / PRF / CRH blocks composed like commitment.tcc:100-320
 //   cmta <seed> <out_r1cs.bin> <out_wit.bin>            two chained compression gadgets + hard-wired padding, composed like sha256_CMTA_gadget (commitment.tcc:12-110)
 //   notehashes <seed> <count>                           Note::cm / NoteS::cm / Compute_PRF / Compute_CRH on seeded hex inputs (send/Note.h, util.h)
 //   e2e <r1cs.bin> <wit.bin> <r_hex> <s_hex> <outdir>   is_satisfied, generator, write pk.txt/vk.txt, prove(r,s),
@@ -333,6 +334,31 @@ static int cmd_cmta(uint64_t seed, const char *r1cs_out, const char *wit_out) {
   printf("cmta constraints=%zu variables=%zu terms=%zu,%zu,%zu zero_terms=%zu,%zu,%zu digest=", pb.num_constraints(), pb.num_variables(), terms[0], terms[1], terms[2], zeros[0], zeros[1], zeros[2]);
   for (bool b : cmtA.get_digest()) printf("%d", b ? 1 : 0); printf("\n"); return 0; }
 
+// The other three hash blocks of BlockMaze's circuits, composed from libsnark's own classes exactly as the reference composes them (send/circuit/commitment.tcc:
+// sha256_CMTS_gadget :100-170 — 736-bit message, the serial number split 32 / 224 over the two blocks; sha256_PRF_gadget :172-258 — 512-bit message and a block of pure
+// padding; sha256_CRH_gadget :260-320 — 416 bits and their padding in ONE block).  commitment.tcc itself includes circuit/utils.tcc (BOOST_FOREACH) and cannot be built here.
+static int cmd_hashblock(const std::string &kind, uint64_t seed, const char *r1cs_out, const char *wit_out) {
+  protoboard<FrT> pb; pb_variable<FrT> ZERO; ZERO.allocate(pb, "zero");
+  std::vector<size_t> widths = kind == "cmts" ? std::vector<size_t>{64, 160, 256, 256} : kind == "prf" ? std::vector<size_t>{256, 256} : std::vector<size_t>{160, 256};
+  std::vector<pb_variable_array<FrT>> in(widths.size()); size_t msg_bits = 0; for (size_t i = 0; i < widths.size(); i++) { in[i].allocate(pb, widths[i], "in"); msg_bits += widths[i]; }
+  digest_variable<FrT> out(pb, 256, "out");
+  auto padding = [&](size_t total) { pb_variable_array<FrT> p; size_t n = total - msg_bits; for (size_t i = 0; i < n; i++) { size_t from_end = n - 1 - i; bool bit = i == 0 || (from_end < 64 && ((uint64_t)msg_bits >> from_end) & 1); p.emplace_back(bit ? pb_variable<FrT>(0) : ZERO); } return p; };   // from_bits (utils.tcc:3-12): ONE is variable 0
+  std::unique_ptr<digest_variable<FrT>> inter; std::unique_ptr<block_variable<FrT>> b1, b2; std::unique_ptr<sha256_compression_function_gadget<FrT>> h1, h2;
+  if (kind == "crh") { b1.reset(new block_variable<FrT>(pb, {in[0], in[1], padding(512)}, "b1")); h1.reset(new sha256_compression_function_gadget<FrT>(pb, SHA256_default_IV<FrT>(pb), b1->bits, out, "h1")); }
+  else { inter.reset(new digest_variable<FrT>(pb, 256, ""));
+    if (kind == "cmts") { pb_variable_array<FrT> first(in[3].begin(), in[3].begin() + 32), last(in[3].begin() + 32, in[3].end()); b1.reset(new block_variable<FrT>(pb, {in[0], in[1], in[2], first}, "b1")); b2.reset(new block_variable<FrT>(pb, {last, padding(1024)}, "b2")); }
+    else { b1.reset(new block_variable<FrT>(pb, {in[0], in[1]}, "b1")); b2.reset(new block_variable<FrT>(pb, {padding(1024)}, "b2")); }
+    h1.reset(new sha256_compression_function_gadget<FrT>(pb, SHA256_default_IV<FrT>(pb), b1->bits, *inter, "h1")); h2.reset(new sha256_compression_function_gadget<FrT>(pb, pb_linear_combination_array<FrT>(inter->bits), b2->bits, out, "h2")); }
+  pb.add_r1cs_constraint(r1cs_constraint<FrT>(1, ZERO, 0), "zero"); if (inter) inter->generate_r1cs_constraints(); h1->generate_r1cs_constraints(); if (h2) h2->generate_r1cs_constraints();
+  SplitMix g(seed); pb.val(ZERO) = FrT::zero(); for (size_t i = 0; i < in.size(); i++) { bit_vector bv(widths[i]); for (auto &&b : bv) b = g.next() & 1; in[i].fill_with_bits(pb, bv); }
+  h1->generate_r1cs_witness(); if (h2) h2->generate_r1cs_witness();
+  if (!pb.is_satisfied()) { fprintf(stderr, "unsatisfied\n"); return 1; }
+  save_r1cs(r1cs_out, pb.get_constraint_system()); save_wit(wit_out, pb.full_variable_assignment());
+  size_t terms[3] = {0, 0, 0}, zeros[3] = {0, 0, 0};
+  for (auto &c : pb.get_constraint_system().constraints) { const linear_combination<FrT> *l[3] = {&c.a, &c.b, &c.c}; for (int m = 0; m < 3; m++) for (auto &t : l[m]->terms) { terms[m]++; if (t.coeff.is_zero()) zeros[m]++; } }
+  printf("%s constraints=%zu variables=%zu terms=%zu,%zu,%zu zero_terms=%zu,%zu,%zu digest=", kind.c_str(), pb.num_constraints(), pb.num_variables(), terms[0], terms[1], terms[2], zeros[0], zeros[1], zeros[2]);
+  for (bool b : out.get_digest()) printf("%d", b ? 1 : 0); printf("\n"); return 0; }
+
 // host note hashing through the reference's own classes (send/Note.h:14-80, util.h:233-258, uint256.h:222-248 via uint256S / uint160S)
 static int cmd_notehashes(uint64_t seed, int count) {
   SplitMix g(seed); auto hex = [&](int nbytes) { std::string s = "0x"; char b[3]; for (int i = 0; i < nbytes; i++) { snprintf(b, 3, "%02x", (unsigned)(g.next() & 0xff)); s += b; } return s; };
@@ -405,6 +431,7 @@ int main(int argc, char **argv) {
   if (m == "merklegadget" && argc == 6) return cmd_merklegadget(atoi(argv[2]), argv[3], argv[4], strtoull(argv[5], 0, 0));
   if (m == "lesscmp" && argc == 6) return cmd_lesscmp(strtoull(argv[2], 0, 0), strtoull(argv[3], 0, 0), argv[4], argv[5]);
   if (m == "cmta" && argc == 5) return cmd_cmta(strtoull(argv[2], 0, 0), argv[3], argv[4]);
+  if (m == "hashblock" && argc == 6 && (!strcmp(argv[2], "cmts") || !strcmp(argv[2], "prf") || !strcmp(argv[2], "crh"))) return cmd_hashblock(argv[2], strtoull(argv[3], 0, 0), argv[4], argv[5]);
   if (m == "notehashes" && argc == 4) return cmd_notehashes(strtoull(argv[2], 0, 0), atoi(argv[3]));
   if (m == "e2e" && argc == 7) return cmd_e2e(argv[2], argv[3], argv[4], argv[5], argv[6]);
   if (m == "prove" && argc == 7) return cmd_prove(argv[2], argv[3], atoi(argv[4]), argv[5], argv[6]);

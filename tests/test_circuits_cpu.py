@@ -259,6 +259,20 @@ def test_cmta_block_matches_libsnark_composition(tmp_path, golden_dir):
         z = o.load_witness(wp); assert o.r1cs_is_satisfied(cs, z)
         msg = bytes(sum(b << (7 - j) for j, b in enumerate(bits[8 * i:8 * i + 8])) for i in range(72)); assert "".join(str(int(v)) for v in o.from_arr(z[577:833])) == "".join(format(x, "08b") for x in hashlib.sha256(msg).digest()) == gold["seed%d" % seed]["digest_bits"]
 
+@pytest.mark.parametrize("kind,nbits,msg_blocks", [("cmts", 736, 2), ("prf", 512, 2), ("crh", 416, 1)])
+def test_hash_blocks_match_libsnark_composition(kind, nbits, msg_blocks, tmp_path, golden_dir):
+    """sha256_CMTS_gadget / sha256_PRF_gadget / sha256_CRH_gadget (send/circuit/commitment.tcc:100-320) built in oracle/ref_harness.cpp (cmd_hashblock) from libsnark's own
+    block_variable / digest_variable / sha256_compression_function_gadget — the serial number split 32 / 224 over CMTS's two blocks, PRF's second block of pure padding,
+    CRH's message and padding in one block: same canonical R1CS as this engine's block, bit-identical witness, and the digest is SHA-256 of the message"""
+    gold = json.load(open(os.path.join(golden_dir, "hash_blocks.json")))[kind]; p = str(tmp_path / "c.bin"); e.circuit_export(kind, p); cs = o.R1CS.load(p)
+    assert (cs.n_cons, cs.n_vars) == (gold["constraints"], gold["variables"]) == (msg_blocks * 27280 + 1 + 256 * (msg_blocks - 1), msg_blocks * 24792 + 1 + nbits + 256 * msg_blocks) and canonical_hash(cs) == gold["canonical_r1cs_sha256"]
+    for seed in (3, 4):
+        g = o.SplitMix64(seed); bits = [g.next() & 1 for _ in range(nbits)]; wp = str(tmp_path / "w.bin"); e.witness_hashblock(kind, bits, wp)
+        assert hashlib.sha256(open(wp, "rb").read()).hexdigest() == gold["seed%d" % seed]["witness_sha256"]
+        z = o.load_witness(wp); assert o.r1cs_is_satisfied(cs, z)
+        msg = bytes(sum(b << (7 - j) for j, b in enumerate(bits[8 * i:8 * i + 8])) for i in range(nbits // 8))
+        assert "".join(str(int(v)) for v in o.from_arr(z[1 + nbits:1 + nbits + 256])) == "".join(format(x, "08b") for x in hashlib.sha256(msg).digest()) == gold["seed%d" % seed]["digest_bits"]
+
 # ---- mint / redeem / deposit: the variable layout as the reference's constructors allocate it (read off the sources cited below; the reference-DUMPED table of SURVEY.md
 # Appendix C exists for send only).  Same kind of check as for send: every range holds what the reference's witness generator puts there, and inside every compression
 # gadget the packed message schedule, the packed working variables of all 64 rounds and the reduced output sit at the gadget's offsets.
@@ -311,3 +325,57 @@ def test_deposit_layout_follows_the_reference_constructor(tmp_path):
         nxt = _check_hasher(z, name, msg, nxt + 256, nxt)
     assert nxt == 252636 and rng(252636, 252643) == [(d["index"] >> i) & 1 for i in range(8)]               # positions: fill_with_bits_of_ulong, little-endian
     assert len(z) - 1 - 256739 == 8 * 24792 + 7 * 256 + 260                                                  # 8 hashers, 7 internal digests, the selectors' and the root copy's variables
+
+
+# ---- mint / redeem / deposit: the ORDER of the constraints, block by block as the reference's generate_r1cs_constraints() emit them.  A block of booleanity constraints is
+# located by the variables it binds (the variable ranges are those of the layout tests above); the size of every other block is taken from a gadget the REFERENCE compiled
+# (tests/golden: one SHA-256 compression, the CMTA / CMTS / PRF / CRH compositions, comparison.tcc's block, libsnark's Merkle gadget), and the walk has to end exactly at
+# the constraint count measured on the compiled reference (167,270 / 167,853 / 503,863).  A swapped pair of equally sized blocks, a missing duplicate, a
+# block of the wrong kind all break the walk.
+def _block_sizes(golden_dir):
+    J = lambda n: json.load(open(os.path.join(golden_dir, n)))
+    hb = J("hash_blocks.json"); cmta = J("cmta_gadget.json")["constraints"] - 1; less = J("lesscmp_gadget.json")["constraints"] - 128      # (- the ZERO row; - the two 64-bit booleanity blocks of the test circuit)
+    return dict(cmta=cmta, cmts=hb["cmts"]["constraints"] - 1, prf=hb["prf"]["constraints"] - 1, crh=hb["crh"]["constraints"] - 1, less=less, merkle8=J("merkle_gadget.json")["depth8"]["constraints"])
+
+class _Walk:
+    def __init__(self, cs): self.cs, self.pos = cs, 0
+    def bools(self, vars_, what):
+        got = [_bool_var(self.cs, self.pos + k) for k in range(len(vars_))]; assert got == list(vars_), (what, self.pos); self.pos += len(vars_)
+    def unpacker(self, first, last):                                                   # multipacking_gadget with enforce_bitness: per 253-bit chunk the packing constraint, then the bitness of its bits (basic_gadgets.tcc:31-58)
+        v = first
+        while v <= last: self.pos += 1; hi = min(v + 252, last); self.bools(range(v, hi + 1), "unpacker chunk"); v = hi + 1
+    def hash2(self, inter_first, size, what): self.bools(range(inter_first, inter_first + 256), what + " intermediate digest"); self.pos += size - 256    # ShaTwoBlock: the intermediate digest's bitness, then two compressions
+    def skip(self, n): self.pos += n
+R_ = lambda a, n: range(a, a + n)
+
+@pytest.mark.parametrize("kind", ["mint", "redeem"])
+def test_mint_redeem_constraint_order(kind, tmp_path, golden_dir):
+    """mint/circuit/gadget.tcc:165-193 + note.tcc:44-72 + add_cmp.tcc:23-29;  redeem/circuit/gadget.tcc:151-175 + note.tcc:48-79 + sub_cmp.tcc:29-37"""
+    redeem = kind == "redeem"; p = str(tmp_path / "c.bin"); e.circuit_export(kind, p); cs = o.R1CS.load(p); S = _block_sizes(golden_dir); wk = _Walk(cs)
+    cmtA_old, sn_old, cmtA, value_s, value, value_old, sk, r, r_old, sn = R_(5, 256), R_(261, 256), R_(517, 256), R_(773, 64), R_(838, 64), R_(902, 64), R_(966, 256), R_(1222, 256), R_(1478, 256), R_(1734, 256)
+    h0 = 2060 if redeem else 1993; prf_i, old_i, new_i = h0, h0 + 256 + 2 * 24792, h0 + 2 * (256 + 2 * 24792)
+    wk.unpacker(5, 836)
+    wk.bools(list(value_old) + list(value_s) + list(value) + list(sk) + list(r) + list(r_old), "note")
+    if redeem: wk.bools(list(sn) + list(sn_old), "note: sn, sn_old"); wk.skip(1); assert S["less"] == 71; wk.skip(S["less"])        # `equal`, then less_comparison_gadget
+    else: wk.skip(1)                                                                                                              # value_old + value_s = value
+    wk.skip(1)                                                                                                                    # ZERO
+    wk.bools(sn, "sn"); wk.hash2(prf_i, S["prf"], "PRF")
+    wk.bools(list(sn_old) + list(cmtA_old), "sn_old, cmtA_old"); wk.hash2(old_i, S["cmta"], "CMTA_old")
+    wk.bools(cmtA, "cmtA"); wk.hash2(new_i, S["cmta"], "CMTA")
+    assert wk.pos == cs.n_cons == (167853 if redeem else 167270)
+
+def test_deposit_constraint_order(tmp_path, golden_dir):
+    """deposit/circuit/gadget.tcc:200-234 + note.tcc:64-103 + merkle.tcc:36-52 (position bits, then libsnark's authentication path and check-read gadget: the block the
+    reference-compiled Merkle gadget dump measures)"""
+    p = str(tmp_path / "c.bin"); e.circuit_export("deposit", p); cs = o.R1CS.load(p); S = _block_sizes(golden_dir); wk = _Walk(cs)
+    rt, pk_recv, cmtB_old, sn_old, cmtB, sn_s = R_(7, 256), R_(263, 160), R_(423, 256), R_(679, 256), R_(935, 256), R_(1191, 256)
+    value_s, r_s, sn_A_old, cmtS, value_old, r_old, value, sn, r, sk = R_(1449, 64), R_(1513, 256), R_(1769, 256), R_(2025, 256), R_(2281, 64), R_(2345, 256), R_(2601, 64), R_(2665, 256), R_(2921, 256), R_(3177, 256)
+    step = 256 + 2 * 24792; prf_sn, prf_sn_s, cmts_i, old_i, new_i = [3436 + k * step for k in range(5)]; positions = R_(3436 + 5 * step, 8)
+    wk.unpacker(7, 1446)
+    wk.bools(list(value_s) + list(value_old) + list(value), "note values"); wk.skip(1)                                            # value_old + value_s = value
+    wk.bools(list(pk_recv) + list(r_s) + list(sn_A_old) + list(sn_old) + list(r_old) + list(sn) + list(r) + list(sk), "note digests"); wk.skip(1)   # ZERO
+    wk.bools(sn_s, "sn_s"); wk.hash2(prf_sn_s, S["prf"], "PRF(sn_s)"); wk.bools(sn, "sn"); wk.hash2(prf_sn, S["prf"], "PRF(sn)")
+    wk.bools(list(sn_old) + list(cmtS), "sn_old, cmtS"); wk.hash2(cmts_i, S["cmts"], "CMTS")
+    wk.bools(cmtB_old, "cmtB_old"); wk.hash2(old_i, S["cmta"], "CMTB_old"); wk.bools(cmtB, "cmtB"); wk.hash2(new_i, S["cmta"], "CMTB")
+    wk.bools(list(rt) + [1447] + list(positions), "rt, value_enforce, positions"); wk.skip(S["merkle8"])
+    assert wk.pos == cs.n_cons == 503863
