@@ -52,7 +52,7 @@ zkgpu_msm *zkgpu_msm_create(int group, const uint8_t *points, size_t n, int wind
   zkgpu_msm *h = nullptr;
   int rc = guarded([&] { if (group != 1 && group != 2) { g_err = "group must be 1 or 2"; return ZKGPU_ERR_ARG; }
     int c = window_bits ? window_bits : auto_window(n); std::unique_ptr<zkgpu_msm> m(new zkgpu_msm); m->group = group; m->n = n;
-    if (group == 1) { std::vector<G1AffineRaw> raw(n ? n : 1); for (size_t i = 0; i < n; i++) g1_to_raw(points + 64 * i, raw[i]); m->g1.reset(new MsmG1(raw.data(), n, c, (filter_ones & 1) != 0, true, (filter_ones & 2) != 0, (filter_ones & 4) != 0)); }
+    if (group == 1) { std::vector<G1AffineRaw> raw(n ? n : 1); for (size_t i = 0; i < n; i++) g1_to_raw(points + 64 * i, raw[i]); m->g1.reset(new MsmG1(raw.data(), n, c, (filter_ones & 1) != 0, true, (filter_ones & 2) != 0)); }
     else { std::vector<G2AffineRaw> raw(n ? n : 1); for (size_t i = 0; i < n; i++) g2_to_raw(points + 128 * i, raw[i]); m->g2.reset(new MsmG2(raw.data(), n, c, (filter_ones & 1) != 0, true, (filter_ones & 2) != 0)); }
     m->scalars = DevBuf<Fe32>(n ? n : 1); h = m.release(); return ZKGPU_OK; });
   return rc == ZKGPU_OK ? h : nullptr;

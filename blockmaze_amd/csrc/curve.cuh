@@ -49,18 +49,6 @@ struct XYZZ {
     F X3 = Rv.sqr() - PPP - Q.dbl();
     Y = Rv * (Q - X3) - Y * PPP; X = X3; ZZ = ZZ * PP; ZZZ = ZZZ * PPP;
   }
-  // The same mixed addition in the lazy domain of field.cuh — the inner loop of the H query's accumulation (msm.cuh: k_hacc_runs).  Coordinates live in [0, 2p), the
-  // affine operand (px, py: sign already applied) in [0, p]; 8 products and 2 squarings without a final subtraction, 7 differences that add 2p after a borrow.  The
-  // point at infinity is NOT representable here: the caller keeps a flag beside the accumulator and lifts the first point itself.  Returns false and leaves the
-  // accumulator untouched when the operand is +-acc (P = 0 mod p, i.e. the limbs are 0 or p); the caller then takes its slow path (madd_inl on normalized values).
-  __device__ __forceinline__ bool madd_lazy(const F &px, const F &py) {
-    F Pv = F::sub_lazy(F::mul_lazy(px, ZZ), X);
-    if (__builtin_expect((Pv.l[0] == 0u || Pv.l[0] == F::modulus_limb0()) && Pv.is_zero_lazy(), 0)) return false;
-    F Rv = F::sub_lazy(F::mul_lazy(py, ZZZ), Y), PP = F::sqr_lazy(Pv), PPP = F::mul_lazy(Pv, PP), Q = F::mul_lazy(X, PP);
-    F X3 = F::sub_lazy(F::sub_lazy(F::sub_lazy(F::sqr_lazy(Rv), PPP), Q), Q);
-    Y = F::sub_lazy(F::mul_lazy(Rv, F::sub_lazy(Q, X3)), F::mul_lazy(Y, PPP)); X = X3; ZZ = F::mul_lazy(ZZ, PP); ZZZ = F::mul_lazy(ZZZ, PPP);
-    return true;
-  }
   // general addition acc += o (EFD add-2008-s), complete
   ZK_HD void add_inl(const XYZZ &o) {
     if (o.is_inf()) return;

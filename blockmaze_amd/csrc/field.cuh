@@ -43,8 +43,9 @@ struct Fp {
   __device__ __forceinline__ Fp sqr() const { Fp r = sqr_raw(*this); cond_sub<1>(r); return r; }                   // dedicated squaring: 36 limb products instead of 64 (fp.tcc:594 squared())
   // ---- the lazy domain: values in [0, 2p) ----------------------------------------------------------------------------------------------------------------------
   // Both moduli leave two spare bits (p < 2^254).  A Montgomery product of a, b < 2p is (ab + mp)/R < (4p^2 + Rp)/R < 2p because R = 2^256 > 4p, so products need no final
-  // subtraction when they feed further products; a difference stays in [0, 2p) when 2p is added after a borrow.  normalize() brings a value back to [0, p).  The bucket
-  // accumulation's mixed addition (curve.cuh: madd_lazy) lives in this domain: 7 differences at 25 instructions, no reduction after any of the 10 products.
+  // subtraction when they feed further products; a difference stays in [0, 2p) when 2p is added after a borrow.  normalize() brings a value back to [0, p).  The 29-bit
+  // kernels of msm.cuh hand their results over in this domain (k_hacc_combine29); round 3's first version of the H accumulation lived in it (tools/mul_probe.hip compares
+  // the two product forms).
   static __device__ __forceinline__ Fp mul_lazy(const Fp &a, const Fp &b) { return mul_raw(a, b); }
   static __device__ __forceinline__ Fp sqr_lazy(const Fp &a) { return sqr_raw(a); }
   static __device__ __forceinline__ Fp sub_lazy(const Fp &a, const Fp &b) { Fp d = a; sub_fix<2>(d, b); return d; }

@@ -371,8 +371,7 @@ void R1csDev::eval(const Fe32 *z, Fe32 *abc, size_t m) {
   Stage st("r1cs.rows"); Impl &d = *impl; hipStream_t s = gpu().stream; if (m < d.n_cons + d.n_inputs + 1) throw GpuError("r1cs: domain too small");
   R1csMatrices M; for (int mm = 0; mm < 3; mm++) { M.rowptr[mm] = d.rowptr[mm].get(); M.col[mm] = d.col[mm].get(); M.cid[mm] = d.cid[mm].get(); }
   if (++d.seq == 0) d.seq = 1;
-  static const bool merged = [] { const char *e = getenv("ZK_R1CS_MERGED"); return !e || atoi(e) != 0; }();
-  if (merged && d.n_long_any) { const uint32_t sb = (uint32_t)cdiv(m, 256);
+  if (d.n_long_any) { const uint32_t sb = (uint32_t)cdiv(m, 256);   // rows of more than 16 terms exist: the one-launch form (short rows and one wave per long row) const uint32_t sb = (uint32_t)cdiv(m, 256);
     hipLaunchKernelGGL(k_r1cs_rows_all, dim3(sb + (unsigned)cdiv(d.n_long_any, 4)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)d.n_cons, (uint32_t)d.n_inputs, (uint32_t)m, (const uint32_t *)d.long_any.get(), (uint32_t)d.n_long_any, sb, (Fr *)abc, d.seq, d.d_fail);
     return; }
   hipLaunchKernelGGL(k_r1cs_rows3, dim3(cdiv(m, 256)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)d.n_cons, (uint32_t)d.n_inputs, (uint32_t)m, (Fr *)abc, d.seq, d.d_fail);

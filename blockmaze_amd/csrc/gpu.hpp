@@ -55,7 +55,7 @@ void upload_async(void *dev, const void *pinned_host, size_t bytes);   // on the
 struct WsortBuffers;                           // the sorted witness digits an MSM leaves for the MSMs over the same scalar vector (msm_impl.hpp)
 class MsmG1 {
  public:
-  MsmG1(const G1AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false, bool glv = false);   // glv: halve the scalars with the curve's endomorphism (needs tables + uniform); tables: precompute 2^(cw) P if the size cap allows; uniform: one-pass sort with overflow fallback (msm_impl.hpp)
+  MsmG1(const G1AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false);   // tables: precompute 2^(cw) P if the size cap allows; uniform: one-pass sort with overflow fallback (msm_impl.hpp)
   MsmG1(const MsmG1 &peer, bool filter_ones, bool uniform_scalars);   // shares the peer's resident points / fixed-base table (immutable); owns only its workspace
   ~MsmG1();
   // scalars_dev: Fr (Montgomery) on the device.  scalar_index_dev: optional gather map (point i uses scalars[index[i]]).
@@ -72,7 +72,7 @@ class MsmG1 {
 };
 class MsmG2 {
  public:
-  MsmG2(const G2AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false, bool glv = false);   // (glv is ignored for G2)
+  MsmG2(const G2AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false);
   MsmG2(const MsmG2 &peer, bool filter_ones, bool uniform_scalars);
   ~MsmG2();
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);

@@ -17,9 +17,11 @@ class GpuContext {
     // (GPU_MAX_HW_QUEUES is raised by the library constructor in gpu.hip, before any HIP call of this process can have read it)
     int n = 0; if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
     device = device_index % n;
-    HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipGetDeviceProperties(&prop, device)); const char *pe = getenv("ZK_STREAM_PRIORITY"); const int pm = pe ? atoi(pe) : 0; int lo = 0, hi = 0; HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (lo = least urgent; numerically greater)
-    if (pm & 1) HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi)); else HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));   // (round 1: a high-priority main stream gave nothing for one proof and cost 15 % with four in flight)
-    for (int i = 0; i < 4; i++) { if (pm & 2) HIP_CHECK(hipStreamCreateWithPriority(&aux[i], hipStreamNonBlocking, lo)); else HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking)); } HIP_CHECK(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming)); for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&join_event[i], hipEventDisableTiming));
+    HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    // (measured and dropped: a high-priority main stream and low-priority auxiliary streams (1-2 % slower), and confining the auxiliary streams to 32-128 CUs with
+    // hipExtStreamCreateWithCUMask — profiles/r03h_ab_cumask.txt: the transforms are not slowed by sharing SIMDs, the proof is bound by VALU issue as a whole)
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming)); for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&join_event[i], hipEventDisableTiming));
   }
 };
 GpuContext &gpu();

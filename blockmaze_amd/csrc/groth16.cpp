@@ -292,8 +292,8 @@ static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &
 // streams, labels and the per-object vectors (everything that is not shared between the provers of one key)
 static void finish_setup(Prover::Impl &p) {
   const bool one_stream = env_int("ZK_MSM_ONE_STREAM", 0) != 0;   // diagnostic: everything on the main stream, so that a kernel trace shows every kernel's stand-alone duration
-  if (env_int("ZK_MSM_SHARE_SORT", 1)) { p.pair_AL = p.c_fold && p.a0 == p.l0 && p.L->share_sort_with(p.A->sort_handle()); p.b2_first = env_int("ZK_B2_FIRST", 1) != 0; p.pair_B = p.b2_first ? p.B1->share_sort_with(p.B2->sort_handle()) : p.B2->share_sort_with(p.B1->sort_handle()); }
-  if (!one_stream) { p.A->set_stream(0); p.L->set_stream(p.pair_AL ? 0 : 1); p.B1->set_stream(2); p.B2->set_stream(p.pair_B ? 2 : 3); if (!p.pair_B && env_int("ZK_MSM_SPLIT_ONES", 1)) p.B2->split_ones_path(); }   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
+  { p.pair_AL = p.c_fold && p.a0 == p.l0 && p.L->share_sort_with(p.A->sort_handle()); p.b2_first = true; p.pair_B = p.B1->share_sort_with(p.B2->sort_handle()); }   // MSMs over the same scalars share one sort: L* follows A, B1 follows B2 (the long G2 accumulation first)
+  if (!one_stream) { p.A->set_stream(0); p.L->set_stream(p.pair_AL ? 0 : 1); p.B1->set_stream(2); p.B2->set_stream(p.pair_B ? 2 : 3); if (!p.pair_B) p.B2->split_ones_path(); }   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
   p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
   p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host = PinnedBuf<Fe32>(p.nv + 1 + 8); p.packed = DevBuf<uint8_t>(32 * (p.nv + 1 + 8));
 }
@@ -314,7 +314,7 @@ Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world, 
   if (p.c_fold) { if (pk.L_star.size() != p.nv + 1) { pk.L_star.resize(p.nv + 1); p.dom->fold_c_into_l(pk.H_lagrange.data(), pk.cs, pk.L.data(), pk.L_star.data()); } Lq = &pk.L_star; }
   shard_range(Lq->size(), shard_rank, shard_world, p.l0, e); size_t nL = e - p.l0;
   p.A.reset(new MsmG1(pk.A.data() + p.a0, nA, cw, true)); p.L.reset(new MsmG1(Lq->data() + p.l0, nL, cw, true));
-  p.B1.reset(new MsmG1(pk.B_g1.data() + p.b0, nB, cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data() + p.b0, nB, cw, true)); p.H.reset(new MsmG1(Hq->data() + p.h0, nH, ch, false, env_int("ZK_MSM_H_TABLES", 1) != 0, true, env_int("ZK_MSM_GLV", 0) != 0));   // GLV (msm.cuh) is implemented and tested but off: measured, the accumulation does not get faster on the 151 MB table (0.56 vs 0.53 ms) and the decomposition costs 0.1 ms in the sort   // (with tables the H accumulation gathers from a table 16x larger and slows from 0.40 to 0.51 ms, but the reduction drops from 0.53 to 0.23 ms: measured 3 % better per proof, 10 % better with four proofs in flight)
+  p.B1.reset(new MsmG1(pk.B_g1.data() + p.b0, nB, cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data() + p.b0, nB, cw, true)); p.H.reset(new MsmG1(Hq->data() + p.h0, nH, ch, false, env_int("ZK_MSM_H_TABLES", 1) != 0, true));   // (with tables the H accumulation gathers from a table 16x larger, but the weighted bucket sum shrinks by the number of windows)
   finish_setup(p);
   p.B_idx = std::make_shared<DevBuf<uint32_t>>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx->upload(pk.B_idx.data(), pk.B_idx.size());
 }
@@ -383,11 +383,9 @@ static RsTerms rs_terms(const Fe32 *r_in, const Fe32 *s_in, const HG1 &delta_g1,
   RsTerms t; t.r = r_in ? fr_of(*r_in) : random_fr().from_mont(); t.s = s_in ? fr_of(*s_in) : random_fr().from_mont(); HFr rs = (t.r.to_mont() * t.s.to_mont()).from_mont();   // canonical scalars
   t.r_delta = delta_g1.mul(t.r.l); t.s_delta = delta_g1.mul(t.s.l); t.rs_delta_neg = delta_g1.mul(rs.l).neg(); t.s_delta2 = delta_g2.mul(t.s.l); return t; }
 static void enqueue_all(Prover::Impl &p) {
-  // ZK_WITNESS_MSM_START: where each witness MSM (auxiliary streams; order B2, L, A, B1) is released relative to the critical chain, one digit per MSM or one for all:
-  // 0 = at once, 1 = after the row kernels, 2 = after the three inverse transforms, 3 = after the coset transforms, 4 = after all transforms (overlapping the H-query MSM only).
-  // Measured (send): all 0: 2.85 ms, 1: 2.38-2.44, 2: 2.47-2.50, 3: 2.62, 4: 3.0 — at time 0 the five full-chip classify kernels fight the row and transform kernels for the CUs.
-  static const std::array<int, 4> start = [] { std::array<int, 4> a{1, 1, 1, 1}; const char *e = getenv("ZK_WITNESS_MSM_START"); size_t n = e ? strlen(e) : 0;
-    for (int j = 0; j < 4 && n; j++) { char ch = e[n == 1 ? 0 : (size_t)j < n ? j : n - 1]; a[j] = ch >= '0' && ch <= '4' ? ch - '0' : 1; } return a; }();
+  // The witness MSMs (auxiliary streams; order B2, L, A, B1) are released after the row kernels (release point 1 of 0 = at once .. 4 = after all transforms): started at time 0 their
+  // full-chip sort kernels fight the row and transform kernels for the CUs; later release points only move the contention into the H accumulation (profiles/r03i_ab_start.txt).
+  static const std::array<int, 4> start{1, 1, 1, 1};
   // about 80 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
   // (auxiliary streams) while this one submits the critical chain
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();

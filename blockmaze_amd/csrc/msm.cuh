@@ -8,8 +8,10 @@
 //   classify   one thread per (point, scalar): leave Montgomery form, drop zeros / points at infinity, append "ones" to a compacted index list (one atomic per
 //              wave), histogram the signed c-bit digits (in LDS first when the bucket array is small)
 //   plan       bucket offsets (scan), buckets ranked by decreasing size, tasks of at most 16 entries; one single-workgroup launch for small bucket arrays
-//   scatter    counting sort of (table index, sign) by bucket.  H query (uniform scalars): classify + scan + scatter collapse into ONE pass with fixed slots per
-//              bucket (k_msm_scatter_direct), falling back to the two-pass sort if a bucket overflows
+//   scatter    counting sort of (table index, sign) by bucket
+//   H query    (uniform scalars, fixed-base table) has a path of its own: one-pass sort by workgroup-local binning (k_hsort_bin / k_hsort_group), accumulation over
+//              fixed-length runs of the sorted entries on nine 29-bit limbs (k_hacc_runs29), pieces added up per bucket (k_hacc_combine29), weighted bucket sum by weight
+//              bits (k_bitsum_*); an overflow of the sort's regions or a degenerate key sends the MSM back to the general path below
 //   accumulate one lane per task walks its slice of the sorted list with mixed additions (XYZZ accumulator in VGPRs, next point's gather in flight)
 //   combine    buckets cut into several tasks: a quad (or a workgroup for very full buckets) adds the partial sums
 //   reduce     sum_b b*B_b by segments: running sums inside a segment, a small scalar multiple for the segment offset, then workgroup-level trees — all with
@@ -20,7 +22,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "curve.cuh"
-#include "glv_params.h"
 
 namespace zk {
 
@@ -53,42 +54,13 @@ template <int C, class Fn> __device__ __forceinline__ void for_each_digit(const 
     fn(w, dg);
   }
 }
-// ---- GLV: k = k1 + k2*lambda with |k1|, |k2| < 2^128, lambda*(x, y) = (beta*x, y) ------------------------------------------
-// Halves the windows an MSM with fixed-base tables needs (9 of 16 bits instead of 16): the H query's table shrinks from 268 MB to 151 MB and fits the Infinity Cache.
-// An entry of the second half carries bit 30; the accumulation kernel multiplies x by beta for it.  Any integers c1, c2 give a correct decomposition (the basis
-// vectors are multiples of r under (x, y) -> x + y*lambda), so the truncated quotients below are fine.
-__device__ __forceinline__ void mp_mul_lo8(const uint32_t *x, int nx, const uint32_t *y, int ny, uint32_t out[8]) {   // low 256 bits of x*y
-  for (int i = 0; i < 8; i++) out[i] = 0;
-  for (int i = 0; i < nx && i < 8; i++) { uint64_t c = 0; for (int j = 0; j < ny && i + j < 8; j++) { uint64_t t = (uint64_t)x[i] * y[j] + out[i + j] + c; out[i + j] = (uint32_t)t; c = t >> 32; }
-    for (int t = i + ny; c && t < 8; t++) { uint64_t u = (uint64_t)out[t] + c; out[t] = (uint32_t)u; c = u >> 32; } }
+// fn(w, digit) for every window: the compiled-in walk for the window sizes in use (C > 0; the host checks c == C before it launches such an instantiation), otherwise the
+// digit array of signed_digits (runtime c, W)
+template <int C, class Fn> __device__ __forceinline__ void msm_walk_digits(const uint32_t (&k)[8], int c, int W, Fn &&fn) {
+  if constexpr (C > 0) { for_each_digit<C>(k, [&](int w, int d) { fn(w, d); }); }
+  else { int dig[MSM_MAX_WINDOWS]; signed_digits(k, c, W, dig); for (int w = 0; w < W; w++) fn(w, dig[w]); }
 }
-template <int NY> __device__ __forceinline__ void mp_mul_hi(const uint32_t k[8], const uint32_t (&y)[NY], uint32_t out[NY]) {   // floor(k*y / 2^256), NY limbs
-  uint32_t p[8 + NY]; for (int i = 0; i < 8 + NY; i++) p[i] = 0;
-  for (int i = 0; i < 8; i++) { uint64_t c = 0; for (int j = 0; j < NY; j++) { uint64_t t = (uint64_t)k[i] * y[j] + p[i + j] + c; p[i + j] = (uint32_t)t; c = t >> 32; } p[i + NY] = (uint32_t)c; }
-  for (int j = 0; j < NY; j++) out[j] = p[8 + j];
-}
-__device__ __forceinline__ void mp_sub8(uint32_t a[8], const uint32_t b[8]) { uint64_t br = 0; for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)a[i] - b[i] - br; a[i] = (uint32_t)t; br = (t >> 32) & 1; } }
-__device__ __forceinline__ bool mp_abs8(uint32_t a[8]) { if (!(a[7] >> 31)) return false; uint64_t c = 1; for (int i = 0; i < 8; i++) { c += (uint32_t)~a[i]; a[i] = (uint32_t)c; c >>= 32; } return true; }   // two's complement -> magnitude; true if it was negative
-__device__ __forceinline__ void glv_decompose(const uint32_t k[8], uint32_t k1[8], bool &neg1, uint32_t k2[8], bool &neg2) {
-  uint32_t c1[3], c2[5], t[8]; mp_mul_hi<3>(k, GLV_G1, c1); mp_mul_hi<5>(k, GLV_G2, c2);
-  for (int i = 0; i < 8; i++) k1[i] = k[i];
-  mp_mul_lo8(c1, 3, GLV_A1, 2, t); mp_sub8(k1, t); mp_mul_lo8(c2, 5, GLV_A2, 4, t); mp_sub8(k1, t);           // k1 = k - c1 a1 - c2 a2
-  mp_mul_lo8(c1, 3, GLV_NB1, 4, k2); mp_mul_lo8(c2, 5, GLV_B2, 2, t); mp_sub8(k2, t);                          // k2 = c1 (-b1) - c2 b2
-  neg1 = mp_abs8(k1); neg2 = mp_abs8(k2);
-}
-// signed digits of k for the sort kernels: W digits, or with GLV the W digits of |k1| followed by the W digits of |k2| (signs applied)
-__device__ __forceinline__ int msm_digits(const uint32_t k[8], int c, int W, int glv, int *dig) {
-  if (!glv) { signed_digits(k, c, W, dig); return W; }
-  uint32_t k1[8], k2[8]; bool n1, n2; glv_decompose(k, k1, n1, k2, n2); signed_digits(k1, c, W, dig); signed_digits(k2, c, W, dig + W);
-  if (n1) for (int w = 0; w < W; w++) dig[w] = -dig[w];
-  if (n2) for (int w = 0; w < W; w++) dig[W + w] = -dig[W + w];
-  return 2 * W;
-}
-template <int C, class Fn> __device__ __forceinline__ void msm_walk_digits(const uint32_t (&k)[8], int c, int W, int glv, Fn &&fn) {   // fn(e, w, digit): e = entry number (w, or W + w for the second GLV half)
-  if constexpr (C > 0) { for_each_digit<C>(k, [&](int w, int d) { fn(w, w, d); }); }
-  else { int dig[MSM_MAX_WINDOWS]; const int nd = msm_digits(k, c, W, glv, dig); for (int e = 0; e < nd; e++) fn(e, e < W ? e : e - W, dig[e]); }
-}
-constexpr uint32_t MSM_ENTRY_SIGN = 0x80000000u, MSM_ENTRY_PHI = 0x40000000u;   // entry = table index | sign | second GLV half
+constexpr uint32_t MSM_ENTRY_SIGN = 0x80000000u;   // entry = table index | sign
 
 struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; };
 
@@ -99,7 +71,7 @@ struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; };
 constexpr uint32_t MSM_LDS_HIST = 4096;
 template <int C>
 __global__ void __launch_bounds__(256) k_msm_classify(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
-                               uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t n_hist, int glv, uint32_t *__restrict__ hist, uint32_t *__restrict__ ones, MsmCounters *cnt, MsmCounters *cnt_next) {
+                               uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t n_hist, uint32_t *__restrict__ hist, uint32_t *__restrict__ ones, MsmCounters *cnt, MsmCounters *cnt_next) {
   __shared__ uint32_t lh[MSM_LDS_HIST]; const bool use_lds = n_hist <= MSM_LDS_HIST;
   if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = MsmCounters{0, 0, {0, 0}};   // the counters alternate between two slots: this run clears the next run's
   if (use_lds) { for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) lh[b] = 0; __syncthreads(); }
@@ -110,62 +82,44 @@ __global__ void __launch_bounds__(256) k_msm_classify(const Fr *__restrict__ sca
     uint64_t m = __ballot(is_one); if (m) { uint32_t lane = threadIdx.x & 63, base = 0; if (lane == (uint32_t)__ffsll((long long)m) - 1) base = atomicAdd(&cnt->n_ones, (uint32_t)__popcll(m));
       base = __shfl(base, __ffsll((long long)m) - 1, 64); if (is_one) ones[base + __popcll(m & ((1ull << lane) - 1))] = i; } }
   if (live && !is_one)
-    msm_walk_digits<C>(k.l, c, W, glv, [&](int, int w, int d) { if (d) { uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; atomicAdd(use_lds ? &lh[key] : &hist[key], 1u); } });   // hist_stride = 2^(c-1): buckets per window; 0: all windows share one bucket array (precomputed 2^(cw) P)
+    msm_walk_digits<C>(k.l, c, W, [&](int w, int d) { if (d) { uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; atomicAdd(use_lds ? &lh[key] : &hist[key], 1u); } });   // hist_stride = 2^(c-1): buckets per window; 0: all windows share one bucket array (precomputed 2^(cw) P)
   { uint64_t m = __ballot(live && !is_one); if (m && (threadIdx.x & 63) == (uint32_t)__ffsll((long long)m) - 1) atomicAdd(&cnt->n_other, (uint32_t)__popcll(m)); }
   if (use_lds) { __syncthreads(); for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) if (lh[b]) atomicAdd(&hist[b], lh[b]); }
 }
 
 template <int C>
 __global__ void __launch_bounds__(256) k_msm_scatter(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf,
-                              uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t point_stride, uint32_t n_hist, int glv, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ fill, uint32_t *__restrict__ entries) {
+                              uint32_t n, int c, int W, int filter_ones, uint32_t hist_stride, uint32_t point_stride, uint32_t n_hist, const uint32_t *__restrict__ offsets, uint32_t *__restrict__ fill, uint32_t *__restrict__ entries) {
   __shared__ uint32_t lcnt[MSM_LDS_HIST], lbase[MSM_LDS_HIST]; const bool use_lds = n_hist <= MSM_LDS_HIST;
   if (use_lds) { for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) lcnt[b] = 0; __syncthreads(); }
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; bool live = i < n && !(point_is_inf && point_is_inf[i]); Fr k = Fr::zero();
   if (live) { k = scalars[scalar_index ? scalar_index[i] : i].from_mont(); live = !k.is_zero(); }
   if (live && filter_ones) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; if (o == 0) live = false; }
-  auto entry_of = [&](int e, int w, int d) { return (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u) | (e >= W ? MSM_ENTRY_PHI : 0u); };   // point_stride = n: the entry addresses 2^(cw) P_i in the precomputed table
+  auto entry_of = [&](int w, int d) { return (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u); };   // point_stride = n: the entry addresses 2^(cw) P_i in the precomputed table
   if (!use_lds) {
-    if (live) msm_walk_digits<C>(k.l, c, W, glv, [&](int e, int w, int d) { if (!d) return; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; entries[offsets[key] + atomicAdd(&fill[key], 1u)] = entry_of(e, w, d); });
+    if (live) msm_walk_digits<C>(k.l, c, W, [&](int w, int d) { if (!d) return; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; entries[offsets[key] + atomicAdd(&fill[key], 1u)] = entry_of(w, d); });
     return;
   }
   // small bucket arrays: the workgroup counts its entries per bucket in LDS, reserves its share of every bucket with one global atomic, then walks the digits a second
   // time to place them (ranks come from the LDS counters; nothing per entry is kept in registers or scratch between the two walks)
-  if (live) msm_walk_digits<C>(k.l, c, W, glv, [&](int, int w, int d) { if (d) atomicAdd(&lcnt[(uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1], 1u); });
+  if (live) msm_walk_digits<C>(k.l, c, W, [&](int w, int d) { if (d) atomicAdd(&lcnt[(uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1], 1u); });
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < n_hist; b += blockDim.x) { const uint32_t m = lcnt[b]; lbase[b] = m ? offsets[b] + atomicAdd(&fill[b], m) : 0; lcnt[b] = 0; }
   __syncthreads();
-  if (live) msm_walk_digits<C>(k.l, c, W, glv, [&](int e, int w, int d) { if (!d) return; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; entries[lbase[key] + atomicAdd(&lcnt[key], 1u)] = entry_of(e, w, d); });
+  if (live) msm_walk_digits<C>(k.l, c, W, [&](int w, int d) { if (!d) return; uint32_t key = (uint32_t)w * hist_stride + (uint32_t)(d < 0 ? -d : d) - 1; entries[lbase[key] + atomicAdd(&lcnt[key], 1u)] = entry_of(w, d); });
 }
 
-// One-pass sort for scalars known to be uniform (the H query: coefficients of the quotient polynomial) with all windows sharing one bucket array: every bucket owns
-// `cap` slots (about twice its expected load), an entry goes to slot atomicAdd(count[b]) of its bucket — no histogram pass, no prefix scan.  A bucket that would
-// overflow sets counters->pad[0]; the host then repeats the MSM on the two-pass path (any input stays correct, only uniform ones are fast).
-template <int DUMMY = 0>
-__global__ void k_msm_scatter_direct(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf, uint32_t n, int c, int W, uint32_t point_stride,
-                                     uint32_t cap, uint32_t *__restrict__ counts, uint32_t *__restrict__ entries, MsmCounters *cnt, MsmCounters *cnt_next,
-                                     const Fr *__restrict__ mul_b, const Fr *__restrict__ mul_z, int z_is_table, int glv) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i == 0) *cnt_next = MsmCounters{0, 0, {0, 0}}; if (i >= n) return;
-  if (point_is_inf && point_is_inf[i]) return;
-  Fr k = scalars[scalar_index ? scalar_index[i] : i]; if (mul_b) k = k * mul_b[i] * mul_z[z_is_table ? i : 0];   // mul_b: the scalar is the product a*b*z (the pointwise step of the witness map, fused)
-  k = k.from_mont();
-  if (k.is_zero()) return;
-  int dig[MSM_MAX_WINDOWS]; const int nd = msm_digits(k.l, c, W, glv, dig); bool over = false;
-  for (int e = 0; e < nd; e++) { int d = dig[e]; if (!d) continue; const int w = e < W ? e : e - W; uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, slot = atomicAdd(&counts[key], 1u);
-    if (slot < cap) entries[(size_t)key * cap + slot] = (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u) | (e >= W ? MSM_ENTRY_PHI : 0u); else over = true; }
-  if (over) atomicOr(&cnt->pad[0], 1u);
-}
-
-// ---- H query, second generation of the one-pass sort: workgroup-local binning ------------------------------------------------
-// k_msm_scatter_direct above pays one device-scope atomic and one isolated 4-byte store per digit (4.2 M of each for the send circuit: 0.34 ms, 13.6x the algorithmic
-// traffic).  Here the 2^(c-1) buckets are cut into HSORT_GROUPS groups by their high bits, and the sort runs in two short kernels whose atomics are all in LDS:
+// ---- H query: one-pass sort by workgroup-local binning ------------------------------------------------
+// A one-pass sort with fixed slots per bucket pays one device-scope atomic and one isolated 4-byte store per digit (4.2 M of each for the send circuit: 0.34 ms, 13.6x the
+// algorithmic traffic; round 1).  Here the 2^(c-1) buckets are cut into HSORT_GROUPS groups by their high bits, and the sort runs in two short kernels whose atomics are all in LDS:
 //   k_hsort_bin    a workgroup takes HSORT_TILE scalars (forming a*b*z on the way), counts its digits per group in LDS, reserves its share of every group's region
 //                  with ONE device-scope atomic per group (65 K per MSM instead of 4.2 M), then writes each entry next to its workgroup-mates of the same group:
 //                  runs of ~128 bytes per group and workgroup instead of isolated words.  Entry = low bucket bits | sign | table index.
 //   k_hsort_group  one workgroup per group: the group's entries (16 K for send) are counted per bucket in LDS, the counts are scanned, and every entry moves to its
-//                  final place inside the group's region of the output (a 64 KB window that lives in this XCD's L2 while it is written).  Emits counts[] / offsets[].
-// Uniform scalars fill every group to within a few per cent of n*W/G, so a region holds 1.25x that; a region that would overflow raises the same flag as before
-// and the host repeats the MSM on the two-pass path (any input stays correct).  With every bucket holding lambda +- 3 sqrt(lambda) entries there is also no need
-// for a task plan: each bucket is cut into equal slices (k_msm_accumulate_slices; how many: msm_impl.hpp, h_slices), whose partial sums one quad adds up (k_msm_combine_slices).
+//                  final place inside the group's region of the output (a 64 KB window that lives in this XCD's L2 while it is written).  Emits counts[] / offsets[]
+//                  and the number of entries of the group.  The entries keep their low bucket bits: k_hacc_runs29 finds the bucket boundaries by them.
+// Uniform scalars fill every group to within a few per cent of n*W/G, so a region holds 1.25x that; a region that would overflow raises a flag and the host repeats
+// the MSM on the two-pass path (any input stays correct).
 constexpr uint32_t HSORT_GROUPS = 1024 /* at most; the shape says how many are used */, HSORT_BIN_THREADS = 256, HSORT_PER_THREAD = 2, HSORT_TILE = HSORT_BIN_THREADS * HSORT_PER_THREAD, HSORT_GROUP_THREADS = 512, HSORT_MAX_PER_THREAD = 48, HSORT_SLICES = 8, HSORT_STAGE_W = 20 /* staged entries per scalar: at most 254 / c + 1 digits, c >= 13 */;
 struct HsortShape { uint32_t groups, low_bits, idx_bits, region; };     // groups * 2^low_bits = buckets; bucket = group << low_bits | low; entry = low << (idx_bits + 1) | sign << idx_bits | index; region: entry slots per group
 template <int C>
@@ -181,7 +135,7 @@ __global__ void __launch_bounds__(HSORT_BIN_THREADS) k_hsort_bin(const Fr *__res
     if (live[q]) { Fr v = scalars[i]; if (mul_b) v = v * mul_b[i] * mul_z[z_is_table ? i : 0]; k[q] = v.from_mont(); live[q] = !k[q].is_zero(); } }
   const uint32_t low_mask = (1u << sh.low_bits) - 1;
 #pragma unroll
-  for (int q = 0; q < (int)HSORT_PER_THREAD; q++) if (live[q]) msm_walk_digits<C>(k[q].l, c, W, 0, [&](int, int, int d) { if (d) atomicAdd(&lcnt[((uint32_t)(d < 0 ? -d : d) - 1) >> sh.low_bits], 1u); });
+  for (int q = 0; q < (int)HSORT_PER_THREAD; q++) if (live[q]) msm_walk_digits<C>(k[q].l, c, W, [&](int, int d) { if (d) atomicAdd(&lcnt[((uint32_t)(d < 0 ? -d : d) - 1) >> sh.low_bits], 1u); });
   __syncthreads();
   // exclusive scan of the group counts (where each group's run starts in the staging tile) and the reservation of the runs in the groups' regions
   { uint32_t s = 0; const uint32_t per = (sh.groups + HSORT_BIN_THREADS - 1) / HSORT_BIN_THREADS, lo = threadIdx.x * per; for (uint32_t j = 0; j < per; j++) if (lo + j < sh.groups) s += lcnt[lo + j];
@@ -197,7 +151,7 @@ __global__ void __launch_bounds__(HSORT_BIN_THREADS) k_hsort_bin(const Fr *__res
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < (int)HSORT_PER_THREAD; q++) if (live[q]) { const uint32_t i = blockIdx.x * HSORT_TILE + q * HSORT_BIN_THREADS + threadIdx.x;
-    msm_walk_digits<C>(k[q].l, c, W, 0, [&](int, int w, int d) { if (!d) return; const uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, g = key >> sh.low_bits, p = atomicAdd(&lcnt[g], 1u);
+    msm_walk_digits<C>(k[q].l, c, W, [&](int w, int d) { if (!d) return; const uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, g = key >> sh.low_bits, p = atomicAdd(&lcnt[g], 1u);
       if (p < HSORT_TILE * HSORT_STAGE_W) { stage[p] = ((key & low_mask) << (sh.idx_bits + 1)) | ((d < 0 ? 1u : 0u) << sh.idx_bits) | (i + (uint32_t)w * point_stride); stage_g[p] = (uint16_t)g; } }); }
   __syncthreads();
   // copy-out: consecutive lanes write consecutive words of a group's run (about 128 bytes per group and workgroup) instead of one isolated word per digit
@@ -205,9 +159,9 @@ __global__ void __launch_bounds__(HSORT_BIN_THREADS) k_hsort_bin(const Fr *__res
   for (uint32_t p = threadIdx.x; p < total; p += blockDim.x) { const uint32_t g = stage_g[p], pos = gbase[g] + (p - lpos[g]); if (pos < sh.region) mid[(size_t)g * sh.region + pos] = stage[p]; }
 }
 static __global__ void __launch_bounds__(HSORT_GROUP_THREADS) k_hsort_group(const uint32_t *__restrict__ mid, uint32_t *__restrict__ group_fill, HsortShape sh, uint32_t *__restrict__ entries, uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets,
-                                                                            uint32_t *__restrict__ group_n, int keep_low) {   // keep_low: entries stay in the staging format (low bucket bits | sign | index) — what k_hacc_runs walks; group_n[g] = entries of group g
+                                                                            uint32_t *__restrict__ group_n) {   // group_n[g] = entries of group g
   __shared__ uint32_t lcnt[1024], lpre[1024];                        // 2^low_bits <= 1024 buckets per group
-  const uint32_t g = blockIdx.x, nb = 1u << sh.low_bits, n_g = min(group_fill[g], sh.region), idx_mask = (1u << sh.idx_bits) - 1; const uint32_t *src = mid + (size_t)g * sh.region;
+  const uint32_t g = blockIdx.x, nb = 1u << sh.low_bits, n_g = min(group_fill[g], sh.region); const uint32_t *src = mid + (size_t)g * sh.region;
   for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lcnt[b] = 0;
   __syncthreads();
   if (threadIdx.x == 0) { group_fill[g] = 0; group_n[g] = n_g; }     // (read above by every thread of this workgroup only, before the barrier) cleared for the next run
@@ -224,7 +178,7 @@ static __global__ void __launch_bounds__(HSORT_GROUP_THREADS) k_hsort_group(cons
   __syncthreads();
   uint32_t *dst = entries + (size_t)g * sh.region;
 #pragma unroll
-  for (int j = 0; j < (int)HSORT_MAX_PER_THREAD; j++) if (j < ne) { const uint32_t v = e[j], b = v >> (sh.idx_bits + 1), r = atomicAdd(&lcnt[b], 1u); dst[lpre[b] + r] = keep_low ? v : (v & idx_mask) | (((v >> sh.idx_bits) & 1u) ? MSM_ENTRY_SIGN : 0u); }
+  for (int j = 0; j < (int)HSORT_MAX_PER_THREAD; j++) if (j < ne) { const uint32_t v = e[j], b = v >> (sh.idx_bits + 1), r = atomicAdd(&lcnt[b], 1u); dst[lpre[b] + r] = v; }
 }
 
 static __global__ void k_fr_mul3(const Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ z, int z_is_table, uint32_t n, Fr *__restrict__ out) {
@@ -323,120 +277,34 @@ static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_small(const ui
 // task_off: exclusive scan of ntasks over the SORTED bucket list (n_buckets + 1 entries, the last one = total)
 template <class F>
 __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
-                                                              const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, uint32_t n_buckets, uint32_t max_tasks, uint32_t task, const F *__restrict__ beta, XYZZ<F> *__restrict__ buckets, XYZZ<F> *__restrict__ partials) {
+                                                              const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, uint32_t n_buckets, uint32_t max_tasks, uint32_t task, XYZZ<F> *__restrict__ buckets, XYZZ<F> *__restrict__ partials) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= max_tasks || t >= task_off[n_buckets]) return;
   uint32_t lo = 0, hi = n_buckets;                         // largest i with task_off[i] <= t
   while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (task_off[mid] <= t) lo = mid; else hi = mid; }
   uint32_t b = order[lo], j = t - task_off[lo], cnt = counts[b], beg = offsets[b] + j * task, end = offsets[b] + min(cnt, (j + 1) * task);
   XYZZ<F> acc = XYZZ<F>::inf();
-  const uint32_t imask = beta ? ~(MSM_ENTRY_SIGN | MSM_ENTRY_PHI) : ~MSM_ENTRY_SIGN; F bt = F::zero(); if (beta) bt = *beta;
+  const uint32_t imask = ~MSM_ENTRY_SIGN;
   uint32_t v = entries[beg], vn = beg + 1 < end ? entries[beg + 1] : v; Affine<F> p = points[v & imask];   // (beg < end: tasks exist only for non-empty slices)
 #pragma unroll 1
   for (uint32_t e = beg; e < end; e++) {                 // software pipeline: the next point and the entry after it are in flight while this point is added (random table gathers)
     Affine<F> pn = points[vn & imask]; uint32_t vnn = e + 2 < end ? entries[e + 2] : vn;
-    if (beta && (v & MSM_ENTRY_PHI)) p.x = p.x * bt;     // second GLV half: lambda*(x, y) = (beta*x, y)
     if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; vn = vnn; }
   if (cnt <= task) buckets[b] = acc; else partials[t] = acc;
 }
-// The same accumulation for the group-sorted H query: no plan, lane t takes slice t % S of bucket t / S — the entries [cnt*j/S, cnt*(j+1)/S) of the bucket.  With
-// uniform scalars every slice of a wave is within an entry or two of the same length.
-// point gathers of the accumulation kernels: every table entry is read once per MSM, so the loads are marked non-temporal (VARIANT & 1) — they should not evict the
-// sorted entries and partial sums from the L2
-template <int NT, class F> __device__ __forceinline__ Affine<F> load_point(const Affine<F> *p) {
-  if constexpr (NT) { typedef uint32_t v4u __attribute__((ext_vector_type(4))); Affine<F> r; const uint32_t *s = reinterpret_cast<const uint32_t *>(p); uint32_t *d = reinterpret_cast<uint32_t *>(&r);
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(Affine<F>) / 16; i++) { v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(s) + i); d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w; } return r; }
-  else return *p;
-}
-template <int VARIANT, class F>
-__global__ void __launch_bounds__(256) k_msm_accumulate_slices(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
-                                                               uint32_t n_buckets, uint32_t slices, XYZZ<F> *__restrict__ partials) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; if (t >= n_buckets * slices) return;
-  const uint32_t b = t / slices, j = t - b * slices, cnt = counts[b], beg = offsets[b] + (cnt * j) / slices, end = offsets[b] + (cnt * (j + 1)) / slices;
-  XYZZ<F> acc = XYZZ<F>::inf(); constexpr int NT = VARIANT & 1;
-  if (beg < end) {
-    if constexpr (VARIANT & 2) {                             // two points in flight
-      uint32_t v0 = entries[beg], v1 = beg + 1 < end ? entries[beg + 1] : v0, v2 = beg + 2 < end ? entries[beg + 2] : v1; Affine<F> p0 = load_point<NT>(points + (v0 & ~MSM_ENTRY_SIGN)), p1 = load_point<NT>(points + (v1 & ~MSM_ENTRY_SIGN));
-#pragma unroll 1
-      for (uint32_t e = beg; e < end; e++) { Affine<F> p2 = load_point<NT>(points + (v2 & ~MSM_ENTRY_SIGN)); uint32_t v3 = e + 3 < end ? entries[e + 3] : v2;
-        if (v0 >> 31) p0.y = p0.y.neg(); acc.madd_inl(p0); v0 = v1; p0 = p1; v1 = v2; p1 = p2; v2 = v3; }
-    } else {
-      uint32_t v = entries[beg], vn = beg + 1 < end ? entries[beg + 1] : v; Affine<F> p = load_point<NT>(points + (v & ~MSM_ENTRY_SIGN));
-#pragma unroll 1
-      for (uint32_t e = beg; e < end; e++) {                 // software pipeline as in k_msm_accumulate_tasks
-        Affine<F> pn = load_point<NT>(points + (vn & ~MSM_ENTRY_SIGN)); uint32_t vnn = e + 2 < end ? entries[e + 2] : vn;
-        if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; vn = vnn; } } }
-  partials[t] = acc;
-}
-template <class F>
-__global__ void __launch_bounds__(256) k_msm_combine_slices(const XYZZ<F> *__restrict__ partials, uint32_t n_buckets, uint32_t slices, uint32_t lq, XYZZ<F> *__restrict__ buckets) {
-  // 2^lq quads per bucket (slices divisible by it): each adds its share of the bucket's partial sums serially, then lq shuffle levels
-  const uint32_t per = slices >> lq, q = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, b = q >> lq, sub = q & ((1u << lq) - 1); const int k = threadIdx.x & 3;
-  const bool live = b < n_buckets; const XYZZ<F> *src = partials + (size_t)(live ? b : 0) * slices + sub * per; XYZZ<F> acc = src[0], nxt = per > 1 ? src[1] : acc;
-#pragma unroll 1
-  for (uint32_t j = 1; j < per; j++) { XYZZ<F> cur = nxt; if (j + 1 < per) nxt = src[j + 1]; acc = quad_add(acc, cur, k); }
-#pragma unroll 1
-  for (uint32_t d = (1u << lq) >> 1; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if (sub + d < (1u << lq)) acc = quad_add(acc, o, k); }   // (the quads of a bucket are neighbours in one wave: 2^lq <= 16)
-  if (live && sub == 0 && k == 0) buckets[b] = acc;
-}
-// ---- H query accumulation over fixed-length runs (round 3) ---------------------------------------------------------------------------------------------------------
-// k_msm_accumulate_slices above cuts every bucket into the same NUMBER of slices; bucket sizes are Poisson (128 +- 11 for send), so the 64 lanes of a wave hold slices of
-// different lengths and the wave runs for the longest (+12 % measured).  Here a lane takes a RUN of `run` consecutive entries of its group's sorted list, wherever the
-// bucket boundaries fall: every lane of the chip does the same number of additions.  The entries keep their low bucket bits (k_hsort_group, keep_low), so a lane sees a
-// boundary as a change of those bits: it stores the sum so far as piece (this run - the bucket's first run) of the old bucket, and starts over.  Bucket b's pieces sit at
-// partials[b * maxp + 0 .. np): no plan, no atomics; a bucket with more than maxp pieces (non-uniform scalars) raises the overflow flag of the one-pass sort and the host
-// repeats the MSM on the two-pass path.  The additions run in the lazy domain (curve.cuh: madd_lazy; field.cuh), the infinity flag beside the accumulator; pieces are
-// stored as they are, in [0, 2p) — k_hacc_combine normalizes what it loads.
-template <class F> __device__ __forceinline__ void hacc_flush(const XYZZ<F> &acc, bool inf, uint32_t bucket, uint32_t t, uint32_t g, const uint32_t *__restrict__ offsets, const HsortShape &sh, uint32_t run, uint32_t maxp, XYZZ<F> *__restrict__ partials, MsmCounters *cnt) {
-  const uint32_t piece = t - (offsets[bucket] - g * sh.region) / run;
-  if (piece >= maxp) { atomicOr(&cnt->pad[0], 1u); return; }
-  XYZZ<F> *dst = partials + (size_t)bucket * maxp + piece;
-  if (inf) *dst = XYZZ<F>::inf(); else *dst = acc;
-}
-// The grid is one-dimensional over the runs of all groups: every workgroup scans the groups' run counts in LDS (at most 1024 of them) and finds its lanes' (group, run)
-// pairs itself.  A grid of groups x (region / run) left a third of the workgroups without work, and the dispatcher — which cannot tell them apart — then gave some CUs
-// five working workgroups and others three: 0.46 ms instead of 0.34 for the same additions (profiles/r03a_ab_hacc.txt).
-template <int ANY_INF, class F>
-__global__ void __launch_bounds__(256) k_hacc_runs(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ group_n, const uint32_t *__restrict__ offsets, HsortShape sh, uint32_t run, uint32_t maxp,
-                                                   XYZZ<F> *__restrict__ partials, MsmCounters *cnt) {
-  __shared__ uint32_t base[HSORT_GROUPS + 1], wave_tot[4];
-  { const uint32_t per = (sh.groups + 255) / 256, lo = threadIdx.x * per; uint32_t s = 0;                       // exclusive scan of ceil(n_g / run) over the groups
-    for (uint32_t j = 0; j < per; j++) if (lo + j < sh.groups) s += (min(group_n[lo + j], sh.region) + run - 1) / run;
-    uint32_t inc = s; for (int d = 1; d < 64; d <<= 1) { uint32_t u = __shfl_up(inc, d, 64); if ((int)(threadIdx.x & 63) >= d) inc += u; }
-    if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    uint32_t ex = inc - s; for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) ex += wave_tot[wv];
-    for (uint32_t j = 0; j < per; j++) if (lo + j < sh.groups) { base[lo + j] = ex; ex += (min(group_n[lo + j], sh.region) + run - 1) / run; }
-    if (threadIdx.x == 255) base[sh.groups] = ex;
-    __syncthreads(); }
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= base[sh.groups]) return;
-  uint32_t glo = 0, ghi = sh.groups; while (ghi - glo > 1) { const uint32_t mid = (glo + ghi) >> 1; if (base[mid] <= r) glo = mid; else ghi = mid; }   // the group g with base[g] <= r < base[g + 1]
-  const uint32_t g = glo, t = r - base[g], n_g = min(group_n[g], sh.region), beg = t * run;
-  const uint32_t end = min(beg + run, n_g), idx_mask = (1u << sh.idx_bits) - 1, shift = sh.idx_bits + 1; const uint32_t *e = entries + (size_t)g * sh.region;
-  uint32_t v = e[beg], vn = beg + 1 < end ? e[beg + 1] : v; Affine<F> p = points[v & idx_mask];
-  uint32_t cur = v >> shift; bool inf = true; XYZZ<F> acc = XYZZ<F>::inf();
-#pragma unroll 1
-  for (uint32_t i = beg; i < end; i++) {                   // software pipeline: the next point and the entry after it are in flight while this point is added (random table gathers)
-    Affine<F> pn = points[vn & idx_mask]; const uint32_t vnn = i + 2 < end ? e[i + 2] : vn;
-    const uint32_t low = v >> shift;
-    if (low != cur) { hacc_flush(acc, inf, (g << sh.low_bits) | cur, t, g, offsets, sh, run, maxp, partials, cnt); cur = low; inf = true; }
-    F py = p.y; F::neg_masked(py, 0u - ((v >> sh.idx_bits) & 1u));
-    if (ANY_INF && p.is_inf()) { }                         // a key point at infinity adds nothing
-    else if (inf) { acc.X = p.x; acc.Y = py; acc.ZZ = F::one(); acc.ZZZ = F::one(); inf = false; }
-    else if (!acc.madd_lazy(p.x, py)) atomicOr(&cnt->pad[0], 1u);   // operand = +-acc (a key with repeated points; never for random ones): the complete formulas are not in this loop — they would cost it a wave
-                                                                     // of occupancy in registers — so the MSM is repeated on the general path, like after an overflow of the sort
-    v = vn; p = pn; vn = vnn;
-  }
-  hacc_flush(acc, inf, (g << sh.low_bits) | cur, t, g, offsets, sh, run, maxp, partials, cnt);
-}
-// ---- the same accumulation on nine 29-bit limbs ---------------------------------------------------------------------------------------------------------------
-// v_addc_co_u32 / v_subb_co_u32 issue at the rate of v_mad_u64_u32 on gfx950 (tools/valu_probe.hip: 32 T lane-ops/s, v_add_u32 61 T), so in k_hacc_runs the carry
-// additions cost as much as the multiplications: 12.3 k issue cycles per mixed addition, which is what the kernel measures (0.38 ms for 3.8 M additions).  On 29-bit limbs
+// ---- H query accumulation over fixed-length runs, on nine 29-bit limbs (round 3) ---------------------------------------------------------------------------------
+// Round 2 cut every bucket into the same NUMBER of slices; bucket sizes are Poisson (128 +- 11 for send), so the 64 lanes of a wave held slices of different lengths
+// and the wave ran for the longest.  Here a lane takes a RUN of `run` consecutive entries of its group's sorted list, wherever the bucket boundaries fall: every lane of
+// the chip does the same number of additions.  A lane sees a boundary as a change of the entries' low bucket bits: it stores the sum so far as piece (this run - the
+// bucket's first run) of the old bucket, and starts over.  Bucket b's pieces sit at partials[b * maxp + 0 .. np): no plan, no atomics; a bucket with more than maxp
+// pieces (non-uniform scalars) raises the overflow flag of the one-pass sort and the host repeats the MSM on the two-pass path.
+// v_addc_co_u32 / v_subb_co_u32 issue at the rate of v_mad_u64_u32 on gfx950 (tools/valu_probe.hip: 32 T lane-ops/s, v_add_u32 61 T), so the carry
+// additions of a product on 8 x 32-bit limbs cost as much as its multiplications: the 32-bit form of this loop measured 12.3 k cycles per mixed addition (0.38 ms).  On 29-bit limbs
 // (field29_gfx950.inc: Montgomery radix 2^261) a product is 162 v_mad_u64_u32 and NO carry instruction, a difference nine 32-bit operations and a parallel carry step.
 // The table this kernel gathers from holds the same points as the fixed-base table with coordinates x * 2^261 instead of x * 2^256 (k_table_to_r261 at key load: one
-// product per coordinate; canonical, 8 words each, so the record size and the gather pattern do not change); limbs are unpacked after the load.  A piece is converted
-// back (one product per coordinate with 2^256 mod p) when it is stored, so everything downstream sees the lazy 8 x 32-bit form it saw before.  Operand = +-accumulator
-// (P = 0) is not looked for in the loop: it leaves ZZ = 0 (mod p) for good, which the store notices and reports like an overflow of the sort.
+// product per coordinate; canonical, 8 words each, so the record size and the gather pattern do not change); limbs are unpacked after the load.  A piece is stored as
+// its 36 limbs; k_hacc_combine29 adds a bucket's pieces on 29-bit limbs too and converts the sum (one product per coordinate with 2^256 mod p) to the 8 x 32-bit form
+// the weighted bucket sum reads.  Operand = +-accumulator (P = 0) is not looked for in the loop: it leaves ZZ = 0 (mod p) for good, which the combine notices and
+// reports like an overflow of the sort.
 #include "field29_gfx950.inc"
 struct XYZZ29 { Fq29 X, Y, ZZ, ZZZ;
   // madd-2008-s in two steps, so that the caller can start the NEXT point's gather between them, into the registers this point's coordinates just left (its words are
@@ -487,7 +355,7 @@ template <int ANY_INF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_hacc_runs29(const Affine<Fq> *__restrict__ points261, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ group_n, const uint32_t *__restrict__ offsets, HsortShape sh, uint32_t run, uint32_t maxp,
                                                      Piece29 *__restrict__ partials, MsmCounters *cnt) {
   __shared__ uint32_t base[HSORT_GROUPS + 1], wave_tot[4];
-  { const uint32_t per = (sh.groups + 255) / 256, lo = threadIdx.x * per; uint32_t s = 0;                       // exclusive scan of ceil(n_g / run) over the groups (as in k_hacc_runs)
+  { const uint32_t per = (sh.groups + 255) / 256, lo = threadIdx.x * per; uint32_t s = 0;                       // exclusive scan of ceil(n_g / run) over the groups 
     for (uint32_t j = 0; j < per; j++) if (lo + j < sh.groups) s += (min(group_n[lo + j], sh.region) + run - 1) / run;
     uint32_t inc = s; for (int d = 1; d < 64; d <<= 1) { uint32_t u = __shfl_up(inc, d, 64); if ((int)(threadIdx.x & 63) >= d) inc += u; }
     if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = inc;
@@ -545,20 +413,6 @@ static __global__ void k_table_to_r261(const Affine<Fq> *__restrict__ in, Affine
   for (int j = 0; j < 8; j++) c.l[j] = FQ_TWO261[j];
   const Affine<Fq> p = in[i]; out[i] = {p.x * c, p.y * c};
 }
-// bucket b = the sum of its pieces: 2^ll neighbouring lanes share them (lane-serial additions, ll shuffle levels); an empty bucket becomes the point at infinity
-template <class F> __device__ __forceinline__ XYZZ<F> xyzz_normalize(const XYZZ<F> &a) { return {a.X.normalize(), a.Y.normalize(), a.ZZ.normalize(), a.ZZZ.normalize()}; }
-template <class F>
-__global__ void __launch_bounds__(256) k_hacc_combine(const XYZZ<F> *__restrict__ partials, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts, HsortShape sh, uint32_t run, uint32_t maxp, uint32_t n_buckets, uint32_t ll, XYZZ<F> *__restrict__ buckets) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = t >> ll, sub = t & ((1u << ll) - 1), step = 1u << ll; const bool live = b < n_buckets; uint32_t np = 0;
-  if (live) { const uint32_t cnt = counts[b], off = offsets[b] - (b >> sh.low_bits) * sh.region; if (cnt) np = min((off + cnt - 1) / run - off / run + 1, maxp); }
-  const XYZZ<F> *src = partials + (size_t)(live ? b : 0) * maxp; XYZZ<F> acc = XYZZ<F>::inf();
-  if (sub < np) { XYZZ<F> nxt = src[sub];
-#pragma unroll 1
-    for (uint32_t j = sub; j < np; j += step) { XYZZ<F> cur = xyzz_normalize(nxt); if (j + step < np) nxt = src[j + step]; acc.add_inl(cur); } }
-#pragma unroll 1
-  for (uint32_t d = step >> 1; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); if (sub + d < step) acc.add_inl(o); }
-  if (live && sub == 0) buckets[b] = acc;
-}
 // ---- sums by the 64 quads of a 256-thread workgroup ------------------------------------------------------------------------
 // quad q adds elements q, q+64, ...; then a tree over the 16 quads of each wave (shuffles) and over the 4 waves (LDS).  The result is valid in lanes 0..3.
 // tree over the 64 quads of a 256-thread workgroup: 16 quads per wave by shuffles, the 4 waves through LDS.  Every quad brings `acc`; the sum is valid in lanes 0..3.
@@ -580,39 +434,6 @@ template <class F> __device__ __forceinline__ XYZZ<F> block_quad_sum(const XYZZ<
 #pragma unroll 1
     for (uint32_t j = q; j < len; j += 64) { XYZZ<F> cur = nxt; if (j + 64 < len) nxt = src[j + 64]; acc = quad_add(acc, cur, k); } }
   return block_quad_tree(acc, lds, min(len, 64u));
-}
-
-// The same combine with plain lanes: 2^ll lanes per bucket (neighbours in a wave) add slices / 2^ll partial sums each with the lane-serial addition (14 products,
-// none of the quad form's exchange instructions), then ll shuffle levels.  Fewer issue slots than one quad per bucket adding all of them; the chain is about as long.
-template <class F>
-__global__ void __launch_bounds__(256) k_msm_combine_lanes(const XYZZ<F> *__restrict__ partials, uint32_t n_buckets, uint32_t slices, uint32_t ll, XYZZ<F> *__restrict__ buckets) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = t >> ll, sub = t & ((1u << ll) - 1), per = slices >> ll; const bool live = b < n_buckets;
-  const XYZZ<F> *src = partials + (size_t)(live ? b : 0) * slices + sub * per; XYZZ<F> acc = src[0], nxt = per > 1 ? src[1] : acc;
-#pragma unroll 1
-  for (uint32_t j = 1; j < per; j++) { XYZZ<F> cur = nxt; if (j + 1 < per) nxt = src[j + 1]; acc.add_inl(cur); }
-#pragma unroll 1
-  for (uint32_t d = (1u << ll) >> 1; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, d); if (sub + d < (1u << ll)) acc.add_inl(o); }
-  if (live && sub == 0) buckets[b] = acc;
-}
-
-// buckets that were cut into several tasks: add up the partial sums.  Buckets are ranked by decreasing size (order[], cls_start[]).  One quad per bucket adds up
-// to COMBINE_QUAD_MAX partials serially (with precomputed tables every bucket of the H query holds ~8 of them); buckets with more get a whole workgroup each
-// (the first `heavy_blocks` workgroups walk the ranks of the fullest size class and pick those).
-// Planning for the one-pass sort in ONE single-workgroup launch: with uniform scalars every bucket holds about the same number of entries, so the size ordering
-// is pointless (order = identity); counts are clipped to the slot capacity, task_off = exclusive scan of the task counts, empty buckets are set to infinity.
-// cls_start[] = n_buckets for every class: the combine kernel then looks at every bucket's task count itself.
-constexpr uint32_t PLAN_DIRECT_MAX = 32768;    // task counts of all buckets are staged in LDS as bytes (clip <= 4080 entries, i.e. at most 255 tasks per bucket)
-static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_direct(uint32_t *__restrict__ counts, uint32_t n_buckets, uint32_t clip, uint32_t task, uint32_t *__restrict__ task_off, uint32_t *__restrict__ cls_start) {
-  __shared__ uint32_t sh[PLAN_THREADS]; __shared__ uint8_t nt_lds[PLAN_DIRECT_MAX];
-  // (order / rank_of are the identity in this mode and were written once by the host; an empty bucket is set to infinity by the combine kernel)
-  for (uint32_t b = threadIdx.x; b < n_buckets; b += PLAN_THREADS) { uint32_t cnt = counts[b]; if (cnt > clip) { cnt = clip; counts[b] = cnt; } nt_lds[b] = (uint8_t)((cnt + task - 1) / task); }   // coalesced pass over the buckets
-  __syncthreads();
-  const uint32_t per = (n_buckets + PLAN_THREADS - 1) / PLAN_THREADS, lo = threadIdx.x * per; uint32_t s = 0, total;
-  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) s += nt_lds[lo + j];
-  uint32_t ex = block_exclusive_scan_1024(s, sh, &total);
-  for (uint32_t j = 0; j < per; j++) if (lo + j < n_buckets) { task_off[lo + j] = ex; ex += nt_lds[lo + j]; }
-  if (threadIdx.x == 0) task_off[n_buckets] = total;
-  if (threadIdx.x < BSORT_CLASSES) cls_start[threadIdx.x] = n_buckets;
 }
 
 constexpr uint32_t COMBINE_QUAD_MAX = 24;
@@ -670,47 +491,6 @@ __global__ void __launch_bounds__(256) k_msm_sum_ones(const Affine<F> *__restric
   if (k == 0) partial[t] = acc;
 }
 
-// ---- witness MSMs without buckets -------------------------------------------------------------------------------------------
-// 97 % of a BlockMaze assignment is 0 or 1 and most of the rest are 32-bit words (7,574 of 227,047 scalars of the send circuit are neither, with 36 K
-// non-zero 8-bit digits between them).  Pippenger's machinery — histogram, plan, counting sort, bucket accumulation, combine, weighted bucket reduction, six launches
-// of mostly dependent additions — is the wrong tool for that: with the fixed-base table T[w][i] = 2^(cw) P_i resident, every non-zero digit d of a scalar is simply one
-// more term d * T[w][i] of a plain point sum.  So:
-//   k_wmsm_classify   one pass over the scalars: indices of the ones and (table index, digit) pairs of everything else, both appended with one atomic per wave
-//   k_wmsm_sum        one quad per strided share of both lists: small multiples by double-and-add (at most c - 1 doublings), mixed additions for the ones, then the
-//                     workgroup's tree; one partial sum per workgroup
-//   k_xyzz_group_sum  the partial sums
-// The same group element as multi_exp_with_mixed_addition (multiexp.tcc:443-496) computes, with chains of ~25 dependent additions instead of ~150.
-template <int C>
-__global__ void __launch_bounds__(256) k_wmsm_classify(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf, uint32_t n, int c, int W, uint32_t point_stride,
-                                                       uint32_t *__restrict__ ones, uint2 *__restrict__ others, uint32_t others_cap, MsmCounters *cnt, MsmCounters *cnt_next) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *cnt_next = MsmCounters{0, 0, {0, 0}};
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63; bool live = i < n && !(point_is_inf && point_is_inf[i]); Fr k = Fr::zero();
-  if (live) { k = scalars[scalar_index ? scalar_index[i] : i].from_mont(); live = !k.is_zero(); }
-  bool is_one = false; if (live) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; is_one = o == 0; }
-  { uint64_t m = __ballot(is_one); if (m) { uint32_t base = 0; const int first = __ffsll((long long)m) - 1; if ((int)lane == first) base = atomicAdd(&cnt->n_ones, (uint32_t)__popcll(m));
-      base = __shfl(base, first, 64); if (is_one) ones[base + __popcll(m & ((1ull << lane) - 1))] = i; } }
-  const bool other = live && !is_one; uint32_t nd = 0;
-  if (other) msm_walk_digits<C>(k.l, c, W, 0, [&](int, int, int d) { nd += d != 0; });
-  if (__ballot(other)) {                                               // wave-level exclusive scan of the digit counts, one atomic for the whole wave
-    uint32_t inc = nd; for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += t; }
-    const uint32_t total = __shfl(inc, 63, 64); uint32_t base = 0; if (lane == 63) base = atomicAdd(&cnt->n_other, total); base = __shfl(base, 63, 64);
-    uint32_t pos = base + inc - nd;
-    if (other) msm_walk_digits<C>(k.l, c, W, 0, [&](int, int w, int d) { if (!d) return; if (pos < others_cap) others[pos] = make_uint2(i + (uint32_t)w * point_stride, (uint32_t)(d < 0 ? -d : d) | (d < 0 ? 0x80000000u : 0u)); else atomicOr(&cnt->pad[0], 1u); pos++; });
-  }
-}
-template <class F>
-__global__ void __launch_bounds__(256) k_wmsm_sum(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ ones, const uint2 *__restrict__ others, uint32_t others_cap, const MsmCounters *cnt, uint32_t n_quads, XYZZ<F> *__restrict__ partial) {
-  __shared__ XYZZ<F> lds[4];
-  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; const int k = threadIdx.x & 3; const uint32_t n1 = cnt->n_ones, n2 = min(cnt->n_other, others_cap); XYZZ<F> acc = XYZZ<F>::inf();
-#pragma unroll 1
-  for (uint32_t j = t; j < n2; j += n_quads) { const uint2 e = others[j]; Affine<F> p = points[e.x]; if (e.y >> 31) p.y = p.y.neg(); acc = quad_add(acc, quad_mul_small_affine(p, e.y & 0x7fffffffu, k), k); }
-  if (t < n1) { Affine<F> nxt = points[ones[t]];
-#pragma unroll 1
-    for (uint32_t j = t; j < n1; j += n_quads) { Affine<F> cur = nxt; if (j + n_quads < n1) nxt = points[ones[j + n_quads]]; acc = quad_madd(acc, cur, k); } }   // the next point's gather is in flight during the addition
-  acc = block_quad_tree(acc, lds);
-  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
-}
-
 // ---- witness MSMs in three launches -----------------------------------------------------------------------------------------
 // Measured with several proofs in flight (tools/inflight_probe.py): the four witness MSMs — 5 % of a proof's field products — took as much of the machine as the H query,
 // because the general path above spends ten launches of tiny, dependent kernels on each of them (classify, plan, scatter, accumulate, combine, reduce, three tree
@@ -737,11 +517,11 @@ __global__ void __launch_bounds__(256) k_wsort(const Fr *__restrict__ scalars, c
   { uint64_t m = __ballot(is_one); if (m) { uint32_t base = 0; const int first = __ffsll((long long)m) - 1; if ((int)lane == first) base = atomicAdd(&cnt->n_ones, (uint32_t)__popcll(m));
       base = __shfl(base, first, 64); if (is_one) ones[base + __popcll(m & ((1ull << lane) - 1))] = i; } }
   const bool other = live && !is_one;
-  if (other) msm_walk_digits<C>(k.l, c, W, 0, [&](int, int, int d) { if (d) atomicAdd(&lcnt[(uint32_t)(d < 0 ? -d : d) - 1], 1u); });
+  if (other) msm_walk_digits<C>(k.l, c, W, [&](int, int d) { if (d) atomicAdd(&lcnt[(uint32_t)(d < 0 ? -d : d) - 1], 1u); });
   __syncthreads();
   if (threadIdx.x < NB) { const uint32_t m = lcnt[threadIdx.x]; uint32_t b = m ? atomicAdd(&fill[threadIdx.x], m) : 0; if (b + m > cap) atomicOr(&cnt->pad[0], 1u); lbase[threadIdx.x] = b; lcnt[threadIdx.x] = 0; }
   __syncthreads();
-  if (other) msm_walk_digits<C>(k.l, c, W, 0, [&](int, int w, int d) { if (!d) return; const uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, pos = lbase[key] + atomicAdd(&lcnt[key], 1u);
+  if (other) msm_walk_digits<C>(k.l, c, W, [&](int w, int d) { if (!d) return; const uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, pos = lbase[key] + atomicAdd(&lcnt[key], 1u);
     if (pos < cap) entries[(size_t)key * cap + pos] = (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u); });
 }
 // k_wacc_lanes + k_wacc_fold replace the first version of k_wacc (one workgroup of 64 quads per bucket, measured: 188 us, every SIMD of the chip busy with quad

@@ -31,7 +31,7 @@ __device__ __forceinline__ Fq2 fin(const Fq2 &v) { return fq2_in(v); }
 __device__ __forceinline__ Fq fout(const Fq &v) { return v.from_mont(); }
 __device__ __forceinline__ Fq2 fout(const Fq2 &v) { return fq2_out(v); }
 template <class F> __device__ __forceinline__ Affine<F> to_affine(const XYZZ<F> &p) { if (p.is_inf()) return Affine<F>::inf(); F zi = p.ZZ.inv(), z3i = p.ZZZ.inv(); return {p.X * zi, p.Y * z3i}; }
-// a, b, out: affine canonical.  OP: 0 add of a point with a non-trivial ZZ, 1 dbl, 2 madd, 3 mul_small, 4 madd in the lazy domain (curve.cuh: madd_lazy; G1 only).
+// a, b, out: affine canonical.  OP: 0 add of a point with a non-trivial ZZ, 1 dbl, 2 madd, 3 mul_small.
 // One kernel per operation: with all of them inlined into one function hipcc 7.2's register allocator crashed (RAGreedy, splitSeparateComponents).
 template <int OP, class F> __global__ void k_probe_group(const Affine<F> *a, const Affine<F> *b, Affine<F> *out, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
@@ -40,11 +40,6 @@ template <int OP, class F> __global__ void k_probe_group(const Affine<F> *a, con
   else if constexpr (OP == 1) { acc = acc.dbl_inl().dbl_inl(); acc.add_inl(XYZZ<F>::from_affine(pa).dbl_inl().neg()); }                                                                  // 4a - 2a = 2a through dbl() of a non-affine point
   else if constexpr (OP == 2) { Affine<F> pb = {fin(b[i].x), fin(b[i].y)}; acc.madd_inl(pb); }
   else if constexpr (OP == 3) { uint32_t k = reinterpret_cast<const uint32_t *>(&b[i])[0]; acc = acc.mul_small(k); }
-  else if constexpr (sizeof(F) == 32) {   // acc = 2a (non-trivial ZZ) + b - b' ... : three lazy additions (b, then -b, then b again) so that values well inside [0, 2p) feed the formulas; P = 0 (b = +-acc) reports infinity
-    Affine<F> pb = {fin(b[i].x), fin(b[i].y)}; acc = acc.dbl_inl(); bool ok = !acc.is_inf() && !pb.is_inf();
-    F ny = pb.y; F::neg_masked(ny, 0xffffffffu);
-    ok = ok && acc.madd_lazy(pb.x, pb.y); ok = ok && acc.madd_lazy(pb.x, ny); ok = ok && acc.madd_lazy(pb.x, pb.y);
-    acc = ok ? XYZZ<F>{acc.X.normalize(), acc.Y.normalize(), acc.ZZ.normalize(), acc.ZZZ.normalize()} : XYZZ<F>::inf(); }
   Affine<F> r = to_affine(acc); out[i] = {fout(r.x), fout(r.y)};
 }
 
@@ -66,7 +61,7 @@ void probe_fq2(int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t 
 template <class F, class A> static void probe_group_t(int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n) {
   unsigned g = (unsigned)((n + 63) / 64); hipStream_t s = gpu_stream();
 #define ZK_PG(OP) run_probe<A>([&](const A *x, const A *y, A *o) { hipLaunchKernelGGL((k_probe_group<OP, F>), dim3(g), dim3(64), 0, s, (const Affine<F> *)x, (const Affine<F> *)y, (Affine<F> *)o, (uint32_t)n); }, (const A *)a, (const A *)b, (A *)out, n)
-  switch (op) { case 0: ZK_PG(0); break; case 1: ZK_PG(1); break; case 2: ZK_PG(2); break; case 3: ZK_PG(3); break; case 4: if (sizeof(F) == 32) { ZK_PG(4); break; } [[fallthrough]]; default: throw GpuError("probe_group: unknown operation"); }
+  switch (op) { case 0: ZK_PG(0); break; case 1: ZK_PG(1); break; case 2: ZK_PG(2); break; case 3: ZK_PG(3); break; default: throw GpuError("probe_group: unknown operation"); }
 #undef ZK_PG
 }
 void probe_group(int group, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n) {

@@ -46,13 +46,13 @@ def fq2_op(op, a, b=None):
     bb = np.ascontiguousarray(b, dtype=np.uint64) if b is not None else None
     _check(lib().zkgpu_test_fq2_op({"mul": 0, "sqr": 1, "inv": 2}[op], _bytes(a), _bytes(bb) if bb is not None else None, _bytes(out), ctypes.c_size_t(n))); return out
 def group_op(group, op, a, b=None):
-    """group 1: (n,8) words, group 2: (n,16) words.  op: add / dbl / madd / mul_small (b = uint32 multipliers) / madd_lazy (G1: 2a + b - b + b through the lazy-domain mixed addition; infinity when b = +-2a)"""
+    """group 1: (n,8) words, group 2: (n,16) words.  op: add / dbl / madd / mul_small (b = uint32 multipliers)"""
     a = np.ascontiguousarray(a, dtype=np.uint64); out = np.zeros_like(a); n = a.shape[0]
     if op == "mul_small":
         bb = np.zeros_like(a); bb[:, 0] = np.asarray(b, dtype=np.uint64)
     else:
         bb = np.ascontiguousarray(b, dtype=np.uint64) if b is not None else None
-    _check(lib().zkgpu_test_group_op(group, {"add": 0, "dbl": 1, "madd": 2, "mul_small": 3, "madd_lazy": 4}[op], _bytes(a), _bytes(bb) if bb is not None else None, _bytes(out), ctypes.c_size_t(n))); return out
+    _check(lib().zkgpu_test_group_op(group, {"add": 0, "dbl": 1, "madd": 2, "mul_small": 3}[op], _bytes(a), _bytes(bb) if bb is not None else None, _bytes(out), ctypes.c_size_t(n))); return out
 
 def msm(group, points, scalars, window_bits=0, filter_ones=False):
     points = np.ascontiguousarray(points, dtype=np.uint64); scalars = np.ascontiguousarray(scalars, dtype=np.uint64); n = scalars.size // 4

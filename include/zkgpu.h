@@ -43,7 +43,7 @@ int zkgpu_test_field_op(int field, int op, const uint8_t *a, const uint8_t *b, u
 /* (field ops 6..9 probe the lazy domain of field.cuh: 6 mul, 7 square, 8 sub on operands pushed towards 2p, 9 masked negation; results normalized) */
 /* op: 0 mul, 1 square(a), 2 inverse(a) on Fq2 (64-byte elements c0 | c1) */
 int zkgpu_test_fq2_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
-/* group: 1 = G1, 2 = G2.  op: 0 general add, 1 double(a), 2 mixed add (b affine), 3 a*k for 32-bit k (k in b's first 4 bytes), 4 (G1) 2a + b - b + b through the lazy-domain mixed addition */
+/* group: 1 = G1, 2 = G2.  op: 0 general add, 1 double(a), 2 mixed add (b affine), 3 a*k for 32-bit k (k in b's first 4 bytes) */
 int zkgpu_test_group_op(int group, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
 
 /* ---- multi-scalar multiplication ------------------------------------------------------------------------------------ */

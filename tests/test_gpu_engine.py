@@ -48,16 +48,6 @@ def test_g1_group_law_matches_oracle():
         assert o.g1_from(add[i])[0] == exp and o.g1_from(madd[i])[0] == exp, i
         assert o.g1_from(dbl[i])[0] == o.g1_op("dbl", p) and o.g1_from(mul[i])[0] == o.g1_op("mul", p, k=ks[i]), i
 
-def test_g1_lazy_mixed_addition_matches_oracle():
-    """curve.cuh madd_lazy (the H query's inner loop): 2a + b - b + b in the lazy domain == 2a + b; operand = +-accumulator is reported, not computed"""
-    n = 64; g = o.SplitMix64(79); P = o.g1_consecutive(g.field(), n); Q = o.g1_consecutive(g.field(), n)
-    Q[3] = o.g1_arr([o.g1_op("dbl", o.g1_from(P[3])[0])])[0]                               # b = 2a: P = 0, R = 0
-    Q[4] = o.g1_arr([o.g1_op("neg", o.g1_op("dbl", o.g1_from(P[4])[0]))])[0]              # b = -2a: P = 0
-    got = e.group_op(1, "madd_lazy", P, Q)
-    for i in range(n):
-        p, q = o.g1_from(P[i])[0], o.g1_from(Q[i])[0]; exp = None if i in (3, 4) else o.g1_op("add", o.g1_op("dbl", p), q)
-        assert o.g1_from(got[i])[0] == exp, i
-
 def test_g2_group_law_matches_oracle():
     n = 16; g = o.SplitMix64(78); P = o.g2_consecutive(g.field(), n); Q = o.g2_consecutive(g.field(), n); Q[3] = P[3]; P[5] = 0
     add = e.group_op(2, "add", P, Q); madd = e.group_op(2, "madd", P, Q); dbl = e.group_op(2, "dbl", P)
@@ -111,17 +101,6 @@ def test_msm_one_pass_sort_and_its_overflow_fallback():
     K = rand_field_arr(4242, n); m.set_scalars(K); assert o.g1_from(m.run())[0] == o.msm_g1(P, K)
     same = o.to_arr([0x1234567 << 40 | 3] * n); m.set_scalars(same); assert o.g1_from(m.run())[0] == o.msm_g1(P, same)          # every digit equal: overflow
     K2 = rand_field_arr(4243, n); m.set_scalars(K2); assert o.g1_from(m.run())[0] == o.msm_g1(P, K2)
-    m.close()
-
-def test_msm_glv_halves_match_oracle():
-    """GLV (k = k1 + k2*lambda, second half on (beta*x, y)) on top of the tables and the one-pass sort: uniform scalars, the edge scalars of the decomposition, and
-    the overflow fallback (which has to decompose the same way on the two-pass path)"""
-    n = 5000; g = o.SplitMix64(91); P = o.g1_consecutive(g.field(), n); P[17] = 0; m = e.ResidentMsm(1, P, 12, filter_ones=2 | 4)
-    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
-    K = rand_field_arr(777, n); edge = [0, 1, 2, o.R_MOD - 1, o.R_MOD - 2, lam, lam + 1, lam - 1, (lam * lam) % o.R_MOD, (o.R_MOD - 1) // 2, 1 << 127, (1 << 128) - 1, 1 << 253]
-    K[:len(edge)] = o.to_arr(edge); m.set_scalars(K); assert o.g1_from(m.run())[0] == o.msm_g1(P, K)
-    same = o.to_arr([lam * 12345 % o.R_MOD] * n); m.set_scalars(same); assert o.g1_from(m.run())[0] == o.msm_g1(P, same)          # every digit equal: overflow -> two-pass path
-    K2 = rand_field_arr(778, n); m.set_scalars(K2); assert o.g1_from(m.run())[0] == o.msm_g1(P, K2)
     m.close()
 
 def test_msm_degenerate_inputs():

@@ -1,7 +1,7 @@
 """GPU parity at the sizes BASELINE.json names, against the ORACLE (not only against properties or the product's own verifier):
   * one G1 multi-exponentiation of 2^18 full-width scalars and one witness-like (0 / 1 / small / full mix) MSM of 227,047 pairs vs liboracle's BDLO12
   * the witness map (R1CS rows + 7 transforms) of the exported send circuit on a real send witness vs liboracle's coefficient vector
-  * every shipped switch (ZK_FOLD_C, ZK_H_LAGRANGE, ZK_MSM_PRECOMPUTE, NTT radix / tile shape, submit threads): same proof bytes as the default
+  * every shipped switch (ZK_FOLD_C, ZK_H_LAGRANGE, ZK_MSM_PRECOMPUTE, ZK_MSM_H_TABLES, NTT radix / tile shape, submit / witness threads, one stream, the overflow hook): same proof bytes as the default
     configuration, on the golden fixtures (bytes of the reference prover) and on the full-size send key
   * BASELINE.json configs[2] / configs[4] shapes: the send circuit and the depth-32 deposit circuit cut into 8 shards (emulated on one GPU), and 64 send instances
     proved against one resident key and decided by the batched verifier."""
@@ -52,7 +52,7 @@ def test_witness_map_of_the_send_circuit_matches_oracle(tmp_path):
     assert got.shape == exp.shape == (262145, 4) and np.array_equal(got, exp)
 
 SWITCHES = [{"ZK_FOLD_C": "0"}, {"ZK_H_LAGRANGE": "0"}, {"ZK_MSM_PRECOMPUTE": "0"}, {"ZK_MSM_H_TABLES": "0"}, {"ZK_NTT_RADIX_LOG": "1"}, {"ZK_NTT_RADIX_LOG": "3"}, {"ZK_NTT_LOGC": "1"},
-            {"ZK_NTT_LOGC": "2", "ZK_NTT_RADIX_LOG": "3"}, {"ZK_SUBMIT_THREADS": "0"}, {"ZK_MSM_SPLIT_ONES": "0"}, {"ZK_WITNESS_MSM_START": "0213"}, {"ZK_MSM_NO_DIRECT_SORT": "1"}, {"ZK_MSM_NO_HSORT": "1"}, {"ZK_MSM_SPARSE": "1"}, {"ZK_MSM_ONE_STREAM": "1"}, {"ZK_MSM_HOST_TAIL": "1", "ZK_MSM_WFUSED": "0"}, {"ZK_MSM_WFUSED": "0"}, {"ZK_MSM_SHARE_SORT": "0"}, {"ZK_B2_FIRST": "0"}, {"ZK_MSM_MAPPED_RESULT": "1"}, {"ZK_MSM_H_SLICES": "8"}, {"ZK_MSM_H_SLICES": "16", "ZK_MSM_H_COMBINE_LQ": "1"}, {"ZK_MSM_WACC": "quads"}, {"ZK_MSM_WACC": "lanes"}, {"ZK_WITNESS_THREADS": "0"}, {"ZK_WITNESS_DENSE": "1"}, {"ZK_MSM_H_BITSUM": "0"}, {"ZK_R1CS_MERGED": "0"}, {"ZK_MSM_H_COMBINE_LANES": "-1"}, {"ZK_MSM_H_COMBINE_LANES": "2"}, {"ZK_MSM_GLV": "1"}]
+            {"ZK_NTT_LOGC": "2", "ZK_NTT_RADIX_LOG": "3"}, {"ZK_SUBMIT_THREADS": "0"}, {"ZK_MSM_ONE_STREAM": "1"}, {"ZK_WITNESS_THREADS": "0"}, {"ZK_WITNESS_DENSE": "1"}, {"ZK_MSM_DIRECT_CAP": "1"}]   # (the last one: the test hook that forces every one-pass sort into its overflow fallback, i.e. the general MSM path)
 PROVE_CODE = """
 import json, os, sys
 sys.path.insert(0, %r)
