@@ -106,16 +106,29 @@ def run_rank(args):
         if backend != "nccl" and torch.cuda.is_available(): torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count())); os.environ["ZK_DEVICE"] = str(local_rank % max(1, torch.cuda.device_count()))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
+    # host budget of a rank: with N ranks on one node every rank gets 1/N of the usable cores, is pinned to them, and sizes the prover's helper threads accordingly
+    # (4 submit threads + a 3-thread witness pool per prover by default: 8 ranks x 8 threads on a 16-core pod would oversubscribe the host inside the timed region)
+    cores = usable_cores(); per_rank = max(1, cores // world)
+    if world > 1:
+        try:
+            mine = sorted(os.sched_getaffinity(0))[:cores][local_rank % world * per_rank:(local_rank % world + 1) * per_rank]
+            if mine: os.sched_setaffinity(0, mine)
+        except Exception: pass
+        if per_rank < 4: os.environ.setdefault("ZK_SUBMIT_THREADS", "0")        # too few cores for helper threads: this rank's one thread submits everything itself
+        os.environ.setdefault("ZK_WITNESS_THREADS", str(max(0, min(3, per_rank - 1))))
     from blockmaze_amd import engine as e
     import workload as w
     hx = lambda a: [("0x" + x.hex()) if isinstance(x, bytes) else x for x in a]
     e.init()                                                                 # raises "no HIP device visible" on a box without a GPU: there is no CPU path to fall back to
 
     # ---- untimed setup: test keys for the send circuit (seeded toxic waste), resident prover, one witness per step -----------------
-    tmp = tempfile.mkdtemp(prefix="zkbench_%d_" % rank); pk_path, vk_path = os.path.join(tmp, "sendpk.txt"), os.path.join(tmp, "sendvk.txt")
-    t0 = time.time(); e.keygen("send", pk_path, vk_path, seed=0xB10C4A2E); t_keygen = time.time() - t0
-    shard = args.shard_msm and world > 1
-    t0 = time.time(); prover = e.Prover(pk_path, rank, world) if shard else e.Prover(pk_path); t_load = time.time() - t0
+    # ONE key for all ranks of the node: rank 0 generates it (and, by loading it first, leaves the fast container beside it); the others wait at the barrier and load that
+    tmp = tempfile.mkdtemp(prefix="zkbench_%d_" % rank); key_dir = tmp if world == 1 else os.path.join(tempfile.gettempdir(), "zkbench_key_%s" % os.environ.get("MASTER_PORT", "0")); os.makedirs(key_dir, exist_ok=True)
+    pk_path, vk_path = os.path.join(key_dir, "sendpk.txt"), os.path.join(key_dir, "sendvk.txt"); shard = args.shard_msm and world > 1; t_keygen = 0.0
+    def load(): return e.Prover(pk_path, rank, world) if shard else e.Prover(pk_path)
+    if rank == 0: t0 = time.time(); e.keygen("send", pk_path, vk_path, seed=0xB10C4A2E); t_keygen = time.time() - t0; t0 = time.time(); prover = load(); t_load = time.time() - t0
+    if dist is not None: dist.barrier()
+    if rank != 0: t0 = time.time(); prover = load(); t_load = time.time() - t0
     n_inst = max(2, min(args.steps + args.warmup, MAX_DISTINCT_WITNESSES)); insts, zs = [], []; wp = os.path.join(tmp, "w.bin")
     for i in range(n_inst):
         d = w.send_instance(i if shard else rank + i * world); e.witness_send(*hx(w.send_args(d)), wp); insts.append(d); zs.append(read_witness(wp))
@@ -143,7 +156,7 @@ def run_rank(args):
     assert last is None or e.verify(vk_path, last, w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]])), "proof from the timed region does not verify"
 
     extra = {}
-    if not shard and not args.no_extra_legs:
+    if world == 1 and not args.no_extra_legs:                      # (N > 1: only the timed region and the roofline leg — the driver's scaling runs pass no flags)
         nx = max(3, min(args.steps, 10))
         # the device pipeline alone: the assignment already resident in HBM (no host hand-over per proof)
         prover.set_witness(zs[0]); prover.prove_resident(); t0 = time.perf_counter()
@@ -200,12 +213,15 @@ def run_rank(args):
     if os.path.exists(pmc):
         try: j = json.load(open(pmc)); traffic = j.get("k_msm_accumulate_H", {}).get("hbm_bytes_per_launch"); traffic_src = "profiles/pmc_summary.json (%s)" % j.get("tag", "untagged")
         except Exception: traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_msm_accumulate_slices<Fq> (H query)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+    roofline = {"bound": "hbm", "kernel": "k_hacc_runs29 (bucket accumulation of the H-query MSM)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": H_PAIRS * BYTES_PER_G1_PAIR}
-    # what actually bounds that kernel: 254-bit field products on the integer VALU.  One mixed addition = 10 products; the H accumulation does one per
-    # non-zero signed 16-bit digit (262,143 scalars x 16 windows, a digit is zero with probability 2^-16); ceiling = tools/fmul_bench.hip on the same chip
-    madds = H_PAIRS * 16 * (1.0 - 2.0 ** -16); gprod = madds * 10 / (dom_ms * 1e-3) / 1e9
-    roofline_valu = {"bound": "valu-int (not part of the contract: the number that tracks this kernel's quality)", "kernel": roofline["kernel"], "achieved": round(gprod, 2), "peak": 126.0, "unit": "G field products/s", "frac": round(gprod / 126.0, 4)}
+    # what actually bounds that kernel: 254-bit field arithmetic on the integer VALU.  A lane lifts the first point of its run of 12 sorted entries and adds the
+    # other 11: one mixed addition = 8 products + 2 squarings on nine 29-bit limbs.  Two ceilings, both measured on this chip: (i) the products alone at the rate of
+    # tools/mul_probe.hip (165 G products/s, 207 G squarings/s chip-wide); (ii) instruction issue: 2,275 VALU instructions per mixed addition (ISA count) at the 4.4 cycles
+    # per wave-instruction and SIMD that mixed integer code sustains (tools/valu_probe.hip), 1,024 SIMDs at 2.1 GHz
+    madds = H_PAIRS * 16 * (1.0 - 2.0 ** -16) * (11.0 / 12.0); t_prod = madds * (8 / 165e9 + 2 / 207e9) * 1e3; t_issue = madds / 64 * 2275 * 4.4 / 1024 / 2.1e9 * 1e3
+    roofline_valu = {"bound": "valu-int (not part of the contract: the figures that track this kernel's quality)", "kernel": roofline["kernel"], "mixed_additions": int(madds), "achieved_ms": round(dom_ms, 4),
+                     "floor_ms_field_products_only": round(t_prod, 4), "frac_of_product_ceiling": round(t_prod / dom_ms, 4), "floor_ms_instruction_issue": round(t_issue, 4), "frac_of_issue_ceiling": round(t_issue / dom_ms, 4)}
 
     # ---- CPU baseline legs (rank 0, N = 1 only): the reference's own code on the host cores -------------------------------
     cpu = None; cpu_more = {}
@@ -215,7 +231,7 @@ def run_rank(args):
             kv = harness_kv(harness, "bench_prover", r1cs_path, w0)
             if "prover_total_s" in kv:
                 cpu = {"value": round(1.0 / float(kv["prover_total_s"]), 5), "unit": "proofs/s", "cores": 1, "kind": "reference",
-                       "sample": "1 send proof by libsnark's r1cs_gg_ppzksnark_prover (oracle/_ref), key of the send circuit's shape with synthetic points; %.2f s" % float(kv["prover_total_s"])}
+                       "sample": "1 send proof by libsnark's r1cs_gg_ppzksnark_prover (oracle/_ref), on a key of the send circuit's shape with synthetic points (timing only); %.2f s" % float(kv["prover_total_s"])}
             if os.path.exists(harness_mt):                                   # the reference's -DMULTICORE build (OpenMP over FFT butterflies and multi_exp chunks) on all host cores
                 ncores = usable_cores(); kv = harness_kv(harness_mt, "bench_prover", r1cs_path, w0, env=dict(os.environ, OMP_NUM_THREADS=str(ncores)))
                 if "prover_total_s" in kv: cpu_more["multicore"] = {"value": round(1.0 / float(kv["prover_total_s"]), 5), "unit": "proofs/s", "cores": int(kv.get("threads", ncores)), "kind": "reference", "sample": "same proof, libsnark built with -DMULTICORE -fopenmp; %.2f s" % float(kv["prover_total_s"])}
@@ -235,7 +251,7 @@ def run_rank(args):
     if rank == 0:
         line = {
             "metric": "Groth16 proofs/sec (send circuit, alt_bn128)", "value": round(rate, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery)", "data": "synthetic",
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery; the H accumulation on nine 29-bit limbs)", "data": "synthetic witnesses (seeded send instances, every constraint satisfied) on a proving key made by this repo's GPU generator for the real send circuit; only the libsnark CPU leg uses a key with synthetic points of the same shape",
             "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "distinct_witnesses": n_inst,
                        "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
                        "includes": "one prover call per step on a fresh HOST-buffer assignment (a different witness every step): hand-over to the device, R1CS rows, the 7 NTTs of the witness map (4 run per proof; both transforms of C and the final inverse are folded into the L and H queries at key load), 5 MSM, host proof assembly, hex serialisation; excludes witness generation and key load"},
