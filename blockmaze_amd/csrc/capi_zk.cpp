@@ -47,40 +47,48 @@ struct ProverUnit { std::shared_ptr<Prover> prover; std::unique_ptr<Circuit> cir
 typedef std::vector<std::shared_ptr<ProverUnit>> UnitList;
 // A reload (the key file's size or mtime changed) never touches the old list: it publishes a NEW one, and the old units die when the last proof running on them lets
 // go of its reference — a caller can therefore never see a destroyed unit or mutex, however the reload interleaves with proofs in flight.
-struct ProverSlot { FileStamp stamp; std::shared_ptr<const UnitList> units; std::atomic<unsigned> next{0}; };
+struct ProverSlot { FileStamp stamp; std::vector<std::shared_ptr<const UnitList>> units /* one list per device slot, built on first use */; std::atomic<unsigned> next{0}; };
 struct VkSlot { FileStamp stamp; std::shared_ptr<PreparedVerifyingKey> vk; std::shared_ptr<BatchVerifier> gpu; };
 std::mutex g_cache_mutex; std::map<std::string, ProverSlot> g_provers; std::map<std::string, VkSlot> g_vks;
 
 std::unique_ptr<Circuit> make_circuit(CircuitKind k, bool emit) {
   switch (k) { case CircuitKind::Mint: return make_mint_circuit(emit); case CircuitKind::Send: return make_send_circuit(emit); case CircuitKind::Redeem: return make_redeem_circuit(emit); default: return make_deposit_circuit(emit, 8); } }
 
-// after the first load from text: leave the container behind for the next process start (a read-only key directory simply goes without)
-void write_container_quietly(const std::string &pk_path, const ProvingKeyHost &pk) {
-  std::string cp = key_container_path(pk_path); KeyStamp ks; if (cp.empty() || pk.H_lagrange.empty() || pk.L_star.empty() || !key_stamp_of(pk_path, ks)) return;
+// after the first load from text: leave the container behind for the next process start (a read-only key directory simply goes without).  `before` is the key file's
+// stamp taken BEFORE it was read: the container is written under that stamp, and only if the file still carries it — a key replaced while it was being parsed
+// must not leave the old key's tables behind under the new file's size and mtime.
+void write_container_quietly(const std::string &pk_path, const ProvingKeyHost &pk, const FileStamp &before) {
+  std::string cp = key_container_path(pk_path); FileStamp now; if (cp.empty() || pk.H_lagrange.empty() || pk.L_star.empty() || !stamp_of(pk_path, now) || !(now == before)) return;
+  KeyStamp ks; ks.size = before.size; ks.mtime_s = before.mtime; ks.mtime_ns = before.mtime_ns;
   try { save_key_container(cp, pk, ks); } catch (const std::exception &) {} }
 // A unit of the key's pool, locked for the caller (the reference keeps the unit alive, the lock is released first: members are destroyed in reverse order)
 struct HeldUnit { std::shared_ptr<ProverUnit> unit; std::unique_lock<std::mutex> lock; };
-// loads the key on first use or when the file changed; loading is serialised by g_gpu_mutex, which also guards the slot table
+// Loads the key on first use or when the file changed; loading is serialised by g_gpu_mutex, which also guards the slot table.  With several devices (ZK_DEVICES)
+// the pools are built LAZILY, one device at a time: a caller is routed to device (turn mod D); that device's pool — the key's tables once, ZK_PROVERS_PER_KEY prover
+// objects sharing them — is built when the first caller arrives there (from the key's container: 0.1 s), so a process that never has two proofs in flight keeps one
+// copy of one key on one GPU, and 8 devices x 4 keys are not 32 key loads at the first call.  A prover's helper threads start with its first proof (groth16.cpp).
 HeldUnit acquire_prover(CircuitKind k) {
   std::string path = key_path(k, true); FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("proving key not found: " + path);
-  std::shared_ptr<const UnitList> units; unsigned turn = 0;
+  const size_t D = (size_t)std::max(1, gpu_device_slots()); std::vector<std::shared_ptr<const UnitList>> lists; unsigned turn = 0; size_t dev = 0;
   { std::lock_guard<std::mutex> lk(g_gpu_mutex); ProverSlot &slot = g_provers[path];
-    if (!slot.units || !(slot.stamp == st)) {
+    if (slot.units.size() != D || !(slot.stamp == st)) { slot.units.assign(D, nullptr); slot.stamp = st; }          // (a changed key file: new lists; the old provers die with the last proof running on them)
+    turn = slot.next.fetch_add(1); dev = turn % D;
+    bool any_free = false; for (size_t d = 0; d < D && !any_free; d++) if (slot.units[d]) for (auto &u : *slot.units[d]) { std::unique_lock<std::mutex> t(u->busy, std::try_to_lock); if (t.owns_lock()) { any_free = true; break; } }
+    if (!slot.units[dev] && any_free) { for (size_t d = 0; d < D; d++) if (slot.units[d]) { dev = d; break; } }     // somebody is free on a device that is already loaded: no new pool yet
+    if (!slot.units[dev]) {
       bool cached = false; ProvingKeyHost pk = load_proving_key_fast(path, cached); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 6; if (n < 1) n = 1; if (n > 7) n = 7;
-      // per device of the process's list (ZK_DEVICES): one prover built from the key, the rest of that device's members share its tables.  The list is interleaved by
-      // device — d0u0 d1u0 ... d0u1 d1u1 ... — so that callers walking it from a rotating start (below) spread over the GPUs before they double up on one.
-      auto fresh = std::make_shared<UnitList>(); const int D = std::max(1, gpu_device_slots()); std::vector<std::shared_ptr<Prover>> first(D);
-      for (int i = 0; i < n; i++) for (int dslot = 0; dslot < D; dslot++) { auto u = std::make_shared<ProverUnit>();
-        if (i == 0) { u->prover.reset(new Prover(pk, 0, 1, dslot)); first[dslot] = u->prover; } else u->prover.reset(new Prover(*first[dslot]));
+      auto fresh = std::make_shared<UnitList>(); std::shared_ptr<Prover> first;
+      for (int i = 0; i < n; i++) { auto u = std::make_shared<ProverUnit>();
+        if (i == 0) { u->prover.reset(new Prover(pk, 0, 1, (int)dev)); first = u->prover; } else u->prover.reset(new Prover(*first));   // the pool's members share the first one's device tables
         u->circuit = make_circuit(k, false);
         if (u->circuit->board.num_variables() != u->prover->num_variables() || u->circuit->num_inputs() != u->prover->num_inputs()) throw std::runtime_error("proving key does not belong to the " + std::string(circuit_name(k)) + " circuit: " + path);
         fresh->push_back(std::move(u)); }
-      slot.units = std::move(fresh); slot.stamp = st;
-      if (!cached) write_container_quietly(path, pk); }
-    units = slot.units; turn = slot.next.fetch_add(1); }
-  const size_t D = (size_t)std::max(1, gpu_device_slots()), start = turn % D;   // first free member; the walk starts on a rotating DEVICE (the list is interleaved by device), so one device's callers keep reusing its first member — warm circuit board, warm buffers —
-  for (size_t j = 0; j < units->size(); j++) { const auto &u = (*units)[(start + j) % units->size()]; std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) return HeldUnit{u, std::move(lk)}; }   // and only concurrent callers fan out
-  const std::shared_ptr<ProverUnit> &u = (*units)[turn % units->size()]; return HeldUnit{u, std::unique_lock<std::mutex>(u->busy)};
+      slot.units[dev] = std::move(fresh);
+      if (!cached) write_container_quietly(path, pk, st); }
+    lists = slot.units; }
+  // first free member, this caller's device first (warm circuit board, warm buffers), then the other loaded devices; otherwise wait for a member of this device
+  for (size_t dd = 0; dd < D; dd++) { const auto &l = lists[(dev + dd) % D]; if (!l) continue; for (const auto &u : *l) { std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) return HeldUnit{u, std::move(lk)}; } }
+  const std::shared_ptr<ProverUnit> &u = (*lists[dev])[(turn / D) % lists[dev]->size()]; return HeldUnit{u, std::unique_lock<std::mutex>(u->busy)};
 }
 std::shared_ptr<PreparedVerifyingKey> vk_for_path(const std::string &path) {
   FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("verification key not found: " + path);
@@ -237,8 +245,8 @@ int zkgpu_keygen_from_r1cs(const char *r1cs_path, uint64_t seed, const char *pk_
 int zkgpu_keygen(int kind, int tree_depth, uint64_t seed, const char *pk_path, const char *vk_path) { return guarded([&] { std::unique_ptr<Circuit> c = kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true);
   ProvingKeyHost pk; VerifyingKeyHost vk; generate_keys(c->r1cs(), seed ? ToxicWaste::from_seed(seed) : ToxicWaste::random(), pk, vk); save_proving_key(pk_path, pk); save_verifying_key(vk_path, vk); return ZKGPU_OK; }); }
 
-zkgpu_prover *zkgpu_prover_load_shard(const char *pk_path, size_t shard_rank, size_t shard_world) { zkgpu_prover *h = nullptr; guarded([&] { bool cached = false; ProvingKeyHost pk = load_proving_key_fast(pk_path, cached); std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(pk, shard_rank, shard_world));
-  if (!cached) write_container_quietly(pk_path, pk); h = p.release(); return ZKGPU_OK; }); return h; }
+zkgpu_prover *zkgpu_prover_load_shard(const char *pk_path, size_t shard_rank, size_t shard_world) { zkgpu_prover *h = nullptr; guarded([&] { FileStamp before; if (!stamp_of(pk_path, before)) throw std::runtime_error(std::string("proving key not found: ") + pk_path); bool cached = false; ProvingKeyHost pk = load_proving_key_fast(pk_path, cached); std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(pk, shard_rank, shard_world));
+  if (!cached) write_container_quietly(pk_path, pk, before); h = p.release(); return ZKGPU_OK; }); return h; }
 /* pure host logic of the multi-device pool, for the CPU tests: parses `spec` as ZK_DEVICES would be (n_visible devices, `fallback` = ZK_DEVICE / LOCAL_RANK) into out_devices (returns
  * the count), and writes the device slot of each of the first n_order pool members (ZK_PROVERS_PER_KEY = per_device) into out_order in pool order */
 int zkgpu_test_device_plan(const char *spec, int n_visible, int fallback, int per_device, int *out_devices, int *out_order, int n_order) {
@@ -298,6 +306,9 @@ int zkgpu_profile_enable(int on) { return guarded([&] { profile_enable(on != 0);
 int zkgpu_profile_report(char *buf, size_t cap) { return guarded([&] { std::string r = profile_report(); if (r.size() + 1 > cap) return ZKGPU_ERR_ARG; memcpy(buf, r.c_str(), r.size() + 1); return ZKGPU_OK; }); }
 int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs) { int res = 0; int rc = guarded_host([&] { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(vk_path); Proof p;   // host verifier on the prepared key (cached by the file's size and mtime)
   if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK; } res = verify_proof(*vk, (const Fe32 *)inputs, n_inputs, p) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
+/* test entry: the decision of the GPU verifier's schedule (verify_sched.hpp), interpreted on the HOST — no device needed; stats (optional): rounds, slots, products, linear operations, constants */
+int zkgpu_test_verify_schedule(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs, uint32_t *stats) { int res = 0; int rc = guarded_host([&] { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(vk_path); Proof p;
+  if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK; } res = verify_by_schedule_on_host(*vk, (const Fe32 *)inputs, n_inputs, p, stats) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
 // batched verification on the GPU (kernel K9).  proofs_hex: n * 512 characters; inputs: n * n_inputs canonical field elements; ok[i] = 1 accept / 0 reject
 // (a record that is not 512 hex digits of values below q is rejected without reaching the device, like proof_from_hex in zkgpu_verify)
 int zkgpu_verify_batch(const char *vk_path, const char *proofs_hex, const uint8_t *inputs, size_t n_inputs, size_t n, uint8_t *ok) { return guarded([&] {
@@ -306,16 +317,20 @@ int zkgpu_verify_batch(const char *vk_path, const char *proofs_hex, const uint8_
   if (slot.v->num_inputs() != n_inputs) { for (size_t i = 0; i < n; i++) ok[i] = 0; return ZKGPU_OK; }                // strong IC: wrong input count rejects (r1cs_gg_ppzksnark.tcc:584-590)
   std::vector<Proof> ps(n); std::vector<uint8_t> parsed(n);
   for (size_t i = 0; i < n; i++) { parsed[i] = strnlen(proofs_hex + 512 * i, 512) == 512 && proof_from_hex(proofs_hex + 512 * i, ps[i]); if (!parsed[i]) memset(&ps[i], 0, sizeof(Proof)); }
-  slot.v->verify(ps.data(), (const Fe32 *)inputs, n, ok); for (size_t i = 0; i < n; i++) if (!parsed[i]) ok[i] = 0; return ZKGPU_OK; }); }
+  slot.v->verify(ps.data(), (const Fe32 *)inputs, n, ok);
+  for (size_t i = 0; i < n; i++) { if (!parsed[i]) ok[i] = 0; else if (ok[i] == 2) ok[i] = verify_proof(*vk_for_path(vk_path), (const Fe32 *)inputs + i * n_inputs, n_inputs, ps[i]) ? 1 : 0; }   // 2: input accumulator at infinity, the host verifier decides (pairing.cuh)
+  return ZKGPU_OK; }); }
 // ---- verifyBatch: the optional batch entry of include/zk_batch.h ---------------------------------------------------
 // go-ethereum checks every ZK transaction twice, once in the pool and once in the block (core/tx_pool.go:612-645, core/state_processor.go:106-163), one cgo call
-// and one key load per proof.  A block's worth of proofs in ONE call is what the GPU verifier (kernel K9, one lane per proof) is for: from ZK_VERIFY_GPU_MIN
-// proofs of a kind on (default 24: the break-even against the prepared host verifier) the kind's records go to the device in one launch, smaller groups are checked
-// on the host.  Decisions are exactly those of the kind's verifyXproof symbol.
+// and one key load per proof.  A block's worth of proofs in ONE call is what the GPU verifier is for (kernel K9, since round 3 one workgroup per proof interpreting the
+// operation schedule of verify_sched.hpp: 4.0 ms per launch up to a few hundred proofs, 15,000 proofs/s at 64, 110,000 at 512): from ZK_VERIFY_GPU_MIN proofs of a kind
+// on (default 3: the host loop below costs 2.5 ms per proof on one thread) the kind's records go to the device in one launch, smaller groups are checked on the host.
+// Decisions are exactly those of the kind's verifyXproof symbol.  The verifyXproof symbols themselves stay on the prepared host verifier: one proof is 2.5 ms there
+// against 4.0 ms on the device, and go-ethereum issues them one at a time under its pool lock.
 int verifyBatch(const zk_verify_item *items, int n, unsigned char *ok) {
   if (n < 0 || (n && (!items || !ok))) return -1;
   try {
-    static const size_t gpu_min = [] { const char *e = getenv("ZK_VERIFY_GPU_MIN"); long v = e ? atol(e) : 24; return (size_t)(v < 1 ? 1 : v); }();
+    static const size_t gpu_min = [] { const char *e = getenv("ZK_VERIFY_GPU_MIN"); long v = e ? atol(e) : 3; return (size_t)(v < 1 ? 1 : v); }();
     int accepted = 0; std::vector<int> idx[4];
     for (int i = 0; i < n; i++) { ok[i] = 0; if (items[i].kind >= 0 && items[i].kind <= 3) idx[items[i].kind].push_back(i); }
     for (int k = 0; k < 4; k++) { if (idx[k].empty()) continue; const CircuitKind kind = (CircuitKind)k; const size_t m = idx[k].size();
@@ -324,7 +339,7 @@ int verifyBatch(const zk_verify_item *items, int n, unsigned char *ok) {
         std::vector<Fe32> in = pack_public_bits(public_bits(kind, it.args, it.value_s)); ni = in.size(); inputs.insert(inputs.end(), in.begin(), in.end()); }
       const std::string path = key_path(kind, false);
       if (m >= gpu_min && gpu_available()) { std::lock_guard<std::mutex> lk(g_gpu_mutex); std::shared_ptr<BatchVerifier> v = gpu_verifier_for_path(path);
-        if (v->num_inputs() == ni) v->verify(ps.data(), inputs.data(), m, res.data()); }
+        if (v->num_inputs() == ni) { v->verify(ps.data(), inputs.data(), m, res.data()); for (size_t j = 0; j < m; j++) if (res[j] == 2) res[j] = parsed[j] && verify_proof(*vk_for_path(path), inputs.data() + j * ni, ni, ps[j]); } }
       else { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(path); for (size_t j = 0; j < m; j++) res[j] = parsed[j] && verify_proof(*vk, inputs.data() + j * ni, ni, ps[j]); }
       for (size_t j = 0; j < m; j++) { ok[idx[k][j]] = parsed[j] && res[j]; accepted += ok[idx[k][j]]; } }
     return accepted;

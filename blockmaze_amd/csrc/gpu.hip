@@ -15,7 +15,9 @@
 // two streams sharing a queue run one after the other (measured: the B1 MSM then ends at 2.7 ms instead of 1.4 ms).  The runtime reads the variable when its first API
 // call initialises it, so it has to be in the environment before ANY HIP call of the process: a load-time constructor with the earliest user priority does that —
 // it runs when the dynamic loader maps libzkgpu.so (program start for a cgo binary linked against libzk_*.so), before this library's own code-object registration
-// and long before gpu_available().  A host that wants another value exports the variable itself (it is not overwritten).
+// and long before gpu_available().  A host that wants another value exports the variable itself (it is not overwritten).  A host that dlopen()s the library late —
+// after it has started threads that call getenv, or after its own first HIP call — must export GPU_MAX_HW_QUEUES itself before that call: setenv is not thread safe and
+// comes too late then.
 __attribute__((constructor(101))) static void zkgpu_load_time_environment() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 namespace zk {
@@ -44,10 +46,18 @@ GpuContext &gpu() {
 }
 // lanes 1.. round robin for provers; lane 0 (device slot 0) stays with everything else.  A lane keeps the device slot of its first user; asking for a lane on another
 // slot skips lanes bound elsewhere.
+// A lane is lent to ONE prover at a time and handed back by its destructor (gpu_lane_release): a process that reloads keys or clones provers for ever keeps cycling
+// through the same 31 stream sets instead of running out of them (the lanes' HIP streams themselves live for the life of the process and are reused).
+static int g_lane_users[MAX_LANES];
 int gpu_lane_acquire(int device_slot) {
-  for (int tries = 0; tries < 2 * MAX_LANES; tries++) { int lane = 1 + (int)(g_next_lane.fetch_add(1) % (MAX_LANES - 1)); std::lock_guard<std::mutex> lk(g_lane_mutex);
-    static bool claimed[MAX_LANES]; if (!claimed[lane]) { claimed[lane] = true; g_lane_slot[lane].store(device_slot); return lane; } if (g_lane_slot[lane].load() == device_slot) return lane; }
-  throw GpuError("no stream lane left for device slot " + std::to_string(device_slot)); }
+  std::lock_guard<std::mutex> lk(g_lane_mutex);
+  for (int pass = 0; pass < 2; pass++)                                                   // first a free lane already bound to this device slot (its context exists), then any free lane that was never bound
+    for (int lane = 1; lane < MAX_LANES; lane++) { if (g_lane_users[lane]) continue; const bool bound = g_lanes[lane].load() != nullptr;
+      if (pass == 0 ? (bound && g_lane_slot[lane].load() == device_slot) : !bound) { g_lane_users[lane] = 1; g_lane_slot[lane].store(device_slot); return lane; } }
+  int best = -1; for (int lane = 1; lane < MAX_LANES; lane++) if (g_lane_slot[lane].load() == device_slot && (best < 0 || g_lane_users[lane] < g_lane_users[best])) best = lane;   // all lent out: share the least used lane of this device
+  if (best < 0) throw GpuError("no stream lane left for device slot " + std::to_string(device_slot));
+  g_lane_users[best]++; return best; }
+void gpu_lane_release(int lane) { if (lane <= 0 || lane >= MAX_LANES) return; std::lock_guard<std::mutex> lk(g_lane_mutex); if (g_lane_users[lane] > 0) g_lane_users[lane]--; }
 int gpu_lane_current() { return t_lane; }
 void gpu_lane_select(int lane) { t_lane = lane < 0 || lane >= MAX_LANES ? 0 : lane; }
 bool gpu_available() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0; }

@@ -3,6 +3,7 @@
 #include "gpu_internal.hpp"
 #include "pairing.cuh"
 #include "pairing_host.hpp"
+#include "verify_sched.hpp"
 
 namespace zk {
 using host::HFq; using host::HFq2; using host::HG1;
@@ -14,7 +15,7 @@ static const uint64_t ATE_LOOP[2] = {0x9d797039be763ba8ull, 0x1ull};          //
 template <class T> struct DevArr { DevBuf<uint8_t> b; DevArr() = default; explicit DevArr(size_t n) : b(n * sizeof(T)) {} T *get() const { return (T *)b.get(); }
   void upload(const T *h, size_t n) { b.upload((const uint8_t *)h, n * sizeof(T)); } };
 struct BatchVerifier::Impl {
-  size_t n_inputs = 0; DevBuf<uint32_t> prog; DevArr<EllCoeffsDev> gamma, delta; DevArr<FrobeniusDev> frob; DevArr<Fq12> alpha_beta; DevArr<Affine<Fq>> tables; Affine<Fq> ic0; VerifyConsts K; size_t prog_len = 0;
+  size_t n_inputs = 0; DevBuf<uint32_t> sched_prog; DevArr<Fq> sched_consts; SchedInfo si{}; DevBuf<uint32_t> prog; DevArr<EllCoeffsDev> gamma, delta; DevArr<FrobeniusDev> frob; DevArr<Fq12> alpha_beta; DevArr<Affine<Fq>> tables; Affine<Fq> ic0; VerifyConsts K; size_t prog_len = 0;
 };
 
 // registers of the program
@@ -66,6 +67,11 @@ BatchVerifier::BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2Affine
   host::G2Precomp pg = host::precompute_g2(fq2_of(gamma_g2.x0, gamma_g2.x1), fq2_of(gamma_g2.y0, gamma_g2.y1)), pd = host::precompute_g2(fq2_of(delta_g2.x0, delta_g2.x1), fq2_of(delta_g2.y0, delta_g2.y1));
   std::vector<EllCoeffsDev> lg(pg.size()), ld(pd.size()); for (size_t i = 0; i < pg.size(); i++) { lg[i] = to_dev<EllCoeffsDev>(pg[i]); ld[i] = to_dev<EllCoeffsDev>(pd[i]); }
   d.gamma = DevArr<EllCoeffsDev>(lg.size()); d.gamma.upload(lg.data(), lg.size()); d.delta = DevArr<EllCoeffsDev>(ld.size()); d.delta.upload(ld.data(), ld.size());
+  { vsched::Schedule sc = vsched::build(alpha_g1_beta_g2, pg, pd);   // the one-wave-per-proof kernel's schedule (verify_sched.hpp)
+    sc.prog.resize(sc.prog.size() + 4 + 256 * 16, 0u);   // (the kernel prefetches one round ahead: one round's worth of padding)
+    d.sched_prog = DevBuf<uint32_t>(sc.prog.size()); d.sched_prog.upload(sc.prog.data(), sc.prog.size()); d.sched_consts = DevArr<Fq>(sc.consts.size()); d.sched_consts.upload((const Fq *)sc.consts.data(), sc.consts.size());
+    d.si.n_rounds = sc.n_rounds; d.si.n_slots = sc.n_slots; d.si.n_consts = (uint32_t)sc.consts.size(); d.si.alpha_beta_const = sc.alpha_beta_const; for (int k = 0; k < 16; k++) d.si.out_slot[k] = sc.out_slot[k];
+    if (((size_t)sc.n_slots + sc.consts.size()) * 32 > 160 * 1024) throw GpuError("verify: the schedule needs more LDS than a CU has"); }
   std::vector<uint32_t> prog = assemble_program(pg.size()); d.prog_len = prog.size(); d.prog = DevBuf<uint32_t>(prog.size()); d.prog.upload(prog.data(), prog.size());
   FrobeniusDev fr = to_dev<FrobeniusDev>(host::frobenius_tables()); d.frob = DevArr<FrobeniusDev>(1); d.frob.upload(&fr, 1);
   Fq12 ab = to_dev<Fq12>(alpha_g1_beta_g2); d.alpha_beta = DevArr<Fq12>(1); d.alpha_beta.upload(&ab, 1);
@@ -91,8 +97,16 @@ void BatchVerifier::verify(const void *proofs_mont, const Fe32 *inputs_canonical
   DevArr<VerifyItem> items(n); DevBuf<Fe32> in(n * d.n_inputs + 1); DevArr<Affine<Fq>> acc(n); DevBuf<uint8_t> out(n);
   items.upload((const VerifyItem *)proofs_mont, n); if (d.n_inputs) in.upload(inputs_canonical, n * d.n_inputs);
   Stage st("verify.batch");
+  // up to WAVE_MAX proofs: one wave each (latency of a proof ~ the schedule's rounds); beyond that the lane-per-proof kernel, whose 46 ms floor is then amortised over thousands
+  static const size_t wave_max = [] { const char *e = getenv("ZK_VERIFY_WAVE_MAX"); long v = e ? atol(e) : 2048; return (size_t)(v < 0 ? 0 : v); }();   // (measured: 4.3 ms per 512 proofs here, 25 ms for anything up to 16,384 there)
+  if (n <= wave_max) { DevArr<NegAcc3> acc3(n);
+    static bool attr_set = false; const size_t lds = ((size_t)d.si.n_slots + d.si.n_consts) * 32; if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)k_verify_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    hipLaunchKernelGGL(k_verify_acc_wave, dim3((unsigned)n), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(), (uint32_t)d.n_inputs, (uint32_t)n, acc3.get());
+    hipLaunchKernelGGL(k_verify_sched, dim3((unsigned)n), dim3(256), lds, s, d.sched_prog.get(), (const uint4 *)d.sched_consts.get(), items.get(), acc3.get(), (uint32_t)n, d.si, out.get()); HIP_CHECK(hipStreamSynchronize(s));   // (acc3 lives until the kernels are done)
+  } else {
   hipLaunchKernelGGL(k_verify_acc, dim3(cdiv(n, 64)), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(), (uint32_t)d.n_inputs, (uint32_t)n, acc.get());
   hipLaunchKernelGGL(k_verify_batch, dim3(cdiv(n, 64)), dim3(64), 0, s, d.prog.get(), items.get(), acc.get(), d.gamma.get(), d.delta.get(), d.frob.get(), d.alpha_beta.get(), d.K, (uint32_t)n, out.get());
+  }
   HIP_CHECK(hipGetLastError()); out.download(ok, n);
 }
 

@@ -15,7 +15,9 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <climits>
 #include "groth16.hpp"
+#include "verify_sched.hpp"
 
 namespace zk {
 using namespace host;
@@ -160,7 +162,10 @@ std::string key_container_path(const std::string &pk_path) {
   const char *on = getenv("ZK_KEY_CACHE"); if (on && atoi(on) == 0) return "";
   if (env_int_early("ZK_H_LAGRANGE", 1) == 0 || env_int_early("ZK_FOLD_C", 1) == 0) return "";   // the container holds the TRANSFORMED queries: a run that switches a transform off works from the text key
   const char *dir = getenv("ZK_KEY_CACHE_DIR"); if (!dir || !*dir) return pk_path + ".gpucache";
-  std::string flat = pk_path; for (char &ch : flat) if (ch == '/') ch = '_'; return std::string(dir) + "/" + flat + ".gpucache"; }
+  // one file per ABSOLUTE key path: the name carries a 64-bit hash of it (flattening '/' to '_' let /a/b_c/k and /a/b/c_k share a container)
+  char abs[PATH_MAX]; std::string full = realpath(pk_path.c_str(), abs) ? std::string(abs) : pk_path; uint64_t hsh = 0xcbf29ce484222325ull; for (unsigned char ch : full) { hsh ^= ch; hsh *= 0x100000001b3ull; }
+  std::string base = full.substr(full.find_last_of('/') == std::string::npos ? 0 : full.find_last_of('/') + 1); char hex[17]; snprintf(hex, sizeof hex, "%016llx", (unsigned long long)hsh);
+  return std::string(dir) + "/" + base + "." + hex + ".gpucache"; }
 void save_key_container(const std::string &path, const ProvingKeyHost &pk, const KeyStamp &src) {
   if (pk.H_lagrange.empty() || pk.L_star.empty()) throw std::runtime_error("key container: the key has not been transformed yet");
   ContainerHeader h; memset(&h, 0, sizeof h); memcpy(h.magic, CONTAINER_MAGIC, 8); h.version = 1; h.flags = 3; h.src_size = src.size; h.src_mtime_s = src.mtime_s; h.src_mtime_ns = src.mtime_ns;
@@ -168,7 +173,7 @@ void save_key_container(const std::string &path, const ProvingKeyHost &pk, const
   std::vector<Section> secs = sections_of(pk); size_t total = 0; for (auto &s : secs) total += align64(s.bytes);
   std::vector<uint8_t> buf(total, 0); size_t off = 0; for (auto &s : secs) { if (s.bytes) memcpy(buf.data() + off, s.p, s.bytes); off += align64(s.bytes); }
   h.payload_bytes = total; h.checksum = checksum64(buf.data(), total);
-  const std::string tmp = path + ".tmp." + std::to_string((long)getpid()); FILE *f = fopen(tmp.c_str(), "wb"); if (!f) throw std::runtime_error("key container: cannot write " + tmp);
+  const std::string tmp = path + ".tmp." + std::to_string((long)getpid()); const int wfd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600); FILE *f = wfd < 0 ? nullptr : fdopen(wfd, "wb"); if (!f) { if (wfd >= 0) close(wfd); throw std::runtime_error("key container: cannot write " + tmp); }   // readable by the owner only: the payload is trusted as far as the checks of load_key_container go
   bool ok = fwrite(&h, 1, sizeof h, f) == sizeof h && fwrite(buf.data(), 1, total, f) == total; ok = fclose(f) == 0 && ok;
   if (!ok || rename(tmp.c_str(), path.c_str())) { remove(tmp.c_str()); throw std::runtime_error("key container: cannot write " + path); } }
 bool load_key_container(const std::string &path, const KeyStamp &src, ProvingKeyHost &pk) {
@@ -183,8 +188,11 @@ bool load_key_container(const std::string &path, const KeyStamp &src, ProvingKey
   for (int m = 0; m < 3; m++) { k.cs.rowptr[m].resize(h.n_cons + 1); k.cs.col[m].resize(h.nnz[m]); k.cs.coeff[m].resize(h.nnz[m]); }
   std::vector<Section> secs = sections_of(k); size_t total = 0; for (auto &s : secs) total += align64(s.bytes); if (total != h.payload_bytes) return false;
   size_t off = 0; for (auto &s : secs) { if (s.bytes) memcpy(const_cast<void *>(s.p), pay + off, s.bytes); off += align64(s.bytes); }
-  for (int m = 0; m < 3; m++) { if (k.cs.rowptr[m][0] != 0 || k.cs.rowptr[m][h.n_cons] != h.nnz[m]) return false; }
-  for (uint32_t i : k.B_idx) if (i >= h.nA) return false;
+  // the same range and monotonicity checks as the text loader: a container with a valid checksum but indices out of range would make k_r1cs_rows_all / the B-query gather read out of bounds on the device
+  for (int m = 0; m < 3; m++) { if (k.cs.rowptr[m][0] != 0 || k.cs.rowptr[m][h.n_cons] != h.nnz[m]) return false;
+    for (size_t r = 0; r < h.n_cons; r++) if (k.cs.rowptr[m][r] > k.cs.rowptr[m][r + 1]) return false;
+    for (uint32_t cidx : k.cs.col[m]) if (cidx > h.n_vars) return false; }
+  for (size_t i = 0; i < k.B_idx.size(); i++) if (k.B_idx[i] >= h.nA || (i && k.B_idx[i] <= k.B_idx[i - 1])) return false;
   pk = std::move(k); return true; }
 ProvingKeyHost load_proving_key_fast(const std::string &pk_path, bool &from_container) {
   from_container = false; KeyStamp st; std::string cp = key_container_path(pk_path); ProvingKeyHost pk;
@@ -285,7 +293,7 @@ struct Prover::Impl {
   int owner(int j) const { return j == 1 && pair_AL ? 2 : j == 0 && pair_B ? 3 : j; }
   void settle(int j) { const int o = owner(j); if (pending[o]) { pending[o] = false; workers[o]->wait(); } if (inline_result[j]) { inline_result[j] = false; switch (j) { case 0: rB2 = B2->result(); break; case 1: rL = L->result(); break; case 2: rA = A->result(); break; default: rB1 = B1->result(); } } }
   void settle_all_quietly() { for (int j = 0; j < 4; j++) { try { settle(j); } catch (...) {} } }
-  ~Impl() { settle_all_quietly(); for (auto &w : workers) w.reset(); }
+  ~Impl() { settle_all_quietly(); for (auto &w : workers) w.reset(); gpu_lane_release(lane); }
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &e) { size_t base = n / world, rem = n % world; b = rank * base + (rank < rem ? rank : rem); e = b + base + (rank < rem ? 1 : 0); }
@@ -491,6 +499,26 @@ bool verify_proof(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_
   return final_exponentiation(q1 * (q2 * q3).conj()) == vk.alpha_g1_beta_g2;                                               // :556-560
 }
 
+// The decision of verify_proof() taken by the GPU verifier's SCHEDULE (verify_sched.hpp) interpreted on the host: what kernel K9 computes, without a GPU.  Test entry
+// (zkgpu_test_verify_schedule): the schedule is checked against the host verifier and the oracle on the CPU before any device runs it.
+// stats: rounds, slots, products, linear operations, constants.
+bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t stats[5]) {
+  const VerifyingKeyHost &vk = pvk.vk; vsched::Schedule S = vsched::build(vk.alpha_g1_beta_g2, pvk.gamma, pvk.delta);
+  if (stats) { stats[0] = S.n_rounds; stats[1] = S.n_slots; stats[2] = S.n_mul; stats[3] = S.n_lin; stats[4] = (uint32_t)S.consts.size(); }
+  if (vk.IC.size() != n_inputs + 1) return false;
+  HG1 acc = g1_of(vk.IC[0]);
+  for (size_t j = 0; j < n_inputs; j++) { const uint8_t *b = reinterpret_cast<const uint8_t *>(&inputs[j]);
+    for (int w = 0; w < 32; w++) if (b[w]) { const size_t k = j * 32 * 255 + (size_t)w * 255 + b[w] - 1; if (!(pvk.ic_x[k].is_zero() && pvk.ic_y[k].is_zero())) acc = acc.add(HG1::from_affine(pvk.ic_x[k], pvk.ic_y[k])); } }
+  if (is_zero_raw(&proof.A, sizeof proof.A) || is_zero_raw(&proof.B, sizeof proof.B) || is_zero_raw(&proof.C, sizeof proof.C)) return false;
+  if (acc.is_inf()) return verify_proof(pvk, inputs, n_inputs, proof);                    // (the kernel hands such a proof back to the host verifier: the gamma pairing is the identity then)
+  HFq accx, accy; acc.to_affine(accx, accy); HFq in[vsched::N_INPUTS];
+  in[vsched::IN_AX] = fq_of(proof.A.x); in[vsched::IN_AY] = fq_of(proof.A.y); in[vsched::IN_BX0] = fq_of(proof.B.x0); in[vsched::IN_BX1] = fq_of(proof.B.x1); in[vsched::IN_BY0] = fq_of(proof.B.y0); in[vsched::IN_BY1] = fq_of(proof.B.y1);
+  in[vsched::IN_CX] = fq_of(proof.C.x); in[vsched::IN_CY] = fq_of(proof.C.y); in[vsched::IN_NACCX] = accx; in[vsched::IN_NACCY] = accy.neg(); in[vsched::IN_NACCW] = HFq::one();
+  std::vector<HFq> out = vsched::simulate(S, in); bool ok = true;
+  for (int k = 0; k < vsched::N_RESULT; k++) ok = ok && out[k] == S.consts[S.alpha_beta_const + k];
+  for (int k = 0; k < vsched::N_CHECK; k++) ok = ok && out[vsched::N_RESULT + k].is_zero();
+  return ok;
+}
 std::unique_ptr<BatchVerifier> make_batch_verifier(const VerifyingKeyHost &vk) { return std::unique_ptr<BatchVerifier>(new BatchVerifier(vk.alpha_g1_beta_g2, vk.gamma_g2, vk.delta_g2, vk.IC.data(), vk.IC.size())); }
 
 static void put_hex_fq(std::string &o, const Fe32 &mont) { HFq c = fq_of(mont).from_mont(); static const char *d = "0123456789abcdef"; for (int i = 3; i >= 0; i--) for (int k = 15; k >= 0; k--) o.push_back(d[(c.l[i] >> (4 * k)) & 15]); }

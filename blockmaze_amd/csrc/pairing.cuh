@@ -1,4 +1,6 @@
-// Batched Groth16 verification on the GPU (kernel K9): one lane per proof.
+// Batched Groth16 verification on the GPU (kernel K9).  Two kernels: k_verify_sched (round 3, at the end of this file) — one 256-thread
+// workgroup per proof interpreting the operation schedule of verify_sched.hpp, 4 ms per launch — for blocks of up to a few thousand proofs, and the first generation below,
+// one LANE per proof, whose 25 ms floor only pays from several thousand proofs on.
 //
 // Restates r1cs_gg_ppzksnark_verifier_strong_IC (SNARK/.../r1cs_gg_ppzksnark.tcc:509-623) over libff's optimal-ate pairing
 // (FF/algebra/curves/alt_bn128/alt_bn128_pairing.cpp: doubling / mixed-addition steps :242-293, G2 precomputation :305-366, miller_loop :368-418,
@@ -17,6 +19,10 @@
 
 namespace zk {
 
+__device__ __forceinline__ Fq shfl_down_fq(const Fq &v, int delta) { Fq r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = __shfl_down(v.l[i], delta, 64);
+  return r; }
 struct Fq6 {
   Fq2 c0, c1, c2;
   static __device__ __forceinline__ Fq6 zero() { return {Fq2::zero(), Fq2::zero(), Fq2::zero()}; }
@@ -118,6 +124,67 @@ __global__ void __launch_bounds__(64) k_verify_batch(const uint32_t *__restrict_
     }
   }
   ok[i] = (good && R[0] == *alpha_beta) ? 1 : 0;                                                                                                                    // :556-560
+}
+
+
+// ---- second generation: one WAVE per proof, interpreting the operation schedule of verify_sched.hpp ----------------------------------------------------------------
+// Every round of the schedule is one operation per lane on field elements held in LDS (or read from the key's table of constants): a Montgomery product, or a sum of
+// up to 12 terms +-2^s x.  The schedule is the same for every proof, so the workgroups of a launch never diverge; a proof costs ~2,900 rounds instead of 26,000 dependent
+// products on one lane.  Measured on MI355X (tools/verify_bench.py): 4.0 ms per launch for 1..512 proofs (one wave alone on a SIMD issues an instruction every ~7 cycles,
+// tools/valu_probe.hip, so a round of one 370-instruction product is 1.3 us whatever the other lanes do); 15,000 proofs/s at n = 64, 110,000 at n = 512.  What would make
+// it faster is fewer instructions per operation — the 29-bit limbs of the H accumulation (msm.cuh) with their carry-free sums — not more lanes.  ok[i]: 1 accept, 0 reject, 2 = the input accumulator was the point at infinity (the host verifier decides: the
+// gamma pairing is the identity then, which a fixed schedule cannot express).
+struct SchedInfo { uint32_t n_rounds, n_slots, n_consts, alpha_beta_const, out_slot[16]; };
+constexpr uint32_t VS_CONST_FLAG = 0x8000u;
+// LDS: [n_slots working values | n_consts constants of the key] — the constants are copied in once per proof (40 KB, coalesced), so that every operand of every round is
+// one LDS read: with the constants in global memory a round's critical path held a dependent global load (measured: 1.4 us per round instead of ~0.6).
+// The instruction words of round r + 1 are fetched while round r computes (prog is padded by one round's worth of words).
+struct NegAcc3 { Fq xw, nyw, w; };     // -acc = (x, -y) as (x w, -y w, w), w = ZZ ZZZ of the accumulation's extended Jacobian sum; w = 0: the point at infinity
+// barrier over the workgroup's LDS traffic only: __syncthreads() also drains the outstanding GLOBAL loads (s_waitcnt vmcnt(0)) — here the next round's instruction words,
+// fetched a round ahead precisely so that nobody waits for them
+__device__ __forceinline__ void vs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+static __global__ void __launch_bounds__(256) k_verify_sched(const uint32_t *__restrict__ prog, const uint4 *__restrict__ consts, const VerifyItem *__restrict__ items, const NegAcc3 *__restrict__ neg_acc, uint32_t n, SchedInfo si, uint8_t *__restrict__ ok) {
+  extern __shared__ uint32_t vs_lds[]; Fq *slots = reinterpret_cast<Fq *>(vs_lds);
+  const uint32_t i = blockIdx.x, lane = threadIdx.x; if (i >= n) return;
+  { uint4 *dst = reinterpret_cast<uint4 *>(slots + si.n_slots); for (uint32_t k = lane; k < si.n_consts * 2; k += 256) dst[k] = consts[k]; }
+  const VerifyItem &it = items[i]; const NegAcc3 nacc = neg_acc[i];
+  if (lane < 11) { Fq v = lane == 0 ? it.A.x : lane == 1 ? it.A.y : lane == 2 ? it.B.x.c0 : lane == 3 ? it.B.x.c1 : lane == 4 ? it.B.y.c0 : lane == 5 ? it.B.y.c1 : lane == 6 ? it.C.x : lane == 7 ? it.C.y : lane == 8 ? nacc.xw : lane == 9 ? nacc.nyw : nacc.w; slots[lane] = v; }   // vsched::IN_* order
+  __syncthreads();
+  auto at = [&](uint32_t ref) -> const Fq & { return slots[(ref & VS_CONST_FLAG) ? si.n_slots + (ref & (VS_CONST_FLAG - 1)) : ref]; };
+  auto fetch = [&](const uint32_t *base, uint32_t hd, uint4 &hq, uint4 &q0, uint4 &q1, uint4 &q2, uint4 &q3) { const uint32_t cnt = (hd >> 4) & 1023, wn = (hd >> 19) & 31; hq = *reinterpret_cast<const uint4 *>(base);
+    if (lane < cnt) { const uint4 *w = reinterpret_cast<const uint4 *>(base + 4 + lane * wn); q0 = w[0]; if (wn > 4) { q1 = w[1]; q2 = w[2]; q3 = w[3]; } } };
+  const uint32_t *pc = prog; uint4 hq, q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0; fetch(pc, __builtin_amdgcn_readfirstlane(pc[0]), hq, q0, q1, q2, q3);
+#pragma unroll 1
+  for (uint32_t r = 0; r < si.n_rounds; r++) {
+    const uint32_t h = __builtin_amdgcn_readfirstlane(hq.x), hnext = __builtin_amdgcn_readfirstlane(hq.y), kind = h & 15, count = (h >> 4) & 1023, nterms = (h >> 14) & 31, wpl = (h >> 19) & 31; const bool live = lane < count;   // vsched::hdr; word 1: the next round's header
+    const uint32_t wd[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    pc += 4 + count * wpl; fetch(pc, hnext, hq, q0, q1, q2, q3);          // the next round's header and words: in flight during this round's arithmetic, no load waited for here
+    Fq v = Fq::zero();
+    if (kind == 1) { if (live) v = at(wd[1]) * at(wd[2]); }
+    else if (live) {
+#pragma unroll
+      for (uint32_t t = 0; t < 12; t++) { if (t >= nterms) break; const uint32_t e = wd[1 + t]; Fq x = at(e & 0xffff);
+#pragma unroll 1
+        for (uint32_t s = (e >> 17) & 7; s; s--) x = x + x;
+        if ((e >> 16) & 1) v = v - x; else v = v + x; } }
+    vs_lds_barrier();                     // every lane has read its operands
+    if (live) slots[wd[0]] = v;
+    vs_lds_barrier();                     // ... and written its result before the next round reads
+  }
+  if (lane == 0) { bool good = !it.A.is_inf() && !it.B.is_inf() && !it.C.is_inf();
+    for (int k = 0; k < 12; k++) good = good && slots[si.out_slot[k]] == slots[si.n_slots + si.alpha_beta_const + k];
+    for (int k = 12; k < 16; k++) good = good && slots[si.out_slot[k]].is_zero();
+    ok[i] = nacc.w.is_zero() ? 2 : good ? 1 : 0; }
+}
+// acc_i = IC[0] + sum_j inputs[i][j] * IC[j+1] by ONE WAVE per proof: the (input, window) pairs are dealt to the lanes, a shuffle tree adds the lanes' sums, lane 0
+// hands the sum over as (X ZZZ, -Y ZZ, ZZ ZZZ) = (x w, -y w, w): no inversion (verify_sched.hpp evaluates the gamma lines times w).
+static __global__ void __launch_bounds__(64) k_verify_acc_wave(const Affine<Fq> *__restrict__ tables, Affine<Fq> ic0, const Fr *__restrict__ inputs, uint32_t n_inputs, uint32_t n, NegAcc3 *__restrict__ acc_out) {
+  const uint32_t i = blockIdx.x, lane = threadIdx.x; if (i >= n) return; XYZZ<Fq> acc = XYZZ<Fq>::inf();
+#pragma unroll 1
+  for (uint32_t q = lane; q < n_inputs * 32; q += 64) { const uint32_t j = q >> 5, w = q & 31; const Fr k = inputs[(size_t)i * n_inputs + j]; const uint32_t d = (k.l[w >> 2] >> ((w & 3) * 8)) & 0xffu; if (d) acc.madd_inl(tables[(size_t)j * 32 * 255 + w * 255 + d - 1]); }
+#pragma unroll 1
+  for (int d = 32; d >= 1; d >>= 1) { XYZZ<Fq> o = {shfl_down_fq(acc.X, d), shfl_down_fq(acc.Y, d), shfl_down_fq(acc.ZZ, d), shfl_down_fq(acc.ZZZ, d)}; if ((int)lane + d < 64) acc.add_inl(o); }
+  if (lane == 0) { acc.madd_inl(ic0); acc_out[i] = {acc.X * acc.ZZZ, (acc.Y * acc.ZZ).neg(), acc.ZZ * acc.ZZZ}; }
 }
 
 }  // namespace zk

@@ -48,6 +48,28 @@ def test_pairing_values_of_the_reference(ref_vectors, tmp_path):
     vk = str(tmp_path / "vkx.txt"); write_vk(vk, gts[1], G2, neg_g2, [o.g1_op("mul", G1, k=77)])          # the GT value of another pair: rejected
     assert not e.verify(vk, proof_hex(G1, G2, o.g1_op("mul", G1, k=77)), [])
 
+@pytest.mark.parametrize("name", ["groth16_small", "groth16_step"])
+def test_gpu_verifier_schedule_on_the_host(golden_dir, name):
+    """kernel K9's operation schedule (csrc/verify_sched.hpp: the whole pairing check as ~4,000 rounds of 64 field operations) interpreted on the HOST: the same decisions
+    as the host verifier on the reference prover's proofs and on every kind of tampering — the schedule is proven right before a GPU ever runs it"""
+    d = os.path.join(golden_dir, name); meta = json.load(open(os.path.join(d, "meta.json"))); z = o.load_witness(os.path.join(d, "wit.bin")); vk = os.path.join(d, "vk.txt")
+    inputs = o.from_arr(z[:meta["n_inputs"]]); proof = meta["proof"]; ok, st = e.verify_schedule_on_host(vk, proof, inputs); assert ok and e.verify(vk, proof, inputs)
+    assert 1000 < st["rounds"] < 6000 and st["slots"] * 32 <= 160 * 1024 and st["products"] > 20000, st                                        # fits the LDS of one CU
+    for j in range(len(inputs)): bad = list(inputs); bad[j] = (bad[j] + 1) % o.R_MOD; assert not e.verify_schedule_on_host(vk, proof, bad)[0]
+    assert not e.verify_schedule_on_host(vk, proof, inputs[:-1])[0]
+    for k in range(8): pos = 64 * k + 21; assert not e.verify_schedule_on_host(vk, proof[:pos] + ("0" if proof[pos] != "0" else "1") + proof[pos + 1:], inputs)[0]      # every coordinate of A, B, C
+    assert not e.verify_schedule_on_host(vk, "0" * 512, inputs)[0]
+
+def test_gpu_verifier_schedule_reproduces_reference_pairing_values(ref_vectors, tmp_path):
+    """the schedule's Miller loop and final exponentiation against the reference's reduced_pairing VALUES, as test_pairing_values_of_the_reference does for the host verifier"""
+    G1, G2 = o.g1_gen(), o.g2_gen(); neg_g2 = (G2[0], ((o.Q_MOD - G2[1][0]) % o.Q_MOD, (o.Q_MOD - G2[1][1]) % o.Q_MOD)); n = 0
+    for l in ref_vectors:
+        if l[0] != "pairing": continue
+        a, b = H(l[1].split("=")[1]), H(l[2].split("=")[1]); gt = [int(l[3].split("=")[1])] + [int(x) for x in l[4:]]
+        A, B = o.g1_op("mul", G1, k=a), o.g2_op("mul", G2, k=b); C = o.g1_op("mul", G1, k=77); vk = str(tmp_path / ("vk%d.txt" % n)); write_vk(vk, gt, G2, neg_g2, [C]); n += 1
+        assert e.verify_schedule_on_host(vk, proof_hex(A, B, C), [])[0] and not e.verify_schedule_on_host(vk, proof_hex(o.g1_op("dbl", A), B, C), [])[0]
+    assert n == 3
+
 def test_verify_batch_symbol(tmp_path, monkeypatch):
     zk = e.Zk(); assert hasattr(zk.L, "verifyBatch")
     monkeypatch.setenv("ZK_PRFKEY_DIR", str(tmp_path))                                                     # no key files there: no decision can be made
