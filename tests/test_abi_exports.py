@@ -59,9 +59,17 @@ def test_dropin_libraries_export_exactly_the_reference_symbols(zkgpu):
 def driver(tmp_path_factory, zkgpu):
     import subprocess
     exe = str(tmp_path_factory.mktemp("drv") / "dropin_driver"); lib = os.path.join(ROOT, "blockmaze_amd", "lib")
-    subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(ROOT, "tests", "dropin_driver.c"), "-L" + lib, "-lzk_mint", "-lzk_send", "-lzk_deposit", "-lzk_redeem", "-lff", "-lsnark",
+    subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(ROOT, "tests", "dropin_driver.c"), "-L" + lib, "-lzk_mint", "-lzk_send", "-lzk_deposit", "-lzk_redeem", "-lff", "-lsnark", "-lpthread",
                            "-Wl,-rpath," + lib, "-Wl,-rpath-link," + os.path.join(ROOT, "blockmaze_amd")])     # the reference's cgo link line (zktx.go:4) minus gmp/stdc++
     return exe
+
+def test_c_driver_merkle_roots_through_the_deposit_library(driver):
+    """genRoot over 0, 1 and 16 leaves through the thin libzk_deposit.so exactly as the cgo side calls it (zktx.go:611 GenRT) — the SURVEY §8c goldens"""
+    import subprocess
+    out = dict(l.split() for l in subprocess.run([driver, "roots"], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert out["genRoot0"] == "8eb3c27b218349e6b9b6037b8042f3751ee820e8a0319a1bda439b247456088c"
+    assert out["genRoot1"] == "a19a0d1fac447f65d273d5831827ccfa96c193a1b39618a23d11628d48e27a9e"
+    assert out["genRoot16"] == "2630f036430a646118dbb95ba55e9e3803e35a680398d01f9942513ebbb7911e"
 
 def test_c_driver_links_like_cgo_and_hashes_match(driver):
     import subprocess

@@ -139,12 +139,25 @@ def test_mint_redeem_deposit_full_size_against_libsnark(all_keys, tmp_path):
         legs.append("%s %s%.1f s" % (kind, "prover+verifier " if with_prover else "verifier ", time.time() - t0))
     record_leg("libsnark on the full-size mint / redeem / deposit keys, reference fixtures (" + ", ".join(legs) + ")")
 
+def _build_driver(tmp_path):
+    lib = os.path.join(ROOT, "blockmaze_amd", "lib"); exe = str(tmp_path / "drv")
+    subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(ROOT, "tests", "dropin_driver.c"), "-L" + lib, "-lzk_mint", "-lzk_send", "-lzk_deposit", "-lzk_redeem", "-lff", "-lsnark", "-lpthread", "-Wl,-rpath," + lib, "-Wl,-rpath-link," + os.path.join(ROOT, "blockmaze_amd")])
+    return exe
+
 def test_c_driver_send_through_thin_libraries(send_keys, tmp_path):
     """tests/dropin_driver.c linked with the reference's cgo link line: genSendproof + verifySendproof on the reference's send fixture"""
-    lib = os.path.join(ROOT, "blockmaze_amd", "lib"); exe = str(tmp_path / "drv")
-    subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(ROOT, "tests", "dropin_driver.c"), "-L" + lib, "-lzk_mint", "-lzk_send", "-lzk_deposit", "-lzk_redeem", "-lff", "-lsnark", "-Wl,-rpath," + lib, "-Wl,-rpath-link," + os.path.join(ROOT, "blockmaze_amd")])
-    out = subprocess.run([exe, "send"], capture_output=True, text=True, env=dict(os.environ, ZK_PRFKEY_DIR=str(send_keys))).stdout
+    out = subprocess.run([_build_driver(tmp_path), "send"], capture_output=True, text=True, env=dict(os.environ, ZK_PRFKEY_DIR=str(send_keys))).stdout
     assert "proof_len 512" in out and "verify 1" in out and "verify_wrong 0" in out and "head 0000000000" not in out
+
+def test_c_driver_all_circuits_and_threads(all_keys, tmp_path):
+    """the same C caller for mint, redeem and deposit (the fixtures of the reference's main.cpp files; deposit computes its root with genRoot(n = 16): the golden value of
+    SURVEY.md §8c) and from 8 pthreads at once, every thread proving and verifying all four circuits twice through the thin libzk_*.so — cgo calls arrive on arbitrary
+    OS threads (zktx.go:406-430)"""
+    exe = _build_driver(tmp_path); env = dict(os.environ, ZK_PRFKEY_DIR=str(all_keys))
+    for kind in ("mint", "redeem", "deposit"):
+        r = subprocess.run([exe, kind], capture_output=True, text=True, env=env); assert r.returncode == 0 and (kind + " ") in r.stdout and "proof_len 512" in r.stdout and "verify 1 verify_wrong 0" in r.stdout and "head 0000000000" not in r.stdout, (kind, r.stdout[-400:], r.stderr[-400:])
+        if kind == "deposit": assert "root 2630f036430a646118dbb95ba55e9e3803e35a680398d01f9942513ebbb7911e" in r.stdout
+    r = subprocess.run([exe, "threads"], capture_output=True, text=True, env=env, timeout=600); assert r.returncode == 0 and "threads_good 64 of 64" in r.stdout, (r.stdout[-600:], r.stderr[-600:])
 
 def test_msm_sharding_matches_unsharded(send_keys, golden_dir, tmp_path):
     """K7: the queries cut into 1, 2, 3 and 8 contiguous shards (here all on one GPU), partial records added on the host: same proof bytes"""
