@@ -285,7 +285,7 @@ struct Prover::Impl {
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
   std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; std::shared_ptr<DevBuf<uint32_t>> B_idx; DevBuf<Fe32> z, abc; DevBuf<uint8_t> packed; PinnedBuf<Fe32> z_host;
-  std::unique_ptr<SubmitWorker> workers[4];
+  std::unique_ptr<SubmitWorker> workers[4], scan_workers[4];
   // The submit thread of a witness MSM also waits for its stream and finishes the MSM on the host (Horner combine, or the host tail of msm_impl.hpp): four threads do that
   // side by side while the H chain is still running.  pending[j]: job j (order B2, L, A, B1) was posted and its result slot is not valid before workers[j]->wait().
   HG2 rB2; HG1 rL, rA, rB1; bool pending[4] = {false, false, false, false}, inline_result[4] = {false, false, false, false};
@@ -349,7 +349,8 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   uint8_t *pk = reinterpret_cast<uint8_t *>(p.z_host.get()); uint64_t *ones = (uint64_t *)pk, *other = ones + words; uint32_t *off = (uint32_t *)(other + words);
   const size_t vals_at = ((words * 20 + 31) / 32) * 32; Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
   uint64_t o1[4]; memcpy(o1, &one, 32); const uint64_t *zz = reinterpret_cast<const uint64_t *>(z) - 4;   // zz + 4 i = entry i of [ONE, z_1 .. z_n]; entry 0 is handled apart
-  constexpr size_t T = 4; const size_t cap_t = max_other / T; size_t used[T] = {0, 0, 0, 0}; bool fits[T] = {true, true, true, true};
+  static const size_t T = [] { const char *e = getenv("ZK_SCAN_THREADS"); int v = e ? atoi(e) : 4; return (size_t)(v < 1 ? 1 : v > 8 ? 8 : v); }();   // threads 1 .. 3 are the submit workers; more only with ZK_SCAN_THREADS
+  const size_t cap_t = max_other / T; size_t used[8] = {0}; bool fits[8] = {true, true, true, true, true, true, true, true};
   auto scan = [&](size_t t) { const size_t w0 = words * t / T, w1 = words * (t + 1) / T, base = t * cap_t; size_t n_other = 0;
     for (size_t w = w0; w < w1; w++) { uint64_t mo = 0, mx = 0; const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; off[w] = (uint32_t)(base + n_other);
       for (size_t i = lo ? lo : 1; i < hi; i++) { const uint64_t *v = zz + 4 * i;                                // branch-free classification of the block
@@ -360,10 +361,11 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
       ones[w] = mo; other[w] = mx; }
     used[t] = n_other; };
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
-  if (threaded && words >= 512) { for (size_t t = 1; t < T; t++) { if (!p.workers[t]) p.workers[t].reset(new SubmitWorker(p.lane)); p.workers[t]->post([&scan, t] { scan(t); }); } scan(0); for (size_t t = 1; t < T; t++) p.workers[t]->wait(); }
+  auto worker = [&](size_t t) -> SubmitWorker & { std::unique_ptr<SubmitWorker> &w = t < 4 ? p.workers[t] : p.scan_workers[t - 4]; if (!w) w.reset(new SubmitWorker(p.lane)); return *w; };
+  if (threaded && words >= 512) { for (size_t t = 1; t < T; t++) worker(t).post([&scan, t] { scan(t); }); scan(0); for (size_t t = 1; t < T; t++) worker(t).wait(); }
   else for (size_t t = 0; t < T; t++) scan(t);
   static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;   // (test switch: the plain-copy branch below, which no BlockMaze assignment reaches on its own)
-  const bool compact = fits[0] && fits[1] && fits[2] && fits[3] && !force_dense;
+  bool compact = !force_dense; for (size_t t = 0; t < T; t++) compact = compact && fits[t];
   if (compact) { upload_async(p.packed.get(), pk, vals_at); for (size_t t = 0; t < T; t++) if (used[t]) upload_async(p.packed.get() + vals_at + 32 * t * cap_t, pk + vals_at + 32 * t * cap_t, 32 * used[t]);
     expand_witness_dev(p.packed.get(), words, one, n, p.z.get()); }
   else { Fe32 *h = p.z_host.get(); h[0] = one; memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * n); }      // dense assignment: plain copy
@@ -413,14 +415,16 @@ static void enqueue_all(Prover::Impl &p) {
   const int job_stream[4] = {3, 1, 0, 2};                       // the auxiliary stream each MSM was bound to in the constructor (set_stream)
   const bool use_threads = threaded;
   p.settle_all_quietly();                                       // (nothing is pending unless an earlier proof was abandoned by an exception)
-  auto release = [&](int point) { bool any = false; for (int j = 0; j < 4; j++) any |= start[j] == point; if (!any) return; gpu_fork_record();      // one event; each stream's wait is issued by the thread that feeds it
+  // phase 0: record the fork event (one event; each stream's wait is issued by the thread that feeds it); phase 1: hand the jobs to the submit threads.  The main chain's
+  // next launch goes in between: waking the threads costs this one ~10 us, which the device would otherwise spend idle behind the row kernel
+  auto release = [&](int point, int phase = 2) { bool any = false; for (int j = 0; j < 4; j++) any |= start[j] == point; if (!any) return; if (phase != 1) gpu_fork_record(); if (phase == 0) return;
     for (int j = 0; j < 4; j++) if (start[j] == point && !skip_w && job_used[j]) { const int sj = job_stream[j]; std::function<void()> job = jobs[j], fin = finish[j];
       if (use_threads) { if (!p.workers[j]) p.workers[j].reset(new SubmitWorker(p.lane)); p.workers[j]->post([sj, job, fin] { gpu_fork_wait(sj); job(); fin(); }); p.pending[j] = true; } else { gpu_fork_wait(sj); job(); p.inline_result[j] = true; if (j == 2 && p.pair_AL) p.inline_result[1] = true; if (j == 3 && p.pair_B) p.inline_result[0] = true; } } };
   release(0);
-  p.cs->eval(p.z.get(), p.abc.get(), p.m); release(1);
+  p.cs->eval(p.z.get(), p.abc.get(), p.m); release(1, 0);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
   const int nvec = p.c_fold ? 2 : 3;                          // A, B (and C unless it is folded into the L query)
-  if (!skip_n) p.dom->ifft(p.abc.get(), nvec, p.m); release(2);
+  if (!skip_n) p.dom->ifft(p.abc.get(), nvec, p.m); release(1, 1); release(2);
   const bool fuse_pointwise = p.c_fold && p.H->one_pass_sort();   // zinv*a*b is then formed inside the H query's sort kernel
   if (!skip_n) p.dom->coset_fft(p.abc.get(), nvec, p.m); if (!fuse_pointwise) p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.c_fold ? nullptr : p.abc.get() + 2 * p.m); release(3);
   if (!p.h_lagrange) p.dom->icoset_fft(p.abc.get(), 1, p.m);
@@ -451,7 +455,8 @@ bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
   p.settle(3); HG1 gB1 = p.beta_g1.add(p.rB1).add(t.s_delta); c_part = c_part.add(gB1.mul(t.r.l)); double tb1 = now_ms();                                // :491 and r*B1 of :495
   p.settle(0); HG2 gB2 = p.beta_g2.add(p.rB2).add(t.s_delta2); out.B = raw_of(gB2); double tb2 = now_ms();                                              // :492
   gpu_sync(); double t3 = now_ms();
-  if (trace) fprintf(stderr, "trace: enqueue %.3f A %.3f L %.3f B1 %.3f B2 %.3f sync %.3f\n", t2 - t1, ta - t1, tl - t1, tb1 - t1, tb2 - t1, t3 - t1);
+  if (trace) { timespec bt; clock_gettime(CLOCK_BOOTTIME, &bt); const double boot_ms = bt.tv_sec * 1e3 + bt.tv_nsec * 1e-6;   // (rocprofv3's kernel trace is stamped with CLOCK_BOOTTIME: t1_boot places this proof on its time line)
+    fprintf(stderr, "trace: enqueue %.3f A %.3f L %.3f B1 %.3f B2 %.3f sync %.3f upload %.3f t1_boot %.4f\n", t2 - t1, ta - t1, tl - t1, tb1 - t1, tb2 - t1, t3 - t1, last.upload_ms, boot_ms - (now_ms() - t1)); }
   if (!p.cs->check_result()) return false;
   out.C = raw_of(p.H->result().add(c_part)); double t4 = now_ms();                                                                                    // :495
   last.qap_ms = t2 - t1; last.msm_ms = t3 - t1; last.finish_ms = t4 - t3; last.total_ms = last.upload_ms + (t4 - t1); return true;
