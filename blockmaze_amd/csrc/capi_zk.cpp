@@ -132,9 +132,22 @@ template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
   } catch (const std::exception &e) { zkgpu_set_error(e.what()); fprintf(stderr, "libzkgpu: %s\n", e.what()); return dup_string(proof_to_hex(default_proof())); }
   catch (...) { zkgpu_set_error("unknown error"); return dup_string(proof_to_hex(default_proof())); }
 }
+// The verdicts for m proofs of ONE circuit kind — where every verification of the cgo layer ends up, the single-proof verifyXproof symbols (m = 1) and verifyBatch alike.
+// From ZK_VERIFY_GPU_MIN proofs on (default 1: since kernel K9 keeps its values on 29-bit limbs a proof takes 2.1 ms on ONE compute unit of the device, 2.5 ms on a host
+// core) the records go to the device in one launch — one workgroup per proof, concurrent callers on separate streams (gpu_verify.hip) —, otherwise, or when the process
+// sees no device, to the prepared host verifier.  res[j]: 1 accept, 0 reject.  A record the device hands back (input accumulator at infinity) is decided by the host verifier.
+void verify_group(CircuitKind kind, const Proof *ps, const uint8_t *parsed, const Fe32 *inputs, size_t ni, size_t m, uint8_t *res) {
+  static const size_t gpu_min = [] { const char *e = getenv("ZK_VERIFY_GPU_MIN"); long v = e ? atol(e) : 1; return (size_t)(v < 1 ? 1 : v); }();
+  const std::string path = key_path(kind, false);
+  if (m >= gpu_min && gpu_available()) { std::shared_ptr<BatchVerifier> v; { std::lock_guard<std::mutex> lk(g_gpu_mutex); v = gpu_verifier_for_path(path); }   // (building a key's verifier is serialised; using it is not)
+    if (v->num_inputs() == ni) { v->verify(ps, inputs, m, res); for (size_t j = 0; j < m; j++) if (res[j] == 2) res[j] = parsed[j] && verify_proof(*vk_for_path(path), inputs + j * ni, ni, ps[j]); }
+    else for (size_t j = 0; j < m; j++) res[j] = 0; }                                                                       // strong IC: a wrong input count rejects (r1cs_gg_ppzksnark.tcc:584-590)
+  else { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(path); for (size_t j = 0; j < m; j++) res[j] = parsed[j] && verify_proof(*vk, inputs + j * ni, ni, ps[j]); }
+  for (size_t j = 0; j < m; j++) res[j] = parsed[j] && res[j] == 1;
+}
 bool verify(CircuitKind k, const char *data, const std::vector<bool> &public_bits) {
   bool ok = false;
-  try { Proof p; if (data && strnlen(data, 512) == 512 && proof_from_hex(data, p)) { std::vector<Fe32> inputs = pack_public_bits(public_bits); ok = verify_proof(*vk_for(k), inputs.data(), inputs.size(), p); } }
+  try { Proof p; if (data && strnlen(data, 512) == 512 && proof_from_hex(data, p)) { std::vector<Fe32> inputs = pack_public_bits(public_bits); uint8_t parsed = 1, res = 0; verify_group(k, &p, &parsed, inputs.data(), inputs.size(), 1, &res); ok = res == 1; } }
   catch (const std::exception &e) { zkgpu_set_error(e.what()); fprintf(stderr, "libzkgpu: %s\n", e.what()); ok = false; } catch (...) { ok = false; }
   printf("Verifying %s proof %s!!!\n", circuit_name(k), ok ? "successfully" : "unsuccessfully"); fflush(stdout); return ok;
 }
@@ -306,7 +319,7 @@ int zkgpu_profile_enable(int on) { return guarded([&] { profile_enable(on != 0);
 int zkgpu_profile_report(char *buf, size_t cap) { return guarded([&] { std::string r = profile_report(); if (r.size() + 1 > cap) return ZKGPU_ERR_ARG; memcpy(buf, r.c_str(), r.size() + 1); return ZKGPU_OK; }); }
 int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs) { int res = 0; int rc = guarded_host([&] { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(vk_path); Proof p;   // host verifier on the prepared key (cached by the file's size and mtime)
   if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK; } res = verify_proof(*vk, (const Fe32 *)inputs, n_inputs, p) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
-/* test entry: the decision of the GPU verifier's schedule (verify_sched.hpp), interpreted on the HOST — no device needed; stats (optional): rounds, slots, products, linear operations, constants */
+/* test entry: the decision of the GPU verifier's schedule (verify_sched.hpp), interpreted on the HOST — no device needed; stats[8] (optional): rounds, slots, products, linear operations, constants, rounds of products / eight-lane sums / one-lane sums */
 int zkgpu_test_verify_schedule(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs, uint32_t *stats) { int res = 0; int rc = guarded_host([&] { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(vk_path); Proof p;
   if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK; } res = verify_by_schedule_on_host(*vk, (const Fe32 *)inputs, n_inputs, p, stats) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
 // batched verification on the GPU (kernel K9).  proofs_hex: n * 512 characters; inputs: n * n_inputs canonical field elements; ok[i] = 1 accept / 0 reject
@@ -322,26 +335,20 @@ int zkgpu_verify_batch(const char *vk_path, const char *proofs_hex, const uint8_
   return ZKGPU_OK; }); }
 // ---- verifyBatch: the optional batch entry of include/zk_batch.h ---------------------------------------------------
 // go-ethereum checks every ZK transaction twice, once in the pool and once in the block (core/tx_pool.go:612-645, core/state_processor.go:106-163), one cgo call
-// and one key load per proof.  A block's worth of proofs in ONE call is what the GPU verifier is for (kernel K9, since round 3 one workgroup per proof interpreting the
-// operation schedule of verify_sched.hpp: 4.0 ms per launch up to a few hundred proofs, 15,000 proofs/s at 64, 110,000 at 512): from ZK_VERIFY_GPU_MIN proofs of a kind
-// on (default 3: the host loop below costs 2.5 ms per proof on one thread) the kind's records go to the device in one launch, smaller groups are checked on the host.
-// Decisions are exactly those of the kind's verifyXproof symbol.  The verifyXproof symbols themselves stay on the prepared host verifier: one proof is 2.5 ms there
-// against 4.0 ms on the device, and go-ethereum issues them one at a time under its pool lock.
+// and one key load per proof.  A block's worth of proofs in ONE call is what the GPU verifier is for (kernel K9: one workgroup per proof interpreting the operation
+// schedule of verify_sched.hpp on 29-bit limbs — 2.1 ms per launch up to 256 proofs, 31,000 proofs/s at 64, 124,000 at 512): the records are grouped by circuit kind and
+// every group goes through verify_group above, exactly like the kind's verifyXproof symbol.
 int verifyBatch(const zk_verify_item *items, int n, unsigned char *ok) {
   if (n < 0 || (n && (!items || !ok))) return -1;
   try {
-    static const size_t gpu_min = [] { const char *e = getenv("ZK_VERIFY_GPU_MIN"); long v = e ? atol(e) : 3; return (size_t)(v < 1 ? 1 : v); }();
     int accepted = 0; std::vector<int> idx[4];
     for (int i = 0; i < n; i++) { ok[i] = 0; if (items[i].kind >= 0 && items[i].kind <= 3) idx[items[i].kind].push_back(i); }
     for (int k = 0; k < 4; k++) { if (idx[k].empty()) continue; const CircuitKind kind = (CircuitKind)k; const size_t m = idx[k].size();
       std::vector<Proof> ps(m); std::vector<uint8_t> parsed(m), res(m, 0); std::vector<Fe32> inputs; size_t ni = 0;
       for (size_t j = 0; j < m; j++) { const zk_verify_item &it = items[idx[k][j]]; parsed[j] = it.proof && strnlen(it.proof, 512) == 512 && proof_from_hex(it.proof, ps[j]); if (!parsed[j]) memset(&ps[j], 0, sizeof(Proof));
         std::vector<Fe32> in = pack_public_bits(public_bits(kind, it.args, it.value_s)); ni = in.size(); inputs.insert(inputs.end(), in.begin(), in.end()); }
-      const std::string path = key_path(kind, false);
-      if (m >= gpu_min && gpu_available()) { std::lock_guard<std::mutex> lk(g_gpu_mutex); std::shared_ptr<BatchVerifier> v = gpu_verifier_for_path(path);
-        if (v->num_inputs() == ni) { v->verify(ps.data(), inputs.data(), m, res.data()); for (size_t j = 0; j < m; j++) if (res[j] == 2) res[j] = parsed[j] && verify_proof(*vk_for_path(path), inputs.data() + j * ni, ni, ps[j]); } }
-      else { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(path); for (size_t j = 0; j < m; j++) res[j] = parsed[j] && verify_proof(*vk, inputs.data() + j * ni, ni, ps[j]); }
-      for (size_t j = 0; j < m; j++) { ok[idx[k][j]] = parsed[j] && res[j]; accepted += ok[idx[k][j]]; } }
+      verify_group(kind, ps.data(), parsed.data(), inputs.data(), ni, m, res.data());
+      for (size_t j = 0; j < m; j++) { ok[idx[k][j]] = res[j]; accepted += res[j]; } }
     return accepted;
   } catch (const std::exception &e) { zkgpu_set_error(e.what()); fprintf(stderr, "libzkgpu: verifyBatch: %s\n", e.what()); for (int i = 0; i < n; i++) ok[i] = 0; return -1; }
   catch (...) { for (int i = 0; i < n; i++) ok[i] = 0; return -1; }

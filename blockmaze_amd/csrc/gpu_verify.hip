@@ -1,5 +1,8 @@
 // Host driver of the batched GPU verifier (kernel K9, pairing.cuh): assembles the bytecode and the per-key tables once, then checks any number of proofs per launch.
+#include <atomic>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include "gpu_internal.hpp"
 #include "pairing.cuh"
 #include "pairing_host.hpp"
@@ -14,8 +17,15 @@ static const uint64_t ATE_LOOP[2] = {0x9d797039be763ba8ull, 0x1ull};          //
 // typed view of a byte allocation (DevBuf is instantiated for the raw interface types only)
 template <class T> struct DevArr { DevBuf<uint8_t> b; DevArr() = default; explicit DevArr(size_t n) : b(n * sizeof(T)) {} T *get() const { return (T *)b.get(); }
   void upload(const T *h, size_t n) { b.upload((const uint8_t *)h, n * sizeof(T)); } };
+// One small verification in flight: its own stream, pinned staging and device buffers for up to CTX_CAP proofs — go-ethereum's verifyXproof calls arrive one proof at a
+// time from many threads, and a proof occupies ONE compute unit for ~2 ms: several contexts let them overlap instead of queueing behind one stream.
+struct VerifyCtx { std::mutex m; hipStream_t s = nullptr; uint8_t *h = nullptr; DevBuf<uint8_t> d; };
 struct BatchVerifier::Impl {
-  size_t n_inputs = 0; DevBuf<uint32_t> sched_prog; DevArr<Fq> sched_consts; SchedInfo si{}; DevBuf<uint32_t> prog; DevArr<EllCoeffsDev> gamma, delta; DevArr<FrobeniusDev> frob; DevArr<Fq12> alpha_beta; DevArr<Affine<Fq>> tables; Affine<Fq> ic0; VerifyConsts K; size_t prog_len = 0;
+  size_t n_inputs = 0; DevBuf<uint32_t> sched_prog, sched_consts; SchedInfo si{}; DevBuf<uint32_t> prog; DevArr<EllCoeffsDev> gamma, delta; DevArr<FrobeniusDev> frob; DevArr<Fq12> alpha_beta; DevArr<Affine<Fq>> tables; Affine<Fq> ic0; VerifyConsts K; size_t prog_len = 0;
+  static constexpr size_t CTX_CAP = 64; std::vector<std::unique_ptr<VerifyCtx>> ctxs; std::atomic<unsigned> next_ctx{0}; std::mutex big; size_t lds = 0;
+  // layout of a context's staging area (host and device alike): proofs | inputs | -acc | verdicts
+  size_t off_in() const { return CTX_CAP * sizeof(VerifyItem); } size_t off_acc() const { return off_in() + CTX_CAP * (n_inputs + 1) * sizeof(Fe32); } size_t off_ok() const { return off_acc() + CTX_CAP * sizeof(NegAcc3); } size_t ctx_bytes() const { return off_ok() + CTX_CAP; }
+  ~Impl() { for (auto &c : ctxs) { if (c->h) hipHostFree(c->h); if (c->s) hipStreamDestroy(c->s); } }
 };
 
 // registers of the program
@@ -67,11 +77,15 @@ BatchVerifier::BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2Affine
   host::G2Precomp pg = host::precompute_g2(fq2_of(gamma_g2.x0, gamma_g2.x1), fq2_of(gamma_g2.y0, gamma_g2.y1)), pd = host::precompute_g2(fq2_of(delta_g2.x0, delta_g2.x1), fq2_of(delta_g2.y0, delta_g2.y1));
   std::vector<EllCoeffsDev> lg(pg.size()), ld(pd.size()); for (size_t i = 0; i < pg.size(); i++) { lg[i] = to_dev<EllCoeffsDev>(pg[i]); ld[i] = to_dev<EllCoeffsDev>(pd[i]); }
   d.gamma = DevArr<EllCoeffsDev>(lg.size()); d.gamma.upload(lg.data(), lg.size()); d.delta = DevArr<EllCoeffsDev>(ld.size()); d.delta.upload(ld.data(), ld.size());
-  { vsched::Schedule sc = vsched::build(alpha_g1_beta_g2, pg, pd);   // the one-wave-per-proof kernel's schedule (verify_sched.hpp)
-    sc.prog.resize(sc.prog.size() + 4 + 256 * 16, 0u);   // (the kernel prefetches one round ahead: one round's worth of padding)
-    d.sched_prog = DevBuf<uint32_t>(sc.prog.size()); d.sched_prog.upload(sc.prog.data(), sc.prog.size()); d.sched_consts = DevArr<Fq>(sc.consts.size()); d.sched_consts.upload((const Fq *)sc.consts.data(), sc.consts.size());
-    d.si.n_rounds = sc.n_rounds; d.si.n_slots = sc.n_slots; d.si.n_consts = (uint32_t)sc.consts.size(); d.si.alpha_beta_const = sc.alpha_beta_const; for (int k = 0; k < 16; k++) d.si.out_slot[k] = sc.out_slot[k];
-    if (((size_t)sc.n_slots + sc.consts.size()) * 32 > 160 * 1024) throw GpuError("verify: the schedule needs more LDS than a CU has"); }
+  { vsched::Schedule sc = vsched::build(alpha_g1_beta_g2, pg, pd);   // the workgroup-per-proof kernel's schedule (verify_sched.hpp)
+    sc.prog.resize(sc.prog.size() + 4 + 256 * vsched::WPL, 0u);   // (the kernel prefetches one round ahead: one round's worth of padding)
+    const std::vector<uint32_t> c29 = vsched::consts29(sc);
+    d.sched_prog = DevBuf<uint32_t>(sc.prog.size()); d.sched_prog.upload(sc.prog.data(), sc.prog.size()); d.sched_consts = DevBuf<uint32_t>(c29.size()); d.sched_consts.upload(c29.data(), c29.size());
+    d.si.n_rounds = sc.n_rounds; d.si.n_slots = sc.n_slots; d.si.n_consts = (uint32_t)sc.consts.size(); for (int k = 0; k < 16; k++) d.si.out_slot[k] = sc.out_slot[k];
+    d.lds = ((size_t)sc.n_slots + sc.consts.size()) * l29::STRIDE * 4; if (d.lds > 160 * 1024) throw GpuError("verify: the schedule needs more LDS than a CU has");
+    static std::once_flag attr; std::call_once(attr, [&] { HIP_CHECK(hipFuncSetAttribute((const void *)k_verify_sched29, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }); }
+  { static const int n_ctx = [] { const char *e = getenv("ZK_VERIFY_STREAMS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : v > 32 ? 32 : v; }();
+    for (int k = 0; k < n_ctx; k++) { std::unique_ptr<VerifyCtx> c(new VerifyCtx); HIP_CHECK(hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking)); HIP_CHECK(hipHostMalloc((void **)&c->h, d.ctx_bytes())); c->d = DevBuf<uint8_t>(d.ctx_bytes()); d.ctxs.push_back(std::move(c)); } }
   std::vector<uint32_t> prog = assemble_program(pg.size()); d.prog_len = prog.size(); d.prog = DevBuf<uint32_t>(prog.size()); d.prog.upload(prog.data(), prog.size());
   FrobeniusDev fr = to_dev<FrobeniusDev>(host::frobenius_tables()); d.frob = DevArr<FrobeniusDev>(1); d.frob.upload(&fr, 1);
   Fq12 ab = to_dev<Fq12>(alpha_g1_beta_g2); d.alpha_beta = DevArr<Fq12>(1); d.alpha_beta.upload(&ab, 1);
@@ -93,19 +107,29 @@ BatchVerifier::~BatchVerifier() = default;
 size_t BatchVerifier::num_inputs() const { return impl->n_inputs; }
 size_t BatchVerifier::program_length() const { return impl->prog_len; }
 void BatchVerifier::verify(const void *proofs_mont, const Fe32 *inputs_canonical, size_t n, uint8_t *ok) {
-  if (!n) return; Impl &d = *impl; hipStream_t s = gpu().stream; static_assert(sizeof(VerifyItem) == 256, "proof record");
+  if (!n) return; Impl &d = *impl; static_assert(sizeof(VerifyItem) == 256, "proof record"); hipStream_t s = gpu().stream;   // (gpu() also selects the device for this thread)
+  if (n <= Impl::CTX_CAP) {   // a few proofs: one of the small contexts, nothing allocated, everything asynchronous on the context's stream until the one synchronisation
+    VerifyCtx *c = nullptr; for (size_t k = 0; k < d.ctxs.size() && !c; k++) { VerifyCtx *t = d.ctxs[(d.next_ctx.fetch_add(1) + k) % d.ctxs.size()].get(); if (t->m.try_lock()) c = t; }
+    if (!c) { c = d.ctxs[d.next_ctx.fetch_add(1) % d.ctxs.size()].get(); c->m.lock(); }
+    std::lock_guard<std::mutex> lk(c->m, std::adopt_lock); uint8_t *dv = c->d.get();
+    memcpy(c->h, proofs_mont, n * sizeof(VerifyItem)); if (d.n_inputs) memcpy(c->h + d.off_in(), inputs_canonical, n * d.n_inputs * sizeof(Fe32));
+    HIP_CHECK(hipMemcpyAsync(dv, c->h, n * sizeof(VerifyItem), hipMemcpyHostToDevice, c->s)); if (d.n_inputs) HIP_CHECK(hipMemcpyAsync(dv + d.off_in(), c->h + d.off_in(), n * d.n_inputs * sizeof(Fe32), hipMemcpyHostToDevice, c->s));
+    { Stage st("verify.batch", c->s);
+      hipLaunchKernelGGL(k_verify_acc_wave, dim3((unsigned)n), dim3(64), 0, c->s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)(dv + d.off_in()), (uint32_t)d.n_inputs, (uint32_t)n, (NegAcc3 *)(dv + d.off_acc()));
+      hipLaunchKernelGGL(k_verify_sched29, dim3((unsigned)n), dim3(256), d.lds, c->s, d.sched_prog.get(), (const uint4 *)d.sched_consts.get(), (const VerifyItem *)dv, (const NegAcc3 *)(dv + d.off_acc()), (uint32_t)n, d.si, dv + d.off_ok()); }
+    HIP_CHECK(hipGetLastError()); HIP_CHECK(hipMemcpyAsync(c->h + d.off_ok(), dv + d.off_ok(), n, hipMemcpyDeviceToHost, c->s)); HIP_CHECK(hipStreamSynchronize(c->s)); memcpy(ok, c->h + d.off_ok(), n); return; }
+  std::lock_guard<std::mutex> lk(d.big);
   DevArr<VerifyItem> items(n); DevBuf<Fe32> in(n * d.n_inputs + 1); DevArr<Affine<Fq>> acc(n); DevBuf<uint8_t> out(n);
   items.upload((const VerifyItem *)proofs_mont, n); if (d.n_inputs) in.upload(inputs_canonical, n * d.n_inputs);
   Stage st("verify.batch");
-  // up to WAVE_MAX proofs: one wave each (latency of a proof ~ the schedule's rounds); beyond that the lane-per-proof kernel, whose 46 ms floor is then amortised over thousands
-  static const size_t wave_max = [] { const char *e = getenv("ZK_VERIFY_WAVE_MAX"); long v = e ? atol(e) : 2048; return (size_t)(v < 0 ? 0 : v); }();   // (measured: 4.3 ms per 512 proofs here, 25 ms for anything up to 16,384 there)
+  // up to WAVE_MAX proofs: one workgroup each (latency of a proof ~ the schedule's rounds, 256 proofs at a time on the chip's 256 CUs); beyond that the lane-per-proof kernel, whose 25 ms floor is then amortised over thousands
+  static const size_t wave_max = [] { const char *e = getenv("ZK_VERIFY_WAVE_MAX"); long v = e ? atol(e) : 2048; return (size_t)(v < 0 ? 0 : v); }();
   if (n <= wave_max) { DevArr<NegAcc3> acc3(n);
-    static bool attr_set = false; const size_t lds = ((size_t)d.si.n_slots + d.si.n_consts) * 32; if (!attr_set) { HIP_CHECK(hipFuncSetAttribute((const void *)k_verify_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
     hipLaunchKernelGGL(k_verify_acc_wave, dim3((unsigned)n), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(), (uint32_t)d.n_inputs, (uint32_t)n, acc3.get());
-    hipLaunchKernelGGL(k_verify_sched, dim3((unsigned)n), dim3(256), lds, s, d.sched_prog.get(), (const uint4 *)d.sched_consts.get(), items.get(), acc3.get(), (uint32_t)n, d.si, out.get()); HIP_CHECK(hipStreamSynchronize(s));   // (acc3 lives until the kernels are done)
+    hipLaunchKernelGGL(k_verify_sched29, dim3((unsigned)n), dim3(256), d.lds, s, d.sched_prog.get(), (const uint4 *)d.sched_consts.get(), items.get(), acc3.get(), (uint32_t)n, d.si, out.get()); HIP_CHECK(hipStreamSynchronize(s));   // (acc3 lives until the kernels are done)
   } else {
-  hipLaunchKernelGGL(k_verify_acc, dim3(cdiv(n, 64)), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(), (uint32_t)d.n_inputs, (uint32_t)n, acc.get());
-  hipLaunchKernelGGL(k_verify_batch, dim3(cdiv(n, 64)), dim3(64), 0, s, d.prog.get(), items.get(), acc.get(), d.gamma.get(), d.delta.get(), d.frob.get(), d.alpha_beta.get(), d.K, (uint32_t)n, out.get());
+    hipLaunchKernelGGL(k_verify_acc, dim3(cdiv(n, 64)), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(), (uint32_t)d.n_inputs, (uint32_t)n, acc.get());
+    hipLaunchKernelGGL(k_verify_batch, dim3(cdiv(n, 64)), dim3(64), 0, s, d.prog.get(), items.get(), acc.get(), d.gamma.get(), d.delta.get(), d.frob.get(), d.alpha_beta.get(), d.K, (uint32_t)n, out.get());
   }
   HIP_CHECK(hipGetLastError()); out.download(ok, n);
 }

@@ -506,10 +506,10 @@ bool verify_proof(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_
 
 // The decision of verify_proof() taken by the GPU verifier's SCHEDULE (verify_sched.hpp) interpreted on the host: what kernel K9 computes, without a GPU.  Test entry
 // (zkgpu_test_verify_schedule): the schedule is checked against the host verifier and the oracle on the CPU before any device runs it.
-// stats: rounds, slots, products, linear operations, constants.
-bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t stats[5]) {
+// stats: rounds, slots, products, linear operations, constants, then the rounds of products / eight-lane sums / one-lane sums.
+bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t stats[8]) {
   const VerifyingKeyHost &vk = pvk.vk; vsched::Schedule S = vsched::build(vk.alpha_g1_beta_g2, pvk.gamma, pvk.delta);
-  if (stats) { stats[0] = S.n_rounds; stats[1] = S.n_slots; stats[2] = S.n_mul; stats[3] = S.n_lin; stats[4] = (uint32_t)S.consts.size(); }
+  if (stats) { stats[0] = S.n_rounds; stats[1] = S.n_slots; stats[2] = S.n_mul; stats[3] = S.n_lin; stats[4] = (uint32_t)S.consts.size(); stats[5] = S.rounds_of_kind[vsched::K_MUL]; stats[6] = S.rounds_of_kind[vsched::K_LIN8]; stats[7] = S.rounds_of_kind[vsched::K_LIN1]; }
   if (vk.IC.size() != n_inputs + 1) return false;
   HG1 acc = g1_of(vk.IC[0]);
   for (size_t j = 0; j < n_inputs; j++) { const uint8_t *b = reinterpret_cast<const uint8_t *>(&inputs[j]);
@@ -520,8 +520,11 @@ bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inp
   in[vsched::IN_AX] = fq_of(proof.A.x); in[vsched::IN_AY] = fq_of(proof.A.y); in[vsched::IN_BX0] = fq_of(proof.B.x0); in[vsched::IN_BX1] = fq_of(proof.B.x1); in[vsched::IN_BY0] = fq_of(proof.B.y0); in[vsched::IN_BY1] = fq_of(proof.B.y1);
   in[vsched::IN_CX] = fq_of(proof.C.x); in[vsched::IN_CY] = fq_of(proof.C.y); in[vsched::IN_NACCX] = accx; in[vsched::IN_NACCY] = accy.neg(); in[vsched::IN_NACCW] = HFq::one();
   std::vector<HFq> out = vsched::simulate(S, in); bool ok = true;
-  for (int k = 0; k < vsched::N_RESULT; k++) ok = ok && out[k] == S.consts[S.alpha_beta_const + k];
-  for (int k = 0; k < vsched::N_CHECK; k++) ok = ok && out[vsched::N_RESULT + k].is_zero();
+  for (int k = 0; k < vsched::N_RESULT + vsched::N_CHECK; k++) ok = ok && out[k].is_zero();                                    // the GT value minus alpha_g1_beta_g2, then the on-curve residues
+  // ... and the same program on the kernel's own limb arithmetic (every bound asserted on the way): value by value the same verdicts
+  uint32_t words[vsched::N_INPUTS][8]; for (int i = 0; i < vsched::N_INPUTS; i++) memcpy(words[i], in[i].l, 32);
+  std::vector<bool> zero29 = vsched::simulate29(S, words);
+  for (int k = 0; k < vsched::N_RESULT + vsched::N_CHECK; k++) if (zero29[k] != out[k].is_zero()) throw std::runtime_error("verify schedule: the 29-bit model and the field model disagree on output " + std::to_string(k));
   return ok;
 }
 std::unique_ptr<BatchVerifier> make_batch_verifier(const VerifyingKeyHost &vk) { return std::unique_ptr<BatchVerifier>(new BatchVerifier(vk.alpha_g1_beta_g2, vk.gamma_g2, vk.delta_g2, vk.IC.data(), vk.IC.size())); }

@@ -88,7 +88,7 @@ struct PreparedVerifyingKey { VerifyingKeyHost vk; host::G2Precomp gamma, delta;
 std::shared_ptr<PreparedVerifyingKey> prepare_verifying_key(const VerifyingKeyHost &vk);
 bool verify_proof(const PreparedVerifyingKey &pvk, const Fe32 *inputs /* canonical */, size_t n_inputs, const Proof &proof);
 
-bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t stats[5]);   // the GPU verifier's schedule interpreted on the host (test entry)
+bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t stats[8]);   // the GPU verifier's schedule interpreted on the host (test entry)
 // the same decision for n proofs at once on the GPU (kernel K9): one BatchVerifier per verifying key
 std::unique_ptr<BatchVerifier> make_batch_verifier(const VerifyingKeyHost &vk);
 static_assert(sizeof(Proof) == 256, "proof record");

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include "curve.cuh"
 
+#include "field29.cuh"
 namespace zk {
 
 constexpr int MSM_MAX_WINDOWS = 64;
@@ -305,7 +306,6 @@ __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *_
 // its 36 limbs; k_hacc_combine29 adds a bucket's pieces on 29-bit limbs too and converts the sum (one product per coordinate with 2^256 mod p) to the 8 x 32-bit form
 // the weighted bucket sum reads.  Operand = +-accumulator (P = 0) is not looked for in the loop: it leaves ZZ = 0 (mod p) for good, which the combine notices and
 // reports like an overflow of the sort.
-#include "field29_gfx950.inc"
 struct XYZZ29 { Fq29 X, Y, ZZ, ZZZ;
   // madd-2008-s in two steps, so that the caller can start the NEXT point's gather between them, into the registers this point's coordinates just left (its words are
   // dead after the first two products; loading the next point at the top of the loop instead cost 16 registers and with them the fourth wave per SIMD).

@@ -16,6 +16,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "curve.cuh"
+#include "field29.cuh"
+#include "verify_sched.hpp"
 
 namespace zk {
 
@@ -127,53 +129,70 @@ __global__ void __launch_bounds__(64) k_verify_batch(const uint32_t *__restrict_
 }
 
 
-// ---- second generation: one WAVE per proof, interpreting the operation schedule of verify_sched.hpp ----------------------------------------------------------------
-// Every round of the schedule is one operation per lane on field elements held in LDS (or read from the key's table of constants): a Montgomery product, or a sum of
-// up to 12 terms +-2^s x.  The schedule is the same for every proof, so the workgroups of a launch never diverge; a proof costs ~2,900 rounds instead of 26,000 dependent
-// products on one lane.  Measured on MI355X (tools/verify_bench.py): 4.0 ms per launch for 1..512 proofs (one wave alone on a SIMD issues an instruction every ~7 cycles,
-// tools/valu_probe.hip, so a round of one 370-instruction product is 1.3 us whatever the other lanes do); 15,000 proofs/s at n = 64, 110,000 at n = 512.  What would make
-// it faster is fewer instructions per operation — the 29-bit limbs of the H accumulation (msm.cuh) with their carry-free sums — not more lanes.  ok[i]: 1 accept, 0 reject, 2 = the input accumulator was the point at infinity (the host verifier decides: the
-// gamma pairing is the identity then, which a fixed schedule cannot express).
-struct SchedInfo { uint32_t n_rounds, n_slots, n_consts, alpha_beta_const, out_slot[16]; };
+// ---- the schedule kernel: one 256-thread WORKGROUP per proof, interpreting the operation schedule of verify_sched.hpp -------------------------------------------
+// Every round of the schedule is one operation per lane on field elements held in LDS: a Montgomery product, or a linear combination with small integer coefficients
+// (LIN8: eight lanes per value — three terms each on 64-bit limb accumulators, one carry step, a DPP tree over the eight lanes, one Barrett-like step; LIN1: one lane,
+// up to three terms).  Values are nine 29-bit limbs (Montgomery radix 2^261, field29_gfx950.inc / l29:: in verify_sched.hpp): 162 multiply-adds per product and no
+// carry instruction, no modular correction per term of a sum.  The schedule is the same for every proof, so the workgroups of a launch never diverge.
+// History on MI355X (tools/verify_bench.py): one LANE per proof (round 1-2, the kernels above) 46 -> 25 ms per launch; one workgroup per proof on 8 x 32-bit limbs with
+// NAF sums (round 3, first half): 4.0 ms, 2,944 rounds of ~1.36 us — a wave alone on a SIMD issues an instruction every ~7 cycles (tools/valu_probe.hip), so a round is
+// as long as its longest lane's instruction count; this form: see profiles/r03_verify_batch.txt.
+// ok[i]: 1 accept, 0 reject, 2 = the input accumulator was the point at infinity (the host verifier decides: the gamma pairing is the identity then, which a fixed
+// schedule cannot express).
+struct SchedInfo { uint32_t n_rounds, n_slots, n_consts, out_slot[16]; };
 constexpr uint32_t VS_CONST_FLAG = 0x8000u;
-// LDS: [n_slots working values | n_consts constants of the key] — the constants are copied in once per proof (40 KB, coalesced), so that every operand of every round is
-// one LDS read: with the constants in global memory a round's critical path held a dependent global load (measured: 1.4 us per round instead of ~0.6).
+// LDS: [n_slots working values | n_consts constants of the key], 48 bytes each — the constants are copied in once per proof (coalesced), so that every operand of every
+// round is LDS reads: with the constants in global memory a round's critical path held a dependent global load (measured: 1.4 us per round instead of ~0.6).
 // The instruction words of round r + 1 are fetched while round r computes (prog is padded by one round's worth of words).
 struct NegAcc3 { Fq xw, nyw, w; };     // -acc = (x, -y) as (x w, -y w, w), w = ZZ ZZZ of the accumulation's extended Jacobian sum; w = 0: the point at infinity
 // barrier over the workgroup's LDS traffic only: __syncthreads() also drains the outstanding GLOBAL loads (s_waitcnt vmcnt(0)) — here the next round's instruction words,
 // fetched a round ahead precisely so that nobody waits for them
 __device__ __forceinline__ void vs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-static __global__ void __launch_bounds__(256) k_verify_sched(const uint32_t *__restrict__ prog, const uint4 *__restrict__ consts, const VerifyItem *__restrict__ items, const NegAcc3 *__restrict__ neg_acc, uint32_t n, SchedInfo si, uint8_t *__restrict__ ok) {
-  extern __shared__ uint32_t vs_lds[]; Fq *slots = reinterpret_cast<Fq *>(vs_lds);
+__device__ __forceinline__ void vs_load(const uint32_t *lds, uint32_t n_slots, uint32_t ref, uint32_t (&x)[9]) {
+  const uint32_t idx = (ref & VS_CONST_FLAG) ? n_slots + (ref & (VS_CONST_FLAG - 1)) : (ref & 0xffffu); const uint32_t *p = lds + idx * l29::STRIDE;
+  const uint4 q0 = *reinterpret_cast<const uint4 *>(p), q1 = *reinterpret_cast<const uint4 *>(p + 4); x[0] = q0.x; x[1] = q0.y; x[2] = q0.z; x[3] = q0.w; x[4] = q1.x; x[5] = q1.y; x[6] = q1.z; x[7] = q1.w; x[8] = p[8]; }
+__device__ __forceinline__ void vs_store(uint32_t *lds, uint32_t slot, const uint32_t (&x)[9]) { uint32_t *p = lds + slot * l29::STRIDE;
+  *reinterpret_cast<uint4 *>(p) = make_uint4(x[0], x[1], x[2], x[3]); *reinterpret_cast<uint4 *>(p + 4) = make_uint4(x[4], x[5], x[6], x[7]); p[8] = x[8]; }
+// lane i += lane i - N within its row of 16 (DPP row_shr; lanes without a source add 0)
+template <int N> __device__ __forceinline__ void vs_add_from_below(uint32_t (&l)[9]) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) l[i] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l[i], 0x110 + N, 0xf, 0xf, true); }
+static __global__ void __launch_bounds__(256) k_verify_sched29(const uint32_t *__restrict__ prog, const uint4 *__restrict__ consts, const VerifyItem *__restrict__ items, const NegAcc3 *__restrict__ neg_acc, uint32_t n, SchedInfo si, uint8_t *__restrict__ ok) {
+  extern __shared__ uint4 vs_lds4[]; uint32_t *lds = reinterpret_cast<uint32_t *>(vs_lds4);
   const uint32_t i = blockIdx.x, lane = threadIdx.x; if (i >= n) return;
-  { uint4 *dst = reinterpret_cast<uint4 *>(slots + si.n_slots); for (uint32_t k = lane; k < si.n_consts * 2; k += 256) dst[k] = consts[k]; }
+  { uint4 *dst = vs_lds4 + si.n_slots * (l29::STRIDE / 4); for (uint32_t k = lane; k < si.n_consts * (l29::STRIDE / 4); k += 256) dst[k] = consts[k]; }
   const VerifyItem &it = items[i]; const NegAcc3 nacc = neg_acc[i];
-  if (lane < 11) { Fq v = lane == 0 ? it.A.x : lane == 1 ? it.A.y : lane == 2 ? it.B.x.c0 : lane == 3 ? it.B.x.c1 : lane == 4 ? it.B.y.c0 : lane == 5 ? it.B.y.c1 : lane == 6 ? it.C.x : lane == 7 ? it.C.y : lane == 8 ? nacc.xw : lane == 9 ? nacc.nyw : nacc.w; slots[lane] = v; }   // vsched::IN_* order
+  if (lane < 11) { const Fq v = lane == 0 ? it.A.x : lane == 1 ? it.A.y : lane == 2 ? it.B.x.c0 : lane == 3 ? it.B.x.c1 : lane == 4 ? it.B.y.c0 : lane == 5 ? it.B.y.c1 : lane == 6 ? it.C.x : lane == 7 ? it.C.y : lane == 8 ? nacc.xw : lane == 9 ? nacc.nyw : nacc.w;   // vsched::IN_* order
+    uint32_t w[8], l[9];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = v.l[k];
+    l29::lift(w, l); vs_store(lds, lane, l); }
   __syncthreads();
-  auto at = [&](uint32_t ref) -> const Fq & { return slots[(ref & VS_CONST_FLAG) ? si.n_slots + (ref & (VS_CONST_FLAG - 1)) : ref]; };
-  auto fetch = [&](const uint32_t *base, uint32_t hd, uint4 &hq, uint4 &q0, uint4 &q1, uint4 &q2, uint4 &q3) { const uint32_t cnt = (hd >> 4) & 1023, wn = (hd >> 19) & 31; hq = *reinterpret_cast<const uint4 *>(base);
-    if (lane < cnt) { const uint4 *w = reinterpret_cast<const uint4 *>(base + 4 + lane * wn); q0 = w[0]; if (wn > 4) { q1 = w[1]; q2 = w[2]; q3 = w[3]; } } };
-  const uint32_t *pc = prog; uint4 hq, q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0; fetch(pc, __builtin_amdgcn_readfirstlane(pc[0]), hq, q0, q1, q2, q3);
+  const uint32_t *pc = prog; uint4 hq = *reinterpret_cast<const uint4 *>(pc), wq = make_uint4(0, 0, 0, 0);
+  { const uint32_t cnt = (__builtin_amdgcn_readfirstlane(hq.x) >> 4) & 1023; if (lane < cnt) wq = *reinterpret_cast<const uint4 *>(pc + 4 + lane * 4); }
 #pragma unroll 1
   for (uint32_t r = 0; r < si.n_rounds; r++) {
-    const uint32_t h = __builtin_amdgcn_readfirstlane(hq.x), hnext = __builtin_amdgcn_readfirstlane(hq.y), kind = h & 15, count = (h >> 4) & 1023, nterms = (h >> 14) & 31, wpl = (h >> 19) & 31; const bool live = lane < count;   // vsched::hdr; word 1: the next round's header
-    const uint32_t wd[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-    pc += 4 + count * wpl; fetch(pc, hnext, hq, q0, q1, q2, q3);          // the next round's header and words: in flight during this round's arithmetic, no load waited for here
-    Fq v = Fq::zero();
-    if (kind == 1) { if (live) v = at(wd[1]) * at(wd[2]); }
-    else if (live) {
+    const uint32_t h = __builtin_amdgcn_readfirstlane(hq.x), hnext = __builtin_amdgcn_readfirstlane(hq.y), kind = h & 15, count = (h >> 4) & 1023; const bool live = lane < count;   // vsched::hdr; word 1: the next round's header
+    const uint4 wd = wq;
+    pc += 4 + count * 4; hq = *reinterpret_cast<const uint4 *>(pc); if (lane < ((hnext >> 4) & 1023)) wq = *reinterpret_cast<const uint4 *>(pc + 4 + lane * 4);   // the next round's header and words: in flight during this round's arithmetic
+    uint32_t v[9];
+    if (kind == 1) {
+      if (live) { Fq29 a, b; vs_load(lds, si.n_slots, wd.y, a.l); vs_load(lds, si.n_slots, wd.z, b.l); const Fq29 pr = Fq29::mul(a, b);
 #pragma unroll
-      for (uint32_t t = 0; t < 12; t++) { if (t >= nterms) break; const uint32_t e = wd[1 + t]; Fq x = at(e & 0xffff);
-#pragma unroll 1
-        for (uint32_t s = (e >> 17) & 7; s; s--) x = x + x;
-        if ((e >> 16) & 1) v = v - x; else v = v + x; } }
+        for (int k = 0; k < 9; k++) v[k] = pr.l[k]; }
+    } else {
+      uint64_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (live) { uint32_t x[9]; vs_load(lds, si.n_slots, wd.y & 0xffffu, x); l29::term(acc, x, wd.y >> 17, (wd.y >> 16) & 1); vs_load(lds, si.n_slots, wd.z & 0xffffu, x); l29::term(acc, x, wd.z >> 17, (wd.z >> 16) & 1); vs_load(lds, si.n_slots, wd.w & 0xffffu, x); l29::term(acc, x, wd.w >> 17, (wd.w >> 16) & 1); }
+      l29::norm64(acc, v);
+      if (kind == 2) { vs_add_from_below<4>(v); vs_add_from_below<2>(v); l29::norm32(v); vs_add_from_below<1>(v); }   // the sum of a group's eight lanes arrives in its last lane
+      l29::barrett(v);
+    }
     vs_lds_barrier();                     // every lane has read its operands
-    if (live) slots[wd[0]] = v;
+    if (live && (kind != 2 || (lane & 7) == 7)) vs_store(lds, wd.x, v);
     vs_lds_barrier();                     // ... and written its result before the next round reads
   }
   if (lane == 0) { bool good = !it.A.is_inf() && !it.B.is_inf() && !it.C.is_inf();
-    for (int k = 0; k < 12; k++) good = good && slots[si.out_slot[k]] == slots[si.n_slots + si.alpha_beta_const + k];
-    for (int k = 12; k < 16; k++) good = good && slots[si.out_slot[k]].is_zero();
+    for (int k = 0; k < 16; k++) { uint32_t x[9]; vs_load(lds, si.n_slots, si.out_slot[k], x); good = good && l29::multiple_of_p(x); }   // the GT value minus alpha_g1_beta_g2, and the on-curve residues: all zero
     ok[i] = nacc.w.is_zero() ? 2 : good ? 1 : 0; }
 }
 // acc_i = IC[0] + sum_j inputs[i][j] * IC[j+1] by ONE WAVE per proof: the (input, window) pairs are dealt to the lanes, a shuffle tree adds the lanes' sums, lane 0

@@ -177,11 +177,11 @@ def verify_batch(vk_path, proofs_hex, inputs):
     ok = (ctypes.c_uint8 * max(1, n))(); _check(lib().zkgpu_verify_batch(vk_path.encode(), blob, buf, ctypes.c_size_t(ni), ctypes.c_size_t(n), ok)); return [bool(ok[i]) for i in range(n)]
 
 def verify_schedule_on_host(vk_path, proof_hex, inputs):
-    """the GPU verifier's operation schedule (csrc/verify_sched.hpp) interpreted on the host: (accept, {rounds, slots, products, linear_ops, constants}); needs no device"""
-    buf = b"".join(int(x).to_bytes(32, "little") for x in inputs); st = (ctypes.c_uint32 * 5)()
+    """the GPU verifier's operation schedule (csrc/verify_sched.hpp) interpreted on the host: (accept, {rounds, slots, products, linear_ops, constants, mul_rounds, lin8_rounds, lin1_rounds}); needs no device"""
+    buf = b"".join(int(x).to_bytes(32, "little") for x in inputs); st = (ctypes.c_uint32 * 8)()
     rc = lib().zkgpu_test_verify_schedule(vk_path.encode(), proof_hex.encode(), buf, ctypes.c_size_t(len(inputs)), st)
     if rc < 0: _check(rc)
-    return rc == 1, dict(zip(("rounds", "slots", "products", "linear_ops", "constants"), (int(x) for x in st)))
+    return rc == 1, dict(zip(("rounds", "slots", "products", "linear_ops", "constants", "mul_rounds", "lin8_rounds", "lin1_rounds"), (int(x) for x in st)))
 def verify(vk_path, proof_hex, inputs):
     """inputs: list of ints (packed public input).  True / False."""
     buf = b"".join(int(x).to_bytes(32, "little") for x in inputs)

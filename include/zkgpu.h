@@ -128,7 +128,7 @@ int zkgpu_profile_report(char *buf, size_t cap);
 int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs);
 /* the same decision for n proofs in one GPU launch (kernel K9; r1cs_gg_ppzksnark_verifier_strong_IC, r1cs_gg_ppzksnark.tcc:509-623, one lane per proof).
    proofs_hex: n * 512 characters (no separators); inputs: n * n_inputs canonical field elements of 32 bytes; ok[i] = 1 accept / 0 reject.  Returns ZKGPU_OK or an error */
-/* test entry: the GPU verifier's operation schedule interpreted on the host (no device needed); returns 1 accept / 0 reject; stats[5] (optional): rounds, slots, products, linear operations, constants */
+/* test entry: the GPU verifier's operation schedule interpreted on the host (no device needed); returns 1 accept / 0 reject; stats[8] (optional): rounds, slots, products, linear operations, constants, rounds of products / eight-lane sums / one-lane sums */
 int zkgpu_test_verify_schedule(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs, uint32_t *stats);
 int zkgpu_verify_batch(const char *vk_path, const char *proofs_hex, const uint8_t *inputs, size_t n_inputs, size_t n, uint8_t *ok);
 

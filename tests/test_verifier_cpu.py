@@ -50,11 +50,13 @@ def test_pairing_values_of_the_reference(ref_vectors, tmp_path):
 
 @pytest.mark.parametrize("name", ["groth16_small", "groth16_step"])
 def test_gpu_verifier_schedule_on_the_host(golden_dir, name):
-    """kernel K9's operation schedule (csrc/verify_sched.hpp: the whole pairing check as ~4,000 rounds of 64 field operations) interpreted on the HOST: the same decisions
-    as the host verifier on the reference prover's proofs and on every kind of tampering — the schedule is proven right before a GPU ever runs it"""
+    """kernel K9's operation schedule (csrc/verify_sched.hpp: the whole pairing check as ~2,100 rounds of one field operation per lane) interpreted on the HOST, twice: on
+    the host field type (what the program means) and on the kernel's own 29-bit limb arithmetic with every bound asserted (what the kernel does; a disagreement between
+    the two raises).  The same decisions as the host verifier on the reference prover's proofs and on every kind of tampering — the schedule is proven right before a GPU
+    ever runs it"""
     d = os.path.join(golden_dir, name); meta = json.load(open(os.path.join(d, "meta.json"))); z = o.load_witness(os.path.join(d, "wit.bin")); vk = os.path.join(d, "vk.txt")
     inputs = o.from_arr(z[:meta["n_inputs"]]); proof = meta["proof"]; ok, st = e.verify_schedule_on_host(vk, proof, inputs); assert ok and e.verify(vk, proof, inputs)
-    assert 1000 < st["rounds"] < 6000 and st["slots"] * 32 <= 160 * 1024 and st["products"] > 20000, st                                        # fits the LDS of one CU
+    assert 1000 < st["rounds"] < 2500 and st["rounds"] == st["mul_rounds"] + st["lin8_rounds"] + st["lin1_rounds"] and (st["slots"] + st["constants"]) * 48 <= 160 * 1024 and st["products"] > 20000, st      # fits the LDS of one CU
     for j in range(len(inputs)): bad = list(inputs); bad[j] = (bad[j] + 1) % o.R_MOD; assert not e.verify_schedule_on_host(vk, proof, bad)[0]
     assert not e.verify_schedule_on_host(vk, proof, inputs[:-1])[0]
     for k in range(8): pos = 64 * k + 21; assert not e.verify_schedule_on_host(vk, proof[:pos] + ("0" if proof[pos] != "0" else "1") + proof[pos + 1:], inputs)[0]      # every coordinate of A, B, C
