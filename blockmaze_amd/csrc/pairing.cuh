@@ -187,9 +187,8 @@ static __global__ void __launch_bounds__(256) k_verify_sched29(const uint32_t *_
       if (kind == 2) { vs_add_from_below<4>(v); vs_add_from_below<2>(v); l29::norm32(v); vs_add_from_below<1>(v); }   // the sum of a group's eight lanes arrives in its last lane
       l29::barrett(v);
     }
-    vs_lds_barrier();                     // every lane has read its operands
-    if (live && (kind != 2 || (lane & 7) == 7)) vs_store(lds, wd.x, v);
-    vs_lds_barrier();                     // ... and written its result before the next round reads
+    if (live && (kind != 2 || (lane & 7) == 7)) vs_store(lds, wd.x, v);   // (no barrier between a round's reads and its writes: the builder never hands out a slot as destination in the round that reads it last)
+    vs_lds_barrier();                     // every result is written before the next round reads
   }
   if (lane == 0) { bool good = !it.A.is_inf() && !it.B.is_inf() && !it.C.is_inf();
     for (int k = 0; k < 16; k++) { uint32_t x[9]; vs_load(lds, si.n_slots, si.out_slot[k], x); good = good && l29::multiple_of_p(x); }   // the GT value minus alpha_g1_beta_g2, and the on-curve residues: all zero

@@ -75,7 +75,8 @@ inline void mul_model(const uint32_t (&a)[9], const uint32_t (&b)[9], uint32_t (
     for (int i = k > 8 ? k - 8 : 0; i <= (k < 8 ? k : 8); i++) acc += (unsigned __int128)a[i] * b[k - i];
     if (k < 9) { for (int i = 0; i < k; i++) acc += (unsigned __int128)m[i] * p29::P[k - i]; m[k] = ((uint32_t)acc * p29::INV) & p29::MASK; acc += (unsigned __int128)m[k] * p29::P[0]; if (acc >> 64) throw std::runtime_error("mul29: column overflow"); if ((uint32_t)acc & p29::MASK) throw std::runtime_error("mul29: reduction"); acc >>= 29; }
     else { for (int i = k - 8; i < 9; i++) acc += (unsigned __int128)m[i] * p29::P[k - i]; if (acc >> 64) throw std::runtime_error("mul29: column overflow"); r[k - 9] = (uint32_t)acc & p29::MASK; acc >>= 29; } }
-  if (acc >> 32) throw std::runtime_error("mul29: top limb overflow"); r[8] = (uint32_t)acc; }
+  if (acc >> 32) throw std::runtime_error("mul29: top limb overflow");
+  r[8] = (uint32_t)acc; }
 }  // namespace l29
 
 namespace vsched {
@@ -229,8 +230,8 @@ inline Schedule build(const host::HFq12 &alpha_g1_beta_g2, const host::G2Precomp
   F12 A = exp_neg_z(first), Bq = T.mul(A, A), Cq = T.mul(Bq, Bq), D = T.mul(Cq, Bq), E = exp_neg_z(D), Fq_ = T.mul(E, E), G = exp_neg_z(Fq_), H = T.conj(D), I = T.conj(G), J = T.mul(I, E), K = T.mul(J, H), L = T.mul(K, Bq), M = T.mul(K, E), N = T.mul(M, first),
       O = T.frob(L, 1), P = T.mul(O, N), Q = T.frob(K, 2), R = T.mul(Q, P), S = T.conj(first), Tt = T.mul(S, L), U = T.frob(Tt, 3), V = T.mul(U, R);
   // outputs in tower order (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 — each c0 then c1) MINUS vk.alpha_g1_beta_g2: sixteen values that must all be zero
-  std::vector<int> outs; { int k = 0; for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) { const F2 &c = V[2 * j + i]; const HFq2 *c2 = i == 0 ? &alpha_g1_beta_g2.c0.c0 + j : &alpha_g1_beta_g2.c1.c0 + j;
-      outs.push_back(b.lin({{1, c.c0}, {-1, b.constant(c2->c0)}})); outs.push_back(b.lin({{1, c.c1}, {-1, b.constant(c2->c1)}})); k += 2; } }
+  std::vector<int> outs; { for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) { const F2 &c = V[2 * j + i]; const HFq2 *c2 = i == 0 ? &alpha_g1_beta_g2.c0.c0 + j : &alpha_g1_beta_g2.c1.c0 + j;
+      outs.push_back(b.lin({{1, c.c0}, {-1, b.constant(c2->c0)}})); outs.push_back(b.lin({{1, c.c1}, {-1, b.constant(c2->c1)}})); } }
   for (int k = 0; k < N_CHECK; k++) outs.push_back(chk[k]);
 
   // ---- liveness, rounds, slots -----------------------------------------------------------------------------------------------------------------------------------
@@ -271,7 +272,12 @@ inline Schedule build(const host::HFq12 &alpha_g1_beta_g2, const host::G2Precomp
     for (size_t k = 0; k < rd.ns.size(); k++) { const Builder::Node &nd = b.nodes[rd.ns[k]];
       if (rd.kind == K_MUL) { words[k * WPL + 1] = ref(nd.a); words[k * WPL + 2] = ref(nd.b); sc.n_mul++; }
       else { for (uint32_t l = 0; l < lanes_per; l++) for (uint32_t t = 0; t < TERMS_PER_LANE; t++) { const size_t idx = (size_t)t * lanes_per + l; words[(k * lanes_per + l) * WPL + 1 + t] = idx < nd.terms.size() ? term_word(nd.terms[idx]) : no_term; } sc.n_lin++; } }
+    // destinations come from the slots freed in EARLIER rounds only (this round's operands are released below, after the assignment): no lane writes a slot that another
+    // lane of the same round still reads, so the kernel needs one barrier per round, not two
     for (size_t k = 0; k < rd.ns.size(); k++) { int s; if (!free_slots.empty()) { s = free_slots.back(); free_slots.pop_back(); } else s = (int)next_slot++; slot[rd.ns[k]] = s; for (uint32_t l = 0; l < lanes_per; l++) words[(k * lanes_per + l) * WPL] = (uint32_t)s; }
+    { std::vector<char> is_dst(next_slot, 0); for (int n : rd.ns) is_dst[slot[n]] = 1;
+      for (size_t q = 0; q < words.size(); q++) { const uint32_t pos = (uint32_t)(q % WPL), wv = words[q]; const bool operand = pos && (rd.kind == K_MUL ? pos < 3 : (wv >> 17) != 0);
+        if (operand && !(wv & CONST_FLAG) && is_dst[wv & 0x7fffu]) throw std::runtime_error("verify schedule: a round writes a slot it reads"); } }
     sc.prog.insert(sc.prog.end(), words.begin(), words.end());
     for (int n : rd.ns) { const Builder::Node &nd = b.nodes[n]; auto release = [&](int o) { if (b.nodes[o].kind != 3 && o >= N_INPUTS && last_use[o] == (int)r && !is_out[o] && slot[o] >= 0) { free_slots.push_back(slot[o]); slot[o] = -2; } };
       if (nd.kind == K_MUL) { release(nd.a); release(nd.b); } else for (auto &t : nd.terms) release(t.second); }
@@ -317,7 +323,8 @@ inline std::vector<bool> simulate29(const Schedule &S, const uint32_t (*in_words
       else { uint32_t part[LIN_GROUP][9];
         for (uint32_t l = 0; l < per; l++) { uint64_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
           for (uint32_t t = 0; t < TERMS_PER_LANE; t++) { const uint32_t e = w[l * WPL + 1 + t]; uint32_t x[9]; load(e & 0xffff, x); const bool neg = (e >> 16) & 1; if (neg) for (int i = 0; i < 9; i++) if (x[i] > p29::K6[i]) bad("K6 - x has a negative limb"); l29::term(acc, x, e >> 17, neg); }
-          for (int i = 0; i < 9; i++) if (acc[i] >> 40) bad("a limb accumulator is above 2^40"); l29::norm64(acc, part[l]); }
+          for (int i = 0; i < 9; i++) { if (acc[i] >> 40) bad("a limb accumulator is above 2^40"); }
+          l29::norm64(acc, part[l]); }
         if (per == LIN_GROUP) {   // the kernel's tree: lanes 4..7 += lanes 0..3, a carry step, then lane 6 += 4, 7 += 5, 7 += 6
           uint32_t hi[4][9]; for (int j = 0; j < 4; j++) for (int i = 0; i < 9; i++) { const uint64_t s2 = (uint64_t)part[j][i] + part[j + 4][i]; if (s2 >> 32) bad("tree level 1 overflows"); hi[j][i] = (uint32_t)s2; }
           for (int i = 0; i < 9; i++) { const uint64_t s2 = (uint64_t)hi[0][i] + hi[2][i], s3 = (uint64_t)hi[1][i] + hi[3][i]; if ((s2 | s3) >> 32) bad("tree level 2 overflows"); hi[2][i] = (uint32_t)s2; hi[3][i] = (uint32_t)s3; }
