@@ -285,7 +285,7 @@ struct Prover::Impl {
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
   std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; std::shared_ptr<DevBuf<uint32_t>> B_idx; DevBuf<Fe32> z, abc; DevBuf<uint8_t> packed; PinnedBuf<Fe32> z_host;
-  std::unique_ptr<SubmitWorker> workers[4], scan_workers[4];
+  std::unique_ptr<SubmitWorker> workers[4];
   // The submit thread of a witness MSM also waits for its stream and finishes the MSM on the host (Horner combine, or the host tail of msm_impl.hpp): four threads do that
   // side by side while the H chain is still running.  pending[j]: job j (order B2, L, A, B1) was posted and its result slot is not valid before workers[j]->wait().
   HG2 rB2; HG1 rL, rA, rB1; bool pending[4] = {false, false, false, false}, inline_result[4] = {false, false, false, false};
@@ -349,8 +349,7 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   uint8_t *pk = reinterpret_cast<uint8_t *>(p.z_host.get()); uint64_t *ones = (uint64_t *)pk, *other = ones + words; uint32_t *off = (uint32_t *)(other + words);
   const size_t vals_at = ((words * 20 + 31) / 32) * 32; Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
   uint64_t o1[4]; memcpy(o1, &one, 32); const uint64_t *zz = reinterpret_cast<const uint64_t *>(z) - 4;   // zz + 4 i = entry i of [ONE, z_1 .. z_n]; entry 0 is handled apart
-  static const size_t T = [] { const char *e = getenv("ZK_SCAN_THREADS"); int v = e ? atoi(e) : 4; return (size_t)(v < 1 ? 1 : v > 8 ? 8 : v); }();   // threads 1 .. 3 are the submit workers; more only with ZK_SCAN_THREADS
-  const size_t cap_t = max_other / T; size_t used[8] = {0}; bool fits[8] = {true, true, true, true, true, true, true, true};
+  constexpr size_t T = 4; const size_t cap_t = max_other / T; size_t used[T] = {0, 0, 0, 0}; bool fits[T] = {true, true, true, true};   // (six and eight threads were measured: no faster, the wake-ups cost what the extra threads gain)
   auto scan = [&](size_t t) { const size_t w0 = words * t / T, w1 = words * (t + 1) / T, base = t * cap_t; size_t n_other = 0;
     for (size_t w = w0; w < w1; w++) { uint64_t mo = 0, mx = 0; const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; off[w] = (uint32_t)(base + n_other);
       for (size_t i = lo ? lo : 1; i < hi; i++) { const uint64_t *v = zz + 4 * i;                                // branch-free classification of the block
@@ -361,7 +360,7 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
       ones[w] = mo; other[w] = mx; }
     used[t] = n_other; };
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
-  auto worker = [&](size_t t) -> SubmitWorker & { std::unique_ptr<SubmitWorker> &w = t < 4 ? p.workers[t] : p.scan_workers[t - 4]; if (!w) w.reset(new SubmitWorker(p.lane)); return *w; };
+  auto worker = [&](size_t t) -> SubmitWorker & { if (!p.workers[t]) p.workers[t].reset(new SubmitWorker(p.lane)); return *p.workers[t]; };
   if (threaded && words >= 512) { for (size_t t = 1; t < T; t++) worker(t).post([&scan, t] { scan(t); }); scan(0); for (size_t t = 1; t < T; t++) worker(t).wait(); }
   else for (size_t t = 0; t < T; t++) scan(t);
   static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;   // (test switch: the plain-copy branch below, which no BlockMaze assignment reaches on its own)
