@@ -24,6 +24,15 @@ def adjusted(c):
         assert lo <= l[i] < 4 << B, (c, i, l[i])
     assert l[NL - 1] > 0 and sum(v << (B * i) for i, v in enumerate(l)) == c * Q
     return l
+def adjusted_light(c):
+    """c*p with limbs 0..7 in [2^29 + 64, 2 * 2^29 + 64): a + KL - t has no negative limb for t with exact 29-bit limbs (a product's result) and value below c p"""
+    l = limbs29(c * Q); lo = (1 << B) + 64
+    for i in range(NL - 1):
+        n = 1 if l[i] + (1 << B) >= lo else 2
+        l[i] += n << B; l[i + 1] -= n
+        assert lo <= l[i] < lo + (1 << B), (c, i, l[i])
+    assert l[NL - 1] > 0 and sum(v << (B * i) for i, v in enumerate(l)) == c * Q
+    return l
 INV = (-pow(Q, -1, 1 << B)) % (1 << B)
 P29 = limbs29(Q); ONE29 = limbs29(RP % Q); RCONV = limbs29((1 << 256) % Q)
 KS = {c: adjusted(c) for c in (2, 4, 6)}
@@ -62,78 +71,104 @@ def check_bounds_add():
     for c, need in ((cP, U), (cR, S), (cX, PPP + 2 * Qv), (cT, nX), (cY, Bv)): assert KS[c][NL - 1] >= int(need * Q) >> (B * (NL - 1)), (c, need)
 check_bounds_add()
 
-out = ["// GENERATED by gen_field29.py - do not edit.  Fq on nine 29-bit limbs (R' = 2^261) for k_hacc_runs29 (msm.cuh); device compilation only.",
-       "// value bounds of the mixed addition, in units of p (interval arithmetic in the generator): " + ", ".join("%s < %.2f" % kv for kv in BOUNDS["bounds"].items()),
-       "struct Fq29 {",
-       "  uint32_t l[9];",
-       "  static constexpr uint32_t MASK = 0x%xu, INV = 0x%xu;   // INV = -p^-1 mod 2^29" % (M, INV)]
-def arr(name, v, comment=""): out.append("  static constexpr uint32_t %s[9] = {%s};%s" % (name, ", ".join("0x%xu" % x for x in v), ("   // " + comment) if comment else ""))
-arr("P29", P29, "p"); arr("ONE", ONE29, "2^261 mod p: the field's one"); arr("RCONV", RCONV, "2^256 mod p as a plain integer: a Montgomery product with it turns v 2^261 into v 2^256 (the 8 x 32-bit form)")
-for c, v in KS.items(): arr("K%d" % c, v, "%d p, low limbs in [3 * 2^29 + 64, 4 * 2^29)" % c)
-def mads(pairs, const_b, first):
-    """one asm statement: acc (+)= sum of the pairs' products; no carries: the column stays below 2^64"""
-    txt = " ".join('"v_mad_u64_u32 %%0, vcc, %%%d, %%%d, %s\\n\\t"' % (1 + 2 * i, 2 + 2 * i, "0" if first and i == 0 else "%0") for i in range(len(pairs)))
-    ins = ", ".join('"v"(%s), "%s"(%s)' % (x, "s" if const_b else "v", y) for x, y in pairs)
-    out.append("    asm(%s : \"%s\"(acc) : %s : \"vcc\");" % (txt, "=&v" if first else "+v", ins))
-def product(sig, columns, prologue):
-    out.append("  static __device__ __forceinline__ Fq29 %s {" % sig)
-    out.append("    uint64_t acc; uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8; Fq29 r;")
-    out.extend(prologue)
-    for k in range(17):
-        first = k == 0
-        if columns[k]: mads(columns[k], False, first)
-        if k < 9:
-            mp = [("m%d" % i, "P29[%d]" % (k - i)) for i in range(0, k)]
-            if mp: mads(mp, True, False)
-            out.append("    m%d = ((uint32_t)acc * INV) & MASK;" % k)
-            mads([("m%d" % k, "P29[0]")], True, False)
-            out.append("    acc >>= 29;")
-        else:
-            mads([("m%d" % i, "P29[%d]" % (k - i)) for i in range(k - 8, 9)], True, False)
-            out.append("    r.l[%d] = (uint32_t)acc & MASK; acc >>= 29;" % (k - 9))
-    out.append("    r.l[8] = (uint32_t)acc;")
-    out.append("    return r;")
-    out.append("  }")
-product("mul(const Fq29 &a, const Fq29 &b)", [[("a.l[%d]" % i, "b.l[%d]" % (k - i)) for i in range(max(0, k - 8), min(k, 8) + 1)] for k in range(17)], [])
-cols = [[] for _ in range(17)]
-for i in range(9):
-    cols[2 * i].append(("a.l[%d]" % i, "a.l[%d]" % i))
-    for j in range(i + 1, 9): cols[i + j].append(("a.l[%d]" % i, "d%d" % j))
-assert sum(len(c) for c in cols) == 45
-product("sqr(const Fq29 &a)", cols, ["    const uint32_t " + ", ".join("d%d = a.l[%d] << 1" % (j, j) for j in range(1, 9)) + ";   // a normalized: 2 a_j < 2^30 + 16"])
-out.append("""  // one parallel carry step: limbs 0..7 back below 2^29 + 8 (inputs below 2^32)
-  __device__ __forceinline__ Fq29 norm() const { Fq29 r; r.l[0] = l[0] & MASK;
-#pragma unroll
-    for (int i = 1; i < 8; i++) r.l[i] = (l[i] & MASK) + (l[i - 1] >> 29);
-    r.l[8] = l[8] + (l[7] >> 29); return r; }
-  // a - b (mod p) as a + K_C - b, normalized.  b: limbs below 3 * (2^29 + 8), value below C p
-  template <int C> static __device__ __forceinline__ Fq29 sub(const Fq29 &a, const Fq29 &b) { Fq29 d;
-#pragma unroll
-    for (int i = 0; i < 9; i++) d.l[i] = a.l[i] + (C == 2 ? K2[i] : C == 4 ? K4[i] : K6[i]) - b.l[i];
-    return d.norm(); }
-  // neg ? -a : a for a canonical a (limbs below 2^29): K_2 - a is left as it is (limbs below 2^31, fine as ONE operand of a product)
-  static __device__ __forceinline__ Fq29 cond_neg(const Fq29 &a, bool neg) { Fq29 r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.l[i] = neg ? K2[i] - a.l[i] : a.l[i];
-    return r; }
-  static __device__ __forceinline__ Fq29 one() { Fq29 r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.l[i] = ONE[i];
-    return r; }
-  // the 8 x 32-bit words of a canonical value (below 2^256) <-> its limbs
-  static __device__ __forceinline__ Fq29 unpack(const uint32_t (&w)[8]) { Fq29 r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) { const int bit = 29 * i, j = bit >> 5, s = bit & 31; uint32_t v = w[j] >> s; if (s > 3 && j + 1 < 8) v |= w[j + 1] << (32 - s); r.l[i] = i < 8 ? v & MASK : v; }
-    return r; }
-  // Montgomery product with 2^256 mod p: x = v 2^261 becomes v 2^256 (mod p), below 2p, as 8 x 32-bit words — the lazy domain of field.cuh
-  __device__ __forceinline__ void to_words(uint32_t (&w)[8]) const { Fq29 c;
-#pragma unroll
-    for (int i = 0; i < 9; i++) c.l[i] = RCONV[i];
-    const Fq29 t = mul(*this, c);   // exact 29-bit limbs, value below 2p < 2^255
-#pragma unroll
-    for (int j = 0; j < 8; j++) { const int bit = 32 * j, i = bit / 29, s = bit - 29 * i; uint32_t v = t.l[i] >> s; v |= t.l[i + 1] << (29 - s); if (29 - s + 29 < 32 && i + 2 < 9) v |= t.l[i + 2] << (58 - s); w[j] = v; } }
-};""")
-
+HEADER = ["// GENERATED by gen_field29.py - do not edit.  Fq and Fr on nine 29-bit limbs (R' = 2^261): Fq29 for k_hacc_runs29 (msm.cuh) and the verifier's schedule",
+          "// (pairing.cuh), Fr29 for the transforms (ntt.cuh); device compilation only.",
+          "// value bounds of the mixed addition, in units of p (interval arithmetic in the generator): " + ", ".join("%s < %.2f" % kv for kv in BOUNDS["bounds"].items())]
+def gen_struct():
+    """the struct for the modulus the globals (P29, INV, ONE29, RCONV, KS) currently describe, under the name Fq29 (the caller renames)"""
+    global out, cols
+    out = [
+           "struct Fq29 {",
+           "  uint32_t l[9];",
+           "  static constexpr uint32_t MASK = 0x%xu, INV = 0x%xu;   // INV = -p^-1 mod 2^29" % (M, INV)]
+    def arr(name, v, comment=""): out.append("  static constexpr uint32_t %s[9] = {%s};%s" % (name, ", ".join("0x%xu" % x for x in v), ("   // " + comment) if comment else ""))
+    arr("P29", P29, "p"); arr("ONE", ONE29, "2^261 mod p: the field's one"); arr("RCONV", RCONV, "2^256 mod p as a plain integer: a Montgomery product with it turns v 2^261 into v 2^256 (the 8 x 32-bit form)")
+    for c, v in KS.items(): arr("K%d" % c, v, "%d p, low limbs in [3 * 2^29 + 64, 4 * 2^29)" % c)
+    arr("KL2", adjusted_light(2), "2 p, low limbs in [2^29 + 64, 2 * 2^29 + 64)"); assert adjusted_light(2)[NL - 1] >= int(1.5 * Q) >> (B * (NL - 1))   # a subtrahend below 1.5 p never exceeds KL2's top limb
+    def mads(pairs, const_b, first):
+        """one asm statement: acc (+)= sum of the pairs' products; no carries: the column stays below 2^64"""
+        txt = " ".join('"v_mad_u64_u32 %%0, vcc, %%%d, %%%d, %s\\n\\t"' % (1 + 2 * i, 2 + 2 * i, "0" if first and i == 0 else "%0") for i in range(len(pairs)))
+        ins = ", ".join('"v"(%s), "%s"(%s)' % (x, "s" if const_b else "v", y) for x, y in pairs)
+        out.append("    asm(%s : \"%s\"(acc) : %s : \"vcc\");" % (txt, "=&v" if first else "+v", ins))
+    def product(sig, columns, prologue):
+        out.append("  static __device__ __forceinline__ Fq29 %s {" % sig)
+        out.append("    uint64_t acc; uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8; Fq29 r;")
+        out.extend(prologue)
+        for k in range(17):
+            first = k == 0
+            if columns[k]: mads(columns[k], False, first)
+            if k < 9:
+                mp = [("m%d" % i, "P29[%d]" % (k - i)) for i in range(0, k)]
+                if mp: mads(mp, True, False)
+                out.append("    m%d = ((uint32_t)acc * INV) & MASK;" % k)
+                mads([("m%d" % k, "P29[0]")], True, False)
+                out.append("    acc >>= 29;")
+            else:
+                mads([("m%d" % i, "P29[%d]" % (k - i)) for i in range(k - 8, 9)], True, False)
+                out.append("    r.l[%d] = (uint32_t)acc & MASK; acc >>= 29;" % (k - 9))
+        out.append("    r.l[8] = (uint32_t)acc;")
+        out.append("    return r;")
+        out.append("  }")
+    product("mul(const Fq29 &a, const Fq29 &b)", [[("a.l[%d]" % i, "b.l[%d]" % (k - i)) for i in range(max(0, k - 8), min(k, 8) + 1)] for k in range(17)], [])
+    cols = [[] for _ in range(17)]
+    for i in range(9):
+        cols[2 * i].append(("a.l[%d]" % i, "a.l[%d]" % i))
+        for j in range(i + 1, 9): cols[i + j].append(("a.l[%d]" % i, "d%d" % j))
+    assert sum(len(c) for c in cols) == 45
+    product("sqr(const Fq29 &a)", cols, ["    const uint32_t " + ", ".join("d%d = a.l[%d] << 1" % (j, j) for j in range(1, 9)) + ";   // a normalized: 2 a_j < 2^30 + 16"])
+    out.append("""  // one parallel carry step: limbs 0..7 back below 2^29 + 8 (inputs below 2^32)
+      __device__ __forceinline__ Fq29 norm() const { Fq29 r; r.l[0] = l[0] & MASK;
+    #pragma unroll
+        for (int i = 1; i < 8; i++) r.l[i] = (l[i] & MASK) + (l[i - 1] >> 29);
+        r.l[8] = l[8] + (l[7] >> 29); return r; }
+""" + ("""      // a - b (mod p) as a + K_C - b, normalized.  b: limbs below 3 * (2^29 + 8), value below C p
+      template <int C> static __device__ __forceinline__ Fq29 sub(const Fq29 &a, const Fq29 &b) { Fq29 d;
+    #pragma unroll
+        for (int i = 0; i < 9; i++) d.l[i] = a.l[i] + (C == 2 ? K2[i] : C == 4 ? K4[i] : K6[i]) - b.l[i];
+        return d.norm(); }
+      // neg ? -a : a for a canonical a (limbs below 2^29): K_2 - a is left as it is (limbs below 2^31, fine as ONE operand of a product)
+      static __device__ __forceinline__ Fq29 cond_neg(const Fq29 &a, bool neg) { Fq29 r;
+    #pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = neg ? K2[i] - a.l[i] : a.l[i];
+        return r; }
+""" if KS else "") + """      // a - t (mod p) as a + KL_2 - t for a product's result t (exact 29-bit limbs, value below 2 p); limbs of the difference: a's + 2^30 + 64 at most, NOT normalized
+      static __device__ __forceinline__ Fq29 sub_product(const Fq29 &a, const Fq29 &t) { Fq29 d;
+    #pragma unroll
+        for (int i = 0; i < 9; i++) d.l[i] = a.l[i] + KL2[i] - t.l[i];
+        return d; }
+      // KL_2 - t: minus a product's result (limbs below 2^30 + 64: fine as ONE operand of a product)
+      static __device__ __forceinline__ Fq29 neg_product(const Fq29 &t) { Fq29 d;
+    #pragma unroll
+        for (int i = 0; i < 9; i++) d.l[i] = KL2[i] - t.l[i];
+        return d; }
+      // limb-wise sum, NOT normalized
+      static __device__ __forceinline__ Fq29 add_raw(const Fq29 &a, const Fq29 &b) { Fq29 d;
+    #pragma unroll
+        for (int i = 0; i < 9; i++) d.l[i] = a.l[i] + b.l[i];
+        return d; }
+      static __device__ __forceinline__ Fq29 one() { Fq29 r;
+    #pragma unroll
+        for (int i = 0; i < 9; i++) r.l[i] = ONE[i];
+        return r; }
+      // the 8 x 32-bit words of a canonical value (below 2^256) <-> its limbs
+      static __device__ __forceinline__ Fq29 unpack(const uint32_t (&w)[8]) { Fq29 r;
+    #pragma unroll
+        for (int i = 0; i < 9; i++) { const int bit = 29 * i, j = bit >> 5, s = bit & 31; uint32_t v = w[j] >> s; if (s > 3 && j + 1 < 8) v |= w[j + 1] << (32 - s); r.l[i] = i < 8 ? v & MASK : v; }
+        return r; }
+      // the 8 x 32-bit words of a value with exact 29-bit limbs below 2^256
+      __device__ __forceinline__ void pack_words(uint32_t (&w)[8]) const {
+    #pragma unroll
+        for (int j = 0; j < 8; j++) { const int bit = 32 * j, i = bit / 29, s = bit - 29 * i; uint32_t v = l[i] >> s; v |= l[i + 1] << (29 - s); if (29 - s + 29 < 32 && i + 2 < 9) v |= l[i + 2] << (58 - s); w[j] = v; } }
+      // Montgomery product with 2^256 mod p: x = v 2^261 becomes v 2^256 (mod p), below 2p, as 8 x 32-bit words — the lazy domain of field.cuh
+      __device__ __forceinline__ void to_words(uint32_t (&w)[8]) const { Fq29 c;
+    #pragma unroll
+        for (int i = 0; i < 9; i++) c.l[i] = RCONV[i];
+        const Fq29 t = mul(*this, c);   // exact 29-bit limbs, value below 2p < 2^255
+    #pragma unroll
+        for (int j = 0; j < 8; j++) { const int bit = 32 * j, i = bit / 29, s = bit - 29 * i; uint32_t v = t.l[i] >> s; v |= t.l[i + 1] << (29 - s); if (29 - s + 29 < 32 && i + 2 < 9) v |= t.l[i + 2] << (58 - s); w[j] = v; } }
+    };""")
+    
+    return out
 # ---- self-check: the column lists above, evaluated on integers, against big-number arithmetic -------------------------------------------------------
 def model_product(columns, env):
     """mirrors product(): columns[k] = pairs of operand names looked up in env (limb values); returns the nine result limbs"""
@@ -155,7 +190,7 @@ def self_check():
     def norm(l): return [l[0] & M] + [(l[i] & M) + (l[i - 1] >> B) for i in range(1, 8)] + [l[8] + (l[7] >> B)]
     for it in range(2000):
         # a: an un-normalized difference (limbs up to 2^31.4, value below 8p), b: normalized
-        bv = rnd.randrange(0, 8 * Q); b = norm(limbs29(bv)); av = rnd.randrange(0, 2 * Q); a = [x + y - z for x, y, z in zip(limbs29(av), KS[6], limbs29(rnd.randrange(0, 5 * Q)))]
+        bv = rnd.randrange(0, 8 * Q); b = norm(limbs29(bv)); av = rnd.randrange(0, 2 * Q); a = [x + y - z for x, y, z in zip(limbs29(av), KS[6] if KS else adjusted_light(2), limbs29(rnd.randrange(0, (5 if KS else 2) * Q)))]
         if it < 50: a = [min(int(2 ** 31.4), (1 << 32) - 1)] * 8 + [a[8]]; b = [(1 << 29) + 7] * 8 + [b[8]]      # the column bound at its worst
         assert all(0 <= x < 1 << 32 for x in a)
         env = {"a%d" % i: a[i] for i in range(9)}; env.update({"b%d" % i: b[i] for i in range(9)})
@@ -163,6 +198,9 @@ def self_check():
         env = {"a%d" % i: b[i] for i in range(9)}; env.update({"d%d" % i: (b[i] << 1) & 0xffffffff for i in range(1, 9)})
         r = model_product(sqrcols, env); assert val(r) % Q == val(b) * val(b) * RPinv % Q
         # difference + normalization
+        if not KS:   # the light difference: a + KL_2 - t for a product's result t, then one carry step
+            tv = rnd.randrange(0, 2 * Q); d = [x + k - y for x, k, y in zip(b, adjusted_light(2), limbs29(tv))]; assert all(0 <= x < 1 << 32 for x in d); n = norm(d); assert val(n) == val(b) + 2 * Q - tv and all(x < (1 << 29) + 8 for x in n[:8])
+            continue
         c = rnd.choice([2, 4, 6]); sv = rnd.randrange(0, c * Q); sl = limbs29(sv)
         if c == 4: s1, s2 = rnd.randrange(0, Q + Q // 8), rnd.randrange(0, Q + Q // 8); sl = [x + 2 * y for x, y in zip(limbs29(s1), limbs29(s2))]; sv = s1 + 2 * s2      # PPP + 2Q, limb-wise
         d = [x + k - y for x, k, y in zip(b, KS[c], sl)]; assert all(0 <= x < 1 << 32 for x in d), d
@@ -180,7 +218,7 @@ def self_check():
             if 29 - sft + 29 < 32 and i + 2 < 9: v |= (t[i + 2] << (58 - sft)) & 0xffffffff
             back.append(v & 0xffffffff)
         assert sum(x << (32 * j) for j, x in enumerate(back)) == val(t)
-self_check()
+gen_struct(); self_check()
 
 # ---- plain constants + the linear-combination pipeline of the verifier's schedule (verify_sched.hpp, k_verify_sched29 in pairing.cuh) -------------------------
 # LIN: v = sum c_t * y_t over 64-bit limb accumulators (y = x or K_6 - x), one parallel carry step to 32-bit limbs, a tree of limb-wise sums, then a Barrett-like
@@ -238,5 +276,10 @@ carr("P", P29, "p"); carr("K6", KS[6], "6 p, low limbs in [3 * 2^29 + 64, 4 * 2^
 prm.append("constexpr uint32_t KP[5][9] = {%s};   // k p, k = 0 .. 4, exact limbs" % ", ".join("{" + ", ".join("0x%xu" % x for x in limbs29(k * Q)) + "}" for k in range(5)))
 prm.append("} }")
 open(__file__.replace("gen_field29.py", "field29_params.h"), "w").write("\n".join(prm) + "\n")
-open(__file__.replace("gen_field29.py", "field29_gfx950.inc"), "w").write("\n".join(out) + "\n")
+FQ_LINES = gen_struct()
+# ---- the same arithmetic for Fr (the transforms): constants of the scalar field, same column schedule, same self-check --------------------------------------------
+R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+Q_SAVE = Q; KS_SAVE = KS; Q = R_MOD; INV = (-pow(Q, -1, 1 << B)) % (1 << B); P29 = limbs29(Q); ONE29 = limbs29(RP % Q); RCONV = limbs29((1 << 256) % Q); KS = {}   # (no borrow-adjusted 2p, 4p, 6p with limbs in [3 * 2^29 + 64, 4 * 2^29) exist for r = 1 mod 2^28; the transforms only subtract products)
+FR_LINES = [l.replace("Fq29", "Fr29") for l in gen_struct()]; self_check()
+open(__file__.replace("gen_field29.py", "field29_gfx950.inc"), "w").write("\n".join(HEADER + FQ_LINES + FR_LINES) + "\n")
 print("bounds:", BOUNDS)

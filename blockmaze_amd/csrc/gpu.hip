@@ -116,35 +116,41 @@ static HFr fr_root_of_unity(size_t n) { HFr w; memcpy(w.l, FR_ROOT_OF_UNITY_2_28
 static HFr fr_coset_gen() { HFr g; memcpy(g.l, FR_COSET_GEN, 32); return g; }
 
 // tables for one power-of-two transform size n with root w: tw[j] = w^j, itw[j] = w^-j (j < n/2)
+// tw261 / itw261: the same powers times 2^261 instead of 2^256 (canonical integers, 8 words): the factor form of the tile kernels, which compute on 29-bit limbs (ntt.cuh)
 struct Radix2Tables {
-  int logn; size_t n; DevBuf<Fe32> tw, itw;
-  Radix2Tables(size_t n_, const HFr &w) : logn((int)ceil_log2(n_)), n(n_), tw(n_ / 2 ? n_ / 2 : 1), itw(n_ / 2 ? n_ / 2 : 1) {
-    std::vector<Fe32> a(n / 2 ? n / 2 : 1), b(a.size()); HFr wi = w.inv(), x = HFr::one(), y = HFr::one();
-    for (size_t j = 0; j < n / 2; j++) { memcpy(&a[j], x.l, 32); memcpy(&b[j], y.l, 32); x = x * w; y = y * wi; }
-    if (n / 2 == 0) { memcpy(&a[0], x.l, 32); memcpy(&b[0], y.l, 32); }
-    tw.upload(a.data(), a.size()); itw.upload(b.data(), b.size());
+  int logn; size_t n; DevBuf<Fe32> tw, itw, tw261, itw261;
+  Radix2Tables(size_t n_, const HFr &w) : logn((int)ceil_log2(n_)), n(n_), tw(n_ / 2 ? n_ / 2 : 1), itw(n_ / 2 ? n_ / 2 : 1), tw261(n_ / 2 ? n_ / 2 : 1), itw261(n_ / 2 ? n_ / 2 : 1) {
+    std::vector<Fe32> a(n / 2 ? n / 2 : 1), b(a.size()), a5(a.size()), b5(a.size()); HFr wi = w.inv(), x = HFr::one(), y = HFr::one();
+    auto times32 = [](HFr v) { for (int i = 0; i < 5; i++) v = v + v; return v; };   // the Montgomery integer of v is v 2^256: five doublings give v 2^261 (mod r)
+    for (size_t j = 0; j < std::max<size_t>(n / 2, 1); j++) { memcpy(&a[j], x.l, 32); memcpy(&b[j], y.l, 32); HFr x5 = times32(x), y5 = times32(y); memcpy(&a5[j], x5.l, 32); memcpy(&b5[j], y5.l, 32); x = x * w; y = y * wi; }
+    tw.upload(a.data(), a.size()); itw.upload(b.data(), b.size()); tw261.upload(a5.data(), a5.size()); itw261.upload(b5.data(), b5.size());
   }
 };
 static std::vector<Fe32> geometric_table(size_t n, const HFr &first, const HFr &ratio) { std::vector<Fe32> t(n); HFr x = first; for (size_t i = 0; i < n; i++) { memcpy(&t[i], x.l, 32); x = x * ratio; } return t; }
 
 // in-place radix-2 transform of `batch` vectors: data = post * NTT(pre * data), natural order in and out.  Up to 2^22 points: two LDS-tiled passes
 // (k_ntt_cols: data -> scratch, k_ntt_rows: scratch -> data; one pass in place when the whole vector fits a tile); beyond that the stage-per-launch path.
-static int ntt_pref_log_c() { static const int v = [] { const char *e = getenv("ZK_NTT_LOGC"); int x = e ? atoi(e) : 0; return x < 0 ? 0 : x > 3 ? 3 : x; }(); return v; }
-static void radix2_transform(Fe32 *data, Fe32 *scratch, const Fe32 *tw, int logn, const Fe32 *pre_scale, const Fe32 *post_scale, int batch, size_t stride, size_t scratch_stride) {
+static int ntt_pref_log_c() { static const int v = [] { const char *e = getenv("ZK_NTT_LOGC"); int x = e ? atoi(e) : 1;   // two columns per tile since the tiles compute on 29-bit limbs (1.01 against 1.04 ms per send proof; one column was best for the 32-bit passes)
+    return x < 0 ? 0 : x > 3 ? 3 : x; }(); return v; }
+static Fe32 fe261(HFr v) { for (int i = 0; i < 5; i++) v = v + v; Fe32 o; memcpy(&o, v.l, 32); return o; }   // f 2^261 mod r as a canonical integer (the host type holds f 2^256: five doublings)
+// data = post * NTT(pre * data) * scale.  The tile kernels take the per-element factor as pre261 (f 2^261) and the constant as scale261; pre_scale (f 2^256) is the same
+// table for the stage-per-launch path beyond 2^22 points, which folds a constant scale into it
+static void radix2_transform(Fe32 *data, Fe32 *scratch, const Fe32 *tw, const Fe32 *tw261, int logn, const Fe32 *pre_scale, const Fe32 *pre261, const Fe32 &scale261, const Fe32 *post_scale, int batch, size_t stride, size_t scratch_stride) {
+  Fr sc; memcpy(&sc, &scale261, 32);
   hipStream_t s = gpu().stream; size_t n = (size_t)1 << logn;
   static const int rl = [] { const char *e = getenv("ZK_NTT_RADIX_LOG"); int x = e ? atoi(e) : 2; return x < 1 ? 1 : x > 3 ? 3 : x; }();   // radix-4 passes on one-column tiles measured best with two vectors per launch (twice the waves of radix 8: the passes are latency bound), radix 8 with three
   static const bool lds_raised = [] { HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_cols, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); return true; }(); (void)lds_raised;
   auto threads_for = [](int logN, int logC) { int g = logN + logC - rl; unsigned t = 1u << (g < 6 ? 6 : g > 8 ? 8 : g); return t; };   // one butterfly group per thread and pass, 64..256 threads
-  auto lds_for = [](int logN, int logC) { size_t e = (size_t)1 << (logN + logC); return sizeof(Fr) * (e + (e >> 4) + 1) + (sizeof(Fr) << logN) / 2; };   // padded tile (ntt_pad) + twiddle table
+  auto lds_for = [](int logN, int logC) { size_t e = (size_t)1 << (logN + logC); return sizeof(Fr29) * (e + (e >> 4) + 1) + (sizeof(Fr29) << logN) / 2; };   // padded tile (ntt_pad) + twiddle table, 36 bytes an element
   if (logn <= NTT_TILE_LOG) {          // n2 = 1: the column pass alone is the whole transform
     if (post_scale) throw GpuError("ntt: post scale on a single-pass transform");
-    hipLaunchKernelGGL(k_ntt_cols, dim3(1, batch), dim3(threads_for(logn, 0)), lds_for(logn, 0), s, (const Fr *)data, (Fr *)data, (const Fr *)pre_scale, (const Fr *)tw, logn, logn, 0, rl, stride, stride);
+    hipLaunchKernelGGL(k_ntt_cols, dim3(1, batch), dim3(threads_for(logn, 0)), lds_for(logn, 0), s, (const Fr *)data, (Fr *)data, (const Fr *)pre261, (const Fr *)tw261, sc, logn, logn, 0, rl, stride, stride);
     return;
   }
   if (logn <= 2 * NTT_TILE_LOG) {
     int l1 = logn / 2, l2 = logn - l1, c1 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l1, l2)), c2 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l2, l1));
-    hipLaunchKernelGGL(k_ntt_cols, dim3((unsigned)(1u << (l2 - c1)), batch), dim3(threads_for(l1, c1)), lds_for(l1, c1), s, (const Fr *)data, (Fr *)scratch, (const Fr *)pre_scale, (const Fr *)tw, logn, l1, c1, rl, stride, scratch_stride);
-    hipLaunchKernelGGL(k_ntt_rows, dim3((unsigned)(1u << (l1 - c2)), batch), dim3(threads_for(l2, c2)), lds_for(l2, c2), s, (const Fr *)scratch, (Fr *)data, (const Fr *)post_scale, (const Fr *)tw, logn, l1, c2, rl, scratch_stride, stride);
+    hipLaunchKernelGGL(k_ntt_cols, dim3((unsigned)(1u << (l2 - c1)), batch), dim3(threads_for(l1, c1)), lds_for(l1, c1), s, (const Fr *)data, (Fr *)scratch, (const Fr *)pre261, (const Fr *)tw261, sc, logn, l1, c1, rl, stride, scratch_stride);
+    hipLaunchKernelGGL(k_ntt_rows, dim3((unsigned)(1u << (l1 - c2)), batch), dim3(threads_for(l2, c2)), lds_for(l2, c2), s, (const Fr *)scratch, (Fr *)data, (const Fr *)post_scale, (const Fr *)tw261, sc, logn, l1, c2, rl, scratch_stride, stride);
     return;
   }
   hipLaunchKernelGGL(k_ntt_bitrev_scale, dim3(cdiv(n, 256), batch), dim3(256), 0, s, (const Fr *)data, (Fr *)scratch, (const Fr *)pre_scale, logn, stride, scratch_stride);
@@ -179,15 +185,16 @@ struct DomainTables {                                            // immutable pe
   size_t m = 0; bool step = false; size_t B = 0, S = 0;           // step: m = B + S
   std::unique_ptr<Radix2Tables> big, small;                       // basic: only `big` (size m)
   DevBuf<Fe32> coset_fwd, coset_inv, zinv, wpow, winvpow;
-  DevBuf<Fe32> scale_big, scale_small;                            // 1/n folded into the loads of the inverse transforms
+  DevBuf<Fe32> scale_big, scale_small;                            // 1/n as a table: the pre-scale of the stage-per-launch path (beyond 2^22 points)
+  DevBuf<Fe32> coset_fwd261; Fe32 one261, inv_big261, inv_small261; // the tile kernels' factor forms (f 2^261): g^i per element, the constants 1, 1/B (or 1/m), 1/S
   HFr half;
 };
 struct Domain::Impl {
   std::shared_ptr<DomainTables> t; DomainTables &d_;              // (d_ keeps the code below unchanged: every table is reached through it)
-  size_t &m; bool &step; size_t &B, &S; std::unique_ptr<Radix2Tables> &big, &small; DevBuf<Fe32> &coset_fwd, &coset_inv, &zinv, &wpow, &winvpow, &scale_big, &scale_small; HFr &half;
+  size_t &m; bool &step; size_t &B, &S; std::unique_ptr<Radix2Tables> &big, &small; DevBuf<Fe32> &coset_fwd, &coset_inv, &zinv, &wpow, &winvpow, &scale_big, &scale_small, &coset_fwd261; Fe32 &one261, &inv_big261, &inv_small261; HFr &half;
   DevBuf<Fe32> scratch; size_t scratch_stride = 0;                // per object
   explicit Impl(std::shared_ptr<DomainTables> tt) : t(tt), d_(*t), m(d_.m), step(d_.step), B(d_.B), S(d_.S), big(d_.big), small(d_.small), coset_fwd(d_.coset_fwd), coset_inv(d_.coset_inv), zinv(d_.zinv), wpow(d_.wpow), winvpow(d_.winvpow),
-                                                        scale_big(d_.scale_big), scale_small(d_.scale_small), half(d_.half) {}
+                                                        scale_big(d_.scale_big), scale_small(d_.scale_small), coset_fwd261(d_.coset_fwd261), one261(d_.one261), inv_big261(d_.inv_big261), inv_small261(d_.inv_small261), half(d_.half) {}
 };
 Domain::Domain(const Domain &peer) : impl(new Impl(peer.impl->t)) { Impl &d = *impl; d.scratch_stride = d.m; d.scratch = DevBuf<Fe32>(d.step ? 6 * d.B : 3 * d.m); }
 
@@ -205,7 +212,7 @@ Domain::Domain(size_t min_size) : impl(new Impl(std::make_shared<DomainTables>()
     // cosetFFT: multiply by g^i then FFT.  icosetFFT: iFFT (incl. 1/m) then multiply by g^-i  (basic_radix2_domain.tcc:74-88)
     auto cf = geometric_table(d.m, one, g), ci = geometric_table(d.m, minv, ginv), sc = geometric_table(d.m, minv, one);
     d.coset_fwd = DevBuf<Fe32>(d.m); d.coset_fwd.upload(cf.data(), d.m); d.coset_inv = DevBuf<Fe32>(d.m); d.coset_inv.upload(ci.data(), d.m);
-    d.scale_big = DevBuf<Fe32>(d.m); d.scale_big.upload(sc.data(), d.m);
+    d.scale_big = DevBuf<Fe32>(d.m); d.scale_big.upload(sc.data(), d.m); d.inv_big261 = fe261(minv); d.inv_small261 = fe261(one);
     HFr z = (g.pow_u64(d.m) - one).inv(); Fe32 zz; memcpy(&zz, z.l, 32); d.zinv = DevBuf<Fe32>(1); d.zinv.upload(&zz, 1);       // divide_by_Z_on_coset :103-112
   } else {
     HFr w = fr_root_of_unity((size_t)1 << ceil_log2(d.m)), wb = w.sqr(), ws = fr_root_of_unity(d.S), winv = w.inv();   // step_radix2_domain.tcc:20-37
@@ -214,7 +221,7 @@ Domain::Domain(size_t min_size) : impl(new Impl(std::make_shared<DomainTables>()
     auto sb = geometric_table(d.B, HFr::from_u64(d.B).inv(), one), ss = geometric_table(d.S, HFr::from_u64(d.S).inv(), one);
     d.coset_fwd = DevBuf<Fe32>(d.m); d.coset_fwd.upload(cf.data(), d.m); d.coset_inv = DevBuf<Fe32>(d.m); d.coset_inv.upload(ci.data(), d.m);
     d.wpow = DevBuf<Fe32>(d.B); d.wpow.upload(wp.data(), d.B); d.winvpow = DevBuf<Fe32>(d.S); d.winvpow.upload(wip.data(), d.S);
-    d.scale_big = DevBuf<Fe32>(d.B); d.scale_big.upload(sb.data(), d.B); d.scale_small = DevBuf<Fe32>(d.S); d.scale_small.upload(ss.data(), d.S);
+    d.scale_big = DevBuf<Fe32>(d.B); d.scale_big.upload(sb.data(), d.B); d.scale_small = DevBuf<Fe32>(d.S); d.scale_small.upload(ss.data(), d.S); d.inv_big261 = fe261(HFr::from_u64(d.B).inv()); d.inv_small261 = fe261(HFr::from_u64(d.S).inv());
     // divide_by_Z_on_coset (:242-260): P[i] /= (g^S * Z0 * w^(2S i) - w^S * Z0) for i < B ; P[B+i] /= Z1
     std::vector<Fe32> zt(d.m); HFr Z0 = g.pow_u64(d.B) - one, cSZ0 = g.pow_u64(d.S) * Z0, wS = w.pow_u64(d.S), wSZ0 = wS * Z0, w2S = w.pow_u64(2 * d.S), elt = one;
     // batch inversion of the B denominators
@@ -224,6 +231,7 @@ Domain::Domain(size_t min_size) : impl(new Impl(std::make_shared<DomainTables>()
     HFr cw = g * w, Z1 = ((cw.pow_u64(d.B) - one) * (cw.pow_u64(d.S) - wS)).inv(); for (size_t i = 0; i < d.S; i++) memcpy(&zt[d.B + i], Z1.l, 32);
     d.zinv = DevBuf<Fe32>(d.m); d.zinv.upload(zt.data(), d.m);
   }
+  d.one261 = fe261(one); { auto cf = geometric_table(d.m, one, g); for (auto &f : cf) { HFr v; memcpy(v.l, &f, 32); f = fe261(v); } d.coset_fwd261 = DevBuf<Fe32>(d.m); d.coset_fwd261.upload(cf.data(), d.m); }
   d.scratch_stride = d.m; d.scratch = DevBuf<Fe32>(d.step ? 6 * d.B : 3 * d.m);
 }
 Domain::~Domain() = default;
@@ -234,32 +242,32 @@ static void mul_table(Fe32 *a, const Fe32 *t, size_t n, int batch, size_t stride
 
 void Domain::fft(Fe32 *data, int batch, size_t stride) {
   Stage st("ntt.forward"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
-  if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->tw.get(), d.big->logn, nullptr, nullptr, batch, stride, d.scratch_stride); return; }
+  if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, batch, stride, d.scratch_stride); return; }
   // step_radix2_domain::FFT (:39-77): c / d / e pre-pass in place, then a B-point and an S-point transform of every vector; scratch = [d: 3B | transform scratch: 3B]
   hipStream_t s = gpu().stream; Fe32 *dbuf = d.scratch.get(), *tmp = d.scratch.get() + 3 * d.B;
   hipLaunchKernelGGL(k_step_fwd_pre, dim3(cdiv(d.B, 256), batch), dim3(256), 0, s, (Fr *)data, (Fr *)dbuf, (const Fr *)d.wpow.get(), (uint32_t)d.B, (uint32_t)d.S, stride);
   hipLaunchKernelGGL(k_step_fold, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (const Fr *)dbuf, (Fr *)data, (uint32_t)d.B, (uint32_t)d.S, stride);
-  radix2_transform(data, tmp, d.big->tw.get(), d.big->logn, nullptr, nullptr, batch, stride, d.B); radix2_transform(data + d.B, tmp, d.small->tw.get(), d.small->logn, nullptr, nullptr, batch, stride, d.B);
+  radix2_transform(data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, batch, stride, d.B); radix2_transform(data + d.B, tmp, d.small->tw.get(), d.small->tw261.get(), d.small->logn, nullptr, nullptr, d.one261, nullptr, batch, stride, d.B);
 }
 void Domain::ifft(Fe32 *data, int batch, size_t stride) {
   Stage st("ntt.inverse"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
-  if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, d.scale_big.get(), nullptr, batch, stride, d.scratch_stride); return; }   // 1/m folded into the load
+  if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, batch, stride, d.scratch_stride); return; }   // 1/m: the row pass's final factor
   // step_radix2_domain::iFFT (:79-140): both inverse transforms in place (1/B, 1/S folded into their loads), then the recombination pass
   hipStream_t s = gpu().stream; Fe32 *tmp = d.scratch.get() + 3 * d.B;
-  radix2_transform(data, tmp, d.big->itw.get(), d.big->logn, d.scale_big.get(), nullptr, batch, stride, d.B); radix2_transform(data + d.B, tmp, d.small->itw.get(), d.small->logn, d.scale_small.get(), nullptr, batch, stride, d.B);
+  radix2_transform(data, tmp, d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, batch, stride, d.B); radix2_transform(data + d.B, tmp, d.small->itw.get(), d.small->itw261.get(), d.small->logn, d.scale_small.get(), nullptr, d.inv_small261, nullptr, batch, stride, d.B);
   Fr half; memcpy(&half, d.half.l, 32);
   hipLaunchKernelGGL(k_step_inv_post, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half, (uint32_t)d.B, (uint32_t)d.S, stride);
 }
 void Domain::coset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
-  if (!d.step) { Stage st("ntt.forward"); radix2_transform(data, d.scratch.get(), d.big->tw.get(), d.big->logn, d.coset_fwd.get(), nullptr, batch, stride, d.scratch_stride); return; }   // g^i folded into the load
+  if (!d.step) { Stage st("ntt.forward"); radix2_transform(data, d.scratch.get(), d.big->tw.get(), d.big->tw261.get(), d.big->logn, d.coset_fwd.get(), d.coset_fwd261.get(), d.one261, nullptr, batch, stride, d.scratch_stride); return; }   // g^i folded into the load
   mul_table(data, d.coset_fwd.get(), d.m, batch, stride); fft(data, batch, stride);
 }
 void Domain::icoset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl;
   if (!d.step) { Stage st("ntt.inverse");   // coset_inv carries 1/m; it is folded into the store unless the transform is a single pass
-    if (d.big->logn <= NTT_TILE_LOG) { radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, nullptr, nullptr, batch, stride, d.scratch_stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride); }
-    else radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->logn, nullptr, d.coset_inv.get(), batch, stride, d.scratch_stride);
+    if (d.big->logn <= NTT_TILE_LOG) { radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, batch, stride, d.scratch_stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride); }
+    else radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, nullptr, nullptr, d.one261, d.coset_inv.get(), batch, stride, d.scratch_stride);
     return; }
   ifft(data, batch, stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride);
 }

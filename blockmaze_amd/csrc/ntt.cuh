@@ -6,14 +6,15 @@
 // the pre/post passes in step_domain kernels, step_radix2_domain (domains/step_radix2_domain.tcc:39-153,242-260).
 // Field arithmetic is exact, so any butterfly schedule gives bit-identical vectors; the schedule here is the GPU one:
 //   * n = n1 * n2: a column pass (k_ntt_cols) and a row pass (k_ntt_rows), each holding its tile in LDS — natural order in and out, no bit-reversal pass over HBM
-//   * inside a tile: decimation-in-frequency stages three at a time with the eight values of a butterfly group in registers (one LDS round trip and one barrier
-//     per three stages), stage twiddles staged in LDS, tile padded against bank conflicts
+//   * inside a tile: elements on nine 29-bit limbs, Cooley-Tukey stages two (or three) at a time with the values of a butterfly group in registers (one LDS round
+//     trip and one barrier per pass), stage twiddles staged in LDS, tile padded against bank conflicts
 //   * `batch` independent vectors per launch (the witness map transforms A, B, C together)
 //   * scaling by 1/n and the coset shift g^i are folded into the load of the column pass or the store of the row pass
 //   * beyond 2^22 points: bit-reversal gather + one launch per stage (k_ntt_bitrev_scale, k_ntt_local, k_ntt_stage)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "field.cuh"
+#include "field29.cuh"
 
 namespace zk {
 
@@ -61,71 +62,93 @@ __global__ void k_ntt_stage(Fr *__restrict__ data, const Fr *__restrict__ tw, in
 //   decimation-in-frequency stages in LDS, multiplies by the step twiddles and stores Y[k1*n2 + i2] to the same positions (safe in place).
 // k_ntt_rows: the outer sums — C adjacent rows k1 (contiguous loads), log2(n2) stages in LDS, stores X[k1 + n1*k2] in runs of C.
 // tw[j] = w_n^j for j < n/2.  Optional tables: `pre` multiplies the input (natural index), `post` the output (natural index).
-constexpr int NTT_TILE_LOG = 11;             // at most 2048 elements per workgroup: 68 KiB of LDS for the padded tile + up to 32 KiB for its twiddles (the launch raises the dynamic LDS limit)
+constexpr int NTT_TILE_LOG = 11;             // at most 2048 elements per workgroup: 77 KiB of LDS for the padded tile + up to 36 KiB for its twiddles (the launch raises the dynamic LDS limit)
 constexpr int NTT_TILE_THREADS = 256;
 
-__device__ __forceinline__ Fr ntt_twiddle(const Fr *__restrict__ tw, uint32_t e, uint32_t half_n) { return e < half_n ? tw[e] : tw[e - half_n].neg(); }   // w^(n/2) = -1
-
-// R decimation-in-frequency stages (s, s-1, ..., s-R+1) of the N-point transforms over the rows of tile[N][C] (element i of column c at tile[i*C + c]) with the
-// 2^R values of a butterfly group held in registers: one LDS round trip and one barrier per R stages.  twl[j] = w_N^j (j < N/2) is an LDS copy of the twiddles.
-// LDS layout of a tile: element e sits at e + (e >> 4) (one 32-byte pad per 16 elements).  Without it the last radix-8 pass (each lane owns 8 consecutive elements, so
-// lanes are 16 elements = 512 bytes apart) and the bit-reversed read-out put all 64 lanes of an access on the same 8 banks.
+// Round 3: INSIDE a tile the elements live on nine 29-bit limbs (Fr29, field29_gfx950.inc: Montgomery radix 2^261): a product is 162 multiply-adds and no carry
+// instruction (the 8 x 32-bit product: 128 + 128 and a conditional subtraction), sums and differences are nine independent 32-bit operations and a parallel carry step.
+// HBM keeps the 8 x 32-bit Montgomery form (radix 2^256), so nothing outside the two tile kernels changes.  Conversions cost nothing: the eight words of x 2^256 ARE the
+// integer of (x / 32) 2^261 — the transform is linear, the factor 1/32 rides through it —, and the multiplication every element gets on its way out (step twiddle in the
+// column pass, the constant one in the row pass) uses the 2^261-form of its factor (tw261[j] = w^j 2^261 mod r, canonical, 8 words), which cancels the 2^261 and leaves
+// y 2^256 below 2 r: packed to words and reduced once, the canonical form the next kernel expects.
+// The butterflies are Cooley-Tukey's (u + c v, u - c v) in natural-in / bit-reversed-out order (the polynomial view: f mod (x^M - e) splits into f0 + c f1 and f0 - c f1
+// with c^2 = e, so all butterflies of a block share the twiddle c = w^(bitrev(block) * span)): with the product BEFORE the sum a value grows by at most 2.2 r per stage
+// (u + t below u + 1.2 r, u + 2r - t below u + 2 r; t = c v below v / 169 + r) — 25 r after eleven stages, no reduction inside a tile; Gentleman-Sande's (u + v, (u - v) c)
+// doubles the sum path every stage.  Same positions in and out as the decimation-in-frequency passes this replaces: position p ends up holding output bitrev(p).
+// LDS layout of a tile: element e sits at e + (e >> 4) (one element of padding per 16) as before.
 __device__ __forceinline__ uint32_t ntt_pad(uint32_t e) { return e + (e >> 4); }
-template <int R> __device__ __forceinline__ void ntt_lds_pass(Fr *tile, const Fr *twl, int logN, int logC, int s) {
+__device__ __forceinline__ Fr29 ntt29_from_words(const Fr &v) { uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) w[i] = v.l[i];
+  return Fr29::unpack(w); }
+// value (any multiple of r added, exact limbs, below 2 r) -> canonical 8 x 32-bit words
+__device__ __forceinline__ Fr ntt29_to_words(const Fr29 &t) { uint32_t w[8]; t.pack_words(w); Fr r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = w[i];
+  return Fr::reduce_once(r); }
+// R stages (s, s-1, ..., s-R+1; stage st pairs positions 2^(st-1) apart) of the N-point transforms over the rows of tile[N][C] (element i of column c at tile[i*C + c]) with
+// the 2^R values of a butterfly group held in registers: one LDS round trip and one barrier per R stages.  twl[j] = w_N^j 2^261 (j < N/2) is an LDS copy of the twiddles.
+template <int R> __device__ __forceinline__ void ntt29_lds_pass(Fr29 *tile, const Fr29 *twl, int logN, int logC, int s) {
   const uint32_t groups = (1u << (logN - R)) << logC, cmask = (1u << logC) - 1; const int sh = s - R;
   for (uint32_t w = threadIdx.x; w < groups; w += blockDim.x) {
-    const uint32_t g = w >> logC, c = w & cmask, base = ((g >> sh) << s) | (g & ((1u << sh) - 1)); Fr x[1 << R];
+    const uint32_t g = w >> logC, c = w & cmask, base = ((g >> sh) << s) | (g & ((1u << sh) - 1)); Fr29 x[1 << R];
 #pragma unroll
     for (int q = 0; q < (1 << R); q++) x[q] = tile[ntt_pad(((base + ((uint32_t)q << sh)) << logC) + c)];
 #pragma unroll
-    for (int t = 0; t < R; t++) { const int st = s - t, hx = 1 << (R - 1 - t);
+    for (int t = 0; t < R; t++) { const int st = s - t, hx = 1 << (R - 1 - t), bits = logN - st;   // bits: the width of the block index at this stage (0: the first stage, no twiddle)
 #pragma unroll
       for (int q = 0; q < (1 << R); q++) if (!(q & hx)) {
-        uint32_t j = (base + ((uint32_t)q << sh)) & ((1u << (st - 1)) - 1); Fr u = x[q], v = x[q + hx]; x[q] = u + v; Fr d = u - v; if (j) d = d * twl[j << (logN - st)]; x[q + hx] = d; }
+        const uint32_t blk = (base + ((uint32_t)q << sh)) >> st; Fr29 u = x[q], v = x[q + hx];
+        if (bits) v = Fr29::mul(v, twl[(__brev(blk) >> (32 - bits)) << (st - 1)]);   // (bits is the same for the whole workgroup)
+        x[q] = Fr29::add_raw(u, v).norm(); x[q + hx] = Fr29::sub_product(u, v).norm(); }
     }
 #pragma unroll
     for (int q = 0; q < (1 << R); q++) tile[ntt_pad(((base + ((uint32_t)q << sh)) << logC) + c)] = x[q];
   }
   __syncthreads();
 }
-// log2(N) DIF stages; afterwards position p holds output bitrev(p).  tws = n / N: twl[j] = tw[j * tws]
-__device__ __forceinline__ void ntt_lds_dif(Fr *tile, Fr *twl, int logN, int logC, const Fr *__restrict__ tw, uint32_t tws, int radix_log) {
-  for (uint32_t j = threadIdx.x; j < (1u << logN) / 2; j += blockDim.x) twl[j] = tw[j * tws];
+// log2(N) stages; afterwards position p holds output bitrev(p).  tws = n / N: twl[j] = tw261[j * tws]
+__device__ __forceinline__ void ntt29_lds_transform(Fr29 *tile, Fr29 *twl, int logN, int logC, const Fr *__restrict__ tw261, uint32_t tws, int radix_log) {
+  for (uint32_t j = threadIdx.x; j < (1u << logN) / 2; j += blockDim.x) twl[j] = ntt29_from_words(tw261[j * tws]);
   __syncthreads();
   int s = logN;
-  if (radix_log >= 3) for (; s >= 3; s -= 3) ntt_lds_pass<3>(tile, twl, logN, logC, s);
-  if (radix_log >= 2) for (; s >= 2; s -= 2) ntt_lds_pass<2>(tile, twl, logN, logC, s);
-  for (; s >= 1; s -= 1) ntt_lds_pass<1>(tile, twl, logN, logC, s);
+  if (radix_log >= 3) for (; s >= 3; s -= 3) ntt29_lds_pass<3>(tile, twl, logN, logC, s);
+  if (radix_log >= 2) for (; s >= 2; s -= 2) ntt29_lds_pass<2>(tile, twl, logN, logC, s);
+  for (; s >= 1; s -= 1) ntt29_lds_pass<1>(tile, twl, logN, logC, s);
 }
-__global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(const Fr *__restrict__ src, Fr *__restrict__ dst, const Fr *__restrict__ pre, const Fr *__restrict__ tw,
+// tw261[j] = w_n^j 2^261 mod r for j < n/2, canonical
+// pre261 (optional): a factor per input element, scale261: one factor for the whole vector (applied by the pass that stores the final values: the row pass, or this one
+// when it is the whole transform) — both as f 2^261 mod r, canonical
+__global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(const Fr *__restrict__ src, Fr *__restrict__ dst, const Fr *__restrict__ pre261, const Fr *__restrict__ tw261, Fr scale261,
                                                                int logn, int log_n1, int logC, int radix_log, size_t stride_in, size_t stride_out) {
-  extern __shared__ uint32_t lds_raw[]; Fr *tile = reinterpret_cast<Fr *>(lds_raw);
+  extern __shared__ uint32_t lds_raw[]; Fr29 *tile = reinterpret_cast<Fr29 *>(lds_raw);
   // XCD-aware tile order.  A one-column tile reads 32 bytes of every 128-byte line it touches; the other three quarters belong to the next three columns.  Workgroup b
   // runs on XCD b % 8 (MI355X_MICROARCH.md, observed dispatch order), each XCD has its own L2, so with tile = blockIdx.x four different L2s fetched every line: 4.2x the
   // algorithmic traffic (PMC, profiles/r02e).  Giving XCD x the contiguous columns [x * n_tiles / 8, (x + 1) * n_tiles / 8) in dispatch order lets the four tiles of a
   // line share one L2 fetch.  (A different placement only costs the extra fetches again: results do not depend on it.)
   const uint32_t n_tiles = gridDim.x, tile_no = n_tiles >= 8 && n_tiles % 8 == 0 ? (blockIdx.x % 8) * (n_tiles / 8) + blockIdx.x / 8 : blockIdx.x;
-  const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, c0 = tile_no << logC, elems = (1u << log_n1) << logC, half_n = 1u << (logn - 1);
+  const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, c0 = tile_no << logC, elems = (1u << log_n1) << logC, half_n = logn ? 1u << (logn - 1) : 1u;
   const Fr *s = src + blockIdx.y * stride_in; Fr *d = dst + blockIdx.y * stride_out;
-  for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t g = ((w >> logC) << log_n2) + c0 + (w & (C - 1)); Fr v = s[g]; if (pre) v = v * pre[g]; tile[ntt_pad(w)] = v; }
+  for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t g = ((w >> logC) << log_n2) + c0 + (w & (C - 1)); Fr29 v = ntt29_from_words(s[g]); if (pre261) v = Fr29::mul(ntt29_from_words(pre261[g]), v); tile[ntt_pad(w)] = v; }   // (x 2^256)(f 2^261) / 2^261 = x f 2^256, exact limbs, below 2 r
   __syncthreads();
-  ntt_lds_dif(tile, tile + ntt_pad(elems), log_n1, logC, tw, n2, radix_log);
+  ntt29_lds_transform(tile, tile + ntt_pad(elems), log_n1, logC, tw261, n2, radix_log);
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
-    uint32_t k1 = w >> logC, c = w & (C - 1), i2 = c0 + c, p = log_n1 ? bitrev32(k1, log_n1) : 0; Fr v = tile[ntt_pad((p << logC) + c)];
-    uint32_t e = i2 * k1; if (e) v = v * ntt_twiddle(tw, e, half_n);
-    d[(k1 << log_n2) + i2] = v;
+    uint32_t k1 = w >> logC, c = w & (C - 1), i2 = c0 + c, p = log_n1 ? bitrev32(k1, log_n1) : 0; const Fr29 v = tile[ntt_pad((p << logC) + c)];
+    const uint32_t e = i2 * k1; Fr29 t = ntt29_from_words(log_n2 ? tw261[e < half_n ? e : e - half_n] : scale261); if (e >= half_n) t = Fr29::neg_product(t);   // w^(n/2) = -1; the factor also brings the element back below 2 r
+    d[(k1 << log_n2) + i2] = ntt29_to_words(Fr29::mul(t, v));
   }
 }
-__global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_rows(const Fr *__restrict__ src, Fr *__restrict__ dst, const Fr *__restrict__ post, const Fr *__restrict__ tw,
+__global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_rows(const Fr *__restrict__ src, Fr *__restrict__ dst, const Fr *__restrict__ post, const Fr *__restrict__ tw261, Fr scale261,
                                                                int logn, int log_n1, int logC, int radix_log, size_t stride_in, size_t stride_out) {
-  extern __shared__ uint32_t lds_raw[]; Fr *tile = reinterpret_cast<Fr *>(lds_raw);
+  extern __shared__ uint32_t lds_raw[]; Fr29 *tile = reinterpret_cast<Fr29 *>(lds_raw);
   const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, r0 = blockIdx.x << logC, elems = n2 << logC;
   const Fr *s = src + blockIdx.y * stride_in; Fr *d = dst + blockIdx.y * stride_out;
-  for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t c = w >> log_n2, i2 = w & (n2 - 1); tile[ntt_pad((i2 << logC) + c)] = s[((size_t)(r0 + c) << log_n2) + i2]; }
+  for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t c = w >> log_n2, i2 = w & (n2 - 1); tile[ntt_pad((i2 << logC) + c)] = ntt29_from_words(s[((size_t)(r0 + c) << log_n2) + i2]); }
   __syncthreads();
-  ntt_lds_dif(tile, tile + ntt_pad(elems), log_n2, logC, tw, 1u << log_n1, radix_log);
+  ntt29_lds_transform(tile, tile + ntt_pad(elems), log_n2, logC, tw261, 1u << log_n1, radix_log);
+  const Fr29 one = ntt29_from_words(scale261);   // 2^261 mod r when nothing is to be scaled: the product then only brings the element back below 2 r
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
-    uint32_t k2 = w >> logC, c = w & (C - 1), p = bitrev32(k2, log_n2), o = (k2 << log_n1) + r0 + c; Fr v = tile[ntt_pad((p << logC) + c)];
+    uint32_t k2 = w >> logC, c = w & (C - 1), p = bitrev32(k2, log_n2), o = (k2 << log_n1) + r0 + c; Fr v = ntt29_to_words(Fr29::mul(one, tile[ntt_pad((p << logC) + c)]));
     if (post) v = v * post[o];
     d[o] = v;
   }
