@@ -133,40 +133,54 @@ static std::vector<Fe32> geometric_table(size_t n, const HFr &first, const HFr &
 static int ntt_pref_log_c() { static const int v = [] { const char *e = getenv("ZK_NTT_LOGC"); int x = e ? atoi(e) : 1;   // two columns per tile since the tiles compute on 29-bit limbs (1.01 against 1.04 ms per send proof; one column was best for the 32-bit passes)
     return x < 0 ? 0 : x > 3 ? 3 : x; }(); return v; }
 static Fe32 fe261(HFr v) { for (int i = 0; i < 5; i++) v = v + v; Fe32 o; memcpy(&o, v.l, 32); return o; }   // f 2^261 mod r as a canonical integer (the host type holds f 2^256: five doublings)
-// data = post * NTT(pre * data) * scale.  The tile kernels take the per-element factor as pre261 (f 2^261) and the constant as scale261; pre_scale (f 2^256) is the same
-// table for the stage-per-launch path beyond 2^22 points, which folds a constant scale into it
-static void radix2_transform(Fe32 *data, Fe32 *scratch, const Fe32 *tw, const Fe32 *tw261, int logn, const Fe32 *pre_scale, const Fe32 *pre261, const Fe32 &scale261, const Fe32 *post_scale, int batch, size_t stride, size_t scratch_stride) {
-  Fr sc; memcpy(&sc, &scale261, 32);
-  hipStream_t s = gpu().stream; size_t n = (size_t)1 << logn;
-  static const int rl = [] { const char *e = getenv("ZK_NTT_RADIX_LOG"); int x = e ? atoi(e) : 2; return x < 1 ? 1 : x > 3 ? 3 : x; }();   // radix-4 passes on one-column tiles measured best with two vectors per launch (twice the waves of radix 8: the passes are latency bound), radix 8 with three
-  static const bool lds_raised = [] { HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_cols, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); return true; }(); (void)lds_raised;
-  auto threads_for = [](int logN, int logC) { int g = logN + logC - rl; unsigned t = 1u << (g < 6 ? 6 : g > 8 ? 8 : g); return t; };   // one butterfly group per thread and pass, 64..256 threads
-  auto lds_for = [](int logN, int logC) { size_t e = (size_t)1 << (logN + logC); return sizeof(Fr29) * (e + (e >> 4) + 1) + (sizeof(Fr29) << logN) / 2; };   // padded tile (ntt_pad) + twiddle table, 36 bytes an element
+// One in-place radix-2 transform of `batch` vectors: data = post * NTT(pre * data) * scale, natural order in and out.  The tile kernels take the per-element factor as
+// pre261 (f 2^261) and the constant as scale261; pre_scale (f 2^256) is the same table for the stage-per-launch path beyond 2^22 points, which folds a constant scale into it.
+struct NttCall { Fe32 *data, *scratch; const Fe32 *tw, *tw261; int logn; const Fe32 *pre_scale, *pre261; Fe32 scale261; const Fe32 *post_scale; size_t stride, scratch_stride; };
+static int ntt_radix_log() { static const int rl = [] { const char *e = getenv("ZK_NTT_RADIX_LOG"); int x = e ? atoi(e) : 2; return x < 1 ? 1 : x > 3 ? 3 : x; }(); return rl; }   // radix-4 passes measured best with two vectors per launch (twice the waves of radix 8: the passes are latency bound), radix 8 with three
+static bool ntt_two_pass(int logn) { return logn > NTT_TILE_LOG && logn <= 2 * NTT_TILE_LOG; }
+static unsigned ntt_threads_for(int logN, int logC) { int g = logN + logC - ntt_radix_log(); return 1u << (g < 6 ? 6 : g > 8 ? 8 : g); }   // one butterfly group per thread and pass, 64..256 threads
+static size_t ntt_lds_for(int logN, int logC) { size_t e = (size_t)1 << (logN + logC); return sizeof(Fr29) * (e + (e >> 4) + 1) + (sizeof(Fr29) << logN) / 2; }   // padded tile (ntt_pad) + twiddle table, 36 bytes an element
+static void ntt_raise_lds() { static const bool done = [] { HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_cols, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); return true; }(); (void)done; }
+// up to two transforms of the two-pass range (2^12 .. 2^22 points) in ONE column launch and ONE row launch (k_ntt_cols: data -> scratch, k_ntt_rows: scratch -> data)
+static void ntt_two_pass_launch(const NttCall *calls, int n_calls, int batch) {
+  hipStream_t s = gpu().stream; ntt_raise_lds(); NttJob cj[2], rj[2]; memset(cj, 0, sizeof cj); memset(rj, 0, sizeof rj); unsigned tc = 64, tr = 64; size_t lc = 0, lr = 0;
+  for (int k = 0; k < n_calls; k++) { const NttCall &c = calls[k]; const int l1 = c.logn / 2, l2 = c.logn - l1, c1 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l1, l2)), c2 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l2, l1));
+    Fr sc; memcpy(&sc, &c.scale261, 32);
+    cj[k] = NttJob{(const Fr *)c.data, (Fr *)c.scratch, (const Fr *)c.pre261, (const Fr *)c.tw261, sc, c.logn, l1, c1, 1u << (l2 - c1), c.stride, c.scratch_stride};
+    rj[k] = NttJob{(const Fr *)c.scratch, (Fr *)c.data, (const Fr *)c.post_scale, (const Fr *)c.tw261, sc, c.logn, l1, c2, 1u << (l1 - c2), c.scratch_stride, c.stride};
+    tc = std::max(tc, ntt_threads_for(l1, c1)); tr = std::max(tr, ntt_threads_for(l2, c2)); lc = std::max(lc, ntt_lds_for(l1, c1)); lr = std::max(lr, ntt_lds_for(l2, c2)); }
+  hipLaunchKernelGGL(k_ntt_cols, dim3(cj[0].tiles + cj[1].tiles, batch), dim3(tc), lc, s, cj[0], cj[1], ntt_radix_log());
+  hipLaunchKernelGGL(k_ntt_rows, dim3(rj[0].tiles + rj[1].tiles, batch), dim3(tr), lr, s, rj[0], rj[1], ntt_radix_log());
+}
+static void radix2_transform(const NttCall &c, int batch) {
+  hipStream_t s = gpu().stream; size_t n = (size_t)1 << c.logn; Fe32 *data = c.data, *scratch = c.scratch; const int logn = c.logn; const size_t stride = c.stride, scratch_stride = c.scratch_stride;
   if (logn <= NTT_TILE_LOG) {          // n2 = 1: the column pass alone is the whole transform
-    if (post_scale) throw GpuError("ntt: post scale on a single-pass transform");
-    hipLaunchKernelGGL(k_ntt_cols, dim3(1, batch), dim3(threads_for(logn, 0)), lds_for(logn, 0), s, (const Fr *)data, (Fr *)data, (const Fr *)pre261, (const Fr *)tw261, sc, logn, logn, 0, rl, stride, stride);
+    if (c.post_scale) throw GpuError("ntt: post scale on a single-pass transform");
+    ntt_raise_lds(); Fr sc; memcpy(&sc, &c.scale261, 32); NttJob j{(const Fr *)data, (Fr *)data, (const Fr *)c.pre261, (const Fr *)c.tw261, sc, logn, logn, 0, 1u, stride, stride}, none; memset(&none, 0, sizeof none);
+    hipLaunchKernelGGL(k_ntt_cols, dim3(1, batch), dim3(ntt_threads_for(logn, 0)), ntt_lds_for(logn, 0), s, j, none, ntt_radix_log());
     return;
   }
-  if (logn <= 2 * NTT_TILE_LOG) {
-    int l1 = logn / 2, l2 = logn - l1, c1 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l1, l2)), c2 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l2, l1));
-    hipLaunchKernelGGL(k_ntt_cols, dim3((unsigned)(1u << (l2 - c1)), batch), dim3(threads_for(l1, c1)), lds_for(l1, c1), s, (const Fr *)data, (Fr *)scratch, (const Fr *)pre261, (const Fr *)tw261, sc, logn, l1, c1, rl, stride, scratch_stride);
-    hipLaunchKernelGGL(k_ntt_rows, dim3((unsigned)(1u << (l1 - c2)), batch), dim3(threads_for(l2, c2)), lds_for(l2, c2), s, (const Fr *)scratch, (Fr *)data, (const Fr *)post_scale, (const Fr *)tw261, sc, logn, l1, c2, rl, scratch_stride, stride);
-    return;
-  }
-  hipLaunchKernelGGL(k_ntt_bitrev_scale, dim3(cdiv(n, 256), batch), dim3(256), 0, s, (const Fr *)data, (Fr *)scratch, (const Fr *)pre_scale, logn, stride, scratch_stride);
+  if (ntt_two_pass(logn)) { ntt_two_pass_launch(&c, 1, batch); return; }
+  hipLaunchKernelGGL(k_ntt_bitrev_scale, dim3(cdiv(n, 256), batch), dim3(256), 0, s, (const Fr *)data, (Fr *)scratch, (const Fr *)c.pre_scale, logn, stride, scratch_stride);
   int L = NTT_LOCAL_LOG;
-  hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> L), batch), dim3(NTT_LOCAL_THREADS), sizeof(Fr) << L, s, (Fr *)scratch, (const Fr *)tw, logn, L, scratch_stride);
-  for (int st = L + 1; st <= logn; st++) hipLaunchKernelGGL(k_ntt_stage, dim3(cdiv(n / 2, 256), batch), dim3(256), 0, s, (Fr *)scratch, (const Fr *)tw, logn, st, scratch_stride);
+  hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> L), batch), dim3(NTT_LOCAL_THREADS), sizeof(Fr) << L, s, (Fr *)scratch, (const Fr *)c.tw, logn, L, scratch_stride);
+  for (int st = L + 1; st <= logn; st++) hipLaunchKernelGGL(k_ntt_stage, dim3(cdiv(n / 2, 256), batch), dim3(256), 0, s, (Fr *)scratch, (const Fr *)c.tw, logn, st, scratch_stride);
   for (int b = 0; b < batch; b++) HIP_CHECK(hipMemcpyAsync(data + b * stride, scratch + b * scratch_stride, n * sizeof(Fe32), hipMemcpyDeviceToDevice, s));
-  if (post_scale) hipLaunchKernelGGL(k_fr_mul_table, dim3(cdiv(n, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)post_scale, (uint32_t)n, stride);
+  if (c.post_scale) hipLaunchKernelGGL(k_fr_mul_table, dim3(cdiv(n, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)c.post_scale, (uint32_t)n, stride);
+}
+// the two transforms of a step-radix-2 domain: one pair of launches when both are in the two-pass range, one after the other otherwise
+static void radix2_transform_pair(const NttCall &a, const NttCall &b, int batch) {
+  if (ntt_two_pass(a.logn) && ntt_two_pass(b.logn)) { NttCall both[2] = {a, b}; ntt_two_pass_launch(both, 2, batch); return; }
+  radix2_transform(a, batch); radix2_transform(b, batch);
 }
 
 // ---- step-radix-2 helper kernels (domains/step_radix2_domain.tcc:39-153) ---------------------------------------------
 // forward pre-pass: c[i] = a[i] + a[i+B] (i<S) else a[i];  d[i] = w^i * (a[i] - a[i+B] (i<S) else a[i]);  e[i] = sum_j d[i + j*S]
 // (in place: c overwrites a[0..B); blockIdx.y = vector of the batch)
-__global__ void k_step_fwd_pre(Fr *a_all, Fr *__restrict__ dbuf_all, const Fr *__restrict__ wpow, uint32_t B, uint32_t S, size_t stride) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= B) return; Fr *a = a_all + blockIdx.y * stride, *dbuf = dbuf_all + (size_t)blockIdx.y * B; Fr x = a[i];
-  if (i < S) { Fr y = a[i + B]; a[i] = x + y; dbuf[i] = wpow[i] * (x - y); } else { dbuf[i] = wpow[i] * x; }
+// (cf, optional: the coset factors g^i of cosetFFT, multiplied in on the way — one pass over the vector and one launch less than a separate table multiplication)
+__global__ void k_step_fwd_pre(Fr *a_all, Fr *__restrict__ dbuf_all, const Fr *__restrict__ wpow, const Fr *__restrict__ cf, uint32_t B, uint32_t S, size_t stride) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= B) return; Fr *a = a_all + blockIdx.y * stride, *dbuf = dbuf_all + (size_t)blockIdx.y * B; Fr x = a[i]; if (cf) x = x * cf[i];
+  if (i < S) { Fr y = a[i + B]; if (cf) y = y * cf[i + B]; a[i] = x + y; dbuf[i] = wpow[i] * (x - y); } else { if (cf) a[i] = x; dbuf[i] = wpow[i] * x; }
 }
 __global__ void k_step_fold(const Fr *__restrict__ dbuf_all, Fr *__restrict__ a_all, uint32_t B, uint32_t S, size_t stride) {   // e overwrites a[B..B+S)
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= S) return; const Fr *dbuf = dbuf_all + (size_t)blockIdx.y * B; Fr acc = Fr::zero(); for (uint32_t j = i; j < B; j += S) acc = acc + dbuf[j];
@@ -240,34 +254,35 @@ bool Domain::is_step() const { return impl->step; }
 
 static void mul_table(Fe32 *a, const Fe32 *t, size_t n, int batch, size_t stride) { hipLaunchKernelGGL(k_fr_mul_table, dim3(cdiv(n, 256), batch), dim3(256), 0, gpu().stream, (Fr *)a, (const Fr *)t, (uint32_t)n, stride); }
 
-void Domain::fft(Fe32 *data, int batch, size_t stride) {
-  Stage st("ntt.forward"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
-  if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, batch, stride, d.scratch_stride); return; }
+void Domain::fft(Fe32 *data, int batch, size_t stride) { fft_with_factors(data, batch, stride, nullptr); }
+void Domain::fft_with_factors(Fe32 *data, int batch, size_t stride, const Fe32 *cf) {   // step domains only: cf = the coset factors, folded into the pre-pass
+  Stage st("ntt.forward"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3"); if (!d.step && cf) throw GpuError("domain: factors on a basic domain go through coset_fft");
+  if (!d.step) { radix2_transform(NttCall{data, d.scratch.get(), d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.scratch_stride}, batch); return; }
   // step_radix2_domain::FFT (:39-77): c / d / e pre-pass in place, then a B-point and an S-point transform of every vector; scratch = [d: 3B | transform scratch: 3B]
   hipStream_t s = gpu().stream; Fe32 *dbuf = d.scratch.get(), *tmp = d.scratch.get() + 3 * d.B;
-  hipLaunchKernelGGL(k_step_fwd_pre, dim3(cdiv(d.B, 256), batch), dim3(256), 0, s, (Fr *)data, (Fr *)dbuf, (const Fr *)d.wpow.get(), (uint32_t)d.B, (uint32_t)d.S, stride);
+  hipLaunchKernelGGL(k_step_fwd_pre, dim3(cdiv(d.B, 256), batch), dim3(256), 0, s, (Fr *)data, (Fr *)dbuf, (const Fr *)d.wpow.get(), (const Fr *)cf, (uint32_t)d.B, (uint32_t)d.S, stride);
   hipLaunchKernelGGL(k_step_fold, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (const Fr *)dbuf, (Fr *)data, (uint32_t)d.B, (uint32_t)d.S, stride);
-  radix2_transform(data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, batch, stride, d.B); radix2_transform(data + d.B, tmp, d.small->tw.get(), d.small->tw261.get(), d.small->logn, nullptr, nullptr, d.one261, nullptr, batch, stride, d.B);
+  radix2_transform_pair(NttCall{data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, NttCall{data + d.B, dbuf, d.small->tw.get(), d.small->tw261.get(), d.small->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, batch);   // (dbuf is free again after the fold: the S-point transform's scratch)
 }
 void Domain::ifft(Fe32 *data, int batch, size_t stride) {
   Stage st("ntt.inverse"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
-  if (!d.step) { radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, batch, stride, d.scratch_stride); return; }   // 1/m: the row pass's final factor
+  if (!d.step) { radix2_transform(NttCall{data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, stride, d.scratch_stride}, batch); return; }   // 1/m: the row pass's final factor
   // step_radix2_domain::iFFT (:79-140): both inverse transforms in place (1/B, 1/S folded into their loads), then the recombination pass
   hipStream_t s = gpu().stream; Fe32 *tmp = d.scratch.get() + 3 * d.B;
-  radix2_transform(data, tmp, d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, batch, stride, d.B); radix2_transform(data + d.B, tmp, d.small->itw.get(), d.small->itw261.get(), d.small->logn, d.scale_small.get(), nullptr, d.inv_small261, nullptr, batch, stride, d.B);
+  radix2_transform_pair(NttCall{data, tmp, d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, stride, d.B}, NttCall{data + d.B, d.scratch.get(), d.small->itw.get(), d.small->itw261.get(), d.small->logn, d.scale_small.get(), nullptr, d.inv_small261, nullptr, stride, d.B}, batch);
   Fr half; memcpy(&half, d.half.l, 32);
   hipLaunchKernelGGL(k_step_inv_post, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half, (uint32_t)d.B, (uint32_t)d.S, stride);
 }
 void Domain::coset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
-  if (!d.step) { Stage st("ntt.forward"); radix2_transform(data, d.scratch.get(), d.big->tw.get(), d.big->tw261.get(), d.big->logn, d.coset_fwd.get(), d.coset_fwd261.get(), d.one261, nullptr, batch, stride, d.scratch_stride); return; }   // g^i folded into the load
-  mul_table(data, d.coset_fwd.get(), d.m, batch, stride); fft(data, batch, stride);
+  if (!d.step) { Stage st("ntt.forward"); radix2_transform(NttCall{data, d.scratch.get(), d.big->tw.get(), d.big->tw261.get(), d.big->logn, d.coset_fwd.get(), d.coset_fwd261.get(), d.one261, nullptr, stride, d.scratch_stride}, batch); return; }   // g^i folded into the load
+  fft_with_factors(data, batch, stride, d.coset_fwd.get());
 }
 void Domain::icoset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl;
   if (!d.step) { Stage st("ntt.inverse");   // coset_inv carries 1/m; it is folded into the store unless the transform is a single pass
-    if (d.big->logn <= NTT_TILE_LOG) { radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, batch, stride, d.scratch_stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride); }
-    else radix2_transform(data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, nullptr, nullptr, d.one261, d.coset_inv.get(), batch, stride, d.scratch_stride);
+    if (d.big->logn <= NTT_TILE_LOG) { radix2_transform(NttCall{data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.scratch_stride}, batch); mul_table(data, d.coset_inv.get(), d.m, batch, stride); }
+    else radix2_transform(NttCall{data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, nullptr, nullptr, d.one261, d.coset_inv.get(), stride, d.scratch_stride}, batch);
     return; }
   ifft(data, batch, stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride);
 }

@@ -117,36 +117,42 @@ __device__ __forceinline__ void ntt29_lds_transform(Fr29 *tile, Fr29 *twl, int l
   for (; s >= 1; s -= 1) ntt29_lds_pass<1>(tile, twl, logN, logC, s);
 }
 // tw261[j] = w_n^j 2^261 mod r for j < n/2, canonical
-// pre261 (optional): a factor per input element, scale261: one factor for the whole vector (applied by the pass that stores the final values: the row pass, or this one
-// when it is the whole transform) — both as f 2^261 mod r, canonical
-__global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(const Fr *__restrict__ src, Fr *__restrict__ dst, const Fr *__restrict__ pre261, const Fr *__restrict__ tw261, Fr scale261,
-                                                               int logn, int log_n1, int logC, int radix_log, size_t stride_in, size_t stride_out) {
+// One transform's share of a tile launch.  factor261: the column pass's optional factor per input element (f 2^261); post: the row pass's optional factor per output
+// element (f 2^256, multiplied on the 8 x 32-bit side); scale261: one factor for the whole vector, applied by the pass that stores the final values (the row pass, or the
+// column pass when it is the whole transform); tw261[j] = w_n^j 2^261 mod r for j < n/2 — all canonical.
+// A launch carries up to TWO jobs (blockIdx.x < a.tiles: job a, else job b): the B-point and the S-point transform of a step-radix-2 domain (mint, redeem, deposit-32)
+// run side by side in one launch instead of one after the other — each alone fills half the chip or less and is as long as its dependent passes.
+struct NttJob { const Fr *src; Fr *dst; const Fr *factor; const Fr *tw261; Fr scale261; int logn, log_n1, logC; uint32_t tiles; size_t stride_in, stride_out; };
+__global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(NttJob ja, NttJob jb, int radix_log) {
   extern __shared__ uint32_t lds_raw[]; Fr29 *tile = reinterpret_cast<Fr29 *>(lds_raw);
-  // XCD-aware tile order.  A one-column tile reads 32 bytes of every 128-byte line it touches; the other three quarters belong to the next three columns.  Workgroup b
+  const bool second = blockIdx.x >= ja.tiles; const NttJob &j = second ? jb : ja; const uint32_t bid = blockIdx.x - (second ? ja.tiles : 0u);
+  const int logn = j.logn, log_n1 = j.log_n1, logC = j.logC; const Fr *__restrict__ tw261 = j.tw261; const Fr *__restrict__ pre261 = j.factor;
+  // XCD-aware tile order.  A narrow tile reads 32 or 64 bytes of every 128-byte line it touches; the rest belongs to the next columns.  Workgroup b
   // runs on XCD b % 8 (MI355X_MICROARCH.md, observed dispatch order), each XCD has its own L2, so with tile = blockIdx.x four different L2s fetched every line: 4.2x the
-  // algorithmic traffic (PMC, profiles/r02e).  Giving XCD x the contiguous columns [x * n_tiles / 8, (x + 1) * n_tiles / 8) in dispatch order lets the four tiles of a
+  // algorithmic traffic (PMC, profiles/r02e).  Giving XCD x the contiguous columns [x * n_tiles / 8, (x + 1) * n_tiles / 8) in dispatch order lets the tiles of a
   // line share one L2 fetch.  (A different placement only costs the extra fetches again: results do not depend on it.)
-  const uint32_t n_tiles = gridDim.x, tile_no = n_tiles >= 8 && n_tiles % 8 == 0 ? (blockIdx.x % 8) * (n_tiles / 8) + blockIdx.x / 8 : blockIdx.x;
+  const uint32_t n_tiles = j.tiles, tile_no = n_tiles >= 8 && n_tiles % 8 == 0 ? (bid % 8) * (n_tiles / 8) + bid / 8 : bid;
   const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, c0 = tile_no << logC, elems = (1u << log_n1) << logC, half_n = logn ? 1u << (logn - 1) : 1u;
-  const Fr *s = src + blockIdx.y * stride_in; Fr *d = dst + blockIdx.y * stride_out;
+  const Fr *s = j.src + blockIdx.y * j.stride_in; Fr *d = j.dst + blockIdx.y * j.stride_out;
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t g = ((w >> logC) << log_n2) + c0 + (w & (C - 1)); Fr29 v = ntt29_from_words(s[g]); if (pre261) v = Fr29::mul(ntt29_from_words(pre261[g]), v); tile[ntt_pad(w)] = v; }   // (x 2^256)(f 2^261) / 2^261 = x f 2^256, exact limbs, below 2 r
   __syncthreads();
   ntt29_lds_transform(tile, tile + ntt_pad(elems), log_n1, logC, tw261, n2, radix_log);
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
     uint32_t k1 = w >> logC, c = w & (C - 1), i2 = c0 + c, p = log_n1 ? bitrev32(k1, log_n1) : 0; const Fr29 v = tile[ntt_pad((p << logC) + c)];
-    const uint32_t e = i2 * k1; Fr29 t = ntt29_from_words(log_n2 ? tw261[e < half_n ? e : e - half_n] : scale261); if (e >= half_n) t = Fr29::neg_product(t);   // w^(n/2) = -1; the factor also brings the element back below 2 r
+    const uint32_t e = i2 * k1; Fr29 t = ntt29_from_words(log_n2 ? tw261[e < half_n ? e : e - half_n] : j.scale261); if (e >= half_n) t = Fr29::neg_product(t);   // w^(n/2) = -1; the factor also brings the element back below 2 r
     d[(k1 << log_n2) + i2] = ntt29_to_words(Fr29::mul(t, v));
   }
 }
-__global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_rows(const Fr *__restrict__ src, Fr *__restrict__ dst, const Fr *__restrict__ post, const Fr *__restrict__ tw261, Fr scale261,
-                                                               int logn, int log_n1, int logC, int radix_log, size_t stride_in, size_t stride_out) {
+__global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_rows(NttJob ja, NttJob jb, int radix_log) {
   extern __shared__ uint32_t lds_raw[]; Fr29 *tile = reinterpret_cast<Fr29 *>(lds_raw);
-  const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, r0 = blockIdx.x << logC, elems = n2 << logC;
-  const Fr *s = src + blockIdx.y * stride_in; Fr *d = dst + blockIdx.y * stride_out;
+  const bool second = blockIdx.x >= ja.tiles; const NttJob &j = second ? jb : ja; const uint32_t bid = blockIdx.x - (second ? ja.tiles : 0u);
+  const int logn = j.logn, log_n1 = j.log_n1, logC = j.logC; const Fr *__restrict__ tw261 = j.tw261; const Fr *__restrict__ post = j.factor;
+  const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, r0 = bid << logC, elems = n2 << logC;
+  const Fr *s = j.src + blockIdx.y * j.stride_in; Fr *d = j.dst + blockIdx.y * j.stride_out;
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) { uint32_t c = w >> log_n2, i2 = w & (n2 - 1); tile[ntt_pad((i2 << logC) + c)] = ntt29_from_words(s[((size_t)(r0 + c) << log_n2) + i2]); }
   __syncthreads();
   ntt29_lds_transform(tile, tile + ntt_pad(elems), log_n2, logC, tw261, 1u << log_n1, radix_log);
-  const Fr29 one = ntt29_from_words(scale261);   // 2^261 mod r when nothing is to be scaled: the product then only brings the element back below 2 r
+  const Fr29 one = ntt29_from_words(j.scale261);   // 2^261 mod r when nothing is to be scaled: the product then only brings the element back below 2 r
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
     uint32_t k2 = w >> logC, c = w & (C - 1), p = bitrev32(k2, log_n2), o = (k2 << log_n1) + r0 + c; Fr v = ntt29_to_words(Fr29::mul(one, tile[ntt_pad((p << logC) + c)]));
     if (post) v = v * post[o];
