@@ -504,6 +504,20 @@ __global__ void __launch_bounds__(256) k_msm_sum_ones(const Affine<F> *__restric
 //             eight quads, then a Horner chain of 7 doublings and 7 additions; (1) the tree over the ones' partial sums.  The host adds the two results.
 // The sort only depends on the scalars: MSMs over the same scalar vector (A and L*; B1 and B2) share one k_wsort (msm_impl.hpp: WsortBuffers).
 constexpr uint32_t WFUSED_MAX_BUCKETS = 128;
+// Key load: groups[g * 15 + v - 1] = the sum of P_(4g + j) over the bits j of v, v = 1 .. 15, affine (the all-zero record when the sum is the point at infinity; points
+// beyond n count as infinity).  46 % of a BlockMaze assignment are ones — bits of SHA-256 states, as good as independent — so a group of four scalars holds two ones on
+// average, which this table turns into one mixed addition (none for 1/16 of the groups): the ones are 80 % of a witness MSM's additions.  3.75x the memory of the points
+// (54 MB for the A query, 65 MB for the G2 half of B).
+template <class F>
+__global__ void __launch_bounds__(64) k_ones_groups(const Affine<F> *__restrict__ points, uint32_t n, Affine<F> *__restrict__ groups) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; if (4 * g >= n) return;
+  Affine<F> p0 = points[4 * g], p1 = 4 * g + 1 < n ? points[4 * g + 1] : Affine<F>::inf(), p2 = 4 * g + 2 < n ? points[4 * g + 2] : Affine<F>::inf(), p3 = 4 * g + 3 < n ? points[4 * g + 3] : Affine<F>::inf();
+#pragma unroll 1
+  for (uint32_t v = 1; v < 16; v++) { XYZZ<F> acc = XYZZ<F>::inf();
+    if (v & 1) acc.madd_inl(p0); if (v & 2) acc.madd_inl(p1); if (v & 4) acc.madd_inl(p2); if (v & 8) acc.madd_inl(p3);
+    Affine<F> o = Affine<F>::inf(); if (!acc.is_inf()) { const F iz3 = acc.ZZZ.inv(), iz2 = (acc.ZZ * iz3).sqr(); o = {acc.X * iz2, acc.Y * iz3}; }   // ZZ / ZZZ = 1 / Z
+    groups[(size_t)g * 15 + v - 1] = o; }
+}
 template <int C>
 __global__ void __launch_bounds__(256) k_wsort(const Fr *__restrict__ scalars, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf, uint32_t n, int c, int W, uint32_t point_stride, uint32_t NB, uint32_t cap,
                                                uint32_t *__restrict__ fill, uint32_t *__restrict__ fill_next, uint32_t *__restrict__ entries, uint32_t *__restrict__ ones, MsmCounters *cnt, MsmCounters *cnt_next) {
@@ -514,8 +528,11 @@ __global__ void __launch_bounds__(256) k_wsort(const Fr *__restrict__ scalars, c
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63; bool live = i < n && !(point_is_inf && point_is_inf[i]); Fr k = Fr::zero();
   if (live) { k = scalars[scalar_index ? scalar_index[i] : i].from_mont(); live = !k.is_zero(); }
   bool is_one = false; if (live) { uint32_t o = k.l[0] ^ 1u; for (int j = 1; j < 8; j++) o |= k.l[j]; is_one = o == 0; }
-  { uint64_t m = __ballot(is_one); if (m) { uint32_t base = 0; const int first = __ffsll((long long)m) - 1; if ((int)lane == first) base = atomicAdd(&cnt->n_ones, (uint32_t)__popcll(m));
-      base = __shfl(base, first, 64); if (is_one) ones[base + __popcll(m & ((1ull << lane) - 1))] = i; } }
+  // the ones, four consecutive points at a time: lanes 4g .. 4g + 3 form the nibble v of their flags, and the quad's first lane appends ONE entry g * 15 + v - 1 — the index
+  // of the precomputed sum of that subset in the groups table (k_ones_groups) — instead of up to four point indices: 15/16 of an addition per group against 2 on average
+  { const uint64_t m = __ballot(is_one); const uint32_t v = (uint32_t)(m >> (lane & ~3u)) & 15u; const bool lead = (lane & 3u) == 0 && v != 0; const uint64_t ml = __ballot(lead);
+    if (ml) { uint32_t base = 0; const int first = __ffsll((long long)ml) - 1; if ((int)lane == first) base = atomicAdd(&cnt->n_ones, (uint32_t)__popcll(ml));
+      base = __shfl(base, first, 64); if (lead) ones[base + __popcll(ml & ((1ull << lane) - 1))] = (i >> 2) * 15u + v - 1u; } }
   const bool other = live && !is_one;
   if (other) msm_walk_digits<C>(k.l, c, W, [&](int, int d) { if (d) atomicAdd(&lcnt[(uint32_t)(d < 0 ? -d : d) - 1], 1u); });
   __syncthreads();
@@ -531,13 +548,13 @@ constexpr uint32_t WFUSED_BUCKET_LANES = 4096, WFUSED_ONES_LANES = 8192, WFUSED_
 // Lanes are dealt to the buckets in proportion to their fill (a witness puts thousands of equal values into one bucket): slice length T = total / lanes, bucket b gets
 // ceil(fill_b / T) lanes, lane_off[] (NB + 1 prefix sums, recomputed by every workgroup, written out by the first) tells the next kernel where each bucket's partial sums lie.
 template <class F>
-__global__ void __launch_bounds__(256) k_wacc_lanes(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap, uint32_t NB, const uint32_t *__restrict__ ones, const MsmCounters *cnt,
+__global__ void __launch_bounds__(256) k_wacc_lanes(const Affine<F> *__restrict__ points, const Affine<F> *__restrict__ groups, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap, uint32_t NB, const uint32_t *__restrict__ ones, const MsmCounters *cnt,
                                                     XYZZ<F> *__restrict__ partial, uint32_t *__restrict__ lane_off) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; XYZZ<F> acc = XYZZ<F>::inf();
   if (t >= WFUSED_BUCKET_LANES) { const uint32_t u = t - WFUSED_BUCKET_LANES; if (u >= WFUSED_ONES_LANES) return; const uint32_t n1 = cnt->n_ones;     // (whole workgroups: 4096 is a multiple of 256)
-    if (u < n1) { Affine<F> p = points[ones[u]];
+    if (u < n1) { Affine<F> p = groups[ones[u]];
 #pragma unroll 1
-      for (uint32_t i = u; i < n1; i += WFUSED_ONES_LANES) { Affine<F> pn = p; if (i + WFUSED_ONES_LANES < n1) pn = points[ones[i + WFUSED_ONES_LANES]]; acc.madd_inl(p); p = pn; } }
+      for (uint32_t i = u; i < n1; i += WFUSED_ONES_LANES) { Affine<F> pn = p; if (i + WFUSED_ONES_LANES < n1) pn = groups[ones[i + WFUSED_ONES_LANES]]; acc.madd_inl(p); p = pn; } }
     partial[t] = acc; return; }
   __shared__ uint32_t m_of[WFUSED_MAX_BUCKETS], off[WFUSED_MAX_BUCKETS + 1], slice;
   if (threadIdx.x < NB) m_of[threadIdx.x] = min(fill[threadIdx.x], cap);
@@ -566,7 +583,7 @@ __global__ void __launch_bounds__(256) k_wacc_fold(const XYZZ<F> *__restrict__ p
 // workgroup b < NB stride over bucket b's entries directly (workgroups NB .. NB + 127 over the list of ones) and the workgroup's tree leaves the sum.
 constexpr uint32_t WFUSED_ONES_BLOCKS = 128;
 template <class F>
-__global__ void __launch_bounds__(256) k_wacc_quads(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap, uint32_t NB, const uint32_t *__restrict__ ones, const MsmCounters *cnt,
+__global__ void __launch_bounds__(256) k_wacc_quads(const Affine<F> *__restrict__ points, const Affine<F> *__restrict__ groups, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap, uint32_t NB, const uint32_t *__restrict__ ones, const MsmCounters *cnt,
                                                     XYZZ<F> *__restrict__ out) {
   __shared__ XYZZ<F> lds[4]; const uint32_t q = threadIdx.x >> 2, b = blockIdx.x; const int k = threadIdx.x & 3; XYZZ<F> acc = XYZZ<F>::inf();
   if (b < NB) { const uint32_t m = min(fill[b], cap); const uint32_t *e = entries + (size_t)b * cap;
@@ -575,9 +592,9 @@ __global__ void __launch_bounds__(256) k_wacc_quads(const Affine<F> *__restrict_
       for (uint32_t i = q; i < m; i += 64) { uint32_t vn = v; Affine<F> pn = p; if (i + 64 < m) { vn = e[i + 64]; pn = points[vn & ~MSM_ENTRY_SIGN]; } if (v >> 31) p.y = p.y.neg(); acc = quad_madd(acc, p, k); v = vn; p = pn; } }
     acc = block_quad_tree(acc, lds, min(m, 64u)); }
   else { const uint32_t n1 = cnt->n_ones, u = (b - NB) * 64 + q, stride = WFUSED_ONES_BLOCKS * 64;
-    if (u < n1) { Affine<F> p = points[ones[u]];
+    if (u < n1) { Affine<F> p = groups[ones[u]];
 #pragma unroll 1
-      for (uint32_t i = u; i < n1; i += stride) { Affine<F> pn = p; if (i + stride < n1) pn = points[ones[i + stride]]; acc = quad_madd(acc, p, k); p = pn; } }
+      for (uint32_t i = u; i < n1; i += stride) { Affine<F> pn = p; if (i + stride < n1) pn = groups[ones[i + stride]]; acc = quad_madd(acc, p, k); p = pn; } }
     acc = block_quad_tree(acc, lds); }
   if (threadIdx.x == 0) out[b] = acc;
 }

@@ -19,7 +19,7 @@ struct MsmImpl {
   size_t n; int c, W, WB; uint32_t NB;   // W digit windows; WB bucket arrays (1 when the multiples 2^(cw) P are precomputed, else W)
   bool filter_ones; uint32_t seg, n_ones_quads; std::string label = "msm"; int stream_id = -1;   // -1: main stream, 0..3: auxiliary stream
   // the key's points (with the fixed-base table when there is one) are immutable and shared by every prover object of the key on this device; everything else below is per-object workspace
-  struct Bases { size_t n = 0; int c = 0, W = 0, WB = 0; bool any_inf = false; DevBuf<RawAffine> points, points261 /* the same table with coordinates x 2^261: what k_hacc_runs29 gathers from (G1, uniform scalars, fixed-base table) */; DevBuf<uint8_t> inf; };
+  struct Bases { size_t n = 0; int c = 0, W = 0, WB = 0; bool any_inf = false; DevBuf<RawAffine> points, points261 /* the same table with coordinates x 2^261: what k_hacc_runs29 gathers from (G1, uniform scalars, fixed-base table) */, ones_groups /* 15 subset sums per four consecutive points: what the fused witness path adds for the scalars equal to one */; DevBuf<uint8_t> inf; };
   std::shared_ptr<const Bases> bases; const DevBuf<RawAffine> &points; const DevBuf<uint8_t> &inf; bool any_inf = false;
   bool split_ones = false; hipStream_t ones_stream = nullptr; hipEvent_t ev_classified = nullptr, ev_ones = nullptr;   // the ones path on a stream of its own, beside the bucket path (general path of the G2 MSM: both are long chains)
   const Fe32 *prod_b = nullptr, *prod_z = nullptr; bool prod_z_table = false; DevBuf<Fe32> prod_tmp;   // scalars given as a product a*b*z (run_product)
@@ -68,6 +68,8 @@ struct MsmImpl {
     }
     if constexpr (sizeof(F) == 32) if (uniform_hint && !fo && b->WB == 1 && n_) { const size_t tn = n_ * (size_t)b->W; b->points261 = DevBuf<RawAffine>(tn);   // the H query's table once more, in the 29-bit kernels' Montgomery radix
       hipLaunchKernelGGL(k_table_to_r261, dim3(cdiv(tn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq> *)b->points.get(), (Affine<Fq> *)b->points261.get(), tn); HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
+    if (fo && b->WB == 1 && n_) { const size_t ng = (n_ + 3) / 4; b->ones_groups = DevBuf<RawAffine>(ng * 15);   // subset sums of four consecutive points for the scalars equal to one (k_ones_groups)
+      hipLaunchKernelGGL((k_ones_groups<F>), dim3(cdiv(ng, 64)), dim3(64), 0, gpu().stream, (const Affine<F> *)b->points.get(), (uint32_t)n_, (Affine<F> *)b->ones_groups.get()); HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
     return b;
   }
   MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true, bool uniform_hint = false) : MsmImpl(make_bases(host_points, n_, c_, fo, tables, uniform_hint), fo, uniform_hint) {}
@@ -140,9 +142,9 @@ struct MsmImpl {
       uint4 *csrc = (uint4 *)(wc + w.parity); uint4 *cdst = (uint4 *)(res + RS + 1);
       XYZZ<F> *l2 = (XYZZ<F> *)ones_partial.get(); uint32_t n_op;                          // l2: [NB bucket sums | n_op partial sums of the ones]
       { Stage st((label + ".accumulate").c_str(), s); const uint32_t *fl = w.fill.get() + (size_t)w.parity * NB;
-        if (wacc_quads) { n_op = WFUSED_ONES_BLOCKS; hipLaunchKernelGGL((k_wacc_quads<F>), dim3(NB + WFUSED_ONES_BLOCKS), dim3(256), 0, s, (const Affine<F> *)points.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l2); }
+        if (wacc_quads) { n_op = WFUSED_ONES_BLOCKS; hipLaunchKernelGGL((k_wacc_quads<F>), dim3(NB + WFUSED_ONES_BLOCKS), dim3(256), 0, s, (const Affine<F> *)points.get(), (const Affine<F> *)bases->ones_groups.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l2); }
         else { n_op = WFUSED_ONES_GROUPS; XYZZ<F> *l1 = (XYZZ<F> *)partials.get();
-          hipLaunchKernelGGL((k_wacc_lanes<F>), dim3((WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) / 256), dim3(256), 0, s, (const Affine<F> *)points.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l1, lane_off.get());
+          hipLaunchKernelGGL((k_wacc_lanes<F>), dim3((WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) / 256), dim3(256), 0, s, (const Affine<F> *)points.get(), (const Affine<F> *)bases->ones_groups.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l1, lane_off.get());
           hipLaunchKernelGGL((k_wacc_fold<F>), dim3(NB + WFUSED_ONES_GROUPS), dim3(256), 0, s, (const XYZZ<F> *)l1, (const uint32_t *)lane_off.get(), NB, l2); } }
       { Stage st((label + ".reduce").c_str(), s); hipLaunchKernelGGL((k_wtail<F>), dim3(2), dim3(256), 0, s, (const XYZZ<F> *)l2, NB, (const XYZZ<F> *)l2 + NB, n_op, res, csrc, cdst); }
       HIP_CHECK(hipMemcpyAsync(h_result, result.get(), result_bytes(), hipMemcpyDeviceToHost, s)); return;
