@@ -351,10 +351,10 @@ void Domain::qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c) {
 }
 
 // packed: [ones bitmap | other bitmap | block offsets | values] already on the device (layout of Prover::set_witness)
-void expand_witness_dev(const uint8_t *packed, size_t words, const Fe32 &one_value, size_t n, Fe32 *out) {
+void expand_witness_dev(const uint8_t *packed, size_t words, const Fe32 &one_value, bool values_to_mont, size_t n, Fe32 *out) {
   const uint64_t *ones = (const uint64_t *)packed, *other = ones + words; const uint32_t *off = (const uint32_t *)(other + words); const Fr *vals = (const Fr *)(packed + ((words * 20 + 31) / 32) * 32);
   Fr one; memcpy(&one, &one_value, 32);
-  hipLaunchKernelGGL(k_expand_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, ones, other, off, vals, one, (uint32_t)n, (Fr *)out);
+  hipLaunchKernelGGL(k_expand_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, ones, other, off, vals, one, (int)values_to_mont, (uint32_t)n, (Fr *)out);
 }
 void fr_to_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_to_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
 void fr_from_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_from_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }

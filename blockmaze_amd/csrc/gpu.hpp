@@ -129,7 +129,7 @@ class R1csDev {
 };
 
 void fr_to_mont_dev(Fe32 *a, size_t n); void fr_from_mont_dev(Fe32 *a, size_t n);
-void expand_witness_dev(const uint8_t *packed_dev, size_t words, const Fe32 &one_value, size_t n, Fe32 *out);   // compact assignment upload (ntt.cuh: k_expand_witness)
+void expand_witness_dev(const uint8_t *packed_dev, size_t words, const Fe32 &one_value, bool values_to_mont, size_t n, Fe32 *out);   // compact assignment upload (ntt.cuh: k_expand_witness)
 
 // Key loading: y-coordinates of compressed points (x Montgomery; flags bit0 = parity of canonical y, bit1 = point at infinity).  Throws if an x is not on the curve.
 void decompress_g1(const Fe32 *xs, const uint8_t *flags, size_t n, G1AffineRaw *out);

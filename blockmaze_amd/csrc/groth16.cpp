@@ -365,10 +365,11 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   else for (size_t t = 0; t < T; t++) scan(t);
   static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;   // (test switch: the plain-copy branch below, which no BlockMaze assignment reaches on its own)
   bool compact = !force_dense; for (size_t t = 0; t < T; t++) compact = compact && fits[t];
-  if (compact) { upload_async(p.packed.get(), pk, vals_at); for (size_t t = 0; t < T; t++) if (used[t]) upload_async(p.packed.get() + vals_at + 32 * t * cap_t, pk + vals_at + 32 * t * cap_t, 32 * used[t]);
-    expand_witness_dev(p.packed.get(), words, one, n, p.z.get()); }
-  else { Fe32 *h = p.z_host.get(); h[0] = one; memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * n); }      // dense assignment: plain copy
-  if (!montgomery) fr_to_mont_dev(p.z.get(), n);
+  if (compact) {   // the threads' value areas are closed up (a few hundred KB) so that ONE copy carries bitmaps, offsets and values; the few values that are not 0 or 1 are brought into Montgomery form by the expanding kernel itself
+    size_t total = used[0]; for (size_t t = 1; t < T; t++) { if (used[t]) { const uint32_t delta = (uint32_t)(t * cap_t - total); memmove(&vals[total], &vals[t * cap_t], 32 * used[t]); for (size_t w = words * t / T; w < words * (t + 1) / T; w++) off[w] -= delta; } total += used[t]; }
+    upload_async(p.packed.get(), pk, vals_at + 32 * total); Fe32 one_mont; memcpy(&one_mont, FrParams::R1, 32);
+    expand_witness_dev(p.packed.get(), words, one_mont, !montgomery, n, p.z.get()); }
+  else { Fe32 *h = p.z_host.get(); h[0] = one; memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * n); if (!montgomery) fr_to_mont_dev(p.z.get(), n); }      // dense assignment: plain copy
   last.upload_ms = now_ms() - t0;
 }
 void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
@@ -383,7 +384,7 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
     for (uint64_t m = mx; m; m &= m - 1) vals[n_other++] = wide[lo + (size_t)__builtin_ctzll(m)];
     ones[w] = mo; other[w] = mx; }
   static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;
-  if (fits && !force_dense) { upload_async(p.packed.get(), pk, vals_at + 32 * n_other); expand_witness_dev(p.packed.get(), words, one, n, p.z.get()); }
+  if (fits && !force_dense) { upload_async(p.packed.get(), pk, vals_at + 32 * n_other); expand_witness_dev(p.packed.get(), words, one, false, n, p.z.get()); }
   else { Fe32 *h = p.z_host.get(); Fe32 zero; memset(&zero, 0, 32); for (size_t i = 0; i < n; i++) h[i] = tag[i] == 2 ? wide[i] : tag[i] ? one : zero; upload_async(p.z.get(), h, 32 * n); }   // a dense assignment (never a BlockMaze one)
   last.upload_ms = now_ms() - t0;
 }

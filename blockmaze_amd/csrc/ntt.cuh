@@ -205,9 +205,9 @@ __global__ void __launch_bounds__(64) k_r1cs_long_rows3(const uint32_t *__restri
 }
 // Assignment upload in compact form: 97 % of a BlockMaze witness are the bits 0 and 1, so the host sends two bitmaps (value is `one` / value is something else), the
 // running count of "something else" per 64 entries and only those values (0.3 MB instead of 7.3 MB over PCIe); this kernel rebuilds the vector.
-__global__ void k_expand_witness(const uint64_t *__restrict__ ones_bm, const uint64_t *__restrict__ other_bm, const uint32_t *__restrict__ block_off, const Fr *__restrict__ values, Fr one_value, uint32_t n, Fr *__restrict__ out) {
+__global__ void k_expand_witness(const uint64_t *__restrict__ ones_bm, const uint64_t *__restrict__ other_bm, const uint32_t *__restrict__ block_off, const Fr *__restrict__ values, Fr one_value, int values_to_mont, uint32_t n, Fr *__restrict__ out) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; const uint32_t wd = i >> 6, bit = i & 63; const uint64_t ob = other_bm[wd];
-  if ((ob >> bit) & 1) out[i] = values[block_off[wd] + (uint32_t)__popcll(ob & ((1ull << bit) - 1))];
+  if ((ob >> bit) & 1) { Fr v = values[block_off[wd] + (uint32_t)__popcll(ob & ((1ull << bit) - 1))]; if (values_to_mont) v = v.to_mont(); out[i] = v; }   // (a canonical assignment: only these 3 % need the conversion, one_value is the Montgomery one)
   else out[i] = ((ones_bm[wd] >> bit) & 1) ? one_value : Fr::zero();
 }
 // both of the above in ONE launch (the two are independent and each too small to fill the chip for long: 27 + 25 us one after the other at the head of every proof's
