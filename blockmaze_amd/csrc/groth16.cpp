@@ -11,6 +11,7 @@
 #include <fstream>
 #include <stdexcept>
 #include <array>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -269,14 +270,21 @@ void generate_keys(const R1csHost &cs_in, const ToxicWaste &tw, ProvingKeyHost &
 class SubmitWorker {
  public:
   explicit SubmitWorker(int lane) : lane_(lane), th_([this] { loop(); }) {}
-  ~SubmitWorker() { { std::lock_guard<std::mutex> lk(m_); quit_ = true; } cv_.notify_all(); th_.join(); }
-  void post(std::function<void()> job) { { std::lock_guard<std::mutex> lk(m_); job_ = std::move(job); busy_ = true; err_ = nullptr; } cv_.notify_all(); }
-  void wait() { std::unique_lock<std::mutex> lk(m_); done_.wait(lk, [this] { return !busy_; }); if (err_) { std::exception_ptr e = err_; err_ = nullptr; std::rethrow_exception(e); } }
+  ~SubmitWorker() { { std::lock_guard<std::mutex> lk(m_); quit_ = true; } posted_.fetch_add(1, std::memory_order_release); cv_.notify_all(); th_.join(); }
+  void post(std::function<void()> job) { { std::lock_guard<std::mutex> lk(m_); job_ = std::move(job); busy_ = true; err_ = nullptr; } running_.store(true, std::memory_order_release); posted_.fetch_add(1, std::memory_order_release); cv_.notify_all(); }
+  void wait() { spin([this] { return !running_.load(std::memory_order_acquire); }); std::unique_lock<std::mutex> lk(m_); done_.wait(lk, [this] { return !busy_; }); if (err_) { std::exception_ptr e = err_; err_ = nullptr; std::rethrow_exception(e); } }
  private:
-  void loop() { LaneScope lane_scope(lane_); std::unique_lock<std::mutex> lk(m_);
-    for (;;) { cv_.wait(lk, [this] { return quit_ || (busy_ && job_); }); if (quit_) return; std::function<void()> j = std::move(job_); job_ = nullptr; lk.unlock();
-      std::exception_ptr e; try { j(); } catch (...) { e = std::current_exception(); } lk.lock(); err_ = e; busy_ = false; done_.notify_all(); } }
-  int lane_; std::mutex m_; std::condition_variable cv_, done_; std::function<void()> job_; bool busy_ = false, quit_ = false; std::exception_ptr err_; std::thread th_;
+  // A proof hands this thread two jobs a fraction of a millisecond apart (its share of the hand-over scan, then a witness MSM), and the next proof follows as soon: the
+  // thread polls for SPIN_US before it goes to sleep on the condition variable, and so does a waiter — a futex wake-up costs 10-50 us, on the critical path every time.
+  // An idle prover sleeps.
+  static constexpr int SPIN_US = 250;
+  template <class Pred> static void spin(Pred ready) { const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(SPIN_US);
+    for (int k = 0; !ready(); k++) { if ((k & 63) == 63 && std::chrono::steady_clock::now() > t_end) return; __builtin_ia32_pause(); } }
+  void loop() { LaneScope lane_scope(lane_); std::unique_lock<std::mutex> lk(m_); uint32_t seen = 0;
+    for (;;) { if (!(quit_ || (busy_ && job_))) { lk.unlock(); spin([&] { return posted_.load(std::memory_order_acquire) != seen; }); lk.lock(); }
+      cv_.wait(lk, [this] { return quit_ || (busy_ && job_); }); if (quit_) return; seen = posted_.load(std::memory_order_acquire); std::function<void()> j = std::move(job_); job_ = nullptr; lk.unlock();
+      std::exception_ptr e; try { j(); } catch (...) { e = std::current_exception(); } lk.lock(); err_ = e; busy_ = false; running_.store(false, std::memory_order_release); done_.notify_all(); } }
+  int lane_; std::mutex m_; std::condition_variable cv_, done_; std::function<void()> job_; bool busy_ = false, quit_ = false; std::atomic<bool> running_{false}; std::atomic<uint32_t> posted_{0}; std::exception_ptr err_; std::thread th_;
 };
 struct Prover::Impl {
   bool h_lagrange = false;                                     // the H query is held in the coset's Lagrange basis: no inverse coset transform per proof

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Distribution of the per-proof time of a host-buffer send proof (the quantity bench.py averages): percentiles over N steps with distinct witnesses.  python tools/step_times.py [N]"""
+import os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+from blockmaze_amd import engine as e
+from oracle import pyoracle as o
+import workload as w
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+tmp = tempfile.mkdtemp(); pk, vk = os.path.join(tmp, "sendpk.txt"), os.path.join(tmp, "sendvk.txt"); e.keygen("send", pk, vk, seed=1); p = e.Prover(pk); zs = []
+for i in range(16):
+    d = w.send_instance(i); wp = os.path.join(tmp, "w.bin"); e.witness_send(*[("0x" + a.hex()) if isinstance(a, bytes) else a for a in w.send_args(d)], wp); zs.append(o.load_witness(wp))
+for i in range(10): p.prove(zs[i % 16])
+ts = []
+for i in range(N):
+    t0 = time.perf_counter(); p.prove(zs[i % 16]); ts.append(1e3 * (time.perf_counter() - t0))
+s = sorted(ts); pct = lambda q: s[min(len(s) - 1, int(q * len(s)))]
+print("%d steps: mean %.3f ms, min %.3f, p10 %.3f, median %.3f, p90 %.3f, p99 %.3f, max %.3f; steps above 1.5 x median: %d (they add %.3f ms to the mean)" % (N, sum(ts) / N, s[0], pct(0.1), pct(0.5), pct(0.9), pct(0.99), s[-1], sum(1 for t in ts if t > 1.5 * pct(0.5)), sum(t - pct(0.5) for t in ts if t > 1.5 * pct(0.5)) / N))
