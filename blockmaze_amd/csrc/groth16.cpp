@@ -375,8 +375,7 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   bool compact = !force_dense; for (size_t t = 0; t < T; t++) compact = compact && fits[t];
   if (compact) {   // the threads' value areas are closed up (a few hundred KB) so that ONE copy carries bitmaps, offsets and values; the few values that are not 0 or 1 are brought into Montgomery form by the expanding kernel itself
     size_t total = used[0]; for (size_t t = 1; t < T; t++) { if (used[t]) { const uint32_t delta = (uint32_t)(t * cap_t - total); memmove(&vals[total], &vals[t * cap_t], 32 * used[t]); for (size_t w = words * t / T; w < words * (t + 1) / T; w++) off[w] -= delta; } total += used[t]; }
-    upload_async(p.packed.get(), pk, vals_at + 32 * total); Fe32 one_mont; memcpy(&one_mont, FrParams::R1, 32);
-    expand_witness_dev(p.packed.get(), words, one_mont, !montgomery, n, p.z.get()); }
+    Fe32 one_mont; memcpy(&one_mont, FrParams::R1, 32); upload_async(p.packed.get(), pk, vals_at + 32 * total); expand_witness_dev(p.packed.get(), words, one_mont, !montgomery, n, p.z.get()); }   // (letting the kernel read the pinned staging area itself, no copy, was measured: no faster)
   else { Fe32 *h = p.z_host.get(); h[0] = one; memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * n); if (!montgomery) fr_to_mont_dev(p.z.get(), n); }      // dense assignment: plain copy
   last.upload_ms = now_ms() - t0;
 }
