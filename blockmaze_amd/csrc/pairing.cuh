@@ -1,6 +1,6 @@
-// Batched Groth16 verification on the GPU (kernel K9).  Two kernels: k_verify_sched (round 3, at the end of this file) — one 256-thread
-// workgroup per proof interpreting the operation schedule of verify_sched.hpp, 4 ms per launch — for blocks of up to a few thousand proofs, and the first generation below,
-// one LANE per proof, whose 25 ms floor only pays from several thousand proofs on.
+// Batched Groth16 verification on the GPU (kernel K9).  Two kernels: k_verify_sched29 (round 3, at the end of this file) — one 256-thread
+// workgroup per proof interpreting the operation schedule of verify_sched.hpp on 29-bit limbs, 2.1 ms per launch — for one proof up to a few thousand, and the first
+// generation below, one LANE per proof, whose 25 ms floor only pays from several thousand proofs on.
 //
 // Restates r1cs_gg_ppzksnark_verifier_strong_IC (SNARK/.../r1cs_gg_ppzksnark.tcc:509-623) over libff's optimal-ate pairing
 // (FF/algebra/curves/alt_bn128/alt_bn128_pairing.cpp: doubling / mixed-addition steps :242-293, G2 precomputation :305-366, miller_loop :368-418,
