@@ -115,11 +115,13 @@ bool parse_fixed_rs(Fe32 &r, Fe32 &s) {
 inline bool parse_fixed_rs(Fe32 &, Fe32 &) { return false; }
 #endif
 
+static std::atomic<int> g_proofs_in_flight{0};   // genXproof calls of this process that are between acquiring a prover and returning
 // shared tail of the gen*proof functions: assign() has filled the circuit's board
 template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
   try {
     if (!gpu_available()) { zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback"); fprintf(stderr, "libzkgpu: no HIP device visible, cannot generate %s proof\n", circuit_name(k)); return dup_string(proof_to_hex(default_proof())); }
     static const bool trace = getenv("ZK_TRACE_TIMES") != nullptr; auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    struct InFlight { InFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); } ~InFlight() { g_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); } } in_flight;
     double t0 = now(); HeldUnit held = acquire_prover(k); ProverUnit &slot = *held.unit; double t1 = now(); assign(*slot.circuit); double t2 = now();
     printf("Trying to generate %s proof...\n", circuit_name(k)); fflush(stdout);
     Fe32 r, s; bool fixed = parse_fixed_rs(r, s); Proof proof;
@@ -139,7 +141,10 @@ template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
 void verify_group(CircuitKind kind, const Proof *ps, const uint8_t *parsed, const Fe32 *inputs, size_t ni, size_t m, uint8_t *res) {
   static const size_t gpu_min = [] { const char *e = getenv("ZK_VERIFY_GPU_MIN"); long v = e ? atol(e) : 1; return (size_t)(v < 1 ? 1 : v); }();
   const std::string path = key_path(kind, false);
-  if (m >= gpu_min && gpu_available()) { std::shared_ptr<BatchVerifier> v; { std::lock_guard<std::mutex> lk(g_gpu_mutex); v = gpu_verifier_for_path(path); }   // (building a key's verifier is serialised; using it is not)
+  // A single proof goes to the device only while no prover of this process is at work: measured (tools/verify_under_load.py), one verifySendproof takes 1.82 ms on an idle
+  // GPU and 1.88 ms on a host core, but 2.8 ms (p90 4.1) on a GPU that four provers keep busy — the verifier's one workgroup shares its compute unit's issue slots with
+  // their waves, and costs them 17 % of their throughput — against an unchanged 1.87 ms on the host.  Two or more proofs are one launch whatever the load.
+  if (m >= gpu_min && (m >= 2 || g_proofs_in_flight.load(std::memory_order_relaxed) == 0) && gpu_available()) { std::shared_ptr<BatchVerifier> v; { std::lock_guard<std::mutex> lk(g_gpu_mutex); v = gpu_verifier_for_path(path); }   // (building a key's verifier is serialised; using it is not)
     if (v->num_inputs() == ni) { v->verify(ps, inputs, m, res); for (size_t j = 0; j < m; j++) if (res[j] == 2) res[j] = parsed[j] && verify_proof(*vk_for_path(path), inputs + j * ni, ni, ps[j]); }
     else for (size_t j = 0; j < m; j++) res[j] = 0; }                                                                       // strong IC: a wrong input count rejects (r1cs_gg_ppzksnark.tcc:584-590)
   else { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(path); for (size_t j = 0; j < m; j++) res[j] = parsed[j] && verify_proof(*vk, inputs + j * ni, ni, ps[j]); }
