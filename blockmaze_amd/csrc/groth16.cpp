@@ -271,7 +271,7 @@ class SubmitWorker {
  public:
   explicit SubmitWorker(int lane) : lane_(lane), th_([this] { loop(); }) {}
   ~SubmitWorker() { { std::lock_guard<std::mutex> lk(m_); quit_ = true; } posted_.fetch_add(1, std::memory_order_release); cv_.notify_all(); th_.join(); }
-  void post(std::function<void()> job) { { std::lock_guard<std::mutex> lk(m_); job_ = std::move(job); busy_ = true; err_ = nullptr; } running_.store(true, std::memory_order_release); posted_.fetch_add(1, std::memory_order_release); cv_.notify_all(); }
+  void post(std::function<void()> job) { { std::lock_guard<std::mutex> lk(m_); job_ = std::move(job); busy_ = true; err_ = nullptr; running_.store(true, std::memory_order_release); posted_.fetch_add(1, std::memory_order_release); } cv_.notify_all(); }   // (both flags change under the lock: the worker clears running_ under it too, so a job that is picked up by a spurious wake-up cannot finish before running_ is set)
   void wait() { spin([this] { return !running_.load(std::memory_order_acquire); }); std::unique_lock<std::mutex> lk(m_); done_.wait(lk, [this] { return !busy_; }); if (err_) { std::exception_ptr e = err_; err_ = nullptr; std::rethrow_exception(e); } }
  private:
   // A proof hands this thread two jobs a fraction of a millisecond apart (its share of the hand-over scan, then a witness MSM), and the next proof follows as soon: the
