@@ -400,9 +400,12 @@ static RsTerms rs_terms(const Fe32 *r_in, const Fe32 *s_in, const HG1 &delta_g1,
   RsTerms t; t.r = r_in ? fr_of(*r_in) : random_fr().from_mont(); t.s = s_in ? fr_of(*s_in) : random_fr().from_mont(); HFr rs = (t.r.to_mont() * t.s.to_mont()).from_mont();   // canonical scalars
   t.r_delta = delta_g1.mul(t.r.l); t.s_delta = delta_g1.mul(t.s.l); t.rs_delta_neg = delta_g1.mul(rs.l).neg(); t.s_delta2 = delta_g2.mul(t.s.l); return t; }
 static void enqueue_all(Prover::Impl &p) {
-  // The witness MSMs (auxiliary streams; order B2, L, A, B1) are released after the row kernels (release point 1 of 0 = at once .. 4 = after all transforms): started at time 0 their
-  // full-chip sort kernels fight the row and transform kernels for the CUs; later release points only move the contention into the H accumulation (profiles/r03i_ab_start.txt).
-  static const std::array<int, 4> start{1, 1, 1, 1};
+  // The witness MSMs (auxiliary streams; order B2, L, A, B1) are released AT ONCE (release point 0 of 0 .. 4 = after all transforms): their fork event sits right behind the
+  // hand-over kernels and the submit threads — still polling after their share of the hand-over scan — are woken as soon as the row kernel is launched.  Rounds 1-2 released
+  // them after the row kernels (their five full-chip classify kernels then fought the row and transform kernels for the CUs); since the witness path is one light sort
+  // per pair, starting it beside the gather-bound row kernel is worth 4 % of a host-buffer proof (1.095 -> 1.05 ms median, tools/ab_steps.sh); later release points only
+  // move the contention into the transforms and the H accumulation (profiles/r03i_ab_start.txt, and again at the end of round 3: 1.06-1.19 against 1.01 ms).
+  static const std::array<int, 4> start{0, 0, 0, 0};
   // about 80 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
   // (auxiliary streams) while this one submits the critical chain
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
@@ -427,8 +430,8 @@ static void enqueue_all(Prover::Impl &p) {
   auto release = [&](int point, int phase = 2) { bool any = false; for (int j = 0; j < 4; j++) any |= start[j] == point; if (!any) return; if (phase != 1) gpu_fork_record(); if (phase == 0) return;
     for (int j = 0; j < 4; j++) if (start[j] == point && !skip_w && job_used[j]) { const int sj = job_stream[j]; std::function<void()> job = jobs[j], fin = finish[j];
       if (use_threads) { if (!p.workers[j]) p.workers[j].reset(new SubmitWorker(p.lane)); p.workers[j]->post([sj, job, fin] { gpu_fork_wait(sj); job(); fin(); }); p.pending[j] = true; } else { gpu_fork_wait(sj); job(); p.inline_result[j] = true; if (j == 2 && p.pair_AL) p.inline_result[1] = true; if (j == 3 && p.pair_B) p.inline_result[0] = true; } } };
-  release(0);
-  p.cs->eval(p.z.get(), p.abc.get(), p.m); release(1, 0);
+  release(0, 0);
+  p.cs->eval(p.z.get(), p.abc.get(), p.m); release(0, 1); release(1, 0);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
   const int nvec = p.c_fold ? 2 : 3;                          // A, B (and C unless it is folded into the L query)
   if (!skip_n) p.dom->ifft(p.abc.get(), nvec, p.m); release(1, 1); release(2);
