@@ -200,6 +200,24 @@ def test_batched_gpu_verifier_matches_host_verifier(golden_dir, name):
     assert e.verify_batch(vk, [], []) == []
     assert e.verify_batch(vk, [good[0]], [inputs[:-1]]) == [False]                        # wrong number of public inputs (strong IC)
 
+def test_gpu_verifier_random_curve_points_match_host(golden_dir):
+    """K9 on 29-bit limbs keeps lazily reduced values whose bounds the schedule builder proves; here it is fed what a prover never produces — 160 "proofs" made of
+    random multiples of the generators (on the curve, so that the whole pairing runs on arbitrary field values) under random or genuine public inputs, and valid proofs under
+    random public inputs — shuffled among 24 valid proofs with fresh (r, s): every verdict must be the host verifier's, in one launch and record by record"""
+    d = os.path.join(golden_dir, "groth16_small"); meta = json.load(open(os.path.join(d, "meta.json"))); z = o.load_witness(os.path.join(d, "wit.bin")); vk = os.path.join(d, "vk.txt")
+    inputs = o.from_arr(z[:meta["n_inputs"]]); p = e.Prover(os.path.join(d, "pk.txt")); good = [p.prove(z) for _ in range(24)]; p.close()
+    g = o.SplitMix64(2903); G1, G2 = o.g1_gen(), o.g2_gen(); rnd = lambda: 1 + g.next() % (o.R_MOD - 1)
+    def hexof(A, B, C): return o.proof_hex(o.to_arr([A[0], A[1], B[0][0], B[0][1], B[1][0], B[1][1], C[0], C[1]]).reshape(-1))
+    cases = [(pr, inputs) for pr in good]
+    for _ in range(120): cases.append((hexof(o.g1_op("mul", G1, k=rnd()), o.g2_op("mul", G2, k=rnd()), o.g1_op("mul", G1, k=rnd())), [rnd() for _ in inputs] if g.next() & 1 else inputs))
+    for _ in range(40): cases.append((good[g.next() % 24], [rnd() for _ in inputs]))            # a valid proof under random inputs
+    order = list(range(len(cases)))
+    for i in range(len(order) - 1, 0, -1): j = g.next() % (i + 1); order[i], order[j] = order[j], order[i]
+    cases = [cases[i] for i in order]; proofs = [c[0] for c in cases]; ins = [c[1] for c in cases]
+    got = e.verify_batch(vk, proofs, ins); exp = [e.verify(vk, pr, x) for pr, x in zip(proofs, ins)]
+    assert got == exp and sum(got) == 24
+    for pr, x, v in list(zip(proofs, ins, got))[:40]: assert e.verify_batch(vk, [pr], [x]) == [v]       # ... and one record per launch
+
 def test_batched_gpu_verifier_send_at_scale(send_keys, tmp_path):
     """512 send proofs in one launch (4 distinct valid proofs and their corrupted twins, interleaved)"""
     pk_path, vk_path = str(send_keys / "sendpk.txt"), str(send_keys / "sendvk.txt"); p = e.Prover(pk_path); proofs, ins, exp = [], [], []
