@@ -195,6 +195,18 @@ __global__ void k_step_inv_post(Fr *a_all, const Fr *__restrict__ wpow, const Fr
   u1 = u1 * winvpow[i]; Fr u0 = a[i]; a[i] = (u0 + u1) * half; a[B + i] = (u0 - u1) * half;
 }
 
+// iFFT immediately followed by cosetFFT (what the witness map does to A and B): the inverse transform's recombination pass and the forward transform's factor, pre-pass and
+// fold touch the same elements — thread i < S owns the index class {i, i + S, i + 2S, ... < B} and B + i —, so they are ONE pass over the vectors instead of three
+// (k_step_inv_post, k_step_fwd_pre with the coset factors, k_step_fold) and one launch instead of three
+__global__ void k_step_inv_fwd(Fr *a_all, const Fr *__restrict__ wpow, const Fr *__restrict__ winvpow, Fr half, const Fr *__restrict__ cf, uint32_t B, uint32_t S, size_t stride) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= S) return; Fr *a = a_all + blockIdx.y * stride;
+  Fr u1 = a[B + i]; for (uint32_t j = i + S; j < B; j += S) u1 = u1 - a[j] * wpow[j];
+  u1 = u1 * winvpow[i]; const Fr u0 = a[i], lo = (u0 + u1) * half, hi = (u0 - u1) * half;        // the inverse transform's a[i], a[B + i]; a[S..B) are final as they are
+  const Fr x = lo * cf[i], y = hi * cf[B + i]; a[i] = x + y; Fr e = wpow[i] * (x - y);            // the forward pre-pass on g^i a[i]: c[i], d[i]
+  for (uint32_t j = i + S; j < B; j += S) { const Fr xx = a[j] * cf[j]; a[j] = xx; e = e + wpow[j] * xx; }
+  a[B + i] = e;                                                                                  // the fold: e[i] = sum_j d[i + jS]
+}
+
 struct DomainTables {                                            // immutable per key: shared by every Domain object copied from the first
   size_t m = 0; bool step = false; size_t B = 0, S = 0;           // step: m = B + S
   std::unique_ptr<Radix2Tables> big, small;                       // basic: only `big` (size m)
@@ -272,6 +284,15 @@ void Domain::ifft(Fe32 *data, int batch, size_t stride) {
   radix2_transform_pair(NttCall{data, tmp, d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, stride, d.B}, NttCall{data + d.B, d.scratch.get(), d.small->itw.get(), d.small->itw261.get(), d.small->logn, d.scale_small.get(), nullptr, d.inv_small261, nullptr, stride, d.B}, batch);
   Fr half; memcpy(&half, d.half.l, 32);
   hipLaunchKernelGGL(k_step_inv_post, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half, (uint32_t)d.B, (uint32_t)d.S, stride);
+}
+void Domain::ifft_then_coset_fft(Fe32 *data, int batch, size_t stride) {
+  Impl &d = *impl; if (!d.step) { ifft(data, batch, stride); coset_fft(data, batch, stride); return; }
+  if (batch > 3) throw GpuError("domain: batch > 3"); hipStream_t s = gpu().stream; Fe32 *dbuf = d.scratch.get(), *tmp = d.scratch.get() + 3 * d.B; Fr half; memcpy(&half, d.half.l, 32);
+  { Stage st("ntt.inverse");
+    radix2_transform_pair(NttCall{data, tmp, d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, stride, d.B}, NttCall{data + d.B, dbuf, d.small->itw.get(), d.small->itw261.get(), d.small->logn, d.scale_small.get(), nullptr, d.inv_small261, nullptr, stride, d.B}, batch);
+    hipLaunchKernelGGL(k_step_inv_fwd, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half, (const Fr *)d.coset_fwd.get(), (uint32_t)d.B, (uint32_t)d.S, stride); }
+  { Stage st("ntt.forward");
+    radix2_transform_pair(NttCall{data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, NttCall{data + d.B, dbuf, d.small->tw.get(), d.small->tw261.get(), d.small->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, batch); }
 }
 void Domain::coset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");

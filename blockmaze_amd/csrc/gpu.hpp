@@ -102,6 +102,7 @@ class Domain {
   // in place on `batch` device vectors of m elements each, `stride` elements apart (Montgomery form)
   void fft(Fe32 *data, int batch, size_t stride); void ifft(Fe32 *data, int batch, size_t stride);
   void coset_fft(Fe32 *data, int batch, size_t stride); void icoset_fft(Fe32 *data, int batch, size_t stride);
+  void ifft_then_coset_fft(Fe32 *data, int batch, size_t stride);   // = ifft(); coset_fft(); on a step domain the passes between the two transforms are one kernel
  private: void fft_with_factors(Fe32 *data, int batch, size_t stride, const Fe32 *factors); public:
   // key load: the H query (n_in = m - 1 affine points) re-expressed so that sum_j v_j out_j = sum_i icosetFFT(v)_i h_i: the prover then skips the last transform (ecntt.cuh)
   bool supports_h_lagrange() const; void h_query_to_coset_lagrange(const G1AffineRaw *h, size_t n_in, G1AffineRaw *out /* m points */);

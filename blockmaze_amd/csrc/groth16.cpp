@@ -434,9 +434,9 @@ static void enqueue_all(Prover::Impl &p) {
   p.cs->eval(p.z.get(), p.abc.get(), p.m); release(0, 1); release(1, 0);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
   const int nvec = p.c_fold ? 2 : 3;                          // A, B (and C unless it is folded into the L query)
-  if (!skip_n) p.dom->ifft(p.abc.get(), nvec, p.m); release(1, 1); release(2);
+  if (!skip_n) p.dom->ifft_then_coset_fft(p.abc.get(), nvec, p.m); release(1, 1); release(2);   // iFFT, then cosetFFT (a step domain runs the passes between the two as one kernel)
   const bool fuse_pointwise = p.c_fold && p.H->one_pass_sort();   // zinv*a*b is then formed inside the H query's sort kernel
-  if (!skip_n) p.dom->coset_fft(p.abc.get(), nvec, p.m); if (!fuse_pointwise) p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.c_fold ? nullptr : p.abc.get() + 2 * p.m); release(3);
+  if (!fuse_pointwise) p.dom->qap_pointwise(p.abc.get(), p.abc.get() + p.m, p.c_fold ? nullptr : p.abc.get() + 2 * p.m); release(3);
   if (!p.h_lagrange) p.dom->icoset_fft(p.abc.get(), 1, p.m);
   release(4);
   if (skip_h) return;
