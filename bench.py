@@ -79,8 +79,8 @@ def usable_cores():
         except Exception: pass
     return min(n, 64)
 
-def harness_kv(harness, *cmd, env=None):
-    out = subprocess.run([harness, *cmd], capture_output=True, text=True, env=env).stdout; kv = {}
+def harness_kv(harness, *cmd, env=None, timeout=None):
+    out = subprocess.run([harness, *cmd], capture_output=True, text=True, env=env, timeout=timeout).stdout; kv = {}
     for line in out.splitlines():
         tok = line.split()
         for a, b in zip(tok[0::2], tok[1::2]): kv[a] = b
@@ -96,13 +96,12 @@ def run_rank(args):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # torch initialises the HIP runtime before libzkgpu.so is loaded, so the library's own load-time default would come too late here
     import torch
     backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")                 # "gloo": lets the N > 1 code path run on a box with fewer GPUs than ranks (ranks share devices)
-    dist = None
+    grp = None
     if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl": torch.cuda.set_device(local_rank); dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else: dist.init_process_group(backend)
-        log("bench: rank %d of %d joined the process group (backend %s)" % (dist.get_rank(), dist.get_world_size(), backend))
-        assert dist.get_world_size() == args.gpus
+        from blockmaze_amd import sharding
+        grp = sharding.Group(backend, rank, world, local_rank, timeout_s=int(os.environ.get("ZK_BENCH_GROUP_TIMEOUT_S", "600")))   # every torch.distributed call of this script is made there
+        log("bench: rank %d of %d joined the process group (backend %s)" % (grp.dist.get_rank(), grp.dist.get_world_size(), backend))
+        assert grp.dist.get_world_size() == args.gpus
         if backend != "nccl" and torch.cuda.is_available(): torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count())); os.environ["ZK_DEVICE"] = str(local_rank % max(1, torch.cuda.device_count()))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
@@ -122,27 +121,45 @@ def run_rank(args):
     e.init()                                                                 # raises "no HIP device visible" on a box without a GPU: there is no CPU path to fall back to
 
     # ---- untimed setup: test keys for the send circuit (seeded toxic waste), resident prover, one witness per step -----------------
-    # ONE key for all ranks of the node: rank 0 generates it (and, by loading it first, leaves the fast container beside it); the others wait at the barrier and load that
-    tmp = tempfile.mkdtemp(prefix="zkbench_%d_" % rank); key_dir = tmp if world == 1 else os.path.join(tempfile.gettempdir(), "zkbench_key_%s" % os.environ.get("MASTER_PORT", "0")); os.makedirs(key_dir, exist_ok=True)
-    pk_path, vk_path = os.path.join(key_dir, "sendpk.txt"), os.path.join(key_dir, "sendvk.txt"); shard = args.shard_msm and world > 1; t_keygen = 0.0
-    def load(): return e.Prover(pk_path, rank, world) if shard else e.Prover(pk_path)
-    if rank == 0: t0 = time.time(); e.keygen("send", pk_path, vk_path, seed=0xB10C4A2E); t_keygen = time.time() - t0; t0 = time.time(); prover = load(); t_load = time.time() - t0
-    if dist is not None: dist.barrier()
-    if rank != 0: t0 = time.time(); prover = load(); t_load = time.time() - t0
+    # ONE key for all ranks of the node: rank 0 makes a private directory (mkdtemp: no predictable path that a stale or foreign key could sit under), generates the key and,
+    # by loading it first, leaves the fast container beside it; the path travels to the other ranks, which load that.  Every step of the set-up ends with the ranks agreeing
+    # that all of them got through it: a rank that fails takes the group down with a non-zero status instead of leaving the others at a barrier.
+    fail_at = os.environ.get("ZK_BENCH_TEST_FAIL", "")                    # tests only: "<stage>:<rank>" makes that rank raise there (stages: keygen, load)
+    def stage(name, fn):
+        err = None; out = None
+        try:
+            if fail_at == "%s:%d" % (name, rank): raise RuntimeError("ZK_BENCH_TEST_FAIL asked rank %d to fail at '%s'" % (rank, name))
+            out = fn()
+        except Exception as ex:
+            err = ex; log("bench: rank %d failed at '%s': %s" % (rank, name, ex))
+        ok = err is None if grp is None else grp.all_ok(err is None)
+        if not ok:
+            if grp is not None: log("bench: rank %d leaves: a rank failed at '%s'" % (rank, name)); grp.close()
+            raise SystemExit(3)
+        return out
+    tmp = tempfile.mkdtemp(prefix="zkbench_%d_" % rank); shard = args.shard_msm and world > 1; t_keygen = 0.0
+    def make_key():
+        kd = tmp if world == 1 else tempfile.mkdtemp(prefix="zkbench_key_"); t0 = time.time(); e.keygen("send", os.path.join(kd, "sendpk.txt"), os.path.join(kd, "sendvk.txt"), seed=0xB10C4A2E); return kd, time.time() - t0
+    made = stage("keygen", make_key if rank == 0 else (lambda: None))
+    if rank == 0: key_dir, t_keygen = made
+    if grp is not None: key_dir = grp.share_from_rank0(key_dir if rank == 0 else None)
+    pk_path, vk_path = os.path.join(key_dir, "sendpk.txt"), os.path.join(key_dir, "sendvk.txt")
+    def load(): t0 = time.time(); p = e.Prover(pk_path, rank, world) if shard else e.Prover(pk_path); return p, time.time() - t0
+    first = stage("load", load if rank == 0 else (lambda: None))             # rank 0 first: its load from text leaves the container the others map
+    rest = stage("load", load if rank != 0 else (lambda: None))
+    prover, t_load = first if rank == 0 else rest
     n_inst = max(2, min(args.steps + args.warmup, MAX_DISTINCT_WITNESSES)); insts, zs = [], []; wp = os.path.join(tmp, "w.bin")
     for i in range(n_inst):
         d = w.send_instance(i if shard else rank + i * world); e.witness_send(*hx(w.send_args(d)), wp); insts.append(d); zs.append(read_witness(wp))
     e.witness_send(*hx(w.send_args(insts[0])), os.path.join(tmp, "w0.bin"))            # kept on disk for the CPU baseline
 
     def barrier():
-        if dist is not None: dist.barrier()
+        if grp is not None: grp.barrier()
         if torch.cuda.is_available(): torch.cuda.synchronize()
 
-    from blockmaze_amd import sharding
-    coll_dev = None if dist is None else ("cuda" if backend == "nccl" else "cpu")
     if shard:
         def one_proof(i):                                                      # every rank runs the device pipeline on its slice; 384 B per rank are exchanged; rank 0 assembles
-            prover.set_witness(zs[i % n_inst]); recs = sharding.gather_partials(prover.prove_partial(), dist, coll_dev)
+            prover.set_witness(zs[i % n_inst]); recs = grp.gather_partials(prover.prove_partial())
             return prover.finish(recs, 0x1234567 + i, 0x7654321 + i) if rank == 0 else None
     else:
         # host buffer in, fresh (r, s), serialized proof (512 hex characters) out; synchronous.  The C entry point is called with argument objects built once: what is timed
@@ -154,16 +171,20 @@ def run_rank(args):
             if rc != 0: raise RuntimeError("zkgpu_prover_prove failed: %s" % _lib.zkgpu_last_error().decode())
             return _out
     for i in range(args.warmup): one_proof(i)
-    barrier(); t0 = time.perf_counter()
-    last = None
-    for i in range(args.steps): last = one_proof(args.warmup + i)
-    barrier(); dt = time.perf_counter() - t0
-    rate, dt = sharding.aggregate_throughput((args.steps if rank == 0 else 0) if shard else args.steps, dt, dist, coll_dev)      # max over ranks, units summed
+    step_t = [0.0] * (args.steps + 1); clock = time.perf_counter
+    barrier(); t0 = clock()
+    last = None; step_t[0] = t0
+    for i in range(args.steps): last = one_proof(args.warmup + i); step_t[i + 1] = clock()        # (one clock read per step: the spread of the timed region goes into the line)
+    barrier(); dt = clock() - t0
+    units = (args.steps if rank == 0 else 0) if shard else args.steps
+    rate, dt = (units / dt, dt) if grp is None else grp.aggregate_throughput(units, dt)           # max over ranks, units summed
+    per_step = sorted(1e3 * (b - a) for a, b in zip(step_t, step_t[1:])); pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 4) if per_step else None
+    step_ms = {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90), "min": round(per_step[0], 4) if per_step else None, "max": round(per_step[-1], 4) if per_step else None, "rank": rank}
     d = insts[(args.warmup + args.steps - 1) % n_inst]
     if last is not None and not isinstance(last, str): last = last.value.decode()
     assert last is None or e.verify(vk_path, last, w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]])), "proof from the timed region does not verify"
 
-    extra = {}
+    extra = {}; cpu_files = {}                                     # cpu_files: circuit legs whose libsnark time is reported beside them
     if world == 1 and not args.no_extra_legs:                      # (N > 1: only the timed region and the roofline leg — the driver's scaling runs pass no flags)
         nx = max(3, min(args.steps, 10))
         # the device pipeline alone: the assignment already resident in HBM (no host hand-over per proof)
@@ -208,6 +229,36 @@ def run_rank(args):
         ms_mint = 1e3 * (time.perf_counter() - t0) / nx; mp.close()
         assert e.verify(mvk, mproof, w.pack_public([md["cmtA_old"], md["sn_old"], md["cmtA"]], md["value_s"]))
         extra["mint_single_proof"] = {"ms_per_proof": round(ms_mint, 4), "proofs_per_s": round(1e3 / ms_mint, 2)}
+        # BASELINE.json configs[3]: deposit + redeem, a mixed batch on one GPU — two more resident keys beside send's and mint's (all four pk / vk pairs of the deployment have
+        # then been exercised by this run); 16 + 16 proofs through the prover entry point, the two circuits alternating, host-buffer witnesses, one call at a time
+        def circuit_leg(kind, depth=8):
+            tag = kind if depth == 8 else "%s_depth%d" % (kind, depth); pk_, vk_, wf = (os.path.join(tmp, tag + x) for x in ("pk.txt", "vk.txt", "_w.bin"))
+            t0 = time.time(); e.keygen(kind, pk_, vk_, seed=0xB10C4A30 + depth + len(kind), **({"tree_depth": depth} if kind == "deposit" else {})); t_gen = time.time() - t0
+            t0 = time.time(); pv = e.Prover(pk_); t_ld = time.time() - t0
+            if kind == "deposit":
+                dd = w.deposit_instance(1); rt = dd["rt"] if depth == 8 else w.merkle_root_and_path(dd["leaves"], dd["index"], depth=depth)[0]
+                e.witness_deposit(*hx(w.deposit_args(dd)), "".join("0x" + l.hex() for l in dd["leaves"]), len(dd["leaves"]), "0x" + dd["sk"].hex(), wf, **({"tree_depth": depth} if depth != 8 else {}))
+                pub = w.pack_public([rt, dd["pk_recv"], dd["cmtB_old"], dd["sn_old"], dd["cmtB"], dd["sn_s"]])
+            else:
+                md_ = w.mint_instance(1, redeem=True); e.witness_mint_redeem(True, *hx(w.mint_args(md_)), wf); pub = w.pack_public([md_["cmtA_old"], md_["sn_old"], md_["cmtA"]], md_["value_s"])
+            cpu_files[tag] = (kind, depth, wf); return pv, read_witness(wf), vk_, pub, {"keygen": round(t_gen, 2), "key_load": round(t_ld, 2)}
+        dp, dz, dvk, dpub, dset = circuit_leg("deposit"); rp, rz, rvk, rpub, rset = circuit_leg("redeem")
+        dp.prove(dz); rp.prove(rz); n_mix = 16; t0 = time.perf_counter()
+        for i in range(n_mix): dproof = dp.prove(dz); rproof = rp.prove(rz)
+        dt_mix = time.perf_counter() - t0; t0 = time.perf_counter()
+        for i in range(4): dp.prove(dz)
+        ms_dep = 1e3 * (time.perf_counter() - t0) / 4; t0 = time.perf_counter()
+        for i in range(4): rp.prove(rz)
+        ms_red = 1e3 * (time.perf_counter() - t0) / 4; dp.close(); rp.close()
+        assert e.verify(dvk, dproof, dpub) and e.verify(rvk, rproof, rpub), "a proof of the mixed batch does not verify"
+        extra["deposit_redeem_mixed_batch"] = {"config": "BASELINE.json configs[3]: %d deposit + %d redeem proofs alternating against two resident keys, 1 MI355X" % (n_mix, n_mix), "proofs": 2 * n_mix,
+                                               "proofs_per_s": round(2 * n_mix / dt_mix, 2), "ms_per_proof": round(1e3 * dt_mix / (2 * n_mix), 4), "deposit_ms_per_proof": round(ms_dep, 4), "redeem_ms_per_proof": round(ms_red, 4),
+                                               "verified": True, "setup_s": {"deposit": dset, "redeem": rset}}
+        # BASELINE.json configs[4] on ONE GPU: the deposit circuit with the Merkle depth raised to 32 (1,070,591 variables, step domain 2^20 + 2^17, H query of 1,179,647 points)
+        p32, z32, vk32, pub32, set32 = circuit_leg("deposit", 32); proof32 = p32.prove(z32); t0 = time.perf_counter()
+        for i in range(3): proof32 = p32.prove(z32)
+        ms32 = 1e3 * (time.perf_counter() - t0) / 3; p32.close(); assert e.verify(vk32, proof32, pub32), "the depth-32 deposit proof does not verify"
+        extra["deposit_depth32_single_proof"] = {"config": "BASELINE.json configs[4] on one GPU: Merkle depth 32, 2^20-point MSMs", "ms_per_proof": round(ms32, 4), "proofs_per_s": round(1e3 / ms32, 2), "verified": True, "setup_s": set32}
 
     # ---- roofline leg: HIP-event time of the dominant kernel, same stream, after the timed region --------------------------
     e.profile_enable(True); nprof = max(3, min(args.steps, 10))
@@ -251,6 +302,16 @@ def run_rank(args):
                                                               "sample": "reference operator>> on the 77 MB send key + prover, as every genSendproof call of the reference does; %.1f s" % tot}
                 mr = os.path.join(tmp, "mint_r1cs.bin"); e.circuit_export("mint", mr); kv = harness_kv(harness, "bench_prover", mr, os.path.join(tmp, "mint_w.bin"))
                 if "prover_total_s" in kv: cpu_more["mint_single_proof"] = {"value": round(1.0 / float(kv["prover_total_s"]), 5), "unit": "proofs/s", "cores": 1, "kind": "reference", "sample": "BASELINE.json configs[0]: 1 mint proof by libsnark's prover; %.2f s" % float(kv["prover_total_s"])}
+                # configs[3] / [4]: libsnark's prover on the deposit, redeem and depth-32 deposit circuits (same bench_prover leg; the depth-32 one is given 90 s)
+                for tag, (kind, depth, wf) in sorted(cpu_files.items()):
+                    rp_ = os.path.join(tmp, tag + "_r1cs.bin"); L_ = e.lib(); rc_ = L_.zkgpu_circuit_export(e.KIND[kind], depth, rp_.encode()); t0 = time.time()
+                    try:
+                        kv = harness_kv(harness, "bench_prover", rp_, wf, timeout=90 if depth != 8 else 300) if rc_ == 0 else {}
+                        if "prover_total_s" in kv: cpu_more[tag + "_single_proof"] = {"value": round(1.0 / float(kv["prover_total_s"]), 5), "unit": "proofs/s", "cores": 1, "kind": "reference", "sample": "1 %s proof by libsnark's prover (bench_prover leg); %.2f s" % (tag, float(kv["prover_total_s"]))}
+                    except subprocess.TimeoutExpired:
+                        cpu_more[tag + "_single_proof"] = {"value": None, "unit": "proofs/s", "cores": 1, "kind": "reference", "sample": "skipped: libsnark's prover on this circuit did not finish within %d s on this host" % int(time.time() - t0)}
+                    try: os.remove(rp_)
+                    except OSError: pass
         if cpu is None:
             from oracle import pyoracle as o      # checker code, used here ONLY as the timed CPU baseline
             cs = o.R1CS.load(r1cs_path); cs = cs.swapped() if cs.swap_ab_beneficial() else cs; pk, _ = o.parse_pk(pk_path); t0 = time.time(); o.prove(cs, zs[0], pk, 12345, 67890); t = time.time() - t0
@@ -259,7 +320,7 @@ def run_rank(args):
     if rank == 0:
         line = {
             "metric": "Groth16 proofs/sec (send circuit, alt_bn128)", "value": round(rate, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery; the H accumulation and the transforms' tiles on nine 29-bit limbs)", "data": "synthetic witnesses (seeded send instances, every constraint satisfied) on a proving key made by this repo's GPU generator for the real send circuit; only the libsnark CPU leg uses a key with synthetic points of the same shape",
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "step_ms": step_ms, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery; the H accumulation and the transforms' tiles on nine 29-bit limbs)", "data": "synthetic witnesses (seeded send instances, every constraint satisfied) on a proving key made by this repo's GPU generator for the real send circuit; only the libsnark CPU leg uses a key with synthetic points of the same shape",
             "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "distinct_witnesses": n_inst,
                        "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
                        "includes": "one prover call per step on a fresh HOST-buffer assignment (a different witness every step): hand-over to the device, R1CS rows, the 7 NTTs of the witness map (4 run per proof; both transforms of C and the final inverse are folded into the L and H queries at key load), 5 MSM, host proof assembly, hex serialisation; excludes witness generation and key load"},
@@ -267,7 +328,7 @@ def run_rank(args):
             "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2)}}
         real_stdout.write(json.dumps(line) + "\n"); real_stdout.flush()
     prover.close()
-    if dist is not None: dist.destroy_process_group()
+    if grp is not None: grp.close()
     return 0
 
 def main():

@@ -9,6 +9,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,7 +48,7 @@ struct ProverUnit { std::shared_ptr<Prover> prover; std::unique_ptr<Circuit> cir
 typedef std::vector<std::shared_ptr<ProverUnit>> UnitList;
 // A reload (the key file's size or mtime changed) never touches the old list: it publishes a NEW one, and the old units die when the last proof running on them lets
 // go of its reference — a caller can therefore never see a destroyed unit or mutex, however the reload interleaves with proofs in flight.
-struct ProverSlot { FileStamp stamp; std::vector<std::shared_ptr<const UnitList>> units /* one list per device slot, built on first use */; std::atomic<unsigned> next{0}; };
+struct ProverSlot { FileStamp stamp; std::vector<std::shared_ptr<const UnitList>> units /* one list per device slot, built on first use */; std::vector<uint8_t> building /* a caller is loading this device's pool */; std::atomic<unsigned> next{0}; };
 struct VkSlot { FileStamp stamp; std::shared_ptr<PreparedVerifyingKey> vk; std::shared_ptr<BatchVerifier> gpu; };
 std::mutex g_cache_mutex; std::map<std::string, ProverSlot> g_provers; std::map<std::string, VkSlot> g_vks;
 
@@ -63,32 +64,64 @@ void write_container_quietly(const std::string &pk_path, const ProvingKeyHost &p
   try { save_key_container(cp, pk, ks); } catch (const std::exception &) {} }
 // A unit of the key's pool, locked for the caller (the reference keeps the unit alive, the lock is released first: members are destroyed in reverse order)
 struct HeldUnit { std::shared_ptr<ProverUnit> unit; std::unique_lock<std::mutex> lock; };
-// Loads the key on first use or when the file changed; loading is serialised by g_gpu_mutex, which also guards the slot table.  With several devices (ZK_DEVICES)
-// the pools are built LAZILY, one device at a time: a caller is routed to device (turn mod D); that device's pool — the key's tables once, ZK_PROVERS_PER_KEY prover
-// objects sharing them — is built when the first caller arrives there (from the key's container: 0.1 s), so a process that never has two proofs in flight keeps one
-// copy of one key on one GPU, and 8 devices x 4 keys are not 32 key loads at the first call.  A prover's helper threads start with its first proof (groth16.cpp).
+}  // namespace
+// Which device of the list (ZK_DEVICES) a gen*proof call goes to — pure logic, driven by the CPU tests through zkgpu_test_pool_plan.  loaded[d]: device d holds a pool of
+// this key; building[d]: some caller is loading one there right now; busy[d]: proofs running on it.  Policy: the least busy loaded device; but as soon as every loaded
+// device already runs `spill` proofs (default 1) and a device without a pool is left, that one is taken (the caller builds its pool: 0.1 s from the key's container) —
+// a process that never has two proofs in flight keeps one copy of one key on one GPU, one with many concurrent callers spreads over all GPUs of the node before two proofs
+// share a device.  A pool that somebody else is building is never waited for while a loaded device exists.  Returns the device; -1 = wait for a build to finish.
+int zk_pool_pick_device(const uint8_t *loaded, const uint8_t *building, const int *busy, int D, int spill, unsigned turn) {
+  int best = -1, fresh = -1; bool any_building = false;
+  for (int i = 0; i < D; i++) {
+    const int d = (int)((turn + (unsigned)i) % (unsigned)D);                            // ties go round by turn
+    if (loaded[d]) { if (best < 0 || busy[d] < busy[best]) best = d; }
+    else if (building[d]) any_building = true;
+  }
+  for (int d = 0; d < D && fresh < 0; d++) if (!loaded[d] && !building[d]) fresh = d;   // pools appear in list order
+  if (best < 0) return fresh >= 0 && !any_building ? fresh : -1;                         // nothing loaded yet: the first caller builds, the others wait for it
+  if (busy[best] >= spill && fresh >= 0) return fresh;
+  return best;
+}
+namespace {
+std::condition_variable g_pool_cv;   // signalled under g_cache_mutex whenever a pool build ends
+// Loads the key on first use or when the file changed.  g_cache_mutex guards the slot table only; a pool is BUILT outside it (under g_gpu_mutex, which serialises key
+// loads and the other set-up work of the device), so callers that can be served by a loaded device never queue behind a key load.  A prover's helper threads start with
+// its first proof (groth16.cpp).
 HeldUnit acquire_prover(CircuitKind k) {
   std::string path = key_path(k, true); FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("proving key not found: " + path);
-  const size_t D = (size_t)std::max(1, gpu_device_slots()); std::vector<std::shared_ptr<const UnitList>> lists; unsigned turn = 0; size_t dev = 0;
-  { std::lock_guard<std::mutex> lk(g_gpu_mutex); ProverSlot &slot = g_provers[path];
-    if (slot.units.size() != D || !(slot.stamp == st)) { slot.units.assign(D, nullptr); slot.stamp = st; }          // (a changed key file: new lists; the old provers die with the last proof running on them)
-    turn = slot.next.fetch_add(1); dev = turn % D;
-    bool any_free = false; for (size_t d = 0; d < D && !any_free; d++) if (slot.units[d]) for (auto &u : *slot.units[d]) { std::unique_lock<std::mutex> t(u->busy, std::try_to_lock); if (t.owns_lock()) { any_free = true; break; } }
-    if (!slot.units[dev] && any_free) { for (size_t d = 0; d < D; d++) if (slot.units[d]) { dev = d; break; } }     // somebody is free on a device that is already loaded: no new pool yet
-    if (!slot.units[dev]) {
-      bool cached = false; ProvingKeyHost pk = load_proving_key_fast(path, cached); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 6; if (n < 1) n = 1; if (n > 7) n = 7;
-      auto fresh = std::make_shared<UnitList>(); std::shared_ptr<Prover> first;
-      for (int i = 0; i < n; i++) { auto u = std::make_shared<ProverUnit>();
-        if (i == 0) { u->prover.reset(new Prover(pk, 0, 1, (int)dev)); first = u->prover; } else u->prover.reset(new Prover(*first));   // the pool's members share the first one's device tables
-        u->circuit = make_circuit(k, false);
-        if (u->circuit->board.num_variables() != u->prover->num_variables() || u->circuit->num_inputs() != u->prover->num_inputs()) throw std::runtime_error("proving key does not belong to the " + std::string(circuit_name(k)) + " circuit: " + path);
-        fresh->push_back(std::move(u)); }
-      slot.units[dev] = std::move(fresh);
-      if (!cached) write_container_quietly(path, pk, st); }
-    lists = slot.units; }
-  // first free member, this caller's device first (warm circuit board, warm buffers), then the other loaded devices; otherwise wait for a member of this device
-  for (size_t dd = 0; dd < D; dd++) { const auto &l = lists[(dev + dd) % D]; if (!l) continue; for (const auto &u : *l) { std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) return HeldUnit{u, std::move(lk)}; } }
-  const std::shared_ptr<ProverUnit> &u = (*lists[dev])[(turn / D) % lists[dev]->size()]; return HeldUnit{u, std::unique_lock<std::mutex>(u->busy)};
+  const int D = std::max(1, gpu_device_slots());
+  static const int spill = [] { const char *e = getenv("ZK_SPILL_BUSY"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+  std::shared_ptr<const UnitList> list; unsigned turn = 0;
+  { std::unique_lock<std::mutex> lk(g_cache_mutex); ProverSlot &slot = g_provers[path];
+    if ((int)slot.units.size() != D || !(slot.stamp == st)) { slot.units.assign(D, nullptr); slot.building.assign(D, 0); slot.stamp = st; }   // (a changed key file: new lists; the old provers die with the last proof running on them)
+    turn = slot.next.fetch_add(1);
+    for (;;) {
+      std::vector<uint8_t> loaded(D, 0); std::vector<int> busy(D, 0);
+      for (int d = 0; d < D; d++) if (slot.units[d]) { loaded[d] = 1; for (auto &u : *slot.units[d]) { std::unique_lock<std::mutex> t(u->busy, std::try_to_lock); if (!t.owns_lock()) busy[d]++; } }
+      const int dev = zk_pool_pick_device(loaded.data(), slot.building.data(), busy.data(), D, spill, turn);
+      if (dev < 0) { g_pool_cv.wait(lk); if (!(slot.stamp == st)) throw std::runtime_error("proving key changed while it was being loaded: " + path); continue; }
+      if (slot.units[dev]) { list = slot.units[dev]; break; }
+      slot.building[dev] = 1; lk.unlock();
+      std::shared_ptr<UnitList> fresh; std::exception_ptr err;
+      try { std::lock_guard<std::mutex> gl(g_gpu_mutex);
+        bool cached = false; ProvingKeyHost pk = load_proving_key_fast(path, cached); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 6; if (n < 1) n = 1; if (n > 7) n = 7;
+        fresh = std::make_shared<UnitList>(); std::shared_ptr<Prover> first;
+        for (int i = 0; i < n; i++) { auto u = std::make_shared<ProverUnit>();
+          if (i == 0) { u->prover.reset(new Prover(pk, 0, 1, dev)); first = u->prover; } else u->prover.reset(new Prover(*first));   // the pool's members share the first one's device tables
+          u->circuit = make_circuit(k, false);
+          if (u->circuit->board.num_variables() != u->prover->num_variables() || u->circuit->num_inputs() != u->prover->num_inputs()) throw std::runtime_error("proving key does not belong to the " + std::string(circuit_name(k)) + " circuit: " + path);
+          fresh->push_back(std::move(u)); }
+        if (!cached) write_container_quietly(path, pk, st);
+      } catch (...) { err = std::current_exception(); fresh.reset(); }
+      lk.lock(); ProverSlot &again = g_provers[path];                                    // (std::map: the reference stays valid, looked up again for clarity)
+      if (again.stamp == st && (int)again.building.size() == D) { again.building[dev] = 0; if (fresh) again.units[dev] = fresh; }
+      g_pool_cv.notify_all();
+      if (err) std::rethrow_exception(err);
+      list = fresh; break;
+    } }
+  // first free member; otherwise wait for one (by turn)
+  for (const auto &u : *list) { std::unique_lock<std::mutex> lk(u->busy, std::try_to_lock); if (lk.owns_lock()) return HeldUnit{u, std::move(lk)}; }
+  const std::shared_ptr<ProverUnit> &u = (*list)[(turn / (unsigned)D) % list->size()]; return HeldUnit{u, std::unique_lock<std::mutex>(u->busy)};
 }
 std::shared_ptr<PreparedVerifyingKey> vk_for_path(const std::string &path) {
   FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("verification key not found: " + path);
@@ -144,10 +177,27 @@ void verify_group(CircuitKind kind, const Proof *ps, const uint8_t *parsed, cons
   // A single proof goes to the device only while no prover of this process is at work: measured (tools/verify_under_load.py), one verifySendproof takes 1.82 ms on an idle
   // GPU and 1.88 ms on a host core, but 2.8 ms (p90 4.1) on a GPU that four provers keep busy — the verifier's one workgroup shares its compute unit's issue slots with
   // their waves, and costs them 17 % of their throughput — against an unchanged 1.87 ms on the host.  Two or more proofs are one launch whatever the load.
-  if (m >= gpu_min && (m >= 2 || g_proofs_in_flight.load(std::memory_order_relaxed) == 0) && gpu_available()) { std::shared_ptr<BatchVerifier> v; { std::lock_guard<std::mutex> lk(g_gpu_mutex); v = gpu_verifier_for_path(path); }   // (building a key's verifier is serialised; using it is not)
-    if (v->num_inputs() == ni) { v->verify(ps, inputs, m, res); for (size_t j = 0; j < m; j++) if (res[j] == 2) res[j] = parsed[j] && verify_proof(*vk_for_path(path), inputs + j * ni, ni, ps[j]); }
-    else for (size_t j = 0; j < m; j++) res[j] = 0; }                                                                       // strong IC: a wrong input count rejects (r1cs_gg_ppzksnark.tcc:584-590)
-  else { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(path); for (size_t j = 0; j < m; j++) res[j] = parsed[j] && verify_proof(*vk, inputs + j * ni, ni, ps[j]); }
+  bool decided = false;
+  if (m >= gpu_min && (m >= 2 || g_proofs_in_flight.load(std::memory_order_relaxed) == 0) && gpu_available()) {
+    // The device may only ever be FASTER than the host verifier, never a different judge: anything that goes wrong on this branch — building the key's verifier, an
+    // allocation, a launch or stream error, the test hook below — is logged and the whole group is decided by the prepared host verifier instead.  A transient GPU
+    // fault must not reject a valid transaction (the reference's verifier is pure host code, r1cs_gg_ppzksnark.tcc:584-590).
+    try {
+      static const bool fail_hook = getenv("ZK_TEST_FAIL_GPU_VERIFY") != nullptr;      // (tests: makes this branch throw, so that the fallback below is exercised on a healthy GPU)
+      if (fail_hook) throw std::runtime_error("ZK_TEST_FAIL_GPU_VERIFY is set");
+      std::shared_ptr<BatchVerifier> v;
+      { std::lock_guard<std::mutex> lk(g_gpu_mutex); v = gpu_verifier_for_path(path); }  // (building a key's verifier is serialised; using it is not)
+      if (v->num_inputs() == ni) {
+        std::vector<uint8_t> dev(m, 0); v->verify(ps, inputs, m, dev.data());            // (into a scratch vector: a throw half-way leaves `res` untouched)
+        for (size_t j = 0; j < m; j++) res[j] = dev[j] == 2 ? (parsed[j] && verify_proof(*vk_for_path(path), inputs + j * ni, ni, ps[j])) : dev[j];
+      } else for (size_t j = 0; j < m; j++) res[j] = 0;                                  // strong IC: a wrong input count rejects (r1cs_gg_ppzksnark.tcc:584-590)
+      decided = true;
+    } catch (const std::exception &e) {
+      static std::atomic<int> noted{0};
+      if (noted.fetch_add(1, std::memory_order_relaxed) < 8) fprintf(stderr, "libzkgpu: GPU verifier failed (%s); deciding %zu proof(s) on the host\n", e.what(), m);
+    }
+  }
+  if (!decided) { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(path); for (size_t j = 0; j < m; j++) res[j] = parsed[j] && verify_proof(*vk, inputs + j * ni, ni, ps[j]); }
   for (size_t j = 0; j < m; j++) res[j] = parsed[j] && res[j] == 1;
 }
 bool verify(CircuitKind k, const char *data, const std::vector<bool> &public_bits) {
@@ -266,10 +316,25 @@ int zkgpu_keygen(int kind, int tree_depth, uint64_t seed, const char *pk_path, c
 zkgpu_prover *zkgpu_prover_load_shard(const char *pk_path, size_t shard_rank, size_t shard_world) { zkgpu_prover *h = nullptr; guarded([&] { FileStamp before; if (!stamp_of(pk_path, before)) throw std::runtime_error(std::string("proving key not found: ") + pk_path); bool cached = false; ProvingKeyHost pk = load_proving_key_fast(pk_path, cached); std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(pk, shard_rank, shard_world));
   if (!cached) write_container_quietly(pk_path, pk, before); h = p.release(); return ZKGPU_OK; }); return h; }
 /* pure host logic of the multi-device pool, for the CPU tests: parses `spec` as ZK_DEVICES would be (n_visible devices, `fallback` = ZK_DEVICE / LOCAL_RANK) into out_devices (returns
- * the count), and writes the device slot of each of the first n_order pool members (ZK_PROVERS_PER_KEY = per_device) into out_order in pool order */
+ * the count), and writes into out_order the device that each of n_order callers arriving AT THE SAME TIME (nobody has finished yet) is sent to by acquire_prover's policy */
 int zkgpu_test_device_plan(const char *spec, int n_visible, int fallback, int per_device, int *out_devices, int *out_order, int n_order) {
   std::vector<int> l = parse_device_list(spec, n_visible, fallback); for (size_t i = 0; i < l.size(); i++) out_devices[i] = l[i];
-  const int D = std::max<int>(1, (int)l.size()); int k = 0; for (int i = 0; i < per_device && k < n_order; i++) for (int d = 0; d < D && k < n_order; d++) out_order[k++] = d; return (int)l.size(); }
+  const int D = std::max<int>(1, (int)l.size()); std::vector<int> rel(n_order, -1); (void)per_device;
+  zkgpu_test_pool_plan(D, 1, rel.data(), n_order, out_order); return (int)l.size(); }
+/* acquire_prover's device choice replayed on the host: call i first lets go of the proof that call release_before[i] started (-1: nobody finishes), then picks its device
+ * (a pool that has to be built counts as loaded from then on).  out_dev[i] = the device slot.  Returns the number of pools built. */
+int zkgpu_test_pool_plan(int D, int spill, const int *release_before, int n_calls, int *out_dev) {
+  if (D < 1 || D > 64 || n_calls < 0) return -1;
+  std::vector<uint8_t> loaded(D, 0), building(D, 0); std::vector<int> busy(D, 0); int built = 0;
+  for (int i = 0; i < n_calls; i++) {
+    const int r = release_before ? release_before[i] : -1; if (r >= 0 && r < i && out_dev[r] >= 0 && busy[out_dev[r]] > 0) busy[out_dev[r]]--;
+    const int d = zk_pool_pick_device(loaded.data(), building.data(), busy.data(), D, spill < 1 ? 1 : spill, (unsigned)i); out_dev[i] = d; if (d < 0) return -1;
+    if (!loaded[d]) { loaded[d] = 1; built++; } busy[d]++; }
+  return built; }
+/* the stream-lane planner of gpu.hip replayed on the host: n_slots devices whose pools are built one device at a time, `kinds` circuit kinds x per_kind members each taking
+ * a lane.  Returns -1 if any member is left without a lane, else the largest number of provers sharing one lane; out_lanes_per_slot[d] = lanes bound to device slot d. */
+int zkgpu_test_lane_plan(int n_slots, int kinds, int per_kind, int *out_lanes_per_slot) {
+  return lane_plan_simulate(n_slots, kinds, per_kind, out_lanes_per_slot); }
 /* host-only self-test of the container code (tests/test_key_container_cpu.py): a synthetic transformed key of the given shape is written, mapped back and compared; then the
  * file is truncated, a payload byte is flipped, and the source stamp is changed — each must make the loader refuse.  Returns 0 if every step behaved. */
 int zkgpu_test_key_container(const char *path, size_t n_vars, size_t n_cons, size_t m) { int rc = -1; guarded_host([&] {

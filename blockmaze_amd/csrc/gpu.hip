@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <vector>
+#include <algorithm>
 #include <mutex>
 #include <atomic>
 #include <mutex>
@@ -24,7 +26,9 @@ namespace zk {
 
 // Lanes: independent sets of streams (one main + four auxiliary) so that several provers can have a proof in flight at the same time; a thread works on the lane it
 // selected with LaneScope (lane 0 unless told otherwise).  Contexts are created on first use and live for the life of the process.
-constexpr int MAX_LANES = 32;   // lanes beyond the hardware queues share queues; provers sharing a lane share its streams (still correct, merely serialised)
+// (lanes beyond the hardware queues share queues)  Sized for 8 devices x 4 circuit kinds x 7 pool members with a lane each; a single device never binds more than 31.
+constexpr int MAX_LANES_PER_DEVICE = 31, MAX_LANES = 1 + 8 * 28;
+static uint8_t g_lane_claimed[MAX_LANES];   // a lane that was ever lent keeps its device slot (guarded by g_lane_mutex)
 static std::atomic<GpuContext *> g_lanes[MAX_LANES]; static std::atomic<int> g_lane_slot[MAX_LANES]; static std::mutex g_lane_mutex; static thread_local int t_lane = 0; static std::atomic<unsigned> g_next_lane{0};
 std::vector<int> parse_device_list(const char *spec, int n_visible, int fallback_device) {
   std::vector<int> out; if (n_visible <= 0) return out;
@@ -44,19 +48,45 @@ GpuContext &gpu() {
       c = new GpuContext(l[(size_t)g_lane_slot[t_lane].load() % l.size()]); g_lanes[t_lane].store(c, std::memory_order_release); } }
   hipSetDevice(c->device); return *c;
 }
-// lanes 1.. round robin for provers; lane 0 (device slot 0) stays with everything else.  A lane keeps the device slot of its first user; asking for a lane on another
-// slot skips lanes bound elsewhere.
-// A lane is lent to ONE prover at a time and handed back by its destructor (gpu_lane_release): a process that reloads keys or clones provers for ever keeps cycling
-// through the same 31 stream sets instead of running out of them (the lanes' HIP streams themselves live for the life of the process and are reused).
+// Lanes 1.. are lent to provers; lane 0 (device slot 0) stays with everything else.  A lane belongs to the device slot of its first user for good (its streams live on
+// that device).  A lane is lent to ONE prover at a time and handed back by its destructor (gpu_lane_release): a process that reloads keys or clones provers for ever
+// keeps cycling through the same stream sets instead of running out of them.
+// Every device slot may bind at most lane_quota(D) lanes, so that D devices can never starve one another whatever the order in which their pools are built (the cgo
+// layer builds them lazily, one device at a time, every pool member of every circuit kind taking a lane); past its quota a slot shares its least-used lane —
+// provers on one lane share its streams: still correct, merely serialised.
 static int g_lane_users[MAX_LANES];
+int lane_quota(int n_slots) { const int q = (MAX_LANES - 1) / std::max(1, n_slots); return std::max(1, std::min(q, MAX_LANES_PER_DEVICE)); }
+// The planner, free of HIP state so that a CPU test can drive it (zkgpu_test_lane_plan): users[l] = provers holding lane l, slot[l] = its device slot, bound[l] = whether
+// the lane belongs to a slot yet.  Returns the lane to use (and binds / counts it), or -1.
+int lane_plan_pick(int *users, int *slot, uint8_t *bound, int device_slot, int n_slots) {
+  int mine = 0;
+  for (int lane = 1; lane < MAX_LANES; lane++) if (bound[lane] && slot[lane] == device_slot) mine++;
+  for (int lane = 1; lane < MAX_LANES; lane++)                                           // a free lane of this slot: its context exists
+    if (bound[lane] && slot[lane] == device_slot && users[lane] == 0) { users[lane] = 1; return lane; }
+  if (mine < lane_quota(n_slots))
+    for (int lane = 1; lane < MAX_LANES; lane++)                                         // a lane nobody owns yet
+      if (!bound[lane] && users[lane] == 0) { users[lane] = 1; slot[lane] = device_slot; bound[lane] = 1; return lane; }
+  int best = -1;
+  for (int lane = 1; lane < MAX_LANES; lane++)                                           // quota reached (or nothing left): share this slot's least-used lane
+    if (bound[lane] && slot[lane] == device_slot && (best < 0 || users[lane] < users[best])) best = lane;
+  if (best >= 0) users[best]++;
+  return best;
+}
+int lane_plan_simulate(int n_slots, int kinds, int per_kind, int *out_lanes_per_slot) {
+  if (n_slots < 1 || n_slots > 64) return -1;
+  std::vector<int> users(MAX_LANES, 0), slot(MAX_LANES, 0); std::vector<uint8_t> bound(MAX_LANES, 0); int worst = 0;
+  for (int d = 0; d < n_slots; d++)                                                       // lazily, one device at a time: the order that used to starve the later devices
+    for (int k = 0; k < kinds * per_kind; k++) { const int lane = lane_plan_pick(users.data(), slot.data(), bound.data(), d, n_slots); if (lane < 0) return -1; worst = std::max(worst, users[lane]); }
+  for (int d = 0; d < n_slots; d++) { int c = 0; for (int lane = 1; lane < MAX_LANES; lane++) c += bound[lane] && slot[lane] == d; if (out_lanes_per_slot) out_lanes_per_slot[d] = c; }
+  return worst;
+}
 int gpu_lane_acquire(int device_slot) {
   std::lock_guard<std::mutex> lk(g_lane_mutex);
-  for (int pass = 0; pass < 2; pass++)                                                   // first a free lane already bound to this device slot (its context exists), then any free lane that was never bound
-    for (int lane = 1; lane < MAX_LANES; lane++) { if (g_lane_users[lane]) continue; const bool bound = g_lanes[lane].load() != nullptr;
-      if (pass == 0 ? (bound && g_lane_slot[lane].load() == device_slot) : !bound) { g_lane_users[lane] = 1; g_lane_slot[lane].store(device_slot); return lane; } }
-  int best = -1; for (int lane = 1; lane < MAX_LANES; lane++) if (g_lane_slot[lane].load() == device_slot && (best < 0 || g_lane_users[lane] < g_lane_users[best])) best = lane;   // all lent out: share the least used lane of this device
-  if (best < 0) throw GpuError("no stream lane left for device slot " + std::to_string(device_slot));
-  g_lane_users[best]++; return best; }
+  int slot[MAX_LANES]; uint8_t bound[MAX_LANES];
+  for (int lane = 0; lane < MAX_LANES; lane++) { slot[lane] = g_lane_slot[lane].load(); bound[lane] = g_lanes[lane].load() != nullptr || g_lane_users[lane] > 0 || g_lane_claimed[lane]; }
+  const int lane = lane_plan_pick(g_lane_users, slot, bound, device_slot, gpu_device_slots());
+  if (lane < 0) throw GpuError("no stream lane left for device slot " + std::to_string(device_slot));
+  g_lane_slot[lane].store(device_slot); g_lane_claimed[lane] = 1; return lane; }
 void gpu_lane_release(int lane) { if (lane <= 0 || lane >= MAX_LANES) return; std::lock_guard<std::mutex> lk(g_lane_mutex); if (g_lane_users[lane] > 0) g_lane_users[lane]--; }
 int gpu_lane_current() { return t_lane; }
 void gpu_lane_select(int lane) { t_lane = lane < 0 || lane >= MAX_LANES ? 0 : lane; }

@@ -23,6 +23,7 @@ struct G2AffineRaw { Fe32 x0, x1, y0, y1; };  // 128 B
 class GpuContext;
 GpuContext &gpu();                             // lazily initialised process-wide context (device from ZK_DEVICE / LOCAL_RANK)
 bool gpu_available();                          // false if no HIP device is visible
+int lane_plan_simulate(int n_slots, int kinds, int per_kind, int *out_lanes_per_slot);   // the lane planner on a private table (CPU tests)
 int gpu_lane_acquire(int device_slot = 0); void gpu_lane_release(int lane); int gpu_lane_current(); void gpu_lane_select(int lane);   // independent stream sets (gpu.hip); a lane belongs to one device of the list below
 // The devices this process works on: ZK_DEVICES = "all" or a comma-separated list of HIP device indices; without it the single device ZK_DEVICE / LOCAL_RANK (default 0)
 // as before.  Slot k of the list is what device_slot arguments mean.  A plain go-ethereum process calling the cgo symbols from many goroutines thereby uses every GPU

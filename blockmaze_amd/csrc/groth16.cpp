@@ -277,9 +277,17 @@ class SubmitWorker {
   // A proof hands this thread two jobs a fraction of a millisecond apart (its share of the hand-over scan, then a witness MSM), and the next proof follows as soon: the
   // thread polls for SPIN_US before it goes to sleep on the condition variable, and so does a waiter — a futex wake-up costs 10-50 us, on the critical path every time.
   // An idle prover sleeps.
-  static constexpr int SPIN_US = 250;
-  template <class Pred> static void spin(Pred ready) { const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(SPIN_US);
-    for (int k = 0; !ready(); k++) { if ((k & 63) == 63 && std::chrono::steady_clock::now() > t_end) return; __builtin_ia32_pause(); } }
+  // ZK_SPIN_US overrides the 250 us; a host with fewer than four cores gets 0 (no polling: there the spinners would compete with the threads that submit kernels).
+  static int spin_us() { static const int v = [] { const char *e = getenv("ZK_SPIN_US"); if (e) return std::max(0, atoi(e)); return std::thread::hardware_concurrency() >= 4 ? 250 : 0; }(); return v; }
+  static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
+  template <class Pred> static void spin(Pred ready) { const int us = spin_us(); if (us <= 0) return; const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(us);
+    for (int k = 0; !ready(); k++) { if ((k & 63) == 63 && std::chrono::steady_clock::now() > t_end) return; cpu_relax(); } }
   void loop() { LaneScope lane_scope(lane_); std::unique_lock<std::mutex> lk(m_); uint32_t seen = 0;
     for (;;) { if (!(quit_ || (busy_ && job_))) { lk.unlock(); spin([&] { return posted_.load(std::memory_order_acquire) != seen; }); lk.lock(); }
       cv_.wait(lk, [this] { return quit_ || (busy_ && job_); }); if (quit_) return; seen = posted_.load(std::memory_order_acquire); std::function<void()> j = std::move(job_); job_ = nullptr; lk.unlock();

@@ -34,3 +34,37 @@ def gather_partials(partial_bytes, dist, device=None):
     mine = torch.frombuffer(bytearray(partial_bytes), dtype=torch.uint8).to(device) if device is not None else torch.frombuffer(bytearray(partial_bytes), dtype=torch.uint8)
     out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]; dist.all_gather(out, mine)
     return [bytes(t.cpu().numpy().tobytes()) for t in out]
+
+
+class Group:
+    """The ranks of one node as bench.py and the sharded prover use them: join, barrier, agree on success, hand one object from rank 0 to everybody, reduce the timing,
+    gather partial records.  backend "nccl" is RCCL over xGMI (one rank per GPU, collectives on device tensors of that rank's GPU); "gloo" runs the same code path on a box
+    with fewer GPUs than ranks (tests).  Every torch.distributed call of the N > 1 path is made HERE, so that a CPU test can replay them against the real signatures
+    (tests/test_distributed_cpu.py::test_group_calls_bind_to_torch_signatures) before the first run on real multi-GPU hardware."""
+    def __init__(self, backend, rank, world, local_rank, timeout_s=600):
+        import datetime, torch, torch.distributed as dist
+        self.dist, self.torch, self.backend, self.rank, self.world, self.local_rank = dist, torch, backend, rank, world, local_rank
+        if backend == "nccl":
+            self.device = torch.device("cuda", local_rank); torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s), device_id=self.device)
+        else:
+            self.device = torch.device("cpu"); dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+    def _tensor(self, values, dtype):
+        return self.torch.tensor(values, dtype=dtype, device=self.device)
+    def barrier(self):
+        self.dist.barrier()
+    def all_ok(self, ok):
+        """True iff every rank passed True: a rank whose set-up failed takes the whole group down instead of leaving the others at a barrier"""
+        t = self._tensor([1 if ok else 0], self.torch.int32); self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN); return bool(int(t.item()))
+    def share_from_rank0(self, obj):
+        box = [obj if self.rank == 0 else None]; self.dist.broadcast_object_list(box, src=0); return box[0]
+    def aggregate_throughput(self, units_per_rank, seconds):
+        t = self._tensor([seconds], self.torch.float64); self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        u = self._tensor([units_per_rank], self.torch.float64); self.dist.all_reduce(u, op=self.dist.ReduceOp.SUM)
+        return float(u.item()) / float(t.item()), float(t.item())
+    def gather_partials(self, partial_bytes):
+        mine = self.torch.frombuffer(bytearray(partial_bytes), dtype=self.torch.uint8).to(self.device)
+        out = [self.torch.empty_like(mine) for _ in range(self.world)]; self.dist.all_gather(out, mine)
+        return [bytes(t.cpu().numpy().tobytes()) for t in out]
+    def close(self):
+        self.dist.destroy_process_group()

@@ -97,6 +97,8 @@ typedef struct zkgpu_prover zkgpu_prover;
 zkgpu_prover *zkgpu_prover_load(const char *pk_path);   /* parses the reference-format key file, or maps its container <pk_path>.gpucache when that is valid; writes the container after a load from text */
 int zkgpu_key_container_valid(const char *pk_path);
 int zkgpu_test_device_plan(const char *spec, int n_visible, int fallback, int per_device, int *out_devices, int *out_order, int n_order);   /* multi-device pool planning (pure host logic) */
+int zkgpu_test_pool_plan(int n_devices, int spill, const int *release_before, int n_calls, int *out_dev);   /* acquire_prover's device choice replayed on the host (capi_zk.cpp) */
+int zkgpu_test_lane_plan(int n_slots, int kinds, int per_kind, int *out_lanes_per_slot);   /* the stream-lane planner with its per-device quota (gpu.hip) */
 int zkgpu_test_key_container(const char *path, size_t n_vars, size_t n_cons, size_t m);   /* host-only self-test of the container reader / writer; 0 = passed */     /* 1 if a valid container (matching size / mtime of the key file, checksum) is in place */
 /* MSM sharding across GPUs (one process per GPU): a shard holds the contiguous slice rank/world of every query of the key.  prove_partial() runs the whole
  * device pipeline on the resident witness and returns this shard's five partial sums (affine canonical: eA 64 | eB1 64 | eH 64 | eL 64 | eB2 128 = 384 bytes);

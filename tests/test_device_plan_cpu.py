@@ -17,3 +17,29 @@ def test_pool_is_interleaved_by_device():
     assert plan("all", 8, per_device=2)[1] == list(range(8)) * 2
     assert plan("all", 2, per_device=3, n_order=6)[1] == [0, 1, 0, 1, 0, 1]
     assert plan(None, 8, per_device=4, n_order=4)[1] == [0, 0, 0, 0]
+
+def pool_plan(D, releases, spill=1):
+    L = e.lib(); n = len(releases); rel = (ctypes.c_int * n)(*releases); out = (ctypes.c_int * n)(*([-1] * n))
+    built = L.zkgpu_test_pool_plan(D, spill, rel, n, out); return built, list(out)
+
+def test_concurrent_callers_spread_over_the_devices_before_two_share_one():
+    """acquire_prover's policy (capi_zk.cpp: zk_pool_pick_device): nobody finishes -> every caller finds the loaded devices busy and opens the next one; once all
+    devices hold a pool the least busy one is taken"""
+    built, dev = pool_plan(8, [-1] * 20); assert built == 8 and dev[:8] == list(range(8)) and sorted(dev[8:16]) == list(range(8)) and max(dev.count(d) for d in range(8)) == 3
+    built, dev = pool_plan(2, [-1] * 6); assert built == 2 and sorted(dev[:2]) == [0, 1] and dev.count(0) == dev.count(1) == 3
+
+def test_one_caller_at_a_time_stays_on_one_device():
+    """a process that never has two proofs in flight builds ONE pool (one copy of the key on one GPU), whatever ZK_DEVICES lists"""
+    rel = [-1] + list(range(0, 11)); built, dev = pool_plan(8, rel); assert built == 1 and dev == [0] * 12
+    rel = [-1, -1] + list(range(0, 10)); built, dev = pool_plan(8, rel); assert built == 2 and set(dev) == {0, 1}     # two in flight at any time: two devices
+    built, dev = pool_plan(8, [-1] * 6, spill=3); assert built == 2 and dev == [0, 0, 0, 1, 1, 1]                      # ZK_SPILL_BUSY=3: three proofs per device first
+
+def test_lane_planner_never_starves_a_device():
+    """gpu.hip: lane_plan_pick.  The pools are built lazily, one device at a time, every member of every circuit kind taking a stream lane: with a quota per device slot the
+    last device still gets its lanes (8 devices x 4 kinds x 6 members used to throw 'no stream lane left' on the later devices)"""
+    L = e.lib(); per = (ctypes.c_int * 64)()
+    assert L.zkgpu_test_lane_plan(8, 4, 6, per) == 1 and list(per[:8]) == [24] * 8                                   # 192 members, a lane each
+    assert L.zkgpu_test_lane_plan(8, 4, 7, per) == 1 and list(per[:8]) == [28] * 8
+    assert L.zkgpu_test_lane_plan(1, 4, 7, per) == 1 and per[0] == 28
+    worst = L.zkgpu_test_lane_plan(16, 4, 6, per); assert worst == 2 and list(per[:16]) == [14] * 16                  # 16 devices: 14 lanes each, shared by 24 members
+    worst = L.zkgpu_test_lane_plan(1, 8, 7, per); assert worst == 2 and per[0] == 31                                  # one device never binds more than 31 lanes

@@ -32,3 +32,56 @@ def test_two_ranks_gloo():
     for p in procs: p.join(timeout=60); assert p.exitcode == 0
     for rank, rate, slowest, firsts, inst in res:
         assert slowest == 2.0 and rate == 20 / 2.0 and firsts == [1, 2] and inst == ([0, 2, 4] if rank == 0 else [1, 3])
+
+def test_group_calls_bind_to_torch_signatures(monkeypatch):
+    """RCCL has never run under this repo (no multi-GPU box in its rounds).  Every torch.distributed call of the N > 1 path lives in sharding.Group; here the nccl branch is
+    replayed against the REAL signatures of this torch build (inspect.signature(...).bind: a wrong keyword, a missing argument or a wrong argument order raises), with the
+    collectives' effect faked for a world of 2 and device tensors created on the CPU instead — so the first run on 8 GPUs cannot die of an argument error."""
+    import datetime, inspect
+    calls = []
+    def bound(real, impl):
+        sig = inspect.signature(real)
+        def f(*a, **k): ba = sig.bind(*a, **k); ba.apply_defaults(); calls.append((real.__name__, dict(ba.arguments))); return impl(ba.arguments)
+        return f
+    def fake_all_reduce(a): assert isinstance(a["tensor"], torch.Tensor) and isinstance(a["op"], dist.ReduceOp.RedOpType if hasattr(dist.ReduceOp, "RedOpType") else object)
+    def fake_all_gather(a):
+        assert all(t.shape == a["tensor"].shape and t.dtype == a["tensor"].dtype for t in a["tensor_list"])
+        for i, t in enumerate(a["tensor_list"]): t.copy_(a["tensor"] + i)
+    def fake_bcast(a): assert a["src"] == 0 and isinstance(a["object_list"], list) and len(a["object_list"]) == 1
+    monkeypatch.setattr(dist, "init_process_group", bound(dist.init_process_group, lambda a: None))
+    monkeypatch.setattr(dist, "all_reduce", bound(dist.all_reduce, fake_all_reduce)); monkeypatch.setattr(dist, "all_gather", bound(dist.all_gather, fake_all_gather))
+    monkeypatch.setattr(dist, "barrier", bound(dist.barrier, lambda a: None)); monkeypatch.setattr(dist, "broadcast_object_list", bound(dist.broadcast_object_list, fake_bcast))
+    monkeypatch.setattr(dist, "destroy_process_group", bound(dist.destroy_process_group, lambda a: None))
+    set_dev = []; monkeypatch.setattr(torch.cuda, "set_device", lambda d: set_dev.append(d))
+    wanted = []
+    class CpuTensors(sharding.Group):                                                   # (no GPU here: the tensors a rank would create on its device are made on the CPU)
+        def _tensor(self, values, dtype): wanted.append(self.device); return torch.tensor(values, dtype=dtype)
+        def gather_partials(self, partial_bytes): dev = self.device; self.device = torch.device("cpu"); out = sharding.Group.gather_partials(self, partial_bytes); self.device = dev; return out
+    g = CpuTensors("nccl", 0, 2, 0, timeout_s=77)
+    init = calls[0][1]; assert calls[0][0] == "init_process_group" and init["backend"] == "nccl" and init["rank"] == 0 and init["world_size"] == 2
+    assert init["device_id"] == torch.device("cuda", 0) and init["timeout"] == datetime.timedelta(seconds=77) and set_dev == [0] and g.device == torch.device("cuda", 0)
+    g.barrier(); assert g.all_ok(True) is True and g.all_ok(False) is False
+    assert g.share_from_rank0({"key_dir": "/tmp/x"}) == {"key_dir": "/tmp/x"}
+    rate, slowest = g.aggregate_throughput(20, 2.0); assert slowest == 2.0 and rate == 10.0
+    recs = g.gather_partials(bytes(range(1, 97)) * 4); assert len(recs) == 2 and len(recs[0]) == 384 and recs[0][0] == 1 and recs[1][0] == 2
+    g.close()
+    names = [c[0] for c in calls]; assert names.count("all_reduce") == 4 and "all_gather" in names and "broadcast_object_list" in names and names[-1] == "destroy_process_group"
+    assert all(d == torch.device("cuda", 0) for d in wanted)                             # every collective tensor of the nccl branch is asked for on this rank's GPU
+    ops = [c[1]["op"] for c in calls if c[0] == "all_reduce"]; assert ops == [dist.ReduceOp.MIN, dist.ReduceOp.MIN, dist.ReduceOp.MAX, dist.ReduceOp.SUM]
+
+def _group_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    g = sharding.Group("gloo", rank, world, rank, timeout_s=60)
+    ok_all = g.all_ok(True); ok_one = g.all_ok(rank != 1); shared = g.share_from_rank0("dir-of-rank-0" if rank == 0 else None)
+    rate, slowest = g.aggregate_throughput(10, 1.0 + rank); recs = g.gather_partials(bytes([rank + 1]) * 384)
+    q.put((rank, ok_all, ok_one, shared, rate, slowest, [r[0] for r in recs])); g.barrier(); g.close()
+
+def test_group_two_ranks_gloo():
+    """the same Group object over a real (gloo) process group of two ranks: agreement on success, the hand-over from rank 0, the timing reduce and the record gather"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); procs = [ctx.Process(target=_group_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs: p.join(timeout=60); assert p.exitcode == 0
+    for rank, ok_all, ok_one, shared, rate, slowest, firsts in res:
+        assert ok_all is True and ok_one is False and shared == "dir-of-rank-0" and slowest == 2.0 and rate == 10.0 and firsts == [1, 2]

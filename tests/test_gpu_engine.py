@@ -103,6 +103,30 @@ def test_msm_one_pass_sort_and_its_overflow_fallback():
     K2 = rand_field_arr(4243, n); m.set_scalars(K2); assert o.g1_from(m.run())[0] == o.msm_g1(P, K2)
     m.close()
 
+def test_h_path_degenerate_additions_fall_back_and_stay_exact():
+    """the H query's 29-bit run accumulation (k_hacc_runs29, filter_ones=2) uses INCOMPLETE mixed additions: an operand equal to +-the accumulator leaves ZZ = 0 (mod p),
+    which k_hacc_combine29 must notice and send to the general path (complete formulas: alt_bn128_g1.cpp:139-195 '+' with its doubling fallback, multiexp.tcc:165-282).
+    Inputs a key could legally hold: repeated points with equal scalars (doubling inside a run), P / -P pairs with equal scalars (cancellation), every point equal, and a
+    mixture of all three; each must give the oracle's sum and the resident object must keep working on ordinary scalars afterwards."""
+    n = 6000; g = o.SplitMix64(4104); base = o.g1_consecutive(g.field(), n); K = rand_field_arr(4105, n)
+    def neg(pt):                                                                                  # (x, -y): q - y on the stored words, Montgomery form or not
+        r = pt.copy(); r[4:] = o.limbs((o.Q_MOD - o.from_arr(pt)[1]) % o.Q_MOD); return r
+    def run(P, S):
+        m = e.ResidentMsm(1, P, 10, filter_ones=2); m.set_scalars(S); got = o.g1_from(m.run())[0]; assert got == o.msm_g1(P, S)
+        S2 = rand_field_arr(4106, len(P)); m.set_scalars(S2); assert o.g1_from(m.run())[0] == o.msm_g1(P, S2); m.close()        # still usable, still exact
+    # (a) pairs of equal points with equal scalars: the same digit in every window, so both land in the same bucket
+    P = base.copy(); S = K.copy(); P[1::2] = P[0::2]; S[1::2] = S[0::2]; run(P, S)
+    # (b) P, -P with equal scalars: every bucket cancels to the point at infinity (the whole sum is the group's zero)
+    P = base.copy(); S = K.copy()
+    for i in range(0, 400, 2): P[i + 1] = neg(P[i]); S[i + 1] = S[i]
+    P = P[:400]; S = S[:400]; m = e.ResidentMsm(1, P, 10, filter_ones=2); m.set_scalars(S); assert o.g1_from(m.run())[0] is None and o.msm_g1(P, S) is None; m.close()
+    # (c) every point equal, random scalars: every bucket collision is a doubling
+    P = np.repeat(base[:1], 3000, axis=0); S = K[:3000]; run(P, S)
+    # (d) a mixture inside an otherwise ordinary query
+    P = base.copy(); S = K.copy(); P[100:200] = P[99]; S[100:150] = S[99]
+    for i in range(1000, 1100, 2): P[i + 1] = neg(P[i]); S[i + 1] = S[i]
+    run(P, S)
+
 def test_msm_degenerate_inputs():
     assert o.g1_from(e.msm(1, np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)))[0] is None         # empty
     P = o.g1_consecutive(5, 64); assert o.g1_from(e.msm(1, P, np.zeros((64, 4), np.uint64), filter_ones=True))[0] is None   # all-zero scalars

@@ -78,6 +78,28 @@ def test_send_proof_full_size_equals_libsnark_prover_bytes(send_keys, tmp_path):
     rc, out = ref("verify", vk_path, proof, "5", *[str(x) for x in inputs]); assert rc == 0 and "verify 1" in out
     record_leg("libsnark prover+verifier on the full-size send key: same bytes", time.time() - t0)
 
+def test_send_key_made_by_the_libsnark_generator(tmp_path):
+    """the direction a deployment needs: a full-size send key written by the REFERENCE generator (r1cs_gg_ppzksnark.tcc:212-388 via `ref_harness e2e` on the exported
+    send R1CS, serialised with libsnark's operator<<: 943 k compressed points with the real pattern of points at infinity, send/getpvk.cpp:41-51) is loaded by this
+    engine — text parser, k_g1_decompress / k_g2_decompress, the key-load transforms (H into the coset's Lagrange basis, C folded into L) — and the reference's send
+    fixture proved with the harness's (r, s) must give the very proof line the reference prover printed; once through the text loader, once through the container."""
+    import time
+    assert have_ref, "oracle/_ref/ref_harness is missing: run __graft_entry__.build() where /root/reference exists"
+    r1cs, wp, out_dir = str(tmp_path / "send.r1cs"), str(tmp_path / "w.bin"), tmp_path / "refkey"; out_dir.mkdir(); e.circuit_export("send", r1cs)
+    d = w.reference_send_fixture(); e.witness_send(*hexargs(w.send_args(d)), wp); z = o.load_witness(wp); g = o.SplitMix64(4002); r, s = g.field(), g.field()
+    t0 = time.time(); rc, out = ref("e2e", r1cs, wp, "%x" % r, "%x" % s, str(out_dir)); t_ref = time.time() - t0
+    assert rc == 0 and "satisfied 1" in out and "verify 1" in out, out[-800:]
+    ref_proof = [l.split()[1] for l in out.splitlines() if l.startswith("proof ")][0]; pk_path, vk_path = str(out_dir / "pk.txt"), str(out_dir / "vk.txt")
+    assert os.path.getsize(pk_path) > 60e6 and e.lib().zkgpu_key_container_valid(pk_path.encode()) == 0
+    inputs = w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]])
+    p = e.Prover(pk_path); assert (p.n_vars, p.n_inputs, p.m) == (227046, 5, 262144); got = p.prove(z, r, s); fresh = p.prove(z); p.close()
+    assert got == ref_proof                                                              # text loader: the reference prover's bytes under the reference's key
+    assert e.lib().zkgpu_key_container_valid(pk_path.encode()) == 1
+    p = e.Prover(pk_path); again = p.prove(z, r, s); p.close(); assert again == ref_proof     # ... and from the container the first load left behind
+    assert e.verify(vk_path, got, inputs) and e.verify(vk_path, fresh, inputs) and not e.verify(vk_path, got, inputs[::-1])
+    rc, out = ref("verify", vk_path, fresh, "5", *[str(x) for x in inputs]); assert rc == 0 and "verify 1" in out      # the reference verifier on a fresh-randomness proof
+    record_leg("libsnark GENERATOR's full-size send key loaded (text + container): the reference prover's bytes", t_ref)
+
 def test_dropin_symbols_send(send_keys, monkeypatch):
     monkeypatch.setenv("ZK_PRFKEY_DIR", str(send_keys)); zk = e.Zk(); d = w.send_instance(5)
     proof = zk.GenSendProof(*w.send_args(d)); assert len(proof) == 512 and not proof.startswith("0000000000")
@@ -115,7 +137,8 @@ def test_mint_redeem_deposit_full_size_against_libsnark(all_keys, tmp_path):
     """the other three circuits at full size against the REAL libsnark (oracle/_ref/ref_harness): the reference's mint fixture (mint/main.cpp:121-129) and its redeem and
     deposit fixtures (redeem/main.cpp:121-129, deposit/main.cpp:131-167) are proved on the GPU with fixed (r, s); the reference VERIFIER accepts all three proofs under the
     engine-made keys and rejects them against wrong public inputs; the reference PROVER, loading the same key files with its own operator>>, returns the same proof bytes for
-    mint (step-radix-2 domain of 196,608 inside libfqfft, step_radix2_domain.tcc:39-140) and deposit (basic radix-2 domain 2^19)."""
+    mint and redeem (step-radix-2 domain of 196,608 inside libfqfft, step_radix2_domain.tcc:39-140; redeem adds the less_comparison gadget, redeem/circuit/gadget.tcc:70-135)
+    and deposit (basic radix-2 domain 2^19)."""
     import time
     assert have_ref, "oracle/_ref/ref_harness is missing: run __graft_entry__.build() where /root/reference exists"
     def u(h, n=32): return int(h, 16).to_bytes(n, "big")
@@ -123,7 +146,7 @@ def test_mint_redeem_deposit_full_size_against_libsnark(all_keys, tmp_path):
     def mint_like(redeem, value, value_old, value_s):
         sk, r_old, r = u("1"), u("123456"), u("123"); sn_old = w.prf(sk, r_old); sn = w.prf(sk, r)
         return dict(sk=sk, r_old=r_old, r=r, value=value, value_old=value_old, value_s=value_s, sn_old=sn_old, sn=sn, cmtA_old=w.cmt(value_old, sn_old, r_old), cmtA=w.cmt(value, sn, r))
-    cases = [("mint", mint_like(False, 13, 6, 7), True), ("redeem", mint_like(True, 13, 20, 7), False), ("deposit", w.reference_deposit_fixture(), True)]
+    cases = [("mint", mint_like(False, 13, 6, 7), True), ("redeem", mint_like(True, 13, 20, 7), True), ("deposit", w.reference_deposit_fixture(), True)]
     for kind, d, with_prover in cases:
         pk_path, vk_path, wp = str(all_keys / (kind + "pk.txt")), str(all_keys / (kind + "vk.txt")), str(tmp_path / (kind + ".bin"))
         if kind == "deposit":
@@ -249,6 +272,10 @@ def test_deposit_depth32_single_gpu(tmp_path):
     import time; t0 = time.time(); rc, out = ref("verify", vk_path, proof, "6", *[str(x) for x in inputs]); assert rc == 0 and "verify 1" in out, out[-300:]
     rc, out = ref("verify", vk_path, proof, "6", *[str(x) for x in inputs[::-1]]); assert "verify 0" in out
     record_leg("libsnark verifier on the depth-32 deposit proof", time.time() - t0)
+    # ... and the reference PROVER on the same 364 MB key with the same (r, s): the only circuit on the window-by-window MSM path (its tables pass the fixed-base cap) and on
+    # the 2^20 + 2^17 step domain must give the same bytes (libfqfft step_radix2_domain.tcc:39-140, multiexp.tcc:165-282 at n = 1,179,647)
+    t0 = time.time(); rc, out = ref("prove", pk_path, wp, "6", "5", "7"); assert rc == 0 and ("proof " + proof) in out, out[-600:]
+    record_leg("libsnark prover on the depth-32 deposit key: same bytes", time.time() - t0)
 
 @pytest.mark.parametrize("env", [{"ZK_WITNESS_DENSE": "1"}, {"ZK_DEVICES": "all", "ZK_PROVERS_PER_KEY": "2"}, {"ZK_PROVERS_PER_KEY": "1", "ZK_WITNESS_THREADS": "0", "ZK_SUBMIT_THREADS": "0"}], ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
 def test_cgo_symbols_under_process_wide_switches(all_keys, env):
@@ -260,6 +287,18 @@ def test_cgo_symbols_under_process_wide_switches(all_keys, env):
             "print('DENSE', zk.VerifySendProof(p, s['cmtA_old'], s['sn_old'], s['cmtS'], s['cmtA']), zk.VerifyMintProof(q, m['cmtA_old'], m['sn_old'], m['cmtA'], m['value_s']))\n") % (ROOT, os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ZK_PRFKEY_DIR=str(all_keys), **env), timeout=600)
     assert "DENSE True True" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+def test_gpu_verifier_failure_falls_back_to_the_host_verdict(all_keys):
+    """a fault on the GPU branch of verify_group (here forced by ZK_TEST_FAIL_GPU_VERIFY in a fresh process) must not turn an accept into a reject: single-proof symbols
+    and verifyBatch are then decided by the prepared host verifier, valid proofs stay valid, invalid ones stay invalid, and the failure is logged"""
+    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nfrom blockmaze_amd import engine as e\nimport workload as w\nzk = e.Zk()\n"
+            "s = w.send_instance(61); p = zk.GenSendProof(*w.send_args(s)); a = [s['cmtA_old'], s['sn_old'], s['cmtS'], s['cmtA']]\n"
+            "one = (zk.VerifySendProof(p, *a), zk.VerifySendProof(p, *a[::-1]))\n"
+            "rc, ok = zk.VerifyBatch([('send', p, a, 0), ('send', p, a[::-1], 0), ('send', p, a, 0)])\n"
+            "print('FALLBACK', one, rc, ok)\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ZK_PRFKEY_DIR=str(all_keys), ZK_TEST_FAIL_GPU_VERIFY="1"), timeout=600)
+    assert "FALLBACK (True, False) 2 [True, False, True]" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    assert "GPU verifier failed" in r.stderr and "on the host" in r.stderr
 
 def test_concurrent_cgo_calls_overlap_and_stay_correct(all_keys, monkeypatch):
     """cgo calls arrive on arbitrary OS threads (threading): 8 threads call genSendproof / genMintproof / genRedeemproof at the same time (pool of

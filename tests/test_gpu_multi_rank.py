@@ -25,3 +25,21 @@ def test_eight_ranks_keep_their_host_time():
     h1 = one["prover_timings_ms"]["upload_ms"] + one["prover_timings_ms"]["enqueue_ms"]; h8 = eight["prover_timings_ms"]["upload_ms"] + eight["prover_timings_ms"]["enqueue_ms"]
     print("host ms per proof (upload + enqueue): 1 rank %.3f, 8 ranks sharing the pod %.3f; key load 1 rank %.2f s, rank 0 of 8 %.2f s" % (h1, h8, one["setup_s"]["key_load"], eight["setup_s"]["key_load"]))
     assert eight["n_gpus"] == 8 and eight["extra_legs"] is None and h8 < max(1.0, 3 * h1), (h1, h8)
+
+def test_two_ranks_weak_scaling_end_to_end():
+    """bench.py --gpus 2 as the driver's scaling run starts it (no --shard-msm): two ranks, each proving its own instances against the ONE key rank 0 generated (the path of
+    its private directory travels through broadcast_object_list), max-over-ranks timing; every rank verifies the last proof of its timed region before the line is printed
+    (an unverified proof is an assertion failure on that rank, hence rc != 0 for the run)"""
+    j = run(["--gpus", "2", "--steps", "6", "--warmup", "2"])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["proofs_per_step"] == 2 and j["extra_legs"] is None and j["value"] > 0
+    assert set(j["step_ms"]) >= {"p10", "p50", "p90"} and j["step_ms"]["p10"] <= j["step_ms"]["p50"] <= j["step_ms"]["p90"]
+
+@pytest.mark.parametrize("where", ["keygen:0", "load:0", "load:1"])
+def test_a_failing_rank_takes_the_group_down(where):
+    """rank failure modes of the set-up (key generation on rank 0, key load on either rank): the other rank must not be left at a barrier — the ranks agree on success after
+    every stage (sharding.Group.all_ok), everybody leaves with a non-zero status well inside the timeout, and nothing is printed on stdout"""
+    import time
+    env = dict(os.environ, ZK_BENCH_BACKEND="gloo", ZK_BENCH_TEST_FAIL=where); env.pop("RANK", None); env.pop("WORLD_SIZE", None); t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == "" and time.time() - t0 < 240, (r.returncode, r.stdout[-300:], r.stderr[-1500:])
+    assert "failed at '%s'" % where.split(":")[0] in r.stderr and "a rank failed at" in r.stderr, r.stderr[-1500:]
