@@ -70,6 +70,17 @@ def check_bounds_add():
     assert nX <= bX and nY <= bY and nZ <= bZ, (nX, nY, nZ)
     for c, need in ((cP, U), (cR, S), (cX, PPP + 2 * Qv), (cT, nX), (cY, Bv)): assert KS[c][NL - 1] >= int(need * Q) >> (B * (NL - 1)), (c, need)
 check_bounds_add()
+def check_bounds_add_quad():
+    """the quad-cooperative form of the same addition (htail29.cuh: quad29_add): identical formulas and constants, except that S1 enters its product with PPP as
+    S2 + (2p + S1 - S2), i.e. with a value below S + cR instead of S — the product's result must still fit the constant of the difference that follows (cY), and the
+    operand's limbs (a product's result plus a normalized difference: below 2^29 + 2^29 + 8) must stay below the 2^31 a product tolerates in ONE operand"""
+    bX, bY, bZ = 5.5, 3.6, 1.1
+    U = prod(bX, bZ); S = prod(bY, bZ); cP = cR = 2; bP = U + cP; bR = S + cR; PP = prod(bP, bP); PPP = prod(bP, PP); Qv = prod(U, PP); RR = prod(bR, bR)
+    cX = 4; nX = RR + cX; cT = 6; bT = Qv + cT; A = prod(bR, bT); Bv = prod(S + cR, PPP); cY = 2
+    assert cY >= Bv + 0.01 and A + cY <= bY, (Bv, A)
+    assert KS[cY][NL - 1] >= int(Bv * Q) >> (B * (NL - 1))
+    assert (1 << B) + (1 << B) + 8 < (1 << 31)
+check_bounds_add_quad()
 
 HEADER = ["// GENERATED by gen_field29.py - do not edit.  Fq and Fr on nine 29-bit limbs (R' = 2^261): Fq29 for k_hacc_runs29 (msm.cuh) and the verifier's schedule",
           "// (pairing.cuh), Fr29 for the transforms (ntt.cuh); device compilation only.",

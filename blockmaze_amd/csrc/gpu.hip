@@ -402,10 +402,10 @@ void Domain::qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c) {
 }
 
 // packed: [ones bitmap | other bitmap | block offsets | values] already on the device (layout of Prover::set_witness)
-void expand_witness_dev(const uint8_t *packed, size_t words, const Fe32 &one_value, bool values_to_mont, size_t n, Fe32 *out) {
+void expand_witness_dev(const uint8_t *packed, size_t words, const Fe32 &one_value, bool values_to_mont, size_t n, Fe32 *out, uint8_t *tags, uint32_t *other_vars) {
   const uint64_t *ones = (const uint64_t *)packed, *other = ones + words; const uint32_t *off = (const uint32_t *)(other + words); const Fr *vals = (const Fr *)(packed + ((words * 20 + 31) / 32) * 32);
   Fr one; memcpy(&one, &one_value, 32);
-  hipLaunchKernelGGL(k_expand_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, ones, other, off, vals, one, (int)values_to_mont, (uint32_t)n, (Fr *)out);
+  hipLaunchKernelGGL(k_expand_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, ones, other, off, vals, one, (int)values_to_mont, (uint32_t)n, (Fr *)out, tags, other_vars);
 }
 void fr_to_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_to_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
 void fr_from_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_from_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
@@ -451,10 +451,15 @@ R1csDev::R1csDev(const R1csHost &h) : impl(new Impl(std::make_shared<R1csArrays>
   d.ctab = DevBuf<Fe32>(tab.size()); d.ctab.upload(tab.data(), tab.size()); d.own_words();
 }
 R1csDev::~R1csDev() = default;
-void R1csDev::eval(const Fe32 *z, Fe32 *abc, size_t m) {
+void R1csDev::eval(const Fe32 *z, Fe32 *abc, size_t m, const uint8_t *tags, bool write_c) {
   Stage st("r1cs.rows"); Impl &d = *impl; hipStream_t s = gpu().stream; if (m < d.n_cons + d.n_inputs + 1) throw GpuError("r1cs: domain too small");
   R1csMatrices M; for (int mm = 0; mm < 3; mm++) { M.rowptr[mm] = d.rowptr[mm].get(); M.col[mm] = d.col[mm].get(); M.cid[mm] = d.cid[mm].get(); }
   if (++d.seq == 0) d.seq = 1;
+  if (tags) {   // the assignment came in compact form: a byte per variable says 0 / 1 / other (k_r1cs_rows_tagged)
+    const uint32_t sb = (uint32_t)cdiv(m, 256);
+    hipLaunchKernelGGL(k_r1cs_rows_tagged, dim3(sb + (unsigned)cdiv(d.n_long_any, 4)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z, tags, (uint32_t)d.n_cons, (uint32_t)d.n_inputs, (uint32_t)m,
+                       (const uint32_t *)d.long_any.get(), (uint32_t)d.n_long_any, sb, write_c ? 1 : 0, (Fr *)abc, d.seq, d.d_fail);
+    return; }
   if (d.n_long_any) { const uint32_t sb = (uint32_t)cdiv(m, 256);   // rows of more than 16 terms exist: the one-launch form (short rows and one wave per long row) const uint32_t sb = (uint32_t)cdiv(m, 256);
     hipLaunchKernelGGL(k_r1cs_rows_all, dim3(sb + (unsigned)cdiv(d.n_long_any, 4)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)d.n_cons, (uint32_t)d.n_inputs, (uint32_t)m, (const uint32_t *)d.long_any.get(), (uint32_t)d.n_long_any, sb, (Fr *)abc, d.seq, d.d_fail);
     return; }

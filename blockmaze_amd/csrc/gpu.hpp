@@ -54,6 +54,14 @@ void upload_async(void *dev, const void *pinned_host, size_t bytes);   // on the
 
 // A fixed set of base points resident in HBM (one query of a proving key) plus the reusable MSM workspace for it.
 struct WsortBuffers;                           // the sorted witness digits an MSM leaves for the MSMs over the same scalar vector (msm_impl.hpp)
+// An assignment that arrived in compact form (Prover::set_witness*), as the witness MSMs' sort (msm.cuh: k_wsort_tagged) wants it: device pointers, valid for the run that follows
+struct WitnessTags {
+  const uint8_t *tags = nullptr;        // one byte per variable (variable 0 = ONE): 0 the value is zero, 1 it is one, 2 anything else
+  const uint32_t *other_vars = nullptr; // the variables tagged 2, ascending
+  uint32_t n_other = 0;
+  const uint32_t *var_pos = nullptr;    // indexed queries (B): position of a variable in the query's index list, 0xffffffff if it has no point; null for plain queries
+  uint32_t base = 0;                    // plain query: point i belongs to variable base + i; indexed query: first position of this slice of the index list
+};
 class MsmG1 {
  public:
   MsmG1(const G1AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false);   // tables: precompute 2^(cw) P if the size cap allows; uniform: one-pass sort with overflow fallback (msm_impl.hpp)
@@ -62,6 +70,8 @@ class MsmG1 {
   // scalars_dev: Fr (Montgomery) on the device.  scalar_index_dev: optional gather map (point i uses scalars[index[i]]).
   // Enqueues the kernels; result() synchronises and finishes the combine on the host.
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
+  // the same with the whole assignment z_all (variable 0 = ONE) and its tags: the three-launch witness path then sorts from the tags (other paths read the scalars as run() does)
+  void run_tagged(const Fe32 *z_all_dev, const WitnessTags &wt, const uint32_t *scalar_index_dev);
   // scalars a_i * b_i * z (z: one element, or a table of n) formed inside the sort kernel; only when one_pass_sort() (uniform-scalar MSM with fixed-base tables)
   bool one_pass_sort() const; void run_product(const Fe32 *a_dev, const Fe32 *b_dev, const Fe32 *z_dev, bool z_is_table);
   host::HG1 result();
@@ -77,6 +87,7 @@ class MsmG2 {
   MsmG2(const MsmG2 &peer, bool filter_ones, bool uniform_scalars);
   ~MsmG2();
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
+  void run_tagged(const Fe32 *z_all_dev, const WitnessTags &wt, const uint32_t *scalar_index_dev);
   std::shared_ptr<WsortBuffers> sort_handle() const; bool share_sort_with(const std::shared_ptr<WsortBuffers> &leader);
   host::HG2 result(); void set_label(const char *l); void set_stream(int aux); void split_ones_path();
   struct Impl; std::unique_ptr<Impl> impl;
@@ -124,14 +135,14 @@ class R1csDev {
  public:
   explicit R1csDev(const R1csHost &h); explicit R1csDev(const R1csDev &peer); ~R1csDev();   // the copy shares the CSR arrays and owns its failure word
   // z_dev: n_vars+1 Fr (Montgomery, z[0] = 1).  abc: 3 vectors of m (zero padded, aA[n_cons + i] = z_i for i <= n_inputs; r1cs_to_qap.tcc:227-230)
-  void eval(const Fe32 *z_dev, Fe32 *abc, size_t m);
+  void eval(const Fe32 *z_dev, Fe32 *abc, size_t m, const uint8_t *tags_dev = nullptr, bool write_c = true);   // tags: one byte per variable (0 / 1 / 2 = other) when the assignment came in compact form; write_c = false: the C vector is not stored (it is folded into the L query)
   bool satisfied(const Fe32 *abc, size_t m);    // synchronises
   bool check_result() const;                    // eval() also tests a*b == c row by row; true if the last eval() found every constraint satisfied (read after the main stream has been synchronised)
   struct Impl; std::unique_ptr<Impl> impl;
 };
 
 void fr_to_mont_dev(Fe32 *a, size_t n); void fr_from_mont_dev(Fe32 *a, size_t n);
-void expand_witness_dev(const uint8_t *packed_dev, size_t words, const Fe32 &one_value, bool values_to_mont, size_t n, Fe32 *out);   // compact assignment upload (ntt.cuh: k_expand_witness)
+void expand_witness_dev(const uint8_t *packed_dev, size_t words, const Fe32 &one_value, bool values_to_mont, size_t n, Fe32 *out, uint8_t *tags_out = nullptr, uint32_t *other_vars_out = nullptr);   // tags_out / other_vars_out: see WitnessTags   // compact assignment upload (ntt.cuh: k_expand_witness)
 
 // Key loading: y-coordinates of compressed points (x Montgomery; flags bit0 = parity of canonical y, bit1 = point at infinity).  Throws if an x is not on the curve.
 void decompress_g1(const Fe32 *xs, const uint8_t *flags, size_t n, G1AffineRaw *out);

@@ -8,6 +8,7 @@ MsmG1::~MsmG1() = default;
 std::shared_ptr<WsortBuffers> MsmG1::sort_handle() const { return impl->wfused && impl->ws_leader ? impl->ws : nullptr; }
 bool MsmG1::share_sort_with(const std::shared_ptr<WsortBuffers> &leader) { if (!impl->wfused || !leader || leader->NB != impl->NB || leader->n != impl->n) return false; impl->share_sort(leader); return true; }
 void MsmG1::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
+void MsmG1::run_tagged(const Fe32 *z_all, const WitnessTags &wt, const uint32_t *idx) { impl->run_tagged(z_all, wt, idx); }
 bool MsmG1::one_pass_sort() const { return impl->hsort; }
 void MsmG1::run_product(const Fe32 *a, const Fe32 *b, const Fe32 *z, bool z_is_table) { impl->run_product(a, b, z, z_is_table); }
 void MsmG1::set_label(const char *l) { impl->label = l; }

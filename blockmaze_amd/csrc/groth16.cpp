@@ -300,7 +300,7 @@ struct Prover::Impl {
   int lane = 0;                                                // this prover's stream set: provers on different lanes overlap on the device
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
-  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; std::shared_ptr<DevBuf<uint32_t>> B_idx; DevBuf<Fe32> z, abc; DevBuf<uint8_t> packed; PinnedBuf<Fe32> z_host;
+  std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; std::shared_ptr<DevBuf<uint32_t>> B_idx; DevBuf<Fe32> z, abc; DevBuf<uint8_t> packed, tags; DevBuf<uint32_t> other_vars; std::shared_ptr<DevBuf<uint32_t>> B_pos /* inverse of the B query's index list */; uint32_t n_other = 0; bool tags_valid = false /* the assignment on the device came in compact form: tags holds 0 / 1 / 2 per variable */; PinnedBuf<Fe32> z_host;
   std::unique_ptr<SubmitWorker> workers[4];
   // The submit thread of a witness MSM also waits for its stream and finishes the MSM on the host (Horner combine, or the host tail of msm_impl.hpp): four threads do that
   // side by side while the H chain is still running.  pending[j]: job j (order B2, L, A, B1) was posted and its result slot is not valid before workers[j]->wait().
@@ -319,7 +319,7 @@ static void finish_setup(Prover::Impl &p) {
   { p.pair_AL = p.c_fold && p.a0 == p.l0 && p.L->share_sort_with(p.A->sort_handle()); p.b2_first = true; p.pair_B = p.B1->share_sort_with(p.B2->sort_handle()); }   // MSMs over the same scalars share one sort: L* follows A, B1 follows B2 (the long G2 accumulation first)
   if (!one_stream) { p.A->set_stream(0); p.L->set_stream(p.pair_AL ? 0 : 1); p.B1->set_stream(2); p.B2->set_stream(p.pair_B ? 2 : 3); if (!p.pair_B) p.B2->split_ones_path(); }   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
   p.A->set_label("msm_A"); p.L->set_label("msm_L"); p.B1->set_label("msm_B1"); p.B2->set_label("msm_B2"); p.H->set_label("msm_H");
-  p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host = PinnedBuf<Fe32>(p.nv + 1 + 8); p.packed = DevBuf<uint8_t>(32 * (p.nv + 1 + 8));
+  p.z = DevBuf<Fe32>(p.nv + 1); p.abc = DevBuf<Fe32>(3 * p.m); p.z_host = PinnedBuf<Fe32>(p.nv + 1 + 8); p.packed = DevBuf<uint8_t>(32 * (p.nv + 1 + 8)); p.tags = DevBuf<uint8_t>(p.nv + 1 + 64); p.other_vars = DevBuf<uint32_t>((p.nv + 1) / 4 + 64);
 }
 Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world, int device_slot) : impl(new Impl) {
   Impl &p = *impl; p.lane = gpu_lane_acquire(device_slot); LaneScope lane_scope(p.lane); p.nv = pk.cs.n_vars; p.ni = pk.cs.n_inputs; if (shard_world == 0 || shard_rank >= shard_world) throw std::runtime_error("prover: bad shard"); p.cs.reset(new R1csDev(pk.cs)); p.dom.reset(new Domain(pk.cs.n_cons + p.ni + 1)); p.m = p.dom->m();
@@ -341,12 +341,14 @@ Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world, 
   p.B1.reset(new MsmG1(pk.B_g1.data() + p.b0, nB, cw, true)); p.B2.reset(new MsmG2(pk.B_g2.data() + p.b0, nB, cw, true)); p.H.reset(new MsmG1(Hq->data() + p.h0, nH, ch, false, env_int("ZK_MSM_H_TABLES", 1) != 0, true));   // (with tables the H accumulation gathers from a table 16x larger, but the weighted bucket sum shrinks by the number of windows)
   finish_setup(p);
   p.B_idx = std::make_shared<DevBuf<uint32_t>>(pk.B_idx.size() + 1); if (!pk.B_idx.empty()) p.B_idx->upload(pk.B_idx.data(), pk.B_idx.size());
+  { std::vector<uint32_t> pos(p.nv + 1, 0xffffffffu); for (size_t j = 0; j < pk.B_idx.size(); j++) pos[pk.B_idx[j]] = (uint32_t)j;   // variable -> its position in the B query (k_wsort_tagged)
+    p.B_pos = std::make_shared<DevBuf<uint32_t>>(pos.size()); p.B_pos->upload(pos.data(), pos.size()); }
 }
 Prover::Prover(const Prover &peer) : impl(new Impl) {
   Impl &p = *impl; const Impl &o = *peer.impl; p.lane = gpu_lane_acquire(gpu_slot_of_lane(o.lane)); LaneScope lane_scope(p.lane);   // same device as the peer: the shared tables live there
   p.h_lagrange = o.h_lagrange; p.c_fold = o.c_fold; p.nv = o.nv; p.ni = o.ni; p.m = o.m; p.a0 = o.a0; p.l0 = o.l0; p.b0 = o.b0; p.h0 = o.h0;
   p.alpha_g1 = o.alpha_g1; p.beta_g1 = o.beta_g1; p.delta_g1 = o.delta_g1; p.beta_g2 = o.beta_g2; p.delta_g2 = o.delta_g2;
-  p.cs.reset(new R1csDev(*o.cs)); p.dom.reset(new Domain(*o.dom)); p.B_idx = o.B_idx;
+  p.cs.reset(new R1csDev(*o.cs)); p.dom.reset(new Domain(*o.dom)); p.B_idx = o.B_idx; p.B_pos = o.B_pos;
   p.A.reset(new MsmG1(*o.A, true, false)); p.L.reset(new MsmG1(*o.L, true, false)); p.B1.reset(new MsmG1(*o.B1, true, false)); p.B2.reset(new MsmG2(*o.B2, true, false)); p.H.reset(new MsmG1(*o.H, false, true));
   finish_setup(p);
 }
@@ -383,8 +385,8 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   bool compact = !force_dense; for (size_t t = 0; t < T; t++) compact = compact && fits[t];
   if (compact) {   // the threads' value areas are closed up (a few hundred KB) so that ONE copy carries bitmaps, offsets and values; the few values that are not 0 or 1 are brought into Montgomery form by the expanding kernel itself
     size_t total = used[0]; for (size_t t = 1; t < T; t++) { if (used[t]) { const uint32_t delta = (uint32_t)(t * cap_t - total); memmove(&vals[total], &vals[t * cap_t], 32 * used[t]); for (size_t w = words * t / T; w < words * (t + 1) / T; w++) off[w] -= delta; } total += used[t]; }
-    Fe32 one_mont; memcpy(&one_mont, FrParams::R1, 32); upload_async(p.packed.get(), pk, vals_at + 32 * total); expand_witness_dev(p.packed.get(), words, one_mont, !montgomery, n, p.z.get()); }   // (letting the kernel read the pinned staging area itself, no copy, was measured: no faster)
-  else { Fe32 *h = p.z_host.get(); h[0] = one; memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * n); if (!montgomery) fr_to_mont_dev(p.z.get(), n); }      // dense assignment: plain copy
+    Fe32 one_mont; memcpy(&one_mont, FrParams::R1, 32); upload_async(p.packed.get(), pk, vals_at + 32 * total); expand_witness_dev(p.packed.get(), words, one_mont, !montgomery, n, p.z.get(), p.tags.get(), p.other_vars.get()); p.tags_valid = true; p.n_other = (uint32_t)total; }   // (letting the kernel read the pinned staging area itself, no copy, was measured: no faster)
+  else { Fe32 *h = p.z_host.get(); h[0] = one; memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * n); if (!montgomery) fr_to_mont_dev(p.z.get(), n); p.tags_valid = false; }      // dense assignment: plain copy
   last.upload_ms = now_ms() - t0;
 }
 void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
@@ -399,8 +401,8 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
     for (uint64_t m = mx; m; m &= m - 1) vals[n_other++] = wide[lo + (size_t)__builtin_ctzll(m)];
     ones[w] = mo; other[w] = mx; }
   static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;
-  if (fits && !force_dense) { upload_async(p.packed.get(), pk, vals_at + 32 * n_other); expand_witness_dev(p.packed.get(), words, one, false, n, p.z.get()); }
-  else { Fe32 *h = p.z_host.get(); Fe32 zero; memset(&zero, 0, 32); for (size_t i = 0; i < n; i++) h[i] = tag[i] == 2 ? wide[i] : tag[i] ? one : zero; upload_async(p.z.get(), h, 32 * n); }   // a dense assignment (never a BlockMaze one)
+  if (fits && !force_dense) { upload_async(p.packed.get(), pk, vals_at + 32 * n_other); expand_witness_dev(p.packed.get(), words, one, false, n, p.z.get(), p.tags.get(), p.other_vars.get()); p.tags_valid = true; p.n_other = (uint32_t)n_other; }
+  else { Fe32 *h = p.z_host.get(); Fe32 zero; memset(&zero, 0, 32); for (size_t i = 0; i < n; i++) h[i] = tag[i] == 2 ? wide[i] : tag[i] ? one : zero; upload_async(p.z.get(), h, 32 * n); p.tags_valid = false; }   // a dense assignment (never a BlockMaze one)
   last.upload_ms = now_ms() - t0;
 }
 struct RsTerms { HFr r, s; HG1 r_delta, s_delta, rs_delta_neg; HG2 s_delta2; };
@@ -424,8 +426,12 @@ static void enqueue_all(Prover::Impl &p) {
   constexpr bool skip_w = false, skip_h = false, skip_n = false;
 #endif
   Prover::Impl *pp = &p;
-  auto runB2 = [pp] { pp->B2->run(pp->z.get(), pp->B_idx->get() + pp->b0); }; auto runL = [pp] { pp->L->run(pp->z.get() + (pp->c_fold ? 0 : pp->ni + 1) + pp->l0, nullptr); };       // r1cs_gg_ppzksnark.tcc:442-462,477-484
-  auto runA = [pp] { pp->A->run(pp->z.get() + pp->a0, nullptr); }; auto runB1 = [pp] { pp->B1->run(pp->z.get(), pp->B_idx->get() + pp->b0); };
+  // (an assignment that arrived in compact form: the witness MSMs sort from its tags — WitnessTags, k_wsort_tagged; ZK_WSORT_TAGGED=0 keeps the scalar-reading sort)
+  static const bool sort_tags = env_int("ZK_WSORT_TAGGED", 1) != 0; const bool tg = sort_tags && p.tags_valid;
+  auto wt = [pp, tg](const uint32_t *var_pos, size_t base) { WitnessTags t; if (tg) { t.tags = pp->tags.get(); t.other_vars = pp->other_vars.get(); t.n_other = pp->n_other; } t.var_pos = var_pos; t.base = (uint32_t)base; return t; };
+  const WitnessTags wtB = wt(p.B_pos->get(), p.b0), wtL = wt(nullptr, (p.c_fold ? 0 : p.ni + 1) + p.l0), wtA = wt(nullptr, p.a0);
+  auto runB2 = [pp, wtB] { pp->B2->run_tagged(pp->z.get(), wtB, pp->B_idx->get() + pp->b0); }; auto runL = [pp, wtL] { pp->L->run_tagged(pp->z.get(), wtL, nullptr); };       // r1cs_gg_ppzksnark.tcc:442-462,477-484
+  auto runA = [pp, wtA] { pp->A->run_tagged(pp->z.get(), wtA, nullptr); }; auto runB1 = [pp, wtB] { pp->B1->run_tagged(pp->z.get(), wtB, pp->B_idx->get() + pp->b0); };
   // job order: B2, L, A, B1 (longest first).  A follower of a shared sort is queued behind its leader by the leader's job: its own slot stays empty.
   std::function<void()> jobs[4] = { runB2, runL, [pp, runA, runL] { runA(); if (pp->pair_AL) runL(); }, [pp, runB1, runB2] { if (pp->pair_B && pp->b2_first) { runB2(); runB1(); } else { runB1(); if (pp->pair_B) runB2(); } } };   // the G2 MSM first: its long accumulation then overlaps the transforms, not the H accumulation
   std::function<void()> finish[4] = { [pp] { pp->rB2 = pp->B2->result(); }, [pp] { pp->rL = pp->L->result(); }, [pp] { pp->rA = pp->A->result(); if (pp->pair_AL) pp->rL = pp->L->result(); }, [pp] { pp->rB1 = pp->B1->result(); if (pp->pair_B) pp->rB2 = pp->B2->result(); } };
@@ -439,7 +445,8 @@ static void enqueue_all(Prover::Impl &p) {
     for (int j = 0; j < 4; j++) if (start[j] == point && !skip_w && job_used[j]) { const int sj = job_stream[j]; std::function<void()> job = jobs[j], fin = finish[j];
       if (use_threads) { if (!p.workers[j]) p.workers[j].reset(new SubmitWorker(p.lane)); p.workers[j]->post([sj, job, fin] { gpu_fork_wait(sj); job(); fin(); }); p.pending[j] = true; } else { gpu_fork_wait(sj); job(); p.inline_result[j] = true; if (j == 2 && p.pair_AL) p.inline_result[1] = true; if (j == 3 && p.pair_B) p.inline_result[0] = true; } } };
   release(0, 0);
-  p.cs->eval(p.z.get(), p.abc.get(), p.m); release(0, 1); release(1, 0);
+  static const bool use_tags = env_int("ZK_ROWS_TAGGED", 1) != 0;
+  p.cs->eval(p.z.get(), p.abc.get(), p.m, use_tags && p.tags_valid ? p.tags.get() : nullptr, !p.c_fold); release(0, 1); release(1, 0);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
   const int nvec = p.c_fold ? 2 : 3;                          // A, B (and C unless it is folded into the L query)
   if (!skip_n) p.dom->ifft_then_coset_fft(p.abc.get(), nvec, p.m); release(1, 1); release(2);   // iFFT, then cosetFFT (a step domain runs the passes between the two as one kernel)

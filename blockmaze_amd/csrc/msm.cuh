@@ -24,6 +24,8 @@
 #include "curve.cuh"
 
 #include "field29.cuh"
+namespace zk { struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; }; }
+#include "htail29.cuh"
 namespace zk {
 
 constexpr int MSM_MAX_WINDOWS = 64;
@@ -63,7 +65,7 @@ template <int C, class Fn> __device__ __forceinline__ void msm_walk_digits(const
 }
 constexpr uint32_t MSM_ENTRY_SIGN = 0x80000000u;   // entry = table index | sign
 
-struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; };
+// (struct MsmCounters { n_ones, n_other, pad[2] }: declared at the top — htail29.cuh needs it)
 
 // scalars: Fr in Montgomery form.  scalar_index (optional): scalar for point i is scalars[scalar_index[i]] (sparse
 // B-query, kc_multiexp.tcc:52-56); otherwise scalars[i].  point_is_inf (optional): byte flags of key points at infinity.
@@ -387,7 +389,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 // sum to the lazy 8 x 32-bit form (one product per coordinate with 2^256 mod p) that the weighted bucket sum reads.  ZZ = 0 (mod p) in a sum — two pieces were +-each
 // other somewhere, or an operand of the accumulation was +-its accumulator — raises the flag that sends the MSM to the general path.
 static __global__ void __launch_bounds__(256) k_hacc_combine29(const Piece29 *__restrict__ partials, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts, HsortShape sh, uint32_t run, uint32_t maxp, uint32_t n_buckets, uint32_t ll,
-                                                        XYZZ<Fq> *__restrict__ buckets, MsmCounters *cnt) {
+                                                        XYZZ<Fq> *__restrict__ buckets, Point29Rec *__restrict__ buckets29, MsmCounters *cnt) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = t >> ll, sub = t & ((1u << ll) - 1), step = 1u << ll; const bool live = b < n_buckets; uint32_t np = 0;
   if (live) { const uint32_t c = counts[b], off = offsets[b] - (b >> sh.low_bits) * sh.region; if (c) np = min((off + c - 1) / run - off / run + 1, maxp); }
   const Piece29 *src = partials + (size_t)(live ? b : 0) * maxp; XYZZ29 acc; bool inf = true;
@@ -401,6 +403,23 @@ static __global__ void __launch_bounds__(256) k_hacc_combine29(const Piece29 *__
 #pragma unroll
     for (int i = 0; i < 9; i++) { o.X.l[i] = __shfl_down(acc.X.l[i], d, 64); o.Y.l[i] = __shfl_down(acc.Y.l[i], d, 64); o.ZZ.l[i] = __shfl_down(acc.ZZ.l[i], d, 64); o.ZZZ.l[i] = __shfl_down(acc.ZZZ.l[i], d, 64); }
     if (sub + d < step && !oinf) { if (inf) { acc = o; inf = false; } else acc = xyzz29_add(acc, o); } }
+  if (live && sub == 0 && buckets29) {   // the weighted sum stays on 29-bit limbs (htail29.cuh): the sum as it is, four coordinate slots of twelve words; all-zero limbs = the point at infinity
+    uint32_t zero_or = 0, p_xor = 0;                                                     // ZZ is a product's result — exact limbs, below 2p: ZZ = 0 (mod p) means 0 or p
+#pragma unroll
+    for (int i = 0; i < 9; i++) { zero_or |= acc.ZZ.l[i]; p_xor |= acc.ZZ.l[i] ^ Fq29::P29[i]; }
+    if (!inf && (zero_or == 0 || p_xor == 0)) atomicOr(&cnt->pad[0], 1u);
+    const uint32_t z = inf ? 0u : ~0u;
+    uint4 *dst = reinterpret_cast<uint4 *>(buckets29 + b);
+    const Fq29 *coord[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
+#pragma unroll
+    for (int c4 = 0; c4 < 4; c4++) {
+      const Fq29 &v = *coord[c4];
+      dst[3 * c4] = make_uint4(v.l[0] & z, v.l[1] & z, v.l[2] & z, v.l[3] & z);
+      dst[3 * c4 + 1] = make_uint4(v.l[4] & z, v.l[5] & z, v.l[6] & z, v.l[7] & z);
+      dst[3 * c4 + 2] = make_uint4(v.l[8] & z, 0u, 0u, 0u);
+    }
+    return;
+  }
   if (live && sub == 0) { XYZZ<Fq> o = XYZZ<Fq>::inf();
     if (!inf) { acc.X.to_words(o.X.l); acc.Y.to_words(o.Y.l); acc.ZZ.to_words(o.ZZ.l); acc.ZZZ.to_words(o.ZZZ.l); if (o.ZZ.is_zero_lazy()) atomicOr(&cnt->pad[0], 1u);
       o = XYZZ<Fq>{o.X.normalize(), o.Y.normalize(), o.ZZ.normalize(), o.ZZZ.normalize()}; }
@@ -531,8 +550,12 @@ __global__ void __launch_bounds__(256) k_wsort(const Fr *__restrict__ scalars, c
   // the ones, four consecutive points at a time: lanes 4g .. 4g + 3 form the nibble v of their flags, and the quad's first lane appends ONE entry g * 15 + v - 1 — the index
   // of the precomputed sum of that subset in the groups table (k_ones_groups) — instead of up to four point indices: 15/16 of an addition per group against 2 on average
   { const uint64_t m = __ballot(is_one); const uint32_t v = (uint32_t)(m >> (lane & ~3u)) & 15u; const bool lead = (lane & 3u) == 0 && v != 0; const uint64_t ml = __ballot(lead);
-    if (ml) { uint32_t base = 0; const int first = __ffsll((long long)ml) - 1; if ((int)lane == first) base = atomicAdd(&cnt->n_ones, (uint32_t)__popcll(ml));
-      base = __shfl(base, first, 64); if (lead) ones[base + __popcll(ml & ((1ull << lane) - 1))] = (i >> 2) * 15u + v - 1u; } }
+    __shared__ uint32_t wave_n[4], wg_at; const uint32_t wave = threadIdx.x >> 6;     // one atomic per workgroup on the list's counter (see k_wsort_tagged)
+    if (lane == 0) wave_n[wave] = (uint32_t)__popcll(ml);
+    __syncthreads();
+    if (threadIdx.x == 0) { const uint32_t tot = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3]; wg_at = tot ? atomicAdd(&cnt->n_ones, tot) : 0u; }
+    __syncthreads();
+    if (lead) { uint32_t base = wg_at; for (uint32_t wv = 0; wv < wave; wv++) base += wave_n[wv]; ones[base + __popcll(ml & ((1ull << lane) - 1))] = (i >> 2) * 15u + v - 1u; } }
   const bool other = live && !is_one;
   if (other) msm_walk_digits<C>(k.l, c, W, [&](int, int d) { if (d) atomicAdd(&lcnt[(uint32_t)(d < 0 ? -d : d) - 1], 1u); });
   __syncthreads();
@@ -540,6 +563,77 @@ __global__ void __launch_bounds__(256) k_wsort(const Fr *__restrict__ scalars, c
   __syncthreads();
   if (other) msm_walk_digits<C>(k.l, c, W, [&](int w, int d) { if (!d) return; const uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, pos = lbase[key] + atomicAdd(&lcnt[key], 1u);
     if (pos < cap) entries[(size_t)key * cap + pos] = (i + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u); });
+}
+// The same sort for an assignment that arrived in compact form (Prover::set_witness: 97 % of a BlockMaze assignment are the bits 0 and 1, so the device holds a byte per
+// variable — 0 / 1 / 2 = anything else — and the list of the variables tagged 2, both written by k_expand_witness).  k_wsort reads the 32-byte scalar of EVERY point and
+// takes it out of Montgomery form (a field product per lane, 227 K + 136 K of them per proof) only to find a bit in 97 % of the cases; here
+//   workgroups [0, ones_blocks)   one lane per point: ONE byte decides "is one" (the nibble / subset-sum entry of k_wsort, unchanged); zeros and others do nothing;
+//   the workgroups after them     one lane per listed variable (a few thousand): its position in this query (identity minus `base`, or the B query's inverse index),
+//                                 the scalar's digits, the same LDS counting and region reservation as k_wsort.
+// WitnessTags travels by value; tags / z are the full vectors (variable 0 = ONE).  A plain query (A, L): point i belongs to variable base + i.  An indexed query (B):
+// point i belongs to variable scalar_index[i], var_pos is the inverse of the query's whole index list (0xffffffff: no point for that variable) and `base` the first
+// position of this slice (a shard) in it.
+// (struct WitnessTags { tags, other_vars, n_other, var_pos, base }: gpu.hpp — the prover fills it)
+template <int C>
+__global__ void __launch_bounds__(256) k_wsort_tagged(const Fr *__restrict__ z, WitnessTags wt, const uint32_t *__restrict__ scalar_index, const uint8_t *__restrict__ point_is_inf, uint32_t n, int c, int W, uint32_t point_stride,
+                                                      uint32_t NB, uint32_t cap, uint32_t ones_blocks, uint32_t *__restrict__ fill, uint32_t *__restrict__ fill_next, uint32_t *__restrict__ entries, uint32_t *__restrict__ ones,
+                                                      MsmCounters *cnt, MsmCounters *cnt_next) {
+  __shared__ uint32_t lcnt[WFUSED_MAX_BUCKETS], lbase[WFUSED_MAX_BUCKETS];
+  if (blockIdx.x == 0) {                                                                 // the two counter sets alternate: this run clears the next run's
+    if (threadIdx.x == 0) *cnt_next = MsmCounters{0, 0, {0, 0}};
+    if (threadIdx.x < NB) fill_next[threadIdx.x] = 0;
+  }
+  const uint32_t lane = threadIdx.x & 63;
+  if (blockIdx.x < ones_blocks) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_one = false;
+    if (i < n && !(point_is_inf && point_is_inf[i])) is_one = wt.tags[scalar_index ? scalar_index[i] : wt.base + i] == 1;
+    const uint64_t m = __ballot(is_one);                                                 // lanes 4g .. 4g + 3 form the nibble of their flags: ONE entry g * 15 + v - 1 per group (k_ones_groups)
+    const uint32_t v = (uint32_t)(m >> (lane & ~3u)) & 15u;
+    const bool lead = (lane & 3u) == 0 && v != 0;
+    const uint64_t ml = __ballot(lead);
+    // ONE atomic per workgroup on the list's counter (3,500 waves adding to one address, one after the other, were what this kernel spent its 40 us on): the waves'
+    // counts meet in LDS, the first lane reserves the workgroup's run
+    __shared__ uint32_t wave_n[4], wg_at;
+    const uint32_t wave = threadIdx.x >> 6;
+    if (lane == 0) wave_n[wave] = (uint32_t)__popcll(ml);
+    __syncthreads();
+    if (threadIdx.x == 0) { const uint32_t tot = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3]; wg_at = tot ? atomicAdd(&cnt->n_ones, tot) : 0u; }
+    __syncthreads();
+    if (lead) {
+      uint32_t at = wg_at;
+      for (uint32_t wv = 0; wv < wave; wv++) at += wave_n[wv];
+      ones[at + __popcll(ml & ((1ull << lane) - 1))] = (i >> 2) * 15u + v - 1u;
+    }
+    return;
+  }
+  if (threadIdx.x < NB) lcnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t j = (blockIdx.x - ones_blocks) * blockDim.x + threadIdx.x;
+  bool live = j < wt.n_other;
+  uint32_t pos = 0;
+  Fr k = Fr::zero();
+  if (live) {
+    const uint32_t var = wt.other_vars[j];
+    pos = (wt.var_pos ? wt.var_pos[var] : var) - wt.base;                                 // (a variable outside this slice wraps to a huge value)
+    live = (wt.var_pos ? wt.var_pos[var] != 0xffffffffu : true) && pos < n && !(point_is_inf && point_is_inf[pos]);
+    if (live) { k = z[var].from_mont(); live = !k.is_zero(); }
+  }
+  if (live) msm_walk_digits<C>(k.l, c, W, [&](int, int d) { if (d) atomicAdd(&lcnt[(uint32_t)(d < 0 ? -d : d) - 1], 1u); });
+  __syncthreads();
+  if (threadIdx.x < NB) {
+    const uint32_t mcount = lcnt[threadIdx.x];
+    const uint32_t b = mcount ? atomicAdd(&fill[threadIdx.x], mcount) : 0;
+    if (b + mcount > cap) atomicOr(&cnt->pad[0], 1u);
+    lbase[threadIdx.x] = b;
+    lcnt[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  if (live) msm_walk_digits<C>(k.l, c, W, [&](int w, int d) {
+    if (!d) return;
+    const uint32_t key = (uint32_t)(d < 0 ? -d : d) - 1, slot = lbase[key] + atomicAdd(&lcnt[key], 1u);
+    if (slot < cap) entries[(size_t)key * cap + slot] = (pos + (uint32_t)w * point_stride) | (d < 0 ? MSM_ENTRY_SIGN : 0u);
+  });
 }
 // k_wacc_lanes + k_wacc_fold replace the first version of k_wacc (one workgroup of 64 quads per bucket, measured: 188 us, every SIMD of the chip busy with quad
 // arithmetic and with tree levels in which most quads idle — 0.5 ms of the machine per proof for 5 % of its field products).  Accumulation is lane-serial (10 products per
@@ -598,25 +692,33 @@ __global__ void __launch_bounds__(256) k_wacc_quads(const Affine<F> *__restrict_
     acc = block_quad_tree(acc, lds); }
   if (threadIdx.x == 0) out[b] = acc;
 }
-// sum_b (b + 1) * bucket_b as sum_s 2^s S_s, S_s = the sum of the buckets whose weight has bit s: for s < 7 those are the 64 weights "i with a one inserted at bit s"
-// (i = 0..63), eight per quad of group s and none skipped; S_7 is bucket 127 alone.  The eight S_s go to the host as they are (res[0..7]; res[8] = the sum of the ones):
-// its Horner rule for window sums finishes with one-bit windows on the MSM's submit thread (7 doublings, 8 additions) — on the device that was 10 more dependent quad
-// operations, 150 us of the G2 chain.
+// sum_b (b + 1) * bucket_b as sum_s 2^s S_s, S_s = the sum of the buckets whose weight has bit s: for s < top = log2 NB those are the NB / 2 weights "i with a one inserted
+// at bit s"; S_top is bucket NB - 1 alone.  The S_s go to the host as they are (res[0..7]; res[8] = the sum of the ones): its Horner rule for window sums finishes with
+// one-bit windows on the MSM's submit thread (7 doublings, 8 additions) — on the device that was 10 more dependent quad operations, 150 us of the G2 chain.
+// Round 4: ONE WORKGROUP PER WEIGHT BIT (workgroups 0 .. top - 1: a quad per bucket and the workgroup's tree, six dependent additions; round 3 had all eight sums in one
+// workgroup, eight buckets per quad and a three-level tree: eleven), workgroup `top` hands on bucket NB - 1 and clears the unused slots, workgroup top + 1 adds the ones'
+// partial sums and carries the counters along.
 constexpr int WTAIL_SLOTS = 8;
 template <class F>
 __global__ void __launch_bounds__(256) k_wtail(const XYZZ<F> *__restrict__ buckets, uint32_t NB, const XYZZ<F> *__restrict__ ones_partial, uint32_t n_ones_partial, XYZZ<F> *__restrict__ res, uint4 *copy_src, uint4 *copy_dst) {
-  __shared__ XYZZ<F> lds[4]; const uint32_t q = threadIdx.x >> 2; const int k = threadIdx.x & 3;
-  if (blockIdx.x == 1) { XYZZ<F> acc = block_quad_sum(ones_partial, n_ones_partial, lds); if (threadIdx.x == 0) { res[WTAIL_SLOTS] = acc; if (copy_src) *copy_dst = *copy_src; } return; }
-  const uint32_t s_ = q >> 3, j = q & 7, half = NB >> 1, per = half >> 3; XYZZ<F> acc = XYZZ<F>::inf();                  // NB is a power of two, 16 <= NB <= 128; top = log2 NB
-  const uint32_t top = 31 - __clz(NB);
-  auto weight = [&](uint32_t i) { return ((i >> s_) << (s_ + 1)) | (1u << s_) | (i & ((1u << s_) - 1)); };
-  if (s_ < top) { XYZZ<F> nxt = buckets[weight(j * per) - 1];
-#pragma unroll 1
-    for (uint32_t i = j * per; i < (j + 1) * per; i++) { XYZZ<F> cur = nxt; if (i + 1 < (j + 1) * per) nxt = buckets[weight(i + 1) - 1]; acc = quad_add(acc, cur, k); } }
-  else if (s_ == top && j == 0) acc = buckets[NB - 1];
-#pragma unroll 1
-  for (int d = 4; d >= 1; d >>= 1) { XYZZ<F> o = shfl_down_struct(acc, 4 * d); if ((int)j + d < 8) acc = quad_add(acc, o, k); }
-  if (j == 0 && k == 0) res[s_] = acc;                                                                                      // (groups above `top` hold the point at infinity)
+  __shared__ XYZZ<F> lds[4];
+  const uint32_t q = threadIdx.x >> 2, s_ = blockIdx.x, top = 31 - __clz(NB), half = NB >> 1;       // NB is a power of two, 16 <= NB <= 128
+  const int k = threadIdx.x & 3;
+  if (s_ == top + 1) {
+    XYZZ<F> acc = block_quad_sum(ones_partial, n_ones_partial, lds);
+    if (threadIdx.x == 0) { res[WTAIL_SLOTS] = acc; if (copy_src) *copy_dst = *copy_src; }
+    return;
+  }
+  if (s_ == top) {
+    if (threadIdx.x == 0) res[top] = buckets[NB - 1];
+    if (threadIdx.x > top && threadIdx.x < (uint32_t)WTAIL_SLOTS) res[threadIdx.x] = XYZZ<F>::inf();   // slots above `top` hold the point at infinity
+    return;
+  }
+  auto bucket_of = [&](uint32_t i) { return (((i >> s_) << (s_ + 1)) | (1u << s_) | (i & ((1u << s_) - 1))) - 1; };
+  XYZZ<F> acc = XYZZ<F>::inf();
+  if (q < half) acc = buckets[bucket_of(q)];                                                    // half <= 64: at most one bucket per quad
+  acc = block_quad_tree(acc, lds, min(half, 64u));
+  if (threadIdx.x == 0) res[s_] = acc;
 }
 
 // ---- weighted bucket sum of the H query by weight bits ----------------------------------------------------------------------------------------------------------

@@ -28,9 +28,11 @@ struct MsmImpl {
   // witness MSMs in three launches (k_wsort / k_wacc / k_wtail); needs the fixed-base tables and at most 128 buckets
   bool wfused = false, wacc_quads = false, ws_leader = true, overflow_noted = false; std::shared_ptr<WsortBuffers> ws;
   const Fe32 *last_scalars = nullptr; const uint32_t *last_index = nullptr;
+  WitnessTags wtags; const Fe32 *z_all = nullptr; bool tagged = false;   // this run's assignment came in compact form (run_tagged): the witness sort reads tags instead of scalars
   DevBuf<uint32_t> zeroed;                                          // [hist | fill | counters]: cleared once; every run leaves them cleared
   DevBuf<uint32_t> offsets, entries, ones, ntasks, task_off, order, rank_of, block_hist, block_off, cls_start; uint32_t bsort_blocks; std::unique_ptr<Scanner> bsort_scanner; Scanner scanner, task_scanner; uint32_t max_tasks;
   DevBuf<uint32_t> lane_off;   // fused witness path: where each bucket's lanes start
+  DevBuf<uint8_t> hb29, hmarg; bool htail29 = false;   // H path: bucket sums and marginal sums on 29-bit limbs (htail29.cuh: Point29Rec)
   DevBuf<uint8_t> buckets, partials, seg_out, seg_l2, ones_partial, ones_l2;   // XYZZ<F> arrays (partials: Piece29 on the H path), kept as bytes to stay out of the header
   uint8_t *h_result = nullptr, *res_dev = nullptr;                  // the MSM's result — RS sums, the ones sum, the counters — in pinned host memory, and that memory's device address (the kernels write there directly)
   static constexpr uint32_t HEAVY_BLOCKS = 256, GROUP = 256;
@@ -85,6 +87,7 @@ struct MsmImpl {
       ws->fill = DevBuf<uint32_t>(2 * NB); ws->fill.zero(); ws->entries = DevBuf<uint32_t>((size_t)NB * ws->cap); ws->ones = DevBuf<uint32_t>(n); ws->counters = DevBuf<uint32_t>(2 * sizeof(MsmCounters) / 4); ws->counters.zero();
       HIP_CHECK(hipEventCreateWithFlags(&ws->sorted, hipEventDisableTiming)); }
     max_tasks = (uint32_t)((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1);
+    if (const char *e = getenv("ZK_MSM_H_RUN")) { const int v = atoi(e); if (v >= 4 && v <= 64) h_run = (uint32_t)v; }   // (tuning knob: entries per lane of the H accumulation)
     if (bases->points261.size()) {   // group-binned one-pass sort: G groups of 2^low buckets, about 16 K entries per group (one workgroup sorts a group in registers + LDS)
       size_t total = n * (size_t)W; uint32_t G = 256; while (G < HSORT_GROUPS && total / G > 16384) G <<= 1; uint32_t low = 0; while ((G << low) < NB) low++; uint32_t ib = 1; while (((size_t)1 << ib) < total) ib++;
       size_t region = ((total / G) * 5 / 4 + 1024 + 255) & ~(size_t)255; if (getenv("ZK_MSM_DIRECT_CAP")) region = 256;   // (test hook: regions far too small force the overflow fallback)
@@ -97,7 +100,9 @@ struct MsmImpl {
     seg_out = DevBuf<uint8_t>(std::max<size_t>((size_t)WB * (NB / seg), (size_t)32 * cdiv(NB, 512)) * sizeof(XYZZ<F>)); /* (also the chunk sums of the bit-sum tail: log2(NB) x NB/512) */ seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
     ones_partial = DevBuf<uint8_t>(std::max<size_t>(n_ones_quads, wfused ? (size_t)NB + WFUSED_ONES_BLOCKS : 0) * sizeof(XYZZ<F>)); if (wfused) lane_off = DevBuf<uint32_t>(WFUSED_MAX_BUCKETS + 1); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
     RS = WB; if (wfused) { bitsum = true; RS = WTAIL_SLOTS; }   // k_wtail leaves eight sums by weight bit
-    else if (hsort && NB >= 512) { bitsum = true; RS = 1; while ((1u << (RS - 1)) < NB) RS++; }   // RS = log2(NB) + 1
+    else if (hsort && NB >= 512) { bitsum = true; RS = 1; while ((1u << (RS - 1)) < NB) RS++;   // RS = log2(NB) + 1
+      static const bool tail29 = [] { const char *e = getenv("ZK_MSM_H_TAIL29"); return !e || atoi(e) != 0; }();   // (0: round 2's bit sums on 8 x 32-bit limbs, kept for A/B)
+      if (tail29) { htail29 = true; hb29 = DevBuf<uint8_t>((size_t)NB * sizeof(Point29Rec)); hmarg = DevBuf<uint8_t>((size_t)htail_marg_count(htail_shape(NB)) * sizeof(Point29Rec)); } }
     zeroed.zero();                                                                  // (the ones slot of the result stays the point at infinity when the ones path is off: h_result is cleared below)
     HIP_CHECK(hipHostMalloc((void **)&h_result, result_bytes())); memset(h_result, 0, result_bytes());
     { void *d = nullptr; HIP_CHECK(hipHostGetDevicePointer(&d, h_result, 0)); res_dev = (uint8_t *)d; }   // the last kernel of an MSM writes its few sums straight into the pinned host copy: no copy kernel behind it (1.125 -> 1.10 ms median per proof; round 2 had measured no difference, at 1.45 ms)
@@ -118,7 +123,11 @@ struct MsmImpl {
       const Fe32 *pb = prod_b; prod_b = nullptr; run_impl(sc, last_index); HIP_CHECK(hipStreamSynchronize(stream())); prod_b = pb; hsort = true; } }
   // sum_i (a_i b_i z) P_i; only on the H path, where the product is formed inside the sort kernel
   void run_product(const Fe32 *a, const Fe32 *b, const Fe32 *z, bool z_is_table) { if (!hsort) throw GpuError("msm: run_product needs the one-pass sort"); prod_b = b; prod_z = z; prod_z_table = z_is_table; run_impl(a, nullptr); }
-  void run(const Fe32 *scalars, const uint32_t *scalar_index) { prod_b = nullptr; run_impl(scalars, scalar_index); }
+  void run(const Fe32 *scalars, const uint32_t *scalar_index) { prod_b = nullptr; tagged = false; run_impl(scalars, scalar_index); }
+  // z_all_: the whole assignment (variable 0 = ONE); a plain query reads its scalars from z_all_ + wt.base, an indexed one through scalar_index
+  void run_tagged(const Fe32 *z_all_, const WitnessTags &wt, const uint32_t *scalar_index) {
+    prod_b = nullptr; wtags = wt; z_all = z_all_; tagged = wt.tags != nullptr && wt.other_vars != nullptr;
+    run_impl(scalar_index ? z_all_ : z_all_ + wt.base, scalar_index); }
 
   void run_impl(const Fe32 *scalars, const uint32_t *scalar_index) {
     hipStream_t s = stream(); size_t nbk = (size_t)WB * NB; const uint32_t hist_stride = WB == 1 ? 0 : NB, point_stride = WB == 1 && W > 1 ? (uint32_t)n : 0; const uint8_t *infp = any_inf ? inf.get() : nullptr;
@@ -135,9 +144,15 @@ struct MsmImpl {
       parity ^= 1;   // (undo the flip above: this path has its own counters, and the general path — which may follow as the overflow fallback — relies on strict alternation of its two slots)
       WsortBuffers &w = *ws; MsmCounters *wc = (MsmCounters *)w.counters.get();
       if (ws_leader) { w.parity ^= 1; w.leader_stream = stream_id; Stage st((label + ".sort").c_str(), s); const uint8_t *winf = w.shared ? nullptr : infp;   // a shared sort keeps every point: the tables differ in which points are at infinity, and the additions skip those
+        if (tagged) { const uint32_t ones_blocks = cdiv(n, 256), other_blocks = cdiv(wtags.n_other, 256);   // the sort from the assignment's tags (k_wsort_tagged)
+#define ZK_CALL(CC) hipLaunchKernelGGL(k_wsort_tagged<CC>, dim3(ones_blocks + other_blocks), dim3(256), 0, s, (const Fr *)z_all, wtags, scalar_index, winf, (uint32_t)n, c, W, point_stride, NB, w.cap, ones_blocks, w.fill.get() + (size_t)w.parity * NB, w.fill.get() + (size_t)(w.parity ^ 1) * NB, w.entries.get(), w.ones.get(), wc + w.parity, wc + (w.parity ^ 1))
+          ZK_MSM_DISPATCH_C(c, ZK_CALL);
+#undef ZK_CALL
+        } else {
 #define ZK_CALL(CC) hipLaunchKernelGGL(k_wsort<CC>, dim3(cdiv(n, 256)), dim3(256), 0, s, (const Fr *)scalars, scalar_index, winf, (uint32_t)n, c, W, point_stride, NB, w.cap, w.fill.get() + (size_t)w.parity * NB, w.fill.get() + (size_t)(w.parity ^ 1) * NB, w.entries.get(), w.ones.get(), wc + w.parity, wc + (w.parity ^ 1))
         ZK_MSM_DISPATCH_C(c, ZK_CALL);
 #undef ZK_CALL
+        }
         if (w.shared) HIP_CHECK(hipEventRecord(w.sorted, s)); }
       else if (w.leader_stream != stream_id) HIP_CHECK(hipStreamWaitEvent(s, w.sorted, 0));   // (a follower on the leader's stream is simply queued behind it)
       uint4 *csrc = (uint4 *)(wc + w.parity); uint4 *cdst = (uint4 *)(res + RS + 1);
@@ -147,7 +162,7 @@ struct MsmImpl {
         else { n_op = WFUSED_ONES_GROUPS; XYZZ<F> *l1 = (XYZZ<F> *)partials.get();
           hipLaunchKernelGGL((k_wacc_lanes<F>), dim3((WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) / 256), dim3(256), 0, s, (const Affine<F> *)points.get(), (const Affine<F> *)bases->ones_groups.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l1, lane_off.get());
           hipLaunchKernelGGL((k_wacc_fold<F>), dim3(NB + WFUSED_ONES_GROUPS), dim3(256), 0, s, (const XYZZ<F> *)l1, (const uint32_t *)lane_off.get(), NB, l2); } }
-      { Stage st((label + ".reduce").c_str(), s); hipLaunchKernelGGL((k_wtail<F>), dim3(2), dim3(256), 0, s, (const XYZZ<F> *)l2, NB, (const XYZZ<F> *)l2 + NB, n_op, res, csrc, cdst); }
+      { Stage st((label + ".reduce").c_str(), s); const uint32_t top = 31 - (uint32_t)__builtin_clz(NB); hipLaunchKernelGGL((k_wtail<F>), dim3(top + 2), dim3(256), 0, s, (const XYZZ<F> *)l2, NB, (const XYZZ<F> *)l2 + NB, n_op, res, csrc, cdst); }   // one workgroup per weight bit, one for bucket NB - 1, one for the ones
       return;
     }
     const bool hs_run = hsort && scalar_index == nullptr;
@@ -162,7 +177,7 @@ struct MsmImpl {
         if (any_inf) hipLaunchKernelGGL(k_hacc_runs29<1>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(), offsets.get(), hs, h_run, h_maxp, (Piece29 *)partials.get(), cnt);
         else hipLaunchKernelGGL(k_hacc_runs29<0>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(), offsets.get(), hs, h_run, h_maxp, (Piece29 *)partials.get(), cnt); }
       { Stage st((label + ".combine").c_str(), s); constexpr uint32_t ll = 1;   // two lanes per bucket
-        hipLaunchKernelGGL(k_hacc_combine29, dim3(cdiv(nbk << ll, 256)), dim3(256), 0, s, (const Piece29 *)partials.get(), offsets.get(), hist(), hs, h_run, h_maxp, (uint32_t)nbk, ll, (XYZZ<Fq> *)bucket_array(), cnt); }
+        hipLaunchKernelGGL(k_hacc_combine29, dim3(cdiv(nbk << ll, 256)), dim3(256), 0, s, (const Piece29 *)partials.get(), offsets.get(), hist(), hs, h_run, h_maxp, (uint32_t)nbk, ll, (XYZZ<Fq> *)bucket_array(), htail29 ? (Point29Rec *)hb29.get() : nullptr, cnt); }
       }
     } else
     { Stage st((label + ".sort").c_str(), s);
@@ -190,7 +205,11 @@ struct MsmImpl {
       { Stage st((label + ".combine").c_str(), s);
         hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(HEAVY_BLOCKS + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), HEAVY_BLOCKS, (const XYZZ<F> *)partials.get(), bucket_array(), zeroed.get(), (uint32_t)(2 * nbk), 0); }
     }
-    if (bitsum && hs_run) { Stage st_red((label + ".reduce").c_str(), s);
+    if (bitsum && hs_run && htail29) { if constexpr (sizeof(F) == 32) { Stage st_red((label + ".reduce").c_str(), s);   // marginal sums, then the sums by weight bit (htail29.cuh)
+      const HtailShape ts = htail_shape(NB); const uint32_t L = 1u << ts.lo_bits, H = 1u << ts.hi_bits;
+      hipLaunchKernelGGL(k_hmarg29<0>, dim3((L - 1) + (H - 1) + 1), dim3(256), 0, s, (const Point29Rec *)hb29.get(), NB, (Point29Rec *)hmarg.get());
+      hipLaunchKernelGGL(k_hbits29<0>, dim3(ts.top + 1), dim3(256), 0, s, (const Point29Rec *)hmarg.get(), NB, (XYZZ<Fq> *)res, cnt, (uint4 *)(res + RS + 1)); } }
+    else if (bitsum && hs_run) { Stage st_red((label + ".reduce").c_str(), s);
       uint32_t per = 8; while (per > 4 && (NB / 2) % (64 * per)) per >>= 1; const uint32_t top = (uint32_t)RS - 1, chunks = (NB / 2) / (64 * per);   // sums by weight bit; the host's Horner rule does the rest (combine() with c = 1)
       hipLaunchKernelGGL((k_bitsum_chunks<F>), dim3(chunks, top), dim3(256), 0, s, (const XYZZ<F> *)bucket_array(), per, (XYZZ<F> *)seg_out.get());
       hipLaunchKernelGGL((k_bitsum_final<F>), dim3(top + 1), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), chunks, top, (const XYZZ<F> *)bucket_array(), NB, res, (uint4 *)cnt, (uint4 *)(res + RS + 1)); }

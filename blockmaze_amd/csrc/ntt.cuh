@@ -205,10 +205,14 @@ __global__ void __launch_bounds__(64) k_r1cs_long_rows3(const uint32_t *__restri
 }
 // Assignment upload in compact form: 97 % of a BlockMaze witness are the bits 0 and 1, so the host sends two bitmaps (value is `one` / value is something else), the
 // running count of "something else" per 64 entries and only those values (0.3 MB instead of 7.3 MB over PCIe); this kernel rebuilds the vector.
-__global__ void k_expand_witness(const uint64_t *__restrict__ ones_bm, const uint64_t *__restrict__ other_bm, const uint32_t *__restrict__ block_off, const Fr *__restrict__ values, Fr one_value, int values_to_mont, uint32_t n, Fr *__restrict__ out) {
+// tags (optional): one byte per variable — 0 the value is zero, 1 it is one, 2 anything else — for the kernels that need not look at the 32-byte value of a bit
+// (k_r1cs_rows_tagged below, k_wsort_tagged in msm.cuh); other_vars (optional): the list of the variables tagged 2, in the order of `values`.
+constexpr uint8_t ZTAG_ZERO = 0, ZTAG_ONE = 1, ZTAG_OTHER = 2;
+__global__ void k_expand_witness(const uint64_t *__restrict__ ones_bm, const uint64_t *__restrict__ other_bm, const uint32_t *__restrict__ block_off, const Fr *__restrict__ values, Fr one_value, int values_to_mont, uint32_t n, Fr *__restrict__ out,
+                                 uint8_t *__restrict__ tags, uint32_t *__restrict__ other_vars) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; const uint32_t wd = i >> 6, bit = i & 63; const uint64_t ob = other_bm[wd];
-  if ((ob >> bit) & 1) { Fr v = values[block_off[wd] + (uint32_t)__popcll(ob & ((1ull << bit) - 1))]; if (values_to_mont) v = v.to_mont(); out[i] = v; }   // (a canonical assignment: only these 3 % need the conversion, one_value is the Montgomery one)
-  else out[i] = ((ones_bm[wd] >> bit) & 1) ? one_value : Fr::zero();
+  if ((ob >> bit) & 1) { const uint32_t at = block_off[wd] + (uint32_t)__popcll(ob & ((1ull << bit) - 1)); Fr v = values[at]; if (values_to_mont) v = v.to_mont(); out[i] = v; if (tags) tags[i] = ZTAG_OTHER; if (other_vars) other_vars[at] = i; }   // (a canonical assignment: only these 3 % need the conversion, one_value is the Montgomery one)
+  else { const bool is_one = (ones_bm[wd] >> bit) & 1; out[i] = is_one ? one_value : Fr::zero(); if (tags) tags[i] = is_one ? ZTAG_ONE : ZTAG_ZERO; }
 }
 // both of the above in ONE launch (the two are independent and each too small to fill the chip for long: 27 + 25 us one after the other at the head of every proof's
 // critical chain): the first `short_blocks` workgroups take the one-lane rows, the others four long rows each, one per wave
@@ -232,6 +236,109 @@ __global__ void __launch_bounds__(256) k_r1cs_rows_all(R1csMatrices M, const Fr 
     for (int d = 32; d >= 1; d >>= 1) { if ((uint32_t)d >= len) continue; Fr o; for (int i = 0; i < 8; i++) o.l[i] = __shfl_down(acc.l[i], d, 64); acc = acc + o; }
     v[mm] = acc; }
   if (lane == 0) { abc[r] = v[0]; abc[m + r] = v[1]; abc[2 * (size_t)m + r] = v[2]; if (v[0] * v[1] != v[2]) *fail = seq; }
+}
+// ---- the same evaluation for an assignment that arrived in compact form (k_expand_witness wrote a tag per variable) ---------------------------------------------------
+// 97 % of a BlockMaze assignment are the bits 0 and 1.  A term whose variable is 0 contributes nothing and is skipped after ONE byte load; a term whose variable is 1
+// contributes its coefficient — a 32-byte load from the small coefficient table and a modular addition, no product, whatever the coefficient (k_r1cs_rows_all runs the
+// product path in every iteration in which ANY lane of the wave meets a coefficient other than +-1, i.e. nearly always: ~450 instructions per term); only a variable holding
+// something else (packed words, field values: 3 %) loads its value and pays the product.  Rows of one gadget are neighbours, so whole waves skip the product path.
+// write_c = 0: the C polynomial is folded into the L query (ecntt.cuh) — its row value is still formed for the satisfiability test but not stored.
+__device__ __forceinline__ Fr r1cs_term_tagged(const Fr &acc, uint32_t ci, uint32_t col, const Fr *__restrict__ ctab, const Fr *__restrict__ z, const uint8_t *__restrict__ tags) {
+  const uint8_t t = tags[col];
+  if (t == ZTAG_ZERO) return acc;
+  const Fr coef = ctab[ci];
+  if (t == ZTAG_ONE) return acc + coef;
+  const Fr v = z[col];
+  if (ci == 0) return acc + v;
+  if (ci == 1) return acc - v;
+  return acc + coef * v;
+}
+// One lane, one row, all three matrices.  The walk is a chain of dependent loads (row pointer -> column index -> tag -> coefficient), and a lane that takes them one
+// term at a time spends the kernel waiting for the L2: the first R1CS_HEAD terms of each matrix are therefore fetched together — 6 row pointers, then 24 indices, then 12
+// tags in flight at once — and only rows with more terms than that (up to R1CS_LONG_ROW) go on term by term.
+constexpr int R1CS_HEAD = 4;
+__device__ __forceinline__ void r1cs_rows_tagged_lane(const R1csMatrices &M, uint32_t r, const Fr *__restrict__ ctab, const Fr *__restrict__ z, const uint8_t *__restrict__ tags, Fr (&out)[3]) {
+  uint32_t beg[3], end[3];
+#pragma unroll
+  for (int mm = 0; mm < 3; mm++) { beg[mm] = M.rowptr[mm][r]; end[mm] = M.rowptr[mm][r + 1]; }
+  uint32_t col[3][R1CS_HEAD], cid[3][R1CS_HEAD];
+#pragma unroll
+  for (int mm = 0; mm < 3; mm++) {
+#pragma unroll
+    for (int j = 0; j < R1CS_HEAD; j++) {
+      const bool valid = beg[mm] + j < end[mm];
+      col[mm][j] = valid ? M.col[mm][beg[mm] + j] : 0u;
+      cid[mm][j] = valid ? M.cid[mm][beg[mm] + j] : 0u;
+    }
+  }
+  uint8_t tag[3][R1CS_HEAD];
+#pragma unroll
+  for (int mm = 0; mm < 3; mm++) {
+#pragma unroll
+    for (int j = 0; j < R1CS_HEAD; j++) tag[mm][j] = beg[mm] + j < end[mm] ? tags[col[mm][j]] : ZTAG_ZERO;
+  }
+#pragma unroll
+  for (int mm = 0; mm < 3; mm++) {
+    Fr acc = Fr::zero();
+#pragma unroll
+    for (int j = 0; j < R1CS_HEAD; j++) {
+      if (tag[mm][j] == ZTAG_ZERO) continue;
+      const Fr coef = ctab[cid[mm][j]];
+      if (tag[mm][j] == ZTAG_ONE) { acc = acc + coef; continue; }
+      const Fr v = z[col[mm][j]];
+      if (cid[mm][j] == 0) acc = acc + v;
+      else if (cid[mm][j] == 1) acc = acc - v;
+      else acc = acc + coef * v;
+    }
+    for (uint32_t k = beg[mm] + R1CS_HEAD; k < end[mm]; k++) acc = r1cs_term_tagged(acc, M.cid[mm][k], M.col[mm][k], ctab, z, tags);
+    out[mm] = acc;
+  }
+}
+__global__ void __launch_bounds__(256) k_r1cs_rows_tagged(R1csMatrices M, const Fr *__restrict__ ctab, const Fr *__restrict__ z, const uint8_t *__restrict__ tags, uint32_t n_rows, uint32_t n_inputs, uint32_t m,
+                                                          const uint32_t *__restrict__ long_rows, uint32_t n_long, uint32_t short_blocks, int write_c, Fr *__restrict__ abc, uint32_t seq, uint32_t *fail) {
+  if (blockIdx.x < short_blocks) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    if (r >= n_rows) {                                                                   // input-consistency rows and the zero padding up to the domain size
+      abc[r] = r <= n_rows + n_inputs ? z[r - n_rows] : Fr::zero();
+      abc[m + r] = Fr::zero();
+      if (write_c) abc[2 * (size_t)m + r] = Fr::zero();
+      return;
+    }
+    if (M.rowptr[0][r + 1] - M.rowptr[0][r] > R1CS_LONG_ROW || M.rowptr[1][r + 1] - M.rowptr[1][r] > R1CS_LONG_ROW || M.rowptr[2][r + 1] - M.rowptr[2][r] > R1CS_LONG_ROW) return;
+    Fr v[3];
+    r1cs_rows_tagged_lane(M, r, ctab, z, tags, v);
+    abc[r] = v[0];
+    abc[m + r] = v[1];
+    if (write_c) abc[2 * (size_t)m + r] = v[2];
+    if (v[0] * v[1] != v[2]) *fail = seq;
+    return;
+  }
+  const uint32_t w = (blockIdx.x - short_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // a row of more than R1CS_LONG_ROW terms: one wave
+  if (w >= n_long) return;
+  const uint32_t r = long_rows[w];
+  Fr v[3];
+#pragma unroll
+  for (int mm = 0; mm < 3; mm++) {
+    Fr acc = Fr::zero();
+    const uint32_t *col = M.col[mm], *cid = M.cid[mm];
+    for (uint32_t k = M.rowptr[mm][r] + lane, e = M.rowptr[mm][r + 1]; k < e; k += 64) acc = r1cs_term_tagged(acc, cid[k], col[k], ctab, z, tags);
+    const uint32_t len = M.rowptr[mm][r + 1] - M.rowptr[mm][r];                          // (wave-uniform) the long matrix of a packing constraint has 32..35 terms, the other two have one
+#pragma unroll 1
+    for (int d = 32; d >= 1; d >>= 1) {
+      if ((uint32_t)d >= len) continue;
+      Fr o;
+      for (int i = 0; i < 8; i++) o.l[i] = __shfl_down(acc.l[i], d, 64);
+      acc = acc + o;
+    }
+    v[mm] = acc;
+  }
+  if (lane == 0) {
+    abc[r] = v[0];
+    abc[m + r] = v[1];
+    if (write_c) abc[2 * (size_t)m + r] = v[2];
+    if (v[0] * v[1] != v[2]) *fail = seq;
+  }
 }
 // satisfiability: flag[0] |= (a[i]*b[i] != c[i]) over the constraint rows (protoboard::is_satisfied, sendcgo.cpp:209)
 __global__ void k_r1cs_check(const Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ c, uint32_t n_rows, uint32_t *flag) {
