@@ -5,6 +5,7 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <stdexcept>
 #include "circuit.hpp"
 
 namespace zk { namespace circuit {
@@ -42,14 +43,23 @@ namespace {
 const LC ONE_LC = LC::constant(HFr::one());
 const HFr TWO = HFr::from_u64(2);
 
+// Where a gadget's bit array lives on the board: `first` if its variables are consecutive and ascending (alloc_array, or allocations made one after the other), so that
+// the native witness path writes the bits of a word with Board::set_bits_run instead of one indexed byte store per bit
+struct BitRun {
+  Var first = 0; uint32_t count = 0; bool consecutive = false;
+  BitRun() {}
+  explicit BitRun(const VarArray &v) : first(v.empty() ? 0 : v[0]), count((uint32_t)v.size()), consecutive(!v.empty() && v[0] != 0) { for (size_t i = 0; i < v.size(); i++) consecutive = consecutive && v[i] == v[0] + i; }
+  void write(Board &b, const VarArray &vars, uint64_t bits) const { if (consecutive) b.set_bits_run(first, bits, count); else for (size_t i = 0; i < vars.size(); i++) b.set_bit(vars[i], (bits >> i) & 1); }
+};
 struct LastBits {     // X has X_bits bits; result = the low |result_bits| of them
-  Board &b; Var X; size_t X_bits; Var result; VarArray result_bits, full_bits;
+  Board &b; Var X; size_t X_bits; Var result; VarArray result_bits, full_bits, high_bits; BitRun low_run, high_run;
   LastBits(Board &b, Var X, size_t X_bits, Var result, const VarArray &result_bits) : b(b), X(X), X_bits(X_bits), result(result), result_bits(result_bits), full_bits(result_bits) {
-    for (size_t i = result_bits.size(); i < X_bits; i++) full_bits.push_back(b.alloc()); }
+    for (size_t i = result_bits.size(); i < X_bits; i++) { high_bits.push_back(b.alloc()); full_bits.push_back(high_bits.back()); }
+    low_run = BitRun(result_bits); high_run = BitRun(high_bits); }
   void constraints() { Packing(b, to_lcs(full_bits), X).constraints(true); Packing(b, to_lcs(result_bits), result).constraints(false); }
   void witness() { fill_bits_of_value(b, full_bits, b.get(X)); b.set(result, pack_bits_value(b, to_lcs(result_bits))); }
   // native form: X is known as an integer (< 2^36)
-  uint32_t witness_native(uint64_t x) { b.set(X, HFr::from_u64(x)); for (size_t i = 0; i < full_bits.size(); i++) b.set_bit(full_bits[i], (x >> i) & 1); uint32_t r = (uint32_t)x; b.set(result, HFr::from_u64(r)); return r; }
+  uint32_t witness_native(uint64_t x) { b.set_small(X, x); low_run.write(b, result_bits, x); high_run.write(b, high_bits, x >> result_bits.size()); const uint64_t r = result_bits.size() >= 64 ? x : x & ((1ull << result_bits.size()) - 1); b.set_small(result, r); return (uint32_t)r; }
 };
 inline uint32_t rotr32(uint32_t x, unsigned n) { return (x >> n) | (x << (32 - n)); }
 struct Xor3 {
@@ -63,37 +73,39 @@ struct Xor3 {
 };
 inline const LC &rotr(const LCArray &A, size_t i, size_t k) { return A[(i + k) % 32]; }
 struct SmallSigma {
-  Board &b; Var result; VarArray result_bits; std::vector<Xor3> x; unsigned r1, r2, sh;
+  Board &b; Var result; VarArray result_bits, tmp_bits; BitRun res_run, tmp_run; std::vector<Xor3> x; unsigned r1, r2, sh;
   uint32_t witness_native(uint32_t w) { uint32_t t = rotr32(w, r1) ^ rotr32(w, r2), res = t ^ (w >> sh);
-    for (size_t k = 0; k < 32; k++) { if (!x[k].c_zero) b.set_bit(x[k].tmp, (t >> k) & 1); b.set_bit(result_bits[k], (res >> k) & 1); } b.set(result, HFr::from_u64(res)); return res; }
+    tmp_run.write(b, tmp_bits, t); res_run.write(b, result_bits, res); b.set_small(result, res); return res; }   // (the 32 - sh low positions have a tmp variable: bits 0 .. 31 - sh of t)
   SmallSigma(Board &b, const LCArray &W, Var result, size_t rot1, size_t rot2, size_t shift) : b(b), result(result), result_bits(b.alloc_array(32)), r1((unsigned)rot1), r2((unsigned)rot2), sh((unsigned)shift) {
-    for (size_t i = 0; i < 32; i++) x.emplace_back(b, rotr(W, i, rot1), rotr(W, i, rot2), (i + shift < 32 ? W[i + shift] : ONE_LC), i + shift >= 32, result_bits[i]); }
+    for (size_t i = 0; i < 32; i++) { x.emplace_back(b, rotr(W, i, rot1), rotr(W, i, rot2), (i + shift < 32 ? W[i + shift] : ONE_LC), i + shift >= 32, result_bits[i]); if (!x.back().c_zero) { if (tmp_bits.size() != i) throw std::logic_error("SmallSigma: tmp variables are not the low positions"); tmp_bits.push_back(x.back().tmp); } }
+    res_run = BitRun(result_bits); tmp_run = BitRun(tmp_bits); }
   void constraints() { for (auto &g : x) g.constraints(); Packing(b, to_lcs(result_bits), result).constraints(false); }
   void witness() { for (auto &g : x) g.witness(); b.set(result, pack_bits_value(b, to_lcs(result_bits))); }
 };
 struct BigSigma {
-  Board &b; Var result; VarArray result_bits; std::vector<Xor3> x; unsigned q1, q2, q3;
+  Board &b; Var result; VarArray result_bits, tmp_bits; BitRun res_run, tmp_run; std::vector<Xor3> x; unsigned q1, q2, q3;
   uint32_t witness_native(uint32_t w) { uint32_t t = rotr32(w, q1) ^ rotr32(w, q2), res = t ^ rotr32(w, q3);
-    for (size_t k = 0; k < 32; k++) { b.set_bit(x[k].tmp, (t >> k) & 1); b.set_bit(result_bits[k], (res >> k) & 1); } b.set(result, HFr::from_u64(res)); return res; }
+    tmp_run.write(b, tmp_bits, t); res_run.write(b, result_bits, res); b.set_small(result, res); return res; }
   BigSigma(Board &b, const LCArray &W, Var result, size_t r1, size_t r2, size_t r3) : b(b), result(result), result_bits(b.alloc_array(32)), q1((unsigned)r1), q2((unsigned)r2), q3((unsigned)r3) {
-    for (size_t i = 0; i < 32; i++) x.emplace_back(b, rotr(W, i, r1), rotr(W, i, r2), rotr(W, i, r3), false, result_bits[i]); }
+    for (size_t i = 0; i < 32; i++) { x.emplace_back(b, rotr(W, i, r1), rotr(W, i, r2), rotr(W, i, r3), false, result_bits[i]); tmp_bits.push_back(x.back().tmp); }
+    res_run = BitRun(result_bits); tmp_run = BitRun(tmp_bits); }
   void constraints() { for (auto &g : x) g.constraints(); Packing(b, to_lcs(result_bits), result).constraints(false); }
   void witness() { for (auto &g : x) g.witness(); b.set(result, pack_bits_value(b, to_lcs(result_bits))); }
 };
 struct Choice {
-  Board &b; LCArray X, Y, Z; Var result; VarArray result_bits;
-  Choice(Board &b, const LCArray &X, const LCArray &Y, const LCArray &Z, Var result) : b(b), X(X), Y(Y), Z(Z), result(result), result_bits(b.alloc_array(32)) {}
+  Board &b; LCArray X, Y, Z; Var result; VarArray result_bits; BitRun res_run;
+  Choice(Board &b, const LCArray &X, const LCArray &Y, const LCArray &Z, Var result) : b(b), X(X), Y(Y), Z(Z), result(result), result_bits(b.alloc_array(32)) { res_run = BitRun(result_bits); }
   void constraints() { for (size_t i = 0; i < 32; i++) b.constraint(X[i], Y[i] - Z[i], LC(result_bits[i]) - Z[i]); Packing(b, to_lcs(result_bits), result).constraints(false); }
   void witness() { for (size_t i = 0; i < 32; i++) { bool x = b.eval_bit(X[i]); b.set_bit(result_bits[i], x ? b.eval_bit(Y[i]) : b.eval_bit(Z[i])); } b.set(result, pack_bits_value(b, to_lcs(result_bits))); }
-  uint32_t witness_native(uint32_t e, uint32_t f, uint32_t g) { uint32_t res = (e & f) ^ (~e & g); for (size_t k = 0; k < 32; k++) b.set_bit(result_bits[k], (res >> k) & 1); b.set(result, HFr::from_u64(res)); return res; }
+  uint32_t witness_native(uint32_t e, uint32_t f, uint32_t g) { uint32_t res = (e & f) ^ (~e & g); res_run.write(b, result_bits, res); b.set_small(result, res); return res; }
 };
 struct Majority {
-  Board &b; LCArray X, Y, Z; Var result; VarArray result_bits;
-  Majority(Board &b, const LCArray &X, const LCArray &Y, const LCArray &Z, Var result) : b(b), X(X), Y(Y), Z(Z), result(result), result_bits(b.alloc_array(32)) {}
+  Board &b; LCArray X, Y, Z; Var result; VarArray result_bits; BitRun res_run;
+  Majority(Board &b, const LCArray &X, const LCArray &Y, const LCArray &Z, Var result) : b(b), X(X), Y(Y), Z(Z), result(result), result_bits(b.alloc_array(32)) { res_run = BitRun(result_bits); }
   void constraints() { for (size_t i = 0; i < 32; i++) { boolean_constraint(b, LC(result_bits[i])); LC s = X[i] + Y[i] + Z[i] - LC(result_bits[i]).scaled(TWO); b.constraint(s, ONE_LC - s, LC()); }
     Packing(b, to_lcs(result_bits), result).constraints(false); }
   void witness() { for (size_t i = 0; i < 32; i++) { int v = (int)b.eval_bit(X[i]) + (int)b.eval_bit(Y[i]) + (int)b.eval_bit(Z[i]); b.set_bit(result_bits[i], v >= 2); } b.set(result, pack_bits_value(b, to_lcs(result_bits))); }
-  uint32_t witness_native(uint32_t x, uint32_t y, uint32_t z) { uint32_t res = (x & y) ^ (x & z) ^ (y & z); for (size_t k = 0; k < 32; k++) b.set_bit(result_bits[k], (res >> k) & 1); b.set(result, HFr::from_u64(res)); return res; }
+  uint32_t witness_native(uint32_t x, uint32_t y, uint32_t z) { uint32_t res = (x & y) ^ (x & z) ^ (y & z); res_run.write(b, result_bits, res); b.set_small(result, res); return res; }
 };
 
 // ---- sha256_components.tcc ---------------------------------------------------------------------------------------------
@@ -109,7 +121,7 @@ struct MessageSchedule {
     for (size_t i = 16; i < 64; i++) { cs0[i - 16].constraints(); cs1[i - 16].constraints();
       b.constraint(ONE_LC, LC(sigma0[i]) + LC(sigma1[i]) + LC(packed_W[i - 16]) + LC(packed_W[i - 7]), LC(unreduced_W[i])); red[i - 16].constraints(); } }
   void witness_native(uint32_t W[64]) {   // W[0..15] given; the message bits themselves are inputs of the gadget and already assigned
-    for (size_t i = 0; i < 16; i++) b.set(packed_W[i], HFr::from_u64(W[i]));
+    for (size_t i = 0; i < 16; i++) b.set_small(packed_W[i], W[i]);
     for (size_t i = 16; i < 64; i++) { uint32_t s0 = cs0[i - 16].witness_native(W[i - 15]), s1 = cs1[i - 16].witness_native(W[i - 2]); W[i] = red[i - 16].witness_native((uint64_t)s0 + s1 + W[i - 16] + W[i - 7]); } }
   void witness() { for (size_t i = 0; i < 16; i++) b.set(packed_W[i], pack_bits_value(b, to_lcs(W_bits[i])));
     for (size_t i = 16; i < 64; i++) { cs0[i - 16].witness(); cs1[i - 16].witness(); b.set(unreduced_W[i], b.get(sigma0[i]) + b.get(sigma1[i]) + b.get(packed_W[i - 16]) + b.get(packed_W[i - 7])); red[i - 16].witness(); } }
@@ -132,7 +144,7 @@ struct RoundFunction {
     ra->constraints(); re->constraints(); }
   void witness_native(uint32_t wa, uint32_t wb, uint32_t wc, uint32_t wd, uint32_t we, uint32_t wf, uint32_t wg, uint32_t wh, uint32_t Wi, uint32_t &na, uint32_t &ne) {
     uint32_t S0 = s0->witness_native(wa), S1 = s1->witness_native(we), chv = ch->witness_native(we, wf, wg), mjv = mj->witness_native(wa, wb, wc);
-    b.set(packed_d, HFr::from_u64(wd)); b.set(packed_h, HFr::from_u64(wh));
+    b.set_small(packed_d, wd); b.set_small(packed_h, wh);
     na = ra->witness_native((uint64_t)wh + S1 + chv + K + Wi + S0 + mjv); ne = re->witness_native((uint64_t)wd + wh + S1 + chv + K + Wi); }
   void witness() { s0->witness(); s1->witness(); ch->witness(); mj->witness(); b.set(packed_d, pack_bits_value(b, d)); b.set(packed_h, pack_bits_value(b, h)); HFr k = HFr::from_u64(K);
     b.set(unreduced_new_a, b.get(packed_h) + b.get(sigma1) + b.get(choice) + k + b.get(W) + b.get(sigma0) + b.get(majority));

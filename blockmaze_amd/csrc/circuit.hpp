@@ -63,9 +63,20 @@ class Board {
   void set_input_sizes(size_t n) { cs.n_inputs = n; }
   size_t num_variables() const { return tag.size() - 1; }
   void constraint(const LC &a, const LC &b, const LC &c);
-  HFr get(Var v) const { const uint8_t t = tag[v]; return t == 2 ? wide[v] : t ? HFr::one() : HFr::zero(); }
-  void set(Var v, const HFr &x) { if (x.is_zero()) tag[v] = 0; else if (x == HFr::one()) tag[v] = 1; else { wide[v] = x; tag[v] = 2; } }
-  HFr eval(const LC &lc) const { if (lc.t.size() == 1 && lc.t[0].one) return get(lc.t[0].v); HFr s = HFr::zero(); for (const Term &x : lc.t) { const uint8_t t = tag[x.v]; if (t == 0) continue; s = s + (x.one ? get(x.v) : t == 1 ? x.c : x.c * wide[x.v]); } return s; }
+  // tag 6 (round 4): a SMALL integer (below 2^64) kept as it is in wide[v].l[0] — the packed words and sums of the SHA-256 gadgets, ~850 per compression: the native
+  // witness path used to pay a Montgomery product for each of them on the calling thread; now whoever needs the field element converts (get / eval here, rarely; the
+  // prover's hand-over, on its four scan threads).  TAG_WIDE and TAG_SMALL both have bit 1 set ("neither 0 nor 1") and bit 0 clear.
+  static constexpr uint8_t TAG_WIDE = 2, TAG_SMALL = 6;
+  HFr get(Var v) const { const uint8_t t = tag[v]; return t == TAG_WIDE ? wide[v] : t == TAG_SMALL ? HFr::from_u64(wide[v].l[0]) : t ? HFr::one() : HFr::zero(); }
+  void set(Var v, const HFr &x) { if (x.is_zero()) tag[v] = 0; else if (x == HFr::one()) tag[v] = 1; else { wide[v] = x; tag[v] = TAG_WIDE; } }
+  void set_small(Var v, uint64_t x) { if (x < 2) tag[v] = (uint8_t)x; else { wide[v].l[0] = x; tag[v] = TAG_SMALL; } }
+  // bit i of `bits` -> variable first + i, i < count <= 64: the variables of a gadget's bit array are consecutive, eight of them are one 8-byte store
+  void set_bits_run(Var first, uint64_t bits, size_t count) {
+    uint8_t *t = tag.data() + first; size_t i = 0;
+    for (; i + 8 <= count; i += 8) { const uint64_t x = (bits >> i) & 0xff, sel = (x * 0x0101010101010101ull) & 0x8040201008040201ull, spread = ((sel + 0x7f7f7f7f7f7f7f7full) >> 7) & 0x0101010101010101ull; memcpy(t + i, &spread, 8); }   // byte j of the store = bit j of x
+    for (; i < count; i++) t[i] = (uint8_t)((bits >> i) & 1);
+  }
+  HFr eval(const LC &lc) const { if (lc.t.size() == 1 && lc.t[0].one) return get(lc.t[0].v); HFr s = HFr::zero(); for (const Term &x : lc.t) { const uint8_t t = tag[x.v]; if (t == 0) continue; s = s + (x.one ? get(x.v) : t == 1 ? x.c : x.c * get(x.v)); } return s; }
   bool eval_bit(const LC &lc) const { if (lc.t.size() == 1 && lc.t[0].one) return tag[lc.t[0].v] != 0; if (lc.t.empty()) return false; return !eval(lc).is_zero(); }
   void set_bit(Var v, bool b) { if (v) tag[v] = (uint8_t)b; }   // writes to ONE are dropped (see LessCmp)
   bool bit(Var v) const { return tag[v] != 0; }

@@ -18,6 +18,7 @@
 
 namespace zk {
 
+
 template <class P>
 struct Fp {
   uint32_t l[8];

@@ -35,7 +35,7 @@ def adjusted_light(c):
     return l
 INV = (-pow(Q, -1, 1 << B)) % (1 << B)
 P29 = limbs29(Q); ONE29 = limbs29(RP % Q); RCONV = limbs29((1 << 256) % Q)
-KS = {c: adjusted(c) for c in (2, 4, 6)}
+KS = {c: adjusted(c) for c in (2, 4, 6, 12, 18)}   # (12 p and 18 p: the Fq2 mixed addition of the G2 witness MSM, msm.cuh: XYZZ2_29)
 
 # ---- bounds of the mixed addition (values in units of p; RATIO = 2^261 / p) ------------------------------------------------------------------------
 RATIO = RP / Q
@@ -81,10 +81,37 @@ def check_bounds_add_quad():
     assert KS[cY][NL - 1] >= int(Bv * Q) >> (B * (NL - 1))
     assert (1 << B) + (1 << B) + 8 < (1 << 31)
 check_bounds_add_quad()
+def check_bounds_g2():
+    """the mixed addition over Fq2 on 29-bit limbs (msm.cuh: XYZZ2_29::madd — the G2 half of the B query): Karatsuba products (three Fq products: v0 = a0 b0, v1 = a1 b1,
+    v2 = (a0 + a1)(b0 + b1); c0 = v0 + K_2 - v1, c1 = v2 + K_4 - (v0 + v1)), complex squarings (c0 = (a0 + a1)(a0 + K_12 - a1), c1 = 2 a0 a1), differences with the
+    constants below, and ONE Barrett step (value below 4.1 p) on each component of X3 and Y3.  Returns the invariant it proves: X, Y < 4.1, ZZ / ZZZ components below bZ."""
+    def mul2(a, b):
+        v0 = prod(a[0], b[0]); v1 = prod(a[1], b[1]); v2 = prod(a[0] + a[1], b[0] + b[1])
+        assert v1 + 0.01 <= 2 and v0 + v1 + 0.01 <= 4, (v0, v1)                       # the constants K_2 / K_4 of the two differences
+        return (v0 + 2, v2 + 4)
+    def sqr2(a, c):
+        assert a[1] + 0.01 <= c; m = prod(a[0], a[1]); return (prod(a[0] + a[1], a[0] + c), 2 * m)
+    def sub2(a, b, c):
+        assert b[0] + 0.01 <= c[0] and b[1] + 0.01 <= c[1], (b, c)
+        for ci, bi in zip(c, b): assert KS[ci][NL - 1] >= int(bi * Q) >> (B * (NL - 1)), (ci, bi)   # the subtrahend's top limb never exceeds K_c's
+        return (a[0] + c[0], a[1] + c[1])
+    bXY = (4.1, 4.1); bZ = (3.2, 5.7)                                                 # the invariant (ZZ = ZZZ = one for the lifted point: below p)
+    px = (1.0, 1.0); py = (2.0, 2.0)                                                  # y' = K_2 - y, normalized
+    U2 = mul2(px, bZ); S2 = mul2(py, bZ); P = sub2(U2, bXY, (6, 6)); R = sub2(S2, bXY, (6, 6))
+    PP = sqr2(P, 12); PPP = mul2(P, PP); Qv = mul2(bXY, PP); RR = sqr2(R, 12)
+    s = (PPP[0] + 2 * Qv[0], PPP[1] + 2 * Qv[1]); X3 = sub2(RR, s, (12, 18)); assert max(X3) < LIN_MAX_UNITS
+    T = sub2(Qv, bXY, (6, 6))                                                         # X3 after its Barrett step: below 4.1
+    A = mul2(R, T); Bv = mul2(bXY, PPP); Y3 = sub2(A, Bv, (4, 6)); assert max(Y3) < LIN_MAX_UNITS
+    ZZ3 = mul2(bZ, PP); ZZZ3 = mul2(bZ, PPP)
+    assert max(ZZ3[0], ZZZ3[0]) <= bZ[0] and max(ZZ3[1], ZZZ3[1]) <= bZ[1], (ZZ3, ZZZ3)
+    # a product's column: both operands may be sums of two normalized values (Karatsuba), limbs below 2^30 + 16
+    assert 9 * ((1 << 30) + 16) ** 2 + 9 * (1 << 58) + (1 << 35) < 1 << 64
+    return dict(X3=X3, Y3=Y3, ZZ=ZZ3, ZZZ=ZZZ3, P=P, R=R, T=T)
 
 HEADER = ["// GENERATED by gen_field29.py - do not edit.  Fq and Fr on nine 29-bit limbs (R' = 2^261): Fq29 for k_hacc_runs29 (msm.cuh) and the verifier's schedule",
           "// (pairing.cuh), Fr29 for the transforms (ntt.cuh); device compilation only.",
           "// value bounds of the mixed addition, in units of p (interval arithmetic in the generator): " + ", ".join("%s < %.2f" % kv for kv in BOUNDS["bounds"].items())]
+EMIT_BARRETT = False
 def gen_struct():
     """the struct for the modulus the globals (P29, INV, ONE29, RCONV, KS) currently describe, under the name Fq29 (the caller renames)"""
     global out, cols
@@ -95,6 +122,7 @@ def gen_struct():
     def arr(name, v, comment=""): out.append("  static constexpr uint32_t %s[9] = {%s};%s" % (name, ", ".join("0x%xu" % x for x in v), ("   // " + comment) if comment else ""))
     arr("P29", P29, "p"); arr("ONE", ONE29, "2^261 mod p: the field's one"); arr("RCONV", RCONV, "2^256 mod p as a plain integer: a Montgomery product with it turns v 2^261 into v 2^256 (the 8 x 32-bit form)")
     for c, v in KS.items(): arr("K%d" % c, v, "%d p, low limbs in [3 * 2^29 + 64, 4 * 2^29)" % c)
+    if EMIT_BARRETT: arr("NP", NP, "2^264 - p (top limb: 32 bits)")
     arr("KL2", adjusted_light(2), "2 p, low limbs in [2^29 + 64, 2 * 2^29 + 64)"); assert adjusted_light(2)[NL - 1] >= int(1.5 * Q) >> (B * (NL - 1))   # a subtrahend below 1.5 p never exceeds KL2's top limb
     def mads(pairs, const_b, first):
         """one asm statement: acc (+)= sum of the pairs' products; no carries: the column stays below 2^64"""
@@ -135,7 +163,7 @@ def gen_struct():
 """ + ("""      // a - b (mod p) as a + K_C - b, normalized.  b: limbs below 3 * (2^29 + 8), value below C p
       template <int C> static __device__ __forceinline__ Fq29 sub(const Fq29 &a, const Fq29 &b) { Fq29 d;
     #pragma unroll
-        for (int i = 0; i < 9; i++) d.l[i] = a.l[i] + (C == 2 ? K2[i] : C == 4 ? K4[i] : K6[i]) - b.l[i];
+        for (int i = 0; i < 9; i++) d.l[i] = a.l[i] + (C == 2 ? K2[i] : C == 4 ? K4[i] : C == 6 ? K6[i] : C == 12 ? K12[i] : K18[i]) - b.l[i];
         return d.norm(); }
       // neg ? -a : a for a canonical a (limbs below 2^29): K_2 - a is left as it is (limbs below 2^31, fine as ONE operand of a product)
       static __device__ __forceinline__ Fq29 cond_neg(const Fq29 &a, bool neg) { Fq29 r;
@@ -152,7 +180,22 @@ def gen_struct():
     #pragma unroll
         for (int i = 0; i < 9; i++) d.l[i] = KL2[i] - t.l[i];
         return d; }
-      // limb-wise sum, NOT normalized
+""" + ("""      // V - q p with q = max(estimate of V / p from the top limb - 1, 0), as V + q (2^264 - p) with the top limb modulo 2^32 (the q multiples of 2^264 fall out): limbs below
+      // 2^31 and a value below 1200 p in, normalized limbs and a value below 4.1 p out (the model and its check on integers: barrett / lin_check in the generator)
+      __device__ __forceinline__ Fq29 barrett() const {
+        uint32_t q = (uint32_t)(((uint64_t)l[8] * %dull) >> 32) >> %d; q = q ? q - 1 : 0;
+        uint64_t acc[9]; Fq29 r, t;
+    #pragma unroll
+        for (int i = 0; i < 9; i++) acc[i] = (uint64_t)l[i] + (uint64_t)q * NP[i];
+        t.l[0] = (uint32_t)acc[0] & MASK;
+    #pragma unroll
+        for (int i = 1; i < 8; i++) t.l[i] = ((uint32_t)acc[i] & MASK) + (uint32_t)(acc[i - 1] >> 29);
+        t.l[8] = (uint32_t)acc[8] + (uint32_t)(acc[7] >> 29);
+        r.l[0] = t.l[0] & MASK;
+    #pragma unroll
+        for (int i = 1; i < 8; i++) r.l[i] = (t.l[i] & MASK) + (t.l[i - 1] >> 29);
+        r.l[8] = t.l[8] + (t.l[7] >> 29); return r; }
+""" % (MU, MU_SHIFT - 32) if EMIT_BARRETT else "") + """      // limb-wise sum, NOT normalized
       static __device__ __forceinline__ Fq29 add_raw(const Fq29 &a, const Fq29 &b) { Fq29 d;
     #pragma unroll
         for (int i = 0; i < 9; i++) d.l[i] = a.l[i] + b.l[i];
@@ -280,6 +323,7 @@ def lin_check():
         for i in range(8): f[i + 1] += f[i] >> B; f[i] &= M
         assert (V % Q == 0) == any(f == limbs29(k * Q) for k in range(5))
 lin_check()
+BOUNDS_G2 = check_bounds_g2()
 prm = ["// GENERATED by gen_field29.py - do not edit.  Constants of Fq on nine 29-bit limbs, for host and device code (verify_sched.hpp).", "#pragma once", "#include <cstdint>", "namespace zk { namespace p29 {"]
 def carr(name, v, comment=""): prm.append("constexpr uint32_t %s[9] = {%s};%s" % (name, ", ".join("0x%xu" % x for x in v), ("   // " + comment) if comment else ""))
 prm.append("constexpr uint32_t MASK = 0x%xu, INV = 0x%xu, MU = 0x%xu, MU_SHIFT = %d, LIN_MAX_UNITS = %d;   // MU = floor(2^53 / ((p >> 232) + 1)); a linear combination's value stays below LIN_MAX_UNITS p" % (M, INV, MU, MU_SHIFT, LIN_MAX_UNITS))
@@ -287,7 +331,7 @@ carr("P", P29, "p"); carr("K6", KS[6], "6 p, low limbs in [3 * 2^29 + 64, 4 * 2^
 prm.append("constexpr uint32_t KP[5][9] = {%s};   // k p, k = 0 .. 4, exact limbs" % ", ".join("{" + ", ".join("0x%xu" % x for x in limbs29(k * Q)) + "}" for k in range(5)))
 prm.append("} }")
 open(__file__.replace("gen_field29.py", "field29_params.h"), "w").write("\n".join(prm) + "\n")
-FQ_LINES = gen_struct()
+EMIT_BARRETT = True; FQ_LINES = gen_struct(); EMIT_BARRETT = False
 # ---- the same arithmetic for Fr (the transforms): constants of the scalar field, same column schedule, same self-check --------------------------------------------
 R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 Q_SAVE = Q; KS_SAVE = KS; Q = R_MOD; INV = (-pow(Q, -1, 1 << B)) % (1 << B); P29 = limbs29(Q); ONE29 = limbs29(RP % Q); RCONV = limbs29((1 << 256) % Q); KS = {}   # (no borrow-adjusted 2p, 4p, 6p with limbs in [3 * 2^29 + 64, 4 * 2^29) exist for r = 1 mod 2^28; the transforms only subtract products)

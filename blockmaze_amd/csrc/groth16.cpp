@@ -1,5 +1,8 @@
 // see groth16.hpp
 #include <sys/random.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <fcntl.h>
@@ -301,7 +304,7 @@ struct Prover::Impl {
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
   std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; std::shared_ptr<DevBuf<uint32_t>> B_idx; DevBuf<Fe32> z, abc; DevBuf<uint8_t> packed, tags; DevBuf<uint32_t> other_vars; std::shared_ptr<DevBuf<uint32_t>> B_pos /* inverse of the B query's index list */; uint32_t n_other = 0; bool tags_valid = false /* the assignment on the device came in compact form: tags holds 0 / 1 / 2 per variable */; PinnedBuf<Fe32> z_host;
-  std::unique_ptr<SubmitWorker> workers[4];
+  std::unique_ptr<SubmitWorker> workers[4], scan_workers[4];   // scan_workers: only the hand-over scan of a host-buffer assignment (set_witness) on hosts with many cores
   // The submit thread of a witness MSM also waits for its stream and finishes the MSM on the host (Horner combine, or the host tail of msm_impl.hpp): four threads do that
   // side by side while the H chain is still running.  pending[j]: job j (order B2, L, A, B1) was posted and its result slot is not valid before workers[j]->wait().
   HG2 rB2; HG1 rL, rA, rB1; bool pending[4] = {false, false, false, false}, inline_result[4] = {false, false, false, false};
@@ -309,7 +312,7 @@ struct Prover::Impl {
   int owner(int j) const { return j == 1 && pair_AL ? 2 : j == 0 && pair_B ? 3 : j; }
   void settle(int j) { const int o = owner(j); if (pending[o]) { pending[o] = false; workers[o]->wait(); } if (inline_result[j]) { inline_result[j] = false; switch (j) { case 0: rB2 = B2->result(); break; case 1: rL = L->result(); break; case 2: rA = A->result(); break; default: rB1 = B1->result(); } } }
   void settle_all_quietly() { for (int j = 0; j < 4; j++) { try { settle(j); } catch (...) {} } }
-  ~Impl() { settle_all_quietly(); for (auto &w : workers) w.reset(); gpu_lane_release(lane); }
+  ~Impl() { settle_all_quietly(); for (auto &w : workers) w.reset(); for (auto &w : scan_workers) w.reset(); gpu_lane_release(lane); }
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &e) { size_t base = n / world, rem = n % world; b = rank * base + (rank < rem ? rank : rem); e = b + base + (rank < rem ? 1 : 0); }
@@ -358,6 +361,25 @@ size_t Prover::num_variables() const { return impl->nv; }
 size_t Prover::num_inputs() const { return impl->ni; }
 size_t Prover::domain_size() const { return impl->m; }
 
+// 64 consecutive field elements -> two bit masks: "equals one" and "neither zero nor one" (Prover::set_witness).  The scan of a 7.3 MB assignment is on the critical path
+// of every host-buffer proof; with 256-bit loads an element is three instructions instead of a dozen 64-bit ones.
+static void classify_block64_scalar(const uint64_t *v, const uint64_t (&o1)[4], uint64_t &mo, uint64_t &mx) {
+  for (size_t i = 0; i < 64; i++, v += 4) {
+    const uint64_t nz = (v[0] | v[1] | v[2] | v[3]) != 0, is1 = ((v[0] ^ o1[0]) | (v[1] ^ o1[1]) | (v[2] ^ o1[2]) | (v[3] ^ o1[3])) == 0;
+    mo |= is1 << i; mx |= (nz & (is1 ^ 1)) << i; } }
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void classify_block64_avx2(const uint64_t *v, const uint64_t (&o1)[4], uint64_t &mo, uint64_t &mx) {
+  const __m256i one = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(o1));
+  for (size_t i = 0; i < 64; i++, v += 4) {
+    const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(v)), d = _mm256_xor_si256(x, one);
+    const uint64_t z = (uint64_t)_mm256_testz_si256(x, x), is1 = (uint64_t)_mm256_testz_si256(d, d);            // testz: 1 if all bits are zero
+    mo |= is1 << i; mx |= ((z | is1) ^ 1) << i; } }
+static void classify_block64(const uint64_t *v, const uint64_t (&o1)[4], uint64_t &mo, uint64_t &mx) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) classify_block64_avx2(v, o1, mo, mx); else classify_block64_scalar(v, o1, mo, mx); }
+#else
+static void classify_block64(const uint64_t *v, const uint64_t (&o1)[4], uint64_t &mo, uint64_t &mx) { classify_block64_scalar(v, o1, mo, mx); }
+#endif
 void Prover::set_witness(const Fe32 *z, bool montgomery) {
   Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); const size_t n = p.nv + 1, words = (n + 63) / 64;
   Fe32 one; if (montgomery) memcpy(&one, FrParams::R1, 32); else { memset(&one, 0, 32); one.l[0] = 1; }
@@ -367,10 +389,16 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   uint8_t *pk = reinterpret_cast<uint8_t *>(p.z_host.get()); uint64_t *ones = (uint64_t *)pk, *other = ones + words; uint32_t *off = (uint32_t *)(other + words);
   const size_t vals_at = ((words * 20 + 31) / 32) * 32; Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
   uint64_t o1[4]; memcpy(o1, &one, 32); const uint64_t *zz = reinterpret_cast<const uint64_t *>(z) - 4;   // zz + 4 i = entry i of [ONE, z_1 .. z_n]; entry 0 is handled apart
-  constexpr size_t T = 4; const size_t cap_t = max_other / T; size_t used[T] = {0, 0, 0, 0}; bool fits[T] = {true, true, true, true};   // (six and eight threads were measured: no faster, the wake-ups cost what the extra threads gain)
+  // (round 3 measured six and eight threads no faster than four — on assignments that sat in the host's last-level cache.  bench.py cycles through 400 MB of distinct
+  // assignments: each scan then streams 7.3 MB from DRAM, a core sustains ~10 GB/s of that, and eight threads halve the 0.17 ms; hosts with fewer than 12 cores keep four)
+  constexpr size_t TMAX = 8; static const size_t T_many = [] { const char *e = getenv("ZK_SCAN_THREADS"); size_t t = e ? (size_t)atoi(e) : (std::thread::hardware_concurrency() >= 12 ? 8 : 4); return t < 1 ? (size_t)1 : t > TMAX ? TMAX : t; }();
+  static std::atomic<int> scanning{0}; struct Busy { std::atomic<int> &c; int before; explicit Busy(std::atomic<int> &c_) : c(c_), before(c.fetch_add(1)) {} ~Busy() { c.fetch_sub(1); } } busy(scanning);
+  const size_t T = busy.before == 0 ? T_many : std::min<size_t>(T_many, 4);   // several provers handing over at once (proofs in flight): four threads each, as before
+  const size_t cap_t = max_other / T; size_t used[TMAX] = {0, 0, 0, 0, 0, 0, 0, 0}; bool fits[TMAX] = {true, true, true, true, true, true, true, true};
   auto scan = [&](size_t t) { const size_t w0 = words * t / T, w1 = words * (t + 1) / T, base = t * cap_t; size_t n_other = 0;
     for (size_t w = w0; w < w1; w++) { uint64_t mo = 0, mx = 0; const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; off[w] = (uint32_t)(base + n_other);
-      for (size_t i = lo ? lo : 1; i < hi; i++) { const uint64_t *v = zz + 4 * i;                                // branch-free classification of the block
+      if (lo && hi - lo == 64) classify_block64(zz + 4 * lo, o1, mo, mx);                                         // a whole block: 256-bit loads where the host has them
+      else for (size_t i = lo ? lo : 1; i < hi; i++) { const uint64_t *v = zz + 4 * i;                           // branch-free classification of a ragged block
         const uint64_t nz = (v[0] | v[1] | v[2] | v[3]) != 0, is1 = ((v[0] ^ o1[0]) | (v[1] ^ o1[1]) | (v[2] ^ o1[2]) | (v[3] ^ o1[3])) == 0; mo |= is1 << (i - lo); mx |= (nz & (is1 ^ 1)) << (i - lo); }
       if (!lo) mo |= 1;                                                                                          // the constant ONE
       const size_t cnt = (size_t)__builtin_popcountll(mx); if (n_other + cnt > cap_t) { fits[t] = false; return; }
@@ -378,7 +406,7 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
       ones[w] = mo; other[w] = mx; }
     used[t] = n_other; };
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
-  auto worker = [&](size_t t) -> SubmitWorker & { if (!p.workers[t]) p.workers[t].reset(new SubmitWorker(p.lane)); return *p.workers[t]; };
+  auto worker = [&](size_t t) -> SubmitWorker & { std::unique_ptr<SubmitWorker> &w = t < 4 ? p.workers[t] : p.scan_workers[t - 4]; if (!w) w.reset(new SubmitWorker(p.lane)); return *w; };   // threads 1 .. 3: the MSMs' submit threads; 4 .. 7: scan only
   if (threaded && words >= 512) { for (size_t t = 1; t < T; t++) worker(t).post([&scan, t] { scan(t); }); scan(0); for (size_t t = 1; t < T; t++) worker(t).wait(); }
   else for (size_t t = 0; t < T; t++) scan(t);
   static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;   // (test switch: the plain-copy branch below, which no BlockMaze assignment reaches on its own)
@@ -392,17 +420,34 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
 void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
   Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); const size_t n = p.nv + 1, words = (n + 63) / 64; Fe32 one; memcpy(&one, FrParams::R1, 32);
   uint8_t *pk = reinterpret_cast<uint8_t *>(p.z_host.get()); uint64_t *ones = (uint64_t *)pk, *other = ones + words; uint32_t *off = (uint32_t *)(other + words);   // the layout set_witness builds
-  const size_t vals_at = ((words * 20 + 31) / 32) * 32; Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4; size_t n_other = 0; bool fits = true;
+  const size_t vals_at = ((words * 20 + 31) / 32) * 32; Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
   constexpr uint64_t LSB = 0x0101010101010101ull, GATHER = 0x0102040810204080ull;              // (y & LSB) * GATHER >> 56: the low bits of 8 bytes as one byte
-  for (size_t w = 0; w < words && fits; w++) { const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; uint64_t mo = 0, mx = 0; off[w] = (uint32_t)n_other;
-    if (hi - lo == 64) for (size_t k = 0; k < 8; k++) { uint64_t x; memcpy(&x, tag + lo + 8 * k, 8); mo |= (((x & LSB) * GATHER) >> 56) << (8 * k); mx |= ((((x >> 1) & LSB) * GATHER) >> 56) << (8 * k); }
-    else for (size_t i = lo; i < hi; i++) { mo |= (uint64_t)(tag[i] & 1) << (i - lo); mx |= (uint64_t)((tag[i] >> 1) & 1) << (i - lo); }
-    if (n_other + (size_t)__builtin_popcountll(mx) > max_other) { fits = false; break; }
-    for (uint64_t m = mx; m; m &= m - 1) vals[n_other++] = wide[lo + (size_t)__builtin_ctzll(m)];
-    ones[w] = mo; other[w] = mx; }
-  static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;
-  if (fits && !force_dense) { upload_async(p.packed.get(), pk, vals_at + 32 * n_other); expand_witness_dev(p.packed.get(), words, one, false, n, p.z.get(), p.tags.get(), p.other_vars.get()); p.tags_valid = true; p.n_other = (uint32_t)n_other; }
-  else { Fe32 *h = p.z_host.get(); Fe32 zero; memset(&zero, 0, 32); for (size_t i = 0; i < n; i++) h[i] = tag[i] == 2 ? wide[i] : tag[i] ? one : zero; upload_async(p.z.get(), h, 32 * n); p.tags_valid = false; }   // a dense assignment (never a BlockMaze one)
+  // like set_witness: the prover's submit threads — idle at this point of a call — take a quarter of the words each (0.28 -> 0.1 ms for send on the GPU box's host); every
+  // thread owns a quarter of the value area, closed up afterwards
+  constexpr size_t T = 4; const size_t cap_t = max_other / T; size_t used[T] = {0, 0, 0, 0}; bool fits_t[T] = {true, true, true, true};
+  auto scan = [&](size_t t) { const size_t w0 = words * t / T, w1 = words * (t + 1) / T, base = t * cap_t; size_t n_other = 0;
+    for (size_t w = w0; w < w1; w++) { const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; uint64_t mo = 0, mx = 0; off[w] = (uint32_t)(base + n_other);
+      if (hi - lo == 64) for (size_t k = 0; k < 8; k++) { uint64_t x; memcpy(&x, tag + lo + 8 * k, 8); mo |= (((x & LSB) * GATHER) >> 56) << (8 * k); mx |= ((((x >> 1) & LSB) * GATHER) >> 56) << (8 * k); }
+      else for (size_t i = lo; i < hi; i++) { mo |= (uint64_t)(tag[i] & 1) << (i - lo); mx |= (uint64_t)((tag[i] >> 1) & 1) << (i - lo); }
+      if (n_other + (size_t)__builtin_popcountll(mx) > cap_t) { fits_t[t] = false; return; }
+      for (uint64_t m = mx; m; m &= m - 1) { const size_t i = lo + (size_t)__builtin_ctzll(m);
+        if (tag[i] == 6) { const HFr v = HFr::from_u64(wide[i].l[0] | (uint64_t)wide[i].l[1] << 32); memcpy(&vals[base + n_other++], v.l, 32); }   // a small integer the board kept as it was (circuit::Board::TAG_SMALL): its Montgomery form is made here, on the scan threads
+        else vals[base + n_other++] = wide[i]; }
+      ones[w] = mo; other[w] = mx; }
+    used[t] = n_other; };
+  static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
+  auto worker = [&](size_t t) -> SubmitWorker & { if (!p.workers[t]) p.workers[t].reset(new SubmitWorker(p.lane)); return *p.workers[t]; };
+  if (threaded && words >= 512) { for (size_t t = 1; t < T; t++) worker(t).post([&scan, t] { scan(t); }); scan(0); for (size_t t = 1; t < T; t++) worker(t).wait(); }
+  else for (size_t t = 0; t < T; t++) scan(t);
+  bool fits = true; for (size_t t = 0; t < T; t++) fits = fits && fits_t[t];
+  static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr; static const bool trace = getenv("ZK_TRACE_TIMES") != nullptr; const double t1 = now_ms();
+  if (fits && !force_dense) {
+    size_t n_other = used[0];
+    for (size_t t = 1; t < T; t++) { if (used[t]) { const uint32_t delta = (uint32_t)(t * cap_t - n_other); memmove(&vals[n_other], &vals[t * cap_t], 32 * used[t]); for (size_t w = words * t / T; w < words * (t + 1) / T; w++) off[w] -= delta; } n_other += used[t]; }
+    const double t2 = now_ms(); upload_async(p.packed.get(), pk, vals_at + 32 * n_other); const double t3 = now_ms();
+    expand_witness_dev(p.packed.get(), words, one, false, n, p.z.get(), p.tags.get(), p.other_vars.get()); p.tags_valid = true; p.n_other = (uint32_t)n_other;
+    if (trace) fprintf(stderr, "trace-handover: scan %.3f close-up %.3f copy call %.3f (%zu bytes) expand launch %.3f ms\n", t1 - t0, t2 - t1, t3 - t2, vals_at + 32 * n_other, now_ms() - t3); }
+  else { Fe32 *h = p.z_host.get(); Fe32 zero; memset(&zero, 0, 32); for (size_t i = 0; i < n; i++) { if (tag[i] == 6) { const HFr v = HFr::from_u64(wide[i].l[0] | (uint64_t)wide[i].l[1] << 32); memcpy(&h[i], v.l, 32); } else h[i] = tag[i] == 2 ? wide[i] : tag[i] ? one : zero; } upload_async(p.z.get(), h, 32 * n); p.tags_valid = false; }   // a dense assignment (never a BlockMaze one)
   last.upload_ms = now_ms() - t0;
 }
 struct RsTerms { HFr r, s; HG1 r_delta, s_delta, rs_delta_neg; HG2 s_delta2; };

@@ -67,7 +67,7 @@ class Prover {                                    // a proving key resident in H
   bool prove(const Fe32 *z, const Fe32 *r, const Fe32 *s, Proof &out) { set_witness(z, false); return prove_resident(r, s, out); }
   // the two halves of prove(): hand the assignment over (canonical, or already in Montgomery form as the circuit boards hold it), then prove from HBM
   void set_witness(const Fe32 *z, bool montgomery);
-  // the same assignment as one byte per entry — 0, 1, or 2 = "see wide[i]" — entry 0 being the constant ONE (circuit::Board's own form; wide in Montgomery form)
+  // the same assignment as one byte per entry — 0, 1, 2 = "see wide[i]" (Montgomery form) or 6 = "the small integer in the low 64 bits of wide[i]" — entry 0 being the constant ONE (circuit::Board's own form)
   void set_witness_tagged(const uint8_t *tag, const Fe32 *wide);
   bool prove_resident(const Fe32 *r, const Fe32 *s, Proof &out);
   // partial multi-exponentiation results of this shard, affine canonical: eA(64) eB1(64) eH(64) eL(64) eB2(128) = 384 bytes.  false if z is unsatisfying.

@@ -135,32 +135,39 @@ __device__ __forceinline__ QPoint29 block_quad29_tree(QPoint29 acc, Point29Rec *
   return acc;
 }
 
-// how the weights are cut: w = hi * 2^lo_bits + lo
-struct HtailShape { uint32_t top, lo_bits, hi_bits; };
+__device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq> *slot, MsmCounters *cnt);
+// how the weights are cut: w = hi * 2^lo_bits + lo.  A row (2^lo_bits consecutive buckets) is added up in `row_chunks` pieces of at most HTAIL_CHUNK buckets, a workgroup
+// each, so that no quad of the marginal kernel holds more than two buckets: 1 + 6 dependent additions for rows and columns alike.
+constexpr uint32_t HTAIL_CHUNK = 128;
+struct HtailShape { uint32_t top, lo_bits, hi_bits, row_chunks; };
 __host__ __device__ inline HtailShape htail_shape(uint32_t NB) {
   HtailShape s; s.top = 0;
   while ((1u << s.top) < NB) s.top++;
   s.lo_bits = (s.top + 1) / 2; s.hi_bits = s.top - s.lo_bits;
+  s.row_chunks = (1u << s.lo_bits) > HTAIL_CHUNK ? (1u << s.lo_bits) / HTAIL_CHUNK : 1u;
   return s;
 }
-// marginal sums: marg[lo] = C_lo for lo = 1 .. L - 1 (slot 0 unused), marg[L + hi] = R_hi for hi = 1 .. 2^hi_bits (slot L unused; R_(2^hi_bits) = bucket NB - 1)
-__host__ __device__ inline uint32_t htail_marg_count(const HtailShape &s) { return (1u << s.lo_bits) + (1u << s.hi_bits) + 1; }
+// marginal sums: marg[lo] = C_lo for lo = 1 .. L - 1 (slot 0 unused); marg[L + hi * row_chunks + j] = piece j of R_hi for hi = 1 .. H - 1; marg[L + H * row_chunks] =
+// R_H = bucket NB - 1 (the only bucket of that row)
+__host__ __device__ inline uint32_t htail_marg_count(const HtailShape &s) { return (1u << s.lo_bits) + ((1u << s.hi_bits)) * s.row_chunks + 1; }
+__host__ __device__ inline uint32_t htail_marg_blocks(const HtailShape &s) { return ((1u << s.lo_bits) - 1) + ((1u << s.hi_bits) - 1) * s.row_chunks + 1; }
 
-// k_hmarg29: workgroup g < L - 1: column lo = g + 1 — the 2^hi_bits buckets of weight hi * L + lo; workgroup L - 1 + g: row hi = g + 1 — the L buckets of weight
-// hi * L + lo, lo = 0 .. L - 1 (consecutive); the last workgroup copies bucket NB - 1 into the slot of R_(2^hi_bits).  Every quad takes `per` buckets, then the tree.
+// k_hmarg29: workgroup g < L - 1: column lo = g + 1 — the H buckets of weight hi * L + lo; then (H - 1) * row_chunks workgroups: piece j of row hi — buckets of weight
+// hi * L + lo, lo = j * L / row_chunks .. (consecutive); the last workgroup copies bucket NB - 1 into the slot of R_H.  A quad takes one or two buckets, then the tree.
 template <int UNIT>   // (a template only so that the one translation unit that launches it instantiates it)
 __global__ void __launch_bounds__(256) k_hmarg29(const Point29Rec *__restrict__ buckets, uint32_t NB, Point29Rec *__restrict__ marg) {
   __shared__ Point29Rec lds[4];
   const HtailShape sh = htail_shape(NB);
-  const uint32_t L = 1u << sh.lo_bits, H = 1u << sh.hi_bits, g = blockIdx.x, q = threadIdx.x >> 2;
+  const uint32_t L = 1u << sh.lo_bits, H = 1u << sh.hi_bits, RC = sh.row_chunks, g = blockIdx.x, q = threadIdx.x >> 2;
   const int k = threadIdx.x & 3;
-  if (g == (L - 1) + (H - 1)) {
-    if (threadIdx.x < 4) quad29_store(marg + L + H, quad29_load(buckets + NB - 1, k), k);
+  if (g == (L - 1) + (H - 1) * RC) {
+    if (threadIdx.x < 4) quad29_store(marg + L + H * RC, quad29_load(buckets + NB - 1, k), k);
     return;
   }
   const bool column = g < L - 1;
-  const uint32_t count = column ? H : L;                                               // buckets to add up
-  const uint32_t first = column ? g + 1 : (g - (L - 1) + 1) * L;                       // weight of the first one ...
+  const uint32_t rg = g - (L - 1), hi = rg / RC + 1, piece = rg % RC;                 // (rows only)
+  const uint32_t count = column ? H : L / RC;                                          // buckets to add up
+  const uint32_t first = column ? g + 1 : hi * L + piece * (L / RC);                   // weight of the first one ...
   const uint32_t step = column ? L : 1;                                                // ... and the distance to the next
   QPoint29 acc = quad29_inf();
   if (q < count) {
@@ -169,11 +176,11 @@ __global__ void __launch_bounds__(256) k_hmarg29(const Point29Rec *__restrict__ 
     for (uint32_t j = q + 64; j < count; j += 64) acc = quad29_add(acc, quad29_load(buckets + (first + j * step - 1), k), k);
   }
   acc = block_quad29_tree(acc, lds, min(count, 64u));
-  if (threadIdx.x < 4) quad29_store(marg + (column ? g + 1 : L + (g - (L - 1) + 1)), acc, k);
+  if (threadIdx.x < 4) quad29_store(marg + (column ? g + 1 : L + hi * RC + piece), acc, k);
 }
 
 // k_hbits29: workgroup s: T_s from the marginal sums — for s < lo_bits the C_lo with bit s of lo set ("i with a one inserted at bit s", i < L / 2), for
-// lo_bits <= s < top the R_hi with bit s - lo_bits of hi set (i < H / 2), for s = top the one record R_H.  The result leaves the 29-bit domain here: every lane converts
+// lo_bits <= s < top the pieces of the R_hi with bit s - lo_bits of hi set (i < H / 2, row_chunks pieces each), for s = top the one record R_H.  The result leaves the 29-bit domain here: every lane converts
 // its coordinate (a product with 2^256 mod p: the lazy 8 x 32-bit form of field.cuh, normalized) and stores its 32 bytes of res[s] — pinned host memory.  A result with
 // ZZ = 0 (mod p) that is not the point at infinity raises the flag of the one-pass path (MsmCounters::pad[0]); the last workgroup to finish hands the counters to the host.
 template <int UNIT>
@@ -184,11 +191,12 @@ __global__ void __launch_bounds__(256) k_hbits29(const Point29Rec *__restrict__ 
   const int k = threadIdx.x & 3;
   QPoint29 acc = quad29_inf();
   if (s_ == sh.top) {
-    if (q == 0) acc = quad29_load(marg + L + H, k);
+    if (q == 0) acc = quad29_load(marg + L + H * sh.row_chunks, k);
   } else {
     const bool cols = s_ < sh.lo_bits;
-    const uint32_t bit = cols ? s_ : s_ - sh.lo_bits, count = (cols ? L : H) >> 1, base = cols ? 0 : L;
-    auto item = [&](uint32_t i) { return base + (((i >> bit) << (bit + 1)) | (1u << bit) | (i & ((1u << bit) - 1))); };
+    const uint32_t bit = cols ? s_ : s_ - sh.lo_bits, RC = cols ? 1u : sh.row_chunks, count = ((cols ? L : H) >> 1) * RC;
+    auto with_bit = [&](uint32_t i) { return ((i >> bit) << (bit + 1)) | (1u << bit) | (i & ((1u << bit) - 1)); };   // "i with a one inserted at `bit`"
+    auto item = [&](uint32_t j) { return cols ? with_bit(j) : L + with_bit(j / RC) * RC + j % RC; };
     if (q < count) {
       acc = quad29_load(marg + item(q), k);
 #pragma unroll 1
@@ -196,20 +204,80 @@ __global__ void __launch_bounds__(256) k_hbits29(const Point29Rec *__restrict__ 
     }
     acc = block_quad29_tree(acc, lds, min(count, 64u));
   }
-  if (threadIdx.x < 4) {
-    Fq out = Fq::zero();
-    bool bad = false;
-    if (!acc.inf) {
-      acc.c.to_words(out.l);
-      bad = k == 2 && out.is_zero_lazy();                                               // ZZ = 0 (mod p) in something that is not the point at infinity
-      out = out.normalize();
-    }
-    if (bad) atomicOr(&cnt->pad[0], 1u);
-    reinterpret_cast<Fq *>(res + s_)[k] = out;
-  }
+  if (threadIdx.x < 4) quad29_emit(acc, k, res + s_, cnt);                                // (ZZ = 0 mod p in something that is not the point at infinity raises the flag)
   if (threadIdx.x == 0) {
     __threadfence();
-    if (atomicAdd(&cnt->pad[1], 1u) == gridDim.x - 1) { __threadfence(); *copy_dst = *reinterpret_cast<const uint4 *>(cnt); }
+    if (atomicAdd(&cnt->pad[1], 1u) == gridDim.x - 1) { __threadfence(); *copy_dst = *reinterpret_cast<const uint4 *>(cnt); cnt->pad[1] = 0; }   // (the ticket is left at zero: MSMs that share a sort share these counters)
+  }
+}
+
+// ---- the G1 witness MSMs (A, L*, B1) on the same arithmetic (round 4) ------------------------------------------------------------------------------------------------
+// k_wacc_lanes29 (msm.cuh) leaves one Point29Rec per lane; here the two cooperative stages that follow it, the 29-bit forms of k_wacc_fold and k_wtail:
+//   k_wfold29   workgroup b < NB: bucket b = the sum of its lanes' partial sums (lane_off says where they lie); workgroup NB + g: 256 of the ones lanes;
+//   k_wtail29   workgroup s < top: S_s = the sum of the NB / 2 buckets whose weight has bit s (a quad each, then the tree); workgroup top: bucket NB - 1 and the unused
+//               slots; workgroup top + 1: the sum of the ones' partial sums.  Every result leaves the 29-bit domain through the conversion of k_hbits29, a degenerate one
+//               (ZZ = 0 mod p) raises the flag that sends the MSM to the general path, the last workgroup to finish hands the counters to the host.
+__device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq> *slot, MsmCounters *cnt) {   // quad 0 of a workgroup: the result as 8 x 32-bit words
+  Fq out = Fq::zero();
+  bool bad = false;
+  if (!acc.inf) {
+    acc.c.to_words(out.l);
+    bad = k == 2 && out.is_zero_lazy();
+    out = out.normalize();
+  }
+  if (bad) atomicOr(&cnt->pad[0], 1u);
+  reinterpret_cast<Fq *>(slot)[k] = out;
+}
+template <int UNIT>
+__global__ void __launch_bounds__(256) k_wfold29(const Point29Rec *__restrict__ partial, const uint32_t *__restrict__ lane_off, uint32_t NB, uint32_t bucket_lanes, Point29Rec *__restrict__ out) {
+  __shared__ Point29Rec lds[4];
+  const uint32_t b = blockIdx.x, q = threadIdx.x >> 2;
+  const int k = threadIdx.x & 3;
+  uint32_t beg, len;
+  if (b < NB) { beg = lane_off[b]; len = lane_off[b + 1] - beg; } else { beg = bucket_lanes + (b - NB) * 256; len = 256; }
+  QPoint29 acc = quad29_inf();
+  if (q < len) {
+    acc = quad29_load(partial + beg + q, k);
+#pragma unroll 1
+    for (uint32_t j = q + 64; j < len; j += 64) acc = quad29_add(acc, quad29_load(partial + beg + j, k), k);
+  }
+  acc = block_quad29_tree(acc, lds, min(len, 64u));
+  if (threadIdx.x < 4) quad29_store(out + b, acc, k);
+}
+template <int UNIT>
+__global__ void __launch_bounds__(256) k_wtail29(const Point29Rec *__restrict__ buckets, uint32_t NB, const Point29Rec *__restrict__ ones_partial, uint32_t n_ones_partial, uint32_t slots, XYZZ<Fq> *__restrict__ res,
+                                                 MsmCounters *cnt, uint4 *copy_dst) {
+  __shared__ Point29Rec lds[4];
+  const uint32_t q = threadIdx.x >> 2, s_ = blockIdx.x, half = NB >> 1;
+  uint32_t top = 0;
+  while ((1u << top) < NB) top++;
+  const int k = threadIdx.x & 3;
+  QPoint29 acc = quad29_inf();
+  uint32_t slot = s_;
+  if (s_ == top + 1) {                                                                  // the ones
+    if (q < n_ones_partial) {
+      acc = quad29_load(ones_partial + q, k);
+#pragma unroll 1
+      for (uint32_t j = q + 64; j < n_ones_partial; j += 64) acc = quad29_add(acc, quad29_load(ones_partial + j, k), k);
+    }
+    acc = block_quad29_tree(acc, lds, min(n_ones_partial, 64u));
+    slot = slots;
+  } else if (s_ == top) {                                                               // weight NB: one bucket; slots above `top` hold the point at infinity
+    if (q == 0) acc = quad29_load(buckets + NB - 1, k);
+    if (threadIdx.x >= 4 && threadIdx.x < 4 * (slots - top)) reinterpret_cast<Fq *>(res + top + (threadIdx.x >> 2))[k] = Fq::zero();
+  } else {
+    auto bucket_of = [&](uint32_t i) { return (((i >> s_) << (s_ + 1)) | (1u << s_) | (i & ((1u << s_) - 1))) - 1; };
+    if (q < half) {
+      acc = quad29_load(buckets + bucket_of(q), k);
+#pragma unroll 1
+      for (uint32_t j = q + 64; j < half; j += 64) acc = quad29_add(acc, quad29_load(buckets + bucket_of(j), k), k);
+    }
+    acc = block_quad29_tree(acc, lds, min(half, 64u));
+  }
+  if (threadIdx.x < 4) quad29_emit(acc, k, res + slot, cnt);
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&cnt->pad[1], 1u) == gridDim.x - 1) { __threadfence(); *copy_dst = *reinterpret_cast<const uint4 *>(cnt); cnt->pad[1] = 0; }   // (the ticket is left at zero: MSMs that share a sort share these counters)
   }
 }
 

@@ -666,6 +666,189 @@ __global__ void __launch_bounds__(256) k_wacc_lanes(const Affine<F> *__restrict_
     for (uint32_t i = beg; i < end; i++) { Affine<F> pn = points[vn & ~MSM_ENTRY_SIGN]; uint32_t vnn = i + 2 < end ? e[i + 2] : vn; if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; vn = vnn; } }
   partial[t] = acc;
 }
+// The lane-serial accumulation of a G1 witness MSM on 29-bit limbs (round 4): k_wacc_lanes with the arithmetic of k_hacc_runs29 — the same madd-2008-s in two steps, 2,275
+// instructions instead of ~4,400 — gathering from the tables with coordinates x 2^261 (Bases::points261 / groups261) and leaving a Point29Rec per lane for k_wfold29 /
+// k_wtail29 (htail29.cuh).  Incomplete formulas: an operand equal to +-the accumulator leaves ZZ = 0 (mod p), which travels through the fold and the tail to a result slot,
+// where k_wtail29 flags it (the MSM is then repeated on the general path).
+template <int UNIT>
+__global__ void __launch_bounds__(256) k_wacc_lanes29(const Affine<Fq> *__restrict__ points261, const Affine<Fq> *__restrict__ groups261, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap, uint32_t NB,
+                                                      const uint32_t *__restrict__ ones, const MsmCounters *cnt, Point29Rec *__restrict__ partial, uint32_t *__restrict__ lane_off) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t m_of[WFUSED_MAX_BUCKETS], off[WFUSED_MAX_BUCKETS + 1], slice;
+  const bool ones_lane = t >= WFUSED_BUCKET_LANES;                                       // (whole workgroups: 4096 is a multiple of 256)
+  if (!ones_lane) {
+    if (threadIdx.x < NB) m_of[threadIdx.x] = min(fill[threadIdx.x], cap);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (uint32_t b = 0; b < NB; b++) tot += m_of[b];
+      const uint32_t T = max(WFUSED_MIN_SLICE, (tot + (WFUSED_BUCKET_LANES - NB) - 1) / (WFUSED_BUCKET_LANES - NB));
+      uint32_t o = 0;
+      for (uint32_t b = 0; b < NB; b++) { off[b] = o; o += (m_of[b] + T - 1) / T; }
+      off[NB] = o; slice = T;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x <= NB) lane_off[threadIdx.x] = off[threadIdx.x];
+  }
+  const uint32_t *list = ones; const Affine<Fq> *table = groups261; uint32_t first = 0, n_items = 0, stride = 1;   // the lane's list: n_items table indices, `stride` apart
+  if (ones_lane) {
+    const uint32_t u = t - WFUSED_BUCKET_LANES, n1 = cnt->n_ones;
+    if (u >= WFUSED_ONES_LANES) return;
+    first = u; stride = WFUSED_ONES_LANES; n_items = u < n1 ? (n1 - u + stride - 1) / stride : 0;
+  } else {
+    if (t >= off[NB]) return;
+    uint32_t lo = 0, hi = NB;                                                             // the bucket b with off[b] <= t < off[b + 1]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= t) lo = mid; else hi = mid; }
+    const uint32_t beg = (t - off[lo]) * slice, end = min(m_of[lo], beg + slice);
+    list = entries + (size_t)lo * cap; table = points261; first = beg; n_items = end > beg ? end - beg : 0;
+  }
+  XYZZ29 acc; bool inf = true;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { acc.X.l[i] = 0; acc.Y.l[i] = 0; acc.ZZ.l[i] = 0; acc.ZZZ.l[i] = 0; }
+  if (n_items) {
+    uint32_t v = list[first];
+    Affine<Fq> p = table[v & ~MSM_ENTRY_SIGN];
+#pragma unroll 1
+    for (uint32_t i = 0; i < n_items; i++) {
+      uint32_t vn = v; Affine<Fq> pn = p;
+      if (i + 1 < n_items) { vn = list[first + (size_t)(i + 1) * stride]; pn = table[vn & ~MSM_ENTRY_SIGN]; }   // the next point's gather is in flight during this addition
+      if (!p.is_inf()) {
+        const Fq29 px = Fq29::unpack(p.x.l), py = Fq29::cond_neg(Fq29::unpack(p.y.l), (v >> 31) != 0);
+        if (inf) { acc.X = px; acc.Y = py.norm(); acc.ZZ = Fq29::one(); acc.ZZZ = Fq29::one(); inf = false; }
+        else { Fq29 Pv, Rv; acc.madd_head(px, py, Pv, Rv); acc.madd_tail(Pv, Rv); }
+      }
+      v = vn; p = pn;
+    }
+  }
+  const uint32_t z = inf ? 0u : ~0u;                                                     // the record of htail29.cuh: four coordinate slots of twelve words, all-zero = infinity
+  uint4 *dst = reinterpret_cast<uint4 *>(partial + t);
+  const Fq29 *coord[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
+#pragma unroll
+  for (int c4 = 0; c4 < 4; c4++) {
+    const Fq29 &w = *coord[c4];
+    dst[3 * c4] = make_uint4(w.l[0] & z, w.l[1] & z, w.l[2] & z, w.l[3] & z);
+    dst[3 * c4 + 1] = make_uint4(w.l[4] & z, w.l[5] & z, w.l[6] & z, w.l[7] & z);
+    dst[3 * c4 + 2] = make_uint4(w.l[8] & z, 0u, 0u, 0u);
+  }
+}
+// ---- the G2 witness MSM (the G2 half of the B query, kc_multiexp.tcc:21-85) accumulated lane by lane on 29-bit limbs -----------------------------------------------------
+// Round 2 left this accumulation quad-cooperative (k_wacc_quads<Fq2>): a lane-serial mixed addition over Fq2 on 8 x 32-bit limbs keeps ~450 registers alive.  On nine
+// 29-bit limbs it fits (an accumulator is 72 registers) and needs a quarter of the instructions: four lanes no longer repeat each other's sums and selects, a product has no
+// carry instruction, and a difference is nine additions and one carry step.  Fq2 = Fq[u] / (u^2 + 1):
+//   product   Karatsuba, three Fq products:  v0 = a0 b0, v1 = a1 b1, v2 = (a0 + a1)(b0 + b1);  c0 = v0 - v1, c1 = v2 - v0 - v1   (the two sums go into their product as
+//             they are: limbs below 2^30 + 16 on both sides still fit the 64-bit column);
+//   square    complex squaring, two Fq products:  c0 = (a0 + a1)(a0 - a1), c1 = 2 a0 a1;
+//   X3, Y3    one Barrett step per component (Fq29::barrett: below 4.1 p) so that the next addition's differences take the constants K_6.
+// Every constant of a difference and every value bound is checked by interval arithmetic in gen_field29.py (check_bounds_g2): X, Y < 4.1 p, ZZ / ZZZ < (3.2, 5.7) p per
+// component.  The formulas are incomplete like the H accumulation's: an operand equal to +-the accumulator leaves ZZ = 0 (mod p), which the lane finds when it stores its
+// sum and reports like a sort overflow — the MSM is then repeated on the general path (complete formulas, msm_impl.hpp: finish_sync).
+struct Fq2_29 { Fq29 c0, c1; };
+__device__ __forceinline__ Fq2_29 fq2_29_mul(const Fq2_29 &a, const Fq2_29 &b) {
+  const Fq29 v0 = Fq29::mul(a.c0, b.c0), v1 = Fq29::mul(a.c1, b.c1), v2 = Fq29::mul(Fq29::add_raw(a.c0, a.c1), Fq29::add_raw(b.c0, b.c1));
+  return {Fq29::sub<2>(v0, v1), Fq29::sub<4>(v2, Fq29::add_raw(v0, v1))};
+}
+__device__ __forceinline__ Fq2_29 fq2_29_sqr(const Fq2_29 &a) {                            // components of a below 12 p
+  const Fq29 m = Fq29::mul(a.c0, a.c1);
+  Fq29 twice;
+#pragma unroll
+  for (int i = 0; i < 9; i++) twice.l[i] = 2u * m.l[i];
+  return {Fq29::mul(Fq29::add_raw(a.c0, a.c1), Fq29::sub<12>(a.c0, a.c1)), twice.norm()};
+}
+template <int C0, int C1> __device__ __forceinline__ Fq2_29 fq2_29_sub(const Fq2_29 &a, const Fq2_29 &b) { return {Fq29::sub<C0>(a.c0, b.c0), Fq29::sub<C1>(a.c1, b.c1)}; }
+struct XYZZ2_29 {
+  Fq2_29 X, Y, ZZ, ZZZ;
+  // madd-2008-s; px canonical, py canonical or K_2 - y, both with normalized limbs
+  __device__ __forceinline__ void madd(const Fq2_29 &px, const Fq2_29 &py) {
+    const Fq2_29 P = fq2_29_sub<6, 6>(fq2_29_mul(px, ZZ), X), R = fq2_29_sub<6, 6>(fq2_29_mul(py, ZZZ), Y);
+    const Fq2_29 PP = fq2_29_sqr(P), PPP = fq2_29_mul(P, PP), Q = fq2_29_mul(X, PP), RR = fq2_29_sqr(R);
+    Fq2_29 s;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { s.c0.l[i] = PPP.c0.l[i] + 2u * Q.c0.l[i]; s.c1.l[i] = PPP.c1.l[i] + 2u * Q.c1.l[i]; }
+    Fq2_29 X3 = fq2_29_sub<12, 18>(RR, s);
+    X3 = {X3.c0.barrett(), X3.c1.barrett()};
+    Fq2_29 Y3 = fq2_29_sub<4, 6>(fq2_29_mul(R, fq2_29_sub<6, 6>(Q, X3)), fq2_29_mul(Y, PPP));
+    Y = {Y3.c0.barrett(), Y3.c1.barrett()};
+    X = X3; ZZ = fq2_29_mul(ZZ, PP); ZZZ = fq2_29_mul(ZZZ, PPP);
+  }
+};
+// a table point (coordinates x 2^261, canonical words) -> limbs; neg: the point's negative (y -> K_2 - y, normalized)
+__device__ __forceinline__ void g2_29_unpack(const Affine<Fq2> &p, bool neg, Fq2_29 &px, Fq2_29 &py) {
+  px = {Fq29::unpack(p.x.c0.l), Fq29::unpack(p.x.c1.l)};
+  py = {Fq29::cond_neg(Fq29::unpack(p.y.c0.l), neg).norm(), Fq29::cond_neg(Fq29::unpack(p.y.c1.l), neg).norm()};
+}
+// Lane-serial accumulation of the G2 witness MSM (the layout of k_wacc_lanes: the first WFUSED_BUCKET_LANES lanes share the buckets' entries in slices proportional to
+// the fill, the next WFUSED_ONES_LANES stride over the list of ones), from the tables with coordinates x 2^261 (points261 / groups261, k_table_to_r261_g2 at key load).
+// A lane's sum leaves the 29-bit domain when it is stored: eight products with 2^256 mod p give the lazy 8 x 32-bit form that k_wacc_fold<Fq2> adds up.
+template <int UNIT>   // (a template only so that the one translation unit that launches it instantiates it)
+__global__ void __launch_bounds__(256) k_wacc_lanes_g2_29(const Affine<Fq2> *__restrict__ points261, const Affine<Fq2> *__restrict__ groups261, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap,
+                                                          uint32_t NB, const uint32_t *__restrict__ ones, MsmCounters *cnt, XYZZ<Fq2> *__restrict__ partial, uint32_t *__restrict__ lane_off) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t m_of[WFUSED_MAX_BUCKETS], off[WFUSED_MAX_BUCKETS + 1], slice;
+  const bool ones_lane = t >= WFUSED_BUCKET_LANES;                                       // (whole workgroups: 4096 is a multiple of 256)
+  if (!ones_lane) {
+    if (threadIdx.x < NB) m_of[threadIdx.x] = min(fill[threadIdx.x], cap);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (uint32_t b = 0; b < NB; b++) tot += m_of[b];
+      const uint32_t T = max(WFUSED_MIN_SLICE, (tot + (WFUSED_BUCKET_LANES - NB) - 1) / (WFUSED_BUCKET_LANES - NB));
+      uint32_t o = 0;
+      for (uint32_t b = 0; b < NB; b++) { off[b] = o; o += (m_of[b] + T - 1) / T; }
+      off[NB] = o; slice = T;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x <= NB) lane_off[threadIdx.x] = off[threadIdx.x];
+  }
+  // the lane's list: n_items table indices, `stride` apart in `list`, from `table`
+  const uint32_t *list; const Affine<Fq2> *table; uint32_t first = 0, n_items = 0, stride = 1;
+  if (ones_lane) {
+    const uint32_t u = t - WFUSED_BUCKET_LANES, n1 = cnt->n_ones;
+    if (u >= WFUSED_ONES_LANES) return;
+    list = ones; table = groups261; first = u; stride = WFUSED_ONES_LANES; n_items = u < n1 ? (n1 - u + stride - 1) / stride : 0;
+  } else {
+    if (t >= off[NB]) return;
+    uint32_t lo = 0, hi = NB;                                                             // the bucket b with off[b] <= t < off[b + 1]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= t) lo = mid; else hi = mid; }
+    const uint32_t beg = (t - off[lo]) * slice, end = min(m_of[lo], beg + slice);
+    list = entries + (size_t)lo * cap; table = points261; first = beg; n_items = end > beg ? end - beg : 0;
+  }
+  XYZZ2_29 acc; bool inf = true;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { acc.X.c0.l[i] = acc.X.c1.l[i] = acc.Y.c0.l[i] = acc.Y.c1.l[i] = acc.ZZ.c0.l[i] = acc.ZZ.c1.l[i] = acc.ZZZ.c0.l[i] = acc.ZZZ.c1.l[i] = 0; }
+  if (n_items) {
+    uint32_t v = list[first];
+    Affine<Fq2> p = table[v & ~MSM_ENTRY_SIGN];
+#pragma unroll 1
+    for (uint32_t i = 0; i < n_items; i++) {
+      uint32_t vn = v; Affine<Fq2> pn = p;
+      if (i + 1 < n_items) { vn = list[first + (size_t)(i + 1) * stride]; pn = table[vn & ~MSM_ENTRY_SIGN]; }   // the next point's gather is in flight during this addition
+      if (!p.is_inf()) {
+        Fq2_29 px, py; g2_29_unpack(p, (v >> 31) != 0, px, py);
+        if (inf) { acc.X = px; acc.Y = py; acc.ZZ.c0 = Fq29::one(); acc.ZZZ.c0 = Fq29::one(); inf = false; }   // lift: ZZ = ZZZ = 1 (their u-components stay zero)
+        else acc.madd(px, py);
+      }
+      v = vn; p = pn;
+    }
+  }
+  XYZZ<Fq2> o = XYZZ<Fq2>::inf();
+  if (!inf) {
+    acc.X.c0.to_words(o.X.c0.l); acc.X.c1.to_words(o.X.c1.l); acc.Y.c0.to_words(o.Y.c0.l); acc.Y.c1.to_words(o.Y.c1.l);
+    acc.ZZ.c0.to_words(o.ZZ.c0.l); acc.ZZ.c1.to_words(o.ZZ.c1.l); acc.ZZZ.c0.to_words(o.ZZZ.c0.l); acc.ZZZ.c1.to_words(o.ZZZ.c1.l);
+    if (o.ZZ.c0.is_zero_lazy() && o.ZZ.c1.is_zero_lazy()) atomicOr(&cnt->pad[0], 1u);     // an operand was +-the accumulator somewhere: the general path repeats the MSM
+    o = XYZZ<Fq2>{{o.X.c0.normalize(), o.X.c1.normalize()}, {o.Y.c0.normalize(), o.Y.c1.normalize()}, {o.ZZ.c0.normalize(), o.ZZ.c1.normalize()}, {o.ZZZ.c0.normalize(), o.ZZZ.c1.normalize()}};
+  }
+  partial[t] = o;
+}
+// the G2 tables of the kernel above: coordinates x 2^261 (mod p) from x 2^256, component by component; (0, 0) stays the point at infinity
+static __global__ void k_table_to_r261_g2(const Affine<Fq2> *__restrict__ in, Affine<Fq2> *__restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fq c;
+#pragma unroll
+  for (int j = 0; j < 8; j++) c.l[j] = FQ_TWO261[j];
+  const Affine<Fq2> p = in[i];
+  out[i] = {{p.x.c0 * c, p.x.c1 * c}, {p.y.c0 * c, p.y.c1 * c}};
+}
 // workgroup b < NB: bucket b = the sum of its lanes' partial sums; workgroup NB + g: 256 of the ones lanes
 template <class F>
 __global__ void __launch_bounds__(256) k_wacc_fold(const XYZZ<F> *__restrict__ partial, const uint32_t *__restrict__ lane_off, uint32_t NB, XYZZ<F> *__restrict__ out) {

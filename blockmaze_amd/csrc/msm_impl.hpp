@@ -19,12 +19,12 @@ struct MsmImpl {
   size_t n; int c, W, WB; uint32_t NB;   // W digit windows; WB bucket arrays (1 when the multiples 2^(cw) P are precomputed, else W)
   bool filter_ones; uint32_t seg, n_ones_quads; std::string label = "msm"; int stream_id = -1;   // -1: main stream, 0..3: auxiliary stream
   // the key's points (with the fixed-base table when there is one) are immutable and shared by every prover object of the key on this device; everything else below is per-object workspace
-  struct Bases { size_t n = 0; int c = 0, W = 0, WB = 0; bool any_inf = false; DevBuf<RawAffine> points, points261 /* the same table with coordinates x 2^261: what k_hacc_runs29 gathers from (G1, uniform scalars, fixed-base table) */, ones_groups /* 15 subset sums per four consecutive points: what the fused witness path adds for the scalars equal to one */; DevBuf<uint8_t> inf; };
+  struct Bases { size_t n = 0; int c = 0, W = 0, WB = 0; bool any_inf = false; DevBuf<RawAffine> points, points261 /* the same table with coordinates x 2^261: what k_hacc_runs29 gathers from (G1, uniform scalars, fixed-base table) and k_wacc_lanes_g2_29 (G2 witness MSM) */, groups261 /* ones_groups in that form (G2) */, ones_groups /* 15 subset sums per four consecutive points: what the fused witness path adds for the scalars equal to one */; DevBuf<uint8_t> inf; };
   std::shared_ptr<const Bases> bases; const DevBuf<RawAffine> &points; const DevBuf<uint8_t> &inf; bool any_inf = false;
   bool split_ones = false; hipStream_t ones_stream = nullptr; hipEvent_t ev_classified = nullptr, ev_ones = nullptr;   // the ones path on a stream of its own, beside the bucket path (general path of the G2 MSM: both are long chains)
   const Fe32 *prod_b = nullptr, *prod_z = nullptr; bool prod_z_table = false; DevBuf<Fe32> prod_tmp;   // scalars given as a product a*b*z (run_product)
   // H query (uniform scalars, one bucket array): group-binned one-pass sort, accumulation over runs of h_run entries on 29-bit limbs, at most h_maxp pieces per bucket
-  bool hsort = false; HsortShape hs{0, 0, 0, 0}; DevBuf<uint32_t> group_fill, mid, group_n; uint32_t h_run = 12, h_maxp = 16;   // (run length swept on MI355X, accumulate + combine inside a send proof: 8: 0.397, 12: 0.382, 16: 0.402 ms, profiles/r03f_ab.txt)
+  bool hsort = false; HsortShape hs{0, 0, 0, 0}; DevBuf<uint32_t> group_fill, mid, group_n; uint32_t h_run = 12, h_maxp = 16;   // (run length swept on MI355X, accumulate + combine inside a send proof: 8: 0.397, 12: 0.382, 16: 0.402 ms, profiles/r03f_ab.txt; again in round 4 with the 29-bit tail, whole proof: 12: 1.038, 16: 1.052, 20: 1.057, 24: 1.090 ms, profiles/r04a_hrun_sweep.txt; window 15 / 16 / 17: 0.992 / 0.952 / 0.976 ms, profiles/r04d_ab.txt)
   // witness MSMs in three launches (k_wsort / k_wacc / k_wtail); needs the fixed-base tables and at most 128 buckets
   bool wfused = false, wacc_quads = false, ws_leader = true, overflow_noted = false; std::shared_ptr<WsortBuffers> ws;
   const Fe32 *last_scalars = nullptr; const uint32_t *last_index = nullptr;
@@ -50,11 +50,13 @@ struct MsmImpl {
   const MsmCounters *host_counters() const { return (const MsmCounters *)(h_result + (size_t)(RS + 1) * sizeof(XYZZ<F>)); }
   XYZZ<F> *bucket_array() { return reinterpret_cast<XYZZ<F> *>(buckets.get()); }
 
-  // Precomputed multiples 2^(cw) P unless switched off (ZK_MSM_PRECOMPUTE=0), the table would pass ZK_MSM_PRECOMPUTE_MAX_MB (default 768 MB: measured on MI355X, the
-  // random 64-byte gathers from a table far beyond the 256 MB Infinity Cache cost more than the smaller bucket reduction saves — deposit at depth 32: 9.1 ms
-  // without, 13.1 ms with 2-9 GB tables; send / mint / deposit-8 gain 1-5 %), or its indices would not fit the 31 bits of a sorted entry.
+  // Precomputed multiples 2^(cw) P unless switched off (ZK_MSM_PRECOMPUTE=0), the table would pass ZK_MSM_PRECOMPUTE_MAX_MB, or its indices would not fit the 31 bits of
+  // a sorted entry.  The cap was 768 MB through round 3 — round 1 had measured the depth-32 deposit key slower with its 2-9 GB of tables (13.1 against 9.1 ms), on the
+  // general-path kernels of that time.  With tables an MSM takes the fused paths (one bucket array: k_hsort_* / k_hacc_runs29 for the H query, k_wsort / k_wacc_* /
+  // k_wtail for the witness MSMs), which is worth far more than the gathers from a multi-GB table cost: depth-32 deposit 6.6 ms at 768 MB, 4.1 ms at 1.4 GB (H only),
+  // 3.27 ms from 3 GB on (all five queries; profiles/r04g_deposit32_caps.txt).  Default since round 4: 8 GB per table — a key's tables add up to ~14 GB at depth 32, of 288.
   static bool use_precompute(size_t n_, int W_) { static const bool on = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE"); return !e || atoi(e) != 0; }();
-    static const size_t cap = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE_MAX_MB"); return (size_t)(e ? atol(e) : 768) << 20; }();
+    static const size_t cap = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE_MAX_MB"); return (size_t)(e ? atol(e) : 8192) << 20; }();
     return on && n_ > 0 && W_ > 1 && n_ * (size_t)W_ < (1ull << 31) && n_ * (size_t)W_ * sizeof(RawAffine) <= cap; }
   static std::shared_ptr<const Bases> make_bases(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables, bool uniform_hint) {
     auto b = std::make_shared<Bases>(); b->n = n_; b->c = c_; b->W = msm_num_windows(c_); b->WB = tables && use_precompute(n_, b->W) ? 1 : b->W;
@@ -72,8 +74,20 @@ struct MsmImpl {
       hipLaunchKernelGGL(k_table_to_r261, dim3(cdiv(tn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq> *)b->points.get(), (Affine<Fq> *)b->points261.get(), tn); HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
     if (fo && b->WB == 1 && n_) { const size_t ng = (n_ + 3) / 4; b->ones_groups = DevBuf<RawAffine>(ng * 15);   // subset sums of four consecutive points for the scalars equal to one (k_ones_groups)
       hipLaunchKernelGGL((k_ones_groups<F>), dim3(cdiv(ng, 64)), dim3(64), 0, gpu().stream, (const Affine<F> *)b->points.get(), (uint32_t)n_, (Affine<F> *)b->ones_groups.get()); HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
+    if constexpr (sizeof(F) == 32) if (fo && b->WB == 1 && n_ && w29()) {   // a G1 witness MSM accumulates, folds and sums on 29-bit limbs: both tables once more with coordinates x 2^261
+      const size_t tn = n_ * (size_t)b->W, gn = b->ones_groups.size(); b->points261 = DevBuf<RawAffine>(tn); b->groups261 = DevBuf<RawAffine>(gn ? gn : 1);
+      hipLaunchKernelGGL(k_table_to_r261, dim3(cdiv(tn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq> *)b->points.get(), (Affine<Fq> *)b->points261.get(), tn);
+      if (gn) hipLaunchKernelGGL(k_table_to_r261, dim3(cdiv(gn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq> *)b->ones_groups.get(), (Affine<Fq> *)b->groups261.get(), gn);
+      HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
+    if constexpr (sizeof(F) == 64) if (fo && b->WB == 1 && n_ && g2_lanes29()) {   // the G2 witness MSM accumulates on 29-bit limbs: both tables once more with coordinates x 2^261
+      const size_t tn = n_ * (size_t)b->W, gn = b->ones_groups.size(); b->points261 = DevBuf<RawAffine>(tn); b->groups261 = DevBuf<RawAffine>(gn ? gn : 1);
+      hipLaunchKernelGGL(k_table_to_r261_g2, dim3(cdiv(tn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq2> *)b->points.get(), (Affine<Fq2> *)b->points261.get(), tn);
+      if (gn) hipLaunchKernelGGL(k_table_to_r261_g2, dim3(cdiv(gn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq2> *)b->ones_groups.get(), (Affine<Fq2> *)b->groups261.get(), gn);
+      HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
     return b;
   }
+  static bool w29() { static const bool on = [] { const char *e = getenv("ZK_WITNESS_G1_29"); return !e || atoi(e) != 0; }(); return on; }   // (0: round 2's 8 x 32-bit witness kernels for G1, kept for A/B)
+  static bool g2_lanes29() { static const bool on = [] { const char *e = getenv("ZK_G2_LANES29"); return !e || atoi(e) != 0; }(); return on; }   // (0: round 2's quad-cooperative G2 accumulation, kept for A/B)
   MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true, bool uniform_hint = false) : MsmImpl(make_bases(host_points, n_, c_, fo, tables, uniform_hint), fo, uniform_hint) {}
   MsmImpl(std::shared_ptr<const Bases> shared, bool fo, bool uniform_hint)
       : n(shared->n), c(shared->c), W(shared->W), WB(shared->WB), NB(1u << (shared->c - 1)), filter_ones(fo), bases(shared), points(shared->points), inf(shared->inf), any_inf(shared->any_inf),
@@ -88,7 +102,7 @@ struct MsmImpl {
       HIP_CHECK(hipEventCreateWithFlags(&ws->sorted, hipEventDisableTiming)); }
     max_tasks = (uint32_t)((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1);
     if (const char *e = getenv("ZK_MSM_H_RUN")) { const int v = atoi(e); if (v >= 4 && v <= 64) h_run = (uint32_t)v; }   // (tuning knob: entries per lane of the H accumulation)
-    if (bases->points261.size()) {   // group-binned one-pass sort: G groups of 2^low buckets, about 16 K entries per group (one workgroup sorts a group in registers + LDS)
+    if (sizeof(F) == 32 && uniform_hint && bases->points261.size()) {   // (G1, uniform scalars — G2 keeps a 261-form table for another purpose: k_wacc_lanes_g2_29) group-binned one-pass sort: G groups of 2^low buckets, about 16 K entries per group (one workgroup sorts a group in registers + LDS)
       size_t total = n * (size_t)W; uint32_t G = 256; while (G < HSORT_GROUPS && total / G > 16384) G <<= 1; uint32_t low = 0; while ((G << low) < NB) low++; uint32_t ib = 1; while (((size_t)1 << ib) < total) ib++;
       size_t region = ((total / G) * 5 / 4 + 1024 + 255) & ~(size_t)255; if (getenv("ZK_MSM_DIRECT_CAP")) region = 256;   // (test hook: regions far too small force the overflow fallback)
       if (W <= (int)HSORT_STAGE_W && (G << low) == NB && low >= 1 && low <= 10 && low + 1 + ib <= 32 && region <= (size_t)HSORT_GROUP_THREADS * HSORT_MAX_PER_THREAD) {
@@ -96,9 +110,9 @@ struct MsmImpl {
         const size_t lam = total / NB; h_maxp = (uint32_t)((lam + lam / 2 + 32 + h_run - 1) / h_run + 2); } }   // pieces per bucket: room for 1.5x the expected load + 32 entries
     { size_t nbk = (size_t)WB * NB; bsort_blocks = cdiv(nbk, BSORT_BLOCK); order = DevBuf<uint32_t>(nbk); rank_of = DevBuf<uint32_t>(nbk); block_hist = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); block_off = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); bsort_scanner.reset(new Scanner((size_t)bsort_blocks * BSORT_CLASSES)); }
     buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>));
-    partials = DevBuf<uint8_t>(std::max<size_t>(std::max<size_t>((size_t)max_tasks * sizeof(XYZZ<F>), hsort ? (size_t)NB * h_maxp * sizeof(Piece29) : 0), wfused ? ((size_t)WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) * sizeof(XYZZ<F>) : 0));
+    partials = DevBuf<uint8_t>(std::max<size_t>(std::max<size_t>((size_t)max_tasks * sizeof(XYZZ<F>), hsort ? (size_t)NB * h_maxp * sizeof(Piece29) : 0), wfused ? ((size_t)WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) * std::max(sizeof(XYZZ<F>), sizeof(Point29Rec)) : 0));
     seg_out = DevBuf<uint8_t>(std::max<size_t>((size_t)WB * (NB / seg), (size_t)32 * cdiv(NB, 512)) * sizeof(XYZZ<F>)); /* (also the chunk sums of the bit-sum tail: log2(NB) x NB/512) */ seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
-    ones_partial = DevBuf<uint8_t>(std::max<size_t>(n_ones_quads, wfused ? (size_t)NB + WFUSED_ONES_BLOCKS : 0) * sizeof(XYZZ<F>)); if (wfused) lane_off = DevBuf<uint32_t>(WFUSED_MAX_BUCKETS + 1); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
+    ones_partial = DevBuf<uint8_t>(std::max<size_t>(n_ones_quads, wfused ? (size_t)NB + WFUSED_ONES_BLOCKS : 0) * std::max(sizeof(XYZZ<F>), sizeof(Point29Rec))); if (wfused) lane_off = DevBuf<uint32_t>(WFUSED_MAX_BUCKETS + 1); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
     RS = WB; if (wfused) { bitsum = true; RS = WTAIL_SLOTS; }   // k_wtail leaves eight sums by weight bit
     else if (hsort && NB >= 512) { bitsum = true; RS = 1; while ((1u << (RS - 1)) < NB) RS++;   // RS = log2(NB) + 1
       static const bool tail29 = [] { const char *e = getenv("ZK_MSM_H_TAIL29"); return !e || atoi(e) != 0; }();   // (0: round 2's bit sums on 8 x 32-bit limbs, kept for A/B)
@@ -158,7 +172,16 @@ struct MsmImpl {
       uint4 *csrc = (uint4 *)(wc + w.parity); uint4 *cdst = (uint4 *)(res + RS + 1);
       XYZZ<F> *l2 = (XYZZ<F> *)ones_partial.get(); uint32_t n_op;                          // l2: [NB bucket sums | n_op partial sums of the ones]
       { Stage st((label + ".accumulate").c_str(), s); const uint32_t *fl = w.fill.get() + (size_t)w.parity * NB;
-        if (wacc_quads) { n_op = WFUSED_ONES_BLOCKS; hipLaunchKernelGGL((k_wacc_quads<F>), dim3(NB + WFUSED_ONES_BLOCKS), dim3(256), 0, s, (const Affine<F> *)points.get(), (const Affine<F> *)bases->ones_groups.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l2); }
+        if (wacc_quads && bases->points261.size()) { if constexpr (sizeof(F) == 64) { n_op = WFUSED_ONES_GROUPS; XYZZ<F> *l1 = (XYZZ<F> *)partials.get();   // G2, lane by lane on 29-bit limbs, then the same fold as G1
+          hipLaunchKernelGGL(k_wacc_lanes_g2_29<0>, dim3((WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) / 256), dim3(256), 0, s, (const Affine<Fq2> *)bases->points261.get(), (const Affine<Fq2> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, (XYZZ<Fq2> *)l1, lane_off.get());
+          hipLaunchKernelGGL((k_wacc_fold<F>), dim3(NB + WFUSED_ONES_GROUPS), dim3(256), 0, s, (const XYZZ<F> *)l1, (const uint32_t *)lane_off.get(), NB, l2); } }
+        else if (wacc_quads) { n_op = WFUSED_ONES_BLOCKS; hipLaunchKernelGGL((k_wacc_quads<F>), dim3(NB + WFUSED_ONES_BLOCKS), dim3(256), 0, s, (const Affine<F> *)points.get(), (const Affine<F> *)bases->ones_groups.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l2); }
+        else if (sizeof(F) == 32 && bases->points261.size() && bases->groups261.size()) { if constexpr (sizeof(F) == 32) {   // G1 on 29-bit limbs throughout: lanes, fold, tail (msm.cuh: k_wacc_lanes29; htail29.cuh)
+          Point29Rec *p1 = (Point29Rec *)partials.get(), *p2 = (Point29Rec *)ones_partial.get(); const uint32_t top = 31 - (uint32_t)__builtin_clz(NB);
+          hipLaunchKernelGGL(k_wacc_lanes29<0>, dim3((WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) / 256), dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), (const Affine<Fq> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, p1, lane_off.get());
+          hipLaunchKernelGGL(k_wfold29<0>, dim3(NB + WFUSED_ONES_GROUPS), dim3(256), 0, s, (const Point29Rec *)p1, (const uint32_t *)lane_off.get(), NB, (uint32_t)WFUSED_BUCKET_LANES, p2);
+          hipLaunchKernelGGL(k_wtail29<0>, dim3(top + 2), dim3(256), 0, s, (const Point29Rec *)p2, NB, (const Point29Rec *)p2 + NB, (uint32_t)WFUSED_ONES_GROUPS, (uint32_t)WTAIL_SLOTS, (XYZZ<Fq> *)res, wc + w.parity, cdst); }
+          return; }
         else { n_op = WFUSED_ONES_GROUPS; XYZZ<F> *l1 = (XYZZ<F> *)partials.get();
           hipLaunchKernelGGL((k_wacc_lanes<F>), dim3((WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) / 256), dim3(256), 0, s, (const Affine<F> *)points.get(), (const Affine<F> *)bases->ones_groups.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l1, lane_off.get());
           hipLaunchKernelGGL((k_wacc_fold<F>), dim3(NB + WFUSED_ONES_GROUPS), dim3(256), 0, s, (const XYZZ<F> *)l1, (const uint32_t *)lane_off.get(), NB, l2); } }
@@ -206,8 +229,8 @@ struct MsmImpl {
         hipLaunchKernelGGL((k_msm_combine_tasks<F>), dim3(HEAVY_BLOCKS + cdiv(nbk, 64)), dim3(256), 0, s, order.get(), task_off.get(), cls_start.get(), HEAVY_BLOCKS, (const XYZZ<F> *)partials.get(), bucket_array(), zeroed.get(), (uint32_t)(2 * nbk), 0); }
     }
     if (bitsum && hs_run && htail29) { if constexpr (sizeof(F) == 32) { Stage st_red((label + ".reduce").c_str(), s);   // marginal sums, then the sums by weight bit (htail29.cuh)
-      const HtailShape ts = htail_shape(NB); const uint32_t L = 1u << ts.lo_bits, H = 1u << ts.hi_bits;
-      hipLaunchKernelGGL(k_hmarg29<0>, dim3((L - 1) + (H - 1) + 1), dim3(256), 0, s, (const Point29Rec *)hb29.get(), NB, (Point29Rec *)hmarg.get());
+      const HtailShape ts = htail_shape(NB);
+      hipLaunchKernelGGL(k_hmarg29<0>, dim3(htail_marg_blocks(ts)), dim3(256), 0, s, (const Point29Rec *)hb29.get(), NB, (Point29Rec *)hmarg.get());
       hipLaunchKernelGGL(k_hbits29<0>, dim3(ts.top + 1), dim3(256), 0, s, (const Point29Rec *)hmarg.get(), NB, (XYZZ<Fq> *)res, cnt, (uint4 *)(res + RS + 1)); } }
     else if (bitsum && hs_run) { Stage st_red((label + ".reduce").c_str(), s);
       uint32_t per = 8; while (per > 4 && (NB / 2) % (64 * per)) per >>= 1; const uint32_t top = (uint32_t)RS - 1, chunks = (NB / 2) / (64 * per);   // sums by weight bit; the host's Horner rule does the rest (combine() with c = 1)

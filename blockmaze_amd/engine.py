@@ -165,7 +165,7 @@ class Prover:
 def profile_enable(on=True): _check(lib().zkgpu_profile_enable(int(on)))
 def profile_report():
     import json
-    buf = ctypes.create_string_buffer(1 << 16); _check(lib().zkgpu_profile_report(buf, ctypes.c_size_t(len(buf)))); return json.loads(buf.value.decode())
+    buf = ctypes.create_string_buffer(1 << 22); _check(lib().zkgpu_profile_report(buf, ctypes.c_size_t(len(buf)))); return json.loads(buf.value.decode())
 
 def verify_batch(vk_path, proofs_hex, inputs):
     """proofs_hex: list of n 512-character strings; inputs: list of n lists of canonical ints -> list of n booleans (GPU, kernel K9)"""

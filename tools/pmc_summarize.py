@@ -19,8 +19,8 @@ def load(d, counter):
         acc[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 fetch = load(sys.argv[1], "FETCH_SIZE"); write = load(sys.argv[2], "WRITE_SIZE")
-GATHER64 = ("k_hacc_runs29", "k_msm_accumulate_tasks<Fq>", "k_msm_accumulate_tasks<Fp", "k_wacc_lanes<Fq>", "k_wacc_lanes<Fp", "k_msm_sum_ones<Fq>")   # 64-byte point records fetched by index
-GATHER128 = ("k_msm_accumulate_tasks<Fq2>", "k_wacc_quads<Fq2>", "k_msm_sum_ones<Fq2>")
+GATHER64 = ("k_hacc_runs29", "k_msm_accumulate_tasks<Fq>", "k_msm_accumulate_tasks<Fp", "k_wacc_lanes<Fq>", "k_wacc_lanes<Fp", "k_wacc_lanes29", "k_msm_sum_ones<Fq>")   # 64-byte point records fetched by index
+GATHER128 = ("k_msm_accumulate_tasks<Fq2>", "k_wacc_quads<Fq2>", "k_wacc_lanes_g2_29", "k_msm_sum_ones<Fq2>")
 try: CAL = {k.strip(): v["factor_expected_over_raw"] for k, v in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r03_pmc_calibration.json")))["patterns"].items()}
 except Exception: CAL = {}
 F_STREAM, F_G64, F_G128 = CAL.get("k_stream", 2.0), CAL.get("void k_gather<64>", 1.0), CAL.get("void k_gather<128>", 1.35)
