@@ -81,6 +81,15 @@ def check_bounds_add_quad():
     assert KS[cY][NL - 1] >= int(Bv * Q) >> (B * (NL - 1))
     assert (1 << B) + (1 << B) + 8 < (1 << 31)
 check_bounds_add_quad()
+def check_bounds_dbl():
+    """the doubling of an affine point (msm.cuh: xyzz29_dbl_affine, mdbl-2008-s-1): x < p, y < 2 p (K_2 - y); the result keeps to the invariant of the mixed addition"""
+    x, y = 1.0, 2.0; U = 2 * y; V = prod(U, U); W = prod(U, V); S = prod(x, V); M = 3 * prod(x, x)
+    cX = 4; assert cX >= 2 * S + 0.01; nX = prod(M, M) + cX; cT = 6; assert cT >= nX + 0.01; bT = S + cT
+    A = prod(M, bT); Bv = prod(W, y); cY = 2; assert cY >= Bv + 0.01; nY = A + cY
+    assert nX <= 5.5 and nY <= 3.6 and V <= 1.1 and W <= 1.1, (nX, nY, V, W)
+    assert 3 * ((1 << B) + 8) < 1 << 31                                                 # 3 x^2 and 2 y before their carry step: limbs below 2^31
+    for c, need in ((cX, 2 * S), (cT, nX), (cY, Bv)): assert KS[c][NL - 1] >= int(need * Q) >> (B * (NL - 1)), (c, need)
+check_bounds_dbl()
 def check_bounds_g2():
     """the mixed addition over Fq2 on 29-bit limbs (msm.cuh: XYZZ2_29::madd — the G2 half of the B query): Karatsuba products (three Fq products: v0 = a0 b0, v1 = a1 b1,
     v2 = (a0 + a1)(b0 + b1); c0 = v0 + K_2 - v1, c1 = v2 + K_4 - (v0 + v1)), complex squarings (c0 = (a0 + a1)(a0 + K_12 - a1), c1 = 2 a0 a1), differences with the

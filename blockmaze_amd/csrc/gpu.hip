@@ -401,11 +401,13 @@ void Domain::qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c) {
   hipLaunchKernelGGL(k_qap_pointwise, dim3(cdiv(impl->m, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (const Fr *)b, (const Fr *)c, (const Fr *)impl->zinv.get(), impl->step ? 1 : 0, (uint32_t)impl->m);
 }
 
-// packed: [ones bitmap | other bitmap | block offsets | values] already on the device (layout of Prover::set_witness)
-void expand_witness_dev(const uint8_t *packed, size_t words, const Fe32 &one_value, bool values_to_mont, size_t n, Fe32 *out, uint8_t *tags, uint32_t *other_vars) {
-  const uint64_t *ones = (const uint64_t *)packed, *other = ones + words; const uint32_t *off = (const uint32_t *)(other + words); const Fr *vals = (const Fr *)(packed + ((words * 20 + 31) / 32) * 32);
+// packed: [ones bitmap | other bitmap | (canon bitmap) | block offsets | values] already on the device (layout of Prover::set_witness / set_witness_tagged).
+// canon: 0 = every value is in Montgomery form, 1 = every value is canonical (the "other" bitmap doubles as the list of values to convert), 2 = a third bitmap says which
+void expand_witness_dev(const uint8_t *packed, size_t words, const Fe32 &one_value, int canon, size_t n, Fe32 *out, uint8_t *tags, uint32_t *other_vars) {
+  const uint64_t *ones = (const uint64_t *)packed, *other = ones + words, *third = other + words; const size_t nbm = canon == 2 ? 3 : 2;
+  const uint32_t *off = (const uint32_t *)(ones + nbm * words); const Fr *vals = (const Fr *)(packed + expand_values_offset(words, canon));
   Fr one; memcpy(&one, &one_value, 32);
-  hipLaunchKernelGGL(k_expand_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, ones, other, off, vals, one, (int)values_to_mont, (uint32_t)n, (Fr *)out, tags, other_vars);
+  hipLaunchKernelGGL(k_expand_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, ones, other, canon == 0 ? (const uint64_t *)nullptr : canon == 1 ? other : third, off, vals, one, (uint32_t)n, (Fr *)out, tags, other_vars);
 }
 void fr_to_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_to_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
 void fr_from_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_from_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }

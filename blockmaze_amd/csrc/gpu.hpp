@@ -142,7 +142,10 @@ class R1csDev {
 };
 
 void fr_to_mont_dev(Fe32 *a, size_t n); void fr_from_mont_dev(Fe32 *a, size_t n);
-void expand_witness_dev(const uint8_t *packed_dev, size_t words, const Fe32 &one_value, bool values_to_mont, size_t n, Fe32 *out, uint8_t *tags_out = nullptr, uint32_t *other_vars_out = nullptr);   // tags_out / other_vars_out: see WitnessTags   // compact assignment upload (ntt.cuh: k_expand_witness)
+// compact assignment upload (ntt.cuh: k_expand_witness).  packed = [ones bitmap | other bitmap | (canon bitmap, canon == 2) | block offsets | values at expand_values_offset()];
+// canon: 0 all values in Montgomery form, 1 all canonical, 2 the third bitmap says which are canonical.  tags_out / other_vars_out: see WitnessTags
+inline size_t expand_values_offset(size_t words, int canon) { return (((canon == 2 ? 28 : 20) * words + 31) / 32) * 32; }
+void expand_witness_dev(const uint8_t *packed_dev, size_t words, const Fe32 &one_value, int canon, size_t n, Fe32 *out, uint8_t *tags_out = nullptr, uint32_t *other_vars_out = nullptr);   // compact assignment upload (ntt.cuh: k_expand_witness)
 
 // Key loading: y-coordinates of compressed points (x Montgomery; flags bit0 = parity of canonical y, bit1 = point at infinity).  Throws if an x is not on the curve.
 void decompress_g1(const Fe32 *xs, const uint8_t *flags, size_t n, G1AffineRaw *out);

@@ -387,7 +387,7 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   // 7 MB assignment is memory-bound on one core (0.3 ms for send), so the prover's four submit threads — idle at this point of a proof — take a quarter of the words
   // each; every thread owns a quarter of the value area, the per-word offsets make the pieces look like one list to the kernel.
   uint8_t *pk = reinterpret_cast<uint8_t *>(p.z_host.get()); uint64_t *ones = (uint64_t *)pk, *other = ones + words; uint32_t *off = (uint32_t *)(other + words);
-  const size_t vals_at = ((words * 20 + 31) / 32) * 32; Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
+  const size_t vals_at = expand_values_offset(words, 1); Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
   uint64_t o1[4]; memcpy(o1, &one, 32); const uint64_t *zz = reinterpret_cast<const uint64_t *>(z) - 4;   // zz + 4 i = entry i of [ONE, z_1 .. z_n]; entry 0 is handled apart
   // (round 3 measured six and eight threads no faster than four — on assignments that sat in the host's last-level cache.  bench.py cycles through 400 MB of distinct
   // assignments: each scan then streams 7.3 MB from DRAM, a core sustains ~10 GB/s of that, and eight threads halve the 0.17 ms; hosts with fewer than 12 cores keep four)
@@ -413,27 +413,27 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   bool compact = !force_dense; for (size_t t = 0; t < T; t++) compact = compact && fits[t];
   if (compact) {   // the threads' value areas are closed up (a few hundred KB) so that ONE copy carries bitmaps, offsets and values; the few values that are not 0 or 1 are brought into Montgomery form by the expanding kernel itself
     size_t total = used[0]; for (size_t t = 1; t < T; t++) { if (used[t]) { const uint32_t delta = (uint32_t)(t * cap_t - total); memmove(&vals[total], &vals[t * cap_t], 32 * used[t]); for (size_t w = words * t / T; w < words * (t + 1) / T; w++) off[w] -= delta; } total += used[t]; }
-    Fe32 one_mont; memcpy(&one_mont, FrParams::R1, 32); upload_async(p.packed.get(), pk, vals_at + 32 * total); expand_witness_dev(p.packed.get(), words, one_mont, !montgomery, n, p.z.get(), p.tags.get(), p.other_vars.get()); p.tags_valid = true; p.n_other = (uint32_t)total; }   // (letting the kernel read the pinned staging area itself, no copy, was measured: no faster)
+    Fe32 one_mont; memcpy(&one_mont, FrParams::R1, 32); upload_async(p.packed.get(), pk, vals_at + 32 * total); expand_witness_dev(p.packed.get(), words, one_mont, montgomery ? 0 : 1, n, p.z.get(), p.tags.get(), p.other_vars.get()); p.tags_valid = true; p.n_other = (uint32_t)total; }   // (letting the kernel read the pinned staging area itself, no copy, was measured: no faster)
   else { Fe32 *h = p.z_host.get(); h[0] = one; memcpy(&h[1], z, 32 * p.nv); upload_async(p.z.get(), h, 32 * n); if (!montgomery) fr_to_mont_dev(p.z.get(), n); p.tags_valid = false; }      // dense assignment: plain copy
   last.upload_ms = now_ms() - t0;
 }
 void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
   Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); const size_t n = p.nv + 1, words = (n + 63) / 64; Fe32 one; memcpy(&one, FrParams::R1, 32);
-  uint8_t *pk = reinterpret_cast<uint8_t *>(p.z_host.get()); uint64_t *ones = (uint64_t *)pk, *other = ones + words; uint32_t *off = (uint32_t *)(other + words);   // the layout set_witness builds
-  const size_t vals_at = ((words * 20 + 31) / 32) * 32; Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
+  uint8_t *pk = reinterpret_cast<uint8_t *>(p.z_host.get()); uint64_t *ones = (uint64_t *)pk, *other = ones + words, *canon = other + words; uint32_t *off = (uint32_t *)(canon + words);   // the layout set_witness builds, with a third bitmap: the values that are still canonical (the board's small integers)
+  const size_t vals_at = expand_values_offset(words, 2); Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
   constexpr uint64_t LSB = 0x0101010101010101ull, GATHER = 0x0102040810204080ull;              // (y & LSB) * GATHER >> 56: the low bits of 8 bytes as one byte
   // like set_witness: the prover's submit threads — idle at this point of a call — take a quarter of the words each (0.28 -> 0.1 ms for send on the GPU box's host); every
   // thread owns a quarter of the value area, closed up afterwards
   constexpr size_t T = 4; const size_t cap_t = max_other / T; size_t used[T] = {0, 0, 0, 0}; bool fits_t[T] = {true, true, true, true};
   auto scan = [&](size_t t) { const size_t w0 = words * t / T, w1 = words * (t + 1) / T, base = t * cap_t; size_t n_other = 0;
-    for (size_t w = w0; w < w1; w++) { const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; uint64_t mo = 0, mx = 0; off[w] = (uint32_t)(base + n_other);
-      if (hi - lo == 64) for (size_t k = 0; k < 8; k++) { uint64_t x; memcpy(&x, tag + lo + 8 * k, 8); mo |= (((x & LSB) * GATHER) >> 56) << (8 * k); mx |= ((((x >> 1) & LSB) * GATHER) >> 56) << (8 * k); }
-      else for (size_t i = lo; i < hi; i++) { mo |= (uint64_t)(tag[i] & 1) << (i - lo); mx |= (uint64_t)((tag[i] >> 1) & 1) << (i - lo); }
+    for (size_t w = w0; w < w1; w++) { const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; uint64_t mo = 0, mx = 0, mc = 0; off[w] = (uint32_t)(base + n_other);
+      if (hi - lo == 64) for (size_t k = 0; k < 8; k++) { uint64_t x; memcpy(&x, tag + lo + 8 * k, 8); mo |= (((x & LSB) * GATHER) >> 56) << (8 * k); mx |= ((((x >> 1) & LSB) * GATHER) >> 56) << (8 * k); mc |= ((((x >> 2) & LSB) * GATHER) >> 56) << (8 * k); }
+      else for (size_t i = lo; i < hi; i++) { mo |= (uint64_t)(tag[i] & 1) << (i - lo); mx |= (uint64_t)((tag[i] >> 1) & 1) << (i - lo); mc |= (uint64_t)((tag[i] >> 2) & 1) << (i - lo); }
       if (n_other + (size_t)__builtin_popcountll(mx) > cap_t) { fits_t[t] = false; return; }
-      for (uint64_t m = mx; m; m &= m - 1) { const size_t i = lo + (size_t)__builtin_ctzll(m);
-        if (tag[i] == 6) { const HFr v = HFr::from_u64(wide[i].l[0] | (uint64_t)wide[i].l[1] << 32); memcpy(&vals[base + n_other++], v.l, 32); }   // a small integer the board kept as it was (circuit::Board::TAG_SMALL): its Montgomery form is made here, on the scan threads
-        else vals[base + n_other++] = wide[i]; }
-      ones[w] = mo; other[w] = mx; }
+      for (uint64_t m = mx; m; m &= m - 1) { const size_t i = lo + (size_t)__builtin_ctzll(m); Fe32 &dst = vals[base + n_other++];
+        if ((mc >> (i - lo)) & 1) { memset(&dst, 0, 32); dst.l[0] = wide[i].l[0]; dst.l[1] = wide[i].l[1]; }   // a small integer the board kept as it was (circuit::Board::TAG_SMALL, only its low 64 bits are meaningful): the device converts it
+        else dst = wide[i]; }
+      ones[w] = mo; other[w] = mx; canon[w] = mc; }
     used[t] = n_other; };
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
   auto worker = [&](size_t t) -> SubmitWorker & { if (!p.workers[t]) p.workers[t].reset(new SubmitWorker(p.lane)); return *p.workers[t]; };
@@ -445,7 +445,7 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
     size_t n_other = used[0];
     for (size_t t = 1; t < T; t++) { if (used[t]) { const uint32_t delta = (uint32_t)(t * cap_t - n_other); memmove(&vals[n_other], &vals[t * cap_t], 32 * used[t]); for (size_t w = words * t / T; w < words * (t + 1) / T; w++) off[w] -= delta; } n_other += used[t]; }
     const double t2 = now_ms(); upload_async(p.packed.get(), pk, vals_at + 32 * n_other); const double t3 = now_ms();
-    expand_witness_dev(p.packed.get(), words, one, false, n, p.z.get(), p.tags.get(), p.other_vars.get()); p.tags_valid = true; p.n_other = (uint32_t)n_other;
+    expand_witness_dev(p.packed.get(), words, one, 2, n, p.z.get(), p.tags.get(), p.other_vars.get()); p.tags_valid = true; p.n_other = (uint32_t)n_other;
     if (trace) fprintf(stderr, "trace-handover: scan %.3f close-up %.3f copy call %.3f (%zu bytes) expand launch %.3f ms\n", t1 - t0, t2 - t1, t3 - t2, vals_at + 32 * n_other, now_ms() - t3); }
   else { Fe32 *h = p.z_host.get(); Fe32 zero; memset(&zero, 0, 32); for (size_t i = 0; i < n; i++) { if (tag[i] == 6) { const HFr v = HFr::from_u64(wide[i].l[0] | (uint64_t)wide[i].l[1] << 32); memcpy(&h[i], v.l, 32); } else h[i] = tag[i] == 2 ? wide[i] : tag[i] ? one : zero; } upload_async(p.z.get(), h, 32 * n); p.tags_valid = false; }   // a dense assignment (never a BlockMaze one)
   last.upload_ms = now_ms() - t0;

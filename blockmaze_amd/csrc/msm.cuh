@@ -11,7 +11,7 @@
 //   scatter    counting sort of (table index, sign) by bucket
 //   H query    (uniform scalars, fixed-base table) has a path of its own: one-pass sort by workgroup-local binning (k_hsort_bin / k_hsort_group), accumulation over
 //              fixed-length runs of the sorted entries on nine 29-bit limbs (k_hacc_runs29), pieces added up per bucket (k_hacc_combine29), weighted bucket sum by weight
-//              bits (k_bitsum_*); an overflow of the sort's regions or a degenerate key sends the MSM back to the general path below
+//              bits from two-level marginal sums (htail29.cuh: k_hmarg29 / k_hbits29); an overflow of the sort's regions or a degenerate key sends the MSM back to the general path below
 //   accumulate one lane per task walks its slice of the sorted list with mixed additions (XYZZ accumulator in VGPRs, next point's gather in flight)
 //   combine    buckets cut into several tasks: a quad (or a workgroup for very full buckets) adds the partial sums
 //   reduce     sum_b b*B_b by segments: running sums inside a segment, a small scalar multiple for the segment offset, then workgroup-level trees — all with
@@ -313,8 +313,9 @@ struct XYZZ29 { Fq29 X, Y, ZZ, ZZZ;
   // dead after the first two products; loading the next point at the top of the loop instead cost 16 registers and with them the fourth wave per SIMD).
   // px normalized, py possibly K_2 - y (limbs below 2^31); bounds: gen_field29.py
   __device__ __forceinline__ void madd_head(const Fq29 &px, const Fq29 &py, Fq29 &Pv, Fq29 &Rv) const { Pv = Fq29::sub<6>(Fq29::mul(px, ZZ), X); Rv = Fq29::sub<4>(Fq29::mul(py, ZZZ), Y); }
-  __device__ __forceinline__ void madd_tail(const Fq29 &Pv, const Fq29 &Rv) {
-    const Fq29 PP = Fq29::sqr(Pv), PPP = Fq29::mul(Pv, PP), Q = Fq29::mul(X, PP);
+  __device__ __forceinline__ void madd_tail(const Fq29 &Pv, const Fq29 &Rv) { madd_tail_pp(Pv, Rv, Fq29::sqr(Pv)); }
+  __device__ __forceinline__ void madd_tail_pp(const Fq29 &Pv, const Fq29 &Rv, const Fq29 &PP) {
+    const Fq29 PPP = Fq29::mul(Pv, PP), Q = Fq29::mul(X, PP);
     Fq29 s;
 #pragma unroll
     for (int i = 0; i < 9; i++) s.l[i] = PPP.l[i] + 2u * Q.l[i];
@@ -322,6 +323,33 @@ struct XYZZ29 { Fq29 X, Y, ZZ, ZZZ;
     Y = Fq29::sub<2>(Fq29::mul(Rv, Fq29::sub<6>(Q, X3)), Fq29::mul(Y, PPP)); X = X3; ZZ = Fq29::mul(ZZ, PP); ZZZ = Fq29::mul(ZZZ, PPP);
   }
 };
+// a product's or a squaring's result (exact 29-bit limbs, value below 2 p) is 0 (mod p) iff it is 0 or p
+__device__ __forceinline__ bool fq29_product_is_zero(const Fq29 &t) {
+  uint32_t zero_or = 0, p_xor = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { zero_or |= t.l[i]; p_xor |= t.l[i] ^ Fq29::P29[i]; }
+  return zero_or == 0 || p_xor == 0;
+}
+// 2 (x, y) for an affine point (mdbl-2008-s-1, a = 0): x canonical, y canonical or K_2 - y with normalized limbs.  The result keeps to the invariant of madd
+// (X < 5.1 p, Y < 3.2 p, ZZ, ZZZ < 1.1 p; gen_field29.py: check_bounds_dbl).  Used where a witness MSM meets the same point twice in a row (see k_wacc_lanes29).
+__device__ __forceinline__ XYZZ29 xyzz29_dbl_affine(const Fq29 &x, const Fq29 &y) {
+  Fq29 U, M3;
+#pragma unroll
+  for (int i = 0; i < 9; i++) U.l[i] = 2u * y.l[i];
+  U = U.norm();
+  const Fq29 V = Fq29::sqr(U), W = Fq29::mul(U, V), S = Fq29::mul(x, V), xx = Fq29::sqr(x);
+#pragma unroll
+  for (int i = 0; i < 9; i++) M3.l[i] = 3u * xx.l[i];
+  const Fq29 M = M3.norm();
+  Fq29 S2;
+#pragma unroll
+  for (int i = 0; i < 9; i++) S2.l[i] = 2u * S.l[i];
+  XYZZ29 r;
+  r.X = Fq29::sub<4>(Fq29::sqr(M), S2);
+  r.Y = Fq29::sub<2>(Fq29::mul(M, Fq29::sub<6>(S, r.X)), Fq29::mul(W, y));
+  r.ZZ = V; r.ZZZ = W;
+  return r;
+}
 // add-2008-s on two accumulators within the invariant of madd (gen_field29.py: check_bounds_add); neither at infinity, and not +-each other (that leaves ZZ = 0 mod p)
 __device__ __forceinline__ XYZZ29 xyzz29_add(const XYZZ29 &a, const XYZZ29 &b) {
   const Fq29 U1 = Fq29::mul(a.X, b.ZZ), S1 = Fq29::mul(a.Y, b.ZZZ), Pv = Fq29::sub<2>(Fq29::mul(b.X, a.ZZ), U1), Rv = Fq29::sub<2>(Fq29::mul(b.Y, a.ZZZ), S1);
@@ -510,17 +538,20 @@ __global__ void __launch_bounds__(256) k_msm_sum_ones(const Affine<F> *__restric
   if (k == 0) partial[t] = acc;
 }
 
-// ---- witness MSMs in three launches -----------------------------------------------------------------------------------------
+// ---- witness MSMs in four launches (sort, lanes, fold, tail) -----------------------------------------------------------------------------------------
 // Measured with several proofs in flight (tools/inflight_probe.py): the four witness MSMs — 5 % of a proof's field products — took as much of the machine as the H query,
 // because the general path above spends ten launches of tiny, dependent kernels on each of them (classify, plan, scatter, accumulate, combine, reduce, three tree
 // levels, the ones sum).  With fixed-base tables all windows share at most 128 buckets, and a workgroup is exactly the right size for one bucket:
-//   k_wsort   one pass over the scalars: the ones go to a compacted list, every non-zero digit to its bucket's REGION (cap slots per bucket; a workgroup counts in LDS,
-//             reserves with one atomic per bucket, walks the digits again to place them).  No histogram pass, no plan.  A bucket that would overflow raises the flag
-//             that sends the MSM back to the general path.
-//   k_wacc_lanes / k_wacc_fold   4,096 lanes share the buckets' entries in equal slices, 8,192 more stride over the list of ones (plain lane-serial mixed additions);
-//             then one workgroup per bucket folds its lanes' partial sums, and 32 more fold the ones lanes to 32 partial sums.
-//   k_wtail   two workgroups: (0) sum_b (b + 1) B_b as sum_k 2^k S_k with S_k the sum of the buckets whose weight has bit k — eight plain sums by eight groups of
-//             eight quads, then a Horner chain of 7 doublings and 7 additions; (1) the tree over the ones' partial sums.  The host adds the two results.
+//   sort      k_wsort_tagged (the assignment arrived in compact form: a byte per variable says 0 / 1 / other) or k_wsort (plain vector): the ones go to a compacted list —
+//             four consecutive points at a time, as an index into the table of their subset sums —, every non-zero digit of the other scalars to its bucket's REGION
+//             (cap slots per bucket; a workgroup counts in LDS, reserves with one atomic per bucket, walks the digits again to place them).  No histogram pass, no
+//             plan.  A bucket that would overflow raises the flag that sends the MSM back to the general path.
+//   lanes     4,096 lanes share the buckets' entries in equal slices, 8,192 more stride over the list of ones: lane-serial mixed additions on nine 29-bit limbs
+//             (k_wacc_lanes29 for G1 — complete: a repeated query point is doubled —, k_wacc_lanes_g2_29 over Fq2);
+//   fold      one workgroup per bucket adds its lanes' partial sums, 32 more fold the ones lanes to 32 partial sums: quad-cooperative trees (htail29.cuh: k_wfold29 on
+//             29-bit limbs for G1; k_wacc_fold<Fq2> on 8 x 32-bit limbs for G2);
+//   tail      sum_b (b + 1) B_b as sum_k 2^k S_k, S_k = the sum of the buckets whose weight has bit k: one workgroup per weight bit, one for the ones' partial sums
+//             (k_wtail29 / k_wtail<Fq2>); the host's Horner rule finishes with one-bit windows and adds the ones.
 // The sort only depends on the scalars: MSMs over the same scalar vector (A and L*; B1 and B2) share one k_wsort (msm_impl.hpp: WsortBuffers).
 constexpr uint32_t WFUSED_MAX_BUCKETS = 128;
 // Key load: groups[g * 15 + v - 1] = the sum of P_(4g + j) over the bits j of v, v = 1 .. 15, affine (the all-zero record when the sum is the point at infinity; points
@@ -641,35 +672,11 @@ __global__ void __launch_bounds__(256) k_wsort_tagged(const Fr *__restrict__ z, 
 constexpr uint32_t WFUSED_BUCKET_LANES = 4096, WFUSED_ONES_LANES = 8192, WFUSED_ONES_GROUPS = WFUSED_ONES_LANES / 256, WFUSED_MIN_SLICE = 8;
 // Lanes are dealt to the buckets in proportion to their fill (a witness puts thousands of equal values into one bucket): slice length T = total / lanes, bucket b gets
 // ceil(fill_b / T) lanes, lane_off[] (NB + 1 prefix sums, recomputed by every workgroup, written out by the first) tells the next kernel where each bucket's partial sums lie.
-template <class F>
-__global__ void __launch_bounds__(256) k_wacc_lanes(const Affine<F> *__restrict__ points, const Affine<F> *__restrict__ groups, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap, uint32_t NB, const uint32_t *__restrict__ ones, const MsmCounters *cnt,
-                                                    XYZZ<F> *__restrict__ partial, uint32_t *__restrict__ lane_off) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; XYZZ<F> acc = XYZZ<F>::inf();
-  if (t >= WFUSED_BUCKET_LANES) { const uint32_t u = t - WFUSED_BUCKET_LANES; if (u >= WFUSED_ONES_LANES) return; const uint32_t n1 = cnt->n_ones;     // (whole workgroups: 4096 is a multiple of 256)
-    if (u < n1) { Affine<F> p = groups[ones[u]];
-#pragma unroll 1
-      for (uint32_t i = u; i < n1; i += WFUSED_ONES_LANES) { Affine<F> pn = p; if (i + WFUSED_ONES_LANES < n1) pn = groups[ones[i + WFUSED_ONES_LANES]]; acc.madd_inl(p); p = pn; } }
-    partial[t] = acc; return; }
-  __shared__ uint32_t m_of[WFUSED_MAX_BUCKETS], off[WFUSED_MAX_BUCKETS + 1], slice;
-  if (threadIdx.x < NB) m_of[threadIdx.x] = min(fill[threadIdx.x], cap);
-  __syncthreads();
-  if (threadIdx.x == 0) { uint32_t tot = 0; for (uint32_t b = 0; b < NB; b++) tot += m_of[b];
-    const uint32_t T = max(WFUSED_MIN_SLICE, (tot + (WFUSED_BUCKET_LANES - NB) - 1) / (WFUSED_BUCKET_LANES - NB)); uint32_t o = 0; for (uint32_t b = 0; b < NB; b++) { off[b] = o; o += (m_of[b] + T - 1) / T; } off[NB] = o; slice = T; }
-  __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x <= NB) lane_off[threadIdx.x] = off[threadIdx.x];
-  if (t >= off[NB]) return;
-  uint32_t lo = 0, hi = NB;                                                                    // the bucket b with off[b] <= t < off[b + 1]
-  while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (off[mid] <= t) lo = mid; else hi = mid; }
-  const uint32_t b = lo, beg = (t - off[b]) * slice, end = min(m_of[b], beg + slice); const uint32_t *e = entries + (size_t)b * cap;
-  { uint32_t v = e[beg], vn = beg + 1 < end ? e[beg + 1] : v; Affine<F> p = points[v & ~MSM_ENTRY_SIGN];
-#pragma unroll 1
-    for (uint32_t i = beg; i < end; i++) { Affine<F> pn = points[vn & ~MSM_ENTRY_SIGN]; uint32_t vnn = i + 2 < end ? e[i + 2] : vn; if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; vn = vnn; } }
-  partial[t] = acc;
-}
 // The lane-serial accumulation of a G1 witness MSM on 29-bit limbs (round 4): k_wacc_lanes with the arithmetic of k_hacc_runs29 — the same madd-2008-s in two steps, 2,275
 // instructions instead of ~4,400 — gathering from the tables with coordinates x 2^261 (Bases::points261 / groups261) and leaving a Point29Rec per lane for k_wfold29 /
-// k_wtail29 (htail29.cuh).  Incomplete formulas: an operand equal to +-the accumulator leaves ZZ = 0 (mod p), which travels through the fold and the tail to a result slot,
-// where k_wtail29 flags it (the MSM is then repeated on the general path).
+// k_wtail29 (htail29.cuh).  COMPLETE in the lane (unlike the H accumulation): an operand equal to the accumulator is doubled, one equal to its negative leaves the
+// point at infinity — repeated query points are a property of real keys, not an accident.  The fold and the tail stay incomplete (two partial SUMS that coincide):
+// ZZ = 0 (mod p) travels to a result slot, where k_wtail29 flags it and the MSM is repeated on the general path.
 template <int UNIT>
 __global__ void __launch_bounds__(256) k_wacc_lanes29(const Affine<Fq> *__restrict__ points261, const Affine<Fq> *__restrict__ groups261, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap, uint32_t NB,
                                                       const uint32_t *__restrict__ ones, const MsmCounters *cnt, Point29Rec *__restrict__ partial, uint32_t *__restrict__ lane_off) {
@@ -715,7 +722,14 @@ __global__ void __launch_bounds__(256) k_wacc_lanes29(const Affine<Fq> *__restri
       if (!p.is_inf()) {
         const Fq29 px = Fq29::unpack(p.x.l), py = Fq29::cond_neg(Fq29::unpack(p.y.l), (v >> 31) != 0);
         if (inf) { acc.X = px; acc.Y = py.norm(); acc.ZZ = Fq29::one(); acc.ZZZ = Fq29::one(); inf = false; }
-        else { Fq29 Pv, Rv; acc.madd_head(px, py, Pv, Rv); acc.madd_tail(Pv, Rv); }
+        else {
+          Fq29 Pv, Rv; acc.madd_head(px, py, Pv, Rv);
+          const Fq29 PP = Fq29::sqr(Pv);
+          // the query points of a key repeat (two variables that enter the same constraint with the same coefficient and no other have the same A-query point), and a
+          // lane meets such a pair back to back in most proofs: P = 0 means the operand is +-the accumulator — double it (R = 0 too) or leave the point at infinity
+          if (fq29_product_is_zero(PP)) { if (fq29_product_is_zero(Fq29::sqr(Rv))) acc = xyzz29_dbl_affine(px, py.norm()); else inf = true; }
+          else acc.madd_tail_pp(Pv, Rv, PP);
+        }
       }
       v = vn; p = pn;
     }
@@ -856,25 +870,6 @@ __global__ void __launch_bounds__(256) k_wacc_fold(const XYZZ<F> *__restrict__ p
   if (b < NB) { beg = lane_off[b]; len = lane_off[b + 1] - beg; } else { beg = WFUSED_BUCKET_LANES + (b - NB) * 256; len = 256; }
   XYZZ<F> acc = block_quad_sum(partial + beg, len, lds); if (threadIdx.x == 0) out[b] = acc;
 }
-// The cooperative form of the two kernels above in one launch, for G2: a lane-serial Fq2 addition keeps ~450 registers alive and runs at 30 us, so there the 64 quads of
-// workgroup b < NB stride over bucket b's entries directly (workgroups NB .. NB + 127 over the list of ones) and the workgroup's tree leaves the sum.
-constexpr uint32_t WFUSED_ONES_BLOCKS = 128;
-template <class F>
-__global__ void __launch_bounds__(256) k_wacc_quads(const Affine<F> *__restrict__ points, const Affine<F> *__restrict__ groups, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap, uint32_t NB, const uint32_t *__restrict__ ones, const MsmCounters *cnt,
-                                                    XYZZ<F> *__restrict__ out) {
-  __shared__ XYZZ<F> lds[4]; const uint32_t q = threadIdx.x >> 2, b = blockIdx.x; const int k = threadIdx.x & 3; XYZZ<F> acc = XYZZ<F>::inf();
-  if (b < NB) { const uint32_t m = min(fill[b], cap); const uint32_t *e = entries + (size_t)b * cap;
-    if (q < m) { uint32_t v = e[q]; Affine<F> p = points[v & ~MSM_ENTRY_SIGN];
-#pragma unroll 1
-      for (uint32_t i = q; i < m; i += 64) { uint32_t vn = v; Affine<F> pn = p; if (i + 64 < m) { vn = e[i + 64]; pn = points[vn & ~MSM_ENTRY_SIGN]; } if (v >> 31) p.y = p.y.neg(); acc = quad_madd(acc, p, k); v = vn; p = pn; } }
-    acc = block_quad_tree(acc, lds, min(m, 64u)); }
-  else { const uint32_t n1 = cnt->n_ones, u = (b - NB) * 64 + q, stride = WFUSED_ONES_BLOCKS * 64;
-    if (u < n1) { Affine<F> p = groups[ones[u]];
-#pragma unroll 1
-      for (uint32_t i = u; i < n1; i += stride) { Affine<F> pn = p; if (i + stride < n1) pn = groups[ones[i + stride]]; acc = quad_madd(acc, p, k); p = pn; } }
-    acc = block_quad_tree(acc, lds); }
-  if (threadIdx.x == 0) out[b] = acc;
-}
 // sum_b (b + 1) * bucket_b as sum_s 2^s S_s, S_s = the sum of the buckets whose weight has bit s: for s < top = log2 NB those are the NB / 2 weights "i with a one inserted
 // at bit s"; S_top is bucket NB - 1 alone.  The S_s go to the host as they are (res[0..7]; res[8] = the sum of the ones): its Horner rule for window sums finishes with
 // one-bit windows on the MSM's submit thread (7 doublings, 8 additions) — on the device that was 10 more dependent quad operations, 150 us of the G2 chain.
@@ -904,26 +899,7 @@ __global__ void __launch_bounds__(256) k_wtail(const XYZZ<F> *__restrict__ bucke
   if (threadIdx.x == 0) res[s_] = acc;
 }
 
-// ---- weighted bucket sum of the H query by weight bits ----------------------------------------------------------------------------------------------------------
-// sum_b (b + 1) S_b over NB = 2^top buckets as sum_s 2^s T_s, T_s = the sum of the buckets whose weight has bit s (k_wtail's idea at full size).  For s < top those
-// are the NB / 2 weights "i with a one inserted at bit s"; weight NB itself (bucket NB - 1) is T_top.  k_bitsum_chunks: workgroup (chunk, s) adds 512 of them (eight per
-// quad, then the workgroup tree: 480 workgroups, one round of the chip; with 256 per workgroup the 960 workgroups ran in two rounds, 147 us); k_bitsum_final: workgroup s adds the chunks' partial sums.  The host finishes with the Horner rule it already has (combine() with
-// one-bit "windows": top doublings and additions).  Chain: 12 + 7 dependent quad additions instead of the 27 + 12 + 6 of k_msm_reduce_segments and its two group sums.
-template <class F>
-__global__ void __launch_bounds__(256) k_bitsum_chunks(const XYZZ<F> *__restrict__ buckets, uint32_t per, XYZZ<F> *__restrict__ out) {   // `per` elements per quad, 64 * per per workgroup
-  __shared__ XYZZ<F> lds[4]; const uint32_t s_ = blockIdx.y, q = threadIdx.x >> 2, base = blockIdx.x * 64 * per + q; const int k = threadIdx.x & 3;
-  auto bucket_of = [&](uint32_t i) { return (((i >> s_) << (s_ + 1)) | (1u << s_) | (i & ((1u << s_) - 1))) - 1; };
-  XYZZ<F> acc = XYZZ<F>::inf(), nxt = buckets[bucket_of(base)];
-#pragma unroll 1
-  for (uint32_t j = 0; j < per; j++) { XYZZ<F> cur = nxt; if (j + 1 < per) nxt = buckets[bucket_of(base + 64 * (j + 1))]; acc = quad_add(acc, cur, k); }
-  acc = block_quad_tree(acc, lds); if (threadIdx.x == 0) out[s_ * gridDim.x + blockIdx.x] = acc;
-}
-template <class F>
-__global__ void __launch_bounds__(256) k_bitsum_final(const XYZZ<F> *__restrict__ partial, uint32_t chunks, uint32_t top, const XYZZ<F> *__restrict__ buckets, uint32_t NB, XYZZ<F> *__restrict__ res, uint4 *copy_src, uint4 *copy_dst) {
-  __shared__ XYZZ<F> lds[4]; const uint32_t s_ = blockIdx.x;
-  if (s_ == top) { if (threadIdx.x < 4) { XYZZ<F> v = buckets[NB - 1]; if (threadIdx.x == 0) { res[top] = v; if (copy_src) *copy_dst = *copy_src; } } return; }
-  XYZZ<F> acc = block_quad_sum(partial + (size_t)s_ * chunks, chunks, lds); if (threadIdx.x == 0) res[s_] = acc;
-}
+// (the weighted bucket sum of the H query — sums by weight bit from two-level marginal sums, on 29-bit limbs — lives in htail29.cuh: k_hmarg29 / k_hbits29)
 
 // ---- fixed-base precomputation: table[w*n + i] = 2^(c*w) * P_i, affine ------------------------------------------------
 // The query points of a proving key never change, and 288 GB of HBM is plenty: with every window's multiple of every point stored, all windows of an MSM

@@ -26,7 +26,7 @@ struct MsmImpl {
   // H query (uniform scalars, one bucket array): group-binned one-pass sort, accumulation over runs of h_run entries on 29-bit limbs, at most h_maxp pieces per bucket
   bool hsort = false; HsortShape hs{0, 0, 0, 0}; DevBuf<uint32_t> group_fill, mid, group_n; uint32_t h_run = 12, h_maxp = 16;   // (run length swept on MI355X, accumulate + combine inside a send proof: 8: 0.397, 12: 0.382, 16: 0.402 ms, profiles/r03f_ab.txt; again in round 4 with the 29-bit tail, whole proof: 12: 1.038, 16: 1.052, 20: 1.057, 24: 1.090 ms, profiles/r04a_hrun_sweep.txt; window 15 / 16 / 17: 0.992 / 0.952 / 0.976 ms, profiles/r04d_ab.txt)
   // witness MSMs in three launches (k_wsort / k_wacc / k_wtail); needs the fixed-base tables and at most 128 buckets
-  bool wfused = false, wacc_quads = false, ws_leader = true, overflow_noted = false; std::shared_ptr<WsortBuffers> ws;
+  bool wfused = false, ws_leader = true, overflow_noted = false; std::shared_ptr<WsortBuffers> ws;
   const Fe32 *last_scalars = nullptr; const uint32_t *last_index = nullptr;
   WitnessTags wtags; const Fe32 *z_all = nullptr; bool tagged = false;   // this run's assignment came in compact form (run_tagged): the witness sort reads tags instead of scalars
   DevBuf<uint32_t> zeroed;                                          // [hist | fill | counters]: cleared once; every run leaves them cleared
@@ -74,20 +74,18 @@ struct MsmImpl {
       hipLaunchKernelGGL(k_table_to_r261, dim3(cdiv(tn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq> *)b->points.get(), (Affine<Fq> *)b->points261.get(), tn); HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
     if (fo && b->WB == 1 && n_) { const size_t ng = (n_ + 3) / 4; b->ones_groups = DevBuf<RawAffine>(ng * 15);   // subset sums of four consecutive points for the scalars equal to one (k_ones_groups)
       hipLaunchKernelGGL((k_ones_groups<F>), dim3(cdiv(ng, 64)), dim3(64), 0, gpu().stream, (const Affine<F> *)b->points.get(), (uint32_t)n_, (Affine<F> *)b->ones_groups.get()); HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
-    if constexpr (sizeof(F) == 32) if (fo && b->WB == 1 && n_ && w29()) {   // a G1 witness MSM accumulates, folds and sums on 29-bit limbs: both tables once more with coordinates x 2^261
+    if constexpr (sizeof(F) == 32) if (fo && b->WB == 1 && n_) {   // a G1 witness MSM accumulates, folds and sums on 29-bit limbs: both tables once more with coordinates x 2^261
       const size_t tn = n_ * (size_t)b->W, gn = b->ones_groups.size(); b->points261 = DevBuf<RawAffine>(tn); b->groups261 = DevBuf<RawAffine>(gn ? gn : 1);
       hipLaunchKernelGGL(k_table_to_r261, dim3(cdiv(tn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq> *)b->points.get(), (Affine<Fq> *)b->points261.get(), tn);
       if (gn) hipLaunchKernelGGL(k_table_to_r261, dim3(cdiv(gn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq> *)b->ones_groups.get(), (Affine<Fq> *)b->groups261.get(), gn);
       HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
-    if constexpr (sizeof(F) == 64) if (fo && b->WB == 1 && n_ && g2_lanes29()) {   // the G2 witness MSM accumulates on 29-bit limbs: both tables once more with coordinates x 2^261
+    if constexpr (sizeof(F) == 64) if (fo && b->WB == 1 && n_) {   // the G2 witness MSM accumulates on 29-bit limbs: both tables once more with coordinates x 2^261
       const size_t tn = n_ * (size_t)b->W, gn = b->ones_groups.size(); b->points261 = DevBuf<RawAffine>(tn); b->groups261 = DevBuf<RawAffine>(gn ? gn : 1);
       hipLaunchKernelGGL(k_table_to_r261_g2, dim3(cdiv(tn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq2> *)b->points.get(), (Affine<Fq2> *)b->points261.get(), tn);
       if (gn) hipLaunchKernelGGL(k_table_to_r261_g2, dim3(cdiv(gn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq2> *)b->ones_groups.get(), (Affine<Fq2> *)b->groups261.get(), gn);
       HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
     return b;
   }
-  static bool w29() { static const bool on = [] { const char *e = getenv("ZK_WITNESS_G1_29"); return !e || atoi(e) != 0; }(); return on; }   // (0: round 2's 8 x 32-bit witness kernels for G1, kept for A/B)
-  static bool g2_lanes29() { static const bool on = [] { const char *e = getenv("ZK_G2_LANES29"); return !e || atoi(e) != 0; }(); return on; }   // (0: round 2's quad-cooperative G2 accumulation, kept for A/B)
   MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true, bool uniform_hint = false) : MsmImpl(make_bases(host_points, n_, c_, fo, tables, uniform_hint), fo, uniform_hint) {}
   MsmImpl(std::shared_ptr<const Bases> shared, bool fo, bool uniform_hint)
       : n(shared->n), c(shared->c), W(shared->W), WB(shared->WB), NB(1u << (shared->c - 1)), filter_ones(fo), bases(shared), points(shared->points), inf(shared->inf), any_inf(shared->any_inf),
@@ -96,7 +94,7 @@ struct MsmImpl {
     seg = NB >= 4096 ? (WB == 1 ? 4 : 16) : 4;   // buckets per segment of the weighted reduction on the general path (one bucket array: few segments, short dependent chain)
     n_ones_quads = 16384;
     if (filter_ones && WB == 1 && n && NB >= 16 && NB <= WFUSED_MAX_BUCKETS && n * (size_t)W < (1ull << 31)) {
-      wfused = true; wacc_quads = sizeof(F) > 32;   // G2 accumulates by quads, G1 by lanes (msm.cuh)
+      wfused = true;
       ws = std::make_shared<WsortBuffers>(); ws->NB = NB; ws->n = n; ws->cap = getenv("ZK_MSM_DIRECT_CAP") ? 2 : (uint32_t)std::min<size_t>(std::max<size_t>(8192, n / 8), 1u << 17);   // (test hook: a tiny region forces the overflow fallback)
       ws->fill = DevBuf<uint32_t>(2 * NB); ws->fill.zero(); ws->entries = DevBuf<uint32_t>((size_t)NB * ws->cap); ws->ones = DevBuf<uint32_t>(n); ws->counters = DevBuf<uint32_t>(2 * sizeof(MsmCounters) / 4); ws->counters.zero();
       HIP_CHECK(hipEventCreateWithFlags(&ws->sorted, hipEventDisableTiming)); }
@@ -111,12 +109,11 @@ struct MsmImpl {
     { size_t nbk = (size_t)WB * NB; bsort_blocks = cdiv(nbk, BSORT_BLOCK); order = DevBuf<uint32_t>(nbk); rank_of = DevBuf<uint32_t>(nbk); block_hist = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); block_off = DevBuf<uint32_t>((size_t)bsort_blocks * BSORT_CLASSES); bsort_scanner.reset(new Scanner((size_t)bsort_blocks * BSORT_CLASSES)); }
     buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>));
     partials = DevBuf<uint8_t>(std::max<size_t>(std::max<size_t>((size_t)max_tasks * sizeof(XYZZ<F>), hsort ? (size_t)NB * h_maxp * sizeof(Piece29) : 0), wfused ? ((size_t)WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) * std::max(sizeof(XYZZ<F>), sizeof(Point29Rec)) : 0));
-    seg_out = DevBuf<uint8_t>(std::max<size_t>((size_t)WB * (NB / seg), (size_t)32 * cdiv(NB, 512)) * sizeof(XYZZ<F>)); /* (also the chunk sums of the bit-sum tail: log2(NB) x NB/512) */ seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
-    ones_partial = DevBuf<uint8_t>(std::max<size_t>(n_ones_quads, wfused ? (size_t)NB + WFUSED_ONES_BLOCKS : 0) * std::max(sizeof(XYZZ<F>), sizeof(Point29Rec))); if (wfused) lane_off = DevBuf<uint32_t>(WFUSED_MAX_BUCKETS + 1); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
+    seg_out = DevBuf<uint8_t>(std::max<size_t>((size_t)WB * (NB / seg), (size_t)32 * cdiv(NB, 512)) * sizeof(XYZZ<F>)); seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
+    ones_partial = DevBuf<uint8_t>(std::max<size_t>(n_ones_quads, wfused ? (size_t)NB + WFUSED_ONES_GROUPS : 0) * std::max(sizeof(XYZZ<F>), sizeof(Point29Rec))); if (wfused) lane_off = DevBuf<uint32_t>(WFUSED_MAX_BUCKETS + 1); ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
     RS = WB; if (wfused) { bitsum = true; RS = WTAIL_SLOTS; }   // k_wtail leaves eight sums by weight bit
     else if (hsort && NB >= 512) { bitsum = true; RS = 1; while ((1u << (RS - 1)) < NB) RS++;   // RS = log2(NB) + 1
-      static const bool tail29 = [] { const char *e = getenv("ZK_MSM_H_TAIL29"); return !e || atoi(e) != 0; }();   // (0: round 2's bit sums on 8 x 32-bit limbs, kept for A/B)
-      if (tail29) { htail29 = true; hb29 = DevBuf<uint8_t>((size_t)NB * sizeof(Point29Rec)); hmarg = DevBuf<uint8_t>((size_t)htail_marg_count(htail_shape(NB)) * sizeof(Point29Rec)); } }
+      htail29 = true; hb29 = DevBuf<uint8_t>((size_t)NB * sizeof(Point29Rec)); hmarg = DevBuf<uint8_t>((size_t)htail_marg_count(htail_shape(NB)) * sizeof(Point29Rec)); }
     zeroed.zero();                                                                  // (the ones slot of the result stays the point at infinity when the ones path is off: h_result is cleared below)
     HIP_CHECK(hipHostMalloc((void **)&h_result, result_bytes())); memset(h_result, 0, result_bytes());
     { void *d = nullptr; HIP_CHECK(hipHostGetDevicePointer(&d, h_result, 0)); res_dev = (uint8_t *)d; }   // the last kernel of an MSM writes its few sums straight into the pinned host copy: no copy kernel behind it (1.125 -> 1.10 ms median per proof; round 2 had measured no difference, at 1.45 ms)
@@ -170,22 +167,25 @@ struct MsmImpl {
         if (w.shared) HIP_CHECK(hipEventRecord(w.sorted, s)); }
       else if (w.leader_stream != stream_id) HIP_CHECK(hipStreamWaitEvent(s, w.sorted, 0));   // (a follower on the leader's stream is simply queued behind it)
       uint4 *csrc = (uint4 *)(wc + w.parity); uint4 *cdst = (uint4 *)(res + RS + 1);
-      XYZZ<F> *l2 = (XYZZ<F> *)ones_partial.get(); uint32_t n_op;                          // l2: [NB bucket sums | n_op partial sums of the ones]
-      { Stage st((label + ".accumulate").c_str(), s); const uint32_t *fl = w.fill.get() + (size_t)w.parity * NB;
-        if (wacc_quads && bases->points261.size()) { if constexpr (sizeof(F) == 64) { n_op = WFUSED_ONES_GROUPS; XYZZ<F> *l1 = (XYZZ<F> *)partials.get();   // G2, lane by lane on 29-bit limbs, then the same fold as G1
-          hipLaunchKernelGGL(k_wacc_lanes_g2_29<0>, dim3((WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) / 256), dim3(256), 0, s, (const Affine<Fq2> *)bases->points261.get(), (const Affine<Fq2> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, (XYZZ<Fq2> *)l1, lane_off.get());
-          hipLaunchKernelGGL((k_wacc_fold<F>), dim3(NB + WFUSED_ONES_GROUPS), dim3(256), 0, s, (const XYZZ<F> *)l1, (const uint32_t *)lane_off.get(), NB, l2); } }
-        else if (wacc_quads) { n_op = WFUSED_ONES_BLOCKS; hipLaunchKernelGGL((k_wacc_quads<F>), dim3(NB + WFUSED_ONES_BLOCKS), dim3(256), 0, s, (const Affine<F> *)points.get(), (const Affine<F> *)bases->ones_groups.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l2); }
-        else if (sizeof(F) == 32 && bases->points261.size() && bases->groups261.size()) { if constexpr (sizeof(F) == 32) {   // G1 on 29-bit limbs throughout: lanes, fold, tail (msm.cuh: k_wacc_lanes29; htail29.cuh)
-          Point29Rec *p1 = (Point29Rec *)partials.get(), *p2 = (Point29Rec *)ones_partial.get(); const uint32_t top = 31 - (uint32_t)__builtin_clz(NB);
-          hipLaunchKernelGGL(k_wacc_lanes29<0>, dim3((WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) / 256), dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), (const Affine<Fq> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, p1, lane_off.get());
-          hipLaunchKernelGGL(k_wfold29<0>, dim3(NB + WFUSED_ONES_GROUPS), dim3(256), 0, s, (const Point29Rec *)p1, (const uint32_t *)lane_off.get(), NB, (uint32_t)WFUSED_BUCKET_LANES, p2);
+      XYZZ<F> *l2 = (XYZZ<F> *)ones_partial.get();                                         // (G2) l2: [NB bucket sums | the partial sums of the ones]
+      // accumulate / fold / tail.  G1 (A, L*, B1): on 29-bit limbs throughout (msm.cuh: k_wacc_lanes29; htail29.cuh: k_wfold29, k_wtail29).  G2 (B2): the lanes on 29-bit
+      // limbs over Fq2 (k_wacc_lanes_g2_29), fold and tail quad-cooperative on 8 x 32-bit limbs (k_wacc_fold<Fq2>, k_wtail<Fq2>).
+      const uint32_t *fl = w.fill.get() + (size_t)w.parity * NB; const uint32_t top = 31 - (uint32_t)__builtin_clz(NB); const dim3 lanes_grid((WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) / 256), fold_grid(NB + WFUSED_ONES_GROUPS);
+      if constexpr (sizeof(F) == 32) {
+        Point29Rec *p1 = (Point29Rec *)partials.get(), *p2 = (Point29Rec *)ones_partial.get();
+        { Stage st((label + ".accumulate").c_str(), s);
+          hipLaunchKernelGGL(k_wacc_lanes29<0>, lanes_grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), (const Affine<Fq> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, p1, lane_off.get());
+          hipLaunchKernelGGL(k_wfold29<0>, fold_grid, dim3(256), 0, s, (const Point29Rec *)p1, (const uint32_t *)lane_off.get(), NB, (uint32_t)WFUSED_BUCKET_LANES, p2); }
+        { Stage st((label + ".reduce").c_str(), s);
           hipLaunchKernelGGL(k_wtail29<0>, dim3(top + 2), dim3(256), 0, s, (const Point29Rec *)p2, NB, (const Point29Rec *)p2 + NB, (uint32_t)WFUSED_ONES_GROUPS, (uint32_t)WTAIL_SLOTS, (XYZZ<Fq> *)res, wc + w.parity, cdst); }
-          return; }
-        else { n_op = WFUSED_ONES_GROUPS; XYZZ<F> *l1 = (XYZZ<F> *)partials.get();
-          hipLaunchKernelGGL((k_wacc_lanes<F>), dim3((WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) / 256), dim3(256), 0, s, (const Affine<F> *)points.get(), (const Affine<F> *)bases->ones_groups.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, l1, lane_off.get());
-          hipLaunchKernelGGL((k_wacc_fold<F>), dim3(NB + WFUSED_ONES_GROUPS), dim3(256), 0, s, (const XYZZ<F> *)l1, (const uint32_t *)lane_off.get(), NB, l2); } }
-      { Stage st((label + ".reduce").c_str(), s); const uint32_t top = 31 - (uint32_t)__builtin_clz(NB); hipLaunchKernelGGL((k_wtail<F>), dim3(top + 2), dim3(256), 0, s, (const XYZZ<F> *)l2, NB, (const XYZZ<F> *)l2 + NB, n_op, res, csrc, cdst); }   // one workgroup per weight bit, one for bucket NB - 1, one for the ones
+      } else {
+        XYZZ<F> *l1 = (XYZZ<F> *)partials.get();
+        { Stage st((label + ".accumulate").c_str(), s);
+          hipLaunchKernelGGL(k_wacc_lanes_g2_29<0>, lanes_grid, dim3(256), 0, s, (const Affine<Fq2> *)bases->points261.get(), (const Affine<Fq2> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, (XYZZ<Fq2> *)l1, lane_off.get());
+          hipLaunchKernelGGL((k_wacc_fold<F>), fold_grid, dim3(256), 0, s, (const XYZZ<F> *)l1, (const uint32_t *)lane_off.get(), NB, l2); }
+        { Stage st((label + ".reduce").c_str(), s);
+          hipLaunchKernelGGL((k_wtail<F>), dim3(top + 2), dim3(256), 0, s, (const XYZZ<F> *)l2, NB, (const XYZZ<F> *)l2 + NB, (uint32_t)WFUSED_ONES_GROUPS, res, csrc, cdst); }   // one workgroup per weight bit, one for bucket NB - 1, one for the ones
+      }
       return;
     }
     const bool hs_run = hsort && scalar_index == nullptr;
@@ -232,10 +232,6 @@ struct MsmImpl {
       const HtailShape ts = htail_shape(NB);
       hipLaunchKernelGGL(k_hmarg29<0>, dim3(htail_marg_blocks(ts)), dim3(256), 0, s, (const Point29Rec *)hb29.get(), NB, (Point29Rec *)hmarg.get());
       hipLaunchKernelGGL(k_hbits29<0>, dim3(ts.top + 1), dim3(256), 0, s, (const Point29Rec *)hmarg.get(), NB, (XYZZ<Fq> *)res, cnt, (uint4 *)(res + RS + 1)); } }
-    else if (bitsum && hs_run) { Stage st_red((label + ".reduce").c_str(), s);
-      uint32_t per = 8; while (per > 4 && (NB / 2) % (64 * per)) per >>= 1; const uint32_t top = (uint32_t)RS - 1, chunks = (NB / 2) / (64 * per);   // sums by weight bit; the host's Horner rule does the rest (combine() with c = 1)
-      hipLaunchKernelGGL((k_bitsum_chunks<F>), dim3(chunks, top), dim3(256), 0, s, (const XYZZ<F> *)bucket_array(), per, (XYZZ<F> *)seg_out.get());
-      hipLaunchKernelGGL((k_bitsum_final<F>), dim3(top + 1), dim3(256), 0, s, (const XYZZ<F> *)seg_out.get(), chunks, top, (const XYZZ<F> *)bucket_array(), NB, res, (uint4 *)cnt, (uint4 *)(res + RS + 1)); }
     else { Stage st_red((label + ".reduce").c_str(), s);
       if (RS > WB) memset(h_result + (size_t)WB * sizeof(XYZZ<F>), 0, (size_t)(RS - WB) * sizeof(XYZZ<F>));   // (a bit-sum MSM on its fallback path: one window sum in slot 0, the other slots at infinity; the host may write here: the run that used these slots was synchronised before this one started)
       uint32_t spw = NB / seg, nseg = (uint32_t)WB * spw; uint4 *csrc = (uint4 *)cnt; uint4 *cdst = (uint4 *)(res + RS + 1);

@@ -208,10 +208,12 @@ __global__ void __launch_bounds__(64) k_r1cs_long_rows3(const uint32_t *__restri
 // tags (optional): one byte per variable — 0 the value is zero, 1 it is one, 2 anything else — for the kernels that need not look at the 32-byte value of a bit
 // (k_r1cs_rows_tagged below, k_wsort_tagged in msm.cuh); other_vars (optional): the list of the variables tagged 2, in the order of `values`.
 constexpr uint8_t ZTAG_ZERO = 0, ZTAG_ONE = 1, ZTAG_OTHER = 2;
-__global__ void k_expand_witness(const uint64_t *__restrict__ ones_bm, const uint64_t *__restrict__ other_bm, const uint32_t *__restrict__ block_off, const Fr *__restrict__ values, Fr one_value, int values_to_mont, uint32_t n, Fr *__restrict__ out,
-                                 uint8_t *__restrict__ tags, uint32_t *__restrict__ other_vars) {
+// canon_bm (optional): the variables whose value arrives canonical and is brought into Montgomery form here (a host-buffer assignment: all of them, i.e. other_bm itself;
+// a circuit board: its small integers, circuit::Board::TAG_SMALL) — the device has the multipliers to spare, the calling thread does not.
+__global__ void k_expand_witness(const uint64_t *__restrict__ ones_bm, const uint64_t *__restrict__ other_bm, const uint64_t *__restrict__ canon_bm, const uint32_t *__restrict__ block_off, const Fr *__restrict__ values, Fr one_value, uint32_t n,
+                                 Fr *__restrict__ out, uint8_t *__restrict__ tags, uint32_t *__restrict__ other_vars) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; const uint32_t wd = i >> 6, bit = i & 63; const uint64_t ob = other_bm[wd];
-  if ((ob >> bit) & 1) { const uint32_t at = block_off[wd] + (uint32_t)__popcll(ob & ((1ull << bit) - 1)); Fr v = values[at]; if (values_to_mont) v = v.to_mont(); out[i] = v; if (tags) tags[i] = ZTAG_OTHER; if (other_vars) other_vars[at] = i; }   // (a canonical assignment: only these 3 % need the conversion, one_value is the Montgomery one)
+  if ((ob >> bit) & 1) { const uint32_t at = block_off[wd] + (uint32_t)__popcll(ob & ((1ull << bit) - 1)); Fr v = values[at]; if (canon_bm && ((canon_bm[wd] >> bit) & 1)) v = v.to_mont(); out[i] = v; if (tags) tags[i] = ZTAG_OTHER; if (other_vars) other_vars[at] = i; }   // (a canonical assignment: only these 3 % need the conversion, one_value is the Montgomery one)
   else { const bool is_one = (ones_bm[wd] >> bit) & 1; out[i] = is_one ? one_value : Fr::zero(); if (tags) tags[i] = is_one ? ZTAG_ONE : ZTAG_ZERO; }
 }
 // both of the above in ONE launch (the two are independent and each too small to fill the chip for long: 27 + 25 us one after the other at the head of every proof's

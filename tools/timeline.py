@@ -15,7 +15,7 @@ def col(r, *names):
 ev = sorted(((int(col(r, "Start_Timestamp")), int(col(r, "End_Timestamp")), col(r, "Kernel_Name"), col(r, "Stream_Id", "Queue_Id")) for r in rows), key=lambda t: t[0])
 starts = []
 for i, e in enumerate(ev):
-    if "k_r1cs_rows" in e[2] and (not starts or e[0] - ev[starts[-1]][0] > 1000000): starts.append(i)      # three row kernels per proof: keep the first
+    if "k_r1cs_rows" in e[2] and (not starts or e[0] - ev[starts[-1]][0] > 300000): starts.append(i)       # (row kernels less than 0.3 ms apart belong to one proof; proofs follow each other in less than 1 ms since round 4)
 k = back if back < len(starts) - 1 else len(starts) - 2          # argument = proof number from the start of the trace
 lo = ev[starts[k]][0] - 100000; hi = ev[starts[k + 1]][0] - 100000
 sel = [e for e in ev if lo <= e[0] < hi]
