@@ -335,6 +335,8 @@ int zkgpu_test_pool_plan(int D, int spill, const int *release_before, int n_call
  * a lane.  Returns -1 if any member is left without a lane, else the largest number of provers sharing one lane; out_lanes_per_slot[d] = lanes bound to device slot d. */
 int zkgpu_test_lane_plan(int n_slots, int kinds, int per_kind, int *out_lanes_per_slot) {
   return lane_plan_simulate(n_slots, kinds, per_kind, out_lanes_per_slot); }
+/* the hand-over's block classifiers, scalar against the forms the host's CPU selects (AVX2 where it has it): see groth16.cpp: test_scan_blocks */
+int zkgpu_test_scan_blocks(const uint8_t *tags64, const uint64_t *elems64x4, const uint64_t *one4, uint64_t *out10) { return guarded_host([&] { test_scan_blocks(tags64, elems64x4, one4, out10); return ZKGPU_OK; }); }
 /* host-only self-test of the container code (tests/test_key_container_cpu.py): a synthetic transformed key of the given shape is written, mapped back and compared; then the
  * file is truncated, a payload byte is flipped, and the source stamp is changed — each must make the loader refuse.  Returns 0 if every step behaved. */
 int zkgpu_test_key_container(const char *path, size_t n_vars, size_t n_cons, size_t m) { int rc = -1; guarded_host([&] {

@@ -380,6 +380,34 @@ static void classify_block64(const uint64_t *v, const uint64_t (&o1)[4], uint64_
 #else
 static void classify_block64(const uint64_t *v, const uint64_t (&o1)[4], uint64_t &mo, uint64_t &mx) { classify_block64_scalar(v, o1, mo, mx); }
 #endif
+// 64 tag bytes of a circuit board -> three bit masks (bit 0: "is one", bit 1: "has a value", bit 2: "that value is a small integer"), Prover::set_witness_tagged
+static void tags_block64_scalar(const uint8_t *tag, uint64_t &mo, uint64_t &mx, uint64_t &mc) {
+  constexpr uint64_t LSB = 0x0101010101010101ull, GATHER = 0x0102040810204080ull;              // (y & LSB) * GATHER >> 56: the low bits of 8 bytes as one byte
+  for (size_t k = 0; k < 8; k++) { uint64_t x; memcpy(&x, tag + 8 * k, 8);
+    mo |= (((x & LSB) * GATHER) >> 56) << (8 * k); mx |= ((((x >> 1) & LSB) * GATHER) >> 56) << (8 * k); mc |= ((((x >> 2) & LSB) * GATHER) >> 56) << (8 * k); } }
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void tags_block64_avx2(const uint8_t *tag, uint64_t &mo, uint64_t &mx, uint64_t &mc) {
+  const __m256i lo = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(tag)), hi = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(tag + 32));
+  // bit b of every byte -> the byte's sign bit (a 16-bit shift by 7 - b: what spills over from the lower byte lands below the sign bit) -> movemask
+  mo |= (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(lo, 7)) | (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(hi, 7)) << 32;
+  mx |= (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(lo, 6)) | (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(hi, 6)) << 32;
+  mc |= (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(lo, 5)) | (uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(hi, 5)) << 32; }
+static bool host_has_avx2() { static const bool v = __builtin_cpu_supports("avx2"); return v; }
+#else
+static bool host_has_avx2() { return false; }
+#endif
+// host-only self-test of the two block classifiers (tests/test_key_container_cpu.py is the model: pure host logic reachable through the C-ABI): the AVX2 forms must give
+// the scalar forms' masks.  out[0..2] / out[3..5]: tag masks scalar / fast; out[6..7] / out[8..9]: element masks (is one, has another value) scalar / fast
+void test_scan_blocks(const uint8_t tags[64], const uint64_t elems[256], const uint64_t one[4], uint64_t out[10]) {
+  for (int i = 0; i < 10; i++) out[i] = 0;
+  tags_block64_scalar(tags, out[0], out[1], out[2]);
+#if defined(__x86_64__)
+  if (host_has_avx2()) tags_block64_avx2(tags, out[3], out[4], out[5]); else
+#endif
+  tags_block64_scalar(tags, out[3], out[4], out[5]);
+  uint64_t o1[4] = {one[0], one[1], one[2], one[3]};
+  classify_block64_scalar(elems, o1, out[6], out[7]); classify_block64(elems, o1, out[8], out[9]);
+}
 void Prover::set_witness(const Fe32 *z, bool montgomery) {
   Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); const size_t n = p.nv + 1, words = (n + 63) / 64;
   Fe32 one; if (montgomery) memcpy(&one, FrParams::R1, 32); else { memset(&one, 0, 32); one.l[0] = 1; }
@@ -421,19 +449,28 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
   Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); const size_t n = p.nv + 1, words = (n + 63) / 64; Fe32 one; memcpy(&one, FrParams::R1, 32);
   uint8_t *pk = reinterpret_cast<uint8_t *>(p.z_host.get()); uint64_t *ones = (uint64_t *)pk, *other = ones + words, *canon = other + words; uint32_t *off = (uint32_t *)(canon + words);   // the layout set_witness builds, with a third bitmap: the values that are still canonical (the board's small integers)
   const size_t vals_at = expand_values_offset(words, 2); Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
-  constexpr uint64_t LSB = 0x0101010101010101ull, GATHER = 0x0102040810204080ull;              // (y & LSB) * GATHER >> 56: the low bits of 8 bytes as one byte
+  const bool avx2 = host_has_avx2();
   // like set_witness: the prover's submit threads — idle at this point of a call — take a quarter of the words each (0.28 -> 0.1 ms for send on the GPU box's host); every
   // thread owns a quarter of the value area, closed up afterwards
   constexpr size_t T = 4; const size_t cap_t = max_other / T; size_t used[T] = {0, 0, 0, 0}; bool fits_t[T] = {true, true, true, true};
-  auto scan = [&](size_t t) { const size_t w0 = words * t / T, w1 = words * (t + 1) / T, base = t * cap_t; size_t n_other = 0;
-    for (size_t w = w0; w < w1; w++) { const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; uint64_t mo = 0, mx = 0, mc = 0; off[w] = (uint32_t)(base + n_other);
-      if (hi - lo == 64) for (size_t k = 0; k < 8; k++) { uint64_t x; memcpy(&x, tag + lo + 8 * k, 8); mo |= (((x & LSB) * GATHER) >> 56) << (8 * k); mx |= ((((x >> 1) & LSB) * GATHER) >> 56) << (8 * k); mc |= ((((x >> 2) & LSB) * GATHER) >> 56) << (8 * k); }
-      else for (size_t i = lo; i < hi; i++) { mo |= (uint64_t)(tag[i] & 1) << (i - lo); mx |= (uint64_t)((tag[i] >> 1) & 1) << (i - lo); mc |= (uint64_t)((tag[i] >> 2) & 1) << (i - lo); }
-      if (n_other + (size_t)__builtin_popcountll(mx) > cap_t) { fits_t[t] = false; return; }
+  auto scan = [&](size_t t) { const size_t w0 = words * t / T, w1 = words * (t + 1) / T, base = t * cap_t; size_t n_other = 0, pend_lo = 0; uint64_t pend_mx = 0, pend_mc = 0;
+    auto copy_values = [&](size_t lo, uint64_t mx, uint64_t mc) {
       for (uint64_t m = mx; m; m &= m - 1) { const size_t i = lo + (size_t)__builtin_ctzll(m); Fe32 &dst = vals[base + n_other++];
         if ((mc >> (i - lo)) & 1) { memset(&dst, 0, 32); dst.l[0] = wide[i].l[0]; dst.l[1] = wide[i].l[1]; }   // a small integer the board kept as it was (circuit::Board::TAG_SMALL, only its low 64 bits are meaningful): the device converts it
-        else dst = wide[i]; }
+        else dst = wide[i]; } };
+    for (size_t w = w0; w < w1; w++) { const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; uint64_t mo = 0, mx = 0, mc = 0; off[w] = (uint32_t)(base + n_other + (size_t)__builtin_popcountll(pend_mx));
+      if (hi - lo == 64) {
+#if defined(__x86_64__)
+        if (avx2) tags_block64_avx2(tag + lo, mo, mx, mc); else
+#endif
+        tags_block64_scalar(tag + lo, mo, mx, mc); }
+      else for (size_t i = lo; i < hi; i++) { mo |= (uint64_t)(tag[i] & 1) << (i - lo); mx |= (uint64_t)((tag[i] >> 1) & 1) << (i - lo); mc |= (uint64_t)((tag[i] >> 2) & 1) << (i - lo); }
+      if (n_other + (size_t)__builtin_popcountll(mx) + (size_t)__builtin_popcountll(pend_mx) > cap_t) { fits_t[t] = false; return; }
+      for (uint64_t m = mx; m; m &= m - 1) __builtin_prefetch(&wide[lo + (size_t)__builtin_ctzll(m)]);            // this block's values are fetched while the previous block's are copied:
+      copy_values(pend_lo, pend_mx, pend_mc);                                                                      // the 7,600 values lie scattered over a 7 MB array, one cache miss each
+      pend_lo = lo; pend_mx = mx; pend_mc = mc;
       ones[w] = mo; other[w] = mx; canon[w] = mc; }
+    copy_values(pend_lo, pend_mx, pend_mc);
     used[t] = n_other; };
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
   auto worker = [&](size_t t) -> SubmitWorker & { if (!p.workers[t]) p.workers[t].reset(new SubmitWorker(p.lane)); return *p.workers[t]; };

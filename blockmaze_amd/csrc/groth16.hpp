@@ -98,4 +98,5 @@ std::string proof_to_hex(const Proof &p);
 bool proof_from_hex(const char *hex, Proof &p);   // reads exactly 512 characters; false on a non-hex character
 Proof default_proof();                            // (G1::one, G2::one, G1::one) — r1cs_gg_ppzksnark.hpp:309-315
 
+void test_scan_blocks(const uint8_t tags[64], const uint64_t elems[256], const uint64_t one[4], uint64_t out[10]);   // host-only self-test of the hand-over's block classifiers (scalar against AVX2 forms)
 }  // namespace zk
