@@ -364,78 +364,124 @@ __device__ __forceinline__ XYZZ29 xyzz29_add(const XYZZ29 &a, const XYZZ29 &b) {
 // up.  (Converting here, four products per piece, looked cheap per lane and was not per wave: with 64 lanes and buckets of ~11 runs some lane reaches a bucket boundary
 // in nearly every iteration, so the whole wave walked the conversion code every time: 0.366 ms, no faster than the 32-bit loop.)
 struct Piece29 { uint32_t w[36]; };
-__device__ __forceinline__ void hacc_flush29(const XYZZ29 &acc, bool inf, uint32_t bucket, uint32_t t, uint32_t g, const uint32_t *__restrict__ offsets, const HsortShape &sh, uint32_t run, uint32_t maxp, Piece29 *__restrict__ partials, MsmCounters *cnt) {
-  const uint32_t piece = t - (offsets[bucket] - g * sh.region) / run;
+__device__ __forceinline__ void hacc_flush29(const XYZZ29 &acc, bool inf, uint32_t bucket, uint32_t t, uint32_t g, const uint32_t *__restrict__ offsets, const HsortShape &sh, uint32_t run, uint32_t maxp,
+                                             Piece29 *__restrict__ partials, MsmCounters *cnt) {
+  const uint32_t piece = t - (offsets[bucket] - g * sh.region) / run;                    // which of the bucket's pieces this lane holds: runs since the bucket's first entry
   if (piece >= maxp) { atomicOr(&cnt->pad[0], 1u); return; }
-  uint4 *dst = reinterpret_cast<uint4 *>(partials + (size_t)bucket * maxp + piece); const uint32_t z = inf ? 0u : ~0u;
-  dst[0] = make_uint4(acc.X.l[0], acc.X.l[1], acc.X.l[2], acc.X.l[3]); dst[1] = make_uint4(acc.X.l[4], acc.X.l[5], acc.X.l[6], acc.X.l[7]); dst[2] = make_uint4(acc.X.l[8], acc.Y.l[0], acc.Y.l[1], acc.Y.l[2]);
-  dst[3] = make_uint4(acc.Y.l[3], acc.Y.l[4], acc.Y.l[5], acc.Y.l[6]); dst[4] = make_uint4(acc.Y.l[7], acc.Y.l[8], acc.ZZ.l[0] & z, acc.ZZ.l[1] & z); dst[5] = make_uint4(acc.ZZ.l[2] & z, acc.ZZ.l[3] & z, acc.ZZ.l[4] & z, acc.ZZ.l[5] & z);
-  dst[6] = make_uint4(acc.ZZ.l[6] & z, acc.ZZ.l[7] & z, acc.ZZ.l[8] & z, acc.ZZZ.l[0]); dst[7] = make_uint4(acc.ZZZ.l[1], acc.ZZZ.l[2], acc.ZZZ.l[3], acc.ZZZ.l[4]); dst[8] = make_uint4(acc.ZZZ.l[5], acc.ZZZ.l[6], acc.ZZZ.l[7], acc.ZZZ.l[8]);
+  uint4 *dst = reinterpret_cast<uint4 *>(partials + (size_t)bucket * maxp + piece);
+  const uint32_t z = inf ? 0u : ~0u;                                                     // all-zero ZZ limbs = the point at infinity
+  const Fq29 &X = acc.X, &Y = acc.Y, &ZZ = acc.ZZ, &ZZZ = acc.ZZZ;
+  dst[0] = make_uint4(X.l[0], X.l[1], X.l[2], X.l[3]);
+  dst[1] = make_uint4(X.l[4], X.l[5], X.l[6], X.l[7]);
+  dst[2] = make_uint4(X.l[8], Y.l[0], Y.l[1], Y.l[2]);
+  dst[3] = make_uint4(Y.l[3], Y.l[4], Y.l[5], Y.l[6]);
+  dst[4] = make_uint4(Y.l[7], Y.l[8], ZZ.l[0] & z, ZZ.l[1] & z);
+  dst[5] = make_uint4(ZZ.l[2] & z, ZZ.l[3] & z, ZZ.l[4] & z, ZZ.l[5] & z);
+  dst[6] = make_uint4(ZZ.l[6] & z, ZZ.l[7] & z, ZZ.l[8] & z, ZZZ.l[0]);
+  dst[7] = make_uint4(ZZZ.l[1], ZZZ.l[2], ZZZ.l[3], ZZZ.l[4]);
+  dst[8] = make_uint4(ZZZ.l[5], ZZZ.l[6], ZZZ.l[7], ZZZ.l[8]);
 }
 __device__ __forceinline__ XYZZ29 piece29_load(const Piece29 *p, bool &inf) {
-  const uint4 *s = reinterpret_cast<const uint4 *>(p); uint32_t w[36];
+  const uint4 *s = reinterpret_cast<const uint4 *>(p);
+  uint32_t w[36];
 #pragma unroll
   for (int i = 0; i < 9; i++) { const uint4 v = s[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
-  XYZZ29 r; uint32_t o = 0;
+  XYZZ29 r;
+  uint32_t zz_or = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) { r.X.l[i] = w[i]; r.Y.l[i] = w[9 + i]; r.ZZ.l[i] = w[18 + i]; r.ZZZ.l[i] = w[27 + i]; o |= w[18 + i]; }
-  inf = o == 0; return r;
+  for (int i = 0; i < 9; i++) { r.X.l[i] = w[i]; r.Y.l[i] = w[9 + i]; r.ZZ.l[i] = w[18 + i]; r.ZZZ.l[i] = w[27 + i]; zz_or |= w[18 + i]; }
+  inf = zz_or == 0;
+  return r;
 }
 template <int ANY_INF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_hacc_runs29(const Affine<Fq> *__restrict__ points261, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ group_n, const uint32_t *__restrict__ offsets, HsortShape sh, uint32_t run, uint32_t maxp,
-                                                     Piece29 *__restrict__ partials, MsmCounters *cnt) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_hacc_runs29(const Affine<Fq> *__restrict__ points261, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ group_n, const uint32_t *__restrict__ offsets, HsortShape sh, uint32_t run, uint32_t maxp,
+              Piece29 *__restrict__ partials, MsmCounters *cnt) {
+  // which run is this lane's?  base[g] = the number of runs in the groups before g: an exclusive scan of ceil(n_g / run), recomputed by every workgroup
   __shared__ uint32_t base[HSORT_GROUPS + 1], wave_tot[4];
-  { const uint32_t per = (sh.groups + 255) / 256, lo = threadIdx.x * per; uint32_t s = 0;                       // exclusive scan of ceil(n_g / run) over the groups 
+  {
+    const uint32_t per = (sh.groups + 255) / 256, lo = threadIdx.x * per;
+    uint32_t s = 0;
     for (uint32_t j = 0; j < per; j++) if (lo + j < sh.groups) s += (min(group_n[lo + j], sh.region) + run - 1) / run;
-    uint32_t inc = s; for (int d = 1; d < 64; d <<= 1) { uint32_t u = __shfl_up(inc, d, 64); if ((int)(threadIdx.x & 63) >= d) inc += u; }
+    uint32_t inc = s;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t u = __shfl_up(inc, d, 64); if ((int)(threadIdx.x & 63) >= d) inc += u; }
     if ((threadIdx.x & 63) == 63) wave_tot[threadIdx.x >> 6] = inc;
     __syncthreads();
-    uint32_t ex = inc - s; for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) ex += wave_tot[wv];
+    uint32_t ex = inc - s;
+    for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) ex += wave_tot[wv];
     for (uint32_t j = 0; j < per; j++) if (lo + j < sh.groups) { base[lo + j] = ex; ex += (min(group_n[lo + j], sh.region) + run - 1) / run; }
     if (threadIdx.x == 255) base[sh.groups] = ex;
-    __syncthreads(); }
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; if (r >= base[sh.groups]) return;
-  uint32_t glo = 0, ghi = sh.groups; while (ghi - glo > 1) { const uint32_t mid = (glo + ghi) >> 1; if (base[mid] <= r) glo = mid; else ghi = mid; }
-  const uint32_t g = glo, t = r - base[g], n_g = min(group_n[g], sh.region), beg = t * run;
-  const uint32_t end = min(beg + run, n_g), idx_mask = (1u << sh.idx_bits) - 1, shift = sh.idx_bits + 1; const uint32_t *e = entries + (size_t)g * sh.region;
-  uint32_t v = e[beg], vn = beg + 1 < end ? e[beg + 1] : v; Affine<Fq> p = points261[v & idx_mask];
-  uint32_t cur = v >> shift; bool inf = true; XYZZ29 acc;
+    __syncthreads();
+  }
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= base[sh.groups]) return;
+  uint32_t glo = 0, ghi = sh.groups;                                                     // the group g with base[g] <= r < base[g + 1]
+  while (ghi - glo > 1) { const uint32_t mid = (glo + ghi) >> 1; if (base[mid] <= r) glo = mid; else ghi = mid; }
+  const uint32_t g = glo, t = r - base[g], n_g = min(group_n[g], sh.region), beg = t * run, end = min(beg + run, n_g);
+  const uint32_t idx_mask = (1u << sh.idx_bits) - 1, shift = sh.idx_bits + 1;            // entry = low bucket bits | sign | table index
+  const uint32_t *e = entries + (size_t)g * sh.region;
+  uint32_t v = e[beg], vn = beg + 1 < end ? e[beg + 1] : v, cur = v >> shift;
+  Affine<Fq> p = points261[v & idx_mask];
+  bool inf = true;
+  XYZZ29 acc;
 #pragma unroll
   for (int i = 0; i < 9; i++) { acc.X.l[i] = 0; acc.Y.l[i] = 0; acc.ZZ.l[i] = 0; acc.ZZZ.l[i] = 0; }
 #pragma unroll 1
   for (uint32_t i = beg; i < end; i++) {
-    Affine<Fq> pn = points261[vn & idx_mask]; const uint32_t vnn = i + 2 < end ? e[i + 2] : vn, low = v >> shift;   // software pipeline: the next point's gather is in flight during this addition
-    if (low != cur) { hacc_flush29(acc, inf, (g << sh.low_bits) | cur, t, g, offsets, sh, run, maxp, partials, cnt); cur = low; inf = true; }
-    if (ANY_INF && p.is_inf()) { }                         // a key point at infinity adds nothing
-    else { const Fq29 px = Fq29::unpack(p.x.l), py = Fq29::cond_neg(Fq29::unpack(p.y.l), (v >> sh.idx_bits) & 1u);
-      if (inf) { acc.X = px; acc.Y = py.norm(); acc.ZZ = Fq29::one(); acc.ZZZ = Fq29::one(); inf = false; } else { Fq29 Pv, Rv; acc.madd_head(px, py, Pv, Rv); acc.madd_tail(Pv, Rv); } }
+    const Affine<Fq> pn = points261[vn & idx_mask];                                      // software pipeline: the next point's gather is in flight during this addition
+    const uint32_t vnn = i + 2 < end ? e[i + 2] : vn, low = v >> shift;
+    if (low != cur) {                                                                    // a bucket boundary inside the run: the sum so far is a piece of the bucket left behind
+      hacc_flush29(acc, inf, (g << sh.low_bits) | cur, t, g, offsets, sh, run, maxp, partials, cnt);
+      cur = low; inf = true;
+    }
+    if (ANY_INF && p.is_inf()) {                                                         // a key point at infinity adds nothing
+    } else {
+      const Fq29 px = Fq29::unpack(p.x.l), py = Fq29::cond_neg(Fq29::unpack(p.y.l), (v >> sh.idx_bits) & 1u);
+      if (inf) { acc.X = px; acc.Y = py.norm(); acc.ZZ = Fq29::one(); acc.ZZZ = Fq29::one(); inf = false; }
+      else { Fq29 Pv, Rv; acc.madd_head(px, py, Pv, Rv); acc.madd_tail(Pv, Rv); }
+    }
     v = vn; p = pn; vn = vnn;
   }
   hacc_flush29(acc, inf, (g << sh.low_bits) | cur, t, g, offsets, sh, run, maxp, partials, cnt);
 }
-// bucket b = the sum of its pieces, still on 29-bit limbs (14 products of 162 multiply-adds); 2^ll neighbouring lanes share the pieces, the first of them converts the
-// sum to the lazy 8 x 32-bit form (one product per coordinate with 2^256 mod p) that the weighted bucket sum reads.  ZZ = 0 (mod p) in a sum — two pieces were +-each
-// other somewhere, or an operand of the accumulation was +-its accumulator — raises the flag that sends the MSM to the general path.
-static __global__ void __launch_bounds__(256) k_hacc_combine29(const Piece29 *__restrict__ partials, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts, HsortShape sh, uint32_t run, uint32_t maxp, uint32_t n_buckets, uint32_t ll,
-                                                        XYZZ<Fq> *__restrict__ buckets, Point29Rec *__restrict__ buckets29, MsmCounters *cnt) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = t >> ll, sub = t & ((1u << ll) - 1), step = 1u << ll; const bool live = b < n_buckets; uint32_t np = 0;
-  if (live) { const uint32_t c = counts[b], off = offsets[b] - (b >> sh.low_bits) * sh.region; if (c) np = min((off + c - 1) / run - off / run + 1, maxp); }
-  const Piece29 *src = partials + (size_t)(live ? b : 0) * maxp; XYZZ29 acc; bool inf = true;
+// bucket b = the sum of its pieces, still on 29-bit limbs (14 products of 162 multiply-adds); 2^ll neighbouring lanes share the pieces.  The sum leaves as a Point29Rec
+// for the weighted bucket sum (htail29.cuh) — or, with buckets29 = null, converted to the lazy 8 x 32-bit form (one product per coordinate with 2^256 mod p).  ZZ = 0
+// (mod p) in a sum — two pieces were +-each other somewhere, or an operand of the accumulation was +-its accumulator — raises the flag that sends the MSM to the general path.
+static __global__ void __launch_bounds__(256) k_hacc_combine29(const Piece29 *__restrict__ partials, const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts, HsortShape sh, uint32_t run, uint32_t maxp, uint32_t n_buckets,
+                                                               uint32_t ll, XYZZ<Fq> *__restrict__ buckets, Point29Rec *__restrict__ buckets29, MsmCounters *cnt) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = t >> ll, sub = t & ((1u << ll) - 1), step = 1u << ll;
+  const bool live = b < n_buckets;
+  uint32_t np = 0;                                                                       // how many pieces the accumulation left for this bucket
+  if (live) {
+    const uint32_t c = counts[b], off = offsets[b] - (b >> sh.low_bits) * sh.region;
+    if (c) np = min((off + c - 1) / run - off / run + 1, maxp);
+  }
+  const Piece29 *src = partials + (size_t)(live ? b : 0) * maxp;
+  XYZZ29 acc;
+  bool inf = true;
 #pragma unroll
   for (int i = 0; i < 9; i++) { acc.X.l[i] = 0; acc.Y.l[i] = 0; acc.ZZ.l[i] = 0; acc.ZZZ.l[i] = 0; }
 #pragma unroll 1
-  for (uint32_t j = sub; j < np; j += step) { bool pinf; const XYZZ29 cur = piece29_load(src + j, pinf); if (pinf) continue; if (inf) { acc = cur; inf = false; } else acc = xyzz29_add(acc, cur); }
+  for (uint32_t j = sub; j < np; j += step) {
+    bool pinf;
+    const XYZZ29 cur = piece29_load(src + j, pinf);
+    if (pinf) continue;
+    if (inf) { acc = cur; inf = false; } else acc = xyzz29_add(acc, cur);
+  }
 #pragma unroll 1
-  for (uint32_t d = step >> 1; d >= 1; d >>= 1) {
-    XYZZ29 o; const bool oinf = __shfl_down((int)inf, d, 64) != 0;
+  for (uint32_t d = step >> 1; d >= 1; d >>= 1) {                                        // the lanes of a bucket meet by shuffles
+    XYZZ29 o;
+    const bool oinf = __shfl_down((int)inf, d, 64) != 0;
 #pragma unroll
-    for (int i = 0; i < 9; i++) { o.X.l[i] = __shfl_down(acc.X.l[i], d, 64); o.Y.l[i] = __shfl_down(acc.Y.l[i], d, 64); o.ZZ.l[i] = __shfl_down(acc.ZZ.l[i], d, 64); o.ZZZ.l[i] = __shfl_down(acc.ZZZ.l[i], d, 64); }
-    if (sub + d < step && !oinf) { if (inf) { acc = o; inf = false; } else acc = xyzz29_add(acc, o); } }
-  if (live && sub == 0 && buckets29) {   // the weighted sum stays on 29-bit limbs (htail29.cuh): the sum as it is, four coordinate slots of twelve words; all-zero limbs = the point at infinity
-    uint32_t zero_or = 0, p_xor = 0;                                                     // ZZ is a product's result — exact limbs, below 2p: ZZ = 0 (mod p) means 0 or p
-#pragma unroll
-    for (int i = 0; i < 9; i++) { zero_or |= acc.ZZ.l[i]; p_xor |= acc.ZZ.l[i] ^ Fq29::P29[i]; }
-    if (!inf && (zero_or == 0 || p_xor == 0)) atomicOr(&cnt->pad[0], 1u);
+    for (int i = 0; i < 9; i++) {
+      o.X.l[i] = __shfl_down(acc.X.l[i], d, 64); o.Y.l[i] = __shfl_down(acc.Y.l[i], d, 64);
+      o.ZZ.l[i] = __shfl_down(acc.ZZ.l[i], d, 64); o.ZZZ.l[i] = __shfl_down(acc.ZZZ.l[i], d, 64);
+    }
+    if (sub + d < step && !oinf) { if (inf) { acc = o; inf = false; } else acc = xyzz29_add(acc, o); }
+  }
+  if (!live || sub != 0) return;
+  if (buckets29) {   // the weighted sum stays on 29-bit limbs (htail29.cuh): the sum as it is, four coordinate slots of twelve words; all-zero limbs = the point at infinity
+    if (!inf && fq29_product_is_zero(acc.ZZ)) atomicOr(&cnt->pad[0], 1u);                // (ZZ is a product's result, or the lifted one: exact limbs)
     const uint32_t z = inf ? 0u : ~0u;
     uint4 *dst = reinterpret_cast<uint4 *>(buckets29 + b);
     const Fq29 *coord[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
@@ -448,10 +494,13 @@ static __global__ void __launch_bounds__(256) k_hacc_combine29(const Piece29 *__
     }
     return;
   }
-  if (live && sub == 0) { XYZZ<Fq> o = XYZZ<Fq>::inf();
-    if (!inf) { acc.X.to_words(o.X.l); acc.Y.to_words(o.Y.l); acc.ZZ.to_words(o.ZZ.l); acc.ZZZ.to_words(o.ZZZ.l); if (o.ZZ.is_zero_lazy()) atomicOr(&cnt->pad[0], 1u);
-      o = XYZZ<Fq>{o.X.normalize(), o.Y.normalize(), o.ZZ.normalize(), o.ZZZ.normalize()}; }
-    buckets[b] = o; }
+  XYZZ<Fq> o = XYZZ<Fq>::inf();
+  if (!inf) {
+    acc.X.to_words(o.X.l); acc.Y.to_words(o.Y.l); acc.ZZ.to_words(o.ZZ.l); acc.ZZZ.to_words(o.ZZZ.l);
+    if (o.ZZ.is_zero_lazy()) atomicOr(&cnt->pad[0], 1u);
+    o = XYZZ<Fq>{o.X.normalize(), o.Y.normalize(), o.ZZ.normalize(), o.ZZZ.normalize()};
+  }
+  buckets[b] = o;
 }
 // table of the 29-bit kernel: coordinates x * 2^261 (mod p) from x * 2^256 — a Montgomery product with the plain integer 2^261 mod p; (0, 0) stays the point at infinity
 static __global__ void k_table_to_r261(const Affine<Fq> *__restrict__ in, Affine<Fq> *__restrict__ out, size_t n) {

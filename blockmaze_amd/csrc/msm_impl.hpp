@@ -199,7 +199,7 @@ struct MsmImpl {
       { Stage st((label + ".accumulate").c_str(), s); const dim3 grid(cdiv(cdiv(n * (size_t)W, h_run) + hs.groups, 256));   // one lane per run: at most ceil(entries / run) + one short run per group
         if (any_inf) hipLaunchKernelGGL(k_hacc_runs29<1>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(), offsets.get(), hs, h_run, h_maxp, (Piece29 *)partials.get(), cnt);
         else hipLaunchKernelGGL(k_hacc_runs29<0>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(), offsets.get(), hs, h_run, h_maxp, (Piece29 *)partials.get(), cnt); }
-      { Stage st((label + ".combine").c_str(), s); constexpr uint32_t ll = 1;   // two lanes per bucket
+      { Stage st((label + ".combine").c_str(), s); const size_t pieces = n * (size_t)W / NB / h_run; const uint32_t ll = pieces > 40 ? 3 : pieces > 18 ? 2 : 1;   // 2 / 4 / 8 lanes per bucket: about six pieces a lane (send: 12 pieces, two lanes; deposit at depth 32: 48 pieces — two lanes took 256 us there)
         hipLaunchKernelGGL(k_hacc_combine29, dim3(cdiv(nbk << ll, 256)), dim3(256), 0, s, (const Piece29 *)partials.get(), offsets.get(), hist(), hs, h_run, h_maxp, (uint32_t)nbk, ll, (XYZZ<Fq> *)bucket_array(), htail29 ? (Point29Rec *)hb29.get() : nullptr, cnt); }
       }
     } else
