@@ -304,7 +304,7 @@ struct Prover::Impl {
   size_t nv, ni, m; size_t a0 = 0, l0 = 0, b0 = 0, h0 = 0;   // first element of this shard in each query
   HG1 alpha_g1, beta_g1, delta_g1; HG2 beta_g2, delta_g2;
   std::unique_ptr<MsmG1> A, B1, H, L; std::unique_ptr<MsmG2> B2; std::unique_ptr<R1csDev> cs; std::unique_ptr<Domain> dom; std::shared_ptr<DevBuf<uint32_t>> B_idx; DevBuf<Fe32> z, abc; DevBuf<uint8_t> packed, tags; DevBuf<uint32_t> other_vars; std::shared_ptr<DevBuf<uint32_t>> B_pos /* inverse of the B query's index list */; uint32_t n_other = 0; bool tags_valid = false /* the assignment on the device came in compact form: tags holds 0 / 1 / 2 per variable */; PinnedBuf<Fe32> z_host;
-  std::unique_ptr<SubmitWorker> workers[4], scan_workers[4];   // scan_workers: only the hand-over scan of a host-buffer assignment (set_witness) on hosts with many cores
+  std::unique_ptr<SubmitWorker> workers[4], scan_workers[12];   // scan_workers: only the hand-over scan of a host-buffer assignment (set_witness) on hosts with many cores
   // The submit thread of a witness MSM also waits for its stream and finishes the MSM on the host (Horner combine, or the host tail of msm_impl.hpp): four threads do that
   // side by side while the H chain is still running.  pending[j]: job j (order B2, L, A, B1) was posted and its result slot is not valid before workers[j]->wait().
   HG2 rB2; HG1 rL, rA, rB1; bool pending[4] = {false, false, false, false}, inline_result[4] = {false, false, false, false};
@@ -418,11 +418,12 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   const size_t vals_at = expand_values_offset(words, 1); Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
   uint64_t o1[4]; memcpy(o1, &one, 32); const uint64_t *zz = reinterpret_cast<const uint64_t *>(z) - 4;   // zz + 4 i = entry i of [ONE, z_1 .. z_n]; entry 0 is handled apart
   // (round 3 measured six and eight threads no faster than four — on assignments that sat in the host's last-level cache.  bench.py cycles through 400 MB of distinct
-  // assignments: each scan then streams 7.3 MB from DRAM, a core sustains ~10 GB/s of that, and eight threads halve the 0.17 ms; hosts with fewer than 12 cores keep four)
-  constexpr size_t TMAX = 8; static const size_t T_many = [] { const char *e = getenv("ZK_SCAN_THREADS"); size_t t = e ? (size_t)atoi(e) : (std::thread::hardware_concurrency() >= 12 ? 8 : 4); return t < 1 ? (size_t)1 : t > TMAX ? TMAX : t; }();
+  // assignments: each scan then streams 7.3 MB from DRAM, a core sustains ~10 GB/s of that, and eight threads halve the 0.17 ms; sixteen gain another 5-8 % per proof on the
+  // GPU boxes (256 hardware threads visible; profiles/r04v_scan.txt); hosts with fewer than 32 / 12 hardware threads keep eight / four)
+  constexpr size_t TMAX = 16; static const size_t T_many = [] { const char *e = getenv("ZK_SCAN_THREADS"); const unsigned hw = std::thread::hardware_concurrency(); size_t t = e ? (size_t)atoi(e) : (hw >= 32 ? 16 : hw >= 12 ? 8 : 4); return t < 1 ? (size_t)1 : t > TMAX ? TMAX : t; }();
   static std::atomic<int> scanning{0}; struct Busy { std::atomic<int> &c; int before; explicit Busy(std::atomic<int> &c_) : c(c_), before(c.fetch_add(1)) {} ~Busy() { c.fetch_sub(1); } } busy(scanning);
   const size_t T = busy.before == 0 ? T_many : std::min<size_t>(T_many, 4);   // several provers handing over at once (proofs in flight): four threads each, as before
-  const size_t cap_t = max_other / T; size_t used[TMAX] = {0, 0, 0, 0, 0, 0, 0, 0}; bool fits[TMAX] = {true, true, true, true, true, true, true, true};
+  const size_t cap_t = max_other / T; size_t used[TMAX] = {}; bool fits[TMAX]; for (size_t t = 0; t < TMAX; t++) fits[t] = true;
   auto scan = [&](size_t t) { const size_t w0 = words * t / T, w1 = words * (t + 1) / T, base = t * cap_t; size_t n_other = 0;
     for (size_t w = w0; w < w1; w++) { uint64_t mo = 0, mx = 0; const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; off[w] = (uint32_t)(base + n_other);
       if (lo && hi - lo == 64) classify_block64(zz + 4 * lo, o1, mo, mx);                                         // a whole block: 256-bit loads where the host has them
