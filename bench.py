@@ -109,16 +109,25 @@ def run_rank(args):
     # (4 submit threads + a 3-thread witness pool per prover by default: 8 ranks x 8 threads on a 16-core pod would oversubscribe the host inside the timed region)
     cores = usable_cores(); per_rank = max(1, cores // world)
     if world > 1:
-        try:
-            mine = sorted(os.sched_getaffinity(0))[:cores][local_rank % world * per_rank:(local_rank % world + 1) * per_rank]
-            if mine: os.sched_setaffinity(0, mine)
-        except Exception: pass
         if per_rank < 4: os.environ.setdefault("ZK_SUBMIT_THREADS", "0")        # too few cores for helper threads: this rank's one thread submits everything itself
         os.environ.setdefault("ZK_WITNESS_THREADS", str(max(0, min(3, per_rank - 1))))
     from blockmaze_amd import engine as e
     import workload as w
     hx = lambda a: [("0x" + x.hex()) if isinstance(x, bytes) else x for x in a]
     e.init()                                                                 # raises "no HIP device visible" on a box without a GPU: there is no CPU path to fall back to
+    # N > 1: a rank runs on CPUs of the socket its GPU hangs off (MI355X hosts have two; the old placement cut the first `cores` CPUs, all on socket 0, over the ranks of both
+    # sockets' GPUs).  N = 1 keeps the kernel's placement: binding the one rank to its GPU's socket was measured and decided nothing (profiles/r04w_host_placement.txt:
+    # 1,015 and 909 proofs/s bound, 859 and 932 unbound on one shared box — the hand-over's 0.12-0.26 ms spread from process to process follows the other tenants, not the socket).
+    # ZK_BENCH_BIND=1 / 0 forces / forbids the binding.
+    host_binding = "none"
+    if os.environ.get("ZK_BENCH_BIND", "1" if world > 1 else "0") != "0" and hasattr(os, "sched_setaffinity"):
+        try:
+            from blockmaze_amd import sharding as placement
+            n_dev = max(1, torch.cuda.device_count()); gpu_nodes = [e.device_numa_node(i) for i in range(n_dev)]
+            mine = placement.host_cpus_for_rank(local_rank, world, gpu_nodes, placement.host_node_cpus(), os.sched_getaffinity(0), cores)
+            if mine:
+                os.sched_setaffinity(0, mine); host_binding = "GPU on NUMA node %d: rank bound to %d of its CPUs" % (gpu_nodes[local_rank % n_dev], len(mine))
+        except Exception as ex: log("bench: rank %d keeps the kernel's placement (%s)" % (rank, ex))
 
     # ---- untimed setup: test keys for the send circuit (seeded toxic waste), resident prover, one witness per step -----------------
     # ONE key for all ranks of the node: rank 0 makes a private directory (mkdtemp: no predictable path that a stale or foreign key could sit under), generates the key and,
@@ -327,7 +336,7 @@ def run_rank(args):
             "metric": "Groth16 proofs/sec (send circuit, alt_bn128)", "value": round(rate, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "step_ms": step_ms, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery; all MSM accumulations, the H query's weighted bucket sum and the transforms' tiles on nine 29-bit limbs)", "data": "synthetic witnesses (seeded send instances, every constraint satisfied) on a proving key made by this repo's GPU generator for the real send circuit; only the libsnark CPU leg uses a key with synthetic points of the same shape",
             "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "distinct_witnesses": n_inst,
-                       "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
+                       "host_binding": host_binding, "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
                        "includes": "one prover call per step on a fresh HOST-buffer assignment (a different witness every step): hand-over to the device, R1CS rows, the 7 NTTs of the witness map (4 run per proof; both transforms of C and the final inverse are folded into the L and H queries at key load), 5 MSM, host proof assembly, hex serialisation; excludes witness generation and key load"},
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "cpu_baseline_variants": cpu_more or None, "extra_legs": extra or None,
             "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2)}}

@@ -42,6 +42,7 @@ extern "C" {
 const char *zkgpu_last_error(void) { return g_err.c_str(); }
 const char *zkgpu_version(void) { return "blockmaze_amd 0.1 (gfx950)"; }
 int zkgpu_device_count(void) { return gpu_available() ? 1 : 0; }
+int zkgpu_device_numa_node(int device) { int node = -1; guarded([&] { if (gpu_available()) node = gpu_device_numa_node(device); return ZKGPU_OK; }); return node; }
 int zkgpu_init(void) { return guarded([] { gpu(); return ZKGPU_OK; }); }
 
 int zkgpu_test_field_op(int field, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n) { return guarded([&] { probe_field(field, op, a, b, out, n); return ZKGPU_OK; }); }

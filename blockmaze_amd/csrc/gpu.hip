@@ -91,6 +91,21 @@ void gpu_lane_release(int lane) { if (lane <= 0 || lane >= MAX_LANES) return; st
 int gpu_lane_current() { return t_lane; }
 void gpu_lane_select(int lane) { t_lane = lane < 0 || lane >= MAX_LANES ? 0 : lane; }
 bool gpu_available() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0; }
+// NUMA node of the host socket visible device `device` hangs off (sysfs entry of its PCI function), -1 unknown.  A rank launcher binds its process to that node's CPUs
+// (bench.py); the library itself only moves its scan threads next to the caller's buffer (hostnuma.hpp).
+int gpu_device_numa_node(int device) {
+  char id[64] = {0};
+  if (hipDeviceGetPCIBusId(id, (int)sizeof(id), device) != hipSuccess) return -1;
+  for (char *c = id; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');      // sysfs spells the address in lower case
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", id);
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
+}
 void gpu_sync() { HIP_CHECK(hipStreamSynchronize(gpu().stream)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamSynchronize(gpu().aux[i])); }
 void gpu_join_aux() { GpuContext &g = gpu(); for (int i = 0; i < 4; i++) { HIP_CHECK(hipEventRecord(g.join_event[i], g.aux[i])); HIP_CHECK(hipStreamWaitEvent(g.stream, g.join_event[i], 0)); } }
 bool profiling_enabled();

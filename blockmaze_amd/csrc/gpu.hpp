@@ -22,6 +22,7 @@ struct G2AffineRaw { Fe32 x0, x1, y0, y1; };  // 128 B
 
 class GpuContext;
 GpuContext &gpu();                             // lazily initialised process-wide context (device from ZK_DEVICE / LOCAL_RANK)
+int gpu_device_numa_node(int device);            // NUMA node of the socket the device hangs off, -1 unknown (sysfs)
 bool gpu_available();                          // false if no HIP device is visible
 int lane_plan_simulate(int n_slots, int kinds, int per_kind, int *out_lanes_per_slot);   // the lane planner on a private table (CPU tests)
 int gpu_lane_acquire(int device_slot = 0); void gpu_lane_release(int lane); int gpu_lane_current(); void gpu_lane_select(int lane);   // independent stream sets (gpu.hip); a lane belongs to one device of the list below

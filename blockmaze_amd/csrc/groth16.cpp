@@ -498,7 +498,8 @@ static void enqueue_all(Prover::Impl &p) {
   // them after the row kernels (their five full-chip classify kernels then fought the row and transform kernels for the CUs); since the witness path is one light sort
   // per pair, starting it beside the gather-bound row kernel is worth 4 % of a host-buffer proof (1.095 -> 1.05 ms median, tools/ab_steps.sh); later release points only
   // move the contention into the transforms and the H accumulation (profiles/r03i_ab_start.txt, and again at the end of round 3: 1.06-1.19 against 1.01 ms).
-  static const std::array<int, 4> start{0, 0, 0, 0};
+  static const std::array<int, 4> start = [] { std::array<int, 4> v{0, 0, 0, 0}; const char *e = getenv("ZK_WMSM_START");   // four digits 0..4, one per job (B2, L, A [+ L], B1 [+ B2]); measurement switch
+    for (int j = 0; e && j < 4 && e[j] >= '0' && e[j] <= '4'; j++) v[j] = e[j] - '0'; return v; }();
   // about 80 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
   // (auxiliary streams) while this one submits the critical chain
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();

@@ -125,7 +125,8 @@ __device__ __forceinline__ void ntt29_lds_transform(Fr29 *tile, Fr29 *twl, int l
 struct NttJob { const Fr *src; Fr *dst; const Fr *factor; const Fr *tw261; Fr scale261; int logn, log_n1, logC; uint32_t tiles; size_t stride_in, stride_out; };
 __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(NttJob ja, NttJob jb, int radix_log) {
   extern __shared__ uint32_t lds_raw[]; Fr29 *tile = reinterpret_cast<Fr29 *>(lds_raw);
-  const bool second = blockIdx.x >= ja.tiles; const NttJob &j = second ? jb : ja; const uint32_t bid = blockIdx.x - (second ? ja.tiles : 0u);
+  const bool second = blockIdx.x >= ja.tiles; const NttJob j = second ? jb : ja;   // by value: uniform selects, a reference would put both jobs on the stack
+  const uint32_t bid = blockIdx.x - (second ? ja.tiles : 0u);
   const int logn = j.logn, log_n1 = j.log_n1, logC = j.logC; const Fr *__restrict__ tw261 = j.tw261; const Fr *__restrict__ pre261 = j.factor;
   // XCD-aware tile order.  A narrow tile reads 32 or 64 bytes of every 128-byte line it touches; the rest belongs to the next columns.  Workgroup b
   // runs on XCD b % 8 (MI355X_MICROARCH.md, observed dispatch order), each XCD has its own L2, so with tile = blockIdx.x four different L2s fetched every line: 4.2x the

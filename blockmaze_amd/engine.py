@@ -34,6 +34,7 @@ def _bytes(a):
     a = np.ascontiguousarray(a); return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
 
 def device_count(): return int(lib().zkgpu_device_count())
+def device_numa_node(device=0): return int(lib().zkgpu_device_numa_node(int(device)))   # -1 unknown
 def init(): _check(lib().zkgpu_init())
 
 # arrays are uint64 with 4 words per field element (canonical, little-endian), same convention as oracle/pyoracle.py

@@ -18,6 +18,40 @@ def msm_range(n, rank, world):
     """contiguous slice [begin, end) of an n-point query owned by `rank`; slices tile [0, n) exactly"""
     base, rem = divmod(n, world); begin = rank * base + min(rank, rem); return begin, begin + base + (1 if rank < rem else 0)
 
+def parse_cpulist(text):
+    """'0-63,128-191' (sysfs) -> [0, ..., 63, 128, ..., 191]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part: continue
+        a, _, b = part.partition("-"); out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+def host_node_cpus():
+    """{NUMA node: its CPUs} from sysfs; {} where there is none"""
+    import glob, os, re
+    nodes = {}
+    for d in glob.glob("/sys/devices/system/node/node[0-9]*"):
+        try: nodes[int(re.search(r"node(\d+)$", d).group(1))] = parse_cpulist(open(os.path.join(d, "cpulist")).read())
+        except Exception: pass
+    return nodes
+
+def host_cpus_for_rank(local_rank, world, gpu_nodes, node_cpus, allowed, cores):
+    """The CPUs a rank should run on (pure function; tests/test_distributed_cpu.py).  A rank stays on the socket its GPU hangs off: the hand-over scans the rank's 7 MB
+    assignments and writes pinned staging memory, and from the other socket both take twice as long (profiles/r04w_mode_probe.txt).  gpu_nodes[i]: NUMA node of local GPU i
+    (-1 unknown); node_cpus: {node: [cpus]}; allowed: the process's affinity mask; cores: what the whole job may really use (cgroup quota).
+      world == 1 -> every allowed CPU of the GPU's node (threads float inside the socket);
+      world  > 1 -> the ranks of one socket cut that socket's allowed CPUs into slices of cores // world.
+    Unknown node, or a node without an allowed CPU: the old placement (slices of the first `cores` allowed CPUs)."""
+    allowed = sorted(allowed); node = gpu_nodes[local_rank % len(gpu_nodes)] if gpu_nodes else -1
+    mine = [c for c in node_cpus.get(node, []) if c in set(allowed)] if node is not None and node >= 0 else []
+    if world <= 1: return mine or allowed
+    per = max(1, cores // world)
+    if not mine:
+        cut = allowed[:cores][local_rank % world * per:(local_rank % world + 1) * per]; return cut or allowed
+    peers = [r for r in range(world) if gpu_nodes[r % len(gpu_nodes)] == node]; k = peers.index(local_rank % world) if local_rank % world in peers else 0
+    per = max(1, min(per, len(mine) // max(1, len(peers)))); cut = mine[k * per:(k + 1) * per]
+    return cut or mine
+
 def aggregate_throughput(units_per_rank, seconds, dist=None, device=None):
     """whole-job rate: all ranks' units over the slowest rank's time (max-reduce over the process group)"""
     if dist is not None:

@@ -35,6 +35,7 @@ extern "C" {
 const char *zkgpu_last_error(void);
 const char *zkgpu_version(void);
 int zkgpu_device_count(void);                       /* number of visible HIP devices (0 on a CPU-only host) */
+int zkgpu_device_numa_node(int device);             /* NUMA node of the host socket visible device `device` hangs off (sysfs), -1 unknown: what a rank launcher binds its process to */
 int zkgpu_init(void);                               /* create the device context now instead of lazily */
 
 /* ---- device arithmetic probes (parity tests of the __device__ field / curve code) ---------------------------------- */

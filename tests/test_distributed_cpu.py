@@ -85,3 +85,18 @@ def test_group_two_ranks_gloo():
     for p in procs: p.join(timeout=60); assert p.exitcode == 0
     for rank, ok_all, ok_one, shared, rate, slowest, firsts in res:
         assert ok_all is True and ok_one is False and shared == "dir-of-rank-0" and slowest == 2.0 and rate == 10.0 and firsts == [1, 2]
+
+def test_ranks_are_placed_on_their_gpus_socket():
+    """sharding.host_cpus_for_rank: a rank runs on the CPUs of the NUMA node its GPU hangs off (bench.py binds itself before it allocates its assignments)"""
+    from blockmaze_amd import sharding as s
+    assert s.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and s.parse_cpulist("5") == [5] and s.parse_cpulist("") == []
+    nodes = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}; everything = set(range(256)); gpus = [0, 0, 0, 0, 1, 1, 1, 1]
+    assert s.host_cpus_for_rank(0, 1, [0], nodes, everything, 16) == nodes[0]                                # one rank: the whole socket of its GPU
+    assert s.host_cpus_for_rank(0, 1, [1], nodes, everything, 16) == nodes[1]
+    assert s.host_cpus_for_rank(0, 1, [-1], nodes, everything, 16) == sorted(everything)                     # unknown: no restriction
+    cuts = [s.host_cpus_for_rank(r, 8, gpus, nodes, everything, 16) for r in range(8)]
+    assert all(len(c) == 2 for c in cuts) and len(set(sum(cuts, []))) == 16                                   # 16 usable cores over 8 ranks, no CPU twice
+    assert all(set(cuts[r]) <= set(nodes[gpus[r]]) for r in range(8))                                         # each on its own GPU's socket
+    assert s.host_cpus_for_rank(5, 8, gpus, nodes, set(range(0, 64)), 16) == [10, 11]                         # a cpuset without that socket: the old slices of the allowed CPUs
+    assert s.host_cpus_for_rank(1, 2, [0], nodes, everything, 64) == list(range(32, 64))                      # two ranks sharing one GPU (gloo test runs): disjoint halves
+    assert isinstance(s.host_node_cpus(), dict)

@@ -11,8 +11,10 @@ tmp = tempfile.mkdtemp(); pk, vk = os.path.join(tmp, "sendpk.txt"), os.path.join
 for i in range(16):
     d = w.send_instance(i); wp = os.path.join(tmp, "w.bin"); e.witness_send(*[("0x" + a.hex()) if isinstance(a, bytes) else a for a in w.send_args(d)], wp); zs.append(o.load_witness(wp))
 for i in range(10): p.prove(zs[i % 16])
-ts = []
+ts = []; parts = []
 for i in range(N):
-    t0 = time.perf_counter(); p.prove(zs[i % 16]); ts.append(1e3 * (time.perf_counter() - t0))
+    t0 = time.perf_counter(); p.prove(zs[i % 16]); ts.append(1e3 * (time.perf_counter() - t0)); parts.append(p.timings())
 s = sorted(ts); pct = lambda q: s[min(len(s) - 1, int(q * len(s)))]
 print("%d steps: mean %.3f ms, min %.3f, p10 %.3f, median %.3f, p90 %.3f, p99 %.3f, max %.3f; steps above 1.5 x median: %d (they add %.3f ms to the mean)" % (N, sum(ts) / N, s[0], pct(0.1), pct(0.5), pct(0.9), pct(0.99), s[-1], sum(1 for t in ts if t > 1.5 * pct(0.5)), sum(t - pct(0.5) for t in ts if t > 1.5 * pct(0.5)) / N))
+med = lambda k: sorted(d[k] for d in parts)[len(parts) // 2]
+print("  medians of the prover's own clocks: " + ", ".join("%s %.3f" % (k, med(k)) for k in ("upload_ms", "enqueue_ms", "device_ms", "finish_ms", "total_ms")) + "; cpus allowed %d" % len(os.sched_getaffinity(0)))
