@@ -35,7 +35,8 @@ const char *circuit_name(CircuitKind k);
 struct MintInputs { uint64_t value, value_old, value_s; Blob256 sn_old, r_old, sn, r, cmtA_old, cmtA, sk; };
 struct RedeemInputs { uint64_t value, value_old, value_s; Blob256 sn_old, r_old, sn, r, cmtA_old, cmtA, sk; };
 struct SendInputs { uint64_t value_old, value_s, value; Blob256 sn_old, r_old, r_s, sn, r, cmtA_old, cmtS, cmtA, sk; Blob160 pk_recv, pk_sender; };
-struct DepositInputs { uint64_t value, value_old, value_s; Blob256 sn_old, r_old, sn, r, sn_s, r_s, sn_A_old, cmtB_old, cmtB, cmtS, sk, rt; Blob160 pk_recv; std::vector<Blob256> path; std::vector<bool> index_bits; };
+struct DepositInputs { uint64_t value, value_old, value_s; Blob256 sn_old, r_old, sn, r, sn_s, r_s, sn_A_old, cmtB_old, cmtB, cmtS, sk, rt; Blob160 pk_recv;
+    std::vector<Blob256> path; std::vector<bool> index_bits; };
 
 // A circuit instance: construct once (allocates variables; with emit = true also emits the constraint system), then
 // assign() any number of witnesses.
@@ -65,14 +66,18 @@ void assign_sha256_two_to_one(Circuit &c, const std::vector<bool> &left, const s
 std::unique_ptr<Circuit> make_lesscmp_test_circuit(bool emit);
 void assign_lesscmp_test(Circuit &c, uint64_t value_old, uint64_t value_s);
 
-// test circuit: one sha256_CMTA_gadget (send/circuit/commitment.tcc:12-110): two chained compressions with hard-wired padding; bit vectors of 64 / 256 / 256 entries
+// test circuit: one sha256_CMTA_gadget (send/circuit/commitment.tcc:12-110): two chained compressions with hard-wired padding; bit vectors of 64 / 256 / 256
+// entries
 std::unique_ptr<Circuit> make_cmta_test_circuit(bool emit);
-std::unique_ptr<Circuit> make_hashblock_test_circuit(bool emit, int which /* 0 CMTS, 1 PRF, 2 CRH */); size_t hashblock_input_bits(int which); void assign_hashblock_test(Circuit &c, const std::vector<bool> &bits);
+std::unique_ptr<Circuit> make_hashblock_test_circuit(bool emit, int which /* 0 CMTS, 1 PRF, 2 CRH */);
+size_t hashblock_input_bits(int which);
+void assign_hashblock_test(Circuit &c, const std::vector<bool> &bits);
 void assign_cmta_test(Circuit &c, const std::vector<bool> &v, const std::vector<bool> &sn, const std::vector<bool> &r);
 
 // test circuit: libsnark's merkle_tree_check_read_gadget as its self-test composes it (merkle_tree_check_read_gadget.tcc:131-196)
 std::unique_ptr<Circuit> make_merkle_test_circuit(bool emit, size_t depth);
-void assign_merkle_test(Circuit &c, const Blob256 &leaf, const std::vector<Blob256> &path /* leaf level first */, const std::vector<bool> &index_bits, const Blob256 &root);
+void assign_merkle_test(Circuit &c, const Blob256 &leaf, const std::vector<Blob256> &path /* leaf level first */, const std::vector<bool> &index_bits,
+    const Blob256 &root);
 
 // public inputs of a statement packed the way the verifier side does it (X_gadget::witness_map, e.g. send/circuit/gadget.tcc:274-291;
 // pack_bit_vector_into_field_element_vector, field_utils.tcc:78-102): 253-bit chunks, little-endian within a chunk

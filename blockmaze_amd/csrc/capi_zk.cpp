@@ -39,37 +39,55 @@ char *hash_out(const Blob256 &h) { return dup_string(blob_to_hex(h.b, 32)); }
 std::string key_dir() { const char *e = getenv("ZK_PRFKEY_DIR"); return e && *e ? e : "/usr/local/prfKey"; }
 std::string key_path(CircuitKind k, bool pk) { return key_dir() + "/" + circuit_name(k) + (pk ? "pk.txt" : "vk.txt"); }
 
-struct FileStamp { off_t size = -1; time_t mtime = 0; long mtime_ns = 0; bool operator==(const FileStamp &o) const { return size == o.size && mtime == o.mtime && mtime_ns == o.mtime_ns; } };
-bool stamp_of(const std::string &p, FileStamp &s) { struct stat st; if (stat(p.c_str(), &st)) return false; s.size = st.st_size; s.mtime = st.st_mtim.tv_sec; s.mtime_ns = st.st_mtim.tv_nsec; return true; }
+struct FileStamp { off_t size = -1; time_t mtime = 0; long mtime_ns = 0; bool operator==(const FileStamp &o) const {
+    return size == o.size && mtime == o.mtime && mtime_ns == o.mtime_ns; } };
+bool stamp_of(const std::string &p, FileStamp &s) {
+  struct stat st;
+  if (stat(p.c_str(), &st)) return false;
+  s.size = st.st_size;
+  s.mtime = st.st_mtim.tv_sec;
+  s.mtime_ns = st.st_mtim.tv_nsec;
+  return true;
+}
 
 // One proving key = a small pool of provers (ZK_PROVERS_PER_KEY, default 6), each with its own circuit board, device buffers and stream set: cgo calls
 // that arrive concurrently (tx pool, RPC goroutines, block processing) overlap on the GPU instead of queueing behind one mutex.
 struct ProverUnit { std::shared_ptr<Prover> prover; std::unique_ptr<Circuit> circuit; std::mutex busy; };
 typedef std::vector<std::shared_ptr<ProverUnit>> UnitList;
-// A reload (the key file's size or mtime changed) never touches the old list: it publishes a NEW one, and the old units die when the last proof running on them lets
-// go of its reference — a caller can therefore never see a destroyed unit or mutex, however the reload interleaves with proofs in flight.
-struct ProverSlot { FileStamp stamp; std::vector<std::shared_ptr<const UnitList>> units /* one list per device slot, built on first use */; std::vector<uint8_t> building /* a caller is loading this device's pool */; std::atomic<unsigned> next{0}; };
+// A reload (the key file's size or mtime changed) never touches the old list: it publishes a NEW one, and the old units die when the last proof running on them
+// lets go of its reference — a caller can therefore never see a destroyed unit or mutex, however the reload interleaves with proofs in flight.
+struct ProverSlot { FileStamp stamp; std::vector<std::shared_ptr<const UnitList>> units /* one list per device slot, built on first use */;
+    std::vector<uint8_t> building /* a caller is loading this device's pool */; std::atomic<unsigned> next{0}; };
 struct VkSlot { FileStamp stamp; std::shared_ptr<PreparedVerifyingKey> vk; std::shared_ptr<BatchVerifier> gpu; };
 std::mutex g_cache_mutex; std::map<std::string, ProverSlot> g_provers; std::map<std::string, VkSlot> g_vks;
 
 std::unique_ptr<Circuit> make_circuit(CircuitKind k, bool emit) {
-  switch (k) { case CircuitKind::Mint: return make_mint_circuit(emit); case CircuitKind::Send: return make_send_circuit(emit); case CircuitKind::Redeem: return make_redeem_circuit(emit); default: return make_deposit_circuit(emit, 8); } }
+  switch (k) {
+    case CircuitKind::Mint: return make_mint_circuit(emit);
+    case CircuitKind::Send: return make_send_circuit(emit);
+    case CircuitKind::Redeem: return make_redeem_circuit(emit);
+    default: return make_deposit_circuit(emit, 8);
+  }
+}
 
-// after the first load from text: leave the container behind for the next process start (a read-only key directory simply goes without).  `before` is the key file's
-// stamp taken BEFORE it was read: the container is written under that stamp, and only if the file still carries it — a key replaced while it was being parsed
-// must not leave the old key's tables behind under the new file's size and mtime.
+// after the first load from text: leave the container behind for the next process start (a read-only key directory simply goes without). `before` is the key
+// file's stamp taken BEFORE it was read: the container is written under that stamp, and only if the file still carries it — a key replaced while it was being
+// parsed must not leave the old key's tables behind under the new file's size and mtime.
 void write_container_quietly(const std::string &pk_path, const ProvingKeyHost &pk, const FileStamp &before) {
-  std::string cp = key_container_path(pk_path); FileStamp now; if (cp.empty() || pk.H_lagrange.empty() || pk.L_star.empty() || !stamp_of(pk_path, now) || !(now == before)) return;
+  std::string cp = key_container_path(pk_path);
+  FileStamp now;
+  if (cp.empty() || pk.H_lagrange.empty() || pk.L_star.empty() || !stamp_of(pk_path, now) || !(now == before)) return;
   KeyStamp ks; ks.size = before.size; ks.mtime_s = before.mtime; ks.mtime_ns = before.mtime_ns;
   try { save_key_container(cp, pk, ks); } catch (const std::exception &) {} }
 // A unit of the key's pool, locked for the caller (the reference keeps the unit alive, the lock is released first: members are destroyed in reverse order)
 struct HeldUnit { std::shared_ptr<ProverUnit> unit; std::unique_lock<std::mutex> lock; };
 }  // namespace
-// Which device of the list (ZK_DEVICES) a gen*proof call goes to — pure logic, driven by the CPU tests through zkgpu_test_pool_plan.  loaded[d]: device d holds a pool of
-// this key; building[d]: some caller is loading one there right now; busy[d]: proofs running on it.  Policy: the least busy loaded device; but as soon as every loaded
-// device already runs `spill` proofs (default 1) and a device without a pool is left, that one is taken (the caller builds its pool: 0.1 s from the key's container) —
-// a process that never has two proofs in flight keeps one copy of one key on one GPU, one with many concurrent callers spreads over all GPUs of the node before two proofs
-// share a device.  A pool that somebody else is building is never waited for while a loaded device exists.  Returns the device; -1 = wait for a build to finish.
+// Which device of the list (ZK_DEVICES) a gen*proof call goes to — pure logic, driven by the CPU tests through zkgpu_test_pool_plan. loaded[d]: device d holds
+// a pool of this key; building[d]: some caller is loading one there right now; busy[d]: proofs running on it. Policy: the least busy loaded device; but as soon
+// as every loaded device already runs `spill` proofs (default 1) and a device without a pool is left, that one is taken (the caller builds its pool: 0.1 s from
+// the key's container) — a process that never has two proofs in flight keeps one copy of one key on one GPU, one with many concurrent callers spreads over all
+// GPUs of the node before two proofs share a device. A pool that somebody else is building is never waited for while a loaded device exists. Returns the
+// device; -1 = wait for a build to finish.
 int zk_pool_pick_device(const uint8_t *loaded, const uint8_t *building, const int *busy, int D, int spill, unsigned turn) {
   int best = -1, fresh = -1; bool any_building = false;
   for (int i = 0; i < D; i++) {
@@ -84,32 +102,58 @@ int zk_pool_pick_device(const uint8_t *loaded, const uint8_t *building, const in
 }
 namespace {
 std::condition_variable g_pool_cv;   // signalled under g_cache_mutex whenever a pool build ends
-// Loads the key on first use or when the file changed.  g_cache_mutex guards the slot table only; a pool is BUILT outside it (under g_gpu_mutex, which serialises key
-// loads and the other set-up work of the device), so callers that can be served by a loaded device never queue behind a key load.  A prover's helper threads start with
-// its first proof (groth16.cpp).
+// Loads the key on first use or when the file changed. g_cache_mutex guards the slot table only; a pool is BUILT outside it (under g_gpu_mutex, which
+// serialises key loads and the other set-up work of the device), so callers that can be served by a loaded device never queue behind a key load. A prover's
+// helper threads start with its first proof (groth16.cpp).
 HeldUnit acquire_prover(CircuitKind k) {
   std::string path = key_path(k, true); FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("proving key not found: " + path);
   const int D = std::max(1, gpu_device_slots());
   static const int spill = [] { const char *e = getenv("ZK_SPILL_BUSY"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
   std::shared_ptr<const UnitList> list; unsigned turn = 0;
   { std::unique_lock<std::mutex> lk(g_cache_mutex); ProverSlot &slot = g_provers[path];
-    if ((int)slot.units.size() != D || !(slot.stamp == st)) { slot.units.assign(D, nullptr); slot.building.assign(D, 0); slot.stamp = st; }   // (a changed key file: new lists; the old provers die with the last proof running on them)
+    // (a changed key file: new lists; the old provers die with the last proof running on them)
+    if ((int)slot.units.size() != D || !(slot.stamp == st)) {
+      slot.units.assign(D, nullptr);
+      slot.building.assign(D, 0);
+      slot.stamp = st;
+    }
     turn = slot.next.fetch_add(1);
     for (;;) {
       std::vector<uint8_t> loaded(D, 0); std::vector<int> busy(D, 0);
-      for (int d = 0; d < D; d++) if (slot.units[d]) { loaded[d] = 1; for (auto &u : *slot.units[d]) { std::unique_lock<std::mutex> t(u->busy, std::try_to_lock); if (!t.owns_lock()) busy[d]++; } }
+      for (int d = 0; d < D; d++) if (slot.units[d]) {
+        loaded[d] = 1;
+        for (auto &u : *slot.units[d]) {
+          std::unique_lock<std::mutex> t(u->busy, std::try_to_lock);
+          if (!t.owns_lock()) busy[d]++;
+        }
+      }
       const int dev = zk_pool_pick_device(loaded.data(), slot.building.data(), busy.data(), D, spill, turn);
-      if (dev < 0) { g_pool_cv.wait(lk); if (!(slot.stamp == st)) throw std::runtime_error("proving key changed while it was being loaded: " + path); continue; }
+      if (dev < 0) {
+        g_pool_cv.wait(lk);
+        if (!(slot.stamp == st)) throw std::runtime_error("proving key changed while it was being loaded: " + path);
+        continue;
+      }
       if (slot.units[dev]) { list = slot.units[dev]; break; }
       slot.building[dev] = 1; lk.unlock();
       std::shared_ptr<UnitList> fresh; std::exception_ptr err;
       try { std::lock_guard<std::mutex> gl(g_gpu_mutex);
-        bool cached = false; ProvingKeyHost pk = load_proving_key_fast(path, cached); const char *e = getenv("ZK_PROVERS_PER_KEY"); int n = e ? atoi(e) : 6; if (n < 1) n = 1; if (n > 7) n = 7;
+        bool cached = false;
+        ProvingKeyHost pk = load_proving_key_fast(path, cached);
+        const char *e = getenv("ZK_PROVERS_PER_KEY");
+        int n = e ? atoi(e) : 6;
+        if (n < 1) n = 1;
+        if (n > 7) n = 7;
         fresh = std::make_shared<UnitList>(); std::shared_ptr<Prover> first;
         for (int i = 0; i < n; i++) { auto u = std::make_shared<ProverUnit>();
-          if (i == 0) { u->prover.reset(new Prover(pk, 0, 1, dev)); first = u->prover; } else u->prover.reset(new Prover(*first));   // the pool's members share the first one's device tables
+          // the pool's members share the first one's device tables
+          if (i == 0) {
+            u->prover.reset(new Prover(pk, 0, 1, dev));
+            first = u->prover;
+          } else u->prover.reset(new Prover(*first));
           u->circuit = make_circuit(k, false);
-          if (u->circuit->board.num_variables() != u->prover->num_variables() || u->circuit->num_inputs() != u->prover->num_inputs()) throw std::runtime_error("proving key does not belong to the " + std::string(circuit_name(k)) + " circuit: " + path);
+          if (u->circuit->board.num_variables() != u->prover->num_variables() ||
+              u->circuit->num_inputs() != u->prover->num_inputs()) throw std::runtime_error("proving key does not belong to the " +
+              std::string(circuit_name(k)) + " circuit: " + path);
           fresh->push_back(std::move(u)); }
         if (!cached) write_container_quietly(path, pk, st);
       } catch (...) { err = std::current_exception(); fresh.reset(); }
@@ -137,11 +181,22 @@ std::shared_ptr<BatchVerifier> gpu_verifier_for_path(const std::string &path) {
   return slot.gpu;
 }
 #ifdef ZKGPU_TEST_HOOKS
-// test builds only (make TEST_HOOKS=1): ZK_FIXED_RS="<r hex>:<s hex>" makes proofs reproducible.  The release library does not contain this code: an environment
+// test builds only (make TEST_HOOKS=1): ZK_FIXED_RS="<r hex>:<s hex>" makes proofs reproducible. The release library does not contain this code: an environment
 // variable must never be able to remove the zero-knowledge property (the reference draws r, s from std::random_device, r1cs_gg_ppzksnark.tcc:418-419).
 bool parse_fixed_rs(Fe32 &r, Fe32 &s) {
   const char *e = getenv("ZK_FIXED_RS"); if (!e) return false; const char *colon = strchr(e, ':'); if (!colon) return false;
-  auto parse = [](const char *b, const char *en, Fe32 &o) { memset(&o, 0, sizeof o); int n = 0; for (const char *p = en; p-- > b;) { char ch = *p; int d = ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : -1; if (d < 0 || n >= 64) return false; o.l[n / 8] |= (uint32_t)d << (4 * (n % 8)); n++; } return n > 0; };
+  auto parse = [](const char *b, const char *en, Fe32 &o) {
+    memset(&o, 0, sizeof o);
+    int n = 0;
+    for (const char *p = en; p-- > b;) {
+      char ch = *p;
+      int d = ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : -1;
+      if (d < 0 || n >= 64) return false;
+      o.l[n / 8] |= (uint32_t)d << (4 * (n % 8));
+      n++;
+    }
+    return n > 0;
+  };
   return parse(e, colon, r) && parse(colon + 1, e + strlen(e), s);
 }
 #else
@@ -152,57 +207,91 @@ static std::atomic<int> g_proofs_in_flight{0};   // genXproof calls of this proc
 // shared tail of the gen*proof functions: assign() has filled the circuit's board
 template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
   try {
-    if (!gpu_available()) { zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback"); fprintf(stderr, "libzkgpu: no HIP device visible, cannot generate %s proof\n", circuit_name(k)); return dup_string(proof_to_hex(default_proof())); }
-    static const bool trace = getenv("ZK_TRACE_TIMES") != nullptr; auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    struct InFlight { InFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); } ~InFlight() { g_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); } } in_flight;
+    if (!gpu_available()) {
+      zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback");
+      fprintf(stderr, "libzkgpu: no HIP device visible, cannot generate %s proof\n", circuit_name(k));
+      return dup_string(proof_to_hex(default_proof()));
+    }
+    static const bool trace = getenv("ZK_TRACE_TIMES") != nullptr;
+    auto now = [] {
+      return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    struct InFlight { InFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); } ~InFlight() {
+        g_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); } } in_flight;
     double t0 = now(); HeldUnit held = acquire_prover(k); ProverUnit &slot = *held.unit; double t1 = now(); assign(*slot.circuit); double t2 = now();
     printf("Trying to generate %s proof...\n", circuit_name(k)); fflush(stdout);
     Fe32 r, s; bool fixed = parse_fixed_rs(r, s); Proof proof;
-    slot.prover->set_witness_tagged(slot.circuit->board.tag.data(), reinterpret_cast<const Fe32 *>(slot.circuit->board.wide.data()));   // the board's own form (one byte per 0 / 1, Montgomery values for the rest): no conversion, no scan
+    // the board's own form (one byte per 0 / 1, Montgomery values for the rest): no conversion, no scan
+    slot.prover->set_witness_tagged(slot.circuit->board.tag.data(), reinterpret_cast<const Fe32 *>(slot.circuit->board.wide.data()));
     double t3 = now();
-    if (!slot.prover->prove_resident(fixed ? &r : nullptr, fixed ? &s : nullptr, proof)) { printf("can not generate %s proof\n", circuit_name(k)); fflush(stdout); proof = default_proof(); }
+    if (!slot.prover->prove_resident(fixed ? &r : nullptr, fixed ? &s : nullptr, proof)) {
+      printf("can not generate %s proof\n", circuit_name(k));
+      fflush(stdout);
+      proof = default_proof();
+    }
     double t4 = now(); char *out = dup_string(proof_to_hex(proof));
     if (trace) fprintf(stderr, "trace-abi: acquire %.3f witness %.3f upload %.3f prove %.3f hex %.3f ms\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3, now() - t4);
     return out;
-  } catch (const std::exception &e) { zkgpu_set_error(e.what()); fprintf(stderr, "libzkgpu: %s\n", e.what()); return dup_string(proof_to_hex(default_proof())); }
+  }
+  catch (const std::exception &e) {
+    zkgpu_set_error(e.what());
+    fprintf(stderr, "libzkgpu: %s\n", e.what());
+    return dup_string(proof_to_hex(default_proof()));
+  }
   catch (...) { zkgpu_set_error("unknown error"); return dup_string(proof_to_hex(default_proof())); }
 }
-// The verdicts for m proofs of ONE circuit kind — where every verification of the cgo layer ends up, the single-proof verifyXproof symbols (m = 1) and verifyBatch alike.
-// From ZK_VERIFY_GPU_MIN proofs on (default 1: since kernel K9 keeps its values on 29-bit limbs a proof takes 2.1 ms on ONE compute unit of the device, 2.5 ms on a host
-// core) the records go to the device in one launch — one workgroup per proof, concurrent callers on separate streams (gpu_verify.hip) —, otherwise, or when the process
-// sees no device, to the prepared host verifier.  res[j]: 1 accept, 0 reject.  A record the device hands back (input accumulator at infinity) is decided by the host verifier.
+// The verdicts for m proofs of ONE circuit kind — where every verification of the cgo layer ends up, the single-proof verifyXproof symbols (m = 1) and
+// verifyBatch alike. From ZK_VERIFY_GPU_MIN proofs on (default 1: since kernel K9 keeps its values on 29-bit limbs a proof takes 2.1 ms on ONE compute unit of
+// the device, 2.5 ms on a host core) the records go to the device in one launch — one workgroup per proof, concurrent callers on separate streams
+// (gpu_verify.hip) —, otherwise, or when the process sees no device, to the prepared host verifier. res[j]: 1 accept, 0 reject. A record the device hands back
+// (input accumulator at infinity) is decided by the host verifier.
 void verify_group(CircuitKind kind, const Proof *ps, const uint8_t *parsed, const Fe32 *inputs, size_t ni, size_t m, uint8_t *res) {
   static const size_t gpu_min = [] { const char *e = getenv("ZK_VERIFY_GPU_MIN"); long v = e ? atol(e) : 1; return (size_t)(v < 1 ? 1 : v); }();
   const std::string path = key_path(kind, false);
-  // A single proof goes to the device only while no prover of this process is at work: measured (tools/verify_under_load.py), one verifySendproof takes 1.82 ms on an idle
-  // GPU and 1.88 ms on a host core, but 2.8 ms (p90 4.1) on a GPU that four provers keep busy — the verifier's one workgroup shares its compute unit's issue slots with
-  // their waves, and costs them 17 % of their throughput — against an unchanged 1.87 ms on the host.  Two or more proofs are one launch whatever the load.
+  // A single proof goes to the device only while no prover of this process is at work: measured (tools/verify_under_load.py), one verifySendproof takes 1.82 ms
+  // on an idle GPU and 1.88 ms on a host core, but 2.8 ms (p90 4.1) on a GPU that four provers keep busy — the verifier's one workgroup shares its compute
+  // unit's issue slots with their waves, and costs them 17 % of their throughput — against an unchanged 1.87 ms on the host. Two or more proofs are one launch
+  // whatever the load.
   bool decided = false;
   if (m >= gpu_min && (m >= 2 || g_proofs_in_flight.load(std::memory_order_relaxed) == 0) && gpu_available()) {
-    // The device may only ever be FASTER than the host verifier, never a different judge: anything that goes wrong on this branch — building the key's verifier, an
-    // allocation, a launch or stream error, the test hook below — is logged and the whole group is decided by the prepared host verifier instead.  A transient GPU
-    // fault must not reject a valid transaction (the reference's verifier is pure host code, r1cs_gg_ppzksnark.tcc:584-590).
+    // The device may only ever be FASTER than the host verifier, never a different judge: anything that goes wrong on this branch — building the key's
+    // verifier, an allocation, a launch or stream error, the test hook below — is logged and the whole group is decided by the prepared host verifier instead.
+    // A transient GPU fault must not reject a valid transaction (the reference's verifier is pure host code, r1cs_gg_ppzksnark.tcc:584-590).
     try {
-      static const bool fail_hook = getenv("ZK_TEST_FAIL_GPU_VERIFY") != nullptr;      // (tests: makes this branch throw, so that the fallback below is exercised on a healthy GPU)
+      // (tests: makes this branch throw, so that the fallback below is exercised on a healthy GPU)
+      static const bool fail_hook = getenv("ZK_TEST_FAIL_GPU_VERIFY") != nullptr;
       if (fail_hook) throw std::runtime_error("ZK_TEST_FAIL_GPU_VERIFY is set");
       std::shared_ptr<BatchVerifier> v;
       { std::lock_guard<std::mutex> lk(g_gpu_mutex); v = gpu_verifier_for_path(path); }  // (building a key's verifier is serialised; using it is not)
       if (v->num_inputs() == ni) {
         std::vector<uint8_t> dev(m, 0); v->verify(ps, inputs, m, dev.data());            // (into a scratch vector: a throw half-way leaves `res` untouched)
         for (size_t j = 0; j < m; j++) res[j] = dev[j] == 2 ? (parsed[j] && verify_proof(*vk_for_path(path), inputs + j * ni, ni, ps[j])) : dev[j];
-      } else for (size_t j = 0; j < m; j++) res[j] = 0;                                  // strong IC: a wrong input count rejects (r1cs_gg_ppzksnark.tcc:584-590)
+      // strong IC: a wrong input count rejects (r1cs_gg_ppzksnark.tcc:584-590)
+      } else for (size_t j = 0; j < m; j++) res[j] = 0;
       decided = true;
     } catch (const std::exception &e) {
       static std::atomic<int> noted{0};
-      if (noted.fetch_add(1, std::memory_order_relaxed) < 8) fprintf(stderr, "libzkgpu: GPU verifier failed (%s); deciding %zu proof(s) on the host\n", e.what(), m);
+      if (noted.fetch_add(1, std::memory_order_relaxed) < 8) fprintf(stderr, "libzkgpu: GPU verifier failed (%s); deciding %zu proof(s) on the host\n",
+          e.what(), m);
     }
   }
-  if (!decided) { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(path); for (size_t j = 0; j < m; j++) res[j] = parsed[j] && verify_proof(*vk, inputs + j * ni, ni, ps[j]); }
+  if (!decided) {
+    std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(path);
+    for (size_t j = 0; j < m; j++) res[j] = parsed[j] && verify_proof(*vk, inputs + j * ni, ni, ps[j]);
+  }
   for (size_t j = 0; j < m; j++) res[j] = parsed[j] && res[j] == 1;
 }
 bool verify(CircuitKind k, const char *data, const std::vector<bool> &public_bits) {
   bool ok = false;
-  try { Proof p; if (data && strnlen(data, 512) == 512 && proof_from_hex(data, p)) { std::vector<Fe32> inputs = pack_public_bits(public_bits); uint8_t parsed = 1, res = 0; verify_group(k, &p, &parsed, inputs.data(), inputs.size(), 1, &res); ok = res == 1; } }
+  try {
+    Proof p;
+    if (data && strnlen(data, 512) == 512 && proof_from_hex(data, p)) {
+      std::vector<Fe32> inputs = pack_public_bits(public_bits);
+      uint8_t parsed = 1, res = 0;
+      verify_group(k, &p, &parsed, inputs.data(), inputs.size(), 1, &res);
+      ok = res == 1;
+    }
+  }
   catch (const std::exception &e) { zkgpu_set_error(e.what()); fprintf(stderr, "libzkgpu: %s\n", e.what()); ok = false; } catch (...) { ok = false; }
   printf("Verifying %s proof %s!!!\n", circuit_name(k), ok ? "successfully" : "unsuccessfully"); fflush(stdout); return ok;
 }
@@ -211,109 +300,327 @@ void append(std::vector<bool> &v, const std::vector<bool> &w) { v.insert(v.end()
 std::vector<bool> public_bits(CircuitKind k, const char *const *a, uint64_t value_s) {
   std::vector<bool> bits; auto h256 = [&](const char *s) { append(bits, blob_bits(blob256_from_hex(s ? s : "").b, 32)); };
   switch (k) {
-    case CircuitKind::Mint: case CircuitKind::Redeem: h256(a[0]); h256(a[1]); h256(a[2]); append(bits, u64_bits(value_s)); break;                        // cmtA_old, sn_old, cmtA, value_s (mint/circuit/gadget.tcc:252-269)
-    case CircuitKind::Send: h256(a[0]); h256(a[1]); h256(a[2]); h256(a[3]); break;                                                                       // cmtA_old, sn_old, cmtS, cmtA_new (send/circuit/gadget.tcc:274-291)
-    default: h256(a[0]); append(bits, blob_bits(blob160_from_hex(a[1] ? a[1] : "").b, 20)); h256(a[2]); h256(a[3]); h256(a[4]); h256(a[5]); break;      // RT, pk, cmtb_old, sn_old, cmtb, sns (deposit/circuit/gadget.tcc:301-323)
+    // cmtA_old, sn_old, cmtA, value_s (mint/circuit/gadget.tcc:252-269)
+    case CircuitKind::Mint: case CircuitKind::Redeem: h256(a[0]);
+    h256(a[1]);
+    h256(a[2]);
+    append(bits, u64_bits(value_s));
+    break;
+    // cmtA_old, sn_old, cmtS, cmtA_new (send/circuit/gadget.tcc:274-291)
+    case CircuitKind::Send: h256(a[0]);
+    h256(a[1]);
+    h256(a[2]);
+    h256(a[3]);
+    break;
+    // RT, pk, cmtb_old, sn_old, cmtb, sns (deposit/circuit/gadget.tcc:301-323)
+    default: h256(a[0]);
+    append(bits, blob_bits(blob160_from_hex(a[1] ? a[1] : "").b, 20));
+    h256(a[2]);
+    h256(a[3]);
+    h256(a[4]);
+    h256(a[5]);
+    break;
   }
   return bits; }
 }  // namespace
 
 template <class Fn> static int guarded(Fn fn) {
-  try { if (!gpu_available()) { zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback"); return ZKGPU_ERR_NO_DEVICE; } std::lock_guard<std::mutex> lk(g_gpu_mutex); return fn(); }
-  catch (const std::exception &e) { zkgpu_set_error(e.what()); return ZKGPU_ERR_RUNTIME; } catch (...) { zkgpu_set_error("unknown error"); return ZKGPU_ERR_RUNTIME; } }
-template <class Fn> static int guarded_host(Fn fn) { try { return fn(); } catch (const std::exception &e) { zkgpu_set_error(e.what()); return ZKGPU_ERR_RUNTIME; } catch (...) { zkgpu_set_error("unknown error"); return ZKGPU_ERR_RUNTIME; } }
+  try {
+    if (!gpu_available()) {
+      zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback");
+      return ZKGPU_ERR_NO_DEVICE;
+    }
+    std::lock_guard<std::mutex> lk(g_gpu_mutex);
+    return fn();
+  }
+  catch (const std::exception &e) {
+    zkgpu_set_error(e.what());
+    return ZKGPU_ERR_RUNTIME;
+  }
+  catch (...) {
+    zkgpu_set_error("unknown error");
+    return ZKGPU_ERR_RUNTIME;
+  }
+}
+template <class Fn> static int guarded_host(Fn fn) {
+  try {
+    return fn();
+  }
+  catch (const std::exception &e) {
+    zkgpu_set_error(e.what());
+    return ZKGPU_ERR_RUNTIME;
+  }
+  catch (...) {
+    zkgpu_set_error("unknown error");
+    return ZKGPU_ERR_RUNTIME;
+  }
+}
 
-struct zkgpu_prover { std::shared_ptr<Prover> p; std::mutex m; std::vector<std::shared_ptr<Prover>> lanes; };   // lanes: the extra prover objects of prove_batch (share p's tables), created on first use   // proofs on different prover objects may run concurrently (each has its own streams); one object is used by one thread at a time
+// lanes: the extra prover objects of prove_batch (share p's tables), created on first use // proofs on different prover objects may run concurrently (each has
+// its own streams); one object is used by one thread at a time
+struct zkgpu_prover { std::shared_ptr<Prover> p; std::mutex m; std::vector<std::shared_ptr<Prover>> lanes; };
 template <class Fn> static int guarded_prover(zkgpu_prover *h, Fn fn) {
-  try { if (!gpu_available()) { zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback"); return ZKGPU_ERR_NO_DEVICE; } if (!h) return ZKGPU_ERR_ARG; std::lock_guard<std::mutex> lk(h->m); return fn(); }
-  catch (const std::exception &e) { zkgpu_set_error(e.what()); return ZKGPU_ERR_RUNTIME; } catch (...) { zkgpu_set_error("unknown error"); return ZKGPU_ERR_RUNTIME; } }
+  try {
+    if (!gpu_available()) {
+      zkgpu_set_error("no HIP device visible; libzkgpu has no CPU fallback");
+      return ZKGPU_ERR_NO_DEVICE;
+    }
+    if (!h) return ZKGPU_ERR_ARG;
+    std::lock_guard<std::mutex> lk(h->m);
+    return fn();
+  }
+  catch (const std::exception &e) {
+    zkgpu_set_error(e.what());
+    return ZKGPU_ERR_RUNTIME;
+  }
+  catch (...) {
+    zkgpu_set_error("unknown error");
+    return ZKGPU_ERR_RUNTIME;
+  }
+}
 
 extern "C" {
-char *zkgpu_abi_genCMT(uint64_t value, char *sn_string, char *r_string) { return hash_out(note_cm(value, blob256_from_hex(sn_string), blob256_from_hex(r_string))); }
-char *zkgpu_abi_genCMTS(uint64_t value_s, char *pk_string, char *r_s_string, char *sn_old_string) { return hash_out(note_s_cm(value_s, blob160_from_hex(pk_string), blob256_from_hex(r_s_string), blob256_from_hex(sn_old_string))); }
+char *zkgpu_abi_genCMT(uint64_t value, char *sn_string, char *r_string) {
+  return hash_out(note_cm(value, blob256_from_hex(sn_string), blob256_from_hex(r_string)));
+}
+char *zkgpu_abi_genCMTS(uint64_t value_s, char *pk_string, char *r_s_string, char *sn_old_string) {
+  return hash_out(note_s_cm(value_s, blob160_from_hex(pk_string), blob256_from_hex(r_s_string), blob256_from_hex(sn_old_string)));
+}
 char *zkgpu_abi_computePRF(char *sk_string, char *r_string) { return hash_out(compute_prf(blob256_from_hex(sk_string), blob256_from_hex(r_string))); }
 char *zkgpu_abi_computeCRH(char *pk_string, char *r_string) { return hash_out(compute_crh(blob160_from_hex(pk_string), blob256_from_hex(r_string))); }
-static std::vector<Blob256> parse_cmtarray(const char *cmtarray, int n) { std::vector<Blob256> leaves; std::string s = cmtarray ? cmtarray : ""; if (n > 256) n = 256;   // boost::array<uint256, 256> (depositcgo.cpp:304)
+// boost::array<uint256, 256> (depositcgo.cpp:304)
+static std::vector<Blob256> parse_cmtarray(const char *cmtarray, int n) {
+  std::vector<Blob256> leaves;
+  std::string s = cmtarray ? cmtarray : "";
+  if (n > 256) n = 256;
   for (int i = 0; i < n; i++) leaves.push_back(blob256_from_hex((size_t)i * 66 < s.size() ? s.substr((size_t)i * 66, 66).c_str() : "")); return leaves; }
 char *zkgpu_abi_genRoot(char *cmtarray, int n) { return hash_out(merkle_root(parse_cmtarray(cmtarray, n), 8)); }
 
-char *zkgpu_abi_genMintproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk) {
-  MintInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn), blob256_from_hex(r), blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
+char *zkgpu_abi_genMintproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s,
+    char *sk) {
+  MintInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn), blob256_from_hex(r),
+      blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
   return generate(CircuitKind::Mint, [&](Circuit &c) { assign_mint(c, in); }); }
-bool zkgpu_abi_verifyMintproof(char *data, char *cmtA_old, char *sn_old, char *cmtA, uint64_t value_s) {   // mint_gadget::witness_map (mint/circuit/gadget.tcc:252-269)
+// mint_gadget::witness_map (mint/circuit/gadget.tcc:252-269)
+bool zkgpu_abi_verifyMintproof(char *data, char *cmtA_old, char *sn_old, char *cmtA, uint64_t value_s) {
   const char *a[3] = {cmtA_old, sn_old, cmtA}; return verify(CircuitKind::Mint, data, public_bits(CircuitKind::Mint, a, value_s)); }
-char *zkgpu_abi_genRedeemproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk) {
-  RedeemInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn), blob256_from_hex(r), blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
+char *zkgpu_abi_genRedeemproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s,
+    char *sk) {
+  RedeemInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn), blob256_from_hex(r),
+      blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
   return generate(CircuitKind::Redeem, [&](Circuit &c) { assign_redeem(c, in); }); }
 bool zkgpu_abi_verifyRedeemproof(char *data, char *cmtA_old, char *sn_old, char *cmtA, uint64_t value_s) {
   const char *a[3] = {cmtA_old, sn_old, cmtA}; return verify(CircuitKind::Redeem, data, public_bits(CircuitKind::Redeem, a, value_s)); }
 
-static SendInputs send_inputs(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender) {
+static SendInputs send_inputs(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new,
+    char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender) {
   SendInputs in;   // sendcgo.cpp:317-333: note_old = (value_A, sn, r), notes = (value_s, pk_recv, r_s, sn), note_new = (value_A_new, sn_A_new, r_A_new)
-  in.value_old = value_A; in.value_s = value_s; in.value = value_A_new; in.sn_old = blob256_from_hex(sn); in.r_old = blob256_from_hex(r); in.r_s = blob256_from_hex(r_s); in.sn = blob256_from_hex(sn_A_new); in.r = blob256_from_hex(r_A_new);
-  in.cmtA_old = blob256_from_hex(cmtA); in.cmtS = blob256_from_hex(cmt_s); in.cmtA = blob256_from_hex(cmt_A_new); in.sk = blob256_from_hex(sk); in.pk_recv = blob160_from_hex(pk_recv); in.pk_sender = blob160_from_hex(pk_sender); return in; }
-char *zkgpu_abi_genSendproof(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender) {
+  in.value_old = value_A;
+  in.value_s = value_s;
+  in.value = value_A_new;
+  in.sn_old = blob256_from_hex(sn);
+  in.r_old = blob256_from_hex(r);
+  in.r_s = blob256_from_hex(r_s);
+  in.sn = blob256_from_hex(sn_A_new);
+  in.r = blob256_from_hex(r_A_new);
+  in.cmtA_old = blob256_from_hex(cmtA);
+  in.cmtS = blob256_from_hex(cmt_s);
+  in.cmtA = blob256_from_hex(cmt_A_new);
+  in.sk = blob256_from_hex(sk);
+  in.pk_recv = blob160_from_hex(pk_recv);
+  in.pk_sender = blob160_from_hex(pk_sender);
+  return in;
+}
+char *zkgpu_abi_genSendproof(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new,
+    char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender) {
   SendInputs in = send_inputs(value_A, r_s, sn, r, cmt_s, cmtA, value_s, pk_recv, value_A_new, sn_A_new, r_A_new, cmt_A_new, sk, pk_sender);
   return generate(CircuitKind::Send, [&](Circuit &c) { assign_send(c, in); }); }
-bool zkgpu_abi_verifySendproof(char *data, char *cmtA_old, char *sn_old, char *cmtS, char *cmtA_new) {   // send_gadget::witness_map (send/circuit/gadget.tcc:274-291)
+// send_gadget::witness_map (send/circuit/gadget.tcc:274-291)
+bool zkgpu_abi_verifySendproof(char *data, char *cmtA_old, char *sn_old, char *cmtS, char *cmtA_new) {
   const char *a[4] = {cmtA_old, sn_old, cmtS, cmtA_new}; return verify(CircuitKind::Send, data, public_bits(CircuitKind::Send, a, 0)); }
 
 // depositcgo.cpp:327-444: the Merkle path of cmtS is rebuilt from cmtarray (the tree holds the leaves up to and including the first occurrence of cmtS plus
 // everything appended afterwards, i.e. all n leaves); RT is ignored and the root recomputed
-static DepositInputs deposit_inputs(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old, char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *sk, size_t depth) {
-  DepositInputs in; in.value = value; in.value_old = value_old; in.value_s = value_s; in.sn_old = blob256_from_hex(sn_old); in.r_old = blob256_from_hex(r_old); in.sn = blob256_from_hex(sn); in.r = blob256_from_hex(r);
-  in.sn_s = blob256_from_hex(sns); in.r_s = blob256_from_hex(rs); in.cmtB_old = blob256_from_hex(cmtB_old); in.cmtB = blob256_from_hex(cmtB); in.cmtS = blob256_from_hex(cmtS); in.sk = blob256_from_hex(sk); in.pk_recv = blob160_from_hex(pk);
+static DepositInputs deposit_inputs(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old,
+    char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *sk, size_t depth) {
+  DepositInputs in;
+  in.value = value;
+  in.value_old = value_old;
+  in.value_s = value_s;
+  in.sn_old = blob256_from_hex(sn_old);
+  in.r_old = blob256_from_hex(r_old);
+  in.sn = blob256_from_hex(sn);
+  in.r = blob256_from_hex(r);
+  in.sn_s = blob256_from_hex(sns);
+  in.r_s = blob256_from_hex(rs);
+  in.cmtB_old = blob256_from_hex(cmtB_old);
+  in.cmtB = blob256_from_hex(cmtB);
+  in.cmtS = blob256_from_hex(cmtS);
+  in.sk = blob256_from_hex(sk);
+  in.pk_recv = blob160_from_hex(pk);
   in.sn_A_old = blob256_from_hex(sn_A_old);
-  std::vector<Blob256> leaves = parse_cmtarray(cmtarray, n); size_t index = 0; bool found = false; for (size_t i = 0; i < leaves.size(); i++) if (!memcmp(leaves[i].b, in.cmtS.b, 32)) { index = i; found = true; break; }
-  if (!found) throw std::runtime_error("cmtS is not among the commitments of cmtarray");   // the reference throws out of IncrementalMerkleTree::path() here (IncrementalMerkleTree.tcc:214-216), taking the Go process with it
+  std::vector<Blob256> leaves = parse_cmtarray(cmtarray, n);
+  size_t index = 0;
+  bool found = false;
+  for (size_t i = 0; i < leaves.size(); i++) if (!memcmp(leaves[i].b, in.cmtS.b, 32)) {
+    index = i;
+    found = true;
+    break;
+  }
+  // the reference throws out of IncrementalMerkleTree::path() here (IncrementalMerkleTree.tcc:214-216), taking the Go process with it
+  if (!found) throw std::runtime_error("cmtS is not among the commitments of cmtarray");
   in.path = merkle_path(leaves, depth, index, in.index_bits); in.rt = merkle_root(leaves, depth); return in; }
-char *zkgpu_abi_genDepositproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old, char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *RT, char *sk) {
-  (void)RT; return generate(CircuitKind::Deposit, [&](Circuit &c) { assign_deposit(c, deposit_inputs(value, value_old, sn_old, r_old, sn, r, sns, rs, cmtB_old, cmtB, value_s, pk, sn_A_old, cmtS, cmtarray, n, sk, 8)); }); }
-bool zkgpu_abi_verifyDepositproof(char *data, char *RT, char *pk, char *cmtb_old, char *snold, char *cmtb, char *sns) {   // deposit_gadget::witness_map (deposit/circuit/gadget.tcc:301-323)
+char *zkgpu_abi_genDepositproof(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old,
+    char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *RT, char *sk) {
+  (void)RT;
+  return generate(CircuitKind::Deposit, [&](Circuit &c) { assign_deposit(c, deposit_inputs(value, value_old, sn_old, r_old, sn, r, sns, rs, cmtB_old, cmtB,
+      value_s, pk, sn_A_old, cmtS, cmtarray, n, sk, 8)); });
+}
+// deposit_gadget::witness_map (deposit/circuit/gadget.tcc:301-323)
+bool zkgpu_abi_verifyDepositproof(char *data, char *RT, char *pk, char *cmtb_old, char *snold, char *cmtb, char *sns) {
   const char *a[6] = {RT, pk, cmtb_old, snold, cmtb, sns}; return verify(CircuitKind::Deposit, data, public_bits(CircuitKind::Deposit, a, 0)); }
 
 // ---- engine-level entry points for keys, circuits and the resident prover (include/zkgpu.h) ---------------------------
-static void write_r1cs_file(const char *path, const R1csHost &cs) { FILE *f = fopen(path, "wb"); if (!f) throw std::runtime_error(std::string("cannot write ") + path);
+static void write_r1cs_file(const char *path, const R1csHost &cs) {
+  FILE *f = fopen(path, "wb");
+  if (!f) throw std::runtime_error(std::string("cannot write ") + path);
   uint64_t hdr[3] = {cs.n_inputs, cs.n_vars, cs.n_cons}; fwrite("R1CSBM01", 1, 8, f); fwrite(hdr, 8, 3, f);
-  for (int m = 0; m < 3; m++) { uint64_t nnz = cs.col[m].size(); fwrite(&nnz, 8, 1, f); fwrite(cs.rowptr[m].data(), 4, cs.rowptr[m].size(), f); fwrite(cs.col[m].data(), 4, nnz, f); fwrite(cs.coeff[m].data(), 32, nnz, f); } fclose(f); }
-static R1csHost read_r1cs_file(const char *path) { FILE *f = fopen(path, "rb"); if (!f) throw std::runtime_error(std::string("cannot open ") + path); char mg[8]; uint64_t hdr[3]; R1csHost cs;
-  if (fread(mg, 1, 8, f) != 8 || memcmp(mg, "R1CSBM01", 8) || fread(hdr, 8, 3, f) != 3) { fclose(f); throw std::runtime_error("bad R1CS file"); } cs.n_inputs = hdr[0]; cs.n_vars = hdr[1]; cs.n_cons = hdr[2];
-  for (int m = 0; m < 3; m++) { uint64_t nnz; if (fread(&nnz, 8, 1, f) != 1) { fclose(f); throw std::runtime_error("bad R1CS file"); } cs.rowptr[m].resize(cs.n_cons + 1); cs.col[m].resize(nnz); cs.coeff[m].resize(nnz);
-    if (fread(cs.rowptr[m].data(), 4, cs.n_cons + 1, f) != cs.n_cons + 1 || fread(cs.col[m].data(), 4, nnz, f) != nnz || fread(cs.coeff[m].data(), 32, nnz, f) != nnz) { fclose(f); throw std::runtime_error("truncated R1CS file"); } } fclose(f); return cs; }
-static void write_witness_file(const char *path, const std::vector<Fe32> &z) { FILE *f = fopen(path, "wb"); if (!f) throw std::runtime_error(std::string("cannot write ") + path); uint64_t n = z.size(); fwrite(&n, 8, 1, f); fwrite(z.data(), 32, n, f); fclose(f); }
+  for (int m = 0; m < 3; m++) {
+    uint64_t nnz = cs.col[m].size();
+    fwrite(&nnz, 8, 1, f);
+    fwrite(cs.rowptr[m].data(), 4, cs.rowptr[m].size(), f);
+    fwrite(cs.col[m].data(), 4, nnz, f);
+    fwrite(cs.coeff[m].data(), 32, nnz, f);
+  }
+  fclose(f);
+}
+static R1csHost read_r1cs_file(const char *path) {
+  FILE *f = fopen(path, "rb");
+  if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+  char mg[8];
+  uint64_t hdr[3];
+  R1csHost cs;
+  if (fread(mg, 1, 8, f) != 8 || memcmp(mg, "R1CSBM01", 8) || fread(hdr, 8, 3, f) != 3) {
+    fclose(f);
+    throw std::runtime_error("bad R1CS file");
+  }
+  cs.n_inputs = hdr[0];
+  cs.n_vars = hdr[1];
+  cs.n_cons = hdr[2];
+  for (int m = 0; m < 3; m++) {
+    uint64_t nnz;
+    if (fread(&nnz, 8, 1, f) != 1) {
+      fclose(f);
+      throw std::runtime_error("bad R1CS file");
+    }
+    cs.rowptr[m].resize(cs.n_cons + 1);
+    cs.col[m].resize(nnz);
+    cs.coeff[m].resize(nnz);
+    if (fread(cs.rowptr[m].data(), 4, cs.n_cons + 1, f) != cs.n_cons + 1 || fread(cs.col[m].data(), 4, nnz, f) != nnz || fread(cs.coeff[m].data(), 32, nnz,
+        f) != nnz) {
+      fclose(f);
+      throw std::runtime_error("truncated R1CS file");
+    }
+  }
+  fclose(f);
+  return cs;
+}
+static void write_witness_file(const char *path, const std::vector<Fe32> &z) {
+  FILE *f = fopen(path, "wb");
+  if (!f) throw std::runtime_error(std::string("cannot write ") + path);
+  uint64_t n = z.size();
+  fwrite(&n, 8, 1, f);
+  fwrite(z.data(), 32, n, f);
+  fclose(f);
+}
 
-int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path) { return guarded_host([&] { std::unique_ptr<Circuit> c = kind == 100 ? make_sha256_two_to_one(true) : kind == 101 ? make_merkle_test_circuit(true, tree_depth) : kind == 102 ? make_lesscmp_test_circuit(true) : kind == 103 ? make_cmta_test_circuit(true) : kind >= 104 && kind <= 106 ? make_hashblock_test_circuit(true, kind - 104) : kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true); write_r1cs_file(r1cs_path, c->r1cs()); return ZKGPU_OK; }); }
+int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path) {
+  return guarded_host([&] { std::unique_ptr<Circuit> c = kind == 100 ? make_sha256_two_to_one(true) : kind == 101 ? make_merkle_test_circuit(true,
+      tree_depth) : kind == 102 ? make_lesscmp_test_circuit(true) : kind == 103 ? make_cmta_test_circuit(true) : kind >= 104 && kind <= 106 ?
+      make_hashblock_test_circuit(true, kind - 104) : kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true,
+      tree_depth) : make_circuit((CircuitKind)kind, true); write_r1cs_file(r1cs_path, c->r1cs()); return ZKGPU_OK; });
+}
 /* bits: 64 + 256 + 256 bytes, each 0 or 1, in the circuit's bit order */
-int zkgpu_witness_cmta(const uint8_t *bits, const char *wit_path) { return guarded_host([&] { auto c = make_cmta_test_circuit(false); std::vector<bool> v(bits, bits + 64), sn(bits + 64, bits + 320), r(bits + 320, bits + 576); assign_cmta_test(*c, v, sn, r); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
+int zkgpu_witness_cmta(const uint8_t *bits, const char *wit_path) {
+  return guarded_host([&] { auto c = make_cmta_test_circuit(false); std::vector<bool> v(bits, bits + 64), sn(bits + 64, bits + 320), r(bits + 320, bits + 576);
+      assign_cmta_test(*c, v, sn, r); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; });
+}
 /* which: 0 CMTS (736 input bits), 1 PRF (512), 2 CRH (416); bits: one byte (0 / 1) per input bit, in the block's message order */
-int zkgpu_witness_hashblock(int which, const uint8_t *bits, const char *wit_path) { return guarded_host([&] { if (which < 0 || which > 2) throw std::runtime_error("hashblock: which must be 0, 1 or 2"); auto c = make_hashblock_test_circuit(false, which);
-  assign_hashblock_test(*c, std::vector<bool>(bits, bits + hashblock_input_bits(which))); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
-int zkgpu_witness_lesscmp(uint64_t value_old, uint64_t value_s, const char *wit_path) { return guarded_host([&] { auto c = make_lesscmp_test_circuit(false); assign_lesscmp_test(*c, value_old, value_s); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
-int zkgpu_witness_sha256(const uint8_t left[32], const uint8_t right[32], const char *wit_path) { return guarded_host([&] { auto c = make_sha256_two_to_one(false); assign_sha256_two_to_one(*c, blob_bits(left, 32), blob_bits(right, 32)); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
+int zkgpu_witness_hashblock(int which, const uint8_t *bits, const char *wit_path) { return guarded_host([&] {
+    if (which < 0 || which > 2) throw std::runtime_error("hashblock: which must be 0, 1 or 2"); auto c = make_hashblock_test_circuit(false, which);
+  assign_hashblock_test(*c, std::vector<bool>(bits, bits + hashblock_input_bits(which))); std::vector<Fe32> z; c->export_assignment(z);
+      write_witness_file(wit_path, z); return ZKGPU_OK; }); }
+int zkgpu_witness_lesscmp(uint64_t value_old, uint64_t value_s, const char *wit_path) {
+  return guarded_host([&] { auto c = make_lesscmp_test_circuit(false); assign_lesscmp_test(*c, value_old, value_s); std::vector<Fe32> z;
+      c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; });
+}
+int zkgpu_witness_sha256(const uint8_t left[32], const uint8_t right[32], const char *wit_path) {
+  return guarded_host([&] { auto c = make_sha256_two_to_one(false); assign_sha256_two_to_one(*c, blob_bits(left, 32), blob_bits(right, 32));
+      std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; });
+}
 /* Merkle test circuit: leaf and depth siblings (leaf level first, 32 bytes each, in hashing byte order), position of the leaf; the root is computed */
-int zkgpu_witness_merkle(int depth, const uint8_t leaf[32], const uint8_t *siblings, uint64_t position, const char *wit_path) { return guarded_host([&] { auto c = make_merkle_test_circuit(false, depth);
+int zkgpu_witness_merkle(int depth, const uint8_t leaf[32], const uint8_t *siblings, uint64_t position, const char *wit_path) { return guarded_host([&] {
+    auto c = make_merkle_test_circuit(false, depth);
   Blob256 lf; memcpy(lf.b, leaf, 32); std::vector<Blob256> path(depth); std::vector<bool> idx(depth); Blob256 cur = lf;
-  for (int d = 0; d < depth; d++) { memcpy(path[d].b, siblings + 32 * d, 32); idx[d] = (position >> d) & 1; Blob256 nx; if (idx[d]) sha256_compress_raw(path[d].b, cur.b, nx.b); else sha256_compress_raw(cur.b, path[d].b, nx.b); cur = nx; }
+  for (int d = 0; d < depth; d++) {
+    memcpy(path[d].b, siblings + 32 * d, 32);
+    idx[d] = (position >> d) & 1;
+    Blob256 nx;
+    if (idx[d]) sha256_compress_raw(path[d].b, cur.b, nx.b);
+    else sha256_compress_raw(cur.b, path[d].b, nx.b);
+    cur = nx;
+  }
   assign_merkle_test(*c, lf, path, idx, cur); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
-int zkgpu_witness_deposit(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old, char *cmtB, uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *sk, int tree_depth, const char *wit_path) {
-  return guarded_host([&] { DepositInputs in = deposit_inputs(value, value_old, sn_old, r_old, sn, r, sns, rs, cmtB_old, cmtB, value_s, pk, sn_A_old, cmtS, cmtarray, n, sk, (size_t)tree_depth);
-    auto c = make_deposit_circuit(false, (size_t)tree_depth); assign_deposit(*c, in); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
-int zkgpu_witness_send(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender, const char *wit_path) {
-  return guarded_host([&] { auto c = make_send_circuit(false); assign_send(*c, send_inputs(value_A, r_s, sn, r, cmt_s, cmtA, value_s, pk_recv, value_A_new, sn_A_new, r_A_new, cmt_A_new, sk, pk_sender)); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
-int zkgpu_witness_mint_redeem(int redeem, uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA, uint64_t value_s, char *sk, const char *wit_path) {
-  return guarded_host([&] { MintInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn), blob256_from_hex(r), blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
-    auto c = redeem ? make_redeem_circuit(false) : make_mint_circuit(false); if (redeem) { RedeemInputs ri{in.value, in.value_old, in.value_s, in.sn_old, in.r_old, in.sn, in.r, in.cmtA_old, in.cmtA, in.sk}; assign_redeem(*c, ri); } else assign_mint(*c, in);
+int zkgpu_witness_deposit(uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *sns, char *rs, char *cmtB_old, char *cmtB,
+    uint64_t value_s, char *pk, char *sn_A_old, char *cmtS, char *cmtarray, int n, char *sk, int tree_depth, const char *wit_path) {
+  return guarded_host([&] { DepositInputs in = deposit_inputs(value, value_old, sn_old, r_old, sn, r, sns, rs, cmtB_old, cmtB, value_s, pk, sn_A_old, cmtS,
+      cmtarray, n, sk, (size_t)tree_depth);
+    auto c = make_deposit_circuit(false, (size_t)tree_depth); assign_deposit(*c, in); std::vector<Fe32> z; c->export_assignment(z);
+        write_witness_file(wit_path, z); return ZKGPU_OK; }); }
+int zkgpu_witness_send(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new,
+    char *sn_A_new, char *r_A_new, char *cmt_A_new, char *sk, char *pk_sender, const char *wit_path) {
+  return guarded_host([&] { auto c = make_send_circuit(false); assign_send(*c, send_inputs(value_A, r_s, sn, r, cmt_s, cmtA, value_s, pk_recv, value_A_new,
+      sn_A_new, r_A_new, cmt_A_new, sk, pk_sender)); std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; });
+}
+int zkgpu_witness_mint_redeem(int redeem, uint64_t value, uint64_t value_old, char *sn_old, char *r_old, char *sn, char *r, char *cmtA_old, char *cmtA,
+    uint64_t value_s, char *sk, const char *wit_path) {
+  return guarded_host([&] { MintInputs in{value, value_old, value_s, blob256_from_hex(sn_old), blob256_from_hex(r_old), blob256_from_hex(sn),
+      blob256_from_hex(r), blob256_from_hex(cmtA_old), blob256_from_hex(cmtA), blob256_from_hex(sk)};
+    auto c = redeem ? make_redeem_circuit(false) : make_mint_circuit(false);
+    if (redeem) {
+      RedeemInputs ri{in.value, in.value_old, in.value_s, in.sn_old, in.r_old, in.sn, in.r, in.cmtA_old, in.cmtA, in.sk};
+      assign_redeem(*c, ri);
+    } else assign_mint(*c, in);
     std::vector<Fe32> z; c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; }); }
 
-int zkgpu_debug_time_send_witness(double out[3]) { return guarded_host([&] { auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  SendInputs in{}; in.value_old = 22; in.value_s = 8; in.value = 14; double t0 = now(); auto c = make_send_circuit(false); double t1 = now(); assign_send(*c, in); double t2 = now(); std::vector<Fe32> z; c->export_assignment(z); double t3 = now();
+int zkgpu_debug_time_send_witness(double out[3]) { return guarded_host([&] { auto now = [] {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  SendInputs in{};
+  in.value_old = 22;
+  in.value_s = 8;
+  in.value = 14;
+  double t0 = now();
+  auto c = make_send_circuit(false);
+  double t1 = now();
+  assign_send(*c, in);
+  double t2 = now();
+  std::vector<Fe32> z;
+  c->export_assignment(z);
+  double t3 = now();
   assign_send(*c, in); double t4 = now(); out[0] = t1 - t0; out[1] = t4 - t3; out[2] = t3 - t2; return ZKGPU_OK; }); }
-int zkgpu_keygen_from_r1cs(const char *r1cs_path, uint64_t seed, const char *pk_path, const char *vk_path) { return guarded([&] { R1csHost cs = read_r1cs_file(r1cs_path); ProvingKeyHost pk; VerifyingKeyHost vk;
-  generate_keys(cs, seed ? ToxicWaste::from_seed(seed) : ToxicWaste::random(), pk, vk); save_proving_key(pk_path, pk); save_verifying_key(vk_path, vk); return ZKGPU_OK; }); }
-int zkgpu_keygen(int kind, int tree_depth, uint64_t seed, const char *pk_path, const char *vk_path) { return guarded([&] { std::unique_ptr<Circuit> c = kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true);
-  ProvingKeyHost pk; VerifyingKeyHost vk; generate_keys(c->r1cs(), seed ? ToxicWaste::from_seed(seed) : ToxicWaste::random(), pk, vk); save_proving_key(pk_path, pk); save_verifying_key(vk_path, vk); return ZKGPU_OK; }); }
+int zkgpu_keygen_from_r1cs(const char *r1cs_path, uint64_t seed, const char *pk_path, const char *vk_path) { return guarded([&] {
+    R1csHost cs = read_r1cs_file(r1cs_path); ProvingKeyHost pk; VerifyingKeyHost vk;
+  generate_keys(cs, seed ? ToxicWaste::from_seed(seed) : ToxicWaste::random(), pk, vk); save_proving_key(pk_path, pk); save_verifying_key(vk_path, vk);
+      return ZKGPU_OK; }); }
+int zkgpu_keygen(int kind, int tree_depth, uint64_t seed, const char *pk_path, const char *vk_path) { return guarded([&] {
+    std::unique_ptr<Circuit> c = kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true, tree_depth) : make_circuit((CircuitKind)kind, true);
+  ProvingKeyHost pk; VerifyingKeyHost vk; generate_keys(c->r1cs(), seed ? ToxicWaste::from_seed(seed) : ToxicWaste::random(), pk, vk);
+      save_proving_key(pk_path, pk); save_verifying_key(vk_path, vk); return ZKGPU_OK; }); }
 
-zkgpu_prover *zkgpu_prover_load_shard(const char *pk_path, size_t shard_rank, size_t shard_world) { zkgpu_prover *h = nullptr; guarded([&] { FileStamp before; if (!stamp_of(pk_path, before)) throw std::runtime_error(std::string("proving key not found: ") + pk_path); bool cached = false; ProvingKeyHost pk = load_proving_key_fast(pk_path, cached); std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(pk, shard_rank, shard_world));
+zkgpu_prover *zkgpu_prover_load_shard(const char *pk_path, size_t shard_rank, size_t shard_world) { zkgpu_prover *h = nullptr; guarded([&] { FileStamp before;
+    if (!stamp_of(pk_path, before)) throw std::runtime_error(std::string("proving key not found: ") + pk_path); bool cached = false;
+    ProvingKeyHost pk = load_proving_key_fast(pk_path, cached); std::unique_ptr<zkgpu_prover> p(new zkgpu_prover);
+    p->p.reset(new Prover(pk, shard_rank, shard_world));
   if (!cached) write_container_quietly(pk_path, pk, before); h = p.release(); return ZKGPU_OK; }); return h; }
 /* pure host logic of the multi-device pool, for the CPU tests: parses `spec` as ZK_DEVICES would be (n_visible devices, `fallback` = ZK_DEVICE / LOCAL_RANK) into out_devices (returns
  * the count), and writes into out_order the device that each of n_order callers arriving AT THE SAME TIME (nobody has finished yet) is sent to by acquire_prover's policy */
@@ -336,42 +643,148 @@ int zkgpu_test_pool_plan(int D, int spill, const int *release_before, int n_call
 int zkgpu_test_lane_plan(int n_slots, int kinds, int per_kind, int *out_lanes_per_slot) {
   return lane_plan_simulate(n_slots, kinds, per_kind, out_lanes_per_slot); }
 /* the hand-over's block classifiers, scalar against the forms the host's CPU selects (AVX2 where it has it): see groth16.cpp: test_scan_blocks */
-int zkgpu_test_scan_blocks(const uint8_t *tags64, const uint64_t *elems64x4, const uint64_t *one4, uint64_t *out10) { return guarded_host([&] { test_scan_blocks(tags64, elems64x4, one4, out10); return ZKGPU_OK; }); }
+int zkgpu_test_scan_blocks(const uint8_t *tags64, const uint64_t *elems64x4, const uint64_t *one4, uint64_t *out10) {
+  return guarded_host([&] { test_scan_blocks(tags64, elems64x4, one4, out10); return ZKGPU_OK; });
+}
 /* host-only self-test of the container code (tests/test_key_container_cpu.py): a synthetic transformed key of the given shape is written, mapped back and compared; then the
  * file is truncated, a payload byte is flipped, and the source stamp is changed — each must make the loader refuse.  Returns 0 if every step behaved. */
 int zkgpu_test_key_container(const char *path, size_t n_vars, size_t n_cons, size_t m) { int rc = -1; guarded_host([&] {
-  ProvingKeyHost pk; uint64_t s = 0x1234; auto rnd = [&](void *p, size_t n) { uint8_t *b = (uint8_t *)p; for (size_t i = 0; i < n; i++) { s = s * 6364136223846793005ull + 1442695040888963407ull; b[i] = (uint8_t)(s >> 56); } };
-  pk.cs.n_inputs = 3; pk.cs.n_vars = n_vars; pk.cs.n_cons = n_cons; pk.A.resize(n_vars + 1); pk.L_star.resize(n_vars + 1); pk.H_lagrange.resize(m); size_t nB = n_vars / 2 + 1; pk.B_idx.resize(nB); pk.B_g1.resize(nB); pk.B_g2.resize(nB);
-  rnd(&pk.alpha_g1, 64); rnd(&pk.beta_g1, 64); rnd(&pk.delta_g1, 64); rnd(&pk.beta_g2, 128); rnd(&pk.delta_g2, 128); rnd(pk.A.data(), pk.A.size() * 64); rnd(pk.L_star.data(), pk.L_star.size() * 64); rnd(pk.H_lagrange.data(), m * 64); rnd(pk.B_g1.data(), nB * 64); rnd(pk.B_g2.data(), nB * 128);
+  ProvingKeyHost pk;
+  uint64_t s = 0x1234;
+  auto rnd = [&](void *p, size_t n) {
+    uint8_t *b = (uint8_t *)p;
+    for (size_t i = 0; i < n; i++) {
+      s = s * 6364136223846793005ull + 1442695040888963407ull;
+      b[i] = (uint8_t)(s >> 56);
+    }
+  };
+  pk.cs.n_inputs = 3;
+  pk.cs.n_vars = n_vars;
+  pk.cs.n_cons = n_cons;
+  pk.A.resize(n_vars + 1);
+  pk.L_star.resize(n_vars + 1);
+  pk.H_lagrange.resize(m);
+  size_t nB = n_vars / 2 + 1;
+  pk.B_idx.resize(nB);
+  pk.B_g1.resize(nB);
+  pk.B_g2.resize(nB);
+  rnd(&pk.alpha_g1, 64);
+  rnd(&pk.beta_g1, 64);
+  rnd(&pk.delta_g1, 64);
+  rnd(&pk.beta_g2, 128);
+  rnd(&pk.delta_g2, 128);
+  rnd(pk.A.data(), pk.A.size() * 64);
+  rnd(pk.L_star.data(), pk.L_star.size() * 64);
+  rnd(pk.H_lagrange.data(), m * 64);
+  rnd(pk.B_g1.data(), nB * 64);
+  rnd(pk.B_g2.data(), nB * 128);
   for (size_t i = 0; i < nB; i++) pk.B_idx[i] = (uint32_t)(2 * i);
-  for (int k = 0; k < 3; k++) { pk.cs.rowptr[k].resize(n_cons + 1); pk.cs.rowptr[k][0] = 0; for (size_t i = 0; i < n_cons; i++) pk.cs.rowptr[k][i + 1] = pk.cs.rowptr[k][i] + (uint32_t)((i + k) % 3); size_t nnz = pk.cs.rowptr[k][n_cons]; pk.cs.col[k].resize(nnz); pk.cs.coeff[k].resize(nnz); for (size_t e = 0; e < nnz; e++) pk.cs.col[k][e] = (uint32_t)(e % (n_vars + 1)); rnd(pk.cs.coeff[k].data(), nnz * 32); }
+  for (int k = 0; k < 3; k++) {
+    pk.cs.rowptr[k].resize(n_cons + 1);
+    pk.cs.rowptr[k][0] = 0;
+    for (size_t i = 0; i < n_cons; i++) pk.cs.rowptr[k][i + 1] = pk.cs.rowptr[k][i] + (uint32_t)((i + k) % 3);
+    size_t nnz = pk.cs.rowptr[k][n_cons];
+    pk.cs.col[k].resize(nnz);
+    pk.cs.coeff[k].resize(nnz);
+    for (size_t e = 0; e < nnz; e++) pk.cs.col[k][e] = (uint32_t)(e % (n_vars + 1));
+    rnd(pk.cs.coeff[k].data(), nnz * 32);
+  }
   KeyStamp st{12345, 1700000000, 42}; save_key_container(path, pk, st); ProvingKeyHost q;
-  auto same = [&](const ProvingKeyHost &a, const ProvingKeyHost &b) { bool ok = !memcmp(&a.alpha_g1, &b.alpha_g1, 64) && !memcmp(&a.delta_g2, &b.delta_g2, 128) && a.B_idx == b.B_idx && a.cs.n_cons == b.cs.n_cons && a.cs.n_vars == b.cs.n_vars && a.cs.n_inputs == b.cs.n_inputs;
-    ok = ok && a.A.size() == b.A.size() && !memcmp(a.A.data(), b.A.data(), a.A.size() * 64) && a.L_star.size() == b.L_star.size() && !memcmp(a.L_star.data(), b.L_star.data(), a.L_star.size() * 64) && a.H_lagrange.size() == b.H_lagrange.size() && !memcmp(a.H_lagrange.data(), b.H_lagrange.data(), a.H_lagrange.size() * 64);
-    ok = ok && a.B_g2.size() == b.B_g2.size() && !memcmp(a.B_g2.data(), b.B_g2.data(), a.B_g2.size() * 128) && !memcmp(a.B_g1.data(), b.B_g1.data(), a.B_g1.size() * 64);
-    for (int k = 0; k < 3 && ok; k++) ok = a.cs.rowptr[k] == b.cs.rowptr[k] && a.cs.col[k] == b.cs.col[k] && a.cs.coeff[k].size() == b.cs.coeff[k].size() && !memcmp(a.cs.coeff[k].data(), b.cs.coeff[k].data(), a.cs.coeff[k].size() * 32); return ok; };
+  auto same = [&](const ProvingKeyHost &a, const ProvingKeyHost &b) {
+    bool ok = !memcmp(&a.alpha_g1, &b.alpha_g1, 64) && !memcmp(&a.delta_g2, &b.delta_g2,
+        128) && a.B_idx == b.B_idx && a.cs.n_cons == b.cs.n_cons && a.cs.n_vars == b.cs.n_vars && a.cs.n_inputs == b.cs.n_inputs;
+    ok = ok && a.A.size() == b.A.size() && !memcmp(a.A.data(), b.A.data(), a.A.size() * 64) && a.L_star.size() == b.L_star.size() && !memcmp(a.L_star.data(),
+        b.L_star.data(), a.L_star.size() * 64) && a.H_lagrange.size() == b.H_lagrange.size() && !memcmp(a.H_lagrange.data(), b.H_lagrange.data(),
+        a.H_lagrange.size() * 64);
+    ok = ok && a.B_g2.size() == b.B_g2.size() && !memcmp(a.B_g2.data(), b.B_g2.data(), a.B_g2.size() * 128) && !memcmp(a.B_g1.data(), b.B_g1.data(),
+        a.B_g1.size() * 64);
+    for (int k = 0; k < 3 && ok; k++) ok = a.cs.rowptr[k] == b.cs.rowptr[k] && a.cs.col[k] == b.cs.col[k] && a.cs.coeff[k].size() == b.cs.coeff[k].size() &&
+        !memcmp(a.cs.coeff[k].data(), b.cs.coeff[k].data(), a.cs.coeff[k].size() * 32);
+    return ok;
+  };
   if (!load_key_container(path, st, q) || !same(pk, q)) { rc = 1; return ZKGPU_OK; }
-  KeyStamp other = st; other.mtime_ns++; if (load_key_container(path, other, q)) { rc = 2; return ZKGPU_OK; }                       // the key file changed: stale
+  // the key file changed: stale
+  KeyStamp other = st;
+  other.mtime_ns++;
+  if (load_key_container(path, other, q)) {
+    rc = 2;
+    return ZKGPU_OK;
+  }
   struct stat sb; if (stat(path, &sb)) { rc = 3; return ZKGPU_OK; }
-  { FILE *f = fopen(path, "r+b"); fseek(f, (long)(sb.st_size / 2), SEEK_SET); int ch = fgetc(f); fseek(f, (long)(sb.st_size / 2), SEEK_SET); fputc(ch ^ 1, f); fclose(f); if (load_key_container(path, st, q)) { rc = 4; return ZKGPU_OK; }   // bit rot: checksum
-    f = fopen(path, "r+b"); fseek(f, (long)(sb.st_size / 2), SEEK_SET); fputc(ch, f); fclose(f); if (!load_key_container(path, st, q)) { rc = 5; return ZKGPU_OK; } }
-  if (truncate(path, sb.st_size - 64)) { rc = 6; return ZKGPU_OK; } if (load_key_container(path, st, q)) { rc = 7; return ZKGPU_OK; }                                      // truncated
+  // bit rot: checksum
+  {
+    FILE *f = fopen(path, "r+b");
+    fseek(f, (long)(sb.st_size / 2), SEEK_SET);
+    int ch = fgetc(f);
+    fseek(f, (long)(sb.st_size / 2), SEEK_SET);
+    fputc(ch ^ 1, f);
+    fclose(f);
+    if (load_key_container(path, st, q)) {
+      rc = 4;
+      return ZKGPU_OK;
+    }
+    f = fopen(path, "r+b");
+    fseek(f, (long)(sb.st_size / 2), SEEK_SET);
+    fputc(ch, f);
+    fclose(f);
+    if (!load_key_container(path, st, q)) {
+      rc = 5;
+      return ZKGPU_OK;
+    }
+  }
+  // truncated
+  if (truncate(path, sb.st_size - 64)) {
+    rc = 6;
+    return ZKGPU_OK;
+  }
+  if (load_key_container(path, st, q)) {
+    rc = 7;
+    return ZKGPU_OK;
+  }
   rc = 0; return ZKGPU_OK; }); return rc; }
 /* 1 if a valid container exists for this key file (what the next load will use), 0 if not */
-int zkgpu_key_container_valid(const char *pk_path) { int r = 0; guarded_host([&] { KeyStamp ks; ProvingKeyHost pk; std::string cp = key_container_path(pk_path); r = !cp.empty() && key_stamp_of(pk_path, ks) && load_key_container(cp, ks, pk) ? 1 : 0; return ZKGPU_OK; }); return r; }
+int zkgpu_key_container_valid(const char *pk_path) {
+  int r = 0;
+  guarded_host([&] { KeyStamp ks; ProvingKeyHost pk; std::string cp = key_container_path(pk_path);
+      r = !cp.empty() && key_stamp_of(pk_path, ks) && load_key_container(cp, ks, pk) ? 1 : 0; return ZKGPU_OK; });
+  return r;
+}
 zkgpu_prover *zkgpu_prover_load(const char *pk_path) { return zkgpu_prover_load_shard(pk_path, 0, 1); }
-int zkgpu_prover_prove_partial(zkgpu_prover *h, uint8_t out[384]) { return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; if (!h->p->prove_partial(out)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } return ZKGPU_OK; }); }
-int zkgpu_prover_finish(zkgpu_prover *h, const uint8_t *records, size_t n, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_host([&] { if (!h) return ZKGPU_ERR_ARG; Proof p; h->p->finish_from_partials(records, n, (const Fe32 *)r, (const Fe32 *)s, p);
+int zkgpu_prover_prove_partial(zkgpu_prover *h, uint8_t out[384]) {
+  return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; if (!h->p->prove_partial(out)) {
+      zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } return ZKGPU_OK; });
+}
+int zkgpu_prover_finish(zkgpu_prover *h, const uint8_t *records, size_t n, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_host([&] {
+    if (!h) return ZKGPU_ERR_ARG; Proof p; h->p->finish_from_partials(records, n, (const Fe32 *)r, (const Fe32 *)s, p);
   std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
-zkgpu_prover *zkgpu_prover_clone(zkgpu_prover *h) { zkgpu_prover *out = nullptr; guarded([&] { if (!h) return ZKGPU_ERR_ARG; std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(*h->p)); out = p.release(); return ZKGPU_OK; }); return out; }
+zkgpu_prover *zkgpu_prover_clone(zkgpu_prover *h) {
+  zkgpu_prover *out = nullptr;
+  guarded([&] { if (!h) return ZKGPU_ERR_ARG; std::unique_ptr<zkgpu_prover> p(new zkgpu_prover); p->p.reset(new Prover(*h->p)); out = p.release();
+      return ZKGPU_OK; });
+  return out;
+}
 int zkgpu_prover_prove_batch(zkgpu_prover *h, const uint8_t *zs, size_t n, const uint8_t *rs, char *proofs_hex) { return guarded_prover(h, [&] {
   if (!h || (n && (!zs || !proofs_hex))) return ZKGPU_ERR_ARG; if (!n) return ZKGPU_OK;
   static const size_t want = [] { const char *e = getenv("ZK_BATCH_LANES"); long v = e ? atol(e) : 6; return (size_t)(v < 1 ? 1 : v > 7 ? 7 : v); }();
-  const size_t K = std::min(want, n); { std::lock_guard<std::mutex> lk(g_gpu_mutex); while (h->lanes.size() + 1 < K) h->lanes.push_back(std::make_shared<Prover>(*h->p)); }
+  const size_t K = std::min(want, n);
+  {
+    std::lock_guard<std::mutex> lk(g_gpu_mutex);
+    while (h->lanes.size() + 1 < K) h->lanes.push_back(std::make_shared<Prover>(*h->p));
+  }
   const size_t zbytes = 32 * h->p->num_variables(); std::vector<uint8_t> bad(n, 0); std::vector<std::string> errs(K); std::vector<std::thread> th;
   auto work = [&](size_t lane) { Prover &pv = lane ? *h->lanes[lane - 1] : *h->p;
-    try { for (size_t i = lane; i < n; i += K) { Proof pr; const Fe32 *r = rs ? (const Fe32 *)(rs + 64 * i) : nullptr, *s_ = rs ? (const Fe32 *)(rs + 64 * i + 32) : nullptr;
-        if (!pv.prove((const Fe32 *)(zs + zbytes * i), r, s_, pr)) { bad[i] = 1; pr = default_proof(); } std::string hx = proof_to_hex(pr); memcpy(proofs_hex + 513 * i, hx.c_str(), 513); } }
+    try {
+      for (size_t i = lane; i < n; i += K) {
+        Proof pr;
+        const Fe32 *r = rs ? (const Fe32 *)(rs + 64 * i) : nullptr, *s_ = rs ? (const Fe32 *)(rs + 64 * i + 32) : nullptr;
+        if (!pv.prove((const Fe32 *)(zs + zbytes * i), r, s_, pr)) {
+          bad[i] = 1;
+          pr = default_proof();
+        }
+        std::string hx = proof_to_hex(pr);
+        memcpy(proofs_hex + 513 * i, hx.c_str(), 513);
+      }
+    }
     catch (const std::exception &e) { errs[lane] = e.what(); } catch (...) { errs[lane] = "unknown error"; } };
   for (size_t lane = 1; lane < K; lane++) th.emplace_back(work, lane);
   work(0); for (auto &t : th) t.join();
@@ -380,35 +793,74 @@ int zkgpu_prover_prove_batch(zkgpu_prover *h, const uint8_t *zs, size_t n, const
   if (!which.empty()) { zkgpu_set_error("assignment does not satisfy the constraint system: batch record(s) " + which); return ZKGPU_ERR_UNSATISFIED; }
   return ZKGPU_OK; }); }
 void zkgpu_prover_destroy(zkgpu_prover *h) { guarded([&] { delete h; return ZKGPU_OK; }); }
-int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]) { if (!h) return ZKGPU_ERR_ARG; out[0] = h->p->num_variables(); out[1] = h->p->num_inputs(); out[2] = h->p->domain_size(); return ZKGPU_OK; }
-int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; Proof p;
-  if (!h->p->prove((const Fe32 *)z, (const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
-int zkgpu_prover_set_witness(zkgpu_prover *h, const uint8_t *z) { return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; h->p->set_witness((const Fe32 *)z, false); gpu_sync(); return ZKGPU_OK; }); }
-int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; Proof p;
-  if (!h->p->prove_resident((const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
-int zkgpu_prover_timings(zkgpu_prover *h, double out[5]) { if (!h) return ZKGPU_ERR_ARG; out[0] = h->p->last.upload_ms; out[1] = h->p->last.qap_ms; out[2] = h->p->last.msm_ms; out[3] = h->p->last.finish_ms; out[4] = h->p->last.total_ms; return ZKGPU_OK; }
+int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]) {
+  if (!h) return ZKGPU_ERR_ARG;
+  out[0] = h->p->num_variables();
+  out[1] = h->p->num_inputs();
+  out[2] = h->p->domain_size();
+  return ZKGPU_OK;
+}
+int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_prover(h, [&] {
+    if (!h) return ZKGPU_ERR_ARG; Proof p;
+  if (!h->p->prove((const Fe32 *)z, (const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system");
+      return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
+int zkgpu_prover_set_witness(zkgpu_prover *h, const uint8_t *z) {
+  return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; h->p->set_witness((const Fe32 *)z, false); gpu_sync(); return ZKGPU_OK; });
+}
+int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_prover(h, [&] {
+    if (!h) return ZKGPU_ERR_ARG; Proof p;
+  if (!h->p->prove_resident((const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system");
+      return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
+int zkgpu_prover_timings(zkgpu_prover *h, double out[5]) {
+  if (!h) return ZKGPU_ERR_ARG;
+  out[0] = h->p->last.upload_ms;
+  out[1] = h->p->last.qap_ms;
+  out[2] = h->p->last.msm_ms;
+  out[3] = h->p->last.finish_ms;
+  out[4] = h->p->last.total_ms;
+  return ZKGPU_OK;
+}
 int zkgpu_profile_enable(int on) { return guarded([&] { profile_enable(on != 0); return ZKGPU_OK; }); }
-int zkgpu_profile_report(char *buf, size_t cap) { return guarded([&] { std::string r = profile_report(); if (r.size() + 1 > cap) return ZKGPU_ERR_ARG; memcpy(buf, r.c_str(), r.size() + 1); return ZKGPU_OK; }); }
-int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs) { int res = 0; int rc = guarded_host([&] { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(vk_path); Proof p;   // host verifier on the prepared key (cached by the file's size and mtime)
-  if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK; } res = verify_proof(*vk, (const Fe32 *)inputs, n_inputs, p) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
+int zkgpu_profile_report(char *buf, size_t cap) {
+  return guarded([&] { std::string r = profile_report(); if (r.size() + 1 > cap) return ZKGPU_ERR_ARG; memcpy(buf, r.c_str(), r.size() + 1); return ZKGPU_OK;
+      });
+}
+// host verifier on the prepared key (cached by the file's size and mtime)
+int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs) { int res = 0; int rc = guarded_host([&] {
+    std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(vk_path); Proof p;
+  if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK;
+      } res = verify_proof(*vk, (const Fe32 *)inputs, n_inputs, p) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
 /* test entry: the decision of the GPU verifier's schedule (verify_sched.hpp), interpreted on the HOST — no device needed; stats[8] (optional): rounds, slots, products, linear operations, constants, rounds of products / eight-lane sums / one-lane sums */
-int zkgpu_test_verify_schedule(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs, uint32_t *stats) { int res = 0; int rc = guarded_host([&] { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(vk_path); Proof p;
-  if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK; } res = verify_by_schedule_on_host(*vk, (const Fe32 *)inputs, n_inputs, p, stats) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
+int zkgpu_test_verify_schedule(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs, uint32_t *stats) { int res = 0;
+    int rc = guarded_host([&] { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(vk_path); Proof p;
+  if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK;
+      } res = verify_by_schedule_on_host(*vk, (const Fe32 *)inputs, n_inputs, p, stats) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
 // batched verification on the GPU (kernel K9).  proofs_hex: n * 512 characters; inputs: n * n_inputs canonical field elements; ok[i] = 1 accept / 0 reject
 // (a record that is not 512 hex digits of values below q is rejected without reaching the device, like proof_from_hex in zkgpu_verify)
 int zkgpu_verify_batch(const char *vk_path, const char *proofs_hex, const uint8_t *inputs, size_t n_inputs, size_t n, uint8_t *ok) { return guarded([&] {
   if (!vk_path || (!proofs_hex && n) || !ok) return ZKGPU_ERR_ARG;
   struct { std::shared_ptr<BatchVerifier> v; } slot{gpu_verifier_for_path(vk_path)};                                  // caller holds the device mutex (guarded)
-  if (slot.v->num_inputs() != n_inputs) { for (size_t i = 0; i < n; i++) ok[i] = 0; return ZKGPU_OK; }                // strong IC: wrong input count rejects (r1cs_gg_ppzksnark.tcc:584-590)
+  // strong IC: wrong input count rejects (r1cs_gg_ppzksnark.tcc:584-590)
+  if (slot.v->num_inputs() != n_inputs) {
+    for (size_t i = 0; i < n; i++) ok[i] = 0;
+    return ZKGPU_OK;
+  }
   std::vector<Proof> ps(n); std::vector<uint8_t> parsed(n);
-  for (size_t i = 0; i < n; i++) { parsed[i] = strnlen(proofs_hex + 512 * i, 512) == 512 && proof_from_hex(proofs_hex + 512 * i, ps[i]); if (!parsed[i]) memset(&ps[i], 0, sizeof(Proof)); }
+  for (size_t i = 0; i < n; i++) {
+    parsed[i] = strnlen(proofs_hex + 512 * i, 512) == 512 && proof_from_hex(proofs_hex + 512 * i, ps[i]);
+    if (!parsed[i]) memset(&ps[i], 0, sizeof(Proof));
+  }
   slot.v->verify(ps.data(), (const Fe32 *)inputs, n, ok);
-  for (size_t i = 0; i < n; i++) { if (!parsed[i]) ok[i] = 0; else if (ok[i] == 2) ok[i] = verify_proof(*vk_for_path(vk_path), (const Fe32 *)inputs + i * n_inputs, n_inputs, ps[i]) ? 1 : 0; }   // 2: input accumulator at infinity, the host verifier decides (pairing.cuh)
+  // 2: input accumulator at infinity, the host verifier decides (pairing.cuh)
+  for (size_t i = 0; i < n; i++) {
+    if (!parsed[i]) ok[i] = 0;
+    else if (ok[i] == 2) ok[i] = verify_proof(*vk_for_path(vk_path), (const Fe32 *)inputs + i * n_inputs, n_inputs, ps[i]) ? 1 : 0;
+  }
   return ZKGPU_OK; }); }
-// ---- verifyBatch: the optional batch entry of include/zk_batch.h ---------------------------------------------------
-// go-ethereum checks every ZK transaction twice, once in the pool and once in the block (core/tx_pool.go:612-645, core/state_processor.go:106-163), one cgo call
-// and one key load per proof.  A block's worth of proofs in ONE call is what the GPU verifier is for (kernel K9: one workgroup per proof interpreting the operation
-// schedule of verify_sched.hpp on 29-bit limbs — 2.1 ms per launch up to 256 proofs, 31,000 proofs/s at 64, 124,000 at 512): the records are grouped by circuit kind and
+// ---- verifyBatch: the optional batch entry of include/zk_batch.h --------------------------------------------------- go-ethereum checks
+// every ZK transaction twice, once in the pool and once in the block (core/tx_pool.go:612-645, core/state_processor.go:106-163), one cgo call and one key load
+// per proof. A block's worth of proofs in ONE call is what the GPU verifier is for (kernel K9: one workgroup per proof interpreting the operation schedule of
+// verify_sched.hpp on 29-bit limbs — 2.1 ms per launch up to 256 proofs, 31,000 proofs/s at 64, 124,000 at 512): the records are grouped by circuit kind and
 // every group goes through verify_group above, exactly like the kind's verifyXproof symbol.
 int verifyBatch(const zk_verify_item *items, int n, unsigned char *ok) {
   if (n < 0 || (n && (!items || !ok))) return -1;
@@ -417,12 +869,21 @@ int verifyBatch(const zk_verify_item *items, int n, unsigned char *ok) {
     for (int i = 0; i < n; i++) { ok[i] = 0; if (items[i].kind >= 0 && items[i].kind <= 3) idx[items[i].kind].push_back(i); }
     for (int k = 0; k < 4; k++) { if (idx[k].empty()) continue; const CircuitKind kind = (CircuitKind)k; const size_t m = idx[k].size();
       std::vector<Proof> ps(m); std::vector<uint8_t> parsed(m), res(m, 0); std::vector<Fe32> inputs; size_t ni = 0;
-      for (size_t j = 0; j < m; j++) { const zk_verify_item &it = items[idx[k][j]]; parsed[j] = it.proof && strnlen(it.proof, 512) == 512 && proof_from_hex(it.proof, ps[j]); if (!parsed[j]) memset(&ps[j], 0, sizeof(Proof));
+      for (size_t j = 0; j < m; j++) {
+        const zk_verify_item &it = items[idx[k][j]];
+        parsed[j] = it.proof && strnlen(it.proof, 512) == 512 && proof_from_hex(it.proof, ps[j]);
+        if (!parsed[j]) memset(&ps[j], 0, sizeof(Proof));
         std::vector<Fe32> in = pack_public_bits(public_bits(kind, it.args, it.value_s)); ni = in.size(); inputs.insert(inputs.end(), in.begin(), in.end()); }
       verify_group(kind, ps.data(), parsed.data(), inputs.data(), ni, m, res.data());
       for (size_t j = 0; j < m; j++) { ok[idx[k][j]] = res[j]; accepted += res[j]; } }
     return accepted;
-  } catch (const std::exception &e) { zkgpu_set_error(e.what()); fprintf(stderr, "libzkgpu: verifyBatch: %s\n", e.what()); for (int i = 0; i < n; i++) ok[i] = 0; return -1; }
+  }
+  catch (const std::exception &e) {
+    zkgpu_set_error(e.what());
+    fprintf(stderr, "libzkgpu: verifyBatch: %s\n", e.what());
+    for (int i = 0; i < n; i++) ok[i] = 0;
+    return -1;
+  }
   catch (...) { for (int i = 0; i < n; i++) ok[i] = 0; return -1; }
 }
 
@@ -432,12 +893,21 @@ char *genCMTS(uint64_t v, char *a, char *b, char *c) { return zkgpu_abi_genCMTS(
 char *computePRF(char *a, char *b) { return zkgpu_abi_computePRF(a, b); }
 char *computeCRH(char *a, char *b) { return zkgpu_abi_computeCRH(a, b); }
 char *genRoot(char *a, int n) { return zkgpu_abi_genRoot(a, n); }
-char *genMintproof(uint64_t a, uint64_t b, char *c, char *d, char *e, char *f, char *g, char *h, uint64_t i, char *j) { return zkgpu_abi_genMintproof(a, b, c, d, e, f, g, h, i, j); }
+char *genMintproof(uint64_t a, uint64_t b, char *c, char *d, char *e, char *f, char *g, char *h, uint64_t i, char *j) {
+  return zkgpu_abi_genMintproof(a, b, c, d, e, f, g, h, i, j);
+}
 bool verifyMintproof(char *a, char *b, char *c, char *d, uint64_t e) { return zkgpu_abi_verifyMintproof(a, b, c, d, e); }
-char *genRedeemproof(uint64_t a, uint64_t b, char *c, char *d, char *e, char *f, char *g, char *h, uint64_t i, char *j) { return zkgpu_abi_genRedeemproof(a, b, c, d, e, f, g, h, i, j); }
+char *genRedeemproof(uint64_t a, uint64_t b, char *c, char *d, char *e, char *f, char *g, char *h, uint64_t i, char *j) {
+  return zkgpu_abi_genRedeemproof(a, b, c, d, e, f, g, h, i, j);
+}
 bool verifyRedeemproof(char *a, char *b, char *c, char *d, uint64_t e) { return zkgpu_abi_verifyRedeemproof(a, b, c, d, e); }
-char *genSendproof(uint64_t a, char *b, char *c, char *d, char *e, char *f, uint64_t g, char *h, uint64_t i, char *j, char *k, char *l, char *m, char *n) { return zkgpu_abi_genSendproof(a, b, c, d, e, f, g, h, i, j, k, l, m, n); }
+char *genSendproof(uint64_t a, char *b, char *c, char *d, char *e, char *f, uint64_t g, char *h, uint64_t i, char *j, char *k, char *l, char *m, char *n) {
+  return zkgpu_abi_genSendproof(a, b, c, d, e, f, g, h, i, j, k, l, m, n);
+}
 bool verifySendproof(char *a, char *b, char *c, char *d, char *e) { return zkgpu_abi_verifySendproof(a, b, c, d, e); }
-char *genDepositproof(uint64_t a, uint64_t b, char *c, char *d, char *e, char *f, char *g, char *h, char *i, char *j, uint64_t k, char *l, char *m, char *n, char *o, int p, char *q, char *r) { return zkgpu_abi_genDepositproof(a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p, q, r); }
+char *genDepositproof(uint64_t a, uint64_t b, char *c, char *d, char *e, char *f, char *g, char *h, char *i, char *j, uint64_t k, char *l, char *m, char *n,
+    char *o, int p, char *q, char *r) {
+  return zkgpu_abi_genDepositproof(a, b, c, d, e, f, g, h, i, j, k, l, m, n, o, p, q, r);
+}
 bool verifyDepositproof(char *a, char *b, char *c, char *d, char *e, char *f, char *g) { return zkgpu_abi_verifyDepositproof(a, b, c, d, e, f, g); }
 }  // extern "C"

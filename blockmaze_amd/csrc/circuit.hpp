@@ -51,11 +51,15 @@ inline LCArray to_lcs(const VarArray &v) { LCArray r; r.reserve(v.size()); for (
 
 class Board {
  public:
-  explicit Board(bool emit_constraints) : emit(emit_constraints) { tag.push_back(1); wide.push_back(HFr::one()); for (int m = 0; m < 3; m++) cs.rowptr[m].push_back(0); }
+  explicit Board(bool emit_constraints) : emit(emit_constraints) {
+    tag.push_back(1);
+    wide.push_back(HFr::one());
+    for (int m = 0; m < 3; m++) cs.rowptr[m].push_back(0);
+  }
   bool emit;                                   // false: witness-only pass (allocation still happens, constraints are skipped)
-  // The assignment, variable 0 = ONE.  97 % of a BlockMaze witness is 0 or 1 (bits of SHA-256 states), so a value is ONE BYTE — tag 0 / 1 — unless it is something
-  // else (tag 2, value in wide[]): a SHA round writes ~900 bytes instead of 28 KB of field elements, and the prover takes tags + wide values as they are
-  // (Prover::set_witness_tagged: no scan of a 7 MB vector to find the zeros and ones again).
+  // The assignment, variable 0 = ONE. 97 % of a BlockMaze witness is 0 or 1 (bits of SHA-256 states), so a value is ONE BYTE — tag 0 / 1 — unless it is
+  // something else (tag 2, value in wide[]): a SHA round writes ~900 bytes instead of 28 KB of field elements, and the prover takes tags + wide values as they
+  // are (Prover::set_witness_tagged: no scan of a 7 MB vector to find the zeros and ones again).
   std::vector<uint8_t> tag; std::vector<HFr> wide;
   R1csHost cs;
   Var alloc() { tag.push_back(0); wide.push_back(HFr::zero()); return (Var)(tag.size() - 1); }
@@ -63,21 +67,42 @@ class Board {
   void set_input_sizes(size_t n) { cs.n_inputs = n; }
   size_t num_variables() const { return tag.size() - 1; }
   void constraint(const LC &a, const LC &b, const LC &c);
-  // tag 6 (round 4): a SMALL integer (below 2^64) kept as it is in wide[v].l[0] — the packed words and sums of the SHA-256 gadgets, ~850 per compression: the native
-  // witness path used to pay a Montgomery product for each of them on the calling thread; now whoever needs the field element converts (get / eval here, rarely; the
-  // prover's hand-over, on its four scan threads).  TAG_WIDE and TAG_SMALL both have bit 1 set ("neither 0 nor 1") and bit 0 clear.
+  // tag 6 (round 4): a SMALL integer (below 2^64) kept as it is in wide[v].l[0] — the packed words and sums of the SHA-256 gadgets, ~850 per compression: the
+  // native witness path used to pay a Montgomery product for each of them on the calling thread; now whoever needs the field element converts (get / eval here,
+  // rarely; the prover's hand-over, on its four scan threads). TAG_WIDE and TAG_SMALL both have bit 1 set ("neither 0 nor 1") and bit 0 clear.
   static constexpr uint8_t TAG_WIDE = 2, TAG_SMALL = 6;
-  HFr get(Var v) const { const uint8_t t = tag[v]; return t == TAG_WIDE ? wide[v] : t == TAG_SMALL ? HFr::from_u64(wide[v].l[0]) : t ? HFr::one() : HFr::zero(); }
+  HFr get(Var v) const {
+    const uint8_t t = tag[v];
+    return t == TAG_WIDE ? wide[v] : t == TAG_SMALL ? HFr::from_u64(wide[v].l[0]) : t ? HFr::one() : HFr::zero();
+  }
   void set(Var v, const HFr &x) { if (x.is_zero()) tag[v] = 0; else if (x == HFr::one()) tag[v] = 1; else { wide[v] = x; tag[v] = TAG_WIDE; } }
   void set_small(Var v, uint64_t x) { if (x < 2) tag[v] = (uint8_t)x; else { wide[v].l[0] = x; tag[v] = TAG_SMALL; } }
   // bit i of `bits` -> variable first + i, i < count <= 64: the variables of a gadget's bit array are consecutive, eight of them are one 8-byte store
   void set_bits_run(Var first, uint64_t bits, size_t count) {
     uint8_t *t = tag.data() + first; size_t i = 0;
-    for (; i + 8 <= count; i += 8) { const uint64_t x = (bits >> i) & 0xff, sel = (x * 0x0101010101010101ull) & 0x8040201008040201ull, spread = ((sel + 0x7f7f7f7f7f7f7f7full) >> 7) & 0x0101010101010101ull; memcpy(t + i, &spread, 8); }   // byte j of the store = bit j of x
+    // byte j of the store = bit j of x
+    for (; i + 8 <= count; i += 8) {
+      const uint64_t x = (bits >> i) & 0xff, sel = (x * 0x0101010101010101ull) & 0x8040201008040201ull,
+          spread = ((sel + 0x7f7f7f7f7f7f7f7full) >> 7) & 0x0101010101010101ull;
+      memcpy(t + i, &spread, 8);
+    }
     for (; i < count; i++) t[i] = (uint8_t)((bits >> i) & 1);
   }
-  HFr eval(const LC &lc) const { if (lc.t.size() == 1 && lc.t[0].one) return get(lc.t[0].v); HFr s = HFr::zero(); for (const Term &x : lc.t) { const uint8_t t = tag[x.v]; if (t == 0) continue; s = s + (x.one ? get(x.v) : t == 1 ? x.c : x.c * get(x.v)); } return s; }
-  bool eval_bit(const LC &lc) const { if (lc.t.size() == 1 && lc.t[0].one) return tag[lc.t[0].v] != 0; if (lc.t.empty()) return false; return !eval(lc).is_zero(); }
+  HFr eval(const LC &lc) const {
+    if (lc.t.size() == 1 && lc.t[0].one) return get(lc.t[0].v);
+    HFr s = HFr::zero();
+    for (const Term &x : lc.t) {
+      const uint8_t t = tag[x.v];
+      if (t == 0) continue;
+      s = s + (x.one ? get(x.v) : t == 1 ? x.c : x.c * get(x.v));
+    }
+    return s;
+  }
+  bool eval_bit(const LC &lc) const {
+    if (lc.t.size() == 1 && lc.t[0].one) return tag[lc.t[0].v] != 0;
+    if (lc.t.empty()) return false;
+    return !eval(lc).is_zero();
+  }
   void set_bit(Var v, bool b) { if (v) tag[v] = (uint8_t)b; }   // writes to ONE are dropped (see LessCmp)
   bool bit(Var v) const { return tag[v] != 0; }
   void finish() { cs.n_vars = num_variables(); cs.n_cons = cs.rowptr[0].size() - 1; }
@@ -98,7 +123,8 @@ struct Packing {      // packed = sum bits[i] 2^i
   void witness_from_bits() { b.set(packed_var, pack_bits_value(b, bits)); }
 };
 
-struct Digest { Board &b; VarArray bits; Digest(Board &b, size_t n) : b(b), bits(b.alloc_array(n)) {} void constraints() { for (Var v : bits) boolean_constraint(b, LC(v)); }
+struct Digest { Board &b; VarArray bits; Digest(Board &b, size_t n) : b(b), bits(b.alloc_array(n)) {} void constraints() {
+    for (Var v : bits) boolean_constraint(b, LC(v)); }
   void fill(const std::vector<bool> &v) { for (size_t i = 0; i < bits.size(); i++) b.set_bit(bits[i], v[i]); }
   std::vector<bool> get() const { std::vector<bool> r(bits.size()); for (size_t i = 0; i < bits.size(); i++) r[i] = b.bit(bits[i]); return r; } };
 
@@ -111,9 +137,10 @@ struct Sha256Compression {
 };
 LCArray sha256_default_iv();          // sha256_components.tcc:38-56
 
-// Witness generation is 9 (send) to 18 (deposit) SHA-256 compression gadgets of 24,792 variables each, most of them independent of one another: run_parallel hands the
-// tasks of one wave to a small process-wide pool of helper threads (the caller works too) and returns when all of them are done.  Tasks of one call must write disjoint
-// variables and read nothing another task of the same call writes — the circuits below order their waves so that this holds and the result equals the sequential order's.
+// Witness generation is 9 (send) to 18 (deposit) SHA-256 compression gadgets of 24,792 variables each, most of them independent of one another: run_parallel
+// hands the tasks of one wave to a small process-wide pool of helper threads (the caller works too) and returns when all of them are done. Tasks of one call
+// must write disjoint variables and read nothing another task of the same call writes — the circuits below order their waves so that this holds and the result
+// equals the sequential order's.
 void run_parallel(std::vector<std::function<void()>> tasks);
 
 }  }  // namespace zk::circuit

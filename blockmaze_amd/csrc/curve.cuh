@@ -44,7 +44,12 @@ struct XYZZ {
     if (p.is_inf()) return;
     if (is_inf()) { X = p.x; Y = p.y; ZZ = F::one(); ZZZ = F::one(); return; }
     F U2 = p.x * ZZ, S2 = p.y * ZZZ, Pv = U2 - X, Rv = S2 - Y;
-    if (Pv.is_zero()) { if (Rv.is_zero()) *this = dbl_affine_inl(p); else *this = inf(); return; }   // (inlined: an out-of-line call takes p by address, which pins it in scratch memory for every iteration of the caller's loop)
+    // (inlined: an out-of-line call takes p by address, which pins it in scratch memory for every iteration of the caller's loop)
+    if (Pv.is_zero()) {
+      if (Rv.is_zero()) *this = dbl_affine_inl(p);
+      else *this = inf();
+      return;
+    }
     F PP = Pv.sqr(), PPP = Pv * PP, Q = X * PP;
     F X3 = Rv.sqr() - PPP - Q.dbl();
     Y = Rv * (Q - X3) - Y * PPP; X = X3; ZZ = ZZ * PP; ZZZ = ZZZ * PPP;
@@ -88,9 +93,13 @@ template <class P> __device__ __forceinline__ Fp<P> lane_sel(bool c, const Fp<P>
   return r;
 }
 __device__ __forceinline__ Fq2 lane_sel(bool c, const Fq2 &a, const Fq2 &b) { return {lane_sel(c, a.c0, b.c0), lane_sel(c, a.c1, b.c1)}; }
-template <class F> __device__ __forceinline__ F quad_sel(int k, const F &a, const F &b, const F &c, const F &d) { return lane_sel(k < 2, lane_sel(k == 0, a, b), lane_sel(k == 2, c, d)); }
+template <class F> __device__ __forceinline__ F quad_sel(int k, const F &a, const F &b, const F &c, const F &d) {
+  return lane_sel(k < 2, lane_sel(k == 0, a, b), lane_sel(k == 2, c, d));
+}
 
-template <class F> __device__ __forceinline__ XYZZ<F> xyzz_sel(bool c, const XYZZ<F> &a, const XYZZ<F> &b) { return {lane_sel(c, a.X, b.X), lane_sel(c, a.Y, b.Y), lane_sel(c, a.ZZ, b.ZZ), lane_sel(c, a.ZZZ, b.ZZZ)}; }
+template <class F> __device__ __forceinline__ XYZZ<F> xyzz_sel(bool c, const XYZZ<F> &a, const XYZZ<F> &b) {
+  return {lane_sel(c, a.X, b.X), lane_sel(c, a.Y, b.Y), lane_sel(c, a.ZZ, b.ZZ), lane_sel(c, a.ZZZ, b.ZZZ)};
+}
 // The special cases (an operand at infinity, equal or opposite operands) are resolved with limb-wise selects AFTER the general formulas have run on
 // whatever the inputs were: an early `return a` / `return b` makes the compiler park both points in scratch memory and select between the two copies
 // by address, which put a memory round trip into every addition of the dependent chain.
@@ -117,10 +126,14 @@ template <class F> __device__ __forceinline__ XYZZ<F> quad_add(const XYZZ<F> &a,
   F PPP = quad_pick<0>(m), Q = quad_pick<1>(m); XYZZ<F> r; r.ZZ = quad_pick<2>(m); r.X = RR - PPP - Q.dbl();
   m = quad_sel(k, Rv, S1, ZZZ12, ZZZ12) * lane_sel(k == 0, Q - r.X, PPP);
   r.Y = quad_pick<0>(m) - quad_pick<1>(m); r.ZZZ = quad_pick<2>(m);
-  if (Pv.is_zero() && !a_inf && !b_inf) { if (Rv.is_zero()) r = quad_dbl_inl(a, k); else r = XYZZ<F>::inf(); }      // b = +-a: rare, uniform within the quad; inlined so that `a` never has its address taken
+  // b = +-a: rare, uniform within the quad; inlined so that `a` never has its address taken
+  if (Pv.is_zero() && !a_inf && !b_inf) {
+    if (Rv.is_zero()) r = quad_dbl_inl(a, k);
+    else r = XYZZ<F>::inf();
+  }
   return xyzz_sel(b_inf, a, xyzz_sel(a_inf, b, r));
 }
-// madd-2008-s (affine operand):  round 1: U2 = X2*ZZ1 | S2 = Y2*ZZZ1      round 2: P^2 | R^2      round 3: P*PP | X1*PP | ZZ1*PP      round 4: R*(Q - X3) | Y1*PPP | ZZZ1*PPP
+// madd-2008-s (affine operand): round 1: U2 = X2*ZZ1 | S2 = Y2*ZZZ1 round 2: P^2 | R^2 round 3: P*PP | X1*PP | ZZ1*PP round 4: R*(Q - X3) | Y1*PPP | ZZZ1*PPP
 template <class F> __device__ __forceinline__ XYZZ<F> quad_madd(const XYZZ<F> &a, const Affine<F> &p, int k) {
   const bool a_inf = a.is_inf(), p_inf = p.is_inf();
   F m = lane_sel(k == 0, p.x, p.y) * lane_sel(k == 0, a.ZZ, a.ZZZ);

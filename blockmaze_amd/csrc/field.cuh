@@ -33,25 +33,40 @@ struct Fp {
   ZK_HD bool operator==(const Fp &b) const { uint32_t o = 0; for (int i = 0; i < 8; i++) o |= l[i] ^ b.l[i]; return o == 0; }
   ZK_HD bool operator!=(const Fp &b) const { return !(*this == b); }
 
-  // Device code: every carry chain is one v_addc / v_subb per limb (field_mul_gfx950.inc, generated); hipcc lowers the limb loops of the host versions below to 64-bit
-  // adds and sign extensions, about five instructions per limb (measured in the H-query accumulation: 1,100 of 4,215 instructions per mixed addition were such code).
+  // Device code: every carry chain is one v_addc / v_subb per limb (field_mul_gfx950.inc, generated); hipcc lowers the limb loops of the host versions below to
+  // 64-bit adds and sign extensions, about five instructions per limb (measured in the H-query accumulation: 1,100 of 4,215 instructions per mixed addition
+  // were such code).
 #if defined(__HIP_DEVICE_COMPILE__)
 #include "field_mul_gfx950.inc"   // mul_raw / sqr_raw / add_raw / sub_fix / cond_sub / cond_neg / neg_masked (gen_field_mul.py)
   static __device__ __forceinline__ Fp reduce_once(const Fp &a) { Fp r = a; cond_sub<1>(r); return r; }          // r = a - p if a >= p (a < 2p)
   friend __device__ __forceinline__ Fp operator+(const Fp &a, const Fp &b) { Fp s = a; add_raw(s, b); cond_sub<1>(s); return s; }   // no carry out: 2p < 2^256
   friend __device__ __forceinline__ Fp operator-(const Fp &a, const Fp &b) { Fp d = a; sub_fix<1>(d, b); return d; }
   friend __device__ __forceinline__ Fp operator*(const Fp &a, const Fp &b) { Fp r = mul_raw(a, b); cond_sub<1>(r); return r; }
-  __device__ __forceinline__ Fp sqr() const { Fp r = sqr_raw(*this); cond_sub<1>(r); return r; }                   // dedicated squaring: 36 limb products instead of 64 (fp.tcc:594 squared())
-  // ---- the lazy domain: values in [0, 2p) ----------------------------------------------------------------------------------------------------------------------
-  // Both moduli leave two spare bits (p < 2^254).  A Montgomery product of a, b < 2p is (ab + mp)/R < (4p^2 + Rp)/R < 2p because R = 2^256 > 4p, so products need no final
-  // subtraction when they feed further products; a difference stays in [0, 2p) when 2p is added after a borrow.  normalize() brings a value back to [0, p).  The 29-bit
-  // kernels of msm.cuh hand their results over in this domain (k_hacc_combine29); round 3's first version of the H accumulation lived in it (tools/mul_probe.hip compares
+  // dedicated squaring: 36 limb products instead of 64 (fp.tcc:594 squared())
+  __device__ __forceinline__ Fp sqr() const {
+    Fp r = sqr_raw(*this);
+    cond_sub<1>(r);
+    return r;
+  }
+  // ---- the lazy domain: values in [0, 2p)
+  // ---------------------------------------------------------------------------------------------------------------------- Both moduli leave two spare bits (p
+  // < 2^254). A Montgomery product of a, b < 2p is (ab + mp)/R < (4p^2 + Rp)/R < 2p because R = 2^256 > 4p, so products need no final subtraction when they
+  // feed further products; a difference stays in [0, 2p) when 2p is added after a borrow. normalize() brings a value back to [0, p). The 29-bit kernels of
+  // msm.cuh hand their results over in this domain (k_hacc_combine29); round 3's first version of the H accumulation lived in it (tools/mul_probe.hip compares
   // the two product forms).
   static __device__ __forceinline__ Fp mul_lazy(const Fp &a, const Fp &b) { return mul_raw(a, b); }
   static __device__ __forceinline__ Fp sqr_lazy(const Fp &a) { return sqr_raw(a); }
   static __device__ __forceinline__ Fp sub_lazy(const Fp &a, const Fp &b) { Fp d = a; sub_fix<2>(d, b); return d; }
   __device__ __forceinline__ Fp normalize() const { return reduce_once(*this); }
-  __device__ __forceinline__ bool is_zero_lazy() const { uint32_t o = 0, q = 0; for (int i = 0; i < 8; i++) { o |= l[i]; q |= l[i] ^ P::MOD[i]; } return o == 0 || q == 0; }   // 0 or p
+  // 0 or p
+  __device__ __forceinline__ bool is_zero_lazy() const {
+    uint32_t o = 0, q = 0;
+    for (int i = 0; i < 8; i++) {
+      o |= l[i];
+      q |= l[i] ^ P::MOD[i];
+    }
+    return o == 0 || q == 0;
+  }
 #else
   // r = a - MOD if a >= MOD (a < 2*MOD)
   static ZK_HD Fp reduce_once(const Fp &a) {
@@ -73,7 +88,8 @@ struct Fp {
     for (int i = 0; i < 8; i++) { c += (uint64_t)d.l[i] + (P::MOD[i] & mask); d.l[i] = (uint32_t)c; c >>= 32; }
     return d;
   }
-  // Montgomery product a*b/R mod p, host reference of the device's column product: coarsely integrated operand scanning, one row of a*b_i followed by one reduction row m*p.
+  // Montgomery product a*b/R mod p, host reference of the device's column product: coarsely integrated operand scanning, one row of a*b_i followed by one
+  // reduction row m*p.
   friend ZK_HD Fp operator*(const Fp &a, const Fp &b) {
     uint32_t t[8];
     for (int j = 0; j < 8; j++) t[j] = 0;
@@ -100,7 +116,11 @@ struct Fp {
   ZK_HD Fp normalize() const { return *this; }
   ZK_HD bool is_zero_lazy() const { return is_zero(); }
 #endif
-  ZK_HD Fp neg() const { return zero() - *this; }   // 0 - 0 borrows nothing, so zero stays zero; (a `cond ? *this : ...` here makes the compiler select between two memory copies and pins the operand in scratch)
+  // 0 - 0 borrows nothing, so zero stays zero; (a `cond ? *this : ...` here makes the compiler select between two memory copies and pins the operand in
+  // scratch)
+  ZK_HD Fp neg() const {
+    return zero() - *this;
+  }
   ZK_HD Fp dbl() const { return *this + *this; }
 
   ZK_HD Fp to_mont() const { return (*this) * r2(); }              // canonical -> Montgomery
@@ -146,7 +166,11 @@ struct Fq2 {
   // complex squaring: 2 base-field products
   ZK_HD Fq2 sqr() const { Fq ab = c0 * c1; return {(c0 + c1) * (c0 - c1), ab.dbl()}; }
   ZK_HD Fq2 mul_fq(const Fq &k) const { return {c0 * k, c1 * k}; }
-  ZK_HD Fq2 mul_xi() const { Fq a = c0.dbl().dbl().dbl() + c0, b = c1.dbl().dbl().dbl() + c1; return {a - c1, b + c0}; }   // times xi = 9 + u, the Fq6 non-residue (alt_bn128_init.cpp:158)
+  // times xi = 9 + u, the Fq6 non-residue (alt_bn128_init.cpp:158)
+  ZK_HD Fq2 mul_xi() const {
+    Fq a = c0.dbl().dbl().dbl() + c0, b = c1.dbl().dbl().dbl() + c1;
+    return {a - c1, b + c0};
+  }
   ZK_HD Fq2 frob(unsigned p) const { return (p & 1) ? Fq2{c0, c1.neg()} : *this; }                                          // x -> x^(q^p)
   ZK_HD Fq2 inv() const { Fq t = (c0.sqr() + c1.sqr()).inv(); return {c0 * t, (c1 * t).neg()}; }
 };

@@ -13,51 +13,73 @@
 #include "ntt.cuh"
 #include "ecntt.cuh"
 
-// Every prover runs five HIP streams at once (the critical chain + four witness MSMs).  The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and
-// two streams sharing a queue run one after the other (measured: the B1 MSM then ends at 2.7 ms instead of 1.4 ms).  The runtime reads the variable when its first API
-// call initialises it, so it has to be in the environment before ANY HIP call of the process: a load-time constructor with the earliest user priority does that —
-// it runs when the dynamic loader maps libzkgpu.so (program start for a cgo binary linked against libzk_*.so), before this library's own code-object registration
-// and long before gpu_available().  A host that wants another value exports the variable itself (it is not overwritten).  A host that dlopen()s the library late —
-// after it has started threads that call getenv, or after its own first HIP call — must export GPU_MAX_HW_QUEUES itself before that call: setenv is not thread safe and
-// comes too late then.
+// Every prover runs five HIP streams at once (the critical chain + four witness MSMs). The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default
+// 4), and two streams sharing a queue run one after the other (measured: the B1 MSM then ends at 2.7 ms instead of 1.4 ms). The runtime reads the variable when
+// its first API call initialises it, so it has to be in the environment before ANY HIP call of the process: a load-time constructor with the earliest user
+// priority does that — it runs when the dynamic loader maps libzkgpu.so (program start for a cgo binary linked against libzk_*.so), before this library's own
+// code-object registration and long before gpu_available(). A host that wants another value exports the variable itself (it is not overwritten). A host that
+// dlopen()s the library late — after it has started threads that call getenv, or after its own first HIP call — must export GPU_MAX_HW_QUEUES itself before
+// that call: setenv is not thread safe and comes too late then.
 __attribute__((constructor(101))) static void zkgpu_load_time_environment() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 namespace zk {
 
-// Lanes: independent sets of streams (one main + four auxiliary) so that several provers can have a proof in flight at the same time; a thread works on the lane it
-// selected with LaneScope (lane 0 unless told otherwise).  Contexts are created on first use and live for the life of the process.
-// (lanes beyond the hardware queues share queues)  Sized for 8 devices x 4 circuit kinds x 7 pool members with a lane each; a single device never binds more than 31.
+// Lanes: independent sets of streams (one main + four auxiliary) so that several provers can have a proof in flight at the same time; a thread works on the
+// lane it selected with LaneScope (lane 0 unless told otherwise). Contexts are created on first use and live for the life of the process. (lanes beyond the
+// hardware queues share queues) Sized for 8 devices x 4 circuit kinds x 7 pool members with a lane each; a single device never binds more than 31.
 constexpr int MAX_LANES_PER_DEVICE = 31, MAX_LANES = 1 + 8 * 28;
 static uint8_t g_lane_claimed[MAX_LANES];   // a lane that was ever lent keeps its device slot (guarded by g_lane_mutex)
-static std::atomic<GpuContext *> g_lanes[MAX_LANES]; static std::atomic<int> g_lane_slot[MAX_LANES]; static std::mutex g_lane_mutex; static thread_local int t_lane = 0; static std::atomic<unsigned> g_next_lane{0};
+static std::atomic<GpuContext *> g_lanes[MAX_LANES];
+static std::atomic<int> g_lane_slot[MAX_LANES];
+static std::mutex g_lane_mutex;
+static thread_local int t_lane = 0;
+static std::atomic<unsigned> g_next_lane{0};
 std::vector<int> parse_device_list(const char *spec, int n_visible, int fallback_device) {
   std::vector<int> out; if (n_visible <= 0) return out;
   if (!spec || !*spec) { out.push_back(((fallback_device % n_visible) + n_visible) % n_visible); return out; }
   if (!strcmp(spec, "all")) { for (int i = 0; i < n_visible; i++) out.push_back(i); return out; }
-  for (const char *p = spec; *p;) { char *end = nullptr; long v = strtol(p, &end, 10); if (end == p) break; if (v >= 0 && v < n_visible) { bool dup = false; for (int x : out) dup |= x == (int)v; if (!dup) out.push_back((int)v); } p = *end == ',' ? end + 1 : end; if (*end && *end != ',') break; }
+  for (const char *p = spec; *p;) {
+    char *end = nullptr;
+    long v = strtol(p, &end, 10);
+    if (end == p) break;
+    if (v >= 0 && v < n_visible) {
+      bool dup = false;
+      for (int x : out) dup |= x == (int)v;
+      if (!dup) out.push_back((int)v);
+    }
+    p = *end == ',' ? end + 1 : end;
+    if (*end && *end != ',') break;
+  }
   if (out.empty()) out.push_back(0);
   return out; }
-static const std::vector<int> &device_list() { static const std::vector<int> l = [] { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) n = 0; const char *e = getenv("ZK_DEVICE"); if (!e) e = getenv("LOCAL_RANK");
+static const std::vector<int> &device_list() {
+  static const std::vector<int> l = [] {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    const char *e = getenv("ZK_DEVICE");
+    if (!e) e = getenv("LOCAL_RANK");
     return parse_device_list(getenv("ZK_DEVICES"), n, e ? atoi(e) : 0); }(); return l; }
 int gpu_device_slots() { return (int)device_list().size(); }
 int gpu_slot_of_lane(int lane) { return lane < 0 || lane >= MAX_LANES ? 0 : g_lane_slot[lane].load(); }
 GpuContext &gpu() {
   GpuContext *c = g_lanes[t_lane].load(std::memory_order_acquire);
   if (!c) { std::lock_guard<std::mutex> lk(g_lane_mutex); c = g_lanes[t_lane].load(std::memory_order_acquire);
-    if (!c) { const std::vector<int> &l = device_list(); if (l.empty()) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
+    if (!c) {
+      const std::vector<int> &l = device_list();
+      if (l.empty()) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
       c = new GpuContext(l[(size_t)g_lane_slot[t_lane].load() % l.size()]); g_lanes[t_lane].store(c, std::memory_order_release); } }
   hipSetDevice(c->device); return *c;
 }
-// Lanes 1.. are lent to provers; lane 0 (device slot 0) stays with everything else.  A lane belongs to the device slot of its first user for good (its streams live on
-// that device).  A lane is lent to ONE prover at a time and handed back by its destructor (gpu_lane_release): a process that reloads keys or clones provers for ever
-// keeps cycling through the same stream sets instead of running out of them.
-// Every device slot may bind at most lane_quota(D) lanes, so that D devices can never starve one another whatever the order in which their pools are built (the cgo
-// layer builds them lazily, one device at a time, every pool member of every circuit kind taking a lane); past its quota a slot shares its least-used lane —
-// provers on one lane share its streams: still correct, merely serialised.
+// Lanes 1.. are lent to provers; lane 0 (device slot 0) stays with everything else. A lane belongs to the device slot of its first user for good (its streams
+// live on that device). A lane is lent to ONE prover at a time and handed back by its destructor (gpu_lane_release): a process that reloads keys or clones
+// provers for ever keeps cycling through the same stream sets instead of running out of them.
+// Every device slot may bind at most lane_quota(D) lanes, so that D devices can never starve one another whatever the order in which their pools are built (the
+// cgo layer builds them lazily, one device at a time, every pool member of every circuit kind taking a lane); past its quota a slot shares its least-used lane
+// — provers on one lane share its streams: still correct, merely serialised.
 static int g_lane_users[MAX_LANES];
 int lane_quota(int n_slots) { const int q = (MAX_LANES - 1) / std::max(1, n_slots); return std::max(1, std::min(q, MAX_LANES_PER_DEVICE)); }
-// The planner, free of HIP state so that a CPU test can drive it (zkgpu_test_lane_plan): users[l] = provers holding lane l, slot[l] = its device slot, bound[l] = whether
-// the lane belongs to a slot yet.  Returns the lane to use (and binds / counts it), or -1.
+// The planner, free of HIP state so that a CPU test can drive it (zkgpu_test_lane_plan): users[l] = provers holding lane l, slot[l] = its device slot, bound[l]
+// = whether the lane belongs to a slot yet. Returns the lane to use (and binds / counts it), or -1.
 int lane_plan_pick(int *users, int *slot, uint8_t *bound, int device_slot, int n_slots) {
   int mine = 0;
   for (int lane = 1; lane < MAX_LANES; lane++) if (bound[lane] && slot[lane] == device_slot) mine++;
@@ -75,24 +97,40 @@ int lane_plan_pick(int *users, int *slot, uint8_t *bound, int device_slot, int n
 int lane_plan_simulate(int n_slots, int kinds, int per_kind, int *out_lanes_per_slot) {
   if (n_slots < 1 || n_slots > 64) return -1;
   std::vector<int> users(MAX_LANES, 0), slot(MAX_LANES, 0); std::vector<uint8_t> bound(MAX_LANES, 0); int worst = 0;
-  for (int d = 0; d < n_slots; d++)                                                       // lazily, one device at a time: the order that used to starve the later devices
-    for (int k = 0; k < kinds * per_kind; k++) { const int lane = lane_plan_pick(users.data(), slot.data(), bound.data(), d, n_slots); if (lane < 0) return -1; worst = std::max(worst, users[lane]); }
-  for (int d = 0; d < n_slots; d++) { int c = 0; for (int lane = 1; lane < MAX_LANES; lane++) c += bound[lane] && slot[lane] == d; if (out_lanes_per_slot) out_lanes_per_slot[d] = c; }
+  // lazily, one device at a time: the order that used to starve the later devices
+  for (int d = 0; d < n_slots; d++)
+    for (int k = 0; k < kinds * per_kind; k++) {
+      const int lane = lane_plan_pick(users.data(), slot.data(), bound.data(), d, n_slots);
+      if (lane < 0) return -1;
+      worst = std::max(worst, users[lane]);
+    }
+  for (int d = 0; d < n_slots; d++) {
+    int c = 0;
+    for (int lane = 1; lane < MAX_LANES; lane++) c += bound[lane] && slot[lane] == d;
+    if (out_lanes_per_slot) out_lanes_per_slot[d] = c;
+  }
   return worst;
 }
 int gpu_lane_acquire(int device_slot) {
   std::lock_guard<std::mutex> lk(g_lane_mutex);
   int slot[MAX_LANES]; uint8_t bound[MAX_LANES];
-  for (int lane = 0; lane < MAX_LANES; lane++) { slot[lane] = g_lane_slot[lane].load(); bound[lane] = g_lanes[lane].load() != nullptr || g_lane_users[lane] > 0 || g_lane_claimed[lane]; }
+  for (int lane = 0; lane < MAX_LANES; lane++) {
+    slot[lane] = g_lane_slot[lane].load();
+    bound[lane] = g_lanes[lane].load() != nullptr || g_lane_users[lane] > 0 || g_lane_claimed[lane];
+  }
   const int lane = lane_plan_pick(g_lane_users, slot, bound, device_slot, gpu_device_slots());
   if (lane < 0) throw GpuError("no stream lane left for device slot " + std::to_string(device_slot));
   g_lane_slot[lane].store(device_slot); g_lane_claimed[lane] = 1; return lane; }
-void gpu_lane_release(int lane) { if (lane <= 0 || lane >= MAX_LANES) return; std::lock_guard<std::mutex> lk(g_lane_mutex); if (g_lane_users[lane] > 0) g_lane_users[lane]--; }
+void gpu_lane_release(int lane) {
+  if (lane <= 0 || lane >= MAX_LANES) return;
+  std::lock_guard<std::mutex> lk(g_lane_mutex);
+  if (g_lane_users[lane] > 0) g_lane_users[lane]--;
+}
 int gpu_lane_current() { return t_lane; }
 void gpu_lane_select(int lane) { t_lane = lane < 0 || lane >= MAX_LANES ? 0 : lane; }
 bool gpu_available() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0; }
-// NUMA node of the host socket visible device `device` hangs off (sysfs entry of its PCI function), -1 unknown.  A rank launcher binds its process to that node's CPUs
-// (bench.py); the library itself only moves its scan threads next to the caller's buffer (hostnuma.hpp).
+// NUMA node of the host socket visible device `device` hangs off (sysfs entry of its PCI function), -1 unknown. A rank launcher binds its process to that
+// node's CPUs (bench.py); the library itself only moves its scan threads next to the caller's buffer (hostnuma.hpp).
 int gpu_device_numa_node(int device) {
   char id[64] = {0};
   if (hipDeviceGetPCIBusId(id, (int)sizeof(id), device) != hipSuccess) return -1;
@@ -107,12 +145,31 @@ int gpu_device_numa_node(int device) {
   return node;
 }
 void gpu_sync() { HIP_CHECK(hipStreamSynchronize(gpu().stream)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamSynchronize(gpu().aux[i])); }
-void gpu_join_aux() { GpuContext &g = gpu(); for (int i = 0; i < 4; i++) { HIP_CHECK(hipEventRecord(g.join_event[i], g.aux[i])); HIP_CHECK(hipStreamWaitEvent(g.stream, g.join_event[i], 0)); } }
+void gpu_join_aux() {
+  GpuContext &g = gpu();
+  for (int i = 0; i < 4; i++) {
+    HIP_CHECK(hipEventRecord(g.join_event[i], g.aux[i]));
+    HIP_CHECK(hipStreamWaitEvent(g.stream, g.join_event[i], 0));
+  }
+}
 bool profiling_enabled();
 void gpu_fork_record() { GpuContext &g = gpu(); HIP_CHECK(hipEventRecord(g.fork_event, g.stream)); }
-void gpu_fork_wait(int i) { GpuContext &g = gpu(); HIP_CHECK(hipStreamWaitEvent(g.aux[i & 3], g.fork_event, 0)); }   // may be called from the thread that submits to that stream
-void gpu_fork_one(int i) { GpuContext &g = gpu(); HIP_CHECK(hipEventRecord(g.join_event[i & 3], g.stream)); HIP_CHECK(hipStreamWaitEvent(g.aux[i & 3], g.join_event[i & 3], 0)); }   // (the stream's join event is free at this point of a proof)
-void gpu_fork_aux() { GpuContext &g = gpu(); HIP_CHECK(hipEventRecord(g.fork_event, g.stream)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(g.aux[i], g.fork_event, 0)); }
+// may be called from the thread that submits to that stream
+void gpu_fork_wait(int i) {
+  GpuContext &g = gpu();
+  HIP_CHECK(hipStreamWaitEvent(g.aux[i & 3], g.fork_event, 0));
+}
+// (the stream's join event is free at this point of a proof)
+void gpu_fork_one(int i) {
+  GpuContext &g = gpu();
+  HIP_CHECK(hipEventRecord(g.join_event[i & 3], g.stream));
+  HIP_CHECK(hipStreamWaitEvent(g.aux[i & 3], g.join_event[i & 3], 0));
+}
+void gpu_fork_aux() {
+  GpuContext &g = gpu();
+  HIP_CHECK(hipEventRecord(g.fork_event, g.stream));
+  for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamWaitEvent(g.aux[i], g.fork_event, 0));
+}
 hipStream_t gpu_stream() { return gpu().stream; }
 
 // ---- optional per-stage timing with HIP events on the compute stream (bench.py's roofline leg; off by default) ----------
@@ -123,10 +180,30 @@ struct StageTimer {
   hipEvent_t get() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; } hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e; }
   struct Open { hipStream_t st; };
   std::vector<hipStream_t> open_streams;
-  size_t begin(const char *name, hipStream_t st) { if (!enabled) return (size_t)-1; std::lock_guard<std::mutex> lk(mu); Span s{name, get(), get()}; HIP_CHECK(hipEventRecord(s.a, st)); open.push_back(s); open_streams.push_back(st); return open.size() - 1; }
+  size_t begin(const char *name, hipStream_t st) {
+    if (!enabled) return (size_t)-1;
+    std::lock_guard<std::mutex> lk(mu);
+    Span s{name, get(), get()};
+    HIP_CHECK(hipEventRecord(s.a, st));
+    open.push_back(s);
+    open_streams.push_back(st);
+    return open.size() - 1;
+  }
   void end(size_t id) { if (id == (size_t)-1) return; std::lock_guard<std::mutex> lk(mu); HIP_CHECK(hipEventRecord(open[id].b, open_streams[id])); }
   void collect() { std::lock_guard<std::mutex> lk(mu); if (open.empty()) return; HIP_CHECK(hipDeviceSynchronize());
-    for (Span &s : open) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { auto &e = acc[s.name]; e.first += ms; e.second++; } pool.push_back(s.a); pool.push_back(s.b); } open.clear(); open_streams.clear(); }
+    for (Span &s : open) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+        auto &e = acc[s.name];
+        e.first += ms;
+        e.second++;
+      }
+      pool.push_back(s.a);
+      pool.push_back(s.b);
+    }
+    open.clear();
+    open_streams.clear();
+  }
 };
 static StageTimer g_timer;
 Stage::Stage(const char *n, hipStream_t st) : id(g_timer.begin(n, st ? st : gpu().stream)) {}
@@ -134,16 +211,51 @@ Stage::~Stage() { g_timer.end(id); }
 bool profiling_enabled() { return g_timer.enabled; }
 void profile_enable(bool on) { g_timer.collect(); g_timer.enabled = on; g_timer.acc.clear(); }
 std::string profile_report() { g_timer.collect(); std::string o = "{"; bool first = true;
-  for (auto &kv : g_timer.acc) { char buf[256]; snprintf(buf, sizeof buf, "%s\"%s\": {\"ms_total\": %.6f, \"count\": %ld}", first ? "" : ", ", kv.first.c_str(), kv.second.first, kv.second.second); o += buf; first = false; } return o + "}"; }
+  for (auto &kv : g_timer.acc) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s\"%s\": {\"ms_total\": %.6f, \"count\": %ld}", first ? "" : ", ", kv.first.c_str(), kv.second.first, kv.second.second);
+    o += buf;
+    first = false;
+  }
+  return o + "}";
+}
 
-template <class T> DevBuf<T>::DevBuf(size_t n) : n_(n) { gpu(); if (n) { hipError_t e = hipMalloc((void **)&p_, n * sizeof(T)); if (e != hipSuccess) { p_ = nullptr; throw GpuError("hipMalloc of " + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e)); } } }
+template <class T> DevBuf<T>::DevBuf(size_t n) : n_(n) {
+  gpu();
+  if (n) {
+    hipError_t e = hipMalloc((void **)&p_, n * sizeof(T));
+    if (e != hipSuccess) {
+      p_ = nullptr;
+      throw GpuError("hipMalloc of " + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e));
+    }
+  }
+}
 template <class T> DevBuf<T>::~DevBuf() { if (p_) hipFree(p_); }
 template <class T> DevBuf<T>::DevBuf(DevBuf &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
-template <class T> DevBuf<T> &DevBuf<T>::operator=(DevBuf &&o) noexcept { if (this != &o) { if (p_) hipFree(p_); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }
-template <class T> void DevBuf<T>::upload(const T *h, size_t n) { HIP_CHECK(hipMemcpyAsync(p_, h, n * sizeof(T), hipMemcpyHostToDevice, gpu().stream)); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
-template <class T> void DevBuf<T>::download(T *h, size_t n) const { HIP_CHECK(hipMemcpyAsync(h, p_, n * sizeof(T), hipMemcpyDeviceToHost, gpu().stream)); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
+template <class T> DevBuf<T> &DevBuf<T>::operator=(DevBuf &&o) noexcept {
+  if (this != &o) {
+    if (p_) hipFree(p_);
+    p_ = o.p_;
+    n_ = o.n_;
+    o.p_ = nullptr;
+    o.n_ = 0;
+  }
+  return *this;
+}
+template <class T> void DevBuf<T>::upload(const T *h, size_t n) {
+  HIP_CHECK(hipMemcpyAsync(p_, h, n * sizeof(T), hipMemcpyHostToDevice, gpu().stream));
+  HIP_CHECK(hipStreamSynchronize(gpu().stream));
+}
+template <class T> void DevBuf<T>::download(T *h, size_t n) const {
+  HIP_CHECK(hipMemcpyAsync(h, p_, n * sizeof(T), hipMemcpyDeviceToHost, gpu().stream));
+  HIP_CHECK(hipStreamSynchronize(gpu().stream));
+}
 template <class T> void DevBuf<T>::zero() { if (n_) HIP_CHECK(hipMemsetAsync(p_, 0, n_ * sizeof(T), gpu().stream)); }
-template class DevBuf<uint8_t>; template class DevBuf<uint32_t>; template class DevBuf<Fe32>; template class DevBuf<G1AffineRaw>; template class DevBuf<G2AffineRaw>;
+template class DevBuf<uint8_t>;
+template class DevBuf<uint32_t>;
+template class DevBuf<Fe32>;
+template class DevBuf<G1AffineRaw>;
+template class DevBuf<G2AffineRaw>;
 
 template <class T> PinnedBuf<T>::PinnedBuf(size_t n) : n_(n) { gpu(); if (n) HIP_CHECK(hipHostMalloc((void **)&p_, n * sizeof(T))); }
 template <class T> PinnedBuf<T>::~PinnedBuf() { release(); }
@@ -157,59 +269,149 @@ void upload_async(void *dev, const void *host, size_t bytes) { HIP_CHECK(hipMemc
 // ======================================================================================================================
 static size_t ceil_log2(size_t n) { size_t r = ((n & (n - 1)) == 0 ? 0 : 1); while (n > 1) { n >>= 1; r++; } return r; }   // FF/common/utils.cpp:32-45
 using host::HFr;
-static HFr fr_root_of_unity(size_t n) { HFr w; memcpy(w.l, FR_ROOT_OF_UNITY_2_28, 32); for (size_t i = 28; i > ceil_log2(n); --i) w = w.sqr(); return w; }   // field_utils.tcc:36-51
+// field_utils.tcc:36-51
+static HFr fr_root_of_unity(size_t n) {
+  HFr w;
+  memcpy(w.l, FR_ROOT_OF_UNITY_2_28, 32);
+  for (size_t i = 28; i > ceil_log2(n); --i) w = w.sqr();
+  return w;
+}
 static HFr fr_coset_gen() { HFr g; memcpy(g.l, FR_COSET_GEN, 32); return g; }
 
 // tables for one power-of-two transform size n with root w: tw[j] = w^j, itw[j] = w^-j (j < n/2)
-// tw261 / itw261: the same powers times 2^261 instead of 2^256 (canonical integers, 8 words): the factor form of the tile kernels, which compute on 29-bit limbs (ntt.cuh)
+// tw261 / itw261: the same powers times 2^261 instead of 2^256 (canonical integers, 8 words): the factor form of the tile kernels, which compute on 29-bit
+// limbs (ntt.cuh)
 struct Radix2Tables {
   int logn; size_t n; DevBuf<Fe32> tw, itw, tw261, itw261;
-  Radix2Tables(size_t n_, const HFr &w) : logn((int)ceil_log2(n_)), n(n_), tw(n_ / 2 ? n_ / 2 : 1), itw(n_ / 2 ? n_ / 2 : 1), tw261(n_ / 2 ? n_ / 2 : 1), itw261(n_ / 2 ? n_ / 2 : 1) {
+  Radix2Tables(size_t n_, const HFr &w) : logn((int)ceil_log2(n_)), n(n_), tw(n_ / 2 ? n_ / 2 : 1), itw(n_ / 2 ? n_ / 2 : 1), tw261(n_ / 2 ? n_ / 2 : 1),
+      itw261(n_ / 2 ? n_ / 2 : 1) {
     std::vector<Fe32> a(n / 2 ? n / 2 : 1), b(a.size()), a5(a.size()), b5(a.size()); HFr wi = w.inv(), x = HFr::one(), y = HFr::one();
-    auto times32 = [](HFr v) { for (int i = 0; i < 5; i++) v = v + v; return v; };   // the Montgomery integer of v is v 2^256: five doublings give v 2^261 (mod r)
-    for (size_t j = 0; j < std::max<size_t>(n / 2, 1); j++) { memcpy(&a[j], x.l, 32); memcpy(&b[j], y.l, 32); HFr x5 = times32(x), y5 = times32(y); memcpy(&a5[j], x5.l, 32); memcpy(&b5[j], y5.l, 32); x = x * w; y = y * wi; }
+    // the Montgomery integer of v is v 2^256: five doublings give v 2^261 (mod r)
+    auto times32 = [](HFr v) {
+      for (int i = 0; i < 5; i++) v = v + v;
+      return v;
+    };
+    for (size_t j = 0; j < std::max<size_t>(n / 2, 1); j++) {
+      memcpy(&a[j], x.l, 32);
+      memcpy(&b[j], y.l, 32);
+      HFr x5 = times32(x), y5 = times32(y);
+      memcpy(&a5[j], x5.l, 32);
+      memcpy(&b5[j], y5.l, 32);
+      x = x * w;
+      y = y * wi;
+    }
     tw.upload(a.data(), a.size()); itw.upload(b.data(), b.size()); tw261.upload(a5.data(), a5.size()); itw261.upload(b5.data(), b5.size());
   }
 };
-static std::vector<Fe32> geometric_table(size_t n, const HFr &first, const HFr &ratio) { std::vector<Fe32> t(n); HFr x = first; for (size_t i = 0; i < n; i++) { memcpy(&t[i], x.l, 32); x = x * ratio; } return t; }
+static std::vector<Fe32> geometric_table(size_t n, const HFr &first, const HFr &ratio) {
+  std::vector<Fe32> t(n);
+  HFr x = first;
+  for (size_t i = 0; i < n; i++) {
+    memcpy(&t[i], x.l, 32);
+    x = x * ratio;
+  }
+  return t;
+}
 
 // in-place radix-2 transform of `batch` vectors: data = post * NTT(pre * data), natural order in and out.  Up to 2^22 points: two LDS-tiled passes
 // (k_ntt_cols: data -> scratch, k_ntt_rows: scratch -> data; one pass in place when the whole vector fits a tile); beyond that the stage-per-launch path.
-static int ntt_pref_log_c() { static const int v = [] { const char *e = getenv("ZK_NTT_LOGC"); int x = e ? atoi(e) : 1;   // two columns per tile since the tiles compute on 29-bit limbs (1.01 against 1.04 ms per send proof; one column was best for the 32-bit passes)
+// two columns per tile since the tiles compute on 29-bit limbs (1.01 against 1.04 ms per send proof; one column was best for the 32-bit passes)
+static int ntt_pref_log_c() {
+  static const int v = [] {
+    const char *e = getenv("ZK_NTT_LOGC");
+    int x = e ? atoi(e) : 1;
     return x < 0 ? 0 : x > 3 ? 3 : x; }(); return v; }
-static Fe32 fe261(HFr v) { for (int i = 0; i < 5; i++) v = v + v; Fe32 o; memcpy(&o, v.l, 32); return o; }   // f 2^261 mod r as a canonical integer (the host type holds f 2^256: five doublings)
-// One in-place radix-2 transform of `batch` vectors: data = post * NTT(pre * data) * scale, natural order in and out.  The tile kernels take the per-element factor as
-// pre261 (f 2^261) and the constant as scale261; pre_scale (f 2^256) is the same table for the stage-per-launch path beyond 2^22 points, which folds a constant scale into it.
-struct NttCall { Fe32 *data, *scratch; const Fe32 *tw, *tw261; int logn; const Fe32 *pre_scale, *pre261; Fe32 scale261; const Fe32 *post_scale; size_t stride, scratch_stride; };
-static int ntt_radix_log() { static const int rl = [] { const char *e = getenv("ZK_NTT_RADIX_LOG"); int x = e ? atoi(e) : 2; return x < 1 ? 1 : x > 3 ? 3 : x; }(); return rl; }   // radix-4 passes measured best with two vectors per launch (twice the waves of radix 8: the passes are latency bound), radix 8 with three
+// f 2^261 mod r as a canonical integer (the host type holds f 2^256: five doublings)
+static Fe32 fe261(HFr v) {
+  for (int i = 0; i < 5; i++) v = v + v;
+  Fe32 o;
+  memcpy(&o, v.l, 32);
+  return o;
+}
+// One in-place radix-2 transform of `batch` vectors: data = post * NTT(pre * data) * scale, natural order in and out. The tile kernels take the per-element
+// factor as pre261 (f 2^261) and the constant as scale261; pre_scale (f 2^256) is the same table for the stage-per-launch path beyond 2^22 points, which folds
+// a constant scale into it.
+struct NttCall { Fe32 *data, *scratch; const Fe32 *tw, *tw261; int logn; const Fe32 *pre_scale, *pre261; Fe32 scale261; const Fe32 *post_scale;
+    size_t stride, scratch_stride; };
+// radix-4 passes measured best with two vectors per launch (twice the waves of radix 8: the passes are latency bound), radix 8 with three
+static int ntt_radix_log() {
+  static const int rl = [] {
+    const char *e = getenv("ZK_NTT_RADIX_LOG");
+    int x = e ? atoi(e) : 2;
+    return x < 1 ? 1 : x > 3 ? 3 : x;
+  }();
+  return rl;
+}
 static bool ntt_two_pass(int logn) { return logn > NTT_TILE_LOG && logn <= 2 * NTT_TILE_LOG; }
-static unsigned ntt_threads_for(int logN, int logC) { int g = logN + logC - ntt_radix_log(); return 1u << (g < 6 ? 6 : g > 8 ? 8 : g); }   // one butterfly group per thread and pass, 64..256 threads
-static size_t ntt_lds_for(int logN, int logC) { size_t e = (size_t)1 << (logN + logC); return sizeof(Fr29) * (e + (e >> 4) + 1) + (sizeof(Fr29) << logN) / 2; }   // padded tile (ntt_pad) + twiddle table, 36 bytes an element
-static void ntt_raise_lds() { static const bool done = [] { HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_cols, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); return true; }(); (void)done; }
-// up to two transforms of the two-pass range (2^12 .. 2^22 points) in ONE column launch and ONE row launch (k_ntt_cols: data -> scratch, k_ntt_rows: scratch -> data)
+// one butterfly group per thread and pass, 64..256 threads
+static unsigned ntt_threads_for(int logN, int logC) {
+  int g = logN + logC - ntt_radix_log();
+  return 1u << (g < 6 ? 6 : g > 8 ? 8 : g);
+}
+// padded tile (ntt_pad) + twiddle table, 36 bytes an element
+static size_t ntt_lds_for(int logN, int logC) {
+  size_t e = (size_t)1 << (logN + logC);
+  return sizeof(Fr29) * (e + (e >> 4) + 1) + (sizeof(Fr29) << logN) / 2;
+}
+static void ntt_raise_lds() {
+  static const bool done = [] {
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_cols, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    return true;
+  }();
+  (void)done;
+}
+// up to two transforms of the two-pass range (2^12 .. 2^22 points) in ONE column launch and ONE row launch (k_ntt_cols: data -> scratch, k_ntt_rows: scratch ->
+// data)
 static void ntt_two_pass_launch(const NttCall *calls, int n_calls, int batch) {
-  hipStream_t s = gpu().stream; ntt_raise_lds(); NttJob cj[2], rj[2]; memset(cj, 0, sizeof cj); memset(rj, 0, sizeof rj); unsigned tc = 64, tr = 64; size_t lc = 0, lr = 0;
-  for (int k = 0; k < n_calls; k++) { const NttCall &c = calls[k]; const int l1 = c.logn / 2, l2 = c.logn - l1, c1 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l1, l2)), c2 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l2, l1));
+  hipStream_t s = gpu().stream;
+  ntt_raise_lds();
+  NttJob cj[2], rj[2];
+  memset(cj, 0, sizeof cj);
+  memset(rj, 0, sizeof rj);
+  unsigned tc = 64, tr = 64;
+  size_t lc = 0, lr = 0;
+  for (int k = 0; k < n_calls; k++) {
+    const NttCall &c = calls[k];
+    const int l1 = c.logn / 2, l2 = c.logn - l1, c1 = std::min(ntt_pref_log_c(), std::min(NTT_TILE_LOG - l1, l2)), c2 = std::min(ntt_pref_log_c(),
+        std::min(NTT_TILE_LOG - l2, l1));
     Fr sc; memcpy(&sc, &c.scale261, 32);
-    cj[k] = NttJob{(const Fr *)c.data, (Fr *)c.scratch, (const Fr *)c.pre261, (const Fr *)c.tw261, sc, c.logn, l1, c1, 1u << (l2 - c1), c.stride, c.scratch_stride};
-    rj[k] = NttJob{(const Fr *)c.scratch, (Fr *)c.data, (const Fr *)c.post_scale, (const Fr *)c.tw261, sc, c.logn, l1, c2, 1u << (l1 - c2), c.scratch_stride, c.stride};
-    tc = std::max(tc, ntt_threads_for(l1, c1)); tr = std::max(tr, ntt_threads_for(l2, c2)); lc = std::max(lc, ntt_lds_for(l1, c1)); lr = std::max(lr, ntt_lds_for(l2, c2)); }
+    cj[k] = NttJob{(const Fr *)c.data, (Fr *)c.scratch, (const Fr *)c.pre261, (const Fr *)c.tw261, sc, c.logn, l1, c1, 1u << (l2 - c1), c.stride,
+        c.scratch_stride};
+    rj[k] = NttJob{(const Fr *)c.scratch, (Fr *)c.data, (const Fr *)c.post_scale, (const Fr *)c.tw261, sc, c.logn, l1, c2, 1u << (l1 - c2), c.scratch_stride,
+        c.stride};
+    tc = std::max(tc, ntt_threads_for(l1, c1));
+    tr = std::max(tr, ntt_threads_for(l2, c2));
+    lc = std::max(lc, ntt_lds_for(l1, c1));
+    lr = std::max(lr, ntt_lds_for(l2, c2));
+  }
   hipLaunchKernelGGL(k_ntt_cols, dim3(cj[0].tiles + cj[1].tiles, batch), dim3(tc), lc, s, cj[0], cj[1], ntt_radix_log());
   hipLaunchKernelGGL(k_ntt_rows, dim3(rj[0].tiles + rj[1].tiles, batch), dim3(tr), lr, s, rj[0], rj[1], ntt_radix_log());
 }
 static void radix2_transform(const NttCall &c, int batch) {
-  hipStream_t s = gpu().stream; size_t n = (size_t)1 << c.logn; Fe32 *data = c.data, *scratch = c.scratch; const int logn = c.logn; const size_t stride = c.stride, scratch_stride = c.scratch_stride;
+  hipStream_t s = gpu().stream;
+  size_t n = (size_t)1 << c.logn;
+  Fe32 *data = c.data, *scratch = c.scratch;
+  const int logn = c.logn;
+  const size_t stride = c.stride, scratch_stride = c.scratch_stride;
   if (logn <= NTT_TILE_LOG) {          // n2 = 1: the column pass alone is the whole transform
     if (c.post_scale) throw GpuError("ntt: post scale on a single-pass transform");
-    ntt_raise_lds(); Fr sc; memcpy(&sc, &c.scale261, 32); NttJob j{(const Fr *)data, (Fr *)data, (const Fr *)c.pre261, (const Fr *)c.tw261, sc, logn, logn, 0, 1u, stride, stride}, none; memset(&none, 0, sizeof none);
+    ntt_raise_lds();
+    Fr sc;
+    memcpy(&sc, &c.scale261, 32);
+    NttJob j{(const Fr *)data, (Fr *)data, (const Fr *)c.pre261, (const Fr *)c.tw261, sc, logn, logn, 0, 1u, stride, stride}, none;
+    memset(&none, 0, sizeof none);
     hipLaunchKernelGGL(k_ntt_cols, dim3(1, batch), dim3(ntt_threads_for(logn, 0)), ntt_lds_for(logn, 0), s, j, none, ntt_radix_log());
     return;
   }
   if (ntt_two_pass(logn)) { ntt_two_pass_launch(&c, 1, batch); return; }
-  hipLaunchKernelGGL(k_ntt_bitrev_scale, dim3(cdiv(n, 256), batch), dim3(256), 0, s, (const Fr *)data, (Fr *)scratch, (const Fr *)c.pre_scale, logn, stride, scratch_stride);
+  hipLaunchKernelGGL(k_ntt_bitrev_scale, dim3(cdiv(n, 256), batch), dim3(256), 0, s, (const Fr *)data, (Fr *)scratch, (const Fr *)c.pre_scale, logn, stride,
+      scratch_stride);
   int L = NTT_LOCAL_LOG;
-  hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> L), batch), dim3(NTT_LOCAL_THREADS), sizeof(Fr) << L, s, (Fr *)scratch, (const Fr *)c.tw, logn, L, scratch_stride);
-  for (int st = L + 1; st <= logn; st++) hipLaunchKernelGGL(k_ntt_stage, dim3(cdiv(n / 2, 256), batch), dim3(256), 0, s, (Fr *)scratch, (const Fr *)c.tw, logn, st, scratch_stride);
+  hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> L), batch), dim3(NTT_LOCAL_THREADS), sizeof(Fr) << L, s, (Fr *)scratch, (const Fr *)c.tw, logn, L,
+      scratch_stride);
+  for (int st = L + 1; st <= logn; st++) hipLaunchKernelGGL(k_ntt_stage, dim3(cdiv(n / 2, 256), batch), dim3(256), 0, s, (Fr *)scratch, (const Fr *)c.tw, logn,
+      st, scratch_stride);
   for (int b = 0; b < batch; b++) HIP_CHECK(hipMemcpyAsync(data + b * stride, scratch + b * scratch_stride, n * sizeof(Fe32), hipMemcpyDeviceToDevice, s));
   if (c.post_scale) hipLaunchKernelGGL(k_fr_mul_table, dim3(cdiv(n, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)c.post_scale, (uint32_t)n, stride);
 }
@@ -222,13 +424,23 @@ static void radix2_transform_pair(const NttCall &a, const NttCall &b, int batch)
 // ---- step-radix-2 helper kernels (domains/step_radix2_domain.tcc:39-153) ---------------------------------------------
 // forward pre-pass: c[i] = a[i] + a[i+B] (i<S) else a[i];  d[i] = w^i * (a[i] - a[i+B] (i<S) else a[i]);  e[i] = sum_j d[i + j*S]
 // (in place: c overwrites a[0..B); blockIdx.y = vector of the batch)
-// (cf, optional: the coset factors g^i of cosetFFT, multiplied in on the way — one pass over the vector and one launch less than a separate table multiplication)
-__global__ void k_step_fwd_pre(Fr *a_all, Fr *__restrict__ dbuf_all, const Fr *__restrict__ wpow, const Fr *__restrict__ cf, uint32_t B, uint32_t S, size_t stride) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= B) return; Fr *a = a_all + blockIdx.y * stride, *dbuf = dbuf_all + (size_t)blockIdx.y * B; Fr x = a[i]; if (cf) x = x * cf[i];
+// (cf, optional: the coset factors g^i of cosetFFT, multiplied in on the way — one pass over the vector and one launch less than a separate table
+// multiplication)
+__global__ void k_step_fwd_pre(Fr *a_all, Fr *__restrict__ dbuf_all, const Fr *__restrict__ wpow, const Fr *__restrict__ cf, uint32_t B, uint32_t S,
+    size_t stride) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  Fr *a = a_all + blockIdx.y * stride, *dbuf = dbuf_all + (size_t)blockIdx.y * B;
+  Fr x = a[i];
+  if (cf) x = x * cf[i];
   if (i < S) { Fr y = a[i + B]; if (cf) y = y * cf[i + B]; a[i] = x + y; dbuf[i] = wpow[i] * (x - y); } else { if (cf) a[i] = x; dbuf[i] = wpow[i] * x; }
 }
 __global__ void k_step_fold(const Fr *__restrict__ dbuf_all, Fr *__restrict__ a_all, uint32_t B, uint32_t S, size_t stride) {   // e overwrites a[B..B+S)
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= S) return; const Fr *dbuf = dbuf_all + (size_t)blockIdx.y * B; Fr acc = Fr::zero(); for (uint32_t j = i; j < B; j += S) acc = acc + dbuf[j];
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S) return;
+  const Fr *dbuf = dbuf_all + (size_t)blockIdx.y * B;
+  Fr acc = Fr::zero();
+  for (uint32_t j = i; j < B; j += S) acc = acc + dbuf[j];
   a_all[blockIdx.y * stride + B + i] = acc;
 }
 // inverse post-pass.  U0 (B values, already scaled by 1/B), U1 (S values, scaled by 1/S):
@@ -240,13 +452,16 @@ __global__ void k_step_inv_post(Fr *a_all, const Fr *__restrict__ wpow, const Fr
   u1 = u1 * winvpow[i]; Fr u0 = a[i]; a[i] = (u0 + u1) * half; a[B + i] = (u0 - u1) * half;
 }
 
-// iFFT immediately followed by cosetFFT (what the witness map does to A and B): the inverse transform's recombination pass and the forward transform's factor, pre-pass and
-// fold touch the same elements — thread i < S owns the index class {i, i + S, i + 2S, ... < B} and B + i —, so they are ONE pass over the vectors instead of three
-// (k_step_inv_post, k_step_fwd_pre with the coset factors, k_step_fold) and one launch instead of three
-__global__ void k_step_inv_fwd(Fr *a_all, const Fr *__restrict__ wpow, const Fr *__restrict__ winvpow, Fr half, const Fr *__restrict__ cf, uint32_t B, uint32_t S, size_t stride) {
+// iFFT immediately followed by cosetFFT (what the witness map does to A and B): the inverse transform's recombination pass and the forward transform's factor,
+// pre-pass and fold touch the same elements — thread i < S owns the index class {i, i + S, i + 2S, ... < B} and B + i —, so they are ONE pass over the vectors
+// instead of three (k_step_inv_post, k_step_fwd_pre with the coset factors, k_step_fold) and one launch instead of three
+__global__ void k_step_inv_fwd(Fr *a_all, const Fr *__restrict__ wpow, const Fr *__restrict__ winvpow, Fr half, const Fr *__restrict__ cf, uint32_t B,
+    uint32_t S, size_t stride) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= S) return; Fr *a = a_all + blockIdx.y * stride;
   Fr u1 = a[B + i]; for (uint32_t j = i + S; j < B; j += S) u1 = u1 - a[j] * wpow[j];
-  u1 = u1 * winvpow[i]; const Fr u0 = a[i], lo = (u0 + u1) * half, hi = (u0 - u1) * half;        // the inverse transform's a[i], a[B + i]; a[S..B) are final as they are
+  // the inverse transform's a[i], a[B + i]; a[S..B) are final as they are
+  u1 = u1 * winvpow[i];
+  const Fr u0 = a[i], lo = (u0 + u1) * half, hi = (u0 - u1) * half;
   const Fr x = lo * cf[i], y = hi * cf[B + i]; a[i] = x + y; Fr e = wpow[i] * (x - y);            // the forward pre-pass on g^i a[i]: c[i], d[i]
   for (uint32_t j = i + S; j < B; j += S) { const Fr xx = a[j] * cf[j]; a[j] = xx; e = e + wpow[j] * xx; }
   a[B + i] = e;                                                                                  // the fold: e[i] = sum_j d[i + jS]
@@ -257,17 +472,32 @@ struct DomainTables {                                            // immutable pe
   std::unique_ptr<Radix2Tables> big, small;                       // basic: only `big` (size m)
   DevBuf<Fe32> coset_fwd, coset_inv, zinv, wpow, winvpow;
   DevBuf<Fe32> scale_big, scale_small;                            // 1/n as a table: the pre-scale of the stage-per-launch path (beyond 2^22 points)
-  DevBuf<Fe32> coset_fwd261; Fe32 one261, inv_big261, inv_small261; // the tile kernels' factor forms (f 2^261): g^i per element, the constants 1, 1/B (or 1/m), 1/S
+  // the tile kernels' factor forms (f 2^261): g^i per element, the constants 1, 1/B (or 1/m), 1/S
+  DevBuf<Fe32> coset_fwd261;
+  Fe32 one261, inv_big261, inv_small261;
   HFr half;
 };
 struct Domain::Impl {
   std::shared_ptr<DomainTables> t; DomainTables &d_;              // (d_ keeps the code below unchanged: every table is reached through it)
-  size_t &m; bool &step; size_t &B, &S; std::unique_ptr<Radix2Tables> &big, &small; DevBuf<Fe32> &coset_fwd, &coset_inv, &zinv, &wpow, &winvpow, &scale_big, &scale_small, &coset_fwd261; Fe32 &one261, &inv_big261, &inv_small261; HFr &half;
+  size_t &m;
+  bool &step;
+  size_t &B, &S;
+  std::unique_ptr<Radix2Tables> &big, &small;
+  DevBuf<Fe32> &coset_fwd, &coset_inv, &zinv, &wpow, &winvpow, &scale_big, &scale_small, &coset_fwd261;
+  Fe32 &one261, &inv_big261, &inv_small261;
+  HFr &half;
   DevBuf<Fe32> scratch; size_t scratch_stride = 0;                // per object
-  explicit Impl(std::shared_ptr<DomainTables> tt) : t(tt), d_(*t), m(d_.m), step(d_.step), B(d_.B), S(d_.S), big(d_.big), small(d_.small), coset_fwd(d_.coset_fwd), coset_inv(d_.coset_inv), zinv(d_.zinv), wpow(d_.wpow), winvpow(d_.winvpow),
-                                                        scale_big(d_.scale_big), scale_small(d_.scale_small), coset_fwd261(d_.coset_fwd261), one261(d_.one261), inv_big261(d_.inv_big261), inv_small261(d_.inv_small261), half(d_.half) {}
+  explicit Impl(std::shared_ptr<DomainTables> tt) : t(tt), d_(*t), m(d_.m), step(d_.step), B(d_.B), S(d_.S), big(d_.big), small(d_.small),
+      coset_fwd(d_.coset_fwd), coset_inv(d_.coset_inv), zinv(d_.zinv), wpow(d_.wpow), winvpow(d_.winvpow),
+                                                        scale_big(d_.scale_big), scale_small(d_.scale_small), coset_fwd261(d_.coset_fwd261), one261(d_.one261),
+                                                            inv_big261(d_.inv_big261), inv_small261(d_.inv_small261), half(d_.half) {
+                                                        }
 };
-Domain::Domain(const Domain &peer) : impl(new Impl(peer.impl->t)) { Impl &d = *impl; d.scratch_stride = d.m; d.scratch = DevBuf<Fe32>(d.step ? 6 * d.B : 3 * d.m); }
+Domain::Domain(const Domain &peer) : impl(new Impl(peer.impl->t)) {
+  Impl &d = *impl;
+  d.scratch_stride = d.m;
+  d.scratch = DevBuf<Fe32>(d.step ? 6 * d.B : 3 * d.m);
+}
 
 Domain::Domain(size_t min_size) : impl(new Impl(std::make_shared<DomainTables>())) {
   Impl &d = *impl; if (min_size <= 1) throw GpuError("domain: size");
@@ -292,9 +522,15 @@ Domain::Domain(size_t min_size) : impl(new Impl(std::make_shared<DomainTables>()
     auto sb = geometric_table(d.B, HFr::from_u64(d.B).inv(), one), ss = geometric_table(d.S, HFr::from_u64(d.S).inv(), one);
     d.coset_fwd = DevBuf<Fe32>(d.m); d.coset_fwd.upload(cf.data(), d.m); d.coset_inv = DevBuf<Fe32>(d.m); d.coset_inv.upload(ci.data(), d.m);
     d.wpow = DevBuf<Fe32>(d.B); d.wpow.upload(wp.data(), d.B); d.winvpow = DevBuf<Fe32>(d.S); d.winvpow.upload(wip.data(), d.S);
-    d.scale_big = DevBuf<Fe32>(d.B); d.scale_big.upload(sb.data(), d.B); d.scale_small = DevBuf<Fe32>(d.S); d.scale_small.upload(ss.data(), d.S); d.inv_big261 = fe261(HFr::from_u64(d.B).inv()); d.inv_small261 = fe261(HFr::from_u64(d.S).inv());
+    d.scale_big = DevBuf<Fe32>(d.B);
+    d.scale_big.upload(sb.data(), d.B);
+    d.scale_small = DevBuf<Fe32>(d.S);
+    d.scale_small.upload(ss.data(), d.S);
+    d.inv_big261 = fe261(HFr::from_u64(d.B).inv());
+    d.inv_small261 = fe261(HFr::from_u64(d.S).inv());
     // divide_by_Z_on_coset (:242-260): P[i] /= (g^S * Z0 * w^(2S i) - w^S * Z0) for i < B ; P[B+i] /= Z1
-    std::vector<Fe32> zt(d.m); HFr Z0 = g.pow_u64(d.B) - one, cSZ0 = g.pow_u64(d.S) * Z0, wS = w.pow_u64(d.S), wSZ0 = wS * Z0, w2S = w.pow_u64(2 * d.S), elt = one;
+    std::vector<Fe32> zt(d.m);
+    HFr Z0 = g.pow_u64(d.B) - one, cSZ0 = g.pow_u64(d.S) * Z0, wS = w.pow_u64(d.S), wSZ0 = wS * Z0, w2S = w.pow_u64(2 * d.S), elt = one;
     // batch inversion of the B denominators
     std::vector<HFr> den(d.B), pre(d.B); for (size_t i = 0; i < d.B; i++) { den[i] = cSZ0 * elt - wSZ0; elt = elt * w2S; }
     HFr acc = one; for (size_t i = 0; i < d.B; i++) { pre[i] = acc; acc = acc * den[i]; } HFr ai = acc.inv();
@@ -302,53 +538,105 @@ Domain::Domain(size_t min_size) : impl(new Impl(std::make_shared<DomainTables>()
     HFr cw = g * w, Z1 = ((cw.pow_u64(d.B) - one) * (cw.pow_u64(d.S) - wS)).inv(); for (size_t i = 0; i < d.S; i++) memcpy(&zt[d.B + i], Z1.l, 32);
     d.zinv = DevBuf<Fe32>(d.m); d.zinv.upload(zt.data(), d.m);
   }
-  d.one261 = fe261(one); { auto cf = geometric_table(d.m, one, g); for (auto &f : cf) { HFr v; memcpy(v.l, &f, 32); f = fe261(v); } d.coset_fwd261 = DevBuf<Fe32>(d.m); d.coset_fwd261.upload(cf.data(), d.m); }
+  d.one261 = fe261(one);
+  {
+    auto cf = geometric_table(d.m, one, g);
+    for (auto &f : cf) {
+      HFr v;
+      memcpy(v.l, &f, 32);
+      f = fe261(v);
+    }
+    d.coset_fwd261 = DevBuf<Fe32>(d.m);
+    d.coset_fwd261.upload(cf.data(), d.m);
+  }
   d.scratch_stride = d.m; d.scratch = DevBuf<Fe32>(d.step ? 6 * d.B : 3 * d.m);
 }
 Domain::~Domain() = default;
 size_t Domain::m() const { return impl->m; }
 bool Domain::is_step() const { return impl->step; }
 
-static void mul_table(Fe32 *a, const Fe32 *t, size_t n, int batch, size_t stride) { hipLaunchKernelGGL(k_fr_mul_table, dim3(cdiv(n, 256), batch), dim3(256), 0, gpu().stream, (Fr *)a, (const Fr *)t, (uint32_t)n, stride); }
+static void mul_table(Fe32 *a, const Fe32 *t, size_t n, int batch, size_t stride) {
+  hipLaunchKernelGGL(k_fr_mul_table, dim3(cdiv(n, 256), batch), dim3(256), 0, gpu().stream, (Fr *)a, (const Fr *)t, (uint32_t)n, stride);
+}
 
 void Domain::fft(Fe32 *data, int batch, size_t stride) { fft_with_factors(data, batch, stride, nullptr); }
 void Domain::fft_with_factors(Fe32 *data, int batch, size_t stride, const Fe32 *cf) {   // step domains only: cf = the coset factors, folded into the pre-pass
-  Stage st("ntt.forward"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3"); if (!d.step && cf) throw GpuError("domain: factors on a basic domain go through coset_fft");
-  if (!d.step) { radix2_transform(NttCall{data, d.scratch.get(), d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.scratch_stride}, batch); return; }
-  // step_radix2_domain::FFT (:39-77): c / d / e pre-pass in place, then a B-point and an S-point transform of every vector; scratch = [d: 3B | transform scratch: 3B]
+  Stage st("ntt.forward");
+  Impl &d = *impl;
+  if (batch > 3) throw GpuError("domain: batch > 3");
+  if (!d.step && cf) throw GpuError("domain: factors on a basic domain go through coset_fft");
+  if (!d.step) {
+    radix2_transform(NttCall{data, d.scratch.get(), d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride,
+        d.scratch_stride}, batch);
+    return;
+  }
+  // step_radix2_domain::FFT (:39-77): c / d / e pre-pass in place, then a B-point and an S-point transform of every vector; scratch = [d: 3B | transform
+  // scratch: 3B]
   hipStream_t s = gpu().stream; Fe32 *dbuf = d.scratch.get(), *tmp = d.scratch.get() + 3 * d.B;
-  hipLaunchKernelGGL(k_step_fwd_pre, dim3(cdiv(d.B, 256), batch), dim3(256), 0, s, (Fr *)data, (Fr *)dbuf, (const Fr *)d.wpow.get(), (const Fr *)cf, (uint32_t)d.B, (uint32_t)d.S, stride);
+  hipLaunchKernelGGL(k_step_fwd_pre, dim3(cdiv(d.B, 256), batch), dim3(256), 0, s, (Fr *)data, (Fr *)dbuf, (const Fr *)d.wpow.get(), (const Fr *)cf,
+      (uint32_t)d.B, (uint32_t)d.S, stride);
   hipLaunchKernelGGL(k_step_fold, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (const Fr *)dbuf, (Fr *)data, (uint32_t)d.B, (uint32_t)d.S, stride);
-  radix2_transform_pair(NttCall{data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, NttCall{data + d.B, dbuf, d.small->tw.get(), d.small->tw261.get(), d.small->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, batch);   // (dbuf is free again after the fold: the S-point transform's scratch)
+  // (dbuf is free again after the fold: the S-point transform's scratch)
+  radix2_transform_pair(NttCall{data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B},
+      NttCall{data + d.B, dbuf, d.small->tw.get(), d.small->tw261.get(), d.small->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, batch);
 }
 void Domain::ifft(Fe32 *data, int batch, size_t stride) {
   Stage st("ntt.inverse"); Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
-  if (!d.step) { radix2_transform(NttCall{data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, stride, d.scratch_stride}, batch); return; }   // 1/m: the row pass's final factor
+  // 1/m: the row pass's final factor
+  if (!d.step) {
+    radix2_transform(NttCall{data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr,
+        stride, d.scratch_stride}, batch);
+    return;
+  }
   // step_radix2_domain::iFFT (:79-140): both inverse transforms in place (1/B, 1/S folded into their loads), then the recombination pass
   hipStream_t s = gpu().stream; Fe32 *tmp = d.scratch.get() + 3 * d.B;
-  radix2_transform_pair(NttCall{data, tmp, d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, stride, d.B}, NttCall{data + d.B, d.scratch.get(), d.small->itw.get(), d.small->itw261.get(), d.small->logn, d.scale_small.get(), nullptr, d.inv_small261, nullptr, stride, d.B}, batch);
+  radix2_transform_pair(NttCall{data, tmp, d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, stride, d.B},
+      NttCall{data + d.B, d.scratch.get(), d.small->itw.get(), d.small->itw261.get(), d.small->logn, d.scale_small.get(), nullptr, d.inv_small261, nullptr,
+      stride, d.B}, batch);
   Fr half; memcpy(&half, d.half.l, 32);
-  hipLaunchKernelGGL(k_step_inv_post, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half, (uint32_t)d.B, (uint32_t)d.S, stride);
+  hipLaunchKernelGGL(k_step_inv_post, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half,
+      (uint32_t)d.B, (uint32_t)d.S, stride);
 }
 void Domain::ifft_then_coset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl; if (!d.step) { ifft(data, batch, stride); coset_fft(data, batch, stride); return; }
-  if (batch > 3) throw GpuError("domain: batch > 3"); hipStream_t s = gpu().stream; Fe32 *dbuf = d.scratch.get(), *tmp = d.scratch.get() + 3 * d.B; Fr half; memcpy(&half, d.half.l, 32);
+  if (batch > 3) throw GpuError("domain: batch > 3");
+  hipStream_t s = gpu().stream;
+  Fe32 *dbuf = d.scratch.get(), *tmp = d.scratch.get() + 3 * d.B;
+  Fr half;
+  memcpy(&half, d.half.l, 32);
   { Stage st("ntt.inverse");
-    radix2_transform_pair(NttCall{data, tmp, d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, stride, d.B}, NttCall{data + d.B, dbuf, d.small->itw.get(), d.small->itw261.get(), d.small->logn, d.scale_small.get(), nullptr, d.inv_small261, nullptr, stride, d.B}, batch);
-    hipLaunchKernelGGL(k_step_inv_fwd, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half, (const Fr *)d.coset_fwd.get(), (uint32_t)d.B, (uint32_t)d.S, stride); }
+    radix2_transform_pair(NttCall{data, tmp, d.big->itw.get(), d.big->itw261.get(), d.big->logn, d.scale_big.get(), nullptr, d.inv_big261, nullptr, stride,
+        d.B}, NttCall{data + d.B, dbuf, d.small->itw.get(), d.small->itw261.get(), d.small->logn, d.scale_small.get(), nullptr, d.inv_small261, nullptr,
+        stride, d.B}, batch);
+    hipLaunchKernelGGL(k_step_inv_fwd, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half,
+        (const Fr *)d.coset_fwd.get(), (uint32_t)d.B, (uint32_t)d.S, stride);
+  }
   { Stage st("ntt.forward");
-    radix2_transform_pair(NttCall{data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, NttCall{data + d.B, dbuf, d.small->tw.get(), d.small->tw261.get(), d.small->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, batch); }
+    radix2_transform_pair(NttCall{data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B},
+        NttCall{data + d.B, dbuf, d.small->tw.get(), d.small->tw261.get(), d.small->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, batch);
+  }
 }
 void Domain::coset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl; if (batch > 3) throw GpuError("domain: batch > 3");
-  if (!d.step) { Stage st("ntt.forward"); radix2_transform(NttCall{data, d.scratch.get(), d.big->tw.get(), d.big->tw261.get(), d.big->logn, d.coset_fwd.get(), d.coset_fwd261.get(), d.one261, nullptr, stride, d.scratch_stride}, batch); return; }   // g^i folded into the load
+  // g^i folded into the load
+  if (!d.step) {
+    Stage st("ntt.forward");
+    radix2_transform(NttCall{data, d.scratch.get(), d.big->tw.get(), d.big->tw261.get(), d.big->logn, d.coset_fwd.get(), d.coset_fwd261.get(), d.one261,
+        nullptr, stride, d.scratch_stride}, batch);
+    return;
+  }
   fft_with_factors(data, batch, stride, d.coset_fwd.get());
 }
 void Domain::icoset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl;
   if (!d.step) { Stage st("ntt.inverse");   // coset_inv carries 1/m; it is folded into the store unless the transform is a single pass
-    if (d.big->logn <= NTT_TILE_LOG) { radix2_transform(NttCall{data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.scratch_stride}, batch); mul_table(data, d.coset_inv.get(), d.m, batch, stride); }
-    else radix2_transform(NttCall{data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, nullptr, nullptr, d.one261, d.coset_inv.get(), stride, d.scratch_stride}, batch);
+    if (d.big->logn <= NTT_TILE_LOG) {
+      radix2_transform(NttCall{data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride,
+          d.scratch_stride}, batch);
+      mul_table(data, d.coset_inv.get(), d.m, batch, stride);
+    }
+    else radix2_transform(NttCall{data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, nullptr, nullptr, d.one261, d.coset_inv.get(),
+        stride, d.scratch_stride}, batch);
     return; }
   ifft(data, batch, stride); mul_table(data, d.coset_inv.get(), d.m, batch, stride);
 }
@@ -356,16 +644,27 @@ void Domain::icoset_fft(Fe32 *data, int batch, size_t stride) {
 bool Domain::supports_h_lagrange() const { return true; }
 void Domain::h_query_to_coset_lagrange(const G1AffineRaw *h, size_t n_in, G1AffineRaw *out) {
   Impl &d = *impl; if (n_in > d.m) throw GpuError("domain: h_query_to_coset_lagrange"); hipStream_t s = gpu().stream; const size_t m = d.m;
-  DevBuf<G1AffineRaw> din(n_in ? n_in : 1), dout(m); DevBuf<uint8_t> data(m * sizeof(XYZZ<Fq>)); if (n_in) din.upload(h, n_in); XYZZ<Fq> *X = (XYZZ<Fq> *)data.get();
-  auto idft = [&](XYZZ<Fq> *part, const Radix2Tables &t, Affine<Fq> *o) {   // unscaled inverse DFT over group elements, natural order in, natural order out (bit reversal in the final conversion)
+  DevBuf<G1AffineRaw> din(n_in ? n_in : 1), dout(m);
+  DevBuf<uint8_t> data(m * sizeof(XYZZ<Fq>));
+  if (n_in) din.upload(h, n_in);
+  XYZZ<Fq> *X = (XYZZ<Fq> *)data.get();
+  // unscaled inverse DFT over group elements, natural order in, natural order out (bit reversal in the final conversion)
+  auto idft = [&](XYZZ<Fq> *part, const Radix2Tables &t, Affine<Fq> *o) {
     for (int st = t.logn; st >= 1; st--) hipLaunchKernelGGL(k_ecntt_stage, dim3(cdiv(t.n / 2, 64)), dim3(64), 0, s, part, (const Fr *)t.itw.get(), t.logn, st);
     hipLaunchKernelGGL(k_ecntt_finish, dim3(cdiv(t.n, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)part, t.logn, o); };
-  hipLaunchKernelGGL(k_ecntt_prescale, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)din.get(), (uint32_t)n_in, (const Fr *)d.coset_inv.get(), (uint32_t)m, X);   // basic: g^-i / m; step: g^-i
+  // basic: g^-i / m; step: g^-i
+  hipLaunchKernelGGL(k_ecntt_prescale, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)din.get(), (uint32_t)n_in, (const Fr *)d.coset_inv.get(),
+      (uint32_t)m, X);
   if (!d.step) idft(X, *d.big, (Affine<Fq> *)dout.get());
   else {
     DevBuf<uint8_t> data2(m * sizeof(XYZZ<Fq>)); XYZZ<Fq> *R = (XYZZ<Fq> *)data2.get();
-    HFr ib = HFr::from_u64(d.B).inv(), is = HFr::from_u64(d.S).inv(), hib = d.half * ib, his = d.half * is; Fr f_hib, f_ib, f_his; memcpy(&f_hib, hib.l, 32); memcpy(&f_ib, ib.l, 32); memcpy(&f_his, his.l, 32);
-    hipLaunchKernelGGL(k_ecntt_step_pre, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, R, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), f_hib, f_ib, f_his, (uint32_t)d.B, (uint32_t)d.S);
+    HFr ib = HFr::from_u64(d.B).inv(), is = HFr::from_u64(d.S).inv(), hib = d.half * ib, his = d.half * is;
+    Fr f_hib, f_ib, f_his;
+    memcpy(&f_hib, hib.l, 32);
+    memcpy(&f_ib, ib.l, 32);
+    memcpy(&f_his, his.l, 32);
+    hipLaunchKernelGGL(k_ecntt_step_pre, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, R, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(),
+        f_hib, f_ib, f_his, (uint32_t)d.B, (uint32_t)d.S);
     idft(R, *d.big, (Affine<Fq> *)dout.get()); idft(R + d.B, *d.small, (Affine<Fq> *)dout.get() + d.B);
   }
   HIP_CHECK(hipGetLastError()); dout.download(out, m);
@@ -373,39 +672,74 @@ void Domain::h_query_to_coset_lagrange(const G1AffineRaw *h, size_t n_in, G1Affi
 // see ecntt.cuh: Lstar (n_vars + 1 points) = L extended to all variables minus the C polynomial's share of the H term
 bool Domain::supports_c_fold() const { return true; }
 void Domain::fold_c_into_l(const G1AffineRaw *h_lagrange, const R1csHost &cs, const G1AffineRaw *L, G1AffineRaw *out) {
-  Impl &d = *impl; hipStream_t s = gpu().stream; const size_t m = d.m, n_all = cs.n_vars + 1; const int logm = d.big->logn;   // (step domains: logm is the size of the big part)
+  // (step domains: logm is the size of the big part)
+  Impl &d = *impl;
+  hipStream_t s = gpu().stream;
+  const size_t m = d.m, n_all = cs.n_vars + 1;
+  const int logm = d.big->logn;
   // column form of C; coefficients classified so that +-1 cost an addition only
   std::vector<uint32_t> colptr(n_all + 1, 0); const std::vector<uint32_t> &rp = cs.rowptr[2], &cl = cs.col[2]; size_t nnz = cl.size();
   for (size_t e = 0; e < nnz; e++) colptr[cl[e] + 1]++; for (size_t v = 0; v < n_all; v++) colptr[v + 1] += colptr[v];
-  std::vector<uint32_t> rowidx(nnz ? nnz : 1), fillp(colptr.begin(), colptr.end() - 1); std::vector<uint8_t> kind(nnz ? nnz : 1); std::vector<Fe32> coef(nnz ? nnz : 1);
+  std::vector<uint32_t> rowidx(nnz ? nnz : 1), fillp(colptr.begin(), colptr.end() - 1);
+  std::vector<uint8_t> kind(nnz ? nnz : 1);
+  std::vector<Fe32> coef(nnz ? nnz : 1);
   Fe32 one{}; one.l[0] = 1; Fe32 minus_one; { HFr mo = HFr::one().neg().from_mont(); memcpy(&minus_one, mo.l, 32); }
-  for (size_t k = 0; k < cs.n_cons; k++) for (uint32_t e = rp[k]; e < rp[k + 1]; e++) { uint32_t pos = fillp[cl[e]]++; rowidx[pos] = (uint32_t)k; coef[pos] = cs.coeff[2][e];
+  for (size_t k = 0; k < cs.n_cons; k++) for (uint32_t e = rp[k]; e < rp[k + 1]; e++) {
+    uint32_t pos = fillp[cl[e]]++;
+    rowidx[pos] = (uint32_t)k;
+    coef[pos] = cs.coeff[2][e];
     kind[pos] = !memcmp(&cs.coeff[2][e], &one, 32) ? 0 : !memcmp(&cs.coeff[2][e], &minus_one, 32) ? 1 : 2; }
   DevBuf<uint32_t> d_colptr(n_all + 1), d_rowidx(rowidx.size()); DevBuf<uint8_t> d_kind(kind.size()); DevBuf<Fe32> d_coef(coef.size());
-  d_colptr.upload(colptr.data(), colptr.size()); d_rowidx.upload(rowidx.data(), rowidx.size()); d_kind.upload(kind.data(), kind.size()); d_coef.upload(coef.data(), coef.size());
-  DevBuf<G1AffineRaw> dp(m), dl(cs.n_vars - cs.n_inputs ? cs.n_vars - cs.n_inputs : 1), dout(n_all); dp.upload(h_lagrange, m); if (cs.n_vars > cs.n_inputs) dl.upload(L, cs.n_vars - cs.n_inputs);
+  d_colptr.upload(colptr.data(), colptr.size());
+  d_rowidx.upload(rowidx.data(), rowidx.size());
+  d_kind.upload(kind.data(), kind.size());
+  d_coef.upload(coef.data(), coef.size());
+  DevBuf<G1AffineRaw> dp(m), dl(cs.n_vars - cs.n_inputs ? cs.n_vars - cs.n_inputs : 1), dout(n_all);
+  dp.upload(h_lagrange, m);
+  if (cs.n_vars > cs.n_inputs) dl.upload(L, cs.n_vars - cs.n_inputs);
   DevBuf<uint8_t> b0(m * sizeof(XYZZ<Fq>)), b1(m * sizeof(XYZZ<Fq>)); XYZZ<Fq> *X = (XYZZ<Fq> *)b0.get(), *Y = (XYZZ<Fq> *)b1.get();
-  auto stages = [&](XYZZ<Fq> *x, const Fe32 *tw, int lg) { for (int st = lg; st >= 1; st--) hipLaunchKernelGGL(k_ecntt_stage, dim3(cdiv(((size_t)1 << lg) / 2, 64)), dim3(64), 0, s, x, (const Fr *)tw, lg, st); };
-  auto columns = [&](const XYZZ<Fq> *U, int lg) { hipLaunchKernelGGL(k_fold_c_columns, dim3(cdiv(n_all, 64)), dim3(64), 0, s, d_colptr.get(), d_rowidx.get(), d_kind.get(), (const Fr *)d_coef.get(), U, lg,
+  auto stages = [&](XYZZ<Fq> *x, const Fe32 *tw, int lg) {
+    for (int st = lg; st >= 1; st--) hipLaunchKernelGGL(k_ecntt_stage, dim3(cdiv(((size_t)1 << lg) / 2, 64)), dim3(64), 0, s, x, (const Fr *)tw, lg, st);
+  };
+  auto columns = [&](const XYZZ<Fq> *U, int lg) { hipLaunchKernelGGL(k_fold_c_columns, dim3(cdiv(n_all, 64)), dim3(64), 0, s, d_colptr.get(), d_rowidx.get(),
+      d_kind.get(), (const Fr *)d_coef.get(), U, lg,
                      (const Affine<Fq> *)dl.get(), (uint32_t)cs.n_inputs, (uint32_t)n_all, (Affine<Fq> *)dout.get()); };
   if (!d.step) {
     HFr zinv; { Fe32 z; d.zinv.download(&z, 1); memcpy(zinv.l, &z, 32); } Fr fz; memcpy(&fz, zinv.l, 32);
-    std::vector<Fe32> gm = geometric_table(m, HFr::from_u64(m).inv(), fr_coset_gen()); DevBuf<Fe32> d_gm(m); d_gm.upload(gm.data(), m);                            // g^i / m
-    hipLaunchKernelGGL(k_ecntt_scale_const, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)dp.get(), fz, (uint32_t)m, X);                                  // zinv * P
-    stages(X, d.big->tw.get(), logm);                                                                                                                              // cosetFFT^T = D_g . DFT_w: the DFT ...
-    hipLaunchKernelGGL(k_ecntt_permute_scale, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, (const Fr *)d_gm.get(), logm, Y);                            // ... then g^i, with the 1/m of the inverse transform
-    stages(Y, d.big->itw.get(), logm);                                                                                                                             // iFFT^T = (1/m) DFT_(1/w); result bit-reversed
+    // g^i / m
+    std::vector<Fe32> gm = geometric_table(m, HFr::from_u64(m).inv(), fr_coset_gen());
+    DevBuf<Fe32> d_gm(m);
+    d_gm.upload(gm.data(), m);
+    // zinv * P
+    hipLaunchKernelGGL(k_ecntt_scale_const, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)dp.get(), fz, (uint32_t)m, X);
+    // cosetFFT^T = D_g . DFT_w: the DFT ...
+    stages(X, d.big->tw.get(), logm);
+    // ... then g^i, with the 1/m of the inverse transform
+    hipLaunchKernelGGL(k_ecntt_permute_scale, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, (const Fr *)d_gm.get(), logm, Y);
+    // iFFT^T = (1/m) DFT_(1/w); result bit-reversed
+    stages(Y, d.big->itw.get(), logm);
     columns(Y, logm);
   } else {
     const int lb = d.big->logn, ls = d.small->logn;
-    hipLaunchKernelGGL(k_ecntt_scale_table, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)dp.get(), (const Fr *)d.zinv.get(), (uint32_t)m, X);             // zinv[j] * P_j (divide_by_Z_on_coset is a table here)
-    stages(X, d.big->tw.get(), lb); stages(X + d.B, d.small->tw.get(), ls);                                                                                        // the two DFTs of the forward transform's transpose
-    hipLaunchKernelGGL(k_ecntt_step_fwd_T, dim3(cdiv(d.B, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, (const XYZZ<Fq> *)(X + d.B), lb, ls, (const Fr *)d.wpow.get(), (const Fr *)d.coset_fwd.get(), Y);   // Pre^T and g^i
+    // zinv[j] * P_j (divide_by_Z_on_coset is a table here)
+    hipLaunchKernelGGL(k_ecntt_scale_table, dim3(cdiv(m, 64)), dim3(64), 0, s, (const Affine<Fq> *)dp.get(), (const Fr *)d.zinv.get(), (uint32_t)m, X);
+    // the two DFTs of the forward transform's transpose
+    stages(X, d.big->tw.get(), lb);
+    stages(X + d.B, d.small->tw.get(), ls);
+    // Pre^T and g^i
+    hipLaunchKernelGGL(k_ecntt_step_fwd_T, dim3(cdiv(d.B, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, (const XYZZ<Fq> *)(X + d.B), lb, ls,
+        (const Fr *)d.wpow.get(), (const Fr *)d.coset_fwd.get(), Y);
     // the inverse transform's transpose, as for the H query: Post^T with 1/B, 1/S, then the inverse DFTs of the parts
-    HFr ib = HFr::from_u64(d.B).inv(), is = HFr::from_u64(d.S).inv(), hib = d.half * ib, his = d.half * is; Fr f_hib, f_ib, f_his; memcpy(&f_hib, hib.l, 32); memcpy(&f_ib, ib.l, 32); memcpy(&f_his, his.l, 32);
-    hipLaunchKernelGGL(k_ecntt_step_pre, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)Y, X, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), f_hib, f_ib, f_his, (uint32_t)d.B, (uint32_t)d.S);
+    HFr ib = HFr::from_u64(d.B).inv(), is = HFr::from_u64(d.S).inv(), hib = d.half * ib, his = d.half * is;
+    Fr f_hib, f_ib, f_his;
+    memcpy(&f_hib, hib.l, 32);
+    memcpy(&f_ib, ib.l, 32);
+    memcpy(&f_his, his.l, 32);
+    hipLaunchKernelGGL(k_ecntt_step_pre, dim3(cdiv(m, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)Y, X, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(),
+        f_hib, f_ib, f_his, (uint32_t)d.B, (uint32_t)d.S);
     stages(X, d.big->itw.get(), lb); stages(X + d.B, d.small->itw.get(), ls);
-    hipLaunchKernelGGL(k_ecntt_unpermute, dim3(cdiv(d.B, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, lb, Y); hipLaunchKernelGGL(k_ecntt_unpermute, dim3(cdiv(d.S, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)(X + d.B), ls, Y + d.B);
+    hipLaunchKernelGGL(k_ecntt_unpermute, dim3(cdiv(d.B, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)X, lb, Y);
+    hipLaunchKernelGGL(k_ecntt_unpermute, dim3(cdiv(d.S, 64)), dim3(64), 0, s, (const XYZZ<Fq> *)(X + d.B), ls, Y + d.B);
     columns(Y, 0);
   }
   HIP_CHECK(hipGetLastError()); dout.download(out, n_all);
@@ -413,16 +747,19 @@ void Domain::fold_c_into_l(const G1AffineRaw *h_lagrange, const R1csHost &cs, co
 const Fe32 *Domain::zinv_dev() const { return impl->zinv.get(); }
 bool Domain::zinv_is_table() const { return impl->step; }
 void Domain::qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c) {
-  hipLaunchKernelGGL(k_qap_pointwise, dim3(cdiv(impl->m, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (const Fr *)b, (const Fr *)c, (const Fr *)impl->zinv.get(), impl->step ? 1 : 0, (uint32_t)impl->m);
+  hipLaunchKernelGGL(k_qap_pointwise, dim3(cdiv(impl->m, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (const Fr *)b, (const Fr *)c,
+      (const Fr *)impl->zinv.get(), impl->step ? 1 : 0, (uint32_t)impl->m);
 }
 
 // packed: [ones bitmap | other bitmap | (canon bitmap) | block offsets | values] already on the device (layout of Prover::set_witness / set_witness_tagged).
-// canon: 0 = every value is in Montgomery form, 1 = every value is canonical (the "other" bitmap doubles as the list of values to convert), 2 = a third bitmap says which
+// canon: 0 = every value is in Montgomery form, 1 = every value is canonical (the "other" bitmap doubles as the list of values to convert), 2 = a third bitmap
+// says which
 void expand_witness_dev(const uint8_t *packed, size_t words, const Fe32 &one_value, int canon, size_t n, Fe32 *out, uint8_t *tags, uint32_t *other_vars) {
   const uint64_t *ones = (const uint64_t *)packed, *other = ones + words, *third = other + words; const size_t nbm = canon == 2 ? 3 : 2;
   const uint32_t *off = (const uint32_t *)(ones + nbm * words); const Fr *vals = (const Fr *)(packed + expand_values_offset(words, canon));
   Fr one; memcpy(&one, &one_value, 32);
-  hipLaunchKernelGGL(k_expand_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, ones, other, canon == 0 ? (const uint64_t *)nullptr : canon == 1 ? other : third, off, vals, one, (uint32_t)n, (Fr *)out, tags, other_vars);
+  hipLaunchKernelGGL(k_expand_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, ones, other,
+      canon == 0 ? (const uint64_t *)nullptr : canon == 1 ? other : third, off, vals, one, (uint32_t)n, (Fr *)out, tags, other_vars);
 }
 void fr_to_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_to_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
 void fr_from_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_from_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
@@ -430,12 +767,31 @@ void fr_from_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_from_m
 // ======================================================================================================================
 // R1CS rows
 // ======================================================================================================================
-struct R1csArrays { size_t n_inputs, n_vars, n_cons; DevBuf<uint32_t> rowptr[3], col[3], cid[3], long_rows[3]; size_t n_long[3] = {0, 0, 0}; DevBuf<Fe32> ctab; DevBuf<uint32_t> long_any; size_t n_long_any = 0; };   // immutable per key
+// immutable per key
+struct R1csArrays { size_t n_inputs, n_vars, n_cons; DevBuf<uint32_t> rowptr[3], col[3], cid[3], long_rows[3]; size_t n_long[3] = {0, 0, 0}; DevBuf<Fe32> ctab;
+    DevBuf<uint32_t> long_any; size_t n_long_any = 0; };
 struct R1csDev::Impl {
-  std::shared_ptr<R1csArrays> a; size_t &n_inputs, &n_vars, &n_cons; DevBuf<uint32_t> (&rowptr)[3], (&col)[3], (&cid)[3], (&long_rows)[3]; size_t (&n_long)[3]; DevBuf<Fe32> &ctab; DevBuf<uint32_t> &long_any; size_t &n_long_any;
-  DevBuf<uint32_t> flag; uint32_t *h_flag = nullptr; uint32_t *h_fail = nullptr, *d_fail = nullptr, seq = 0;   // per object.  h_fail: mapped host word the prover's row kernels store the evaluation number to when a constraint is violated
-  explicit Impl(std::shared_ptr<R1csArrays> aa) : a(aa), n_inputs(a->n_inputs), n_vars(a->n_vars), n_cons(a->n_cons), rowptr(a->rowptr), col(a->col), cid(a->cid), long_rows(a->long_rows), n_long(a->n_long), ctab(a->ctab), long_any(a->long_any), n_long_any(a->n_long_any) {}
-  void own_words() { flag = DevBuf<uint32_t>(1); HIP_CHECK(hipHostMalloc((void **)&h_flag, 4)); HIP_CHECK(hipHostMalloc((void **)&h_fail, 4, hipHostMallocMapped)); *h_fail = 0; HIP_CHECK(hipHostGetDevicePointer((void **)&d_fail, h_fail, 0)); }
+  std::shared_ptr<R1csArrays> a;
+  size_t &n_inputs, &n_vars, &n_cons;
+  DevBuf<uint32_t> (&rowptr)[3], (&col)[3], (&cid)[3], (&long_rows)[3];
+  size_t (&n_long)[3];
+  DevBuf<Fe32> &ctab;
+  DevBuf<uint32_t> &long_any;
+  size_t &n_long_any;
+  // per object. h_fail: mapped host word the prover's row kernels store the evaluation number to when a constraint is violated
+  DevBuf<uint32_t> flag;
+  uint32_t *h_flag = nullptr;
+  uint32_t *h_fail = nullptr, *d_fail = nullptr, seq = 0;
+  explicit Impl(std::shared_ptr<R1csArrays> aa) : a(aa), n_inputs(a->n_inputs), n_vars(a->n_vars), n_cons(a->n_cons), rowptr(a->rowptr), col(a->col),
+      cid(a->cid), long_rows(a->long_rows), n_long(a->n_long), ctab(a->ctab), long_any(a->long_any), n_long_any(a->n_long_any) {
+  }
+  void own_words() {
+    flag = DevBuf<uint32_t>(1);
+    HIP_CHECK(hipHostMalloc((void **)&h_flag, 4));
+    HIP_CHECK(hipHostMalloc((void **)&h_fail, 4, hipHostMallocMapped));
+    *h_fail = 0;
+    HIP_CHECK(hipHostGetDevicePointer((void **)&d_fail, h_fail, 0));
+  }
   ~Impl() { if (h_flag) hipHostFree(h_flag); if (h_fail) hipHostFree(h_fail); }
 };
 R1csDev::R1csDev(const R1csDev &peer) : impl(new Impl(peer.impl->a)) { impl->own_words(); }
@@ -463,7 +819,13 @@ R1csDev::R1csDev(const R1csHost &h) : impl(new Impl(std::make_shared<R1csArrays>
     std::vector<uint32_t> lr; for (size_t i = 0; i < h.n_cons; i++) if (h.rowptr[m][i + 1] - h.rowptr[m][i] > R1CS_LONG_ROW) lr.push_back((uint32_t)i);
     d.n_long[m] = lr.size(); d.long_rows[m] = DevBuf<uint32_t>(lr.size() + 1); if (!lr.empty()) d.long_rows[m].upload(lr.data(), lr.size());
   }
-  { std::vector<uint32_t> lr; for (size_t i = 0; i < h.n_cons; i++) { bool lg = false; for (int m = 0; m < 3; m++) lg |= h.rowptr[m][i + 1] - h.rowptr[m][i] > R1CS_LONG_ROW; if (lg) lr.push_back((uint32_t)i); }
+  {
+    std::vector<uint32_t> lr;
+    for (size_t i = 0; i < h.n_cons; i++) {
+      bool lg = false;
+      for (int m = 0; m < 3; m++) lg |= h.rowptr[m][i + 1] - h.rowptr[m][i] > R1CS_LONG_ROW;
+      if (lg) lr.push_back((uint32_t)i);
+    }
     d.n_long_any = lr.size(); d.long_any = DevBuf<uint32_t>(lr.size() + 1); if (!lr.empty()) d.long_any.upload(lr.data(), lr.size()); }
   d.ctab = DevBuf<Fe32>(tab.size()); d.ctab.upload(tab.data(), tab.size()); d.own_words();
 }
@@ -474,19 +836,26 @@ void R1csDev::eval(const Fe32 *z, Fe32 *abc, size_t m, const uint8_t *tags, bool
   if (++d.seq == 0) d.seq = 1;
   if (tags) {   // the assignment came in compact form: a byte per variable says 0 / 1 / other (k_r1cs_rows_tagged)
     const uint32_t sb = (uint32_t)cdiv(m, 256);
-    hipLaunchKernelGGL(k_r1cs_rows_tagged, dim3(sb + (unsigned)cdiv(d.n_long_any, 4)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z, tags, (uint32_t)d.n_cons, (uint32_t)d.n_inputs, (uint32_t)m,
+    hipLaunchKernelGGL(k_r1cs_rows_tagged, dim3(sb + (unsigned)cdiv(d.n_long_any, 4)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z, tags,
+        (uint32_t)d.n_cons, (uint32_t)d.n_inputs, (uint32_t)m,
                        (const uint32_t *)d.long_any.get(), (uint32_t)d.n_long_any, sb, write_c ? 1 : 0, (Fr *)abc, d.seq, d.d_fail);
     return; }
-  if (d.n_long_any) { const uint32_t sb = (uint32_t)cdiv(m, 256);   // rows of more than 16 terms exist: the one-launch form (short rows and one wave per long row) const uint32_t sb = (uint32_t)cdiv(m, 256);
-    hipLaunchKernelGGL(k_r1cs_rows_all, dim3(sb + (unsigned)cdiv(d.n_long_any, 4)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)d.n_cons, (uint32_t)d.n_inputs, (uint32_t)m, (const uint32_t *)d.long_any.get(), (uint32_t)d.n_long_any, sb, (Fr *)abc, d.seq, d.d_fail);
+  // rows of more than 16 terms exist: the one-launch form (short rows and one wave per long row) const uint32_t sb = (uint32_t)cdiv(m, 256);
+  if (d.n_long_any) {
+    const uint32_t sb = (uint32_t)cdiv(m, 256);
+    hipLaunchKernelGGL(k_r1cs_rows_all, dim3(sb + (unsigned)cdiv(d.n_long_any, 4)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z,
+        (uint32_t)d.n_cons, (uint32_t)d.n_inputs, (uint32_t)m, (const uint32_t *)d.long_any.get(), (uint32_t)d.n_long_any, sb, (Fr *)abc, d.seq, d.d_fail);
     return; }
-  hipLaunchKernelGGL(k_r1cs_rows3, dim3(cdiv(m, 256)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)d.n_cons, (uint32_t)d.n_inputs, (uint32_t)m, (Fr *)abc, d.seq, d.d_fail);
-  if (d.n_long_any) hipLaunchKernelGGL(k_r1cs_long_rows3, dim3((unsigned)d.n_long_any), dim3(64), 0, s, d.long_any.get(), M, (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)m, (Fr *)abc, d.seq, d.d_fail);
+  hipLaunchKernelGGL(k_r1cs_rows3, dim3(cdiv(m, 256)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z, (uint32_t)d.n_cons, (uint32_t)d.n_inputs,
+      (uint32_t)m, (Fr *)abc, d.seq, d.d_fail);
+  if (d.n_long_any) hipLaunchKernelGGL(k_r1cs_long_rows3, dim3((unsigned)d.n_long_any), dim3(64), 0, s, d.long_any.get(), M, (const Fr *)d.ctab.get(),
+      (const Fr *)z, (uint32_t)m, (Fr *)abc, d.seq, d.d_fail);
 }
 bool R1csDev::check_result() const { return *impl->h_fail != impl->seq; }   // valid once the main stream has been synchronised after eval()
 bool R1csDev::satisfied(const Fe32 *abc, size_t m) {
   Impl &d = *impl; hipStream_t s = gpu().stream; d.flag.zero();
-  if (d.n_cons) hipLaunchKernelGGL(k_r1cs_check, dim3(cdiv(d.n_cons, 256)), dim3(256), 0, s, (const Fr *)abc, (const Fr *)(abc + m), (const Fr *)(abc + 2 * m), (uint32_t)d.n_cons, d.flag.get());
+  if (d.n_cons) hipLaunchKernelGGL(k_r1cs_check, dim3(cdiv(d.n_cons, 256)), dim3(256), 0, s, (const Fr *)abc, (const Fr *)(abc + m), (const Fr *)(abc + 2 * m),
+      (uint32_t)d.n_cons, d.flag.get());
   HIP_CHECK(hipMemcpyAsync(d.h_flag, d.flag.get(), 4, hipMemcpyDeviceToHost, s)); HIP_CHECK(hipStreamSynchronize(s)); return *d.h_flag == 0;
 }
 

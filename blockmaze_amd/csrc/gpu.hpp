@@ -25,13 +25,18 @@ GpuContext &gpu();                             // lazily initialised process-wid
 int gpu_device_numa_node(int device);            // NUMA node of the socket the device hangs off, -1 unknown (sysfs)
 bool gpu_available();                          // false if no HIP device is visible
 int lane_plan_simulate(int n_slots, int kinds, int per_kind, int *out_lanes_per_slot);   // the lane planner on a private table (CPU tests)
-int gpu_lane_acquire(int device_slot = 0); void gpu_lane_release(int lane); int gpu_lane_current(); void gpu_lane_select(int lane);   // independent stream sets (gpu.hip); a lane belongs to one device of the list below
-// The devices this process works on: ZK_DEVICES = "all" or a comma-separated list of HIP device indices; without it the single device ZK_DEVICE / LOCAL_RANK (default 0)
-// as before.  Slot k of the list is what device_slot arguments mean.  A plain go-ethereum process calling the cgo symbols from many goroutines thereby uses every GPU
-// of the node: the key pool holds provers on each device (capi_zk.cpp) and spreads the callers over them.
+// independent stream sets (gpu.hip); a lane belongs to one device of the list below
+int gpu_lane_acquire(int device_slot = 0);
+void gpu_lane_release(int lane);
+int gpu_lane_current();
+void gpu_lane_select(int lane);
+// The devices this process works on: ZK_DEVICES = "all" or a comma-separated list of HIP device indices; without it the single device ZK_DEVICE / LOCAL_RANK
+// (default 0) as before. Slot k of the list is what device_slot arguments mean. A plain go-ethereum process calling the cgo symbols from many goroutines
+// thereby uses every GPU of the node: the key pool holds provers on each device (capi_zk.cpp) and spreads the callers over them.
 int gpu_device_slots(); int gpu_slot_of_lane(int lane);
 std::vector<int> parse_device_list(const char *spec, int n_visible, int fallback_device);   // pure function (unit-tested on the CPU)
-struct LaneScope { int prev; explicit LaneScope(int lane) : prev(gpu_lane_current()) { gpu_lane_select(lane); } ~LaneScope() { gpu_lane_select(prev); } LaneScope(const LaneScope &) = delete; };
+struct LaneScope { int prev; explicit LaneScope(int lane) : prev(gpu_lane_current()) { gpu_lane_select(lane); } ~LaneScope() { gpu_lane_select(prev);
+    } LaneScope(const LaneScope &) = delete; };
 
 template <class T> class DevBuf {              // RAII device allocation
  public:
@@ -55,31 +60,42 @@ void upload_async(void *dev, const void *pinned_host, size_t bytes);   // on the
 
 // A fixed set of base points resident in HBM (one query of a proving key) plus the reusable MSM workspace for it.
 struct WsortBuffers;                           // the sorted witness digits an MSM leaves for the MSMs over the same scalar vector (msm_impl.hpp)
-// An assignment that arrived in compact form (Prover::set_witness*), as the witness MSMs' sort (msm.cuh: k_wsort_tagged) wants it: device pointers, valid for the run that follows
+// An assignment that arrived in compact form (Prover::set_witness*), as the witness MSMs' sort (msm.cuh: k_wsort_tagged) wants it: device pointers, valid for
+// the run that follows
 struct WitnessTags {
   const uint8_t *tags = nullptr;        // one byte per variable (variable 0 = ONE): 0 the value is zero, 1 it is one, 2 anything else
   const uint32_t *other_vars = nullptr; // the variables tagged 2, ascending
   uint32_t n_other = 0;
-  const uint32_t *var_pos = nullptr;    // indexed queries (B): position of a variable in the query's index list, 0xffffffff if it has no point; null for plain queries
+  // indexed queries (B): position of a variable in the query's index list, 0xffffffff if it has no point; null for plain queries
+  const uint32_t *var_pos = nullptr;
   uint32_t base = 0;                    // plain query: point i belongs to variable base + i; indexed query: first position of this slice of the index list
 };
 class MsmG1 {
  public:
-  MsmG1(const G1AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false);   // tables: precompute 2^(cw) P if the size cap allows; uniform: one-pass sort with overflow fallback (msm_impl.hpp)
-  MsmG1(const MsmG1 &peer, bool filter_ones, bool uniform_scalars);   // shares the peer's resident points / fixed-base table (immutable); owns only its workspace
+  // tables: precompute 2^(cw) P if the size cap allows; uniform: one-pass sort with overflow fallback (msm_impl.hpp)
+  MsmG1(const G1AffineRaw *host_points, size_t n, int window_bits, bool filter_ones, bool fixed_base_tables = true, bool uniform_scalars = false);
+  // shares the peer's resident points / fixed-base table (immutable); owns only its workspace
+  MsmG1(const MsmG1 &peer, bool filter_ones, bool uniform_scalars);
   ~MsmG1();
   // scalars_dev: Fr (Montgomery) on the device.  scalar_index_dev: optional gather map (point i uses scalars[index[i]]).
   // Enqueues the kernels; result() synchronises and finishes the combine on the host.
   void run(const Fe32 *scalars_dev, const uint32_t *scalar_index_dev);
-  // the same with the whole assignment z_all (variable 0 = ONE) and its tags: the three-launch witness path then sorts from the tags (other paths read the scalars as run() does)
+  // the same with the whole assignment z_all (variable 0 = ONE) and its tags: the three-launch witness path then sorts from the tags (other paths read the
+  // scalars as run() does)
   void run_tagged(const Fe32 *z_all_dev, const WitnessTags &wt, const uint32_t *scalar_index_dev);
-  // scalars a_i * b_i * z (z: one element, or a table of n) formed inside the sort kernel; only when one_pass_sort() (uniform-scalar MSM with fixed-base tables)
+  // scalars a_i * b_i * z (z: one element, or a table of n) formed inside the sort kernel; only when one_pass_sort() (uniform-scalar MSM with fixed-base
+  // tables)
   bool one_pass_sort() const; void run_product(const Fe32 *a_dev, const Fe32 *b_dev, const Fe32 *z_dev, bool z_is_table);
   host::HG1 result();
-  // MSMs over the same scalar vector (same length, same window) can share one sort of its digits: the follower must be run after the leader, on the leader's stream
-  // or on another one (it then waits for the leader's event).  false if either side is not on the three-launch witness path.
+  // MSMs over the same scalar vector (same length, same window) can share one sort of its digits: the follower must be run after the leader, on the leader's
+  // stream or on another one (it then waits for the leader's event). false if either side is not on the three-launch witness path.
   std::shared_ptr<WsortBuffers> sort_handle() const; bool share_sort_with(const std::shared_ptr<WsortBuffers> &leader);
-  size_t size() const; const G1AffineRaw *points_dev() const; void set_label(const char *l); void set_stream(int aux /* -1 main, 0..3 auxiliary */); void split_ones_path();   // split: the scalar-one sum runs on a stream of its own beside the bucket path
+  // split: the scalar-one sum runs on a stream of its own beside the bucket path
+  size_t size() const;
+  const G1AffineRaw *points_dev() const;
+  void set_label(const char *l);
+  void set_stream(int aux /* -1 main, 0..3 auxiliary */);
+  void split_ones_path();
   struct Impl; std::unique_ptr<Impl> impl;
 };
 class MsmG2 {
@@ -97,10 +113,12 @@ class MsmG2 {
 // Batched Groth16 verification on the GPU (kernel K9, pairing.cuh): one lane per proof, the key-dependent tables and the verification program resident in HBM.
 class BatchVerifier {
  public:
-  BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2AffineRaw &gamma_g2, const G2AffineRaw &delta_g2, const G1AffineRaw *ic, size_t n_ic);   // all Montgomery, affine
+  // all Montgomery, affine
+  BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2AffineRaw &gamma_g2, const G2AffineRaw &delta_g2, const G1AffineRaw *ic, size_t n_ic);
   ~BatchVerifier();
   size_t num_inputs() const; size_t program_length() const;
-  // proofs_mont: n records of 256 bytes (A.x A.y | B.x.c0 B.x.c1 B.y.c0 B.y.c1 | C.x C.y, Montgomery); inputs: n * num_inputs() canonical field elements; ok[i] = 1 accept / 0 reject
+  // proofs_mont: n records of 256 bytes (A.x A.y | B.x.c0 B.x.c1 B.y.c0 B.y.c1 | C.x C.y, Montgomery); inputs: n * num_inputs() canonical field elements; ok[i]
+  // = 1 accept / 0 reject
   void verify(const void *proofs_mont, const Fe32 *inputs_canonical, size_t n, uint8_t *ok);
   struct Impl; std::unique_ptr<Impl> impl;
 };
@@ -115,12 +133,16 @@ class Domain {
   // in place on `batch` device vectors of m elements each, `stride` elements apart (Montgomery form)
   void fft(Fe32 *data, int batch, size_t stride); void ifft(Fe32 *data, int batch, size_t stride);
   void coset_fft(Fe32 *data, int batch, size_t stride); void icoset_fft(Fe32 *data, int batch, size_t stride);
-  void ifft_then_coset_fft(Fe32 *data, int batch, size_t stride);   // = ifft(); coset_fft(); on a step domain the passes between the two transforms are one kernel
+  // = ifft(); coset_fft(); on a step domain the passes between the two transforms are one kernel
+  void ifft_then_coset_fft(Fe32 *data, int batch, size_t stride);
  private: void fft_with_factors(Fe32 *data, int batch, size_t stride, const Fe32 *factors); public:
-  // key load: the H query (n_in = m - 1 affine points) re-expressed so that sum_j v_j out_j = sum_i icosetFFT(v)_i h_i: the prover then skips the last transform (ecntt.cuh)
+  // key load: the H query (n_in = m - 1 affine points) re-expressed so that sum_j v_j out_j = sum_i icosetFFT(v)_i h_i: the prover then skips the last
+  // transform (ecntt.cuh)
   bool supports_h_lagrange() const; void h_query_to_coset_lagrange(const G1AffineRaw *h, size_t n_in, G1AffineRaw *out /* m points */);
-  // key load, radix-2 domains: out (n_vars + 1 points) = the L query extended to all variables minus the C polynomial's share of the H term; the prover then transforms A and B only (ecntt.cuh)
-  bool supports_c_fold() const; void fold_c_into_l(const G1AffineRaw *h_lagrange /* m */, const R1csHost &cs, const G1AffineRaw *L /* n_vars - n_inputs */, G1AffineRaw *out);
+  // key load, radix-2 domains: out (n_vars + 1 points) = the L query extended to all variables minus the C polynomial's share of the H term; the prover then
+  // transforms A and B only (ecntt.cuh)
+  bool supports_c_fold() const;
+  void fold_c_into_l(const G1AffineRaw *h_lagrange /* m */, const R1csHost &cs, const G1AffineRaw *L /* n_vars - n_inputs */, G1AffineRaw *out);
   // a = (a*b - c) / Z on the coset (c may be null: a = a*b / Z); zinv_dev(): 1/Z on the coset, one element or (step domains) a table of m
   const Fe32 *zinv_dev() const; bool zinv_is_table() const;
   void qap_pointwise(Fe32 *a, const Fe32 *b, const Fe32 *c);
@@ -136,19 +158,26 @@ class R1csDev {
  public:
   explicit R1csDev(const R1csHost &h); explicit R1csDev(const R1csDev &peer); ~R1csDev();   // the copy shares the CSR arrays and owns its failure word
   // z_dev: n_vars+1 Fr (Montgomery, z[0] = 1).  abc: 3 vectors of m (zero padded, aA[n_cons + i] = z_i for i <= n_inputs; r1cs_to_qap.tcc:227-230)
-  void eval(const Fe32 *z_dev, Fe32 *abc, size_t m, const uint8_t *tags_dev = nullptr, bool write_c = true);   // tags: one byte per variable (0 / 1 / 2 = other) when the assignment came in compact form; write_c = false: the C vector is not stored (it is folded into the L query)
+  // tags: one byte per variable (0 / 1 / 2 = other) when the assignment came in compact form; write_c = false: the C vector is not stored (it is folded into
+  // the L query)
+  void eval(const Fe32 *z_dev, Fe32 *abc, size_t m, const uint8_t *tags_dev = nullptr, bool write_c = true);
   bool satisfied(const Fe32 *abc, size_t m);    // synchronises
-  bool check_result() const;                    // eval() also tests a*b == c row by row; true if the last eval() found every constraint satisfied (read after the main stream has been synchronised)
+  // eval() also tests a*b == c row by row; true if the last eval() found every constraint satisfied (read after the main stream has been synchronised)
+  bool check_result() const;
   struct Impl; std::unique_ptr<Impl> impl;
 };
 
 void fr_to_mont_dev(Fe32 *a, size_t n); void fr_from_mont_dev(Fe32 *a, size_t n);
-// compact assignment upload (ntt.cuh: k_expand_witness).  packed = [ones bitmap | other bitmap | (canon bitmap, canon == 2) | block offsets | values at expand_values_offset()];
-// canon: 0 all values in Montgomery form, 1 all canonical, 2 the third bitmap says which are canonical.  tags_out / other_vars_out: see WitnessTags
+// compact assignment upload (ntt.cuh: k_expand_witness). packed = [ones bitmap | other bitmap | (canon bitmap, canon == 2) | block offsets | values at
+// expand_values_offset()]; canon: 0 all values in Montgomery form, 1 all canonical, 2 the third bitmap says which are canonical. tags_out / other_vars_out: see
+// WitnessTags
 inline size_t expand_values_offset(size_t words, int canon) { return (((canon == 2 ? 28 : 20) * words + 31) / 32) * 32; }
-void expand_witness_dev(const uint8_t *packed_dev, size_t words, const Fe32 &one_value, int canon, size_t n, Fe32 *out, uint8_t *tags_out = nullptr, uint32_t *other_vars_out = nullptr);   // compact assignment upload (ntt.cuh: k_expand_witness)
+// compact assignment upload (ntt.cuh: k_expand_witness)
+void expand_witness_dev(const uint8_t *packed_dev, size_t words, const Fe32 &one_value, int canon, size_t n, Fe32 *out, uint8_t *tags_out = nullptr,
+    uint32_t *other_vars_out = nullptr);
 
-// Key loading: y-coordinates of compressed points (x Montgomery; flags bit0 = parity of canonical y, bit1 = point at infinity).  Throws if an x is not on the curve.
+// Key loading: y-coordinates of compressed points (x Montgomery; flags bit0 = parity of canonical y, bit1 = point at infinity). Throws if an x is not on the
+// curve.
 void decompress_g1(const Fe32 *xs, const uint8_t *flags, size_t n, G1AffineRaw *out);
 void decompress_g2(const Fe32 *xs /* 2 per point */, const uint8_t *flags, size_t n, G2AffineRaw *out);
 // Key generation: out[i] = scalars[i] * base (scalars canonical), results affine Montgomery
@@ -157,7 +186,9 @@ void fixed_base_mul_g2(const host::HG2 &base, const Fe32 *scalars, size_t n, G2A
 void gpu_sync();            // all streams
 void gpu_fork_aux();        // auxiliary streams wait for everything queued on the main stream so far
 void gpu_fork_one(int aux); // the same for one auxiliary stream
-void gpu_fork_record(); void gpu_fork_wait(int aux);   // the two halves of a fork: record the point on the main stream once, let each auxiliary stream wait for it (from any thread)
+// the two halves of a fork: record the point on the main stream once, let each auxiliary stream wait for it (from any thread)
+void gpu_fork_record();
+void gpu_fork_wait(int aux);
 void gpu_join_aux();        // the main stream waits for everything queued on the auxiliary streams
 bool profiling_enabled();
 // per-stage device timing (HIP events on the compute stream); report = JSON object {stage: {ms_total, count}}

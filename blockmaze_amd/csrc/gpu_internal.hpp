@@ -1,4 +1,5 @@
-// Shared by the HIP translation units of libzkgpu (gpu.hip, gpu_msm_g1.hip, gpu_msm_g2.hip, gpu_keyops.hip): device context, error macro, scan helper, stage timer.
+// Shared by the HIP translation units of libzkgpu (gpu.hip, gpu_msm_g1.hip, gpu_msm_g2.hip, gpu_keyops.hip): device context, error macro, scan helper, stage
+// timer.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdlib>
@@ -12,21 +13,31 @@ namespace zk {
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw GpuError(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 class GpuContext {
  public:
-  int device = 0; hipStream_t stream = nullptr; hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t fork_event = nullptr; hipEvent_t join_event[4] = {nullptr, nullptr, nullptr, nullptr}; hipDeviceProp_t prop;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t fork_event = nullptr;
+  hipEvent_t join_event[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipDeviceProp_t prop;
   explicit GpuContext(int device_index) {
     // (GPU_MAX_HW_QUEUES is raised by the library constructor in gpu.hip, before any HIP call of this process can have read it)
-    int n = 0; if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw GpuError("no HIP device visible: the prover's HIP path cannot run (there is no CPU fallback)");
     device = device_index % n;
     HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipGetDeviceProperties(&prop, device));
-    // (measured and dropped: a high-priority main stream and low-priority auxiliary streams (1-2 % slower), and confining the auxiliary streams to 32-128 CUs with
-    // hipExtStreamCreateWithCUMask — profiles/r03h_ab_cumask.txt: the transforms are not slowed by sharing SIMDs, the proof is bound by VALU issue as a whole)
-    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
-    HIP_CHECK(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming)); for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&join_event[i], hipEventDisableTiming));
+    // (measured and dropped: a high-priority main stream and low-priority auxiliary streams (1-2 % slower), and confining the auxiliary streams to 32-128 CUs
+    // with hipExtStreamCreateWithCUMask — profiles/r03h_ab_cumask.txt: the transforms are not slowed by sharing SIMDs, the proof is bound by VALU issue as a
+    // whole)
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) HIP_CHECK(hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming));
+    for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreateWithFlags(&join_event[i], hipEventDisableTiming));
   }
 };
 GpuContext &gpu();
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
-struct Stage { size_t id; explicit Stage(const char *n, hipStream_t st = nullptr); ~Stage(); };   // optional HIP-event timing of a pipeline stage (bench.py's roofline leg)
+// optional HIP-event timing of a pipeline stage (bench.py's roofline leg)
+struct Stage { size_t id; explicit Stage(const char *n, hipStream_t st = nullptr); ~Stage(); };
 
 // exclusive scan of a uint32 array on the stream
 struct Scanner {

@@ -6,7 +6,11 @@ MsmG1::MsmG1(const G1AffineRaw *p, size_t n, int c, bool fo, bool tables, bool u
 MsmG1::MsmG1(const MsmG1 &peer, bool fo, bool uniform) : impl(new Impl(peer.impl->bases, fo, uniform)) {}
 MsmG1::~MsmG1() = default;
 std::shared_ptr<WsortBuffers> MsmG1::sort_handle() const { return impl->wfused && impl->ws_leader ? impl->ws : nullptr; }
-bool MsmG1::share_sort_with(const std::shared_ptr<WsortBuffers> &leader) { if (!impl->wfused || !leader || leader->NB != impl->NB || leader->n != impl->n) return false; impl->share_sort(leader); return true; }
+bool MsmG1::share_sort_with(const std::shared_ptr<WsortBuffers> &leader) {
+  if (!impl->wfused || !leader || leader->NB != impl->NB || leader->n != impl->n) return false;
+  impl->share_sort(leader);
+  return true;
+}
 void MsmG1::run(const Fe32 *s, const uint32_t *idx) { impl->run(s, idx); }
 void MsmG1::run_tagged(const Fe32 *z_all, const WitnessTags &wt, const uint32_t *idx) { impl->run_tagged(z_all, wt, idx); }
 bool MsmG1::one_pass_sort() const { return impl->hsort; }

@@ -1,4 +1,5 @@
-// Host driver of the batched GPU verifier (kernel K9, pairing.cuh): assembles the bytecode and the per-key tables once, then checks any number of proofs per launch.
+// Host driver of the batched GPU verifier (kernel K9, pairing.cuh): assembles the bytecode and the per-key tables once, then checks any number of proofs per
+// launch.
 #include <atomic>
 #include <cstring>
 #include <memory>
@@ -15,16 +16,38 @@ static const uint64_t BN_Z = 4965661367192848881ull;                         // 
 static const uint64_t ATE_LOOP[2] = {0x9d797039be763ba8ull, 0x1ull};          // 6z+2 (alt_bn128_init.cpp:324)
 
 // typed view of a byte allocation (DevBuf is instantiated for the raw interface types only)
-template <class T> struct DevArr { DevBuf<uint8_t> b; DevArr() = default; explicit DevArr(size_t n) : b(n * sizeof(T)) {} T *get() const { return (T *)b.get(); }
+template <class T> struct DevArr { DevBuf<uint8_t> b; DevArr() = default; explicit DevArr(size_t n) : b(n * sizeof(T)) {} T *get() const { return (T *)b.get();
+    }
   void upload(const T *h, size_t n) { b.upload((const uint8_t *)h, n * sizeof(T)); } };
-// One small verification in flight: its own stream, pinned staging and device buffers for up to CTX_CAP proofs — go-ethereum's verifyXproof calls arrive one proof at a
-// time from many threads, and a proof occupies ONE compute unit for ~2 ms: several contexts let them overlap instead of queueing behind one stream.
+// One small verification in flight: its own stream, pinned staging and device buffers for up to CTX_CAP proofs — go-ethereum's verifyXproof calls arrive one
+// proof at a time from many threads, and a proof occupies ONE compute unit for ~2 ms: several contexts let them overlap instead of queueing behind one stream.
 struct VerifyCtx { std::mutex m; hipStream_t s = nullptr; uint8_t *h = nullptr; DevBuf<uint8_t> d; };
 struct BatchVerifier::Impl {
-  size_t n_inputs = 0; DevBuf<uint32_t> sched_prog, sched_consts; SchedInfo si{}; DevBuf<uint32_t> prog; DevArr<EllCoeffsDev> gamma, delta; DevArr<FrobeniusDev> frob; DevArr<Fq12> alpha_beta; DevArr<Affine<Fq>> tables; Affine<Fq> ic0; VerifyConsts K; size_t prog_len = 0;
+  size_t n_inputs = 0;
+  DevBuf<uint32_t> sched_prog, sched_consts;
+  SchedInfo si{};
+  DevBuf<uint32_t> prog;
+  DevArr<EllCoeffsDev> gamma, delta;
+  DevArr<FrobeniusDev> frob;
+  DevArr<Fq12> alpha_beta;
+  DevArr<Affine<Fq>> tables;
+  Affine<Fq> ic0;
+  VerifyConsts K;
+  size_t prog_len = 0;
   static constexpr size_t CTX_CAP = 64; std::vector<std::unique_ptr<VerifyCtx>> ctxs; std::atomic<unsigned> next_ctx{0}; std::mutex big; size_t lds = 0;
   // layout of a context's staging area (host and device alike): proofs | inputs | -acc | verdicts
-  size_t off_in() const { return CTX_CAP * sizeof(VerifyItem); } size_t off_acc() const { return off_in() + CTX_CAP * (n_inputs + 1) * sizeof(Fe32); } size_t off_ok() const { return off_acc() + CTX_CAP * sizeof(NegAcc3); } size_t ctx_bytes() const { return off_ok() + CTX_CAP; }
+  size_t off_in() const {
+    return CTX_CAP * sizeof(VerifyItem);
+  }
+  size_t off_acc() const {
+    return off_in() + CTX_CAP * (n_inputs + 1) * sizeof(Fe32);
+  }
+  size_t off_ok() const {
+    return off_acc() + CTX_CAP * sizeof(NegAcc3);
+  }
+  size_t ctx_bytes() const {
+    return off_ok() + CTX_CAP;
+  }
   ~Impl() { for (auto &c : ctxs) { if (c->h) hipHostFree(c->h); if (c->s) hipStreamDestroy(c->s); } }
 };
 
@@ -35,7 +58,17 @@ enum { rF = 0, rT = 1, r2 = 2, r3 = 3, r4 = 4, r5 = 5, r6 = 6, r7 = 7, r8 = 8, r
 // the same group element as libff's binary cyclotomic_exp (fp12_2over3over2.tcc:337-365).  Uses r9 (accumulator), r11 (src^3), rT (scratch).
 enum { r11 = 11 };
 static void emit_exp_neg_z(std::vector<uint32_t> &p, uint32_t dst, uint32_t src) {
-  std::vector<int> dig; for (uint64_t k = BN_Z; k;) { int t = 0; if (k & 1) { t = (int)(k & 7); if (t >= 4) t -= 8; k -= (uint64_t)(int64_t)t; } dig.push_back(t); k >>= 1; }
+  std::vector<int> dig;
+  for (uint64_t k = BN_Z; k;) {
+    int t = 0;
+    if (k & 1) {
+      t = (int)(k & 7);
+      if (t >= 4) t -= 8;
+      k -= (uint64_t)(int64_t)t;
+    }
+    dig.push_back(t);
+    k >>= 1;
+  }
   p.push_back(vm_ins(VM_CYCSQR, rT, src, 0)); p.push_back(vm_ins(VM_MUL, r11, rT, src)); bool started = false;
   for (size_t i = dig.size(); i-- > 0;) { int d = dig[i];
     if (started) p.push_back(vm_ins(VM_CYCSQR, r9, r9, 0));
@@ -47,59 +80,138 @@ static void emit_exp_neg_z(std::vector<uint32_t> &p, uint32_t dst, uint32_t src)
 }
 static std::vector<uint32_t> assemble_program(size_t n_lines) {
   std::vector<uint32_t> p; uint32_t idx = 0; bool found = false;
-  auto lines = [&] { p.push_back(vm_ins(VM_MUL024, rF, rF, rT)); p.push_back(vm_ins(VM_LINE, rT, 1, idx)); p.push_back(vm_ins(VM_MUL024, rF, rF, rT)); p.push_back(vm_ins(VM_LINE, rT, 2, idx)); p.push_back(vm_ins(VM_MUL024, rF, rF, rT)); idx++; };
+  auto lines = [&] {
+    p.push_back(vm_ins(VM_MUL024, rF, rF, rT));
+    p.push_back(vm_ins(VM_LINE, rT, 1, idx));
+    p.push_back(vm_ins(VM_MUL024, rF, rF, rT));
+    p.push_back(vm_ins(VM_LINE, rT, 2, idx));
+    p.push_back(vm_ins(VM_MUL024, rF, rF, rT));
+    idx++;
+  };
   p.push_back(vm_ins(VM_ONE, rF, 0, 0)); p.push_back(vm_ins(VM_ONE, rONE, 0, 0));
-  for (int i = 127; i >= 0; i--) { bool bit = (ATE_LOOP[i / 64] >> (i % 64)) & 1; if (!found) { found |= bit; continue; }                      // miller_loop :368-418 / precomputation :305-366
+  // miller_loop :368-418 / precomputation :305-366
+  for (int i = 127; i >= 0; i--) {
+    bool bit = (ATE_LOOP[i / 64] >> (i % 64)) & 1;
+    if (!found) {
+      found |= bit;
+      continue;
+    }
     p.push_back(vm_ins(VM_MUL, rF, rF, rF)); p.push_back(vm_ins(VM_DBL, rT, 0, 0)); lines();
     if (bit) { p.push_back(vm_ins(VM_ADD, rT, 0, 0)); lines(); } }
   p.push_back(vm_ins(VM_ADD, rT, 0, 1)); lines(); p.push_back(vm_ins(VM_ADD, rT, 0, 2)); lines();
   if (idx != n_lines || idx > 255) throw GpuError("verify: line count");
   // final_exponentiation :110-238 (first chunk :110-129, last chunk :131-238)
-  p.push_back(vm_ins(VM_CONJ, r3, rF, 0)); p.push_back(vm_ins(VM_INV, r4, rF, 0)); p.push_back(vm_ins(VM_MUL, r3, r3, r4));                 // C0 = conj(f) * f^-1
-  p.push_back(vm_ins(VM_FROB, r4, r3, 2)); p.push_back(vm_ins(VM_MUL, r2, r4, r3));                                                          // first = C0^(q^2) * C0
+  // C0 = conj(f) * f^-1
+  p.push_back(vm_ins(VM_CONJ, r3, rF, 0));
+  p.push_back(vm_ins(VM_INV, r4, rF, 0));
+  p.push_back(vm_ins(VM_MUL, r3, r3, r4));
+  // first = C0^(q^2) * C0
+  p.push_back(vm_ins(VM_FROB, r4, r3, 2));
+  p.push_back(vm_ins(VM_MUL, r2, r4, r3));
   emit_exp_neg_z(p, r3, r2);                                                                                                                   // A
-  p.push_back(vm_ins(VM_CYCSQR, r4, r3, 0)); p.push_back(vm_ins(VM_CYCSQR, r5, r4, 0)); p.push_back(vm_ins(VM_MUL, r6, r5, r4));                  // B = A^2, C = B^2, D = C*B
+  // B = A^2, C = B^2, D = C*B
+  p.push_back(vm_ins(VM_CYCSQR, r4, r3, 0));
+  p.push_back(vm_ins(VM_CYCSQR, r5, r4, 0));
+  p.push_back(vm_ins(VM_MUL, r6, r5, r4));
   emit_exp_neg_z(p, r7, r6);                                                                                                                   // E
   p.push_back(vm_ins(VM_CYCSQR, r5, r7, 0)); emit_exp_neg_z(p, r8, r5);                                                                          // F = E^2, G
-  p.push_back(vm_ins(VM_CONJ, r6, r6, 0)); p.push_back(vm_ins(VM_CONJ, r8, r8, 0));                                                            // H = conj(D), I = conj(G)
-  p.push_back(vm_ins(VM_MUL, r8, r8, r7)); p.push_back(vm_ins(VM_MUL, r8, r8, r6));                                                            // J = I*E, K = J*H
-  p.push_back(vm_ins(VM_MUL, r6, r8, r4)); p.push_back(vm_ins(VM_MUL, r7, r8, r7)); p.push_back(vm_ins(VM_MUL, r7, r7, r2));                  // L = K*B, M = K*E, N = M*first
-  p.push_back(vm_ins(VM_FROB, r4, r6, 1)); p.push_back(vm_ins(VM_MUL, r4, r4, r7));                                                            // O = L^q, P = O*N
-  p.push_back(vm_ins(VM_FROB, r5, r8, 2)); p.push_back(vm_ins(VM_MUL, r4, r5, r4));                                                            // Q = K^(q^2), R = Q*P
-  p.push_back(vm_ins(VM_CONJ, r2, r2, 0)); p.push_back(vm_ins(VM_MUL, r2, r2, r6)); p.push_back(vm_ins(VM_FROB, r2, r2, 3));                  // S = conj(first), T = S*L, U = T^(q^3)
+  // H = conj(D), I = conj(G)
+  p.push_back(vm_ins(VM_CONJ, r6, r6, 0));
+  p.push_back(vm_ins(VM_CONJ, r8, r8, 0));
+  // J = I*E, K = J*H
+  p.push_back(vm_ins(VM_MUL, r8, r8, r7));
+  p.push_back(vm_ins(VM_MUL, r8, r8, r6));
+  // L = K*B, M = K*E, N = M*first
+  p.push_back(vm_ins(VM_MUL, r6, r8, r4));
+  p.push_back(vm_ins(VM_MUL, r7, r8, r7));
+  p.push_back(vm_ins(VM_MUL, r7, r7, r2));
+  // O = L^q, P = O*N
+  p.push_back(vm_ins(VM_FROB, r4, r6, 1));
+  p.push_back(vm_ins(VM_MUL, r4, r4, r7));
+  // Q = K^(q^2), R = Q*P
+  p.push_back(vm_ins(VM_FROB, r5, r8, 2));
+  p.push_back(vm_ins(VM_MUL, r4, r5, r4));
+  // S = conj(first), T = S*L, U = T^(q^3)
+  p.push_back(vm_ins(VM_CONJ, r2, r2, 0));
+  p.push_back(vm_ins(VM_MUL, r2, r2, r6));
+  p.push_back(vm_ins(VM_FROB, r2, r2, 3));
   p.push_back(vm_ins(VM_MUL, rF, r2, r4)); p.push_back(vm_ins(VM_END, 0, 0, 0)); return p;                                                     // result = U*R
 }
 template <class T, class H> static T to_dev(const H &h) { static_assert(sizeof(T) == sizeof(H), "layout"); T t; memcpy(&t, &h, sizeof(T)); return t; }
 
-BatchVerifier::BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2AffineRaw &gamma_g2, const G2AffineRaw &delta_g2, const G1AffineRaw *ic, size_t n_ic) : impl(new Impl) {
+BatchVerifier::BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2AffineRaw &gamma_g2, const G2AffineRaw &delta_g2, const G1AffineRaw *ic,
+    size_t n_ic) : impl(new Impl) {
   Impl &d = *impl; if (n_ic < 1 || n_ic > 17) throw GpuError("verify: IC size"); d.n_inputs = n_ic - 1;
   auto fq2_of = [](const Fe32 &a, const Fe32 &b) { HFq2 r; memcpy(r.c0.l, &a, 32); memcpy(r.c1.l, &b, 32); return r; };
-  host::G2Precomp pg = host::precompute_g2(fq2_of(gamma_g2.x0, gamma_g2.x1), fq2_of(gamma_g2.y0, gamma_g2.y1)), pd = host::precompute_g2(fq2_of(delta_g2.x0, delta_g2.x1), fq2_of(delta_g2.y0, delta_g2.y1));
-  std::vector<EllCoeffsDev> lg(pg.size()), ld(pd.size()); for (size_t i = 0; i < pg.size(); i++) { lg[i] = to_dev<EllCoeffsDev>(pg[i]); ld[i] = to_dev<EllCoeffsDev>(pd[i]); }
-  d.gamma = DevArr<EllCoeffsDev>(lg.size()); d.gamma.upload(lg.data(), lg.size()); d.delta = DevArr<EllCoeffsDev>(ld.size()); d.delta.upload(ld.data(), ld.size());
+  host::G2Precomp pg = host::precompute_g2(fq2_of(gamma_g2.x0, gamma_g2.x1), fq2_of(gamma_g2.y0, gamma_g2.y1)), pd = host::precompute_g2(fq2_of(delta_g2.x0,
+      delta_g2.x1), fq2_of(delta_g2.y0, delta_g2.y1));
+  std::vector<EllCoeffsDev> lg(pg.size()), ld(pd.size());
+  for (size_t i = 0; i < pg.size(); i++) {
+    lg[i] = to_dev<EllCoeffsDev>(pg[i]);
+    ld[i] = to_dev<EllCoeffsDev>(pd[i]);
+  }
+  d.gamma = DevArr<EllCoeffsDev>(lg.size());
+  d.gamma.upload(lg.data(), lg.size());
+  d.delta = DevArr<EllCoeffsDev>(ld.size());
+  d.delta.upload(ld.data(), ld.size());
   { vsched::Schedule sc = vsched::build(alpha_g1_beta_g2, pg, pd);   // the workgroup-per-proof kernel's schedule (verify_sched.hpp)
     sc.prog.resize(sc.prog.size() + 4 + 256 * vsched::WPL, 0u);   // (the kernel prefetches one round ahead: one round's worth of padding)
     const std::vector<uint32_t> c29 = vsched::consts29(sc);
-    d.sched_prog = DevBuf<uint32_t>(sc.prog.size()); d.sched_prog.upload(sc.prog.data(), sc.prog.size()); d.sched_consts = DevBuf<uint32_t>(c29.size()); d.sched_consts.upload(c29.data(), c29.size());
-    d.si.n_rounds = sc.n_rounds; d.si.n_slots = sc.n_slots; d.si.n_consts = (uint32_t)sc.consts.size(); for (int k = 0; k < 16; k++) d.si.out_slot[k] = sc.out_slot[k];
-    d.lds = ((size_t)sc.n_slots + sc.consts.size()) * l29::STRIDE * 4; if (d.lds > 160 * 1024) throw GpuError("verify: the schedule needs more LDS than a CU has");
-    static std::once_flag attr; std::call_once(attr, [&] { HIP_CHECK(hipFuncSetAttribute((const void *)k_verify_sched29, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }); }
+    d.sched_prog = DevBuf<uint32_t>(sc.prog.size());
+    d.sched_prog.upload(sc.prog.data(), sc.prog.size());
+    d.sched_consts = DevBuf<uint32_t>(c29.size());
+    d.sched_consts.upload(c29.data(), c29.size());
+    d.si.n_rounds = sc.n_rounds;
+    d.si.n_slots = sc.n_slots;
+    d.si.n_consts = (uint32_t)sc.consts.size();
+    for (int k = 0; k < 16; k++) d.si.out_slot[k] = sc.out_slot[k];
+    d.lds = ((size_t)sc.n_slots + sc.consts.size()) * l29::STRIDE * 4;
+    if (d.lds > 160 * 1024) throw GpuError("verify: the schedule needs more LDS than a CU has");
+    static std::once_flag attr;
+    std::call_once(attr, [&] { HIP_CHECK(hipFuncSetAttribute((const void *)k_verify_sched29, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+  }
   { static const int n_ctx = [] { const char *e = getenv("ZK_VERIFY_STREAMS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : v > 32 ? 32 : v; }();
-    for (int k = 0; k < n_ctx; k++) { std::unique_ptr<VerifyCtx> c(new VerifyCtx); HIP_CHECK(hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking)); HIP_CHECK(hipHostMalloc((void **)&c->h, d.ctx_bytes())); c->d = DevBuf<uint8_t>(d.ctx_bytes()); d.ctxs.push_back(std::move(c)); } }
-  std::vector<uint32_t> prog = assemble_program(pg.size()); d.prog_len = prog.size(); d.prog = DevBuf<uint32_t>(prog.size()); d.prog.upload(prog.data(), prog.size());
+    for (int k = 0; k < n_ctx; k++) {
+      std::unique_ptr<VerifyCtx> c(new VerifyCtx);
+      HIP_CHECK(hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking));
+      HIP_CHECK(hipHostMalloc((void **)&c->h, d.ctx_bytes()));
+      c->d = DevBuf<uint8_t>(d.ctx_bytes());
+      d.ctxs.push_back(std::move(c));
+    }
+  }
+  std::vector<uint32_t> prog = assemble_program(pg.size());
+  d.prog_len = prog.size();
+  d.prog = DevBuf<uint32_t>(prog.size());
+  d.prog.upload(prog.data(), prog.size());
   FrobeniusDev fr = to_dev<FrobeniusDev>(host::frobenius_tables()); d.frob = DevArr<FrobeniusDev>(1); d.frob.upload(&fr, 1);
   Fq12 ab = to_dev<Fq12>(alpha_g1_beta_g2); d.alpha_beta = DevArr<Fq12>(1); d.alpha_beta.upload(&ab, 1);
-  HFq2 tb = HFq2{HFq::from_u64(3), HFq::zero()} * HFq2{HFq::from_u64(9), HFq::one()}.inv(); d.K.twist_b = to_dev<Fq2>(tb); d.K.two_inv = to_dev<Fq>(HFq::from_u64(2).inv());
+  HFq2 tb = HFq2{HFq::from_u64(3), HFq::zero()} * HFq2{HFq::from_u64(9), HFq::one()}.inv();
+  d.K.twist_b = to_dev<Fq2>(tb);
+  d.K.two_inv = to_dev<Fq>(HFq::from_u64(2).inv());
   memcpy(&d.ic0, &ic[0], sizeof(G1AffineRaw));
   // window tables of IC[1..]: table[j][w*255 + (dgt-1)] = dgt * 2^(8w) * IC[j+1], affine; one batch inversion per point
   std::vector<G1AffineRaw> tab(d.n_inputs * 32 * 255 + 1);
   for (size_t j = 0; j < d.n_inputs; j++) {
-    HFq x, y; memcpy(x.l, &ic[j + 1].x, 32); memcpy(y.l, &ic[j + 1].y, 32); HG1 wbase = (x.is_zero() && y.is_zero()) ? HG1::inf() : HG1::from_affine(x, y); std::vector<HG1> pts(32 * 255);
+    HFq x, y;
+    memcpy(x.l, &ic[j + 1].x, 32);
+    memcpy(y.l, &ic[j + 1].y, 32);
+    HG1 wbase = (x.is_zero() && y.is_zero()) ? HG1::inf() : HG1::from_affine(x, y);
+    std::vector<HG1> pts(32 * 255);
     for (int w = 0; w < 32; w++) { HG1 acc = wbase; for (int dg = 1; dg <= 255; dg++) { pts[w * 255 + dg - 1] = acc; acc = acc.add(wbase); } wbase = acc; }
-    std::vector<HFq> pre(pts.size()); HFq run = HFq::one(); for (size_t k = 0; k < pts.size(); k++) { pre[k] = run; if (!pts[k].is_inf()) run = run * pts[k].Z; }
+    std::vector<HFq> pre(pts.size());
+    HFq run = HFq::one();
+    for (size_t k = 0; k < pts.size(); k++) {
+      pre[k] = run;
+      if (!pts[k].is_inf()) run = run * pts[k].Z;
+    }
     HFq inv = run.inv();
     for (size_t k = pts.size(); k-- > 0;) { G1AffineRaw &o = tab[j * 32 * 255 + k]; if (pts[k].is_inf()) { memset(&o, 0, sizeof o); continue; }
-      HFq zi = inv * pre[k]; inv = inv * pts[k].Z; HFq z2 = zi.sqr(), ax = pts[k].X * z2, ay = pts[k].Y * z2 * zi; memcpy(&o.x, ax.l, 32); memcpy(&o.y, ay.l, 32); }
+      HFq zi = inv * pre[k];
+      inv = inv * pts[k].Z;
+      HFq z2 = zi.sqr(), ax = pts[k].X * z2, ay = pts[k].Y * z2 * zi;
+      memcpy(&o.x, ax.l, 32);
+      memcpy(&o.y, ay.l, 32);
+    }
   }
   d.tables = DevArr<Affine<Fq>>(tab.size()); d.tables.upload((const Affine<Fq> *)tab.data(), tab.size());
 }
@@ -107,29 +219,54 @@ BatchVerifier::~BatchVerifier() = default;
 size_t BatchVerifier::num_inputs() const { return impl->n_inputs; }
 size_t BatchVerifier::program_length() const { return impl->prog_len; }
 void BatchVerifier::verify(const void *proofs_mont, const Fe32 *inputs_canonical, size_t n, uint8_t *ok) {
-  if (!n) return; Impl &d = *impl; static_assert(sizeof(VerifyItem) == 256, "proof record"); hipStream_t s = gpu().stream;   // (gpu() also selects the device for this thread)
-  if (n <= Impl::CTX_CAP) {   // a few proofs: one of the small contexts, nothing allocated, everything asynchronous on the context's stream until the one synchronisation
-    VerifyCtx *c = nullptr; for (size_t k = 0; k < d.ctxs.size() && !c; k++) { VerifyCtx *t = d.ctxs[(d.next_ctx.fetch_add(1) + k) % d.ctxs.size()].get(); if (t->m.try_lock()) c = t; }
+  // (gpu() also selects the device for this thread)
+  if (!n) return;
+  Impl &d = *impl;
+  static_assert(sizeof(VerifyItem) == 256, "proof record");
+  hipStream_t s = gpu().stream;
+  // a few proofs: one of the small contexts, nothing allocated, everything asynchronous on the context's stream until the one synchronisation
+  if (n <= Impl::CTX_CAP) {
+    VerifyCtx *c = nullptr;
+    for (size_t k = 0; k < d.ctxs.size() && !c; k++) {
+      VerifyCtx *t = d.ctxs[(d.next_ctx.fetch_add(1) + k) % d.ctxs.size()].get();
+      if (t->m.try_lock()) c = t;
+    }
     if (!c) { c = d.ctxs[d.next_ctx.fetch_add(1) % d.ctxs.size()].get(); c->m.lock(); }
     std::lock_guard<std::mutex> lk(c->m, std::adopt_lock); uint8_t *dv = c->d.get();
     memcpy(c->h, proofs_mont, n * sizeof(VerifyItem)); if (d.n_inputs) memcpy(c->h + d.off_in(), inputs_canonical, n * d.n_inputs * sizeof(Fe32));
-    HIP_CHECK(hipMemcpyAsync(dv, c->h, n * sizeof(VerifyItem), hipMemcpyHostToDevice, c->s)); if (d.n_inputs) HIP_CHECK(hipMemcpyAsync(dv + d.off_in(), c->h + d.off_in(), n * d.n_inputs * sizeof(Fe32), hipMemcpyHostToDevice, c->s));
+    HIP_CHECK(hipMemcpyAsync(dv, c->h, n * sizeof(VerifyItem), hipMemcpyHostToDevice, c->s));
+    if (d.n_inputs) HIP_CHECK(hipMemcpyAsync(dv + d.off_in(), c->h + d.off_in(), n * d.n_inputs * sizeof(Fe32), hipMemcpyHostToDevice, c->s));
     { Stage st("verify.batch", c->s);
-      hipLaunchKernelGGL(k_verify_acc_wave, dim3((unsigned)n), dim3(64), 0, c->s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)(dv + d.off_in()), (uint32_t)d.n_inputs, (uint32_t)n, (NegAcc3 *)(dv + d.off_acc()));
-      hipLaunchKernelGGL(k_verify_sched29, dim3((unsigned)n), dim3(256), d.lds, c->s, d.sched_prog.get(), (const uint4 *)d.sched_consts.get(), (const VerifyItem *)dv, (const NegAcc3 *)(dv + d.off_acc()), (uint32_t)n, d.si, dv + d.off_ok()); }
-    HIP_CHECK(hipGetLastError()); HIP_CHECK(hipMemcpyAsync(c->h + d.off_ok(), dv + d.off_ok(), n, hipMemcpyDeviceToHost, c->s)); HIP_CHECK(hipStreamSynchronize(c->s)); memcpy(ok, c->h + d.off_ok(), n); return; }
+      hipLaunchKernelGGL(k_verify_acc_wave, dim3((unsigned)n), dim3(64), 0, c->s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)(dv + d.off_in()),
+          (uint32_t)d.n_inputs, (uint32_t)n, (NegAcc3 *)(dv + d.off_acc()));
+      hipLaunchKernelGGL(k_verify_sched29, dim3((unsigned)n), dim3(256), d.lds, c->s, d.sched_prog.get(), (const uint4 *)d.sched_consts.get(),
+          (const VerifyItem *)dv, (const NegAcc3 *)(dv + d.off_acc()), (uint32_t)n, d.si, dv + d.off_ok());
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(c->h + d.off_ok(), dv + d.off_ok(), n, hipMemcpyDeviceToHost, c->s));
+    HIP_CHECK(hipStreamSynchronize(c->s));
+    memcpy(ok, c->h + d.off_ok(), n);
+    return;
+  }
   std::lock_guard<std::mutex> lk(d.big);
   DevArr<VerifyItem> items(n); DevBuf<Fe32> in(n * d.n_inputs + 1); DevArr<Affine<Fq>> acc(n); DevBuf<uint8_t> out(n);
   items.upload((const VerifyItem *)proofs_mont, n); if (d.n_inputs) in.upload(inputs_canonical, n * d.n_inputs);
   Stage st("verify.batch");
-  // up to WAVE_MAX proofs: one workgroup each (latency of a proof ~ the schedule's rounds, 256 proofs at a time on the chip's 256 CUs); beyond that the lane-per-proof kernel, whose 25 ms floor is then amortised over thousands
+  // up to WAVE_MAX proofs: one workgroup each (latency of a proof ~ the schedule's rounds, 256 proofs at a time on the chip's 256 CUs); beyond that the
+  // lane-per-proof kernel, whose 25 ms floor is then amortised over thousands
   static const size_t wave_max = [] { const char *e = getenv("ZK_VERIFY_WAVE_MAX"); long v = e ? atol(e) : 2048; return (size_t)(v < 0 ? 0 : v); }();
   if (n <= wave_max) { DevArr<NegAcc3> acc3(n);
-    hipLaunchKernelGGL(k_verify_acc_wave, dim3((unsigned)n), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(), (uint32_t)d.n_inputs, (uint32_t)n, acc3.get());
-    hipLaunchKernelGGL(k_verify_sched29, dim3((unsigned)n), dim3(256), d.lds, s, d.sched_prog.get(), (const uint4 *)d.sched_consts.get(), items.get(), acc3.get(), (uint32_t)n, d.si, out.get()); HIP_CHECK(hipStreamSynchronize(s));   // (acc3 lives until the kernels are done)
+    hipLaunchKernelGGL(k_verify_acc_wave, dim3((unsigned)n), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(),
+        (uint32_t)d.n_inputs, (uint32_t)n, acc3.get());
+    // (acc3 lives until the kernels are done)
+    hipLaunchKernelGGL(k_verify_sched29, dim3((unsigned)n), dim3(256), d.lds, s, d.sched_prog.get(), (const uint4 *)d.sched_consts.get(), items.get(),
+        acc3.get(), (uint32_t)n, d.si, out.get());
+    HIP_CHECK(hipStreamSynchronize(s));
   } else {
-    hipLaunchKernelGGL(k_verify_acc, dim3(cdiv(n, 64)), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(), (uint32_t)d.n_inputs, (uint32_t)n, acc.get());
-    hipLaunchKernelGGL(k_verify_batch, dim3(cdiv(n, 64)), dim3(64), 0, s, d.prog.get(), items.get(), acc.get(), d.gamma.get(), d.delta.get(), d.frob.get(), d.alpha_beta.get(), d.K, (uint32_t)n, out.get());
+    hipLaunchKernelGGL(k_verify_acc, dim3(cdiv(n, 64)), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(), (uint32_t)d.n_inputs,
+        (uint32_t)n, acc.get());
+    hipLaunchKernelGGL(k_verify_batch, dim3(cdiv(n, 64)), dim3(64), 0, s, d.prog.get(), items.get(), acc.get(), d.gamma.get(), d.delta.get(), d.frob.get(),
+        d.alpha_beta.get(), d.K, (uint32_t)n, out.get());
   }
   HIP_CHECK(hipGetLastError()); out.download(ok, n);
 }

@@ -16,7 +16,8 @@ struct ProvingKeyHost {                           // r1cs_gg_ppzksnark.hpp:72-11
   std::vector<G1AffineRaw> A;                     // n_vars + 1 (entries may be infinity)
   std::vector<uint32_t> B_idx; std::vector<G2AffineRaw> B_g2; std::vector<G1AffineRaw> B_g1;   // sparse knowledge-commitment vector
   std::vector<G1AffineRaw> H;                     // m - 1
-  mutable std::vector<G1AffineRaw> L_star;        // likewise: n_vars + 1 points, the L query extended to all variables minus the C polynomial's share of the H term (ecntt.cuh)
+  // likewise: n_vars + 1 points, the L query extended to all variables minus the C polynomial's share of the H term (ecntt.cuh)
+  mutable std::vector<G1AffineRaw> L_star;
   mutable std::vector<G1AffineRaw> H_lagrange;    // filled by the first Prover built on this key: H in the Lagrange basis of the coset, m points (ecntt.cuh)
   std::vector<G1AffineRaw> L;                     // n_vars - n_inputs
   R1csHost cs;                                    // as stored in the key (A/B already swapped if the generator found it beneficial)
@@ -32,19 +33,23 @@ VerifyingKeyHost load_verifying_key(const std::string &path);   // host only
 void save_proving_key(const std::string &path, const ProvingKeyHost &pk);
 void save_verifying_key(const std::string &path, const VerifyingKeyHost &vk);
 
-// ---- the fast key container ------------------------------------------------------------------------------
-// The reference parses its key file on every call (sendcgo.cpp:64-81: 54 s for send); this engine parses it once per process — still 0.9 s: 77 MB of decimal text,
-// 1.08 M square roots, and the key transforms of ecntt.cuh.  The container holds the RESULT of all that as raw, 64-byte aligned arrays (uncompressed affine Montgomery
-// points with H already in the coset's Lagrange basis and C folded into L, the constraint system in CSR form), so a later process start maps the file and copies:
+// ---- the fast key container ------------------------------------------------------------------------------ The reference parses its key
+// file on every call (sendcgo.cpp:64-81: 54 s for send); this engine parses it once per process — still 0.9 s: 77 MB of decimal text, 1.08 M square roots, and
+// the key transforms of ecntt.cuh. The container holds the RESULT of all that as raw, 64-byte aligned arrays (uncompressed affine Montgomery points with H
+// already in the coset's Lagrange basis and C folded into L, the constraint system in CSR form), so a later process start maps the file and copies:
 //   header: magic "ZKGPUKC1", flags, the source key file's size and mtime (a stale or foreign container is ignored), shape, payload length, 64-bit checksum
 //   payload: alpha_g1 beta_g1 delta_g1 | beta_g2 delta_g2 | A | B_idx | B_g1 | B_g2 | H_lagrange | L_star | rowptr[3] col[3] coeff[3]
 // Written next to the key file as <key>.gpucache (or under $ZK_KEY_CACHE_DIR) after the first load from text; ZK_KEY_CACHE=0 disables both reading and writing.
-struct KeyStamp { int64_t size = -1, mtime_s = 0, mtime_ns = 0; bool operator==(const KeyStamp &o) const { return size == o.size && mtime_s == o.mtime_s && mtime_ns == o.mtime_ns; } };
+struct KeyStamp { int64_t size = -1, mtime_s = 0, mtime_ns = 0; bool operator==(const KeyStamp &o) const {
+    return size == o.size && mtime_s == o.mtime_s && mtime_ns == o.mtime_ns; } };
 bool key_stamp_of(const std::string &path, KeyStamp &out);
 std::string key_container_path(const std::string &pk_path);            // "" if the cache is disabled
-void save_key_container(const std::string &path, const ProvingKeyHost &pk, const KeyStamp &source);   // pk must carry H_lagrange and L_star (filled by the first Prover built on it); atomic (temporary file + rename)
-bool load_key_container(const std::string &path, const KeyStamp &source, ProvingKeyHost &pk);          // false: missing, stale, truncated, wrong checksum or wrong version — the caller falls back to the text key
-// text key or its container, whichever is valid; `from_container` tells which.  After building the first Prover on a key that came from text, call save_key_container.
+// pk must carry H_lagrange and L_star (filled by the first Prover built on it); atomic (temporary file + rename)
+void save_key_container(const std::string &path, const ProvingKeyHost &pk, const KeyStamp &source);
+// false: missing, stale, truncated, wrong checksum or wrong version — the caller falls back to the text key
+bool load_key_container(const std::string &path, const KeyStamp &source, ProvingKeyHost &pk);
+// text key or its container, whichever is valid; `from_container` tells which. After building the first Prover on a key that came from text, call
+// save_key_container.
 ProvingKeyHost load_proving_key_fast(const std::string &pk_path, bool &from_container);
 
 // ---- generator (r1cs_gg_ppzksnark.tcc:212-388) --------------------------------------------------------------------------
@@ -56,7 +61,9 @@ class Prover {                                    // a proving key resident in H
  public:
   // shard_rank / shard_world: this object holds only the contiguous slice [n*rank/world, n*(rank+1)/world) of every query (kernel K7);
   // a sharded prover produces partial sums (prove_partial), any process then adds the ranks' partials and assembles the proof (finish_from_partials)
-  explicit Prover(const ProvingKeyHost &pk, size_t shard_rank = 0, size_t shard_world = 1, int device_slot = 0); ~Prover();   // device_slot: index into the process's device list (ZK_DEVICES)
+  // device_slot: index into the process's device list (ZK_DEVICES)
+  explicit Prover(const ProvingKeyHost &pk, size_t shard_rank = 0, size_t shard_world = 1, int device_slot = 0);
+  ~Prover();
   // a second prover on the same key: shares the peer's immutable device state (query tables, twiddles, constraint system: 1.8 GB for send) and owns only its
   // streams, sort / bucket workspaces and vectors (about 0.25 GB), so a pool of provers per key costs little HBM and no second key load
   explicit Prover(const Prover &peer);
@@ -67,7 +74,8 @@ class Prover {                                    // a proving key resident in H
   bool prove(const Fe32 *z, const Fe32 *r, const Fe32 *s, Proof &out) { set_witness(z, false); return prove_resident(r, s, out); }
   // the two halves of prove(): hand the assignment over (canonical, or already in Montgomery form as the circuit boards hold it), then prove from HBM
   void set_witness(const Fe32 *z, bool montgomery);
-  // the same assignment as one byte per entry — 0, 1, 2 = "see wide[i]" (Montgomery form) or 6 = "the small integer in the low 64 bits of wide[i]" — entry 0 being the constant ONE (circuit::Board's own form)
+  // the same assignment as one byte per entry — 0, 1, 2 = "see wide[i]" (Montgomery form) or 6 = "the small integer in the low 64 bits of wide[i]" — entry 0
+  // being the constant ONE (circuit::Board's own form)
   void set_witness_tagged(const uint8_t *tag, const Fe32 *wide);
   bool prove_resident(const Fe32 *r, const Fe32 *s, Proof &out);
   // partial multi-exponentiation results of this shard, affine canonical: eA(64) eB1(64) eH(64) eL(64) eB2(128) = 384 bytes.  false if z is unsatisfying.
@@ -84,11 +92,13 @@ bool verify_proof(const VerifyingKeyHost &vk, const Fe32 *inputs /* canonical */
 // The key-dependent half of the check done once (libsnark's r1cs_gg_ppzksnark_verifier_process_vk, :509-522, plus window tables of the IC points): the line
 // coefficients of gamma_g2 and delta_g2, and 2^(8w) d IC_j for every byte value d.  A call then costs three Miller loops, one final exponentiation and 32
 // mixed additions per public input instead of a 254-bit scalar multiplication each — 2.5 -> about 1.3 ms per proof on the host.
-struct PreparedVerifyingKey { VerifyingKeyHost vk; host::G2Precomp gamma, delta; std::vector<host::HFq> ic_x, ic_y; /* [j][w*255 + d-1], affine; (0,0) = infinity */ };
+struct PreparedVerifyingKey { VerifyingKeyHost vk; host::G2Precomp gamma, delta; std::vector<host::HFq> ic_x, ic_y;
+    /* [j][w*255 + d-1], affine; (0,0) = infinity */ };
 std::shared_ptr<PreparedVerifyingKey> prepare_verifying_key(const VerifyingKeyHost &vk);
 bool verify_proof(const PreparedVerifyingKey &pvk, const Fe32 *inputs /* canonical */, size_t n_inputs, const Proof &proof);
 
-bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t stats[8]);   // the GPU verifier's schedule interpreted on the host (test entry)
+// the GPU verifier's schedule interpreted on the host (test entry)
+bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t stats[8]);
 // the same decision for n proofs at once on the GPU (kernel K9): one BatchVerifier per verifying key
 std::unique_ptr<BatchVerifier> make_batch_verifier(const VerifyingKeyHost &vk);
 static_assert(sizeof(Proof) == 256, "proof record");
@@ -98,5 +108,6 @@ std::string proof_to_hex(const Proof &p);
 bool proof_from_hex(const char *hex, Proof &p);   // reads exactly 512 characters; false on a non-hex character
 Proof default_proof();                            // (G1::one, G2::one, G1::one) — r1cs_gg_ppzksnark.hpp:309-315
 
-void test_scan_blocks(const uint8_t tags[64], const uint64_t elems[256], const uint64_t one[4], uint64_t out[10]);   // host-only self-test of the hand-over's block classifiers (scalar against AVX2 forms)
+// host-only self-test of the hand-over's block classifiers (scalar against AVX2 forms)
+void test_scan_blocks(const uint8_t tags[64], const uint64_t elems[256], const uint64_t one[4], uint64_t out[10]);
 }  // namespace zk

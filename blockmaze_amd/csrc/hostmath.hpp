@@ -16,7 +16,14 @@ template <class P>
 struct HFp {
   uint64_t l[4];
   static constexpr uint64_t mod(int i) { return (uint64_t)P::MOD[2 * i] | ((uint64_t)P::MOD[2 * i + 1] << 32); }
-  static uint64_t inv64() { static const uint64_t v = [] { uint64_t p = mod(0), x = 1; for (int i = 0; i < 6; i++) x *= 2 - p * x; return (uint64_t)0 - x; }(); return v; }
+  static uint64_t inv64() {
+    static const uint64_t v = [] {
+      uint64_t p = mod(0), x = 1;
+      for (int i = 0; i < 6; i++) x *= 2 - p * x;
+      return (uint64_t)0 - x;
+    }();
+    return v;
+  }
   static HFp zero() { HFp r; memset(r.l, 0, 32); return r; }
   static HFp one() { HFp r; memcpy(r.l, P::R1, 32); return r; }
   static HFp r2() { HFp r; memcpy(r.l, P::R2, 32); return r; }
@@ -24,9 +31,33 @@ struct HFp {
   bool operator==(const HFp &b) const { return memcmp(l, b.l, 32) == 0; }
   bool operator!=(const HFp &b) const { return !(*this == b); }
   static bool geq_mod(const uint64_t *a) { for (int i = 3; i >= 0; i--) { if (a[i] != mod(i)) return a[i] > mod(i); } return true; }
-  static void sub_mod(uint64_t *a) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)a[i] - mod(i) - br; a[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } }
-  friend HFp operator+(const HFp &a, const HFp &b) { HFp r; uint64_t c = 0; for (int i = 0; i < 4; i++) { u128 s = (u128)a.l[i] + b.l[i] + c; r.l[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } if (c || geq_mod(r.l)) sub_mod(r.l); return r; }
-  friend HFp operator-(const HFp &a, const HFp &b) { HFp r; uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)a.l[i] - b.l[i] - br; r.l[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+  static void sub_mod(uint64_t *a) {
+    uint64_t br = 0;
+    for (int i = 0; i < 4; i++) {
+      u128 d = (u128)a[i] - mod(i) - br;
+      a[i] = (uint64_t)d;
+      br = (uint64_t)(d >> 64) & 1;
+    }
+  }
+  friend HFp operator+(const HFp &a, const HFp &b) {
+    HFp r;
+    uint64_t c = 0;
+    for (int i = 0; i < 4; i++) {
+      u128 s = (u128)a.l[i] + b.l[i] + c;
+      r.l[i] = (uint64_t)s;
+      c = (uint64_t)(s >> 64);
+    }
+    if (c || geq_mod(r.l)) sub_mod(r.l);
+    return r;
+  }
+  friend HFp operator-(const HFp &a, const HFp &b) {
+    HFp r;
+    uint64_t br = 0;
+    for (int i = 0; i < 4; i++) {
+      u128 d = (u128)a.l[i] - b.l[i] - br;
+      r.l[i] = (uint64_t)d;
+      br = (uint64_t)(d >> 64) & 1;
+    }
     if (br) { uint64_t c = 0; for (int i = 0; i < 4; i++) { u128 s = (u128)r.l[i] + mod(i) + c; r.l[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } } return r; }
   HFp neg() const { return is_zero() ? *this : zero() - *this; }
   HFp dbl() const { return *this + *this; }
@@ -45,9 +76,29 @@ struct HFp {
   HFp to_mont() const { return *this * r2(); }
   HFp from_mont() const { HFp o = zero(); o.l[0] = 1; return *this * o; }
   static HFp from_u64(uint64_t v) { HFp r = zero(); r.l[0] = v; return r.to_mont(); }
-  HFp pow(const uint64_t *e, int limbs) const { HFp r = one(); bool found = false; for (int i = limbs * 64 - 1; i >= 0; i--) { if (found) r = r.sqr(); if ((e[i / 64] >> (i % 64)) & 1) { found = true; r = r * *this; } } return r; }
+  HFp pow(const uint64_t *e, int limbs) const {
+    HFp r = one();
+    bool found = false;
+    for (int i = limbs * 64 - 1; i >= 0; i--) {
+      if (found) r = r.sqr();
+      if ((e[i / 64] >> (i % 64)) & 1) {
+        found = true;
+        r = r * *this;
+      }
+    }
+    return r;
+  }
   HFp pow_u64(uint64_t e) const { return pow(&e, 1); }
-  HFp inv() const { uint64_t e[4]; uint64_t br = 2; for (int i = 0; i < 4; i++) { u128 d = (u128)mod(i) - br; e[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } return pow(e, 4); }
+  HFp inv() const {
+    uint64_t e[4];
+    uint64_t br = 2;
+    for (int i = 0; i < 4; i++) {
+      u128 d = (u128)mod(i) - br;
+      e[i] = (uint64_t)d;
+      br = (uint64_t)(d >> 64) & 1;
+    }
+    return pow(e, 4);
+  }
   bool canonical_lsb() const { return from_mont().l[0] & 1; }
 };
 using HFr = HFp<FrParams>;
@@ -55,7 +106,16 @@ using HFq = HFp<FqParams>;
 
 // (q+1)/4 square root, q = 3 mod 4 (fp.tcc:724 with s = 1).  false for non-residues.
 inline bool fq_sqrt(const HFq &a, HFq &out) {
-  uint64_t e[4]; { uint64_t c = 1; for (int i = 0; i < 4; i++) { u128 s = (u128)HFq::mod(i) + c; e[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } for (int i = 0; i < 4; i++) e[i] = (e[i] >> 2) | (i < 3 ? e[i + 1] << 62 : 0); }
+  uint64_t e[4];
+  {
+    uint64_t c = 1;
+    for (int i = 0; i < 4; i++) {
+      u128 s = (u128)HFq::mod(i) + c;
+      e[i] = (uint64_t)s;
+      c = (uint64_t)(s >> 64);
+    }
+    for (int i = 0; i < 4; i++) e[i] = (e[i] >> 2) | (i < 3 ? e[i + 1] << 62 : 0);
+  }
   HFq x = a.pow(e, 4); if (x.sqr() != a) return false; out = x; return true; }
 
 struct HFq2 {
@@ -69,13 +129,27 @@ struct HFq2 {
   friend HFq2 operator-(const HFq2 &a, const HFq2 &b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
   HFq2 neg() const { return {c0.neg(), c1.neg()}; }
   HFq2 dbl() const { return {c0.dbl(), c1.dbl()}; }
-  friend HFq2 operator*(const HFq2 &a, const HFq2 &b) { HFq aA = a.c0 * b.c0, bB = a.c1 * b.c1, s = (a.c0 + a.c1) * (b.c0 + b.c1); return {aA - bB, s - aA - bB}; }
+  friend HFq2 operator*(const HFq2 &a, const HFq2 &b) {
+    HFq aA = a.c0 * b.c0, bB = a.c1 * b.c1, s = (a.c0 + a.c1) * (b.c0 + b.c1);
+    return {aA - bB, s - aA - bB};
+  }
   HFq2 sqr() const { HFq ab = c0 * c1; return {(c0 + c1) * (c0 - c1), ab.dbl()}; }
   HFq2 mul_fq(const HFq &k) const { return {c0 * k, c1 * k}; }
   HFq2 mul_xi() const { HFq n0 = c0.dbl().dbl().dbl() + c0, n1 = c1.dbl().dbl().dbl() + c1; return {n0 - c1, n1 + c0}; }   // (9+u)
   HFq2 inv() const { HFq t = (c0.sqr() + c1.sqr()).inv(); return {c0 * t, (c1 * t).neg()}; }
   HFq2 frob(unsigned p) const { return (p & 1) ? HFq2{c0, c1.neg()} : *this; }
-  HFq2 pow(const uint64_t *e, int limbs) const { HFq2 r = one(); bool found = false; for (int i = limbs * 64 - 1; i >= 0; i--) { if (found) r = r.sqr(); if ((e[i / 64] >> (i % 64)) & 1) { found = true; r = r * *this; } } return r; }
+  HFq2 pow(const uint64_t *e, int limbs) const {
+    HFq2 r = one();
+    bool found = false;
+    for (int i = limbs * 64 - 1; i >= 0; i--) {
+      if (found) r = r.sqr();
+      if ((e[i / 64] >> (i % 64)) & 1) {
+        found = true;
+        r = r * *this;
+      }
+    }
+    return r;
+  }
 };
 
 // Jacobian points, formulas as in the reference (alt_bn128_g1.cpp:139-358): add-2007-bl, madd-2007-bl, dbl-2009-l
@@ -93,7 +167,18 @@ struct HPoint {
     if (U1 == U2) { if (S1 == S2) return dbl(); return inf(); }
     F H = U2 - U1, I = H.dbl().sqr(), J = H * I, r = (S2 - S1).dbl(), V = U1 * I; HPoint R;
     R.X = r.sqr() - J - V.dbl(); R.Y = r * (V - R.X) - (S1 * J).dbl(); R.Z = ((Z + o.Z).sqr() - Z1Z1 - Z2Z2) * H; return R; }
-  HPoint mul(const uint64_t k[4]) const { HPoint r = inf(); bool found = false; for (int i = 255; i >= 0; i--) { if (found) r = r.dbl(); if ((k[i / 64] >> (i % 64)) & 1) { found = true; r = r.add(*this); } } return r; }
+  HPoint mul(const uint64_t k[4]) const {
+    HPoint r = inf();
+    bool found = false;
+    for (int i = 255; i >= 0; i--) {
+      if (found) r = r.dbl();
+      if ((k[i / 64] >> (i % 64)) & 1) {
+        found = true;
+        r = r.add(*this);
+      }
+    }
+    return r;
+  }
   void to_affine(F &x, F &y) const { if (is_inf()) { x = F::zero(); y = F::zero(); return; } F zi = Z.inv(), z2 = zi.sqr(); x = X * z2; y = Y * z2 * zi; }
   // from the device's extended-Jacobian (X, Y, ZZ, ZZZ): Z := ZZZ/ZZ is avoided by mapping to (X*ZZ, Y*ZZZ^? ...) — use affine-free identity:
   // (X, Y, ZZ, ZZZ) with ZZ^3 = ZZZ^2 equals Jacobian (X*ZZ^... ) — simplest exact map: Z = ZZZ/ZZ would need an inversion, so scale instead:

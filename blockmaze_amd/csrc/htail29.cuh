@@ -1,25 +1,30 @@
 // Weighted bucket sum of the H query on nine 29-bit limbs: sum_b (b + 1) S_b over NB = 2^top buckets, after k_hacc_combine29 (msm.cuh).
 //
-// Replaces libff's running-sum reduction of the bucket array (FF/algebra/scalar_multiplication/multiexp.tcc:244-278) — a chain of 2 NB dependent additions there — and
-// round 2's k_bitsum_chunks / k_bitsum_final (sums by weight bit on 8 x 32-bit limbs: top * NB / 2 = 245 K quad additions for send, 13 % of a proof's VALU instructions).
+// Replaces libff's running-sum reduction of the bucket array (FF/algebra/scalar_multiplication/multiexp.tcc:244-278) — a chain of 2 NB dependent additions
+// there — and round 2's k_bitsum_chunks / k_bitsum_final (sums by weight bit on 8 x 32-bit limbs: top * NB / 2 = 245 K quad additions for send, 13 % of a
+// proof's VALU instructions).
 //
-// Same result slots as before — T_s = the sum of the buckets whose weight w = b + 1 has bit s, s = 0 .. top, finished by the host's Horner rule — but formed in two levels:
+// Same result slots as before — T_s = the sum of the buckets whose weight w = b + 1 has bit s, s = 0 .. top, finished by the host's Horner rule — but formed in
+// two levels:
 //   w = hi * L + lo  (L = 2^lo_bits)      C_lo = sum over hi of S_(hi, lo)      R_hi = sum over lo of S_(hi, lo)
 //   T_s = sum of the C_lo whose lo has bit s              (s <  lo_bits)
 //   T_s = sum of the R_hi whose hi has bit s - lo_bits    (s >= lo_bits;  T_top = R_(2^hi_bits) = bucket NB - 1 alone)
-// i.e. 2 NB additions for the marginal sums and a few hundred for the bit sums instead of top * NB / 2: 3.7 x fewer for NB = 32,768, and a dependent chain of 7 + 7
-// additions instead of 16 + 6.  Everything stays on the 29-bit limbs of the accumulation (field29_gfx950.inc); the one conversion per result slot happens at the very end.
+// i.e. 2 NB additions for the marginal sums and a few hundred for the bit sums instead of top * NB / 2: 3.7 x fewer for NB = 32,768, and a dependent chain of 7
+// + 7 additions instead of 16 + 6. Everything stays on the 29-bit limbs of the accumulation (field29_gfx950.inc); the one conversion per result slot happens at
+// the very end.
 //
-// The additions are quad-cooperative like curve.cuh's, with the point SPREAD over the quad: lane k of a DPP quad holds coordinate k of (X, Y, ZZ, ZZZ) — nine registers a
-// point instead of 36 — and fetches what it needs from its neighbours with quad_perm moves.  One addition = four rounds of ONE product per lane (add-2008-s):
+// The additions are quad-cooperative like curve.cuh's, with the point SPREAD over the quad: lane k of a DPP quad holds coordinate k of (X, Y, ZZ, ZZZ) — nine
+// registers a point instead of 36 — and fetches what it needs from its neighbours with quad_perm moves. One addition = four rounds of ONE product per lane
+// (add-2008-s):
 //   round 1   U1 = X1 ZZ2 | S1 = Y1 ZZZ2 | U2 = X2 ZZ1 | S2 = Y2 ZZZ1                     (own coordinate of a  x  the partner lane's coordinate of b)
-//   round 2   P^2 | R^2 | ZZ1 ZZ2 | ZZZ1 ZZZ2                                              (P = U2 - U1 on lane 0, R = S2 - S1 on lane 1; lanes 2, 3 hold -P, -R)
+//   round 2 P^2 | R^2 | ZZ1 ZZ2 | ZZZ1 ZZZ2 (P = U2 - U1 on lane 0, R = S2 - S1 on lane 1; lanes 2, 3 hold -P, -R)
 //   round 3   P PP | U1 PP | ZZ12 PP | (idle)                                              -> PPP, Q, ZZ3
-//   round 4   ZZZ12 PPP | R (Q - X3) | (idle) | S1 PPP                                     -> ZZZ3, and Y3 = R (Q - X3) - S1 PPP;  S1 is rebuilt on lane 3 as S2 + (-R)
-// Value bounds: the formulas and reduction constants are those of xyzz29_add (msm.cuh), whose interval arithmetic lives in gen_field29.py (check_bounds_add); the one
-// difference — S1 enters its product as S2 + (2p + S1 - S2) < S1 + 2p — is covered by check_bounds_add_quad there.
-// Operand = +-the other operand leaves ZZ = 0 (mod p) for good, exactly as in the accumulation: k_hbits29 looks for it in every result slot and raises the flag that sends
-// the MSM to the general path (complete formulas).  The point at infinity is a record whose ZZ limbs are all zero; it is tracked as a quad-uniform flag beside the limbs.
+//   round 4 ZZZ12 PPP | R (Q - X3) | (idle) | S1 PPP -> ZZZ3, and Y3 = R (Q - X3) - S1 PPP; S1 is rebuilt on lane 3 as S2 + (-R)
+// Value bounds: the formulas and reduction constants are those of xyzz29_add (msm.cuh), whose interval arithmetic lives in gen_field29.py (check_bounds_add);
+// the one difference — S1 enters its product as S2 + (2p + S1 - S2) < S1 + 2p — is covered by check_bounds_add_quad there.
+// Operand = +-the other operand leaves ZZ = 0 (mod p) for good, exactly as in the accumulation: k_hbits29 looks for it in every result slot and raises the flag
+// that sends the MSM to the general path (complete formulas). The point at infinity is a record whose ZZ limbs are all zero; it is tracked as a quad-uniform
+// flag beside the limbs.
 #pragma once
 #include "curve.cuh"
 #include "field29.cuh"
@@ -108,8 +113,8 @@ __device__ __forceinline__ QPoint29 quad29_shfl_down(const QPoint29 &p, int lane
   r.inf = __shfl_down((int)p.inf, lanes, 64) != 0;
   return r;
 }
-// tree over the quads of a workgroup of up to 256 threads: the 16 quads of a wave by shuffles, the waves through LDS (one record each).  `live` = how many quads (the
-// first ones) hold something: levels whose partner quads are all empty are skipped, whole waves at a time.  The sum is valid in quad 0.
+// tree over the quads of a workgroup of up to 256 threads: the 16 quads of a wave by shuffles, the waves through LDS (one record each). `live` = how many quads
+// (the first ones) hold something: levels whose partner quads are all empty are skipped, whole waves at a time. The sum is valid in quad 0.
 __device__ __forceinline__ QPoint29 block_quad29_tree(QPoint29 acc, Point29Rec *lds, uint32_t live) {
   const uint32_t q = threadIdx.x >> 2, wq = q & 15, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   const int k = threadIdx.x & 3;
@@ -136,8 +141,8 @@ __device__ __forceinline__ QPoint29 block_quad29_tree(QPoint29 acc, Point29Rec *
 }
 
 __device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq> *slot, MsmCounters *cnt);
-// how the weights are cut: w = hi * 2^lo_bits + lo.  A row (2^lo_bits consecutive buckets) is added up in `row_chunks` pieces of at most HTAIL_CHUNK buckets, a workgroup
-// each, so that no quad of the marginal kernel holds more than two buckets: 1 + 6 dependent additions for rows and columns alike.
+// how the weights are cut: w = hi * 2^lo_bits + lo. A row (2^lo_bits consecutive buckets) is added up in `row_chunks` pieces of at most HTAIL_CHUNK buckets, a
+// workgroup each, so that no quad of the marginal kernel holds more than two buckets: 1 + 6 dependent additions for rows and columns alike.
 constexpr uint32_t HTAIL_CHUNK = 128;
 struct HtailShape { uint32_t top, lo_bits, hi_bits, row_chunks; };
 __host__ __device__ inline HtailShape htail_shape(uint32_t NB) {
@@ -147,13 +152,14 @@ __host__ __device__ inline HtailShape htail_shape(uint32_t NB) {
   s.row_chunks = (1u << s.lo_bits) > HTAIL_CHUNK ? (1u << s.lo_bits) / HTAIL_CHUNK : 1u;
   return s;
 }
-// marginal sums: marg[lo] = C_lo for lo = 1 .. L - 1 (slot 0 unused); marg[L + hi * row_chunks + j] = piece j of R_hi for hi = 1 .. H - 1; marg[L + H * row_chunks] =
-// R_H = bucket NB - 1 (the only bucket of that row)
+// marginal sums: marg[lo] = C_lo for lo = 1 .. L - 1 (slot 0 unused); marg[L + hi * row_chunks + j] = piece j of R_hi for hi = 1 .. H - 1; marg[L + H *
+// row_chunks] = R_H = bucket NB - 1 (the only bucket of that row)
 __host__ __device__ inline uint32_t htail_marg_count(const HtailShape &s) { return (1u << s.lo_bits) + ((1u << s.hi_bits)) * s.row_chunks + 1; }
 __host__ __device__ inline uint32_t htail_marg_blocks(const HtailShape &s) { return ((1u << s.lo_bits) - 1) + ((1u << s.hi_bits) - 1) * s.row_chunks + 1; }
 
-// k_hmarg29: workgroup g < L - 1: column lo = g + 1 — the H buckets of weight hi * L + lo; then (H - 1) * row_chunks workgroups: piece j of row hi — buckets of weight
-// hi * L + lo, lo = j * L / row_chunks .. (consecutive); the last workgroup copies bucket NB - 1 into the slot of R_H.  A quad takes one or two buckets, then the tree.
+// k_hmarg29: workgroup g < L - 1: column lo = g + 1 — the H buckets of weight hi * L + lo; then (H - 1) * row_chunks workgroups: piece j of row hi — buckets of
+// weight hi * L + lo, lo = j * L / row_chunks .. (consecutive); the last workgroup copies bucket NB - 1 into the slot of R_H. A quad takes one or two buckets,
+// then the tree.
 template <int UNIT>   // (a template only so that the one translation unit that launches it instantiates it)
 __global__ void __launch_bounds__(256) k_hmarg29(const Point29Rec *__restrict__ buckets, uint32_t NB, Point29Rec *__restrict__ marg) {
   __shared__ Point29Rec lds[4];
@@ -179,12 +185,14 @@ __global__ void __launch_bounds__(256) k_hmarg29(const Point29Rec *__restrict__ 
   if (threadIdx.x < 4) quad29_store(marg + (column ? g + 1 : L + hi * RC + piece), acc, k);
 }
 
-// k_hbits29: workgroup s: T_s from the marginal sums — for s < lo_bits the C_lo with bit s of lo set ("i with a one inserted at bit s", i < L / 2), for
-// lo_bits <= s < top the pieces of the R_hi with bit s - lo_bits of hi set (i < H / 2, row_chunks pieces each), for s = top the one record R_H.  The result leaves the 29-bit domain here: every lane converts
-// its coordinate (a product with 2^256 mod p: the lazy 8 x 32-bit form of field.cuh, normalized) and stores its 32 bytes of res[s] — pinned host memory.  A result with
-// ZZ = 0 (mod p) that is not the point at infinity raises the flag of the one-pass path (MsmCounters::pad[0]); the last workgroup to finish hands the counters to the host.
+// k_hbits29: workgroup s: T_s from the marginal sums — for s < lo_bits the C_lo with bit s of lo set ("i with a one inserted at bit s", i < L / 2), for lo_bits
+// <= s < top the pieces of the R_hi with bit s - lo_bits of hi set (i < H / 2, row_chunks pieces each), for s = top the one record R_H. The result leaves the
+// 29-bit domain here: every lane converts its coordinate (a product with 2^256 mod p: the lazy 8 x 32-bit form of field.cuh, normalized) and stores its 32
+// bytes of res[s] — pinned host memory. A result with ZZ = 0 (mod p) that is not the point at infinity raises the flag of the one-pass path
+// (MsmCounters::pad[0]); the last workgroup to finish hands the counters to the host.
 template <int UNIT>
-__global__ void __launch_bounds__(256) k_hbits29(const Point29Rec *__restrict__ marg, uint32_t NB, XYZZ<Fq> *__restrict__ res, MsmCounters *cnt, uint4 *copy_dst) {
+__global__ void __launch_bounds__(256) k_hbits29(const Point29Rec *__restrict__ marg, uint32_t NB, XYZZ<Fq> *__restrict__ res, MsmCounters *cnt,
+    uint4 *copy_dst) {
   __shared__ Point29Rec lds[4];
   const HtailShape sh = htail_shape(NB);
   const uint32_t L = 1u << sh.lo_bits, H = 1u << sh.hi_bits, s_ = blockIdx.x, q = threadIdx.x >> 2;
@@ -204,20 +212,30 @@ __global__ void __launch_bounds__(256) k_hbits29(const Point29Rec *__restrict__ 
     }
     acc = block_quad29_tree(acc, lds, min(count, 64u));
   }
-  if (threadIdx.x < 4) quad29_emit(acc, k, res + s_, cnt);                                // (ZZ = 0 mod p in something that is not the point at infinity raises the flag)
+  // (ZZ = 0 mod p in something that is not the point at infinity raises the flag)
+  if (threadIdx.x < 4) quad29_emit(acc, k, res + s_, cnt);
   if (threadIdx.x == 0) {
     __threadfence();
-    if (atomicAdd(&cnt->pad[1], 1u) == gridDim.x - 1) { __threadfence(); *copy_dst = *reinterpret_cast<const uint4 *>(cnt); cnt->pad[1] = 0; }   // (the ticket is left at zero: MSMs that share a sort share these counters)
+    // (the ticket is left at zero: MSMs that share a sort share these counters)
+    if (atomicAdd(&cnt->pad[1], 1u) == gridDim.x - 1) {
+      __threadfence();
+      *copy_dst = *reinterpret_cast<const uint4 *>(cnt);
+      cnt->pad[1] = 0;
+    }
   }
 }
 
-// ---- the G1 witness MSMs (A, L*, B1) on the same arithmetic (round 4) ------------------------------------------------------------------------------------------------
-// k_wacc_lanes29 (msm.cuh) leaves one Point29Rec per lane; here the two cooperative stages that follow it, the 29-bit forms of k_wacc_fold and k_wtail:
+// ---- the G1 witness MSMs (A, L*, B1) on the same arithmetic (round 4)
+// ------------------------------------------------------------------------------------------------ k_wacc_lanes29 (msm.cuh) leaves one Point29Rec per lane;
+// here the two cooperative stages that follow it, the 29-bit forms of k_wacc_fold and k_wtail:
 //   k_wfold29   workgroup b < NB: bucket b = the sum of its lanes' partial sums (lane_off says where they lie); workgroup NB + g: 256 of the ones lanes;
-//   k_wtail29   workgroup s < top: S_s = the sum of the NB / 2 buckets whose weight has bit s (a quad each, then the tree); workgroup top: bucket NB - 1 and the unused
-//               slots; workgroup top + 1: the sum of the ones' partial sums.  Every result leaves the 29-bit domain through the conversion of k_hbits29, a degenerate one
+//   k_wtail29 workgroup s < top: S_s = the sum of the NB / 2 buckets whose weight has bit s (a quad each, then the tree); workgroup top: bucket NB - 1 and the
+//               unused
+//               slots; workgroup top + 1: the sum of the ones' partial sums. Every result leaves the 29-bit domain through the conversion of k_hbits29, a
+//               degenerate one
 //               (ZZ = 0 mod p) raises the flag that sends the MSM to the general path, the last workgroup to finish hands the counters to the host.
-__device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq> *slot, MsmCounters *cnt) {   // quad 0 of a workgroup: the result as 8 x 32-bit words
+// quad 0 of a workgroup: the result as 8 x 32-bit words
+__device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq> *slot, MsmCounters *cnt) {
   Fq out = Fq::zero();
   bool bad = false;
   if (!acc.inf) {
@@ -229,7 +247,8 @@ __device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq>
   reinterpret_cast<Fq *>(slot)[k] = out;
 }
 template <int UNIT>
-__global__ void __launch_bounds__(256) k_wfold29(const Point29Rec *__restrict__ partial, const uint32_t *__restrict__ lane_off, uint32_t NB, uint32_t bucket_lanes, Point29Rec *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_wfold29(const Point29Rec *__restrict__ partial, const uint32_t *__restrict__ lane_off, uint32_t NB,
+    uint32_t bucket_lanes, Point29Rec *__restrict__ out) {
   __shared__ Point29Rec lds[4];
   const uint32_t b = blockIdx.x, q = threadIdx.x >> 2;
   const int k = threadIdx.x & 3;
@@ -245,7 +264,8 @@ __global__ void __launch_bounds__(256) k_wfold29(const Point29Rec *__restrict__ 
   if (threadIdx.x < 4) quad29_store(out + b, acc, k);
 }
 template <int UNIT>
-__global__ void __launch_bounds__(256) k_wtail29(const Point29Rec *__restrict__ buckets, uint32_t NB, const Point29Rec *__restrict__ ones_partial, uint32_t n_ones_partial, uint32_t slots, XYZZ<Fq> *__restrict__ res,
+__global__ void __launch_bounds__(256) k_wtail29(const Point29Rec *__restrict__ buckets, uint32_t NB, const Point29Rec *__restrict__ ones_partial,
+    uint32_t n_ones_partial, uint32_t slots, XYZZ<Fq> *__restrict__ res,
                                                  MsmCounters *cnt, uint4 *copy_dst) {
   __shared__ Point29Rec lds[4];
   const uint32_t q = threadIdx.x >> 2, s_ = blockIdx.x, half = NB >> 1;
@@ -277,7 +297,12 @@ __global__ void __launch_bounds__(256) k_wtail29(const Point29Rec *__restrict__ 
   if (threadIdx.x < 4) quad29_emit(acc, k, res + slot, cnt);
   if (threadIdx.x == 0) {
     __threadfence();
-    if (atomicAdd(&cnt->pad[1], 1u) == gridDim.x - 1) { __threadfence(); *copy_dst = *reinterpret_cast<const uint4 *>(cnt); cnt->pad[1] = 0; }   // (the ticket is left at zero: MSMs that share a sort share these counters)
+    // (the ticket is left at zero: MSMs that share a sort share these counters)
+    if (atomicAdd(&cnt->pad[1], 1u) == gridDim.x - 1) {
+      __threadfence();
+      *copy_dst = *reinterpret_cast<const uint4 *>(cnt);
+      cnt->pad[1] = 0;
+    }
   }
 }
 

@@ -10,7 +10,8 @@ namespace zk {
 struct FqPowConsts { uint32_t sqrt_exp[8]; uint32_t qm3o4[8]; uint32_t qm1o2[8]; };   // (q+1)/4, (q-3)/4, (q-1)/2
 
 // y = sqrt(x^3 + 3) with the parity of the canonical y chosen by lsb; flags: bit0 = lsb of y, bit1 = point is zero.  ok[i] = 0 if x^3+3 is a non-residue.
-__global__ void k_g1_decompress(const Fq *__restrict__ xs, const uint8_t *__restrict__ flags, Affine<Fq> *__restrict__ out, uint32_t n, FqPowConsts pc, uint32_t *bad) {
+__global__ void k_g1_decompress(const Fq *__restrict__ xs, const uint8_t *__restrict__ flags, Affine<Fq> *__restrict__ out, uint32_t n, FqPowConsts pc,
+    uint32_t *bad) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
   if (flags[i] & 2) { out[i] = Affine<Fq>::inf(); return; }
   Fq x = xs[i], three = Fq::from_u64(3), y2 = x.sqr() * x + three, y = y2.pow(pc.sqrt_exp);
@@ -32,7 +33,8 @@ __device__ __noinline__ bool fq2_sqrt(const Fq2 &a, Fq2 &out, const FqPowConsts 
   else { Fq2 b = fq2_pow(Fq2::one() + alpha, pc.qm1o2); out = b * x0; }
   return true;
 }
-__global__ void k_g2_decompress(const Fq2 *__restrict__ xs, const uint8_t *__restrict__ flags, Affine<Fq2> *__restrict__ out, uint32_t n, FqPowConsts pc, Fq2 twist_b, uint32_t *bad) {
+__global__ void k_g2_decompress(const Fq2 *__restrict__ xs, const uint8_t *__restrict__ flags, Affine<Fq2> *__restrict__ out, uint32_t n, FqPowConsts pc,
+    Fq2 twist_b, uint32_t *bad) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
   if (flags[i] & 2) { out[i] = Affine<Fq2>::inf(); return; }
   Fq2 x = xs[i], y2 = x.sqr() * x + twist_b, y;
@@ -44,7 +46,8 @@ __global__ void k_g2_decompress(const Fq2 *__restrict__ xs, const uint8_t *__res
 // out[i] = scalars[i] * G for a fixed G, from an 8-bit window table: table[w * 255 + (d - 1)] = d * 2^(8w) * G (affine), w < 32.
 // scalars canonical.  Result affine (one Fermat inversion per point; infinity for scalar 0).
 template <class F>
-__global__ void __launch_bounds__(128) k_fixed_base_mul(const Affine<F> *__restrict__ table, const Fr *__restrict__ scalars, Affine<F> *__restrict__ out, uint32_t n) {
+__global__ void __launch_bounds__(128) k_fixed_base_mul(const Affine<F> *__restrict__ table, const Fr *__restrict__ scalars, Affine<F> *__restrict__ out,
+    uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
   Fr k = scalars[i]; XYZZ<F> acc = XYZZ<F>::inf();
   for (int w = 0; w < 32; w++) { uint32_t d = (k.l[w >> 2] >> ((w & 3) * 8)) & 0xffu; if (d) acc.madd_inl(table[w * 255 + d - 1]); }

@@ -24,7 +24,8 @@ bool g2_on_curve(const HFq2 &x, const HFq2 &y) { if (x.is_zero() && y.is_zero())
 
 struct G2Proj { HFq2 X, Y, Z; };
 static void doubling_step(const HFq &two_inv, G2Proj &c, EllCoeffs &o) {      // alt_bn128_pairing.cpp:242-268
-  HFq2 A = (c.X * c.Y).mul_fq(two_inv), B = c.Y.sqr(), C = c.Z.sqr(), D = C + C + C, E = twist_b() * D, F = E + E + E, G = (B + F).mul_fq(two_inv), H = (c.Y + c.Z).sqr() - (B + C), I = E - B, J = c.X.sqr(), E2 = E.sqr();
+  HFq2 A = (c.X * c.Y).mul_fq(two_inv), B = c.Y.sqr(), C = c.Z.sqr(), D = C + C + C, E = twist_b() * D, F = E + E + E, G = (B + F).mul_fq(two_inv),
+      H = (c.Y + c.Z).sqr() - (B + C), I = E - B, J = c.X.sqr(), E2 = E.sqr();
   c.X = A * (B - F); c.Y = G.sqr() - (E2 + E2 + E2); c.Z = B * H; o.ell_0 = I.mul_xi(); o.ell_VW = H.neg(); o.ell_VV = J + J + J; }
 static void mixed_addition_step(const HFq2 &x2, const HFq2 &y2, G2Proj &c, EllCoeffs &o) {   // :270-293
   HFq2 D = c.X - x2 * c.Z, E = c.Y - y2 * c.Z, F = D.sqr(), G = E.sqr(), H = D * F, I = c.X * F, J = H + c.Z * G - (I + I);
@@ -34,7 +35,9 @@ G2Precomp precompute_g2(const HFq2 &qx, const HFq2 &qy) {                    // 
   for (int i = 127; i >= 0; i--) { bool bit = (ATE_LOOP[i / 64] >> (i % 64)) & 1; if (!found) { found |= bit; continue; }
     doubling_step(two_inv, R, c); out.push_back(c); if (bit) { mixed_addition_step(qx, qy, R, c); out.push_back(c); } }
   const FrobeniusTables &t = frobenius_tables();
-  HFq2 q1x = t.twist_mul_by_q_x * qx.frob(1), q1y = t.twist_mul_by_q_y * qy.frob(1), q2x = t.twist_mul_by_q_x * q1x.frob(1), q2y = (t.twist_mul_by_q_y * q1y.frob(1)).neg();   // mul_by_q, alt_bn128_g2.cpp:367-372
+  // mul_by_q, alt_bn128_g2.cpp:367-372
+  HFq2 q1x = t.twist_mul_by_q_x * qx.frob(1), q1y = t.twist_mul_by_q_y * qy.frob(1), q2x = t.twist_mul_by_q_x * q1x.frob(1),
+      q2y = (t.twist_mul_by_q_y * q1y.frob(1)).neg();
   mixed_addition_step(q1x, q1y, R, c); out.push_back(c); mixed_addition_step(q2x, q2y, R, c); out.push_back(c); return out; }
 HFq12 miller_loop(const HFq &px, const HFq &py, const G2Precomp &q) {        // :368-418
   HFq12 f = HFq12::one(); bool found = false; size_t idx = 0;
@@ -46,7 +49,8 @@ HFq12 miller_loop(const HFq &px, const HFq &py, const G2Precomp &q) {        // 
 static HFq12 exp_by_neg_z(const HFq12 &a) { return a.cyclo_exp(BN_Z).conj(); }
 HFq12 final_exponentiation(const HFq12 &elt) {                               // :110-238
   HFq12 C0 = elt.conj() * elt.inv(), first = C0.frob(2) * C0;
-  HFq12 A = exp_by_neg_z(first), B = A.sqr(), C = B.sqr(), D = C * B, E = exp_by_neg_z(D), F = E.sqr(), G = exp_by_neg_z(F), H = D.conj(), I = G.conj(), J = I * E, K = J * H, L = K * B, M = K * E, N = M * first,
+  HFq12 A = exp_by_neg_z(first), B = A.sqr(), C = B.sqr(), D = C * B, E = exp_by_neg_z(D), F = E.sqr(), G = exp_by_neg_z(F), H = D.conj(), I = G.conj(),
+      J = I * E, K = J * H, L = K * B, M = K * E, N = M * first,
         O = L.frob(1), P = O * N, Q = K.frob(2), R = Q * P, S = first.conj(), T = S * L, U = T.frob(3);
   return U * R; }
 

@@ -21,7 +21,9 @@ struct HFq6 {
   HFq6 neg() const { return {c0.neg(), c1.neg(), c2.neg()}; }
   friend HFq6 operator*(const HFq6 &a, const HFq6 &b) {   // Karatsuba, fp6_3over2.tcc:94-108
     HFq2 aA = a.c0 * b.c0, bB = a.c1 * b.c1, cC = a.c2 * b.c2;
-    return {aA + ((a.c1 + a.c2) * (b.c1 + b.c2) - bB - cC).mul_xi(), (a.c0 + a.c1) * (b.c0 + b.c1) - aA - bB + cC.mul_xi(), (a.c0 + a.c2) * (b.c0 + b.c2) - aA + bB - cC}; }
+    return {aA + ((a.c1 + a.c2) * (b.c1 + b.c2) - bB - cC).mul_xi(), (a.c0 + a.c1) * (b.c0 + b.c1) - aA - bB + cC.mul_xi(),
+        (a.c0 + a.c2) * (b.c0 + b.c2) - aA + bB - cC};
+  }
   HFq6 sqr() const { return *this * *this; }
   HFq6 mul_by_v() const { return {c2.mul_xi(), c0, c1}; }                 // Fp12 mul_by_non_residue
   HFq6 mul_fq2(const HFq2 &k) const { return {c0 * k, c1 * k, c2 * k}; }
@@ -33,18 +35,38 @@ struct HFq6 {
 
 struct FrobeniusTables { HFq2 fq6_c1[6], fq6_c2[6], fq12_c1[12], twist_mul_by_q_x, twist_mul_by_q_y; };
 const FrobeniusTables &frobenius_tables();     // xi^((q^i-1)/3), xi^(2(q^i-1)/3), xi^((q^i-1)/6); alt_bn128_init.cpp:160-201
-inline HFq6 fq6_frob(const HFq6 &a, unsigned p) { const FrobeniusTables &t = frobenius_tables(); return {a.c0.frob(p), t.fq6_c1[p % 6] * a.c1.frob(p), t.fq6_c2[p % 6] * a.c2.frob(p)}; }
+inline HFq6 fq6_frob(const HFq6 &a, unsigned p) {
+  const FrobeniusTables &t = frobenius_tables();
+  return {a.c0.frob(p), t.fq6_c1[p % 6] * a.c1.frob(p), t.fq6_c2[p % 6] * a.c2.frob(p)};
+}
 
 struct HFq12 {
   HFq6 c0, c1;
   static HFq12 one() { return {HFq6::one(), HFq6::zero()}; }
-  friend HFq12 operator*(const HFq12 &a, const HFq12 &b) { HFq6 aA = a.c0 * b.c0, bB = a.c1 * b.c1; return {aA + bB.mul_by_v(), (a.c0 + a.c1) * (b.c0 + b.c1) - aA - bB}; }
+  friend HFq12 operator*(const HFq12 &a, const HFq12 &b) {
+    HFq6 aA = a.c0 * b.c0, bB = a.c1 * b.c1;
+    return {aA + bB.mul_by_v(), (a.c0 + a.c1) * (b.c0 + b.c1) - aA - bB};
+  }
   HFq12 sqr() const { return *this * *this; }
   HFq12 inv() const { HFq6 t = (c0.sqr() - c1.sqr().mul_by_v()).inv(); return {c0 * t, (c1 * t).neg()}; }
   HFq12 conj() const { return {c0, c1.neg()}; }                            // unitary_inverse
   HFq12 frob(unsigned p) const { const FrobeniusTables &t = frobenius_tables(); return {fq6_frob(c0, p), fq6_frob(c1, p).mul_fq2(t.fq12_c1[p % 12])}; }
-  HFq12 cyclo_exp(uint64_t e) const { HFq12 r = one(); bool found = false; for (int i = 63; i >= 0; i--) { if (found) r = r.sqr(); if ((e >> i) & 1) { found = true; r = r * *this; } } return r; }
-  HFq12 mul_by_024(const HFq2 &ell_0, const HFq2 &ell_VW, const HFq2 &ell_VV) const { HFq12 s{{ell_0, HFq2::zero(), ell_VV}, {HFq2::zero(), ell_VW, HFq2::zero()}}; return *this * s; }
+  HFq12 cyclo_exp(uint64_t e) const {
+    HFq12 r = one();
+    bool found = false;
+    for (int i = 63; i >= 0; i--) {
+      if (found) r = r.sqr();
+      if ((e >> i) & 1) {
+        found = true;
+        r = r * *this;
+      }
+    }
+    return r;
+  }
+  HFq12 mul_by_024(const HFq2 &ell_0, const HFq2 &ell_VW, const HFq2 &ell_VV) const {
+    HFq12 s{{ell_0, HFq2::zero(), ell_VV}, {HFq2::zero(), ell_VW, HFq2::zero()}};
+    return *this * s;
+  }
   bool operator==(const HFq12 &o) const { return c0 == o.c0 && c1 == o.c1; }
 };
 
@@ -53,7 +75,9 @@ typedef std::vector<EllCoeffs> G2Precomp;
 G2Precomp precompute_g2(const HFq2 &qx, const HFq2 &qy);                                   // affine Q
 HFq12 miller_loop(const HFq &px, const HFq &py, const G2Precomp &q);                      // affine P
 HFq12 final_exponentiation(const HFq12 &f);
-inline HFq12 reduced_pairing(const HFq &px, const HFq &py, const HFq2 &qx, const HFq2 &qy) { return final_exponentiation(miller_loop(px, py, precompute_g2(qx, qy))); }
+inline HFq12 reduced_pairing(const HFq &px, const HFq &py, const HFq2 &qx, const HFq2 &qy) {
+  return final_exponentiation(miller_loop(px, py, precompute_g2(qx, qy)));
+}
 bool g1_on_curve(const HFq &x, const HFq &y);
 bool g2_on_curve(const HFq2 &x, const HFq2 &y);
 

@@ -11,7 +11,7 @@ import sys
 
 LIMIT = 160
 BLOCK_WORDS = ("else", "do", "try", "const", "mutable", "noexcept", "override")
-WRAP_AT = (", ", " && ", " || ", " ? ", " : ", " + ", " - ", " = ", " | ", " ^ ", " << ")
+WRAP_RANKS = (("; ", "{ "), (", ",), (" && ", " || ", " ? ", " : ", " + ", " - ", " = ", " | ", " ^ ", " << "))
 
 
 def code_and_comment(text):
@@ -157,7 +157,7 @@ def wrap_piece(text, indent, limit):
     out, pre = [], " " * indent
     while len(pre) + len(text) > limit:
         room = limit - len(pre)
-        best, quote, i = -1, None, 0
+        last, quote, i = [-1, -1, -1], None, 0
         while i < min(len(text), room):
             c = text[i]
             if quote:
@@ -173,10 +173,13 @@ def wrap_piece(text, indent, limit):
                 i = j + 2 if j >= 0 else len(text)
                 continue
             else:
-                for w in WRAP_AT:
-                    if text.startswith(w, i) and i + len(w) <= room and i > 8:
-                        best = i + len(w)
+                for rank, seps in enumerate(WRAP_RANKS):
+                    for w in seps:
+                        if text.startswith(w, i) and i + len(w) <= room and i > 8:
+                            last[rank] = i + len(w)
             i += 1
+        # a statement boundary inside a lambda body beats a comma, a comma beats an operator — unless that leaves the line less than half full
+        best = last[0] if last[0] > room // 2 else last[1] if last[1] > room * 2 // 5 else max(last)
         if best <= 0:
             break
         out.append(pre + text[:best].rstrip())
@@ -297,7 +300,12 @@ def main():
     for path in files:
         with open(path) as f:
             src = f.readlines()
-        new = [l + "\n" for l in reformat(src, limit)]
+        new = src
+        for _ in range(4):                                  # (a wrapped line can expose another statement split: repeat until nothing moves)
+            nxt = [l + "\n" for l in reformat(new, limit)]
+            if nxt == new:
+                break
+            new = nxt
         if new != src:
             changed += 1
             if check:
