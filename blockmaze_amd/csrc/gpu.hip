@@ -332,7 +332,7 @@ static Fe32 fe261(HFr v) {
 // factor as pre261 (f 2^261) and the constant as scale261; pre_scale (f 2^256) is the same table for the stage-per-launch path beyond 2^22 points, which folds
 // a constant scale into it.
 struct NttCall { Fe32 *data, *scratch; const Fe32 *tw, *tw261; int logn; const Fe32 *pre_scale, *pre261; Fe32 scale261; const Fe32 *post_scale;
-    size_t stride, scratch_stride; };
+    size_t stride, scratch_stride; const Fe32 *out261 = nullptr; };   // out261: two-pass range only (NttJob::out261)
 // radix-4 passes measured best with two vectors per launch (twice the waves of radix 8: the passes are latency bound), radix 8 with three
 static int ntt_radix_log() {
   static const int rl = [] {
@@ -377,9 +377,9 @@ static void ntt_two_pass_launch(const NttCall *calls, int n_calls, int batch) {
         std::min(NTT_TILE_LOG - l2, l1));
     Fr sc; memcpy(&sc, &c.scale261, 32);
     cj[k] = NttJob{(const Fr *)c.data, (Fr *)c.scratch, (const Fr *)c.pre261, (const Fr *)c.tw261, sc, c.logn, l1, c1, 1u << (l2 - c1), c.stride,
-        c.scratch_stride};
+        c.scratch_stride, nullptr};
     rj[k] = NttJob{(const Fr *)c.scratch, (Fr *)c.data, (const Fr *)c.post_scale, (const Fr *)c.tw261, sc, c.logn, l1, c2, 1u << (l1 - c2), c.scratch_stride,
-        c.stride};
+        c.stride, (const Fr *)c.out261};
     tc = std::max(tc, ntt_threads_for(l1, c1));
     tr = std::max(tr, ntt_threads_for(l2, c2));
     lc = std::max(lc, ntt_lds_for(l1, c1));
@@ -399,12 +399,14 @@ static void radix2_transform(const NttCall &c, int batch) {
     ntt_raise_lds();
     Fr sc;
     memcpy(&sc, &c.scale261, 32);
-    NttJob j{(const Fr *)data, (Fr *)data, (const Fr *)c.pre261, (const Fr *)c.tw261, sc, logn, logn, 0, 1u, stride, stride}, none;
+    if (c.out261) throw GpuError("ntt: output factors on a single-pass transform");
+    NttJob j{(const Fr *)data, (Fr *)data, (const Fr *)c.pre261, (const Fr *)c.tw261, sc, logn, logn, 0, 1u, stride, stride, nullptr}, none;
     memset(&none, 0, sizeof none);
     hipLaunchKernelGGL(k_ntt_cols, dim3(1, batch), dim3(ntt_threads_for(logn, 0)), ntt_lds_for(logn, 0), s, j, none, ntt_radix_log());
     return;
   }
   if (ntt_two_pass(logn)) { ntt_two_pass_launch(&c, 1, batch); return; }
+  if (c.out261) throw GpuError("ntt: output factors outside the two-pass range");
   hipLaunchKernelGGL(k_ntt_bitrev_scale, dim3(cdiv(n, 256), batch), dim3(256), 0, s, (const Fr *)data, (Fr *)scratch, (const Fr *)c.pre_scale, logn, stride,
       scratch_stride);
   int L = NTT_LOCAL_LOG;
@@ -474,6 +476,7 @@ struct DomainTables {                                            // immutable pe
   DevBuf<Fe32> scale_big, scale_small;                            // 1/n as a table: the pre-scale of the stage-per-launch path (beyond 2^22 points)
   // the tile kernels' factor forms (f 2^261): g^i per element, the constants 1, 1/B (or 1/m), 1/S
   DevBuf<Fe32> coset_fwd261;
+  DevBuf<Fe32> inv_coset261;                                       // radix-2 domains in the two-pass range: 1/m g^i 2^261, the inverse transform's output factors when the coset transform follows
   Fe32 one261, inv_big261, inv_small261;
   HFr half;
 };
@@ -548,6 +551,16 @@ Domain::Domain(size_t min_size) : impl(new Impl(std::make_shared<DomainTables>()
     }
     d.coset_fwd261 = DevBuf<Fe32>(d.m);
     d.coset_fwd261.upload(cf.data(), d.m);
+    if (!d.step && ntt_two_pass(d.big->logn)) {
+      auto ic = geometric_table(d.m, HFr::from_u64(d.m).inv(), g);
+      for (auto &f : ic) {
+        HFr v;
+        memcpy(v.l, &f, 32);
+        f = fe261(v);
+      }
+      d.t->inv_coset261 = DevBuf<Fe32>(d.m);
+      d.t->inv_coset261.upload(ic.data(), d.m);
+    }
   }
   d.scratch_stride = d.m; d.scratch = DevBuf<Fe32>(d.step ? 6 * d.B : 3 * d.m);
 }
@@ -598,8 +611,20 @@ void Domain::ifft(Fe32 *data, int batch, size_t stride) {
       (uint32_t)d.B, (uint32_t)d.S, stride);
 }
 void Domain::ifft_then_coset_fft(Fe32 *data, int batch, size_t stride) {
-  Impl &d = *impl; if (!d.step) { ifft(data, batch, stride); coset_fft(data, batch, stride); return; }
+  Impl &d = *impl;
   if (batch > 3) throw GpuError("domain: batch > 3");
+  if (!d.step) {
+    // ZK_NTT_FOLD_COSET=0: the two transforms as they are called one by one (g^i multiplied in by the forward transform's column pass)
+    static const bool fold = [] { const char *e = getenv("ZK_NTT_FOLD_COSET"); return !e || atoi(e) != 0; }();
+    if (!fold || !d.t->inv_coset261.get()) { ifft(data, batch, stride); coset_fft(data, batch, stride); return; }
+    { Stage st("ntt.inverse");      // 1/m and g^i leave with the row pass's last product
+      radix2_transform(NttCall{data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, nullptr, nullptr, d.inv_big261, nullptr, stride,
+          d.scratch_stride, d.t->inv_coset261.get()}, batch); }
+    { Stage st("ntt.forward");
+      radix2_transform(NttCall{data, d.scratch.get(), d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride,
+          d.scratch_stride}, batch); }
+    return;
+  }
   hipStream_t s = gpu().stream;
   Fe32 *dbuf = d.scratch.get(), *tmp = d.scratch.get() + 3 * d.B;
   Fr half;

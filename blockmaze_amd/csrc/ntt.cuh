@@ -129,7 +129,19 @@ __device__ __forceinline__ void ntt29_lds_transform(Fr29 *tile, Fr29 *twl, int l
 // row pass, or the column pass when it is the whole transform); tw261[j] = w_n^j 2^261 mod r for j < n/2 — all canonical.
 // A launch carries up to TWO jobs (blockIdx.x < a.tiles: job a, else job b): the B-point and the S-point transform of a step-radix-2 domain (mint, redeem,
 // deposit-32) run side by side in one launch instead of one after the other — each alone fills half the chip or less and is as long as its dependent passes.
-struct NttJob { const Fr *src; Fr *dst; const Fr *factor; const Fr *tw261; Fr scale261; int logn, log_n1, logC; uint32_t tiles; size_t stride_in, stride_out; };
+// out261 (row pass only): a factor per OUTPUT element in place of the constant scale261 — the inverse transform of a radix-2 domain hands the coset factor g^i of the
+// forward transform that follows to its own last product (1/m g^i 2^261), which costs that product a 32-byte load and saves the next column pass a product per element.
+struct NttJob {
+  const Fr *src;
+  Fr *dst;
+  const Fr *factor;
+  const Fr *tw261;
+  Fr scale261;
+  int logn, log_n1, logC;
+  uint32_t tiles;
+  size_t stride_in, stride_out;
+  const Fr *out261;
+};
 __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(NttJob ja, NttJob jb, int radix_log) {
   extern __shared__ uint32_t lds_raw[]; Fr29 *tile = reinterpret_cast<Fr29 *>(lds_raw);
   const bool second = blockIdx.x >= ja.tiles; const NttJob j = second ? jb : ja;   // by value: uniform selects, a reference would put both jobs on the stack
@@ -164,7 +176,7 @@ __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(NttJob ja, NttJob
 __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_rows(NttJob ja, NttJob jb, int radix_log) {
   extern __shared__ uint32_t lds_raw[]; Fr29 *tile = reinterpret_cast<Fr29 *>(lds_raw);
   const bool second = blockIdx.x >= ja.tiles; const NttJob &j = second ? jb : ja; const uint32_t bid = blockIdx.x - (second ? ja.tiles : 0u);
-  const int logn = j.logn, log_n1 = j.log_n1, logC = j.logC; const Fr *__restrict__ tw261 = j.tw261; const Fr *__restrict__ post = j.factor;
+  const int logn = j.logn, log_n1 = j.log_n1, logC = j.logC; const Fr *__restrict__ tw261 = j.tw261; const Fr *__restrict__ post = j.factor; const Fr *__restrict__ out261 = j.out261;
   const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, r0 = bid << logC, elems = n2 << logC;
   const Fr *s = j.src + blockIdx.y * j.stride_in; Fr *d = j.dst + blockIdx.y * j.stride_out;
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
@@ -176,7 +188,8 @@ __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_rows(NttJob ja, NttJob
   const Fr29 one = ntt29_from_words(j.scale261);   // 2^261 mod r when nothing is to be scaled: the product then only brings the element back below 2 r
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
     uint32_t k2 = w >> logC, c = w & (C - 1), p = bitrev32(k2, log_n2), o = (k2 << log_n1) + r0 + c;
-    Fr v = ntt29_to_words(Fr29::mul(one, tile[ntt_pad((p << logC) + c)]));
+    const Fr29 f = out261 ? ntt29_from_words(out261[o]) : one;
+    Fr v = ntt29_to_words(Fr29::mul(f, tile[ntt_pad((p << logC) + c)]));
     if (post) v = v * post[o];
     d[o] = v;
   }
