@@ -59,6 +59,15 @@ def check_bounds():
         assert KS[c][NL - 1] >= int(need * Q) >> (B * (NL - 1)), (c, need)
     return dict(cP=cP, cR=cR, cX=cX, cT=cT, cY=cY, bounds=dict(X=nX, Y=nY, ZZ=nZZ, ZZZ=nZZZ, P=bP, R=bR, T=bT))
 BOUNDS = check_bounds()
+def check_bounds_ntt_stages():
+    """the transform tiles (ntt.cuh: ntt29_lds_pass) normalize after every second butterfly stage: a normalized limb (below 2^29 + 8) that goes through two un-normalized
+    differences u + KL_2 - t (each adds at most 2^30 + 64, sub_product) must still be a legal wide operand of a product (below 2^31.4, the column bound in check_bounds),
+    and fit 32 bits with room for the carry step"""
+    wide = int(2 ** 31.4); limb = (1 << 29) + 8
+    for stage in range(2): limb += (1 << 30) + 64
+    assert limb < wide, (limb, wide)
+    assert limb + (1 << 30) + 64 >= wide            # (and a third stage would not fit: the rule in ntt29_lds_pass is as lazy as it can be)
+check_bounds_ntt_stages()
 def check_bounds_add():
     """the general addition of two accumulators (k_hacc_combine29): add-2008-s on operands within the invariant above stays within it"""
     bX, bY, bZ = 5.5, 3.6, 1.1

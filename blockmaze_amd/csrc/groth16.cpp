@@ -973,8 +973,8 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); const size_t n = p.nv + 1, words = (n + 63) / 64;
   Fe32 one; if (montgomery) memcpy(&one, FrParams::R1, 32); else { memset(&one, 0, 32); one.l[0] = 1; }
   // compact form (k_expand_witness): bitmaps of the entries equal to one / to anything else than 0 and 1, offsets, and the "anything else" values only. The
-  // scan of the 7 MB assignment is memory-bound on one core (0.3 ms for send), so the prover's four submit threads — idle at this point of a proof — take a
-  // quarter of the words each; every thread owns a quarter of the value area, the per-word offsets make the pieces look like one list to the kernel.
+  // scan of the 7 MB assignment is memory-bound on one core (0.3 ms for send), so the prover's submit threads — idle at this point of a proof — and, on hosts
+  // with many cores, a dozen scan threads share it chunk by chunk (below); the per-word offsets make the value area look like one list to the kernel.
   uint8_t *pk = reinterpret_cast<uint8_t *>(p.z_host.get());
   uint64_t *ones = (uint64_t *)pk, *other = ones + words;
   uint32_t *off = (uint32_t *)(other + words);
@@ -998,21 +998,49 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
       } } busy(scanning);
   // several provers handing over at once (proofs in flight): four threads each, as before
   const size_t T = busy.before == 0 ? T_many : std::min<size_t>(T_many, 4);
-  const size_t cap_t = max_other / T; size_t used[TMAX] = {}; bool fits[TMAX]; for (size_t t = 0; t < TMAX; t++) fits[t] = true;
-  auto scan = [&](size_t t) { const size_t w0 = words * t / T, w1 = words * (t + 1) / T, base = t * cap_t; size_t n_other = 0;
-    for (size_t w = w0; w < w1; w++) { uint64_t mo = 0, mx = 0; const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n; off[w] = (uint32_t)(base + n_other);
-      // a whole block: 256-bit loads where the host has them
-      if (lo && hi - lo == 64) classify_block64(zz + 4 * lo, o1, mo, mx);
-      else for (size_t i = lo ? lo : 1; i < hi; i++) { const uint64_t *v = zz + 4 * i;                           // branch-free classification of a ragged block
-        const uint64_t nz = (v[0] | v[1] | v[2] | v[3]) != 0, is1 = ((v[0] ^ o1[0]) | (v[1] ^ o1[1]) | (v[2] ^ o1[2]) | (v[3] ^ o1[3])) == 0;
-        mo |= is1 << (i - lo);
-        mx |= (nz & (is1 ^ 1)) << (i - lo);
+  // The words are handed out in chunks of 32 (2,048 entries = 64 KB of the assignment) from one counter instead of being cut into T equal parts: with equal parts the
+  // hand-over takes as long as its SLOWEST thread, and on the two-socket GPU hosts some of the sixteen threads always sit on the other socket from the caller's buffer, share
+  // a core or meet another tenant (0.13 to 0.30 ms from process to process for one and the same build, profiles/r04w_host_placement.txt); with chunks a slow thread
+  // simply takes fewer.  A chunk is classified first (its masks stay on the stack), reserves room for its values with ONE atomic on the shared cursor of the value area,
+  // and copies them there: off[w] is an absolute position, so k_expand_witness does not care in which order the chunks arrived, and nothing has to be closed up afterwards.
+  constexpr size_t CHUNK_WORDS = 32;
+  const size_t n_chunks = (words + CHUNK_WORDS - 1) / CHUNK_WORDS;
+  std::atomic<size_t> next_chunk{0}, value_cursor{0};
+  std::atomic<bool> overflow{false};
+  auto scan = [&](size_t) {
+    for (;;) {
+      const size_t ch = next_chunk.fetch_add(1, std::memory_order_relaxed);
+      if (ch >= n_chunks || overflow.load(std::memory_order_relaxed)) break;
+      const size_t w0 = ch * CHUNK_WORDS, w1 = std::min(words, w0 + CHUNK_WORDS);
+      uint64_t mo[CHUNK_WORDS], mx[CHUNK_WORDS];
+      size_t cnt = 0;
+      for (size_t w = w0; w < w1; w++) {
+        uint64_t o = 0, x = 0;
+        const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n;
+        // a whole block: 256-bit loads where the host has them
+        if (lo && hi - lo == 64) classify_block64(zz + 4 * lo, o1, o, x);
+        else for (size_t i = lo ? lo : 1; i < hi; i++) {                                                             // branch-free classification of a ragged block
+          const uint64_t *v = zz + 4 * i;
+          const uint64_t nz = (v[0] | v[1] | v[2] | v[3]) != 0, is1 = ((v[0] ^ o1[0]) | (v[1] ^ o1[1]) | (v[2] ^ o1[2]) | (v[3] ^ o1[3])) == 0;
+          o |= is1 << (i - lo);
+          x |= (nz & (is1 ^ 1)) << (i - lo);
+        }
+        if (!lo) o |= 1;                                                                                           // the constant ONE
+        mo[w - w0] = o;
+        mx[w - w0] = x;
+        cnt += (size_t)__builtin_popcountll(x);
       }
-      if (!lo) mo |= 1;                                                                                          // the constant ONE
-      const size_t cnt = (size_t)__builtin_popcountll(mx); if (n_other + cnt > cap_t) { fits[t] = false; return; }
-      for (uint64_t m = mx; m; m &= m - 1) memcpy(&vals[base + n_other++], zz + 4 * (lo + (size_t)__builtin_ctzll(m)), 32);
-      ones[w] = mo; other[w] = mx; }
-    used[t] = n_other; };
+      size_t at = cnt ? value_cursor.fetch_add(cnt, std::memory_order_relaxed) : 0;
+      if (at + cnt > max_other) { overflow.store(true, std::memory_order_relaxed); break; }                        // too many other values: the call takes the dense path
+      for (size_t w = w0; w < w1; w++) {
+        const size_t lo = 64 * w;
+        off[w] = (uint32_t)at;
+        for (uint64_t m = mx[w - w0]; m; m &= m - 1) memcpy(&vals[at++], zz + 4 * (lo + (size_t)__builtin_ctzll(m)), 32);   // (the chunk's 64 KB are still in this core's cache)
+        ones[w] = mo[w - w0];
+        other[w] = mx[w - w0];
+      }
+    }
+  };
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
   // threads 1 .. 3: the MSMs' submit threads; 4 .. 7: scan only
   auto worker = [&](size_t t) -> SubmitWorker & { std::unique_ptr<SubmitWorker> &w = t < 4 ? p.workers[t] : p.scan_workers[t - 4];
@@ -1025,19 +1053,10 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   else for (size_t t = 0; t < T; t++) scan(t);
   // (test switch: the plain-copy branch below, which no BlockMaze assignment reaches on its own)
   static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;
-  bool compact = !force_dense; for (size_t t = 0; t < T; t++) compact = compact && fits[t];
-  // the threads' value areas are closed up (a few hundred KB) so that ONE copy carries bitmaps, offsets and values; the few values that are not 0 or 1 are
-  // brought into Montgomery form by the expanding kernel itself
+  const bool compact = !force_dense && !overflow.load();
+  // ONE copy carries bitmaps, offsets and values (a few hundred KB); the few values that are not 0 or 1 are brought into Montgomery form by the expanding kernel itself
   if (compact) {
-    size_t total = used[0];
-    for (size_t t = 1; t < T; t++) {
-      if (used[t]) {
-        const uint32_t delta = (uint32_t)(t * cap_t - total);
-        memmove(&vals[total], &vals[t * cap_t], 32 * used[t]);
-        for (size_t w = words * t / T; w < words * (t + 1) / T; w++) off[w] -= delta;
-      }
-      total += used[t];
-    }
+    const size_t total = value_cursor.load();
     // (letting the kernel read the pinned staging area itself, no copy, was measured: no faster)
     Fe32 one_mont;
     memcpy(&one_mont, FrParams::R1, 32);
@@ -1070,45 +1089,63 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
   uint32_t *off = (uint32_t *)(canon + words);
   const size_t vals_at = expand_values_offset(words, 2); Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
   const bool avx2 = host_has_avx2();
-  // like set_witness: the prover's submit threads — idle at this point of a call — take a quarter of the words each (0.28 -> 0.1 ms for send on the GPU box's
-  // host); every thread owns a quarter of the value area, closed up afterwards
-  constexpr size_t T = 4; const size_t cap_t = max_other / T; size_t used[T] = {0, 0, 0, 0}; bool fits_t[T] = {true, true, true, true};
-  auto scan = [&](size_t t) {
-    const size_t w0 = words * t / T, w1 = words * (t + 1) / T, base = t * cap_t;
-    size_t n_other = 0, pend_lo = 0;
-    uint64_t pend_mx = 0, pend_mc = 0;
-    auto copy_values = [&](size_t lo, uint64_t mx, uint64_t mc) {
-      for (uint64_t m = mx; m; m &= m - 1) { const size_t i = lo + (size_t)__builtin_ctzll(m); Fe32 &dst = vals[base + n_other++];
-        // a small integer the board kept as it was (circuit::Board::TAG_SMALL, only its low 64 bits are meaningful): the device converts it
-        if ((mc >> (i - lo)) & 1) {
-          memset(&dst, 0, 32);
-          dst.l[0] = wide[i].l[0];
-          dst.l[1] = wide[i].l[1];
-        }
-        else dst = wide[i]; } };
-    for (size_t w = w0; w < w1; w++) {
-      const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n;
-      uint64_t mo = 0, mx = 0, mc = 0;
-      off[w] = (uint32_t)(base + n_other + (size_t)__builtin_popcountll(pend_mx));
-      if (hi - lo == 64) {
+  // like set_witness: the prover's submit threads — idle at this point of a call — share the words chunk by chunk (0.28 -> 0.1 ms for send on the GPU box's host with
+  // four threads).  A chunk of 32 words is classified first — every value it will need is prefetched on the way: the 7,600 values lie scattered over a 7 MB array of board
+  // entries, one cache miss each —, reserves its run of the value area with one atomic, then copies the values, which have had the whole chunk's time to arrive.
+  constexpr size_t T = 4, CHUNK_WORDS = 32;
+  const size_t n_chunks = (words + CHUNK_WORDS - 1) / CHUNK_WORDS;
+  std::atomic<size_t> next_chunk{0}, value_cursor{0};
+  std::atomic<bool> overflow{false};
+  auto scan = [&](size_t) {
+    for (;;) {
+      const size_t ch = next_chunk.fetch_add(1, std::memory_order_relaxed);
+      if (ch >= n_chunks || overflow.load(std::memory_order_relaxed)) break;
+      const size_t w0 = ch * CHUNK_WORDS, w1 = std::min(words, w0 + CHUNK_WORDS);
+      uint64_t mo[CHUNK_WORDS], mx[CHUNK_WORDS], mc[CHUNK_WORDS];
+      size_t cnt = 0;
+      for (size_t w = w0; w < w1; w++) {
+        const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n;
+        uint64_t o = 0, x = 0, c = 0;
+        if (hi - lo == 64) {
 #if defined(__x86_64__)
-        if (avx2) tags_block64_avx2(tag + lo, mo, mx, mc); else
+          if (avx2) tags_block64_avx2(tag + lo, o, x, c); else
 #endif
-        tags_block64_scalar(tag + lo, mo, mx, mc); }
-      else for (size_t i = lo; i < hi; i++) {
-        mo |= (uint64_t)(tag[i] & 1) << (i - lo);
-        mx |= (uint64_t)((tag[i] >> 1) & 1) << (i - lo);
-        mc |= (uint64_t)((tag[i] >> 2) & 1) << (i - lo);
+          tags_block64_scalar(tag + lo, o, x, c);
+        }
+        else for (size_t i = lo; i < hi; i++) {
+          o |= (uint64_t)(tag[i] & 1) << (i - lo);
+          x |= (uint64_t)((tag[i] >> 1) & 1) << (i - lo);
+          c |= (uint64_t)((tag[i] >> 2) & 1) << (i - lo);
+        }
+        for (uint64_t m = x; m; m &= m - 1) __builtin_prefetch(&wide[lo + (size_t)__builtin_ctzll(m)]);
+        mo[w - w0] = o;
+        mx[w - w0] = x;
+        mc[w - w0] = c;
+        cnt += (size_t)__builtin_popcountll(x);
       }
-      if (n_other + (size_t)__builtin_popcountll(mx) + (size_t)__builtin_popcountll(pend_mx) > cap_t) { fits_t[t] = false; return; }
-      // this block's values are fetched while the previous block's are copied:
-      for (uint64_t m = mx; m; m &= m - 1) __builtin_prefetch(&wide[lo + (size_t)__builtin_ctzll(m)]);
-      // the 7,600 values lie scattered over a 7 MB array, one cache miss each
-      copy_values(pend_lo, pend_mx, pend_mc);
-      pend_lo = lo; pend_mx = mx; pend_mc = mc;
-      ones[w] = mo; other[w] = mx; canon[w] = mc; }
-    copy_values(pend_lo, pend_mx, pend_mc);
-    used[t] = n_other; };
+      size_t at = cnt ? value_cursor.fetch_add(cnt, std::memory_order_relaxed) : 0;
+      if (at + cnt > max_other) { overflow.store(true, std::memory_order_relaxed); break; }
+      for (size_t w = w0; w < w1; w++) {
+        const size_t lo = 64 * w;
+        const uint64_t c = mc[w - w0];
+        off[w] = (uint32_t)at;
+        for (uint64_t m = mx[w - w0]; m; m &= m - 1) {
+          const size_t i = lo + (size_t)__builtin_ctzll(m);
+          Fe32 &dst = vals[at++];
+          // a small integer the board kept as it was (circuit::Board::TAG_SMALL, only its low 64 bits are meaningful): the device converts it
+          if ((c >> (i - lo)) & 1) {
+            memset(&dst, 0, 32);
+            dst.l[0] = wide[i].l[0];
+            dst.l[1] = wide[i].l[1];
+          }
+          else dst = wide[i];
+        }
+        ones[w] = mo[w - w0];
+        other[w] = mx[w - w0];
+        canon[w] = c;
+      }
+    }
+  };
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
   auto worker = [&](size_t t) -> SubmitWorker & { if (!p.workers[t]) p.workers[t].reset(new SubmitWorker(p.lane)); return *p.workers[t]; };
   if (threaded && words >= 512) {
@@ -1117,23 +1154,15 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
     for (size_t t = 1; t < T; t++) worker(t).wait();
   }
   else for (size_t t = 0; t < T; t++) scan(t);
-  bool fits = true; for (size_t t = 0; t < T; t++) fits = fits && fits_t[t];
+  const bool fits = !overflow.load();
   static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;
   static const bool trace = getenv("ZK_TRACE_TIMES") != nullptr;
   const double t1 = now_ms();
   if (fits && !force_dense) {
-    size_t n_other = used[0];
-    for (size_t t = 1; t < T; t++) {
-      if (used[t]) {
-        const uint32_t delta = (uint32_t)(t * cap_t - n_other);
-        memmove(&vals[n_other], &vals[t * cap_t], 32 * used[t]);
-        for (size_t w = words * t / T; w < words * (t + 1) / T; w++) off[w] -= delta;
-      }
-      n_other += used[t];
-    }
+    const size_t n_other = value_cursor.load();
     const double t2 = now_ms(); upload_async(p.packed.get(), pk, vals_at + 32 * n_other); const double t3 = now_ms();
     expand_witness_dev(p.packed.get(), words, one, 2, n, p.z.get(), p.tags.get(), p.other_vars.get()); p.tags_valid = true; p.n_other = (uint32_t)n_other;
-    if (trace) fprintf(stderr, "trace-handover: scan %.3f close-up %.3f copy call %.3f (%zu bytes) expand launch %.3f ms\n", t1 - t0, t2 - t1, t3 - t2,
+    if (trace) fprintf(stderr, "trace-handover: scan %.3f (close-up: none) %.3f copy call %.3f (%zu bytes) expand launch %.3f ms\n", t1 - t0, t2 - t1, t3 - t2,
         vals_at + 32 * n_other, now_ms() - t3);
   }
   // a dense assignment (never a BlockMaze one)

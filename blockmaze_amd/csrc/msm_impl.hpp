@@ -380,8 +380,7 @@ struct MsmImpl {
       {
         Stage st((label + ".combine").c_str(), s);
         const size_t pieces = n * (size_t)W / NB / h_run;
-        static const int ll_env = [] { const char *e = getenv("ZK_MSM_COMBINE_LL"); return e ? std::max(1, std::min(3, atoi(e))) : 0; }();   // log2 of the lanes per bucket, 1 .. 3
-        const uint32_t ll = ll_env ? (uint32_t)ll_env : pieces > 40 ? 3 : pieces > 18 ? 2 : 1;
+        const uint32_t ll = pieces > 40 ? 3 : pieces > 18 ? 2 : 1;
         hipLaunchKernelGGL(k_hacc_combine29, dim3(cdiv(nbk << ll, 256)), dim3(256), 0, s, (const Piece29 *)partials.get(), offsets.get(), hist(), hs, h_run,
             h_maxp, (uint32_t)nbk, ll, (XYZZ<Fq> *)bucket_array(), htail29 ? (Point29Rec *)hb29.get() : nullptr, cnt);
       }

@@ -107,7 +107,13 @@ template <int R> __device__ __forceinline__ void ntt29_lds_pass(Fr29 *tile, cons
       for (int q = 0; q < (1 << R); q++) if (!(q & hx)) {
         const uint32_t blk = (base + ((uint32_t)q << sh)) >> st; Fr29 u = x[q], v = x[q + hx];
         if (bits) v = Fr29::mul(v, twl[(__brev(blk) >> (32 - bits)) << (st - 1)]);   // (bits is the same for the whole workgroup)
-        x[q] = Fr29::add_raw(u, v).norm(); x[q + hx] = Fr29::sub_product(u, v).norm(); }
+        // limbs are brought back to 29 bits after every SECOND stage (and after the last one of the pass): a product takes one operand with limbs up to 2^31.4, and
+        // two stages add at most 2 (2^30 + 64) to a normalized limb (gen_field29.py: check_bounds_ntt_stages) — a third would not fit
+        const Fr29 sum = Fr29::add_raw(u, v), dif = Fr29::sub_product(u, v);
+        const bool carry_now = (t & 1) == 1 || t == R - 1;
+        x[q] = carry_now ? sum.norm() : sum;
+        x[q + hx] = carry_now ? dif.norm() : dif;
+      }
     }
 #pragma unroll
     for (int q = 0; q < (1 << R); q++) tile[ntt_pad(((base + ((uint32_t)q << sh)) << logC) + c)] = x[q];
