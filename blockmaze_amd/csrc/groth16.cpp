@@ -774,6 +774,12 @@ struct Prover::Impl {
   PinnedBuf<Fe32> z_host;
   // scan_workers: only the hand-over scan of a host-buffer assignment (set_witness) on hosts with many cores
   std::unique_ptr<SubmitWorker> workers[4], scan_workers[12];
+  // thread t of a hand-over scan: 1 .. 3 are the MSMs' submit threads (idle at that point of a proof), 4 .. 15 scan only
+  SubmitWorker &scan_worker(size_t t) {
+    std::unique_ptr<SubmitWorker> &w = t < 4 ? workers[t] : scan_workers[t - 4];
+    if (!w) w.reset(new SubmitWorker(lane));
+    return *w;
+  }
   // The submit thread of a witness MSM also waits for its stream and finishes the MSM on the host (Horner combine, or the host tail of msm_impl.hpp): four
   // threads do that side by side while the H chain is still running. pending[j]: job j (order B2, L, A, B1) was posted and its result slot is not valid before
   // workers[j]->wait().
@@ -969,6 +975,27 @@ void test_scan_blocks(const uint8_t tags[64], const uint64_t elems[256], const u
   uint64_t o1[4] = {one[0], one[1], one[2], one[3]};
   classify_block64_scalar(elems, o1, out[6], out[7]); classify_block64(elems, o1, out[8], out[9]);
 }
+// How many threads share a hand-over scan.  (Round 3 measured six and eight threads no faster than four — on assignments that sat in the host's last-level cache.
+// bench.py cycles through 400 MB of distinct assignments: each scan then streams 7.3 MB from DRAM, a core sustains ~10 GB/s of that, and eight threads halve the
+// 0.17 ms; sixteen gain another 5-8 % per proof on the GPU boxes (256 hardware threads visible; profiles/r04v_scan.txt); hosts with fewer than 32 / 12 hardware
+// threads keep eight / four.)  Several provers handing over at once (proofs in flight) get four threads each.
+struct ScanCrew {
+  static constexpr size_t TMAX = 16;
+  static size_t many() {
+    static const size_t v = [] {
+      const char *e = getenv("ZK_SCAN_THREADS");
+      const unsigned hw = std::thread::hardware_concurrency();
+      const size_t t = e ? (size_t)atoi(e) : (hw >= 32 ? 16 : hw >= 12 ? 8 : 4);
+      return t < 1 ? (size_t)1 : t > TMAX ? TMAX : t;
+    }();
+    return v;
+  }
+  static std::atomic<int> &scanning() { static std::atomic<int> c{0}; return c; }
+  int before;
+  size_t threads;
+  ScanCrew() : before(scanning().fetch_add(1)), threads(before == 0 ? many() : std::min<size_t>(many(), 4)) {}
+  ~ScanCrew() { scanning().fetch_sub(1); }
+};
 void Prover::set_witness(const Fe32 *z, bool montgomery) {
   Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); const size_t n = p.nv + 1, words = (n + 63) / 64;
   Fe32 one; if (montgomery) memcpy(&one, FrParams::R1, 32); else { memset(&one, 0, 32); one.l[0] = 1; }
@@ -983,27 +1010,14 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   uint64_t o1[4];
   memcpy(o1, &one, 32);
   const uint64_t *zz = reinterpret_cast<const uint64_t *>(z) - 4;
-  // (round 3 measured six and eight threads no faster than four — on assignments that sat in the host's last-level cache. bench.py cycles through 400 MB of
-  // distinct assignments: each scan then streams 7.3 MB from DRAM, a core sustains ~10 GB/s of that, and eight threads halve the 0.17 ms; sixteen gain another
-  // 5-8 % per proof on the GPU boxes (256 hardware threads visible; profiles/r04v_scan.txt); hosts with fewer than 32 / 12 hardware threads keep eight / four)
-  constexpr size_t TMAX = 16;
-  static const size_t T_many = [] {
-    const char *e = getenv("ZK_SCAN_THREADS");
-    const unsigned hw = std::thread::hardware_concurrency();
-    size_t t = e ? (size_t)atoi(e) : (hw >= 32 ? 16 : hw >= 12 ? 8 : 4);
-    return t < 1 ? (size_t)1 : t > TMAX ? TMAX : t;
-  }();
-  static std::atomic<int> scanning{0};
-  struct Busy { std::atomic<int> &c; int before; explicit Busy(std::atomic<int> &c_) : c(c_), before(c.fetch_add(1)) {} ~Busy() { c.fetch_sub(1);
-      } } busy(scanning);
-  // several provers handing over at once (proofs in flight): four threads each, as before
-  const size_t T = busy.before == 0 ? T_many : std::min<size_t>(T_many, 4);
+  ScanCrew crew;
+  const size_t T = crew.threads;
   // The words are handed out in chunks of 32 (2,048 entries = 64 KB of the assignment) from one counter instead of being cut into T equal parts: with equal parts the
   // hand-over takes as long as its SLOWEST thread, and on the two-socket GPU hosts some of the sixteen threads always sit on the other socket from the caller's buffer, share
   // a core or meet another tenant (0.13 to 0.30 ms from process to process for one and the same build, profiles/r04w_host_placement.txt); with chunks a slow thread
   // simply takes fewer.  A chunk is classified first (its masks stay on the stack), reserves room for its values with ONE atomic on the shared cursor of the value area,
   // and copies them there: off[w] is an absolute position, so k_expand_witness does not care in which order the chunks arrived, and nothing has to be closed up afterwards.
-  constexpr size_t CHUNK_WORDS = 32;
+  constexpr size_t CHUNK_WORDS = 32, CHUNK_MAX = CHUNK_WORDS;   // (16 / 8 / 4 words per chunk: 0.10-0.16 / 0.15-0.35 / 0.39-0.56 ms against 0.07-0.15 — the two counters are shared across sockets; profiles/r04y_chunk_sweep.txt)
   const size_t n_chunks = (words + CHUNK_WORDS - 1) / CHUNK_WORDS;
   std::atomic<size_t> next_chunk{0}, value_cursor{0};
   std::atomic<bool> overflow{false};
@@ -1012,7 +1026,7 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
       const size_t ch = next_chunk.fetch_add(1, std::memory_order_relaxed);
       if (ch >= n_chunks || overflow.load(std::memory_order_relaxed)) break;
       const size_t w0 = ch * CHUNK_WORDS, w1 = std::min(words, w0 + CHUNK_WORDS);
-      uint64_t mo[CHUNK_WORDS], mx[CHUNK_WORDS];
+      uint64_t mo[CHUNK_MAX], mx[CHUNK_MAX];
       size_t cnt = 0;
       for (size_t w = w0; w < w1; w++) {
         uint64_t o = 0, x = 0;
@@ -1042,9 +1056,7 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
     }
   };
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
-  // threads 1 .. 3: the MSMs' submit threads; 4 .. 7: scan only
-  auto worker = [&](size_t t) -> SubmitWorker & { std::unique_ptr<SubmitWorker> &w = t < 4 ? p.workers[t] : p.scan_workers[t - 4];
-      if (!w) w.reset(new SubmitWorker(p.lane)); return *w; };
+  auto worker = [&](size_t t) -> SubmitWorker & { return p.scan_worker(t); };
   if (threaded && words >= 512) {
     for (size_t t = 1; t < T; t++) worker(t).post([&scan, t] { scan(t); });
     scan(0);
@@ -1092,7 +1104,9 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
   // like set_witness: the prover's submit threads — idle at this point of a call — share the words chunk by chunk (0.28 -> 0.1 ms for send on the GPU box's host with
   // four threads).  A chunk of 32 words is classified first — every value it will need is prefetched on the way: the 7,600 values lie scattered over a 7 MB array of board
   // entries, one cache miss each —, reserves its run of the value area with one atomic, then copies the values, which have had the whole chunk's time to arrive.
-  constexpr size_t T = 4, CHUNK_WORDS = 32;
+  constexpr size_t CHUNK_WORDS = 32;
+  ScanCrew crew;
+  const size_t T = crew.threads;
   const size_t n_chunks = (words + CHUNK_WORDS - 1) / CHUNK_WORDS;
   std::atomic<size_t> next_chunk{0}, value_cursor{0};
   std::atomic<bool> overflow{false};
@@ -1147,7 +1161,7 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
     }
   };
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
-  auto worker = [&](size_t t) -> SubmitWorker & { if (!p.workers[t]) p.workers[t].reset(new SubmitWorker(p.lane)); return *p.workers[t]; };
+  auto worker = [&](size_t t) -> SubmitWorker & { return p.scan_worker(t); };
   if (threaded && words >= 512) {
     for (size_t t = 1; t < T; t++) worker(t).post([&scan, t] { scan(t); });
     scan(0);

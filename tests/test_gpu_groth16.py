@@ -386,3 +386,18 @@ def test_key_generation_executables(tmp_path):
     pk, vk = str(tmp_path / "mintpk.txt"), str(tmp_path / "mintvk.txt"); assert os.path.getsize(pk) > 40e6 and os.path.getsize(vk) > 1000
     m = w.mint_instance(9); wp = str(tmp_path / "w.bin"); e.witness_mint_redeem(False, *hexargs(w.mint_args(m)), wp); p = e.Prover(pk); proof = p.prove(o.load_witness(wp)); p.close()
     assert e.verify(vk, proof, w.pack_public([m["cmtA_old"], m["sn_old"], m["cmtA"]], m["value_s"]))
+
+def test_hand_over_takes_the_dense_path_on_its_own_for_a_random_assignment(tmp_path):
+    """Prover::set_witness: an assignment with more than a quarter of its entries neither 0 nor 1 overruns the compact form's value area — noticed by the chunk whose
+    reservation ends past it (groth16.cpp: the scan's shared cursor) — and goes up as a plain copy instead.  No BlockMaze circuit does that (ZK_WITNESS_DENSE forces the
+    same branch for them); a random R1CS of 40,000 variables does, on the threaded scan (625 words).  Proof bytes = the oracle's; a second system takes the
+    plain-copy path again with a ragged last word (33,001 entries), each proved twice by one prover object: the same."""
+    from r1cs_util import random_r1cs
+    for seed, nv, nc in ((77, 40000, 40050), (78, 33000, 33001)):
+        cs, z = random_r1cs(seed, 6, nv, nc); others = int(np.count_nonzero((z[:, 1:] != 0).any(axis=1) | (z[:, 0] > 1)))
+        assert others > (nv + 1) // 4                                                 # dense enough to overrun the value area
+        d = tmp_path / ("s%d" % seed); d.mkdir(); cs.save(str(d / "r1cs.bin")); pk_path, vk_path = str(d / "pk.txt"), str(d / "vk.txt")
+        e.keygen_from_r1cs(str(d / "r1cs.bin"), pk_path, vk_path, seed=seed)
+        pk, cs_key = o.parse_pk(pk_path); g = o.SplitMix64(seed); r, s = g.field(), g.field(); exp = o.proof_hex(o.prove(cs_key, z, pk, r, s))
+        p = e.Prover(pk_path); got = p.prove(z, r, s); again = p.prove(z, r, s); p.close(); assert got == exp and again == exp
+        assert e.verify(vk_path, got, o.from_arr(z[:cs.n_inputs]))
