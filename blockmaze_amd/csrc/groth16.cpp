@@ -772,13 +772,11 @@ struct Prover::Impl {
   uint32_t n_other = 0;
   bool tags_valid = false /* the assignment on the device came in compact form: tags holds 0 / 1 / 2 per variable */;
   PinnedBuf<Fe32> z_host;
-  // scan_workers: only the hand-over scan of a host-buffer assignment (set_witness) on hosts with many cores
-  std::unique_ptr<SubmitWorker> workers[4], scan_workers[12];
-  // thread t of a hand-over scan: 1 .. 3 are the MSMs' submit threads (idle at that point of a proof), 4 .. 15 scan only
+  std::unique_ptr<SubmitWorker> workers[4];
+  // submit thread t (1 .. 3) of this prover, idle while the assignment is handed over: the scan's helpers when the process's ScanPool is taken by another prover
   SubmitWorker &scan_worker(size_t t) {
-    std::unique_ptr<SubmitWorker> &w = t < 4 ? workers[t] : scan_workers[t - 4];
-    if (!w) w.reset(new SubmitWorker(lane));
-    return *w;
+    if (!workers[t]) workers[t].reset(new SubmitWorker(lane));
+    return *workers[t];
   }
   // The submit thread of a witness MSM also waits for its stream and finishes the MSM on the host (Horner combine, or the host tail of msm_impl.hpp): four
   // threads do that side by side while the H chain is still running. pending[j]: job j (order B2, L, A, B1) was posted and its result slot is not valid before
@@ -807,7 +805,7 @@ struct Prover::Impl {
     }
   }
   void settle_all_quietly() { for (int j = 0; j < 4; j++) { try { settle(j); } catch (...) {} } }
-  ~Impl() { settle_all_quietly(); for (auto &w : workers) w.reset(); for (auto &w : scan_workers) w.reset(); gpu_lane_release(lane); }
+  ~Impl() { settle_all_quietly(); for (auto &w : workers) w.reset(); gpu_lane_release(lane); }
 };
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &e) {
@@ -975,13 +973,21 @@ void test_scan_blocks(const uint8_t tags[64], const uint64_t elems[256], const u
   uint64_t o1[4] = {one[0], one[1], one[2], one[3]};
   classify_block64_scalar(elems, o1, out[6], out[7]); classify_block64(elems, o1, out[8], out[9]);
 }
-// How many threads share a hand-over scan.  (Round 3 measured six and eight threads no faster than four — on assignments that sat in the host's last-level cache.
-// bench.py cycles through 400 MB of distinct assignments: each scan then streams 7.3 MB from DRAM, a core sustains ~10 GB/s of that, and eight threads halve the
-// 0.17 ms; sixteen gain another 5-8 % per proof on the GPU boxes (256 hardware threads visible; profiles/r04v_scan.txt); hosts with fewer than 32 / 12 hardware
-// threads keep eight / four.)  Several provers handing over at once (proofs in flight) get four threads each.
-struct ScanCrew {
+// The threads that share a hand-over scan: ONE pool for the process, woken by ONE broadcast.  (Round 3 measured six and eight threads no faster than four — on
+// assignments that sat in the host's last-level cache.  bench.py cycles through 400 MB of distinct assignments: each scan then streams 7.3 MB from DRAM, a core
+// sustains ~10 GB/s of that, and eight threads halve the 0.17 ms; sixteen gain another 5-8 % per proof on the GPU boxes — 256 hardware threads visible,
+// profiles/r04v_scan.txt; hosts with fewer than 32 / 12 hardware threads keep eight / four.)
+// Until the end of round 4 every prover object kept twelve scan threads of its own and posted a job to each of them: fifteen mutex + futex round trips, 30-39 us of the
+// calling thread's time before it scanned a single word (tools/handover_trace.py, profiles/r04y_handover_sweep.txt: a third of the hand-over).  Here the caller publishes
+// the job, bumps an epoch and wakes everybody with one notify_all; the helpers — polling for ZK_SPIN_US after their last scan, asleep on the condition variable after
+// that — take chunks until none are left.  The caller scans too and does NOT wait for helpers that never woke up in time: it closes the round (no new helper may
+// enter) and waits only for those inside.  One scan at a time: a prover that finds the pool taken (several proofs in flight) scans with its own three submit threads
+// as before.
+class ScanPool {
+ public:
   static constexpr size_t TMAX = 16;
-  static size_t many() {
+  // threads that share a scan when the pool is free (the caller included)
+  static size_t crew() {
     static const size_t v = [] {
       const char *e = getenv("ZK_SCAN_THREADS");
       const unsigned hw = std::thread::hardware_concurrency();
@@ -990,14 +996,102 @@ struct ScanCrew {
     }();
     return v;
   }
-  static std::atomic<int> &scanning() { static std::atomic<int> c{0}; return c; }
-  int before;
-  size_t threads;
-  ScanCrew() : before(scanning().fetch_add(1)), threads(before == 0 ? many() : std::min<size_t>(many(), 4)) {}
-  ~ScanCrew() { scanning().fetch_sub(1); }
+  static ScanPool &get() { static ScanPool pool; return pool; }
+  // Runs job() on the caller and on the pool's helpers, returns when nobody is inside job() any more.  false: the pool is busy with another prover's scan (nothing ran).
+  bool run(const std::function<void()> &job) {
+    if (taken_.exchange(true, std::memory_order_acquire)) return false;
+    start_threads();
+    job_ = &job;
+    state_.store(0, std::memory_order_release);                    // open: helpers may enter
+    { std::lock_guard<std::mutex> lk(m_); epoch_.fetch_add(1, std::memory_order_release); }
+    cv_.notify_all();
+    job();
+    uint32_t st = state_.fetch_or(CLOSED, std::memory_order_acq_rel) | CLOSED;   // closed: a helper that wakes up now stays out
+    for (int k = 0; st != CLOSED; k++) {
+      if ((k & 255) == 255) std::this_thread::yield(); else cpu_relax();
+      st = state_.load(std::memory_order_acquire);
+    }
+    job_ = nullptr;
+    taken_.store(false, std::memory_order_release);
+    return true;
+  }
+  // wake the helpers without a job (they find the round closed and poll for the next one): called where a scan is expected soon
+  void nudge() {
+    if (threads_started_.load(std::memory_order_acquire) == 0 || taken_.load(std::memory_order_acquire)) return;
+    { std::lock_guard<std::mutex> lk(m_); epoch_.fetch_add(1, std::memory_order_release); }
+    cv_.notify_all();
+  }
+  ~ScanPool() {
+    { std::lock_guard<std::mutex> lk(m_); quit_.store(true); epoch_.fetch_add(1, std::memory_order_release); }
+    cv_.notify_all();
+    for (auto &t : threads_) t.join();
+  }
+ private:
+  static constexpr uint32_t CLOSED = 1u << 31;
+  static void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
+  static int spin_us() {
+    static const int v = [] { const char *e = getenv("ZK_SPIN_US"); if (e) return std::max(0, atoi(e)); return std::thread::hardware_concurrency() >= 4 ? 250 : 0; }();
+    return v;
+  }
+  void start_threads() {                                            // (called with taken_ held: one caller at a time)
+    if (!threads_.empty() || crew() < 2) return;
+    for (size_t i = 0; i + 1 < crew(); i++) threads_.emplace_back([this] { loop(); });
+    threads_started_.store(threads_.size(), std::memory_order_release);
+  }
+  void loop() {
+    uint32_t seen = 0;
+    for (;;) {
+      // poll for a while (the next proof's scan follows within a millisecond when proofs come back to back), then sleep
+      const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us());
+      for (int k = 0; spin_us() > 0 && epoch_.load(std::memory_order_acquire) == seen; k++) {
+        if ((k & 63) == 63 && std::chrono::steady_clock::now() > t_end) break;
+        cpu_relax();
+      }
+      if (epoch_.load(std::memory_order_acquire) == seen) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return quit_.load() || epoch_.load(std::memory_order_acquire) != seen; });
+      }
+      if (quit_.load()) return;
+      seen = epoch_.load(std::memory_order_acquire);
+      // enter the round unless it is closed already (the caller finished without us)
+      uint32_t st = state_.load(std::memory_order_acquire);
+      bool inside = false;
+      while (!(st & CLOSED)) {
+        if (state_.compare_exchange_weak(st, st + 1, std::memory_order_acq_rel)) { inside = true; break; }
+      }
+      if (!inside) continue;
+      (*job_)();                                                    // (valid: the caller does not leave run() while anybody is inside)
+      state_.fetch_sub(1, std::memory_order_acq_rel);
+    }
+  }
+  std::atomic<bool> taken_{false};
+  std::atomic<size_t> threads_started_{0};
+  std::atomic<uint32_t> epoch_{0}, state_{CLOSED};
+  const std::function<void()> *job_ = nullptr;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::atomic<bool> quit_{false};
+  std::vector<std::thread> threads_;
+};
+// Calls of this process that are handing over an assignment or proving right now.  The scan pool, and the wake-up that precedes the next scan, are for a caller that
+// has the prover to itself (one proof after the other: bench.py's loop, a node proving its own transactions one by one); with several proofs in flight the helpers would
+// only take the cores from the other callers' witness generators and submit threads (a soak of six genSendproof callers: 1,260 proofs/s with the pool used by whoever
+// found it free, 1,390 with three submit threads per caller).
+static std::atomic<int> g_calls_busy{0};
+struct BusyCall {
+  int others;
+  BusyCall() : others(g_calls_busy.fetch_add(1, std::memory_order_acq_rel)) {}
+  ~BusyCall() { g_calls_busy.fetch_sub(1, std::memory_order_acq_rel); }
+  bool alone() const { return others == 0; }
 };
 void Prover::set_witness(const Fe32 *z, bool montgomery) {
-  Impl &p = *impl; LaneScope lane_scope(p.lane); double t0 = now_ms(); const size_t n = p.nv + 1, words = (n + 63) / 64;
+  Impl &p = *impl; LaneScope lane_scope(p.lane); BusyCall busy; double t0 = now_ms(); const size_t n = p.nv + 1, words = (n + 63) / 64;
   Fe32 one; if (montgomery) memcpy(&one, FrParams::R1, 32); else { memset(&one, 0, 32); one.l[0] = 1; }
   // compact form (k_expand_witness): bitmaps of the entries equal to one / to anything else than 0 and 1, offsets, and the "anything else" values only. The
   // scan of the 7 MB assignment is memory-bound on one core (0.3 ms for send), so the prover's submit threads — idle at this point of a proof — and, on hosts
@@ -1010,8 +1104,6 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   uint64_t o1[4];
   memcpy(o1, &one, 32);
   const uint64_t *zz = reinterpret_cast<const uint64_t *>(z) - 4;
-  ScanCrew crew;
-  const size_t T = crew.threads;
   // The words are handed out in chunks of 32 (2,048 entries = 64 KB of the assignment) from one counter instead of being cut into T equal parts: with equal parts the
   // hand-over takes as long as its SLOWEST thread, and on the two-socket GPU hosts some of the sixteen threads always sit on the other socket from the caller's buffer, share
   // a core or meet another tenant (0.13 to 0.30 ms from process to process for one and the same build, profiles/r04w_host_placement.txt); with chunks a slow thread
@@ -1057,12 +1149,24 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   };
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
   auto worker = [&](size_t t) -> SubmitWorker & { return p.scan_worker(t); };
+  static const bool trace = getenv("ZK_TRACE_TIMES") != nullptr;
+  double t_posted = t0, t_own = t0, t_joined = t0;
+  size_t T = 1;
   if (threaded && words >= 512) {
-    for (size_t t = 1; t < T; t++) worker(t).post([&scan, t] { scan(t); });
-    scan(0);
-    for (size_t t = 1; t < T; t++) worker(t).wait();
+    // the process's scan pool when it is free; with several proofs in flight whoever finds it taken shares the scan with its own three submit threads
+    const std::function<void()> job = [&] { scan(0); };
+    T = ScanPool::crew();
+    if (T < 2 || !busy.alone() || !ScanPool::get().run(job)) {
+      T = 4;
+      for (size_t t = 1; t < T; t++) worker(t).post([&scan, t] { scan(t); });
+      if (trace) t_posted = now_ms();
+      scan(0);
+      if (trace) t_own = now_ms();
+      for (size_t t = 1; t < T; t++) worker(t).wait();
+    }
+    if (trace) { t_joined = now_ms(); if (t_own == t0) t_own = t_joined; }
   }
-  else for (size_t t = 0; t < T; t++) scan(t);
+  else scan(0);
   // (test switch: the plain-copy branch below, which no BlockMaze assignment reaches on its own)
   static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;
   const bool compact = !force_dense && !overflow.load();
@@ -1076,6 +1180,8 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
     expand_witness_dev(p.packed.get(), words, one_mont, montgomery ? 0 : 1, n, p.z.get(), p.tags.get(), p.other_vars.get());
     p.tags_valid = true;
     p.n_other = (uint32_t)total;
+    if (trace) fprintf(stderr, "trace-handover-host: threads %zu post %.3f own scan %.3f join %.3f copy + expand calls %.3f ms\n", T, t_posted - t0, t_own - t_posted, t_joined - t_own,
+        now_ms() - t_joined);
   }
   // dense assignment: plain copy
   else {
@@ -1091,6 +1197,7 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
 void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
   Impl &p = *impl;
   LaneScope lane_scope(p.lane);
+  BusyCall busy;
   double t0 = now_ms();
   const size_t n = p.nv + 1, words = (n + 63) / 64;
   Fe32 one;
@@ -1105,8 +1212,6 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
   // four threads).  A chunk of 32 words is classified first — every value it will need is prefetched on the way: the 7,600 values lie scattered over a 7 MB array of board
   // entries, one cache miss each —, reserves its run of the value area with one atomic, then copies the values, which have had the whole chunk's time to arrive.
   constexpr size_t CHUNK_WORDS = 32;
-  ScanCrew crew;
-  const size_t T = crew.threads;
   const size_t n_chunks = (words + CHUNK_WORDS - 1) / CHUNK_WORDS;
   std::atomic<size_t> next_chunk{0}, value_cursor{0};
   std::atomic<bool> overflow{false};
@@ -1163,11 +1268,14 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
   auto worker = [&](size_t t) -> SubmitWorker & { return p.scan_worker(t); };
   if (threaded && words >= 512) {
-    for (size_t t = 1; t < T; t++) worker(t).post([&scan, t] { scan(t); });
-    scan(0);
-    for (size_t t = 1; t < T; t++) worker(t).wait();
+    const std::function<void()> job = [&] { scan(0); };
+    if (ScanPool::crew() < 2 || !busy.alone() || !ScanPool::get().run(job)) {
+      for (size_t t = 1; t < 4; t++) worker(t).post([&scan, t] { scan(t); });
+      scan(0);
+      for (size_t t = 1; t < 4; t++) worker(t).wait();
+    }
   }
-  else for (size_t t = 0; t < T; t++) scan(t);
+  else scan(0);
   const bool fits = !overflow.load();
   static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;
   static const bool trace = getenv("ZK_TRACE_TIMES") != nullptr;
@@ -1316,7 +1424,7 @@ static void assemble(const Prover::Impl &p, const RsTerms &t, const HG1 &eA, con
   HG1 gC = eH.add(eL).add(gA.mul(t.s.l)).add(gB1.mul(t.r.l)).add(t.rs_delta_neg);                                       // :495
   out.A = raw_of(gA); out.B = raw_of(gB2); out.C = raw_of(gC); }
 bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
-  Impl &p = *impl; LaneScope lane_scope(p.lane); double t1 = now_ms(); run_device(p);
+  Impl &p = *impl; LaneScope lane_scope(p.lane); BusyCall busy; double t1 = now_ms(); run_device(p);
   // host work overlapped with the kernels
   RsTerms t = rs_terms(r_in, s_in, p.delta_g1, p.delta_g2);
   double t2 = now_ms();
@@ -1337,6 +1445,10 @@ bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
   double tb1 = now_ms();
   p.settle(0); HG2 gB2 = p.beta_g2.add(p.rB2).add(t.s_delta2); out.B = raw_of(gB2); double tb2 = now_ms();                                              // :492
   gpu_sync(); double t3 = now_ms();
+  // the next proof's hand-over is usually microseconds away (proofs come back to back): the scan helpers are woken now — they poll for ZK_SPIN_US before they sleep again —
+  // while this thread finishes the proof (ZK_SCAN_NUDGE=0: they are woken by the scan itself, 30-50 us late)
+  static const bool nudge = env_int("ZK_SCAN_NUDGE", 1) != 0;
+  if (nudge && busy.alone() && g_calls_busy.load(std::memory_order_acquire) == 1) ScanPool::get().nudge();
   // (rocprofv3's kernel trace is stamped with CLOCK_BOOTTIME: t1_boot places this proof on its time line)
   if (trace) {
     timespec bt;
