@@ -476,7 +476,8 @@ struct DomainTables {                                            // immutable pe
   DevBuf<Fe32> scale_big, scale_small;                            // 1/n as a table: the pre-scale of the stage-per-launch path (beyond 2^22 points)
   // the tile kernels' factor forms (f 2^261): g^i per element, the constants 1, 1/B (or 1/m), 1/S
   DevBuf<Fe32> coset_fwd261;
-  DevBuf<Fe32> inv_coset261;                                       // radix-2 domains in the two-pass range: 1/m g^i 2^261, the inverse transform's output factors when the coset transform follows
+  // radix-2 domains in the two-pass range: 1/m g^i 2^261, the inverse transform's output factors when the coset transform follows
+  DevBuf<Fe32> inv_coset261;
   Fe32 one261, inv_big261, inv_small261;
   HFr half;
 };

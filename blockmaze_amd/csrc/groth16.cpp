@@ -773,7 +773,8 @@ struct Prover::Impl {
   bool tags_valid = false /* the assignment on the device came in compact form: tags holds 0 / 1 / 2 per variable */;
   PinnedBuf<Fe32> z_host;
   std::unique_ptr<SubmitWorker> workers[4];
-  // submit thread t (1 .. 3) of this prover, idle while the assignment is handed over: the scan's helpers when the process's ScanPool is taken by another prover
+  // submit thread t (1 .. 3) of this prover, idle while the assignment is handed over: the scan's helpers when the process's ScanPool is taken by another
+  // prover
   SubmitWorker &scan_worker(size_t t) {
     if (!workers[t]) workers[t].reset(new SubmitWorker(lane));
     return *workers[t];
@@ -977,12 +978,12 @@ void test_scan_blocks(const uint8_t tags[64], const uint64_t elems[256], const u
 // assignments that sat in the host's last-level cache.  bench.py cycles through 400 MB of distinct assignments: each scan then streams 7.3 MB from DRAM, a core
 // sustains ~10 GB/s of that, and eight threads halve the 0.17 ms; sixteen gain another 5-8 % per proof on the GPU boxes — 256 hardware threads visible,
 // profiles/r04v_scan.txt; hosts with fewer than 32 / 12 hardware threads keep eight / four.)
-// Until the end of round 4 every prover object kept twelve scan threads of its own and posted a job to each of them: fifteen mutex + futex round trips, 30-39 us of the
-// calling thread's time before it scanned a single word (tools/handover_trace.py, profiles/r04y_handover_sweep.txt: a third of the hand-over).  Here the caller publishes
-// the job, bumps an epoch and wakes everybody with one notify_all; the helpers — polling for ZK_SPIN_US after their last scan, asleep on the condition variable after
-// that — take chunks until none are left.  The caller scans too and does NOT wait for helpers that never woke up in time: it closes the round (no new helper may
-// enter) and waits only for those inside.  One scan at a time: a prover that finds the pool taken (several proofs in flight) scans with its own three submit threads
-// as before.
+// Until the end of round 4 every prover object kept twelve scan threads of its own and posted a job to each of them: fifteen mutex + futex round trips, 30-39
+// us of the calling thread's time before it scanned a single word (tools/handover_trace.py, profiles/r04y_handover_sweep.txt: a third of the hand-over). Here
+// the caller publishes the job, bumps an epoch and wakes everybody with one notify_all; the helpers — polling for ZK_SPIN_US after their last scan, asleep on
+// the condition variable after that — take chunks until none are left. The caller scans too and does NOT wait for helpers that never woke up in time: it closes
+// the round (no new helper may enter) and waits only for those inside. One scan at a time: a prover that finds the pool taken (several proofs in flight) scans
+// with its own three submit threads as before.
 class ScanPool {
  public:
   static constexpr size_t TMAX = 16;
@@ -997,7 +998,8 @@ class ScanPool {
     return v;
   }
   static ScanPool &get() { static ScanPool pool; return pool; }
-  // Runs job() on the caller and on the pool's helpers, returns when nobody is inside job() any more.  false: the pool is busy with another prover's scan (nothing ran).
+  // Runs job() on the caller and on the pool's helpers, returns when nobody is inside job() any more. false: the pool is busy with another prover's scan
+  // (nothing ran).
   bool run(const std::function<void()> &job) {
     if (taken_.exchange(true, std::memory_order_acquire)) return false;
     start_threads();
@@ -1018,8 +1020,9 @@ class ScanPool {
   // wake the helpers without a job (they find the round closed and poll for the next one): called where a scan is expected soon
   void nudge() {
     if (threads_started_.load(std::memory_order_acquire) == 0 || taken_.load(std::memory_order_acquire)) return;
+    // ONE helper is woken here (a notify_all with fifteen sleepers costs the calling thread 15 us, on the critical path of its proof); that helper wakes the others
     { std::lock_guard<std::mutex> lk(m_); epoch_.fetch_add(1, std::memory_order_release); }
-    cv_.notify_all();
+    cv_.notify_one();
   }
   ~ScanPool() {
     { std::lock_guard<std::mutex> lk(m_); quit_.store(true); epoch_.fetch_add(1, std::memory_order_release); }
@@ -1036,7 +1039,11 @@ class ScanPool {
 #endif
   }
   static int spin_us() {
-    static const int v = [] { const char *e = getenv("ZK_SPIN_US"); if (e) return std::max(0, atoi(e)); return std::thread::hardware_concurrency() >= 4 ? 250 : 0; }();
+    static const int v = [] {
+      const char *e = getenv("ZK_SPIN_US");
+      if (e) return std::max(0, atoi(e));
+      return std::thread::hardware_concurrency() >= 4 ? 250 : 0;
+    }();
     return v;
   }
   void start_threads() {                                            // (called with taken_ held: one caller at a time)
@@ -1056,6 +1063,8 @@ class ScanPool {
       if (epoch_.load(std::memory_order_acquire) == seen) {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [&] { return quit_.load() || epoch_.load(std::memory_order_acquire) != seen; });
+        lk.unlock();
+        cv_.notify_all();                                           // (woken from sleep: pass it on — the caller may have woken only this one, see nudge())
       }
       if (quit_.load()) return;
       seen = epoch_.load(std::memory_order_acquire);
@@ -1079,10 +1088,10 @@ class ScanPool {
   std::atomic<bool> quit_{false};
   std::vector<std::thread> threads_;
 };
-// Calls of this process that are handing over an assignment or proving right now.  The scan pool, and the wake-up that precedes the next scan, are for a caller that
-// has the prover to itself (one proof after the other: bench.py's loop, a node proving its own transactions one by one); with several proofs in flight the helpers would
-// only take the cores from the other callers' witness generators and submit threads (a soak of six genSendproof callers: 1,260 proofs/s with the pool used by whoever
-// found it free, 1,390 with three submit threads per caller).
+// Calls of this process that are handing over an assignment or proving right now. The scan pool, and the wake-up that precedes the next scan, are for a caller
+// that has the prover to itself (one proof after the other: bench.py's loop, a node proving its own transactions one by one); with several proofs in flight the
+// helpers would only take the cores from the other callers' witness generators and submit threads (a soak of six genSendproof callers: 1,260 proofs/s with the
+// pool used by whoever found it free, 1,390 with three submit threads per caller).
 static std::atomic<int> g_calls_busy{0};
 struct BusyCall {
   int others;
@@ -1104,12 +1113,15 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   uint64_t o1[4];
   memcpy(o1, &one, 32);
   const uint64_t *zz = reinterpret_cast<const uint64_t *>(z) - 4;
-  // The words are handed out in chunks of 32 (2,048 entries = 64 KB of the assignment) from one counter instead of being cut into T equal parts: with equal parts the
-  // hand-over takes as long as its SLOWEST thread, and on the two-socket GPU hosts some of the sixteen threads always sit on the other socket from the caller's buffer, share
-  // a core or meet another tenant (0.13 to 0.30 ms from process to process for one and the same build, profiles/r04w_host_placement.txt); with chunks a slow thread
-  // simply takes fewer.  A chunk is classified first (its masks stay on the stack), reserves room for its values with ONE atomic on the shared cursor of the value area,
-  // and copies them there: off[w] is an absolute position, so k_expand_witness does not care in which order the chunks arrived, and nothing has to be closed up afterwards.
-  constexpr size_t CHUNK_WORDS = 32, CHUNK_MAX = CHUNK_WORDS;   // (16 / 8 / 4 words per chunk: 0.10-0.16 / 0.15-0.35 / 0.39-0.56 ms against 0.07-0.15 — the two counters are shared across sockets; profiles/r04y_chunk_sweep.txt)
+  // The words are handed out in chunks of 32 (2,048 entries = 64 KB of the assignment) from one counter instead of being cut into T equal parts: with equal
+  // parts the hand-over takes as long as its SLOWEST thread, and on the two-socket GPU hosts some of the sixteen threads always sit on the other socket from
+  // the caller's buffer, share a core or meet another tenant (0.13 to 0.30 ms from process to process for one and the same build,
+  // profiles/r04w_host_placement.txt); with chunks a slow thread simply takes fewer. A chunk is classified first (its masks stay on the stack), reserves room
+  // for its values with ONE atomic on the shared cursor of the value area, and copies them there: off[w] is an absolute position, so k_expand_witness does not
+  // care in which order the chunks arrived, and nothing has to be closed up afterwards.
+  // (16 / 8 / 4 words per chunk: 0.10-0.16 / 0.15-0.35 / 0.39-0.56 ms against 0.07-0.15 — the two counters are shared across sockets;
+  // profiles/r04y_chunk_sweep.txt)
+  constexpr size_t CHUNK_WORDS = 32, CHUNK_MAX = CHUNK_WORDS;
   const size_t n_chunks = (words + CHUNK_WORDS - 1) / CHUNK_WORDS;
   std::atomic<size_t> next_chunk{0}, value_cursor{0};
   std::atomic<bool> overflow{false};
@@ -1125,7 +1137,8 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
         const size_t lo = 64 * w, hi = lo + 64 < n ? lo + 64 : n;
         // a whole block: 256-bit loads where the host has them
         if (lo && hi - lo == 64) classify_block64(zz + 4 * lo, o1, o, x);
-        else for (size_t i = lo ? lo : 1; i < hi; i++) {                                                             // branch-free classification of a ragged block
+        // branch-free classification of a ragged block
+        else for (size_t i = lo ? lo : 1; i < hi; i++) {
           const uint64_t *v = zz + 4 * i;
           const uint64_t nz = (v[0] | v[1] | v[2] | v[3]) != 0, is1 = ((v[0] ^ o1[0]) | (v[1] ^ o1[1]) | (v[2] ^ o1[2]) | (v[3] ^ o1[3])) == 0;
           o |= is1 << (i - lo);
@@ -1137,11 +1150,16 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
         cnt += (size_t)__builtin_popcountll(x);
       }
       size_t at = cnt ? value_cursor.fetch_add(cnt, std::memory_order_relaxed) : 0;
-      if (at + cnt > max_other) { overflow.store(true, std::memory_order_relaxed); break; }                        // too many other values: the call takes the dense path
+      // too many other values: the call takes the dense path
+      if (at + cnt > max_other) {
+        overflow.store(true, std::memory_order_relaxed);
+        break;
+      }
       for (size_t w = w0; w < w1; w++) {
         const size_t lo = 64 * w;
         off[w] = (uint32_t)at;
-        for (uint64_t m = mx[w - w0]; m; m &= m - 1) memcpy(&vals[at++], zz + 4 * (lo + (size_t)__builtin_ctzll(m)), 32);   // (the chunk's 64 KB are still in this core's cache)
+        // (the chunk's 64 KB are still in this core's cache)
+        for (uint64_t m = mx[w - w0]; m; m &= m - 1) memcpy(&vals[at++], zz + 4 * (lo + (size_t)__builtin_ctzll(m)), 32);
         ones[w] = mo[w - w0];
         other[w] = mx[w - w0];
       }
@@ -1170,7 +1188,8 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
   // (test switch: the plain-copy branch below, which no BlockMaze assignment reaches on its own)
   static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr;
   const bool compact = !force_dense && !overflow.load();
-  // ONE copy carries bitmaps, offsets and values (a few hundred KB); the few values that are not 0 or 1 are brought into Montgomery form by the expanding kernel itself
+  // ONE copy carries bitmaps, offsets and values (a few hundred KB); the few values that are not 0 or 1 are brought into Montgomery form by the expanding
+  // kernel itself
   if (compact) {
     const size_t total = value_cursor.load();
     // (letting the kernel read the pinned staging area itself, no copy, was measured: no faster)
@@ -1180,7 +1199,8 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
     expand_witness_dev(p.packed.get(), words, one_mont, montgomery ? 0 : 1, n, p.z.get(), p.tags.get(), p.other_vars.get());
     p.tags_valid = true;
     p.n_other = (uint32_t)total;
-    if (trace) fprintf(stderr, "trace-handover-host: threads %zu post %.3f own scan %.3f join %.3f copy + expand calls %.3f ms\n", T, t_posted - t0, t_own - t_posted, t_joined - t_own,
+    if (trace) fprintf(stderr, "trace-handover-host: threads %zu post %.3f own scan %.3f join %.3f copy + expand calls %.3f ms\n", T, t_posted - t0,
+        t_own - t_posted, t_joined - t_own,
         now_ms() - t_joined);
   }
   // dense assignment: plain copy
@@ -1208,9 +1228,10 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
   uint32_t *off = (uint32_t *)(canon + words);
   const size_t vals_at = expand_values_offset(words, 2); Fe32 *vals = (Fe32 *)(pk + vals_at); const size_t max_other = n / 4;
   const bool avx2 = host_has_avx2();
-  // like set_witness: the prover's submit threads — idle at this point of a call — share the words chunk by chunk (0.28 -> 0.1 ms for send on the GPU box's host with
-  // four threads).  A chunk of 32 words is classified first — every value it will need is prefetched on the way: the 7,600 values lie scattered over a 7 MB array of board
-  // entries, one cache miss each —, reserves its run of the value area with one atomic, then copies the values, which have had the whole chunk's time to arrive.
+  // like set_witness: the prover's submit threads — idle at this point of a call — share the words chunk by chunk (0.28 -> 0.1 ms for send on the GPU box's
+  // host with four threads). A chunk of 32 words is classified first — every value it will need is prefetched on the way: the 7,600 values lie scattered over a
+  // 7 MB array of board entries, one cache miss each —, reserves its run of the value area with one atomic, then copies the values, which have had the whole
+  // chunk's time to arrive.
   constexpr size_t CHUNK_WORDS = 32;
   const size_t n_chunks = (words + CHUNK_WORDS - 1) / CHUNK_WORDS;
   std::atomic<size_t> next_chunk{0}, value_cursor{0};
@@ -1445,8 +1466,8 @@ bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
   double tb1 = now_ms();
   p.settle(0); HG2 gB2 = p.beta_g2.add(p.rB2).add(t.s_delta2); out.B = raw_of(gB2); double tb2 = now_ms();                                              // :492
   gpu_sync(); double t3 = now_ms();
-  // the next proof's hand-over is usually microseconds away (proofs come back to back): the scan helpers are woken now — they poll for ZK_SPIN_US before they sleep again —
-  // while this thread finishes the proof (ZK_SCAN_NUDGE=0: they are woken by the scan itself, 30-50 us late)
+  // the next proof's hand-over is usually microseconds away (proofs come back to back): the scan helpers are woken now — they poll for ZK_SPIN_US before they
+  // sleep again — while this thread finishes the proof (ZK_SCAN_NUDGE=0: they are woken by the scan itself, 30-50 us late)
   static const bool nudge = env_int("ZK_SCAN_NUDGE", 1) != 0;
   if (nudge && busy.alone() && g_calls_busy.load(std::memory_order_acquire) == 1) ScanPool::get().nudge();
   // (rocprofv3's kernel trace is stamped with CLOCK_BOOTTIME: t1_boot places this proof on its time line)

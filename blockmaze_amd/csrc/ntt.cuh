@@ -107,8 +107,8 @@ template <int R> __device__ __forceinline__ void ntt29_lds_pass(Fr29 *tile, cons
       for (int q = 0; q < (1 << R); q++) if (!(q & hx)) {
         const uint32_t blk = (base + ((uint32_t)q << sh)) >> st; Fr29 u = x[q], v = x[q + hx];
         if (bits) v = Fr29::mul(v, twl[(__brev(blk) >> (32 - bits)) << (st - 1)]);   // (bits is the same for the whole workgroup)
-        // limbs are brought back to 29 bits after every SECOND stage (and after the last one of the pass): a product takes one operand with limbs up to 2^31.4, and
-        // two stages add at most 2 (2^30 + 64) to a normalized limb (gen_field29.py: check_bounds_ntt_stages) — a third would not fit
+        // limbs are brought back to 29 bits after every SECOND stage (and after the last one of the pass): a product takes one operand with limbs up to 2^31.4,
+        // and two stages add at most 2 (2^30 + 64) to a normalized limb (gen_field29.py: check_bounds_ntt_stages) — a third would not fit
         const Fr29 sum = Fr29::add_raw(u, v), dif = Fr29::sub_product(u, v);
         const bool carry_now = (t & 1) == 1 || t == R - 1;
         x[q] = carry_now ? sum.norm() : sum;
@@ -132,11 +132,11 @@ __device__ __forceinline__ void ntt29_lds_transform(Fr29 *tile, Fr29 *twl, int l
 // tw261[j] = w_n^j 2^261 mod r for j < n/2, canonical
 // One transform's share of a tile launch. factor261: the column pass's optional factor per input element (f 2^261); post: the row pass's optional factor per
 // output element (f 2^256, multiplied on the 8 x 32-bit side); scale261: one factor for the whole vector, applied by the pass that stores the final values (the
-// row pass, or the column pass when it is the whole transform); tw261[j] = w_n^j 2^261 mod r for j < n/2 — all canonical.
-// A launch carries up to TWO jobs (blockIdx.x < a.tiles: job a, else job b): the B-point and the S-point transform of a step-radix-2 domain (mint, redeem,
-// deposit-32) run side by side in one launch instead of one after the other — each alone fills half the chip or less and is as long as its dependent passes.
-// out261 (row pass only): a factor per OUTPUT element in place of the constant scale261 — the inverse transform of a radix-2 domain hands the coset factor g^i of the
-// forward transform that follows to its own last product (1/m g^i 2^261), which costs that product a 32-byte load and saves the next column pass a product per element.
+// row pass, or the column pass when it is the whole transform); tw261[j] = w_n^j 2^261 mod r for j < n/2 — all canonical. A launch carries up to TWO jobs
+// (blockIdx.x < a.tiles: job a, else job b): the B-point and the S-point transform of a step-radix-2 domain (mint, redeem, deposit-32) run side by side in one
+// launch instead of one after the other — each alone fills half the chip or less and is as long as its dependent passes. out261 (row pass only): a factor per
+// OUTPUT element in place of the constant scale261 — the inverse transform of a radix-2 domain hands the coset factor g^i of the forward transform that follows
+// to its own last product (1/m g^i 2^261), which costs that product a 32-byte load and saves the next column pass a product per element.
 struct NttJob {
   const Fr *src;
   Fr *dst;
@@ -182,7 +182,10 @@ __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(NttJob ja, NttJob
 __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_rows(NttJob ja, NttJob jb, int radix_log) {
   extern __shared__ uint32_t lds_raw[]; Fr29 *tile = reinterpret_cast<Fr29 *>(lds_raw);
   const bool second = blockIdx.x >= ja.tiles; const NttJob &j = second ? jb : ja; const uint32_t bid = blockIdx.x - (second ? ja.tiles : 0u);
-  const int logn = j.logn, log_n1 = j.log_n1, logC = j.logC; const Fr *__restrict__ tw261 = j.tw261; const Fr *__restrict__ post = j.factor; const Fr *__restrict__ out261 = j.out261;
+  const int logn = j.logn, log_n1 = j.log_n1, logC = j.logC;
+  const Fr *__restrict__ tw261 = j.tw261;
+  const Fr *__restrict__ post = j.factor;
+  const Fr *__restrict__ out261 = j.out261;
   const int log_n2 = logn - log_n1; const uint32_t n2 = 1u << log_n2, C = 1u << logC, r0 = bid << logC, elems = n2 << logC;
   const Fr *s = j.src + blockIdx.y * j.stride_in; Fr *d = j.dst + blockIdx.y * j.stride_out;
   for (uint32_t w = threadIdx.x; w < elems; w += blockDim.x) {
