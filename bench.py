@@ -94,6 +94,17 @@ def run_rank(args):
     sys.stdout.flush(); real_stdout = os.fdopen(os.dup(1), "w"); os.dup2(2, 1)
     os.environ.setdefault("ZK_DEVICE", str(local_rank))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # torch initialises the HIP runtime before libzkgpu.so is loaded, so the library's own load-time default would come too late here
+    # N = 1: the process is confined to a block of 32 neighbouring cores BEFORE the HIP runtime and torch start their threads (see the comment at `host_binding` below; for
+    # N > 1 the ranks are placed after the devices are known).  The block is the one this process is running on: which socket hardly matters, compactness does.
+    host_binding = "none"; bind = os.environ.get("ZK_BENCH_BIND", "1") != "0" and hasattr(os, "sched_setaffinity")
+    if bind and world == 1:
+        try:
+            from blockmaze_amd import sharding as placement
+            here = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[36]); nodes = placement.host_node_cpus()      # the CPU this thread last ran on
+            node = next((k for k, v in nodes.items() if here in v), -1)
+            mine = placement.host_cpus_for_rank(0, 1, [node], nodes, os.sched_getaffinity(0), usable_cores(), near_cpu=here)
+            if mine: os.sched_setaffinity(0, mine); host_binding = "rank confined to CPUs %d..%d (%d, NUMA node %d) before the runtime starts" % (mine[0], mine[-1], len(mine), node)
+        except Exception as ex: log("bench: the kernel's placement stays (%s)" % ex)
     import torch
     backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")                 # "gloo": lets the N > 1 code path run on a box with fewer GPUs than ranks (ranks share devices)
     grp = None
@@ -115,18 +126,18 @@ def run_rank(args):
     import workload as w
     hx = lambda a: [("0x" + x.hex()) if isinstance(x, bytes) else x for x in a]
     e.init()                                                                 # raises "no HIP device visible" on a box without a GPU: there is no CPU path to fall back to
-    # N > 1: a rank runs on CPUs of the socket its GPU hangs off (MI355X hosts have two; the old placement cut the first `cores` CPUs, all on socket 0, over the ranks of both
-    # sockets' GPUs).  N = 1 keeps the kernel's placement: binding the one rank to its GPU's socket was measured and decided nothing (profiles/r04w_host_placement.txt:
-    # 1,015 and 909 proofs/s bound, 859 and 932 unbound on one shared box — the hand-over's 0.12-0.26 ms spread from process to process follows the other tenants, not the socket).
-    # ZK_BENCH_BIND=1 / 0 forces / forbids the binding.
-    host_binding = "none"
-    if os.environ.get("ZK_BENCH_BIND", "1" if world > 1 else "0") != "0" and hasattr(os, "sched_setaffinity"):
+    # A rank lives on a COMPACT set of CPUs near its GPU, chosen before it allocates a single assignment: a block of 32 neighbouring cores for N = 1, disjoint slices of the
+    # GPU's socket for N > 1 (the old placement cut the first `cores` CPUs, all on socket 0, over the ranks of both sockets' GPUs).  On the 256-thread GPU hosts the same build
+    # takes 0.98-0.99 ms per proof with its helper threads free to roam (a helper that is woken lands on a cold core) and 0.90-0.93 ms on 16-32 neighbouring cores
+    # (profiles/r04y_affinity_sweep.txt); which socket hardly matters.  What any launcher does with numactl / taskset; ZK_BENCH_BIND=0 leaves the placement to the kernel.
+    if bind and world > 1:
         try:
             from blockmaze_amd import sharding as placement
             n_dev = max(1, torch.cuda.device_count()); gpu_nodes = [e.device_numa_node(i) for i in range(n_dev)]
-            mine = placement.host_cpus_for_rank(local_rank, world, gpu_nodes, placement.host_node_cpus(), os.sched_getaffinity(0), cores)
+            here = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[36])              # the CPU this thread last ran on
+            mine = placement.host_cpus_for_rank(local_rank, world, gpu_nodes, placement.host_node_cpus(), os.sched_getaffinity(0), cores, near_cpu=here)
             if mine:
-                os.sched_setaffinity(0, mine); host_binding = "GPU on NUMA node %d: rank bound to %d of its CPUs" % (gpu_nodes[local_rank % n_dev], len(mine))
+                os.sched_setaffinity(0, mine); host_binding = "GPU on NUMA node %d: rank bound to CPUs %d..%d (%d)" % (gpu_nodes[local_rank % n_dev], mine[0], mine[-1], len(mine))
         except Exception as ex: log("bench: rank %d keeps the kernel's placement (%s)" % (rank, ex))
 
     # ---- untimed setup: test keys for the send circuit (seeded toxic waste), resident prover, one witness per step -----------------

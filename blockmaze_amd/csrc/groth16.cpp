@@ -1,4 +1,5 @@
 // see groth16.hpp
+#include <sched.h>
 #include <sys/random.h>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -668,6 +669,18 @@ void generate_keys(const R1csHost &cs_in, const ToxicWaste &tw, ProvingKeyHost &
 // ======================================================================================================================
 // A helper thread that lives as long as its prover: submitting a witness MSM (about a dozen launches, several microseconds of host time each) must not cost a
 // thread creation per proof on the critical path.  post() hands over a job, wait() blocks until it has run and rethrows what it threw.
+// CPUs this process may run on (its affinity mask, not the machine's size): a rank that a launcher pinned to two cores of a 256-thread host must not start sixteen
+// polling helpers.  (A cgroup CPU quota is not visible here; bench.py sizes its ranks by it and pins them accordingly.)
+static unsigned usable_cpus() {
+  static const unsigned v = [] {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) return (unsigned)CPU_COUNT(&set);
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw ? hw : 1u;
+  }();
+  return v;
+}
 class SubmitWorker {
  public:
   explicit SubmitWorker(int lane) : lane_(lane), th_([this] { loop(); }) {}
@@ -705,7 +718,7 @@ class SubmitWorker {
     static const int v = [] {
       const char *e = getenv("ZK_SPIN_US");
       if (e) return std::max(0, atoi(e));
-      return std::thread::hardware_concurrency() >= 4 ? 250 : 0;
+      return usable_cpus() >= 4 ? 250 : 0;
     }();
     return v;
   }
@@ -991,8 +1004,8 @@ class ScanPool {
   static size_t crew() {
     static const size_t v = [] {
       const char *e = getenv("ZK_SCAN_THREADS");
-      const unsigned hw = std::thread::hardware_concurrency();
-      const size_t t = e ? (size_t)atoi(e) : (hw >= 32 ? 16 : hw >= 12 ? 8 : 4);
+      const unsigned hw = usable_cpus();
+      const size_t t = e ? (size_t)atoi(e) : (hw >= 32 ? 16 : hw >= 12 ? 8 : hw >= 4 ? 4 : 1);
       return t < 1 ? (size_t)1 : t > TMAX ? TMAX : t;
     }();
     return v;
@@ -1042,7 +1055,7 @@ class ScanPool {
     static const int v = [] {
       const char *e = getenv("ZK_SPIN_US");
       if (e) return std::max(0, atoi(e));
-      return std::thread::hardware_concurrency() >= 4 ? 250 : 0;
+      return usable_cpus() >= 4 ? 250 : 0;
     }();
     return v;
   }

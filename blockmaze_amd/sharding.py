@@ -35,16 +35,21 @@ def host_node_cpus():
         except Exception: pass
     return nodes
 
-def host_cpus_for_rank(local_rank, world, gpu_nodes, node_cpus, allowed, cores):
-    """The CPUs a rank should run on (pure function; tests/test_distributed_cpu.py).  A rank stays on the socket its GPU hangs off: the hand-over scans the rank's 7 MB
-    assignments and writes pinned staging memory, and from the other socket both take twice as long (profiles/r04w_mode_probe.txt).  gpu_nodes[i]: NUMA node of local GPU i
-    (-1 unknown); node_cpus: {node: [cpus]}; allowed: the process's affinity mask; cores: what the whole job may really use (cgroup quota).
-      world == 1 -> every allowed CPU of the GPU's node (threads float inside the socket);
+def host_cpus_for_rank(local_rank, world, gpu_nodes, node_cpus, allowed, cores, near_cpu=None, block=32):
+    """The CPUs a rank should run on (pure function; tests/test_distributed_cpu.py).  Two measured facts (profiles/r04w_host_placement.txt, r04y_affinity_sweep.txt): the
+    socket matters less than COMPACTNESS — one and the same build takes 0.98-0.99 ms per proof with its twenty helper threads free to roam a 256-thread host (a helper that
+    is woken lands on a cold, deeply idle core) and 0.90-0.93 ms confined to 16-32 neighbouring cores of either socket —, and ranks must not share cores.
+      world == 1 -> a block of `block` neighbouring allowed CPUs on the GPU's node, the block that contains `near_cpu` (where the process runs now) if it is on that node;
       world  > 1 -> the ranks of one socket cut that socket's allowed CPUs into slices of cores // world.
-    Unknown node, or a node without an allowed CPU: the old placement (slices of the first `cores` allowed CPUs)."""
+    gpu_nodes[i]: NUMA node of local GPU i (-1 unknown); node_cpus: {node: [cpus]}; allowed: the process's affinity mask; cores: what the whole job may really use (cgroup
+    quota).  Unknown node, or a node without an allowed CPU: the same rules over all allowed CPUs."""
     allowed = sorted(allowed); node = gpu_nodes[local_rank % len(gpu_nodes)] if gpu_nodes else -1
     mine = [c for c in node_cpus.get(node, []) if c in set(allowed)] if node is not None and node >= 0 else []
-    if world <= 1: return mine or allowed
+    if world <= 1:
+        cand = mine or allowed
+        if len(cand) <= block: return cand
+        at = cand.index(near_cpu) // block * block if near_cpu in cand else 0
+        return cand[at:at + block] if len(cand[at:at + block]) >= block // 2 else cand[-block:]
     per = max(1, cores // world)
     if not mine:
         cut = allowed[:cores][local_rank % world * per:(local_rank % world + 1) * per]; return cut or allowed

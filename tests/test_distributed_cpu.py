@@ -91,9 +91,12 @@ def test_ranks_are_placed_on_their_gpus_socket():
     from blockmaze_amd import sharding as s
     assert s.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and s.parse_cpulist("5") == [5] and s.parse_cpulist("") == []
     nodes = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}; everything = set(range(256)); gpus = [0, 0, 0, 0, 1, 1, 1, 1]
-    assert s.host_cpus_for_rank(0, 1, [0], nodes, everything, 16) == nodes[0]                                # one rank: the whole socket of its GPU
-    assert s.host_cpus_for_rank(0, 1, [1], nodes, everything, 16) == nodes[1]
-    assert s.host_cpus_for_rank(0, 1, [-1], nodes, everything, 16) == sorted(everything)                     # unknown: no restriction
+    assert s.host_cpus_for_rank(0, 1, [0], nodes, everything, 16) == list(range(0, 32))                      # one rank: a block of 32 neighbouring cores on its GPU's socket
+    assert s.host_cpus_for_rank(0, 1, [1], nodes, everything, 16, near_cpu=100) == list(range(96, 128))      # ... the block it is running on, if that is on the socket
+    assert s.host_cpus_for_rank(0, 1, [1], nodes, everything, 16, near_cpu=3) == list(range(64, 96))         # (running on the other socket: the socket's first block)
+    assert s.host_cpus_for_rank(0, 1, [0], nodes, everything, 16, near_cpu=190) == list(range(160, 192))
+    assert s.host_cpus_for_rank(0, 1, [-1], nodes, everything, 16, near_cpu=70) == list(range(64, 96))       # unknown node: a block of the allowed CPUs all the same
+    assert s.host_cpus_for_rank(0, 1, [0], nodes, set(range(8)), 16) == list(range(8))                       # a small cpuset: all of it
     cuts = [s.host_cpus_for_rank(r, 8, gpus, nodes, everything, 16) for r in range(8)]
     assert all(len(c) == 2 for c in cuts) and len(set(sum(cuts, []))) == 16                                   # 16 usable cores over 8 ranks, no CPU twice
     assert all(set(cuts[r]) <= set(nodes[gpus[r]]) for r in range(8))                                         # each on its own GPU's socket
