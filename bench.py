@@ -95,14 +95,14 @@ def run_rank(args):
     os.environ.setdefault("ZK_DEVICE", str(local_rank))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # torch initialises the HIP runtime before libzkgpu.so is loaded, so the library's own load-time default would come too late here
     # N = 1: the process is confined to a block of 32 neighbouring cores BEFORE the HIP runtime and torch start their threads (see the comment at `host_binding` below; for
-    # N > 1 the ranks are placed after the devices are known).  The block is the one this process is running on: which socket hardly matters, compactness does.
+    # N > 1 the ranks are placed after the devices are known).  The block is the quietest one of the socket this process is running on (a 0.1 s sample of /proc/stat, SMT siblings included: the hosts are shared): which socket hardly matters, compactness does.
     host_binding = "none"; bind = os.environ.get("ZK_BENCH_BIND", "1") != "0" and hasattr(os, "sched_setaffinity")
     if bind and world == 1:
         try:
             from blockmaze_amd import sharding as placement
             here = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[36]); nodes = placement.host_node_cpus()      # the CPU this thread last ran on
             node = next((k for k, v in nodes.items() if here in v), -1)
-            mine = placement.host_cpus_for_rank(0, 1, [node], nodes, os.sched_getaffinity(0), usable_cores(), near_cpu=here)
+            mine = placement.host_cpus_for_rank(0, 1, [node], nodes, os.sched_getaffinity(0), usable_cores(), near_cpu=here, busy=placement.cpu_busy_fractions(0.1), siblings=placement.cpu_siblings())
             if mine: os.sched_setaffinity(0, mine); host_binding = "rank confined to CPUs %d..%d (%d, NUMA node %d) before the runtime starts" % (mine[0], mine[-1], len(mine), node)
         except Exception as ex: log("bench: the kernel's placement stays (%s)" % ex)
     import torch

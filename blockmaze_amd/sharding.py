@@ -35,11 +35,48 @@ def host_node_cpus():
         except Exception: pass
     return nodes
 
-def host_cpus_for_rank(local_rank, world, gpu_nodes, node_cpus, allowed, cores, near_cpu=None, block=32):
+def cpu_busy_fractions(sample_s=0.1):
+    """{cpu: busy fraction over a short sample of /proc/stat}; {} where that cannot be read.  The GPU hosts are shared: a block of cores (or their SMT siblings) that another
+    tenant is using is a bad place for a rank's helper threads."""
+    import time
+    def snap():
+        out = {}
+        for line in open("/proc/stat"):
+            if line.startswith("cpu") and line[3].isdigit():
+                f = line.split(); v = [int(x) for x in f[1:9]]; out[int(f[0][3:])] = (sum(v), v[3] + v[4])       # total, idle + iowait
+        return out
+    try:
+        a = snap(); time.sleep(sample_s); b = snap()
+        return {c: 1.0 - (b[c][1] - a[c][1]) / max(1, b[c][0] - a[c][0]) for c in b if c in a}
+    except Exception:
+        return {}
+
+def cpu_siblings():
+    """{cpu: [its SMT siblings, itself included]} from sysfs; {} where there is none"""
+    import glob, re
+    out = {}
+    for d in glob.glob("/sys/devices/system/cpu/cpu[0-9]*/topology/thread_siblings_list"):
+        try: out[int(re.search(r"cpu(\d+)/topology", d).group(1))] = parse_cpulist(open(d).read())
+        except Exception: pass
+    return out
+
+def quietest_block(cands, block, busy, siblings, prefer=None):
+    """Of the aligned blocks of `block` CPUs in the list `cands`, the one whose cores — SMT siblings included — were least busy (pure function); ties and missing data go to
+    the block that contains `prefer`, else to the first."""
+    blocks = [cands[i:i + block] for i in range(0, len(cands), block)]; blocks = [b for b in blocks if len(b) >= max(1, block // 2)] or [cands]
+    def load(b):
+        cores = set(b)
+        for c in b: cores.update(siblings.get(c, []))
+        return round(sum(busy.get(c, 0.0) for c in cores), 2)
+    best = min(blocks, key=lambda b: (load(b) if busy else 0.0, 0 if prefer in b else 1))
+    return best
+
+def host_cpus_for_rank(local_rank, world, gpu_nodes, node_cpus, allowed, cores, near_cpu=None, block=32, busy=None, siblings=None):
     """The CPUs a rank should run on (pure function; tests/test_distributed_cpu.py).  Two measured facts (profiles/r04w_host_placement.txt, r04y_affinity_sweep.txt): the
     socket matters less than COMPACTNESS — one and the same build takes 0.98-0.99 ms per proof with its twenty helper threads free to roam a 256-thread host (a helper that
     is woken lands on a cold, deeply idle core) and 0.90-0.93 ms confined to 16-32 neighbouring cores of either socket —, and ranks must not share cores.
-      world == 1 -> a block of `block` neighbouring allowed CPUs on the GPU's node, the block that contains `near_cpu` (where the process runs now) if it is on that node;
+      world == 1 -> a block of `block` neighbouring allowed CPUs on the GPU's node: the one whose cores and SMT siblings were least busy in a short sample (`busy`,
+                    `siblings`: the hosts are shared), the block that contains `near_cpu` (where the process runs now) among equals;
       world  > 1 -> the ranks of one socket cut that socket's allowed CPUs into slices of cores // world.
     gpu_nodes[i]: NUMA node of local GPU i (-1 unknown); node_cpus: {node: [cpus]}; allowed: the process's affinity mask; cores: what the whole job may really use (cgroup
     quota).  Unknown node, or a node without an allowed CPU: the same rules over all allowed CPUs."""
@@ -48,8 +85,7 @@ def host_cpus_for_rank(local_rank, world, gpu_nodes, node_cpus, allowed, cores, 
     if world <= 1:
         cand = mine or allowed
         if len(cand) <= block: return cand
-        at = cand.index(near_cpu) // block * block if near_cpu in cand else 0
-        return cand[at:at + block] if len(cand[at:at + block]) >= block // 2 else cand[-block:]
+        return quietest_block(cand, block, busy or {}, siblings or {}, prefer=near_cpu)
     per = max(1, cores // world)
     if not mine:
         cut = allowed[:cores][local_rank % world * per:(local_rank % world + 1) * per]; return cut or allowed

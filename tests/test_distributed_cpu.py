@@ -97,6 +97,12 @@ def test_ranks_are_placed_on_their_gpus_socket():
     assert s.host_cpus_for_rank(0, 1, [0], nodes, everything, 16, near_cpu=190) == list(range(160, 192))
     assert s.host_cpus_for_rank(0, 1, [-1], nodes, everything, 16, near_cpu=70) == list(range(64, 96))       # unknown node: a block of the allowed CPUs all the same
     assert s.host_cpus_for_rank(0, 1, [0], nodes, set(range(8)), 16) == list(range(8))                       # a small cpuset: all of it
+    sib = {c: [c % 128, c % 128 + 128] for c in range(256)}; busy = {c: 0.0 for c in range(256)}; busy[130] = 0.9; busy[40] = 0.5   # a neighbour on the SMT sibling of core 2, another on core 40
+    assert s.host_cpus_for_rank(0, 1, [0], nodes, everything, 16, near_cpu=5, busy=busy, siblings=sib) == list(range(32, 64))     # blocks 0-31 and 128-159 share cores with 130 (0.9); 32-63 and 160-191 with 40 (0.5)
+    busy[40] = 0.95; assert s.host_cpus_for_rank(0, 1, [0], nodes, everything, 16, near_cpu=150, busy=busy, siblings=sib) == list(range(128, 160))   # now the first pair is the quieter one: the half it runs on
+    assert s.host_cpus_for_rank(0, 1, [0], nodes, everything, 16, near_cpu=5, busy={c: 0.0 for c in range(256)}, siblings=sib) == list(range(0, 32))   # all quiet: where it runs
+    assert s.quietest_block(list(range(64)), 32, {}, {}, prefer=40) == list(range(32, 64))
+    assert isinstance(s.cpu_busy_fractions(0.01), dict) and isinstance(s.cpu_siblings(), dict)
     cuts = [s.host_cpus_for_rank(r, 8, gpus, nodes, everything, 16) for r in range(8)]
     assert all(len(c) == 2 for c in cuts) and len(set(sum(cuts, []))) == 16                                   # 16 usable cores over 8 ranks, no CPU twice
     assert all(set(cuts[r]) <= set(nodes[gpus[r]]) for r in range(8))                                         # each on its own GPU's socket
