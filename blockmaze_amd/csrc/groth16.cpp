@@ -1101,6 +1101,35 @@ class ScanPool {
   std::atomic<bool> quit_{false};
   std::vector<std::thread> threads_;
 };
+// host-only self-test of the pool (tests/test_device_plan_cpu.py, and tests/sanitize_driver.cpp under ASan / UBSan): `callers` threads each run `rounds` rounds of a
+// chunk-counting job — through the pool when they get it, alone when it is taken — and every chunk of every round must have been counted exactly once.  Returns the
+// number of rounds that ran on the pool, -1 on a miscount.
+int test_scan_pool(int callers, int rounds) {
+  std::atomic<int> pooled{0}, bad{0};
+  auto caller = [&] {
+    constexpr size_t N = 3000;
+    std::vector<std::atomic<uint8_t>> hits(N);
+    for (int r = 0; r < rounds; r++) {
+      for (auto &h : hits) h.store(0, std::memory_order_relaxed);
+      std::atomic<size_t> next{0};
+      const std::function<void()> job = [&] {
+        for (;;) {
+          const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+          if (i >= N) break;
+          hits[i].fetch_add(1, std::memory_order_relaxed);
+        }
+      };
+      if (ScanPool::get().run(job)) pooled.fetch_add(1); else job();
+      for (auto &h : hits) if (h.load(std::memory_order_relaxed) != 1) bad.fetch_add(1);
+      if (r % 7 == 3) ScanPool::get().nudge();
+    }
+  };
+  std::vector<std::thread> th;
+  for (int c = 1; c < callers; c++) th.emplace_back(caller);
+  caller();
+  for (auto &t : th) t.join();
+  return bad.load() ? -1 : pooled.load();
+}
 // Calls of this process that are handing over an assignment or proving right now. The scan pool, and the wake-up that precedes the next scan, are for a caller
 // that has the prover to itself (one proof after the other: bench.py's loop, a node proving its own transactions one by one); with several proofs in flight the
 // helpers would only take the cores from the other callers' witness generators and submit threads (a soak of six genSendproof callers: 1,260 proofs/s with the

@@ -110,4 +110,5 @@ Proof default_proof();                            // (G1::one, G2::one, G1::one)
 
 // host-only self-test of the hand-over's block classifiers (scalar against AVX2 forms)
 void test_scan_blocks(const uint8_t tags[64], const uint64_t elems[256], const uint64_t one[4], uint64_t out[10]);
+int test_scan_pool(int callers, int rounds);   // host-only self-test of the hand-over's scan pool: rounds that ran on the pool, -1 on a miscount
 }  // namespace zk

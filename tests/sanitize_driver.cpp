@@ -61,6 +61,7 @@ int main(int argc, char **argv) {
     CHECK(zkgpu_witness_lesscmp(5, 9, w.c_str()) == ZKGPU_OK); }
   // ---- container, device plan, batch entry
   CHECK(zkgpu_test_key_container((tmp + "/k.gpucache").c_str(), 300, 500, 512) == 0);
+  CHECK(zkgpu_test_scan_pool(3, 200) >= 0);
   { int dev[64], ord[8]; CHECK(zkgpu_test_device_plan("0,1,,x", 4, 0, 2, dev, ord, 8) >= 1); CHECK(zkgpu_test_device_plan(nullptr, 0, 0, 2, dev, ord, 8) == 0); }
   { zk_verify_item it[3]; memset(it, 0, sizeof it); it[0].kind = 1; it[0].proof = hex512.c_str(); it[1].kind = 99; it[2].kind = 2; it[2].proof = nullptr; unsigned char ok[3] = {9, 9, 9}; CHECK(verifyBatch(it, 3, ok) == -1 && !ok[0] && !ok[1] && !ok[2]); CHECK(verifyBatch(nullptr, 0, nullptr) == 0); }
   if (fails) { fprintf(stderr, "%d check(s) failed\n", fails); return 1; }

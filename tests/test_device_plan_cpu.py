@@ -1,6 +1,6 @@
 """Multi-device pool planning (pure host logic of gpu.hip / capi_zk.cpp, no GPU needed): how ZK_DEVICES is read and in which order the members of a key's prover pool
 are laid out — interleaved by device, so that concurrent cgo callers reach every GPU of the node before two of them share one."""
-import ctypes
+import ctypes, os
 from blockmaze_amd import engine as e
 
 def plan(spec, n_visible, fallback=0, per_device=2, n_order=16):
@@ -43,3 +43,13 @@ def test_lane_planner_never_starves_a_device():
     assert L.zkgpu_test_lane_plan(1, 4, 7, per) == 1 and per[0] == 28
     worst = L.zkgpu_test_lane_plan(16, 4, 6, per); assert worst == 2 and list(per[:16]) == [14] * 16                  # 16 devices: 14 lanes each, shared by 24 members
     worst = L.zkgpu_test_lane_plan(1, 8, 7, per); assert worst == 2 and per[0] == 31                                  # one device never binds more than 31 lanes
+
+def test_scan_pool_counts_every_chunk_once_under_concurrent_callers():
+    """groth16.cpp: ScanPool — one caller at a time gets the pool (one broadcast wakes the helpers, the caller scans along, closes the round and waits only for helpers that are
+    inside), the others run their job alone; whoever runs it, every chunk of every round is taken exactly once.  ZK_SCAN_THREADS=4: three helpers even on a small host."""
+    import subprocess, sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from blockmaze_amd import engine as e; L = e.lib(); "
+            "a = L.zkgpu_test_scan_pool(1, 300); b = L.zkgpu_test_scan_pool(4, 300); print('POOL', a, b)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ZK_SCAN_THREADS="4", ZK_SPIN_US="50"), timeout=300)
+    tok = r.stdout.split(); assert "POOL" in tok, (r.stdout[-300:], r.stderr[-800:]); a, b = int(tok[tok.index("POOL") + 1]), int(tok[tok.index("POOL") + 2])
+    assert a == 300 and 1 <= b <= 1200                      # a lone caller always gets the pool; four callers share it, nobody miscounts (-1)
