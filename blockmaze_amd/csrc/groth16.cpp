@@ -666,11 +666,11 @@ void generate_keys(const R1csHost &cs_in, const ToxicWaste &tw, ProvingKeyHost &
 
 // ======================================================================================================================
 // prover
-// ======================================================================================================================
-// A helper thread that lives as long as its prover: submitting a witness MSM (about a dozen launches, several microseconds of host time each) must not cost a
-// thread creation per proof on the critical path.  post() hands over a job, wait() blocks until it has run and rethrows what it threw.
-// CPUs this process may run on (its affinity mask, not the machine's size): a rank that a launcher pinned to two cores of a 256-thread host must not start sixteen
-// polling helpers.  (A cgroup CPU quota is not visible here; bench.py sizes its ranks by it and pins them accordingly.)
+// ====================================================================================================================== A helper thread that lives as long as
+// its prover: submitting a witness MSM (about a dozen launches, several microseconds of host time each) must not cost a thread creation per proof on the
+// critical path. post() hands over a job, wait() blocks until it has run and rethrows what it threw. CPUs this process may run on (its affinity mask, not the
+// machine's size): a rank that a launcher pinned to two cores of a 256-thread host must not start sixteen polling helpers. (A cgroup CPU quota is not visible
+// here; bench.py sizes its ranks by it and pins them accordingly.)
 static unsigned usable_cpus() {
   static const unsigned v = [] {
     cpu_set_t set;
@@ -1033,7 +1033,8 @@ class ScanPool {
   // wake the helpers without a job (they find the round closed and poll for the next one): called where a scan is expected soon
   void nudge() {
     if (threads_started_.load(std::memory_order_acquire) == 0 || taken_.load(std::memory_order_acquire)) return;
-    // ONE helper is woken here (a notify_all with fifteen sleepers costs the calling thread 15 us, on the critical path of its proof); that helper wakes the others
+    // ONE helper is woken here (a notify_all with fifteen sleepers costs the calling thread 15 us, on the critical path of its proof); that helper wakes the
+    // others
     { std::lock_guard<std::mutex> lk(m_); epoch_.fetch_add(1, std::memory_order_release); }
     cv_.notify_one();
   }
@@ -1101,9 +1102,9 @@ class ScanPool {
   std::atomic<bool> quit_{false};
   std::vector<std::thread> threads_;
 };
-// host-only self-test of the pool (tests/test_device_plan_cpu.py, and tests/sanitize_driver.cpp under ASan / UBSan): `callers` threads each run `rounds` rounds of a
-// chunk-counting job — through the pool when they get it, alone when it is taken — and every chunk of every round must have been counted exactly once.  Returns the
-// number of rounds that ran on the pool, -1 on a miscount.
+// host-only self-test of the pool (tests/test_device_plan_cpu.py, and tests/sanitize_driver.cpp under ASan / UBSan): `callers` threads each run `rounds` rounds
+// of a chunk-counting job — through the pool when they get it, alone when it is taken — and every chunk of every round must have been counted exactly once.
+// Returns the number of rounds that ran on the pool, -1 on a miscount.
 int test_scan_pool(int callers, int rounds) {
   std::atomic<int> pooled{0}, bad{0};
   auto caller = [&] {

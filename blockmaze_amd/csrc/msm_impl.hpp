@@ -166,10 +166,11 @@ struct MsmImpl {
       HIP_CHECK(hipEventCreateWithFlags(&ws->sorted, hipEventDisableTiming)); }
     max_tasks = (uint32_t)((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1);
     // (tuning knob: entries per lane of the H accumulation)
-    // All lanes of the H accumulation do the same amount of work, so the chip runs it in lock-step rounds of workgroups and the last round's fill decides: swept once more
-    // at the end of round 4 in steps of one, whole proofs (profiles/r04y_hrun_sweep.txt): runs of 11 beat 12 for mint / redeem (+1.5 %), send (device side 0.828 -> 0.816 ms)
-    // and deposit at depth 8 (668 -> 720 proofs/s); at depth 32 (18.9 M entries, exactly six rounds of 12) 12 stays ahead of 11 by 4 %.  (A stand-alone measurement at key
-    // load picks 13 everywhere — right for the MSM alone, wrong inside a proof, where the witness MSMs hold part of the chip: 0.85 ms.)
+    // All lanes of the H accumulation do the same amount of work, so the chip runs it in lock-step rounds of workgroups and the last round's fill decides:
+    // swept once more at the end of round 4 in steps of one, whole proofs (profiles/r04y_hrun_sweep.txt): runs of 11 beat 12 for mint / redeem (+1.5 %), send
+    // (device side 0.828 -> 0.816 ms) and deposit at depth 8 (668 -> 720 proofs/s); at depth 32 (18.9 M entries, exactly six rounds of 12) 12 stays ahead of 11
+    // by 4 %. (A stand-alone measurement at key load picks 13 everywhere — right for the MSM alone, wrong inside a proof, where the witness MSMs hold part of
+    // the chip: 0.85 ms.)
     h_run = n * (size_t)W > ((size_t)12 << 20) ? 12 : 11;
     if (const char *e = getenv("ZK_MSM_H_RUN")) {
       const int v = atoi(e);
