@@ -102,7 +102,7 @@ def run_rank(args):
             from blockmaze_amd import sharding as placement
             here = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[36]); nodes = placement.host_node_cpus()      # the CPU this thread last ran on
             node = next((k for k, v in nodes.items() if here in v), -1)
-            mine = placement.host_cpus_for_rank(0, 1, [node], nodes, os.sched_getaffinity(0), usable_cores(), near_cpu=here, busy=placement.cpu_busy_fractions(0.1), siblings=placement.cpu_siblings())
+            mine = placement.host_cpus_for_rank(0, 1, [node], nodes, os.sched_getaffinity(0), usable_cores(), near_cpu=here, busy=placement.cpu_busy_fractions(0.1), siblings=placement.cpu_siblings(), block=int(os.environ.get("ZK_BENCH_BLOCK", "32")))
             if mine: os.sched_setaffinity(0, mine); host_binding = "rank confined to CPUs %d..%d (%d, NUMA node %d) before the runtime starts" % (mine[0], mine[-1], len(mine), node)
         except Exception as ex: log("bench: the kernel's placement stays (%s)" % ex)
     import torch

@@ -27,3 +27,5 @@ s = sorted(ts); pct = lambda q: s[min(len(s) - 1, int(q * len(s)))]
 print("%d steps: mean %.3f ms, min %.3f, p10 %.3f, median %.3f, p90 %.3f, p99 %.3f, max %.3f; steps above 1.5 x median: %d (they add %.3f ms to the mean)" % (N, sum(ts) / N, s[0], pct(0.1), pct(0.5), pct(0.9), pct(0.99), s[-1], sum(1 for t in ts if t > 1.5 * pct(0.5)), sum(t - pct(0.5) for t in ts if t > 1.5 * pct(0.5)) / N))
 med = lambda k: sorted(d[k] for d in parts)[len(parts) // 2]
 print("  medians of the prover's own clocks: " + ", ".join("%s %.3f" % (k, med(k)) for k in ("upload_ms", "enqueue_ms", "device_ms", "finish_ms", "total_ms")) + "; cpus allowed %d; AnonHugePages of this process %s kB" % (len(os.sched_getaffinity(0)), next((l.split()[1] for l in open("/proc/self/smaps_rollup") if l.startswith("AnonHugePages")), "?")))
+slow = [(t, d) for t, d in zip(ts, parts) if t > 1.5 * pct(0.5)]
+if slow: print("  the slow steps' own clocks (step: upload / device / finish ms): " + "; ".join("%.2f: %.2f / %.2f / %.2f" % (t, d["upload_ms"], d["device_ms"], d["finish_ms"]) for t, d in slow[:12]))
