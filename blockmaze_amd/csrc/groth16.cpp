@@ -1022,7 +1022,9 @@ class ScanPool {
     start_threads();
     job_ = &job;
     state_.store(0, std::memory_order_release);                    // open: helpers may enter
-    { std::lock_guard<std::mutex> lk(m_); epoch_.fetch_add(1, std::memory_order_release); }
+    // (no lock around the bump: the calling thread is on its proof's critical path and must not wait for a helper that was preempted while it held the mutex; a helper
+    // that misses this wake-up between its check and its sleep misses this round, nothing else — nobody waits for a helper that is not inside)
+    epoch_.fetch_add(1, std::memory_order_release);
     cv_.notify_all();
     job();
     uint32_t st = state_.fetch_or(CLOSED, std::memory_order_acq_rel) | CLOSED;   // closed: a helper that wakes up now stays out
@@ -1039,7 +1041,7 @@ class ScanPool {
     if (threads_started_.load(std::memory_order_acquire) == 0 || taken_.load(std::memory_order_acquire)) return;
     // ONE helper is woken here (a notify_all with fifteen sleepers costs the calling thread 15 us, on the critical path of its proof); that helper wakes the
     // others
-    { std::lock_guard<std::mutex> lk(m_); epoch_.fetch_add(1, std::memory_order_release); }
+    epoch_.fetch_add(1, std::memory_order_release);                 // (no lock: see run())
     cv_.notify_one();
   }
   ~ScanPool() {
