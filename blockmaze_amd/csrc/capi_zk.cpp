@@ -838,7 +838,7 @@ int zkgpu_test_verify_schedule(const char *vk_path, const char *proof_hex, const
   if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK;
       } res = verify_by_schedule_on_host(*vk, (const Fe32 *)inputs, n_inputs, p, stats) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
 // batched verification on the GPU (kernel K9).  proofs_hex: n * 512 characters; inputs: n * n_inputs canonical field elements; ok[i] = 1 accept / 0 reject
-// (a record that is not 512 hex digits of values below q is rejected without reaching the device, like proof_from_hex in zkgpu_verify)
+// (a record that is not 512 hex digits is rejected without reaching the device; coordinates are taken modulo q like proof_from_hex in zkgpu_verify)
 int zkgpu_verify_batch(const char *vk_path, const char *proofs_hex, const uint8_t *inputs, size_t n_inputs, size_t n, uint8_t *ok) { return guarded([&] {
   if (!vk_path || (!proofs_hex && n) || !ok) return ZKGPU_ERR_ARG;
   struct { std::shared_ptr<BatchVerifier> v; } slot{gpu_verifier_for_path(vk_path)};                                  // caller holds the device mutex (guarded)

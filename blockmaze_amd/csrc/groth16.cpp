@@ -1702,6 +1702,7 @@ std::string proof_to_hex(const Proof &p) {
   return o;
 }
 bool proof_from_hex(const char *hex, Proof &p) {
+  static const bool strict = [] { const char *e = getenv("ZK_STRICT_PROOF_ENCODING"); return e && *e && *e != '0'; }();
   Fe32 v[8];
   for (int k = 0; k < 8; k++) {
     HFq c = HFq::zero();
@@ -1711,8 +1712,13 @@ bool proof_from_hex(const char *hex, Proof &p) {
       if (dgt < 0) return false;
       c.l[(63 - i) / 16] |= (uint64_t)dgt << (4 * ((63 - i) % 16));
     }
-    // values >= q cannot come from a prover; the reference would reduce them inside Fp's constructor — reject instead of aliasing
-    if (HFq::geq_mod(c.l)) return false; v[k] = fe_of(c.to_mont()); }
+    // Any 256-bit value is a coordinate: the reference builds the field element with Fp_model(const bigint&) (sendcgo.cpp:422-446 -> fp.tcc:190-194), one
+    // Montgomery product with R^2, which leaves value mod q.  to_mont() is that product (a < 2^256, R^2 < q: the sum stays below 2q, one subtraction), so a
+    // coordinate c and c + kq are the same proof here as they are there — consensus needs the same accept set, not a stricter one (ZK_STRICT_PROOF_ENCODING=1
+    // restores the rejection for deployments that want canonical encodings only; INTEGRATION.md "Not verbatim").
+    if (strict && HFq::geq_mod(c.l)) return false;
+    v[k] = fe_of(c.to_mont());
+  }
   p.A = {v[0], v[1]}; p.B = {v[3], v[2], v[5], v[4]}; p.C = {v[6], v[7]}; return true;
 }
 Proof default_proof() {

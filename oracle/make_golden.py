@@ -18,6 +18,11 @@ possible in the build container, where /root/reference exists) and stores its OU
   cmta_gadget.json           two chained compression gadgets with hard-wired padding, composed like sha256_CMTA_gadget (commitment.tcc:12-110)
   note_hashes.txt            Note::cm / NoteS::cm / Compute_PRF / Compute_CRH of send/Note.h and util.h on seeded hex strings
 
+  verify_mutations_<fixture>.txt  the reference verifier's VERDICT (ref_harness verifymany = r1cs_gg_ppzksnark_verifier_strong_IC behind sendcgo.cpp:388-448's
+                             hex parsing) on ~290 seeded mutations of each key fixture's proof (tests/verify_mutations.py): aliases c + kq, special values,
+                             off-curve, off-subgroup, malleations, re-randomisations, other statements.  Verdict 2 = the reference process aborts
+  hex_blobs.txt              uint256S / uint160S (send/uint256.h:222-248) and Compute_PRF / Compute_CRH of the parsed blob for ~150 odd C strings
+
 Fixtures are data only; no reference source is copied.
 """
 import hashlib, json, os, subprocess, sys, tempfile
@@ -96,11 +101,25 @@ def blockmaze_fixture():
             res[kind] = r
     json.dump(res, open(os.path.join(GOLD, "hash_blocks.json"), "w"), indent=1)
 
+def verdict_fixture():
+    import verify_mutations as vm
+    with tempfile.TemporaryDirectory() as t:
+        for name, seed in (("groth16_small", 0x5EED0001), ("groth16_step", 0x5EED0002)):
+            d = os.path.join(GOLD, name); meta = json.load(open(os.path.join(d, "meta.json"))); z = o.load_witness(os.path.join(d, "wit.bin")); vk = os.path.join(d, "vk.txt")
+            cs = vm.cases(vk, meta["proof"], o.from_arr(z[:meta["n_inputs"]]), seed); v = vm.reference_verdicts(HARNESS, vk, cs, t)
+            assert v[0] == 1 and sum(1 for x in v if x == 1) > 100 and sum(1 for x in v if x == 0) > 100
+            vm.write_cases(os.path.join(GOLD, "verify_mutations_%s.txt" % name), cs, v); print(name, len(cs), "cases:", v.count(1), "accepted,", v.count(0), "rejected,", v.count(2), "abort the reference")
+        strings = vm.blob_strings(0x5EED0003); res = vm.reference_blobs(HARNESS, strings, t)
+        with open(os.path.join(GOLD, "hex_blobs.txt"), "w") as f:
+            for x, r in zip(strings, res): f.write((x.hex() or "-") + " " + " ".join(r) + "\n")
+        print("hex_blobs:", len(strings), "strings")
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if "--verdicts-only" in sys.argv: verdict_fixture(); sys.exit(0)
     if "--gadgets-only" not in sys.argv:      # the key fixtures come from the reference generator's std::random_device: regenerating them changes pk/vk/proof (consistently)
         run("vectors", os.path.join(GOLD, "ref_vectors.txt"))
         groth16_fixture("groth16_small", 7, 3, 40, 60, 99)
         groth16_fixture("groth16_step", 8, 4, 30, 40, 100)
-    gadget_fixture(); blockmaze_fixture()
+    gadget_fixture(); blockmaze_fixture(); verdict_fixture()
     print("golden fixtures written to", GOLD)

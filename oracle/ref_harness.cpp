@@ -26,6 +26,9 @@
 //                                                       verify; prints "proof <hex>"
 //   prove <pk.txt> <wit.bin> <n_inputs> <r_hex> <s_hex> load pk with the reference operator>>, prove(r,s)
 //   verify <vk.txt> <proof_hex> <n_inputs> <in0_dec> …  reference verifier_strong_IC -> "verify 0|1"
+//   verifymany <vk.txt> <cases.txt>                     the same for every line "<512 hex> <n_inputs> <in0_dec> …" of a file (one key load): "v <line> 0|1"
+//   hexblobs <strings.txt>                              every line = one C string, hex-escaped: uint256S / uint160S (send/uint256.h:222-248) and the hashes
+//                                                       Compute_PRF(x, 0), Compute_CRH(x, 0) of the parsed blobs -> "blob <line> <u256> <u160> <prf> <crh>"
 //   bench_prover <r1cs.bin> <wit.bin> [threads]         time the stock r1cs_gg_ppzksnark_prover on a key of the
 //                                                       right shape (synthetic points), prints seconds per phase
 #include <cstdio>
@@ -37,6 +40,9 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <unistd.h>
+#include <fcntl.h>
+#include <sys/wait.h>
 #ifdef MULTICORE
 #include <omp.h>
 #endif
@@ -398,6 +404,31 @@ static int cmd_verify(int argc, char **argv) {
   std::vector<FrT> primary; for (size_t i = 0; i < n; i++) primary.push_back(FrT(bigint<4>(argv[5 + i])));
   double t0 = now_s(); bool ok = r1cs_gg_ppzksnark_verifier_strong_IC<ppT>(vk, primary, proof_from_hex(ph)); printf("verify %d verify_s %.4f\n", ok ? 1 : 0, now_s() - t0); return ok ? 0 : 1; }
 
+// one verdict per line of a file: what verifySendproof (sendcgo.cpp:388-448) decides for that character string and those public inputs.  The characters are
+// the caller's business: a line that is not 512 lowercase hex digits is not fed to the reference (convertFromAscii, sendcgo.cpp:25-35, has no defined value there).
+static int cmd_verifymany(const char *vk_path, const char *cases_path) {
+  auto vk = read_obj<r1cs_gg_ppzksnark_verification_key<ppT>>(vk_path); std::ifstream in(cases_path); std::string line; size_t k = 0;
+  while (std::getline(in, line)) {
+    std::istringstream ls(line); std::string ph; size_t n = 0; ls >> ph >> n; if (ph.size() != 512) { fprintf(stderr, "line %zu: not 512 characters\n", k); return 2; }
+    for (char c : ph) if (!((c >= '0' && c <= '9') || (c >= 'a' && c <= 'f'))) { fprintf(stderr, "line %zu: not lowercase hex\n", k); return 2; }
+    std::vector<FrT> primary; for (size_t i = 0; i < n; i++) { std::string d; ls >> d; primary.push_back(FrT(bigint<4>(d.c_str()))); }
+    // every case in a child process: the reference goes on to the pairing after is_well_formed() has failed (r1cs_gg_ppzksnark.tcc:528-560), and with B = (0, 0)
+    // (Z = 1) the Miller loop's value is 0, whose inversion in the final exponentiation trips assert(!is_zero()) (fp.tcc:648) in a build without -DNDEBUG such as
+    // this one: SIGABRT.  Reported as "v <line> A" — the verdict of an NDEBUG build for the same input is "reject" (result was already false).
+    fflush(stdout); pid_t pid = fork(); if (pid < 0) { perror("fork"); return 2; }
+    if (pid == 0) { int fd = open("/dev/null", O_WRONLY); if (fd >= 0) dup2(fd, 2); bool ok = r1cs_gg_ppzksnark_verifier_strong_IC<ppT>(vk, primary, proof_from_hex(ph)); _exit(ok ? 1 : 0); }
+    int st = 0; if (waitpid(pid, &st, 0) != pid) { perror("waitpid"); return 2; }
+    if (WIFEXITED(st)) printf("v %zu %d\n", k++, WEXITSTATUS(st)); else printf("v %zu A\n", k++); }
+  return 0; }
+
+static int cmd_hexblobs(const char *path) {
+  std::ifstream in(path); std::string line; size_t k = 0;
+  while (std::getline(in, line)) {
+    std::string s; for (size_t i = 0; i + 1 < line.size(); i += 2) s.push_back((char)strtoul(line.substr(i, 2).c_str(), nullptr, 16));
+    uint256 a = uint256S(s); uint160 b = uint160S(s); uint256 zero = uint256S("");
+    printf("blob %zu %s %s %s %s\n", k++, a.GetHex().c_str(), b.GetHex().c_str(), Compute_PRF(a, zero).GetHex().c_str(), Compute_CRH(b, zero).GetHex().c_str()); }
+  return 0; }
+
 static int cmd_bench_prover(const char *r1cs_path, const char *wit_path) {
   // Times the STOCK prover (r1cs_gg_ppzksnark.tcc:391-506) on a proving key of the exact shape the generator
   // would emit for this R1CS, but with cheap synthetic points (i·G) — prover time does not depend on point values.
@@ -436,5 +467,7 @@ int main(int argc, char **argv) {
   if (m == "e2e" && argc == 7) return cmd_e2e(argv[2], argv[3], argv[4], argv[5], argv[6]);
   if (m == "prove" && argc == 7) return cmd_prove(argv[2], argv[3], atoi(argv[4]), argv[5], argv[6]);
   if (m == "verify" && argc >= 5) return cmd_verify(argc, argv);
+  if (m == "verifymany" && argc == 4) return cmd_verifymany(argv[2], argv[3]);
+  if (m == "hexblobs" && argc == 3) return cmd_hexblobs(argv[2]);
   if (m == "bench_prover" && argc >= 4) return cmd_bench_prover(argv[2], argv[3]);
   fprintf(stderr, "bad arguments\n"); return 2; }

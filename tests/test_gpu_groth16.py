@@ -9,6 +9,7 @@ import pytest
 from oracle import pyoracle as o
 from blockmaze_amd import engine as e
 import workload as w
+import verify_mutations as vm
 from conftest import record_leg
 
 pytestmark = pytest.mark.gpu
@@ -222,6 +223,45 @@ def test_batched_gpu_verifier_matches_host_verifier(golden_dir, name):
         if all(c in "0123456789abcdef" for c in pr) and pr != "0" * 512: assert o.verify(ovk, x, o.proof_words_from_hex(pr)) == g_
     assert e.verify_batch(vk, [], []) == []
     assert e.verify_batch(vk, [good[0]], [inputs[:-1]]) == [False]                        # wrong number of public inputs (strong IC)
+
+@pytest.mark.parametrize("name", ["groth16_small", "groth16_step"])
+def test_gpu_verifier_verdicts_are_the_reference_s_on_mutated_proofs(golden_dir, name):
+    """kernel K9 on the ~290 committed mutations of the reference prover's proof (tests/golden/verify_mutations_*.txt: aliases c + kq, special values, off-curve,
+    off-subgroup, malleations, re-randomisations, other statements) — one launch per input count, and one proof per launch for every fifth case: the verdict of the
+    reference's verifier behind sendcgo.cpp:388-448 every time (an encoding on which the assert-enabled reference aborts is rejected)"""
+    vk = os.path.join(golden_dir, name, "vk.txt"); cases = vm.read_golden(os.path.join(golden_dir, "verify_mutations_%s.txt" % name)); assert len(cases) >= 200; n_acc = 0
+    for ni in sorted(set(len(c[2]) for c in cases)):
+        grp = [c for c in cases if len(c[2]) == ni]; got = e.verify_batch(vk, [c[1] for c in grp], [c[2] for c in grp])
+        for c, g_ in zip(grp, got): assert vm.agrees(g_, c[3]), (c[0], c[3]); n_acc += int(g_)
+    assert n_acc >= 100
+    for c in cases[::5]: assert vm.agrees(e.verify_batch(vk, [c[1]], [c[2]])[0], c[3]), (c[0], c[3])
+
+def test_verify_symbols_decide_like_libsnark_on_mutated_proofs(all_keys, monkeypatch, tmp_path):
+    """the accept set at the BOUNDARY, all four kinds at full size: a proof from gen*proof, ~280 seeded mutations of its 512 characters each (tests/verify_mutations.py),
+    the verdict of the reference's verifier (oracle/_ref/ref_harness verifymany: r1cs_gg_ppzksnark_verifier_strong_IC on the engine-made vk.txt read by libsnark's
+    operator>>, hex parsed as in sendcgo.cpp:388-448 / mintcgo.cpp / depositcgo.cpp:446-551 / redeemcgo.cpp) — and verify*proof (kernel K9, one proof per launch) as well
+    as verifyBatch (one launch per kind) return exactly that for every case; then the same proofs against other statements"""
+    import time
+    assert have_ref, "oracle/_ref/ref_harness is missing: run __graft_entry__.build() where /root/reference exists"
+    monkeypatch.setenv("ZK_PRFKEY_DIR", str(all_keys)); zk = e.Zk(); legs = []; items = []; expect = []
+    m = w.mint_instance(41); r = w.mint_instance(42, redeem=True); sd = w.send_instance(43); dd = w.deposit_instance(44)
+    kinds = [("mint", zk.GenMintProof(*w.mint_args(m)), [m["cmtA_old"], m["sn_old"], m["cmtA"]], m["value_s"], zk.VerifyMintProof),
+             ("redeem", zk.GenRedeemProof(*w.mint_args(r)), [r["cmtA_old"], r["sn_old"], r["cmtA"]], r["value_s"], zk.VerifyRedeemProof),
+             ("send", zk.GenSendProof(*w.send_args(sd)), [sd["cmtA_old"], sd["sn_old"], sd["cmtS"], sd["cmtA"]], None, zk.VerifySendProof),
+             ("deposit", zk.GenDepositProof(*w.deposit_args(dd), dd["leaves"], dd["rt"], dd["sk"]), [dd["rt"], dd["pk_recv"], dd["cmtB_old"], dd["sn_old"], dd["cmtB"], dd["sn_s"]], None, zk.VerifyDepositProof)]
+    for kind, proof, args, value_s, fn in kinds:
+        vk = str(all_keys / (kind + "vk.txt")); inputs = w.pack_public(args, value_s); tail = [] if value_s is None else [value_s]; assert fn(proof, *args, *tail), kind
+        cases = [c for c in vm.cases(vk, proof, inputs, 0xC0DE + len(kind)) if c[2] == inputs]; t0 = time.time(); ref_v = vm.reference_verdicts(HARNESS, vk, cases, tmp_path); legs.append("%s %d cases %.1f s" % (kind, len(cases), time.time() - t0))
+        assert len(cases) >= 200 and ref_v.count(1) >= 100 and ref_v.count(0) >= 90, (kind, len(cases), ref_v.count(1))
+        for (label, h, _), v in zip(cases, ref_v):
+            assert vm.agrees(fn(h, *args, *tail), v), (kind, label, v)
+            items.append((kind, h, args, value_s or 0)); expect.append(v == 1)
+        # other statements: the reference packs whatever it is given (gadget.tcc witness_map) — a proof is bound to its own public input
+        for j in range(len(args)):
+            other = list(args); other[j] = bytes(x ^ (1 if i == len(args[j]) - 1 else 0) for i, x in enumerate(args[j])); oin = w.pack_public(other, value_s)
+            v = vm.reference_verdicts(HARNESS, vk, [("other statement", proof, oin)], tmp_path)[0]; assert v == 0 and fn(proof, *other, *tail) is False, (kind, j)
+    rc, ok = zk.VerifyBatch(items); assert ok == expect and rc == sum(expect)
+    record_leg("libsnark verifier on mutated proofs of all four kinds (" + ", ".join(legs) + ")")
 
 def test_gpu_verifier_random_curve_points_match_host(golden_dir):
     """K9 on 29-bit limbs keeps lazily reduced values whose bounds the schedule builder proves; here it is fed what a prover never produces — 160 "proofs" made of

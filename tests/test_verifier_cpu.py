@@ -4,10 +4,14 @@
     reference's GT value for e(aG1, bG2) and whose other two pairings cancel (delta = -gamma, C = IC[0]); the proof (aG1, bG2, IC[0]) is accepted iff the
     engine's Miller loop + final exponentiation reproduce that value bit for bit
   * verifyBatch (include/zk_batch.h) is exported and fails cleanly without keys."""
-import ctypes, json, os
+import ctypes, json, os, subprocess, sys
 import pytest
 from oracle import pyoracle as o
 from blockmaze_amd import engine as e
+import verify_mutations as vm
+from conftest import record_leg
+
+HARNESS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_harness")
 
 def H(x): return int(x, 16)
 
@@ -71,6 +75,70 @@ def test_gpu_verifier_schedule_reproduces_reference_pairing_values(ref_vectors, 
         A, B = o.g1_op("mul", G1, k=a), o.g2_op("mul", G2, k=b); C = o.g1_op("mul", G1, k=77); vk = str(tmp_path / ("vk%d.txt" % n)); write_vk(vk, gt, G2, neg_g2, [C]); n += 1
         assert e.verify_schedule_on_host(vk, proof_hex(A, B, C), [])[0] and not e.verify_schedule_on_host(vk, proof_hex(o.g1_op("dbl", A), B, C), [])[0]
     assert n == 3
+
+# ---- the ACCEPT SET: the same verdict as the reference on every 512-character input (round 5) ----------------------------------------------------------------
+@pytest.mark.parametrize("name", ["groth16_small", "groth16_step"])
+def test_verdicts_are_the_reference_s_on_mutated_proofs(golden_dir, name):
+    """tests/golden/verify_mutations_<fixture>.txt: ~290 mutations of the reference prover's proof with the verdict of the reference's own verifier behind
+    sendcgo.cpp:388-448's parsing (oracle/make_golden.py, ref_harness verifymany).  The host verifier — what verify*proof runs when the device is busy or absent —, the
+    oracle, and on every second case kernel K9's schedule (interpreted on the host on both arithmetics) decide every one of them the same way: aliases c + kq of
+    accepted proofs ARE accepted (Fp_model(bigint) reduces, fp.tcc:190-194), as are (-A, -B) and re-randomisations; the six encodings on which an assert-enabled
+    reference build aborts (B = (0, 0), verdict 2) are rejected, like the reference's NDEBUG build does"""
+    d = os.path.join(golden_dir, name); vk = os.path.join(d, "vk.txt"); cases = vm.read_golden(os.path.join(golden_dir, "verify_mutations_%s.txt" % name)); ovk = o.parse_vk(vk)
+    assert len(cases) >= 200 and sum(1 for c in cases if c[3] == 1) >= 100 and sum(1 for c in cases if c[3] == 0) >= 100 and sum(1 for c in cases if c[3] == vm.ABORT) == 6
+    assert sum(1 for c in cases if c[3] == 1 and "alias" in c[0]) >= 70                                  # the point of the exercise
+    for i, (label, h, ins, verdict) in enumerate(cases):
+        assert vm.agrees(e.verify(vk, h, ins), verdict), (label, verdict)
+        assert vm.agrees(o.verify(ovk, ins, o.proof_words_from_hex(h)), verdict), ("oracle", label, verdict)
+        if i % 2 == 0: assert vm.agrees(e.verify_schedule_on_host(vk, h, ins)[0], verdict), ("K9 schedule", label, verdict)
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("name", ["groth16_small", "groth16_step"])
+def test_verdicts_against_the_live_reference(golden_dir, name, tmp_path):
+    """the same comparison with FRESH mutations (another seed than the committed fixture's) decided by the reference binary on the spot"""
+    import time
+    d = os.path.join(golden_dir, name); meta = json.load(open(os.path.join(d, "meta.json"))); z = o.load_witness(os.path.join(d, "wit.bin")); vk = os.path.join(d, "vk.txt")
+    cases = vm.cases(vk, meta["proof"], o.from_arr(z[:meta["n_inputs"]]), 0xA11A5 + len(name)); t0 = time.time(); ref = vm.reference_verdicts(HARNESS, vk, cases, tmp_path); record_leg("verifymany " + name, time.time() - t0)
+    assert len(cases) >= 200 and ref.count(1) >= 100
+    for (label, h, ins), verdict in zip(cases, ref): assert vm.agrees(e.verify(vk, h, ins), verdict), (label, verdict)
+
+@pytest.mark.skipif(not os.path.exists(HARNESS + "_nd"), reason="oracle/_ref/ref_harness_nd not built")
+def test_where_the_reference_aborts_its_ndebug_build_rejects(golden_dir, tmp_path):
+    """verdict 2 of the fixtures: with B = (0, 0) the reference reaches assert(!is_zero()) in Fp::invert (fp.tcc:648) — it computes the pairing although
+    is_well_formed() already failed — and the process dies; compiled with -DNDEBUG (libff's default build type) the very same call returns false, which is what this
+    repo answers.  Every other case is decided alike by the two builds"""
+    for name in ("groth16_small", "groth16_step"):
+        cases = vm.read_golden(os.path.join(golden_dir, "verify_mutations_%s.txt" % name)); vk = os.path.join(golden_dir, name, "vk.txt")
+        nd = vm.reference_verdicts(HARNESS + "_nd", vk, [c[:3] for c in cases], tmp_path)
+        for c, v in zip(cases, nd): assert v == (0 if c[3] == vm.ABORT else c[3]), c[0]
+        assert all("(0,0)" in c[0] and ("B" in c[0] or "all" in c[0]) for c in cases if c[3] == vm.ABORT)
+
+def test_strict_encoding_is_an_opt_in_switch(golden_dir):
+    """ZK_STRICT_PROOF_ENCODING=1 ("Not verbatim"): coordinates >= q are rejected instead of reduced; the default is the reference's behaviour"""
+    d = os.path.join(golden_dir, "groth16_small"); cases = vm.read_golden(os.path.join(golden_dir, "verify_mutations_groth16_small.txt")); vk = os.path.join(d, "vk.txt")
+    al = next(c for c in cases if c[0] == "alias all +1q"); can = cases[0]; assert al[3] == 1 and can[3] == 1
+    code = "import sys; sys.path.insert(0, %r); from blockmaze_amd import engine as e; print(int(e.verify(%r, %r, %r)), int(e.verify(%r, %r, %r)))" % (os.path.dirname(os.path.dirname(golden_dir)), vk, can[1], can[2], vk, al[1], al[2])
+    for env, want in (({}, "1 1"), ({"ZK_STRICT_PROOF_ENCODING": "1"}, "1 0"), ({"ZK_STRICT_PROOF_ENCODING": "0"}, "1 1")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300); assert r.stdout.split("\n")[-2].strip() == want, (env, r.stdout, r.stderr)
+
+def test_hex_arguments_parse_like_uint256S(golden_dir):
+    """tests/golden/hex_blobs.txt: 130 C strings — short, long, odd length, mixed case, blanks, characters that are no hex digits in every position — with what the
+    reference's uint256S / uint160S (send/uint256.h:222-248) make of them and the reference's Compute_PRF(x, 0) / Compute_CRH(x, 0) (send/util.h:233-258).  The cgo
+    symbols computePRF / computeCRH / genCMT, fed the same strings, give the same hashes: every char* argument of the boundary goes through this parser"""
+    from oracle import pyoracle  # noqa: F401
+    import hashlib
+    zk = e.Zk(); L = zk.L; n = 0
+    for line in open(os.path.join(golden_dir, "hex_blobs.txt")):
+        t = line.split(); s = b"" if t[0] == "-" else bytes.fromhex(t[0]); u256, u160, prf, crh = t[1:5]
+        assert L.computePRF(s, b"").decode() == prf, s
+        assert L.computeCRH(s, b"").decode() == crh, s
+        blob = bytes.fromhex(u256)[::-1]; assert prf == hashlib.sha256(blob + bytes(32)).digest()[::-1].hex()            # (what the golden line itself says: the hash of the parsed blob)
+        assert L.genCMT(ctypes.c_uint64(5), s, s).decode() == hashlib.sha256((5).to_bytes(8, "little") + blob + blob).digest()[::-1].hex(); n += 1
+    assert n >= 120
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not built")
+def test_hex_arguments_against_the_live_reference(tmp_path):
+    strings = vm.blob_strings(0xB10B5, n_random=300); ref = vm.reference_blobs(HARNESS, strings, tmp_path); L = e.Zk().L
+    for s, (u256, u160, prf, crh) in zip(strings, ref): assert L.computePRF(s, b"").decode() == prf and L.computeCRH(s, b"").decode() == crh, s
 
 def test_verify_batch_symbol(tmp_path, monkeypatch):
     zk = e.Zk(); assert hasattr(zk.L, "verifyBatch")
