@@ -527,6 +527,21 @@ struct HashBlockTestCircuit : Circuit {
     else g1->witness();
   }
 };
+// test circuit: the public-input unpacker of the four circuits on its own (e.g. send/circuit/gadget.tcc:87-106,198: libsnark's multipacking_gadget over the unpacked bits with
+// chunks of Fr's capacity, constraints with enforce_bitness) — packed inputs, then the bits; compared with libsnark's own class (oracle/ref_harness.cpp cmd_unpacker)
+struct UnpackerTestCircuit : Circuit {
+  VarArray packed, bits; std::unique_ptr<MultiPacking> up;
+  UnpackerTestCircuit(bool emit, size_t nbits) : Circuit(emit) {
+    Board &b = board;
+    packed = b.alloc_array((nbits + 252) / 253); b.set_input_sizes(packed.size());
+    bits = b.alloc_array(nbits);
+    up.reset(new MultiPacking(b, bits, packed));
+    if (emit) up->constraints(true);
+    b.finish();
+  }
+};
+std::unique_ptr<Circuit> make_unpacker_test_circuit(bool emit, size_t nbits) { return std::unique_ptr<Circuit>(new UnpackerTestCircuit(emit, nbits)); }
+void assign_unpacker_test(Circuit &c, const std::vector<bool> &bits) { auto &u = static_cast<UnpackerTestCircuit &>(c); fill(u.board, u.bits, bits); u.up->witness_from_bits(); }
 std::unique_ptr<Circuit> make_hashblock_test_circuit(bool emit, int which) { return std::unique_ptr<Circuit>(new HashBlockTestCircuit(emit, which)); }
 size_t hashblock_input_bits(int which) { size_t n = 0; for (size_t w : HashBlockTestCircuit::widths(which)) n += w; return n; }
 void assign_hashblock_test(Circuit &c, const std::vector<bool> &bits) { static_cast<HashBlockTestCircuit &>(c).assign(bits); }

@@ -74,6 +74,10 @@ size_t hashblock_input_bits(int which);
 void assign_hashblock_test(Circuit &c, const std::vector<bool> &bits);
 void assign_cmta_test(Circuit &c, const std::vector<bool> &v, const std::vector<bool> &sn, const std::vector<bool> &r);
 
+// test circuit: the public-input unpacker (multipacking_gadget, enforce_bitness) over nbits bits
+std::unique_ptr<Circuit> make_unpacker_test_circuit(bool emit, size_t nbits);
+void assign_unpacker_test(Circuit &c, const std::vector<bool> &bits);
+
 // test circuit: libsnark's merkle_tree_check_read_gadget as its self-test composes it (merkle_tree_check_read_gadget.tcc:131-196)
 std::unique_ptr<Circuit> make_merkle_test_circuit(bool emit, size_t depth);
 void assign_merkle_test(Circuit &c, const Blob256 &leaf, const std::vector<Blob256> &path /* leaf level first */, const std::vector<bool> &index_bits,

@@ -537,7 +537,7 @@ static void write_witness_file(const char *path, const std::vector<Fe32> &z) {
 int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path) {
   return guarded_host([&] { std::unique_ptr<Circuit> c = kind == 100 ? make_sha256_two_to_one(true) : kind == 101 ? make_merkle_test_circuit(true,
       tree_depth) : kind == 102 ? make_lesscmp_test_circuit(true) : kind == 103 ? make_cmta_test_circuit(true) : kind >= 104 && kind <= 106 ?
-      make_hashblock_test_circuit(true, kind - 104) : kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true,
+      make_hashblock_test_circuit(true, kind - 104) : kind == 107 ? make_unpacker_test_circuit(true, (size_t)tree_depth) : kind == (int)CircuitKind::Deposit ? make_deposit_circuit(true,
       tree_depth) : make_circuit((CircuitKind)kind, true); write_r1cs_file(r1cs_path, c->r1cs()); return ZKGPU_OK; });
 }
 /* bits: 64 + 256 + 256 bytes, each 0 or 1, in the circuit's bit order */
@@ -550,6 +550,11 @@ int zkgpu_witness_hashblock(int which, const uint8_t *bits, const char *wit_path
     if (which < 0 || which > 2) throw std::runtime_error("hashblock: which must be 0, 1 or 2"); auto c = make_hashblock_test_circuit(false, which);
   assign_hashblock_test(*c, std::vector<bool>(bits, bits + hashblock_input_bits(which))); std::vector<Fe32> z; c->export_assignment(z);
       write_witness_file(wit_path, z); return ZKGPU_OK; }); }
+/* bits: nbits bytes, each 0 or 1 */
+int zkgpu_witness_unpacker(int nbits, const uint8_t *bits, const char *wit_path) {
+  return guarded_host([&] { auto c = make_unpacker_test_circuit(false, (size_t)nbits); assign_unpacker_test(*c, std::vector<bool>(bits, bits + nbits)); std::vector<Fe32> z;
+      c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; });
+}
 int zkgpu_witness_lesscmp(uint64_t value_old, uint64_t value_s, const char *wit_path) {
   return guarded_host([&] { auto c = make_lesscmp_test_circuit(false); assign_lesscmp_test(*c, value_old, value_s); std::vector<Fe32> z;
       c->export_assignment(z); write_witness_file(wit_path, z); return ZKGPU_OK; });

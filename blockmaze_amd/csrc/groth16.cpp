@@ -669,15 +669,28 @@ void generate_keys(const R1csHost &cs_in, const ToxicWaste &tw, ProvingKeyHost &
 // ====================================================================================================================== A helper thread that lives as long as
 // its prover: submitting a witness MSM (about a dozen launches, several microseconds of host time each) must not cost a thread creation per proof on the
 // critical path. post() hands over a job, wait() blocks until it has run and rethrows what it threw. CPUs this process may run on (its affinity mask, not the
-// machine's size): a rank that a launcher pinned to two cores of a 256-thread host must not start sixteen polling helpers. (A cgroup CPU quota is not visible
-// here; bench.py sizes its ranks by it and pins them accordingly.)
+// machine's size): a rank that a launcher pinned to two cores of a 256-thread host must not start sixteen polling helpers.  A cgroup CPU quota counts as well
+// (cpu.max of cgroup v2, cpu.cfs_quota_us / cpu.cfs_period_us of v1): go-ethereum under a Kubernetes CPU limit without a cpuset sees every CPU of the host in its
+// affinity mask, and fifteen spinning helpers would get the process throttled on the proof's critical path.
+static unsigned cgroup_cpu_quota() {   // 0: none
+  auto read2 = [](const char *path, long long &a, long long &b, bool two) -> bool {
+    FILE *f = fopen(path, "r"); if (!f) return false; char t[64] = {0}; bool ok;
+    if (two) { ok = fscanf(f, "%63s %lld", t, &b) == 2; if (ok) { if (!strcmp(t, "max")) a = -1; else a = atoll(t); } }
+    else ok = fscanf(f, "%lld", &a) == 1;
+    fclose(f); return ok; };
+  long long quota = -1, period = 0;
+  if (read2("/sys/fs/cgroup/cpu.max", quota, period, true)) { if (quota > 0 && period > 0) return (unsigned)std::max<long long>(1, (quota + period - 1) / period); return 0; }
+  if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", quota, period, false) && quota > 0) { long long per = 0, dummy = 0;
+    if (read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", per, dummy, false) && per > 0) return (unsigned)std::max<long long>(1, (quota + per - 1) / per); }
+  return 0;
+}
 static unsigned usable_cpus() {
   static const unsigned v = [] {
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) return (unsigned)CPU_COUNT(&set);
-    const unsigned hw = std::thread::hardware_concurrency();
-    return hw ? hw : 1u;
+    unsigned n = 0; cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = (unsigned)CPU_COUNT(&set);
+    if (!n) { const unsigned hw = std::thread::hardware_concurrency(); n = hw ? hw : 1u; }
+    const unsigned q = cgroup_cpu_quota();
+    return q && q < n ? q : n;
   }();
   return v;
 }
@@ -1019,6 +1032,8 @@ class ScanPool {
   // (nothing ran).
   bool run(const std::function<void()> &job) {
     if (taken_.exchange(true, std::memory_order_acquire)) return false;
+    // (released on every way out: start_threads() can throw std::system_error when the process is out of threads, job() may throw)
+    struct Release { ScanPool &p; ~Release() { p.job_ = nullptr; p.taken_.store(false, std::memory_order_release); } } release{*this};
     start_threads();
     job_ = &job;
     state_.store(0, std::memory_order_release);                    // open: helpers may enter
@@ -1026,14 +1041,15 @@ class ScanPool {
     // that misses this wake-up between its check and its sleep misses this round, nothing else — nobody waits for a helper that is not inside)
     epoch_.fetch_add(1, std::memory_order_release);
     cv_.notify_all();
-    job();
+    // (whatever job() does on this thread, nobody may leave while a helper is still inside it: close the round and wait before the exception travels on)
+    std::exception_ptr err;
+    try { job(); } catch (...) { err = std::current_exception(); }
     uint32_t st = state_.fetch_or(CLOSED, std::memory_order_acq_rel) | CLOSED;   // closed: a helper that wakes up now stays out
     for (int k = 0; st != CLOSED; k++) {
       if ((k & 255) == 255) std::this_thread::yield(); else cpu_relax();
       st = state_.load(std::memory_order_acquire);
     }
-    job_ = nullptr;
-    taken_.store(false, std::memory_order_release);
+    if (err) std::rethrow_exception(err);
     return true;
   }
   // wake the helpers without a job (they find the round closed and poll for the next one): called where a scan is expected soon
@@ -1041,7 +1057,11 @@ class ScanPool {
     if (threads_started_.load(std::memory_order_acquire) == 0 || taken_.load(std::memory_order_acquire)) return;
     // ONE helper is woken here (a notify_all with fifteen sleepers costs the calling thread 15 us, on the critical path of its proof); that helper wakes the
     // others
-    epoch_.fetch_add(1, std::memory_order_release);                 // (no lock: see run())
+    // the bump under the mutex when it is free (off the critical path, and then no helper can sit between its check and its sleep and miss this one wake-up —
+    // with notify_one nobody else would poll for the next scan); contended, without it as in run()
+    std::unique_lock<std::mutex> lk(m_, std::try_to_lock);
+    epoch_.fetch_add(1, std::memory_order_release);
+    if (lk.owns_lock()) lk.unlock();
     cv_.notify_one();
   }
   ~ScanPool() {
@@ -1068,7 +1088,8 @@ class ScanPool {
   }
   void start_threads() {                                            // (called with taken_ held: one caller at a time)
     if (!threads_.empty() || crew() < 2) return;
-    for (size_t i = 0; i + 1 < crew(); i++) threads_.emplace_back([this] { loop(); });
+    try { for (size_t i = 0; i + 1 < crew(); i++) threads_.emplace_back([this] { loop(); }); }
+    catch (const std::system_error &) { if (threads_.empty()) throw; }   // (a smaller crew is a crew)
     threads_started_.store(threads_.size(), std::memory_order_release);
   }
   void loop() {
@@ -1225,11 +1246,15 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
     T = ScanPool::crew();
     if (T < 2 || !busy.alone() || !ScanPool::get().run(job)) {
       T = 4;
-      for (size_t t = 1; t < T; t++) worker(t).post([&scan, t] { scan(t); });
+      // (the workers are constructed before anything is posted, and this frame — which the posted jobs refer to — is not left before all of them are back)
+      SubmitWorker *ws[4] = {nullptr, &worker(1), &worker(2), &worker(3)};
+      for (size_t t = 1; t < T; t++) ws[t]->post([&scan, t] { scan(t); });
       if (trace) t_posted = now_ms();
-      scan(0);
+      std::exception_ptr own;
+      try { scan(0); } catch (...) { own = std::current_exception(); }
       if (trace) t_own = now_ms();
-      for (size_t t = 1; t < T; t++) worker(t).wait();
+      for (size_t t = 1; t < T; t++) { try { ws[t]->wait(); } catch (...) { if (!own) own = std::current_exception(); } }
+      if (own) std::rethrow_exception(own);
     }
     if (trace) { t_joined = now_ms(); if (t_own == t0) t_own = t_joined; }
   }
@@ -1340,9 +1365,12 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
   if (threaded && words >= 512) {
     const std::function<void()> job = [&] { scan(0); };
     if (ScanPool::crew() < 2 || !busy.alone() || !ScanPool::get().run(job)) {
-      for (size_t t = 1; t < 4; t++) worker(t).post([&scan, t] { scan(t); });
-      scan(0);
-      for (size_t t = 1; t < 4; t++) worker(t).wait();
+      SubmitWorker *ws[4] = {nullptr, &worker(1), &worker(2), &worker(3)};     // (constructed before anything is posted; see set_witness)
+      for (size_t t = 1; t < 4; t++) ws[t]->post([&scan, t] { scan(t); });
+      std::exception_ptr own;
+      try { scan(0); } catch (...) { own = std::current_exception(); }
+      for (size_t t = 1; t < 4; t++) { try { ws[t]->wait(); } catch (...) { if (!own) own = std::current_exception(); } }
+      if (own) std::rethrow_exception(own);
     }
   }
   else scan(0);

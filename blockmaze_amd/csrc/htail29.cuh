@@ -214,6 +214,9 @@ __global__ void __launch_bounds__(256) k_hbits29(const Point29Rec *__restrict__ 
   }
   // (ZZ = 0 mod p in something that is not the point at infinity raises the flag)
   if (threadIdx.x < 4) quad29_emit(acc, k, res + s_, cnt);
+  // (lane 2 of the quad may have raised the degenerate-sum flag with an atomic of its own: every lane's writes are ordered before the ticket below by this barrier and
+  // lane 0's fence, whatever wave the lanes sit in)
+  __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
     // (the ticket is left at zero: MSMs that share a sort share these counters)
@@ -295,6 +298,9 @@ __global__ void __launch_bounds__(256) k_wtail29(const Point29Rec *__restrict__ 
     acc = block_quad29_tree(acc, lds, min(half, 64u));
   }
   if (threadIdx.x < 4) quad29_emit(acc, k, res + slot, cnt);
+  // (lane 2 of the quad may have raised the degenerate-sum flag with an atomic of its own: every lane's writes are ordered before the ticket below by this barrier and
+  // lane 0's fence, whatever wave the lanes sit in)
+  __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
     // (the ticket is left at zero: MSMs that share a sort share these counters)

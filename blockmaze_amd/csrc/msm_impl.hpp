@@ -2,6 +2,8 @@
 #pragma once
 #include <cstring>
 #include <memory>
+#include <atomic>
+#include <cstdio>
 #include "gpu_internal.hpp"
 
 // window sizes with a compiled-in digit walk (msm.cuh: for_each_digit); every other size takes the runtime path (C = 0). An instantiation with C > 0 ignores
@@ -89,7 +91,36 @@ struct MsmImpl {
   static bool use_precompute(size_t n_, int W_) { static const bool on = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE"); return !e || atoi(e) != 0; }();
     static const size_t cap = [] { const char *e = getenv("ZK_MSM_PRECOMPUTE_MAX_MB"); return (size_t)(e ? atol(e) : 8192) << 20; }();
     return on && n_ > 0 && W_ > 1 && n_ * (size_t)W_ < (1ull << 31) && n_ * (size_t)W_ * sizeof(RawAffine) <= cap; }
+  // What a query's tables take while they are built: both coordinate forms of the table, the subset sums of the ones (15 / 4 records a point, twice), and the
+  // precompute kernel's scratch.  Tables are an optimisation: with less free HBM than that (a smaller device, many keys x ZK_DEVICES pools, another tenant) the
+  // query is loaded without them — the window-by-window path — instead of failing the key load.
+  static bool tables_fit_device(size_t n_, int W_, bool fo) {
+    static const double share = [] { const char *e = getenv("ZK_MSM_TABLES_FREE_SHARE"); const double v = e ? atof(e) : 0.6; return v > 0 && v <= 1 ? v : 0.6; }();
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return true;
+    const size_t table = n_ * (size_t)W_ * sizeof(RawAffine), scratch = (size_t)(W_ - 1) * n_ * (sizeof(XYZZ<F>) + sizeof(F)), groups = fo ? (n_ + 3) / 4 * 15 * sizeof(RawAffine) : 0;
+    const bool ok = (double)(2 * table + 2 * groups + scratch) <= share * (double)fr;
+    if (!ok) { static std::atomic<int> noted{0}; if (noted.fetch_add(1) < 4) fprintf(stderr,
+        "libzkgpu: %.1f GB of fixed-base tables for a query of %zu points do not fit the device's free memory (%.1f GB): loading it without tables\n",
+        (2 * table + 2 * groups + scratch) / 1e9, n_, fr / 1e9); }
+    return ok;
+  }
   static std::shared_ptr<const Bases> make_bases(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables, bool uniform_hint) {
+    if (tables && use_precompute(n_, msm_num_windows(c_))) {
+      if (!tables_fit_device(n_, msm_num_windows(c_), fo)) tables = false;
+      else {
+        // (an allocation can still fail half-way — another process took the memory meanwhile: once more without tables)
+        try { return make_bases_impl(host_points, n_, c_, fo, true, uniform_hint); }
+        catch (const GpuError &e) {
+          (void)hipGetLastError();
+          fprintf(stderr, "libzkgpu: building the fixed-base tables of a query of %zu points failed (%s): loading it without tables\n", n_, e.what());
+          tables = false;
+        }
+      }
+    }
+    return make_bases_impl(host_points, n_, c_, fo, tables, uniform_hint);
+  }
+  static std::shared_ptr<const Bases> make_bases_impl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables, bool uniform_hint) {
     auto b = std::make_shared<Bases>(); b->n = n_; b->c = c_; b->W = msm_num_windows(c_); b->WB = tables && use_precompute(n_, b->W) ? 1 : b->W;
     if (c_ < 6 || c_ > 20 || b->W > MSM_MAX_WINDOWS) throw GpuError("msm: unsupported window size");
     b->points = DevBuf<RawAffine>((n_ ? n_ : 1) * (size_t)(b->WB == 1 ? b->W : 1)); b->inf = DevBuf<uint8_t>(n_ ? n_ : 1);

@@ -101,13 +101,14 @@ class R1cs:
         except Exception: pass
 
 # ---- circuits, keys, prover, verifier ---------------------------------------------------------------------------------
-KIND = {"mint": 0, "send": 1, "deposit": 2, "redeem": 3, "sha256": 100, "merkle": 101, "lesscmp": 102, "cmta": 103, "cmts": 104, "prf": 105, "crh": 106}
+KIND = {"mint": 0, "send": 1, "deposit": 2, "redeem": 3, "sha256": 100, "merkle": 101, "lesscmp": 102, "cmta": 103, "cmts": 104, "prf": 105, "crh": 106, "unpacker": 107}
 def circuit_export(kind, path, tree_depth=8): _check(lib().zkgpu_circuit_export(KIND[kind], tree_depth, path.encode()))
 def keygen(kind, pk_path, vk_path, seed=0, tree_depth=8): _check(lib().zkgpu_keygen(KIND[kind], tree_depth, ctypes.c_uint64(seed), pk_path.encode(), vk_path.encode()))
 def keygen_from_r1cs(r1cs_path, pk_path, vk_path, seed=0): _check(lib().zkgpu_keygen_from_r1cs(r1cs_path.encode(), ctypes.c_uint64(seed), pk_path.encode(), vk_path.encode()))
 def witness_sha256(left32, right32, path): _check(lib().zkgpu_witness_sha256(bytes(left32), bytes(right32), path.encode()))
 def witness_hashblock(kind, bits, path): _check(lib().zkgpu_witness_hashblock(KIND[kind] - 104, bytes(bits), path.encode()))
 def witness_cmta(bits576, path): _check(lib().zkgpu_witness_cmta(bytes(bits576), path.encode()))
+def witness_unpacker(bits, path): _check(lib().zkgpu_witness_unpacker(len(bits), bytes(bits), path.encode()))
 def witness_lesscmp(value_old, value_s, path): _check(lib().zkgpu_witness_lesscmp(ctypes.c_uint64(value_old), ctypes.c_uint64(value_s), path.encode()))
 def _s(x): return x if isinstance(x, bytes) else x.encode()
 def witness_send(value_A, r_s, sn, r, cmt_s, cmtA, value_s, pk_recv, value_A_new, sn_A_new, r_A_new, cmt_A_new, sk, pk_sender, path):

@@ -74,12 +74,13 @@ void zkgpu_r1cs_destroy(zkgpu_r1cs *cs);
 int zkgpu_witness_map(zkgpu_r1cs *cs, const uint8_t *z, uint8_t *h_out);
 
 /* ---- circuits, keys, resident prover, verifier -------------------------------------------------------------------- */
-/* kind: 0 mint, 1 send, 2 deposit, 3 redeem (100 / 101 / 102 / 103 = test circuits: libsnark's sha256 two-to-one, Merkle check-read, BlockMaze's less-comparison block, one sha256_CMTA_gadget).  tree_depth only matters for deposit (reference: 8). */
+/* kind: 0 mint, 1 send, 2 deposit, 3 redeem (100 / 101 / 102 / 103 = test circuits: libsnark's sha256 two-to-one, Merkle check-read, BlockMaze's less-comparison block, one sha256_CMTA_gadget; 104..106 the CMTS / PRF / CRH blocks; 107 the public-input unpacker over tree_depth bits).  tree_depth only matters for deposit (reference: 8) and kind 107. */
 /* writes the circuit's constraint system as an "R1CSBM01" file: magic, u64 n_inputs / n_vars / n_cons, then per matrix u64 nnz, u32 rowptr[n_cons+1], u32 col[nnz], 32-byte coeff[nnz] */
 int zkgpu_circuit_export(int kind, int tree_depth, const char *r1cs_path);
 /* witness files: u64 n, then n 32-byte canonical values (the full assignment without ONE).  Same arguments as the gen*proof symbols. */
 int zkgpu_witness_sha256(const uint8_t left[32], const uint8_t right[32], const char *wit_path);
 int zkgpu_witness_lesscmp(uint64_t value_old, uint64_t value_s, const char *wit_path);
+int zkgpu_witness_unpacker(int nbits, const uint8_t *bits /* nbits bytes of 0 / 1 */, const char *wit_path);
 int zkgpu_witness_hashblock(int which /* 0 CMTS, 1 PRF, 2 CRH: circuit kinds 104..106 of zkgpu_circuit_export */, const uint8_t *bits /* 736 / 512 / 416 bytes of 0 / 1 */, const char *wit_path);
 int zkgpu_witness_cmta(const uint8_t *bits /* 576 bytes of 0 / 1: value[64], sn[256], r[256] */, const char *wit_path);
 int zkgpu_witness_send(uint64_t value_A, char *r_s, char *sn, char *r, char *cmt_s, char *cmtA, uint64_t value_s, char *pk_recv, uint64_t value_A_new, char *sn_A_new,

@@ -18,6 +18,7 @@ possible in the build container, where /root/reference exists) and stores its OU
   cmta_gadget.json           two chained compression gadgets with hard-wired padding, composed like sha256_CMTA_gadget (commitment.tcc:12-110)
   note_hashes.txt            Note::cm / NoteS::cm / Compute_PRF / Compute_CRH of send/Note.h and util.h on seeded hex strings
 
+  unpacker_gadget.json       libsnark's multipacking_gadget as the circuits build their public-input unpacker (832 / 1024 / 1440 bits)
   verify_mutations_<fixture>.txt  the reference verifier's VERDICT (ref_harness verifymany = r1cs_gg_ppzksnark_verifier_strong_IC behind sendcgo.cpp:388-448's
                              hex parsing) on ~290 seeded mutations of each key fixture's proof (tests/verify_mutations.py): aliases c + kq, special values,
                              off-curve, off-subgroup, malleations, re-randomisations, other statements.  Verdict 2 = the reference process aborts
@@ -101,6 +102,19 @@ def blockmaze_fixture():
             res[kind] = r
     json.dump(res, open(os.path.join(GOLD, "hash_blocks.json"), "w"), indent=1)
 
+def unpacker_fixture():
+    """libsnark's multipacking_gadget as the four circuits build their public-input unpacker: 832 bits (mint / redeem), 1024 (send), 1440 (deposit)"""
+    from test_circuits_cpu import canonical_hash
+    res = {}
+    with tempfile.TemporaryDirectory() as t:
+        for nbits in (832, 1024, 1440):
+            r = {}
+            for seed in (5, 6):
+                out = run("unpacker", str(nbits), str(seed), t + "/r.bin", t + "/w.bin"); kv = dict(p.split("=") for p in out.split()[1:]); assert kv["satisfied"] == "1"
+                r.update(canonical_r1cs_sha256=canonical_hash(o.R1CS.load(t + "/r.bin")), constraints=int(kv["constraints"]), variables=int(kv["variables"]), inputs=int(kv["inputs"])); r["seed%d" % seed] = {"witness_sha256": sha(t + "/w.bin")}
+            res["bits%d" % nbits] = r
+    json.dump(res, open(os.path.join(GOLD, "unpacker_gadget.json"), "w"), indent=1)
+
 def verdict_fixture():
     import verify_mutations as vm
     with tempfile.TemporaryDirectory() as t:
@@ -117,9 +131,10 @@ def verdict_fixture():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if "--verdicts-only" in sys.argv: verdict_fixture(); sys.exit(0)
+    if "--unpacker-only" in sys.argv: unpacker_fixture(); sys.exit(0)
     if "--gadgets-only" not in sys.argv:      # the key fixtures come from the reference generator's std::random_device: regenerating them changes pk/vk/proof (consistently)
         run("vectors", os.path.join(GOLD, "ref_vectors.txt"))
         groth16_fixture("groth16_small", 7, 3, 40, 60, 99)
         groth16_fixture("groth16_step", 8, 4, 30, 40, 100)
-    gadget_fixture(); blockmaze_fixture(); verdict_fixture()
+    gadget_fixture(); blockmaze_fixture(); unpacker_fixture(); verdict_fixture()
     print("golden fixtures written to", GOLD)

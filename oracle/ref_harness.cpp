@@ -18,6 +18,7 @@
 //   vectors <out.txt>                                   field / curve / domain / MSM / pairing known-answer vectors
 //   sha256gadget <out_r1cs.bin> <out_wit.bin> <seed>    libsnark sha256_compression_function_gadget R1CS + witness
 //   merklegadget <depth> <out_r1cs.bin> <out_wit.bin> <seed>
+//   unpacker <nbits> <seed> <out_r1cs.bin> <out_wit.bin>  libsnark's multipacking_gadget as the four circuits build their public-input unpacker (e.g. send/circuit/gadget.tcc:87-106,198)
 //   lesscmp <value_old> <value_s> <out_r1cs.bin> <out_wit.bin>   BlockMaze's less_comparison_gadget block (send/circuit/comparison.tcc) R1CS + witness
 //   hashblock cmts|prf|crh <seed> <out_r1cs.bin> <out_wit.bin>   the CMTS / PRF / CRH blocks composed like commitment.tcc:100-320
 //   cmta <seed> <out_r1cs.bin> <out_wit.bin>            two chained compression gadgets + hard-wired padding, composed like sha256_CMTA_gadget (commitment.tcc:12-110)
@@ -318,6 +319,16 @@ static int cmd_lesscmp(uint64_t v_old, uint64_t v_s, const char *r1cs_out, const
   save_r1cs(r1cs_out, pb.get_constraint_system()); save_wit(wit_out, pb.full_variable_assignment());
   printf("lesscmp constraints=%zu variables=%zu satisfied=%d packed_old=%s packed_s=%s\n", pb.num_constraints(), pb.num_variables(), pb.is_satisfied() ? 1 : 0, hex_of(pb.val(value_old_packed)).c_str(), hex_of(pb.val(value_s_packed)).c_str()); return 0; }
 
+// The public-input unpacker of the four circuits: packed inputs allocated first and declared the primary input (send/circuit/gadget.tcc:87-88), then the unpacked bits
+// (:90-93: digest_variables / a 64-bit array, i.e. consecutive variables), multipacking_gadget(pb, bits, packed, FieldT::capacity()) (:99-105) and
+// generate_r1cs_constraints(true) (:198); the witness goes from the bits to the packed values (generate_r1cs_witness_from_bits, :268).
+static int cmd_unpacker(size_t nbits, uint64_t seed, const char *r1cs_out, const char *wit_out) {
+  protoboard<FrT> pb; pb_variable_array<FrT> packed, bits; size_t np = (nbits + FrT::capacity() - 1) / FrT::capacity(); packed.allocate(pb, np, "packed"); pb.set_input_sizes(np); bits.allocate(pb, nbits, "bits");
+  multipacking_gadget<FrT> unpacker(pb, bits, packed, FrT::capacity(), "unpacker"); unpacker.generate_r1cs_constraints(true);
+  SplitMix g(seed); std::vector<bool> bv(nbits); for (size_t i = 0; i < nbits; i++) bv[i] = g.next() & 1; bits.fill_with_bits(pb, bv); unpacker.generate_r1cs_witness_from_bits();
+  save_r1cs(r1cs_out, pb.get_constraint_system()); save_wit(wit_out, pb.full_variable_assignment());
+  printf("unpacker bits=%zu constraints=%zu variables=%zu inputs=%zu satisfied=%d\n", nbits, pb.num_constraints(), pb.num_variables(), np, pb.is_satisfied() ? 1 : 0); return 0; }
+
 // Two chained libsnark compression gadgets composed the way BlockMaze's sha256_CMTA_gadget composes them (send/circuit/commitment.tcc:12-110, which itself cannot be
 // included: its padding comes from utils.tcc's from_bits): ZERO, value[64], sn[256], r[256], the output digest; then the intermediate digest, block1 = value | sn |
 // r[0..192), block2 = r[192..256) | padding for a 576-bit message made of the constant ONE and the variable ZERO, hasher1 from SHA256_default_IV, hasher2 from the
@@ -460,6 +471,7 @@ int main(int argc, char **argv) {
   if (m == "vectors" && argc == 3) return cmd_vectors(argv[2]);
   if (m == "sha256gadget" && argc == 5) return cmd_sha256gadget(argv[2], argv[3], strtoull(argv[4], 0, 0));
   if (m == "merklegadget" && argc == 6) return cmd_merklegadget(atoi(argv[2]), argv[3], argv[4], strtoull(argv[5], 0, 0));
+  if (m == "unpacker" && argc == 6) return cmd_unpacker(strtoull(argv[2], 0, 0), strtoull(argv[3], 0, 0), argv[4], argv[5]);
   if (m == "lesscmp" && argc == 6) return cmd_lesscmp(strtoull(argv[2], 0, 0), strtoull(argv[3], 0, 0), argv[4], argv[5]);
   if (m == "cmta" && argc == 5) return cmd_cmta(strtoull(argv[2], 0, 0), argv[3], argv[4]);
   if (m == "hashblock" && argc == 6 && (!strcmp(argv[2], "cmts") || !strcmp(argv[2], "prf") || !strcmp(argv[2], "crh"))) return cmd_hashblock(argv[2], strtoull(argv[3], 0, 0), argv[4], argv[5]);

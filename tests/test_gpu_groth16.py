@@ -134,6 +134,34 @@ def test_dropin_symbols_all_four_circuits_mixed(all_keys, monkeypatch):
     wrong_rt = bytes.fromhex("39524a6ae253fca75a89240d93c0c6d893bcb66e783606dbb1fc7dff92dc543c"); assert not zk.VerifyDepositProof(p, wrong_rt, dd["pk_recv"], dd["cmtB_old"], dd["sn_old"], dd["cmtB"], dd["sn_s"])   # deposit/main.cpp wrong_rt
     missing = dict(dd); missing["leaves"] = dd["leaves"][:9]; assert zk.GenDepositProof(*w.deposit_args(missing), missing["leaves"], dd["rt"], dd["sk"]).startswith("0000000000")   # cmtS not in cmtarray: sentinel, not a crash
 
+def test_reference_fixtures_with_their_golden_values_through_the_cgo_symbols(all_keys, monkeypatch):
+    """SURVEY.md §8(c)'s golden values — captured from the reference's own executables and libzk_*.so — as LITERAL strings through the drop-in symbols on the GPU path:
+    the send fixture of send/main.cpp:123-142 (sn_old, cmtA_old, sn, cmtA, r_s, cmtS), the deposit fixture of deposit/main.cpp:131-167 (cmtS at leaf 9, wit.root = the
+    root of the 16 leaves, tree.root = the 10-leaf prefix tree, wrong_root), the mint / redeem fixtures of mint/main.cpp:121-129, redeem/main.cpp:121-129"""
+    monkeypatch.setenv("ZK_PRFKEY_DIR", str(all_keys)); zk = e.Zk(); L = zk.L; H = lambda b: b"0x" + b.hex().encode(); U = lambda h, n=32: int(h, 16).to_bytes(n, "big"); c64 = __import__("ctypes").c_uint64
+    sn_old, cmtA_old = "4a31770fe5354a1a9632ebe1481e108cd82ce514ac094c57b5ffdfaea8ac138a", "036bdbabf553bd57e41289b8c13b80a9aef29c464a2cfca0c9e99c69fb9be4ff"
+    sn, cmtA = "9b2d319b594f146c785aac11592a3e59f32cd6e6176a4d7a52d15a0b8eb6db06", "589effbb69ee8401c4108ad1e9a3de34e0fc81e283c6da9e95e6b9555dcb2835"
+    r_s, cmtS = "8fe3dac1d2c00b427c4406d3fdfe43df999e7c8cc70dd9bf57953c2a9622e1b9", "e4b1743ea76c314992849f07fd9d8352d63e669773862df96305a4fd924cdbb4"
+    sk, r_old, r, pk_sender, pk_recv = b"0x1", b"0x123456", b"0x12", b"0x456", b"0x123"                                                # short strings, as main.cpp writes them (uint256S zero-extends)
+    assert L.computePRF(sk, r_old).decode() == sn_old and L.genCMT(c64(22), b"0x" + sn_old.encode(), r_old).decode() == cmtA_old and L.computeCRH(pk_sender, r).decode() == r_s
+    assert L.computePRF(sk, r).decode() == sn and L.genCMT(c64(14), b"0x" + sn.encode(), r).decode() == cmtA and L.genCMTS(c64(8), pk_recv, b"0x" + r_s.encode(), b"0x" + sn_old.encode()).decode() == cmtS
+    X = lambda h: b"0x" + h.encode()
+    proof = L.genSendproof(c64(22), X(r_s), X(sn_old), r_old, X(cmtS), X(cmtA_old), c64(8), pk_recv, c64(14), X(sn), r, X(cmtA), sk, pk_sender).decode(); assert len(proof) == 512 and not proof.startswith("0000000000")
+    assert L.verifySendproof(proof.encode(), X(cmtA_old), X(sn_old), X(cmtS), X(cmtA)) and not L.verifySendproof(proof.encode(), X(cmtA), X(sn_old), X(cmtS), X(cmtA_old))
+    # deposit: value 264 = 255 + 9, leaves "1".."16" with cmtS at index 9
+    d_cmtS, wit_root, tree_root, wrong_root = "e4593e968e75e96fd5c51212cadd046547226e98c1715de9a10e6dfa3e9fdca5", "2630f036430a646118dbb95ba55e9e3803e35a680398d01f9942513ebbb7911e", "6b3ab57816ea4d7bb6410b4a81484d1b64d08e33cc29160a789eb7a94c75f267", "39524a6ae253fca75a89240d93c0c6d893bcb66e783606dbb1fc7dff92dc543c"
+    dd = w.reference_deposit_fixture(); assert dd["cmtS"].hex() == d_cmtS; leaves = b"".join(H(x) for x in dd["leaves"])
+    assert L.genRoot(leaves, 16).decode() == wit_root and L.genRoot(leaves[:66 * 10], 10).decode() == tree_root and L.genCMTS(c64(9), b"0x123", b"0x123", b"0x123").decode() == d_cmtS
+    dp = zk.GenDepositProof(*w.deposit_args(dd), dd["leaves"], U(wrong_root), dd["sk"]); assert not dp.startswith("0000000000")               # the RT argument is ignored, the root is recomputed (depositcgo.cpp:402-403)
+    va = [H(dd[k]) for k in ("pk_recv", "cmtB_old", "sn_old", "cmtB", "sn_s")]
+    assert L.verifyDepositproof(dp.encode(), X(wit_root), *va) and not L.verifyDepositproof(dp.encode(), X(wrong_root), *va) and not L.verifyDepositproof(dp.encode(), X(tree_root), *va)
+    # mint 13 = 6 + 7 and redeem 13 = 20 - 7 with sk "1", r_old "123456", r "123"
+    for redeem, v, vo, vs in ((False, 13, 6, 7), (True, 13, 20, 7)):
+        r3 = b"0x123"; so = L.computePRF(sk, r_old); sn_ = L.computePRF(sk, r3); co = L.genCMT(c64(vo), b"0x" + so, r_old); cn = L.genCMT(c64(v), b"0x" + sn_, r3); assert so.decode() == sn_old
+        gen, ver = (L.genRedeemproof, L.verifyRedeemproof) if redeem else (L.genMintproof, L.verifyMintproof)
+        pr = gen(c64(v), c64(vo), b"0x" + so, r_old, b"0x" + sn_, r3, b"0x" + co, b"0x" + cn, c64(vs), sk); assert not pr.startswith(b"0000000000")
+        assert ver(pr, b"0x" + co, b"0x" + so, b"0x" + cn, c64(vs)) and not ver(pr, b"0x" + co, b"0x" + so, b"0x" + cn, c64(vs + 1))
+
 def test_mint_redeem_deposit_full_size_against_libsnark(all_keys, tmp_path):
     """the other three circuits at full size against the REAL libsnark (oracle/_ref/ref_harness): the reference's mint fixture (mint/main.cpp:121-129) and its redeem and
     deposit fixtures (redeem/main.cpp:121-129, deposit/main.cpp:131-167) are proved on the GPU with fixed (r, s); the reference VERIFIER accepts all three proofs under the

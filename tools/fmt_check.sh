@@ -14,8 +14,11 @@ AFTER=${1:-$ROOT}; if [ -z "$FMT_CHECK_COMPARE_ONLY" ]; then asm "$W/head" "$W/b
 # .file / .ident lines name paths and compilers, and hipcc derives the ids of a compilation unit (__hip_cuid_*, __hip_fatbin_*, __hip_gpubin_handle_*) from its source text
 norm() { grep -v '^\s*\.file\|^\s*\.ident' "$1" | sed 's/__hip_\(cuid\|gpubin_handle\|fatbin\)_[0-9a-f]*/__hip_\1_ID/g'; }
 bad=0
+# every expected assembly file must exist on BOTH sides: a unit that fails to compile (its errors go to /dev/null above) is a failure, not a silent skip
+for src in "$ROOT"/blockmaze_amd/csrc/*.hip; do n=$(basename "${src%.hip}"); for s in "$n.device.s" "$n.host.s"; do for side in before after; do [ -s "$W/$side/$s" ] || { echo "MISSING: $side/$s (did not compile)"; bad=1; }; done; done; done
+for src in "$ROOT"/blockmaze_amd/csrc/*.cpp; do s=$(basename "${src%.cpp}").s; for side in before after; do [ -s "$W/$side/$s" ] || { echo "MISSING: $side/$s (did not compile)"; bad=1; }; done; done
 for f in "$W"/before/*.s; do
-  b=$(basename "$f")
+  b=$(basename "$f"); [ -s "$W/after/$b" ] || continue
   # (an assert() carries its line number as an immediate: such a difference is listed, not hidden)
   if ! diff <(norm "$f") <(norm "$W/after/$b") > "$W/$b.diff"; then echo "DIFFERENT: $b ($(wc -l < "$W/$b.diff") diff lines, $W/$b.diff)"; bad=1; else echo "same: $b"; fi
 done
