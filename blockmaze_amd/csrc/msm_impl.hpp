@@ -408,6 +408,11 @@ struct MsmImpl {
       {
         Stage st((label + ".accumulate").c_str(), s);
         const dim3 grid(cdiv(cdiv(n * (size_t)W, h_run) + hs.groups, 256));
+        // (experiment switch: unused dynamic LDS caps the workgroups per compute unit — 160 KB a CU: 41 KB -> 3 waves per SIMD, 54 KB -> 2)
+        static const unsigned h_lds = [] { const char *e = getenv("ZK_HACC_DYNLDS_KB"); return e ? (unsigned)atoi(e) * 1024u : 0u; }();
+        if (h_lds) hipLaunchKernelGGL(k_hacc_runs29<1>, grid, dim3(256), h_lds, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(),
+            offsets.get(), hs, h_run, h_maxp, (Piece29 *)partials.get(), cnt);
+        else
         if (any_inf) hipLaunchKernelGGL(k_hacc_runs29<1>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(),
             offsets.get(), hs, h_run, h_maxp, (Piece29 *)partials.get(), cnt);
         else hipLaunchKernelGGL(k_hacc_runs29<0>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(),
@@ -418,6 +423,14 @@ struct MsmImpl {
         Stage st((label + ".combine").c_str(), s);
         const size_t pieces = n * (size_t)W / NB / h_run;
         const uint32_t ll = pieces > 40 ? 3 : pieces > 18 ? 2 : 1;
+        // round 5: with the 29-bit tail the sums are formed by quads (htail29.cuh: k_hacc_combine29q) — ZK_HCOMBINE_QUADS = log2 of the quads per bucket + 1, 0 = the
+        // two-lane kernel; default: one quad up to 18 pieces, two up to 40, four beyond
+        static const int hq = [] { const char *e = getenv("ZK_HCOMBINE_QUADS"); return e ? atoi(e) : -1; }();
+        if (htail29 && hq != 0) {
+          const uint32_t lq = hq > 0 ? (uint32_t)(hq - 1) : pieces > 40 ? 2 : pieces > 18 ? 1 : 0;
+          hipLaunchKernelGGL(k_hacc_combine29q<0>, dim3(cdiv((nbk << lq) * 4, 256)), dim3(256), 0, s, (const uint32_t *)partials.get(), offsets.get(), hist(), hs.low_bits,
+              hs.region, h_run, h_maxp, (uint32_t)nbk, lq, (Point29Rec *)hb29.get(), cnt);
+        } else
         hipLaunchKernelGGL(k_hacc_combine29, dim3(cdiv(nbk << ll, 256)), dim3(256), 0, s, (const Piece29 *)partials.get(), offsets.get(), hist(), hs, h_run,
             h_maxp, (uint32_t)nbk, ll, (XYZZ<Fq> *)bucket_array(), htail29 ? (Point29Rec *)hb29.get() : nullptr, cnt);
       }
