@@ -126,6 +126,31 @@ def check_bounds_g2():
     assert 9 * ((1 << 30) + 16) ** 2 + 9 * (1 << 58) + (1 << 35) < 1 << 64
     return dict(X3=X3, Y3=Y3, ZZ=ZZ3, ZZZ=ZZZ3, P=P, R=R, T=T)
 
+def check_bounds_oct():
+    """the general addition over Fq2 with the point spread over EIGHT lanes (oct29.cuh: oct29_add — fold and tail of the G2 witness MSM, round 5): the formulas of
+    add-2008-s in the four rounds of quad29_add, every Fq2 product as two dual products mul2 (component 0: a0 b0 + (K_6 - a1) b1, component 1: a0 b1 + a1 b0), every
+    difference with the constants of the G1 form.  Operands: sums left by the lanes (XYZZ2_29::madd: X, Y < 4.1 p after their Barrett step, ZZ / ZZZ components below
+    5.7 p) or earlier results of this addition.  Proves: the invariant X < 5.5, Y < 4.1, ZZ, ZZZ < 5.7 per component is kept, every negated operand stays below 6 p
+    (K_6), every subtrahend below its constant, and the columns of mul2 below 2^64 with the limb sizes the kernel feeds it."""
+    bX, bY, bZ = 5.5, 4.1, 5.7; NEG = 6.0
+    def m2(a, b):
+        assert a <= NEG - 0.01, a                                                     # (a's partner component is negated with K_6)
+        return max(prod(a, b) + prod(NEG, b) - 1.0, 2 * prod(a, b) - 1.0)              # (x y + z w) / 2^261 + p  in units of p
+    U = m2(bX, bZ); S = m2(bY, bZ); cP = cR = 2; assert cP >= U + 0.01 and cR >= S + 0.01
+    bP = U + cP; bR = S + cR; PP = m2(bP, bP); RR = m2(bR, bR); Z12 = m2(bZ, bZ)
+    PPP = m2(bP, PP); Qv = m2(U, PP); ZZ3 = m2(Z12, PP)
+    cX = 4; assert cX >= PPP + 2 * Qv + 0.01; nX = RR + cX; cT = 6; assert cT >= nX + 0.01; bT = Qv + cT
+    S1r = S + cR                                                                      # S1 rebuilt as S2 + (K_2 + S1 - S2), like the quad form
+    ZZZ3 = m2(Z12, PPP); A = m2(bR, bT); Bv = m2(S1r, PPP); cY = 2; assert cY >= Bv + 0.01; nY = A + cY
+    assert nX <= bX and nY <= bY and max(ZZ3, ZZZ3) <= bZ, (nX, nY, ZZ3, ZZZ3)
+    for c, need in ((cP, U), (cR, S), (cX, PPP + 2 * Qv), (cT, nX), (cY, Bv), (6, NEG - 0.01)): assert KS[c][NL - 1] >= int(need * Q) >> (B * (NL - 1)), (c, need)
+    # columns of mul2: 9 terms x y and 9 terms z w, x and z with limbs up to 2^30 + 8 (S1 rebuilt: a product's result plus a normalized difference), y and w normalized
+    assert 18 * ((1 << 30) + 8) * ((1 << 29) + 8) + 9 * (1 << 58) + (1 << 35) < 1 << 64
+    # the negation K_6 - v takes limbs below 3 * (2^29 + 8)
+    assert (1 << 30) + 8 < 3 * ((1 << 29) + 8)
+    return dict(X=nX, Y=nY, ZZ=ZZ3, ZZZ=ZZZ3, P=bP, R=bR, T=bT)
+BOUNDS_OCT = check_bounds_oct()
+
 HEADER = ["// GENERATED by gen_field29.py - do not edit.  Fq and Fr on nine 29-bit limbs (R' = 2^261): Fq29 for k_hacc_runs29 (msm.cuh) and the verifier's schedule",
           "// (pairing.cuh), Fr29 for the transforms (ntt.cuh); device compilation only.",
           "// value bounds of the mixed addition, in units of p (interval arithmetic in the generator): " + ", ".join("%s < %.2f" % kv for kv in BOUNDS["bounds"].items())]
@@ -153,7 +178,7 @@ def gen_struct():
         out.extend(prologue)
         for k in range(17):
             first = k == 0
-            if columns[k]: mads(columns[k], False, first)
+            for ch in range(0, len(columns[k]), 9): mads(columns[k][ch:ch + 9], False, first and ch == 0)   # (an asm statement takes 30 operands: nine pairs a time)
             if k < 9:
                 mp = [("m%d" % i, "P29[%d]" % (k - i)) for i in range(0, k)]
                 if mp: mads(mp, True, False)
@@ -167,6 +192,10 @@ def gen_struct():
         out.append("    return r;")
         out.append("  }")
     product("mul(const Fq29 &a, const Fq29 &b)", [[("a.l[%d]" % i, "b.l[%d]" % (k - i)) for i in range(max(0, k - 8), min(k, 8) + 1)] for k in range(17)], [])
+    # a b + c d with ONE reduction (the two halves of an Fq2 product's component: a0 b0 + (-a1) b1, a0 b1 + a1 b0): 162 + 81 multiply-adds instead of 2 x 162.  Columns
+    # of up to 18 + 9 terms: every operand normalized (limbs below 2^29 + 8) except a and c, whose limbs may reach 2^30 + 8 (check_bounds_oct)
+    product("mul2(const Fq29 &a, const Fq29 &b, const Fq29 &c, const Fq29 &d)",
+            [[("a.l[%d]" % i, "b.l[%d]" % (k - i)) for i in range(max(0, k - 8), min(k, 8) + 1)] + [("c.l[%d]" % i, "d.l[%d]" % (k - i)) for i in range(max(0, k - 8), min(k, 8) + 1)] for k in range(17)], [])
     cols = [[] for _ in range(17)]
     for i in range(9):
         cols[2 * i].append(("a.l[%d]" % i, "a.l[%d]" % i))
@@ -259,6 +288,7 @@ def self_check():
     import random; rnd = random.Random(29); RPinv = pow(RP, -1, Q)
     mulcols = [[("a%d" % i, "b%d" % (k - i)) for i in range(max(0, k - 8), min(k, 8) + 1)] for k in range(17)]
     sqrcols = [[(x.replace("a.l[", "a").replace("]", ""), y.replace("a.l[", "a").replace("]", "")) for x, y in c] for c in cols]
+    mul2cols = [[("a%d" % i, "b%d" % (k - i)) for i in range(max(0, k - 8), min(k, 8) + 1)] + [("c%d" % i, "d%d" % (k - i)) for i in range(max(0, k - 8), min(k, 8) + 1)] for k in range(17)]
     def norm(l): return [l[0] & M] + [(l[i] & M) + (l[i - 1] >> B) for i in range(1, 8)] + [l[8] + (l[7] >> B)]
     for it in range(2000):
         # a: an un-normalized difference (limbs up to 2^31.4, value below 8p), b: normalized
@@ -269,6 +299,13 @@ def self_check():
         r = model_product(mulcols, env); assert all(x <= M for x in r[:8]) and val(r) % Q == val(a) * val(b) * RPinv % Q and val(r) < val(a) * val(b) // RP + Q + 1
         env = {"a%d" % i: b[i] for i in range(9)}; env.update({"d%d" % i: (b[i] << 1) & 0xffffffff for i in range(1, 9)})
         r = model_product(sqrcols, env); assert val(r) % Q == val(b) * val(b) * RPinv % Q
+        # the dual product a b + c d: a, c raw sums of two normalized values (limbs up to 2^30 + 8), b, d normalized; at its worst in the first iterations
+        wide = lambda: [x + y for x, y in zip(norm(limbs29(rnd.randrange(0, 6 * Q))), norm(limbs29(rnd.randrange(0, 6 * Q))))]
+        a2, c2 = wide(), wide(); b2, d2 = norm(limbs29(rnd.randrange(0, 8 * Q))), norm(limbs29(rnd.randrange(0, 8 * Q)))
+        if it < 50: a2 = [(1 << 30) + 8] * 8 + [a2[8]]; c2 = [(1 << 30) + 8] * 8 + [c2[8]]; b2 = [(1 << 29) + 7] * 8 + [b2[8]]; d2 = [(1 << 29) + 7] * 8 + [d2[8]]
+        env = {}
+        for nm, v in (("a", a2), ("b", b2), ("c", c2), ("d", d2)): env.update({"%s%d" % (nm, i): v[i] for i in range(9)})
+        r = model_product(mul2cols, env); tot = val(a2) * val(b2) + val(c2) * val(d2); assert all(x <= M for x in r[:8]) and val(r) % Q == tot * RPinv % Q and val(r) < tot // RP + Q + 1
         # difference + normalization
         if not KS:   # the light difference: a + KL_2 - t for a product's result t, then one carry step
             tv = rnd.randrange(0, 2 * Q); d = [x + k - y for x, k, y in zip(b, adjusted_light(2), limbs29(tv))]; assert all(0 <= x < 1 << 32 for x in d); n = norm(d); assert val(n) == val(b) + 2 * Q - tv and all(x < (1 << 29) + 8 for x in n[:8])
@@ -355,4 +392,4 @@ R_MOD = 218882428718392752222464057452572750885483644004160343436982041865758084
 Q_SAVE = Q; KS_SAVE = KS; Q = R_MOD; INV = (-pow(Q, -1, 1 << B)) % (1 << B); P29 = limbs29(Q); ONE29 = limbs29(RP % Q); RCONV = limbs29((1 << 256) % Q); KS = {}   # (no borrow-adjusted 2p, 4p, 6p with limbs in [3 * 2^29 + 64, 4 * 2^29) exist for r = 1 mod 2^28; the transforms only subtract products)
 FR_LINES = [l.replace("Fq29", "Fr29") for l in gen_struct()]; self_check()
 open(__file__.replace("gen_field29.py", "field29_gfx950.inc"), "w").write("\n".join(HEADER + FQ_LINES + FR_LINES) + "\n")
-print("bounds:", BOUNDS)
+print("bounds:", BOUNDS); print("bounds of the oct addition:", BOUNDS_OCT)

@@ -334,6 +334,7 @@ static Fe32 fe261(HFr v) {
 struct NttCall { Fe32 *data, *scratch; const Fe32 *tw, *tw261; int logn; const Fe32 *pre_scale, *pre261; Fe32 scale261; const Fe32 *post_scale;
     size_t stride, scratch_stride; const Fe32 *out261 = nullptr; };   // out261: two-pass range only (NttJob::out261)
 // radix-4 passes measured best with two vectors per launch (twice the waves of radix 8: the passes are latency bound), radix 8 with three
+static int ntt_prio_bits() { static const int v = [] { const char *e = getenv("ZK_NTT_PRIO"); const int x = e ? atoi(e) : 0; return (x < 0 ? 0 : x > 3 ? 3 : x) << 8; }(); return v; }
 static int ntt_radix_log() {
   static const int rl = [] {
     const char *e = getenv("ZK_NTT_RADIX_LOG");
@@ -385,8 +386,8 @@ static void ntt_two_pass_launch(const NttCall *calls, int n_calls, int batch) {
     lc = std::max(lc, ntt_lds_for(l1, c1));
     lr = std::max(lr, ntt_lds_for(l2, c2));
   }
-  hipLaunchKernelGGL(k_ntt_cols, dim3(cj[0].tiles + cj[1].tiles, batch), dim3(tc), lc, s, cj[0], cj[1], ntt_radix_log());
-  hipLaunchKernelGGL(k_ntt_rows, dim3(rj[0].tiles + rj[1].tiles, batch), dim3(tr), lr, s, rj[0], rj[1], ntt_radix_log());
+  hipLaunchKernelGGL(k_ntt_cols, dim3(cj[0].tiles + cj[1].tiles, batch), dim3(tc), lc, s, cj[0], cj[1], ntt_radix_log() | ntt_prio_bits());
+  hipLaunchKernelGGL(k_ntt_rows, dim3(rj[0].tiles + rj[1].tiles, batch), dim3(tr), lr, s, rj[0], rj[1], ntt_radix_log() | ntt_prio_bits());
 }
 static void radix2_transform(const NttCall &c, int batch) {
   hipStream_t s = gpu().stream;

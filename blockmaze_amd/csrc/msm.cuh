@@ -29,6 +29,7 @@
 #include "field29.cuh"
 namespace zk { struct MsmCounters { uint32_t n_ones; uint32_t n_other; uint32_t pad[2]; }; }
 #include "htail29.cuh"
+#include "oct29.cuh"
 namespace zk {
 
 constexpr int MSM_MAX_WINDOWS = 64;
@@ -1065,7 +1066,9 @@ __device__ __forceinline__ void g2_29_unpack(const Affine<Fq2> &p, bool neg, Fq2
 // proportional to the fill, the next WFUSED_ONES_LANES stride over the list of ones), from the tables with coordinates x 2^261 (points261 / groups261,
 // k_table_to_r261_g2 at key load). A lane's sum leaves the 29-bit domain when it is stored: eight products with 2^256 mod p give the lazy 8 x 32-bit form that
 // k_wacc_fold<Fq2> adds up.
-template <int UNIT>   // (a template only so that the one translation unit that launches it instantiates it)
+// REC29 (round 5): the sum stays on 29-bit limbs — a Point29Rec2 (oct29.cuh: eight slots, component-major) for k_wfold_g2_29; no conversion, and the degenerate
+// case (ZZ = 0 mod p) is left to the tail, where it arrives in at least one result: a product with ZZ = 0 stays 0.
+template <int REC29>
 __global__ void __launch_bounds__(256) k_wacc_lanes_g2_29(const Affine<Fq2> *__restrict__ points261, const Affine<Fq2> *__restrict__ groups261,
     const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap,
                                                           uint32_t NB, const uint32_t *__restrict__ ones, MsmCounters *cnt, XYZZ<Fq2> *__restrict__ partial,
@@ -1130,6 +1133,19 @@ __global__ void __launch_bounds__(256) k_wacc_lanes_g2_29(const Affine<Fq2> *__r
       }
       v = vn; p = pn;
     }
+  }
+  if constexpr (REC29 != 0) {
+    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<Point29Rec2 *>(partial) + t);
+    const uint32_t z = inf ? 0u : ~0u;
+    const Fq29 *slot[8] = {&acc.X.c0, &acc.Y.c0, &acc.ZZ.c0, &acc.ZZZ.c0, &acc.X.c1, &acc.Y.c1, &acc.ZZ.c1, &acc.ZZZ.c1};
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const Fq29 &v = *slot[e];
+      dst[3 * e] = make_uint4(v.l[0] & z, v.l[1] & z, v.l[2] & z, v.l[3] & z);
+      dst[3 * e + 1] = make_uint4(v.l[4] & z, v.l[5] & z, v.l[6] & z, v.l[7] & z);
+      dst[3 * e + 2] = make_uint4(v.l[8] & z, 0u, 0u, 0u);
+    }
+    return;
   }
   XYZZ<Fq2> o = XYZZ<Fq2>::inf();
   if (!inf) {

@@ -247,11 +247,11 @@ struct MsmImpl {
     }
     buckets = DevBuf<uint8_t>((size_t)WB * NB * sizeof(XYZZ<F>));
     partials = DevBuf<uint8_t>(std::max<size_t>(std::max<size_t>((size_t)max_tasks * sizeof(XYZZ<F>), hsort ? (size_t)NB * h_maxp * sizeof(Piece29) : 0),
-        wfused ? ((size_t)WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) * std::max(sizeof(XYZZ<F>), sizeof(Point29Rec)) : 0));
+        wfused ? ((size_t)WFUSED_BUCKET_LANES + WFUSED_ONES_LANES) * std::max(std::max(sizeof(XYZZ<F>), sizeof(Point29Rec)), sizeof(F) == 64 ? sizeof(Point29Rec2) : (size_t)0) : 0));
     seg_out = DevBuf<uint8_t>(std::max<size_t>((size_t)WB * (NB / seg), (size_t)32 * cdiv(NB, 512)) * sizeof(XYZZ<F>));
     seg_l2 = DevBuf<uint8_t>((size_t)WB * cdiv(NB / seg, GROUP) * sizeof(XYZZ<F>));
-    ones_partial = DevBuf<uint8_t>(std::max<size_t>(n_ones_quads, wfused ? (size_t)NB + WFUSED_ONES_GROUPS : 0) * std::max(sizeof(XYZZ<F>),
-        sizeof(Point29Rec)));
+    ones_partial = DevBuf<uint8_t>(std::max<size_t>(n_ones_quads, wfused ? (size_t)NB + WFUSED_ONES_GROUPS : 0) * std::max(std::max(sizeof(XYZZ<F>),
+        sizeof(Point29Rec)), sizeof(F) == 64 ? sizeof(Point29Rec2) : (size_t)0));
     if (wfused) lane_off = DevBuf<uint32_t>(WFUSED_MAX_BUCKETS + 1);
     ones_l2 = DevBuf<uint8_t>((size_t)cdiv(n_ones_quads, GROUP) * sizeof(XYZZ<F>));
     RS = WB; if (wfused) { bitsum = true; RS = WTAIL_SLOTS; }   // k_wtail leaves eight sums by weight bit
@@ -381,6 +381,22 @@ struct MsmImpl {
               (uint32_t)WFUSED_ONES_GROUPS, (uint32_t)WTAIL_SLOTS, (XYZZ<Fq> *)res, wc + w.parity, cdst);
         }
       } else {
+        // round 5: fold and tail on 29-bit limbs with the point spread over eight lanes (oct29.cuh); ZK_G2_OCT=0: the quad-cooperative kernels on 8 x 32-bit limbs
+        static const bool oct = [] { const char *e = getenv("ZK_G2_OCT"); return !e || atoi(e) != 0; }();
+        if (oct) {
+          Point29Rec2 *p1 = (Point29Rec2 *)partials.get(), *p2 = (Point29Rec2 *)ones_partial.get();
+          { Stage st((label + ".accumulate").c_str(), s);
+            hipLaunchKernelGGL(k_wacc_lanes_g2_29<1>, lanes_grid, dim3(256), 0, s, (const Affine<Fq2> *)bases->points261.get(),
+                (const Affine<Fq2> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, (XYZZ<Fq2> *)p1, lane_off.get());
+            hipLaunchKernelGGL(k_wfold_g2_29<0>, fold_grid, dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p1, (const uint32_t *)lane_off.get(), NB,
+                (uint32_t)WFUSED_BUCKET_LANES, p2);
+          }
+          { Stage st((label + ".reduce").c_str(), s);
+            hipLaunchKernelGGL(k_wtail_g2_29<0>, dim3(top + 2), dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p2, NB, (const Point29Rec2 *)p2 + NB,
+                (uint32_t)WFUSED_ONES_GROUPS, (uint32_t)WTAIL_SLOTS, (XYZZ<Fq2> *)res, wc + w.parity, cdst);
+          }
+          return;
+        }
         XYZZ<F> *l1 = (XYZZ<F> *)partials.get();
         { Stage st((label + ".accumulate").c_str(), s);
           hipLaunchKernelGGL(k_wacc_lanes_g2_29<0>, lanes_grid, dim3(256), 0, s, (const Affine<Fq2> *)bases->points261.get(),

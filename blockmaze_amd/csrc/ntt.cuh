@@ -149,6 +149,8 @@ struct NttJob {
   const Fr *out261;
 };
 __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(NttJob ja, NttJob jb, int radix_log) {
+  // (experiment switch ZK_NTT_PRIO: bits 8.. of radix_log = the wave priority of this kernel, s_setprio)
+  { const int prio = radix_log >> 8; radix_log &= 0xff; if (prio == 1) __builtin_amdgcn_s_setprio(1); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio == 3) __builtin_amdgcn_s_setprio(3); }
   extern __shared__ uint32_t lds_raw[]; Fr29 *tile = reinterpret_cast<Fr29 *>(lds_raw);
   const bool second = blockIdx.x >= ja.tiles; const NttJob j = second ? jb : ja;   // by value: uniform selects, a reference would put both jobs on the stack
   const uint32_t bid = blockIdx.x - (second ? ja.tiles : 0u);
@@ -180,6 +182,8 @@ __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(NttJob ja, NttJob
   }
 }
 __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_rows(NttJob ja, NttJob jb, int radix_log) {
+  // (experiment switch ZK_NTT_PRIO: bits 8.. of radix_log = the wave priority of this kernel, s_setprio)
+  { const int prio = radix_log >> 8; radix_log &= 0xff; if (prio == 1) __builtin_amdgcn_s_setprio(1); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio == 3) __builtin_amdgcn_s_setprio(3); }
   extern __shared__ uint32_t lds_raw[]; Fr29 *tile = reinterpret_cast<Fr29 *>(lds_raw);
   const bool second = blockIdx.x >= ja.tiles; const NttJob &j = second ? jb : ja; const uint32_t bid = blockIdx.x - (second ? ja.tiles : 0u);
   const int logn = j.logn, log_n1 = j.log_n1, logC = j.logC;

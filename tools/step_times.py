@@ -29,3 +29,4 @@ med = lambda k: sorted(d[k] for d in parts)[len(parts) // 2]
 print("  medians of the prover's own clocks: " + ", ".join("%s %.3f" % (k, med(k)) for k in ("upload_ms", "enqueue_ms", "device_ms", "finish_ms", "total_ms")) + "; cpus allowed %d; AnonHugePages of this process %s kB" % (len(os.sched_getaffinity(0)), next((l.split()[1] for l in open("/proc/self/smaps_rollup") if l.startswith("AnonHugePages")), "?")))
 slow = [(t, d) for t, d in zip(ts, parts) if t > 1.5 * pct(0.5)]
 if slow: print("  the slow steps' own clocks (step: upload / device / finish ms): " + "; ".join("%.2f: %.2f / %.2f / %.2f" % (t, d["upload_ms"], d["device_ms"], d["finish_ms"]) for t, d in slow[:12]))
+print("RESULT median_ms %.4f p10_ms %.4f device_ms %.4f upload_ms %.4f" % (pct(0.5), pct(0.1), med("device_ms"), med("upload_ms")))
