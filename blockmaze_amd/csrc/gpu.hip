@@ -334,7 +334,7 @@ static Fe32 fe261(HFr v) {
 struct NttCall { Fe32 *data, *scratch; const Fe32 *tw, *tw261; int logn; const Fe32 *pre_scale, *pre261; Fe32 scale261; const Fe32 *post_scale;
     size_t stride, scratch_stride; const Fe32 *out261 = nullptr; };   // out261: two-pass range only (NttJob::out261)
 // radix-4 passes measured best with two vectors per launch (twice the waves of radix 8: the passes are latency bound), radix 8 with three
-static int ntt_prio_bits() { static const int v = [] { const char *e = getenv("ZK_NTT_PRIO"); const int x = e ? atoi(e) : 0; return (x < 0 ? 0 : x > 3 ? 3 : x) << 8; }(); return v; }
+static int ntt_prio_bits() { static const int v = (int)(zk_prio_bits("ntt") >> 24) << 8; return v; }
 static int ntt_radix_log() {
   static const int rl = [] {
     const char *e = getenv("ZK_NTT_RADIX_LOG");
@@ -431,6 +431,7 @@ static void radix2_transform_pair(const NttCall &a, const NttCall &b, int batch)
 // multiplication)
 __global__ void k_step_fwd_pre(Fr *a_all, Fr *__restrict__ dbuf_all, const Fr *__restrict__ wpow, const Fr *__restrict__ cf, uint32_t B, uint32_t S,
     size_t stride) {
+  zk_take_prio(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   Fr *a = a_all + blockIdx.y * stride, *dbuf = dbuf_all + (size_t)blockIdx.y * B;
@@ -439,6 +440,7 @@ __global__ void k_step_fwd_pre(Fr *a_all, Fr *__restrict__ dbuf_all, const Fr *_
   if (i < S) { Fr y = a[i + B]; if (cf) y = y * cf[i + B]; a[i] = x + y; dbuf[i] = wpow[i] * (x - y); } else { if (cf) a[i] = x; dbuf[i] = wpow[i] * x; }
 }
 __global__ void k_step_fold(const Fr *__restrict__ dbuf_all, Fr *__restrict__ a_all, uint32_t B, uint32_t S, size_t stride) {   // e overwrites a[B..B+S)
+  zk_take_prio(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= S) return;
   const Fr *dbuf = dbuf_all + (size_t)blockIdx.y * B;
@@ -450,6 +452,7 @@ __global__ void k_step_fold(const Fr *__restrict__ dbuf_all, Fr *__restrict__ a_
 //   tmp[i] = U0[i]*w^i ; U1[i] -= sum_{j>=1} tmp[i + j*S] ; U1[i] *= w^-i ; a[i] = (U0[i]+U1[i])/2 (i<S) ; a[B+i] = (U0[i]-U1[i])/2 ; a[i] = U0[i] (S<=i<B)
 // In place on a = [U0 (B) | U1 (S)]: thread i < S reads U0[i], U0[i + kS], U1[i] and writes a[i], a[B+i]; entries a[S..B) = U0[S..B) stay as they are.
 __global__ void k_step_inv_post(Fr *a_all, const Fr *__restrict__ wpow, const Fr *__restrict__ winvpow, Fr half, uint32_t B, uint32_t S, size_t stride) {
+  zk_take_prio(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= S) return; Fr *a = a_all + blockIdx.y * stride;
   Fr u1 = a[B + i]; for (uint32_t j = i + S; j < B; j += S) u1 = u1 - a[j] * wpow[j];
   u1 = u1 * winvpow[i]; Fr u0 = a[i]; a[i] = (u0 + u1) * half; a[B + i] = (u0 - u1) * half;
@@ -460,6 +463,7 @@ __global__ void k_step_inv_post(Fr *a_all, const Fr *__restrict__ wpow, const Fr
 // instead of three (k_step_inv_post, k_step_fwd_pre with the coset factors, k_step_fold) and one launch instead of three
 __global__ void k_step_inv_fwd(Fr *a_all, const Fr *__restrict__ wpow, const Fr *__restrict__ winvpow, Fr half, const Fr *__restrict__ cf, uint32_t B,
     uint32_t S, size_t stride) {
+  zk_take_prio(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= S) return; Fr *a = a_all + blockIdx.y * stride;
   Fr u1 = a[B + i]; for (uint32_t j = i + S; j < B; j += S) u1 = u1 - a[j] * wpow[j];
   // the inverse transform's a[i], a[B + i]; a[S..B) are final as they are
@@ -589,8 +593,8 @@ void Domain::fft_with_factors(Fe32 *data, int batch, size_t stride, const Fe32 *
   // scratch: 3B]
   hipStream_t s = gpu().stream; Fe32 *dbuf = d.scratch.get(), *tmp = d.scratch.get() + 3 * d.B;
   hipLaunchKernelGGL(k_step_fwd_pre, dim3(cdiv(d.B, 256), batch), dim3(256), 0, s, (Fr *)data, (Fr *)dbuf, (const Fr *)d.wpow.get(), (const Fr *)cf,
-      (uint32_t)d.B, (uint32_t)d.S, stride);
-  hipLaunchKernelGGL(k_step_fold, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (const Fr *)dbuf, (Fr *)data, (uint32_t)d.B, (uint32_t)d.S, stride);
+      (uint32_t)d.B, (uint32_t)d.S | zk_prio_bits("step"), stride);
+  hipLaunchKernelGGL(k_step_fold, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (const Fr *)dbuf, (Fr *)data, (uint32_t)d.B, (uint32_t)d.S | zk_prio_bits("step"), stride);
   // (dbuf is free again after the fold: the S-point transform's scratch)
   radix2_transform_pair(NttCall{data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B},
       NttCall{data + d.B, dbuf, d.small->tw.get(), d.small->tw261.get(), d.small->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, batch);
@@ -610,7 +614,7 @@ void Domain::ifft(Fe32 *data, int batch, size_t stride) {
       stride, d.B}, batch);
   Fr half; memcpy(&half, d.half.l, 32);
   hipLaunchKernelGGL(k_step_inv_post, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half,
-      (uint32_t)d.B, (uint32_t)d.S, stride);
+      (uint32_t)d.B, (uint32_t)d.S | zk_prio_bits("step"), stride);
 }
 void Domain::ifft_then_coset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl;
@@ -636,7 +640,7 @@ void Domain::ifft_then_coset_fft(Fe32 *data, int batch, size_t stride) {
         d.B}, NttCall{data + d.B, dbuf, d.small->itw.get(), d.small->itw261.get(), d.small->logn, d.scale_small.get(), nullptr, d.inv_small261, nullptr,
         stride, d.B}, batch);
     hipLaunchKernelGGL(k_step_inv_fwd, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half,
-        (const Fr *)d.coset_fwd.get(), (uint32_t)d.B, (uint32_t)d.S, stride);
+        (const Fr *)d.coset_fwd.get(), (uint32_t)d.B, (uint32_t)d.S | zk_prio_bits("step"), stride);
   }
   { Stage st("ntt.forward");
     radix2_transform_pair(NttCall{data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B},
@@ -786,7 +790,7 @@ void expand_witness_dev(const uint8_t *packed, size_t words, const Fe32 &one_val
   const uint32_t *off = (const uint32_t *)(ones + nbm * words); const Fr *vals = (const Fr *)(packed + expand_values_offset(words, canon));
   Fr one; memcpy(&one, &one_value, 32);
   hipLaunchKernelGGL(k_expand_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, ones, other,
-      canon == 0 ? (const uint64_t *)nullptr : canon == 1 ? other : third, off, vals, one, (uint32_t)n, (Fr *)out, tags, other_vars);
+      canon == 0 ? (const uint64_t *)nullptr : canon == 1 ? other : third, off, vals, one, (uint32_t)n | zk_prio_bits("expand"), (Fr *)out, tags, other_vars);
 }
 void fr_to_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_to_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
 void fr_from_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_from_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
@@ -864,7 +868,7 @@ void R1csDev::eval(const Fe32 *z, Fe32 *abc, size_t m, const uint8_t *tags, bool
   if (tags) {   // the assignment came in compact form: a byte per variable says 0 / 1 / other (k_r1cs_rows_tagged)
     const uint32_t sb = (uint32_t)cdiv(m, 256);
     hipLaunchKernelGGL(k_r1cs_rows_tagged, dim3(sb + (unsigned)cdiv(d.n_long_any, 4)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z, tags,
-        (uint32_t)d.n_cons, (uint32_t)d.n_inputs, (uint32_t)m,
+        (uint32_t)d.n_cons, (uint32_t)d.n_inputs | zk_prio_bits("rows"), (uint32_t)m,
                        (const uint32_t *)d.long_any.get(), (uint32_t)d.n_long_any, sb, write_c ? 1 : 0, (Fr *)abc, d.seq, d.d_fail);
     return; }
   // rows of more than 16 terms exist: the one-launch form (short rows and one wave per long row) const uint32_t sb = (uint32_t)cdiv(m, 256);

@@ -10,6 +10,24 @@
 #include "msm.cuh"
 
 namespace zk {
+// Wave priorities (round 5).  A proof is one VALU-saturating kernel (the H accumulation: four waves a SIMD, 52 % of the proof's instructions) and two dozen short
+// dependent chains: the transforms and the other kernels of the critical chain, and the four witness MSMs beside them.  Whichever wave of a SIMD is oldest issues next,
+// so the chains used to wait for each other and for the accumulation at random: the transforms took 222-244 us beside the witness MSMs against 148 us alone.  With
+// s_setprio the order is explicit — chain kernels 3, witness MSMs 2, H accumulation 0: the chain runs at its stand-alone speed, the witness MSMs take the slots it
+// leaves and still finish before the accumulation needs the whole chip (device side of a send proof 0.812 -> 0.765 ms; every other ranking tried is slower:
+// profiles/r05_priorities.txt).  ZK_PRIO="family:level,..." overrides single families (ntt, rows, hsort, htail, step, expand, wit, wlanes, hacc; 0 = the hardware's
+// default for everything: ZK_PRIO=off).  The level travels in bits 24.. of a small integer argument (field29.cuh: zk_take_prio).
+inline uint32_t zk_prio_bits(const char *family) {
+  static const std::string s = [] { const char *e = getenv("ZK_PRIO"); return std::string(e ? e : ""); }();
+  static const char *defaults = "ntt:3,rows:3,hsort:3,htail:3,step:3,expand:3,wit:2,wlanes:2,hacc:0";
+  if (s == "off") return 0;
+  const std::string key = std::string(family) + ":";
+  for (const std::string &src : {s, std::string(defaults)}) {
+    const size_t at = src.find(key);
+    if (at != std::string::npos && (at == 0 || src[at - 1] == ',')) { const int v = atoi(src.c_str() + at + key.size()); return (uint32_t)(v < 0 ? 0 : v > 3 ? 3 : v) << 24; }
+  }
+  return 0;
+}
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw GpuError(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 class GpuContext {
  public:

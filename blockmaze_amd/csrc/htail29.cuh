@@ -162,6 +162,7 @@ __host__ __device__ inline uint32_t htail_marg_blocks(const HtailShape &s) { ret
 // then the tree.
 template <int UNIT>   // (a template only so that the one translation unit that launches it instantiates it)
 __global__ void __launch_bounds__(256) k_hmarg29(const Point29Rec *__restrict__ buckets, uint32_t NB, Point29Rec *__restrict__ marg) {
+  zk_take_prio(NB);
   __shared__ Point29Rec lds[4];
   const HtailShape sh = htail_shape(NB);
   const uint32_t L = 1u << sh.lo_bits, H = 1u << sh.hi_bits, RC = sh.row_chunks, g = blockIdx.x, q = threadIdx.x >> 2;
@@ -193,6 +194,7 @@ __global__ void __launch_bounds__(256) k_hmarg29(const Point29Rec *__restrict__ 
 template <int UNIT>
 __global__ void __launch_bounds__(256) k_hbits29(const Point29Rec *__restrict__ marg, uint32_t NB, XYZZ<Fq> *__restrict__ res, MsmCounters *cnt,
     uint4 *copy_dst) {
+  zk_take_prio(NB);
   __shared__ Point29Rec lds[4];
   const HtailShape sh = htail_shape(NB);
   const uint32_t L = 1u << sh.lo_bits, H = 1u << sh.hi_bits, s_ = blockIdx.x, q = threadIdx.x >> 2;
@@ -247,6 +249,7 @@ template <int UNIT>
 __global__ void __launch_bounds__(256) k_hacc_combine29q(const uint32_t *__restrict__ partials /* Piece29 records of 36 words */, const uint32_t *__restrict__ offsets,
     const uint32_t *__restrict__ counts, uint32_t low_bits, uint32_t region, uint32_t run, uint32_t maxp, uint32_t n_buckets, uint32_t lq,
     Point29Rec *__restrict__ buckets29, MsmCounters *cnt) {
+  zk_take_prio(lq);
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, qd = t >> 2, b = qd >> lq, sub = qd & ((1u << lq) - 1), step = 1u << lq;
   const int k = threadIdx.x & 3;
   const bool live = b < n_buckets;
@@ -308,6 +311,7 @@ __device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq>
 template <int UNIT>
 __global__ void __launch_bounds__(256) k_wfold29(const Point29Rec *__restrict__ partial, const uint32_t *__restrict__ lane_off, uint32_t NB,
     uint32_t bucket_lanes, Point29Rec *__restrict__ out) {
+  zk_take_prio(NB);
   __shared__ Point29Rec lds[4];
   const uint32_t b = blockIdx.x, q = threadIdx.x >> 2;
   const int k = threadIdx.x & 3;
@@ -326,6 +330,7 @@ template <int UNIT>
 __global__ void __launch_bounds__(256) k_wtail29(const Point29Rec *__restrict__ buckets, uint32_t NB, const Point29Rec *__restrict__ ones_partial,
     uint32_t n_ones_partial, uint32_t slots, XYZZ<Fq> *__restrict__ res,
                                                  MsmCounters *cnt, uint4 *copy_dst) {
+  zk_take_prio(NB);
   __shared__ Point29Rec lds[4];
   const uint32_t q = threadIdx.x >> 2, s_ = blockIdx.x, half = NB >> 1;
   uint32_t top = 0;

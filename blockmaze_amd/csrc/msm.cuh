@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(HSORT_BIN_THREADS) k_hsort_bin(const Fr *__res
                                                                  uint32_t n, int c, int W, uint32_t point_stride, HsortShape sh,
                                                                      uint32_t *__restrict__ group_fill, uint32_t *__restrict__ mid, MsmCounters *cnt,
                                                                      MsmCounters *cnt_next) {
+  zk_take_prio(sh.low_bits);
   __shared__ uint32_t lcnt[HSORT_GROUPS], lpos[HSORT_GROUPS], gbase[HSORT_GROUPS];
   __shared__ uint32_t stage[HSORT_TILE * HSORT_STAGE_W];
   __shared__ uint16_t stage_g[HSORT_TILE * HSORT_STAGE_W];
@@ -221,6 +222,7 @@ __global__ void __launch_bounds__(HSORT_BIN_THREADS) k_hsort_bin(const Fr *__res
 static __global__ void __launch_bounds__(HSORT_GROUP_THREADS) k_hsort_group(const uint32_t *__restrict__ mid, uint32_t *__restrict__ group_fill, HsortShape sh,
     uint32_t *__restrict__ entries, uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets,
                                                                             uint32_t *__restrict__ group_n) {   // group_n[g] = entries of group g
+  zk_take_prio(sh.low_bits);
   __shared__ uint32_t lcnt[1024], lpre[1024];                        // 2^low_bits <= 1024 buckets per group
   const uint32_t g = blockIdx.x, nb = 1u << sh.low_bits, n_g = min(group_fill[g], sh.region); const uint32_t *src = mid + (size_t)g * sh.region;
   for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lcnt[b] = 0;
@@ -524,6 +526,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 k_hacc_runs29(const Affine<Fq> *__restrict__ points261, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ group_n,
     const uint32_t *__restrict__ offsets, HsortShape sh, uint32_t run, uint32_t maxp,
               Piece29 *__restrict__ partials, MsmCounters *cnt) {
+  zk_take_prio(maxp);
   // which run is this lane's?  base[g] = the number of runs in the groups before g: an exclusive scan of ceil(n_g / run), recomputed by every workgroup
   __shared__ uint32_t base[HSORT_GROUPS + 1], wave_tot[4];
   {
@@ -939,6 +942,7 @@ __global__ void __launch_bounds__(256) k_wacc_lanes29(const Affine<Fq> *__restri
     const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap, uint32_t NB,
                                                       const uint32_t *__restrict__ ones, const MsmCounters *cnt, Point29Rec *__restrict__ partial,
                                                           uint32_t *__restrict__ lane_off) {
+  zk_take_prio(NB);
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ uint32_t m_of[WFUSED_MAX_BUCKETS], off[WFUSED_MAX_BUCKETS + 1], slice;
   const bool ones_lane = t >= WFUSED_BUCKET_LANES;                                       // (whole workgroups: 4096 is a multiple of 256)
@@ -1073,6 +1077,7 @@ __global__ void __launch_bounds__(256) k_wacc_lanes_g2_29(const Affine<Fq2> *__r
     const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap,
                                                           uint32_t NB, const uint32_t *__restrict__ ones, MsmCounters *cnt, XYZZ<Fq2> *__restrict__ partial,
                                                               uint32_t *__restrict__ lane_off) {
+  zk_take_prio(NB);
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ uint32_t m_of[WFUSED_MAX_BUCKETS], off[WFUSED_MAX_BUCKETS + 1], slice;
   const bool ones_lane = t >= WFUSED_BUCKET_LANES;                                       // (whole workgroups: 4096 is a multiple of 256)

@@ -372,12 +372,12 @@ struct MsmImpl {
         Point29Rec *p1 = (Point29Rec *)partials.get(), *p2 = (Point29Rec *)ones_partial.get();
         { Stage st((label + ".accumulate").c_str(), s);
           hipLaunchKernelGGL(k_wacc_lanes29<0>, lanes_grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(),
-              (const Affine<Fq> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, p1, lane_off.get());
-          hipLaunchKernelGGL(k_wfold29<0>, fold_grid, dim3(256), 0, s, (const Point29Rec *)p1, (const uint32_t *)lane_off.get(), NB,
+              (const Affine<Fq> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB | zk_prio_bits("wlanes"), w.ones.get(), wc + w.parity, p1, lane_off.get());
+          hipLaunchKernelGGL(k_wfold29<0>, fold_grid, dim3(256), 0, s, (const Point29Rec *)p1, (const uint32_t *)lane_off.get(), NB | zk_prio_bits("wit"),
               (uint32_t)WFUSED_BUCKET_LANES, p2);
         }
         { Stage st((label + ".reduce").c_str(), s);
-          hipLaunchKernelGGL(k_wtail29<0>, dim3(top + 2), dim3(256), 0, s, (const Point29Rec *)p2, NB, (const Point29Rec *)p2 + NB,
+          hipLaunchKernelGGL(k_wtail29<0>, dim3(top + 2), dim3(256), 0, s, (const Point29Rec *)p2, NB | zk_prio_bits("wit"), (const Point29Rec *)p2 + NB,
               (uint32_t)WFUSED_ONES_GROUPS, (uint32_t)WTAIL_SLOTS, (XYZZ<Fq> *)res, wc + w.parity, cdst);
         }
       } else {
@@ -387,12 +387,12 @@ struct MsmImpl {
           Point29Rec2 *p1 = (Point29Rec2 *)partials.get(), *p2 = (Point29Rec2 *)ones_partial.get();
           { Stage st((label + ".accumulate").c_str(), s);
             hipLaunchKernelGGL(k_wacc_lanes_g2_29<1>, lanes_grid, dim3(256), 0, s, (const Affine<Fq2> *)bases->points261.get(),
-                (const Affine<Fq2> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, (XYZZ<Fq2> *)p1, lane_off.get());
-            hipLaunchKernelGGL(k_wfold_g2_29<0>, fold_grid, dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p1, (const uint32_t *)lane_off.get(), NB,
+                (const Affine<Fq2> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB | zk_prio_bits("wlanes"), w.ones.get(), wc + w.parity, (XYZZ<Fq2> *)p1, lane_off.get());
+            hipLaunchKernelGGL(k_wfold_g2_29<0>, fold_grid, dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p1, (const uint32_t *)lane_off.get(), NB | zk_prio_bits("wit"),
                 (uint32_t)WFUSED_BUCKET_LANES, p2);
           }
           { Stage st((label + ".reduce").c_str(), s);
-            hipLaunchKernelGGL(k_wtail_g2_29<0>, dim3(top + 2), dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p2, NB, (const Point29Rec2 *)p2 + NB,
+            hipLaunchKernelGGL(k_wtail_g2_29<0>, dim3(top + 2), dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p2, NB | zk_prio_bits("wit"), (const Point29Rec2 *)p2 + NB,
                 (uint32_t)WFUSED_ONES_GROUPS, (uint32_t)WTAIL_SLOTS, (XYZZ<Fq2> *)res, wc + w.parity, cdst);
           }
           return;
@@ -414,10 +414,11 @@ struct MsmImpl {
     if (hs_run) {
       if constexpr (sizeof(F) == 32) {
       { Stage st((label + ".sort").c_str(), s);
-#define ZK_CALL(CC) hipLaunchKernelGGL(k_hsort_bin<CC>, dim3(cdiv(n, HSORT_TILE)), dim3(HSORT_BIN_THREADS), 0, s, (const Fr *)scalars, (const Fr *)prod_b, (const Fr *)prod_z, (int)prod_z_table, infp, (uint32_t)n, c, W, point_stride, hs, group_fill.get(), mid.get(), cnt, counters_next())
+        HsortShape hs_prio = hs; hs_prio.low_bits |= zk_prio_bits("hsort");
+#define ZK_CALL(CC) hipLaunchKernelGGL(k_hsort_bin<CC>, dim3(cdiv(n, HSORT_TILE)), dim3(HSORT_BIN_THREADS), 0, s, (const Fr *)scalars, (const Fr *)prod_b, (const Fr *)prod_z, (int)prod_z_table, infp, (uint32_t)n, c, W, point_stride, hs_prio, group_fill.get(), mid.get(), cnt, counters_next())
         ZK_MSM_DISPATCH_C(c, ZK_CALL);
 #undef ZK_CALL
-        hipLaunchKernelGGL(k_hsort_group, dim3(hs.groups), dim3(HSORT_GROUP_THREADS), 0, s, (const uint32_t *)mid.get(), group_fill.get(), hs, entries.get(),
+        hipLaunchKernelGGL(k_hsort_group, dim3(hs.groups), dim3(HSORT_GROUP_THREADS), 0, s, (const uint32_t *)mid.get(), group_fill.get(), hs_prio, entries.get(),
             hist(), offsets.get(), group_n.get());
       }
       // one lane per run: at most ceil(entries / run) + one short run per group
@@ -427,12 +428,12 @@ struct MsmImpl {
         // (experiment switch: unused dynamic LDS caps the workgroups per compute unit — 160 KB a CU: 41 KB -> 3 waves per SIMD, 54 KB -> 2)
         static const unsigned h_lds = [] { const char *e = getenv("ZK_HACC_DYNLDS_KB"); return e ? (unsigned)atoi(e) * 1024u : 0u; }();
         if (h_lds) hipLaunchKernelGGL(k_hacc_runs29<1>, grid, dim3(256), h_lds, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(),
-            offsets.get(), hs, h_run, h_maxp, (Piece29 *)partials.get(), cnt);
+            offsets.get(), hs, h_run, h_maxp | zk_prio_bits("hacc"), (Piece29 *)partials.get(), cnt);
         else
         if (any_inf) hipLaunchKernelGGL(k_hacc_runs29<1>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(),
-            offsets.get(), hs, h_run, h_maxp, (Piece29 *)partials.get(), cnt);
+            offsets.get(), hs, h_run, h_maxp | zk_prio_bits("hacc"), (Piece29 *)partials.get(), cnt);
         else hipLaunchKernelGGL(k_hacc_runs29<0>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(),
-            offsets.get(), hs, h_run, h_maxp, (Piece29 *)partials.get(), cnt);
+            offsets.get(), hs, h_run, h_maxp | zk_prio_bits("hacc"), (Piece29 *)partials.get(), cnt);
       }
       // 2 / 4 / 8 lanes per bucket: about six pieces a lane (send: 12 pieces, two lanes; deposit at depth 32: 48 pieces — two lanes took 256 us there)
       {
@@ -445,7 +446,7 @@ struct MsmImpl {
         if (htail29 && hq != 0) {
           const uint32_t lq = hq > 0 ? (uint32_t)(hq - 1) : pieces > 40 ? 2 : pieces > 18 ? 1 : 0;
           hipLaunchKernelGGL(k_hacc_combine29q<0>, dim3(cdiv((nbk << lq) * 4, 256)), dim3(256), 0, s, (const uint32_t *)partials.get(), offsets.get(), hist(), hs.low_bits,
-              hs.region, h_run, h_maxp, (uint32_t)nbk, lq, (Point29Rec *)hb29.get(), cnt);
+              hs.region, h_run, h_maxp, (uint32_t)nbk, lq | zk_prio_bits("htail"), (Point29Rec *)hb29.get(), cnt);
         } else
         hipLaunchKernelGGL(k_hacc_combine29, dim3(cdiv(nbk << ll, 256)), dim3(256), 0, s, (const Piece29 *)partials.get(), offsets.get(), hist(), hs, h_run,
             h_maxp, (uint32_t)nbk, ll, (XYZZ<Fq> *)bucket_array(), htail29 ? (Point29Rec *)hb29.get() : nullptr, cnt);
@@ -494,8 +495,8 @@ struct MsmImpl {
       if constexpr (sizeof(F) == 32) {
         Stage st_red((label + ".reduce").c_str(), s);
       const HtailShape ts = htail_shape(NB);
-      hipLaunchKernelGGL(k_hmarg29<0>, dim3(htail_marg_blocks(ts)), dim3(256), 0, s, (const Point29Rec *)hb29.get(), NB, (Point29Rec *)hmarg.get());
-      hipLaunchKernelGGL(k_hbits29<0>, dim3(ts.top + 1), dim3(256), 0, s, (const Point29Rec *)hmarg.get(), NB, (XYZZ<Fq> *)res, cnt, (uint4 *)(res + RS + 1));
+      hipLaunchKernelGGL(k_hmarg29<0>, dim3(htail_marg_blocks(ts)), dim3(256), 0, s, (const Point29Rec *)hb29.get(), NB | zk_prio_bits("htail"), (Point29Rec *)hmarg.get());
+      hipLaunchKernelGGL(k_hbits29<0>, dim3(ts.top + 1), dim3(256), 0, s, (const Point29Rec *)hmarg.get(), NB | zk_prio_bits("htail"), (XYZZ<Fq> *)res, cnt, (uint4 *)(res + RS + 1));
     }
   }
     else { Stage st_red((label + ".reduce").c_str(), s);

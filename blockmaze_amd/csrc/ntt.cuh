@@ -149,7 +149,7 @@ struct NttJob {
   const Fr *out261;
 };
 __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(NttJob ja, NttJob jb, int radix_log) {
-  // (experiment switch ZK_NTT_PRIO: bits 8.. of radix_log = the wave priority of this kernel, s_setprio)
+  // (bits 8.. of radix_log: the kernel's wave priority, gpu_internal.hpp: zk_prio_bits)
   { const int prio = radix_log >> 8; radix_log &= 0xff; if (prio == 1) __builtin_amdgcn_s_setprio(1); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio == 3) __builtin_amdgcn_s_setprio(3); }
   extern __shared__ uint32_t lds_raw[]; Fr29 *tile = reinterpret_cast<Fr29 *>(lds_raw);
   const bool second = blockIdx.x >= ja.tiles; const NttJob j = second ? jb : ja;   // by value: uniform selects, a reference would put both jobs on the stack
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_cols(NttJob ja, NttJob
   }
 }
 __global__ void __launch_bounds__(NTT_TILE_THREADS) k_ntt_rows(NttJob ja, NttJob jb, int radix_log) {
-  // (experiment switch ZK_NTT_PRIO: bits 8.. of radix_log = the wave priority of this kernel, s_setprio)
+  // (bits 8.. of radix_log: the kernel's wave priority, gpu_internal.hpp: zk_prio_bits)
   { const int prio = radix_log >> 8; radix_log &= 0xff; if (prio == 1) __builtin_amdgcn_s_setprio(1); else if (prio == 2) __builtin_amdgcn_s_setprio(2); else if (prio == 3) __builtin_amdgcn_s_setprio(3); }
   extern __shared__ uint32_t lds_raw[]; Fr29 *tile = reinterpret_cast<Fr29 *>(lds_raw);
   const bool second = blockIdx.x >= ja.tiles; const NttJob &j = second ? jb : ja; const uint32_t bid = blockIdx.x - (second ? ja.tiles : 0u);
@@ -289,6 +289,7 @@ constexpr uint8_t ZTAG_ZERO = 0, ZTAG_ONE = 1, ZTAG_OTHER = 2;
 __global__ void k_expand_witness(const uint64_t *__restrict__ ones_bm, const uint64_t *__restrict__ other_bm, const uint64_t *__restrict__ canon_bm,
     const uint32_t *__restrict__ block_off, const Fr *__restrict__ values, Fr one_value, uint32_t n,
                                  Fr *__restrict__ out, uint8_t *__restrict__ tags, uint32_t *__restrict__ other_vars) {
+  zk_take_prio(n);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; const uint32_t wd = i >> 6, bit = i & 63; const uint64_t ob = other_bm[wd];
   // (a canonical assignment: only these 3 % need the conversion, one_value is the Montgomery one)
   if ((ob >> bit) & 1) {
@@ -401,6 +402,7 @@ __global__ void __launch_bounds__(256) k_r1cs_rows_tagged(R1csMatrices M, const 
     const uint8_t *__restrict__ tags, uint32_t n_rows, uint32_t n_inputs, uint32_t m,
                                                           const uint32_t *__restrict__ long_rows, uint32_t n_long, uint32_t short_blocks, int write_c,
                                                               Fr *__restrict__ abc, uint32_t seq, uint32_t *fail) {
+  zk_take_prio(n_inputs);
   if (blockIdx.x < short_blocks) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m) return;

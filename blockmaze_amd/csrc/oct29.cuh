@@ -158,6 +158,7 @@ constexpr uint32_t OCT_BLOCK = 512;                                             
 template <int UNIT>
 __global__ void __launch_bounds__(OCT_BLOCK) k_wfold_g2_29(const Point29Rec2 *__restrict__ partial, const uint32_t *__restrict__ lane_off, uint32_t NB,
     uint32_t bucket_lanes, Point29Rec2 *__restrict__ out) {
+  zk_take_prio(NB);
   __shared__ Point29Rec2 lds[OCT_BLOCK / 64];
   const uint32_t b = blockIdx.x, q = threadIdx.x >> 3, nq = OCT_BLOCK / 8;
   const int e = threadIdx.x & 7, k = e & 3; const bool h0 = e < 4;
@@ -177,6 +178,7 @@ __global__ void __launch_bounds__(OCT_BLOCK) k_wfold_g2_29(const Point29Rec2 *__
 template <int UNIT>
 __global__ void __launch_bounds__(OCT_BLOCK) k_wtail_g2_29(const Point29Rec2 *__restrict__ buckets, uint32_t NB, const Point29Rec2 *__restrict__ ones_partial,
     uint32_t n_ones_partial, uint32_t slots, XYZZ<Fq2> *__restrict__ res, MsmCounters *cnt, uint4 *copy_dst) {
+  zk_take_prio(NB);
   __shared__ Point29Rec2 lds[OCT_BLOCK / 64];
   const uint32_t q = threadIdx.x >> 3, nq = OCT_BLOCK / 8, s_ = blockIdx.x, half = NB >> 1;
   uint32_t top = 0;
