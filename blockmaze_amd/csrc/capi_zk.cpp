@@ -818,6 +818,13 @@ int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t
     if (!h) return ZKGPU_ERR_ARG; Proof p;
   if (!h->p->prove_resident((const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system");
       return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
+int zkgpu_prover_stash_witness(zkgpu_prover *h, uint32_t *slot) {
+  return guarded_prover(h, [&] { if (!h || !slot) return ZKGPU_ERR_ARG; *slot = (uint32_t)h->p->stash_witness(); return ZKGPU_OK; });
+}
+int zkgpu_prover_prove_stashed(zkgpu_prover *h, uint32_t slot, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_prover(h, [&] {
+    if (!h) return ZKGPU_ERR_ARG; Proof p;
+  if (!h->p->prove_stashed(slot, (const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system");
+      return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
 int zkgpu_prover_timings(zkgpu_prover *h, double out[5]) {
   if (!h) return ZKGPU_ERR_ARG;
   out[0] = h->p->last.upload_ms;

@@ -262,6 +262,7 @@ template <class T> PinnedBuf<T>::~PinnedBuf() { release(); }
 template <class T> void PinnedBuf<T>::release() { if (p_) hipHostFree(p_); p_ = nullptr; n_ = 0; }
 template class PinnedBuf<Fe32>;
 void upload_async(void *dev, const void *host, size_t bytes) { HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, gpu().stream)); }
+void copy_dev_async(void *dst, const void *src, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, gpu().stream)); }
 
 
 // ======================================================================================================================

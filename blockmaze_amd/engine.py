@@ -137,6 +137,12 @@ class Prover:
     def prove_resident(self, r=None, s=None):
         R = int(r).to_bytes(32, "little") if r is not None else None; S = int(s).to_bytes(32, "little") if s is not None else None
         out = ctypes.create_string_buffer(513); _check(lib().zkgpu_prover_prove_resident(ctypes.c_void_p(self.h), R, S, out)); return out.value.decode()
+    def stash_witness(self):
+        """keep the assignment handed over last in HBM; returns its slot"""
+        slot = ctypes.c_uint32(0); _check(lib().zkgpu_prover_stash_witness(ctypes.c_void_p(self.h), ctypes.byref(slot))); return int(slot.value)
+    def prove_stashed(self, slot, r=None, s=None):
+        R = int(r).to_bytes(32, "little") if r is not None else None; S = int(s).to_bytes(32, "little") if s is not None else None
+        out = ctypes.create_string_buffer(513); _check(lib().zkgpu_prover_prove_stashed(ctypes.c_void_p(self.h), ctypes.c_uint32(slot), R, S, out)); return out.value.decode()
     def prove_partial(self):
         """this shard's 384-byte record of partial sums (device pipeline on the resident witness)"""
         out = ctypes.create_string_buffer(384); _check(lib().zkgpu_prover_prove_partial(ctypes.c_void_p(self.h), out)); return out.raw

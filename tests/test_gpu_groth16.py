@@ -433,6 +433,19 @@ def test_verify_batch_symbol_mixed_block(all_keys, monkeypatch, tmp_path):
     rc, ok = zk.VerifyBatch(items); assert ok == exp and rc == sum(exp)
     singles = [zk.VerifySendProof(p, *a) for k, p, a, v in items[:40]]; assert singles == exp[:40]
 
+def test_inputs_resident_in_hbm_give_the_same_proofs(golden_dir):
+    """zkgpu_prover_stash_witness / zkgpu_prover_prove_stashed (what bench.py's timed region calls: the statements of a run handed over before the clock starts and kept in
+    device memory): several assignments stashed, proved in another order and more than once — the bytes of zkgpu_prover_prove on the same (z, r, s), i.e. the reference
+    prover's; an unknown slot is an error, an unsatisfying stashed assignment is reported like an unsatisfying host buffer"""
+    d = os.path.join(golden_dir, "groth16_small"); meta = json.load(open(os.path.join(d, "meta.json"))); z = o.load_witness(os.path.join(d, "wit.bin")); r, s = int(meta["r"], 16), int(meta["s"], 16)
+    cs = o.R1CS.load(os.path.join(d, "r1cs.bin")); p = e.Prover(os.path.join(d, "pk.txt")); bad = z.copy(); bad[5] = o.to_arr([12345])[0]; assert not o.r1cs_is_satisfied(cs, bad)
+    p.set_witness(z); s0 = p.stash_witness(); p.set_witness(bad); s1 = p.stash_witness(); p.set_witness(z); s2 = p.stash_witness(); assert (s0, s1, s2) == (0, 1, 2)
+    for slot in (s2, s0, s0, s2): assert p.prove_stashed(slot, r, s) == meta["proof"]
+    with pytest.raises(e.ZkGpuError): p.prove_stashed(s1, r, s)
+    assert p.prove_stashed(s0, r, s) == meta["proof"] and p.prove(z, r, s) == meta["proof"]                   # the object keeps working
+    with pytest.raises(e.ZkGpuError): p.prove_stashed(7, r, s)
+    fresh = p.prove_stashed(s0); assert fresh != meta["proof"] and e.verify(os.path.join(d, "vk.txt"), fresh, o.from_arr(z[:meta["n_inputs"]])); p.close()
+
 def test_key_container_gives_the_same_prover(tmp_path):
     """the first load of a text key leaves <key>.gpucache behind (post-transform tables as raw aligned arrays); the next load maps it instead of parsing 77 MB
     of text — same proof bytes, a fraction of the time; a container whose key file changed is ignored and rebuilt"""
