@@ -59,6 +59,15 @@ def check_bounds():
         assert KS[c][NL - 1] >= int(need * Q) >> (B * (NL - 1)), (c, need)
     return dict(cP=cP, cR=cR, cX=cX, cT=cT, cY=cY, bounds=dict(X=nX, Y=nY, ZZ=nZZ, ZZZ=nZZZ, P=bP, R=bR, T=bT))
 BOUNDS = check_bounds()
+def check_bounds_dual_y():
+    """round 5: the mixed addition's Y3 = R (Q - X3) - Y PPP as ONE dual product mul2(R, Q - X3, K_4 - Y, PPP) (msm.cuh: XYZZ29::madd_tail_pp): the negated Y needs
+    Y < 4 p (the invariant: 3.6 p) with normalized limbs, all four operands are normalized (the column bound of mul2 with 18 + 9 terms below 2^58 + ...), and the
+    result — a product's, below ((R)(Q - X3) + (4)(PPP)) / 2^261 + p — stays within the invariant with room to spare"""
+    b = BOUNDS["bounds"]; PPP = prod(b["P"], prod(b["P"], b["P"])); nY = (b["R"] * b["T"] + 4.0 * PPP) / RATIO + 1.0
+    assert 3.6 + 0.01 <= 4 and KS[4][NL - 1] >= int(3.6 * Q) >> (B * (NL - 1)) and nY <= 3.6, nY
+    assert 18 * ((1 << 29) + 8) ** 2 + 9 * (1 << 58) + (1 << 35) < 1 << 64
+    return nY
+BOUNDS_DUAL_Y = check_bounds_dual_y()
 def check_bounds_ntt_stages():
     """the transform tiles (ntt.cuh: ntt29_lds_pass) normalize after every second butterfly stage: a normalized limb (below 2^29 + 8) that goes through two un-normalized
     differences u + KL_2 - t (each adds at most 2^30 + 64, sub_product) must still be a legal wide operand of a product (below 2^31.4, the column bound in check_bounds),

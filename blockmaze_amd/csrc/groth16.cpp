@@ -858,6 +858,8 @@ static void finish_setup(Prover::Impl &p) {
   }
   // the witness MSMs only need z: they overlap the QAP / H chain on the main stream
   if (!one_stream) {
+    // (the follower of a shared sort stays on its leader's stream: on a stream of its own — four witness chains side by side, measured in round 5 — the H
+    // accumulation gets the chip to itself again, 0.33 -> 0.29 ms, but the head of the chain loses more: device side 0.759 -> 0.827 ms, profiles/r05_priorities.txt)
     p.A->set_stream(0);
     p.L->set_stream(p.pair_AL ? 0 : 1);
     p.B1->set_stream(2);

@@ -230,63 +230,6 @@ __global__ void __launch_bounds__(256) k_hbits29(const Point29Rec *__restrict__ 
   }
 }
 
-// ---- the H query's combine, quad-cooperative (round 5) ------------------------------------------------------------------------------------------------------
-// Bucket b = the sum of the pieces k_hacc_runs29 left for it (msm.cuh: Piece29, 36 raw limbs: X | Y | ZZ | ZZZ), with the point SPREAD over a quad like the two
-// kernels above: 2^lq quads per bucket, a quad adds every 2^lq-th piece (the next piece's nine limbs per lane are in flight during an addition), the quads of a
-// bucket meet by one shuffle level.  k_hacc_combine29 (msm.cuh) does the same sums with two plain lanes per bucket — 14 products of 162 multiply-adds in ONE
-// lane's instruction stream per addition, six additions deep, one wave per SIMD: 77-80 us at the end of every send proof, where nothing else runs.  Here an
-// addition is four rounds of one product per lane (~1,150 instructions) and the chip holds two to four waves per SIMD.  Same results: the sum leaves as a
-// Point29Rec, ZZ = 0 (mod p) in something that is not the point at infinity raises the flag of the one-pass path.
-
-__device__ __forceinline__ QPoint29 quad29_load_piece(const uint32_t *piece_words, int k) {
-  QPoint29 p; const uint32_t *s = piece_words + 9 * k; uint32_t o = 0;
-#pragma unroll
-  for (int i = 0; i < 9; i++) { p.c.l[i] = s[i]; o |= s[i]; }
-  p.inf = __builtin_amdgcn_update_dpp(0, (int)o, 0xAA, 0xf, 0xf, false) == 0;           // [2,2,2,2]: all-zero ZZ limbs = the point at infinity
-  return p;
-}
-template <int UNIT>
-__global__ void __launch_bounds__(256) k_hacc_combine29q(const uint32_t *__restrict__ partials /* Piece29 records of 36 words */, const uint32_t *__restrict__ offsets,
-    const uint32_t *__restrict__ counts, uint32_t low_bits, uint32_t region, uint32_t run, uint32_t maxp, uint32_t n_buckets, uint32_t lq,
-    Point29Rec *__restrict__ buckets29, MsmCounters *cnt) {
-  zk_take_prio(lq);
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, qd = t >> 2, b = qd >> lq, sub = qd & ((1u << lq) - 1), step = 1u << lq;
-  const int k = threadIdx.x & 3;
-  const bool live = b < n_buckets;
-  uint32_t np = 0;                                                                       // how many pieces the accumulation left for this bucket
-  if (live) {
-    const uint32_t c = counts[b], off = offsets[b] - (b >> low_bits) * region;
-    if (c) np = min((off + c - 1) / run - off / run + 1, maxp);
-  }
-  const uint32_t *src = partials + (size_t)(live ? b : 0) * maxp * 36;
-  QPoint29 acc = quad29_inf();
-  if (sub < np) {
-    acc = quad29_load_piece(src + (size_t)sub * 36, k);
-    QPoint29 nxt = acc;
-    if (sub + step < np) nxt = quad29_load_piece(src + (size_t)(sub + step) * 36, k);
-#pragma unroll 1
-    for (uint32_t j = sub + step; j < np; j += step) {
-      const QPoint29 cur = nxt;
-      if (j + step < np) nxt = quad29_load_piece(src + (size_t)(j + step) * 36, k);
-      acc = quad29_add(acc, cur, k);
-    }
-  }
-#pragma unroll 1
-  for (uint32_t d = step >> 1; d >= 1; d >>= 1) {                                        // the quads of a bucket meet by shuffles (whole quads: uniform inside a quad)
-    const QPoint29 o = quad29_shfl_down(acc, 4 * d);
-    if (sub + d < step) acc = quad29_add(acc, o, k);
-  }
-  if (!live || sub != 0) return;
-  // (ZZ on lane 2 is a product's result, a piece's ZZ or the lifted one: exact limbs)
-  if (k == 2 && !acc.inf) {
-    uint32_t zero_or = 0, p_xor = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) { zero_or |= acc.c.l[i]; p_xor |= acc.c.l[i] ^ Fq29::P29[i]; }
-    if (zero_or == 0 || p_xor == 0) atomicOr(&cnt->pad[0], 1u);
-  }
-  quad29_store(buckets29 + b, acc, k);
-}
-
 // ---- the G1 witness MSMs (A, L*, B1) on the same arithmetic (round 4)
 // ------------------------------------------------------------------------------------------------ k_wacc_lanes29 (msm.cuh) leaves one Point29Rec per lane;
 // here the two cooperative stages that follow it, the 29-bit forms of k_wacc_fold and k_wtail:
@@ -329,7 +272,7 @@ __global__ void __launch_bounds__(256) k_wfold29(const Point29Rec *__restrict__ 
 template <int UNIT>
 __global__ void __launch_bounds__(256) k_wtail29(const Point29Rec *__restrict__ buckets, uint32_t NB, const Point29Rec *__restrict__ ones_partial,
     uint32_t n_ones_partial, uint32_t slots, XYZZ<Fq> *__restrict__ res,
-                                                 MsmCounters *cnt, uint4 *copy_dst) {
+                                                 MsmCounters *cnt, uint4 *copy_dst, uint32_t ticket_shift) {
   zk_take_prio(NB);
   __shared__ Point29Rec lds[4];
   const uint32_t q = threadIdx.x >> 2, s_ = blockIdx.x, half = NB >> 1;
@@ -364,11 +307,12 @@ __global__ void __launch_bounds__(256) k_wtail29(const Point29Rec *__restrict__ 
   __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
-    // (the ticket is left at zero: MSMs that share a sort share these counters)
-    if (atomicAdd(&cnt->pad[1], 1u) == gridDim.x - 1) {
+    // (the ticket is left at zero: MSMs that share a sort share these counters — and may run side by side on two streams: the leader counts in the low half of
+    // the word, the follower in the high half, ticket_shift = 0 / 16)
+    if (((atomicAdd(&cnt->pad[1], 1u << ticket_shift) >> ticket_shift) & 0xffffu) == gridDim.x - 1) {
       __threadfence();
       *copy_dst = *reinterpret_cast<const uint4 *>(cnt);
-      cnt->pad[1] = 0;
+      atomicAnd(&cnt->pad[1], ~(0xffffu << ticket_shift));
     }
   }
 }

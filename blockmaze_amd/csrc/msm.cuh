@@ -445,7 +445,13 @@ struct XYZZ29 { Fq29 X, Y, ZZ, ZZZ;
 #pragma unroll
     for (int i = 0; i < 9; i++) s.l[i] = PPP.l[i] + 2u * Q.l[i];
     const Fq29 X3 = Fq29::sub<4>(Fq29::sqr(Rv), s);
-    Y = Fq29::sub<2>(Fq29::mul(Rv, Fq29::sub<6>(Q, X3)), Fq29::mul(Y, PPP)); X = X3; ZZ = Fq29::mul(ZZ, PP); ZZZ = Fq29::mul(ZZZ, PPP);
+    // Y3 = R (Q - X3) + (K_4 - Y) PPP as ONE dual product (round 5; Fq29::mul2: one Montgomery reduction for both halves — 81 multiply-adds and nine m_k fewer per
+    // mixed addition, proof window -5 us; operands normalized, bounds: gen_field29.py, check_bounds_dual_y)
+    ZZ = Fq29::mul(ZZ, PP); ZZZ = Fq29::mul(ZZZ, PPP);
+    Fq29 zero;
+#pragma unroll
+    for (int i = 0; i < 9; i++) zero.l[i] = 0;
+    Y = Fq29::mul2(Rv, Fq29::sub<6>(Q, X3), Fq29::sub<4>(zero, Y), PPP); X = X3;
   }
 };
 // a product's or a squaring's result (exact 29-bit limbs, value below 2 p) is 0 (mod p) iff it is 0 or p
@@ -584,6 +590,7 @@ static __global__ void __launch_bounds__(256) k_hacc_combine29(const Piece29 *__
     const uint32_t *__restrict__ counts, HsortShape sh, uint32_t run, uint32_t maxp, uint32_t n_buckets,
                                                                uint32_t ll, XYZZ<Fq> *__restrict__ buckets, Point29Rec *__restrict__ buckets29,
                                                                    MsmCounters *cnt) {
+  zk_take_prio(ll);
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, b = t >> ll, sub = t & ((1u << ll) - 1), step = 1u << ll;
   const bool live = b < n_buckets;
   uint32_t np = 0;                                                                       // how many pieces the accumulation left for this bucket
@@ -1070,12 +1077,12 @@ __device__ __forceinline__ void g2_29_unpack(const Affine<Fq2> &p, bool neg, Fq2
 // proportional to the fill, the next WFUSED_ONES_LANES stride over the list of ones), from the tables with coordinates x 2^261 (points261 / groups261,
 // k_table_to_r261_g2 at key load). A lane's sum leaves the 29-bit domain when it is stored: eight products with 2^256 mod p give the lazy 8 x 32-bit form that
 // k_wacc_fold<Fq2> adds up.
-// REC29 (round 5): the sum stays on 29-bit limbs — a Point29Rec2 (oct29.cuh: eight slots, component-major) for k_wfold_g2_29; no conversion, and the degenerate
-// case (ZZ = 0 mod p) is left to the tail, where it arrives in at least one result: a product with ZZ = 0 stays 0.
-template <int REC29>
+// Round 5: the sum stays on 29-bit limbs — a Point29Rec2 (oct29.cuh: eight slots, component-major) for k_wfold_g2_29; no conversion, and the degenerate case
+// (ZZ = 0 mod p) is left to the tail, where it arrives in at least one result: a product with ZZ = 0 stays 0.
+template <int UNIT>   // (a template only so that the one translation unit that launches it instantiates it)
 __global__ void __launch_bounds__(256) k_wacc_lanes_g2_29(const Affine<Fq2> *__restrict__ points261, const Affine<Fq2> *__restrict__ groups261,
     const uint32_t *__restrict__ entries, const uint32_t *__restrict__ fill, uint32_t cap,
-                                                          uint32_t NB, const uint32_t *__restrict__ ones, MsmCounters *cnt, XYZZ<Fq2> *__restrict__ partial,
+                                                          uint32_t NB, const uint32_t *__restrict__ ones, MsmCounters *cnt, Point29Rec2 *__restrict__ partial,
                                                               uint32_t *__restrict__ lane_off) {
   zk_take_prio(NB);
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1139,8 +1146,8 @@ __global__ void __launch_bounds__(256) k_wacc_lanes_g2_29(const Affine<Fq2> *__r
       v = vn; p = pn;
     }
   }
-  if constexpr (REC29 != 0) {
-    uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<Point29Rec2 *>(partial) + t);
+  {
+    uint4 *dst = reinterpret_cast<uint4 *>(partial + t);
     const uint32_t z = inf ? 0u : ~0u;
     const Fq29 *slot[8] = {&acc.X.c0, &acc.Y.c0, &acc.ZZ.c0, &acc.ZZZ.c0, &acc.X.c1, &acc.Y.c1, &acc.ZZ.c1, &acc.ZZZ.c1};
 #pragma unroll
@@ -1150,18 +1157,7 @@ __global__ void __launch_bounds__(256) k_wacc_lanes_g2_29(const Affine<Fq2> *__r
       dst[3 * e + 1] = make_uint4(v.l[4] & z, v.l[5] & z, v.l[6] & z, v.l[7] & z);
       dst[3 * e + 2] = make_uint4(v.l[8] & z, 0u, 0u, 0u);
     }
-    return;
   }
-  XYZZ<Fq2> o = XYZZ<Fq2>::inf();
-  if (!inf) {
-    acc.X.c0.to_words(o.X.c0.l); acc.X.c1.to_words(o.X.c1.l); acc.Y.c0.to_words(o.Y.c0.l); acc.Y.c1.to_words(o.Y.c1.l);
-    acc.ZZ.c0.to_words(o.ZZ.c0.l); acc.ZZ.c1.to_words(o.ZZ.c1.l); acc.ZZZ.c0.to_words(o.ZZZ.c0.l); acc.ZZZ.c1.to_words(o.ZZZ.c1.l);
-    // an operand was +-the accumulator somewhere: the general path repeats the MSM
-    if (o.ZZ.c0.is_zero_lazy() && o.ZZ.c1.is_zero_lazy()) atomicOr(&cnt->pad[0], 1u);
-    o = XYZZ<Fq2>{{o.X.c0.normalize(), o.X.c1.normalize()}, {o.Y.c0.normalize(), o.Y.c1.normalize()}, {o.ZZ.c0.normalize(), o.ZZ.c1.normalize()},
-        {o.ZZZ.c0.normalize(), o.ZZZ.c1.normalize()}};
-  }
-  partial[t] = o;
 }
 // the G2 tables of the kernel above: coordinates x 2^261 (mod p) from x 2^256, component by component; (0, 0) stays the point at infinity
 static __global__ void k_table_to_r261_g2(const Affine<Fq2> *__restrict__ in, Affine<Fq2> *__restrict__ out, size_t n) {
@@ -1173,44 +1169,7 @@ static __global__ void k_table_to_r261_g2(const Affine<Fq2> *__restrict__ in, Af
   const Affine<Fq2> p = in[i];
   out[i] = {{p.x.c0 * c, p.x.c1 * c}, {p.y.c0 * c, p.y.c1 * c}};
 }
-// workgroup b < NB: bucket b = the sum of its lanes' partial sums; workgroup NB + g: 256 of the ones lanes
-template <class F>
-__global__ void __launch_bounds__(256) k_wacc_fold(const XYZZ<F> *__restrict__ partial, const uint32_t *__restrict__ lane_off, uint32_t NB,
-    XYZZ<F> *__restrict__ out) {
-  __shared__ XYZZ<F> lds[4]; const uint32_t b = blockIdx.x; uint32_t beg, len;
-  if (b < NB) { beg = lane_off[b]; len = lane_off[b + 1] - beg; } else { beg = WFUSED_BUCKET_LANES + (b - NB) * 256; len = 256; }
-  XYZZ<F> acc = block_quad_sum(partial + beg, len, lds); if (threadIdx.x == 0) out[b] = acc;
-}
-// sum_b (b + 1) * bucket_b as sum_s 2^s S_s, S_s = the sum of the buckets whose weight has bit s: for s < top = log2 NB those are the NB / 2 weights "i with a
-// one inserted at bit s"; S_top is bucket NB - 1 alone. The S_s go to the host as they are (res[0..7]; res[8] = the sum of the ones): its Horner rule for
-// window sums finishes with one-bit windows on the MSM's submit thread (7 doublings, 8 additions) — on the device that was 10 more dependent quad operations,
-// 150 us of the G2 chain. Round 4: ONE WORKGROUP PER WEIGHT BIT (workgroups 0 .. top - 1: a quad per bucket and the workgroup's tree, six dependent additions;
-// round 3 had all eight sums in one workgroup, eight buckets per quad and a three-level tree: eleven), workgroup `top` hands on bucket NB - 1 and clears the
-// unused slots, workgroup top + 1 adds the ones' partial sums and carries the counters along.
-constexpr int WTAIL_SLOTS = 8;
-template <class F>
-__global__ void __launch_bounds__(256) k_wtail(const XYZZ<F> *__restrict__ buckets, uint32_t NB, const XYZZ<F> *__restrict__ ones_partial,
-    uint32_t n_ones_partial, XYZZ<F> *__restrict__ res, uint4 *copy_src, uint4 *copy_dst) {
-  __shared__ XYZZ<F> lds[4];
-  const uint32_t q = threadIdx.x >> 2, s_ = blockIdx.x, top = 31 - __clz(NB), half = NB >> 1;       // NB is a power of two, 16 <= NB <= 128
-  const int k = threadIdx.x & 3;
-  if (s_ == top + 1) {
-    XYZZ<F> acc = block_quad_sum(ones_partial, n_ones_partial, lds);
-    if (threadIdx.x == 0) { res[WTAIL_SLOTS] = acc; if (copy_src) *copy_dst = *copy_src; }
-    return;
-  }
-  if (s_ == top) {
-    if (threadIdx.x == 0) res[top] = buckets[NB - 1];
-    if (threadIdx.x > top && threadIdx.x < (uint32_t)WTAIL_SLOTS) res[threadIdx.x] = XYZZ<F>::inf();   // slots above `top` hold the point at infinity
-    return;
-  }
-  auto bucket_of = [&](uint32_t i) { return (((i >> s_) << (s_ + 1)) | (1u << s_) | (i & ((1u << s_) - 1))) - 1; };
-  XYZZ<F> acc = XYZZ<F>::inf();
-  if (q < half) acc = buckets[bucket_of(q)];                                                    // half <= 64: at most one bucket per quad
-  acc = block_quad_tree(acc, lds, min(half, 64u));
-  if (threadIdx.x == 0) res[s_] = acc;
-}
-
+constexpr int WTAIL_SLOTS = 8;   // the tails of the witness MSMs leave eight sums by weight bit (S_s, s = 0 .. 7) and the sum of the ones
 // (the weighted bucket sum of the H query — sums by weight bit from two-level marginal sums, on 29-bit limbs — lives in htail29.cuh: k_hmarg29 / k_hbits29)
 
 // ---- fixed-base precomputation: table[w*n + i] = 2^(c*w) * P_i, affine ------------------------------------------------

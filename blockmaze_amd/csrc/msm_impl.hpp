@@ -361,8 +361,7 @@ struct MsmImpl {
         }
         if (w.shared) HIP_CHECK(hipEventRecord(w.sorted, s)); }
       else if (w.leader_stream != stream_id) HIP_CHECK(hipStreamWaitEvent(s, w.sorted, 0));   // (a follower on the leader's stream is simply queued behind it)
-      uint4 *csrc = (uint4 *)(wc + w.parity); uint4 *cdst = (uint4 *)(res + RS + 1);
-      XYZZ<F> *l2 = (XYZZ<F> *)ones_partial.get();                                         // (G2) l2: [NB bucket sums | the partial sums of the ones]
+      uint4 *cdst = (uint4 *)(res + RS + 1);
       // accumulate / fold / tail. G1 (A, L*, B1): on 29-bit limbs throughout (msm.cuh: k_wacc_lanes29; htail29.cuh: k_wfold29, k_wtail29). G2 (B2): the lanes
       // on 29-bit limbs over Fq2 (k_wacc_lanes_g2_29), fold and tail quad-cooperative on 8 x 32-bit limbs (k_wacc_fold<Fq2>, k_wtail<Fq2>).
       const uint32_t *fl = w.fill.get() + (size_t)w.parity * NB;
@@ -378,34 +377,20 @@ struct MsmImpl {
         }
         { Stage st((label + ".reduce").c_str(), s);
           hipLaunchKernelGGL(k_wtail29<0>, dim3(top + 2), dim3(256), 0, s, (const Point29Rec *)p2, NB | zk_prio_bits("wit"), (const Point29Rec *)p2 + NB,
-              (uint32_t)WFUSED_ONES_GROUPS, (uint32_t)WTAIL_SLOTS, (XYZZ<Fq> *)res, wc + w.parity, cdst);
+              (uint32_t)WFUSED_ONES_GROUPS, (uint32_t)WTAIL_SLOTS, (XYZZ<Fq> *)res, wc + w.parity, cdst, ws_leader ? 0u : 16u);
         }
       } else {
-        // round 5: fold and tail on 29-bit limbs with the point spread over eight lanes (oct29.cuh); ZK_G2_OCT=0: the quad-cooperative kernels on 8 x 32-bit limbs
-        static const bool oct = [] { const char *e = getenv("ZK_G2_OCT"); return !e || atoi(e) != 0; }();
-        if (oct) {
-          Point29Rec2 *p1 = (Point29Rec2 *)partials.get(), *p2 = (Point29Rec2 *)ones_partial.get();
-          { Stage st((label + ".accumulate").c_str(), s);
-            hipLaunchKernelGGL(k_wacc_lanes_g2_29<1>, lanes_grid, dim3(256), 0, s, (const Affine<Fq2> *)bases->points261.get(),
-                (const Affine<Fq2> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB | zk_prio_bits("wlanes"), w.ones.get(), wc + w.parity, (XYZZ<Fq2> *)p1, lane_off.get());
-            hipLaunchKernelGGL(k_wfold_g2_29<0>, fold_grid, dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p1, (const uint32_t *)lane_off.get(), NB | zk_prio_bits("wit"),
-                (uint32_t)WFUSED_BUCKET_LANES, p2);
-          }
-          { Stage st((label + ".reduce").c_str(), s);
-            hipLaunchKernelGGL(k_wtail_g2_29<0>, dim3(top + 2), dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p2, NB | zk_prio_bits("wit"), (const Point29Rec2 *)p2 + NB,
-                (uint32_t)WFUSED_ONES_GROUPS, (uint32_t)WTAIL_SLOTS, (XYZZ<Fq2> *)res, wc + w.parity, cdst);
-          }
-          return;
-        }
-        XYZZ<F> *l1 = (XYZZ<F> *)partials.get();
+        // round 5: fold and tail on 29-bit limbs with the point spread over eight lanes (oct29.cuh: k_wfold_g2_29, k_wtail_g2_29)
+        Point29Rec2 *p1 = (Point29Rec2 *)partials.get(), *p2 = (Point29Rec2 *)ones_partial.get();
         { Stage st((label + ".accumulate").c_str(), s);
           hipLaunchKernelGGL(k_wacc_lanes_g2_29<0>, lanes_grid, dim3(256), 0, s, (const Affine<Fq2> *)bases->points261.get(),
-              (const Affine<Fq2> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB, w.ones.get(), wc + w.parity, (XYZZ<Fq2> *)l1, lane_off.get());
-          hipLaunchKernelGGL((k_wacc_fold<F>), fold_grid, dim3(256), 0, s, (const XYZZ<F> *)l1, (const uint32_t *)lane_off.get(), NB, l2); }
+              (const Affine<Fq2> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB | zk_prio_bits("wlanes"), w.ones.get(), wc + w.parity, p1, lane_off.get());
+          hipLaunchKernelGGL(k_wfold_g2_29<0>, fold_grid, dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p1, (const uint32_t *)lane_off.get(), NB | zk_prio_bits("wit"),
+              (uint32_t)WFUSED_BUCKET_LANES, p2);
+        }
         { Stage st((label + ".reduce").c_str(), s);
-          // one workgroup per weight bit, one for bucket NB - 1, one for the ones
-          hipLaunchKernelGGL((k_wtail<F>), dim3(top + 2), dim3(256), 0, s, (const XYZZ<F> *)l2, NB, (const XYZZ<F> *)l2 + NB, (uint32_t)WFUSED_ONES_GROUPS,
-              res, csrc, cdst);
+          hipLaunchKernelGGL(k_wtail_g2_29<0>, dim3(top + 2), dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p2, NB | zk_prio_bits("wit"), (const Point29Rec2 *)p2 + NB,
+              (uint32_t)WFUSED_ONES_GROUPS, (uint32_t)WTAIL_SLOTS, (XYZZ<Fq2> *)res, wc + w.parity, cdst, ws_leader ? 0u : 16u);
         }
       }
       return;
@@ -425,11 +410,6 @@ struct MsmImpl {
       {
         Stage st((label + ".accumulate").c_str(), s);
         const dim3 grid(cdiv(cdiv(n * (size_t)W, h_run) + hs.groups, 256));
-        // (experiment switch: unused dynamic LDS caps the workgroups per compute unit — 160 KB a CU: 41 KB -> 3 waves per SIMD, 54 KB -> 2)
-        static const unsigned h_lds = [] { const char *e = getenv("ZK_HACC_DYNLDS_KB"); return e ? (unsigned)atoi(e) * 1024u : 0u; }();
-        if (h_lds) hipLaunchKernelGGL(k_hacc_runs29<1>, grid, dim3(256), h_lds, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(),
-            offsets.get(), hs, h_run, h_maxp | zk_prio_bits("hacc"), (Piece29 *)partials.get(), cnt);
-        else
         if (any_inf) hipLaunchKernelGGL(k_hacc_runs29<1>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(),
             offsets.get(), hs, h_run, h_maxp | zk_prio_bits("hacc"), (Piece29 *)partials.get(), cnt);
         else hipLaunchKernelGGL(k_hacc_runs29<0>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(),
@@ -440,16 +420,8 @@ struct MsmImpl {
         Stage st((label + ".combine").c_str(), s);
         const size_t pieces = n * (size_t)W / NB / h_run;
         const uint32_t ll = pieces > 40 ? 3 : pieces > 18 ? 2 : 1;
-        // round 5: with the 29-bit tail the sums are formed by quads (htail29.cuh: k_hacc_combine29q) — ZK_HCOMBINE_QUADS = log2 of the quads per bucket + 1, 0 = the
-        // two-lane kernel; default: one quad up to 18 pieces, two up to 40, four beyond
-        static const int hq = [] { const char *e = getenv("ZK_HCOMBINE_QUADS"); return e ? atoi(e) : -1; }();
-        if (htail29 && hq != 0) {
-          const uint32_t lq = hq > 0 ? (uint32_t)(hq - 1) : pieces > 40 ? 2 : pieces > 18 ? 1 : 0;
-          hipLaunchKernelGGL(k_hacc_combine29q<0>, dim3(cdiv((nbk << lq) * 4, 256)), dim3(256), 0, s, (const uint32_t *)partials.get(), offsets.get(), hist(), hs.low_bits,
-              hs.region, h_run, h_maxp, (uint32_t)nbk, lq | zk_prio_bits("htail"), (Point29Rec *)hb29.get(), cnt);
-        } else
         hipLaunchKernelGGL(k_hacc_combine29, dim3(cdiv(nbk << ll, 256)), dim3(256), 0, s, (const Piece29 *)partials.get(), offsets.get(), hist(), hs, h_run,
-            h_maxp, (uint32_t)nbk, ll, (XYZZ<Fq> *)bucket_array(), htail29 ? (Point29Rec *)hb29.get() : nullptr, cnt);
+            h_maxp, (uint32_t)nbk, ll | zk_prio_bits("htail"), (XYZZ<Fq> *)bucket_array(), htail29 ? (Point29Rec *)hb29.get() : nullptr, cnt);
       }
       }
     } else

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(OCT_BLOCK) k_wfold_g2_29(const Point29Rec2 *__
 // workgroup to finish hands the counters to the host
 template <int UNIT>
 __global__ void __launch_bounds__(OCT_BLOCK) k_wtail_g2_29(const Point29Rec2 *__restrict__ buckets, uint32_t NB, const Point29Rec2 *__restrict__ ones_partial,
-    uint32_t n_ones_partial, uint32_t slots, XYZZ<Fq2> *__restrict__ res, MsmCounters *cnt, uint4 *copy_dst) {
+    uint32_t n_ones_partial, uint32_t slots, XYZZ<Fq2> *__restrict__ res, MsmCounters *cnt, uint4 *copy_dst, uint32_t ticket_shift) {
   zk_take_prio(NB);
   __shared__ Point29Rec2 lds[OCT_BLOCK / 64];
   const uint32_t q = threadIdx.x >> 3, nq = OCT_BLOCK / 8, s_ = blockIdx.x, half = NB >> 1;
@@ -210,10 +210,10 @@ __global__ void __launch_bounds__(OCT_BLOCK) k_wtail_g2_29(const Point29Rec2 *__
   __syncthreads();                                                                      // (the flag of oct29_emit before the ticket, whatever lane raised it)
   if (threadIdx.x == 0) {
     __threadfence();
-    if (atomicAdd(&cnt->pad[1], 1u) == gridDim.x - 1) {
+    if (((atomicAdd(&cnt->pad[1], 1u << ticket_shift) >> ticket_shift) & 0xffffu) == gridDim.x - 1) {   // (the follower of a shared sort counts in the high half)
       __threadfence();
       *copy_dst = *reinterpret_cast<const uint4 *>(cnt);
-      cnt->pad[1] = 0;
+      atomicAnd(&cnt->pad[1], ~(0xffffu << ticket_shift));
     }
   }
 }

@@ -9,6 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzkgpu.so")
+if os.environ.get("ZKGPU_LIB"): LIB_PATH = os.environ["ZKGPU_LIB"]   # (A/B of two builds on one box: tools/ab_device.py "ZKGPU_LIB=tools/other_build.bin")
 
 class ZkGpuError(RuntimeError):
     pass
