@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="only the timed region and the roofline leg (what the N > 1 scaling runs need)")
     ap.add_argument("--inflight", type=int, default=6, help="extra leg (not `value`): this many prover objects per GPU, one host thread each, proofs overlapping on the device; 0/1 = skip")
-    ap.add_argument("--batch", type=int, default=32, help="extra leg (not `value`): zkgpu_prover_prove_batch with this many witnesses per call (BASELINE.json configs[2]); 0/1 = skip")
+    ap.add_argument("--batch", type=int, default=64, help="extra leg (not `value`): zkgpu_prover_prove_batch with this many witnesses per call (BASELINE.json configs[2]); 0/1 = skip")
     ap.add_argument("--shard-msm", action="store_true", help="N > 1 only: all ranks prove ONE proof per step together, each holding 1/N of every query; one all-gather of 384-byte partial records per proof (strong scaling)")
     return ap.parse_args()
 
@@ -164,7 +164,12 @@ def run_rank(args):
     if rank == 0: key_dir, t_keygen = made
     if grp is not None: key_dir = grp.share_from_rank0(key_dir if rank == 0 else None)
     pk_path, vk_path = os.path.join(key_dir, "sendpk.txt"), os.path.join(key_dir, "sendvk.txt")
-    def load(): t0 = time.time(); p = e.Prover(pk_path, rank, world) if shard else e.Prover(pk_path); return p, time.time() - t0
+    hbm = {}
+    def load():
+        free0 = torch.cuda.mem_get_info()[0] if torch.cuda.is_available() else None
+        t0 = time.time(); p = e.Prover(pk_path, rank, world) if shard else e.Prover(pk_path); dt_ = time.time() - t0
+        if free0 is not None: hbm["key_and_first_prover_gb"] = round((free0 - torch.cuda.mem_get_info()[0]) / 1e9, 3)      # tables (one coordinate form since round 5) + twiddles + constraint system + one prover's workspaces
+        return p, dt_
     first = stage("load", load if rank == 0 else (lambda: None))             # rank 0 first: its load from text leaves the container the others map
     rest = stage("load", load if rank != 0 else (lambda: None))
     prover, t_load = first if rank == 0 else rest
@@ -373,7 +378,7 @@ def run_rank(args):
                        "host_binding": host_binding, "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
                        "includes": "one prover call per step on the next of the run's distinct statements, all of them RESIDENT IN HBM when the timed region starts (handed over before the clock starts, kept in device memory; a step copies its assignment device-to-device and proves it): R1CS rows, the 7 NTTs of the witness map (4 run per proof; both transforms of C and the final inverse are folded into the L and H queries at key load), 5 MSM, host proof assembly, hex serialisation; excludes witness generation and key load.  `value_p50` = 1 / the median step (the mean carries the host's rare 2-5 ms steps); `value_from_host_buffers` = the same prover call handed a fresh host buffer every step (scan + PCIe + expansion included; N = 1 only) — what rounds 1-4 reported as `value`" if not shard else "one proof per step cut into shards; host-buffer hand-over included"},
             "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "cpu_baseline_variants": cpu_more or None, "extra_legs": extra or None,
-            "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2)}}
+            "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2), "hbm": hbm or None}}
         real_stdout.write(json.dumps(line) + "\n"); real_stdout.flush()
     prover.close()
     if grp is not None: grp.close()

@@ -778,10 +778,12 @@ int zkgpu_prover_prove_batch(zkgpu_prover *h, const uint8_t *zs, size_t n, const
     std::lock_guard<std::mutex> lk(g_gpu_mutex);
     while (h->lanes.size() + 1 < K) h->lanes.push_back(std::make_shared<Prover>(*h->p));
   }
-  const size_t zbytes = 32 * h->p->num_variables(); std::vector<uint8_t> bad(n, 0); std::vector<std::string> errs(K); std::vector<std::thread> th;
+  const size_t zbytes = 32 * h->p->num_variables(); std::vector<uint8_t> bad(n, 0); std::vector<std::string> errs(K); std::vector<std::thread> th; std::atomic<size_t> next{0};
   auto work = [&](size_t lane) { Prover &pv = lane ? *h->lanes[lane - 1] : *h->p;
     try {
-      for (size_t i = lane; i < n; i += K) {
+      // (the next statement nobody has taken: a lane that is slowed down — a preempted helper, the lane that shares its SIMDs with another's H accumulation —
+      // simply takes fewer, and the batch ends when the last statement does, not when the unluckiest lane has worked off its fixed share)
+      for (size_t i = next.fetch_add(1, std::memory_order_relaxed); i < n; i = next.fetch_add(1, std::memory_order_relaxed)) {
         Proof pr;
         const Fe32 *r = rs ? (const Fe32 *)(rs + 64 * i) : nullptr, *s_ = rs ? (const Fe32 *)(rs + 64 * i + 32) : nullptr;
         if (!pv.prove((const Fe32 *)(zs + zbytes * i), r, s_, pr)) {

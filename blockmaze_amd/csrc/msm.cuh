@@ -395,7 +395,17 @@ static __global__ void __launch_bounds__(PLAN_THREADS) k_msm_plan_small(const ui
   if (threadIdx.x == 0) task_off[n_buckets] = total;
 }
 // task_off: exclusive scan of ntasks over the SORTED bucket list (n_buckets + 1 entries, the last one = total)
-template <class F>
+// FROM261 (round 5): the table holds coordinates x 2^261 (the form the 29-bit kernels gather from; the x 2^256 copy of a query's fixed-base table is no longer kept
+// beside it) — every loaded coordinate is multiplied by 2^251 (a Montgomery product: x 2^261 2^251 2^-256 = x 2^256).  (0, 0), the point at infinity, stays (0, 0).
+template <class F> __device__ __forceinline__ Affine<F> affine_from_r261(Affine<F> p) {
+  Fq c;
+#pragma unroll
+  for (int j = 0; j < 8; j++) c.l[j] = FQ_TWO251[j];
+  if constexpr (sizeof(F) == 32) { p.x = p.x * c; p.y = p.y * c; }
+  else { p.x = {p.x.c0 * c, p.x.c1 * c}; p.y = {p.y.c0 * c, p.y.c1 * c}; }
+  return p;
+}
+template <class F, int FROM261>
 __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *__restrict__ points, const uint32_t *__restrict__ entries,
     const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ counts,
                                                               const uint32_t *__restrict__ order, const uint32_t *__restrict__ task_off, uint32_t n_buckets,
@@ -412,6 +422,7 @@ __global__ void __launch_bounds__(256) k_msm_accumulate_tasks(const Affine<F> *_
 #pragma unroll 1
   for (uint32_t e = beg; e < end; e++) {
     Affine<F> pn = points[vn & imask]; uint32_t vnn = e + 2 < end ? entries[e + 2] : vn;
+    if constexpr (FROM261 != 0) p = affine_from_r261(p);
     if (v >> 31) p.y = p.y.neg(); acc.madd_inl(p); v = vn; p = pn; vn = vnn; }
   if (cnt <= task) buckets[b] = acc; else partials[t] = acc;
 }

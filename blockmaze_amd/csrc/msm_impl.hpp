@@ -24,7 +24,7 @@ struct MsmImpl {
   bool filter_ones; uint32_t seg, n_ones_quads; std::string label = "msm"; int stream_id = -1;   // -1: main stream, 0..3: auxiliary stream
   // the key's points (with the fixed-base table when there is one) are immutable and shared by every prover object of the key on this device; everything else
   // below is per-object workspace
-  struct Bases { size_t n = 0; int c = 0, W = 0, WB = 0; bool any_inf = false; DevBuf<RawAffine> points,
+  struct Bases { size_t n = 0; int c = 0, W = 0, WB = 0; bool any_inf = false, table261_only = false /* `points` holds the n base points only: the table lives in points261 */; DevBuf<RawAffine> points,
       points261 /* the same table with coordinates x 2^261: what k_hacc_runs29 gathers from (G1, uniform scalars, fixed-base table) and k_wacc_lanes_g2_29 (G2 witness MSM) */, groups261 /* ones_groups in that form (G2) */, ones_groups /* 15 subset sums per four consecutive points: what the fused witness path adds for the scalars equal to one */;
       DevBuf<uint8_t> inf;
     };
@@ -167,6 +167,16 @@ struct MsmImpl {
       if (gn) hipLaunchKernelGGL(k_table_to_r261_g2, dim3(cdiv(gn, 256)), dim3(256), 0, gpu().stream, (const Affine<Fq2> *)b->ones_groups.get(),
           (Affine<Fq2> *)b->groups261.get(), gn);
       HIP_CHECK(hipGetLastError()); HIP_CHECK(hipStreamSynchronize(gpu().stream)); }
+    // Round 5: ONE coordinate form per table.  Whatever the fused paths gather from is in points261 / groups261; the x 2^256 table next to it served the general
+    // path only (fallbacks: an overflowing one-pass sort, a degenerate sum), which now reads points261 and converts on the fly (k_msm_accumulate_tasks<F, 1>).
+    // Kept in the x 2^256 form: the n base points (the general path's sum over the scalars equal to one).  Send: 4.1 -> 2.1 GB per key, deposit-32: 14 -> 7 GB.
+    if (b->points261.size() == n_ * (size_t)b->W && b->WB == 1 && b->W > 1 && n_) {
+      HIP_CHECK(hipStreamSynchronize(gpu().stream));
+      DevBuf<RawAffine> base(n_);
+      HIP_CHECK(hipMemcpyAsync(base.get(), b->points.get(), n_ * sizeof(RawAffine), hipMemcpyDeviceToDevice, gpu().stream));
+      HIP_CHECK(hipStreamSynchronize(gpu().stream));
+      b->points = std::move(base); b->ones_groups = DevBuf<RawAffine>(); b->table261_only = true;
+    }
     return b;
   }
   MsmImpl(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables = true, bool uniform_hint = false) : MsmImpl(make_bases(host_points, n_, c_,
@@ -454,7 +464,9 @@ struct MsmImpl {
     }
     if (!hs_run) {
       { Stage st((label + ".accumulate").c_str(), s);
-        hipLaunchKernelGGL((k_msm_accumulate_tasks<F>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(),
+        if (bases->table261_only) hipLaunchKernelGGL((k_msm_accumulate_tasks<F, 1>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)bases->points261.get(), entries.get(),
+            offsets.get(), hist(), order.get(), task_off.get(), (uint32_t)nbk, max_tasks, MSM_TASK, bucket_array(), (XYZZ<F> *)partials.get());
+        else hipLaunchKernelGGL((k_msm_accumulate_tasks<F, 0>), dim3(cdiv(max_tasks, 256)), dim3(256), 0, s, (const Affine<F> *)points.get(), entries.get(),
             offsets.get(), hist(), order.get(), task_off.get(), (uint32_t)nbk, max_tasks, MSM_TASK, bucket_array(), (XYZZ<F> *)partials.get());
       }
       { Stage st((label + ".combine").c_str(), s);
