@@ -203,6 +203,46 @@ bool parse_fixed_rs(Fe32 &r, Fe32 &s) {
 inline bool parse_fixed_rs(Fe32 &, Fe32 &) { return false; }
 #endif
 
+// ---- one proof's MSMs cut over several GPUs behind the cgo symbols (kernel K7; round 5) --------------------------------------------------------------
+// ZK_SHARD_DEVICES=k: every gen*proof call of the process runs on k shard provers — shard j holds the contiguous slice j of every query of the key on device slot
+// j mod (number of device slots, ZK_DEVICES) —, each on a thread of its own: the assignment goes to every shard, each runs the replicated row / transform pipeline
+// and its slice of the five MSMs (Prover::prove_partial: five partial sums, 384 bytes, written by the kernels into pinned host memory), the calling thread adds the
+// k records and assembles the proof (finish_from_partials: host work only).  No collective, no torch: what a go-ethereum process can use.  It pays where one MSM is
+// much longer than the latency floor of its tails (the deposit circuit at depth 32); for the four deployed circuits proof-level spreading (ZK_DEVICES) is faster.
+// One proof at a time per key (the shard set is locked for the call).  On a box with one GPU all shards share it: the same code path, testable
+// (tests/test_gpu_groth16.py::test_cgo_symbols_with_sharded_msms).
+struct ShardSet { FileStamp stamp; std::vector<std::unique_ptr<Prover>> shards; std::unique_ptr<Circuit> circuit; std::mutex busy; };
+std::mutex g_shard_mutex; std::map<std::string, std::shared_ptr<ShardSet>> g_shard_sets;
+static size_t shard_count() { static const size_t k = [] { const char *e = getenv("ZK_SHARD_DEVICES"); long v = e ? atol(e) : 0; return (size_t)(v < 2 ? 0 : v > 64 ? 64 : v); }(); return k; }
+static std::shared_ptr<ShardSet> shard_set_for(CircuitKind k) {
+  const std::string path = key_path(k, true); FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("proving key not found: " + path);
+  std::lock_guard<std::mutex> lk(g_shard_mutex); std::shared_ptr<ShardSet> &slot = g_shard_sets[path];
+  if (!slot || !(slot->stamp == st)) {
+    std::lock_guard<std::mutex> gl(g_gpu_mutex);
+    bool cached = false; ProvingKeyHost pk = load_proving_key_fast(path, cached); const size_t K = shard_count(), D = (size_t)std::max(1, gpu_device_slots());
+    auto fresh = std::make_shared<ShardSet>(); fresh->stamp = st; fresh->circuit = make_circuit(k, false);
+    for (size_t j = 0; j < K; j++) fresh->shards.emplace_back(new Prover(pk, j, K, (int)(j % D)));
+    if (fresh->circuit->board.num_variables() != fresh->shards[0]->num_variables() || fresh->circuit->num_inputs() != fresh->shards[0]->num_inputs())
+      throw std::runtime_error("proving key does not belong to the " + std::string(circuit_name(k)) + " circuit: " + path);
+    if (!cached) write_container_quietly(path, pk, st);
+    slot = fresh;
+  }
+  return slot;
+}
+// false: the assignment does not satisfy the constraint system
+static bool prove_sharded(ShardSet &set, const Fe32 *r, const Fe32 *s, Proof &proof) {
+  const size_t K = set.shards.size(); std::vector<uint8_t> rec(K * Prover::PARTIAL_BYTES); std::vector<uint8_t> ok(K, 0); std::vector<std::string> errs(K); std::vector<std::thread> th;
+  const uint8_t *tag = set.circuit->board.tag.data(); const Fe32 *wide = reinterpret_cast<const Fe32 *>(set.circuit->board.wide.data());
+  auto work = [&](size_t j) {
+    try { set.shards[j]->set_witness_tagged(tag, wide); ok[j] = set.shards[j]->prove_partial(rec.data() + j * Prover::PARTIAL_BYTES) ? 1 : 0; }
+    catch (const std::exception &e) { errs[j] = e.what(); } catch (...) { errs[j] = "unknown error"; } };
+  for (size_t j = 1; j < K; j++) th.emplace_back(work, j);
+  work(0); for (auto &t : th) t.join();
+  for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
+  for (size_t j = 0; j < K; j++) if (!ok[j]) return false;
+  set.shards[0]->finish_from_partials(rec.data(), K, r, s, proof); return true;   // (r, s null: fresh randomness, drawn inside)
+}
+
 static std::atomic<int> g_proofs_in_flight{0};   // genXproof calls of this process that are between acquiring a prover and returning
 // shared tail of the gen*proof functions: assign() has filled the circuit's board
 template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
@@ -218,6 +258,13 @@ template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
     };
     struct InFlight { InFlight() { g_proofs_in_flight.fetch_add(1, std::memory_order_relaxed); } ~InFlight() {
         g_proofs_in_flight.fetch_sub(1, std::memory_order_relaxed); } } in_flight;
+    if (shard_count()) {
+      std::shared_ptr<ShardSet> set = shard_set_for(k); std::lock_guard<std::mutex> one(set->busy); assign(*set->circuit);
+      printf("Trying to generate %s proof...\n", circuit_name(k)); fflush(stdout);
+      Fe32 r, s; const bool fixed = parse_fixed_rs(r, s); Proof proof;
+      if (!prove_sharded(*set, fixed ? &r : nullptr, fixed ? &s : nullptr, proof)) { printf("can not generate %s proof\n", circuit_name(k)); fflush(stdout); proof = default_proof(); }
+      return dup_string(proof_to_hex(proof));
+    }
     double t0 = now(); HeldUnit held = acquire_prover(k); ProverUnit &slot = *held.unit; double t1 = now(); assign(*slot.circuit); double t2 = now();
     printf("Trying to generate %s proof...\n", circuit_name(k)); fflush(stdout);
     Fe32 r, s; bool fixed = parse_fixed_rs(r, s); Proof proof;

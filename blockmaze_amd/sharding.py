@@ -119,9 +119,13 @@ class Group:
     def __init__(self, backend, rank, world, local_rank, timeout_s=600):
         import datetime, torch, torch.distributed as dist
         self.dist, self.torch, self.backend, self.rank, self.world, self.local_rank = dist, torch, backend, rank, world, local_rank
+        self.host_group = None
         if backend == "nccl":
             self.device = torch.device("cuda", local_rank); torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s), device_id=self.device)
+            # the partial records of a sharded proof are 384 bytes a rank and ALREADY in host memory (the MSM kernels write their results into pinned host buffers): they
+            # are gathered over a second, host-side group (gloo) — no copy to the device and back around a collective of 384 bytes.  RCCL keeps the barrier and the reductions.
+            self.host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=timeout_s))
         else:
             self.device = torch.device("cpu"); dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
     def _tensor(self, values, dtype):
@@ -138,8 +142,9 @@ class Group:
         u = self._tensor([units_per_rank], self.torch.float64); self.dist.all_reduce(u, op=self.dist.ReduceOp.SUM)
         return float(u.item()) / float(t.item()), float(t.item())
     def gather_partials(self, partial_bytes):
-        mine = self.torch.frombuffer(bytearray(partial_bytes), dtype=self.torch.uint8).to(self.device)
-        out = [self.torch.empty_like(mine) for _ in range(self.world)]; self.dist.all_gather(out, mine)
-        return [bytes(t.cpu().numpy().tobytes()) for t in out]
+        """one fixed-size record per rank, in rank order, on every rank: host tensors over the host group (nccl runs) or over the only group there is (gloo runs)"""
+        mine = self.torch.frombuffer(bytearray(partial_bytes), dtype=self.torch.uint8)
+        out = [self.torch.empty_like(mine) for _ in range(self.world)]; self.dist.all_gather(out, mine, group=self.host_group)
+        return [bytes(t.numpy().tobytes()) for t in out]
     def close(self):
         self.dist.destroy_process_group()

@@ -52,18 +52,20 @@ def test_group_calls_bind_to_torch_signatures(monkeypatch):
     monkeypatch.setattr(dist, "all_reduce", bound(dist.all_reduce, fake_all_reduce)); monkeypatch.setattr(dist, "all_gather", bound(dist.all_gather, fake_all_gather))
     monkeypatch.setattr(dist, "barrier", bound(dist.barrier, lambda a: None)); monkeypatch.setattr(dist, "broadcast_object_list", bound(dist.broadcast_object_list, fake_bcast))
     monkeypatch.setattr(dist, "destroy_process_group", bound(dist.destroy_process_group, lambda a: None))
+    HOST = object(); monkeypatch.setattr(dist, "new_group", bound(dist.new_group, lambda a: HOST))                  # (the host-side gloo group of an nccl run: the 384-byte records)
     set_dev = []; monkeypatch.setattr(torch.cuda, "set_device", lambda d: set_dev.append(d))
     wanted = []
     class CpuTensors(sharding.Group):                                                   # (no GPU here: the tensors a rank would create on its device are made on the CPU)
         def _tensor(self, values, dtype): wanted.append(self.device); return torch.tensor(values, dtype=dtype)
-        def gather_partials(self, partial_bytes): dev = self.device; self.device = torch.device("cpu"); out = sharding.Group.gather_partials(self, partial_bytes); self.device = dev; return out
     g = CpuTensors("nccl", 0, 2, 0, timeout_s=77)
     init = calls[0][1]; assert calls[0][0] == "init_process_group" and init["backend"] == "nccl" and init["rank"] == 0 and init["world_size"] == 2
     assert init["device_id"] == torch.device("cuda", 0) and init["timeout"] == datetime.timedelta(seconds=77) and set_dev == [0] and g.device == torch.device("cuda", 0)
     g.barrier(); assert g.all_ok(True) is True and g.all_ok(False) is False
     assert g.share_from_rank0({"key_dir": "/tmp/x"}) == {"key_dir": "/tmp/x"}
     rate, slowest = g.aggregate_throughput(20, 2.0); assert slowest == 2.0 and rate == 10.0
+    ng = [c[1] for c in calls if c[0] == "new_group"]; assert len(ng) == 1 and ng[0]["backend"] == "gloo" and ng[0]["timeout"] == datetime.timedelta(seconds=77) and g.host_group is HOST
     recs = g.gather_partials(bytes(range(1, 97)) * 4); assert len(recs) == 2 and len(recs[0]) == 384 and recs[0][0] == 1 and recs[1][0] == 2
+    ag = [c[1] for c in calls if c[0] == "all_gather"][-1]; assert ag["group"] is HOST and ag["tensor"].device.type == "cpu"           # host tensors over the host group: nothing goes to the device and back
     g.close()
     names = [c[0] for c in calls]; assert names.count("all_reduce") == 4 and "all_gather" in names and "broadcast_object_list" in names and names[-1] == "destroy_process_group"
     assert all(d == torch.device("cuda", 0) for d in wanted)                             # every collective tensor of the nccl branch is asked for on this rank's GPU

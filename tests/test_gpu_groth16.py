@@ -356,6 +356,35 @@ def test_cgo_symbols_under_process_wide_switches(all_keys, env):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ZK_PRFKEY_DIR=str(all_keys), **env), timeout=600)
     assert "DENSE True True" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
+def test_cgo_symbols_with_sharded_msms(all_keys):
+    """ZK_SHARD_DEVICES=3 (capi_zk.cpp: prove_sharded): every gen*proof call runs on three shard provers — contiguous thirds of every query, here all on the box's one GPU —,
+    each on its own thread (replicated rows / transforms, its slice of the five MSMs, a 384-byte record of partial sums), the calling thread adds the records and assembles
+    the proof: no torch, no collective, what a go-ethereum process can use.  Proofs of send, mint and deposit are accepted by the per-proof verifier symbols of an
+    unsharded process, a statement that does not hold yields the failure sentinel, and two callers at once are served one after the other"""
+    code = """
+import os, sys, json, threading
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+from blockmaze_amd import engine as e
+import workload as w
+zk = e.Zk(); out = {}
+d = w.send_instance(31); out['send'] = [zk.GenSendProof(*w.send_args(d)), d['cmtA_old'].hex(), d['sn_old'].hex(), d['cmtS'].hex(), d['cmtA'].hex()]
+bad = dict(d); bad['value_s'] = d['value_s'] + 1; out['sentinel'] = zk.GenSendProof(*w.send_args(bad))
+m = w.mint_instance(32); out['mint'] = [zk.GenMintProof(*w.mint_args(m)), m['cmtA_old'].hex(), m['sn_old'].hex(), m['cmtA'].hex(), m['value_s']]
+dd = w.deposit_instance(33); out['deposit'] = [zk.GenDepositProof(*w.deposit_args(dd), dd['leaves'], dd['rt'], dd['sk'])] + [dd[k].hex() for k in ('rt', 'pk_recv', 'cmtB_old', 'sn_old', 'cmtB', 'sn_s')]
+two = [None, None]
+def call(i): two[i] = zk.GenSendProof(*w.send_args(d))
+ts = [threading.Thread(target=call, args=(i,)) for i in range(2)]; [t.start() for t in ts]; [t.join() for t in ts]; out['two'] = two
+print('RESULT ' + json.dumps(out))
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZK_PRFKEY_DIR=str(all_keys), ZK_SHARD_DEVICES="3"), capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]; assert line, (r.stdout[-2000:], r.stderr[-2000:]); out = json.loads(line[0][7:])
+    os.environ["ZK_PRFKEY_DIR"] = str(all_keys); zk = e.Zk(); B = bytes.fromhex
+    p, *a = out["send"]; assert len(p) == 512 and zk.VerifySendProof(p, *[B(x) for x in a]) and not zk.VerifySendProof(p, B(a[3]), B(a[1]), B(a[2]), B(a[0]))
+    assert out["sentinel"].startswith("0000000000") and out["sentinel"][:128] == "%064x%064x" % (1, 2)
+    p, *a = out["mint"]; assert zk.VerifyMintProof(p, B(a[0]), B(a[1]), B(a[2]), a[3])
+    p, *a = out["deposit"]; assert zk.VerifyDepositProof(p, *[B(x) for x in a])
+    d = out["send"][1:]; assert all(zk.VerifySendProof(q, *[B(x) for x in d]) for q in out["two"]) and out["two"][0] != out["two"][1]
+
 def test_gpu_verifier_failure_falls_back_to_the_host_verdict(all_keys):
     """a fault on the GPU branch of verify_group (here forced by ZK_TEST_FAIL_GPU_VERIFY in a fresh process) must not turn an accept into a reject: single-proof symbols
     and verifyBatch are then decided by the prepared host verifier, valid proofs stay valid, invalid ones stay invalid, and the failure is logged"""
