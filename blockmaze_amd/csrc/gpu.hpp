@@ -87,6 +87,7 @@ class MsmG1 {
   // scalars a_i * b_i * z (z: one element, or a table of n) formed inside the sort kernel; only when one_pass_sort() (uniform-scalar MSM with fixed-base
   // tables)
   bool one_pass_sort() const; void run_product(const Fe32 *a_dev, const Fe32 *b_dev, const Fe32 *z_dev, bool z_is_table);
+  void set_crowded(bool other_proofs_in_flight);   // uniform-scalar path: longer accumulation runs while the chip is shared with other proofs (msm_impl.hpp: h_run_crowded)
   host::HG1 result();
   // MSMs over the same scalar vector (same length, same window) can share one sort of its digits: the follower must be run after the leader, on the leader's
   // stream or on another one (it then waits for the leader's event). false if either side is not on the three-launch witness path.

@@ -16,6 +16,7 @@ void MsmG1::run_tagged(const Fe32 *z_all, const WitnessTags &wt, const uint32_t 
 bool MsmG1::one_pass_sort() const { return impl->hsort; }
 void MsmG1::run_product(const Fe32 *a, const Fe32 *b, const Fe32 *z, bool z_is_table) { impl->run_product(a, b, z, z_is_table); }
 void MsmG1::set_label(const char *l) { impl->label = l; }
+void MsmG1::set_crowded(bool c) { impl->crowded = c; }
 void MsmG1::set_stream(int aux) { impl->stream_id = aux; }
 void MsmG1::split_ones_path() { impl->enable_split_ones(); }
 host::HG1 MsmG1::result() { impl->finish_sync(); return combine<host::HFq, Fq>(impl->host_sums(), impl->RS, impl->bitsum ? 1 : impl->c); }

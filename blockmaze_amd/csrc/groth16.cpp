@@ -1550,7 +1550,7 @@ bool Prover::prove_stashed(size_t slot, const Fe32 *r_in, const Fe32 *s_in, Proo
   return prove_resident(r_in, s_in, out);
 }
 bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
-  Impl &p = *impl; LaneScope lane_scope(p.lane); BusyCall busy; double t1 = now_ms(); run_device(p);
+  Impl &p = *impl; LaneScope lane_scope(p.lane); BusyCall busy; double t1 = now_ms(); p.H->set_crowded(!busy.alone()); run_device(p);
   // host work overlapped with the kernels
   RsTerms t = rs_terms(r_in, s_in, p.delta_g1, p.delta_g2);
   double t2 = now_ms();

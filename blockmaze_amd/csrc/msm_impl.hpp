@@ -43,6 +43,10 @@ struct MsmImpl {
   HsortShape hs{0, 0, 0, 0};
   DevBuf<uint32_t> group_fill, mid, group_n;
   uint32_t h_run = 11, h_maxp = 16;
+  // Several proofs in flight (round 5): the chip is full whatever one accumulation's wave count is, so the runs are made longer — fewer pieces per bucket, i.e.
+  // fewer general additions in the combine (12.6 -> 4.2 pieces a bucket at 40: -6 % of a proof's instructions; six provers in flight 1,730 -> 1,875 proofs/s,
+  // prove_batch(64) 1,680 -> 1,860; 24 / 32 / 48: 1,843 / 1,858 / 1,835; profiles/r05_hacc_sweeps.txt).  One proof at a time keeps the short runs: its latency is the accumulation's last partial round.
+  uint32_t h_run_crowded = 40; bool crowded = false;
   // witness MSMs in three launches (k_wsort / k_wacc / k_wtail); needs the fixed-base tables and at most 128 buckets
   bool wfused = false, ws_leader = true, overflow_noted = false; std::shared_ptr<WsortBuffers> ws;
   const Fe32 *last_scalars = nullptr; const uint32_t *last_index = nullptr;
@@ -217,6 +221,7 @@ struct MsmImpl {
       const int v = atoi(e);
       if (v >= 4 && v <= 64) h_run = (uint32_t)v;
     }
+    { const char *e2 = getenv("ZK_MSM_H_RUN_CROWDED"); const long v2 = e2 ? atol(e2) : 0; if (v2 >= 4 && v2 <= 64) h_run_crowded = (uint32_t)v2; }
     // (G1, uniform scalars — G2 keeps a 261-form table for another purpose: k_wacc_lanes_g2_29) group-binned one-pass sort: G groups of 2^low buckets, about 16
     // K entries per group (one workgroup sorts a group in registers + LDS)
     if (sizeof(F) == 32 && uniform_hint && bases->points261.size()) {
@@ -419,6 +424,7 @@ struct MsmImpl {
       // one lane per run: at most ceil(entries / run) + one short run per group
       {
         Stage st((label + ".accumulate").c_str(), s);
+        const uint32_t h_run = crowded ? std::max(this->h_run, h_run_crowded) : this->h_run;   // (pieces are laid out by h_maxp, sized for the shorter run)
         const dim3 grid(cdiv(cdiv(n * (size_t)W, h_run) + hs.groups, 256));
         if (any_inf) hipLaunchKernelGGL(k_hacc_runs29<1>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(),
             offsets.get(), hs, h_run, h_maxp | zk_prio_bits("hacc"), (Piece29 *)partials.get(), cnt);
@@ -428,6 +434,7 @@ struct MsmImpl {
       // 2 / 4 / 8 lanes per bucket: about six pieces a lane (send: 12 pieces, two lanes; deposit at depth 32: 48 pieces — two lanes took 256 us there)
       {
         Stage st((label + ".combine").c_str(), s);
+        const uint32_t h_run = crowded ? std::max(this->h_run, h_run_crowded) : this->h_run;
         const size_t pieces = n * (size_t)W / NB / h_run;
         const uint32_t ll = pieces > 40 ? 3 : pieces > 18 ? 2 : 1;
         hipLaunchKernelGGL(k_hacc_combine29, dim3(cdiv(nbk << ll, 256)), dim3(256), 0, s, (const Piece29 *)partials.get(), offsets.get(), hist(), hs, h_run,
