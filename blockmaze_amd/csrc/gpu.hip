@@ -594,8 +594,8 @@ void Domain::fft_with_factors(Fe32 *data, int batch, size_t stride, const Fe32 *
   // scratch: 3B]
   hipStream_t s = gpu().stream; Fe32 *dbuf = d.scratch.get(), *tmp = d.scratch.get() + 3 * d.B;
   hipLaunchKernelGGL(k_step_fwd_pre, dim3(cdiv(d.B, 256), batch), dim3(256), 0, s, (Fr *)data, (Fr *)dbuf, (const Fr *)d.wpow.get(), (const Fr *)cf,
-      (uint32_t)d.B, (uint32_t)d.S | zk_prio_bits("step"), stride);
-  hipLaunchKernelGGL(k_step_fold, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (const Fr *)dbuf, (Fr *)data, (uint32_t)d.B, (uint32_t)d.S | zk_prio_bits("step"), stride);
+      (uint32_t)d.B, (uint32_t)d.S | (d.S < (1u << 24) ? zk_prio_bits("step") : 0u), stride);
+  hipLaunchKernelGGL(k_step_fold, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (const Fr *)dbuf, (Fr *)data, (uint32_t)d.B, (uint32_t)d.S | (d.S < (1u << 24) ? zk_prio_bits("step") : 0u), stride);
   // (dbuf is free again after the fold: the S-point transform's scratch)
   radix2_transform_pair(NttCall{data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B},
       NttCall{data + d.B, dbuf, d.small->tw.get(), d.small->tw261.get(), d.small->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, batch);
@@ -615,7 +615,7 @@ void Domain::ifft(Fe32 *data, int batch, size_t stride) {
       stride, d.B}, batch);
   Fr half; memcpy(&half, d.half.l, 32);
   hipLaunchKernelGGL(k_step_inv_post, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half,
-      (uint32_t)d.B, (uint32_t)d.S | zk_prio_bits("step"), stride);
+      (uint32_t)d.B, (uint32_t)d.S | (d.S < (1u << 24) ? zk_prio_bits("step") : 0u), stride);
 }
 void Domain::ifft_then_coset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl;
@@ -641,7 +641,7 @@ void Domain::ifft_then_coset_fft(Fe32 *data, int batch, size_t stride) {
         d.B}, NttCall{data + d.B, dbuf, d.small->itw.get(), d.small->itw261.get(), d.small->logn, d.scale_small.get(), nullptr, d.inv_small261, nullptr,
         stride, d.B}, batch);
     hipLaunchKernelGGL(k_step_inv_fwd, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half,
-        (const Fr *)d.coset_fwd.get(), (uint32_t)d.B, (uint32_t)d.S | zk_prio_bits("step"), stride);
+        (const Fr *)d.coset_fwd.get(), (uint32_t)d.B, (uint32_t)d.S | (d.S < (1u << 24) ? zk_prio_bits("step") : 0u), stride);
   }
   { Stage st("ntt.forward");
     radix2_transform_pair(NttCall{data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B},
@@ -791,7 +791,7 @@ void expand_witness_dev(const uint8_t *packed, size_t words, const Fe32 &one_val
   const uint32_t *off = (const uint32_t *)(ones + nbm * words); const Fr *vals = (const Fr *)(packed + expand_values_offset(words, canon));
   Fr one; memcpy(&one, &one_value, 32);
   hipLaunchKernelGGL(k_expand_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, ones, other,
-      canon == 0 ? (const uint64_t *)nullptr : canon == 1 ? other : third, off, vals, one, (uint32_t)n | zk_prio_bits("expand"), (Fr *)out, tags, other_vars);
+      canon == 0 ? (const uint64_t *)nullptr : canon == 1 ? other : third, off, vals, one, (uint32_t)n | (n < ((size_t)1 << 24) ? zk_prio_bits("expand") : 0u), (Fr *)out, tags, other_vars);   // (the priority rides in bits 24..: not for 16 M variables and more)
 }
 void fr_to_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_to_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
 void fr_from_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_from_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
