@@ -258,7 +258,7 @@ def run_rank(args):
         # B witnesses against one resident key in one call (BASELINE.json configs[2]: a batch of independent send proofs)
         if args.batch > 1 and hasattr(prover, "prove_batch"):
             import numpy as np
-            B = args.batch; batch = np.ascontiguousarray(np.stack([zs[i % n_inst] for i in range(B)])); proofs = prover.prove_batch(batch); reps = max(2, min(6, 128 // B)); t0 = time.perf_counter()   # the B assignments back to back in one host buffer
+            B = args.batch; batch = np.ascontiguousarray(np.stack([zs[i % n_inst] for i in range(B)])); proofs = prover.prove_batch(batch); reps = max(4, min(6, 256 // B)); t0 = time.perf_counter()   # the B assignments back to back in one host buffer
             for _ in range(reps): proofs = prover.prove_batch(batch)
             dtb = time.perf_counter() - t0
             ok = all(e.verify(vk_path, proofs[k], w.pack_public([insts[k % n_inst][x] for x in ("cmtA_old", "sn_old", "cmtS", "cmtA")])) for k in (0, B - 1))
