@@ -621,9 +621,8 @@ void Domain::ifft_then_coset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl;
   if (batch > 3) throw GpuError("domain: batch > 3");
   if (!d.step) {
-    // ZK_NTT_FOLD_COSET=0: the two transforms as they are called one by one (g^i multiplied in by the forward transform's column pass)
-    static const bool fold = [] { const char *e = getenv("ZK_NTT_FOLD_COSET"); return !e || atoi(e) != 0; }();
-    if (!fold || !d.t->inv_coset261.get()) { ifft(data, batch, stride); coset_fft(data, batch, stride); return; }
+    // (without the folded table: the two transforms as they are called one by one, g^i multiplied in by the forward transform's column pass)
+    if (!d.t->inv_coset261.get()) { ifft(data, batch, stride); coset_fft(data, batch, stride); return; }
     { Stage st("ntt.inverse");      // 1/m and g^i leave with the row pass's last product
       radix2_transform(NttCall{data, d.scratch.get(), d.big->itw.get(), d.big->itw261.get(), d.big->logn, nullptr, nullptr, d.inv_big261, nullptr, stride,
           d.scratch_stride, d.t->inv_coset261.get()}, batch); }

@@ -849,10 +849,10 @@ static void finish_setup(Prover::Impl &p) {
   // MSMs over the same scalars share one sort: L* follows A, the two halves of the B query follow each other
   {
     p.pair_AL = p.c_fold && p.a0 == p.l0 && p.L->share_sort_with(p.A->sort_handle());
-    // Since the end of round 4 the G1 half leads and the G2 half follows (ZK_B1_FIRST=0: the other way round, as before): both halves are then done 0.65 ms into the
+    // Since the end of round 4 the G1 half leads and the G2 half follows (round 4's measurement, profiles/r04y_b1_first.txt; the switch is gone): both halves are then done 0.65 ms into the
     // call instead of 0.76 — less of the chain falls beside the H accumulation, which stretched it —, the host has its last scalar multiple (r * B1) ready 0.16 instead of
     // 0.06 ms before the device finishes, and the device side is 4 us shorter (tools/trace_tail.py, profiles/r04y_b1_first.txt)
-    static const bool b1_first = env_int("ZK_B1_FIRST", 1) != 0;
+    const bool b1_first = true;
     p.b2_first = !b1_first;
     p.pair_B = b1_first ? p.B2->share_sort_with(p.B1->sort_handle()) : p.B1->share_sort_with(p.B2->sort_handle());
   }
@@ -1421,11 +1421,8 @@ static void enqueue_all(Prover::Impl &p) {
   // since the witness path is one light sort per pair, starting it beside the gather-bound row kernel is worth 4 % of a host-buffer proof (1.095 -> 1.05 ms
   // median, tools/ab_steps.sh); later release points only move the contention into the transforms and the H accumulation (profiles/r03i_ab_start.txt, and again
   // at the end of round 3: 1.06-1.19 against 1.01 ms).
-  // four digits 0..4, one per job (B2, L, A [+ L], B1 [+ B2]); measurement switch
-  static const std::array<int, 4> start = [] {
-    std::array<int, 4> v{0, 0, 0, 0};
-    const char *e = getenv("ZK_WMSM_START");
-    for (int j = 0; e && j < 4 && e[j] >= '0' && e[j] <= '4'; j++) v[j] = e[j] - '0'; return v; }();
+  // (release point 0 for all four jobs: the measurement switch of rounds 3-4 is gone)
+  const std::array<int, 4> start{0, 0, 0, 0};
   // about 80 launches per proof, and the runtime takes several microseconds of host time for each: helper threads submit the four witness MSMs
   // (auxiliary streams) while this one submits the critical chain
   static const bool threaded = [] { const char *e = getenv("ZK_SUBMIT_THREADS"); return !e || atoi(e) > 0; }();
@@ -1436,9 +1433,9 @@ static void enqueue_all(Prover::Impl &p) {
   constexpr bool skip_w = false, skip_h = false, skip_n = false;
 #endif
   Prover::Impl *pp = &p;
-  // (an assignment that arrived in compact form: the witness MSMs sort from its tags — WitnessTags, k_wsort_tagged; ZK_WSORT_TAGGED=0 keeps the scalar-reading
-  // sort)
-  static const bool sort_tags = env_int("ZK_WSORT_TAGGED", 1) != 0; const bool tg = sort_tags && p.tags_valid;
+  // (an assignment that arrived in compact form: the witness MSMs sort from its tags — WitnessTags, k_wsort_tagged; a dense hand-over
+  // — ZK_WITNESS_DENSE, or an assignment that is not mostly zeros and ones — keeps the scalar-reading sort)
+  const bool tg = p.tags_valid;
   auto wt = [pp, tg](const uint32_t *var_pos, size_t base) {
     WitnessTags t;
     if (tg) {
@@ -1499,8 +1496,7 @@ static void enqueue_all(Prover::Impl &p) {
     }
   };
   release(0, 0);
-  static const bool use_tags = env_int("ZK_ROWS_TAGGED", 1) != 0;
-  p.cs->eval(p.z.get(), p.abc.get(), p.m, use_tags && p.tags_valid ? p.tags.get() : nullptr, !p.c_fold); release(0, 1); release(1, 0);
+  p.cs->eval(p.z.get(), p.abc.get(), p.m, p.tags_valid ? p.tags.get() : nullptr, !p.c_fold); release(0, 1); release(1, 0);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
   const int nvec = p.c_fold ? 2 : 3;                          // A, B (and C unless it is folded into the L query)
   // iFFT, then cosetFFT (a step domain runs the passes between the two as one kernel)
@@ -1572,9 +1568,8 @@ bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
   p.settle(0); HG2 gB2 = p.beta_g2.add(p.rB2).add(t.s_delta2); out.B = raw_of(gB2); double tb2 = now_ms();                                              // :492
   gpu_sync(); double t3 = now_ms();
   // the next proof's hand-over is usually microseconds away (proofs come back to back): the scan helpers are woken now — they poll for ZK_SPIN_US before they
-  // sleep again — while this thread finishes the proof (ZK_SCAN_NUDGE=0: they are woken by the scan itself, 30-50 us late)
-  static const bool nudge = env_int("ZK_SCAN_NUDGE", 1) != 0;
-  if (nudge && busy.alone() && g_calls_busy.load(std::memory_order_acquire) == 1) ScanPool::get().nudge();
+  // sleep again — while this thread finishes the proof (without it they are woken by the scan itself, 30-50 us late: profiles/r04y_nudge_ab.txt)
+  if (busy.alone() && g_calls_busy.load(std::memory_order_acquire) == 1) ScanPool::get().nudge();
   // (rocprofv3's kernel trace is stamped with CLOCK_BOOTTIME: t1_boot places this proof on its time line)
   if (trace) {
     timespec bt;

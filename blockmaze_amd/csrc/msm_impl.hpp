@@ -221,7 +221,6 @@ struct MsmImpl {
       const int v = atoi(e);
       if (v >= 4 && v <= 64) h_run = (uint32_t)v;
     }
-    { const char *e2 = getenv("ZK_MSM_H_RUN_CROWDED"); const long v2 = e2 ? atol(e2) : 0; if (v2 >= 4 && v2 <= 64) h_run_crowded = (uint32_t)v2; }
     // (G1, uniform scalars — G2 keeps a 261-form table for another purpose: k_wacc_lanes_g2_29) group-binned one-pass sort: G groups of 2^low buckets, about 16
     // K entries per group (one workgroup sorts a group in registers + LDS)
     if (sizeof(F) == 32 && uniform_hint && bases->points261.size()) {
