@@ -699,6 +699,7 @@ int zkgpu_test_scan_blocks(const uint8_t *tags64, const uint64_t *elems64x4, con
   return guarded_host([&] { test_scan_blocks(tags64, elems64x4, one4, out10); return ZKGPU_OK; });
 }
 /* the hand-over's scan pool (groth16.cpp: ScanPool) driven from `callers` threads at once, host only: rounds that ran on the pool (>= 0), -1 if a chunk was counted twice or not at all */
+int zkgpu_test_cgroup_quota(const char *root) { int out = -1; guarded_host([&] { out = test_cgroup_quota(root); return ZKGPU_OK; }); return out; }
 int zkgpu_test_scan_pool(int callers, int rounds) { int out = -1; guarded_host([&] { out = test_scan_pool(callers, rounds); return ZKGPU_OK; }); return out; }
 /* host-only self-test of the container code (tests/test_key_container_cpu.py): a synthetic transformed key of the given shape is written, mapped back and compared; then the
  * file is truncated, a payload byte is flipped, and the source stamp is changed — each must make the loader refuse.  Returns 0 if every step behaved. */

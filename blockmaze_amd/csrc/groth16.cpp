@@ -672,18 +672,20 @@ void generate_keys(const R1csHost &cs_in, const ToxicWaste &tw, ProvingKeyHost &
 // machine's size): a rank that a launcher pinned to two cores of a 256-thread host must not start sixteen polling helpers.  A cgroup CPU quota counts as well
 // (cpu.max of cgroup v2, cpu.cfs_quota_us / cpu.cfs_period_us of v1): go-ethereum under a Kubernetes CPU limit without a cpuset sees every CPU of the host in its
 // affinity mask, and fifteen spinning helpers would get the process throttled on the proof's critical path.
-static unsigned cgroup_cpu_quota() {   // 0: none
+static unsigned cgroup_cpu_quota(const char *root = "/sys/fs/cgroup") {   // 0: none
+  const std::string r(root), v2 = r + "/cpu.max", v1q = r + "/cpu/cpu.cfs_quota_us", v1p = r + "/cpu/cpu.cfs_period_us";
   auto read2 = [](const char *path, long long &a, long long &b, bool two) -> bool {
     FILE *f = fopen(path, "r"); if (!f) return false; char t[64] = {0}; bool ok;
     if (two) { ok = fscanf(f, "%63s %lld", t, &b) == 2; if (ok) { if (!strcmp(t, "max")) a = -1; else a = atoll(t); } }
     else ok = fscanf(f, "%lld", &a) == 1;
     fclose(f); return ok; };
   long long quota = -1, period = 0;
-  if (read2("/sys/fs/cgroup/cpu.max", quota, period, true)) { if (quota > 0 && period > 0) return (unsigned)std::max<long long>(1, (quota + period - 1) / period); return 0; }
-  if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", quota, period, false) && quota > 0) { long long per = 0, dummy = 0;
-    if (read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", per, dummy, false) && per > 0) return (unsigned)std::max<long long>(1, (quota + per - 1) / per); }
+  if (read2(v2.c_str(), quota, period, true)) { if (quota > 0 && period > 0) return (unsigned)std::max<long long>(1, (quota + period - 1) / period); return 0; }
+  if (read2(v1q.c_str(), quota, period, false) && quota > 0) { long long per = 0, dummy = 0;
+    if (read2(v1p.c_str(), per, dummy, false) && per > 0) return (unsigned)std::max<long long>(1, (quota + per - 1) / per); }
   return 0;
 }
+int test_cgroup_quota(const char *root) { return (int)cgroup_cpu_quota(root); }   // (host-only test hook: the quota a cgroup directory tree states, 0 = none)
 static unsigned usable_cpus() {
   static const unsigned v = [] {
     unsigned n = 0; cpu_set_t set; CPU_ZERO(&set);

@@ -101,6 +101,7 @@ int zkgpu_key_container_valid(const char *pk_path);
 int zkgpu_test_device_plan(const char *spec, int n_visible, int fallback, int per_device, int *out_devices, int *out_order, int n_order);   /* multi-device pool planning (pure host logic) */
 int zkgpu_test_pool_plan(int n_devices, int spill, const int *release_before, int n_calls, int *out_dev);   /* acquire_prover's device choice replayed on the host (capi_zk.cpp) */
 int zkgpu_test_scan_blocks(const uint8_t *tags64, const uint64_t *elems64x4, const uint64_t *one4, uint64_t *out10);   /* the hand-over's block classifiers: out[0..2] / [3..5] tag masks scalar / fast, out[6..7] / [8..9] element masks scalar / fast */
+int zkgpu_test_cgroup_quota(const char *root);   /* the CPU quota the library would respect when sizing its helper pools (host only): CPUs, rounded up, 0 = none */
 int zkgpu_test_scan_pool(int callers, int rounds);   /* the hand-over's scan pool driven from several threads at once (host only): rounds served by the pool, -1 on a miscount */
 int zkgpu_test_lane_plan(int n_slots, int kinds, int per_kind, int *out_lanes_per_slot);   /* the stream-lane planner with its per-device quota (gpu.hip) */
 int zkgpu_test_key_container(const char *path, size_t n_vars, size_t n_cons, size_t m);   /* host-only self-test of the container reader / writer; 0 = passed */     /* 1 if a valid container (matching size / mtime of the key file, checksum) is in place */

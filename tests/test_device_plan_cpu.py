@@ -53,3 +53,17 @@ def test_scan_pool_counts_every_chunk_once_under_concurrent_callers():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ZK_SCAN_THREADS="4", ZK_SPIN_US="50"), timeout=300)
     tok = r.stdout.split(); assert "POOL" in tok, (r.stdout[-300:], r.stderr[-800:]); a, b = int(tok[tok.index("POOL") + 1]), int(tok[tok.index("POOL") + 2])
     assert a == 300 and 1 <= b <= 1200                      # a lone caller always gets the pool; four callers share it, nobody miscounts (-1)
+
+
+def test_helper_pools_respect_a_cgroup_cpu_quota(tmp_path):
+    """ADVICE (round 4): go-ethereum under a Kubernetes CPU limit without a cpuset sees every CPU of a 256-thread host in its affinity mask; sixteen polling scan helpers
+    would get the process throttled on the proof's critical path.  usable_cpus() = min(affinity, quota): cpu.max of cgroup v2, cpu.cfs_quota_us / cpu.cfs_period_us of v1"""
+    import ctypes
+    from blockmaze_amd import engine as e
+    L = e.lib(); q = lambda d: L.zkgpu_test_cgroup_quota(str(d).encode())
+    v2 = tmp_path / "v2"; v2.mkdir(); (v2 / "cpu.max").write_text("max 100000\n"); assert q(v2) == 0
+    (v2 / "cpu.max").write_text("250000 100000\n"); assert q(v2) == 3                                    # 2.5 CPUs: three threads may run
+    (v2 / "cpu.max").write_text("50000 100000\n"); assert q(v2) == 1
+    v1 = tmp_path / "v1"; (v1 / "cpu").mkdir(parents=True); (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n"); (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n"); assert q(v1) == 0
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("400000\n"); assert q(v1) == 4
+    assert q(tmp_path / "nothing") == 0
