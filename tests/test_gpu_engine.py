@@ -127,6 +127,29 @@ def test_h_path_degenerate_additions_fall_back_and_stay_exact():
     for i in range(1000, 1100, 2): P[i + 1] = neg(P[i]); S[i + 1] = S[i]
     run(P, S)
 
+@pytest.mark.parametrize("group", [1, 2], ids=["G1", "G2"])
+def test_witness_path_degenerate_points_fall_back_and_stay_exact(group):
+    """the fused witness path (window 8, filter_ones) on points a key could legally hold but the incomplete additions of its folds and tails (htail29.cuh quad29_add,
+    oct29.cuh oct29_add — and the G2 lanes) cannot add: every point EQUAL (every fold addition is P + P: ZZ = 0 mod p, flagged, the general path repeats the MSM with
+    complete formulas), P / -P pairs (sums that are the point at infinity: tracked as flags, exact), repeated points inside an ordinary query — with the scalars a witness
+    has (mostly 0 / 1, some small values).  The oracle's sum every time, and the resident object keeps working"""
+    n = 1200 if group == 1 else 480; g = o.SplitMix64(900 + group); base = (o.g1_consecutive if group == 1 else o.g2_consecutive)(g.field(), n); half = base.shape[1] // 2
+    ref = (lambda P, K: o.msm_g1(P, K, mixed=True)) if group == 1 else (lambda P, K: o.msm_g2(P, K, mixed=True)); dec = o.g1_from if group == 1 else o.g2_from
+    def neg(pt):
+        r = pt.copy(); ys = o.from_arr(pt[half:].reshape(-1, 4)); r[half:] = o.to_arr([(o.Q_MOD - y) % o.Q_MOD for y in ys]).reshape(-1); return r
+    def run(P, K):
+        m = e.ResidentMsm(group, P, 8, filter_ones=True); m.set_scalars(K); assert dec(m.run())[0] == ref(P, K)
+        K2 = witness_like_scalars(31, len(P)); m.set_scalars(K2); assert dec(m.run())[0] == ref(P, K2); m.close()
+    ones = o.to_arr([1] * n); small = o.to_arr([5] * n); wl = witness_like_scalars(30 + group, n)
+    same = np.repeat(base[:1], n, axis=0); run(same, ones); run(same, small); run(same, wl)                  # every point equal
+    P = base.copy()
+    for i in range(0, n, 2): P[i + 1] = neg(P[i])
+    m = e.ResidentMsm(group, P, 8, filter_ones=True); m.set_scalars(ones); assert dec(m.run())[0] is None and ref(P, ones) is None; m.close()   # P, -P, all ones: zero
+    run(P, small); run(P, wl)
+    P = base.copy(); P[100:200] = P[99]; P[300:340] = P[7]                                                  # repeated points inside an ordinary query
+    for i in range(400, 440, 2): P[i + 1] = neg(P[i])
+    run(P, ones); run(P, wl)
+
 def test_msm_degenerate_inputs():
     assert o.g1_from(e.msm(1, np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)))[0] is None         # empty
     P = o.g1_consecutive(5, 64); assert o.g1_from(e.msm(1, P, np.zeros((64, 4), np.uint64), filter_ones=True))[0] is None   # all-zero scalars
