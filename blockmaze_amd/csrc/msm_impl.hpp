@@ -211,12 +211,15 @@ struct MsmImpl {
       HIP_CHECK(hipEventCreateWithFlags(&ws->sorted, hipEventDisableTiming)); }
     max_tasks = (uint32_t)((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1);
     // (tuning knob: entries per lane of the H accumulation)
-    // All lanes of the H accumulation do the same amount of work, so the chip runs it in lock-step rounds of workgroups and the last round's fill decides:
-    // swept once more at the end of round 4 in steps of one, whole proofs (profiles/r04y_hrun_sweep.txt): runs of 11 beat 12 for mint / redeem (+1.5 %), send
-    // (device side 0.828 -> 0.816 ms) and deposit at depth 8 (668 -> 720 proofs/s); at depth 32 (18.9 M entries, exactly six rounds of 12) 12 stays ahead of 11
-    // by 4 %. (A stand-alone measurement at key load picks 13 everywhere — right for the MSM alone, wrong inside a proof, where the witness MSMs hold part of
-    // the chip: 0.85 ms.)
-    h_run = n * (size_t)W > ((size_t)12 << 20) ? 12 : 11;
+    // All lanes of the H accumulation do the same amount of work, so the chip runs it in lock-step rounds of workgroups and the last round's fill decides.
+    // Swept in steps of one inside whole proofs, on the prover's own device clock, after the wave priorities of round 5 changed what else holds the chip
+    // meanwhile (profiles/r05_hacc_sweeps.txt, two passes of 100 proofs per point): send 0.751-0.764 ms at 11, 0.737-0.747 at 14; mint / redeem flat within
+    // noise from 11 to 16; deposit at depth 8 (8.4 M entries) best at 11 (1.249 against 1.260-1.264 at 14); deposit at depth 32 (18.9 M) 2.97 at 11-13,
+    // 2.89-2.91 at 15. (A stand-alone measurement of the MSM picks 13 everywhere: wrong inside a proof, where the witness MSMs hold part of the chip.)
+    {
+      const size_t total = n * (size_t)W;
+      h_run = total > ((size_t)12 << 20) ? 15 : total > ((size_t)6 << 20) ? 11 : 14;
+    }
     if (const char *e = getenv("ZK_MSM_H_RUN")) {
       const int v = atoi(e);
       if (v >= 4 && v <= 64) h_run = (uint32_t)v;
