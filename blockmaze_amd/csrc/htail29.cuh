@@ -177,12 +177,13 @@ __global__ void __launch_bounds__(256) k_hmarg29(const Point29Rec *__restrict__ 
   const uint32_t first = column ? g + 1 : hi * L + piece * (L / RC);                   // weight of the first one ...
   const uint32_t step = column ? L : 1;                                                // ... and the distance to the next
   QPoint29 acc = quad29_inf();
+  const uint32_t nq = blockDim.x >> 2;
   if (q < count) {
     acc = quad29_load(buckets + (first + q * step - 1), k);
 #pragma unroll 1
-    for (uint32_t j = q + 64; j < count; j += 64) acc = quad29_add(acc, quad29_load(buckets + (first + j * step - 1), k), k);
+    for (uint32_t j = q + nq; j < count; j += nq) acc = quad29_add(acc, quad29_load(buckets + (first + j * step - 1), k), k);
   }
-  acc = block_quad29_tree(acc, lds, min(count, 64u));
+  acc = block_quad29_tree(acc, lds, min(count, nq));
   if (threadIdx.x < 4) quad29_store(marg + (column ? g + 1 : L + hi * RC + piece), acc, k);
 }
 
@@ -261,12 +262,13 @@ __global__ void __launch_bounds__(256) k_wfold29(const Point29Rec *__restrict__ 
   uint32_t beg, len;
   if (b < NB) { beg = lane_off[b]; len = lane_off[b + 1] - beg; } else { beg = bucket_lanes + (b - NB) * 256; len = 256; }
   QPoint29 acc = quad29_inf();
+  const uint32_t nq = blockDim.x >> 2;
   if (q < len) {
     acc = quad29_load(partial + beg + q, k);
 #pragma unroll 1
-    for (uint32_t j = q + 64; j < len; j += 64) acc = quad29_add(acc, quad29_load(partial + beg + j, k), k);
+    for (uint32_t j = q + nq; j < len; j += nq) acc = quad29_add(acc, quad29_load(partial + beg + j, k), k);
   }
-  acc = block_quad29_tree(acc, lds, min(len, 64u));
+  acc = block_quad29_tree(acc, lds, min(len, nq));
   if (threadIdx.x < 4) quad29_store(out + b, acc, k);
 }
 template <int UNIT>

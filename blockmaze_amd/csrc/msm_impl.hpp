@@ -438,7 +438,7 @@ struct MsmImpl {
         Stage st((label + ".combine").c_str(), s);
         const uint32_t h_run = crowded ? std::max(this->h_run, h_run_crowded) : this->h_run;
         const size_t pieces = n * (size_t)W / NB / h_run;
-        const uint32_t ll = pieces > 40 ? 3 : pieces > 18 ? 2 : 1;
+        const uint32_t ll = pieces > 40 ? 3 : pieces > 18 ? 2 : 1;   // (send, runs of 14: 9 pieces; two and four lanes measure the same, eight lose 30 us)
         hipLaunchKernelGGL(k_hacc_combine29, dim3(cdiv(nbk << ll, 256)), dim3(256), 0, s, (const Piece29 *)partials.get(), offsets.get(), hist(), hs, h_run,
             h_maxp, (uint32_t)nbk, ll | zk_prio_bits("htail"), (XYZZ<Fq> *)bucket_array(), htail29 ? (Point29Rec *)hb29.get() : nullptr, cnt);
       }
@@ -488,7 +488,11 @@ struct MsmImpl {
       if constexpr (sizeof(F) == 32) {
         Stage st_red((label + ".reduce").c_str(), s);
       const HtailShape ts = htail_shape(NB);
-      hipLaunchKernelGGL(k_hmarg29<0>, dim3(htail_marg_blocks(ts)), dim3(256), 0, s, (const Point29Rec *)hb29.get(), NB | zk_prio_bits("htail"), (Point29Rec *)hmarg.get());
+      // one wave per row piece / column of up to 128 buckets (7 additions in a row, then the wave's tree of 4): as fast as four waves with 1 + 6 — a wave alone
+      // issues an instruction every ~8 cycles whatever it does — at 40 % of their instructions, which is what counts with other proofs in flight
+      // (profiles/r05_hacc_sweeps.txt)
+      const uint32_t marg_block = std::max(1u << ts.hi_bits, (1u << ts.lo_bits) / ts.row_chunks) <= 128 ? 64 : 256;
+      hipLaunchKernelGGL(k_hmarg29<0>, dim3(htail_marg_blocks(ts)), dim3(marg_block), 0, s, (const Point29Rec *)hb29.get(), NB | zk_prio_bits("htail"), (Point29Rec *)hmarg.get());
       hipLaunchKernelGGL(k_hbits29<0>, dim3(ts.top + 1), dim3(256), 0, s, (const Point29Rec *)hmarg.get(), NB | zk_prio_bits("htail"), (XYZZ<Fq> *)res, cnt, (uint4 *)(res + RS + 1));
     }
   }

@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(OCT_BLOCK) k_wfold_g2_29(const Point29Rec2 *__
     uint32_t bucket_lanes, Point29Rec2 *__restrict__ out) {
   zk_take_prio(NB);
   __shared__ Point29Rec2 lds[OCT_BLOCK / 64];
-  const uint32_t b = blockIdx.x, q = threadIdx.x >> 3, nq = OCT_BLOCK / 8;
+  const uint32_t b = blockIdx.x, q = threadIdx.x >> 3, nq = blockDim.x >> 3;
   const int e = threadIdx.x & 7, k = e & 3; const bool h0 = e < 4;
   uint32_t beg, len;
   if (b < NB) { beg = lane_off[b]; len = lane_off[b + 1] - beg; } else { beg = bucket_lanes + (b - NB) * 256; len = 256; }
