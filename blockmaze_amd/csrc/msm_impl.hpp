@@ -211,8 +211,8 @@ struct MsmImpl {
       HIP_CHECK(hipEventCreateWithFlags(&ws->sorted, hipEventDisableTiming)); }
     max_tasks = (uint32_t)((n * (size_t)W * 2) / MSM_TASK + (size_t)WB * NB + 1);
     // (tuning knob: entries per lane of the H accumulation)
-    // All lanes of the H accumulation do the same amount of work, so the chip runs it in lock-step rounds of workgroups and the last round's fill decides.
-    // Swept in steps of one inside whole proofs, on the prover's own device clock, after the wave priorities of round 5 changed what else holds the chip
+    // Short runs mean more pieces for the combine, long runs a longer drain at the end of the launch (waves are handed out as slots fall free: alone on the
+    // chip, runs of 11 lose nothing to the last round, runs of 14 cost 25 us) — and inside a proof the witness MSMs hold part of the chip meanwhile.  Swept in steps of one inside whole proofs, on the prover's own device clock, after the wave priorities of round 5 changed what else holds the chip
     // meanwhile (profiles/r05_hacc_sweeps.txt, two passes of 100 proofs per point): send 0.751-0.764 ms at 11, 0.737-0.747 at 14; mint / redeem flat within
     // noise from 11 to 16; deposit at depth 8 (8.4 M entries) best at 11 (1.249 against 1.260-1.264 at 14); deposit at depth 32 (18.9 M) 2.97 at 11-13,
     // 2.89-2.91 at 15. (A stand-alone measurement of the MSM picks 13 everywhere: wrong inside a proof, where the witness MSMs hold part of the chip.)
@@ -489,7 +489,7 @@ struct MsmImpl {
         Stage st_red((label + ".reduce").c_str(), s);
       const HtailShape ts = htail_shape(NB);
       // one wave per row piece / column of up to 128 buckets (7 additions in a row, then the wave's tree of 4): as fast as four waves with 1 + 6 — a wave alone
-      // issues an instruction every ~8 cycles whatever it does — at 40 % of their instructions, which is what counts with other proofs in flight
+      // on its SIMD issues an instruction every 6-8 cycles whatever it does — at 40 % of their instructions, which is what counts with other proofs in flight
       // (profiles/r05_hacc_sweeps.txt)
       const uint32_t marg_block = std::max(1u << ts.hi_bits, (1u << ts.lo_bits) / ts.row_chunks) <= 128 ? 64 : 256;
       hipLaunchKernelGGL(k_hmarg29<0>, dim3(htail_marg_blocks(ts)), dim3(marg_block), 0, s, (const Point29Rec *)hb29.get(), NB | zk_prio_bits("htail"), (Point29Rec *)hmarg.get());
