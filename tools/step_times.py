@@ -20,13 +20,31 @@ tmp = tempfile.mkdtemp(); pk, vk = os.path.join(tmp, "sendpk.txt"), os.path.join
 for i in range(16):
     d = w.send_instance(i); wp = os.path.join(tmp, "w.bin"); e.witness_send(*[("0x" + a.hex()) if isinstance(a, bytes) else a for a in w.send_args(d)], wp); zs.append(place(o.load_witness(wp)))
 for i in range(10): p.prove(zs[i % 16])
-ts = []; parts = []
+def sched():
+    """per thread of this process: (ms on a CPU, ms runnable but waiting for one, time slices) from /proc/self/task/*/schedstat; and the cgroup's throttling counters"""
+    out = {}
+    for t in os.listdir("/proc/self/task"):
+        try: a, b, c = open("/proc/self/task/%s/schedstat" % t).read().split(); out[int(t)] = (int(a) / 1e6, int(b) / 1e6, int(c))
+        except Exception: pass
+    return out
+def throttle():
+    try: return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat")) if k in ("nr_periods", "nr_throttled", "throttled_usec")}
+    except Exception: return {}
+import threading
+main_tid = threading.get_native_id(); s0 = sched(); th0 = throttle()
+ts = []; parts = []; waits = []
 for i in range(N):
+    w0 = int(open("/proc/self/task/%d/schedstat" % main_tid).read().split()[1])
     t0 = time.perf_counter(); p.prove(zs[i % 16]); ts.append(1e3 * (time.perf_counter() - t0)); parts.append(p.timings())
+    waits.append((int(open("/proc/self/task/%d/schedstat" % main_tid).read().split()[1]) - w0) / 1e6)
+s1 = sched(); th1 = throttle()
 s = sorted(ts); pct = lambda q: s[min(len(s) - 1, int(q * len(s)))]
 print("%d steps: mean %.3f ms, min %.3f, p10 %.3f, median %.3f, p90 %.3f, p99 %.3f, max %.3f; steps above 1.5 x median: %d (they add %.3f ms to the mean)" % (N, sum(ts) / N, s[0], pct(0.1), pct(0.5), pct(0.9), pct(0.99), s[-1], sum(1 for t in ts if t > 1.5 * pct(0.5)), sum(t - pct(0.5) for t in ts if t > 1.5 * pct(0.5)) / N))
 med = lambda k: sorted(d[k] for d in parts)[len(parts) // 2]
 print("  medians of the prover's own clocks: " + ", ".join("%s %.3f" % (k, med(k)) for k in ("upload_ms", "enqueue_ms", "device_ms", "finish_ms", "total_ms")) + "; cpus allowed %d; AnonHugePages of this process %s kB" % (len(os.sched_getaffinity(0)), next((l.split()[1] for l in open("/proc/self/smaps_rollup") if l.startswith("AnonHugePages")), "?")))
 slow = [(t, d) for t, d in zip(ts, parts) if t > 1.5 * pct(0.5)]
 if slow: print("  the slow steps' own clocks (step: upload / device / finish ms): " + "; ".join("%.2f: %.2f / %.2f / %.2f" % (t, d["upload_ms"], d["device_ms"], d["finish_ms"]) for t, d in slow[:12]))
+print("  the calling thread waited for a CPU (schedstat run delay): %.3f ms in all, %.3f ms of it inside the %d slow steps (%s)" % (sum(waits), sum(x for t, x in zip(ts, waits) if t > 1.5 * pct(0.5)), len(slow), ", ".join("%.2f" % x for t, x in zip(ts, waits) if t > 1.5 * pct(0.5))[:200]))
+print("  per thread over the run (ms on a CPU / ms waiting for one / slices): " + "; ".join("%s%.0f / %.1f / %d" % ("main " if t == main_tid else "", s1[t][0] - s0.get(t, (0, 0, 0))[0], s1[t][1] - s0.get(t, (0, 0, 0))[1], s1[t][2] - s0.get(t, (0, 0, 0))[2]) for t in sorted(s1) if s1[t][0] - s0.get(t, (0, 0, 0))[0] > 1.0))
+if th1: print("  cgroup cpu.stat over the run: " + ", ".join("%s +%d" % (k, th1[k] - th0.get(k, 0)) for k in th1) + "; cpu.max: " + open("/sys/fs/cgroup/cpu.max").read().strip())
 print("RESULT median_ms %.4f p10_ms %.4f device_ms %.4f upload_ms %.4f" % (pct(0.5), pct(0.1), med("device_ms"), med("upload_ms")))
