@@ -327,7 +327,7 @@ def run_rank(args):
     # profiles/r05_hacc_counters.json measured (rocprofv3 kernel trace, ZK_MSM_ONE_STREAM=1)
     try:
         hc = json.load(open(os.path.join(ROOT, "profiles", "r05_hacc_counters.json"))); alone_ms = hc["wall_us_mean_kernel_trace_only"] / 1e3
-        roofline["avg_launch_ms_alone"] = round(alone_ms, 4); roofline["achieved_alone"] = round(H_PAIRS * BYTES_PER_G1_PAIR / (alone_ms * 1e-3) / 1e9, 3); roofline["alone_source"] = "profiles/r05_hacc_counters.json"
+        roofline["avg_launch_ms_alone"] = round(alone_ms, 4); roofline["achieved_alone"] = round(H_PAIRS * BYTES_PER_G1_PAIR / (alone_ms * 1e-3) / 1e9, 3); roofline["alone_source"] = "profiles/r05_hacc_counters.json"; roofline["frac_alone"] = round(roofline["achieved_alone"] / 8000.0, 6); roofline["note"] = "inside a proof the launch shares the chip with the witness MSMs, which the wave priorities of round 5 deliberately place under it (proof 0.81 -> 0.74 ms while this launch went 0.31 -> 0.35 ms); alone it takes avg_launch_ms_alone"
     except Exception: alone_ms = None
     # what actually bounds that kernel: 254-bit field arithmetic on the integer VALU.  A lane lifts the first point of every piece of its run of 11 sorted
     # entries and adds the others: one mixed addition = 8 products + 2 squarings on nine 29-bit limbs = 2,366 VALU instructions in the loop's ISA (profiles/r05_hacc_isa.txt):
