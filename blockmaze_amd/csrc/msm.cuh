@@ -946,7 +946,9 @@ __global__ void __launch_bounds__(256) k_wsort_tagged(const Fr *__restrict__ z, 
 // k_wacc_lanes + k_wacc_fold replace the first version of k_wacc (one workgroup of 64 quads per bucket, measured: 188 us, every SIMD of the chip busy with quad
 // arithmetic and with tree levels in which most quads idle — 0.5 ms of the machine per proof for 5 % of its field products). Accumulation is lane-serial (10
 // products per point, no exchange overhead, 160 waves in all); only the trees are cooperative, and they skip the levels a short list does not need.
-constexpr uint32_t WFUSED_BUCKET_LANES = 4096, WFUSED_ONES_LANES = 8192, WFUSED_ONES_GROUPS = WFUSED_ONES_LANES / 256, WFUSED_MIN_SLICE = 8;
+// (lane counts swept again at the end of round 5, whole send proofs, device side: buckets 2048 / 4096 / 8192 / 12288 / 16384 with 8192 for the ones: 0.795 / 0.736 /
+// 0.7325 / 0.737 / 0.759 ms; ones 4096 / 6144 / 8192 / 16384 with 8192 for the buckets: 0.778 / 0.743 / 0.7325 / 0.749 — profiles/r05_hacc_sweeps.txt)
+constexpr uint32_t WFUSED_BUCKET_LANES = 8192, WFUSED_ONES_LANES = 8192, WFUSED_ONES_GROUPS = WFUSED_ONES_LANES / 256, WFUSED_MIN_SLICE = 8;
 // Lanes are dealt to the buckets in proportion to their fill (a witness puts thousands of equal values into one bucket): slice length T = total / lanes, bucket
 // b gets ceil(fill_b / T) lanes, lane_off[] (NB + 1 prefix sums, recomputed by every workgroup, written out by the first) tells the next kernel where each
 // bucket's partial sums lie. The lane-serial accumulation of a G1 witness MSM on 29-bit limbs (round 4): k_wacc_lanes with the arithmetic of k_hacc_runs29 —
@@ -963,7 +965,7 @@ __global__ void __launch_bounds__(256) k_wacc_lanes29(const Affine<Fq> *__restri
   zk_take_prio(NB);
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ uint32_t m_of[WFUSED_MAX_BUCKETS], off[WFUSED_MAX_BUCKETS + 1], slice;
-  const bool ones_lane = t >= WFUSED_BUCKET_LANES;                                       // (whole workgroups: 4096 is a multiple of 256)
+  const bool ones_lane = t >= WFUSED_BUCKET_LANES;                                       // (whole workgroups: the lane counts are multiples of 256)
   if (!ones_lane) {
     if (threadIdx.x < NB) m_of[threadIdx.x] = min(fill[threadIdx.x], cap);
     __syncthreads();
@@ -1098,7 +1100,7 @@ __global__ void __launch_bounds__(256) k_wacc_lanes_g2_29(const Affine<Fq2> *__r
   zk_take_prio(NB);
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ uint32_t m_of[WFUSED_MAX_BUCKETS], off[WFUSED_MAX_BUCKETS + 1], slice;
-  const bool ones_lane = t >= WFUSED_BUCKET_LANES;                                       // (whole workgroups: 4096 is a multiple of 256)
+  const bool ones_lane = t >= WFUSED_BUCKET_LANES;                                       // (whole workgroups: the lane counts are multiples of 256)
   if (!ones_lane) {
     if (threadIdx.x < NB) m_of[threadIdx.x] = min(fill[threadIdx.x], cap);
     __syncthreads();
