@@ -249,7 +249,7 @@ __device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq>
     bad = k == 2 && out.is_zero_lazy();
     out = out.normalize();
   }
-  if (bad) atomicOr(&cnt->pad[0], 1u);
+  if (bad) atomicOr(&cnt->pad[0], 2u);                                                   // (bit 1: a degenerate sum; bit 0: a sort region overflowed)
   reinterpret_cast<Fq *>(slot)[k] = out;
 }
 template <int UNIT>

@@ -309,7 +309,9 @@ struct MsmImpl {
     if (wfused && host_counters()->pad[0]) {
       if (!overflow_noted) {
         overflow_noted = true;
-        fprintf(stderr, "libzkgpu: %s: a bucket of the witness sort overflowed (%u slots), general MSM path used\n", label.c_str(), ws->cap);
+        const uint32_t why = host_counters()->pad[0];
+        fprintf(stderr, "libzkgpu: %s: %s%s(flag %u; %u slots a bucket), general MSM path used\n", label.c_str(), (why & 1u) ? "a bucket of the witness sort overflowed " : "",
+            (why & 2u) ? "a sum of the fold / tail met an operand equal to +-its partner (ZZ = 0) " : "", why, ws->cap);
       }
       wfused = false; run_impl(last_scalars, last_index); HIP_CHECK(hipStreamSynchronize(stream())); wfused = true; }
     if (hsort && host_counters()->pad[0]) { const Fe32 *sc = last_scalars; hsort = false;

@@ -150,7 +150,7 @@ __device__ __forceinline__ void oct29_emit(const OPoint29 &acc, int e, XYZZ<Fq2>
     out = out.normalize();
   }
   const uint32_t both = zero & oct29_partner_u32(zero);
-  if (e == 2 && both && !acc.inf) atomicOr(&cnt->pad[0], 1u);
+  if (e == 2 && both && !acc.inf) atomicOr(&cnt->pad[0], 2u);
   reinterpret_cast<Fq *>(slot)[2 * k + h] = out;
 }
 
