@@ -196,8 +196,9 @@ def run_rank(args):
             if rc != 0: raise RuntimeError("zkgpu_prover_prove failed: %s" % _lib.zkgpu_last_error().decode())
             return _out
         # INPUTS RESIDENT IN HBM when the timed region starts (the contract's `value`): every distinct statement of the run is handed over once, before the clock starts, and
-        # kept in device memory (zkgpu_prover_stash_witness: the assignment, its tags, the list of its non-trivial values — 7.5 MB each); a step proves the next one
-        # (zkgpu_prover_prove_stashed: one device-to-device copy on the prover's stream, then the whole pipeline).  The host-buffer-inclusive rate is `value_from_host_buffers`.
+        # kept in device memory AS THE RAW ASSIGNMENT (zkgpu_prover_stash_witness: (n + 1) x 32 B, 7.3 MB each, nothing derived from it); a step proves the next one
+        # (zkgpu_prover_prove_stashed): the tags and the list of values other than 0 / 1 — the classification of libsnark's multi_exp_with_mixed_addition — are derived by a
+        # device kernel inside the timed call, then the whole pipeline runs on the stash in place.  The host-buffer-inclusive rate is `value_from_host_buffers`.
         slots = []
         for z in zs: prover.set_witness(z); slots.append(ctypes.c_uint32(prover.stash_witness()))
         def one_proof(i):
@@ -217,6 +218,18 @@ def run_rank(args):
     last = None; step_t[0] = t0
     for i in range(args.steps): last = one_proof(args.warmup + i); step_t[i + 1] = clock()        # (one clock read per step: the spread of the timed region goes into the line)
     barrier(); dt = clock() - t0; gc.enable()
+    # the same prover call handed a fresh HOST buffer every step (scan of the 7.3 MB assignment into its compact form, one 0.3 MB copy over PCIe, the expansion on the
+    # device): the same K steps, the same barriers, the same percentiles, in every mode — `value_from_host_buffers`, what rounds 1-4 reported as `value`
+    hb_rate = hb_step_ms = None
+    if not shard:
+        gc.collect(); gc.disable()
+        for i in range(args.warmup): host_buffer_proof(i)
+        hb_t = [0.0] * (args.steps + 1); barrier(); hb_t[0] = clock()
+        for i in range(args.steps): host_buffer_proof(args.warmup + i); hb_t[i + 1] = clock()
+        barrier(); hb_dt = clock() - hb_t[0]; gc.enable()
+        hb_rate, hb_dt = (args.steps / hb_dt, hb_dt) if grp is None else grp.aggregate_throughput(args.steps, hb_dt)
+        hb_per = sorted(1e3 * (b - a) for a, b in zip(hb_t, hb_t[1:])); hpct = lambda q: round(hb_per[min(len(hb_per) - 1, int(q * len(hb_per)))], 4) if hb_per else None
+        hb_step_ms = {"p10": hpct(0.10), "p50": hpct(0.50), "p90": hpct(0.90), "min": round(hb_per[0], 4) if hb_per else None, "max": round(hb_per[-1], 4) if hb_per else None, "ms_per_step": round(1e3 * hb_dt / args.steps, 4), "upload_ms_last": round(prover.timings()["upload_ms"], 4)}
     units = (args.steps if rank == 0 else 0) if shard else args.steps
     rate, dt = (units / dt, dt) if grp is None else grp.aggregate_throughput(units, dt)           # max over ranks, units summed
     per_step = sorted(1e3 * (b - a) for a, b in zip(step_t, step_t[1:])); pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 4) if per_step else None
@@ -228,12 +241,6 @@ def run_rank(args):
     extra = {}; cpu_files = {}                                     # cpu_files: circuit legs whose libsnark time is reported beside them
     if world == 1 and not args.no_extra_legs:                      # (N > 1: only the timed region and the roofline leg — the driver's scaling runs pass no flags)
         nx = max(3, min(args.steps, 50))
-        # the same prover call on a fresh HOST buffer every step (hand-over included: the scan of the 7.3 MB assignment into its compact form, one 0.3 MB copy over PCIe, the
-        # expansion on the device): the pessimistic figure, rounds 1-4 reported it as `value`
-        for i in range(3): host_buffer_proof(i)
-        t_hb = []
-        for i in range(nx): t0 = time.perf_counter(); host_buffer_proof(3 + i); t_hb.append(1e3 * (time.perf_counter() - t0))
-        ms_hb = sum(t_hb) / nx; t_hb.sort(); extra["from_host_buffers"] = {"steps": nx, "ms_per_proof": round(ms_hb, 4), "proofs_per_s": round(1e3 / ms_hb, 2), "ms_p50": round(t_hb[nx // 2], 4), "upload_ms_last": round(prover.timings()["upload_ms"], 4)}
         # through the drop-in cgo symbol genSendproof (adds witness generation on the host and hex marshalling), one caller and several at once as go-ethereum's goroutines do
         # (the first call builds the key's pool of provers; each of them starts its helper threads with its first proof: five untimed calls, then n_abi timed ones whose
         # argument tuples were built beforehand — what is timed is the symbol, one caller, a different instance every call)
@@ -323,12 +330,20 @@ def run_rank(args):
     roofline = {"bound": "hbm", "kernel": "k_hacc_runs29 (bucket accumulation of the H-query MSM)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": H_PAIRS * BYTES_PER_G1_PAIR}
     # The kernel shares the chip by design since round 5: the witness MSMs run at a higher wave priority and take their issue slots out of this kernel (gpu_internal.hpp:
-    # zk_prio_bits), so its duration INSIDE a proof (avg_launch_ms, what `achieved` is computed from) includes their work; alone on the chip it takes what
-    # profiles/r05_hacc_counters.json measured (rocprofv3 kernel trace, ZK_MSM_ONE_STREAM=1)
-    try:
-        hc = json.load(open(os.path.join(ROOT, "profiles", "r05_hacc_counters.json"))); alone_ms = hc["wall_us_mean_kernel_trace_only"] / 1e3
-        roofline["avg_launch_ms_alone"] = round(alone_ms, 4); roofline["achieved_alone"] = round(H_PAIRS * BYTES_PER_G1_PAIR / (alone_ms * 1e-3) / 1e9, 3); roofline["alone_source"] = "profiles/r05_hacc_counters.json"; roofline["frac_alone"] = round(roofline["achieved_alone"] / 8000.0, 6); roofline["note"] = "inside a proof the launch shares the chip with the witness MSMs, which the wave priorities of round 5 deliberately place under it (proof 0.81 -> 0.74 ms while this launch went 0.31 -> 0.35 ms); alone it takes avg_launch_ms_alone"
-    except Exception: alone_ms = None
+    # zk_prio_bits), so its duration INSIDE a proof (avg_launch_ms, what `achieved` is computed from) includes their work.  Its duration ALONE on the chip is measured in this
+    # run too: a second prover object on the same resident key with everything on ONE stream (ZK_MSM_ONE_STREAM read at construction), the same HIP-event stage timer
+    alone_ms = None
+    if not shard:
+        try:
+            os.environ["ZK_MSM_ONE_STREAM"] = "1"; solo = prover.clone(); del os.environ["ZK_MSM_ONE_STREAM"]
+            for i in range(3): solo.prove(zs[i % n_inst])
+            e.profile_enable(True)
+            for i in range(nprof): solo.prove(zs[i % n_inst])
+            st1 = e.profile_report(); e.profile_enable(False); solo.close(); alone_ms = st1[dom]["ms_total"] / st1[dom]["count"]
+            roofline["avg_launch_ms_alone"] = round(alone_ms, 4); roofline["achieved_alone"] = round(H_PAIRS * BYTES_PER_G1_PAIR / (alone_ms * 1e-3) / 1e9, 3); roofline["alone_source"] = "measured in this run: a one-stream prover object on the same key, HIP events, %d launches" % st1[dom]["count"]; roofline["frac_alone"] = round(roofline["achieved_alone"] / HBM_PEAK_GBS, 6)
+            roofline["note"] = "inside a proof the launch shares the chip with the witness MSMs, which the wave priorities deliberately place under it; alone it takes avg_launch_ms_alone"
+        except Exception as ex:
+            os.environ.pop("ZK_MSM_ONE_STREAM", None); log("bench: no stand-alone launch time (%s)" % ex); alone_ms = None
     # what actually bounds that kernel: 254-bit field arithmetic on the integer VALU.  A lane lifts the first point of every piece of its run of 11 sorted
     # entries and adds the others: one mixed addition = 8 products + 2 squarings on nine 29-bit limbs = 2,366 VALU instructions in the loop's ISA (profiles/r05_hacc_isa.txt):
     # 1,644 quarter-rate ones (v_mad_u64_u32, v_mul_lo_u32: 4.3 cycles per wave-instruction and SIMD, tools/valu_probe.hip) and 722 full-rate ones (2.25 cycles) — 3.67 cycles
@@ -380,7 +395,7 @@ def run_rank(args):
     if rank == 0:
         line = {
             "metric": "Groth16 proofs/sec (send circuit, alt_bn128)", "value": round(rate, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4), "step_ms": step_ms, "value_p50": (round(1e3 / step_ms["p50"] * (1 if shard else world), 4) if step_ms.get("p50") else None), "value_from_host_buffers": (extra.get("from_host_buffers") or {}).get("proofs_per_s"), "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery; all MSM accumulations, the H query's weighted bucket sum and the transforms' tiles on nine 29-bit limbs)", "data": "synthetic witnesses (seeded send instances, every constraint satisfied) on a proving key made by this repo's GPU generator for the real send circuit; only the libsnark CPU leg uses a key with synthetic points of the same shape",
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "step_ms": step_ms, "value_p50": (round(1e3 / step_ms["p50"] * (1 if shard else world), 4) if step_ms.get("p50") else None), "value_from_host_buffers": (round(hb_rate, 4) if hb_rate else None), "host_buffers_step_ms": hb_step_ms, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery; all MSM accumulations, the H query's weighted bucket sum and the transforms' tiles on nine 29-bit limbs)", "data": "synthetic witnesses (seeded send instances, every constraint satisfied) on a proving key made by this repo's GPU generator for the real send circuit; only the libsnark CPU leg uses a key with synthetic points of the same shape",
             "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "distinct_witnesses": n_inst,
                        "host_binding": host_binding, "clock_warmup": "%d untimed proofs ahead of the %d warm-up steps (the GPU's clocks need ~30 ms of load to rise after the idle set-up)" % (clock_warmup, args.warmup), "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
                        "includes": "one prover call per step on the next of the run's distinct statements, all of them RESIDENT IN HBM when the timed region starts (handed over before the clock starts, kept in device memory; a step copies its assignment device-to-device and proves it): R1CS rows, the 7 NTTs of the witness map (4 run per proof; both transforms of C and the final inverse are folded into the L and H queries at key load), 5 MSM, host proof assembly, hex serialisation; excludes witness generation and key load.  `value_p50` = 1 / the median step (the mean carries the host's rare 2-5 ms steps); `value_from_host_buffers` = the same prover call handed a fresh host buffer every step (scan + PCIe + expansion included; N = 1 only) — what rounds 1-4 reported as `value`" if not shard else "one proof per step cut into shards; host-buffer hand-over included"},

@@ -871,6 +871,13 @@ int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t
 int zkgpu_prover_stash_witness(zkgpu_prover *h, uint32_t *slot) {
   return guarded_prover(h, [&] { if (!h || !slot) return ZKGPU_ERR_ARG; *slot = (uint32_t)h->p->stash_witness(); return ZKGPU_OK; });
 }
+int zkgpu_prover_drop_stash(zkgpu_prover *h, uint32_t slot) {
+  return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; h->p->drop_stash(slot == 0xffffffffu ? (size_t)-1 : (size_t)slot); return ZKGPU_OK; });
+}
+int zkgpu_prover_stash_count(zkgpu_prover *h, uint32_t *count) {
+  if (!h || !count) return ZKGPU_ERR_ARG;
+  *count = (uint32_t)h->p->stash_count(); return ZKGPU_OK;
+}
 int zkgpu_prover_prove_stashed(zkgpu_prover *h, uint32_t slot, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_prover(h, [&] {
     if (!h) return ZKGPU_ERR_ARG; Proof p;
   if (!h->p->prove_stashed(slot, (const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system");

@@ -335,7 +335,7 @@ static Fe32 fe261(HFr v) {
 struct NttCall { Fe32 *data, *scratch; const Fe32 *tw, *tw261; int logn; const Fe32 *pre_scale, *pre261; Fe32 scale261; const Fe32 *post_scale;
     size_t stride, scratch_stride; const Fe32 *out261 = nullptr; };   // out261: two-pass range only (NttJob::out261)
 // radix-4 passes measured best with two vectors per launch (twice the waves of radix 8: the passes are latency bound), radix 8 with three
-static int ntt_prio_bits() { static const int v = (int)(zk_prio_bits("ntt") >> 24) << 8; return v; }
+static int ntt_prio_bits() { static const int v = (int)(zk_prio_bits(ZKP_NTT) >> 24) << 8; return v; }
 static int ntt_radix_log() {
   static const int rl = [] {
     const char *e = getenv("ZK_NTT_RADIX_LOG");
@@ -594,8 +594,8 @@ void Domain::fft_with_factors(Fe32 *data, int batch, size_t stride, const Fe32 *
   // scratch: 3B]
   hipStream_t s = gpu().stream; Fe32 *dbuf = d.scratch.get(), *tmp = d.scratch.get() + 3 * d.B;
   hipLaunchKernelGGL(k_step_fwd_pre, dim3(cdiv(d.B, 256), batch), dim3(256), 0, s, (Fr *)data, (Fr *)dbuf, (const Fr *)d.wpow.get(), (const Fr *)cf,
-      (uint32_t)d.B, (uint32_t)d.S | (d.S < (1u << 24) ? zk_prio_bits("step") : 0u), stride);
-  hipLaunchKernelGGL(k_step_fold, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (const Fr *)dbuf, (Fr *)data, (uint32_t)d.B, (uint32_t)d.S | (d.S < (1u << 24) ? zk_prio_bits("step") : 0u), stride);
+      (uint32_t)d.B, zk_with_prio(d.S, ZKP_STEP), stride);
+  hipLaunchKernelGGL(k_step_fold, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (const Fr *)dbuf, (Fr *)data, (uint32_t)d.B, zk_with_prio(d.S, ZKP_STEP), stride);
   // (dbuf is free again after the fold: the S-point transform's scratch)
   radix2_transform_pair(NttCall{data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B},
       NttCall{data + d.B, dbuf, d.small->tw.get(), d.small->tw261.get(), d.small->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B}, batch);
@@ -615,7 +615,7 @@ void Domain::ifft(Fe32 *data, int batch, size_t stride) {
       stride, d.B}, batch);
   Fr half; memcpy(&half, d.half.l, 32);
   hipLaunchKernelGGL(k_step_inv_post, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half,
-      (uint32_t)d.B, (uint32_t)d.S | (d.S < (1u << 24) ? zk_prio_bits("step") : 0u), stride);
+      (uint32_t)d.B, zk_with_prio(d.S, ZKP_STEP), stride);
 }
 void Domain::ifft_then_coset_fft(Fe32 *data, int batch, size_t stride) {
   Impl &d = *impl;
@@ -640,7 +640,7 @@ void Domain::ifft_then_coset_fft(Fe32 *data, int batch, size_t stride) {
         d.B}, NttCall{data + d.B, dbuf, d.small->itw.get(), d.small->itw261.get(), d.small->logn, d.scale_small.get(), nullptr, d.inv_small261, nullptr,
         stride, d.B}, batch);
     hipLaunchKernelGGL(k_step_inv_fwd, dim3(cdiv(d.S, 256), batch), dim3(256), 0, s, (Fr *)data, (const Fr *)d.wpow.get(), (const Fr *)d.winvpow.get(), half,
-        (const Fr *)d.coset_fwd.get(), (uint32_t)d.B, (uint32_t)d.S | (d.S < (1u << 24) ? zk_prio_bits("step") : 0u), stride);
+        (const Fr *)d.coset_fwd.get(), (uint32_t)d.B, zk_with_prio(d.S, ZKP_STEP), stride);
   }
   { Stage st("ntt.forward");
     radix2_transform_pair(NttCall{data, tmp, d.big->tw.get(), d.big->tw261.get(), d.big->logn, nullptr, nullptr, d.one261, nullptr, stride, d.B},
@@ -790,7 +790,14 @@ void expand_witness_dev(const uint8_t *packed, size_t words, const Fe32 &one_val
   const uint32_t *off = (const uint32_t *)(ones + nbm * words); const Fr *vals = (const Fr *)(packed + expand_values_offset(words, canon));
   Fr one; memcpy(&one, &one_value, 32);
   hipLaunchKernelGGL(k_expand_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, ones, other,
-      canon == 0 ? (const uint64_t *)nullptr : canon == 1 ? other : third, off, vals, one, (uint32_t)n | (n < ((size_t)1 << 24) ? zk_prio_bits("expand") : 0u), (Fr *)out, tags, other_vars);   // (the priority rides in bits 24..: not for 16 M variables and more)
+      canon == 0 ? (const uint64_t *)nullptr : canon == 1 ? other : third, off, vals, one, zk_with_prio(n, ZKP_EXPAND), (Fr *)out, tags, other_vars);   // (the priority rides in bits 24..: not for 16 M variables and more)
+}
+// tags and the list of other values of an assignment that already lies in device memory (k_classify_witness): counters[parity] receives the list's length,
+// counters[parity ^ 1] is cleared for the next call
+void classify_witness_dev(const Fe32 *z, size_t n, uint8_t *tags, uint32_t *other_vars, uint32_t *counters, int parity) {
+  Fr one; memcpy(&one, FrParams::R1, 32);
+  hipLaunchKernelGGL(k_classify_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (const Fr *)z, one, zk_with_prio(n, ZKP_EXPAND), tags, other_vars,
+      counters + (parity & 1), counters + ((parity & 1) ^ 1));
 }
 void fr_to_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_to_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
 void fr_from_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_from_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
@@ -868,7 +875,7 @@ void R1csDev::eval(const Fe32 *z, Fe32 *abc, size_t m, const uint8_t *tags, bool
   if (tags) {   // the assignment came in compact form: a byte per variable says 0 / 1 / other (k_r1cs_rows_tagged)
     const uint32_t sb = (uint32_t)cdiv(m, 256);
     hipLaunchKernelGGL(k_r1cs_rows_tagged, dim3(sb + (unsigned)cdiv(d.n_long_any, 4)), dim3(256), 0, s, M, (const Fr *)d.ctab.get(), (const Fr *)z, tags,
-        (uint32_t)d.n_cons, (uint32_t)d.n_inputs | zk_prio_bits("rows"), (uint32_t)m,
+        (uint32_t)d.n_cons, zk_with_prio(d.n_inputs, ZKP_ROWS), (uint32_t)m,
                        (const uint32_t *)d.long_any.get(), (uint32_t)d.n_long_any, sb, write_c ? 1 : 0, (Fr *)abc, d.seq, d.d_fail);
     return; }
   // rows of more than 16 terms exist: the one-launch form (short rows and one wave per long row) const uint32_t sb = (uint32_t)cdiv(m, 256);

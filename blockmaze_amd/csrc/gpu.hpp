@@ -66,7 +66,8 @@ struct WsortBuffers;                           // the sorted witness digits an M
 struct WitnessTags {
   const uint8_t *tags = nullptr;        // one byte per variable (variable 0 = ONE): 0 the value is zero, 1 it is one, 2 anything else
   const uint32_t *other_vars = nullptr; // the variables tagged 2, ascending
-  uint32_t n_other = 0;
+  uint32_t n_other = 0;                // the list's length — or, with n_other_dev set, an upper bound of it (it sizes the launch)
+  const uint32_t *n_other_dev = nullptr; // the length in device memory, where the list was made on the device (k_classify_witness): no trip to the host
   // indexed queries (B): position of a variable in the query's index list, 0xffffffff if it has no point; null for plain queries
   const uint32_t *var_pos = nullptr;
   uint32_t base = 0;                    // plain query: point i belongs to variable base + i; indexed query: first position of this slice of the index list
@@ -177,6 +178,8 @@ inline size_t expand_values_offset(size_t words, int canon) { return (((canon ==
 // compact assignment upload (ntt.cuh: k_expand_witness)
 void expand_witness_dev(const uint8_t *packed_dev, size_t words, const Fe32 &one_value, int canon, size_t n, Fe32 *out, uint8_t *tags_out = nullptr,
     uint32_t *other_vars_out = nullptr);
+// the same tags and list from an assignment that already lies in device memory (ntt.cuh: k_classify_witness); counters = two words, alternating by parity
+void classify_witness_dev(const Fe32 *z, size_t n, uint8_t *tags_out, uint32_t *other_vars_out, uint32_t *counters, int parity);
 
 // Key loading: y-coordinates of compressed points (x Montgomery; flags bit0 = parity of canonical y, bit1 = point at infinity). Throws if an x is not on the
 // curve.

@@ -17,17 +17,25 @@ namespace zk {
 // leaves and still finish before the accumulation needs the whole chip (device side of a send proof 0.812 -> 0.765 ms; every other ranking tried is slower:
 // profiles/r05_priorities.txt).  ZK_PRIO="family:level,..." overrides single families (ntt, rows, hsort, htail, step, expand, wit, wlanes, hacc; 0 = the hardware's
 // default for everything: ZK_PRIO=off).  The level travels in bits 24.. of a small integer argument (field29.cuh: zk_take_prio).
-inline uint32_t zk_prio_bits(const char *family) {
-  static const std::string s = [] { const char *e = getenv("ZK_PRIO"); return std::string(e ? e : ""); }();
-  static const char *defaults = "ntt:3,rows:3,hsort:3,htail:3,step:3,expand:3,wit:2,wlanes:2,hacc:0";
-  if (s == "off") return 0;
-  const std::string key = std::string(family) + ":";
-  for (const std::string &src : {s, std::string(defaults)}) {
-    const size_t at = src.find(key);
-    if (at != std::string::npos && (at == 0 || src[at - 1] == ',')) { const int v = atoi(src.c_str() + at + key.size()); return (uint32_t)(v < 0 ? 0 : v > 3 ? 3 : v) << 24; }
-  }
-  return 0;
+// (the nine families are resolved ONCE, at first use, into a table indexed by an enumerator: a launch pays one array read, not three std::strings)
+enum ZkPrioFamily { ZKP_NTT, ZKP_ROWS, ZKP_HSORT, ZKP_HTAIL, ZKP_STEP, ZKP_EXPAND, ZKP_WIT, ZKP_WLANES, ZKP_HACC, ZKP_FAMILIES };
+inline uint32_t zk_prio_bits(ZkPrioFamily family) {
+  struct Table { uint32_t bits[ZKP_FAMILIES]; Table() {
+    static const char *const names[ZKP_FAMILIES] = {"ntt", "rows", "hsort", "htail", "step", "expand", "wit", "wlanes", "hacc"};
+    static const int dflt[ZKP_FAMILIES] = {3, 3, 3, 3, 3, 3, 2, 2, 0};
+    const char *e = getenv("ZK_PRIO"); const std::string s = e ? e : "";
+    for (int f = 0; f < ZKP_FAMILIES; f++) {
+      int v = dflt[f];
+      if (s == "off") v = 0;
+      else { const std::string key = std::string(names[f]) + ":"; const size_t at = s.find(key);
+        if (at != std::string::npos && (at == 0 || s[at - 1] == ',')) v = atoi(s.c_str() + at + key.size()); }
+      bits[f] = (uint32_t)(v < 0 ? 0 : v > 3 ? 3 : v) << 24;
+    } } };
+  static const Table t;
+  return t.bits[family];
 }
+// the priority rides in bits 24.. of a small integer argument: a value that does not leave them free travels without one (the kernel then runs at the hardware's default)
+inline uint32_t zk_with_prio(size_t arg, ZkPrioFamily family) { return (uint32_t)arg | (arg < ((size_t)1 << 24) ? zk_prio_bits(family) : 0u); }
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw GpuError(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 class GpuContext {
  public:

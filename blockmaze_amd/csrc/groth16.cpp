@@ -799,8 +799,14 @@ struct Prover::Impl {
   std::shared_ptr<DevBuf<uint32_t>> B_pos /* inverse of the B query's index list */;
   uint32_t n_other = 0;
   bool tags_valid = false /* the assignment on the device came in compact form: tags holds 0 / 1 / 2 per variable */;
-  struct Stash { DevBuf<Fe32> z; DevBuf<uint8_t> tags; DevBuf<uint32_t> other_vars; uint32_t n_other = 0; bool tags_valid = false; };
-  std::vector<std::unique_ptr<Stash>> stashes;                 // assignments kept in HBM (Prover::stash_witness)
+  // assignments kept in HBM (Prover::stash_witness): the RAW vector only — n x 32 B, Montgomery form as libsnark holds it; tags and the list of other values are
+  // derived on the device inside every prove_stashed call.  z_cur: the vector the running proof reads (this prover's z, or a stash in place — no copy)
+  struct Stash { DevBuf<Fe32> z; };
+  std::vector<std::unique_ptr<Stash>> stashes;
+  const Fe32 *z_cur = nullptr; bool z_set = false;
+  bool one_stream = false;                                     // diagnostic (ZK_MSM_ONE_STREAM at construction): every kernel on the main stream, submitted by the calling thread in order
+  DevBuf<uint32_t> other_count;                                // two words, alternating: the length of a list made on the device (k_classify_witness)
+  int classify_parity = 0; bool n_other_on_device = false;
   PinnedBuf<Fe32> z_host;
   std::unique_ptr<SubmitWorker> workers[4];
   // submit thread t (1 .. 3) of this prover, idle while the assignment is handed over: the scan's helpers when the process's ScanPool is taken by another
@@ -847,7 +853,7 @@ static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &
 // streams, labels and the per-object vectors (everything that is not shared between the provers of one key)
 static void finish_setup(Prover::Impl &p) {
   // diagnostic: everything on the main stream, so that a kernel trace shows every kernel's stand-alone duration
-  const bool one_stream = env_int("ZK_MSM_ONE_STREAM", 0) != 0;
+  const bool one_stream = p.one_stream = env_int("ZK_MSM_ONE_STREAM", 0) != 0;
   // MSMs over the same scalars share one sort: L* follows A, the two halves of the B query follow each other
   {
     p.pair_AL = p.c_fold && p.a0 == p.l0 && p.L->share_sort_with(p.A->sort_handle());
@@ -874,7 +880,10 @@ static void finish_setup(Prover::Impl &p) {
   p.z_host = PinnedBuf<Fe32>(p.nv + 1 + 8);
   p.packed = DevBuf<uint8_t>(32 * (p.nv + 1 + 8));
   p.tags = DevBuf<uint8_t>(p.nv + 1 + 64);
-  p.other_vars = DevBuf<uint32_t>((p.nv + 1) / 4 + 64);
+  // (room for every variable: a list made on the device — k_classify_witness — cannot ask the host to take another path when an assignment is not mostly bits)
+  p.other_vars = DevBuf<uint32_t>(p.nv + 1 + 64);
+  p.other_count = DevBuf<uint32_t>(2); const uint32_t zero2[2] = {0, 0}; p.other_count.upload(zero2, 2);
+  p.z_cur = p.z.get();
 }
 Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world, int device_slot) : impl(new Impl) {
   Impl &p = *impl;
@@ -1278,7 +1287,7 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
     upload_async(p.packed.get(), pk, vals_at + 32 * total);
     expand_witness_dev(p.packed.get(), words, one_mont, montgomery ? 0 : 1, n, p.z.get(), p.tags.get(), p.other_vars.get());
     p.tags_valid = true;
-    p.n_other = (uint32_t)total;
+    p.n_other = (uint32_t)total; p.n_other_on_device = false;
     if (trace) fprintf(stderr, "trace-handover-host: threads %zu post %.3f own scan %.3f join %.3f copy + expand calls %.3f ms\n", T, t_posted - t0,
         t_own - t_posted, t_joined - t_own,
         now_ms() - t_joined);
@@ -1292,6 +1301,7 @@ void Prover::set_witness(const Fe32 *z, bool montgomery) {
     if (!montgomery) fr_to_mont_dev(p.z.get(), n);
     p.tags_valid = false;
   }
+  p.z_cur = p.z.get(); p.z_set = true;
   last.upload_ms = now_ms() - t0;
 }
 void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
@@ -1387,7 +1397,7 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
   if (fits && !force_dense) {
     const size_t n_other = value_cursor.load();
     const double t2 = now_ms(); upload_async(p.packed.get(), pk, vals_at + 32 * n_other); const double t3 = now_ms();
-    expand_witness_dev(p.packed.get(), words, one, 2, n, p.z.get(), p.tags.get(), p.other_vars.get()); p.tags_valid = true; p.n_other = (uint32_t)n_other;
+    expand_witness_dev(p.packed.get(), words, one, 2, n, p.z.get(), p.tags.get(), p.other_vars.get()); p.tags_valid = true; p.n_other = (uint32_t)n_other; p.n_other_on_device = false;
     if (trace) fprintf(stderr, "trace-handover: scan %.3f (close-up: none) %.3f copy call %.3f (%zu bytes) expand launch %.3f ms\n", t1 - t0, t2 - t1, t3 - t2,
         vals_at + 32 * n_other, now_ms() - t3);
   }
@@ -1405,6 +1415,7 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
     upload_async(p.z.get(), h, 32 * n);
     p.tags_valid = false;
   }
+  p.z_cur = p.z.get(); p.z_set = true;
   last.upload_ms = now_ms() - t0;
 }
 struct RsTerms { HFr r, s; HG1 r_delta, s_delta, rs_delta_neg; HG2 s_delta2; };
@@ -1444,6 +1455,7 @@ static void enqueue_all(Prover::Impl &p) {
       t.tags = pp->tags.get();
       t.other_vars = pp->other_vars.get();
       t.n_other = pp->n_other;
+      if (pp->n_other_on_device) t.n_other_dev = pp->other_count.get() + (pp->classify_parity & 1);
     }
     t.var_pos = var_pos;
     t.base = (uint32_t)base;
@@ -1452,16 +1464,16 @@ static void enqueue_all(Prover::Impl &p) {
   const WitnessTags wtB = wt(p.B_pos->get(), p.b0), wtL = wt(nullptr, (p.c_fold ? 0 : p.ni + 1) + p.l0), wtA = wt(nullptr, p.a0);
   // r1cs_gg_ppzksnark.tcc:442-462,477-484
   auto runB2 = [pp, wtB] {
-    pp->B2->run_tagged(pp->z.get(), wtB, pp->B_idx->get() + pp->b0);
+    pp->B2->run_tagged(pp->z_cur, wtB, pp->B_idx->get() + pp->b0);
   };
   auto runL = [pp, wtL] {
-    pp->L->run_tagged(pp->z.get(), wtL, nullptr);
+    pp->L->run_tagged(pp->z_cur, wtL, nullptr);
   };
   auto runA = [pp, wtA] {
-    pp->A->run_tagged(pp->z.get(), wtA, nullptr);
+    pp->A->run_tagged(pp->z_cur, wtA, nullptr);
   };
   auto runB1 = [pp, wtB] {
-    pp->B1->run_tagged(pp->z.get(), wtB, pp->B_idx->get() + pp->b0);
+    pp->B1->run_tagged(pp->z_cur, wtB, pp->B_idx->get() + pp->b0);
   };
   // job order: B2, L, A, B1 (longest first).  A follower of a shared sort is queued behind its leader by the leader's job: its own slot stays empty.
   // the G2 MSM first: its long accumulation then overlaps the transforms, not the H accumulation
@@ -1471,7 +1483,7 @@ static void enqueue_all(Prover::Impl &p) {
       if (pp->pair_AL) pp->rL = pp->L->result(); }, [pp] { pp->rB1 = pp->B1->result(); if (pp->pair_B) pp->rB2 = pp->B2->result(); } };
   const bool job_used[4] = {!p.pair_B, !p.pair_AL, true, true};
   const int job_stream[4] = {3, 1, 0, 2};                       // the auxiliary stream each MSM was bound to in the constructor (set_stream)
-  const bool use_threads = threaded;
+  const bool use_threads = threaded && !p.one_stream;          // (one stream: the calling thread submits everything itself, so that the stream's order is the program's)
   p.settle_all_quietly();                                       // (nothing is pending unless an earlier proof was abandoned by an exception)
   // phase 0: record the fork event (one event; each stream's wait is issued by the thread that feeds it); phase 1: hand the jobs to the submit threads. The
   // main chain's next launch goes in between: waking the threads costs this one ~10 us, which the device would otherwise spend idle behind the row kernel
@@ -1498,7 +1510,7 @@ static void enqueue_all(Prover::Impl &p) {
     }
   };
   release(0, 0);
-  p.cs->eval(p.z.get(), p.abc.get(), p.m, p.tags_valid ? p.tags.get() : nullptr, !p.c_fold); release(0, 1); release(1, 0);
+  p.cs->eval(p.z_cur, p.abc.get(), p.m, p.tags_valid ? p.tags.get() : nullptr, !p.c_fold); release(0, 1); release(1, 0);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
   const int nvec = p.c_fold ? 2 : 3;                          // A, B (and C unless it is folded into the L query)
   // iFFT, then cosetFFT (a step domain runs the passes between the two as one kernel)
@@ -1525,25 +1537,35 @@ static void assemble(const Prover::Impl &p, const RsTerms &t, const HG1 &eA, con
   out.A = raw_of(gA); out.B = raw_of(gB2); out.C = raw_of(gC); }
 size_t Prover::stash_witness() {
   Impl &p = *impl; LaneScope lane_scope(p.lane); const size_t n = p.nv + 1;
-  std::unique_ptr<Impl::Stash> st(new Impl::Stash());
-  st->z = DevBuf<Fe32>(n); st->tags = DevBuf<uint8_t>(p.tags.size()); st->other_vars = DevBuf<uint32_t>(p.other_vars.size()); st->n_other = p.n_other; st->tags_valid = p.tags_valid;
-  copy_dev_async(st->z.get(), p.z.get(), 32 * n);
-  copy_dev_async(st->tags.get(), p.tags.get(), p.tags.size());
-  copy_dev_async(st->other_vars.get(), p.other_vars.get(), 4 * p.other_vars.size());
-  gpu_sync(); p.stashes.push_back(std::move(st)); return p.stashes.size() - 1;
+  if (!p.z_set) throw std::runtime_error("stash_witness: no assignment has been handed over to this prover");
+  // a slot that was dropped is used again before the list grows
+  size_t slot = 0; while (slot < p.stashes.size() && p.stashes[slot]) slot++;
+  std::unique_ptr<Impl::Stash> st(new Impl::Stash()); st->z = DevBuf<Fe32>(n);
+  copy_dev_async(st->z.get(), p.z.get(), 32 * n); gpu_sync();
+  if (slot == p.stashes.size()) p.stashes.push_back(std::move(st)); else p.stashes[slot] = std::move(st);
+  return slot;
 }
+void Prover::drop_stash(size_t slot) {
+  Impl &p = *impl; LaneScope lane_scope(p.lane);
+  if (slot == (size_t)-1) { gpu_sync(); p.stashes.clear(); p.z_cur = p.z.get(); return; }
+  if (slot >= p.stashes.size() || !p.stashes[slot]) throw std::runtime_error("drop_stash: no such slot");
+  gpu_sync(); if (p.z_cur == p.stashes[slot]->z.get()) p.z_cur = p.z.get();
+  p.stashes[slot].reset();
+  while (!p.stashes.empty() && !p.stashes.back()) p.stashes.pop_back();
+}
+size_t Prover::stash_count() const { size_t k = 0; for (const auto &s : impl->stashes) k += s ? 1 : 0; return k; }
 bool Prover::prove_stashed(size_t slot, const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
   {
     Impl &p = *impl; LaneScope lane_scope(p.lane); const double t0 = now_ms();
-    if (slot >= p.stashes.size()) throw std::runtime_error("prove_stashed: no such slot");
+    if (slot >= p.stashes.size() || !p.stashes[slot]) throw std::runtime_error("prove_stashed: no such slot");
     const Impl::Stash &st = *p.stashes[slot]; const size_t n = p.nv + 1;
-    // (on the prover's main stream, ahead of the first kernel of the proof; only the entries in use of the list of other values)
-    copy_dev_async(p.z.get(), st.z.get(), 32 * n);
-    if (st.tags_valid) {
-      copy_dev_async(p.tags.get(), st.tags.get(), std::min(p.tags.size(), st.tags.size()));
-      copy_dev_async(p.other_vars.get(), st.other_vars.get(), 4 * (size_t)st.n_other);
-    }
-    p.n_other = st.n_other; p.tags_valid = st.tags_valid; last.upload_ms = now_ms() - t0;
+    // What is resident is the raw vector.  Everything the prover derives from it — the tag byte per variable, the list of the values that are neither 0 nor 1 (what
+    // multi_exp_with_mixed_addition's classification does per call, multiexp.tcc:443-496) — is made HERE, inside the call, by one streaming kernel on the prover's
+    // main stream ahead of the row kernel; the proof reads the stash in place.  The list's length stays on the device (WitnessTags::n_other_dev): the sort's launch
+    // is sized by the bound n.
+    p.classify_parity ^= 1;
+    classify_witness_dev(st.z.get(), n, p.tags.get(), p.other_vars.get(), p.other_count.get(), p.classify_parity);
+    p.z_cur = st.z.get(); p.n_other = (uint32_t)n; p.n_other_on_device = true; p.tags_valid = true; last.upload_ms = now_ms() - t0;
   }
   return prove_resident(r_in, s_in, out);
 }

@@ -78,10 +78,13 @@ class Prover {                                    // a proving key resident in H
   // being the constant ONE (circuit::Board's own form)
   void set_witness_tagged(const uint8_t *tag, const Fe32 *wide);
   bool prove_resident(const Fe32 *r, const Fe32 *s, Proof &out);
-  // Inputs resident in HBM: stash_witness() keeps a copy of the assignment that was handed over last (the expanded vector, its tags and the list of the other
-  // values: 7.5 MB for send) in device memory and returns its slot; prove_stashed(slot, ...) proves it — one device-to-device copy on the prover's own stream
-  // (a few microseconds), no host buffer, no PCIe.  bench.py's `value`: a batch of distinct statements uploaded before the timed region starts.
+  // Inputs resident in HBM: stash_witness() keeps the assignment that was handed over last in device memory — the RAW vector only, (n + 1) x 32 B in
+  // Montgomery form as libsnark holds it, nothing derived from it — and returns its slot (a dropped slot is reused); prove_stashed(slot, ...) proves it in place:
+  // tags and the list of the other values are derived by a device kernel inside the call (k_classify_witness), no host buffer, no PCIe.  bench.py's `value`: a
+  // batch of distinct statements uploaded before the timed region starts.  drop_stash(slot) frees one, drop_stash(-1) all of them.
   size_t stash_witness();
+  void drop_stash(size_t slot);
+  size_t stash_count() const;
   bool prove_stashed(size_t slot, const Fe32 *r, const Fe32 *s, Proof &out);
   // partial multi-exponentiation results of this shard, affine canonical: eA(64) eB1(64) eH(64) eL(64) eB2(128) = 384 bytes.  false if z is unsatisfying.
   static constexpr size_t PARTIAL_BYTES = 384;
@@ -115,7 +118,6 @@ Proof default_proof();                            // (G1::one, G2::one, G1::one)
 
 // host-only self-test of the hand-over's block classifiers (scalar against AVX2 forms)
 void test_scan_blocks(const uint8_t tags[64], const uint64_t elems[256], const uint64_t one[4], uint64_t out[10]);
-int test_cgroup_quota(const char *root);
 int test_cgroup_quota(const char *root);   // host-only: the CPU quota (CPUs, rounded up) a cgroup tree states — cpu.max (v2) or cpu/cpu.cfs_*_us (v1) under `root`; 0 = none
 int test_scan_pool(int callers, int rounds);   // host-only self-test of the hand-over's scan pool: rounds that ran on the pool, -1 on a miscount
 }  // namespace zk

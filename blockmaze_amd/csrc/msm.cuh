@@ -915,10 +915,13 @@ __global__ void __launch_bounds__(256) k_wsort_tagged(const Fr *__restrict__ z, 
     }
     return;
   }
+  // (a list made on the device: its length lies there too, the launch was sized by a bound — workgroups beyond the list leave at once)
+  const uint32_t n_other = wt.n_other_dev ? min(*wt.n_other_dev, wt.n_other) : wt.n_other;
+  if ((blockIdx.x - ones_blocks) * blockDim.x >= n_other) return;
   if (threadIdx.x < NB) lcnt[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t j = (blockIdx.x - ones_blocks) * blockDim.x + threadIdx.x;
-  bool live = j < wt.n_other;
+  bool live = j < n_other;
   uint32_t pos = 0;
   Fr k = Fr::zero();
   if (live) {

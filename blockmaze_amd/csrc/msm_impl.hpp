@@ -390,12 +390,12 @@ struct MsmImpl {
         Point29Rec *p1 = (Point29Rec *)partials.get(), *p2 = (Point29Rec *)ones_partial.get();
         { Stage st((label + ".accumulate").c_str(), s);
           hipLaunchKernelGGL(k_wacc_lanes29<0>, lanes_grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(),
-              (const Affine<Fq> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB | zk_prio_bits("wlanes"), w.ones.get(), wc + w.parity, p1, lane_off.get());
-          hipLaunchKernelGGL(k_wfold29<0>, fold_grid, dim3(256), 0, s, (const Point29Rec *)p1, (const uint32_t *)lane_off.get(), NB | zk_prio_bits("wit"),
+              (const Affine<Fq> *)bases->groups261.get(), w.entries.get(), fl, w.cap, zk_with_prio(NB, ZKP_WLANES), w.ones.get(), wc + w.parity, p1, lane_off.get());
+          hipLaunchKernelGGL(k_wfold29<0>, fold_grid, dim3(256), 0, s, (const Point29Rec *)p1, (const uint32_t *)lane_off.get(), zk_with_prio(NB, ZKP_WIT),
               (uint32_t)WFUSED_BUCKET_LANES, p2);
         }
         { Stage st((label + ".reduce").c_str(), s);
-          hipLaunchKernelGGL(k_wtail29<0>, dim3(top + 2), dim3(256), 0, s, (const Point29Rec *)p2, NB | zk_prio_bits("wit"), (const Point29Rec *)p2 + NB,
+          hipLaunchKernelGGL(k_wtail29<0>, dim3(top + 2), dim3(256), 0, s, (const Point29Rec *)p2, zk_with_prio(NB, ZKP_WIT), (const Point29Rec *)p2 + NB,
               (uint32_t)WFUSED_ONES_GROUPS, (uint32_t)WTAIL_SLOTS, (XYZZ<Fq> *)res, wc + w.parity, cdst, ws_leader ? 0u : 16u);
         }
       } else {
@@ -403,12 +403,12 @@ struct MsmImpl {
         Point29Rec2 *p1 = (Point29Rec2 *)partials.get(), *p2 = (Point29Rec2 *)ones_partial.get();
         { Stage st((label + ".accumulate").c_str(), s);
           hipLaunchKernelGGL(k_wacc_lanes_g2_29<0>, lanes_grid, dim3(256), 0, s, (const Affine<Fq2> *)bases->points261.get(),
-              (const Affine<Fq2> *)bases->groups261.get(), w.entries.get(), fl, w.cap, NB | zk_prio_bits("wlanes"), w.ones.get(), wc + w.parity, p1, lane_off.get());
-          hipLaunchKernelGGL(k_wfold_g2_29<0>, fold_grid, dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p1, (const uint32_t *)lane_off.get(), NB | zk_prio_bits("wit"),
+              (const Affine<Fq2> *)bases->groups261.get(), w.entries.get(), fl, w.cap, zk_with_prio(NB, ZKP_WLANES), w.ones.get(), wc + w.parity, p1, lane_off.get());
+          hipLaunchKernelGGL(k_wfold_g2_29<0>, fold_grid, dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p1, (const uint32_t *)lane_off.get(), zk_with_prio(NB, ZKP_WIT),
               (uint32_t)WFUSED_BUCKET_LANES, p2);
         }
         { Stage st((label + ".reduce").c_str(), s);
-          hipLaunchKernelGGL(k_wtail_g2_29<0>, dim3(top + 2), dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p2, NB | zk_prio_bits("wit"), (const Point29Rec2 *)p2 + NB,
+          hipLaunchKernelGGL(k_wtail_g2_29<0>, dim3(top + 2), dim3(OCT_BLOCK), 0, s, (const Point29Rec2 *)p2, zk_with_prio(NB, ZKP_WIT), (const Point29Rec2 *)p2 + NB,
               (uint32_t)WFUSED_ONES_GROUPS, (uint32_t)WTAIL_SLOTS, (XYZZ<Fq2> *)res, wc + w.parity, cdst, ws_leader ? 0u : 16u);
         }
       }
@@ -418,7 +418,7 @@ struct MsmImpl {
     if (hs_run) {
       if constexpr (sizeof(F) == 32) {
       { Stage st((label + ".sort").c_str(), s);
-        HsortShape hs_prio = hs; hs_prio.low_bits |= zk_prio_bits("hsort");
+        HsortShape hs_prio = hs; hs_prio.low_bits |= zk_prio_bits(ZKP_HSORT);
 #define ZK_CALL(CC) hipLaunchKernelGGL(k_hsort_bin<CC>, dim3(cdiv(n, HSORT_TILE)), dim3(HSORT_BIN_THREADS), 0, s, (const Fr *)scalars, (const Fr *)prod_b, (const Fr *)prod_z, (int)prod_z_table, infp, (uint32_t)n, c, W, point_stride, hs_prio, group_fill.get(), mid.get(), cnt, counters_next())
         ZK_MSM_DISPATCH_C(c, ZK_CALL);
 #undef ZK_CALL
@@ -431,9 +431,9 @@ struct MsmImpl {
         const uint32_t h_run = crowded ? std::max(this->h_run, h_run_crowded) : this->h_run;   // (pieces are laid out by h_maxp, sized for the shorter run)
         const dim3 grid(cdiv(cdiv(n * (size_t)W, h_run) + hs.groups, 256));
         if (any_inf) hipLaunchKernelGGL(k_hacc_runs29<1>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(),
-            offsets.get(), hs, h_run, h_maxp | zk_prio_bits("hacc"), (Piece29 *)partials.get(), cnt);
+            offsets.get(), hs, h_run, zk_with_prio(h_maxp, ZKP_HACC), (Piece29 *)partials.get(), cnt);
         else hipLaunchKernelGGL(k_hacc_runs29<0>, grid, dim3(256), 0, s, (const Affine<Fq> *)bases->points261.get(), entries.get(), group_n.get(),
-            offsets.get(), hs, h_run, h_maxp | zk_prio_bits("hacc"), (Piece29 *)partials.get(), cnt);
+            offsets.get(), hs, h_run, zk_with_prio(h_maxp, ZKP_HACC), (Piece29 *)partials.get(), cnt);
       }
       // 2 / 4 / 8 lanes per bucket: about six pieces a lane (send: 12 pieces, two lanes; deposit at depth 32: 48 pieces — two lanes took 256 us there)
       {
@@ -442,7 +442,7 @@ struct MsmImpl {
         const size_t pieces = n * (size_t)W / NB / h_run;
         const uint32_t ll = pieces > 40 ? 3 : pieces > 18 ? 2 : 1;   // (send, runs of 14: 9 pieces; two and four lanes measure the same, eight lose 30 us)
         hipLaunchKernelGGL(k_hacc_combine29, dim3(cdiv(nbk << ll, 256)), dim3(256), 0, s, (const Piece29 *)partials.get(), offsets.get(), hist(), hs, h_run,
-            h_maxp, (uint32_t)nbk, ll | zk_prio_bits("htail"), (XYZZ<Fq> *)bucket_array(), htail29 ? (Point29Rec *)hb29.get() : nullptr, cnt);
+            h_maxp, (uint32_t)nbk, zk_with_prio(ll, ZKP_HTAIL), (XYZZ<Fq> *)bucket_array(), htail29 ? (Point29Rec *)hb29.get() : nullptr, cnt);
       }
       }
     } else
@@ -494,8 +494,8 @@ struct MsmImpl {
       // on its SIMD issues an instruction every 6-8 cycles whatever it does — at 40 % of their instructions, which is what counts with other proofs in flight
       // (profiles/r05_hacc_sweeps.txt)
       const uint32_t marg_block = std::max(1u << ts.hi_bits, (1u << ts.lo_bits) / ts.row_chunks) <= 128 ? 64 : 256;
-      hipLaunchKernelGGL(k_hmarg29<0>, dim3(htail_marg_blocks(ts)), dim3(marg_block), 0, s, (const Point29Rec *)hb29.get(), NB | zk_prio_bits("htail"), (Point29Rec *)hmarg.get());
-      hipLaunchKernelGGL(k_hbits29<0>, dim3(ts.top + 1), dim3(256), 0, s, (const Point29Rec *)hmarg.get(), NB | zk_prio_bits("htail"), (XYZZ<Fq> *)res, cnt, (uint4 *)(res + RS + 1));
+      hipLaunchKernelGGL(k_hmarg29<0>, dim3(htail_marg_blocks(ts)), dim3(marg_block), 0, s, (const Point29Rec *)hb29.get(), zk_with_prio(NB, ZKP_HTAIL), (Point29Rec *)hmarg.get());
+      hipLaunchKernelGGL(k_hbits29<0>, dim3(ts.top + 1), dim3(256), 0, s, (const Point29Rec *)hmarg.get(), zk_with_prio(NB, ZKP_HTAIL), (XYZZ<Fq> *)res, cnt, (uint4 *)(res + RS + 1));
     }
   }
     else { Stage st_red((label + ".reduce").c_str(), s);

@@ -302,6 +302,37 @@ __global__ void k_expand_witness(const uint64_t *__restrict__ ones_bm, const uin
   }
   else { const bool is_one = (ones_bm[wd] >> bit) & 1; out[i] = is_one ? one_value : Fr::zero(); if (tags) tags[i] = is_one ? ZTAG_ONE : ZTAG_ZERO; }
 }
+// The same tags and list for an assignment that is ALREADY in device memory as plain field elements (Prover::prove_stashed: a statement resident in HBM is the raw
+// vector, n x 32 B, nothing derived from it): one lane per variable reads the value, compares it with 0 and with the Montgomery one — the classification libsnark's
+// multi_exp_with_mixed_addition makes per call (multiexp.tcc:443-496) —, writes the tag byte and appends the variable to the list of other values (the waves'
+// counts meet in LDS, ONE atomic per workgroup on *count; the list's order is therefore by workgroup arrival, as the host scan's chunks leave it).  The two
+// counters alternate between calls: this one clears the next call's.  A 7.3 MB streaming pass for send.
+__global__ void __launch_bounds__(256) k_classify_witness(const Fr *__restrict__ z, Fr one_value, uint32_t n, uint8_t *__restrict__ tags,
+    uint32_t *__restrict__ other_vars, uint32_t *__restrict__ count, uint32_t *__restrict__ count_next) {
+  zk_take_prio(n);
+  __shared__ uint32_t wave_n[4], wg_at;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count_next = 0;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bool other = false;
+  if (i < n) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(z + i); const uint4 lo = p[0], hi = p[1];
+    const uint32_t any = lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w;
+    const uint32_t d1 = (lo.x ^ one_value.l[0]) | (lo.y ^ one_value.l[1]) | (lo.z ^ one_value.l[2]) | (lo.w ^ one_value.l[3]) | (hi.x ^ one_value.l[4]) |
+        (hi.y ^ one_value.l[5]) | (hi.z ^ one_value.l[6]) | (hi.w ^ one_value.l[7]);
+    other = any != 0 && d1 != 0;
+    tags[i] = any == 0 ? ZTAG_ZERO : d1 == 0 ? ZTAG_ONE : ZTAG_OTHER;
+  }
+  const uint64_t m = __ballot(other);
+  if (lane == 0) wave_n[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) { const uint32_t tot = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3]; wg_at = tot ? atomicAdd(count, tot) : 0u; }
+  __syncthreads();
+  if (other) {
+    uint32_t at = wg_at;
+    for (uint32_t wv = 0; wv < wave; wv++) at += wave_n[wv];
+    other_vars[at + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = i;
+  }
+}
 // both of the above in ONE launch (the two are independent and each too small to fill the chip for long: 27 + 25 us one after the other at the head of every
 // proof's critical chain): the first `short_blocks` workgroups take the one-lane rows, the others four long rows each, one per wave
 __global__ void __launch_bounds__(256) k_r1cs_rows_all(R1csMatrices M, const Fr *__restrict__ ctab, const Fr *__restrict__ z, uint32_t n_rows,

@@ -141,6 +141,11 @@ class Prover:
     def stash_witness(self):
         """keep the assignment handed over last in HBM; returns its slot"""
         slot = ctypes.c_uint32(0); _check(lib().zkgpu_prover_stash_witness(ctypes.c_void_p(self.h), ctypes.byref(slot))); return int(slot.value)
+    def drop_stash(self, slot=None):
+        """free a kept assignment (None: all of them)"""
+        _check(lib().zkgpu_prover_drop_stash(ctypes.c_void_p(self.h), ctypes.c_uint32(0xffffffff if slot is None else slot)))
+    def stash_count(self):
+        k = ctypes.c_uint32(0); _check(lib().zkgpu_prover_stash_count(ctypes.c_void_p(self.h), ctypes.byref(k))); return int(k.value)
     def prove_stashed(self, slot, r=None, s=None):
         R = int(r).to_bytes(32, "little") if r is not None else None; S = int(s).to_bytes(32, "little") if s is not None else None
         out = ctypes.create_string_buffer(513); _check(lib().zkgpu_prover_prove_stashed(ctypes.c_void_p(self.h), ctypes.c_uint32(slot), R, S, out)); return out.value.decode()

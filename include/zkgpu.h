@@ -118,9 +118,13 @@ int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, cons
 /* the two halves of zkgpu_prover_prove: upload the assignment into HBM (returns when it is resident), then prove from there any number of times */
 int zkgpu_prover_set_witness(zkgpu_prover *h, const uint8_t *z);
 int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t *s, char proof_hex[513]);
-/* inputs resident in HBM: keep the assignment handed over last in device memory (its slot is returned) / prove a kept assignment: one device-to-device copy on the
- * prover's stream, no host buffer.  What bench.py's `value` times: distinct statements uploaded before the timed region. */
+/* inputs resident in HBM: keep the assignment handed over last in device memory — the RAW vector, (n_vars + 1) x 32 bytes, nothing derived from it; its slot is
+ * returned, a dropped slot is reused — / prove a kept assignment in place: the tags and the list of values other than 0 and 1 (the classification of libsnark's
+ * multi_exp_with_mixed_addition, multiexp.tcc:443-496) are derived by a device kernel INSIDE the call; no host buffer, no copy.  What bench.py's `value` times:
+ * distinct statements uploaded before the timed region.  drop_stash frees a slot (0xffffffff: all of them); ZKGPU_ERR_* if no assignment was handed over / no such slot. */
 int zkgpu_prover_stash_witness(zkgpu_prover *h, uint32_t *slot);
+int zkgpu_prover_drop_stash(zkgpu_prover *h, uint32_t slot);
+int zkgpu_prover_stash_count(zkgpu_prover *h, uint32_t *count);
 int zkgpu_prover_prove_stashed(zkgpu_prover *h, uint32_t slot, const uint8_t *r, const uint8_t *s, char proof_hex[513]);
 /* A second prover object on the same resident key: shares the immutable device tables of `h` (1.8 GB for send), owns its streams and workspaces (about 0.25 GB).
  * Objects may be used from different threads at the same time; their proofs overlap on the device. */

@@ -473,7 +473,35 @@ def test_inputs_resident_in_hbm_give_the_same_proofs(golden_dir):
     with pytest.raises(e.ZkGpuError): p.prove_stashed(s1, r, s)
     assert p.prove_stashed(s0, r, s) == meta["proof"] and p.prove(z, r, s) == meta["proof"]                   # the object keeps working
     with pytest.raises(e.ZkGpuError): p.prove_stashed(7, r, s)
-    fresh = p.prove_stashed(s0); assert fresh != meta["proof"] and e.verify(os.path.join(d, "vk.txt"), fresh, o.from_arr(z[:meta["n_inputs"]])); p.close()
+    fresh = p.prove_stashed(s0); assert fresh != meta["proof"] and e.verify(os.path.join(d, "vk.txt"), fresh, o.from_arr(z[:meta["n_inputs"]]))
+    # a stash is the raw vector only: slots can be dropped and are used again, the count follows, a dropped slot is an error, and the prover's own hand-over still works between
+    assert p.stash_count() == 3; p.drop_stash(s1); assert p.stash_count() == 2
+    with pytest.raises(e.ZkGpuError): p.prove_stashed(s1, r, s)
+    with pytest.raises(e.ZkGpuError): p.drop_stash(s1)
+    p.set_witness(z); assert p.stash_witness() == s1 and p.prove_stashed(s1, r, s) == meta["proof"]
+    assert p.prove_resident(r, s) == meta["proof"]                                                             # (the assignment proved last: the stash, read in place)
+    p.drop_stash(); assert p.stash_count() == 0; p.set_witness(z); assert p.prove_resident(r, s) == meta["proof"] and p.stash_witness() == 0; p.close()
+    q = e.Prover(os.path.join(d, "pk.txt"))
+    with pytest.raises(e.ZkGpuError): q.stash_witness()                                                       # nothing was handed over yet
+    q.close()
+
+def test_stashed_assignments_of_the_send_circuit_classified_on_the_device(tmp_path):
+    """the tags and the list of other values of a statement resident in HBM are derived inside prove_stashed (k_classify_witness; multiexp.tcc:443-496 is part of the
+    prover): full-size send statements — stashed from the compact hand-over AND from the dense one (ZK-independent: a dense upload leaves no tags behind, the stash path
+    must not need any) — give the bytes of zkgpu_prover_prove for the same (r, s)"""
+    import workload as w
+    pk, vk = str(tmp_path / "pk.txt"), str(tmp_path / "vk.txt"); e.keygen("send", pk, vk, seed=77); p = e.Prover(pk); hx = lambda a: [("0x" + x.hex()) if isinstance(x, bytes) else x for x in a]
+    zs = []
+    for i in range(3):
+        d = w.send_instance(40 + i); wp = str(tmp_path / ("w%d.bin" % i)); e.witness_send(*hx(w.send_args(d)), wp); zs.append(o.load_witness(wp))
+    want = [p.prove(z, 1000 + i, 2000 + i) for i, z in enumerate(zs)]; slots = []
+    for z in zs: p.set_witness(z); slots.append(p.stash_witness())
+    for rep in range(2):
+        for i in (2, 0, 1): assert p.prove_stashed(slots[i], 1000 + i, 2000 + i) == want[i]
+    assert p.prove(zs[1], 1001, 2001) == want[1] and p.prove_stashed(slots[0], 1000, 2000) == want[0]         # host buffers and stashes interleaved
+    bad = zs[0].copy(); bad[300000 % len(bad)] = o.to_arr([3])[0]; p.set_witness(bad); sb = p.stash_witness()
+    with pytest.raises(e.ZkGpuError): p.prove_stashed(sb, 1, 2)
+    assert p.prove_stashed(slots[2], 1002, 2002) == want[2]; p.close()
 
 def test_key_container_gives_the_same_prover(tmp_path):
     """the first load of a text key leaves <key>.gpucache behind (post-transform tables as raw aligned arrays); the next load maps it instead of parsing 77 MB
