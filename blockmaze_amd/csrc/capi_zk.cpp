@@ -906,6 +906,14 @@ int zkgpu_test_verify_schedule(const char *vk_path, const char *proof_hex, const
     int rc = guarded_host([&] { std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(vk_path); Proof p;
   if (!proof_hex || strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) { res = 0; return ZKGPU_OK;
       } res = verify_by_schedule_on_host(*vk, (const Fe32 *)inputs, n_inputs, p, stats) ? 1 : 0; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
+/* small verification calls taken by the key's GPU verifier / launches made for them (calls that meet share a launch) */
+int zkgpu_verify_counters(const char *vk_path, uint64_t out[2]) { return guarded([&] { if (!vk_path || !out) return ZKGPU_ERR_ARG; gpu_verifier_for_path(vk_path)->counters(out); return ZKGPU_OK; }); }
+/* test entry (GPU): kernel K9's values after every `every`-th round of its schedule against the host model of the same limb arithmetic.  out[0] = first differing round or -1,
+ * out[1] = the slot, out[2] = the kernel's verdict (1 accept, 0 reject, 2 handed back) */
+int zkgpu_test_verify_trace(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs, uint32_t every, long out[3]) { return guarded([&] {
+  if (!vk_path || !proof_hex || !out || !every) return ZKGPU_ERR_ARG; Proof p; if (strnlen(proof_hex, 512) < 512 || !proof_from_hex(proof_hex, p)) return ZKGPU_ERR_ARG;
+  std::shared_ptr<BatchVerifier> v = gpu_verifier_for_path(vk_path); std::shared_ptr<PreparedVerifyingKey> vk = vk_for_path(vk_path); uint32_t slot = 0; uint8_t ok = 0;
+  out[0] = verify_schedule_trace_on_device(*v, *vk, (const Fe32 *)inputs, n_inputs, p, every, &slot, &ok); out[1] = slot; out[2] = ok; return ZKGPU_OK; }); }
 // batched verification on the GPU (kernel K9).  proofs_hex: n * 512 characters; inputs: n * n_inputs canonical field elements; ok[i] = 1 accept / 0 reject
 // (a record that is not 512 hex digits is rejected without reaching the device; coordinates are taken modulo q like proof_from_hex in zkgpu_verify)
 int zkgpu_verify_batch(const char *vk_path, const char *proofs_hex, const uint8_t *inputs, size_t n_inputs, size_t n, uint8_t *ok) { return guarded([&] {

@@ -120,9 +120,11 @@ class BatchVerifier {
   BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2AffineRaw &gamma_g2, const G2AffineRaw &delta_g2, const G1AffineRaw *ic, size_t n_ic);
   ~BatchVerifier();
   size_t num_inputs() const; size_t program_length() const;
+  void counters(uint64_t out[2]) const;   // small calls taken / launches made for them (calls that meet share a launch)
   // proofs_mont: n records of 256 bytes (A.x A.y | B.x.c0 B.x.c1 B.y.c0 B.y.c1 | C.x C.y, Montgomery); inputs: n * num_inputs() canonical field elements; ok[i]
   // = 1 accept / 0 reject
   void verify(const void *proofs_mont, const Fe32 *inputs_canonical, size_t n, uint8_t *ok);
+  uint8_t trace(const void *proof_mont, const Fe32 *inputs_canonical, uint32_t every, std::vector<uint32_t> &values, uint8_t nacc_out[96]);   // tests (gpu_verify.hip)
   struct Impl; std::unique_ptr<Impl> impl;
 };
 

@@ -1,6 +1,8 @@
 // Host driver of the batched GPU verifier (kernel K9, pairing.cuh): assembles the bytecode and the per-key tables once, then checks any number of proofs per
 // launch.
 #include <atomic>
+#include <condition_variable>
+#include <exception>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -21,7 +23,7 @@ template <class T> struct DevArr { DevBuf<uint8_t> b; DevArr() = default; explic
   void upload(const T *h, size_t n) { b.upload((const uint8_t *)h, n * sizeof(T)); } };
 // One small verification in flight: its own stream, pinned staging and device buffers for up to CTX_CAP proofs — go-ethereum's verifyXproof calls arrive one
 // proof at a time from many threads, and a proof occupies ONE compute unit for ~2 ms: several contexts let them overlap instead of queueing behind one stream.
-struct VerifyCtx { std::mutex m; hipStream_t s = nullptr; uint8_t *h = nullptr; DevBuf<uint8_t> d; };
+struct VerifyCtx { std::mutex m; hipStream_t s = nullptr; uint8_t *h = nullptr /* pinned, mapped */, *hd = nullptr /* the device's view of h */; DevBuf<uint8_t> d; };
 struct BatchVerifier::Impl {
   size_t n_inputs = 0;
   DevBuf<uint32_t> sched_prog, sched_consts;
@@ -35,6 +37,15 @@ struct BatchVerifier::Impl {
   VerifyConsts K;
   size_t prog_len = 0;
   static constexpr size_t CTX_CAP = 64; std::vector<std::unique_ptr<VerifyCtx>> ctxs; std::atomic<unsigned> next_ctx{0}; std::mutex big; size_t lds = 0;
+  // Small calls that meet are ONE launch (go-ethereum's verifyXproof calls arrive one proof at a time from many goroutines; a launch takes the same 0.8 ms for 1 or
+  // 64 proofs): a caller either joins the batch that is waiting for a launch slot or opens one and leads it; a leader launches as soon as fewer than
+  // ZK_VERIFY_IN_FLIGHT (16, on as many streams) launches of this key are under way — alone if nobody came —, so a lone caller never waits for company.
+  // Independent launches overlap on the device (a proof occupies one CU), so sharing only sets in when callers outnumber the slots: measured from C threads through
+  // verifySendproof (tools/verify_threads.sh): 1 / 8 / 16 threads 1,180 / 8,690 / 14,500 verifications/s (2 slots: 1,180 / 5,390 / 10,400).
+  struct Pending { const void *proofs; const Fe32 *inputs; size_t n; uint8_t *ok; bool done = false; std::exception_ptr err; };
+  static int max_in_flight() { static const int v = [] { const char *e = getenv("ZK_VERIFY_IN_FLIGHT"); int k = e ? atoi(e) : 16; return k < 1 ? 1 : k > 32 ? 32 : k; }(); return v; }
+  std::mutex cm; std::condition_variable ccv; std::vector<Pending *> open; size_t open_n = 0; bool open_led = false; int in_flight = 0;
+  std::atomic<uint64_t> launches{0}, calls{0};
   // layout of a context's staging area (host and device alike): proofs | inputs | -acc | verdicts
   size_t off_in() const {
     return CTX_CAP * sizeof(VerifyItem);
@@ -155,26 +166,27 @@ BatchVerifier::BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2Affine
   d.delta = DevArr<EllCoeffsDev>(ld.size());
   d.delta.upload(ld.data(), ld.size());
   { vsched::Schedule sc = vsched::build(alpha_g1_beta_g2, pg, pd);   // the workgroup-per-proof kernel's schedule (verify_sched.hpp)
-    sc.prog.resize(sc.prog.size() + 4 + 256 * vsched::WPL, 0u);   // (the kernel prefetches one round ahead: one round's worth of padding)
     const std::vector<uint32_t> c29 = vsched::consts29(sc);
-    d.sched_prog = DevBuf<uint32_t>(sc.prog.size());
+    d.sched_prog = DevBuf<uint32_t>(sc.prog.size());      // (padded by the builder: the kernel's ring reads PREFETCH_ROUNDS rounds ahead)
     d.sched_prog.upload(sc.prog.data(), sc.prog.size());
     d.sched_consts = DevBuf<uint32_t>(c29.size());
     d.sched_consts.upload(c29.data(), c29.size());
-    d.si.n_rounds = sc.n_rounds;
+    d.si.n_rounds_padded = sc.n_rounds_padded;
     d.si.n_slots = sc.n_slots;
     d.si.n_consts = (uint32_t)sc.consts.size();
-    for (int k = 0; k < 16; k++) d.si.out_slot[k] = sc.out_slot[k];
-    d.lds = ((size_t)sc.n_slots + sc.consts.size()) * l29::STRIDE * 4;
+    for (int k = 0; k < vsched::N_OUT; k++) d.si.out_slot[k] = sc.out_slot[k];
+    d.lds = ((size_t)sc.n_slots + sc.consts.size()) * l29::STRIDE * 4 + (size_t)vsched::PREFETCH_ROUNDS * 256 * 16;   // values, constants, the ring of instruction words
     if (d.lds > 160 * 1024) throw GpuError("verify: the schedule needs more LDS than a CU has");
     static std::once_flag attr;
-    std::call_once(attr, [&] { HIP_CHECK(hipFuncSetAttribute((const void *)k_verify_sched29, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+    std::call_once(attr, [&] { HIP_CHECK(hipFuncSetAttribute((const void *)k_verify_sched29<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_CHECK(hipFuncSetAttribute((const void *)k_verify_sched29<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
   }
-  { static const int n_ctx = [] { const char *e = getenv("ZK_VERIFY_STREAMS"); int v = e ? atoi(e) : 8; return v < 1 ? 1 : v > 32 ? 32 : v; }();
+  { static const int n_ctx = [] { const char *e = getenv("ZK_VERIFY_STREAMS"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : v > 32 ? 32 : v; }();
     for (int k = 0; k < n_ctx; k++) {
       std::unique_ptr<VerifyCtx> c(new VerifyCtx);
       HIP_CHECK(hipStreamCreateWithFlags(&c->s, hipStreamNonBlocking));
-      HIP_CHECK(hipHostMalloc((void **)&c->h, d.ctx_bytes()));
+      HIP_CHECK(hipHostMalloc((void **)&c->h, d.ctx_bytes(), hipHostMallocMapped));
+      HIP_CHECK(hipHostGetDevicePointer((void **)&c->hd, c->h, 0));
       c->d = DevBuf<uint8_t>(d.ctx_bytes());
       d.ctxs.push_back(std::move(c));
     }
@@ -216,51 +228,97 @@ BatchVerifier::BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2Affine
   d.tables = DevArr<Affine<Fq>>(tab.size()); d.tables.upload((const Affine<Fq> *)tab.data(), tab.size());
 }
 BatchVerifier::~BatchVerifier() = default;
+// ZK_VERIFY_FETCH (measurement): 0 = the round's words by a plain load, default 2 = the ring in LDS (pairing.cuh)
+static void launch_sched(BatchVerifier::Impl &d, unsigned n, hipStream_t s, const VerifyItem *items, const NegAcc3 *acc, uint8_t *ok, uint32_t *trace = nullptr,
+    uint32_t trace_every = 1) {
+  static const int fetch = [] { const char *e = getenv("ZK_VERIFY_FETCH"); return e ? atoi(e) : 2; }();
+  const uint4 *prog = (const uint4 *)d.sched_prog.get(), *consts = (const uint4 *)d.sched_consts.get();
+  if (fetch == 0) hipLaunchKernelGGL(k_verify_sched29<0>, dim3(n), dim3(256), d.lds, s, prog, consts, items, acc, (uint32_t)n, d.si, ok, trace, trace_every);
+  else hipLaunchKernelGGL(k_verify_sched29<2>, dim3(n), dim3(256), d.lds, s, prog, consts, items, acc, (uint32_t)n, d.si, ok, trace, trace_every);
+}
 size_t BatchVerifier::num_inputs() const { return impl->n_inputs; }
 size_t BatchVerifier::program_length() const { return impl->prog_len; }
+void BatchVerifier::counters(uint64_t out[2]) const { out[0] = impl->calls.load(); out[1] = impl->launches.load(); }
+// test entry: ONE proof through the kernels with the values of every `every`-th round written out; nacc_out: the 96 bytes the accumulation kernel handed to the
+// schedule kernel (x w, -y w, w; Montgomery)
+uint8_t BatchVerifier::trace(const void *proof_mont, const Fe32 *inputs_canonical, uint32_t every, std::vector<uint32_t> &values, uint8_t nacc_out[96]) {
+  Impl &d = *impl; hipStream_t s = gpu().stream; if (!every) throw GpuError("verify trace: every");
+  DevArr<VerifyItem> items(1); DevBuf<Fe32> in(d.n_inputs + 1); DevArr<NegAcc3> acc3(1); DevBuf<uint8_t> out(1);
+  items.upload((const VerifyItem *)proof_mont, 1); if (d.n_inputs) in.upload(inputs_canonical, d.n_inputs);
+  const size_t dumps = d.si.n_rounds_padded / every + 1, words = (size_t)d.si.n_slots * l29::STRIDE; DevBuf<uint32_t> tr(dumps * words);
+  hipLaunchKernelGGL(k_verify_acc_wave, dim3(1), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(), (uint32_t)d.n_inputs, 1u, acc3.get());
+  launch_sched(d, 1, s, items.get(), acc3.get(), out.get(), tr.get(), every);
+  HIP_CHECK(hipStreamSynchronize(s)); HIP_CHECK(hipGetLastError());
+  values.resize(dumps * words); tr.download(values.data(), values.size()); uint8_t ok = 0; out.download(&ok, 1);
+  HIP_CHECK(hipMemcpy(nacc_out, acc3.get(), 96, hipMemcpyDeviceToHost)); return ok;
+}
 void BatchVerifier::verify(const void *proofs_mont, const Fe32 *inputs_canonical, size_t n, uint8_t *ok) {
   // (gpu() also selects the device for this thread)
   if (!n) return;
   Impl &d = *impl;
   static_assert(sizeof(VerifyItem) == 256, "proof record");
   hipStream_t s = gpu().stream;
-  // a few proofs: one of the small contexts, nothing allocated, everything asynchronous on the context's stream until the one synchronisation
+  // a few proofs: one of the small contexts, nothing allocated; calls that meet share a launch (Impl::Pending)
   if (n <= Impl::CTX_CAP) {
-    VerifyCtx *c = nullptr;
-    for (size_t k = 0; k < d.ctxs.size() && !c; k++) {
-      VerifyCtx *t = d.ctxs[(d.next_ctx.fetch_add(1) + k) % d.ctxs.size()].get();
-      if (t->m.try_lock()) c = t;
+    Impl::Pending me{proofs_mont, inputs_canonical, n, ok}; d.calls.fetch_add(1, std::memory_order_relaxed);
+    std::unique_lock<std::mutex> lk(d.cm);
+    for (;;) {
+      if (d.open_led && d.open_n + n <= Impl::CTX_CAP) {                       // join the batch that is waiting for its slot
+        d.open.push_back(&me); d.open_n += n; d.ccv.wait(lk, [&] { return me.done; });
+        if (me.err) std::rethrow_exception(me.err);
+        return;
+      }
+      if (!d.open_led) break;
+      d.ccv.wait(lk);                                                            // (the waiting batch is full: until it has left)
     }
-    if (!c) { c = d.ctxs[d.next_ctx.fetch_add(1) % d.ctxs.size()].get(); c->m.lock(); }
-    std::lock_guard<std::mutex> lk(c->m, std::adopt_lock); uint8_t *dv = c->d.get();
-    memcpy(c->h, proofs_mont, n * sizeof(VerifyItem)); if (d.n_inputs) memcpy(c->h + d.off_in(), inputs_canonical, n * d.n_inputs * sizeof(Fe32));
-    HIP_CHECK(hipMemcpyAsync(dv, c->h, n * sizeof(VerifyItem), hipMemcpyHostToDevice, c->s));
-    if (d.n_inputs) HIP_CHECK(hipMemcpyAsync(dv + d.off_in(), c->h + d.off_in(), n * d.n_inputs * sizeof(Fe32), hipMemcpyHostToDevice, c->s));
-    { Stage st("verify.batch", c->s);
-      hipLaunchKernelGGL(k_verify_acc_wave, dim3((unsigned)n), dim3(64), 0, c->s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)(dv + d.off_in()),
-          (uint32_t)d.n_inputs, (uint32_t)n, (NegAcc3 *)(dv + d.off_acc()));
-      hipLaunchKernelGGL(k_verify_sched29, dim3((unsigned)n), dim3(256), d.lds, c->s, d.sched_prog.get(), (const uint4 *)d.sched_consts.get(),
-          (const VerifyItem *)dv, (const NegAcc3 *)(dv + d.off_acc()), (uint32_t)n, d.si, dv + d.off_ok());
-    }
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipMemcpyAsync(c->h + d.off_ok(), dv + d.off_ok(), n, hipMemcpyDeviceToHost, c->s));
-    HIP_CHECK(hipStreamSynchronize(c->s));
-    memcpy(ok, c->h + d.off_ok(), n);
+    d.open.assign(1, &me); d.open_n = n; d.open_led = true;
+    d.ccv.wait(lk, [&] { return d.in_flight < Impl::max_in_flight(); });
+    std::vector<Impl::Pending *> batch; batch.swap(d.open); const size_t total = d.open_n; d.open_n = 0; d.open_led = false; d.in_flight++;
+    lk.unlock(); d.ccv.notify_all();
+    std::exception_ptr err;
+    try {
+      VerifyCtx *c = nullptr;
+      for (size_t k = 0; k < d.ctxs.size() && !c; k++) {
+        VerifyCtx *t = d.ctxs[(d.next_ctx.fetch_add(1) + k) % d.ctxs.size()].get();
+        if (t->m.try_lock()) c = t;
+      }
+      if (!c) { c = d.ctxs[d.next_ctx.fetch_add(1) % d.ctxs.size()].get(); c->m.lock(); }
+      std::lock_guard<std::mutex> ck(c->m, std::adopt_lock);
+      // the records go into pinned memory the device reads in place (a few hundred bytes a proof: no copy command), the verdicts come back the same way
+      size_t at = 0;
+      for (Impl::Pending *q : batch) { memcpy(c->h + at * sizeof(VerifyItem), q->proofs, q->n * sizeof(VerifyItem));
+        if (d.n_inputs) memcpy(c->h + d.off_in() + at * d.n_inputs * sizeof(Fe32), q->inputs, q->n * d.n_inputs * sizeof(Fe32));
+        at += q->n; }
+      uint8_t *dv = c->d.get(); volatile uint8_t *hok = c->h + d.off_ok(); for (size_t k = 0; k < total; k++) hok[k] = 0xff;
+      { Stage st("verify.batch", c->s);
+        hipLaunchKernelGGL(k_verify_acc_wave, dim3((unsigned)total), dim3(64), 0, c->s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)(c->hd + d.off_in()),
+            (uint32_t)d.n_inputs, (uint32_t)total, (NegAcc3 *)(dv + d.off_acc()));
+        launch_sched(d, (unsigned)total, c->s, (const VerifyItem *)c->hd, (const NegAcc3 *)(dv + d.off_acc()), c->hd + d.off_ok());
+      }
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(c->s));
+      d.launches.fetch_add(1, std::memory_order_relaxed);
+      at = 0;
+      for (Impl::Pending *q : batch) { for (size_t k = 0; k < q->n; k++) { const uint8_t v = hok[at + k]; if (v > 2) throw GpuError("verify: a verdict did not arrive"); q->ok[k] = v; } at += q->n; }
+    } catch (...) { err = std::current_exception(); }
+    lk.lock(); d.in_flight--;
+    for (Impl::Pending *q : batch) if (q != &me) { q->err = err; q->done = true; }
+    lk.unlock(); d.ccv.notify_all();
+    if (err) std::rethrow_exception(err);
     return;
   }
   std::lock_guard<std::mutex> lk(d.big);
   DevArr<VerifyItem> items(n); DevBuf<Fe32> in(n * d.n_inputs + 1); DevArr<Affine<Fq>> acc(n); DevBuf<uint8_t> out(n);
   items.upload((const VerifyItem *)proofs_mont, n); if (d.n_inputs) in.upload(inputs_canonical, n * d.n_inputs);
   Stage st("verify.batch");
-  // up to WAVE_MAX proofs: one workgroup each (latency of a proof ~ the schedule's rounds, 256 proofs at a time on the chip's 256 CUs); beyond that the
-  // lane-per-proof kernel, whose 25 ms floor is then amortised over thousands
-  static const size_t wave_max = [] { const char *e = getenv("ZK_VERIFY_WAVE_MAX"); long v = e ? atol(e) : 2048; return (size_t)(v < 0 ? 0 : v); }();
+  // up to WAVE_MAX proofs: one workgroup each (a proof's latency is the schedule's ~900 rounds; two workgroups share a CU: 0.9 ms for 256 proofs, 1.7 ms for 512,
+  // 24.5 ms for 8,192 — 330 K proofs/s); beyond that the lane-per-proof kernel, whose 26 ms floor is then amortised over more (profiles/r06_verify_batch.txt)
+  static const size_t wave_max = [] { const char *e = getenv("ZK_VERIFY_WAVE_MAX"); long v = e ? atol(e) : 8192; return (size_t)(v < 0 ? 0 : v); }();
   if (n <= wave_max) { DevArr<NegAcc3> acc3(n);
     hipLaunchKernelGGL(k_verify_acc_wave, dim3((unsigned)n), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(),
         (uint32_t)d.n_inputs, (uint32_t)n, acc3.get());
     // (acc3 lives until the kernels are done)
-    hipLaunchKernelGGL(k_verify_sched29, dim3((unsigned)n), dim3(256), d.lds, s, d.sched_prog.get(), (const uint4 *)d.sched_consts.get(), items.get(),
-        acc3.get(), (uint32_t)n, d.si, out.get());
+    launch_sched(d, (unsigned)n, s, items.get(), acc3.get(), out.get());
     HIP_CHECK(hipStreamSynchronize(s));
   } else {
     hipLaunchKernelGGL(k_verify_acc, dim3(cdiv(n, 64)), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(), (uint32_t)d.n_inputs,

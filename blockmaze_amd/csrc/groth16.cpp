@@ -1707,7 +1707,7 @@ bool verify_proof(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_
 
 // The decision of verify_proof() taken by the GPU verifier's SCHEDULE (verify_sched.hpp) interpreted on the host: what kernel K9 computes, without a GPU. Test
 // entry (zkgpu_test_verify_schedule): the schedule is checked against the host verifier and the oracle on the CPU before any device runs it. stats: rounds,
-// slots, products, linear operations, constants, then the rounds of products / eight-lane sums / one-lane sums.
+// slots, products, linear operations, constants, then the WAVES of products / eight-lane sums / one-lane sums.
 bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t stats[8]) {
   const VerifyingKeyHost &vk = pvk.vk; vsched::Schedule S = vsched::build(vk.alpha_g1_beta_g2, pvk.gamma, pvk.delta);
   if (stats) {
@@ -1716,9 +1716,9 @@ bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inp
     stats[2] = S.n_mul;
     stats[3] = S.n_lin;
     stats[4] = (uint32_t)S.consts.size();
-    stats[5] = S.rounds_of_kind[vsched::K_MUL];
-    stats[6] = S.rounds_of_kind[vsched::K_LIN8];
-    stats[7] = S.rounds_of_kind[vsched::K_LIN1];
+    stats[5] = S.waves_of_kind[vsched::K_MUL];
+    stats[6] = S.waves_of_kind[vsched::K_LIN8];
+    stats[7] = S.waves_of_kind[vsched::K_LIN1];
   }
   if (vk.IC.size() != n_inputs + 1) return false;
   HG1 acc = g1_of(vk.IC[0]);
@@ -1740,19 +1740,40 @@ bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inp
   in[vsched::IN_BY1] = fq_of(proof.B.y1);
   in[vsched::IN_CX] = fq_of(proof.C.x);
   in[vsched::IN_CY] = fq_of(proof.C.y);
-  in[vsched::IN_NACCX] = accx;
-  in[vsched::IN_NACCY] = accy.neg();
-  in[vsched::IN_NACCW] = HFq::one();
+  // (the accumulation kernel hands the point over as (x w, -y w, w) with w = ZZ ZZZ of its sum: a non-trivial w here too, so that the CPU tests cover the scaling)
+  const HFq w = HFq::from_u64(0x9e3779b97f4a7c15ull ^ ((uint64_t)accx.l[0] | (uint64_t)accx.l[1] << 32)) + HFq::one();
+  in[vsched::IN_NACCX] = accx * w;
+  in[vsched::IN_NACCY] = (accy * w).neg();
+  in[vsched::IN_NACCW] = w;
   std::vector<HFq> out = vsched::simulate(S, in); bool ok = true;
-  // the GT value minus alpha_g1_beta_g2, then the on-curve residues
-  for (int k = 0; k < vsched::N_RESULT + vsched::N_CHECK; k++) ok = ok && out[k].is_zero();
+  // the GT comparison, then the on-curve residues: all zero; the norm of the Miller value: not zero
+  for (int k = 0; k < vsched::N_OUT; k++) ok = ok && (k == vsched::OUT_NONZERO ? !out[k].is_zero() : out[k].is_zero());
   // ... and the same program on the kernel's own limb arithmetic (every bound asserted on the way): value by value the same verdicts
   uint32_t words[vsched::N_INPUTS][8]; for (int i = 0; i < vsched::N_INPUTS; i++) memcpy(words[i], in[i].l, 32);
   std::vector<bool> zero29 = vsched::simulate29(S, words);
-  for (int k = 0; k < vsched::N_RESULT + vsched::N_CHECK;
+  for (int k = 0; k < vsched::N_OUT;
       k++) if (zero29[k] != out[k].is_zero()) throw std::runtime_error("verify schedule: the 29-bit model and the field model disagree on output " +
       std::to_string(k));
   return ok;
+}
+// Kernel K9 against the host model of its own arithmetic, value by value: one proof runs through the device kernels with the LDS values written out after every
+// `every`-th round; vsched::simulate29 is fed the same inputs (the accumulation kernel's record included) and must hold the same limbs in every slot that the
+// schedule has written by then.  Returns -1 if every dump agrees, otherwise the first round whose dump differs (slot in *bad_slot); *device_ok = the kernel's verdict.
+long verify_schedule_trace_on_device(BatchVerifier &bv, const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t every,
+    uint32_t *bad_slot, uint8_t *device_ok) {
+  const VerifyingKeyHost &vk = pvk.vk; if (vk.IC.size() != n_inputs + 1 || bv.num_inputs() != n_inputs) throw std::runtime_error("verify trace: input count");
+  vsched::Schedule S = vsched::build(vk.alpha_g1_beta_g2, pvk.gamma, pvk.delta);
+  std::vector<uint32_t> values; uint8_t nacc[96]; const uint8_t ok = bv.trace(&proof, inputs, every, values, nacc); if (device_ok) *device_ok = ok;
+  uint32_t words[vsched::N_INPUTS][8]; const Fe32 *pc = reinterpret_cast<const Fe32 *>(&proof);           // A.x A.y | B.x.c0 B.x.c1 B.y.c0 B.y.c1 | C.x C.y
+  for (int k = 0; k < 8; k++) memcpy(words[k], &pc[k], 32);
+  for (int k = 0; k < 3; k++) memcpy(words[vsched::IN_NACCX + k], nacc + 32 * k, 32);
+  const size_t stride = (size_t)S.n_slots * l29::STRIDE; long first_bad = -1; uint32_t slot_bad = 0; std::vector<char> written(S.n_slots, 0);
+  for (int k = 0; k < vsched::N_INPUTS; k++) written[k] = 1;
+  vsched::simulate29(S, words, [&](uint32_t r, const std::vector<std::array<uint32_t, 9>> &slots) {
+    vsched::for_each_op(S, r, [&](uint32_t, uint32_t, const uint32_t *w) { written[w[0] & 0x7fffu] = 1; });
+    if (first_bad >= 0 || (r + 1) % every != 0 || r >= S.n_rounds) return; const uint32_t *dv = &values[(size_t)(r / every) * stride];
+    for (uint32_t sl = 0; sl < S.n_slots && first_bad < 0; sl++) if (written[sl] && memcmp(dv + (size_t)sl * l29::STRIDE, slots[sl].data(), 36) != 0) { first_bad = (long)r; slot_bad = sl; } });
+  if (bad_slot) *bad_slot = slot_bad; return first_bad;
 }
 std::unique_ptr<BatchVerifier> make_batch_verifier(const VerifyingKeyHost &vk) {
   return std::unique_ptr<BatchVerifier>(new BatchVerifier(vk.alpha_g1_beta_g2, vk.gamma_g2, vk.delta_g2, vk.IC.data(), vk.IC.size()));

@@ -107,6 +107,9 @@ bool verify_proof(const PreparedVerifyingKey &pvk, const Fe32 *inputs /* canonic
 
 // the GPU verifier's schedule interpreted on the host (test entry)
 bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t stats[8]);
+// kernel K9's LDS values after every `every`-th round against vsched::simulate29 on the same inputs: -1 = all equal, else the first differing round (GPU tests)
+long verify_schedule_trace_on_device(BatchVerifier &bv, const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t every,
+    uint32_t *bad_slot, uint8_t *device_ok);
 // the same decision for n proofs at once on the GPU (kernel K9): one BatchVerifier per verifying key
 std::unique_ptr<BatchVerifier> make_batch_verifier(const VerifyingKeyHost &vk);
 static_assert(sizeof(Proof) == 256, "proof record");

@@ -174,11 +174,12 @@ __global__ void __launch_bounds__(64) k_verify_batch(const uint32_t *__restrict_
 // profiles/r03_verify_batch.txt.
 // ok[i]: 1 accept, 0 reject, 2 = the input accumulator was the point at infinity (the host verifier decides: the gamma pairing is the identity then, which a
 // fixed schedule cannot express).
-struct SchedInfo { uint32_t n_rounds, n_slots, n_consts, out_slot[16]; };
+struct SchedInfo { uint32_t n_rounds_padded, n_slots, n_consts, out_slot[vsched::N_OUT]; };
 constexpr uint32_t VS_CONST_FLAG = 0x8000u;
 // LDS: [n_slots working values | n_consts constants of the key], 48 bytes each — the constants are copied in once per proof (coalesced), so that every operand
 // of every round is LDS reads: with the constants in global memory a round's critical path held a dependent global load (measured: 1.4 us per round instead of
-// ~0.6). The instruction words of round r + 1 are fetched while round r computes (prog is padded by one round's worth of words).
+// ~0.6). The instruction words are a dense array (round, lane) -> uint4: the fetch of round r + D depends on r alone, and D = vsched::PREFETCH_ROUNDS rounds
+// are in flight in a ring of registers (the loop is unrolled D times so that the ring's indices are static).
 struct NegAcc3 { Fq xw, nyw, w; };     // -acc = (x, -y) as (x w, -y w, w), w = ZZ ZZZ of the accumulation's extended Jacobian sum; w = 0: the point at infinity
 // barrier over the workgroup's LDS traffic only: __syncthreads() also drains the outstanding GLOBAL loads (s_waitcnt vmcnt(0)) — here the next round's
 // instruction words, fetched a round ahead precisely so that nobody waits for them
@@ -202,10 +203,63 @@ __device__ __forceinline__ void vs_store(uint32_t *lds, uint32_t slot, const uin
 template <int N> __device__ __forceinline__ void vs_add_from_below(uint32_t (&l)[9]) {
 #pragma unroll
   for (int i = 0; i < 9; i++) l[i] += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l[i], 0x110 + N, 0xf, 0xf, true); }
-static __global__ void __launch_bounds__(256) k_verify_sched29(const uint32_t *__restrict__ prog, const uint4 *__restrict__ consts,
-    const VerifyItem *__restrict__ items, const NegAcc3 *__restrict__ neg_acc, uint32_t n, SchedInfo si, uint8_t *__restrict__ ok) {
+// one round of the schedule for this lane: wd = its four instruction words
+__device__ __forceinline__ void vs_round(uint32_t *lds, uint32_t n_slots, const uint4 wd) {
+  constexpr uint32_t LIVE = vsched::LIVE_BIT, STORE = vsched::STORE_BIT;
+  const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane(wd.x) >> vsched::KIND_SHIFT;   // (the builtin returns int: a signed shift would smear the top bit)
+    // the WAVE's kind (every lane of a wave carries it, idle lanes too)
+  const bool live = wd.x & LIVE;
+  uint32_t v[9];
+  if (kind == vsched::K_MUL) {
+    if (live) { Fq29 a, b; vs_load(lds, n_slots, wd.y, a.l); vs_load(lds, n_slots, wd.z, b.l); const Fq29 pr = Fq29::mul(a, b);
+#pragma unroll
+      for (int k = 0; k < 9; k++) v[k] = pr.l[k]; }
+  } else if (kind != vsched::K_IDLE) {
+    uint64_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) {
+      uint32_t x[9];
+      vs_load(lds, n_slots, wd.y & 0xffffu, x);
+      l29::term(acc, x, wd.y >> 17, (wd.y >> 16) & 1);
+      vs_load(lds, n_slots, wd.z & 0xffffu, x);
+      l29::term(acc, x, wd.z >> 17, (wd.z >> 16) & 1);
+      vs_load(lds, n_slots, wd.w & 0xffffu, x);
+      l29::term(acc, x, wd.w >> 17, (wd.w >> 16) & 1);
+    }
+    l29::norm64(acc, v);
+    // the sum of a group's eight lanes arrives in its last lane
+    if (kind == vsched::K_LIN8) {
+      vs_add_from_below<4>(v);
+      vs_add_from_below<2>(v);
+      l29::norm32(v);
+      vs_add_from_below<1>(v);
+    }
+    l29::barrett(v);
+  }
+  // (no barrier between a round's reads and its writes: the builder never hands out a slot as destination in the round that reads it last)
+  if (wd.x & STORE) vs_store(lds, wd.x & 0x7fffu, v);
+}
+// this lane's 16 bytes of round `src` straight from global memory into LDS (no register in between: nothing for the compiler to copy while the load is in flight).
+// lds_wave_base: byte address in LDS of the wave's 64 x 16 bytes, wave-uniform. Completion is counted by vmcnt like any load's; the compiler does not know about
+// this load, the kernel waits for it by hand.
+__device__ __forceinline__ void vs_fetch_to_lds(const uint4 *src, uint32_t lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base)) : "memory");
+}
+// FETCH: how a round's instruction words reach the lane — 0: a plain load at the head of the round (the round waits for it: measurement only; 1.10 ms per launch
+// against 0.95), 2: a ring of vsched::PREFETCH_ROUNDS rounds in LDS filled by LDS-direct loads (the shipped form).  (A ring of registers was measured too: as fast, but
+// the compiler copies the ring at the loop's back edge behind a full wait, and 16 KB of LDS are there to be had.)
+template <int FETCH>
+static __global__ void __launch_bounds__(256) k_verify_sched29(const uint4 *__restrict__ prog, const uint4 *__restrict__ consts,
+    const VerifyItem *__restrict__ items, const NegAcc3 *__restrict__ neg_acc, uint32_t n, SchedInfo si, uint8_t *__restrict__ ok, uint32_t *__restrict__ trace,
+    uint32_t trace_every) {
   extern __shared__ uint4 vs_lds4[]; uint32_t *lds = reinterpret_cast<uint32_t *>(vs_lds4);
   const uint32_t i = blockIdx.x, lane = threadIdx.x; if (i >= n) return;
+  // (tests: proof 0's values after every trace_every-th round, n_slots x 12 words each — compared with the host model of the same arithmetic, vsched::simulate29)
+  auto dump = [&](uint32_t r) { if (trace && i == 0 && (r + 1) % trace_every == 0) { const uint32_t words = si.n_slots * l29::STRIDE; uint32_t *dst = trace + (size_t)(r / trace_every) * words;
+      for (uint32_t k = lane; k < words; k += 256) dst[k] = lds[k]; } };
+  constexpr uint32_t DL = vsched::PREFETCH_ROUNDS; static_assert((DL & (DL - 1)) == 0 && DL <= 32, "ring size");
+  // the LDS ring: after the values and the constants, DL rounds of 4 KB; a wave reads and refills only its own kilobyte of each
+  uint4 *ring_lds = vs_lds4 + (size_t)(si.n_slots + si.n_consts) * (l29::STRIDE / 4);
+  const uint32_t ring_wave_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)ring_lds + (lane >> 6) * 1024u;
   { uint4 *dst = vs_lds4 + si.n_slots * (l29::STRIDE / 4); for (uint32_t k = lane; k < si.n_consts * (l29::STRIDE / 4); k += 256) dst[k] = consts[k]; }
   const VerifyItem &it = items[i]; const NegAcc3 nacc = neg_acc[i];
   // vsched::IN_* order
@@ -217,54 +271,35 @@ static __global__ void __launch_bounds__(256) k_verify_sched29(const uint32_t *_
     for (int k = 0; k < 8; k++) w[k] = v.l[k];
     l29::lift(w, l); vs_store(lds, lane, l); }
   __syncthreads();
-  const uint32_t *pc = prog; uint4 hq = *reinterpret_cast<const uint4 *>(pc), wq = make_uint4(0, 0, 0, 0);
-  { const uint32_t cnt = (__builtin_amdgcn_readfirstlane(hq.x) >> 4) & 1023; if (lane < cnt) wq = *reinterpret_cast<const uint4 *>(pc + 4 + lane * 4); }
+  const uint32_t n_rounds = si.n_rounds_padded - DL;        // (the builder's padding: a multiple of DL rounds, then DL idle ones that are fetched but never run)
+  if constexpr (FETCH == 0) {
 #pragma unroll 1
-  for (uint32_t r = 0; r < si.n_rounds; r++) {
-    // vsched::hdr; word 1: the next round's header
-    const uint32_t h = __builtin_amdgcn_readfirstlane(hq.x), hnext = __builtin_amdgcn_readfirstlane(hq.y), kind = h & 15, count = (h >> 4) & 1023;
-    const bool live = lane < count;
-    const uint4 wd = wq;
-    // the next round's header and words: in flight during this round's arithmetic
-    pc += 4 + count * 4;
-    hq = *reinterpret_cast<const uint4 *>(pc);
-    if (lane < ((hnext >> 4) & 1023)) wq = *reinterpret_cast<const uint4 *>(pc + 4 + lane * 4);
-    uint32_t v[9];
-    if (kind == 1) {
-      if (live) { Fq29 a, b; vs_load(lds, si.n_slots, wd.y, a.l); vs_load(lds, si.n_slots, wd.z, b.l); const Fq29 pr = Fq29::mul(a, b);
+    for (uint32_t r = 0; r < n_rounds; r++) { const uint4 wd = prog[(size_t)r * 256 + lane]; vs_round(lds, si.n_slots, wd); vs_lds_barrier(); dump(r); }
+  } else {
+    // (every load the compiler knows of has been waited for at the barrier above; from here on this wave's only outstanding loads are the ring's, one per round)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < 9; k++) v[k] = pr.l[k]; }
-    } else {
-      uint64_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (live) {
-        uint32_t x[9];
-        vs_load(lds, si.n_slots, wd.y & 0xffffu, x);
-        l29::term(acc, x, wd.y >> 17, (wd.y >> 16) & 1);
-        vs_load(lds, si.n_slots, wd.z & 0xffffu, x);
-        l29::term(acc, x, wd.z >> 17, (wd.z >> 16) & 1);
-        vs_load(lds, si.n_slots, wd.w & 0xffffu, x);
-        l29::term(acc, x, wd.w >> 17, (wd.w >> 16) & 1);
-      }
-      l29::norm64(acc, v);
-      // the sum of a group's eight lanes arrives in its last lane
-      if (kind == 2) {
-        vs_add_from_below<4>(v);
-        vs_add_from_below<2>(v);
-        l29::norm32(v);
-        vs_add_from_below<1>(v);
-      }
-      l29::barrett(v);
+    for (uint32_t d = 0; d < DL; d++) vs_fetch_to_lds(prog + (size_t)d * 256 + lane, ring_wave_base + d * 4096u);
+    const uint4 *pf = prog + (size_t)DL * 256 + lane;
+#pragma unroll 1
+    for (uint32_t r = 0; r < n_rounds; r++) {
+      const uint32_t slot = r & (DL - 1);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DL - 1) : "memory");                     // the oldest of the DL fetches in flight — this round's — has landed
+      const uint4 wd = ring_lds[slot * 256 + lane];
+      vs_round(lds, si.n_slots, wd);
+      vs_fetch_to_lds(pf + (size_t)r * 256, ring_wave_base + slot * 4096u);           // round r + DL into the kilobyte this round's words just left
+      vs_lds_barrier();
+      dump(r);
     }
-    // (no barrier between a round's reads and its writes: the builder never hands out a slot as destination in the round that reads it last)
-    if (live && (kind != 2 || (lane & 7) == 7)) vs_store(lds, wd.x, v);
-    vs_lds_barrier();                     // every result is written before the next round reads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   if (lane == 0) { bool good = !it.A.is_inf() && !it.B.is_inf() && !it.C.is_inf();
-    // the GT value minus alpha_g1_beta_g2, and the on-curve residues: all zero
-    for (int k = 0; k < 16; k++) {
+    // the GT comparison and the on-curve residues: all zero; the norm of the Miller value: not zero
+    for (int k = 0; k < vsched::N_OUT; k++) {
       uint32_t x[9];
       vs_load(lds, si.n_slots, si.out_slot[k], x);
-      good = good && l29::multiple_of_p(x);
+      const bool z = l29::multiple_of_p(x);
+      good = good && (k == vsched::OUT_NONZERO ? !z : z);
     }
     ok[i] = nacc.w.is_zero() ? 2 : good ? 1 : 0; }
 }

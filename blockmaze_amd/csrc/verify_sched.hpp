@@ -24,6 +24,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -112,25 +113,35 @@ inline void mul_model(const uint32_t (&a)[9], const uint32_t (&b)[9], uint32_t (
 namespace vsched {
 using host::HFq; using host::HFq2;
 
-// a round: one operation per lane of a 256-thread workgroup (a dense Fq12 product's 144 Fq products are ONE round)
-constexpr uint32_t CONST_FLAG = 0x8000u, LIN_GROUP = 8, TERMS_PER_LANE = 3, MAX_TERMS = LIN_GROUP * TERMS_PER_LANE, MAX_COEF = 255, LANES = 256;
-// instruction words per lane: MUL dst, a, b, 0; LIN dst, then three terms (src | neg << 16 | |c| << 17; c = 0: no term)
-constexpr uint32_t WPL = 4;
-inline uint32_t hdr(uint32_t kind, uint32_t count) { return kind | count << 4; }
-inline void unhdr(uint32_t h, uint32_t &kind, uint32_t &count) { kind = h & 15; count = (h >> 4) & 1023; }
-enum : uint32_t { K_MUL = 1, K_LIN8 = 2, K_LIN1 = 3 };
+// A ROUND is one operation per lane of a 256-thread workgroup, decided WAVE by wave (round 6): each of the four waves of a round executes one kind of operation
+// (products / eight-lane sums / one-lane sums / nothing), so a level of the dependency graph that holds 78 products of one chain and a dozen sums of another is
+// still one round.  The program is a dense array: round r, lane l -> four words at (r * 256 + l) * 4, no headers, no counts — the kernel's fetch of round r + D
+// depends on nothing but r (a ring of D rounds in flight; the first generation's "next round" fetch sat behind a header load and a branch and was in effect
+// synchronous: ~0.5 us of every round was the wait for it).
+//     word 0: destination slot | live << 16 | store << 17 | kind << 30 (the wave's kind, in every lane's word, idle lanes included)
+//     MUL    slot[dst] = slot[a] * slot[b]                         (words 1, 2: a, b)
+//     LIN8   slot[dst] = sum of up to 24 terms c * slot[src], |c| <= 255   (eight lanes per value, three terms each — words 1..3 —, then a tree over the eight lanes; the
+//                                                                            group's last lane stores)
+//     LIN1   the same with up to 3 terms, one lane per value
+//     term word: src | neg << 16 | |c| << 17; c = 0: no term
+constexpr uint32_t CONST_FLAG = 0x8000u, LIN_GROUP = 8, TERMS_PER_LANE = 3, MAX_TERMS = LIN_GROUP * TERMS_PER_LANE, MAX_COEF = 255, LANES = 256, WAVE = 64,
+    WAVES = LANES / WAVE;
+constexpr uint32_t WPL = 4, LIVE_BIT = 1u << 16, STORE_BIT = 1u << 17, KIND_SHIFT = 30;
+constexpr uint32_t PREFETCH_ROUNDS = 4;   // the kernel's ring of rounds in flight: the program is padded to a multiple of this many rounds, plus as many idle rounds again
+enum : uint32_t { K_IDLE = 0, K_MUL = 1, K_LIN8 = 2, K_LIN1 = 3 };
 // per-proof inputs: fixed slots 0 .. N_INPUTS-1
 enum : int { IN_AX = 0, IN_AY, IN_BX0, IN_BX1, IN_BY0, IN_BY1, IN_CX, IN_CY, IN_NACCX, IN_NACCY, IN_NACCW, N_INPUTS };
 // (IN_NACC*: the negated input accumulator -acc = (x, -y) given as (x w, -y w, w) for any non-zero w in Fq — the gamma line values are evaluated times w, a
-// factor the final
-//  exponentiation kills — so that the accumulation kernel needs no inversion: w = ZZ ZZZ of its extended Jacobian sum)
-// outputs, all of which must be ZERO (mod p): the GT value minus vk.alpha_g1_beta_g2 (tower order), then A, C on the curve and B on the twist (two components)
-constexpr int N_RESULT = 12, N_CHECK = 4;
+// factor the final exponentiation kills — so that the accumulation kernel needs no inversion: w = ZZ ZZZ of its extended Jacobian sum)
+// outputs 0 .. 15 must be ZERO (mod p): the GT comparison (tower order), then A, C on the curve and B on the twist (two components); output 16 must NOT be zero:
+// the norm of the Miller value (below)
+constexpr int N_RESULT = 12, N_CHECK = 4, N_ZERO = N_RESULT + N_CHECK, OUT_NONZERO = N_ZERO, N_OUT = N_ZERO + 1;
 
 struct Schedule {
-  std::vector<uint32_t> prog;        // rounds: [hdr(kind, lanes), the next round's hdr, 0, 0], then lanes * WPL words
+  std::vector<uint32_t> prog;        // n_rounds_padded * LANES * WPL words
   std::vector<HFq> consts;           // CONST_FLAG | index
-  uint32_t n_rounds = 0, n_slots = 0, n_mul = 0, n_lin = 0, rounds_of_kind[4] = {0, 0, 0, 0}, out_slot[N_RESULT + N_CHECK] = {0};
+  uint32_t n_rounds = 0 /* with work */, n_rounds_padded = 0, n_slots = 0, n_mul = 0, n_lin = 0, waves_of_kind[4] = {0, 0, 0, 0}, out_slot[N_OUT] = {0};
+  uint32_t n_levels = 0; std::vector<uint32_t> round_level;   // diagnostics: the dependency depth, and the level every round belongs to
 };
 
 class Builder {
@@ -226,20 +237,10 @@ struct Tower {
     }
     return {b.lin(a), b.lin(c)};
   }
-  F2 inv(const F2 &x) { int n = b.add(b.mul(x.c0, x.c0), b.mul(x.c1, x.c1)), t = fq_inv(n); return {b.mul(x.c0, t), b.neg(b.mul(x.c1, t))}; }
-  // x^(q-2) by 4-bit windows (Fermat; the reference uses mpn_gcdext, fp.tcc:688 — same value): a chain of ~330 dependent products, one lane busy
-  int fq_inv(int x) { int tab[16]; tab[0] = b.one_node; tab[1] = x; for (int i = 2; i < 16; i++) tab[i] = b.mul(tab[i - 1], x);
-    uint32_t e[8]; uint64_t br = 2; for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)FqParams::MOD[i] - br; e[i] = (uint32_t)t; br = (t >> 32) & 1; }
-    int r = -1;
-    for (int w = 63; w >= 0; w--) {
-      if (r >= 0) for (int k = 0; k < 4; k++) r = b.mul(r, r);
-      const uint32_t d = (e[w >> 3] >> ((w & 7) * 4)) & 15;
-      if (d) r = r < 0 ? tab[d] : b.mul(r, tab[d]);
-    }
-    return r; }
 
   F12 one12() { F12 r; for (auto &c : r) c = zero2(); r[0] = one2(); return r; }
-  // 36 Fq2 products (fewer when an operand is sparse: products with the zero node vanish), then per coefficient: lo + xi * hi
+  // 36 Fq2 products (fewer when an operand is sparse: products with the zero node vanish; a square's symmetric products are one node), then per coefficient:
+  // lo + xi * hi
   F12 mul(const F12 &x, const F12 &y) {
     F12 r;
     for (int k = 0; k < 6; k++) { std::vector<std::pair<int, int>> lo0, lo1, hi0, hi1;
@@ -271,20 +272,30 @@ struct Tower {
       if (i) k = k * t.fq12_c1[p % 12];
       F2 v = (p & 1) ? conj(x[e]) : x[e]; r[e] = (j == 0 && i == 0) ? v : mul(v, k2(k)); }
     return r; }
-  // Fq6 = Fq2[v]/(v^3 - xi) on {c0, c1, c2}: only what the Fq12 inverse needs
+  // Fq6 = Fq2[v]/(v^3 - xi) on {c0, c1, c2}: only what the inverse-free Fq12 "inverse" needs. Schoolbook (nine Fq2 products, ONE level of sums — the lanes are
+  // there, the depth is what counts): (a0 b0 + xi (a1 b2 + a2 b1), a0 b1 + a1 b0 + xi a2 b2, a0 b2 + a1 b1 + a2 b0)
   typedef std::array<F2, 3> F6;
-  F6 mul6(const F6 &x, const F6 &y) { F2 aA = mul(x[0], y[0]), bB = mul(x[1], y[1]), cC = mul(x[2], y[2]);
-    return {add(aA, mul_xi(sub(sub(mul(add(x[1], x[2]), add(y[1], y[2])), bB), cC))), add(sub(sub(mul(add(x[0], x[1]), add(y[0], y[1])), aA), bB), mul_xi(cC)),
-        add(sub(mul(add(x[0], x[2]), add(y[0], y[2])), aA), sub(bB, cC))};
+  F6 mul6_xi(const F6 &x, const F6 &y) {
+    const F2 a = mul(x[0], y[0]), bb = mul(x[1], y[2]), c = mul(x[2], y[1]), d = mul(x[0], y[1]), e = mul(x[1], y[0]), f = mul(x[2], y[2]), g = mul(x[0], y[2]),
+        h = mul(x[1], y[1]), i = mul(x[2], y[0]);
+    // xi * t = (9 t0 - t1, 9 t1 + t0)
+    auto plus_xi = [&](const std::vector<F2> &plain, const std::vector<F2> &by_xi) { std::vector<std::pair<int, int>> r0, r1;
+      for (auto &p : plain) { r0.push_back({1, p.c0}); r1.push_back({1, p.c1}); }
+      for (auto &t : by_xi) { r0.push_back({9, t.c0}); r0.push_back({-1, t.c1}); r1.push_back({9, t.c1}); r1.push_back({1, t.c0}); }
+      return F2{b.lin(r0), b.lin(r1)}; };
+    return {plus_xi({a}, {bb, c}), plus_xi({d, e}, {f}), plus_xi({g, h, i}, {})};
   }
   F6 mul_by_v(const F6 &x) { return {mul_xi(x[2]), x[0], x[1]}; }
-  F12 inv(const F12 &x) {   // fp12_2over3over2.tcc:128-137 over fp6_3over2.tcc:128-146
-    F6 c0 = {x[0], x[2], x[4]}, c1 = {x[1], x[3], x[5]}, s0 = mul6(c0, c0), s1 = mul6(c1, c1), m = mul_by_v(s1), t = {sub(s0[0], m[0]), sub(s0[1], m[1]),
+  // The inverse of the Miller value WITHOUT an inversion: x^-1 = P / n with P in Fq12 and n in Fq, both made of products only — n is the norm of x down to Fq
+  // (fp12_2over3over2.tcc:128-137 over fp6_3over2.tcc:128-146 over fp2.tcc's inverse, every division carried along as a denominator). Returns P, sets n.
+  F12 pseudo_inverse(const F12 &x, int &n) {
+    F6 c0 = {x[0], x[2], x[4]}, c1 = {x[1], x[3], x[5]}, s0 = mul6_xi(c0, c0), s1 = mul6_xi(c1, c1), m = mul_by_v(s1), t = {sub(s0[0], m[0]), sub(s0[1], m[1]),
         sub(s0[2], m[2])};
     F2 t0 = sqr(t[0]), t1 = sqr(t[1]), t2 = sqr(t[2]), t3 = mul(t[0], t[1]), t4 = mul(t[0], t[2]), t5 = mul(t[1], t[2]), d0 = sub(t0, mul_xi(t5)),
         d1 = sub(mul_xi(t2), t3), d2 = sub(t1, t4);
-    F2 t6 = inv(add(mul(t[0], d0), mul_xi(add(mul(t[2], d1), mul(t[1], d2)))));
-    F6 ti = {mul(t6, d0), mul(t6, d1), mul(t6, d2)}, r0 = mul6(c0, ti), r1 = mul6(c1, ti);
+    F2 N = add(mul(t[0], d0), mul_xi(add(mul(t[2], d1), mul(t[1], d2))));                 // the norm of t down to Fq2; t^-1 = (d0, d1, d2) / N
+    n = b.add(b.mul(N.c0, N.c0), b.mul(N.c1, N.c1));                                      // N^-1 = conj(N) / n
+    const F2 Nc = conj(N); F6 ti = {mul(Nc, d0), mul(Nc, d1), mul(Nc, d2)}, r0 = mul6_xi(c0, ti), r1 = mul6_xi(c1, ti);
     return {r0[0], neg(r1[0]), r0[1], neg(r1[1]), r0[2], neg(r1[2])}; }
   // the operand of mul_by_024 (fp12_2over3over2.tcc:240-335): (ell_0, 0, ell_VV | 0, ell_VW, 0) in the tower = w^0, w^4, w^3
   F12 sparse(const F2 &ell_0, const F2 &ell_VW, const F2 &ell_VV) {
@@ -300,11 +311,23 @@ struct Tower {
 static const uint64_t BN_Z = 4965661367192848881ull;                         // alt_bn128_init.cpp:327 (final_exponent_z)
 static const uint64_t ATE_LOOP[2] = {0x9d797039be763ba8ull, 0x1ull};          // 6z+2 (alt_bn128_init.cpp:324)
 
+// little-endian 32-bit digits, enough for 2 (48 z^3 + 30 z^2 + 28 z + 2)
+struct Big { std::vector<uint32_t> d;
+  static Big of(uint64_t v) { Big r; r.d = {(uint32_t)v, (uint32_t)(v >> 32)}; return r; }
+  Big operator*(const Big &o) const { Big r; r.d.assign(d.size() + o.d.size(), 0u);
+    for (size_t i = 0; i < d.size(); i++) { uint64_t c = 0; for (size_t j = 0; j < o.d.size() || c; j++) { const uint64_t t = (uint64_t)r.d[i + j] + c + (j < o.d.size() ? (uint64_t)d[i] * o.d[j] : 0); r.d[i + j] = (uint32_t)t; c = t >> 32; } }
+    return r; }
+  Big operator+(const Big &o) const { Big r; r.d.assign(std::max(d.size(), o.d.size()) + 1, 0u); uint64_t c = 0;
+    for (size_t i = 0; i < r.d.size(); i++) { c += (i < d.size() ? d[i] : 0u); c += (i < o.d.size() ? o.d[i] : 0u); r.d[i] = (uint32_t)c; c >>= 32; } return r; }
+  int bits() const { for (size_t i = d.size(); i-- > 0;) if (d[i]) return (int)(32 * i + 32 - __builtin_clz(d[i])); return 0; }
+  bool bit(int i) const { return (size_t)(i >> 5) < d.size() && ((d[i >> 5] >> (i & 31)) & 1); }
+};
+
 // The whole check for one verifying key.  gamma / delta: the precomputed line coefficients of the vk's G2 points (host::precompute_g2).
 inline Schedule build(const host::HFq12 &alpha_g1_beta_g2, const host::G2Precomp &gamma, const host::G2Precomp &delta) {
   Builder b; Tower T(b); const host::FrobeniusTables &ft = host::frobenius_tables();
   const HFq2 twist_b_v = HFq2{HFq::from_u64(3), HFq::zero()} * HFq2{HFq::from_u64(9), HFq::one()}.inv();
-  const int two_inv = b.constant(HFq::from_u64(2).inv()), three = b.constant(HFq::from_u64(3));
+  const int three = b.constant(HFq::from_u64(3));
   const F2 twist_b = T.k2(twist_b_v);
   const int ax = b.input(IN_AX), ay = b.input(IN_AY), cx = b.input(IN_CX), cy = b.input(IN_CY), nx = b.input(IN_NACCX), ny = b.input(IN_NACCY),
       nw = b.input(IN_NACCW);
@@ -316,8 +339,14 @@ inline Schedule build(const host::HFq12 &alpha_g1_beta_g2, const host::G2Precomp
   chk[1] = b.lin({{1, b.mul(cy, cy)}, {-1, b.mul(b.mul(cx, cx), cx)}, {-1, three}});
   { F2 r = T.sub(T.sub(T.sqr(by), T.mul(T.sqr(bx), bx)), twist_b); chk[2] = r.c0; chk[3] = r.c1; }
   // miller_loop :368-418 for e(A, B) with the running G2 point in homogeneous projective coordinates (:242-293), and the precomputed lines of gamma (at -acc)
-  // and delta (at -C)
-  F2 X = bx, Y = by, Z = T.one2(); F12 f = T.one12(); size_t idx = 0;
+  // and delta (at -C).
+  // The chain of the running point is the Miller loop's critical path (the accumulator f needs four levels a bit, f <- f^2 * L): it is written for DEPTH here.
+  // State (X, Y, Z, W) with W = 3 b' Z carried along (b' = the twist's coefficient): E = b' * 3 Z^2 of :247-249 is the product Z W — no constant product on the
+  // chain — and the halvings of :245,251 are dropped: the doubling leaves 4 (X3, Y3, Z3), a representative of the same projective point, and every line of a
+  // later step comes out times a power of 4, a factor in Fq that the final exponentiation kills.  A doubling is two product levels (the degree of its
+  // formulas, 4, allows no less), a mixed addition three (:270-293 in four: H = D F, then J, then X3 = D J — here X3 = F^2 + (D Z) G - 2 (D X) F etc., the same
+  // values from products of the previous level's products).
+  F2 X = bx, Y = by, Z = T.one2(), W = T.k2(twist_b_v + twist_b_v + twist_b_v); F12 f = T.one12(); size_t idx = 0;
   // mul_by_q, alt_bn128_g2.cpp:367-372
   const F2 q1x = T.mul(T.k2(ft.twist_mul_by_q_x), T.conj(bx)), q1y = T.mul(T.k2(ft.twist_mul_by_q_y), T.conj(by)), q2x = T.mul(T.k2(ft.twist_mul_by_q_x),
       T.conj(q1x)), q2y = T.neg(T.mul(T.k2(ft.twist_mul_by_q_y), T.conj(q1y)));
@@ -330,173 +359,201 @@ inline Schedule build(const host::HFq12 &alpha_g1_beta_g2, const host::G2Precomp
     const F12 lg = T.sparse(T.mul_fq(T.k2(g.ell_0), nw), T.mul_fq(T.k2(g.ell_VW), ny), T.mul_fq(T.k2(g.ell_VV), nx)), ld = T.sparse(T.k2(d.ell_0),
         T.mul_fq(T.k2(d.ell_VW), ncy), T.mul_fq(T.k2(d.ell_VV), cx));
     return T.mul(own, T.mul(lg, ld)); };
-  auto dbl_step = [&]() {   // doubling_step_for_flipped_miller_loop :242-268
-    F2 A = T.mul_fq(T.mul(X, Y), two_inv), B = T.sqr(Y), C = T.sqr(Z), D = T.scale(C, 3), E = T.mul(twist_b, D), F = T.scale(E, 3), G = T.mul_fq(T.add(B, F),
-        two_inv), H = T.scale(T.mul(Y, Z), 2) /* = (Y + Z)^2 - (B + C) */, I = T.sub(E, B), J = T.sqr(X), E2 = T.sqr(E);
-    X = T.mul(A, T.sub(B, F)); Y = T.sub(T.sqr(G), T.scale(E2, 3)); Z = T.mul(B, H);
-    return T.sparse(T.mul_xi(I), T.mul_fq(T.neg(H), ay), T.mul_fq(T.scale(J, 3), ax)); };
-  auto add_step = [&](const F2 &x2, const F2 &y2) {   // mixed_addition_step_for_flipped_miller_loop :270-293
-    F2 D = T.sub(X, T.mul(x2, Z)), E = T.sub(Y, T.mul(y2, Z)), F = T.sqr(D), G = T.sqr(E), H = T.mul(D, F), I = T.mul(X, F), J = T.sub(T.add(H, T.mul(Z, G)),
-        T.scale(I, 2)), Y1 = Y;
-    X = T.mul(D, J); Y = T.sub(T.mul(E, T.sub(I, J)), T.mul(H, Y1)); Z = T.mul(Z, H);
-    return T.sparse(T.mul_xi(T.sub(T.mul(E, x2), T.mul(D, y2))), T.mul_fq(D, ay), T.mul_fq(T.neg(E), ax)); };
+  auto dbl_step = [&]() {   // doubling_step_for_flipped_miller_loop :242-268, times 4 (see above)
+    const F2 XY = T.mul(X, Y), B = T.sqr(Y), ZW = T.mul(Z, W) /* E */, YZ = T.mul(Y, Z) /* H / 2 */, J = T.sqr(X), YW = T.mul(Y, W),
+        BmF = T.lin2({{1, B}, {-3, ZW}}), BpF = T.lin2({{1, B}, {3, ZW}}), I = T.sub(ZW, B);
+    const F12 line = T.sparse(T.mul_xi(I), T.mul_fq(T.scale(YZ, -2), ay), T.mul_fq(T.scale(J, 3), ax));
+    X = T.scale(T.mul(XY, BmF), 2); Y = T.lin2({{1, T.sqr(BpF)}, {-12, T.sqr(ZW)}}); Z = T.scale(T.mul(B, YZ), 8); W = T.scale(T.mul(B, YW), 8);
+    return line; };
+  auto add_step = [&](const F2 &x2, const F2 &y2) {   // mixed_addition_step_for_flipped_miller_loop :270-293, the same values in three product levels
+    const F2 D = T.sub(X, T.mul(x2, Z)), E = T.sub(Y, T.mul(y2, Z)), F = T.sqr(D), G = T.sqr(E), DX = T.mul(D, X), DZ = T.mul(D, Z), DW = T.mul(D, W),
+        EX = T.mul(E, X), ED = T.mul(E, D), DY = T.mul(D, Y), EZ = T.mul(E, Z), Wn = T.lin2({{3, EX}, {-1, ED}, {-1, DY}});
+    const F12 line = T.sparse(T.mul_xi(T.sub(T.mul(E, x2), T.mul(D, y2))), T.mul_fq(D, ay), T.mul_fq(T.neg(E), ax));
+    X = T.lin2({{1, T.sqr(F)}, {1, T.mul(DZ, G)}, {-2, T.mul(DX, F)}}); Y = T.sub(T.mul(F, Wn), T.mul(EZ, G)); Z = T.mul(DZ, F); W = T.mul(DW, F);
+    return line; };
   bool found = false;
   for (int i = 127; i >= 0; i--) { const bool bit = (ATE_LOOP[i / 64] >> (i % 64)) & 1; if (!found) { found |= bit; continue; }
     F12 L = lines(dbl_step()); if (bit) L = T.mul(L, lines(add_step(bx, by))); f = T.mul(T.mul(f, f), L); }
   { F12 L1 = lines(add_step(q1x, q1y)), L2 = lines(add_step(q2x, q2y)); f = T.mul(f, T.mul(L1, L2)); }
   if (idx != gamma.size() || idx != delta.size()) throw std::runtime_error("verify schedule: line count");
-  // final_exponentiation :110-238: first chunk f^((q^6 - 1)(q^2 + 1)), then the last chunk's chain with three exponentiations by -z. Squarings in the
-  // cyclotomic subgroup are plain squarings here: with all 144 coefficient products of a round in parallel the Granger-Scott form saves nothing.
-  // alt_bn128_pairing.cpp:84-96: conj(src^z), src in the cyclotomic subgroup. Width-3 NAF of z: 18 non-zero digits in {+-1, +-3}; a negative digit is a
-  // conjugation
+  // final_exponentiation :110-238 WITHOUT the inversion of its first chunk (:116-119, the one Fq inversion of the whole check: 254 dependent squarings with one
+  // lane busy, a fifth of the first generation's rounds).  f^-1 = P / n, n in Fq (Tower::pseudo_inverse); the chain is run on c0' = conj(f) P = f^(q^6-1) n instead
+  // of f^(q^6-1).  Every later operation — product, conjugation, Frobenius map — is multiplicative and fixes Fq, so the scalar rides along: the result is
+  // V' = V n^e with an exponent e that the chain itself determines (below), and V == alpha_beta  <=>  V' == alpha_beta n^e, provided n != 0 — which holds unless
+  // f = 0 (the norm of a field element) and is an output of its own: a proof whose Miller value is zero is rejected, as it was when 0^-1 came out 0.  The power
+  // n^e is an Fq chain of one lane per level beside the last chunk's Fq12 chain: off the critical path.
+  // Squarings in the cyclotomic subgroup are plain squarings here (with all coefficient products of a round in parallel the Granger-Scott form saves nothing, and
+  // c0' is not in the subgroup).
+  // alt_bn128_pairing.cpp:84-96: conj(src^z).  The critical path is the 62 squarings; the products with the powers src^(2^i) of the one bits are a second chain
+  // that keeps pace with the first (a product per squaring at most) and joins it after the last squaring: 63 levels of Fq12 products instead of 80 for the
+  // width-3 NAF chain of the first generation.  Plain bits (no negative digits): a conjugate would be the inverse for the subgroup part but not for the scalar.
   auto exp_neg_z = [&](const F12 &src) {
-    std::vector<int> dig;
-    for (uint64_t k = BN_Z; k;) {
-      int t = 0;
-      if (k & 1) {
-        t = (int)(k & 7);
-        if (t >= 4) t -= 8;
-        k -= (uint64_t)(int64_t)t;
-      }
-      dig.push_back(t);
-      k >>= 1;
+    F12 pw = src, acc{}; bool started = false;
+    for (int i = 0; i < 64; i++) {
+      if (!(BN_Z >> i)) break;
+      if (i) pw = T.mul(pw, pw);
+      if ((BN_Z >> i) & 1) { acc = started ? T.mul(acc, pw) : pw; started = true; }
     }
-    const F12 s3 = T.mul(T.mul(src, src), src), sc = T.conj(src), s3c = T.conj(s3); F12 r = T.one12(); bool started = false;
-    for (size_t i = dig.size(); i-- > 0;) {
-      const int d = dig[i];
-      if (started) r = T.mul(r, r);
-      if (!d) continue;
-      const F12 &m = d == 1 ? src : d == -1 ? sc : d == 3 ? s3 : s3c;
-      r = started ? T.mul(r, m) : m;
-      started = true;
-    }
-    return T.conj(r); };
-  F12 c0 = T.mul(T.conj(f), T.inv(f)), first = T.mul(T.frob(c0, 2), c0);
+    return T.conj(acc); };
+  int n = 0; const F12 P = T.pseudo_inverse(f, n);
+  F12 c0 = T.mul(T.conj(f), P), first = T.mul(T.frob(c0, 2), c0);
   F12 A = exp_neg_z(first), Bq = T.mul(A, A), Cq = T.mul(Bq, Bq), D = T.mul(Cq, Bq), E = exp_neg_z(D), Fq_ = T.mul(E, E), G = exp_neg_z(Fq_), H = T.conj(D),
       I = T.conj(G), J = T.mul(I, E), K = T.mul(J, H), L = T.mul(K, Bq), M = T.mul(K, E), N = T.mul(M, first),
-      O = T.frob(L, 1), P = T.mul(O, N), Q = T.frob(K, 2), R = T.mul(Q, P), S = T.conj(first), Tt = T.mul(S, L), U = T.frob(Tt, 3), V = T.mul(U, R);
-  // outputs in tower order (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 — each c0 then c1) MINUS vk.alpha_g1_beta_g2: sixteen values that must all be zero
+      O = T.frob(L, 1), Pp = T.mul(O, N), Q = T.frob(K, 2), R = T.mul(Q, Pp), S = T.conj(first), Tt = T.mul(S, L), U = T.frob(Tt, 3), V = T.mul(U, R);
+  // the scalar's exponent: first' = first n^2 (n^(q^2) = n); through the chain above — a power z per exp_neg_z, 1 per conjugation and Frobenius map —
+  // A: z, B: 2z, C: 4z, D: 6z, E: 6z^2, F: 12z^2, G: 12z^3, J: 12z^3 + 6z^2, K: J + 6z, L: K + 2z, M: K + 6z^2, N: M + 1, P: L + N, R: K + P, T: L + 1, V: T + R
+  // = 48 z^3 + 30 z^2 + 28 z + 2, times the 2 of n^2
+  const Big zb = Big::of(BN_Z), e_big = (Big::of(48) * zb * zb * zb + Big::of(30) * zb * zb + Big::of(28) * zb + Big::of(2)) * Big::of(2);
+  int s = -1;
+  { int pw = n; const int nb = e_big.bits();
+    for (int i = 0; i < nb; i++) { if (i) pw = b.mul(pw, pw); if (e_big.bit(i)) s = s < 0 ? pw : b.mul(s, pw); } }
+  // outputs in tower order (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 — each c0 then c1): V' MINUS vk.alpha_g1_beta_g2 * n^e — sixteen values that must all be
+  // zero, then n, which must not
   std::vector<int> outs;
   {
     for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) {
       const F2 &c = V[2 * j + i];
       const HFq2 *c2 = i == 0 ? &alpha_g1_beta_g2.c0.c0 + j : &alpha_g1_beta_g2.c1.c0 + j;
-      outs.push_back(b.lin({{1, c.c0}, {-1, b.constant(c2->c0)}})); outs.push_back(b.lin({{1, c.c1}, {-1, b.constant(c2->c1)}})); } }
+      outs.push_back(b.lin({{1, c.c0}, {-1, b.mul(s, b.constant(c2->c0))}})); outs.push_back(b.lin({{1, c.c1}, {-1, b.mul(s, b.constant(c2->c1))}})); } }
   for (int k = 0; k < N_CHECK; k++) outs.push_back(chk[k]);
+  outs.push_back(n);
 
-  // ---- liveness, rounds, slots
+  // ---- liveness, levels, rounds, slots
   // -----------------------------------------------------------------------------------------------------------------------------------
   const size_t nn = b.nodes.size(); std::vector<char> live(nn, 0); for (int o : outs) live[o] = 1;
-  for (size_t n = nn; n-- > 0;) {
-    if (!live[n]) continue;
-    const Builder::Node &nd = b.nodes[n];
+  for (size_t k = nn; k-- > 0;) {
+    if (!live[k]) continue;
+    const Builder::Node &nd = b.nodes[k];
     if (nd.kind == K_MUL) {
       live[nd.a] = live[nd.b] = 1;
     } else if (nd.kind == K_LIN8) for (auto &t : nd.terms) live[t.second] = 1;
   }
-  for (int o : outs) if (b.nodes[o].kind != K_LIN8) throw std::runtime_error("verify schedule: output is not a computed difference");
+  for (int o : outs) if (b.nodes[o].kind != K_LIN8) throw std::runtime_error("verify schedule: output is not a computed sum");
   {
     std::vector<int> seen(outs);
     std::sort(seen.begin(), seen.end());
     if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) throw std::runtime_error("verify schedule: two outputs share a value");
   }
-  int max_level = 0; for (size_t n = 0; n < nn; n++) if (live[n]) max_level = std::max(max_level, b.nodes[n].level);
-  // as LATE as possible: a value is placed one level before its first reader (outputs at the last level). Scheduled as early as possible, everything off the
-  // critical chain — the G2 point's chain, the products of the line values — ran hundreds of levels ahead of its readers and the live values did not fit the
-  // LDS (3,769 slots).
+  int max_level = 0; for (size_t k = 0; k < nn; k++) if (live[k]) max_level = std::max(max_level, b.nodes[k].level);
+  // Levels.  A value may sit anywhere between its earliest level (its operands' depth) and one level before its first reader.  As EARLY as possible, everything
+  // off the critical chain — the products of the line values, the powers of n — runs hundreds of levels ahead of its readers and the live values do not fit the
+  // LDS; as LATE as possible (the first generation), the accumulator's chain f <- f^2 L, which only needs four levels a bit, is compressed into the last 256
+  // levels of the running point's 480 and every one of those levels then needs two rounds.  So: late, but only while the level still has room in its ONE round
+  // (four waves) — the values on the critical path first (they have no choice), then the others from the outputs backwards, each at the latest level below its
+  // readers that has a free lane for it, falling back towards its earliest level; if none has room, at the latest (that level then takes a second round).
   { std::vector<int> alap(nn, max_level + 1); for (int o : outs) alap[o] = max_level;
-    for (size_t n = nn; n-- > 0;) {
-      if (!live[n]) continue;
-      Builder::Node &nd = b.nodes[n];
-      if (alap[n] > max_level) alap[n] = max_level;
-      const int lv = alap[n];
+    for (size_t k = nn; k-- > 0;) {
+      if (!live[k]) continue;
+      const Builder::Node &nd = b.nodes[k];
+      if (alap[k] > max_level) alap[k] = max_level;
+      const int lv = alap[k];
       if (nd.kind == K_MUL) {
         alap[nd.a] = std::min(alap[nd.a], lv - 1);
         alap[nd.b] = std::min(alap[nd.b], lv - 1);
       } else if (nd.kind == K_LIN8) for (auto &t : nd.terms) alap[t.second] = std::min(alap[t.second], lv - 1);
     }
-    for (size_t n = 0; n < nn; n++) if (live[n] && (b.nodes[n].kind == K_MUL || b.nodes[n].kind == K_LIN8)) {
-      if (alap[n] < b.nodes[n].level) throw std::runtime_error("verify schedule: level");
-      b.nodes[n].level = alap[n];
+    struct Load { uint32_t mul = 0, wide = 0, narrow = 0; };
+    std::vector<Load> load(max_level + 2);
+    auto waves_of = [](const Load &l) { const uint32_t per8 = WAVE / LIN_GROUP, w8 = (l.wide + per8 - 1) / per8, spare = w8 * per8 - l.wide;
+      return (l.mul + WAVE - 1) / WAVE + w8 + (l.narrow <= spare ? 0u : (l.narrow + WAVE - 1) / WAVE); };
+    auto with = [&](Load l, const Builder::Node &nd) { if (nd.kind == K_MUL) l.mul++; else if (nd.terms.size() > TERMS_PER_LANE) l.wide++; else l.narrow++; return l; };
+    auto is_op = [&](size_t k) { return live[k] && (b.nodes[k].kind == K_MUL || b.nodes[k].kind == K_LIN8); };
+    std::vector<int> place(nn, -1), ub(nn, max_level + 1);
+    auto put = [&](size_t k, int lv) { place[k] = lv; load[lv] = with(load[lv], b.nodes[k]); const Builder::Node &nd = b.nodes[k];
+      if (nd.kind == K_MUL) { ub[nd.a] = std::min(ub[nd.a], lv - 1); ub[nd.b] = std::min(ub[nd.b], lv - 1); } else for (auto &t : nd.terms) ub[t.second] = std::min(ub[t.second], lv - 1); };
+    for (size_t k = 0; k < nn; k++) if (is_op(k)) { if (alap[k] < b.nodes[k].level) throw std::runtime_error("verify schedule: level"); if (alap[k] == b.nodes[k].level) put(k, alap[k]); }
+    for (int o : outs) ub[o] = std::min(ub[o], max_level);
+    for (size_t k = nn; k-- > 0;) { if (!is_op(k) || place[k] >= 0) continue;
+      const int hi = std::min(ub[k], max_level), lo = b.nodes[k].level; if (hi < lo) throw std::runtime_error("verify schedule: no level for a value");
+      int lv = hi; for (int c = hi; c >= lo; c--) if (waves_of(with(load[c], b.nodes[k])) <= WAVES) { lv = c; break; }
+      put(k, lv); }
+    for (size_t k = 0; k < nn; k++) if (is_op(k)) {
+      const Builder::Node &nd = b.nodes[k]; const int lv = place[k];
+      auto before = [&](int o) { const uint8_t kd = b.nodes[o].kind; if ((kd == K_MUL || kd == K_LIN8) && place[o] >= lv) throw std::runtime_error("verify schedule: order of levels"); };
+      if (nd.kind == K_MUL) { before(nd.a); before(nd.b); } else for (auto &t : nd.terms) before(t.second);
     }
+    for (size_t k = 0; k < nn; k++) if (is_op(k)) b.nodes[k].level = place[k];
   }
   std::vector<std::vector<int>> mul_at(max_level + 1), lin_at(max_level + 1);
-  for (size_t n = 0; n < nn; n++) if (live[n]) {
-    if (b.nodes[n].kind == K_MUL) mul_at[b.nodes[n].level].push_back((int)n);
-    else if (b.nodes[n].kind == K_LIN8) lin_at[b.nodes[n].level].push_back((int)n);
+  for (size_t k = 0; k < nn; k++) if (live[k]) {
+    if (b.nodes[k].kind == K_MUL) mul_at[b.nodes[k].level].push_back((int)k);
+    else if (b.nodes[k].kind == K_LIN8) lin_at[b.nodes[k].level].push_back((int)k);
   }
-  // rounds of a level: products, 256 a round; then the sums. A sum of up to three terms needs one lane (LIN1, 256 a round), a longer one eight (LIN8, 32 a
-  // round); short sums ride in the spare groups of the level's LIN8 rounds when they all fit there (a round costs more than the lanes it leaves idle)
-  struct Round { uint32_t kind; std::vector<int> ns; }; std::vector<Round> rounds;
+  // A level's operations are cut into WAVES — 64 products, or 8 eight-lane sums, or 64 one-lane sums (up to three terms; they ride in the spare groups of the
+  // level's eight-lane waves when they all fit there) — and four waves make a round, whatever their kinds.
+  struct WaveOp { uint32_t kind; std::vector<int> ns; }; struct Round { std::vector<WaveOp> waves; }; std::vector<Round> rounds; std::vector<uint32_t> round_level;
   for (int lv = 1; lv <= max_level; lv++) {
-    for (size_t i = 0; i < mul_at[lv].size(); i += LANES) rounds.push_back(Round{K_MUL, std::vector<int>(mul_at[lv].begin() + i,
-        mul_at[lv].begin() + std::min(mul_at[lv].size(), i + LANES))});
-    std::vector<int> wide, narrow; for (int n : lin_at[lv]) (b.nodes[n].terms.size() > TERMS_PER_LANE ? wide : narrow).push_back(n);
-    const size_t per8 = LANES / LIN_GROUP, spare = wide.empty() ? 0 : (per8 - wide.size() % per8) % per8;
+    std::vector<WaveOp> ws;
+    for (size_t i = 0; i < mul_at[lv].size(); i += WAVE) ws.push_back(WaveOp{K_MUL, std::vector<int>(mul_at[lv].begin() + i,
+        mul_at[lv].begin() + std::min(mul_at[lv].size(), i + WAVE))});
+    std::vector<int> wide, narrow; for (int k : lin_at[lv]) (b.nodes[k].terms.size() > TERMS_PER_LANE ? wide : narrow).push_back(k);
+    const size_t per8 = WAVE / LIN_GROUP, spare = wide.empty() ? 0 : (per8 - wide.size() % per8) % per8;
     if (!wide.empty() && narrow.size() <= spare) { wide.insert(wide.end(), narrow.begin(), narrow.end()); narrow.clear(); }
-    for (size_t i = 0; i < wide.size(); i += per8) rounds.push_back(Round{K_LIN8, std::vector<int>(wide.begin() + i, wide.begin() + std::min(wide.size(),
+    for (size_t i = 0; i < wide.size(); i += per8) ws.push_back(WaveOp{K_LIN8, std::vector<int>(wide.begin() + i, wide.begin() + std::min(wide.size(),
         i + per8))});
-    for (size_t i = 0; i < narrow.size(); i += LANES) rounds.push_back(Round{K_LIN1, std::vector<int>(narrow.begin() + i,
-        narrow.begin() + std::min(narrow.size(), i + LANES))});
+    for (size_t i = 0; i < narrow.size(); i += WAVE) ws.push_back(WaveOp{K_LIN1, std::vector<int>(narrow.begin() + i,
+        narrow.begin() + std::min(narrow.size(), i + WAVE))});
+    for (size_t i = 0; i < ws.size(); i += WAVES) { Round rd; rd.waves.assign(ws.begin() + i, ws.begin() + std::min(ws.size(), i + WAVES)); rounds.push_back(rd);
+      round_level.push_back((uint32_t)lv); }
   }
   std::vector<int> last_use(nn, -1); std::vector<char> is_out(nn, 0); for (int o : outs) is_out[o] = 1;
-  for (size_t r = 0; r < rounds.size(); r++) for (int n : rounds[r].ns) {
-    const Builder::Node &nd = b.nodes[n];
+  for (size_t r = 0; r < rounds.size(); r++) for (const WaveOp &wv : rounds[r].waves) for (int k : wv.ns) {
+    const Builder::Node &nd = b.nodes[k];
     if (nd.kind == K_MUL) {
       last_use[nd.a] = last_use[nd.b] = (int)r;
     } else for (auto &t : nd.terms) last_use[t.second] = (int)r;
   }
-  Schedule sc;
+  Schedule sc; sc.round_level = round_level; sc.n_levels = (uint32_t)max_level;
   sc.consts = b.consts;
   std::vector<int> slot(nn, -1);
   for (int i = 0; i < N_INPUTS; i++) slot[i] = i;
   std::vector<int> free_slots;
   uint32_t next_slot = N_INPUTS;
   if (sc.consts.size() >= CONST_FLAG) throw std::runtime_error("verify schedule: too many constants");
-  auto ref = [&](int n) -> uint32_t { const Builder::Node &nd = b.nodes[n]; if (nd.kind == 3) return CONST_FLAG | nd.cidx;
-      if (slot[n] < 0) throw std::runtime_error("verify schedule: value read before it was written"); return (uint32_t)slot[n]; };
+  auto ref = [&](int k) -> uint32_t { const Builder::Node &nd = b.nodes[k]; if (nd.kind == 3) return CONST_FLAG | nd.cidx;
+      if (slot[k] < 0) throw std::runtime_error("verify schedule: value read before it was written"); return (uint32_t)slot[k]; };
   const uint32_t no_term = CONST_FLAG | b.nodes[b.zero_node].cidx;   // coefficient 0 on the constant zero
   auto term_word = [&](const std::pair<int, int> &t) -> uint32_t { const uint32_t c = (uint32_t)(t.first < 0 ? -t.first : t.first);
       if (!c || c > MAX_COEF) throw std::runtime_error("verify schedule: coefficient"); return ref(t.second) | (t.first < 0 ? 1u << 16 : 0u) | c << 17; };
-  std::vector<size_t> hdr_pos;
+  const size_t padded = (rounds.size() + PREFETCH_ROUNDS - 1) / PREFETCH_ROUNDS * PREFETCH_ROUNDS + PREFETCH_ROUNDS;
+  sc.prog.assign(padded * LANES * WPL, 0u);
   for (size_t r = 0; r < rounds.size(); r++) {
-    const Round &rd = rounds[r];
-    const uint32_t lanes_per = rd.kind == K_LIN8 ? LIN_GROUP : 1, lanes = (uint32_t)rd.ns.size() * lanes_per;
-    // (four header words: every lane's words stay 16-byte aligned; word 1 = the NEXT round's header, filled in below)
-    hdr_pos.push_back(sc.prog.size());
-    sc.prog.push_back(hdr(rd.kind, lanes));
-    sc.rounds_of_kind[rd.kind]++;
-    sc.prog.insert(sc.prog.end(), 3, 0u);
-    std::vector<uint32_t> words((size_t)lanes * WPL, 0u);   // (operands are resolved BEFORE this round's destinations are assigned)
-    for (size_t k = 0; k < rd.ns.size(); k++) { const Builder::Node &nd = b.nodes[rd.ns[k]];
-      if (rd.kind == K_MUL) { words[k * WPL + 1] = ref(nd.a); words[k * WPL + 2] = ref(nd.b); sc.n_mul++; }
-      else {
-        for (uint32_t l = 0; l < lanes_per; l++) for (uint32_t t = 0; t < TERMS_PER_LANE; t++) {
-          const size_t idx = (size_t)t * lanes_per + l;
-          words[(k * lanes_per + l) * WPL + 1 + t] = idx < nd.terms.size() ? term_word(nd.terms[idx]) : no_term;
+    const Round &rd = rounds[r]; uint32_t *words = &sc.prog[r * LANES * WPL];
+    // (operands are resolved BEFORE this round's destinations are assigned)
+    for (size_t wv = 0; wv < rd.waves.size(); wv++) { const WaveOp &op = rd.waves[wv]; const uint32_t lanes_per = op.kind == K_LIN8 ? LIN_GROUP : 1;
+      sc.waves_of_kind[op.kind]++;
+      for (uint32_t l = 0; l < WAVE; l++) { uint32_t *w = words + (wv * WAVE + l) * WPL; w[0] = op.kind << KIND_SHIFT; w[1] = w[2] = w[3] = op.kind == K_MUL ? 0u : no_term; }
+      for (size_t k = 0; k < op.ns.size(); k++) { const Builder::Node &nd = b.nodes[op.ns[k]];
+        if (op.kind == K_MUL) { uint32_t *w = words + (wv * WAVE + k) * WPL; w[0] |= LIVE_BIT | STORE_BIT; w[1] = ref(nd.a); w[2] = ref(nd.b); w[3] = 0; sc.n_mul++; }
+        else {
+          for (uint32_t l = 0; l < lanes_per; l++) { uint32_t *w = words + (wv * WAVE + k * lanes_per + l) * WPL; w[0] |= LIVE_BIT | (l == lanes_per - 1 ? STORE_BIT : 0u);
+            for (uint32_t t = 0; t < TERMS_PER_LANE; t++) { const size_t ti = (size_t)t * lanes_per + l; w[1 + t] = ti < nd.terms.size() ? term_word(nd.terms[ti]) : no_term; } }
+          sc.n_lin++;
         }
-        sc.n_lin++;
       }
     }
     // destinations come from the slots freed in EARLIER rounds only (this round's operands are released below, after the assignment): no lane writes a slot
     // that another lane of the same round still reads, so the kernel needs one barrier per round, not two
-    for (size_t k = 0; k < rd.ns.size(); k++) {
-      int s;
-      if (!free_slots.empty()) {
-        s = free_slots.back();
-        free_slots.pop_back();
-      } else s = (int)next_slot++;
-      slot[rd.ns[k]] = s;
-      for (uint32_t l = 0; l < lanes_per; l++) words[(k * lanes_per + l) * WPL] = (uint32_t)s;
+    std::vector<int> dsts;
+    for (size_t wv = 0; wv < rd.waves.size(); wv++) { const WaveOp &op = rd.waves[wv]; const uint32_t lanes_per = op.kind == K_LIN8 ? LIN_GROUP : 1;
+      for (size_t k = 0; k < op.ns.size(); k++) {
+        int s2;
+        if (!free_slots.empty()) {
+          s2 = free_slots.back();
+          free_slots.pop_back();
+        } else s2 = (int)next_slot++;
+        if (s2 >= (int)CONST_FLAG) throw std::runtime_error("verify schedule: too many live values");
+        slot[op.ns[k]] = s2; dsts.push_back(s2);
+        for (uint32_t l = 0; l < lanes_per; l++) words[(wv * WAVE + k * lanes_per + l) * WPL] |= (uint32_t)s2;
+      }
     }
-    { std::vector<char> is_dst(next_slot, 0); for (int n : rd.ns) is_dst[slot[n]] = 1;
-      for (size_t q = 0; q < words.size(); q++) {
-        const uint32_t pos = (uint32_t)(q % WPL), wv = words[q];
-        const bool operand = pos && (rd.kind == K_MUL ? pos < 3 : (wv >> 17) != 0);
+    { std::vector<char> is_dst(next_slot, 0); for (int s2 : dsts) is_dst[s2] = 1;
+      for (size_t q = 0; q < (size_t)LANES * WPL; q++) {
+        const uint32_t pos = (uint32_t)(q % WPL), wv = words[q], kind = words[q - pos] >> KIND_SHIFT; if (!pos || !(words[q - pos] & LIVE_BIT)) continue;
+        const bool operand = kind == K_MUL ? pos < 3 : (wv >> 17) != 0;
         if (operand && !(wv & CONST_FLAG) && is_dst[wv & 0x7fffu]) throw std::runtime_error("verify schedule: a round writes a slot it reads"); } }
-    sc.prog.insert(sc.prog.end(), words.begin(), words.end());
-    for (int n : rd.ns) {
-      const Builder::Node &nd = b.nodes[n];
+    for (const WaveOp &op : rd.waves) for (int k : op.ns) {
+      const Builder::Node &nd = b.nodes[k];
       auto release = [&](int o) {
         if (b.nodes[o].kind != 3 && o >= N_INPUTS && last_use[o] == (int)r && !is_out[o] && slot[o] >= 0) {
           free_slots.push_back(slot[o]);
@@ -505,36 +562,40 @@ inline Schedule build(const host::HFq12 &alpha_g1_beta_g2, const host::G2Precomp
       };
       if (nd.kind == K_MUL) { release(nd.a); release(nd.b); } else for (auto &t : nd.terms) release(t.second); }
   }
-  // look-ahead: a round's header also carries the next one's, so the kernel can fetch the next round's words without waiting for a header load
-  for (size_t r = 0; r + 1 < hdr_pos.size(); r++) sc.prog[hdr_pos[r] + 1] = sc.prog[hdr_pos[r + 1]];
-  sc.n_rounds = (uint32_t)rounds.size(); sc.n_slots = next_slot; for (size_t k = 0; k < outs.size(); k++) sc.out_slot[k] = (uint32_t)slot[outs[k]];
+  sc.n_rounds = (uint32_t)rounds.size(); sc.n_rounds_padded = (uint32_t)padded; sc.n_slots = next_slot;
+  for (size_t k = 0; k < outs.size(); k++) sc.out_slot[k] = (uint32_t)slot[outs[k]];
   return sc;
 }
 
-// Host interpreter of a schedule on the host field type: what the program means. in: the N_INPUTS values of one proof. Returns the output values (N_RESULT +
-// N_CHECK), all zero for a valid proof.
+// the operations of a round in program order: fn(kind, w) for every live MUL lane / LIN group (w: the group's first lane's words; per: lanes of the group)
+template <class Fn> inline void for_each_op(const Schedule &S, uint32_t r, Fn fn) {
+  for (uint32_t wv = 0; wv < WAVES; wv++) { const uint32_t *base = &S.prog[((size_t)r * LANES + wv * WAVE) * WPL]; const uint32_t kind = base[0] >> KIND_SHIFT;
+    if (kind == K_IDLE) continue; const uint32_t per = kind == K_LIN8 ? LIN_GROUP : 1;
+    for (uint32_t g = 0; g < WAVE / per; g++) { const uint32_t *w = base + (size_t)g * per * WPL; if (!(w[0] & LIVE_BIT)) continue;
+      if ((w[0] >> KIND_SHIFT) != kind) throw std::runtime_error("verify schedule: a wave of two kinds");
+      fn(kind, per, w); } }
+}
+
+// Host interpreter of a schedule on the host field type: what the program means. in: the N_INPUTS values of one proof. Returns the output values (N_OUT): the
+// first N_ZERO all zero and the last one not, for a valid proof.
 inline std::vector<HFq> simulate(const Schedule &S, const HFq *in) {
   std::vector<HFq> slots(S.n_slots, HFq::zero()); for (int i = 0; i < N_INPUTS; i++) slots[i] = in[i];
-  auto val = [&](uint32_t r) { return (r & CONST_FLAG) ? S.consts[r & (CONST_FLAG - 1)] : slots[r & 0xffff]; };
+  auto val = [&](uint32_t r) { return (r & CONST_FLAG) ? S.consts[r & (CONST_FLAG - 1)] : slots[r & 0x7fff]; };
   auto times = [](HFq x, uint32_t c) { HFq r = HFq::zero(); for (; c; c >>= 1) { if (c & 1) r = r + x; x = x + x; } return r; };
-  size_t pc = 0; std::vector<std::pair<uint32_t, HFq>> writes;
-  for (uint32_t r = 0; r < S.n_rounds; r++) {
-    uint32_t kind, count;
-    unhdr(S.prog[pc], kind, count);
-    pc += 4;
+  std::vector<std::pair<uint32_t, HFq>> writes;
+  for (uint32_t r = 0; r < S.n_rounds_padded; r++) {
     writes.clear();
-    const uint32_t per = kind == K_LIN8 ? LIN_GROUP : 1;
-    for (uint32_t g = 0; g < count / per; g++) { const uint32_t *w = &S.prog[pc + (size_t)g * per * WPL]; HFq v = HFq::zero();
+    for_each_op(S, r, [&](uint32_t kind, uint32_t per, const uint32_t *w) { HFq v = HFq::zero();
       if (kind == K_MUL) v = val(w[1]) * val(w[2]);
       else for (uint32_t l = 0; l < per; l++) for (uint32_t t = 0; t < TERMS_PER_LANE; t++) {
         const uint32_t e = w[l * WPL + 1 + t];
         const HFq x = times(val(e & 0xffff), e >> 17);
         v = ((e >> 16) & 1) ? v - x : v + x;
       }
-      writes.push_back({w[0], v}); }
+      writes.push_back({w[0] & 0x7fffu, v}); });
     for (auto &wv : writes) slots[wv.first] = wv.second;   // (all reads of a round happen before its writes, as in the lock-step workgroup)
-    pc += (size_t)count * WPL; }
-  std::vector<HFq> out; for (int k = 0; k < N_RESULT + N_CHECK; k++) out.push_back(slots[S.out_slot[k]]); return out;
+  }
+  std::vector<HFq> out; for (int k = 0; k < N_OUT; k++) out.push_back(slots[S.out_slot[k]]); return out;
 }
 
 // The constants as the kernel wants them: c 2^261 mod p (the host type holds c 2^256: five doublings), canonical, nine limbs in a 12-word record
@@ -551,7 +612,9 @@ inline std::vector<uint32_t> consts29(const Schedule &S) { std::vector<uint32_t>
 // Host interpreter on the DEVICE's arithmetic: the kernel's operations limb by limb (l29::term / norm64 / the lane tree / barrett, and the model of the 29-bit
 // product), every intermediate bound asserted. in_words: the N_INPUTS values as eight 32-bit words each (Montgomery 2^256, canonical — what the kernel is
 // handed). Returns for each output whether it is a multiple of p (what the kernel tests).
-inline std::vector<bool> simulate29(const Schedule &S, const uint32_t (*in_words)[8]) {
+// after_round (optional): called with the round's number and all values once its writes are done
+inline std::vector<bool> simulate29(const Schedule &S, const uint32_t (*in_words)[8],
+    const std::function<void(uint32_t, const std::vector<std::array<uint32_t, 9>> &)> &after_round = nullptr) {
   typedef std::array<uint32_t, 9> V; const std::vector<uint32_t> c29 = consts29(S); std::vector<V> slots(S.n_slots, V{});
   auto bad = [](const char *what) { throw std::runtime_error(std::string("verify schedule (29-bit model): ") + what); };
   // (p >> 232 is just above 3 * 2^20: 5 * 2^22 bounds 6.6 p)
@@ -562,16 +625,12 @@ inline std::vector<bool> simulate29(const Schedule &S, const uint32_t (*in_words
   for (int i = 0; i < N_INPUTS; i++) { uint32_t l[9]; l29::lift(in_words[i], l); check_stored(l); memcpy(slots[i].data(), l, 36); }
   auto load = [&](uint32_t r, uint32_t (&x)[9]) {
     if (r & CONST_FLAG) memcpy(x, &c29[(size_t)(r & (CONST_FLAG - 1)) * l29::STRIDE], 36);
-    else memcpy(x, slots[r & 0xffff].data(), 36);
+    else memcpy(x, slots[r & 0x7fff].data(), 36);
   };
-  size_t pc = 0; std::vector<std::pair<uint32_t, V>> writes;
-  for (uint32_t r = 0; r < S.n_rounds; r++) {
-    uint32_t kind, count;
-    unhdr(S.prog[pc], kind, count);
-    pc += 4;
+  std::vector<std::pair<uint32_t, V>> writes;
+  for (uint32_t r = 0; r < S.n_rounds_padded; r++) {
     writes.clear();
-    const uint32_t per = kind == K_LIN8 ? LIN_GROUP : 1;
-    for (uint32_t g = 0; g < count / per; g++) { const uint32_t *w = &S.prog[pc + (size_t)g * per * WPL]; uint32_t res[9];
+    for_each_op(S, r, [&](uint32_t kind, uint32_t per, const uint32_t *w) { uint32_t res[9];
       if (kind == K_MUL) { uint32_t a[9], bb[9]; load(w[1], a); load(w[2], bb); l29::mul_model(a, bb, res); }
       else { uint32_t part[LIN_GROUP][9];
         for (uint32_t l = 0; l < per; l++) { uint64_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -608,11 +667,12 @@ inline std::vector<bool> simulate29(const Schedule &S, const uint32_t (*in_words
         else memcpy(res, part[0], 36);
         for (int i = 0; i < 8; i++) if (res[i] >> 31) bad("a limb entering the reduction step is above 2^31");
         l29::barrett(res); }
-      check_stored(res); V v; memcpy(v.data(), res, 36); writes.push_back({w[0], v}); }
+      check_stored(res); V v; memcpy(v.data(), res, 36); writes.push_back({w[0] & 0x7fffu, v}); });
     for (auto &wv : writes) slots[wv.first] = wv.second;
-    pc += (size_t)count * WPL; }
+    if (after_round) after_round(r, slots);
+  }
   std::vector<bool> out;
-  for (int k = 0; k < N_RESULT + N_CHECK; k++) {
+  for (int k = 0; k < N_OUT; k++) {
     uint32_t l[9];
     memcpy(l, slots[S.out_slot[k]].data(), 36);
     out.push_back(l29::multiple_of_p(l));

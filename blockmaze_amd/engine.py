@@ -191,11 +191,19 @@ def verify_batch(vk_path, proofs_hex, inputs):
     ok = (ctypes.c_uint8 * max(1, n))(); _check(lib().zkgpu_verify_batch(vk_path.encode(), blob, buf, ctypes.c_size_t(ni), ctypes.c_size_t(n), ok)); return [bool(ok[i]) for i in range(n)]
 
 def verify_schedule_on_host(vk_path, proof_hex, inputs):
-    """the GPU verifier's operation schedule (csrc/verify_sched.hpp) interpreted on the host: (accept, {rounds, slots, products, linear_ops, constants, mul_rounds, lin8_rounds, lin1_rounds}); needs no device"""
+    """the GPU verifier's operation schedule (csrc/verify_sched.hpp) interpreted on the host: (accept, {rounds, slots, products, linear_ops, constants, mul_waves, lin8_waves, lin1_waves}); needs no device"""
     buf = b"".join(int(x).to_bytes(32, "little") for x in inputs); st = (ctypes.c_uint32 * 8)()
     rc = lib().zkgpu_test_verify_schedule(vk_path.encode(), proof_hex.encode(), buf, ctypes.c_size_t(len(inputs)), st)
     if rc < 0: _check(rc)
-    return rc == 1, dict(zip(("rounds", "slots", "products", "linear_ops", "constants", "mul_rounds", "lin8_rounds", "lin1_rounds"), (int(x) for x in st)))
+    return rc == 1, dict(zip(("rounds", "slots", "products", "linear_ops", "constants", "mul_waves", "lin8_waves", "lin1_waves"), (int(x) for x in st)))
+def verify_counters(vk_path):
+    """(small verification calls taken by the key's GPU verifier, launches made for them)"""
+    out = (ctypes.c_uint64 * 2)(); _check(lib().zkgpu_verify_counters(vk_path.encode(), out)); return int(out[0]), int(out[1])
+def verify_trace(vk_path, proof_hex, inputs, every=1):
+    """kernel K9 on one proof with its values written out after every `every`-th round, compared with the host model of the same arithmetic:
+    (first differing round or -1, slot, the kernel's verdict)"""
+    buf = b"".join(int(x).to_bytes(32, "little") for x in inputs); out = (ctypes.c_long * 3)()
+    _check(lib().zkgpu_test_verify_trace(vk_path.encode(), proof_hex.encode(), buf, ctypes.c_size_t(len(inputs)), ctypes.c_uint32(every), out)); return int(out[0]), int(out[1]), int(out[2])
 def verify(vk_path, proof_hex, inputs):
     """inputs: list of ints (packed public input).  True / False."""
     buf = b"".join(int(x).to_bytes(32, "little") for x in inputs)

@@ -145,6 +145,12 @@ int zkgpu_verify(const char *vk_path, const char *proof_hex, const uint8_t *inpu
    proofs_hex: n * 512 characters (no separators); inputs: n * n_inputs canonical field elements of 32 bytes; ok[i] = 1 accept / 0 reject.  Returns ZKGPU_OK or an error */
 /* test entry: the GPU verifier's operation schedule interpreted on the host (no device needed); returns 1 accept / 0 reject; stats[8] (optional): rounds, slots, products, linear operations, constants, rounds of products / eight-lane sums / one-lane sums */
 int zkgpu_test_verify_schedule(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs, uint32_t *stats);
+/* out[0] = small verification calls (up to 64 proofs) taken by this key's GPU verifier, out[1] = kernel launches made for them: calls that meet — go-ethereum verifies
+ * from many goroutines, one proof a call — share a launch */
+int zkgpu_verify_counters(const char *vk_path, uint64_t out[2]);
+/* test entry (needs a GPU): kernel K9's LDS values after every `every`-th round of its schedule against the host model of the same 29-bit limb arithmetic, on one proof.
+ * out[0] = the first round whose values differ or -1, out[1] = the slot, out[2] = the kernel's verdict (1 accept, 0 reject, 2 handed back to the host verifier) */
+int zkgpu_test_verify_trace(const char *vk_path, const char *proof_hex, const uint8_t *inputs, size_t n_inputs, uint32_t every, long out[3]);
 int zkgpu_verify_batch(const char *vk_path, const char *proofs_hex, const uint8_t *inputs, size_t n_inputs, size_t n, uint8_t *ok);
 
 #ifdef __cplusplus

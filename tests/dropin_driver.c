@@ -5,12 +5,14 @@
  *   dropin_driver send              -> genSendproof + verifySendproof on the reference's send fixture (needs keys in $ZK_PRFKEY_DIR and a GPU)
  *   dropin_driver mint|redeem|deposit -> the same for the fixtures of mint/main.cpp:121-129, redeem/main.cpp:121-129, deposit/main.cpp:131-167 (genRoot with n = 16 on the way)
  *   dropin_driver roots             -> genRoot with n = 0, 1 and 16 (SURVEY.md §8c golden values)
+ *   dropin_driver verifybench T N   -> one send proof, then T pthreads calling verifySendproof N times each (geth's goroutines: one proof a call); calls/s on stderr
  *   dropin_driver threads           -> 8 pthreads, each proving and verifying all four circuits twice through the thin libraries: cgo calls arrive on arbitrary OS threads (zktx.go:406-430)
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
+#include <time.h>
 #include "../include/zk_mint.h"
 #include "../include/zk_send.h"
 #include "../include/zk_deposit.h"
@@ -45,8 +47,25 @@ static int run_send(void) {   /* libsnark-vnt/src/send/main.cpp:123-142: value_o
   printf("proof_len %zu head %.10s\nverify %d\nverify_wrong %d\n", strlen(proof), proof, ok, bad); return strlen(proof) == 512 && ok && !bad; }
 static void *thread_main(void *arg) { long good = 0; for (int rep = 0; rep < 2; rep++) good += run_mint(0) + run_send() + run_deposit() + run_mint(1); *(long *)arg = good; return 0; }
 
+struct vb { char *proof, *a, *b, *c, *d; int n; long good; };
+static void *vb_main(void *arg) { struct vb *v = arg; for (int i = 0; i < v->n; i++) v->good += verifySendproof(v->proof, v->a, v->b, v->c, v->d) ? 1 : 0; return 0; }
+static int verify_bench(int T, int N) {
+  char *skh = "0x1", *r_old = "0x123456", *rr = "0x12", *pks = "0x456", *pkr = "0x123";
+  char *sn_old = with0x(computePRF(skh, r_old)), *cmtA_old = with0x(genCMT(22, sn_old, r_old)), *r_s = with0x(computeCRH(pks, rr)), *sn = with0x(computePRF(skh, rr));
+  char *cmtS = with0x(genCMTS(8, pkr, r_s, sn_old)), *cmtA = with0x(genCMT(14, sn, rr));
+  char *proof = genSendproof(22, r_s, sn_old, r_old, cmtS, cmtA_old, 8, pkr, 14, sn, rr, cmtA, skh, pks);
+  for (int i = 0; i < 20; i++) if (!verifySendproof(proof, cmtA_old, sn_old, cmtS, cmtA)) return 0;
+  if (verifySendproof(proof, cmtA, sn_old, cmtS, cmtA_old)) return 0;
+  pthread_t th[64]; struct vb v[64]; if (T > 64) T = 64; struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int i = 0; i < T; i++) { v[i] = (struct vb){proof, cmtA_old, sn_old, cmtS, cmtA, N, 0}; pthread_create(&th[i], 0, vb_main, &v[i]); }
+  long good = 0; for (int i = 0; i < T; i++) { pthread_join(th[i], 0); good += v[i].good; }
+  clock_gettime(CLOCK_MONOTONIC, &t1); double dt = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+  fprintf(stderr, "verifySendproof from %d thread(s), %d calls each: %.3f ms per call, %.0f verifications/s, %ld of %ld accepted\n", T, N, 1e3 * dt / N, T * (double)N / dt, good, (long)T * N);
+  return good == (long)T * N; }
+
 int main(int argc, char **argv) {
   if (argc < 2) return 2;
+  if (!strcmp(argv[1], "verifybench")) return verify_bench(argc > 2 ? atoi(argv[2]) : 8, argc > 3 ? atoi(argv[3]) : 500) ? 0 : 1;
   unsigned char sk[32], r[32], pk[20] = {0x00, 0x11, 0x22, 0x33, 0x44, 0x55, 0x66, 0x77, 0x88, 0x99, 0xaa, 0xbb, 0xcc, 0xdd, 0xee, 0xff, 0x00, 0x11, 0x22, 0x33}, zero[32] = {0};
   for (int i = 0; i < 32; i++) { sk[i] = 1; r[i] = (unsigned char)i; }
   if (!strcmp(argv[1], "hashes")) {

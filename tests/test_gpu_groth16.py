@@ -228,6 +228,15 @@ def test_msm_sharding_matches_unsharded(send_keys, golden_dir, tmp_path):
     assert p.finish(recs, r, s) == exp and e.verify(str(send_keys / "sendvk.txt"), exp, w.pack_public([d["cmtA_old"], d["sn_old"], d["cmtS"], d["cmtA"]])); p.close()
 
 @pytest.mark.parametrize("name", ["groth16_small", "groth16_step"])
+def test_gpu_verifier_values_equal_the_host_model_round_by_round(golden_dir, name):
+    """kernel K9 against the host model of its own arithmetic (vsched::simulate29, the interpreter the CPU tests pin against libsnark's verdicts): after EVERY round of the
+    schedule the LDS slots the schedule has written hold the same nine limbs — on a valid proof (accepted) and on a tampered one (rejected).  A disagreement names its round."""
+    d = os.path.join(golden_dir, name); meta = json.load(open(os.path.join(d, "meta.json"))); z = o.load_witness(os.path.join(d, "wit.bin")); vk = os.path.join(d, "vk.txt")
+    inputs = o.from_arr(z[:meta["n_inputs"]]); good = meta["proof"]; bad = good[:100] + ("0" if good[100] != "0" else "1") + good[101:]
+    assert e.verify_trace(vk, good, inputs, 1) == (-1, 0, 1)
+    r, slot, verdict = e.verify_trace(vk, bad, inputs, 1); assert (r, verdict) == (-1, 0), (r, slot, verdict)
+
+@pytest.mark.parametrize("name", ["groth16_small", "groth16_step"])
 def test_batched_gpu_verifier_matches_host_verifier(golden_dir, name):
     """K9: one lane per proof.  A batch mixing the reference prover's proof, fresh proofs, tampered proofs (each coordinate), wrong public inputs, the
     default proof and garbage must be decided exactly like the host verifier (which is pinned against libsnark's verifier and GT values)."""
@@ -290,6 +299,26 @@ def test_verify_symbols_decide_like_libsnark_on_mutated_proofs(all_keys, monkeyp
             v = vm.reference_verdicts(HARNESS, vk, [("other statement", proof, oin)], tmp_path)[0]; assert v == 0 and fn(proof, *other, *tail) is False, (kind, j)
     rc, ok = zk.VerifyBatch(items); assert ok == expect and rc == sum(expect)
     record_leg("libsnark verifier on mutated proofs of all four kinds (" + ", ".join(legs) + ")")
+
+def test_concurrent_single_proof_verifications_share_launches(golden_dir):
+    """go-ethereum verifies one proof a call from many goroutines: calls that meet inside the GPU verifier are ONE launch (gpu_verify.hip: Impl::Pending) — eight threads,
+    valid and tampered proofs and wrong inputs interleaved, every caller gets its own verdict; fewer launches than calls"""
+    import threading
+    d = os.path.join(golden_dir, "groth16_small"); meta = json.load(open(os.path.join(d, "meta.json"))); z = o.load_witness(os.path.join(d, "wit.bin")); vk = os.path.join(d, "vk.txt")
+    inputs = o.from_arr(z[:meta["n_inputs"]]); good = meta["proof"]; bad = good[:300] + ("0" if good[300] != "0" else "1") + good[301:]; wrong = list(inputs); wrong[0] = (wrong[0] + 1) % o.R_MOD
+    cases = [(good, inputs, True), (bad, inputs, False), (good, wrong, False), (good, inputs, True)]
+    assert [e.verify_batch(vk, [p], [x])[0] for p, x, _ in cases] == [w for _, _, w in cases]
+    c0, l0 = e.verify_counters(vk); errs = []
+    def caller(k):
+        for i in range(60):
+            p, x, want = cases[(i + k) % len(cases)]; got = e.verify_batch(vk, [p], [x])[0]
+            if got != want: errs.append((k, i, got, want))
+    ths = [threading.Thread(target=caller, args=(k,)) for k in range(8)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    c1, l1 = e.verify_counters(vk); assert not errs, errs[:5]; assert c1 - c0 == 480 and 0 < l1 - l0 <= c1 - c0
+    # (a batch of several proofs in one call still is one call)
+    assert e.verify_batch(vk, [good, bad, good], [inputs, inputs, wrong]) == [True, False, False]
 
 def test_gpu_verifier_random_curve_points_match_host(golden_dir):
     """K9 on 29-bit limbs keeps lazily reduced values whose bounds the schedule builder proves; here it is fed what a prover never produces — 160 "proofs" made of
