@@ -660,6 +660,11 @@ int zkgpu_debug_time_send_witness(double out[3]) { return guarded_host([&] { aut
   c->export_assignment(z);
   double t3 = now();
   assign_send(*c, in); double t4 = now(); out[0] = t1 - t0; out[1] = t4 - t3; out[2] = t3 - t2; return ZKGPU_OK; }); }
+/* host only: the groups of variables with identical columns of an R1CS file, flattened as [size, members ...] per group; returns the number of words written (or needed) */
+int zkgpu_test_equal_columns(const char *r1cs_path, uint32_t *out, size_t cap) { int res = 0; int rc = guarded_host([&] {
+    if (!r1cs_path) return ZKGPU_ERR_ARG; const R1csHost cs = read_r1cs_file(r1cs_path); size_t at = 0;
+    for (const auto &g : equal_column_groups(cs)) { if (out && at < cap) out[at] = (uint32_t)g.size(); at++; for (uint32_t v : g) { if (out && at < cap) out[at] = v; at++; } }
+    res = (int)at; return ZKGPU_OK; }); return rc == ZKGPU_OK ? res : rc; }
 int zkgpu_keygen_from_r1cs(const char *r1cs_path, uint64_t seed, const char *pk_path, const char *vk_path) { return guarded([&] {
     R1csHost cs = read_r1cs_file(r1cs_path); ProvingKeyHost pk; VerifyingKeyHost vk;
   generate_keys(cs, seed ? ToxicWaste::from_seed(seed) : ToxicWaste::random(), pk, vk); save_proving_key(pk_path, pk); save_verifying_key(vk_path, vk);
@@ -874,6 +879,9 @@ int zkgpu_prover_stash_witness(zkgpu_prover *h, uint32_t *slot) {
 int zkgpu_prover_drop_stash(zkgpu_prover *h, uint32_t slot) {
   return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; h->p->drop_stash(slot == 0xffffffffu ? (size_t)-1 : (size_t)slot); return ZKGPU_OK; });
 }
+/* process-wide: how often a fast MSM path raised its flag and the MSM was repeated on the general path (soak runs, tests) */
+uint64_t zkgpu_general_path_repeats(void) { return general_path_repeats(); }
+int zkgpu_prover_equal_column_groups(zkgpu_prover *h, uint32_t *count) { if (!h || !count) return ZKGPU_ERR_ARG; *count = (uint32_t)h->p->equal_column_groups(); return ZKGPU_OK; }
 int zkgpu_prover_stash_count(zkgpu_prover *h, uint32_t *count) {
   if (!h || !count) return ZKGPU_ERR_ARG;
   *count = (uint32_t)h->p->stash_count(); return ZKGPU_OK;

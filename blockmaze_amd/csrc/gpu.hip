@@ -799,6 +799,12 @@ void classify_witness_dev(const Fe32 *z, size_t n, uint8_t *tags, uint32_t *othe
   hipLaunchKernelGGL(k_classify_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (const Fr *)z, one, zk_with_prio(n, ZKP_EXPAND), tags, other_vars,
       counters + (parity & 1), counters + ((parity & 1) ^ 1));
 }
+static std::atomic<uint64_t> g_general_path_repeats{0};
+uint64_t general_path_repeats() { return g_general_path_repeats.load(std::memory_order_relaxed); }
+void note_general_path_repeat() { g_general_path_repeats.fetch_add(1, std::memory_order_relaxed); }
+void merge_equal_columns_dev(Fe32 *z, uint8_t *tags, const uint32_t *grp_ptr, const uint32_t *grp_mem, size_t n_groups) {
+  if (n_groups) hipLaunchKernelGGL(k_merge_equal_columns, dim3(cdiv(n_groups, 64)), dim3(64), 0, gpu().stream, (Fr *)z, tags, grp_ptr, grp_mem, (uint32_t)n_groups);
+}
 void fr_to_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_to_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
 void fr_from_mont_dev(Fe32 *a, size_t n) { if (n) hipLaunchKernelGGL(k_fr_from_mont, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (Fr *)a, (uint32_t)n); }
 

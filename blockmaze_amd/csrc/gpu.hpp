@@ -181,6 +181,8 @@ inline size_t expand_values_offset(size_t words, int canon) { return (((canon ==
 void expand_witness_dev(const uint8_t *packed_dev, size_t words, const Fe32 &one_value, int canon, size_t n, Fe32 *out, uint8_t *tags_out = nullptr,
     uint32_t *other_vars_out = nullptr);
 // the same tags and list from an assignment that already lies in device memory (ntt.cuh: k_classify_witness); counters = two words, alternating by parity
+// groups of variables with equal columns folded into one place each (ntt.cuh: k_merge_equal_columns); tags may be null; on the main stream
+void merge_equal_columns_dev(Fe32 *z, uint8_t *tags, const uint32_t *grp_ptr, const uint32_t *grp_mem, size_t n_groups);
 void classify_witness_dev(const Fe32 *z, size_t n, uint8_t *tags_out, uint32_t *other_vars_out, uint32_t *counters, int parity);
 
 // Key loading: y-coordinates of compressed points (x Montgomery; flags bit0 = parity of canonical y, bit1 = point at infinity). Throws if an x is not on the
@@ -198,6 +200,8 @@ void gpu_fork_record();
 void gpu_fork_wait(int aux);
 void gpu_join_aux();        // the main stream waits for everything queued on the auxiliary streams
 bool profiling_enabled();
+uint64_t general_path_repeats();   // how often a fast MSM path raised its flag and the MSM was repeated on the general path, process-wide (tests, soak runs)
+void note_general_path_repeat();
 // per-stage device timing (HIP events on the compute stream); report = JSON object {stage: {ms_total, count}}
 void profile_enable(bool on); std::string profile_report();
 

@@ -805,6 +805,8 @@ struct Prover::Impl {
   std::vector<std::unique_ptr<Stash>> stashes;
   const Fe32 *z_cur = nullptr; bool z_set = false;
   bool one_stream = false;                                     // diagnostic (ZK_MSM_ONE_STREAM at construction): every kernel on the main stream, submitted by the calling thread in order
+  // groups of variables with equal columns (equal_column_groups; k_merge_equal_columns folds each into one place at the head of every proof); shared by the clones
+  std::shared_ptr<DevBuf<uint32_t>> merge_ptr, merge_mem; size_t n_merge_groups = 0;
   DevBuf<uint32_t> other_count;                                // two words, alternating: the length of a list made on the device (k_classify_witness)
   int classify_parity = 0; bool n_other_on_device = false;
   PinnedBuf<Fe32> z_host;
@@ -849,6 +851,33 @@ static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &
   size_t base = n / world, rem = n % world;
   b = rank * base + (rank < rem ? rank : rem);
   e = b + base + (rank < rem ? 1 : 0);
+}
+// Auxiliary variables whose columns are identical in A, B and C (same rows, same coefficients): groups of two or more, members ascending.  One pass over the
+// matrices hashes every column (row, coefficient, matrix in row order), equal hashes are then compared entry by entry.
+std::vector<std::vector<uint32_t>> equal_column_groups(const R1csHost &cs) {
+  const size_t nv = cs.n_vars + 1; std::vector<uint64_t> h(nv, 0); std::vector<uint32_t> cnt(nv, 0);
+  auto mix = [](uint64_t a, uint64_t b) { a ^= b + 0x9e3779b97f4a7c15ull + (a << 6) + (a >> 2); a *= 0xff51afd7ed558ccdull; return a ^ (a >> 33); };
+  for (int m = 0; m < 3; m++) for (size_t r = 0; r < cs.n_cons; r++) for (uint32_t k = cs.rowptr[m][r]; k < cs.rowptr[m][r + 1]; k++) {
+    const uint32_t c = cs.col[m][k]; if (c >= nv) throw std::runtime_error("r1cs: column index"); uint64_t e = mix((uint64_t)m << 40 | r, 0);
+    const uint32_t *w = cs.coeff[m][k].l; for (int i = 0; i < 8; i += 2) e = mix(e, (uint64_t)w[i] | (uint64_t)w[i + 1] << 32);
+    h[c] = mix(h[c], e); cnt[c]++; }
+  std::vector<uint32_t> cand; for (size_t v = cs.n_inputs + 1; v < nv; v++) if (cnt[v]) cand.push_back((uint32_t)v);
+  std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { return h[a] != h[b] ? h[a] < h[b] : a < b; });
+  std::vector<uint32_t> suspects; for (size_t i = 0; i < cand.size(); i++) if ((i && h[cand[i - 1]] == h[cand[i]]) || (i + 1 < cand.size() && h[cand[i + 1]] == h[cand[i]])) suspects.push_back(cand[i]);
+  if (suspects.empty()) return {};
+  // the suspects' columns, explicitly: (matrix, row, coefficient) in order
+  std::vector<int> which(nv, -1); for (size_t i = 0; i < suspects.size(); i++) which[suspects[i]] = (int)i;
+  struct Ent { uint32_t m, r; Fe32 c; }; std::vector<std::vector<Ent>> cols(suspects.size());
+  for (uint32_t m = 0; m < 3; m++) for (size_t r = 0; r < cs.n_cons; r++) for (uint32_t k = cs.rowptr[m][r]; k < cs.rowptr[m][r + 1]; k++) { const int w = which[cs.col[m][k]];
+    if (w >= 0) cols[w].push_back(Ent{m, (uint32_t)r, cs.coeff[m][k]}); }
+  auto same = [&](int a, int b) { if (cols[a].size() != cols[b].size()) return false;
+    for (size_t i = 0; i < cols[a].size(); i++) if (cols[a][i].m != cols[b][i].m || cols[a][i].r != cols[b][i].r || memcmp(&cols[a][i].c, &cols[b][i].c, 32)) return false; return true; };
+  std::vector<std::vector<uint32_t>> groups; std::vector<char> used(suspects.size(), 0);
+  for (size_t i = 0; i < suspects.size(); i++) { if (used[i]) continue; std::vector<uint32_t> g{suspects[i]};
+    for (size_t j = i + 1; j < suspects.size() && h[suspects[j]] == h[suspects[i]]; j++) if (!used[j] && same((int)i, (int)j)) { used[j] = 1; g.push_back(suspects[j]); }
+    if (g.size() > 1) { std::sort(g.begin(), g.end()); groups.push_back(g); } }
+  std::sort(groups.begin(), groups.end());
+  return groups;
 }
 // streams, labels and the per-object vectors (everything that is not shared between the provers of one key)
 static void finish_setup(Prover::Impl &p) {
@@ -943,6 +972,13 @@ Prover::Prover(const ProvingKeyHost &pk, size_t shard_rank, size_t shard_world, 
     std::vector<uint32_t> pos(p.nv + 1, 0xffffffffu);
     for (size_t j = 0; j < pk.B_idx.size(); j++) pos[pk.B_idx[j]] = (uint32_t)j;
     p.B_pos = std::make_shared<DevBuf<uint32_t>>(pos.size()); p.B_pos->upload(pos.data(), pos.size()); }
+  if (env_int("ZK_MERGE_EQUAL_COLUMNS", 1) != 0) {
+    const std::vector<std::vector<uint32_t>> groups = zk::equal_column_groups(pk.cs); std::vector<uint32_t> ptr{0}, mem;
+    for (const auto &g : groups) { mem.insert(mem.end(), g.begin(), g.end()); ptr.push_back((uint32_t)mem.size()); }
+    p.n_merge_groups = groups.size();
+    if (p.n_merge_groups) { p.merge_ptr = std::make_shared<DevBuf<uint32_t>>(ptr.size()); p.merge_ptr->upload(ptr.data(), ptr.size());
+      p.merge_mem = std::make_shared<DevBuf<uint32_t>>(mem.size()); p.merge_mem->upload(mem.data(), mem.size()); }
+  }
 }
 Prover::Prover(const Prover &peer) : impl(new Impl) {
   // same device as the peer: the shared tables live there
@@ -953,6 +989,7 @@ Prover::Prover(const Prover &peer) : impl(new Impl) {
   p.h_lagrange = o.h_lagrange; p.c_fold = o.c_fold; p.nv = o.nv; p.ni = o.ni; p.m = o.m; p.a0 = o.a0; p.l0 = o.l0; p.b0 = o.b0; p.h0 = o.h0;
   p.alpha_g1 = o.alpha_g1; p.beta_g1 = o.beta_g1; p.delta_g1 = o.delta_g1; p.beta_g2 = o.beta_g2; p.delta_g2 = o.delta_g2;
   p.cs.reset(new R1csDev(*o.cs)); p.dom.reset(new Domain(*o.dom)); p.B_idx = o.B_idx; p.B_pos = o.B_pos;
+  p.merge_ptr = o.merge_ptr; p.merge_mem = o.merge_mem; p.n_merge_groups = o.n_merge_groups;
   p.A.reset(new MsmG1(*o.A, true, false));
   p.L.reset(new MsmG1(*o.L, true, false));
   p.B1.reset(new MsmG1(*o.B1, true, false));
@@ -1509,6 +1546,8 @@ static void enqueue_all(Prover::Impl &p) {
       }
     }
   };
+  // (the assignment the proof reads, made equivalent: equal columns folded — on the main stream ahead of the fork, so every witness MSM sees it)
+  if (p.n_merge_groups) merge_equal_columns_dev(const_cast<Fe32 *>(p.z_cur), p.tags_valid ? p.tags.get() : nullptr, p.merge_ptr->get(), p.merge_mem->get(), p.n_merge_groups);
   release(0, 0);
   p.cs->eval(p.z_cur, p.abc.get(), p.m, p.tags_valid ? p.tags.get() : nullptr, !p.c_fold); release(0, 1); release(1, 0);
   // r1cs_to_qap_witness_map with d1 = d2 = d3 = 0 (r1cs_to_qap.tcc:239-322); the row kernels test a*b == c on the way
@@ -1553,6 +1592,7 @@ void Prover::drop_stash(size_t slot) {
   p.stashes[slot].reset();
   while (!p.stashes.empty() && !p.stashes.back()) p.stashes.pop_back();
 }
+size_t Prover::equal_column_groups() const { return impl->n_merge_groups; }
 size_t Prover::stash_count() const { size_t k = 0; for (const auto &s : impl->stashes) k += s ? 1 : 0; return k; }
 bool Prover::prove_stashed(size_t slot, const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
   {

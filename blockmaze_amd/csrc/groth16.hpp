@@ -85,6 +85,7 @@ class Prover {                                    // a proving key resident in H
   size_t stash_witness();
   void drop_stash(size_t slot);
   size_t stash_count() const;
+  size_t equal_column_groups() const;   // groups of variables with identical columns found in the key (their values are folded at the head of every proof)
   bool prove_stashed(size_t slot, const Fe32 *r, const Fe32 *s, Proof &out);
   // partial multi-exponentiation results of this shard, affine canonical: eA(64) eB1(64) eH(64) eL(64) eB2(128) = 384 bytes.  false if z is unsatisfying.
   static constexpr size_t PARTIAL_BYTES = 384;
@@ -121,6 +122,8 @@ Proof default_proof();                            // (G1::one, G2::one, G1::one)
 
 // host-only self-test of the hand-over's block classifiers (scalar against AVX2 forms)
 void test_scan_blocks(const uint8_t tags[64], const uint64_t elems[256], const uint64_t one[4], uint64_t out[10]);
+// auxiliary variables whose columns are identical in A, B and C, in groups of two or more (host only; the prover folds their values, k_merge_equal_columns)
+std::vector<std::vector<uint32_t>> equal_column_groups(const R1csHost &cs);
 int test_cgroup_quota(const char *root);   // host-only: the CPU quota (CPUs, rounded up) a cgroup tree states — cpu.max (v2) or cpu/cpu.cfs_*_us (v1) under `root`; 0 = none
 int test_scan_pool(int callers, int rounds);   // host-only self-test of the hand-over's scan pool: rounds that ran on the pool, -1 on a miscount
 }  // namespace zk

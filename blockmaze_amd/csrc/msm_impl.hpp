@@ -313,8 +313,9 @@ struct MsmImpl {
         fprintf(stderr, "libzkgpu: %s: %s%s(flag %u; %u slots a bucket), general MSM path used\n", label.c_str(), (why & 1u) ? "a bucket of the witness sort overflowed " : "",
             (why & 2u) ? "a sum of the fold / tail met an operand equal to +-its partner (ZZ = 0) " : "", why, ws->cap);
       }
+      note_general_path_repeat();
       wfused = false; run_impl(last_scalars, last_index); HIP_CHECK(hipStreamSynchronize(stream())); wfused = true; }
-    if (hsort && host_counters()->pad[0]) { const Fe32 *sc = last_scalars; hsort = false;
+    if (hsort && host_counters()->pad[0]) { const Fe32 *sc = last_scalars; hsort = false; note_general_path_repeat();
       // hist() held the bucket counts of the group sort; the two-pass path wants it cleared
       HIP_CHECK(hipMemsetAsync(zeroed.get(), 0, 2 * (size_t)WB * NB * sizeof(uint32_t), stream()));
       HIP_CHECK(hipMemsetAsync(group_fill.get(), 0, hs.groups * sizeof(uint32_t), stream()));

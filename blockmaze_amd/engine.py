@@ -144,6 +144,8 @@ class Prover:
     def drop_stash(self, slot=None):
         """free a kept assignment (None: all of them)"""
         _check(lib().zkgpu_prover_drop_stash(ctypes.c_void_p(self.h), ctypes.c_uint32(0xffffffff if slot is None else slot)))
+    def equal_column_groups(self):
+        k = ctypes.c_uint32(0); _check(lib().zkgpu_prover_equal_column_groups(ctypes.c_void_p(self.h), ctypes.byref(k))); return int(k.value)
     def stash_count(self):
         k = ctypes.c_uint32(0); _check(lib().zkgpu_prover_stash_count(ctypes.c_void_p(self.h), ctypes.byref(k))); return int(k.value)
     def prove_stashed(self, slot, r=None, s=None):
@@ -196,6 +198,15 @@ def verify_schedule_on_host(vk_path, proof_hex, inputs):
     rc = lib().zkgpu_test_verify_schedule(vk_path.encode(), proof_hex.encode(), buf, ctypes.c_size_t(len(inputs)), st)
     if rc < 0: _check(rc)
     return rc == 1, dict(zip(("rounds", "slots", "products", "linear_ops", "constants", "mul_waves", "lin8_waves", "lin1_waves"), (int(x) for x in st)))
+def equal_columns(r1cs_path):
+    """groups (lists of variable numbers, 0 = ONE) of auxiliary variables whose columns coincide in A, B and C (host only)"""
+    n = lib().zkgpu_test_equal_columns(r1cs_path.encode(), None, ctypes.c_size_t(0))
+    if n < 0: _check(n)
+    buf = (ctypes.c_uint32 * max(1, n))(); lib().zkgpu_test_equal_columns(r1cs_path.encode(), buf, ctypes.c_size_t(n)); out = []; i = 0
+    while i < n: k = buf[i]; out.append([int(v) for v in buf[i + 1:i + 1 + k]]); i += 1 + k
+    return out
+def general_path_repeats():
+    lib().zkgpu_general_path_repeats.restype = ctypes.c_uint64; return int(lib().zkgpu_general_path_repeats())
 def verify_counters(vk_path):
     """(small verification calls taken by the key's GPU verifier, launches made for them)"""
     out = (ctypes.c_uint64 * 2)(); _check(lib().zkgpu_verify_counters(vk_path.encode(), out)); return int(out[0]), int(out[1])
