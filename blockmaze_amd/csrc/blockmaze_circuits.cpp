@@ -190,7 +190,7 @@ struct SendCircuit : Circuit {
     b.constraint(ONE_LC, LC(ZERO), LC());                                                                             // ZERO == 0
     r_s->constraints(); crh->constraints(); sn->constraints(); prf->constraints(); sn_old->constraints();
     cmtA_old->constraints(); cmt_old->constraints(); cmtS->constraints(); cmt_s->constraints(); cmtA->constraints(); cmt_new->constraints(); }
-  void assign(const SendInputs &in) { Board &b = board;                                                               // gadget.tcc:228-271
+  void assign(const SendInputs &in) { Board &b = board; circuit::wake_helpers();                                    // gadget.tcc:228-271
     static const bool tr = getenv("ZK_TRACE_WITNESS") != nullptr;
     auto now = [] {
       return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -208,8 +208,13 @@ struct SendCircuit : Circuit {
     b.set(ZERO, HFr::zero()); t1 = now();
     // sequential order of the reference: crh (writes r_s), prf (writes sn), cmt_old, cmt_s (reads r_s), cmt_new (reads sn). Two waves of independent hashers
     // give the same board:
-    run_parallel({[&] { crh->witness(); }, [&] { prf->witness(); }, [&] { cmt_old->witness(); }});
-    run_parallel({[&] { cmt_s->witness(); }, [&] { cmt_new->witness(); }});
+    // (round 6) ONE wave of nine compressions: the outputs that a later compression reads — r_s, sn, and every two-block hasher's intermediate digest — are
+    // written first (natively: a microsecond each, in the reference's order), then every compression fills in its own 25,000 variables beside the others and
+    // writes the same outputs again.
+    crh->h1->witness_output_only(); prf->h1->witness_output_only(); prf->h2->witness_output_only();
+    cmt_old->h1->witness_output_only(); cmt_s->h1->witness_output_only(); cmt_new->h1->witness_output_only();
+    run_parallel({[&] { cmt_s->h1->witness(); }, [&] { cmt_s->h2->witness(); }, [&] { cmt_new->h1->witness(); }, [&] { cmt_new->h2->witness(); }, [&] { prf->h1->witness(); },
+        [&] { prf->h2->witness(); }, [&] { cmt_old->h1->witness(); }, [&] { cmt_old->h2->witness(); }, [&] { crh->h1->witness(); }});
     t2 = now();
     cmtA_old->fill(blob_bits(in.cmtA_old.b, 32)); cmtS->fill(blob_bits(in.cmtS.b, 32)); cmtA->fill(blob_bits(in.cmtA.b, 32));
     unpacker->witness_from_bits(); t3 = now(); if (tr) fprintf(stderr, "trace-witness: fills %.3f hashers %.3f rest %.3f ms\n", t1 - t0, t2 - t1, t3 - t2); }

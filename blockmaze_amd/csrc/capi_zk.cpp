@@ -52,7 +52,13 @@ bool stamp_of(const std::string &p, FileStamp &s) {
 
 // One proving key = a small pool of provers (ZK_PROVERS_PER_KEY, default 6), each with its own circuit board, device buffers and stream set: cgo calls
 // that arrive concurrently (tx pool, RPC goroutines, block processing) overlap on the GPU instead of queueing behind one mutex.
-struct ProverUnit { std::shared_ptr<Prover> prover; std::unique_ptr<Circuit> circuit; std::mutex busy; };
+// (tag_dev / wide_dev: the device's addresses of the board's two arrays, pinned and mapped once per unit — the hand-over's kernel reads them in place; null: staged)
+struct ProverUnit { std::shared_ptr<Prover> prover; std::unique_ptr<Circuit> circuit; std::mutex busy; const uint8_t *tag_dev = nullptr; const Fe32 *wide_dev = nullptr;
+  void map_board() { static const bool on = [] { const char *e = getenv("ZK_HANDOVER_MAPPED"); return !e || atoi(e) != 0; }(); if (!on) return;
+    circuit::Board &b = circuit->board; tag_dev = (const uint8_t *)gpu_host_register(b.tag.data(), b.tag.size());
+    wide_dev = tag_dev ? (const Fe32 *)gpu_host_register(b.wide.data(), b.wide.size() * sizeof(b.wide[0])) : nullptr;
+    if (tag_dev && !wide_dev) { gpu_host_unregister(b.tag.data()); tag_dev = nullptr; } }
+  ~ProverUnit() { if (circuit && tag_dev) { gpu_host_unregister(circuit->board.tag.data()); gpu_host_unregister(circuit->board.wide.data()); } } };
 typedef std::vector<std::shared_ptr<ProverUnit>> UnitList;
 // A reload (the key file's size or mtime changed) never touches the old list: it publishes a NEW one, and the old units die when the last proof running on them
 // lets go of its reference — a caller can therefore never see a destroyed unit or mutex, however the reload interleaves with proofs in flight.
@@ -150,7 +156,7 @@ HeldUnit acquire_prover(CircuitKind k) {
             u->prover.reset(new Prover(pk, 0, 1, dev));
             first = u->prover;
           } else u->prover.reset(new Prover(*first));
-          u->circuit = make_circuit(k, false);
+          u->circuit = make_circuit(k, false); u->map_board();
           if (u->circuit->board.num_variables() != u->prover->num_variables() ||
               u->circuit->num_inputs() != u->prover->num_inputs()) throw std::runtime_error("proving key does not belong to the " +
               std::string(circuit_name(k)) + " circuit: " + path);
@@ -269,7 +275,9 @@ template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
     printf("Trying to generate %s proof...\n", circuit_name(k)); fflush(stdout);
     Fe32 r, s; bool fixed = parse_fixed_rs(r, s); Proof proof;
     // the board's own form (one byte per 0 / 1, Montgomery values for the rest): no conversion, no scan
-    slot.prover->set_witness_tagged(slot.circuit->board.tag.data(), reinterpret_cast<const Fe32 *>(slot.circuit->board.wide.data()));
+    { const circuit::Board &bd = slot.circuit->board; static const bool by_scan = getenv("ZK_HANDOVER_SCAN") != nullptr;   // (measurement: the scanning hand-over of rounds 4-5)
+      if (by_scan) slot.prover->set_witness_tagged(bd.tag.data(), reinterpret_cast<const Fe32 *>(bd.wide.data()));
+      else slot.prover->set_witness_board(bd.tag.data(), reinterpret_cast<const Fe32 *>(bd.wide.data()), bd.ever_wide.data(), bd.wide_marks, slot.tag_dev, slot.wide_dev); }
     double t3 = now();
     if (!slot.prover->prove_resident(fixed ? &r : nullptr, fixed ? &s : nullptr, proof)) {
       printf("can not generate %s proof\n", circuit_name(k));

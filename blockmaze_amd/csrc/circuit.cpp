@@ -1,5 +1,6 @@
 // gadgetlib1 subset restated on circuit::Board — see circuit.hpp for the source map.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <condition_variable>
 #include <deque>
@@ -7,6 +8,7 @@
 #include <thread>
 #include <stdexcept>
 #include "circuit.hpp"
+#include <chrono>
 
 namespace zk { namespace circuit {
 
@@ -262,9 +264,9 @@ struct Sha256Compression::Impl {
   VarArray packed_W;
   std::unique_ptr<MessageSchedule> ms;
   std::vector<std::unique_ptr<RoundFunction>> rounds;
-  VarArray unreduced_output, reduced_output;
+  VarArray unreduced_output, reduced_output, output;
   std::vector<LastBits> reduce;
-  Impl(Board &b, const LCArray &prev, const VarArray &block, const VarArray &output) : b(b), prev(prev), block(block) {
+  Impl(Board &b, const LCArray &prev, const VarArray &block, const VarArray &output) : b(b), prev(prev), block(block), output(output) {
     packed_W = b.alloc_array(64); ms.reset(new MessageSchedule(b, block, packed_W));
     auto word = [&](int w) { LCArray r(32); for (int k = 0; k < 32; k++) r[k] = prev[32 * w + 31 - k]; return r; };   // word w, little-endian bits
     std::vector<LCArray> ra{word(0)}, rb{word(1)}, rc{word(2)}, rd{word(3)}, re{word(4)}, rf{word(5)}, rg{word(6)}, rh{word(7)};
@@ -315,6 +317,22 @@ void Sha256Compression::witness() {
   }
   for (int i = 0; i < 8; i++) b.set(s.unreduced_output[i], b.get(s.reduce[i].X));
 }
+// Only the 256 output bits, from the block and the previous state as they stand on the board (FIPS 180-4 6.2.2 on plain words: a microsecond): what a LATER
+// compression reads.  With the outputs of a chain written first, all its compressions can fill in their ~25,000 internal variables side by side
+// (witness() writes the same outputs again).
+void Sha256Compression::witness_output_only() {
+  Impl &s = *impl; Board &b = s.b; uint32_t W[64], st[8], v[8];
+  for (int i = 0; i < 16; i++) { uint32_t w = 0; for (int k = 0; k < 32; k++) w |= (uint32_t)b.bit(s.block[32 * i + 31 - k]) << k; W[i] = w; }
+  for (int i = 0; i < 8; i++) { uint32_t w = 0; for (int k = 0; k < 32; k++) w |= (uint32_t)b.eval_bit(s.prev[32 * i + 31 - k]) << k; st[i] = w; v[i] = w; }
+  auto rotr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+  for (int i = 16; i < 64; i++) W[i] = W[i - 16] + (rotr(W[i - 15], 7) ^ rotr(W[i - 15], 18) ^ (W[i - 15] >> 3)) + W[i - 7] + (rotr(W[i - 2], 17) ^ rotr(W[i - 2], 19) ^ (W[i - 2] >> 10));
+  for (int i = 0; i < 64; i++) {
+    const uint32_t t1 = v[7] + (rotr(v[4], 6) ^ rotr(v[4], 11) ^ rotr(v[4], 25)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + SHA256_K[i] + W[i],
+        t2 = (rotr(v[0], 2) ^ rotr(v[0], 13) ^ rotr(v[0], 22)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+    v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + t1; v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = t1 + t2;
+  }
+  for (int i = 0; i < 8; i++) { const uint32_t o = st[i] + v[i]; for (int k = 0; k < 32; k++) b.set_bit(s.output[32 * i + 31 - k], (o >> k) & 1); }
+}
 void Sha256Compression::witness_reference() { Impl &s = *impl; s.ms->witness(); for (auto &r : s.rounds) r->witness();
   for (size_t i = 0; i < 4; i++) { s.b.set(s.unreduced_output[i], s.b.get(s.rounds[3 - i]->packed_d) + s.b.get(s.rounds[63 - i]->packed_new_a));
                                    s.b.set(s.unreduced_output[4 + i], s.b.get(s.rounds[3 - i]->packed_h) + s.b.get(s.rounds[63 - i]->packed_new_e)); }
@@ -335,7 +353,7 @@ class TaskPool {
   void run(std::vector<std::function<void()>> &tasks) {
     if (tasks.size() <= 1 || threads_.empty()) { for (auto &t : tasks) t(); return; }
     Batch b; b.remaining = tasks.size();
-    { std::lock_guard<std::mutex> lk(m_); for (auto &t : tasks) q_.push_back(Job{std::move(t), &b}); } cv_.notify_all();
+    { std::lock_guard<std::mutex> lk(m_); for (auto &t : tasks) q_.push_back(Job{std::move(t), &b}); queued_.fetch_add((int)tasks.size(), std::memory_order_release); } cv_.notify_all();
     // the caller works as well (possibly on another caller's tasks)
     for (;;) {
       Job j;
@@ -343,7 +361,7 @@ class TaskPool {
         std::lock_guard<std::mutex> lk(m_);
         if (q_.empty()) break;
         j = std::move(q_.front());
-        q_.pop_front();
+        q_.pop_front(); queued_.fetch_sub(1, std::memory_order_release);
       }
       execute(j);
     }
@@ -352,7 +370,7 @@ class TaskPool {
  private:
   TaskPool() {
     const char *e = getenv("ZK_WITNESS_THREADS");
-    long n = e ? atol(e) : 3;
+    long n = e ? atol(e) : 4;
     unsigned hw = std::thread::hardware_concurrency();
     if (hw && (long)hw / 2 < n + 1) n = (long)hw / 2 - 1;
     if (n < 0) n = 0;
@@ -370,21 +388,31 @@ class TaskPool {
     if (e && !j.batch->err) j.batch->err = e;
     if (--j.batch->remaining == 0) j.batch->cv.notify_all();
   }
+  // A helper that has been woken — by a job or by nudge(), which a proof call makes on its way in, a few dozen microseconds before it has tasks — polls for
+  // SPIN_US (an atomic count of queued jobs: no lock while there is nothing) before it sleeps again: waking a sleeping thread costs 30-50 us, which a witness of
+  // 0.1 ms cannot afford twice.
   void loop() {
+    using clock = std::chrono::steady_clock; uint64_t seen = 0; clock::time_point awake_until = clock::now();
     for (;;) {
-      Job j;
+      Job j; bool have = false;
+      if (queued_.load(std::memory_order_acquire) == 0 && clock::now() < awake_until) { __builtin_ia32_pause(); continue; }
       {
         std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [this] { return !q_.empty(); });
-        j = std::move(q_.front());
-        q_.pop_front();
+        if (q_.empty() && clock::now() >= awake_until) { cv_.wait(lk, [&] { return !q_.empty() || nudged_ != seen; }); seen = nudged_; awake_until = clock::now() + std::chrono::microseconds(SPIN_US); }
+        if (!q_.empty()) { j = std::move(q_.front()); q_.pop_front(); queued_.fetch_sub(1, std::memory_order_release); have = true; }
       }
-      execute(j);
+      if (have) { execute(j); awake_until = clock::now() + std::chrono::microseconds(SPIN_US); }
     }
   }
+  static constexpr int SPIN_US = 150;
+  uint64_t nudged_ = 0; std::atomic<int> queued_{0};
+ public:
+  void nudge() { { std::lock_guard<std::mutex> lk(m_); nudged_++; } cv_.notify_all(); }
+ private:
   std::mutex m_; std::condition_variable cv_; std::deque<Job> q_; std::vector<std::thread> threads_;
 };
 }  // namespace
 void run_parallel(std::vector<std::function<void()>> tasks) { TaskPool::instance().run(tasks); }
+void wake_helpers() { TaskPool::instance().nudge(); }
 
 }  }  // namespace zk::circuit

@@ -53,7 +53,7 @@ class Board {
  public:
   explicit Board(bool emit_constraints) : emit(emit_constraints) {
     tag.push_back(1);
-    wide.push_back(HFr::one());
+    wide.push_back(HFr::one()); ever_wide.push_back(0);
     for (int m = 0; m < 3; m++) cs.rowptr[m].push_back(0);
   }
   bool emit;                                   // false: witness-only pass (allocation still happens, constraints are skipped)
@@ -61,8 +61,14 @@ class Board {
   // something else (tag 2, value in wide[]): a SHA round writes ~900 bytes instead of 28 KB of field elements, and the prover takes tags + wide values as they
   // are (Prover::set_witness_tagged: no scan of a 7 MB vector to find the zeros and ones again).
   std::vector<uint8_t> tag; std::vector<HFr> wide;
+  // Which variables have EVER held something else than 0 / 1 in this object: the calls that write such values sit at fixed places of the gadgets, so after one
+  // assignment the set is complete — the prover's hand-over gathers exactly these values (a fixed list: no scan of the tags for them) and uploads the tag bytes
+  // as they are (Prover::set_witness_board).  wide_marks counts the first-time marks (the hashers run on several threads: a lost increment only matters if no
+  // increment at all were seen, and a mark and its increment are made by the same thread before the pool joins).
+  std::vector<uint8_t> ever_wide; uint32_t wide_marks = 0;
+  void mark_wide(Var v) { if (!__atomic_load_n(&ever_wide[v], __ATOMIC_RELAXED)) { __atomic_store_n(&ever_wide[v], (uint8_t)1, __ATOMIC_RELAXED); __atomic_fetch_add(&wide_marks, 1u, __ATOMIC_RELAXED); } }
   R1csHost cs;
-  Var alloc() { tag.push_back(0); wide.push_back(HFr::zero()); return (Var)(tag.size() - 1); }
+  Var alloc() { tag.push_back(0); wide.push_back(HFr::zero()); ever_wide.push_back(0); return (Var)(tag.size() - 1); }
   VarArray alloc_array(size_t n) { VarArray a(n); for (size_t i = 0; i < n; i++) a[i] = alloc(); return a; }
   void set_input_sizes(size_t n) { cs.n_inputs = n; }
   size_t num_variables() const { return tag.size() - 1; }
@@ -75,8 +81,8 @@ class Board {
     const uint8_t t = tag[v];
     return t == TAG_WIDE ? wide[v] : t == TAG_SMALL ? HFr::from_u64(wide[v].l[0]) : t ? HFr::one() : HFr::zero();
   }
-  void set(Var v, const HFr &x) { if (x.is_zero()) tag[v] = 0; else if (x == HFr::one()) tag[v] = 1; else { wide[v] = x; tag[v] = TAG_WIDE; } }
-  void set_small(Var v, uint64_t x) { if (x < 2) tag[v] = (uint8_t)x; else { wide[v].l[0] = x; tag[v] = TAG_SMALL; } }
+  void set(Var v, const HFr &x) { if (x.is_zero()) tag[v] = 0; else if (x == HFr::one()) tag[v] = 1; else { wide[v] = x; tag[v] = TAG_WIDE; mark_wide(v); } }
+  void set_small(Var v, uint64_t x) { if (x < 2) tag[v] = (uint8_t)x; else { wide[v].l[0] = x; tag[v] = TAG_SMALL; mark_wide(v); } }
   // bit i of `bits` -> variable first + i, i < count <= 64: the variables of a gadget's bit array are consecutive, eight of them are one 8-byte store
   void set_bits_run(Var first, uint64_t bits, size_t count) {
     uint8_t *t = tag.data() + first; size_t i = 0;
@@ -133,6 +139,7 @@ struct Sha256Compression {
   // prev_output: 256 LCs (MSB-first words), block: 512 variables, output: 256 variables
   Sha256Compression(Board &b, const LCArray &prev_output, const VarArray &block, const VarArray &output);
   void constraints(); void witness();
+  void witness_output_only();  // the 256 output bits alone, natively from the inputs on the board (what a later compression of a chain reads)
   void witness_reference();   // gadget-by-gadget evaluation exactly as libsnark does it; kept as the cross-check of the native path
 };
 LCArray sha256_default_iv();          // sha256_components.tcc:38-56
@@ -142,5 +149,6 @@ LCArray sha256_default_iv();          // sha256_components.tcc:38-56
 // must write disjoint variables and read nothing another task of the same call writes — the circuits below order their waves so that this holds and the result
 // equals the sequential order's.
 void run_parallel(std::vector<std::function<void()>> tasks);
+void wake_helpers();   // a proof call on its way in: the pool's threads are awake and polling by the time its tasks arrive
 
 }  }  // namespace zk::circuit

@@ -799,6 +799,20 @@ void classify_witness_dev(const Fe32 *z, size_t n, uint8_t *tags, uint32_t *othe
   hipLaunchKernelGGL(k_classify_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (const Fr *)z, one, zk_with_prio(n, ZKP_EXPAND), tags, other_vars,
       counters + (parity & 1), counters + ((parity & 1) ^ 1));
 }
+// a circuit board's assignment from its tag bytes and its candidates' values, both already on the device (k_expand_board); counters as in classify_witness_dev
+void expand_board_dev(const uint8_t *board_tags, size_t n, const uint32_t *cand, const Fe32 *cand_vals, size_t n_cand, Fe32 *z, uint8_t *tags, uint32_t *other_vars,
+    uint32_t *counters, int parity, bool vals_by_var) {
+  Fr one; memcpy(&one, FrParams::R1, 32); const unsigned tb = cdiv(n, 256);
+  hipLaunchKernelGGL(k_expand_board, dim3(tb + cdiv(n_cand, 256)), dim3(256), 0, gpu().stream, board_tags, zk_with_prio(n, ZKP_EXPAND), tb, cand, (const Fr *)cand_vals,
+      (uint32_t)n_cand | (vals_by_var ? 0x80000000u : 0u), one, (Fr *)z, tags, other_vars, counters + (parity & 1), counters + ((parity & 1) ^ 1));
+}
+void *gpu_host_register(void *p, size_t bytes) {
+  if (!p || !bytes) return nullptr; gpu();
+  if (hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  void *d = nullptr; if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || !d) { (void)hipGetLastError(); hipHostUnregister(p); return nullptr; }
+  return d;
+}
+void gpu_host_unregister(void *p) { if (p) { (void)hipHostUnregister(p); (void)hipGetLastError(); } }
 static std::atomic<uint64_t> g_general_path_repeats{0};
 uint64_t general_path_repeats() { return g_general_path_repeats.load(std::memory_order_relaxed); }
 void note_general_path_repeat() { g_general_path_repeats.fetch_add(1, std::memory_order_relaxed); }

@@ -181,6 +181,10 @@ inline size_t expand_values_offset(size_t words, int canon) { return (((canon ==
 void expand_witness_dev(const uint8_t *packed_dev, size_t words, const Fe32 &one_value, int canon, size_t n, Fe32 *out, uint8_t *tags_out = nullptr,
     uint32_t *other_vars_out = nullptr);
 // the same tags and list from an assignment that already lies in device memory (ntt.cuh: k_classify_witness); counters = two words, alternating by parity
+// a circuit board's hand-over (ntt.cuh: k_expand_board): tag bytes and the candidates' values already on the device -> z, tags, the list of other values
+// (vals_by_var: cand_vals is the board's whole wide array — entry = variable number — instead of the gathered list)
+void expand_board_dev(const uint8_t *board_tags, size_t n, const uint32_t *cand, const Fe32 *cand_vals, size_t n_cand, Fe32 *z, uint8_t *tags, uint32_t *other_vars,
+    uint32_t *counters, int parity, bool vals_by_var = false);
 // groups of variables with equal columns folded into one place each (ntt.cuh: k_merge_equal_columns); tags may be null; on the main stream
 void merge_equal_columns_dev(Fe32 *z, uint8_t *tags, const uint32_t *grp_ptr, const uint32_t *grp_mem, size_t n_groups);
 void classify_witness_dev(const Fe32 *z, size_t n, uint8_t *tags_out, uint32_t *other_vars_out, uint32_t *counters, int parity);
@@ -192,6 +196,10 @@ void decompress_g2(const Fe32 *xs /* 2 per point */, const uint8_t *flags, size_
 // Key generation: out[i] = scalars[i] * base (scalars canonical), results affine Montgomery
 void fixed_base_mul_g1(const host::HG1 &base, const Fe32 *scalars, size_t n, G1AffineRaw *out);
 void fixed_base_mul_g2(const host::HG2 &base, const Fe32 *scalars, size_t n, G2AffineRaw *out);
+// host memory the device reads in place: pins the pages of [p, p + bytes) and returns the device's address of p, or null if that is not possible (callers then stage);
+// gpu_host_unregister(p) undoes it
+void *gpu_host_register(void *p, size_t bytes);
+void gpu_host_unregister(void *p);
 void gpu_sync();            // all streams
 void gpu_fork_aux();        // auxiliary streams wait for everything queued on the main stream so far
 void gpu_fork_one(int aux); // the same for one auxiliary stream

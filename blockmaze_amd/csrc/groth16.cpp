@@ -807,6 +807,8 @@ struct Prover::Impl {
   bool one_stream = false;                                     // diagnostic (ZK_MSM_ONE_STREAM at construction): every kernel on the main stream, submitted by the calling thread in order
   // groups of variables with equal columns (equal_column_groups; k_merge_equal_columns folds each into one place at the head of every proof); shared by the clones
   std::shared_ptr<DevBuf<uint32_t>> merge_ptr, merge_mem; size_t n_merge_groups = 0;
+  // set_witness_board: the board's candidates (variables that ever held a value other than 0 / 1), as of the board's mark counter cand_marks
+  std::vector<uint32_t> cand; DevBuf<uint32_t> cand_dev; uint32_t cand_marks = 0; bool cand_valid = false;
   DevBuf<uint32_t> other_count;                                // two words, alternating: the length of a list made on the device (k_classify_witness)
   int classify_parity = 0; bool n_other_on_device = false;
   PinnedBuf<Fe32> z_host;
@@ -1453,6 +1455,36 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
     p.tags_valid = false;
   }
   p.z_cur = p.z.get(); p.z_set = true;
+  last.upload_ms = now_ms() - t0;
+}
+void Prover::set_witness_board(const uint8_t *tag, const Fe32 *wide, const uint8_t *ever_wide, uint32_t marks, const uint8_t *tag_dev, const Fe32 *wide_dev) {
+  Impl &p = *impl; LaneScope lane_scope(p.lane); BusyCall busy; const double t0 = now_ms(); const size_t n = p.nv + 1;
+  if (!p.cand_valid || p.cand_marks != marks) {                 // (first hand-overs of a circuit object only: afterwards the set is complete)
+    p.cand.clear(); for (size_t i = 1; i < n; i++) if (ever_wide[i]) p.cand.push_back((uint32_t)i);
+    if (p.cand_dev.size() < p.cand.size() + 1) p.cand_dev = DevBuf<uint32_t>(p.cand.size() + p.cand.size() / 8 + 64);
+    gpu_sync(); if (!p.cand.empty()) p.cand_dev.upload(p.cand.data(), p.cand.size());
+    p.cand_marks = marks; p.cand_valid = true;
+  }
+  const size_t nc = p.cand.size(), tags_bytes = (n + 31) & ~(size_t)31;
+  static const bool trace = getenv("ZK_TRACE_TIMES") != nullptr;
+  if (tag_dev && wide_dev) {                                    // the board's memory is mapped: the kernel reads the tag bytes and its candidates' values over PCIe itself
+    p.classify_parity ^= 1;
+    expand_board_dev(tag_dev, n, p.cand_dev.get(), wide_dev, nc, p.z.get(), p.tags.get(), p.other_vars.get(), p.other_count.get(), p.classify_parity, true);
+    p.tags_valid = true; p.n_other = (uint32_t)nc; p.n_other_on_device = true; p.z_cur = p.z.get(); p.z_set = true;
+    if (trace) fprintf(stderr, "trace-handover-board: %zu candidates read in place, host %.3f ms\n", nc, now_ms() - t0);
+    last.upload_ms = now_ms() - t0; return;
+  }
+  if (tags_bytes + 32 * nc > 32 * (p.nv + 1 + 8)) { set_witness_tagged(tag, wide); return; }          // (does not fit the staging area: not a BlockMaze board)
+  // pinned staging area and its device twin: [tag bytes | candidate values]; one copy
+  uint8_t *h = reinterpret_cast<uint8_t *>(p.z_host.get()); memcpy(h, tag, n); Fe32 *vals = reinterpret_cast<Fe32 *>(h + tags_bytes);
+  const uint32_t *c = p.cand.data();
+  for (size_t j = 0; j < nc; j++) { if (j + 16 < nc) __builtin_prefetch(&wide[c[j + 16]]); vals[j] = wide[c[j]]; }
+  upload_async(p.packed.get(), h, tags_bytes + 32 * nc);
+  p.classify_parity ^= 1;
+  expand_board_dev(p.packed.get(), n, p.cand_dev.get(), reinterpret_cast<const Fe32 *>(p.packed.get() + tags_bytes), nc, p.z.get(), p.tags.get(), p.other_vars.get(),
+      p.other_count.get(), p.classify_parity);
+  p.tags_valid = true; p.n_other = (uint32_t)nc; p.n_other_on_device = true; p.z_cur = p.z.get(); p.z_set = true;
+  if (trace) fprintf(stderr, "trace-handover-board: %zu candidates, %zu bytes, host %.3f ms\n", nc, tags_bytes + 32 * nc, now_ms() - t0);
   last.upload_ms = now_ms() - t0;
 }
 struct RsTerms { HFr r, s; HG1 r_delta, s_delta, rs_delta_neg; HG2 s_delta2; };

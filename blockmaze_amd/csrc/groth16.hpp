@@ -77,6 +77,11 @@ class Prover {                                    // a proving key resident in H
   // the same assignment as one byte per entry — 0, 1, 2 = "see wide[i]" (Montgomery form) or 6 = "the small integer in the low 64 bits of wide[i]" — entry 0
   // being the constant ONE (circuit::Board's own form)
   void set_witness_tagged(const uint8_t *tag, const Fe32 *wide);
+  // The same from a circuit board that also says which variables EVER held something else than 0 / 1 (circuit::Board::ever_wide, marks = its counter of such
+  // first-time marks): the tag bytes go up as they are, the values of exactly those variables in a fixed order — no scan, no compaction on the host (0.085 -> 0.03 ms for send)
+  // tag_dev / wide_dev (optional): the device's addresses of the two arrays where the board's memory is pinned and mapped (gpu_host_register): the device then reads
+  // them in place — the calling thread only launches
+  void set_witness_board(const uint8_t *tag, const Fe32 *wide, const uint8_t *ever_wide, uint32_t marks, const uint8_t *tag_dev = nullptr, const Fe32 *wide_dev = nullptr);
   bool prove_resident(const Fe32 *r, const Fe32 *s, Proof &out);
   // Inputs resident in HBM: stash_witness() keeps the assignment that was handed over last in device memory — the RAW vector only, (n + 1) x 32 B in
   // Montgomery form as libsnark holds it, nothing derived from it — and returns its slot (a dropped slot is reused); prove_stashed(slot, ...) proves it in place:

@@ -333,6 +333,35 @@ __global__ void __launch_bounds__(256) k_classify_witness(const Fr *__restrict__
     other_vars[at + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = i;
   }
 }
+// The hand-over of a circuit board (Prover::set_witness_board, the cgo path): the board's tag bytes as they are (0, 1, 2 = a Montgomery value in the board's wide
+// array, 6 = a small integer kept canonical) and the values of the board's candidates — the variables that ever held something else than 0 / 1, a fixed list per
+// circuit object — in the list's order.  Workgroups [0, tag_blocks): one lane per variable — zeros and ones from the byte; the others wait for their value.
+// The workgroups after them: one lane per candidate — if its tag says "other" the value goes to its place (a small integer is brought into Montgomery form here)
+// and the variable into the list of other values (one atomic per workgroup; the two counters alternate as in k_classify_witness).
+__global__ void __launch_bounds__(256) k_expand_board(const uint8_t *__restrict__ board_tags, uint32_t n, uint32_t tag_blocks, const uint32_t *__restrict__ cand,
+    const Fr *__restrict__ cand_vals, uint32_t n_cand, Fr one_value, Fr *__restrict__ z, uint8_t *__restrict__ tags, uint32_t *__restrict__ other_vars,
+    uint32_t *__restrict__ count, uint32_t *__restrict__ count_next) {
+  zk_take_prio(n);
+  const bool by_var = n_cand >> 31; n_cand &= 0x7fffffffu;        // (cand_vals: the board's whole array of values, read in place, instead of the gathered list)
+  if (blockIdx.x < tag_blocks) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_next = 0;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return; const uint8_t t = board_tags[i];
+    if (t & 2) tags[i] = ZTAG_OTHER; else { tags[i] = t ? ZTAG_ONE : ZTAG_ZERO; z[i] = t ? one_value : Fr::zero(); }
+    return;
+  }
+  __shared__ uint32_t wave_n[4], wg_at;
+  const uint32_t j = (blockIdx.x - tag_blocks) * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6; bool other = false; uint32_t var = 0;
+  if (j < n_cand) { var = cand[j]; const uint8_t t = board_tags[var];
+    if (t & 2) { other = true; Fr v = cand_vals[by_var ? var : j];
+      if (t & 4) { for (int k = 2; k < 8; k++) v.l[k] = 0; v = v.to_mont(); }                 // (a small integer: only its low 64 bits are meaningful on the board)
+      z[var] = v; } }
+  const uint64_t m = __ballot(other);
+  if (lane == 0) wave_n[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) { const uint32_t tot = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3]; wg_at = tot ? atomicAdd(count, tot) : 0u; }
+  __syncthreads();
+  if (other) { uint32_t at = wg_at; for (uint32_t wv = 0; wv < wave; wv++) at += wave_n[wv]; other_vars[at + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = var; }
+}
 // Variables whose columns coincide in all three matrices of the constraint system (mint and deposit each hold such a pair) have EQUAL points in every query, and
 // an incomplete addition that meets P + P leaves ZZ = 0: the MSM was then repeated on the general path (3 of 57,600 mixed proofs in round 5, whenever both values
 // fell into one bucket on two lanes).  Equal columns make the assignment with z_a + z_b in one place and 0 in the other EQUIVALENT — the same A z, B z, C z, the same
