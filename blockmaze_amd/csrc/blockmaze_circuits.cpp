@@ -106,6 +106,9 @@ struct ShaTwoBlock {   // CMTA / CMTS / PRF: intermediate digest allocated first
     h1.reset(new Sha256Compression(b, sha256_default_iv(), b1, inter.bits)); h2.reset(new Sha256Compression(b, to_lcs(inter.bits), b2, out)); }
   void constraints() { inter.constraints(); h1->constraints(); h2->constraints(); }
   void witness() { h1->witness(); h2->witness(); }
+  // (round 6) the outputs first — the intermediate digest, then the result, natively — so that both compressions, and whoever reads the result, can run side by side
+  void outputs_first() { h1->witness_output_only(); h2->witness_output_only(); }
+  void add_tasks(std::vector<std::function<void()>> &t) { Sha256Compression *a = h1.get(), *c = h2.get(); t.push_back([a] { a->witness(); }); t.push_back([c] { c->witness(); }); }
 };
 struct ShaOneBlock {   // CRH
   std::unique_ptr<Sha256Compression> h1;
@@ -274,7 +277,7 @@ struct MintRedeemCircuit : Circuit {
     cmtA->constraints();
     cmt_new->constraints();
   }
-  template <class In> void assign(const In &in) { Board &b = board;
+  template <class In> void assign(const In &in) { Board &b = board; circuit::wake_helpers();
     fill(b, value, u64_bits(in.value));
     b.set(value_packed, value_by_order(b, value));
     fill(b, value_old, u64_bits(in.value_old));
@@ -285,11 +288,14 @@ struct MintRedeemCircuit : Circuit {
     b.set(ZERO, HFr::zero());
     // (no hasher writes sn_old: filling it before the first wave changes nothing)
     if (!redeem) sn_old->fill(blob_bits(in.sn_old.b, 32));
-    // prf writes sn, cmt_old reads sn_old / r_old / value_old
-    run_parallel({[&] { prf->witness(); }, [&] { cmt_old->witness(); }});
-    // mint/gadget.tcc:213-221: mint overwrites the computed serial number with the given one
+    // prf writes sn, cmt_old reads sn_old / r_old / value_old; mint/gadget.tcc:213-221: mint overwrites the computed serial number with the given one before cmt_new
+    // reads it.  (round 6) One wave of six compressions: every output that a later step reads is written first, natively, in the reference's order.
+    prf->outputs_first(); cmt_old->outputs_first();
     if (!redeem) sn->fill(blob_bits(in.sn.b, 32));
-    cmt_new->witness(); cmtA_old->fill(blob_bits(in.cmtA_old.b, 32)); cmtA->fill(blob_bits(in.cmtA.b, 32)); unpacker->witness_from_bits(); }
+    cmt_new->outputs_first();
+    { std::vector<std::function<void()>> t; cmt_new->add_tasks(t); prf->add_tasks(t); cmt_old->add_tasks(t); run_parallel(std::move(t)); }
+    if (!redeem) sn->fill(blob_bits(in.sn.b, 32));                   // (prf's second compression wrote its own result again: the given one stands, as in the reference)
+    cmtA_old->fill(blob_bits(in.cmtA_old.b, 32)); cmtA->fill(blob_bits(in.cmtA.b, 32)); unpacker->witness_from_bits(); }
 };
 
 
@@ -335,7 +341,7 @@ struct MerkleRead {
     for (size_t k = 0; k < 2; k++) b.constraint(LC(enforce), LC(packed_source[k]) - LC(packed_target[k]), LC());       // field_vector_copy_gadget
   }
   // path: siblings from the leaf level upwards; index_bits[d] = bit d of the leaf position
-  void witness(const std::vector<Blob256> &path, const std::vector<bool> &index_bits) {
+  void witness(const std::vector<Blob256> &path, const std::vector<bool> &index_bits, std::vector<std::function<void()>> *tasks = nullptr) {
     for (size_t d = 0; d < depth; d++) b.set_bit(positions[d], index_bits[d]);                               // fill_with_bits_of_ulong(path_index)
     // authvars (address bit depth-1-i)
     for (size_t i = 0; i < depth; i++) {
@@ -344,11 +350,17 @@ struct MerkleRead {
       if (index_bits[level]) left[i].fill(sib);
       else right[i].fill(sib);
     }
+    // (tasks: the compressions are handed back instead of being run here — every level's digest is written first, natively, up the whole path, so that the
+    // levels can fill in their internals side by side with each other and with the caller's other hashers; finish() after they have run)
     for (size_t i = depth; i-- > 0;) {
       bool is_right = b.bit(positions[depth - 1 - i]);
       const VarArray &in = input_of(i);
       Digest &dst = is_right ? right[i] : left[i];
-      for (size_t k = 0; k < 256; k++) b.set_bit(dst.bits[k], b.bit(in[k])); hashers[i]->witness(); }
+      for (size_t k = 0; k < 256; k++) b.set_bit(dst.bits[k], b.bit(in[k]));
+      if (tasks) { hashers[i]->witness_output_only(); Sha256Compression *h = hashers[i].get(); tasks->push_back([h] { h->witness(); }); } else hashers[i]->witness(); }
+    if (!tasks) finish();
+  }
+  void finish() {
     if (b.bit(enforce)) for (size_t k = 0; k < 256; k++) b.set_bit(root[k], b.bit(computed_root->bits[k]));
     pack_source->witness_from_bits(); pack_target->witness_from_bits();
   }
@@ -400,7 +412,7 @@ struct DepositCircuit : Circuit {
     sn_s->constraints(); prf_sn_s->constraints(); sn->constraints(); prf_sn->constraints(); sn_old->constraints();
     cmtS->constraints(); cmt_s->constraints(); cmtB_old->constraints(); cmt_old->constraints(); cmtB->constraints(); cmt_new->constraints();
     rt->constraints(); boolean_constraint(b, LC(value_enforce)); merkle->constraints(); }
-  void assign(const DepositInputs &in) { Board &b = board;                                                  // gadget.tcc:235-298
+  void assign(const DepositInputs &in) { Board &b = board; circuit::wake_helpers();                       // gadget.tcc:235-298
     fill(b, value_s, u64_bits(in.value_s));
     b.set(value_s_packed, value_by_order(b, value_s));
     fill(b, value_old, u64_bits(in.value_old));
@@ -416,11 +428,18 @@ struct DepositCircuit : Circuit {
     if (in.path.size() != depth || in.index_bits.size() != depth) throw std::runtime_error("deposit: Merkle path length does not match the tree depth");
     // reference order: prf_sn (writes sn), prf_sn_s (writes sn_s), sn_s := given, cmt_s, cmt_old, cmt_new (reads sn), the three commitments := given, merkle
     // (reads cmtS).
-    run_parallel({[&] { prf_sn->witness(); }, [&] { prf_sn_s->witness(); }, [&] { cmt_s->witness(); }, [&] { cmt_old->witness(); }});
+    // (round 6) ONE wave of 10 + depth compressions: every value a later step reads — sn, sn_s, the two-block hashers' intermediate digests, the digests up the
+    // Merkle path — is written first (natively, in the reference's order, the given values where the reference lets them stand); the compressions then fill in their
+    // internals side by side, and the given values are written once more where a compression has written its own result over them.
+    prf_sn->outputs_first(); prf_sn_s->outputs_first();
     sn_s->fill(blob_bits(in.sn_s.b, 32));
+    cmt_s->outputs_first(); cmt_old->outputs_first(); cmt_new->outputs_first();
     cmtS->fill(blob_bits(in.cmtS.b, 32));
     cmtB_old->fill(blob_bits(in.cmtB_old.b, 32));
-    run_parallel({[&] { merkle->witness(in.path, in.index_bits); }, [&] { cmt_new->witness(); }}); cmtB->fill(blob_bits(in.cmtB.b, 32));
+    { std::vector<std::function<void()>> t; merkle->witness(in.path, in.index_bits, &t); cmt_new->add_tasks(t); prf_sn->add_tasks(t); prf_sn_s->add_tasks(t); cmt_s->add_tasks(t);
+      cmt_old->add_tasks(t); run_parallel(std::move(t)); }
+    sn_s->fill(blob_bits(in.sn_s.b, 32)); cmtS->fill(blob_bits(in.cmtS.b, 32)); cmtB_old->fill(blob_bits(in.cmtB_old.b, 32));
+    merkle->finish(); cmtB->fill(blob_bits(in.cmtB.b, 32));
     rt->fill(blob_bits(in.rt.b, 32)); unpacker->witness_from_bits(); }
 };
 
