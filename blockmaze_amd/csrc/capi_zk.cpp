@@ -300,15 +300,20 @@ template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
 // the device, 2.5 ms on a host core) the records go to the device in one launch — one workgroup per proof, concurrent callers on separate streams
 // (gpu_verify.hip) —, otherwise, or when the process sees no device, to the prepared host verifier. res[j]: 1 accept, 0 reject. A record the device hands back
 // (input accumulator at infinity) is decided by the host verifier.
+#ifndef ZK_VERIFY_WHILE_PROVING_DEFAULT
+#define ZK_VERIFY_WHILE_PROVING_DEFAULT true
+#endif
 void verify_group(CircuitKind kind, const Proof *ps, const uint8_t *parsed, const Fe32 *inputs, size_t ni, size_t m, uint8_t *res) {
   static const size_t gpu_min = [] { const char *e = getenv("ZK_VERIFY_GPU_MIN"); long v = e ? atol(e) : 1; return (size_t)(v < 1 ? 1 : v); }();
   const std::string path = key_path(kind, false);
-  // A single proof goes to the device only while no prover of this process is at work: measured (tools/verify_under_load.py), one verifySendproof takes 1.82 ms
-  // on an idle GPU and 1.88 ms on a host core, but 2.8 ms (p90 4.1) on a GPU that four provers keep busy — the verifier's one workgroup shares its compute
-  // unit's issue slots with their waves, and costs them 17 % of their throughput — against an unchanged 1.87 ms on the host. Two or more proofs are one launch
-  // whatever the load.
+  // A single proof also goes to the device while provers of this process are at work (round 6; rounds 3-5 sent it to the host verifier then: K9 took 2.1 ms idle and
+  // 2.8 ms beside four provers, the host 1.87).  K9 now takes 0.74 ms and its waves run at priority 3: verifySendproof 0.85 ms on an idle GPU, 0.92 ms (median; p90 1.09)
+  // beside one busy prover, 1.01 ms (p90 2.1) beside four, against 1.87-1.90 ms on a host core (profiles/r06_verify_under_load.txt).  ZK_VERIFY_WHILE_PROVING=0: the
+  // host verifier while a proof is in flight, as before.
   bool decided = false;
-  if (m >= gpu_min && (m >= 2 || g_proofs_in_flight.load(std::memory_order_relaxed) == 0) && gpu_available()) {
+  // (ZK_VERIFY_WHILE_PROVING: 1 = the device also while provers are at work, 0 = the host verifier then; measured again in round 6, profiles/r06_verify_under_load.txt)
+  static const bool while_proving = [] { const char *e = getenv("ZK_VERIFY_WHILE_PROVING"); return e ? atoi(e) != 0 : ZK_VERIFY_WHILE_PROVING_DEFAULT; }();
+  if (m >= gpu_min && (m >= 2 || while_proving || g_proofs_in_flight.load(std::memory_order_relaxed) == 0) && gpu_available()) {
     // The device may only ever be FASTER than the host verifier, never a different judge: anything that goes wrong on this branch — building the key's
     // verifier, an allocation, a launch or stream error, the test hook below — is logged and the whole group is decided by the prepared host verifier instead.
     // A transient GPU fault must not reject a valid transaction (the reference's verifier is pure host code, r1cs_gg_ppzksnark.tcc:584-590).

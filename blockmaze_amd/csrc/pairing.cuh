@@ -253,6 +253,8 @@ static __global__ void __launch_bounds__(256) k_verify_sched29(const uint4 *__re
     uint32_t trace_every) {
   extern __shared__ uint4 vs_lds4[]; uint32_t *lds = reinterpret_cast<uint32_t *>(vs_lds4);
   const uint32_t i = blockIdx.x, lane = threadIdx.x; if (i >= n) return;
+  // a verification is one dependent chain on one CU: beside a prover's kernels its waves go first (the chain kernels of a proof run at 3 too, the accumulation at 0)
+  __builtin_amdgcn_s_setprio(3);
   // (tests: proof 0's values after every trace_every-th round, n_slots x 12 words each — compared with the host model of the same arithmetic, vsched::simulate29)
   auto dump = [&](uint32_t r) { if (trace && i == 0 && (r + 1) % trace_every == 0) { const uint32_t words = si.n_slots * l29::STRIDE; uint32_t *dst = trace + (size_t)(r / trace_every) * words;
       for (uint32_t k = lane; k < words; k += 256) dst[k] = lds[k]; } };
@@ -308,6 +310,7 @@ static __global__ void __launch_bounds__(256) k_verify_sched29(const uint4 *__re
 static __global__ void __launch_bounds__(64) k_verify_acc_wave(const Affine<Fq> *__restrict__ tables, Affine<Fq> ic0, const Fr *__restrict__ inputs,
     uint32_t n_inputs, uint32_t n, NegAcc3 *__restrict__ acc_out) {
   const uint32_t i = blockIdx.x, lane = threadIdx.x; if (i >= n) return; XYZZ<Fq> acc = XYZZ<Fq>::inf();
+  __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
   for (uint32_t q = lane; q < n_inputs * 32; q += 64) {
     const uint32_t j = q >> 5, w = q & 31;
