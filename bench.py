@@ -107,12 +107,18 @@ def run_rank(args):
         except Exception as ex: log("bench: the kernel's placement stays (%s)" % ex)
     import torch
     backend = os.environ.get("ZK_BENCH_BACKEND", "nccl")                 # "gloo": lets the N > 1 code path run on a box with fewer GPUs than ranks (ranks share devices)
-    grp = None
+    grp = None; rank_info = None
     if world > 1:
         from blockmaze_amd import sharding
         grp = sharding.Group(backend, rank, world, local_rank, timeout_s=int(os.environ.get("ZK_BENCH_GROUP_TIMEOUT_S", "600")))   # every torch.distributed call of this script is made there
         log("bench: rank %d of %d joined the process group (backend %s)" % (grp.dist.get_rank(), grp.dist.get_world_size(), backend))
         assert grp.dist.get_world_size() == args.gpus
+        # an N > 1 run describes itself (device per rank, PCI bus id, the communicator's size, barrier and gather round trips) before it measures anything: stderr
+        # on rank 0, and `ranks` in the JSON line
+        rank_info = grp.describe()
+        if rank == 0:
+            for r_ in rank_info: log("bench: rank %s" % json.dumps(r_))
+            if len({(r_.get("host"), r_.get("pci_bus_id")) for r_ in rank_info}) < len(rank_info) and backend == "nccl": log("bench: WARNING: two ranks report the same device — the rates below are not a scaling measurement")
         if backend != "nccl" and torch.cuda.is_available(): torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count())); os.environ["ZK_DEVICE"] = str(local_rank % max(1, torch.cuda.device_count()))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
@@ -399,7 +405,7 @@ def run_rank(args):
             "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "distinct_witnesses": n_inst,
                        "host_binding": host_binding, "clock_warmup": "%d untimed proofs ahead of the %d warm-up steps (the GPU's clocks need ~30 ms of load to rise after the idle set-up)" % (clock_warmup, args.warmup), "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
                        "includes": "one prover call per step on the next of the run's distinct statements, all of them RESIDENT IN HBM when the timed region starts (handed over before the clock starts, kept in device memory; a step copies its assignment device-to-device and proves it): R1CS rows, the 7 NTTs of the witness map (4 run per proof; both transforms of C and the final inverse are folded into the L and H queries at key load), 5 MSM, host proof assembly, hex serialisation; excludes witness generation and key load.  `value_p50` = 1 / the median step (the mean carries the host's rare 2-5 ms steps); `value_from_host_buffers` = the same prover call handed a fresh host buffer every step (scan + PCIe + expansion included; N = 1 only) — what rounds 1-4 reported as `value`" if not shard else "one proof per step cut into shards; host-buffer hand-over included"},
-            "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "cpu_baseline_variants": cpu_more or None, "extra_legs": extra or None,
+            "ranks": rank_info, "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "cpu_baseline_variants": cpu_more or None, "extra_legs": extra or None,
             "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2), "hbm": hbm or None}}
         real_stdout.write(json.dumps(line) + "\n"); real_stdout.flush()
     prover.close()

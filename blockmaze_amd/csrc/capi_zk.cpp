@@ -242,7 +242,10 @@ static bool prove_sharded(ShardSet &set, const Fe32 *r, const Fe32 *s, Proof &pr
   auto work = [&](size_t j) {
     try { set.shards[j]->set_witness_tagged(tag, wide); ok[j] = set.shards[j]->prove_partial(rec.data() + j * Prover::PARTIAL_BYTES) ? 1 : 0; }
     catch (const std::exception &e) { errs[j] = e.what(); } catch (...) { errs[j] = "unknown error"; } };
-  for (size_t j = 1; j < K; j++) th.emplace_back(work, j);
+  // (a thread that cannot be started — the process is out of threads — must not leave its started siblings joinable when the vector dies: that would end the host
+  // process; they are joined, then the error travels up like any other)
+  try { for (size_t j = 1; j < K; j++) th.emplace_back(work, j); }
+  catch (...) { for (auto &t : th) t.join(); throw; }
   work(0); for (auto &t : th) t.join();
   for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
   for (size_t j = 0; j < K; j++) if (!ok[j]) return false;
@@ -894,6 +897,7 @@ int zkgpu_prover_drop_stash(zkgpu_prover *h, uint32_t slot) {
 }
 /* process-wide: how often a fast MSM path raised its flag and the MSM was repeated on the general path (soak runs, tests) */
 uint64_t zkgpu_general_path_repeats(void) { return general_path_repeats(); }
+uint64_t zkgpu_queries_without_tables(void) { return queries_without_tables(); }
 int zkgpu_prover_equal_column_groups(zkgpu_prover *h, uint32_t *count) { if (!h || !count) return ZKGPU_ERR_ARG; *count = (uint32_t)h->p->equal_column_groups(); return ZKGPU_OK; }
 int zkgpu_prover_stash_count(zkgpu_prover *h, uint32_t *count) {
   if (!h || !count) return ZKGPU_ERR_ARG;

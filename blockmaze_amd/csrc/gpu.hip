@@ -226,6 +226,7 @@ template <class T> DevBuf<T>::DevBuf(size_t n) : n_(n) {
     hipError_t e = hipMalloc((void **)&p_, n * sizeof(T));
     if (e != hipSuccess) {
       p_ = nullptr;
+      if (e == hipErrorOutOfMemory) throw GpuOutOfMemory("hipMalloc of " + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e));
       throw GpuError("hipMalloc of " + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e));
     }
   }
@@ -813,7 +814,9 @@ void *gpu_host_register(void *p, size_t bytes) {
   return d;
 }
 void gpu_host_unregister(void *p) { if (p) { (void)hipHostUnregister(p); (void)hipGetLastError(); } }
-static std::atomic<uint64_t> g_general_path_repeats{0};
+static std::atomic<uint64_t> g_general_path_repeats{0}, g_queries_without_tables{0};
+uint64_t queries_without_tables() { return g_queries_without_tables.load(std::memory_order_relaxed); }
+void note_query_without_tables() { g_queries_without_tables.fetch_add(1, std::memory_order_relaxed); }
 uint64_t general_path_repeats() { return g_general_path_repeats.load(std::memory_order_relaxed); }
 void note_general_path_repeat() { g_general_path_repeats.fetch_add(1, std::memory_order_relaxed); }
 void merge_equal_columns_dev(Fe32 *z, uint8_t *tags, const uint32_t *grp_ptr, const uint32_t *grp_mem, size_t n_groups) {

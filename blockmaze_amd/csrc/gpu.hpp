@@ -14,6 +14,9 @@
 namespace zk {
 
 struct GpuError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct GpuOutOfMemory : GpuError { using GpuError::GpuError; };   // a device allocation that did not fit (DevBuf): the one failure a caller may answer by asking for less
+uint64_t queries_without_tables();   // key queries loaded without their fixed-base tables because the tables did not fit the device (the prover is then several times slower on them)
+void note_query_without_tables();
 
 // raw 32-byte field element / point records as they sit in HBM (Montgomery form, little-endian limbs)
 struct Fe32 { uint32_t l[8]; };

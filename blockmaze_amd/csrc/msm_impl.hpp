@@ -111,14 +111,15 @@ struct MsmImpl {
   }
   static std::shared_ptr<const Bases> make_bases(const RawAffine *host_points, size_t n_, int c_, bool fo, bool tables, bool uniform_hint) {
     if (tables && use_precompute(n_, msm_num_windows(c_))) {
-      if (!tables_fit_device(n_, msm_num_windows(c_), fo)) tables = false;
+      if (!tables_fit_device(n_, msm_num_windows(c_), fo)) { tables = false; note_query_without_tables(); }
       else {
-        // (an allocation can still fail half-way — another process took the memory meanwhile: once more without tables)
+        // (an allocation can still fail half-way — another process took the memory meanwhile: once more without tables.  ONLY an allocation that did not fit: a
+        // kernel fault or a failed synchronisation while the tables are built is an error of the key load, not a reason to go on several times slower in silence)
         try { return make_bases_impl(host_points, n_, c_, fo, true, uniform_hint); }
-        catch (const GpuError &e) {
+        catch (const GpuOutOfMemory &e) {
           (void)hipGetLastError();
           fprintf(stderr, "libzkgpu: building the fixed-base tables of a query of %zu points failed (%s): loading it without tables\n", n_, e.what());
-          tables = false;
+          tables = false; note_query_without_tables();
         }
       }
     }

@@ -146,5 +146,25 @@ class Group:
         mine = self.torch.frombuffer(bytearray(partial_bytes), dtype=self.torch.uint8)
         out = [self.torch.empty_like(mine) for _ in range(self.world)]; self.dist.all_gather(out, mine, group=self.host_group)
         return [bytes(t.numpy().tobytes()) for t in out]
+    def describe(self):
+        """What an N > 1 run should say about itself before it reports a rate (no multi-GPU hardware was available while this was written: the first real run is to be
+        read with this in hand).  After the first barrier, on every rank: the device it computes on (index, name, PCI bus id, total memory), the communicator's size as the
+        backend reports it, and the round trip of a barrier and of one gather of 384-byte records (the sharded prover's only exchange), each timed over ten calls.
+        Returns the list of all ranks' records in rank order (gathered as objects)."""
+        import time
+        self.barrier(); torch = self.torch; rec = {"rank": self.rank, "local_rank": self.local_rank, "backend": self.backend, "world_size_reported": self.dist.get_world_size(), "host": __import__("socket").gethostname()}
+        if self.backend == "nccl":
+            n_vis = torch.cuda.device_count()
+            if n_vis < self.world: raise RuntimeError("nccl run with %d ranks on a node that shows %d devices: one rank per GPU is the contract" % (self.world, n_vis))
+            pr = torch.cuda.get_device_properties(self.local_rank); rec.update({"device": self.local_rank, "name": pr.name, "total_memory_gb": round(pr.total_memory / 1e9, 1), "devices_visible": n_vis})
+            try: rec["pci_bus_id"] = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            except Exception: rec["pci_bus_id"] = None
+        def timed(fn, n=10):
+            fn(); t0 = time.perf_counter()
+            for _ in range(n): fn()
+            if self.backend == "nccl": torch.cuda.synchronize()
+            return round(1e6 * (time.perf_counter() - t0) / n, 1)
+        rec["barrier_us"] = timed(self.barrier); rec["gather_384B_us"] = timed(lambda: self.gather_partials(bytes(384)))
+        box = [None] * self.world; self.dist.all_gather_object(box, rec); return box
     def close(self):
         self.dist.destroy_process_group()

@@ -130,6 +130,9 @@ int zkgpu_prover_stash_count(zkgpu_prover *h, uint32_t *count);
  * no equal points meeting in an incomplete addition); and, process-wide, how often a fast MSM path raised its flag and the MSM was repeated on the general path */
 int zkgpu_prover_equal_column_groups(zkgpu_prover *h, uint32_t *count);
 uint64_t zkgpu_general_path_repeats(void);
+/* key queries this process loaded WITHOUT their fixed-base tables because the tables did not fit the device's free memory: proofs on such a key are several times slower —
+ * a deployment can read the degradation here (and on stderr) instead of guessing it from the proof rate */
+uint64_t zkgpu_queries_without_tables(void);
 int zkgpu_prover_prove_stashed(zkgpu_prover *h, uint32_t slot, const uint8_t *r, const uint8_t *s, char proof_hex[513]);
 /* A second prover object on the same resident key: shares the immutable device tables of `h` (1.8 GB for send), owns its streams and workspaces (about 0.25 GB).
  * Objects may be used from different threads at the same time; their proofs overlap on the device. */

@@ -75,18 +75,20 @@ def _group_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     g = sharding.Group("gloo", rank, world, rank, timeout_s=60)
     ok_all = g.all_ok(True); ok_one = g.all_ok(rank != 1); shared = g.share_from_rank0("dir-of-rank-0" if rank == 0 else None)
-    rate, slowest = g.aggregate_throughput(10, 1.0 + rank); recs = g.gather_partials(bytes([rank + 1]) * 384)
-    q.put((rank, ok_all, ok_one, shared, rate, slowest, [r[0] for r in recs])); g.barrier(); g.close()
+    rate, slowest = g.aggregate_throughput(10, 1.0 + rank); recs = g.gather_partials(bytes([rank + 1]) * 384); info = g.describe()
+    q.put((rank, ok_all, ok_one, shared, rate, slowest, [r[0] for r in recs], [(r["rank"], r["world_size_reported"], r["backend"], r["barrier_us"] > 0, r["gather_384B_us"] > 0) for r in info])); g.barrier(); g.close()
 
 def test_group_two_ranks_gloo():
-    """the same Group object over a real (gloo) process group of two ranks: agreement on success, the hand-over from rank 0, the timing reduce and the record gather"""
+    """the same Group object over a real (gloo) process group of two ranks: agreement on success, the hand-over from rank 0, the timing reduce, the record gather and the
+    run's description of itself (Group.describe)"""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn"); q = ctx.Queue(); procs = [ctx.Process(target=_group_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs: p.start()
     res = sorted(q.get(timeout=120) for _ in range(2))
     for p in procs: p.join(timeout=60); assert p.exitcode == 0
-    for rank, ok_all, ok_one, shared, rate, slowest, firsts in res:
+    for rank, ok_all, ok_one, shared, rate, slowest, firsts, info in res:
         assert ok_all is True and ok_one is False and shared == "dir-of-rank-0" and slowest == 2.0 and rate == 10.0 and firsts == [1, 2]
+        assert info == [(0, 2, "gloo", True, True), (1, 2, "gloo", True, True)]          # Group.describe(): what an N > 1 run says about itself, on every rank, in rank order
 
 def test_ranks_are_placed_on_their_gpus_socket():
     """sharding.host_cpus_for_rank: a rank runs on the CPUs of the NUMA node its GPU hangs off (bench.py binds itself before it allocates its assignments)"""
