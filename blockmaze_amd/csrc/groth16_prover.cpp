@@ -1,3 +1,4 @@
+// Groth16 host code, part 3 of 4: the prover (hand-over of the assignment, the device pipeline's submission, proof assembly, shards, stashes).
 // see groth16.hpp
 #include <sched.h>
 #include <sys/random.h>
@@ -21,649 +22,10 @@
 #include <mutex>
 #include <thread>
 #include <climits>
-#include "groth16.hpp"
+#include "groth16_common.hpp"
 #include "verify_sched.hpp"
 
 namespace zk {
-using namespace host;
-
-static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-static HFq fq_of(const Fe32 &f) { HFq r; memcpy(r.l, &f, 32); return r; }
-static HFr fr_of(const Fe32 &f) { HFr r; memcpy(r.l, &f, 32); return r; }
-static Fe32 fe_of(const HFq &f) { Fe32 r; memcpy(&r, f.l, 32); return r; }
-static Fe32 fe_of_r(const HFr &f) { Fe32 r; memcpy(&r, f.l, 32); return r; }
-static HG1 g1_of(const G1AffineRaw &p) { return HG1::from_affine(fq_of(p.x), fq_of(p.y)); }
-static HFq2 fq2_of(const Fe32 &a, const Fe32 &b) { return {fq_of(a), fq_of(b)}; }
-static HG2 g2_of(const G2AffineRaw &p) { return HG2::from_affine(fq2_of(p.x0, p.x1), fq2_of(p.y0, p.y1)); }
-static G1AffineRaw raw_of(const HG1 &p) { HFq x, y; p.to_affine(x, y); return {fe_of(x), fe_of(y)}; }
-static G2AffineRaw raw_of(const HG2 &p) { HFq2 x, y; p.to_affine(x, y); return {fe_of(x.c0), fe_of(x.c1), fe_of(y.c0), fe_of(y.c1)}; }
-static bool is_zero_raw(const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; for (size_t i = 0; i < n; i++) if (b[i]) return false; return true; }
-
-// ======================================================================================================================
-// key files
-// ======================================================================================================================
-namespace {
-struct Cursor {
-  const uint8_t *p, *end; const char *what;
-  void fail(const char *msg) const { throw std::runtime_error(std::string(what) + ": " + msg); }
-  void skip_ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) p++; }
-  void dec(uint32_t out[8]) { skip_ws(); memset(out, 0, 32); int nd = 0;
-    while (p < end && *p >= '0' && *p <= '9') {
-      uint64_t carry = *p - '0';
-      for (int i = 0; i < 8; i++) {
-        uint64_t v = (uint64_t)out[i] * 10 + carry;
-        out[i] = (uint32_t)v;
-        carry = v >> 32;
-      }
-      p++;
-      nd++;
-    }
-    if (!nd) fail("expected a decimal number"); }
-  size_t size() {
-    uint32_t v[8];
-    dec(v);
-    for (int i = 2; i < 8; i++) if (v[i]) fail("count or index does not fit 64 bits");
-    size_t r = (size_t)v[0] | ((size_t)v[1] << 32);
-    if (r >> 40) fail("implausible count or index");
-    return r;
-  }
-  void eat(char c) { if (p < end && *p == (uint8_t)c) p++; else fail("unexpected byte"); }
-  // compressed points: ASCII is_zero, raw Montgomery X, ASCII lsb(Y)   (alt_bn128_g1.cpp:404-418, alt_bn128_g2.cpp:418-431)
-  void g1(std::vector<Fe32> &xs, std::vector<uint8_t> &flags) {
-    if (end - p < 34) fail("truncated G1");
-    uint8_t z = *p++ - '0';
-    Fe32 x;
-    memcpy(&x, p, 32);
-    p += 32;
-    uint8_t lsb = *p++ - '0';
-    if (z > 1 || lsb > 1) fail("bad G1 flag");
-    xs.push_back(x);
-    flags.push_back((uint8_t)(lsb | (z << 1)));
-  }
-  void g2(std::vector<Fe32> &xs, std::vector<uint8_t> &flags) {
-    if (end - p < 66) fail("truncated G2");
-    uint8_t z = *p++ - '0';
-    Fe32 x[2];
-    memcpy(x, p, 64);
-    p += 64;
-    uint8_t lsb = *p++ - '0';
-    if (z > 1 || lsb > 1) fail("bad G2 flag");
-    xs.push_back(x[0]);
-    xs.push_back(x[1]);
-    flags.push_back((uint8_t)(lsb | (z << 1)));
-  }
-};
-std::vector<uint8_t> slurp(const std::string &path) {
-  std::ifstream f(path, std::ios::binary);
-  if (!f) throw std::runtime_error("cannot open " + path);
-  f.seekg(0, std::ios::end);
-  size_t n = (size_t)f.tellg();
-  f.seekg(0);
-  std::vector<uint8_t> b(n);
-  f.read((char *)b.data(), n);
-  return b;
-}
-
-void put_dec(std::string &o, const uint32_t v[8]) {
-  uint32_t t[8];
-  memcpy(t, v, 32);
-  char buf[80];
-  int n = 0;
-  bool zero = true;
-  for (int i = 0; i < 8; i++) if (t[i]) zero = false;
-  if (zero) { o.push_back('0'); return; }
-  while (true) {
-    uint64_t rem = 0;
-    bool nz = false;
-    for (int i = 7; i >= 0; i--) {
-      uint64_t cur = (rem << 32) | t[i];
-      t[i] = (uint32_t)(cur / 1000000000u);
-      rem = cur % 1000000000u;
-      if (t[i]) nz = true;
-    }
-    for (int k = 0; k < 9; k++) { buf[n++] = (char)('0' + rem % 10); rem /= 10; } if (!nz) break; }
-  while (n > 1 && buf[n - 1] == '0') n--; while (n) o.push_back(buf[--n]); }
-void put_size(std::string &o, size_t v) { o += std::to_string(v); }
-void put_fq_mont(std::string &o, const Fe32 &x) { o.append((const char *)&x, 32); }
-// zero = (0, 1, 0): lsb(Y) = 1
-void put_g1(std::string &o, const G1AffineRaw &p) {
-  bool z = is_zero_raw(&p, sizeof p);
-  o.push_back(z ? '1' : '0');
-  put_fq_mont(o, p.x);
-  o.push_back(z ? '1' : (char)('0' + (fq_of(p.y).from_mont().l[0] & 1)));
-}
-void put_g2(std::string &o, const G2AffineRaw &p) {
-  bool z = is_zero_raw(&p, sizeof p);
-  o.push_back(z ? '1' : '0');
-  put_fq_mont(o, p.x0);
-  put_fq_mont(o, p.x1);
-  o.push_back(z ? '1' : (char)('0' + (fq_of(p.y0).from_mont().l[0] & 1)));
-}
-// vector<G1> operator of libff.so: no per-element newline
-void put_g1_vec(std::string &o, const std::vector<G1AffineRaw> &v) {
-  put_size(o, v.size());
-  o.push_back('\n');
-  for (auto &p : v) put_g1(o, p);
-}
-}  // namespace
-
-static size_t domain_size_for(size_t min_size);
-ProvingKeyHost load_proving_key(const std::string &path) {
-  std::vector<uint8_t> buf = slurp(path); Cursor c{buf.data(), buf.data() + buf.size(), "proving key"}; ProvingKeyHost pk;
-  std::vector<Fe32> x1, x2; std::vector<uint8_t> f1, f2;     // every G1 / G2 of the file, decompressed in one batch each
-  // alpha_g1 beta_g1 beta_g2 delta_g1 delta_g2 (r1cs_gg_ppzksnark.tcc:52-66)
-  c.g1(x1, f1);
-  c.eat('\n');
-  c.g1(x1, f1);
-  c.eat('\n');
-  c.g2(x2, f2);
-  c.eat('\n');
-  c.g1(x1, f1);
-  c.eat('\n');
-  c.g2(x2, f2);
-  c.eat('\n');
-  size_t nA = c.size(); c.eat('\n'); for (size_t i = 0; i < nA; i++) c.g1(x1, f1);
-  size_t dom = c.size(); size_t ni = c.size(); if (ni > nA) c.fail("B query has more entries than variables"); pk.B_idx.resize(ni);
-  // sparse_vector.tcc:272-288; the device gathers z[B_idx[i]]
-  for (size_t i = 0; i < ni; i++) {
-    size_t idx = c.size();
-    if (idx >= nA) c.fail("B query index out of range");
-    if (i && idx <= pk.B_idx[i - 1]) c.fail("B query indices are not increasing");
-    pk.B_idx[i] = (uint32_t)idx;
-  }
-  size_t nB = c.size(); c.eat('\n'); if (nB != ni || dom != nA) c.fail("inconsistent B query");
-  // knowledge_commitment.tcc:121-125
-  for (size_t i = 0; i < nB; i++) {
-    c.g2(x2, f2);
-    c.eat(' ');
-    c.g1(x1, f1);
-    c.eat('\n');
-  }
-  size_t nH = c.size(); c.eat('\n'); for (size_t i = 0; i < nH; i++) c.g1(x1, f1);
-  size_t nL = c.size(); c.eat('\n'); for (size_t i = 0; i < nL; i++) c.g1(x1, f1);
-  // r1cs.tcc:242-254
-  R1csHost &cs = pk.cs;
-  cs.n_inputs = c.size();
-  cs.n_vars = cs.n_inputs + c.size();
-  cs.n_cons = c.size();
-  for (int m = 0; m < 3; m++) { cs.rowptr[m].reserve(cs.n_cons + 1); cs.rowptr[m].push_back(0); }
-  for (size_t i = 0; i < cs.n_cons; i++) for (int m = 0; m < 3; m++) { size_t nt = c.size();
-    for (size_t k = 0; k < nt; k++) {
-      size_t idx = c.size();
-      if (idx > cs.n_vars) c.fail("variable index out of range");
-      Fe32 co;
-      c.dec(co.l);
-      cs.col[m].push_back((uint32_t)idx);
-      cs.coeff[m].push_back(co);
-    }
-    cs.rowptr[m].push_back((uint32_t)cs.col[m].size()); }
-  if (cs.n_inputs > cs.n_vars || nA != cs.n_vars + 1 || nL != cs.n_vars - cs.n_inputs) c.fail("query sizes do not match the constraint system");
-  // r1cs_gg_ppzksnark.tcc:281: m - 1 powers
-  if (nH + 1 != domain_size_for(cs.n_cons + cs.n_inputs + 1)) c.fail("H query size does not match the evaluation domain");
-  std::vector<G1AffineRaw> p1(x1.size()); std::vector<G2AffineRaw> p2(f2.size());
-  decompress_g1(x1.data(), f1.data(), x1.size(), p1.data()); decompress_g2(x2.data(), f2.data(), f2.size(), p2.data());
-  size_t i1 = 0, i2 = 0; pk.alpha_g1 = p1[i1++]; pk.beta_g1 = p1[i1++]; pk.beta_g2 = p2[i2++]; pk.delta_g1 = p1[i1++]; pk.delta_g2 = p2[i2++];
-  pk.A.assign(p1.begin() + i1, p1.begin() + i1 + nA);
-  i1 += nA;
-  pk.B_g1.assign(p1.begin() + i1, p1.begin() + i1 + nB);
-  i1 += nB;
-  pk.B_g2.assign(p2.begin() + i2, p2.begin() + i2 + nB);
-  pk.H.assign(p1.begin() + i1, p1.begin() + i1 + nH); i1 += nH; pk.L.assign(p1.begin() + i1, p1.begin() + i1 + nL); return pk;
-}
-
-// host-only square roots for the handful of points in a verification key
-static G1AffineRaw decompress_host_g1(const Fe32 &xm, uint8_t flags) {
-  if (flags & 2) {
-    G1AffineRaw z;
-    memset(&z, 0, sizeof z);
-    return z;
-  }
-  HFq x = fq_of(xm), y2 = x.sqr() * x + HFq::from_u64(3), y;
-  if (!fq_sqrt(y2, y)) throw std::runtime_error("verification key: G1 point not on the curve");
-  if ((y.from_mont().l[0] & 1) != (uint64_t)(flags & 1)) y = y.neg(); return {fe_of(x), fe_of(y)}; }
-static bool fq2_sqrt_host(const HFq2 &a, HFq2 &out) {   // Adj & Rodriguez-Henriquez Alg. 9, q = 3 mod 4
-  if (a.is_zero()) { out = a; return true; }
-  uint64_t e34[4], e12[4];
-  {
-    uint64_t t[4];
-    uint64_t br = 3;
-    for (int i = 0; i < 4; i++) {
-      u128 d = (u128)HFq::mod(i) - br;
-      t[i] = (uint64_t)d;
-      br = (uint64_t)(d >> 64) & 1;
-    }
-    for (int i = 0; i < 4; i++) e34[i] = (t[i] >> 2) | (i < 3 ? t[i + 1] << 62 : 0);
-    br = 1;
-    for (int i = 0; i < 4; i++) {
-      u128 d = (u128)HFq::mod(i) - br;
-      t[i] = (uint64_t)d;
-      br = (uint64_t)(d >> 64) & 1;
-    }
-    for (int i = 0; i < 4; i++) e12[i] = (t[i] >> 1) | (i < 3 ? t[i + 1] << 63 : 0);
-  }
-  HFq2 a1 = a.pow(e34, 4), x0 = a1 * a, alpha = a1 * x0, a0 = alpha.frob(1) * alpha, m1 = HFq2::one().neg();
-  if (a0 == m1) return false; if (alpha == m1) out = HFq2{x0.c1.neg(), x0.c0}; else out = (HFq2::one() + alpha).pow(e12, 4) * x0; return out.sqr() == a; }
-static G2AffineRaw decompress_host_g2(const Fe32 &x0, const Fe32 &x1, uint8_t flags) { if (flags & 2) { G2AffineRaw z; memset(&z, 0, sizeof z); return z; }
-  HFq2 x = fq2_of(x0, x1), tb = HFq2{HFq::from_u64(3), HFq::zero()} * HFq2{HFq::from_u64(9), HFq::one()}.inv(), y2 = x.sqr() * x + tb, y;
-  if (!fq2_sqrt_host(y2, y)) throw std::runtime_error("verification key: G2 point not on the twist");
-  if ((y.c0.from_mont().l[0] & 1) != (uint64_t)(flags & 1)) y = y.neg(); return {fe_of(x.c0), fe_of(x.c1), fe_of(y.c0), fe_of(y.c1)}; }
-
-VerifyingKeyHost load_verifying_key(const std::string &path) {   // r1cs_gg_ppzksnark.tcc:100-108, accumulation_vector.tcc:63-69
-  std::vector<uint8_t> buf = slurp(path); Cursor c{buf.data(), buf.data() + buf.size(), "verification key"}; VerifyingKeyHost vk;
-  HFq *gt = reinterpret_cast<HFq *>(&vk.alpha_g1_beta_g2); for (int i = 0; i < 12; i++) { Fe32 v; c.dec(v.l); gt[i] = fq_of(v).to_mont(); } c.eat('\n');
-  std::vector<Fe32> x;
-  std::vector<uint8_t> f;
-  c.g2(x, f);
-  c.eat('\n');
-  vk.gamma_g2 = decompress_host_g2(x[0], x[1], f[0]);
-  x.clear();
-  f.clear();
-  c.g2(x, f);
-  c.eat('\n');
-  vk.delta_g2 = decompress_host_g2(x[0], x[1], f[0]);
-  x.clear(); f.clear(); c.g1(x, f); c.eat('\n'); vk.IC.push_back(decompress_host_g1(x[0], f[0]));
-  size_t dom = c.size(), ni = c.size();
-  for (size_t i = 0; i < ni; i++) if (c.size() != i) c.fail("sparse IC vector");
-  size_t nv = c.size();
-  c.eat('\n');
-  if (nv != ni || dom != ni) c.fail("inconsistent IC vector");
-  for (size_t i = 0; i < nv; i++) { x.clear(); f.clear(); c.g1(x, f); c.eat('\n'); vk.IC.push_back(decompress_host_g1(x[0], f[0])); }
-  return vk;
-}
-
-void save_proving_key(const std::string &path, const ProvingKeyHost &pk) {
-  std::string o;
-  o.reserve(64 * (pk.A.size() + pk.H.size() + pk.L.size()) + 200 * pk.B_idx.size() + 40 * (pk.cs.col[0].size() + pk.cs.col[1].size() + pk.cs.col[2].size()));
-  put_g1(o, pk.alpha_g1);
-  o.push_back('\n');
-  put_g1(o, pk.beta_g1);
-  o.push_back('\n');
-  put_g2(o, pk.beta_g2);
-  o.push_back('\n');
-  put_g1(o, pk.delta_g1);
-  o.push_back('\n');
-  put_g2(o, pk.delta_g2);
-  o.push_back('\n');
-  put_g1_vec(o, pk.A);
-  put_size(o, pk.A.size());
-  o.push_back('\n');
-  put_size(o, pk.B_idx.size());
-  o.push_back('\n');
-  for (uint32_t i : pk.B_idx) {
-    put_size(o, i);
-    o.push_back('\n');
-  }
-  put_size(o, pk.B_idx.size());
-  o.push_back('\n');
-  for (size_t i = 0; i < pk.B_idx.size(); i++) {
-    put_g2(o, pk.B_g2[i]);
-    o.push_back(' ');
-    put_g1(o, pk.B_g1[i]);
-    o.push_back('\n');
-  }
-  put_g1_vec(o, pk.H); put_g1_vec(o, pk.L);
-  const R1csHost &cs = pk.cs;
-  put_size(o, cs.n_inputs);
-  o.push_back('\n');
-  put_size(o, cs.n_vars - cs.n_inputs);
-  o.push_back('\n');
-  put_size(o, cs.n_cons);
-  o.push_back('\n');
-  for (size_t i = 0; i < cs.n_cons; i++) for (int m = 0; m < 3; m++) { put_size(o, cs.rowptr[m][i + 1] - cs.rowptr[m][i]); o.push_back('\n');
-    for (uint32_t k = cs.rowptr[m][i]; k < cs.rowptr[m][i + 1]; k++) {
-      put_size(o, cs.col[m][k]);
-      o.push_back('\n');
-      put_dec(o, cs.coeff[m][k].l);
-      o.push_back('\n');
-    }
-  }
-  std::ofstream f(path, std::ios::binary); if (!f) throw std::runtime_error("cannot write " + path); f.write(o.data(), (std::streamsize)o.size());
-}
-void save_verifying_key(const std::string &path, const VerifyingKeyHost &vk) {
-  std::string o; const HFq *gt = reinterpret_cast<const HFq *>(&vk.alpha_g1_beta_g2);
-  for (int i = 0; i < 12; i++) { HFq c = gt[i].from_mont(); Fe32 v = fe_of(c); put_dec(o, v.l); if (i < 11) o.push_back(' '); } o.push_back('\n');
-  put_g2(o, vk.gamma_g2); o.push_back('\n'); put_g2(o, vk.delta_g2); o.push_back('\n'); put_g1(o, vk.IC[0]); o.push_back('\n');
-  size_t n = vk.IC.size() - 1;
-  put_size(o, n);
-  o.push_back('\n');
-  put_size(o, n);
-  o.push_back('\n');
-  for (size_t i = 0; i < n; i++) {
-    put_size(o, i);
-    o.push_back('\n');
-  }
-  put_size(o, n); o.push_back('\n'); for (size_t i = 0; i < n; i++) { put_g1(o, vk.IC[i + 1]); o.push_back('\n'); } o.push_back('\n'); o.push_back('\n');
-  std::ofstream f(path, std::ios::binary); if (!f) throw std::runtime_error("cannot write " + path); f.write(o.data(), (std::streamsize)o.size());
-}
-
-// ======================================================================================================================
-// fast key container
-// ======================================================================================================================
-namespace {
-struct ContainerHeader { char magic[8]; uint32_t version, flags; int64_t src_size, src_mtime_s, src_mtime_ns;
-    uint64_t n_inputs, n_vars, n_cons, m, nA, nB, nH, nL, nnz[3], payload_bytes, checksum; uint8_t pad[256 - 8 - 8 - 24 - 8 * 13]; };
-static_assert(sizeof(ContainerHeader) == 256, "container header");
-const char CONTAINER_MAGIC[8] = {'Z', 'K', 'G', 'P', 'U', 'K', 'C', '1'};
-// four independent multiply-xor lanes over 8-byte words (about 10 GB/s): an integrity check against truncation and bit rot, not a MAC
-uint64_t checksum64(const uint8_t *p, size_t n) {
-  uint64_t h[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull}; size_t i = 0;
-  for (; i + 32 <= n; i += 32) {
-    uint64_t w[4];
-    memcpy(w, p + i, 32);
-    for (int k = 0; k < 4; k++) {
-      h[k] = (h[k] ^ w[k]) * 0x9E3779B97F4A7C15ull;
-      h[k] ^= h[k] >> 29;
-    }
-  }
-  for (; i < n; i++) { h[0] = (h[0] ^ p[i]) * 0x100000001B3ull; }
-  return (h[0] * 3) ^ (h[1] * 5) ^ (h[2] * 7) ^ (h[3] * 11) ^ n; }
-size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
-struct Section { const void *p; size_t bytes; };
-std::vector<Section> sections_of(const ProvingKeyHost &pk) {
-  std::vector<Section> s;
-  s.push_back({&pk.alpha_g1, 64});
-  s.push_back({&pk.beta_g1, 64});
-  s.push_back({&pk.delta_g1, 64});
-  s.push_back({&pk.beta_g2, 128});
-  s.push_back({&pk.delta_g2, 128});
-  s.push_back({pk.A.data(), pk.A.size() * 64});
-  s.push_back({pk.B_idx.data(), pk.B_idx.size() * 4});
-  s.push_back({pk.B_g1.data(), pk.B_g1.size() * 64});
-  s.push_back({pk.B_g2.data(), pk.B_g2.size() * 128});
-  s.push_back({pk.H_lagrange.data(), pk.H_lagrange.size() * 64}); s.push_back({pk.L_star.data(), pk.L_star.size() * 64});
-  for (int m = 0; m < 3; m++) {
-    s.push_back({pk.cs.rowptr[m].data(), pk.cs.rowptr[m].size() * 4});
-    s.push_back({pk.cs.col[m].data(), pk.cs.col[m].size() * 4});
-    s.push_back({pk.cs.coeff[m].data(), pk.cs.coeff[m].size() * 32});
-  }
-  return s; }
-}  // namespace
-static int env_int_early(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
-bool key_stamp_of(const std::string &path, KeyStamp &out) {
-  struct stat st;
-  if (stat(path.c_str(), &st)) return false;
-  out.size = st.st_size;
-  out.mtime_s = st.st_mtim.tv_sec;
-  out.mtime_ns = st.st_mtim.tv_nsec;
-  return true;
-}
-std::string key_container_path(const std::string &pk_path) {
-  const char *on = getenv("ZK_KEY_CACHE"); if (on && atoi(on) == 0) return "";
-  // the container holds the TRANSFORMED queries: a run that switches a transform off works from the text key
-  if (env_int_early("ZK_H_LAGRANGE", 1) == 0 || env_int_early("ZK_FOLD_C", 1) == 0) return "";
-  const char *dir = getenv("ZK_KEY_CACHE_DIR"); if (!dir || !*dir) return pk_path + ".gpucache";
-  // one file per ABSOLUTE key path: the name carries a 64-bit hash of it (flattening '/' to '_' let /a/b_c/k and /a/b/c_k share a container)
-  char abs[PATH_MAX];
-  std::string full = realpath(pk_path.c_str(), abs) ? std::string(abs) : pk_path;
-  uint64_t hsh = 0xcbf29ce484222325ull;
-  for (unsigned char ch : full) {
-    hsh ^= ch;
-    hsh *= 0x100000001b3ull;
-  }
-  std::string base = full.substr(full.find_last_of('/') == std::string::npos ? 0 : full.find_last_of('/') + 1);
-  char hex[17];
-  snprintf(hex, sizeof hex, "%016llx", (unsigned long long)hsh);
-  return std::string(dir) + "/" + base + "." + hex + ".gpucache"; }
-void save_key_container(const std::string &path, const ProvingKeyHost &pk, const KeyStamp &src) {
-  if (pk.H_lagrange.empty() || pk.L_star.empty()) throw std::runtime_error("key container: the key has not been transformed yet");
-  ContainerHeader h;
-  memset(&h, 0, sizeof h);
-  memcpy(h.magic, CONTAINER_MAGIC, 8);
-  h.version = 1;
-  h.flags = 3;
-  h.src_size = src.size;
-  h.src_mtime_s = src.mtime_s;
-  h.src_mtime_ns = src.mtime_ns;
-  h.n_inputs = pk.cs.n_inputs;
-  h.n_vars = pk.cs.n_vars;
-  h.n_cons = pk.cs.n_cons;
-  h.m = pk.H_lagrange.size();
-  h.nA = pk.A.size();
-  h.nB = pk.B_idx.size();
-  h.nH = pk.H_lagrange.size();
-  h.nL = pk.L_star.size();
-  for (int m = 0; m < 3; m++) h.nnz[m] = pk.cs.col[m].size();
-  std::vector<Section> secs = sections_of(pk); size_t total = 0; for (auto &s : secs) total += align64(s.bytes);
-  std::vector<uint8_t> buf(total, 0); size_t off = 0; for (auto &s : secs) { if (s.bytes) memcpy(buf.data() + off, s.p, s.bytes); off += align64(s.bytes); }
-  h.payload_bytes = total; h.checksum = checksum64(buf.data(), total);
-  // readable by the owner only: the payload is trusted as far as the checks of load_key_container go
-  const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
-  const int wfd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
-  FILE *f = wfd < 0 ? nullptr : fdopen(wfd, "wb");
-  if (!f) {
-    if (wfd >= 0) close(wfd);
-    throw std::runtime_error("key container: cannot write " + tmp);
-  }
-  bool ok = fwrite(&h, 1, sizeof h, f) == sizeof h && fwrite(buf.data(), 1, total, f) == total; ok = fclose(f) == 0 && ok;
-  if (!ok || rename(tmp.c_str(), path.c_str())) { remove(tmp.c_str()); throw std::runtime_error("key container: cannot write " + path); } }
-bool load_key_container(const std::string &path, const KeyStamp &src, ProvingKeyHost &pk) {
-  int fd = open(path.c_str(), O_RDONLY);
-  if (fd < 0) return false;
-  struct stat st;
-  if (fstat(fd, &st) || (size_t)st.st_size < sizeof(ContainerHeader)) {
-    close(fd);
-    return false;
-  }
-  const size_t len = (size_t)st.st_size; void *map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0); close(fd); if (map == MAP_FAILED) return false;
-  struct Unmap { void *p; size_t n; ~Unmap() { munmap(p, n); } } unmap{map, len};
-  const ContainerHeader &h = *(const ContainerHeader *)map; const uint8_t *pay = (const uint8_t *)map + sizeof(ContainerHeader);
-  if (memcmp(h.magic, CONTAINER_MAGIC, 8) || h.version != 1 || h.flags != 3 || h.src_size != src.size || h.src_mtime_s != src.mtime_s ||
-      h.src_mtime_ns != src.mtime_ns) return false;
-  if (h.payload_bytes != len - sizeof(ContainerHeader) || checksum64(pay, h.payload_bytes) != h.checksum) return false;
-  if (h.nA != h.n_vars + 1 || h.nL != h.n_vars + 1 || h.nH != h.m || h.n_inputs > h.n_vars || h.nB > h.nA) return false;
-  ProvingKeyHost k;
-  k.A.resize(h.nA);
-  k.B_idx.resize(h.nB);
-  k.B_g1.resize(h.nB);
-  k.B_g2.resize(h.nB);
-  k.H_lagrange.resize(h.nH);
-  k.L_star.resize(h.nL);
-  k.cs.n_inputs = h.n_inputs;
-  k.cs.n_vars = h.n_vars;
-  k.cs.n_cons = h.n_cons;
-  for (int m = 0; m < 3; m++) { k.cs.rowptr[m].resize(h.n_cons + 1); k.cs.col[m].resize(h.nnz[m]); k.cs.coeff[m].resize(h.nnz[m]); }
-  std::vector<Section> secs = sections_of(k); size_t total = 0; for (auto &s : secs) total += align64(s.bytes); if (total != h.payload_bytes) return false;
-  size_t off = 0; for (auto &s : secs) { if (s.bytes) memcpy(const_cast<void *>(s.p), pay + off, s.bytes); off += align64(s.bytes); }
-  // the same range and monotonicity checks as the text loader: a container with a valid checksum but indices out of range would make k_r1cs_rows_all / the
-  // B-query gather read out of bounds on the device
-  for (int m = 0; m < 3; m++) { if (k.cs.rowptr[m][0] != 0 || k.cs.rowptr[m][h.n_cons] != h.nnz[m]) return false;
-    for (size_t r = 0; r < h.n_cons; r++) if (k.cs.rowptr[m][r] > k.cs.rowptr[m][r + 1]) return false;
-    for (uint32_t cidx : k.cs.col[m]) if (cidx > h.n_vars) return false; }
-  for (size_t i = 0; i < k.B_idx.size(); i++) if (k.B_idx[i] >= h.nA || (i && k.B_idx[i] <= k.B_idx[i - 1])) return false;
-  pk = std::move(k); return true; }
-ProvingKeyHost load_proving_key_fast(const std::string &pk_path, bool &from_container) {
-  from_container = false; KeyStamp st; std::string cp = key_container_path(pk_path); ProvingKeyHost pk;
-  if (!cp.empty() && key_stamp_of(pk_path, st) && load_key_container(cp, st, pk)) { from_container = true; return pk; }
-  return load_proving_key(pk_path); }
-
-// ======================================================================================================================
-// generator
-// ======================================================================================================================
-static void urandom(void *p, size_t n) {   // the kernel's CSPRNG through getrandom(2): no file descriptor, no open() per proof
-  uint8_t *b = (uint8_t *)p;
-  while (n) {
-    ssize_t k = getrandom(b, n, 0);
-    if (k < 0) {
-      if (errno == EINTR) continue;
-      throw std::runtime_error("getrandom failed");
-    }
-    b += k;
-    n -= (size_t)k;
-  }
-}
-// uniform in [0, r) by rejection (bigint.tcc:167-179 / fp.tcc:695-721)
-static HFr random_fr() {
-  for (;;) {
-    HFr v;
-    urandom(v.l, 32);
-    v.l[3] &= (1ull << 62) - 1;
-    if (!HFr::geq_mod(v.l)) return v.to_mont();
-  }
-}
-static uint64_t splitmix(uint64_t &s) {
-  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-ToxicWaste ToxicWaste::random() { ToxicWaste t; HFr *f = &t.t; for (int i = 0; i < 7; i++) { do f[i] = random_fr(); while (f[i].is_zero()); } return t; }
-ToxicWaste ToxicWaste::from_seed(uint64_t seed) {
-  ToxicWaste t;
-  HFr *f = &t.t;
-  for (int i = 0; i < 7; i++) {
-    HFr v;
-    for (int k = 0; k < 4; k++) v.l[k] = splitmix(seed);
-    v.l[3] &= (1ull << 61) - 1;
-    f[i] = v.to_mont();
-  }
-  return t;
-}
-
-static size_t ceil_log2(size_t n) { size_t r = ((n & (n - 1)) == 0 ? 0 : 1); while (n > 1) { n >>= 1; r++; } return r; }
-static HFr root_of_unity(size_t n) { HFr w; memcpy(w.l, FR_ROOT_OF_UNITY_2_28, 32); for (size_t i = 28; i > ceil_log2(n); --i) w = w.sqr(); return w; }
-static void batch_inverse(std::vector<HFr> &v) {
-  std::vector<HFr> pre(v.size());
-  HFr acc = HFr::one();
-  for (size_t i = 0; i < v.size(); i++) {
-    pre[i] = acc;
-    acc = acc * v[i];
-  }
-  HFr ai = acc.inv();
-  for (size_t i = v.size(); i-- > 0;) {
-    HFr t = ai * pre[i];
-    ai = ai * v[i];
-    v[i] = t;
-  }
-}
-// L_i(t) on a power-of-two domain (basic_radix2_domain_aux.tcc:182-236)
-static std::vector<HFr> radix2_lagrange(size_t m, const HFr &t) {
-  std::vector<HFr> u(m, HFr::zero()); if (m == 1) { u[0] = HFr::one(); return u; } HFr w = root_of_unity(m), tm = t.pow_u64(m), one = HFr::one();
-  if (tm == one) { HFr wi = one; for (size_t i = 0; i < m; i++) { if (wi == t) { u[i] = one; return u; } wi = wi * w; } }
-  HFr Z = tm - one, l = Z * HFr::from_u64(m).inv(), r = one;
-  std::vector<HFr> den(m);
-  for (size_t i = 0; i < m; i++) {
-    den[i] = t - r;
-    r = r * w;
-  }
-  batch_inverse(den);
-  for (size_t i = 0; i < m; i++) { u[i] = l * den[i]; l = l * w; } return u; }
-struct DomainShape { size_t m; bool step; size_t B, S; };
-static DomainShape domain_shape(size_t min_size) {
-  DomainShape d{0, false, 0, 0};
-  size_t lg = ceil_log2(min_size);
-  if (min_size == ((size_t)1 << lg)) {
-    d.m = min_size;
-    return d;
-  }
-  size_t big = (size_t)1 << (lg - 1), small = min_size - big, rs = (size_t)1 << ceil_log2(small);
-  d.m = small == rs ? min_size : big + rs;
-  if (d.m != ((size_t)1 << ceil_log2(d.m))) {
-    d.step = true;
-    d.B = (size_t)1 << (ceil_log2(d.m) - 1);
-    d.S = d.m - d.B;
-  }
-  return d;
-}
-static size_t domain_size_for(size_t min_size) { return domain_shape(min_size).m; }
-// all Lagrange polynomials at t and Z(t)  (basic_radix2_domain.tcc:90-101; step_radix2_domain.tcc:169-215)
-static std::vector<HFr> domain_lagrange(const DomainShape &d, const HFr &t, HFr &Zt) { HFr one = HFr::one();
-  if (!d.step) { Zt = t.pow_u64(d.m) - one; return radix2_lagrange(d.m, t); }
-  HFr w = root_of_unity((size_t)1 << ceil_log2(d.m)), wb = w.sqr(), wS = w.pow_u64(d.S);
-  std::vector<HFr> ib = radix2_lagrange(d.B, t), is = radix2_lagrange(d.S, t * w.inv()), u(d.m);
-  HFr L0 = t.pow_u64(d.S) - wS, bwS = wb.pow_u64(d.S), elt = one;
-  std::vector<HFr> den(d.B);
-  for (size_t i = 0; i < d.B; i++) {
-    den[i] = elt - wS;
-    elt = elt * bwS;
-  }
-  batch_inverse(den);
-  for (size_t i = 0; i < d.B; i++) u[i] = ib[i] * L0 * den[i];
-  HFr L1 = (t.pow_u64(d.B) - one) * (w.pow_u64(d.B) - one).inv(); for (size_t i = 0; i < d.S; i++) u[d.B + i] = L1 * is[i];
-  Zt = (t.pow_u64(d.B) - one) * (t.pow_u64(d.S) - wS); return u; }
-
-static HG2 default_g2_generator() {
-  HFq v[4];
-  for (int k = 0; k < 4; k++) memcpy(v[k].l, G2_GENERATOR[k], 32);
-  return HG2{HFq2{v[0], v[1]}, HFq2{v[2], v[3]}, HFq2::one()};
-}
-static R1csHost swap_ab_if_beneficial(const R1csHost &in) {   // r1cs.tcc:182-231
-  std::vector<uint8_t> ta(in.n_vars + 1, 0), tb(in.n_vars + 1, 0);
-  for (uint32_t c : in.col[0]) ta[c] = 1;
-  for (uint32_t c : in.col[1]) tb[c] = 1;
-  size_t na = 0, nb = 0;
-  for (size_t i = 0; i <= in.n_vars; i++) {
-    na += ta[i];
-    nb += tb[i];
-  }
-  R1csHost out = in;
-  if (nb > na) {
-    std::swap(out.rowptr[0], out.rowptr[1]);
-    std::swap(out.col[0], out.col[1]);
-    std::swap(out.coeff[0], out.coeff[1]);
-  }
-  return out;
-}
-
-void generate_keys(const R1csHost &cs_in, const ToxicWaste &tw, ProvingKeyHost &pk, VerifyingKeyHost &vk) {
-  pk.cs = swap_ab_if_beneficial(cs_in);
-  const R1csHost &cs = pk.cs;
-  size_t nv = cs.n_vars, ni = cs.n_inputs, nc = cs.n_cons;
-  DomainShape d = domain_shape(nc + ni + 1);
-  size_t m = d.m;
-  HFr Zt; std::vector<HFr> u = domain_lagrange(d, tw.t, Zt); std::vector<HFr> M[3]; for (int k = 0; k < 3; k++) M[k].assign(nv + 1, HFr::zero());
-  // r1cs_to_qap.tcc:128-131
-  for (size_t i = 0; i <= ni; i++) M[0][i] = u[nc + i];
-  for (int k = 0; k < 3; k++) for (size_t i = 0; i < nc; i++) for (uint32_t e = cs.rowptr[k][i]; e < cs.rowptr[k][i + 1];
-      e++) M[k][cs.col[k][e]] = M[k][cs.col[k][e]] + u[i] * fr_of(cs.coeff[k][e]).to_mont();
-  HFr gi = tw.gamma.inv(), di = tw.delta.inv();
-  auto canon = [](const HFr &x) { return fe_of_r(x.from_mont()); };
-  std::vector<Fe32> sA(nv + 1), sB, sH(m - 1), sL(nv - ni), sIC(ni + 1);
-  for (size_t i = 0; i <= nv; i++) sA[i] = canon(M[0][i]);
-  // kc_multiexp.tcc:105-112
-  pk.B_idx.clear();
-  for (size_t i = 0; i <= nv; i++) if (!M[1][i].is_zero()) {
-    pk.B_idx.push_back((uint32_t)i);
-    sB.push_back(canon(M[1][i]));
-  }
-  // :330 batch_exp_with_coeff(Zt/delta, Ht), Ht truncated by 2 (:281)
-  {
-    HFr x = Zt * di;
-    for (size_t i = 0; i + 1 < m; i++) {
-      sH[i] = canon(x);
-      x = x * tw.t;
-    }
-  }
-  for (size_t i = 0; i < nv - ni; i++) { size_t j = ni + 1 + i; sL[i] = canon((tw.beta * M[0][j] + tw.alpha * M[1][j] + M[2][j]) * di); }          // :264-273
-  for (size_t i = 0; i <= ni; i++) sIC[i] = canon((tw.beta * M[0][i] + tw.alpha * M[1][i] + M[2][i]) * gi);                                        // :253-260
-  // G1 generator (1, 2)
-  HG1 g1{HFq::from_u64(1), HFq::from_u64(2), HFq::one()};
-  HG2 g2 = default_g2_generator();
-  // random generators (:297,:307)
-  {
-    HFr k1 = tw.g1_scalar.from_mont(), k2 = tw.g2_scalar.from_mont();
-    g1 = g1.mul(k1.l);
-    g2 = g2.mul(k2.l);
-  }
-  auto mul1 = [&](const HFr &k) {
-    HFr c = k.from_mont();
-    return raw_of(g1.mul(c.l));
-  };
-  auto mul2 = [&](const HFr &k) {
-    HFr c = k.from_mont();
-    return raw_of(g2.mul(c.l));
-  };
-  pk.alpha_g1 = mul1(tw.alpha); pk.beta_g1 = mul1(tw.beta); pk.beta_g2 = mul2(tw.beta); pk.delta_g1 = mul1(tw.delta); pk.delta_g2 = mul2(tw.delta);
-  pk.A.resize(nv + 1); fixed_base_mul_g1(g1, sA.data(), nv + 1, pk.A.data());
-  pk.B_g1.resize(sB.size());
-  pk.B_g2.resize(sB.size());
-  fixed_base_mul_g1(g1, sB.data(), sB.size(), pk.B_g1.data());
-  fixed_base_mul_g2(g2, sB.data(), sB.size(), pk.B_g2.data());
-  pk.H.resize(m - 1); fixed_base_mul_g1(g1, sH.data(), m - 1, pk.H.data()); pk.L.resize(nv - ni); fixed_base_mul_g1(g1, sL.data(), nv - ni, pk.L.data());
-  vk.IC.resize(ni + 1); fixed_base_mul_g1(g1, sIC.data(), ni + 1, vk.IC.data()); vk.gamma_g2 = mul2(tw.gamma); vk.delta_g2 = pk.delta_g2;
-  // :355
-  vk.alpha_g1_beta_g2 = reduced_pairing(fq_of(pk.alpha_g1.x), fq_of(pk.alpha_g1.y), fq2_of(pk.beta_g2.x0, pk.beta_g2.x1), fq2_of(pk.beta_g2.y0, pk.beta_g2.y1));
-}
-
 // ======================================================================================================================
 // prover
 // ====================================================================================================================== A helper thread that lives as long as
@@ -1720,182 +1082,6 @@ void Prover::finish_from_partials(const uint8_t *records, size_t n, const Fe32 *
     if (!z) eB2 = eB2.add(HG2::from_affine(HFq2{v[0], v[1]}, HFq2{v[2], v[3]}));
   }
   assemble(p, rs_terms(r_in, s_in, p.delta_g1, p.delta_g2), eA, eB1, eB2, eH, eL, out);
-}
-
-// ======================================================================================================================
-// verifier and proof encoding
-// ======================================================================================================================
-// one-off use; callers that verify more than once keep the prepared key
-bool verify_proof(const VerifyingKeyHost &vk, const Fe32 *inputs, size_t n_inputs, const Proof &proof) {
-  return verify_proof(*prepare_verifying_key(vk), inputs, n_inputs, proof);
-}
-
-std::shared_ptr<PreparedVerifyingKey> prepare_verifying_key(const VerifyingKeyHost &vk) {
-  auto p = std::make_shared<PreparedVerifyingKey>(); p->vk = vk;
-  p->gamma = precompute_g2(fq2_of(vk.gamma_g2.x0, vk.gamma_g2.x1), fq2_of(vk.gamma_g2.y0, vk.gamma_g2.y1));
-  p->delta = precompute_g2(fq2_of(vk.delta_g2.x0, vk.delta_g2.x1), fq2_of(vk.delta_g2.y0, vk.delta_g2.y1));
-  const size_t ni = vk.IC.size() ? vk.IC.size() - 1 : 0; p->ic_x.assign(ni * 32 * 255, HFq::zero()); p->ic_y.assign(ni * 32 * 255, HFq::zero());
-  for (size_t j = 0; j < ni; j++) {
-    HG1 wbase = is_zero_raw(&vk.IC[j + 1], sizeof(G1AffineRaw)) ? HG1::inf() : g1_of(vk.IC[j + 1]);
-    std::vector<HG1> pts(32 * 255);
-    for (int w = 0; w < 32; w++) { HG1 acc = wbase; for (int d = 1; d <= 255; d++) { pts[w * 255 + d - 1] = acc; acc = acc.add(wbase); } wbase = acc; }
-    // one inversion for the whole table
-    std::vector<HFq> pre(pts.size());
-    HFq run = HFq::one();
-    for (size_t k = 0; k < pts.size(); k++) {
-      pre[k] = run;
-      if (!pts[k].is_inf()) run = run * pts[k].Z;
-    }
-    HFq inv = run.inv();
-    for (size_t k = pts.size(); k-- > 0;) {
-      if (pts[k].is_inf()) continue;
-      HFq zi = inv * pre[k];
-      inv = inv * pts[k].Z;
-      HFq z2 = zi.sqr();
-      p->ic_x[j * 32 * 255 + k] = pts[k].X * z2;
-      p->ic_y[j * 32 * 255 + k] = pts[k].Y * z2 * zi;
-    }
-  }
-  return p;
-}
-bool verify_proof(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof) {
-  const VerifyingKeyHost &vk = pvk.vk; if (vk.IC.size() != n_inputs + 1) return false;                                     // strong IC (:584-590)
-  HG1 acc = g1_of(vk.IC[0]);
-  for (size_t j = 0; j < n_inputs; j++) { const uint8_t *b = reinterpret_cast<const uint8_t *>(&inputs[j]);
-    for (int w = 0; w < 32; w++) if (b[w]) {
-      const size_t k = j * 32 * 255 + (size_t)w * 255 + b[w] - 1;
-      if (!(pvk.ic_x[k].is_zero() && pvk.ic_y[k].is_zero())) acc = acc.add(HG1::from_affine(pvk.ic_x[k], pvk.ic_y[k]));
-    }
-  }
-  HFq ax = fq_of(proof.A.x), ay = fq_of(proof.A.y), cx = fq_of(proof.C.x), cy = fq_of(proof.C.y);
-  HFq2 bx = fq2_of(proof.B.x0, proof.B.x1), by = fq2_of(proof.B.y0, proof.B.y1);
-  if (is_zero_raw(&proof.A, sizeof proof.A) || is_zero_raw(&proof.B, sizeof proof.B) || is_zero_raw(&proof.C, sizeof proof.C)) return false;
-  if (!(g1_on_curve(ax, ay) && g2_on_curve(bx, by) && g1_on_curve(cx, cy))) return false;                                    // is_well_formed: on-curve only
-  HFq accx, accy; acc.to_affine(accx, accy);
-  HFq12 q1 = miller_loop(ax, ay, precompute_g2(bx, by)), q2 = acc.is_inf() ? HFq12::one() : miller_loop(accx, accy, pvk.gamma), q3 = miller_loop(cx, cy,
-      pvk.delta);
-  return final_exponentiation(q1 * (q2 * q3).conj()) == vk.alpha_g1_beta_g2;                                               // :556-560
-}
-
-// The decision of verify_proof() taken by the GPU verifier's SCHEDULE (verify_sched.hpp) interpreted on the host: what kernel K9 computes, without a GPU. Test
-// entry (zkgpu_test_verify_schedule): the schedule is checked against the host verifier and the oracle on the CPU before any device runs it. stats: rounds,
-// slots, products, linear operations, constants, then the WAVES of products / eight-lane sums / one-lane sums.
-bool verify_by_schedule_on_host(const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t stats[8]) {
-  const VerifyingKeyHost &vk = pvk.vk; vsched::Schedule S = vsched::build(vk.alpha_g1_beta_g2, pvk.gamma, pvk.delta);
-  if (stats) {
-    stats[0] = S.n_rounds;
-    stats[1] = S.n_slots;
-    stats[2] = S.n_mul;
-    stats[3] = S.n_lin;
-    stats[4] = (uint32_t)S.consts.size();
-    stats[5] = S.waves_of_kind[vsched::K_MUL];
-    stats[6] = S.waves_of_kind[vsched::K_LIN8];
-    stats[7] = S.waves_of_kind[vsched::K_LIN1];
-  }
-  if (vk.IC.size() != n_inputs + 1) return false;
-  HG1 acc = g1_of(vk.IC[0]);
-  for (size_t j = 0; j < n_inputs; j++) { const uint8_t *b = reinterpret_cast<const uint8_t *>(&inputs[j]);
-    for (int w = 0; w < 32; w++) if (b[w]) {
-      const size_t k = j * 32 * 255 + (size_t)w * 255 + b[w] - 1;
-      if (!(pvk.ic_x[k].is_zero() && pvk.ic_y[k].is_zero())) acc = acc.add(HG1::from_affine(pvk.ic_x[k], pvk.ic_y[k]));
-    }
-  }
-  if (is_zero_raw(&proof.A, sizeof proof.A) || is_zero_raw(&proof.B, sizeof proof.B) || is_zero_raw(&proof.C, sizeof proof.C)) return false;
-  // (the kernel hands such a proof back to the host verifier: the gamma pairing is the identity then)
-  if (acc.is_inf()) return verify_proof(pvk, inputs, n_inputs, proof);
-  HFq accx, accy; acc.to_affine(accx, accy); HFq in[vsched::N_INPUTS];
-  in[vsched::IN_AX] = fq_of(proof.A.x);
-  in[vsched::IN_AY] = fq_of(proof.A.y);
-  in[vsched::IN_BX0] = fq_of(proof.B.x0);
-  in[vsched::IN_BX1] = fq_of(proof.B.x1);
-  in[vsched::IN_BY0] = fq_of(proof.B.y0);
-  in[vsched::IN_BY1] = fq_of(proof.B.y1);
-  in[vsched::IN_CX] = fq_of(proof.C.x);
-  in[vsched::IN_CY] = fq_of(proof.C.y);
-  // (the accumulation kernel hands the point over as (x w, -y w, w) with w = ZZ ZZZ of its sum: a non-trivial w here too, so that the CPU tests cover the scaling)
-  const HFq w = HFq::from_u64(0x9e3779b97f4a7c15ull ^ ((uint64_t)accx.l[0] | (uint64_t)accx.l[1] << 32)) + HFq::one();
-  in[vsched::IN_NACCX] = accx * w;
-  in[vsched::IN_NACCY] = (accy * w).neg();
-  in[vsched::IN_NACCW] = w;
-  std::vector<HFq> out = vsched::simulate(S, in); bool ok = true;
-  // the GT comparison, then the on-curve residues: all zero; the norm of the Miller value: not zero
-  for (int k = 0; k < vsched::N_OUT; k++) ok = ok && (k == vsched::OUT_NONZERO ? !out[k].is_zero() : out[k].is_zero());
-  // ... and the same program on the kernel's own limb arithmetic (every bound asserted on the way): value by value the same verdicts
-  uint32_t words[vsched::N_INPUTS][8]; for (int i = 0; i < vsched::N_INPUTS; i++) memcpy(words[i], in[i].l, 32);
-  std::vector<bool> zero29 = vsched::simulate29(S, words);
-  for (int k = 0; k < vsched::N_OUT;
-      k++) if (zero29[k] != out[k].is_zero()) throw std::runtime_error("verify schedule: the 29-bit model and the field model disagree on output " +
-      std::to_string(k));
-  return ok;
-}
-// Kernel K9 against the host model of its own arithmetic, value by value: one proof runs through the device kernels with the LDS values written out after every
-// `every`-th round; vsched::simulate29 is fed the same inputs (the accumulation kernel's record included) and must hold the same limbs in every slot that the
-// schedule has written by then.  Returns -1 if every dump agrees, otherwise the first round whose dump differs (slot in *bad_slot); *device_ok = the kernel's verdict.
-long verify_schedule_trace_on_device(BatchVerifier &bv, const PreparedVerifyingKey &pvk, const Fe32 *inputs, size_t n_inputs, const Proof &proof, uint32_t every,
-    uint32_t *bad_slot, uint8_t *device_ok) {
-  const VerifyingKeyHost &vk = pvk.vk; if (vk.IC.size() != n_inputs + 1 || bv.num_inputs() != n_inputs) throw std::runtime_error("verify trace: input count");
-  vsched::Schedule S = vsched::build(vk.alpha_g1_beta_g2, pvk.gamma, pvk.delta);
-  std::vector<uint32_t> values; uint8_t nacc[96]; const uint8_t ok = bv.trace(&proof, inputs, every, values, nacc); if (device_ok) *device_ok = ok;
-  uint32_t words[vsched::N_INPUTS][8]; const Fe32 *pc = reinterpret_cast<const Fe32 *>(&proof);           // A.x A.y | B.x.c0 B.x.c1 B.y.c0 B.y.c1 | C.x C.y
-  for (int k = 0; k < 8; k++) memcpy(words[k], &pc[k], 32);
-  for (int k = 0; k < 3; k++) memcpy(words[vsched::IN_NACCX + k], nacc + 32 * k, 32);
-  const size_t stride = (size_t)S.n_slots * l29::STRIDE; long first_bad = -1; uint32_t slot_bad = 0; std::vector<char> written(S.n_slots, 0);
-  for (int k = 0; k < vsched::N_INPUTS; k++) written[k] = 1;
-  vsched::simulate29(S, words, [&](uint32_t r, const std::vector<std::array<uint32_t, 9>> &slots) {
-    vsched::for_each_op(S, r, [&](uint32_t, uint32_t, const uint32_t *w) { written[w[0] & 0x7fffu] = 1; });
-    if (first_bad >= 0 || (r + 1) % every != 0 || r >= S.n_rounds) return; const uint32_t *dv = &values[(size_t)(r / every) * stride];
-    for (uint32_t sl = 0; sl < S.n_slots && first_bad < 0; sl++) if (written[sl] && memcmp(dv + (size_t)sl * l29::STRIDE, slots[sl].data(), 36) != 0) { first_bad = (long)r; slot_bad = sl; } });
-  if (bad_slot) *bad_slot = slot_bad; return first_bad;
-}
-std::unique_ptr<BatchVerifier> make_batch_verifier(const VerifyingKeyHost &vk) {
-  return std::unique_ptr<BatchVerifier>(new BatchVerifier(vk.alpha_g1_beta_g2, vk.gamma_g2, vk.delta_g2, vk.IC.data(), vk.IC.size()));
-}
-
-static void put_hex_fq(std::string &o, const Fe32 &mont) {
-  HFq c = fq_of(mont).from_mont();
-  static const char *d = "0123456789abcdef";
-  for (int i = 3; i >= 0; i--) for (int k = 15; k >= 0; k--) o.push_back(d[(c.l[i] >> (4 * k)) & 15]);
-}
-std::string proof_to_hex(const Proof &p) {
-  std::string o;
-  o.reserve(512);
-  put_hex_fq(o, p.A.x);
-  put_hex_fq(o, p.A.y);
-  put_hex_fq(o, p.B.x1);
-  put_hex_fq(o, p.B.x0);
-  put_hex_fq(o, p.B.y1);
-  put_hex_fq(o, p.B.y0);
-  put_hex_fq(o, p.C.x);
-  put_hex_fq(o, p.C.y);
-  return o;
-}
-bool proof_from_hex(const char *hex, Proof &p) {
-  static const bool strict = [] { const char *e = getenv("ZK_STRICT_PROOF_ENCODING"); return e && *e && *e != '0'; }();
-  Fe32 v[8];
-  for (int k = 0; k < 8; k++) {
-    HFq c = HFq::zero();
-    for (int i = 0; i < 64; i++) {
-      char ch = hex[64 * k + i];
-      int dgt = ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : -1;
-      if (dgt < 0) return false;
-      c.l[(63 - i) / 16] |= (uint64_t)dgt << (4 * ((63 - i) % 16));
-    }
-    // Any 256-bit value is a coordinate: the reference builds the field element with Fp_model(const bigint&) (sendcgo.cpp:422-446 -> fp.tcc:190-194), one
-    // Montgomery product with R^2, which leaves value mod q.  to_mont() is that product (a < 2^256, R^2 < q: the sum stays below 2q, one subtraction), so a
-    // coordinate c and c + kq are the same proof here as they are there — consensus needs the same accept set, not a stricter one (ZK_STRICT_PROOF_ENCODING=1
-    // restores the rejection for deployments that want canonical encodings only; INTEGRATION.md "Not verbatim").
-    if (strict && HFq::geq_mod(c.l)) return false;
-    v[k] = fe_of(c.to_mont());
-  }
-  p.A = {v[0], v[1]}; p.B = {v[3], v[2], v[5], v[4]}; p.C = {v[6], v[7]}; return true;
-}
-Proof default_proof() {
-  Proof p;
-  HG1 g{HFq::from_u64(1), HFq::from_u64(2), HFq::one()};
-  p.A = raw_of(g);
-  p.C = p.A;
-  p.B = raw_of(default_g2_generator());
-  return p;
 }
 
 }  // namespace zk
