@@ -110,7 +110,7 @@ namespace {
 std::condition_variable g_pool_cv;   // signalled under g_cache_mutex whenever a pool build ends
 // Loads the key on first use or when the file changed. g_cache_mutex guards the slot table only; a pool is BUILT outside it (under g_gpu_mutex, which
 // serialises key loads and the other set-up work of the device), so callers that can be served by a loaded device never queue behind a key load. A prover's
-// helper threads start with its first proof (groth16.cpp).
+// helper threads start with its first proof (groth16_prover.cpp).
 HeldUnit acquire_prover(CircuitKind k) {
   std::string path = key_path(k, true); FileStamp st; if (!stamp_of(path, st)) throw std::runtime_error("proving key not found: " + path);
   const int D = std::max(1, gpu_device_slots());
@@ -715,11 +715,11 @@ int zkgpu_test_pool_plan(int D, int spill, const int *release_before, int n_call
  * a lane.  Returns -1 if any member is left without a lane, else the largest number of provers sharing one lane; out_lanes_per_slot[d] = lanes bound to device slot d. */
 int zkgpu_test_lane_plan(int n_slots, int kinds, int per_kind, int *out_lanes_per_slot) {
   return lane_plan_simulate(n_slots, kinds, per_kind, out_lanes_per_slot); }
-/* the hand-over's block classifiers, scalar against the forms the host's CPU selects (AVX2 where it has it): see groth16.cpp: test_scan_blocks */
+/* the hand-over's block classifiers, scalar against the forms the host's CPU selects (AVX2 where it has it): see groth16_prover.cpp: test_scan_blocks */
 int zkgpu_test_scan_blocks(const uint8_t *tags64, const uint64_t *elems64x4, const uint64_t *one4, uint64_t *out10) {
   return guarded_host([&] { test_scan_blocks(tags64, elems64x4, one4, out10); return ZKGPU_OK; });
 }
-/* the hand-over's scan pool (groth16.cpp: ScanPool) driven from `callers` threads at once, host only: rounds that ran on the pool (>= 0), -1 if a chunk was counted twice or not at all */
+/* the hand-over's scan pool (groth16_prover.cpp: ScanPool) driven from `callers` threads at once, host only: rounds that ran on the pool (>= 0), -1 if a chunk was counted twice or not at all */
 int zkgpu_test_cgroup_quota(const char *root) { int out = -1; guarded_host([&] { out = test_cgroup_quota(root); return ZKGPU_OK; }); return out; }
 int zkgpu_test_scan_pool(int callers, int rounds) { int out = -1; guarded_host([&] { out = test_scan_pool(callers, rounds); return ZKGPU_OK; }); return out; }
 /* host-only self-test of the container code (tests/test_key_container_cpu.py): a synthetic transformed key of the given shape is written, mapped back and compared; then the

@@ -394,7 +394,7 @@ def _equal_columns_py(cs):
     return sorted(sorted(g) for g in by.values() if len(g) > 1)
 
 def test_variables_with_equal_columns_are_found(tmp_path):
-    """groth16.cpp: equal_column_groups — what the prover folds into one place per group at the head of every proof (k_merge_equal_columns).  Against a plain Python
+    """groth16_prover.cpp: equal_column_groups — what the prover folds into one place per group at the head of every proof (k_merge_equal_columns).  Against a plain Python
     grouping of the explicit columns: the four circuits (mint, redeem and deposit each hold such variables, send none) and a random system into which a pair, a triple and
     a near-miss (same rows, one coefficient different; same columns but a public input) were planted"""
     from blockmaze_amd import engine as e

@@ -45,7 +45,7 @@ def test_lane_planner_never_starves_a_device():
     worst = L.zkgpu_test_lane_plan(1, 8, 7, per); assert worst == 2 and per[0] == 31                                  # one device never binds more than 31 lanes
 
 def test_scan_pool_counts_every_chunk_once_under_concurrent_callers():
-    """groth16.cpp: ScanPool — one caller at a time gets the pool (one broadcast wakes the helpers, the caller scans along, closes the round and waits only for helpers that are
+    """groth16_prover.cpp: ScanPool — one caller at a time gets the pool (one broadcast wakes the helpers, the caller scans along, closes the round and waits only for helpers that are
     inside), the others run their job alone; whoever runs it, every chunk of every round is taken exactly once.  ZK_SCAN_THREADS=4: three helpers even on a small host."""
     import subprocess, sys
     code = ("import ctypes, sys; sys.path.insert(0, %r); from blockmaze_amd import engine as e; L = e.lib(); "

@@ -577,7 +577,7 @@ def test_equal_columns_are_folded_and_never_send_an_msm_to_the_general_path(tmp_
 
 def test_hand_over_takes_the_dense_path_on_its_own_for_a_random_assignment(tmp_path):
     """Prover::set_witness: an assignment with more than a quarter of its entries neither 0 nor 1 overruns the compact form's value area — noticed by the chunk whose
-    reservation ends past it (groth16.cpp: the scan's shared cursor) — and goes up as a plain copy instead.  No BlockMaze circuit does that (ZK_WITNESS_DENSE forces the
+    reservation ends past it (groth16_prover.cpp: the scan's shared cursor) — and goes up as a plain copy instead.  No BlockMaze circuit does that (ZK_WITNESS_DENSE forces the
     same branch for them); a random R1CS of 40,000 variables does, on the threaded scan (625 words).  Proof bytes = the oracle's; a second system takes the
     plain-copy path again with a ragged last word (33,001 entries), each proved twice by one prover object: the same."""
     from r1cs_util import random_r1cs

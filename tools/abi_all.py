@@ -1,5 +1,6 @@
+"""The four gen*proof symbols from one caller (p50 / mean / p10 / p90 of 100 calls each) and the count of MSMs repeated on the general path.  python tools/abi_all.py  (ZK_TRACE_TIMES=1: the per-call breakdown on stderr)"""
 import os, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from blockmaze_amd import engine as e
 import workload as w

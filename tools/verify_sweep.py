@@ -1,5 +1,6 @@
+"""Device time of the batched verifier over batch sizes (HIP-event stage time of acc + K9 or the lane kernel).  ZK_VERIFY_WAVE_MAX=n: workgroup kernel up to n proofs.  python tools/verify_sweep.py"""
 import os, sys, json, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from blockmaze_amd import engine as e
 from oracle import pyoracle as o
 d = os.path.join(ROOT, "tests", "golden", "groth16_small"); meta = json.load(open(os.path.join(d, "meta.json"))); z = o.load_witness(os.path.join(d, "wit.bin")); vk = os.path.join(d, "vk.txt")
