@@ -278,9 +278,8 @@ template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
     printf("Trying to generate %s proof...\n", circuit_name(k)); fflush(stdout);
     Fe32 r, s; bool fixed = parse_fixed_rs(r, s); Proof proof;
     // the board's own form (one byte per 0 / 1, Montgomery values for the rest): no conversion, no scan
-    { const circuit::Board &bd = slot.circuit->board; static const bool by_scan = getenv("ZK_HANDOVER_SCAN") != nullptr;   // (measurement: the scanning hand-over of rounds 4-5)
-      if (by_scan) slot.prover->set_witness_tagged(bd.tag.data(), reinterpret_cast<const Fe32 *>(bd.wide.data()));
-      else slot.prover->set_witness_board(bd.tag.data(), reinterpret_cast<const Fe32 *>(bd.wide.data()), bd.ever_wide.data(), bd.wide_marks, slot.tag_dev, slot.wide_dev); }
+    { const circuit::Board &bd = slot.circuit->board;
+      slot.prover->set_witness_board(bd.tag.data(), reinterpret_cast<const Fe32 *>(bd.wide.data()), bd.ever_wide.data(), bd.wide_marks, slot.tag_dev, slot.wide_dev); }
     double t3 = now();
     if (!slot.prover->prove_resident(fixed ? &r : nullptr, fixed ? &s : nullptr, proof)) {
       printf("can not generate %s proof\n", circuit_name(k));

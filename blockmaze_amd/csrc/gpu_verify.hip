@@ -39,11 +39,11 @@ struct BatchVerifier::Impl {
   static constexpr size_t CTX_CAP = 64; std::vector<std::unique_ptr<VerifyCtx>> ctxs; std::atomic<unsigned> next_ctx{0}; std::mutex big; size_t lds = 0;
   // Small calls that meet are ONE launch (go-ethereum's verifyXproof calls arrive one proof at a time from many goroutines; a launch takes the same 0.8 ms for 1 or
   // 64 proofs): a caller either joins the batch that is waiting for a launch slot or opens one and leads it; a leader launches as soon as fewer than
-  // ZK_VERIFY_IN_FLIGHT (16, on as many streams) launches of this key are under way — alone if nobody came —, so a lone caller never waits for company.
+  // ZK_VERIFY_STREAMS (16) launches of this key are under way — alone if nobody came —, so a lone caller never waits for company.
   // Independent launches overlap on the device (a proof occupies one CU), so sharing only sets in when callers outnumber the slots: measured from C threads through
-  // verifySendproof (tools/verify_threads.sh): 1 / 8 / 16 threads 1,180 / 8,690 / 14,500 verifications/s (2 slots: 1,180 / 5,390 / 10,400).
+  // verifySendproof (tools/verify_threads.sh): 1 / 8 / 16 threads 1,180 / 8,700 / 14,700 verifications/s (2 streams: 1,180 / 5,390 / 10,400).
   struct Pending { const void *proofs; const Fe32 *inputs; size_t n; uint8_t *ok; bool done = false; std::exception_ptr err; };
-  static int max_in_flight() { static const int v = [] { const char *e = getenv("ZK_VERIFY_IN_FLIGHT"); int k = e ? atoi(e) : 16; return k < 1 ? 1 : k > 32 ? 32 : k; }(); return v; }
+  int max_in_flight() const { return (int)ctxs.size(); }      // as many launches under way as there are streams (ZK_VERIFY_STREAMS, default 16)
   std::mutex cm; std::condition_variable ccv; std::vector<Pending *> open; size_t open_n = 0; bool open_led = false; int in_flight = 0;
   std::atomic<uint64_t> launches{0}, calls{0};
   // layout of a context's staging area (host and device alike): proofs | inputs | -acc | verdicts
@@ -178,8 +178,7 @@ BatchVerifier::BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2Affine
     d.lds = ((size_t)sc.n_slots + sc.consts.size()) * l29::STRIDE * 4 + (size_t)vsched::PREFETCH_ROUNDS * 256 * 16;   // values, constants, the ring of instruction words
     if (d.lds > 160 * 1024) throw GpuError("verify: the schedule needs more LDS than a CU has");
     static std::once_flag attr;
-    std::call_once(attr, [&] { HIP_CHECK(hipFuncSetAttribute((const void *)k_verify_sched29<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_CHECK(hipFuncSetAttribute((const void *)k_verify_sched29<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+    std::call_once(attr, [&] { HIP_CHECK(hipFuncSetAttribute((const void *)k_verify_sched29, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
   }
   { static const int n_ctx = [] { const char *e = getenv("ZK_VERIFY_STREAMS"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : v > 32 ? 32 : v; }();
     for (int k = 0; k < n_ctx; k++) {
@@ -228,13 +227,10 @@ BatchVerifier::BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2Affine
   d.tables = DevArr<Affine<Fq>>(tab.size()); d.tables.upload((const Affine<Fq> *)tab.data(), tab.size());
 }
 BatchVerifier::~BatchVerifier() = default;
-// ZK_VERIFY_FETCH (measurement): 0 = the round's words by a plain load, default 2 = the ring in LDS (pairing.cuh)
 static void launch_sched(BatchVerifier::Impl &d, unsigned n, hipStream_t s, const VerifyItem *items, const NegAcc3 *acc, uint8_t *ok, uint32_t *trace = nullptr,
     uint32_t trace_every = 1) {
-  static const int fetch = [] { const char *e = getenv("ZK_VERIFY_FETCH"); return e ? atoi(e) : 2; }();
-  const uint4 *prog = (const uint4 *)d.sched_prog.get(), *consts = (const uint4 *)d.sched_consts.get();
-  if (fetch == 0) hipLaunchKernelGGL(k_verify_sched29<0>, dim3(n), dim3(256), d.lds, s, prog, consts, items, acc, (uint32_t)n, d.si, ok, trace, trace_every);
-  else hipLaunchKernelGGL(k_verify_sched29<2>, dim3(n), dim3(256), d.lds, s, prog, consts, items, acc, (uint32_t)n, d.si, ok, trace, trace_every);
+  hipLaunchKernelGGL(k_verify_sched29, dim3(n), dim3(256), d.lds, s, (const uint4 *)d.sched_prog.get(), (const uint4 *)d.sched_consts.get(), items, acc, (uint32_t)n, d.si, ok,
+      trace, trace_every);
 }
 size_t BatchVerifier::num_inputs() const { return impl->n_inputs; }
 size_t BatchVerifier::program_length() const { return impl->prog_len; }
@@ -272,7 +268,7 @@ void BatchVerifier::verify(const void *proofs_mont, const Fe32 *inputs_canonical
       d.ccv.wait(lk);                                                            // (the waiting batch is full: until it has left)
     }
     d.open.assign(1, &me); d.open_n = n; d.open_led = true;
-    d.ccv.wait(lk, [&] { return d.in_flight < Impl::max_in_flight(); });
+    d.ccv.wait(lk, [&] { return d.in_flight < d.max_in_flight(); });
     std::vector<Impl::Pending *> batch; batch.swap(d.open); const size_t total = d.open_n; d.open_n = 0; d.open_led = false; d.in_flight++;
     lk.unlock(); d.ccv.notify_all();
     std::exception_ptr err;

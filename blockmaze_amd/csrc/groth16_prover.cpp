@@ -820,6 +820,7 @@ void Prover::set_witness_tagged(const uint8_t *tag, const Fe32 *wide) {
   last.upload_ms = now_ms() - t0;
 }
 void Prover::set_witness_board(const uint8_t *tag, const Fe32 *wide, const uint8_t *ever_wide, uint32_t marks, const uint8_t *tag_dev, const Fe32 *wide_dev) {
+  { static const bool force_dense = getenv("ZK_WITNESS_DENSE") != nullptr; if (force_dense) { set_witness_tagged(tag, wide); return; } }   // (test switch: the plain-copy branch)
   Impl &p = *impl; LaneScope lane_scope(p.lane); BusyCall busy; const double t0 = now_ms(); const size_t n = p.nv + 1;
   if (!p.cand_valid || p.cand_marks != marks) {                 // (first hand-overs of a circuit object only: afterwards the set is complete)
     p.cand.clear(); for (size_t i = 1; i < n; i++) if (ever_wide[i]) p.cand.push_back((uint32_t)i);

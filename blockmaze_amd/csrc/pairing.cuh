@@ -244,10 +244,9 @@ __device__ __forceinline__ void vs_round(uint32_t *lds, uint32_t n_slots, const 
 __device__ __forceinline__ void vs_fetch_to_lds(const uint4 *src, uint32_t lds_wave_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base)) : "memory");
 }
-// FETCH: how a round's instruction words reach the lane — 0: a plain load at the head of the round (the round waits for it: measurement only; 1.10 ms per launch
-// against 0.95), 2: a ring of vsched::PREFETCH_ROUNDS rounds in LDS filled by LDS-direct loads (the shipped form).  (A ring of registers was measured too: as fast, but
-// the compiler copies the ring at the loop's back edge behind a full wait, and 16 KB of LDS are there to be had.)
-template <int FETCH>
+// A round's instruction words reach the lane through a ring of vsched::PREFETCH_ROUNDS rounds in LDS filled by LDS-direct loads.  (Measured against it, n = 1:
+// a plain load at the head of every round — the round waits for it — 1.10 ms per launch against 0.95; a ring of registers as fast, but the compiler copies the ring at
+// the loop's back edge behind a full wait, and 16 KB of LDS are there to be had.  profiles/r06_verify_batch.txt)
 static __global__ void __launch_bounds__(256) k_verify_sched29(const uint4 *__restrict__ prog, const uint4 *__restrict__ consts,
     const VerifyItem *__restrict__ items, const NegAcc3 *__restrict__ neg_acc, uint32_t n, SchedInfo si, uint8_t *__restrict__ ok, uint32_t *__restrict__ trace,
     uint32_t trace_every) {
@@ -274,10 +273,7 @@ static __global__ void __launch_bounds__(256) k_verify_sched29(const uint4 *__re
     l29::lift(w, l); vs_store(lds, lane, l); }
   __syncthreads();
   const uint32_t n_rounds = si.n_rounds_padded - DL;        // (the builder's padding: a multiple of DL rounds, then DL idle ones that are fetched but never run)
-  if constexpr (FETCH == 0) {
-#pragma unroll 1
-    for (uint32_t r = 0; r < n_rounds; r++) { const uint4 wd = prog[(size_t)r * 256 + lane]; vs_round(lds, si.n_slots, wd); vs_lds_barrier(); dump(r); }
-  } else {
+  {
     // (every load the compiler knows of has been waited for at the barrier above; from here on this wave's only outstanding loads are the ring's, one per round)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll

@@ -374,7 +374,7 @@ def test_deposit_depth32_single_gpu(tmp_path):
     t0 = time.time(); rc, out = ref("prove", pk_path, wp, "6", "5", "7"); assert rc == 0 and ("proof " + proof) in out, out[-600:]
     record_leg("libsnark prover on the depth-32 deposit key: same bytes", time.time() - t0)
 
-@pytest.mark.parametrize("env", [{"ZK_WITNESS_DENSE": "1"}, {"ZK_DEVICES": "all", "ZK_PROVERS_PER_KEY": "2"}, {"ZK_PROVERS_PER_KEY": "1", "ZK_WITNESS_THREADS": "0", "ZK_SUBMIT_THREADS": "0"}], ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+@pytest.mark.parametrize("env", [{"ZK_WITNESS_DENSE": "1"}, {"ZK_HANDOVER_MAPPED": "0"}, {"ZK_VERIFY_WHILE_PROVING": "0", "ZK_VERIFY_STREAMS": "2"}, {"ZK_DEVICES": "all", "ZK_PROVERS_PER_KEY": "2"}, {"ZK_PROVERS_PER_KEY": "1", "ZK_WITNESS_THREADS": "0", "ZK_SUBMIT_THREADS": "0"}], ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
 def test_cgo_symbols_under_process_wide_switches(all_keys, env):
     """switches that only the cgo layer reads (a fresh process each: they are read once).  ZK_DEVICES=all: the prover pool spread over every visible GPU (one here);
     one prover per key with no helper threads at all; and the dense hand-over: the cgo path hands the circuit board's tagged assignment to the prover in compact form; an assignment with too many values other than 0 / 1 would go as a plain

@@ -51,7 +51,7 @@ def test_witness_map_of_the_send_circuit_matches_oracle(tmp_path):
     t0 = time.time(); exp = o.witness_map(cs, z); record_leg("oracle witness map of the send circuit", time.time() - t0)
     assert got.shape == exp.shape == (262145, 4) and np.array_equal(got, exp)
 
-SWITCHES = [{"ZK_FOLD_C": "0"}, {"ZK_H_LAGRANGE": "0"}, {"ZK_MSM_PRECOMPUTE": "0"}, {"ZK_MSM_H_TABLES": "0"}, {"ZK_NTT_RADIX_LOG": "1"}, {"ZK_NTT_RADIX_LOG": "3"}, {"ZK_NTT_LOGC": "1"},
+SWITCHES = [{"ZK_MERGE_EQUAL_COLUMNS": "0"}, {"ZK_FOLD_C": "0"}, {"ZK_H_LAGRANGE": "0"}, {"ZK_MSM_PRECOMPUTE": "0"}, {"ZK_MSM_H_TABLES": "0"}, {"ZK_NTT_RADIX_LOG": "1"}, {"ZK_NTT_RADIX_LOG": "3"}, {"ZK_NTT_LOGC": "1"},
             {"ZK_NTT_LOGC": "2", "ZK_NTT_RADIX_LOG": "3"}, {"ZK_SUBMIT_THREADS": "0"}, {"ZK_MSM_ONE_STREAM": "1"}, {"ZK_WITNESS_THREADS": "0"}, {"ZK_WITNESS_DENSE": "1"}, {"ZK_MSM_H_RUN": "16"}, {"ZK_SCAN_THREADS": "1"}, {"ZK_MSM_PRECOMPUTE_MAX_MB": "300"}, {"ZK_PRIO": "off"}, {"ZK_PRIO": "hacc:3,wit:0,ntt:1"}, {"ZK_MSM_TABLES_FREE_SHARE": "0.000001"}, {"ZK_MSM_DIRECT_CAP": "1"}]   # (the last one: the test hook that forces every one-pass sort into its overflow fallback, i.e. the general MSM path)
 PROVE_CODE = """
 import json, os, sys
