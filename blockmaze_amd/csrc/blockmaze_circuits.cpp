@@ -108,7 +108,7 @@ struct ShaTwoBlock {   // CMTA / CMTS / PRF: intermediate digest allocated first
   void witness() { h1->witness(); h2->witness(); }
   // (round 6) the outputs first — the intermediate digest, then the result, natively — so that both compressions, and whoever reads the result, can run side by side
   void outputs_first() { h1->witness_output_only(); h2->witness_output_only(); }
-  void add_tasks(std::vector<std::function<void()>> &t) { Sha256Compression *a = h1.get(), *c = h2.get(); t.push_back([a] { a->witness(); }); t.push_back([c] { c->witness(); }); }
+  void add_tasks(std::vector<std::function<void()>> &t) { Sha256Compression *a = h1.get(), *c = h2.get(); t.push_back([a] { a->witness(true); }); t.push_back([c] { c->witness(true); }); }
 };
 struct ShaOneBlock {   // CRH
   std::unique_ptr<Sha256Compression> h1;
@@ -213,11 +213,10 @@ struct SendCircuit : Circuit {
     // give the same board:
     // (round 6) ONE wave of nine compressions: the outputs that a later compression reads — r_s, sn, and every two-block hasher's intermediate digest — are
     // written first (natively: a microsecond each, in the reference's order), then every compression fills in its own 25,000 variables beside the others and
-    // writes the same outputs again.
-    crh->h1->witness_output_only(); prf->h1->witness_output_only(); prf->h2->witness_output_only();
-    cmt_old->h1->witness_output_only(); cmt_s->h1->witness_output_only(); cmt_new->h1->witness_output_only();
-    run_parallel({[&] { cmt_s->h1->witness(); }, [&] { cmt_s->h2->witness(); }, [&] { cmt_new->h1->witness(); }, [&] { cmt_new->h2->witness(); }, [&] { prf->h1->witness(); },
-        [&] { prf->h2->witness(); }, [&] { cmt_old->h1->witness(); }, [&] { cmt_old->h2->witness(); }, [&] { crh->h1->witness(); }});
+    // leaves the outputs alone (Sha256Compression::witness(true)).
+    crh->h1->witness_output_only(); prf->outputs_first(); cmt_old->outputs_first(); cmt_s->outputs_first(); cmt_new->outputs_first();
+    { std::vector<std::function<void()>> t; cmt_s->add_tasks(t); cmt_new->add_tasks(t); prf->add_tasks(t); cmt_old->add_tasks(t); Sha256Compression *c0 = crh->h1.get(); t.push_back([c0] { c0->witness(true); });
+      run_parallel(std::move(t)); }
     t2 = now();
     cmtA_old->fill(blob_bits(in.cmtA_old.b, 32)); cmtS->fill(blob_bits(in.cmtS.b, 32)); cmtA->fill(blob_bits(in.cmtA.b, 32));
     unpacker->witness_from_bits(); t3 = now(); if (tr) fprintf(stderr, "trace-witness: fills %.3f hashers %.3f rest %.3f ms\n", t1 - t0, t2 - t1, t3 - t2); }
@@ -357,7 +356,7 @@ struct MerkleRead {
       const VarArray &in = input_of(i);
       Digest &dst = is_right ? right[i] : left[i];
       for (size_t k = 0; k < 256; k++) b.set_bit(dst.bits[k], b.bit(in[k]));
-      if (tasks) { hashers[i]->witness_output_only(); Sha256Compression *h = hashers[i].get(); tasks->push_back([h] { h->witness(); }); } else hashers[i]->witness(); }
+      if (tasks) { hashers[i]->witness_output_only(); Sha256Compression *h = hashers[i].get(); tasks->push_back([h] { h->witness(true); }); } else hashers[i]->witness(); }
     if (!tasks) finish();
   }
   void finish() {

@@ -83,9 +83,10 @@ struct LastBits {     // X has X_bits bits; result = the low |result_bits| of th
   void constraints() { Packing(b, to_lcs(full_bits), X).constraints(true); Packing(b, to_lcs(result_bits), result).constraints(false); }
   void witness() { fill_bits_of_value(b, full_bits, b.get(X)); b.set(result, pack_bits_value(b, to_lcs(result_bits))); }
   // native form: X is known as an integer (< 2^36)
-  uint32_t witness_native(uint64_t x) {
+  // (write_low = false: the result's bits are on the board already — Sha256Compression::witness_output_only — and other threads may be reading them: not touched again)
+  uint32_t witness_native(uint64_t x, bool write_low = true) {
     b.set_small(X, x);
-    low_run.write(b, result_bits, x);
+    if (write_low) low_run.write(b, result_bits, x);
     high_run.write(b, high_bits, x >> result_bits.size());
     const uint64_t r = result_bits.size() >= 64 ? x : x & ((1ull << result_bits.size()) - 1);
     b.set_small(result, r);
@@ -289,7 +290,7 @@ void Sha256Compression::constraints() { Impl &s = *impl; s.ms->constraints(); fo
                                    s.b.constraint(ONE_LC, LC(s.rounds[3 - i]->packed_h) + LC(s.rounds[63 - i]->packed_new_e), LC(s.unreduced_output[4 + i])); }
   for (auto &r : s.reduce) r.constraints(); }
 // native SHA-256 arithmetic; every variable gets exactly the value the gadget-by-gadget evaluation (witness_reference) assigns
-void Sha256Compression::witness() {
+void Sha256Compression::witness(bool outputs_written) {
   Impl &s = *impl; Board &b = s.b; uint32_t W[64], st[8];
   for (int i = 0; i < 16; i++) { uint32_t w = 0; for (int k = 0; k < 32; k++) w |= (uint32_t)b.bit(s.block[32 * i + 31 - k]) << k; W[i] = w; }
   for (int i = 0; i < 8; i++) { uint32_t w = 0; for (int k = 0; k < 32; k++) w |= (uint32_t)b.eval_bit(s.prev[32 * i + 31 - k]) << k; st[i] = w; }
@@ -312,14 +313,16 @@ void Sha256Compression::witness() {
     a = na;
   }
   for (int i = 0; i < 4; i++) {
-    s.reduce[i].witness_native((uint64_t)hist_d[3 - i] + hist_na[63 - i]);
-    s.reduce[4 + i].witness_native((uint64_t)hist_h[3 - i] + hist_ne[63 - i]);
+    s.reduce[i].witness_native((uint64_t)hist_d[3 - i] + hist_na[63 - i], !outputs_written);
+    s.reduce[4 + i].witness_native((uint64_t)hist_h[3 - i] + hist_ne[63 - i], !outputs_written);
   }
   for (int i = 0; i < 8; i++) b.set(s.unreduced_output[i], b.get(s.reduce[i].X));
 }
 // Only the 256 output bits, from the block and the previous state as they stand on the board (FIPS 180-4 6.2.2 on plain words: a microsecond): what a LATER
-// compression reads.  With the outputs of a chain written first, all its compressions can fill in their ~25,000 internal variables side by side
-// (witness() writes the same outputs again).
+// compression reads.  With the outputs of a chain written first, all its compressions can fill in their ~25,000 internal variables side by side; witness(true)
+// then leaves the output bits alone.  (It must: the first version wrote them a second time — the same values — while other threads were reading them, and 1 proof in
+// 1,000 came out with ONE bit of a later compression's input state read differently: the board of the failing proof against a sequential witness of the same
+// statement, tools/soak_send.py.  No variable is written while another thread may read it.)
 void Sha256Compression::witness_output_only() {
   Impl &s = *impl; Board &b = s.b; uint32_t W[64], st[8], v[8];
   for (int i = 0; i < 16; i++) { uint32_t w = 0; for (int k = 0; k < 32; k++) w |= (uint32_t)b.bit(s.block[32 * i + 31 - k]) << k; W[i] = w; }

@@ -138,7 +138,7 @@ struct Sha256Compression {
   struct Impl; std::shared_ptr<Impl> impl;
   // prev_output: 256 LCs (MSB-first words), block: 512 variables, output: 256 variables
   Sha256Compression(Board &b, const LCArray &prev_output, const VarArray &block, const VarArray &output);
-  void constraints(); void witness();
+  void constraints(); void witness(bool outputs_written = false);   // outputs_written: witness_output_only() has run — the output bits are not written a second time
   void witness_output_only();  // the 256 output bits alone, natively from the inputs on the board (what a later compression of a chain reads)
   void witness_reference();   // gadget-by-gadget evaluation exactly as libsnark does it; kept as the cross-check of the native path
 };

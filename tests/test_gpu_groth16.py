@@ -575,6 +575,45 @@ def test_equal_columns_are_folded_and_never_send_an_msm_to_the_general_path(tmp_
     z3 = z.copy(); z3[a - 1] = o.to_arr([tot])[0]; z3[b - 1] = o.to_arr([0])[0]; assert p.prove(z3, r, s) == want          # (what the fold leaves, handed over as such)
     assert e.general_path_repeats() == before; p.close()
 
+def test_no_proof_is_lost_when_witnesses_are_generated_on_several_threads(all_keys):
+    """Witness generation fills a statement's SHA-256 compressions in side by side on a helper pool (one wave since round 6).  Its first version wrote a compression's output
+    bits a second time while later compressions were reading them, and one proof in a thousand came back as the failure sentinel.  A soak through the cgo symbols, one caller and
+    two at once, all four circuits interleaved: every proof is generated (a fresh process: the pool's size is read once) and a sample of each kind verifies."""
+    code = """
+import os, sys, threading
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+from blockmaze_amd import engine as e
+import workload as w
+zk = e.Zk(); ss = [w.send_instance(500 + i) for i in range(8)]; ms = [w.mint_instance(500 + i) for i in range(4)]; rs = [w.mint_instance(500 + i, redeem=True) for i in range(4)]; ds = [w.deposit_instance(i) for i in range(2)]
+lost = []; keep = {}
+def run(k, n):
+    for i in range(n):
+        j = i + 3 * k; s = ss[j %% 8]; p = zk.GenSendProof(*w.send_args(s)); keep[('send', k)] = (p, s)
+        if len(p) != 512 or p.startswith('0000000000'): lost.append(('send', k, i))
+        if i %% 4 == 0:
+            m = ms[j %% 4]; p = zk.GenMintProof(*w.mint_args(m)); keep[('mint', k)] = (p, m)
+            if p.startswith('0000000000'): lost.append(('mint', k, i))
+            r = rs[j %% 4]; p = zk.GenRedeemProof(*w.mint_args(r)); keep[('redeem', k)] = (p, r)
+            if p.startswith('0000000000'): lost.append(('redeem', k, i))
+        if i %% 8 == 0:
+            d = ds[j %% 2]; p = zk.GenDepositProof(*w.deposit_args(d), d['leaves'], d['rt'], d['sk']); keep[('deposit', k)] = (p, d)
+            if p.startswith('0000000000'): lost.append(('deposit', k, i))
+run(0, 1200)
+ths = [threading.Thread(target=run, args=(k, 900)) for k in (1, 2)]
+for t in ths: t.start()
+for t in ths: t.join()
+ok = True
+for (kind, k), (p, d) in keep.items():
+    if kind == 'send': ok &= zk.VerifySendProof(p, d['cmtA_old'], d['sn_old'], d['cmtS'], d['cmtA'])
+    elif kind == 'deposit': ok &= zk.VerifyDepositProof(p, d['rt'], d['pk_recv'], d['cmtB_old'], d['sn_old'], d['cmtB'], d['sn_s'])
+    elif kind == 'mint': ok &= zk.VerifyMintProof(p, d['cmtA_old'], d['sn_old'], d['cmtA'], d['value_s'])
+    else: ok &= zk.VerifyRedeemProof(p, d['cmtA_old'], d['sn_old'], d['cmtA'], d['value_s'])
+print('SOAK lost', len(lost), lost[:5], 'verified', ok, 'general-path repeats', e.general_path_repeats())
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, ZK_PRFKEY_DIR=str(all_keys)), timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("SOAK ")]; assert line, (r.stdout[-500:], r.stderr[-1500:])
+    assert line[0].startswith("SOAK lost 0 [] verified True general-path repeats 0"), line[0]
+
 def test_hand_over_takes_the_dense_path_on_its_own_for_a_random_assignment(tmp_path):
     """Prover::set_witness: an assignment with more than a quarter of its entries neither 0 nor 1 overruns the compact form's value area — noticed by the chunk whose
     reservation ends past it (groth16_prover.cpp: the scan's shared cursor) — and goes up as a plain copy instead.  No BlockMaze circuit does that (ZK_WITNESS_DENSE forces the

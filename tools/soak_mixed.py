@@ -31,5 +31,7 @@ def check(kind, d, p):
     return zk.VerifyDepositProof(p, d["rt"], d["pk_recv"], d["cmtB_old"], d["sn_old"], d["cmtB"], d["sn_s"])
 t1 = time.time(); bad = [i for i, (kind, d, p) in enumerate(allp) if not check(kind, d, p)]; tv = time.time() - t1
 print("%d proofs (mint, deposit, redeem, send interleaved) from %d threads in %.2f s = %.1f proofs/s through the cgo symbols, key loads included; rejected by the verify symbols: %d; distinct proofs %d; %d verifications in %.2f s" % (len(allp), K, dt, len(allp) / dt, len(bad), len(set(p for _, _, p in allp)), len(allp) + len(allp) // 4, tv))
+for i in bad[:8]:
+    kind, d, p = allp[i]; print("  rejected: #%d %s proof %s... (%s)" % (i, kind, p[:16], "the failure sentinel: no proof was generated" if p.startswith("0000000000") or len(p) != 512 else "a proof the verifier refuses"))
 print("MSMs repeated on the general path (a fast path raised its flag): %d" % e.general_path_repeats())
 sys.exit(1 if bad else 0)
