@@ -797,7 +797,7 @@ void expand_witness_dev(const uint8_t *packed, size_t words, const Fe32 &one_val
 // counters[parity ^ 1] is cleared for the next call
 void classify_witness_dev(const Fe32 *z, size_t n, uint8_t *tags, uint32_t *other_vars, uint32_t *counters, int parity) {
   Fr one; memcpy(&one, FrParams::R1, 32);
-  hipLaunchKernelGGL(k_classify_witness, dim3(cdiv(n, 256)), dim3(256), 0, gpu().stream, (const Fr *)z, one, zk_with_prio(n, ZKP_EXPAND), tags, other_vars,
+  hipLaunchKernelGGL(k_classify_witness, dim3(cdiv(n, 256 * CLASSIFY_PER_LANE)), dim3(256), 0, gpu().stream, (const Fr *)z, one, zk_with_prio(n, ZKP_EXPAND), tags, other_vars,
       counters + (parity & 1), counters + ((parity & 1) ^ 1));
 }
 // a circuit board's assignment from its tag bytes and its candidates' values, both already on the device (k_expand_board); counters as in classify_witness_dev

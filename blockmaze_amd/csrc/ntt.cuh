@@ -307,31 +307,33 @@ __global__ void k_expand_witness(const uint64_t *__restrict__ ones_bm, const uin
 // multi_exp_with_mixed_addition makes per call (multiexp.tcc:443-496) —, writes the tag byte and appends the variable to the list of other values (the waves'
 // counts meet in LDS, ONE atomic per workgroup on *count; the list's order is therefore by workgroup arrival, as the host scan's chunks leave it).  The two
 // counters alternate between calls: this one clears the next call's.  A 7.3 MB streaming pass for send.
+constexpr uint32_t CLASSIFY_PER_LANE = 8;       // variables a lane classifies (strided by the workgroup's width): 2,048 a workgroup, ONE atomic on the list's counter each
 __global__ void __launch_bounds__(256) k_classify_witness(const Fr *__restrict__ z, Fr one_value, uint32_t n, uint8_t *__restrict__ tags,
     uint32_t *__restrict__ other_vars, uint32_t *__restrict__ count, uint32_t *__restrict__ count_next) {
   zk_take_prio(n);
+  // (887 workgroups of one variable a lane spent 9 of their 13.5 us queueing for the one counter: same-address atomics are served one after the other)
   __shared__ uint32_t wave_n[4], wg_at;
   if (blockIdx.x == 0 && threadIdx.x == 0) *count_next = 0;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  bool other = false;
-  if (i < n) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(z + i); const uint4 lo = p[0], hi = p[1];
-    const uint32_t any = lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w;
-    const uint32_t d1 = (lo.x ^ one_value.l[0]) | (lo.y ^ one_value.l[1]) | (lo.z ^ one_value.l[2]) | (lo.w ^ one_value.l[3]) | (hi.x ^ one_value.l[4]) |
-        (hi.y ^ one_value.l[5]) | (hi.z ^ one_value.l[6]) | (hi.w ^ one_value.l[7]);
-    other = any != 0 && d1 != 0;
-    tags[i] = any == 0 ? ZTAG_ZERO : d1 == 0 ? ZTAG_ONE : ZTAG_OTHER;
-  }
-  const uint64_t m = __ballot(other);
-  if (lane == 0) wave_n[wave] = (uint32_t)__popcll(m);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, base = blockIdx.x * (256u * CLASSIFY_PER_LANE) + threadIdx.x;
+  uint4 lo[CLASSIFY_PER_LANE], hi[CLASSIFY_PER_LANE];
+#pragma unroll
+  for (uint32_t k = 0; k < CLASSIFY_PER_LANE; k++) { const uint32_t i = base + k * 256u; if (i < n) { const uint4 *p = reinterpret_cast<const uint4 *>(z + i); lo[k] = p[0]; hi[k] = p[1]; } }
+  uint32_t mine = 0, before[CLASSIFY_PER_LANE], wave_total = 0;          // mine: bit k = this lane's k-th variable is an "other" one; before[k]: such variables of the wave ahead of it
+#pragma unroll
+  for (uint32_t k = 0; k < CLASSIFY_PER_LANE; k++) { const uint32_t i = base + k * 256u; bool other = false;
+    if (i < n) {
+      const uint32_t any = lo[k].x | lo[k].y | lo[k].z | lo[k].w | hi[k].x | hi[k].y | hi[k].z | hi[k].w;
+      const uint32_t d1 = (lo[k].x ^ one_value.l[0]) | (lo[k].y ^ one_value.l[1]) | (lo[k].z ^ one_value.l[2]) | (lo[k].w ^ one_value.l[3]) | (hi[k].x ^ one_value.l[4]) |
+          (hi[k].y ^ one_value.l[5]) | (hi[k].z ^ one_value.l[6]) | (hi[k].w ^ one_value.l[7]);
+      other = any != 0 && d1 != 0; tags[i] = any == 0 ? ZTAG_ZERO : d1 == 0 ? ZTAG_ONE : ZTAG_OTHER; }
+    const uint64_t m = __ballot(other); before[k] = wave_total + (uint32_t)__popcll(m & ((1ull << lane) - 1)); wave_total += (uint32_t)__popcll(m); mine |= (uint32_t)other << k; }
+  if (lane == 0) wave_n[wave] = wave_total;
   __syncthreads();
   if (threadIdx.x == 0) { const uint32_t tot = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3]; wg_at = tot ? atomicAdd(count, tot) : 0u; }
   __syncthreads();
-  if (other) {
-    uint32_t at = wg_at;
-    for (uint32_t wv = 0; wv < wave; wv++) at += wave_n[wv];
-    other_vars[at + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = i;
-  }
+  if (mine) { uint32_t at = wg_at; for (uint32_t wv = 0; wv < wave; wv++) at += wave_n[wv];
+#pragma unroll
+    for (uint32_t k = 0; k < CLASSIFY_PER_LANE; k++) if ((mine >> k) & 1) other_vars[at + before[k]] = base + k * 256u; }
 }
 // The hand-over of a circuit board (Prover::set_witness_board, the cgo path): the board's tag bytes as they are (0, 1, 2 = a Montgomery value in the board's wide
 // array, 6 = a small integer kept canonical) and the values of the board's candidates — the variables that ever held something else than 0 / 1, a fixed list per
