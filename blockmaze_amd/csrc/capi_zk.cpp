@@ -282,6 +282,7 @@ template <class AssignFn> char *generate(CircuitKind k, AssignFn assign) {
       slot.prover->set_witness_board(bd.tag.data(), reinterpret_cast<const Fe32 *>(bd.wide.data()), bd.ever_wide.data(), bd.wide_marks, slot.tag_dev, slot.wide_dev); }
     double t3 = now();
     if (!slot.prover->prove_resident(fixed ? &r : nullptr, fixed ? &s : nullptr, proof)) {
+      fprintf(stderr, "libzkgpu: %s: the statement's assignment violates the constraint system (constraint %ld among others): no proof\n", circuit_name(k), slot.prover->last_failed_row);
       printf("can not generate %s proof\n", circuit_name(k));
       fflush(stdout);
       proof = default_proof();
@@ -827,7 +828,7 @@ int zkgpu_key_container_valid(const char *pk_path) {
 zkgpu_prover *zkgpu_prover_load(const char *pk_path) { return zkgpu_prover_load_shard(pk_path, 0, 1); }
 int zkgpu_prover_prove_partial(zkgpu_prover *h, uint8_t out[384]) {
   return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; if (!h->p->prove_partial(out)) {
-      zkgpu_set_error("assignment does not satisfy the constraint system"); return ZKGPU_ERR_UNSATISFIED; } return ZKGPU_OK; });
+      zkgpu_set_error("assignment does not satisfy the constraint system (constraint " + std::to_string(h->p->last_failed_row) + " among those violated)"); return ZKGPU_ERR_UNSATISFIED; } return ZKGPU_OK; });
 }
 int zkgpu_prover_finish(zkgpu_prover *h, const uint8_t *records, size_t n, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_host([&] {
     if (!h) return ZKGPU_ERR_ARG; Proof p; h->p->finish_from_partials(records, n, (const Fe32 *)r, (const Fe32 *)s, p);
@@ -879,14 +880,14 @@ int zkgpu_prover_info(zkgpu_prover *h, size_t out[3]) {
 }
 int zkgpu_prover_prove(zkgpu_prover *h, const uint8_t *z, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_prover(h, [&] {
     if (!h) return ZKGPU_ERR_ARG; Proof p;
-  if (!h->p->prove((const Fe32 *)z, (const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system");
+  if (!h->p->prove((const Fe32 *)z, (const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system (constraint " + std::to_string(h->p->last_failed_row) + " among those violated)");
       return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
 int zkgpu_prover_set_witness(zkgpu_prover *h, const uint8_t *z) {
   return guarded_prover(h, [&] { if (!h) return ZKGPU_ERR_ARG; h->p->set_witness((const Fe32 *)z, false); gpu_sync(); return ZKGPU_OK; });
 }
 int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_prover(h, [&] {
     if (!h) return ZKGPU_ERR_ARG; Proof p;
-  if (!h->p->prove_resident((const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system");
+  if (!h->p->prove_resident((const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system (constraint " + std::to_string(h->p->last_failed_row) + " among those violated)");
       return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
 int zkgpu_prover_stash_witness(zkgpu_prover *h, uint32_t *slot) {
   return guarded_prover(h, [&] { if (!h || !slot) return ZKGPU_ERR_ARG; *slot = (uint32_t)h->p->stash_witness(); return ZKGPU_OK; });
@@ -904,7 +905,7 @@ int zkgpu_prover_stash_count(zkgpu_prover *h, uint32_t *count) {
 }
 int zkgpu_prover_prove_stashed(zkgpu_prover *h, uint32_t slot, const uint8_t *r, const uint8_t *s, char proof_hex[513]) { return guarded_prover(h, [&] {
     if (!h) return ZKGPU_ERR_ARG; Proof p;
-  if (!h->p->prove_stashed(slot, (const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system");
+  if (!h->p->prove_stashed(slot, (const Fe32 *)r, (const Fe32 *)s, p)) { zkgpu_set_error("assignment does not satisfy the constraint system (constraint " + std::to_string(h->p->last_failed_row) + " among those violated)");
       return ZKGPU_ERR_UNSATISFIED; } std::string hx = proof_to_hex(p); memcpy(proof_hex, hx.c_str(), 513); return ZKGPU_OK; }); }
 int zkgpu_prover_timings(zkgpu_prover *h, double out[5]) {
   if (!h) return ZKGPU_ERR_ARG;

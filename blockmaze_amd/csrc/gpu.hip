@@ -849,8 +849,8 @@ struct R1csDev::Impl {
   void own_words() {
     flag = DevBuf<uint32_t>(1);
     HIP_CHECK(hipHostMalloc((void **)&h_flag, 4));
-    HIP_CHECK(hipHostMalloc((void **)&h_fail, 4, hipHostMallocMapped));
-    *h_fail = 0;
+    HIP_CHECK(hipHostMalloc((void **)&h_fail, 8, hipHostMallocMapped));   // [evaluation number of the last violation, a row that violated]
+    h_fail[0] = 0; h_fail[1] = 0;
     HIP_CHECK(hipHostGetDevicePointer((void **)&d_fail, h_fail, 0));
   }
   ~Impl() { if (h_flag) hipHostFree(h_flag); if (h_fail) hipHostFree(h_fail); }
@@ -912,7 +912,8 @@ void R1csDev::eval(const Fe32 *z, Fe32 *abc, size_t m, const uint8_t *tags, bool
   if (d.n_long_any) hipLaunchKernelGGL(k_r1cs_long_rows3, dim3((unsigned)d.n_long_any), dim3(64), 0, s, d.long_any.get(), M, (const Fr *)d.ctab.get(),
       (const Fr *)z, (uint32_t)m, (Fr *)abc, d.seq, d.d_fail);
 }
-bool R1csDev::check_result() const { return *impl->h_fail != impl->seq; }   // valid once the main stream has been synchronised after eval()
+bool R1csDev::check_result() const { return *impl->h_fail != impl->seq; }
+uint32_t R1csDev::failed_row() const { return impl->h_fail[1]; }   // a constraint the last evaluation found violated (meaningful while check_result() is false)   // valid once the main stream has been synchronised after eval()
 bool R1csDev::satisfied(const Fe32 *abc, size_t m) {
   Impl &d = *impl; hipStream_t s = gpu().stream; d.flag.zero();
   if (d.n_cons) hipLaunchKernelGGL(k_r1cs_check, dim3(cdiv(d.n_cons, 256)), dim3(256), 0, s, (const Fr *)abc, (const Fr *)(abc + m), (const Fr *)(abc + 2 * m),

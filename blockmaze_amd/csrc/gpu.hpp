@@ -172,6 +172,7 @@ class R1csDev {
   bool satisfied(const Fe32 *abc, size_t m);    // synchronises
   // eval() also tests a*b == c row by row; true if the last eval() found every constraint satisfied (read after the main stream has been synchronised)
   bool check_result() const;
+  uint32_t failed_row() const;   // a constraint the last eval() found violated (while check_result() is false)
   struct Impl; std::unique_ptr<Impl> impl;
 };
 

@@ -98,6 +98,7 @@ class Prover {                                    // a proving key resident in H
   // sum `n` shard records and assemble the proof (r1cs_gg_ppzksnark.tcc:487-495); needs only the key's alpha/beta/delta, no device work
   void finish_from_partials(const uint8_t *records, size_t n, const Fe32 *r, const Fe32 *s, Proof &out);
   struct Timings { double upload_ms, qap_ms, msm_ms, finish_ms, total_ms; } last{};
+  long last_failed_row = -1;   // a constraint the last proof found violated (prove* returned false)
   struct Impl; std::unique_ptr<Impl> impl;
 };
 

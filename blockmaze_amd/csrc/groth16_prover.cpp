@@ -1037,7 +1037,7 @@ bool Prover::prove_resident(const Fe32 *r_in, const Fe32 *s_in, Proof &out) {
     fprintf(stderr, "trace: enqueue %.3f A %.3f L %.3f B1 %.3f B2 %.3f sync %.3f upload %.3f t1_boot %.4f\n", t2 - t1, ta - t1, tl - t1, tb1 - t1, tb2 - t1,
         t3 - t1, last.upload_ms, boot_ms - (now_ms() - t1));
   }
-  if (!p.cs->check_result()) return false;
+  if (!p.cs->check_result()) { last_failed_row = (long)p.cs->failed_row(); return false; }
   out.C = raw_of(p.H->result().add(c_part)); double t4 = now_ms();                                                                                    // :495
   last.qap_ms = t2 - t1; last.msm_ms = t3 - t1; last.finish_ms = t4 - t3; last.total_ms = last.upload_ms + (t4 - t1); return true;
 }
@@ -1057,7 +1057,7 @@ static HG1 get_canon_g1(const uint8_t *o) {
   return HG1::from_affine(x.to_mont(), y.to_mont());
 }
 bool Prover::prove_partial(uint8_t out[PARTIAL_BYTES]) {
-  Impl &p = *impl; LaneScope lane_scope(p.lane); run_device(p); for (int j = 0; j < 4; j++) p.settle(j); gpu_sync(); if (!p.cs->check_result()) return false;
+  Impl &p = *impl; LaneScope lane_scope(p.lane); run_device(p); for (int j = 0; j < 4; j++) p.settle(j); gpu_sync(); if (!p.cs->check_result()) { last_failed_row = (long)p.cs->failed_row(); return false; }
   put_canon_g1(p.rA, out); put_canon_g1(p.rB1, out + 64); put_canon_g1(p.H->result(), out + 128); put_canon_g1(p.rL, out + 192);
   HFq2 x, y;
   p.rB2.to_affine(x, y);

@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) k_r1cs_rows3(R1csMatrices M, const Fr *__
       M.rowptr[2][r] > R1CS_LONG_ROW) return;
   Fr a = r1cs_row_dot(M, 0, r, ctab, z), b = r1cs_row_dot(M, 1, r, ctab, z), c = r1cs_row_dot(M, 2, r, ctab, z);
   abc[r] = a; abc[m + r] = b; abc[2 * (size_t)m + r] = c;
-  if (a * b != c) *fail = seq;
+  if (a * b != c) { fail[1] = r; *fail = seq; }
 }
 __global__ void __launch_bounds__(64) k_r1cs_long_rows3(const uint32_t *__restrict__ rows, R1csMatrices M, const Fr *__restrict__ ctab,
     const Fr *__restrict__ z, uint32_t m, Fr *__restrict__ abc, uint32_t seq, uint32_t *fail) {
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(64) k_r1cs_long_rows3(const uint32_t *__restri
       acc = acc + o;
     }
     v[mm] = acc; }
-  if (lane == 0) { abc[r] = v[0]; abc[m + r] = v[1]; abc[2 * (size_t)m + r] = v[2]; if (v[0] * v[1] != v[2]) *fail = seq; }
+  if (lane == 0) { abc[r] = v[0]; abc[m + r] = v[1]; abc[2 * (size_t)m + r] = v[2]; if (v[0] * v[1] != v[2]) { fail[1] = r; *fail = seq; } }
 }
 // Assignment upload in compact form: 97 % of a BlockMaze witness are the bits 0 and 1, so the host sends two bitmaps (value is `one` / value is something
 // else), the running count of "something else" per 64 entries and only those values (0.3 MB instead of 7.3 MB over PCIe); this kernel rebuilds the vector. tags
@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(256) k_r1cs_rows_all(R1csMatrices M, const Fr 
         M.rowptr[2][r] > R1CS_LONG_ROW) return;
     Fr a = r1cs_row_dot(M, 0, r, ctab, z), b = r1cs_row_dot(M, 1, r, ctab, z), c = r1cs_row_dot(M, 2, r, ctab, z);
     abc[r] = a; abc[m + r] = b; abc[2 * (size_t)m + r] = c;
-    if (a * b != c) *fail = seq;
+    if (a * b != c) { fail[1] = r; *fail = seq; }
     return; }
   const uint32_t w = (blockIdx.x - short_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63; if (w >= n_long) return;
   const uint32_t r = long_rows[w]; Fr v[3];
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256) k_r1cs_rows_all(R1csMatrices M, const Fr 
       acc = acc + o;
     }
     v[mm] = acc; }
-  if (lane == 0) { abc[r] = v[0]; abc[m + r] = v[1]; abc[2 * (size_t)m + r] = v[2]; if (v[0] * v[1] != v[2]) *fail = seq; }
+  if (lane == 0) { abc[r] = v[0]; abc[m + r] = v[1]; abc[2 * (size_t)m + r] = v[2]; if (v[0] * v[1] != v[2]) { fail[1] = r; *fail = seq; } }
 }
 // ---- the same evaluation for an assignment that arrived in compact form (k_expand_witness wrote a tag per variable)
 // --------------------------------------------------- 97 % of a BlockMaze assignment are the bits 0 and 1. A term whose variable is 0 contributes nothing and
@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(256) k_r1cs_rows_tagged(R1csMatrices M, const 
     abc[r] = v[0];
     abc[m + r] = v[1];
     if (write_c) abc[2 * (size_t)m + r] = v[2];
-    if (v[0] * v[1] != v[2]) *fail = seq;
+    if (v[0] * v[1] != v[2]) { fail[1] = r; *fail = seq; }
     return;
   }
   const uint32_t w = (blockIdx.x - short_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // a row of more than R1CS_LONG_ROW terms: one wave
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(256) k_r1cs_rows_tagged(R1csMatrices M, const 
     abc[r] = v[0];
     abc[m + r] = v[1];
     if (write_c) abc[2 * (size_t)m + r] = v[2];
-    if (v[0] * v[1] != v[2]) *fail = seq;
+    if (v[0] * v[1] != v[2]) { fail[1] = r; *fail = seq; }
   }
 }
 // satisfiability: flag[0] |= (a[i]*b[i] != c[i]) over the constraint rows (protoboard::is_satisfied, sendcgo.cpp:209)
