@@ -189,6 +189,7 @@ def run_rank(args):
         if grp is not None: grp.barrier()
         if torch.cuda.is_available(): torch.cuda.synchronize()
 
+    remade = []                                                               # statements whose stash had to be made a second time (stash_failed below): none, normally
     if shard:
         def one_proof(i):                                                      # every rank runs the device pipeline on its slice; 384 B per rank are exchanged; rank 0 assembles
             prover.set_witness(zs[i % n_inst]); recs = grp.gather_partials(prover.prove_partial())
@@ -208,10 +209,23 @@ def run_rank(args):
         # device kernel inside the timed call, then the whole pipeline runs on the stash in place.  The host-buffer-inclusive rate is `value_from_host_buffers`.
         slots = []
         for z in zs: prover.set_witness(z); slots.append(ctypes.c_uint32(prover.stash_witness()))
+        import numpy as np
+        def stash_failed(i):
+            # (seen once, on one box, in three runs out of three, never again: a stashed statement whose host copy proves.  The step then says what it can about the
+            # slot — which constraint, how the resident vector differs from the one handed over, whether the host buffer proves — makes the stash again ONCE beside the
+            # old one and goes on; the line carries the count in config.stash_remade.  A statement that fails from its host buffer too ends the run.)
+            k = i % n_inst; msg = _lib.zkgpu_last_error().decode(); back = prover.read_stash(slots[k].value); diff = np.nonzero((back != zs[k]).any(axis=1))[0]
+            log("bench: prove_stashed(slot %d) failed: %s; the resident vector differs from the one handed over in %d variables%s" % (slots[k].value, msg, len(diff), (" (first: %s)" % diff[:8].tolist()) if len(diff) else ""))
+            if len(remade) >= 3: raise RuntimeError("zkgpu_prover_prove_stashed failed again after %d stashes were made anew: %s" % (len(remade), msg))
+            if _lib.zkgpu_prover_prove(_h, _zp[k], None, None, _out) != 0: raise RuntimeError("statement %d is not provable from its host buffer either: %s" % (k, _lib.zkgpu_last_error().decode()))
+            prover.set_witness(zs[k]); slots[k] = ctypes.c_uint32(prover.stash_witness()); remade.append(k)
+            if _lib.zkgpu_prover_prove_stashed(_h, slots[k], None, None, _out) != 0: raise RuntimeError("zkgpu_prover_prove_stashed failed on a stash made anew: %s" % _lib.zkgpu_last_error().decode())
+            return _out
+        if fail_at.startswith("stash:"):                                      # tests only: statement <k>'s stash holds one wrong value — the step that meets it must say so, make it anew and go on
+            k = int(fail_at.split(":")[1]) % n_inst; wrong = zs[k].copy(); wrong[5000 % len(wrong)] = (3, 0, 0, 0); prover.set_witness(wrong); prover.drop_stash(slots[k].value); slots[k] = ctypes.c_uint32(prover.stash_witness())
         def one_proof(i):
             rc = _lib.zkgpu_prover_prove_stashed(_h, slots[i % n_inst], None, None, _out)
-            if rc != 0: raise RuntimeError("zkgpu_prover_prove_stashed failed: %s" % _lib.zkgpu_last_error().decode())
-            return _out
+            return _out if rc == 0 else stash_failed(i)
     # (the interpreter's cycle collector stays out of the timed region: with torch and numpy loaded a full pass is ~10 ms — thirteen proofs — and its timing is a matter of
     # allocation counts; nothing in the loop makes cycles.  Collected once here, switched back on after the clock stops.)
     import gc; gc.collect(); gc.disable()
@@ -404,8 +418,8 @@ def run_rank(args):
             "metric": "Groth16 proofs/sec (send circuit, alt_bn128)", "value": round(rate, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "step_ms": step_ms, "value_p50": (round(1e3 / step_ms["p50"] * (1 if shard else world), 4) if step_ms.get("p50") else None), "value_from_host_buffers": (round(hb_rate, 4) if hb_rate else None), "host_buffers_step_ms": hb_step_ms, "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "u32 limbs (254-bit Fq/Fr Montgomery; all MSM accumulations, the H query's weighted bucket sum and the transforms' tiles on nine 29-bit limbs)", "data": "synthetic witnesses (seeded send instances, every constraint satisfied) on a proving key made by this repo's GPU generator for the real send circuit; only the libsnark CPU leg uses a key with synthetic points of the same shape",
             "config": {"workload": "send circuit single proof per step (252,286 constraints, domain 2^18; BASELINE.json configs[1])", "proofs_per_step": 1 if shard else world, "distinct_witnesses": n_inst,
-                       "host_binding": host_binding, "clock_warmup": "%d untimed proofs ahead of the %d warm-up steps (the GPU's clocks need ~30 ms of load to rise after the idle set-up)" % (clock_warmup, args.warmup), "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
-                       "includes": "one prover call per step on the next of the run's distinct statements, all of them RESIDENT IN HBM when the timed region starts (handed over before the clock starts, kept in device memory; a step copies its assignment device-to-device and proves it): R1CS rows, the 7 NTTs of the witness map (4 run per proof; both transforms of C and the final inverse are folded into the L and H queries at key load), 5 MSM, host proof assembly, hex serialisation; excludes witness generation and key load.  `value_p50` = 1 / the median step (the mean carries the host's rare 2-5 ms steps); `value_from_host_buffers` = the same prover call handed a fresh host buffer every step (scan + PCIe + expansion included; N = 1 only) — what rounds 1-4 reported as `value`" if not shard else "one proof per step cut into shards; host-buffer hand-over included"},
+                       "host_binding": host_binding, "stash_remade": len(remade), "clock_warmup": "%d untimed proofs ahead of the %d warm-up steps (the GPU's clocks need ~30 ms of load to rise after the idle set-up)" % (clock_warmup, args.warmup), "parallelism": ("one proof per step, every query cut into %d contiguous shards, one all-gather of 384 B per rank" % world) if shard else "independent proofs per GPU, no collective",
+                       "includes": "one prover call per step on the next of the run's distinct statements, all of them RESIDENT IN HBM when the timed region starts (handed over before the clock starts, kept in device memory as the raw vector; a step classifies its assignment on the device and proves it in place): the classification of the values (0 / 1 / other), R1CS rows, the 7 NTTs of the witness map (4 run per proof; both transforms of C and the final inverse are folded into the L and H queries at key load), 5 MSM, host proof assembly, hex serialisation; excludes witness generation and key load.  `value_p50` = 1 / the median step (the mean carries the host's rare 2-5 ms steps); `value_from_host_buffers` = the same prover call handed a fresh host buffer every step (scan + PCIe + expansion included; N = 1 only) — what rounds 1-4 reported as `value`" if not shard else "one proof per step cut into shards; host-buffer hand-over included"},
             "ranks": rank_info, "roofline": roofline, "roofline_valu": roofline_valu, "cpu_baseline": cpu, "cpu_baseline_variants": cpu_more or None, "extra_legs": extra or None,
             "stage_ms_per_proof": {k: round(v, 4) for k, v in sorted(per_proof.items())}, "prover_timings_ms": prover.timings(), "setup_s": {"keygen": round(t_keygen, 2), "key_load": round(t_load, 2), "hbm": hbm or None}}
         real_stdout.write(json.dumps(line) + "\n"); real_stdout.flush()

@@ -899,6 +899,9 @@ int zkgpu_prover_drop_stash(zkgpu_prover *h, uint32_t slot) {
 uint64_t zkgpu_general_path_repeats(void) { return general_path_repeats(); }
 uint64_t zkgpu_queries_without_tables(void) { return queries_without_tables(); }
 int zkgpu_prover_equal_column_groups(zkgpu_prover *h, uint32_t *count) { if (!h || !count) return ZKGPU_ERR_ARG; *count = (uint32_t)h->p->equal_column_groups(); return ZKGPU_OK; }
+int zkgpu_prover_read_stash(zkgpu_prover *h, uint32_t slot, uint8_t *z_out) {
+  return guarded_prover(h, [&] { if (!h || !z_out) return ZKGPU_ERR_ARG; h->p->read_stash(slot, (Fe32 *)z_out); return ZKGPU_OK; });
+}
 int zkgpu_prover_stash_count(zkgpu_prover *h, uint32_t *count) {
   if (!h || !count) return ZKGPU_ERR_ARG;
   *count = (uint32_t)h->p->stash_count(); return ZKGPU_OK;

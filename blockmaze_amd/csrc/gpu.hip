@@ -220,6 +220,7 @@ std::string profile_report() { g_timer.collect(); std::string o = "{"; bool firs
   return o + "}";
 }
 
+static bool alloc_poison() { static const bool on = [] { const char *e = getenv("ZK_DEBUG_POISON_ALLOC"); return e && *e && *e != '0'; }(); return on; }
 template <class T> DevBuf<T>::DevBuf(size_t n) : n_(n) {
   gpu();
   if (n) {
@@ -229,6 +230,9 @@ template <class T> DevBuf<T>::DevBuf(size_t n) : n_(n) {
       if (e == hipErrorOutOfMemory) throw GpuOutOfMemory("hipMalloc of " + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e));
       throw GpuError("hipMalloc of " + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e));
     }
+    // (diagnostic: ZK_DEBUG_POISON_ALLOC=1 fills every new allocation with 0xA5 bytes — whether fresh device memory reads as zeros depends on the host's driver, so
+    // a kernel that reads a word nobody wrote can pass on one box and fail on the next; with the pattern it fails everywhere.  tests/test_gpu_groth16.py runs with it)
+    if (alloc_poison()) { if (hipMemset(p_, 0xA5, n * sizeof(T)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) throw GpuError("hipMemset (ZK_DEBUG_POISON_ALLOC)"); }
   }
 }
 template <class T> DevBuf<T>::~DevBuf() { if (p_) hipFree(p_); }
@@ -258,7 +262,7 @@ template class DevBuf<Fe32>;
 template class DevBuf<G1AffineRaw>;
 template class DevBuf<G2AffineRaw>;
 
-template <class T> PinnedBuf<T>::PinnedBuf(size_t n) : n_(n) { gpu(); if (n) HIP_CHECK(hipHostMalloc((void **)&p_, n * sizeof(T))); }
+template <class T> PinnedBuf<T>::PinnedBuf(size_t n) : n_(n) { gpu(); if (n) { HIP_CHECK(hipHostMalloc((void **)&p_, n * sizeof(T))); if (alloc_poison()) memset(p_, 0xA5, n * sizeof(T)); } }
 template <class T> PinnedBuf<T>::~PinnedBuf() { release(); }
 template <class T> void PinnedBuf<T>::release() { if (p_) hipHostFree(p_); p_ = nullptr; n_ = 0; }
 template class PinnedBuf<Fe32>;

@@ -90,6 +90,7 @@ class Prover {                                    // a proving key resident in H
   size_t stash_witness();
   void drop_stash(size_t slot);
   size_t stash_count() const;
+  void read_stash(size_t slot, Fe32 *out);   // the kept assignment, canonical, n_vars x 32 bytes (tests, diagnostics)
   size_t equal_column_groups() const;   // groups of variables with identical columns found in the key (their values are folded at the head of every proof)
   bool prove_stashed(size_t slot, const Fe32 *r, const Fe32 *s, Proof &out);
   // partial multi-exponentiation results of this shard, affine canonical: eA(64) eB1(64) eH(64) eL(64) eB2(128) = 384 bytes.  false if z is unsatisfying.

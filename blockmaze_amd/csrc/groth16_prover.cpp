@@ -987,6 +987,13 @@ void Prover::drop_stash(size_t slot) {
   p.stashes[slot].reset();
   while (!p.stashes.empty() && !p.stashes.back()) p.stashes.pop_back();
 }
+// a kept assignment back on the host, canonical (what set_witness was given — or its equivalent with equal columns folded once a proof has read it in place)
+void Prover::read_stash(size_t slot, Fe32 *out) {
+  Impl &p = *impl; LaneScope lane_scope(p.lane); const size_t n = p.nv + 1;
+  if (slot >= p.stashes.size() || !p.stashes[slot]) throw std::runtime_error("read_stash: no such slot");
+  gpu_sync(); DevBuf<Fe32> t(n); copy_dev_async(t.get(), p.stashes[slot]->z.get(), 32 * n); fr_from_mont_dev(t.get(), n); gpu_sync();
+  std::vector<Fe32> h(n); t.download(h.data(), n); memcpy(out, h.data() + 1, 32 * p.nv);
+}
 size_t Prover::equal_column_groups() const { return impl->n_merge_groups; }
 size_t Prover::stash_count() const { size_t k = 0; for (const auto &s : impl->stashes) k += s ? 1 : 0; return k; }
 bool Prover::prove_stashed(size_t slot, const Fe32 *r_in, const Fe32 *s_in, Proof &out) {

@@ -146,6 +146,9 @@ class Prover:
         _check(lib().zkgpu_prover_drop_stash(ctypes.c_void_p(self.h), ctypes.c_uint32(0xffffffff if slot is None else slot)))
     def equal_column_groups(self):
         k = ctypes.c_uint32(0); _check(lib().zkgpu_prover_equal_column_groups(ctypes.c_void_p(self.h), ctypes.byref(k))); return int(k.value)
+    def read_stash(self, slot):
+        """the kept assignment of a slot back on the host: (n_vars, 4) uint64 canonical"""
+        z = np.zeros((self.n_vars, 4), dtype=np.uint64); _check(lib().zkgpu_prover_read_stash(ctypes.c_void_p(self.h), ctypes.c_uint32(slot), z.ctypes.data_as(ctypes.c_void_p))); return z
     def stash_count(self):
         k = ctypes.c_uint32(0); _check(lib().zkgpu_prover_stash_count(ctypes.c_void_p(self.h), ctypes.byref(k))); return int(k.value)
     def prove_stashed(self, slot, r=None, s=None):

@@ -126,6 +126,9 @@ int zkgpu_prover_prove_resident(zkgpu_prover *h, const uint8_t *r, const uint8_t
 int zkgpu_prover_stash_witness(zkgpu_prover *h, uint32_t *slot);
 int zkgpu_prover_drop_stash(zkgpu_prover *h, uint32_t slot);
 int zkgpu_prover_stash_count(zkgpu_prover *h, uint32_t *count);
+/* a kept assignment copied back to the host in the layout zkgpu_prover_set_witness takes (n_vars x 32 bytes, canonical): tests and diagnostics — after a proof has read
+ * the slot in place, variables with equal columns hold their folded (equivalent) values */
+int zkgpu_prover_read_stash(zkgpu_prover *h, uint32_t slot, uint8_t *z_out);
 /* groups of variables whose columns coincide in A, B and C found in this key (their values are folded into one place at the head of every proof: an equivalent assignment,
  * no equal points meeting in an incomplete addition); and, process-wide, how often a fast MSM path raised its flag and the MSM was repeated on the general path */
 int zkgpu_prover_equal_column_groups(zkgpu_prover *h, uint32_t *count);

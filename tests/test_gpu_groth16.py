@@ -525,11 +525,13 @@ def test_stashed_assignments_of_the_send_circuit_classified_on_the_device(tmp_pa
         d = w.send_instance(40 + i); wp = str(tmp_path / ("w%d.bin" % i)); e.witness_send(*hx(w.send_args(d)), wp); zs.append(o.load_witness(wp))
     want = [p.prove(z, 1000 + i, 2000 + i) for i, z in enumerate(zs)]; slots = []
     for z in zs: p.set_witness(z); slots.append(p.stash_witness())
+    for i, z in enumerate(zs): assert np.array_equal(p.read_stash(slots[i]), np.asarray(z, dtype=np.uint64).reshape(-1, 4))      # what is resident is the raw vector
     for rep in range(2):
         for i in (2, 0, 1): assert p.prove_stashed(slots[i], 1000 + i, 2000 + i) == want[i]
     assert p.prove(zs[1], 1001, 2001) == want[1] and p.prove_stashed(slots[0], 1000, 2000) == want[0]         # host buffers and stashes interleaved
+    for i, z in enumerate(zs): assert np.array_equal(p.read_stash(slots[i]), np.asarray(z, dtype=np.uint64).reshape(-1, 4))      # ... and proofs leave it as it was (send folds nothing)
     bad = zs[0].copy(); bad[300000 % len(bad)] = o.to_arr([3])[0]; p.set_witness(bad); sb = p.stash_witness()
-    with pytest.raises(e.ZkGpuError): p.prove_stashed(sb, 1, 2)
+    with pytest.raises(e.ZkGpuError, match="constraint [0-9]+ among"): p.prove_stashed(sb, 1, 2)                # the error names a violated constraint
     assert p.prove_stashed(slots[2], 1002, 2002) == want[2]; p.close()
 
 def test_key_container_gives_the_same_prover(tmp_path):

@@ -43,3 +43,14 @@ def test_a_failing_rank_takes_the_group_down(where):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == "" and time.time() - t0 < 240, (r.returncode, r.stdout[-300:], r.stderr[-1500:])
     assert "failed at '%s'" % where.split(":")[0] in r.stderr and "a rank failed at" in r.stderr, r.stderr[-1500:]
+
+def test_a_stash_that_does_not_prove_is_reported_and_made_anew():
+    """bench.py's timed region proves statements kept in HBM.  A resident vector that no longer is the statement handed over (here: one value replaced on purpose) makes the
+    step fail with the violated constraint; the run says how the resident vector differs from the host's, proves the statement from its host buffer, makes the stash
+    once more and carries the count in its line — it does not die without a line, and it does not hide the event"""
+    env = dict(os.environ, ZK_BENCH_TEST_FAIL="stash:3"); env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extra-legs"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.strip()][0]); assert j["config"]["stash_remade"] == 1 and j["value"] > 0
+    assert "differs from the one handed over in 1 variables (first: [5000])" in r.stderr and "constraint " in r.stderr, r.stderr[-2000:]
+    j = run(["--steps", "4", "--warmup", "1", "--no-extra-legs"]); assert j["config"]["stash_remade"] == 0
