@@ -145,15 +145,14 @@ __global__ void __launch_bounds__(256) k_msm_scatter(const Fr *__restrict__ scal
 //                  with ONE device-scope atomic per group (65 K per MSM instead of 4.2 M), then writes each entry next to its workgroup-mates of the same
 //                  group:
 //                  runs of ~128 bytes per group and workgroup instead of isolated words.  Entry = low bucket bits | sign | table index.
-//   k_hsort_group one workgroup per group: the group's entries (16 K for send) are counted per bucket in LDS, the counts are scanned, and every entry moves to
-//                  its
-//                  final place inside the group's region of the output (a 64 KB window that lives in this XCD's L2 while it is written). Emits counts[] /
-//                  offsets[]
-//                  and the number of entries of the group.  The entries keep their low bucket bits: k_hacc_runs29 finds the bucket boundaries by them.
+//   k_hsort_group one workgroup per group: the group's entries (16 K for send) are counted per bucket in LDS, the counts are scanned, every entry moves to its
+//                  final place inside a copy of the group's region IN LDS (dynamic, 4 x region bytes: 86 KB for send — one workgroup a CU anyway), and the copy
+//                  leaves in consecutive words.  (Round 6: 1,024 lanes instead of 512 and the staged copy-out instead of one scattered 4-byte store per entry:
+//                  31.6 -> 17.3 us, +0.9 % proofs/s on one box, tools/ab_lib_value.sh.)  Emits counts[] / offsets[] and the number of entries of the group.  The entries keep their low bucket bits: k_hacc_runs29 finds the bucket boundaries by them.
 // Uniform scalars fill every group to within a few per cent of n*W/G, so a region holds 1.25x that; a region that would overflow raises a flag and the host
 // repeats the MSM on the two-pass path (any input stays correct).
 constexpr uint32_t HSORT_GROUPS = 1024 /* at most; the shape says how many are used */, HSORT_BIN_THREADS = 256, HSORT_PER_THREAD = 2,
-    HSORT_TILE = HSORT_BIN_THREADS * HSORT_PER_THREAD, HSORT_GROUP_THREADS = 512, HSORT_MAX_PER_THREAD = 48, HSORT_SLICES = 8,
+    HSORT_TILE = HSORT_BIN_THREADS * HSORT_PER_THREAD, HSORT_GROUP_THREADS = 1024, HSORT_MAX_PER_THREAD = 24, HSORT_SLICES = 8,
     HSORT_STAGE_W = 20 /* staged entries per scalar: at most 254 / c + 1 digits, c >= 13 */;
 // groups * 2^low_bits = buckets; bucket = group << low_bits | low; entry = low << (idx_bits + 1) | sign << idx_bits | index; region: entry slots per group
 struct HsortShape { uint32_t groups, low_bits, idx_bits, region; };
@@ -256,11 +255,14 @@ static __global__ void __launch_bounds__(HSORT_GROUP_THREADS) k_hsort_group(cons
   }
   __syncthreads();
   uint32_t *dst = entries + (size_t)g * sh.region;
+  extern __shared__ uint32_t hsg_stage[];                            // (dynamic: region words) the group in bucket order, then written out in consecutive words
 #pragma unroll
   for (int j = 0; j < (int)HSORT_MAX_PER_THREAD; j++) if (j < ne) {
     const uint32_t v = e[j], b = v >> (sh.idx_bits + 1), r = atomicAdd(&lcnt[b], 1u);
-    dst[lpre[b] + r] = v;
+    hsg_stage[lpre[b] + r] = v;
   }
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < n_g; p += blockDim.x) dst[p] = hsg_stage[p];
 }
 
 static __global__ void k_fr_mul3(const Fr *__restrict__ a, const Fr *__restrict__ b, const Fr *__restrict__ z, int z_is_table, uint32_t n,

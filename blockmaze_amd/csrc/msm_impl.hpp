@@ -424,7 +424,9 @@ struct MsmImpl {
 #define ZK_CALL(CC) hipLaunchKernelGGL(k_hsort_bin<CC>, dim3(cdiv(n, HSORT_TILE)), dim3(HSORT_BIN_THREADS), 0, s, (const Fr *)scalars, (const Fr *)prod_b, (const Fr *)prod_z, (int)prod_z_table, infp, (uint32_t)n, c, W, point_stride, hs_prio, group_fill.get(), mid.get(), cnt, counters_next())
         ZK_MSM_DISPATCH_C(c, ZK_CALL);
 #undef ZK_CALL
-        hipLaunchKernelGGL(k_hsort_group, dim3(hs.groups), dim3(HSORT_GROUP_THREADS), 0, s, (const uint32_t *)mid.get(), group_fill.get(), hs_prio, entries.get(),
+        static const bool lds_ok = [] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hsort_group), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess; }();
+        if (!lds_ok) throw GpuError("k_hsort_group: the device refuses 128 KB of LDS per workgroup");
+        hipLaunchKernelGGL(k_hsort_group, dim3(hs.groups), dim3(HSORT_GROUP_THREADS), 4 * hs.region, s, (const uint32_t *)mid.get(), group_fill.get(), hs_prio, entries.get(),
             hist(), offsets.get(), group_n.get());
       }
       // one lane per run: at most ceil(entries / run) + one short run per group
