@@ -82,8 +82,9 @@ int main(int argc, char **argv) {
       const std::string wit = slurp(wp); zkgpu_prover *h = zkgpu_prover_load((tmp + "/sendpk.txt").c_str()); CHECK(h != nullptr);
       if (h) { zkgpu_prover *h2 = zkgpu_prover_clone(h); CHECK(h2 != nullptr); const uint8_t *z = (const uint8_t *)wit.data() + 8;
         std::thread a([&] { char out[513]; for (int i = 0; i < 10; i++) CHECK(zkgpu_prover_prove(h, z, nullptr, nullptr, out) == ZKGPU_OK); });
-        std::thread b([&] { char out[513]; uint32_t slot = 0; CHECK(zkgpu_prover_set_witness(h2, z) == ZKGPU_OK && zkgpu_prover_stash_witness(h2, &slot) == ZKGPU_OK);
-          for (int i = 0; i < 10; i++) CHECK(zkgpu_prover_prove_stashed(h2, slot, nullptr, nullptr, out) == ZKGPU_OK); });
+        std::thread b([&] { char out[513]; uint32_t slot[12];                          // (bench.py's set-up and timed region: statements handed over and kept, then proved from HBM in turn)
+          for (int i = 0; i < 12; i++) CHECK(zkgpu_prover_set_witness(h2, z) == ZKGPU_OK && zkgpu_prover_stash_witness(h2, &slot[i]) == ZKGPU_OK);
+          for (int i = 0; i < 10; i++) CHECK(zkgpu_prover_prove_stashed(h2, slot[(5 * i) % 12], nullptr, nullptr, out) == ZKGPU_OK); });
         a.join(); b.join(); printf("gpu: 10 proofs from host buffers beside 10 from a stash on two provers of one key\n"); } }
   }
   if (fails.load()) { fprintf(stderr, "%d checks failed\n", fails.load()); return 1; }
