@@ -85,7 +85,16 @@ int main(int argc, char **argv) {
         std::thread b([&] { char out[513]; uint32_t slot[12];                          // (bench.py's set-up and timed region: statements handed over and kept, then proved from HBM in turn)
           for (int i = 0; i < 12; i++) CHECK(zkgpu_prover_set_witness(h2, z) == ZKGPU_OK && zkgpu_prover_stash_witness(h2, &slot[i]) == ZKGPU_OK);
           for (int i = 0; i < 10; i++) CHECK(zkgpu_prover_prove_stashed(h2, slot[(5 * i) % 12], nullptr, nullptr, out) == ZKGPU_OK); });
-        a.join(); b.join(); printf("gpu: 10 proofs from host buffers beside 10 from a stash on two provers of one key\n"); } }
+        a.join(); b.join(); printf("gpu: 10 proofs from host buffers beside 10 from a stash on two provers of one key\n");
+        // one call, eight statements (the pool's lanes hand them out among themselves), and the batch verifier on their proofs from two threads at once
+        { const size_t nb = 8, zbytes = wit.size() - 8; std::vector<uint8_t> zs(nb * zbytes); for (size_t i = 0; i < nb; i++) memcpy(zs.data() + i * zbytes, z, zbytes);
+          std::vector<char> proofs(513 * nb); CHECK(zkgpu_prover_prove_batch(h, zs.data(), nb, nullptr, proofs.data()) == ZKGPU_OK);
+          size_t info[3] = {0, 0, 0}; CHECK(zkgpu_prover_info(h, info) == ZKGPU_OK); const size_t ni = info[1];
+          std::string all; std::vector<uint8_t> inputs; for (size_t i = 0; i < nb; i++) { all.append(proofs.data() + 513 * i, 512); inputs.insert(inputs.end(), z, z + 32 * ni); }
+          std::atomic<int> good{0};
+          auto vb = [&] { std::vector<uint8_t> ok(nb, 0); if (zkgpu_verify_batch((tmp + "/sendvk.txt").c_str(), all.c_str(), inputs.data(), ni, nb, ok.data()) >= 0) for (uint8_t v : ok) good += v; };
+          std::thread v1(vb), v2(vb); v1.join(); v2.join(); CHECK(good.load() == 2 * (int)nb);
+          printf("gpu: a batch of %zu proofs made in one call, verified by two threads (%d accepted)\n", nb, good.load()); } } }
   }
   if (fails.load()) { fprintf(stderr, "%d checks failed\n", fails.load()); return 1; }
   printf("TSAN OK\n"); return 0;
