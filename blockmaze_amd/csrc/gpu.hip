@@ -267,7 +267,16 @@ template <class T> PinnedBuf<T>::~PinnedBuf() { release(); }
 template <class T> void PinnedBuf<T>::release() { if (p_) hipHostFree(p_); p_ = nullptr; n_ = 0; }
 template class PinnedBuf<Fe32>;
 void upload_async(void *dev, const void *host, size_t bytes) { HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, gpu().stream)); }
-void copy_dev_async(void *dst, const void *src, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, gpu().stream)); }
+// device to device by a kernel of this library: in order with the kernels around it on the compute queue — no copy engine, no choice the runtime makes per size
+// (what keeps a statement in HBM, Prover::stash_witness, is made of this and nothing else)
+static __global__ void k_copy_words16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void copy_dev_async(void *dst, const void *src, size_t bytes) {
+  if (!bytes) return;
+  if (bytes % 16 || (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16) { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, gpu().stream)); return; }
+  const size_t n16 = bytes / 16; hipLaunchKernelGGL(k_copy_words16, dim3((unsigned)std::min<size_t>(cdiv(n16, 256), 4096)), dim3(256), 0, gpu().stream, (const uint4 *)src, (uint4 *)dst, n16);
+}
 
 
 // ======================================================================================================================
