@@ -370,12 +370,8 @@ static size_t ntt_lds_for(int logN, int logC) {
   return sizeof(Fr29) * (e + (e >> 4) + 1) + (sizeof(Fr29) << logN) / 2;
 }
 static void ntt_raise_lds() {
-  static const bool done = [] {
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_cols, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    HIP_CHECK(hipFuncSetAttribute((const void *)k_ntt_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    return true;
-  }();
-  (void)done;
+  static std::atomic<uint64_t> cols_done{0}, rows_done{0};
+  zk_raise_dynamic_lds((const void *)k_ntt_cols, 128 * 1024, cols_done); zk_raise_dynamic_lds((const void *)k_ntt_rows, 128 * 1024, rows_done);
 }
 // up to two transforms of the two-pass range (2^12 .. 2^22 points) in ONE column launch and ONE row launch (k_ntt_cols: data -> scratch, k_ntt_rows: scratch ->
 // data)

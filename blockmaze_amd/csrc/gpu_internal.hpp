@@ -2,6 +2,7 @@
 // timer.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <string>
@@ -37,6 +38,14 @@ inline uint32_t zk_prio_bits(ZkPrioFamily family) {
 // the priority rides in bits 24.. of a small integer argument: a value that does not leave them free travels without one (the kernel then runs at the hardware's default)
 inline uint32_t zk_with_prio(size_t arg, ZkPrioFamily family) { return (uint32_t)arg | (arg < ((size_t)1 << 24) ? zk_prio_bits(family) : 0u); }
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw GpuError(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+// A kernel that asks for more than 64 KB of dynamic LDS has its limit raised first — per DEVICE (the attribute belongs to the function as loaded on the current device: a
+// process that serves several GPUs, ZK_DEVICES, must raise it on each of them), once: `mask` is the caller's static word of devices already done.
+inline void zk_raise_dynamic_lds(const void *kernel, int bytes, std::atomic<uint64_t> &mask) {
+  int dev = 0; HIP_CHECK(hipGetDevice(&dev)); const uint64_t bit = 1ull << (dev & 63);
+  if (mask.load(std::memory_order_acquire) & bit) return;
+  HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  mask.fetch_or(bit, std::memory_order_release);
+}
 class GpuContext {
  public:
   int device = 0;

@@ -177,8 +177,8 @@ BatchVerifier::BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2Affine
     for (int k = 0; k < vsched::N_OUT; k++) d.si.out_slot[k] = sc.out_slot[k];
     d.lds = ((size_t)sc.n_slots + sc.consts.size()) * l29::STRIDE * 4 + (size_t)vsched::PREFETCH_ROUNDS * 256 * 16;   // values, constants, the ring of instruction words
     if (d.lds > 160 * 1024) throw GpuError("verify: the schedule needs more LDS than a CU has");
-    static std::once_flag attr;
-    std::call_once(attr, [&] { HIP_CHECK(hipFuncSetAttribute((const void *)k_verify_sched29, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+    static std::atomic<uint64_t> attr_done{0};
+    zk_raise_dynamic_lds((const void *)k_verify_sched29, 160 * 1024, attr_done);
   }
   { static const int n_ctx = [] { const char *e = getenv("ZK_VERIFY_STREAMS"); int v = e ? atoi(e) : 16; return v < 1 ? 1 : v > 32 ? 32 : v; }();
     for (int k = 0; k < n_ctx; k++) {

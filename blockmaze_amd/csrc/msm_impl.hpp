@@ -424,8 +424,7 @@ struct MsmImpl {
 #define ZK_CALL(CC) hipLaunchKernelGGL(k_hsort_bin<CC>, dim3(cdiv(n, HSORT_TILE)), dim3(HSORT_BIN_THREADS), 0, s, (const Fr *)scalars, (const Fr *)prod_b, (const Fr *)prod_z, (int)prod_z_table, infp, (uint32_t)n, c, W, point_stride, hs_prio, group_fill.get(), mid.get(), cnt, counters_next())
         ZK_MSM_DISPATCH_C(c, ZK_CALL);
 #undef ZK_CALL
-        static const bool lds_ok = [] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hsort_group), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess; }();
-        if (!lds_ok) throw GpuError("k_hsort_group: the device refuses 128 KB of LDS per workgroup");
+        static std::atomic<uint64_t> lds_done{0}; zk_raise_dynamic_lds(reinterpret_cast<const void *>(&k_hsort_group), 128 * 1024, lds_done);
         hipLaunchKernelGGL(k_hsort_group, dim3(hs.groups), dim3(HSORT_GROUP_THREADS), 4 * hs.region, s, (const uint32_t *)mid.get(), group_fill.get(), hs_prio, entries.get(),
             hist(), offsets.get(), group_n.get());
       }
