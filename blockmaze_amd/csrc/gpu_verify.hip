@@ -21,6 +21,47 @@ static const uint64_t ATE_LOOP[2] = {0x9d797039be763ba8ull, 0x1ull};          //
 template <class T> struct DevArr { DevBuf<uint8_t> b; DevArr() = default; explicit DevArr(size_t n) : b(n * sizeof(T)) {} T *get() const { return (T *)b.get();
     }
   void upload(const T *h, size_t n) { b.upload((const uint8_t *)h, n * sizeof(T)); } };
+// acc_i = IC[0] + sum_j inputs[i][j] * IC[j+1] by ONE WORKGROUP of 64 quads per proof, the points SPREAD over the quads (htail29.cuh: lane k of a quad holds coordinate k of
+// (X, Y, ZZ, ZZZ) on nine 29-bit limbs, an addition is four rounds of ONE product per lane).  The (input, window) pairs — 128 for a send statement — are dealt to the
+// quads, the quads' sums meet in the workgroup's tree (four levels by shuffles, two through LDS), quad 0 adds IC[0] and hands the sum over as (x w, -y w, w), w = ZZ ZZZ:
+// no inversion (verify_sched.hpp evaluates the gamma lines times w).  Round 6: the dependent chain is 2 + 6 + 1 additions of 4 products instead of the one-wave kernel's
+// 2 + 6 + 1 of 10 to 14 in single lanes (0.074 ms of a verification's 0.85; now 0.025: `verifySendproof` 0.86 -> 0.81 ms a call, 8,400 -> 9,200 /s from 8 threads).
+// The additions are the incomplete ones of the H tail: an operand equal to +-the other leaves ZZ = 0 (mod p), w = 0, and the schedule kernel hands the proof to the host
+// verifier (verdict 2) — with canonical inputs the partial sums are multiples of ONE point by distinct integers below r or involve different points of the key, so this
+// takes a discrete logarithm (or inputs that are not reduced: the host decides those).  tables261 / ic0_261: coordinates times 2^261, canonical 8-word form.
+static __global__ void __launch_bounds__(256) k_verify_acc_quads(const Affine<Fq> *__restrict__ tables261, Affine<Fq> ic0_261, const Fr *__restrict__ inputs,
+    uint32_t n_inputs, uint32_t n, NegAcc3 *__restrict__ acc_out) {
+  __shared__ Point29Rec lds[4];
+  const uint32_t i = blockIdx.x, q = threadIdx.x >> 2; const int k = threadIdx.x & 3; if (i >= n) return;
+  __builtin_amdgcn_s_setprio(3);
+  auto lift = [&](const Affine<Fq> &pt, bool absent) {                                     // an affine point as a spread (x, y, 1, 1); (0, 0) and a zero digit: the point at infinity
+    QPoint29 r; uint32_t o = 0;
+    const Fq &cw = k == 0 ? pt.x : pt.y;
+#pragma unroll
+    for (int t = 0; t < 8; t++) o |= cw.l[t];
+    const uint32_t ox = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o, 0x00, 0xf, 0xf, false), oy = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o, 0x55, 0xf, 0xf, false);
+    r.c = k < 2 ? Fq29::unpack(cw.l) : Fq29::one(); r.inf = absent || (ox | oy) == 0;
+    return r;
+  };
+  QPoint29 acc = quad29_inf(); bool first = true;
+#pragma unroll 1
+  for (uint32_t pair = q; pair < n_inputs * 32; pair += 64) {
+    const uint32_t j = pair >> 5, w = pair & 31; const Fr kj = inputs[(size_t)i * n_inputs + j]; const uint32_t d = (kj.l[w >> 2] >> ((w & 3) * 8)) & 0xffu;
+    Affine<Fq> pt{Fq::zero(), Fq::zero()}; if (k < 2) { const Affine<Fq> *src = tables261 + ((size_t)j * 32 * 255 + w * 255 + (d ? d - 1 : 0)); if (k == 0) pt.x = src->x; else pt.y = src->y; }
+    const QPoint29 cur = lift(pt, d == 0);
+    if (first) { acc = cur; first = false; } else acc = quad29_add(acc, cur, k);
+  }
+  acc = block_quad29_tree(acc, lds, min(n_inputs * 32, 64u));
+  if (q != 0) return;
+  acc = quad29_add(acc, lift(ic0_261, false), k);
+  // (x w, -y w, w) = (X ZZZ, -Y ZZ, ZZ ZZZ): one product per lane with the partner's coordinate [3, 2, 3, 3]
+  Fq29 m = Fq29::mul(acc.c, quad29_perm<0xFB>(acc.c));
+  if (k == 1) m = Fq29::neg_product(m);
+  Fq out = Fq::zero();
+  if (!acc.inf) { m.to_words(out.l); out = out.normalize(); }
+  if (k < 3) reinterpret_cast<Fq *>(acc_out + i)[k] = out;
+}
+
 // One small verification in flight: its own stream, pinned staging and device buffers for up to CTX_CAP proofs — go-ethereum's verifyXproof calls arrive one
 // proof at a time from many threads, and a proof occupies ONE compute unit for ~2 ms: several contexts let them overlap instead of queueing behind one stream.
 struct VerifyCtx { std::mutex m; hipStream_t s = nullptr; uint8_t *h = nullptr /* pinned, mapped */, *hd = nullptr /* the device's view of h */; DevBuf<uint8_t> d; };
@@ -33,7 +74,8 @@ struct BatchVerifier::Impl {
   DevArr<FrobeniusDev> frob;
   DevArr<Fq12> alpha_beta;
   DevArr<Affine<Fq>> tables;
-  Affine<Fq> ic0;
+  Affine<Fq> ic0, ic0_261;                                                     // (261: coordinates times 2^261, the radix of the 29-bit limbs: k_verify_acc_quads)
+  DevArr<Affine<Fq>> tables261;
   VerifyConsts K;
   size_t prog_len = 0;
   static constexpr size_t CTX_CAP = 64; std::vector<std::unique_ptr<VerifyCtx>> ctxs; std::atomic<unsigned> next_ctx{0}; std::mutex big; size_t lds = 0;
@@ -225,6 +267,11 @@ BatchVerifier::BatchVerifier(const host::HFq12 &alpha_g1_beta_g2, const G2Affine
     }
   }
   d.tables = DevArr<Affine<Fq>>(tab.size()); d.tables.upload((const Affine<Fq> *)tab.data(), tab.size());
+  { HFq c261; memcpy(c261.l, FQ_TWO261, 32);                                              // x 2^256 times the plain integer 2^261 mod q, Montgomery product: x 2^261
+    auto to261 = [&](const G1AffineRaw &a) { G1AffineRaw o; HFq x, y; memcpy(x.l, &a.x, 32); memcpy(y.l, &a.y, 32); x = x * c261; y = y * c261; memcpy(&o.x, x.l, 32); memcpy(&o.y, y.l, 32); return o; };
+    std::vector<G1AffineRaw> t261(tab.size()); for (size_t k = 0; k < tab.size(); k++) t261[k] = to261(tab[k]);
+    d.tables261 = DevArr<Affine<Fq>>(t261.size()); d.tables261.upload((const Affine<Fq> *)t261.data(), t261.size());
+    const G1AffineRaw i261 = to261(ic[0]); memcpy(&d.ic0_261, &i261, sizeof i261); }
 }
 BatchVerifier::~BatchVerifier() = default;
 static void launch_sched(BatchVerifier::Impl &d, unsigned n, hipStream_t s, const VerifyItem *items, const NegAcc3 *acc, uint8_t *ok, uint32_t *trace = nullptr,
@@ -242,7 +289,7 @@ uint8_t BatchVerifier::trace(const void *proof_mont, const Fe32 *inputs_canonica
   DevArr<VerifyItem> items(1); DevBuf<Fe32> in(d.n_inputs + 1); DevArr<NegAcc3> acc3(1); DevBuf<uint8_t> out(1);
   items.upload((const VerifyItem *)proof_mont, 1); if (d.n_inputs) in.upload(inputs_canonical, d.n_inputs);
   const size_t dumps = d.si.n_rounds_padded / every + 1, words = (size_t)d.si.n_slots * l29::STRIDE; DevBuf<uint32_t> tr(dumps * words);
-  hipLaunchKernelGGL(k_verify_acc_wave, dim3(1), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(), (uint32_t)d.n_inputs, 1u, acc3.get());
+  hipLaunchKernelGGL(k_verify_acc_quads, dim3(1), dim3(256), 0, s, (const Affine<Fq> *)d.tables261.get(), d.ic0_261, (const Fr *)in.get(), (uint32_t)d.n_inputs, 1u, acc3.get());
   launch_sched(d, 1, s, items.get(), acc3.get(), out.get(), tr.get(), every);
   HIP_CHECK(hipStreamSynchronize(s)); HIP_CHECK(hipGetLastError());
   values.resize(dumps * words); tr.download(values.data(), values.size()); uint8_t ok = 0; out.download(&ok, 1);
@@ -287,7 +334,7 @@ void BatchVerifier::verify(const void *proofs_mont, const Fe32 *inputs_canonical
         at += q->n; }
       uint8_t *dv = c->d.get(); volatile uint8_t *hok = c->h + d.off_ok(); for (size_t k = 0; k < total; k++) hok[k] = 0xff;
       { Stage st("verify.batch", c->s);
-        hipLaunchKernelGGL(k_verify_acc_wave, dim3((unsigned)total), dim3(64), 0, c->s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)(c->hd + d.off_in()),
+        hipLaunchKernelGGL(k_verify_acc_quads, dim3((unsigned)total), dim3(256), 0, c->s, (const Affine<Fq> *)d.tables261.get(), d.ic0_261, (const Fr *)(c->hd + d.off_in()),
             (uint32_t)d.n_inputs, (uint32_t)total, (NegAcc3 *)(dv + d.off_acc()));
         launch_sched(d, (unsigned)total, c->s, (const VerifyItem *)c->hd, (const NegAcc3 *)(dv + d.off_acc()), c->hd + d.off_ok());
       }
@@ -311,7 +358,7 @@ void BatchVerifier::verify(const void *proofs_mont, const Fe32 *inputs_canonical
   // 24.5 ms for 8,192 — 330 K proofs/s); beyond that the lane-per-proof kernel, whose 26 ms floor is then amortised over more (profiles/r06_verify_batch.txt)
   static const size_t wave_max = [] { const char *e = getenv("ZK_VERIFY_WAVE_MAX"); long v = e ? atol(e) : 8192; return (size_t)(v < 0 ? 0 : v); }();
   if (n <= wave_max) { DevArr<NegAcc3> acc3(n);
-    hipLaunchKernelGGL(k_verify_acc_wave, dim3((unsigned)n), dim3(64), 0, s, (const Affine<Fq> *)d.tables.get(), d.ic0, (const Fr *)in.get(),
+    hipLaunchKernelGGL(k_verify_acc_quads, dim3((unsigned)n), dim3(256), 0, s, (const Affine<Fq> *)d.tables261.get(), d.ic0_261, (const Fr *)in.get(),
         (uint32_t)d.n_inputs, (uint32_t)n, acc3.get());
     // (acc3 lives until the kernels are done)
     launch_sched(d, (unsigned)n, s, items.get(), acc3.get(), out.get());

@@ -301,25 +301,4 @@ static __global__ void __launch_bounds__(256) k_verify_sched29(const uint4 *__re
     }
     ok[i] = nacc.w.is_zero() ? 2 : good ? 1 : 0; }
 }
-// acc_i = IC[0] + sum_j inputs[i][j] * IC[j+1] by ONE WAVE per proof: the (input, window) pairs are dealt to the lanes, a shuffle tree adds the lanes' sums,
-// lane 0 hands the sum over as (X ZZZ, -Y ZZ, ZZ ZZZ) = (x w, -y w, w): no inversion (verify_sched.hpp evaluates the gamma lines times w).
-static __global__ void __launch_bounds__(64) k_verify_acc_wave(const Affine<Fq> *__restrict__ tables, Affine<Fq> ic0, const Fr *__restrict__ inputs,
-    uint32_t n_inputs, uint32_t n, NegAcc3 *__restrict__ acc_out) {
-  const uint32_t i = blockIdx.x, lane = threadIdx.x; if (i >= n) return; XYZZ<Fq> acc = XYZZ<Fq>::inf();
-  __builtin_amdgcn_s_setprio(3);
-#pragma unroll 1
-  for (uint32_t q = lane; q < n_inputs * 32; q += 64) {
-    const uint32_t j = q >> 5, w = q & 31;
-    const Fr k = inputs[(size_t)i * n_inputs + j];
-    const uint32_t d = (k.l[w >> 2] >> ((w & 3) * 8)) & 0xffu;
-    if (d) acc.madd_inl(tables[(size_t)j * 32 * 255 + w * 255 + d - 1]);
-  }
-#pragma unroll 1
-  for (int d = 32; d >= 1; d >>= 1) {
-    XYZZ<Fq> o = {shfl_down_fq(acc.X, d), shfl_down_fq(acc.Y, d), shfl_down_fq(acc.ZZ, d), shfl_down_fq(acc.ZZZ, d)};
-    if ((int)lane + d < 64) acc.add_inl(o);
-  }
-  if (lane == 0) { acc.madd_inl(ic0); acc_out[i] = {acc.X * acc.ZZZ, (acc.Y * acc.ZZ).neg(), acc.ZZ * acc.ZZZ}; }
-}
-
 }  // namespace zk
