@@ -215,7 +215,7 @@ def run_rank(args):
             # slot — which constraint, how the resident vector differs from the one handed over, whether the host buffer proves — makes the stash again ONCE beside the
             # old one and goes on; the line carries the count in config.stash_remade.  A statement that fails from its host buffer too ends the run.)
             k = i % n_inst; msg = _lib.zkgpu_last_error().decode(); back = prover.read_stash(slots[k].value); diff = np.nonzero((back != zs[k]).any(axis=1))[0]
-            log("bench: prove_stashed(slot %d) failed: %s; the resident vector differs from the one handed over in %d variables%s (pairs of variables with opposite columns, which a proof folds in place, included)" % (slots[k].value, msg, len(diff), (" (first: %s)" % diff[:8].tolist()) if len(diff) else ""))
+            log("bench: prove_stashed(slot %d) failed: %s; the resident vector differs from the one handed over in %d variables%s" % (slots[k].value, msg, len(diff), (" (first: %s)" % diff[:8].tolist()) if len(diff) else ""))
             if len(remade) >= 3: raise RuntimeError("zkgpu_prover_prove_stashed failed again after %d stashes were made anew: %s" % (len(remade), msg))
             if _lib.zkgpu_prover_prove(_h, _zp[k], None, None, _out) != 0: raise RuntimeError("statement %d is not provable from its host buffer either: %s" % (k, _lib.zkgpu_last_error().decode()))
             prover.set_witness(zs[k]); slots[k] = ctypes.c_uint32(prover.stash_witness()); remade.append(k)

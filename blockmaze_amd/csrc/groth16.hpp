@@ -130,7 +130,6 @@ Proof default_proof();                            // (G1::one, G2::one, G1::one)
 // host-only self-test of the hand-over's block classifiers (scalar against AVX2 forms)
 void test_scan_blocks(const uint8_t tags[64], const uint64_t elems[256], const uint64_t one[4], uint64_t out[10]);
 // auxiliary variables whose columns are identical in A, B and C, in groups of two or more (host only; the prover folds their values, k_merge_equal_columns)
-constexpr uint32_t EQUAL_COLUMN_NEGATED = 0x80000000u;   // bit 31 of a group member: its columns are minus the first member's
 std::vector<std::vector<uint32_t>> equal_column_groups(const R1csHost &cs);
 int test_cgroup_quota(const char *root);   // host-only: the CPU quota (CPUs, rounded up) a cgroup tree states — cpu.max (v2) or cpu/cpu.cfs_*_us (v1) under `root`; 0 = none
 int test_scan_pool(int callers, int rounds);   // host-only self-test of the hand-over's scan pool: rounds that ran on the pool, -1 on a miscount

@@ -216,40 +216,30 @@ static void shard_range(size_t n, size_t rank, size_t world, size_t &b, size_t &
   b = rank * base + (rank < rem ? rank : rem);
   e = b + base + (rank < rem ? 1 : 0);
 }
-// Auxiliary variables whose columns coincide in A, B and C (same rows, same coefficients) OR are each other's negatives in all three: groups of two or more,
-// members ascending; bit 31 of a member (EQUAL_COLUMN_NEGATED) says its columns are MINUS those of the group's first member.  Such variables have equal or opposite
-// points in every query (L_v = (beta A_v + alpha B_v + C_v) / delta is linear in the columns), so the assignment with sum_v (+-z_v) in one place and zeros in the others
-// is equivalent (k_merge_equal_columns).  One pass finds every column's first coefficient in (matrix, row) order — a column whose first coefficient lies in the upper half
-// of [0, r) is taken negated —, one hashes the columns so normalised (row, coefficient, matrix), equal hashes are then compared entry by entry.
+// Auxiliary variables whose columns are identical in A, B and C (same rows, same coefficients): groups of two or more, members ascending.  One pass over the
+// matrices hashes every column (row, coefficient, matrix in row order), equal hashes are then compared entry by entry.
 std::vector<std::vector<uint32_t>> equal_column_groups(const R1csHost &cs) {
-  const size_t nv = cs.n_vars + 1; std::vector<uint64_t> h(nv, 0); std::vector<uint32_t> cnt(nv, 0); std::vector<uint8_t> flip(nv, 0), seen(nv, 0);
-  auto negated = [](const Fe32 &c) { Fe32 o; uint64_t borrow = 0; bool zero = true;                            // r - c (c != 0), the same residue class whatever form the coefficients are in
-    for (int i = 0; i < 8; i++) { const uint64_t d = (uint64_t)FrParams::MOD[i] - c.l[i] - borrow; o.l[i] = (uint32_t)d; borrow = (d >> 32) & 1; zero = zero && c.l[i] == 0; }
-    return zero ? c : o; };
-  auto upper_half = [&](const Fe32 &c) { const Fe32 n = negated(c); for (int i = 7; i >= 0; i--) if (c.l[i] != n.l[i]) return c.l[i] > n.l[i]; return false; };
-  for (int m = 0; m < 3; m++) for (size_t r = 0; r < cs.n_cons; r++) for (uint32_t k = cs.rowptr[m][r]; k < cs.rowptr[m][r + 1]; k++) {
-    const uint32_t c = cs.col[m][k]; if (c >= nv) throw std::runtime_error("r1cs: column index"); if (!seen[c]) { seen[c] = 1; flip[c] = upper_half(cs.coeff[m][k]) ? 1 : 0; } }
-  auto norm = [&](uint32_t c, const Fe32 &v) { return flip[c] ? negated(v) : v; };
+  const size_t nv = cs.n_vars + 1; std::vector<uint64_t> h(nv, 0); std::vector<uint32_t> cnt(nv, 0);
   auto mix = [](uint64_t a, uint64_t b) { a ^= b + 0x9e3779b97f4a7c15ull + (a << 6) + (a >> 2); a *= 0xff51afd7ed558ccdull; return a ^ (a >> 33); };
   for (int m = 0; m < 3; m++) for (size_t r = 0; r < cs.n_cons; r++) for (uint32_t k = cs.rowptr[m][r]; k < cs.rowptr[m][r + 1]; k++) {
-    const uint32_t c = cs.col[m][k]; uint64_t e = mix((uint64_t)m << 40 | r, 0);
-    const Fe32 cv = norm(c, cs.coeff[m][k]); const uint32_t *w = cv.l; for (int i = 0; i < 8; i += 2) e = mix(e, (uint64_t)w[i] | (uint64_t)w[i + 1] << 32);
+    const uint32_t c = cs.col[m][k]; if (c >= nv) throw std::runtime_error("r1cs: column index"); uint64_t e = mix((uint64_t)m << 40 | r, 0);
+    const uint32_t *w = cs.coeff[m][k].l; for (int i = 0; i < 8; i += 2) e = mix(e, (uint64_t)w[i] | (uint64_t)w[i + 1] << 32);
     h[c] = mix(h[c], e); cnt[c]++; }
   std::vector<uint32_t> cand; for (size_t v = cs.n_inputs + 1; v < nv; v++) if (cnt[v]) cand.push_back((uint32_t)v);
   std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { return h[a] != h[b] ? h[a] < h[b] : a < b; });
   std::vector<uint32_t> suspects; for (size_t i = 0; i < cand.size(); i++) if ((i && h[cand[i - 1]] == h[cand[i]]) || (i + 1 < cand.size() && h[cand[i + 1]] == h[cand[i]])) suspects.push_back(cand[i]);
   if (suspects.empty()) return {};
-  // the suspects' columns, explicitly: (matrix, row, normalised coefficient) in order
+  // the suspects' columns, explicitly: (matrix, row, coefficient) in order
   std::vector<int> which(nv, -1); for (size_t i = 0; i < suspects.size(); i++) which[suspects[i]] = (int)i;
   struct Ent { uint32_t m, r; Fe32 c; }; std::vector<std::vector<Ent>> cols(suspects.size());
   for (uint32_t m = 0; m < 3; m++) for (size_t r = 0; r < cs.n_cons; r++) for (uint32_t k = cs.rowptr[m][r]; k < cs.rowptr[m][r + 1]; k++) { const int w = which[cs.col[m][k]];
-    if (w >= 0) cols[w].push_back(Ent{m, (uint32_t)r, norm(cs.col[m][k], cs.coeff[m][k])}); }
+    if (w >= 0) cols[w].push_back(Ent{m, (uint32_t)r, cs.coeff[m][k]}); }
   auto same = [&](int a, int b) { if (cols[a].size() != cols[b].size()) return false;
     for (size_t i = 0; i < cols[a].size(); i++) if (cols[a][i].m != cols[b][i].m || cols[a][i].r != cols[b][i].r || memcmp(&cols[a][i].c, &cols[b][i].c, 32)) return false; return true; };
   std::vector<std::vector<uint32_t>> groups; std::vector<char> used(suspects.size(), 0);
   for (size_t i = 0; i < suspects.size(); i++) { if (used[i]) continue; std::vector<uint32_t> g{suspects[i]};
     for (size_t j = i + 1; j < suspects.size() && h[suspects[j]] == h[suspects[i]]; j++) if (!used[j] && same((int)i, (int)j)) { used[j] = 1; g.push_back(suspects[j]); }
-    if (g.size() > 1) { std::sort(g.begin(), g.end()); const uint8_t f0 = flip[g[0]]; for (uint32_t &v : g) if (flip[v] != f0) v |= EQUAL_COLUMN_NEGATED; groups.push_back(g); } }
+    if (g.size() > 1) { std::sort(g.begin(), g.end()); groups.push_back(g); } }
   std::sort(groups.begin(), groups.end());
   return groups;
 }

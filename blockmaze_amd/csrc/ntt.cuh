@@ -364,8 +364,7 @@ __global__ void __launch_bounds__(256) k_expand_board(const uint8_t *__restrict_
   __syncthreads();
   if (other) { uint32_t at = wg_at; for (uint32_t wv = 0; wv < wave; wv++) at += wave_n[wv]; other_vars[at + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = var; }
 }
-// Variables whose columns coincide in all three matrices of the constraint system (mint and deposit each hold such a pair) have EQUAL points in every query — and
-// variables whose columns are each other's NEGATIVES (redeem holds such a pair, send two, deposit two) OPPOSITE ones: equal_column_groups marks those members —, and
+// Variables whose columns coincide in all three matrices of the constraint system (mint and deposit each hold such a pair) have EQUAL points in every query, and
 // an incomplete addition that meets P + P leaves ZZ = 0: the MSM was then repeated on the general path (3 of 57,600 mixed proofs in round 5, whenever both values
 // fell into one bucket on two lanes).  Equal columns make the assignment with z_a + z_b in one place and 0 in the other EQUIVALENT — the same A z, B z, C z, the same
 // sums over every query — so the hand-over ends with this kernel: one lane per group of equal columns; if any member is tagged "other", the first such member takes
@@ -375,11 +374,10 @@ __global__ void __launch_bounds__(256) k_expand_board(const uint8_t *__restrict_
 __global__ void k_merge_equal_columns(Fr *__restrict__ z, uint8_t *__restrict__ tags, const uint32_t *__restrict__ grp_ptr, const uint32_t *__restrict__ grp_mem,
     uint32_t n_groups) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; if (g >= n_groups) return;
-  constexpr uint32_t VAR = 0x7fffffffu;                                                  // (bit 31 of a member: its columns are MINUS the first member's — it enters the sum negated)
   const uint32_t lo = grp_ptr[g], hi = grp_ptr[g + 1]; uint32_t target = lo;
-  if (tags) { target = hi; for (uint32_t k = lo; k < hi; k++) if (tags[grp_mem[k] & VAR] == ZTAG_OTHER) { target = k; break; } if (target == hi) return; }
-  Fr s = Fr::zero(); for (uint32_t k = lo; k < hi; k++) { const uint32_t mv = grp_mem[k]; const Fr v = z[mv & VAR]; s = (mv >> 31) ? s - v : s + v; }
-  for (uint32_t k = lo; k < hi; k++) { const uint32_t mv = grp_mem[k], v = mv & VAR; if (k == target) z[v] = (mv >> 31) ? Fr::zero() - s : s; else { z[v] = Fr::zero(); if (tags) tags[v] = ZTAG_ZERO; } }
+  if (tags) { target = hi; for (uint32_t k = lo; k < hi; k++) if (tags[grp_mem[k]] == ZTAG_OTHER) { target = k; break; } if (target == hi) return; }
+  Fr s = Fr::zero(); for (uint32_t k = lo; k < hi; k++) s = s + z[grp_mem[k]];
+  for (uint32_t k = lo; k < hi; k++) { const uint32_t v = grp_mem[k]; if (k == target) z[v] = s; else { z[v] = Fr::zero(); if (tags) tags[v] = ZTAG_ZERO; } }
 }
 // both of the above in ONE launch (the two are independent and each too small to fill the chip for long: 27 + 25 us one after the other at the head of every
 // proof's critical chain): the first `short_blocks` workgroups take the one-lane rows, the others four long rows each, one per wave

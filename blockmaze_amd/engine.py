@@ -202,7 +202,7 @@ def verify_schedule_on_host(vk_path, proof_hex, inputs):
     if rc < 0: _check(rc)
     return rc == 1, dict(zip(("rounds", "slots", "products", "linear_ops", "constants", "mul_waves", "lin8_waves", "lin1_waves"), (int(x) for x in st)))
 def equal_columns(r1cs_path):
-    """groups (lists of variable numbers, 0 = ONE) of auxiliary variables whose columns coincide in A, B and C, or are the negatives of the first member's in all three (bit 31 of such a member is set) (host only)"""
+    """groups (lists of variable numbers, 0 = ONE) of auxiliary variables whose columns coincide in A, B and C (host only)"""
     n = lib().zkgpu_test_equal_columns(r1cs_path.encode(), None, ctypes.c_size_t(0))
     if n < 0: _check(n)
     buf = (ctypes.c_uint32 * max(1, n))(); lib().zkgpu_test_equal_columns(r1cs_path.encode(), buf, ctypes.c_size_t(n)); out = []; i = 0

@@ -101,7 +101,7 @@ int zkgpu_key_container_valid(const char *pk_path);
 int zkgpu_test_device_plan(const char *spec, int n_visible, int fallback, int per_device, int *out_devices, int *out_order, int n_order);   /* multi-device pool planning (pure host logic) */
 int zkgpu_test_pool_plan(int n_devices, int spill, const int *release_before, int n_calls, int *out_dev);   /* acquire_prover's device choice replayed on the host (capi_zk.cpp) */
 int zkgpu_test_scan_blocks(const uint8_t *tags64, const uint64_t *elems64x4, const uint64_t *one4, uint64_t *out10);   /* the hand-over's block classifiers: out[0..2] / [3..5] tag masks scalar / fast, out[6..7] / [8..9] element masks scalar / fast */
-int zkgpu_test_equal_columns(const char *r1cs_path, uint32_t *out, size_t cap);   /* host only: groups of variables with identical columns in A, B and C — or columns that are the NEGATIVES of the group's first member's in all three: such a member has bit 31 set —, flattened [size, members ...]; returns the words written / needed */
+int zkgpu_test_equal_columns(const char *r1cs_path, uint32_t *out, size_t cap);   /* host only: groups of variables with identical columns in A, B and C, flattened [size, members ...]; returns the words written / needed */
 int zkgpu_test_cgroup_quota(const char *root);   /* the CPU quota the library would respect when sizing its helper pools (host only): CPUs, rounded up, 0 = none */
 int zkgpu_test_scan_pool(int callers, int rounds);   /* the hand-over's scan pool driven from several threads at once (host only): rounds served by the pool, -1 on a miscount */
 int zkgpu_test_lane_plan(int n_slots, int kinds, int per_kind, int *out_lanes_per_slot);   /* the stream-lane planner with its per-device quota (gpu.hip) */
@@ -129,7 +129,7 @@ int zkgpu_prover_stash_count(zkgpu_prover *h, uint32_t *count);
 /* a kept assignment copied back to the host in the layout zkgpu_prover_set_witness takes (n_vars x 32 bytes, canonical): tests and diagnostics — after a proof has read
  * the slot in place, variables with equal columns hold their folded (equivalent) values */
 int zkgpu_prover_read_stash(zkgpu_prover *h, uint32_t slot, uint8_t *z_out);
-/* groups of variables whose columns coincide in A, B and C — up to one common sign per variable — found in this key (their values, with that sign, are folded into one place at the head of every proof: an equivalent assignment,
+/* groups of variables whose columns coincide in A, B and C found in this key (their values are folded into one place at the head of every proof: an equivalent assignment,
  * no equal points meeting in an incomplete addition); and, process-wide, how often a fast MSM path raised its flag and the MSM was repeated on the general path */
 int zkgpu_prover_equal_column_groups(zkgpu_prover *h, uint32_t *count);
 uint64_t zkgpu_general_path_repeats(void);

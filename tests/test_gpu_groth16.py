@@ -529,8 +529,7 @@ def test_stashed_assignments_of_the_send_circuit_classified_on_the_device(tmp_pa
     for rep in range(2):
         for i in (2, 0, 1): assert p.prove_stashed(slots[i], 1000 + i, 2000 + i) == want[i]
     assert p.prove(zs[1], 1001, 2001) == want[1] and p.prove_stashed(slots[0], 1000, 2000) == want[0]         # host buffers and stashes interleaved
-    rp = str(tmp_path / "send.bin"); e.circuit_export("send", rp); members = sorted({(v & 0x7fffffff) - 1 for g in e.equal_columns(rp) for v in g}); keep = np.ones(len(zs[0]), dtype=bool); keep[members] = False
-    for i, z in enumerate(zs): assert np.array_equal(p.read_stash(slots[i])[keep], np.asarray(z, dtype=np.uint64).reshape(-1, 4)[keep])      # ... and proofs leave it as it was, but for the two pairs of opposite columns send holds: folded in place
+    for i, z in enumerate(zs): assert np.array_equal(p.read_stash(slots[i]), np.asarray(z, dtype=np.uint64).reshape(-1, 4))      # ... and proofs leave it as it was (send folds nothing)
     bad = zs[0].copy(); bad[300000 % len(bad)] = o.to_arr([3])[0]; p.set_witness(bad); sb = p.stash_witness()
     with pytest.raises(e.ZkGpuError, match="constraint [0-9]+ among"): p.prove_stashed(sb, 1, 2)                # the error names a violated constraint
     assert p.prove_stashed(slots[2], 1002, 2002) == want[2]; p.close()
@@ -557,28 +556,24 @@ def test_key_generation_executables(tmp_path):
     m = w.mint_instance(9); wp = str(tmp_path / "w.bin"); e.witness_mint_redeem(False, *hexargs(w.mint_args(m)), wp); p = e.Prover(pk); proof = p.prove(o.load_witness(wp)); p.close()
     assert e.verify(vk, proof, w.pack_public([m["cmtA_old"], m["sn_old"], m["cmtA"]], m["value_s"]))
 
-@pytest.mark.parametrize("kind", ["mint", "redeem"])
-def test_equal_columns_are_folded_and_never_send_an_msm_to_the_general_path(tmp_path, kind):
-    """Variables whose columns coincide in A, B and C have equal points in every query — and variables whose columns are each other's negatives opposite ones; when the two
-    scalars share a digit the two points used to meet in an incomplete addition now and then (ZZ = 0: the MSM repeated on the general path — 3 of 57,600 mixed proofs in
-    round 5, 4 in one soak of round 6 before the opposite pairs were folded too).  The prover folds such groups into one place at the head of every proof
-    (k_merge_equal_columns): an equivalent assignment.  Mint (a pair with equal columns): the pair's sum split into two EQUAL halves — every digit of the two scalars the same,
-    the worst case; redeem (a pair with opposite columns): both values moved by the same large amount, so that all their high digits agree.  Either gives, for the same
-    (r, s), the bytes of the untouched witness's proof, through the host buffer and a stash, and no MSM is repeated; what the fold leaves, handed over as such, too"""
+def test_equal_columns_are_folded_and_never_send_an_msm_to_the_general_path(tmp_path):
+    """Variables whose columns coincide in A, B and C have equal points in every query; when both hold the same value other than 0 / 1 the two equal points used to meet in an
+    incomplete addition now and then (ZZ = 0: the MSM repeated on the general path — 3 of 57,600 mixed proofs in round 5).  The prover folds such groups into one place at the
+    head of every proof (k_merge_equal_columns): an equivalent assignment.  Mint (the circuit has such a pair): the pair's sum split into two EQUAL halves — every digit of the two
+    scalars the same, the worst case — gives, for the same (r, s), the bytes of the untouched witness's proof, through the host buffer, the board's tags (cgo path: a real
+    statement) and a stash, and no MSM is repeated; ZK_MERGE_EQUAL_COLUMNS=0 is the old behaviour (same bytes, by way of the general path or not)"""
     import workload as w
-    redeem = kind == "redeem"; pk, vk = str(tmp_path / "pk.txt"), str(tmp_path / "vk.txt"); e.keygen(kind, pk, vk, seed=4242); rpath = str(tmp_path / "cs.bin"); e.circuit_export(kind, rpath)
-    groups = e.equal_columns(rpath); assert groups; NEG = 0x80000000; a, b = groups[0][0], groups[0][1] & ~NEG; sign = -1 if groups[0][1] & NEG else 1; assert (sign == -1) == redeem
-    m = w.mint_instance(3, redeem=redeem); hx = lambda x: [("0x" + v.hex()) if isinstance(v, bytes) else v for v in x]; wp = str(tmp_path / "w.bin"); e.witness_mint_redeem(redeem, *hx(w.mint_args(m)), wp); z = o.load_witness(wp)
+    pk, vk = str(tmp_path / "mintpk.txt"), str(tmp_path / "mintvk.txt"); e.keygen("mint", pk, vk, seed=4242); rpath = str(tmp_path / "mint.bin"); e.circuit_export("mint", rpath)
+    groups = e.equal_columns(rpath); assert groups; a, b = groups[0][:2]
+    m = w.mint_instance(3); hx = lambda x: [("0x" + v.hex()) if isinstance(v, bytes) else v for v in x]; wp = str(tmp_path / "w.bin"); e.witness_mint_redeem(False, *hx(w.mint_args(m)), wp); z = o.load_witness(wp)
     p = e.Prover(pk); assert p.equal_column_groups() == len(groups)
     r, s = 0x1234567, 0x7654321; want = p.prove(z, r, s); assert e.verify(vk, want, w.pack_public([m["cmtA_old"], m["sn_old"], m["cmtA"]], m["value_s"]))
-    za, zb = o.from_arr(z[a - 1:a])[0], o.from_arr(z[b - 1:b])[0]; tot = (za + sign * zb) % o.R_MOD                  # what the pair contributes to every product: tot x (the first member's columns)
-    x = tot * pow(2, o.R_MOD - 2, o.R_MOD) % o.R_MOD if sign == 1 else (1 << 200) + (12345 << 64); assert x > 1
-    z2 = z.copy(); z2[a - 1] = o.to_arr([(tot - sign * x) % o.R_MOD])[0]; z2[b - 1] = o.to_arr([x])[0]
+    za, zb = o.from_arr(z[a - 1:a])[0], o.from_arr(z[b - 1:b])[0]; tot = (za + zb) % o.R_MOD; half = tot * pow(2, o.R_MOD - 2, o.R_MOD) % o.R_MOD; assert half > 1
+    z2 = z.copy(); z2[a - 1] = o.to_arr([half])[0]; z2[b - 1] = o.to_arr([half])[0]
     before = e.general_path_repeats()
     for rep in range(6): assert p.prove(z2, r, s) == want
     p.set_witness(z2); slot = p.stash_witness()
     for rep in range(6): assert p.prove_stashed(slot, r, s) == want
-    back = p.read_stash(slot); assert o.from_arr(back[a - 1:a])[0] == tot and o.from_arr(back[b - 1:b])[0] == 0             # (the stash read in place holds the folded, equivalent assignment)
     z3 = z.copy(); z3[a - 1] = o.to_arr([tot])[0]; z3[b - 1] = o.to_arr([0])[0]; assert p.prove(z3, r, s) == want          # (what the fold leaves, handed over as such)
     assert e.general_path_repeats() == before; p.close()
 

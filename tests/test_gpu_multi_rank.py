@@ -52,7 +52,5 @@ def test_a_stash_that_does_not_prove_is_reported_and_made_anew():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extra-legs"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.strip()][0]); assert j["config"]["stash_remade"] == 1 and j["value"] > 0
-    import re
-    m = re.search(r"differs from the one handed over in (\d+) variables \(first: \[([0-9, ]+)\]", r.stderr); assert m and "constraint " in r.stderr, r.stderr[-2000:]
-    assert 5000 in [int(x) for x in m.group(2).split(",")] and int(m.group(1)) <= 5                    # (the planted value, and at most the two pairs of opposite columns a proof folds in place)
+    assert "differs from the one handed over in 1 variables (first: [5000])" in r.stderr and "constraint " in r.stderr, r.stderr[-2000:]
     j = run(["--steps", "4", "--warmup", "1", "--no-extra-legs"]); assert j["config"]["stash_remade"] == 0
