@@ -140,7 +140,7 @@ __device__ __forceinline__ QPoint29 block_quad29_tree(QPoint29 acc, Point29Rec *
   return acc;
 }
 
-__device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq> *slot, MsmCounters *cnt);
+__device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq> *slot, MsmCounters *cnt, uint32_t which = 0);
 // how the weights are cut: w = hi * 2^lo_bits + lo. A row (2^lo_bits consecutive buckets) is added up in `row_chunks` pieces of at most HTAIL_CHUNK buckets, a
 // workgroup each, so that no quad of the marginal kernel holds more than two buckets: 1 + 6 dependent additions for rows and columns alike.
 constexpr uint32_t HTAIL_CHUNK = 128;
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) k_hbits29(const Point29Rec *__restrict__ 
     acc = block_quad29_tree(acc, lds, min(count, 64u));
   }
   // (ZZ = 0 mod p in something that is not the point at infinity raises the flag)
-  if (threadIdx.x < 4) quad29_emit(acc, k, res + s_, cnt);
+  if (threadIdx.x < 4) quad29_emit(acc, k, res + s_, cnt, s_);
   // (lane 2 of the quad may have raised the degenerate-sum flag with an atomic of its own: every lane's writes are ordered before the ticket below by this barrier and
   // lane 0's fence, whatever wave the lanes sit in)
   __syncthreads();
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256) k_hbits29(const Point29Rec *__restrict__ 
 //               degenerate one
 //               (ZZ = 0 mod p) raises the flag that sends the MSM to the general path, the last workgroup to finish hands the counters to the host.
 // quad 0 of a workgroup: the result as 8 x 32-bit words
-__device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq> *slot, MsmCounters *cnt) {
+__device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq> *slot, MsmCounters *cnt, uint32_t which) {
   Fq out = Fq::zero();
   bool bad = false;
   if (!acc.inf) {
@@ -249,7 +249,7 @@ __device__ __forceinline__ void quad29_emit(const QPoint29 &acc, int k, XYZZ<Fq>
     bad = k == 2 && out.is_zero_lazy();
     out = out.normalize();
   }
-  if (bad) atomicOr(&cnt->pad[0], 2u);                                                   // (bit 1: a degenerate sum; bit 0: a sort region overflowed)
+  if (bad) atomicOr(&cnt->pad[0], 2u | (1u << (8 + (which < 23u ? which : 23u))));                      // (bit 1: a degenerate sum — bits 8 .. 31: in which result slot(s); bit 0: a sort region overflowed)
   reinterpret_cast<Fq *>(slot)[k] = out;
 }
 template <int UNIT>
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256) k_wtail29(const Point29Rec *__restrict__ 
     }
     acc = block_quad29_tree(acc, lds, min(half, 64u));
   }
-  if (threadIdx.x < 4) quad29_emit(acc, k, res + slot, cnt);
+  if (threadIdx.x < 4) quad29_emit(acc, k, res + slot, cnt, s_ == top + 1 ? 23u : s_);   // (slot 23 of the flag word: the sum of the ones)
   // (lane 2 of the quad may have raised the degenerate-sum flag with an atomic of its own: every lane's writes are ordered before the ticket below by this barrier and
   // lane 0's fence, whatever wave the lanes sit in)
   __syncthreads();

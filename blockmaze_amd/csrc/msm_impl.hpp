@@ -311,7 +311,7 @@ struct MsmImpl {
       if (!overflow_noted) {
         overflow_noted = true;
         const uint32_t why = host_counters()->pad[0];
-        fprintf(stderr, "libzkgpu: %s: %s%s(flag %u; %u slots a bucket), general MSM path used\n", label.c_str(), (why & 1u) ? "a bucket of the witness sort overflowed " : "",
+        fprintf(stderr, "libzkgpu: %s: %s%s(flag 0x%x: bits 8.. say which result slots, 23 = the sum of the ones; %u slots a bucket), general MSM path used\n", label.c_str(), (why & 1u) ? "a bucket of the witness sort overflowed " : "",
             (why & 2u) ? "a sum of the fold / tail met an operand equal to +-its partner (ZZ = 0) " : "", why, ws->cap);
       }
       note_general_path_repeat();
