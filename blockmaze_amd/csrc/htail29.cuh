@@ -49,7 +49,12 @@ __device__ __forceinline__ Fq29 sel29(bool c, const Fq29 &a, const Fq29 &b) {
 // a point spread over a quad: this lane's coordinate, and whether the point is the point at infinity (the same value in all four lanes)
 struct QPoint29 { Fq29 c; bool inf; };
 
-__device__ __forceinline__ QPoint29 quad29_add(const QPoint29 &A, const QPoint29 &B, int k) {
+// OPP (the witness MSMs' folds and tails): an operand equal to MINUS the other one is noticed — P^2 = 0 (mod p) on lane 0 while R^2 on lane 1 is not — and the sum is
+// the point at infinity, as it should be.  A key's query holds equal points (variables that enter the same constraints with the same coefficients), their small signed
+// digits cancel inside lanes, and now and then two lanes of a bucket are left with one such point each, with opposite signs (found in round 6 from a state dump of
+// mint's A query, tools/degenerate_dump.py: 2 to 4 events in 100,000 mint proofs under concurrent callers, each one MSM repeated on the general path).  An operand
+// EQUAL to the other (a third of the events) is added by way of the generator, see below: the witness folds are complete.
+template <bool OPP = false> __device__ __forceinline__ QPoint29 quad29_add(const QPoint29 &A, const QPoint29 &B, int k) {
   const Fq29 &a = A.c, &b = B.c;
   // round 1
   const Fq29 m1 = Fq29::mul(a, quad29_perm<0x4E>(b));                                  // [2,3,0,1]:  U1 | S1 | U2 | S2
@@ -57,6 +62,13 @@ __device__ __forceinline__ QPoint29 quad29_add(const QPoint29 &A, const QPoint29
   // round 2
   const bool low = k < 2;
   const Fq29 m2 = Fq29::mul(sel29(low, d, a), sel29(low, d, b));                       // PP | RR | ZZ12 | ZZZ12
+  bool opposite = false, zf_p = false, zf_r = false;
+  if (OPP) { uint32_t zero_or = 0, p_xor = 0;                                          // (a product's result — exact limbs, below 2 p — is 0 mod p iff it is 0 or p)
+#pragma unroll
+    for (int i = 0; i < 9; i++) { zero_or |= m2.l[i]; p_xor |= m2.l[i] ^ Fq29::P29[i]; }
+    const int zf = (zero_or == 0 || p_xor == 0) ? 1 : 0;
+    zf_p = __builtin_amdgcn_update_dpp(0, zf, 0x00, 0xf, 0xf, false) != 0; zf_r = __builtin_amdgcn_update_dpp(0, zf, 0x55, 0xf, 0xf, false) != 0;
+    opposite = zf_p && !zf_r && !A.inf && !B.inf; }
   // round 3
   const Fq29 pp = quad29_perm<0x00>(m2), u1 = quad29_perm<0x00>(m1);
   const Fq29 m3 = Fq29::mul(sel29(k == 0, d, sel29(k == 1, u1, m2)), pp);              // PPP | Q | ZZ3 | -
@@ -76,7 +88,18 @@ __device__ __forceinline__ QPoint29 quad29_add(const QPoint29 &A, const QPoint29
   QPoint29 r;
   r.c = sel29(k == 0, x3b, sel29(k == 1, y3, sel29(k == 2, m3, m4x)));                 // X3 | Y3 | ZZ3 | ZZZ3
   r.c = sel29(B.inf, a, sel29(A.inf, b, r.c));                                         // an operand at infinity: the other one
-  r.inf = A.inf && B.inf;
+  r.inf = (A.inf && B.inf) || opposite;
+  if (OPP) {
+    // an operand EQUAL to the other one (P^2 = R^2 = 0): A + B = (A + G) + (B - G) with the curve's generator G = (1, 2) — three additions none of which is
+    // degenerate (A = +-G aside), on the same formulas and bounds; the branch is taken by a whole wave, once in some hundred thousand proofs
+    const bool equal = zf_p && zf_r && !A.inf && !B.inf;
+    if (__ballot(equal)) {
+      const Fq29 one = Fq29::one(), two = Fq29::add_raw(one, one).norm(); QPoint29 G, Gm;
+      G.c = k == 1 ? two : one; G.inf = false; Gm.c = k == 1 ? Fq29::cond_neg(two, true).norm() : one; Gm.inf = false;
+      const QPoint29 t3 = quad29_add<false>(quad29_add<false>(A, G, k), quad29_add<false>(B, Gm, k), k);
+      if (equal) r = t3;
+    }
+  }
   return r;
 }
 
@@ -115,14 +138,14 @@ __device__ __forceinline__ QPoint29 quad29_shfl_down(const QPoint29 &p, int lane
 }
 // tree over the quads of a workgroup of up to 256 threads: the 16 quads of a wave by shuffles, the waves through LDS (one record each). `live` = how many quads
 // (the first ones) hold something: levels whose partner quads are all empty are skipped, whole waves at a time. The sum is valid in quad 0.
-__device__ __forceinline__ QPoint29 block_quad29_tree(QPoint29 acc, Point29Rec *lds, uint32_t live) {
+template <bool OPP = false> __device__ __forceinline__ QPoint29 block_quad29_tree(QPoint29 acc, Point29Rec *lds, uint32_t live) {
   const uint32_t q = threadIdx.x >> 2, wq = q & 15, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   const int k = threadIdx.x & 3;
 #pragma unroll 1
   for (int dq = 8; dq >= 1; dq >>= 1) {
     if (wave * 16 + dq >= live) continue;
     const QPoint29 o = quad29_shfl_down(acc, 4 * dq);
-    if (wq + dq < 16) acc = quad29_add(acc, o, k);
+    if (wq + dq < 16) acc = quad29_add<OPP>(acc, o, k);
   }
   if (n_waves == 1) return acc;
   if ((threadIdx.x & 63) < 4) quad29_store(lds + wave, acc, k);
@@ -134,7 +157,7 @@ __device__ __forceinline__ QPoint29 block_quad29_tree(QPoint29 acc, Point29Rec *
     for (int dq = 2; dq >= 1; dq >>= 1) {
       if ((uint32_t)dq * 16 >= live || (uint32_t)dq >= n_waves) continue;
       const QPoint29 o = quad29_shfl_down(acc, 4 * dq);
-      if (q + dq < n_waves) acc = quad29_add(acc, o, k);
+      if (q + dq < n_waves) acc = quad29_add<OPP>(acc, o, k);
     }
   }
   return acc;
@@ -266,9 +289,9 @@ __global__ void __launch_bounds__(256) k_wfold29(const Point29Rec *__restrict__ 
   if (q < len) {
     acc = quad29_load(partial + beg + q, k);
 #pragma unroll 1
-    for (uint32_t j = q + nq; j < len; j += nq) acc = quad29_add(acc, quad29_load(partial + beg + j, k), k);
+    for (uint32_t j = q + nq; j < len; j += nq) acc = quad29_add<true>(acc, quad29_load(partial + beg + j, k), k);
   }
-  acc = block_quad29_tree(acc, lds, min(len, nq));
+  acc = block_quad29_tree<true>(acc, lds, min(len, nq));
   if (threadIdx.x < 4) quad29_store(out + b, acc, k);
 }
 template <int UNIT>
@@ -287,9 +310,9 @@ __global__ void __launch_bounds__(256) k_wtail29(const Point29Rec *__restrict__ 
     if (q < n_ones_partial) {
       acc = quad29_load(ones_partial + q, k);
 #pragma unroll 1
-      for (uint32_t j = q + 64; j < n_ones_partial; j += 64) acc = quad29_add(acc, quad29_load(ones_partial + j, k), k);
+      for (uint32_t j = q + 64; j < n_ones_partial; j += 64) acc = quad29_add<true>(acc, quad29_load(ones_partial + j, k), k);
     }
-    acc = block_quad29_tree(acc, lds, min(n_ones_partial, 64u));
+    acc = block_quad29_tree<true>(acc, lds, min(n_ones_partial, 64u));
     slot = slots;
   } else if (s_ == top) {                                                               // weight NB: one bucket; slots above `top` hold the point at infinity
     if (q == 0) acc = quad29_load(buckets + NB - 1, k);
@@ -299,9 +322,9 @@ __global__ void __launch_bounds__(256) k_wtail29(const Point29Rec *__restrict__ 
     if (q < half) {
       acc = quad29_load(buckets + bucket_of(q), k);
 #pragma unroll 1
-      for (uint32_t j = q + 64; j < half; j += 64) acc = quad29_add(acc, quad29_load(buckets + bucket_of(j), k), k);
+      for (uint32_t j = q + 64; j < half; j += 64) acc = quad29_add<true>(acc, quad29_load(buckets + bucket_of(j), k), k);
     }
-    acc = block_quad29_tree(acc, lds, min(half, 64u));
+    acc = block_quad29_tree<true>(acc, lds, min(half, 64u));
   }
   if (threadIdx.x < 4) quad29_emit(acc, k, res + slot, cnt, s_ == top + 1 ? 23u : s_);   // (slot 23 of the flag word: the sum of the ones)
   // (lane 2 of the quad may have raised the degenerate-sum flag with an atomic of its own: every lane's writes are ordered before the ticket below by this barrier and

@@ -315,6 +315,18 @@ struct MsmImpl {
             (why & 2u) ? "a sum of the fold / tail met an operand equal to +-its partner (ZZ = 0) " : "", why, ws->cap);
       }
       note_general_path_repeat();
+      // (diagnostic: ZK_DEBUG_DUMP_DEGENERATE=<file prefix> writes what the fast path held when it raised its flag — bucket fills, entries, lane offsets, the lanes'
+      //  partial sums, the bucket sums — for tools/degenerate_dump.py; G1 witness MSMs only)
+      if constexpr (sizeof(F) == 32) { static const char *dump = getenv("ZK_DEBUG_DUMP_DEGENERATE"); static std::atomic<int> dumps{0};
+        if (dump && dumps.fetch_add(1) < 8) { const int k = dumps.load();
+          std::vector<uint32_t> fl(2 * NB), lo(NB + 1), en((size_t)NB * ws->cap); ws->fill.download(fl.data(), fl.size()); lane_off.download(lo.data(), lo.size()); ws->entries.download(en.data(), en.size());
+          std::vector<uint8_t> p1((size_t)WFUSED_BUCKET_LANES * sizeof(Point29Rec)), p2((size_t)NB * sizeof(Point29Rec)); HIP_CHECK(hipMemcpy(p1.data(), partials.get(), p1.size(), hipMemcpyDeviceToHost));
+          HIP_CHECK(hipMemcpy(p2.data(), ones_partial.get(), p2.size(), hipMemcpyDeviceToHost));
+          const std::string path = std::string(dump) + "_" + label + "_" + std::to_string(k) + ".bin"; FILE *f = fopen(path.c_str(), "wb");
+          if (f) { const uint32_t hdr[8] = {NB, ws->cap, (uint32_t)ws->parity, host_counters()->pad[0], (uint32_t)n, (uint32_t)WFUSED_BUCKET_LANES, (uint32_t)sizeof(Point29Rec), 0};
+            fwrite(hdr, 4, 8, f); fwrite(fl.data(), 4, fl.size(), f); fwrite(lo.data(), 4, lo.size(), f);
+            for (uint32_t b = 0; b < NB; b++) fwrite(en.data() + (size_t)b * ws->cap, 4, std::min(std::max(fl[b], fl[NB + b]), ws->cap), f);
+            fwrite(p1.data(), 1, p1.size(), f); fwrite(p2.data(), 1, p2.size(), f); fclose(f); fprintf(stderr, "libzkgpu: %s: state written to %s\n", label.c_str(), path.c_str()); } } }
       wfused = false; run_impl(last_scalars, last_index); HIP_CHECK(hipStreamSynchronize(stream())); wfused = true; }
     if (hsort && host_counters()->pad[0]) { const Fe32 *sc = last_scalars; hsort = false; note_general_path_repeat();
       // hist() held the bucket counts of the group sort; the two-pass path wants it cleared

@@ -5,7 +5,7 @@ import os, sys, tempfile, time
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 from blockmaze_amd import engine as e
 import workload as w
-tmp = tempfile.mkdtemp(); e.keygen("mint", os.path.join(tmp, "mintpk.txt"), os.path.join(tmp, "mintvk.txt"), seed=0xB10C4A2E + 4); os.environ["ZK_PRFKEY_DIR"] = tmp; zk = e.Zk()
+tmp = os.environ.get("ZK_HUNT_DIR") or tempfile.mkdtemp(); os.makedirs(tmp, exist_ok=True); e.keygen("mint", os.path.join(tmp, "mintpk.txt"), os.path.join(tmp, "mintvk.txt"), seed=0xB10C4A2E + 4); os.environ["ZK_PRFKEY_DIR"] = tmp; zk = e.Zk()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000; K = 64
 ms = [w.mint_instance(i) for i in range(K)]; hits = {}
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1; kind = sys.argv[3] if len(sys.argv) > 3 else "mint"
